@@ -1,0 +1,74 @@
+"""ctypes binding of libcfx.so (include/cfx.h).  There is NO fallback: if the shared object is missing
+or fails to load, importing a codec raises - the product path never runs on anything but the HIP kernels."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from .build import LIB, build_lib
+
+CFX_MAX_BATCH = 16
+
+CFX_OK = 0
+ERR_NAMES = {
+    -1: "CFX_ERR_NULL", -2: "CFX_ERR_SHAPE", -3: "CFX_ERR_ALIGN", -4: "CFX_ERR_CODEC",
+    -5: "CFX_ERR_BATCH", -6: "CFX_ERR_LAUNCH", -7: "CFX_ERR_WORKSPACE",
+}
+
+FLAG_UPDATE_CACHE = 1
+FLAG_NO_EF = 2
+
+
+class CompItem(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("base", ctypes.c_void_p), ("new_base", ctypes.c_void_p), ("packet", ctypes.c_void_p)]
+
+
+class DecompItem(ctypes.Structure):
+    _fields_ = [("packet", ctypes.c_void_p), ("base", ctypes.c_void_p), ("recon", ctypes.c_void_p)]
+
+
+# every symbol include/cfx.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("cfx_abi_version", ctypes.c_int, []),
+    ("cfx_create", ctypes.c_void_p, [ctypes.c_int]),
+    ("cfx_destroy", None, [ctypes.c_void_p]),
+    ("cfx_last_error_string", ctypes.c_char_p, [ctypes.c_void_p]),
+    ("cfx_set_rows_per_tile", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_packet_bytes", ctypes.c_size_t, [ctypes.c_int] * 4),
+    ("cfx_workspace_bytes", ctypes.c_size_t, [ctypes.c_int] * 5),
+    ("cfx_compress_batch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    ("cfx_decompress_batch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.POINTER(DecompItem), ctypes.c_void_p]),
+    ("cfx_compress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    ("cfx_decompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    ("cfx_copy_probe", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+]
+
+_lib = None
+
+
+class CfxError(RuntimeError):
+    pass
+
+
+def load(build_if_missing: bool = True) -> ctypes.CDLL:
+    """Load libcfx.so, binding every declared symbol.  Raises (never falls back) when unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        if not build_if_missing:
+            raise CfxError(f"{LIB} is missing: run `python -m compactfusion_amd.build`")
+        build_lib()
+    lib = ctypes.CDLL(LIB)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)     # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cfx_abi_version() != 1:
+        raise CfxError("libcfx.so ABI version mismatch")
+    _lib = lib
+    return lib

@@ -1,0 +1,56 @@
+"""Build libcfx.so (the HIP kernels + C-ABI) in-tree with hipcc for gfx950.
+
+The shared object is git-ignored but travels to the GPU box with the repo snapshot.
+`python -m compactfusion_amd.build` or `__graft_entry__.build()` calls this.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(PKG_DIR)
+SRC = [os.path.join(PKG_DIR, "csrc", "cfx_kernels.hip")]
+INC = os.path.join(REPO, "include")
+LIB = os.path.join(PKG_DIR, "libcfx.so")
+ARCH = "gfx950"
+
+HIPCC_FLAGS = [
+    f"--offload-arch={ARCH}", "-O3", "-std=c++17",
+    "-ffp-contract=off",          # one rounding per reference op: no fma contraction of u*v + base
+    "-fPIC", "-shared",
+]
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libcfx.so")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = SRC + [os.path.join(INC, "cfx.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc_path()] + HIPCC_FLAGS + [f"-I{INC}"] + SRC + ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,174 @@
+"""Torch-tensor front end of the C-ABI (include/cfx.h): PyTorch-ROCm tensors in, device buffers out.
+
+PyTorch is plumbing here (device memory, streams); all arithmetic happens in libcfx.so.  Every function
+raises if the tensors are not on a GPU or the library is missing - there is no CPU path in the product.
+"""
+from __future__ import annotations
+
+import ctypes
+from enum import IntEnum
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import CFX_MAX_BATCH, FLAG_NO_EF, FLAG_UPDATE_CACHE, CfxError, CompItem, DecompItem
+
+
+class Codec(IntEnum):
+    BINARY = 1   # COMPACT_COMPRESS_TYPE.BINARY (comp_rank = -1)
+    INT2 = 2     # COMPACT_COMPRESS_TYPE.INT2
+    INT4 = 3     # residual int4 (compress_quantize.py:522-640 on delta)
+    INT8 = 4     # residual int8 (compress_quantize.py:428-484 on delta)
+    TOPK = 5     # COMPACT_COMPRESS_TYPE.SPARSE, param = sparse_ratio m
+
+
+_ctx = {}
+_ws = {}
+
+
+def _device_index(t: torch.Tensor) -> int:
+    if not t.is_cuda:
+        raise CfxError("compactfusion_amd codecs run on the GPU only (tensor is on %s); there is no CPU fallback" % t.device)
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+def context(device: int):
+    lib = _lib.load()
+    c = _ctx.get(device)
+    if c is None:
+        c = lib.cfx_create(device)
+        if not c:
+            raise CfxError("cfx_create failed")
+        _ctx[device] = c
+    return c
+
+
+def set_rows_per_tile(rows: int, device: Optional[int] = None) -> None:
+    device = torch.cuda.current_device() if device is None else device
+    _lib.load().cfx_set_rows_per_tile(context(device), int(rows))
+
+
+def _check(ctx, rc: int, what: str) -> None:
+    if rc != 0:
+        msg = _lib.load().cfx_last_error_string(ctx)
+        msg = msg.decode() if msg else ""
+        err = _lib.ERR_NAMES.get(rc, str(rc))
+        if rc in (-2, -4, -5):
+            raise ValueError(f"{what}: {err}: {msg}")
+        raise CfxError(f"{what}: {err}: {msg}")
+
+
+def packet_bytes(codec: int, N: int, C: int, param: int = 0) -> int:
+    n = _lib.load().cfx_packet_bytes(int(codec), N, C, param)
+    if n == 0:
+        raise ValueError(f"invalid shape for codec {Codec(codec).name}: N={N} C={C} param={param}")
+    return n
+
+
+def packet_halves(codec: int, N: int, C: int, param: int = 0) -> int:
+    b = packet_bytes(codec, N, C, param)
+    assert b % 2 == 0
+    return b // 2
+
+
+def workspace(codec: int, N: int, C: int, param: int, batch: int, device: int) -> Optional[torch.Tensor]:
+    need = _lib.load().cfx_workspace_bytes(int(codec), N, C, param, batch)
+    if need == 0:
+        return None
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    w = _ws.get(key)
+    if w is None or w.numel() < need:
+        w = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=f"cuda:{device}")
+        _ws[key] = w
+    return w
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream_handle(stream: Optional[torch.cuda.Stream], device: int) -> int:
+    s = stream if stream is not None else torch.cuda.current_stream(device)
+    return s.cuda_stream
+
+
+def _check_nc(t: torch.Tensor, N: int, C: int, name: str) -> None:
+    if t.dtype != torch.float16 or not t.is_contiguous() or t.numel() != N * C:
+        raise ValueError(f"{name}: expected contiguous fp16 with {N}x{C} elements, got {t.dtype} {tuple(t.shape)}")
+
+
+def compress_batch(codec: int, xs: Sequence[torch.Tensor], bases: Sequence[Optional[torch.Tensor]],
+                   new_bases: Sequence[Optional[torch.Tensor]], packets: Sequence[torch.Tensor],
+                   N: int, C: int, param: int = 0, update_cache: bool = True, ef: bool = True,
+                   stream: Optional[torch.cuda.Stream] = None, ws: Optional[torch.Tensor] = None) -> None:
+    """One launch sequence for a batch of (x, base) -> (packet, new_base).  new_base may alias base."""
+    B = len(xs)
+    if not (1 <= B <= CFX_MAX_BATCH):
+        raise ValueError(f"batch {B} out of range 1..{CFX_MAX_BATCH}")
+    dev = _device_index(xs[0])
+    ctx = context(dev)
+    items = (CompItem * B)()
+    for i in range(B):
+        _check_nc(xs[i], N, C, "x")
+        if bases[i] is not None:
+            _check_nc(bases[i], N, C, "base")
+        if new_bases[i] is not None:
+            _check_nc(new_bases[i], N, C, "new_base")
+        _device_index(packets[i])
+        items[i] = CompItem(_ptr(xs[i]), _ptr(bases[i]), _ptr(new_bases[i]), _ptr(packets[i]))
+    flags = (FLAG_UPDATE_CACHE if update_cache else 0) | (0 if ef else FLAG_NO_EF)
+    if ws is None:
+        ws = workspace(codec, N, C, param, B, dev)
+    rc = _lib.load().cfx_compress_batch(ctx, int(codec), N, C, param, flags, B, items,
+                                        _ptr(ws), 0 if ws is None else ws.numel(), _stream_handle(stream, dev))
+    _check(ctx, rc, "cfx_compress_batch")
+
+
+def decompress_batch(codec: int, packets: Sequence[torch.Tensor], bases: Sequence[Optional[torch.Tensor]],
+                     recons: Sequence[torch.Tensor], N: int, C: int, param: int = 0,
+                     stream: Optional[torch.cuda.Stream] = None) -> None:
+    """recon_i = base_i + decode(packet_i) for a batch, one launch.  recon may alias base."""
+    B = len(packets)
+    if not (1 <= B <= CFX_MAX_BATCH):
+        raise ValueError(f"batch {B} out of range 1..{CFX_MAX_BATCH}")
+    dev = _device_index(recons[0])
+    ctx = context(dev)
+    items = (DecompItem * B)()
+    for i in range(B):
+        _check_nc(recons[i], N, C, "recon")
+        if bases[i] is not None:
+            _check_nc(bases[i], N, C, "base")
+        _device_index(packets[i])
+        items[i] = DecompItem(_ptr(packets[i]), _ptr(bases[i]), _ptr(recons[i]))
+    rc = _lib.load().cfx_decompress_batch(ctx, int(codec), N, C, param, B, items, _stream_handle(stream, dev))
+    _check(ctx, rc, "cfx_decompress_batch")
+
+
+def compress(codec: int, x: torch.Tensor, base: Optional[torch.Tensor], N: int, C: int, param: int = 0,
+             update_cache: bool = True, ef: bool = True, new_base: Optional[torch.Tensor] = None,
+             packet: Optional[torch.Tensor] = None):
+    """Single tensor convenience.  Returns (packet fp16 1-D, new_base | None)."""
+    if packet is None:
+        packet = torch.empty(packet_halves(codec, N, C, param), dtype=torch.float16, device=x.device)
+    if update_cache and new_base is None:
+        new_base = torch.empty((N, C), dtype=torch.float16, device=x.device)
+    compress_batch(codec, [x], [base], [new_base if update_cache else None], [packet], N, C, param, update_cache, ef)
+    return packet, (new_base if update_cache else None)
+
+
+def decompress(codec: int, packet: torch.Tensor, base: Optional[torch.Tensor], N: int, C: int, param: int = 0,
+               recon: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if recon is None:
+        recon = torch.empty((N, C), dtype=torch.float16, device=packet.device)
+    if packet.data_ptr() % 16:
+        packet = packet.clone()   # the kernels want a 16-byte aligned packet; a slice of a gather buffer may not be
+    decompress_batch(codec, [packet], [base], [recon], N, C, param)
+    return recon
+
+
+def copy_probe(dst: torch.Tensor, src: torch.Tensor, stream: Optional[torch.cuda.Stream] = None) -> None:
+    dev = _device_index(dst)
+    ctx = context(dev)
+    rc = _lib.load().cfx_copy_probe(ctx, dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size(), _stream_handle(stream, dev))
+    _check(ctx, rc, "cfx_copy_probe")

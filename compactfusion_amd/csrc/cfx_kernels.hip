@@ -1,0 +1,1011 @@
+// libcfx.so - hand-written gfx950 (MI355X / CDNA4) kernels for CompactFusion's residual-compressed
+// activation exchange, behind the C-ABI of include/cfx.h.
+//
+// Design:
+//   * Every kernel is an HBM-bound streaming pass over (N, C) fp16 tensors.  A wavefront (64 lanes)
+//     owns 512 contiguous channels of one row: each lane moves 16 B (8 halves) per access, so one
+//     wave instruction covers 1 KiB contiguous - the coalescing sweet spot on CDNA4.
+//   * A workgroup is 4 waves = a tile of R rows x 512 channels; waves interleave over the rows and keep
+//     several rows of loads in flight (the tiles are too small for occupancy alone to hide HBM latency).
+//   * The scale prologue of the reference (5 eager full-tensor passes, fastpath.py:150-166) is a global
+//     reduction, so compress is stats-pass -> tiny finalize -> apply-pass.  The stats pass accumulates
+//     |x-base| EXACTLY as 64-bit integers in units of 2^-24 (fp16 values are multiples of 2^-24): the
+//     scales are therefore independent of tiling, reduction order and run - bit-reproducible - and equal
+//     to oracle/ref_np.py bit for bit.  Partial sums go to a caller-provided workspace (no atomics).
+//   * For the 1-bit codec the packed signs do not depend on the scales, so the stats pass already emits
+//     them and the error-feedback pass is literally the receiver's dequant+add kernel run on the sender's
+//     own packet: sender and receiver state cannot diverge.
+//   * Tile -> workgroup mapping is identical in the stats and apply passes, so a tile is re-read by a
+//     workgroup with the same index, i.e. (as dispatched on gfx950, block b -> XCD b % 8) from the same
+//     XCD's L2 where the first pass left it.
+//   * fp16 arithmetic is done with native correctly-rounded fp16 instructions, one rounding per reference
+//     op (compile with -ffp-contract=off: an fma would skip the rounding of u*v that fastpath.py:109 has).
+//
+// Reference citations are relative to /root/reference/xfuser/compact/.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "cfx.h"
+
+typedef _Float16 h16;
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef u16 u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned long long u64;
+
+#define TILE_C 512      // channels per wave-row = 64 lanes x 8 halves
+#define WAVES 4         // waves per workgroup
+#define NTHR (WAVES * 64)
+#define UNROLL 4        // rows in flight per wave
+
+struct BatchC { cfx_comp_item it[CFX_MAX_BATCH]; };
+struct BatchD { cfx_decomp_item it[CFX_MAX_BATCH]; };
+
+// ---------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u16 hbits(h16 v) { return __builtin_bit_cast(u16, v); }
+__device__ __forceinline__ h16 hfrom(u16 v) { return __builtin_bit_cast(h16, v); }
+
+__device__ __forceinline__ h16x8 ld8(const h16* p) { return *reinterpret_cast<const h16x8*>(p); }
+__device__ __forceinline__ void st8(h16* p, h16x8 v) { *reinterpret_cast<h16x8*>(p) = v; }
+
+// 8 halves from an address that is only guaranteed 2-byte aligned (packet tail sections).
+__device__ __forceinline__ h16x8 ld8_tail(const h16* p, bool al16) {
+    if (al16) return ld8(p);
+    h16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = p[i];
+    return r;
+}
+
+// |h| as an integer count of 2^-24 (exact for finite fp16; garbage-but-finite for inf/nan).
+__device__ __forceinline__ u64 habs_units(u16 b) {
+    const unsigned e = (b >> 10) & 31u, m = b & 1023u;
+    const unsigned t = e ? (m | 1024u) : m;
+    const unsigned sh = e ? e - 1u : 0u;
+    return (u64)t << sh;
+}
+
+// fp16( fp32(exact_sum * 2^-24) / fp32(n) ) - oracle/ref_np.py mean16_exact
+__device__ __forceinline__ h16 mean16(u64 units, int n) {
+    const float s = (float)units * 0x1p-24f;
+    return (h16)(s / (float)n);
+}
+
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ h16x8 habs8(h16x8 v) {
+    u16x8 b = __builtin_bit_cast(u16x8, v);
+    b &= (u16)0x7fff;
+    return __builtin_bit_cast(h16x8, b);
+}
+
+struct TileCoord {
+    int lane, w, c, r0, r1;
+    bool act;
+};
+__device__ __forceinline__ TileCoord tile_coord(int N, int C, int R) {
+    TileCoord t;
+    t.lane = threadIdx.x & 63;
+    t.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    t.c = blockIdx.x * TILE_C + t.lane * 8;
+    t.act = t.c < C;
+    t.r0 = blockIdx.y * R;
+    t.r1 = min(N, t.r0 + R);
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// abs-mean statistics pass (1-bit and 2-bit codecs)      replaces fastpath.py:150-166 / :614-625 (E1/E2)
+//   rowpart[n][cb]  = sum over the tile's 512 channels of |x-base| (units of 2^-24)
+//   colpart[p][c]   = sum over the tile's R rows
+//   EMIT_BITS: also write bit i of byte j = (x-base)[n,8j+i] >= 0        (fastpath.py:58-85)
+// ---------------------------------------------------------------------------------------------------
+template <bool EMIT_BITS>
+__global__ __launch_bounds__(NTHR) void k_absmean_stats(BatchC batch, int N, int C, int R, u64* ws, size_t ws_stride) {
+    const cfx_comp_item it = batch.it[blockIdx.z];
+    const TileCoord t = tile_coord(N, C, R);
+    const int CB = gridDim.x, cb = blockIdx.x;
+    u64* rowpart = ws + (size_t)blockIdx.z * ws_stride;
+    u64* colpart = rowpart + (size_t)N * CB;
+    const h16* x = (const h16*)it.x;
+    const h16* base = (const h16*)it.base;
+    unsigned char* bitsout = (unsigned char*)it.packet;
+    const int C8 = C >> 3;
+
+    u64 col[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) col[i] = 0;
+
+    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL) {
+        h16x8 xv[UNROLL], bv[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int rr = r + WAVES * j;
+            xv[j] = (h16x8)(h16)0;
+            bv[j] = (h16x8)(h16)0;
+            if (rr < t.r1 && t.act) {
+                xv[j] = ld8(x + (size_t)rr * C + t.c);
+                if (base) bv[j] = ld8(base + (size_t)rr * C + t.c);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int rr = r + WAVES * j;
+            if (rr < t.r1) {
+                u64 rs = 0;
+                if (t.act) {
+                    const h16x8 d = xv[j] - bv[j];
+                    unsigned byte = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        byte |= (d[i] >= (h16)0 ? 1u : 0u) << i;
+                        const u64 u = habs_units(hbits(d[i]));
+                        col[i] += u;
+                        rs += u;
+                    }
+                    if (EMIT_BITS) bitsout[(size_t)rr * C8 + (t.c >> 3)] = (unsigned char)byte;
+                }
+                rs = wave_sum_u64(rs);
+                if (t.lane == 0) rowpart[(size_t)rr * CB + cb] = rs;
+            }
+        }
+    }
+    __shared__ u64 sm[WAVES][TILE_C];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm[t.w][i * 64 + t.lane] = col[i];   // [i][lane]: conflict-free
+    __syncthreads();
+    for (int k = threadIdx.x; k < TILE_C; k += NTHR) {      // k = channel within the tile: coalesced global writes
+        const int s = (k & 7) * 64 + (k >> 3);
+        const int cc = blockIdx.x * TILE_C + k;
+        if (cc < C) colpart[(size_t)blockIdx.y * C + cc] = sm[0][s] + sm[1][s] + sm[2][s] + sm[3][s];
+    }
+}
+
+// finalize: U[n] = rowmean/mean(rowmean) (1-bit, fastpath.py:164-165) or rowmean/(mean+1e-6) (2-bit, :619-622);
+//           V[c] = colmean (fastpath.py:160,166 / :618).  Written straight into the packet tail (replaces the
+//           torch.cat of main.py:149-152).  grid = (1 + ceil(C/256), batch).
+__global__ __launch_bounds__(256) void k_absmean_finalize(BatchC batch, int N, int C, int CB, int P, int per_byte,
+                                                          int eps_mode, const u64* ws, size_t ws_stride) {
+    const cfx_comp_item it = batch.it[blockIdx.y];
+    const u64* rowpart = ws + (size_t)blockIdx.y * ws_stride;
+    const u64* colpart = rowpart + (size_t)N * CB;
+    h16* U = (h16*)((char*)it.packet + (size_t)N * (C / per_byte));
+    h16* V = U + N;
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        __shared__ u64 red[256];
+        u64 acc = 0;
+        for (int n = tid; n < N; n += 256) {
+            u64 s = 0;
+            for (int k = 0; k < CB; ++k) s += rowpart[(size_t)n * CB + k];
+            acc += habs_units(hbits(mean16(s, C)));
+        }
+        red[tid] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        const h16 mu = mean16(red[0], N);
+        const float den = eps_mode ? (float)(h16)((float)mu + 1e-6f) : (float)mu;
+        for (int n = tid; n < N; n += 256) {
+            u64 s = 0;
+            for (int k = 0; k < CB; ++k) s += rowpart[(size_t)n * CB + k];
+            U[n] = (h16)((float)mean16(s, C) / den);
+        }
+    } else {
+        const int c = (blockIdx.x - 1) * 256 + tid;
+        if (c < C) {
+            u64 s = 0;
+            for (int p = 0; p < P; ++p) s += colpart[(size_t)p * C + c];
+            V[c] = mean16(s, N);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 1-bit dequant + base add        replaces _binary_dequant_fastpath (fastpath.py:277-367) AND the
+// UPDATE_CACHE branch of _binary_quant_fastpath (fastpath.py:88-120): out = base + (2b-1)*fp16(u[n]*v[c])
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, int C, int R) {
+    const cfx_decomp_item it = batch.it[blockIdx.z];
+    const TileCoord t = tile_coord(N, C, R);
+    const unsigned char* pk = (const unsigned char*)it.packet;
+    const int C8 = C >> 3;
+    const h16* U = (const h16*)(pk + (size_t)N * C8);
+    const h16* V = U + N;
+    const h16* base = (const h16*)it.base;
+    h16* out = (h16*)it.recon;
+    const bool val16 = (((uintptr_t)V) & 15) == 0;
+    h16x8 v8 = (h16x8)(h16)0;
+    if (t.act) v8 = ld8_tail(V + t.c, val16);
+
+    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL) {
+        h16x8 bv[UNROLL];
+        unsigned by[UNROLL];
+        h16 u[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int rr = r + WAVES * j;
+            bv[j] = (h16x8)(h16)0;
+            by[j] = 0;
+            u[j] = (h16)0;
+            if (rr < t.r1 && t.act) {
+                if (base) bv[j] = ld8(base + (size_t)rr * C + t.c);
+                by[j] = pk[(size_t)rr * C8 + (t.c >> 3)];
+                u[j] = U[rr];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int rr = r + WAVES * j;
+            if (rr < t.r1 && t.act) {
+                const h16x8 s = v8 * u[j];                       // fp16(u*v), one rounding (fastpath.py:109,328)
+                u16x8 sb = __builtin_bit_cast(u16x8, s);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sb[i] ^= ((by[j] >> i) & 1u) ? (u16)0 : (u16)0x8000;   // (2b-1)*s
+                const h16x8 recv = __builtin_bit_cast(h16x8, sb);
+                st8(out + (size_t)rr * C + t.c, base ? (bv[j] + recv) : recv);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 2-bit quantise (+EF)            replaces _int2_quant_fastpath (fastpath.py:486-580)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ h16x8 int2_recv(u16 code, h16x8 thr) {
+    h16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned idx = (code >> (2 * i)) & 3u;
+        const h16 lvl = (idx & 1u) ? (h16)2.0 * thr[i] : (h16)0.5 * thr[i];   // fastpath.py:565-568
+        r[i] = (idx & 2u) ? lvl : -lvl;                                          // (+-1) * lvl
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(NTHR) void k_int2_quant(BatchC batch, int N, int C, int R, int flags) {
+    const cfx_comp_item it = batch.it[blockIdx.z];
+    const TileCoord t = tile_coord(N, C, R);
+    const int C4 = C >> 2;
+    unsigned char* pk = (unsigned char*)it.packet;
+    const h16* TOK = (const h16*)(pk + (size_t)N * C4);
+    const h16* CH = TOK + N;
+    const h16* x = (const h16*)it.x;
+    const h16* base = (const h16*)it.base;
+    h16* nb = (h16*)it.new_base;
+    const bool upd = (flags & CFX_FLAG_UPDATE_CACHE) && nb;
+    const bool ef = !(flags & CFX_FLAG_NO_EF);
+    const bool al16 = (((uintptr_t)CH) & 15) == 0;
+    h16x8 ch8 = (h16x8)(h16)0;
+    if (t.act) ch8 = ld8_tail(CH + t.c, al16);
+
+    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL) {
+        h16x8 xv[UNROLL], bv[UNROLL];
+        h16 tk[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int rr = r + WAVES * j;
+            xv[j] = (h16x8)(h16)0; bv[j] = (h16x8)(h16)0; tk[j] = (h16)0;
+            if (rr < t.r1 && t.act) {
+                xv[j] = ld8(x + (size_t)rr * C + t.c);
+                if (base) bv[j] = ld8(base + (size_t)rr * C + t.c);
+                tk[j] = TOK[rr];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int rr = r + WAVES * j;
+            if (rr < t.r1 && t.act) {
+                const h16x8 d = xv[j] - bv[j];
+                const h16x8 thr = ch8 * tk[j];                                   // fastpath.py:536
+                const h16x8 a = habs8(d);
+                unsigned code = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned s = d[i] >= (h16)0 ? 1u : 0u;                 // fastpath.py:539
+                    const unsigned m = a[i] > thr[i] ? 1u : 0u;                  // fastpath.py:540
+                    code |= ((s << 1) | m) << (2 * i);
+                }
+                *reinterpret_cast<u16*>(pk + (size_t)rr * C4 + (t.c >> 2)) = (u16)code;
+                if (upd) {
+                    h16x8 o;
+                    if (ef) {
+                        const h16x8 recv = int2_recv((u16)code, thr);
+                        o = base ? (bv[j] + recv) : recv;
+                    } else {
+                        o = xv[j];
+                    }
+                    st8(nb + (size_t)rr * C + t.c, o);
+                }
+            }
+        }
+    }
+}
+
+// 2-bit dequant + base add        replaces _int2_dequant_fastpath (fastpath.py:672-741)
+__global__ __launch_bounds__(NTHR) void k_int2_dequant(BatchD batch, int N, int C, int R) {
+    const cfx_decomp_item it = batch.it[blockIdx.z];
+    const TileCoord t = tile_coord(N, C, R);
+    const int C4 = C >> 2;
+    const unsigned char* pk = (const unsigned char*)it.packet;
+    const h16* TOK = (const h16*)(pk + (size_t)N * C4);
+    const h16* CH = TOK + N;
+    const h16* base = (const h16*)it.base;
+    h16* out = (h16*)it.recon;
+    const bool al16 = (((uintptr_t)CH) & 15) == 0;
+    h16x8 ch8 = (h16x8)(h16)0;
+    if (t.act) ch8 = ld8_tail(CH + t.c, al16);
+
+    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL) {
+        h16x8 bv[UNROLL];
+        u16 cd[UNROLL];
+        h16 tk[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int rr = r + WAVES * j;
+            bv[j] = (h16x8)(h16)0; cd[j] = 0; tk[j] = (h16)0;
+            if (rr < t.r1 && t.act) {
+                if (base) bv[j] = ld8(base + (size_t)rr * C + t.c);
+                cd[j] = *reinterpret_cast<const u16*>(pk + (size_t)rr * C4 + (t.c >> 2));
+                tk[j] = TOK[rr];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int rr = r + WAVES * j;
+            if (rr < t.r1 && t.act) {
+                const h16x8 thr = ch8 * tk[j];
+                const h16x8 recv = int2_recv(cd[j], thr);
+                st8(out + (size_t)rr * C + t.c, base ? (bv[j] + recv) : recv);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-channel min/max statistics pass (int4 / int8)    compress_quantize.py:452-453, :552-553
+//   part[p][c] = {min, max} of (x-base) over the tile's rows (fp16 compares are exact)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHR) void k_minmax_stats(BatchC batch, int N, int C, int R, u64* ws, size_t ws_stride) {
+    const cfx_comp_item it = batch.it[blockIdx.z];
+    const TileCoord t = tile_coord(N, C, R);
+    unsigned* part = (unsigned*)(ws + (size_t)blockIdx.z * ws_stride);   // [P][C] of {min16 | max16<<16}
+    const h16* x = (const h16*)it.x;
+    const h16* base = (const h16*)it.base;
+    h16x8 mn = (h16x8)(h16)65504.0f, mx = (h16x8)(h16)-65504.0f;
+    mn = (h16x8)hfrom(0x7c00);   // +inf
+    mx = (h16x8)hfrom(0xfc00);   // -inf
+    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL) {
+        h16x8 xv[UNROLL], bv[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int rr = r + WAVES * j;
+            xv[j] = (h16x8)(h16)0; bv[j] = (h16x8)(h16)0;
+            if (rr < t.r1 && t.act) {
+                xv[j] = ld8(x + (size_t)rr * C + t.c);
+                if (base) bv[j] = ld8(base + (size_t)rr * C + t.c);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int rr = r + WAVES * j;
+            if (rr < t.r1 && t.act) {
+                const h16x8 d = xv[j] - bv[j];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    mn[i] = d[i] < mn[i] ? d[i] : mn[i];
+                    mx[i] = d[i] > mx[i] ? d[i] : mx[i];
+                }
+            }
+        }
+    }
+    __shared__ unsigned sm[WAVES][TILE_C];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm[t.w][i * 64 + t.lane] = (unsigned)hbits(mn[i]) | ((unsigned)hbits(mx[i]) << 16);
+    __syncthreads();
+    for (int k = threadIdx.x; k < TILE_C; k += NTHR) {
+        const int s = (k & 7) * 64 + (k >> 3);
+        const int cc = blockIdx.x * TILE_C + k;
+        if (cc < C) {
+            h16 a = hfrom((u16)(sm[0][s] & 0xffff)), b = hfrom((u16)(sm[0][s] >> 16));
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) {
+                const h16 a2 = hfrom((u16)(sm[w][s] & 0xffff)), b2 = hfrom((u16)(sm[w][s] >> 16));
+                a = a2 < a ? a2 : a;
+                b = b2 > b ? b2 : b;
+            }
+            part[(size_t)blockIdx.y * C + cc] = (unsigned)hbits(a) | ((unsigned)hbits(b) << 16);
+        }
+    }
+}
+
+__device__ __forceinline__ h16 hdiv(h16 a, h16 b) { return (h16)((float)a / (float)b); }   // correctly rounded fp16 quotient
+__device__ __forceinline__ h16 hrint(h16 a) { return __builtin_rintf16(a); }                // round half to even (torch.round)
+__device__ __forceinline__ bool hisnan(h16 a) { return a != a; }
+
+// finalize int4 : scale = fp16(fp16(max-min)/15.000001f), min                     compress_quantize.py:556-558
+//          int8 : scale = fp16(fp16(max-min)/255.0f), zp = clamp(-128 - round(min/scale)) -> int16   :455-463
+__global__ __launch_bounds__(256) void k_minmax_finalize(BatchC batch, int N, int C, int P, int codec, const u64* ws, size_t ws_stride) {
+    const cfx_comp_item it = batch.it[blockIdx.y];
+    const unsigned* part = (const unsigned*)(ws + (size_t)blockIdx.y * ws_stride);
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    h16 mn = hfrom(0x7c00), mx = hfrom(0xfc00);
+    for (int p = 0; p < P; ++p) {
+        const unsigned v = part[(size_t)p * C + c];
+        const h16 a = hfrom((u16)(v & 0xffff)), b = hfrom((u16)(v >> 16));
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    const h16 rng = mx - mn;
+    if (codec == CFX_CODEC_INT4) {
+        h16* S = (h16*)((char*)it.packet + (size_t)(N / 2) * C);
+        S[c] = (h16)((float)rng / 15.000001f);
+        S[C + c] = mn;
+    } else {
+        h16* S = (h16*)((char*)it.packet + (size_t)N * C);
+        short* Z = (short*)(S + C);
+        const h16 scale = (h16)((float)rng / 255.000001f);
+        const h16 r = hrint(hdiv(mn, scale));
+        h16 z = (h16)-128.0f - r;
+        short zi;
+        if (hisnan(z)) zi = 0;
+        else {
+            z = z < (h16)-128.0f ? (h16)-128.0f : z;
+            z = z > (h16)127.0f ? (h16)127.0f : z;
+            zi = (short)(float)z;
+        }
+        S[c] = scale;
+        Z[c] = zi;
+    }
+}
+
+// int8 quantise (+EF)      compress_quantize.py:465-467 ; EF = dequantize_int8 :482 + main.py:232
+__global__ __launch_bounds__(NTHR) void k_int8_quant(BatchC batch, int N, int C, int R, int flags) {
+    const cfx_comp_item it = batch.it[blockIdx.z];
+    const TileCoord t = tile_coord(N, C, R);
+    signed char* q = (signed char*)it.packet;
+    const h16* S = (const h16*)(q + (size_t)N * C);
+    const short* Z = (const short*)(S + C);
+    const h16* x = (const h16*)it.x;
+    const h16* base = (const h16*)it.base;
+    h16* nb = (h16*)it.new_base;
+    const bool upd = (flags & CFX_FLAG_UPDATE_CACHE) && nb;
+    const bool ef = !(flags & CFX_FLAG_NO_EF);
+    h16x8 sc = (h16x8)(h16)1.0f, zp = (h16x8)(h16)0;
+    if (t.act) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sc[i] = S[t.c + i]; zp[i] = (h16)(float)Z[t.c + i]; }
+    }
+    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL) {
+        h16x8 xv[UNROLL], bv[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int rr = r + WAVES * j;
+            xv[j] = (h16x8)(h16)0; bv[j] = (h16x8)(h16)0;
+            if (rr < t.r1 && t.act) {
+                xv[j] = ld8(x + (size_t)rr * C + t.c);
+                if (base) bv[j] = ld8(base + (size_t)rr * C + t.c);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int rr = r + WAVES * j;
+            if (rr < t.r1 && t.act) {
+                const h16x8 d = xv[j] - bv[j];
+                u64 outb = 0;
+                h16x8 qh;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    h16 v = hrint(hdiv(d[i], sc[i]) + zp[i]);            // round(x/scale + zp), fp16 after each op
+                    if (hisnan(v)) v = (h16)0;
+                    v = v < (h16)-128.0f ? (h16)-128.0f : v;
+                    v = v > (h16)127.0f ? (h16)127.0f : v;
+                    qh[i] = v;
+                    outb |= (u64)(unsigned char)(signed char)(int)(float)v << (8 * i);
+                }
+                *reinterpret_cast<u64*>(q + (size_t)rr * C + t.c) = outb;
+                if (upd) {
+                    h16x8 o;
+                    if (ef) {
+                        const h16x8 recv = (qh - zp) * sc;                // (q - zp) * scale
+                        o = base ? (bv[j] + recv) : recv;
+                    } else o = xv[j];
+                    st8(nb + (size_t)rr * C + t.c, o);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(NTHR) void k_int8_dequant(BatchD batch, int N, int C, int R) {
+    const cfx_decomp_item it = batch.it[blockIdx.z];
+    const TileCoord t = tile_coord(N, C, R);
+    const signed char* q = (const signed char*)it.packet;
+    const h16* S = (const h16*)(q + (size_t)N * C);
+    const short* Z = (const short*)(S + C);
+    const h16* base = (const h16*)it.base;
+    h16* out = (h16*)it.recon;
+    h16x8 sc = (h16x8)(h16)1.0f, zp = (h16x8)(h16)0;
+    if (t.act) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sc[i] = S[t.c + i]; zp[i] = (h16)(float)Z[t.c + i]; }
+    }
+    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL) {
+        h16x8 bv[UNROLL];
+        u64 qb[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int rr = r + WAVES * j;
+            bv[j] = (h16x8)(h16)0; qb[j] = 0;
+            if (rr < t.r1 && t.act) {
+                if (base) bv[j] = ld8(base + (size_t)rr * C + t.c);
+                qb[j] = *reinterpret_cast<const u64*>(q + (size_t)rr * C + t.c);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const int rr = r + WAVES * j;
+            if (rr < t.r1 && t.act) {
+                h16x8 qh;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qh[i] = (h16)(float)(int)(signed char)(qb[j] >> (8 * i));
+                const h16x8 recv = (qh - zp) * sc;
+                st8(out + (size_t)rr * C + t.c, base ? (bv[j] + recv) : recv);
+            }
+        }
+    }
+}
+
+// int4 quantise (+EF): one wave step handles the row PAIR (2k, 2k+1) because the reference packs two rows per
+// byte along N (compress_quantize.py:566-573): byte[k][c] = q[2k][c] | q[2k+1][c] << 4.
+// R (rows per tile) is even; pair index space = rows/2.
+__global__ __launch_bounds__(NTHR) void k_int4_quant(BatchC batch, int N, int C, int R, int flags) {
+    const cfx_comp_item it = batch.it[blockIdx.z];
+    const TileCoord t = tile_coord(N, C, R);
+    unsigned char* q = (unsigned char*)it.packet;
+    const h16* S = (const h16*)(q + (size_t)(N / 2) * C);
+    const h16* M = S + C;
+    const h16* x = (const h16*)it.x;
+    const h16* base = (const h16*)it.base;
+    h16* nb = (h16*)it.new_base;
+    const bool upd = (flags & CFX_FLAG_UPDATE_CACHE) && nb;
+    const bool ef = !(flags & CFX_FLAG_NO_EF);
+    const bool al16 = ((((uintptr_t)S) | ((uintptr_t)M)) & 15) == 0;
+    h16x8 sc = (h16x8)(h16)1.0f, mn = (h16x8)(h16)0;
+    if (t.act) { sc = ld8_tail(S + t.c, al16); mn = ld8_tail(M + t.c, al16); }
+    const int k0 = t.r0 >> 1, k1 = t.r1 >> 1;
+    constexpr int U2 = UNROLL / 2;
+    for (int k = k0 + t.w; k < k1; k += WAVES * U2) {
+        h16x8 xv[U2][2], bv[U2][2];
+#pragma unroll
+        for (int j = 0; j < U2; ++j) {
+            const int kk = k + WAVES * j;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                xv[j][h] = (h16x8)(h16)0; bv[j][h] = (h16x8)(h16)0;
+                if (kk < k1 && t.act) {
+                    xv[j][h] = ld8(x + (size_t)(2 * kk + h) * C + t.c);
+                    if (base) bv[j][h] = ld8(base + (size_t)(2 * kk + h) * C + t.c);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < U2; ++j) {
+            const int kk = k + WAVES * j;
+            if (kk < k1 && t.act) {
+                u64 outb = 0;
+                h16x8 qh[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const h16x8 d = xv[j][h] - bv[j][h];
+                    const h16x8 dm = d - mn;                               // (r - min)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        h16 v = hrint(hdiv(dm[i], sc[i]));
+                        if (hisnan(v)) v = (h16)0;
+                        v = v < (h16)0 ? (h16)0 : v;
+                        v = v > (h16)15.0f ? (h16)15.0f : v;
+                        qh[h][i] = v;
+                        outb |= (u64)((unsigned)(float)v & 15u) << (8 * i + 4 * h);
+                    }
+                }
+                *reinterpret_cast<u64*>(q + (size_t)kk * C + t.c) = outb;
+                if (upd) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        h16x8 o;
+                        if (ef) {
+                            const h16x8 recv = qh[h] * sc + mn;            // q*scale + min (two roundings; contraction is off)
+                            o = base ? (bv[j][h] + recv) : recv;
+                        } else o = xv[j][h];
+                        st8(nb + (size_t)(2 * kk + h) * C + t.c, o);
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(NTHR) void k_int4_dequant(BatchD batch, int N, int C, int R) {
+    const cfx_decomp_item it = batch.it[blockIdx.z];
+    const TileCoord t = tile_coord(N, C, R);
+    const unsigned char* q = (const unsigned char*)it.packet;
+    const h16* S = (const h16*)(q + (size_t)(N / 2) * C);
+    const h16* M = S + C;
+    const h16* base = (const h16*)it.base;
+    h16* out = (h16*)it.recon;
+    const bool al16 = ((((uintptr_t)S) | ((uintptr_t)M)) & 15) == 0;
+    h16x8 sc = (h16x8)(h16)1.0f, mn = (h16x8)(h16)0;
+    if (t.act) { sc = ld8_tail(S + t.c, al16); mn = ld8_tail(M + t.c, al16); }
+    const int k0 = t.r0 >> 1, k1 = t.r1 >> 1;
+    constexpr int U2 = UNROLL / 2;
+    for (int k = k0 + t.w; k < k1; k += WAVES * U2) {
+        h16x8 bv[U2][2];
+        u64 qb[U2];
+#pragma unroll
+        for (int j = 0; j < U2; ++j) {
+            const int kk = k + WAVES * j;
+            qb[j] = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                bv[j][h] = (h16x8)(h16)0;
+                if (kk < k1 && t.act && base) bv[j][h] = ld8(base + (size_t)(2 * kk + h) * C + t.c);
+            }
+            if (kk < k1 && t.act) qb[j] = *reinterpret_cast<const u64*>(q + (size_t)kk * C + t.c);
+        }
+#pragma unroll
+        for (int j = 0; j < U2; ++j) {
+            const int kk = k + WAVES * j;
+            if (kk < k1 && t.act) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    h16x8 qh;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) qh[i] = (h16)(float)((qb[j] >> (8 * i + 4 * h)) & 15u);
+                    const h16x8 recv = qh * sc + mn;
+                    st8(out + (size_t)(2 * kk + h) * C + t.c, base ? (bv[j][h] + recv) : recv);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 1:m block top-1 sparsifier on the flat (-1, 1024) view       compress_topk.py:44-105, :128-163
+// One lane owns 8 consecutive flat elements.  Half-blocks of m <= 8 live inside a lane; m = 16 spans two lanes.
+// ---------------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256) void k_topk_compress(BatchC batch, size_t E, int flags) {
+    const cfx_comp_item it = batch.it[blockIdx.y];
+    const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (e >= E) return;   // E % 1024 == 0 and 256*8 = 2048: whole waves exit together
+    const h16* x = (const h16*)it.x;
+    const h16* base = (const h16*)it.base;
+    h16* nb = (h16*)it.new_base;
+    h16* val = (h16*)it.packet;
+    unsigned char* idx = (unsigned char*)(val + E / M);
+    const bool upd = (flags & CFX_FLAG_UPDATE_CACHE) && nb;
+    const bool ef = !(flags & CFX_FLAG_NO_EF);
+    const h16x8 xv = ld8(x + e);
+    h16x8 bv = (h16x8)(h16)0;
+    if (base) bv = ld8(base + e);
+    const h16x8 d = xv - bv;
+    const h16x8 a = habs8(d);
+    unsigned keep = 0;   // bit i set = element i survives
+    if constexpr (M <= 8) {
+        constexpr int HB = 8 / M;   // half-blocks per lane
+        unsigned sel[HB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+            int best = 0;
+            h16 bestv = a[hb * M];
+#pragma unroll
+            for (int i = 1; i < M; ++i) {
+                const h16 v = a[hb * M + i];
+                if (v > bestv) { bestv = v; best = i; }     // strict: first maximum wins (tl.argmax)
+            }
+            sel[hb] = best;
+            keep |= 1u << (hb * M + best);
+            val[e / M + hb] = d[hb * M + best];
+        }
+        if constexpr (M == 8) {
+            const unsigned other = __shfl_xor(sel[0], 1, 64);
+            if ((threadIdx.x & 1) == 0) idx[e / 16] = (unsigned char)((sel[0] << 4) | other);
+        } else {
+#pragma unroll
+            for (int bk = 0; bk < HB / 2; ++bk) idx[e / (2 * M) + bk] = (unsigned char)((sel[2 * bk] << 4) | sel[2 * bk + 1]);
+        }
+    } else {   // M == 16: half-block = lanes (2k, 2k+1); block = 4 lanes
+        int best = 0;
+        h16 bestv = a[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) if (a[i] > bestv) { bestv = a[i]; best = i; }
+        const int odd = threadIdx.x & 1;
+        const unsigned pb = hbits(bestv);
+        const unsigned ob = __shfl_xor(pb, 1, 64);
+        const int oi = __shfl_xor(best, 1, 64);
+        // lower lane wins ties (its elements come first)
+        const bool mine = odd ? (hfrom((u16)pb) > hfrom((u16)ob)) : !(hfrom((u16)ob) > hfrom((u16)pb));
+        const int selidx = mine ? (best + 8 * odd) : (oi + 8 * (1 - odd));   // index within the 16-wide half-block
+        if (mine) { keep |= 1u << best; val[e / 16] = d[best]; }
+        const int other = __shfl_xor(selidx, 2, 64);
+        if ((threadIdx.x & 3) == 0) idx[e / 32] = (unsigned char)((selidx << 4) | other);
+    }
+    if (upd) {
+        h16x8 o;
+        if (ef) {
+            h16x8 recv;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) recv[i] = ((keep >> i) & 1u) ? d[i] : (h16)0;
+            o = base ? (bv + recv) : recv;
+        } else o = xv;
+        st8(nb + e, o);
+    }
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void k_topk_decompress(BatchD batch, size_t E) {
+    const cfx_decomp_item it = batch.it[blockIdx.y];
+    const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (e >= E) return;
+    const h16* val = (const h16*)it.packet;
+    const unsigned char* idx = (const unsigned char*)(val + E / M);
+    const h16* base = (const h16*)it.base;
+    h16* out = (h16*)it.recon;
+    h16x8 recv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const size_t ei = e + i;
+        const size_t hb = ei / M;                    // half-block
+        const unsigned by = idx[hb >> 1];
+        const unsigned sel = (hb & 1) ? (by & 15u) : (by >> 4);
+        recv[i] = ((unsigned)(ei % M) == sel) ? val[hb] : (h16)0;
+    }
+    h16x8 bv = (h16x8)(h16)0;
+    if (base) bv = ld8(base + e);
+    st8(out + e, base ? (bv + recv) : recv);
+}
+
+__global__ __launch_bounds__(256) void k_copy_probe(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side: C-ABI
+// ---------------------------------------------------------------------------------------------------
+struct cfx_ctx {
+    int device;
+    int rows_per_tile;
+    char err[256];
+};
+
+static int fail(cfx_ctx* ctx, int code, const char* msg) {
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
+    return code;
+}
+
+static bool shape_ok(int codec, int N, int C, int param) {
+    if (N <= 0 || C <= 0 || (C % 8) != 0) return false;
+    switch (codec) {
+        case CFX_CODEC_BINARY: return ((size_t)N * (C / 8)) % 2 == 0;
+        case CFX_CODEC_INT2: return true;
+        case CFX_CODEC_INT4: return N % 2 == 0;
+        case CFX_CODEC_INT8: return true;
+        case CFX_CODEC_TOPK:
+            return ((size_t)N * C) % 1024 == 0 && (param == 1 || param == 2 || param == 4 || param == 8 || param == 16);
+        default: return false;
+    }
+}
+
+static int auto_rows(const cfx_ctx* ctx, int N, int C, int batch, bool stats) {
+    if (ctx && ctx->rows_per_tile > 0) {
+        int r = ctx->rows_per_tile;
+        if (stats && r < 16) r = 16;
+        return (r + 1) & ~1;
+    }
+    const int CB = (C + TILE_C - 1) / TILE_C;
+    const int cands[3] = {64, 32, 16};
+    for (int i = 0; i < 3; ++i) {
+        const long tiles = (long)CB * ((N + cands[i] - 1) / cands[i]) * batch;
+        if (tiles >= 1024) return cands[i];
+    }
+    return 16;
+}
+
+extern "C" {
+
+int cfx_abi_version(void) { return CFX_ABI_VERSION; }
+
+cfx_ctx* cfx_create(int device) {
+    cfx_ctx* c = new cfx_ctx();
+    c->device = device;
+    c->rows_per_tile = 0;
+    c->err[0] = 0;
+    return c;
+}
+
+void cfx_destroy(cfx_ctx* ctx) { delete ctx; }
+
+const char* cfx_last_error_string(cfx_ctx* ctx) { return ctx ? ctx->err : "null ctx"; }
+
+int cfx_set_rows_per_tile(cfx_ctx* ctx, int rows) {
+    if (!ctx) return CFX_ERR_NULL;
+    ctx->rows_per_tile = rows < 0 ? 0 : rows;
+    return CFX_OK;
+}
+
+size_t cfx_packet_bytes(int codec, int N, int C, int param) {
+    if (!shape_ok(codec, N, C, param)) return 0;
+    const size_t n = N, c = C;
+    switch (codec) {
+        case CFX_CODEC_BINARY: return n * c / 8 + 2 * (n + c);
+        case CFX_CODEC_INT2: return n * c / 4 + 2 * (n + c);
+        case CFX_CODEC_INT4: return n * c / 2 + 4 * c;
+        case CFX_CODEC_INT8: return n * c + 4 * c;
+        case CFX_CODEC_TOPK: return 2 * (n * c / param) + n * c / (2 * param);
+    }
+    return 0;
+}
+
+// per-tensor workspace in u64 words (worst case R = 16)
+static size_t ws_words(int codec, int N, int C) {
+    const size_t CB = (C + TILE_C - 1) / TILE_C, P = (N + 15) / 16;
+    switch (codec) {
+        case CFX_CODEC_BINARY:
+        case CFX_CODEC_INT2: return (size_t)N * CB + P * C;
+        case CFX_CODEC_INT4:
+        case CFX_CODEC_INT8: return (P * C + 1) / 2;
+        default: return 0;
+    }
+}
+
+size_t cfx_workspace_bytes(int codec, int N, int C, int param, int batch) {
+    if (!shape_ok(codec, N, C, param) || batch < 1 || batch > CFX_MAX_BATCH) return 0;
+    return ws_words(codec, N, C) * 8 * batch;
+}
+
+static int check_launch(cfx_ctx* ctx, const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        char buf[200];
+        snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+        return fail(ctx, CFX_ERR_LAUNCH, buf);
+    }
+    return CFX_OK;
+}
+
+#define AL16(p) ((((uintptr_t)(p)) & 15) == 0)
+
+int cfx_decompress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items, void* stream) {
+    if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "decompress: null ctx/items");
+    if (batch < 1 || batch > CFX_MAX_BATCH) return fail(ctx, CFX_ERR_BATCH, "decompress: batch out of range");
+    if (!shape_ok(codec, N, C, param)) return fail(ctx, codec >= 1 && codec <= 5 ? CFX_ERR_SHAPE : CFX_ERR_CODEC, "decompress: bad codec/shape");
+    BatchD b;
+    memset(&b, 0, sizeof(b));
+    for (int i = 0; i < batch; ++i) {
+        if (!items[i].packet || !items[i].recon) return fail(ctx, CFX_ERR_NULL, "decompress: null packet/recon");
+        if (!AL16(items[i].packet) || !AL16(items[i].recon) || !AL16(items[i].base)) return fail(ctx, CFX_ERR_ALIGN, "decompress: pointers must be 16-byte aligned");
+        b.it[i] = items[i];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int R = auto_rows(ctx, N, C, batch, false);
+    const dim3 grid((C + TILE_C - 1) / TILE_C, (N + R - 1) / R, batch);
+    switch (codec) {
+        case CFX_CODEC_BINARY: hipLaunchKernelGGL(k_binary_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
+        case CFX_CODEC_INT2: hipLaunchKernelGGL(k_int2_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
+        case CFX_CODEC_INT4: hipLaunchKernelGGL(k_int4_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
+        case CFX_CODEC_INT8: hipLaunchKernelGGL(k_int8_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
+        case CFX_CODEC_TOPK: {
+            const size_t E = (size_t)N * C;
+            const dim3 g((unsigned)((E / 8 + 255) / 256), batch);
+            switch (param) {
+                case 1: hipLaunchKernelGGL(k_topk_decompress<1>, g, dim3(256), 0, s, b, E); break;
+                case 2: hipLaunchKernelGGL(k_topk_decompress<2>, g, dim3(256), 0, s, b, E); break;
+                case 4: hipLaunchKernelGGL(k_topk_decompress<4>, g, dim3(256), 0, s, b, E); break;
+                case 8: hipLaunchKernelGGL(k_topk_decompress<8>, g, dim3(256), 0, s, b, E); break;
+                default: hipLaunchKernelGGL(k_topk_decompress<16>, g, dim3(256), 0, s, b, E); break;
+            }
+        } break;
+    }
+    return check_launch(ctx, "decompress launch");
+}
+
+int cfx_compress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "compress: null ctx/items");
+    if (batch < 1 || batch > CFX_MAX_BATCH) return fail(ctx, CFX_ERR_BATCH, "compress: batch out of range");
+    if (!shape_ok(codec, N, C, param)) return fail(ctx, codec >= 1 && codec <= 5 ? CFX_ERR_SHAPE : CFX_ERR_CODEC, "compress: bad codec/shape");
+    const bool upd = flags & CFX_FLAG_UPDATE_CACHE;
+    BatchC b;
+    memset(&b, 0, sizeof(b));
+    for (int i = 0; i < batch; ++i) {
+        if (!items[i].x || !items[i].packet) return fail(ctx, CFX_ERR_NULL, "compress: null x/packet");
+        if (upd && !items[i].new_base) return fail(ctx, CFX_ERR_NULL, "compress: UPDATE_CACHE needs new_base");
+        if (!AL16(items[i].x) || !AL16(items[i].base) || !AL16(items[i].new_base) || !AL16(items[i].packet))
+            return fail(ctx, CFX_ERR_ALIGN, "compress: pointers must be 16-byte aligned");
+        b.it[i] = items[i];
+    }
+    const size_t need = cfx_workspace_bytes(codec, N, C, param, batch);
+    if (need && (!workspace || workspace_bytes < need)) return fail(ctx, CFX_ERR_WORKSPACE, "compress: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t wstride = ws_words(codec, N, C);
+    u64* ws = (u64*)workspace;
+    const int CB = (C + TILE_C - 1) / TILE_C;
+
+    if (codec == CFX_CODEC_TOPK) {
+        const size_t E = (size_t)N * C;
+        const dim3 g((unsigned)((E / 8 + 255) / 256), batch);
+        switch (param) {
+            case 1: hipLaunchKernelGGL(k_topk_compress<1>, g, dim3(256), 0, s, b, E, flags); break;
+            case 2: hipLaunchKernelGGL(k_topk_compress<2>, g, dim3(256), 0, s, b, E, flags); break;
+            case 4: hipLaunchKernelGGL(k_topk_compress<4>, g, dim3(256), 0, s, b, E, flags); break;
+            case 8: hipLaunchKernelGGL(k_topk_compress<8>, g, dim3(256), 0, s, b, E, flags); break;
+            default: hipLaunchKernelGGL(k_topk_compress<16>, g, dim3(256), 0, s, b, E, flags); break;
+        }
+        return check_launch(ctx, "topk compress launch");
+    }
+
+    const int R = auto_rows(ctx, N, C, batch, true);
+    const int P = (N + R - 1) / R;
+    const dim3 grid(CB, P, batch);
+    if (codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT2) {
+        if (codec == CFX_CODEC_BINARY) hipLaunchKernelGGL(k_absmean_stats<true>, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
+        else hipLaunchKernelGGL(k_absmean_stats<false>, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
+        const int per_byte = codec == CFX_CODEC_BINARY ? 8 : 4;
+        hipLaunchKernelGGL(k_absmean_finalize, dim3(1 + (C + 255) / 256, batch), dim3(256), 0, s, b, N, C, CB, P, per_byte,
+                           codec == CFX_CODEC_INT2 ? 1 : 0, (const u64*)ws, wstride);
+        if (codec == CFX_CODEC_INT2) {
+            hipLaunchKernelGGL(k_int2_quant, grid, dim3(NTHR), 0, s, b, N, C, R, flags);
+        } else if (upd) {
+            if (flags & CFX_FLAG_NO_EF) {
+                for (int i = 0; i < batch; ++i)
+                    if (items[i].new_base != items[i].x)
+                        (void)hipMemcpyAsync(items[i].new_base, items[i].x, (size_t)N * C * 2, hipMemcpyDeviceToDevice, s);
+            } else {
+                // error-feedback update == the receiver's dequant+add on our own packet
+                BatchD d;
+                memset(&d, 0, sizeof(d));
+                for (int i = 0; i < batch; ++i) { d.it[i].packet = items[i].packet; d.it[i].base = items[i].base; d.it[i].recon = items[i].new_base; }
+                hipLaunchKernelGGL(k_binary_dequant, grid, dim3(NTHR), 0, s, d, N, C, R);
+            }
+        }
+    } else {
+        hipLaunchKernelGGL(k_minmax_stats, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
+        hipLaunchKernelGGL(k_minmax_finalize, dim3((C + 255) / 256, batch), dim3(256), 0, s, b, N, C, P, codec, (const u64*)ws, wstride);
+        if (codec == CFX_CODEC_INT4) hipLaunchKernelGGL(k_int4_quant, grid, dim3(NTHR), 0, s, b, N, C, R, flags);
+        else hipLaunchKernelGGL(k_int8_quant, grid, dim3(NTHR), 0, s, b, N, C, R, flags);
+    }
+    return check_launch(ctx, "compress launch");
+}
+
+int cfx_compress(cfx_ctx* ctx, int codec, const void* x, const void* base, void* new_base, void* packet, int N, int C, int param,
+                 int flags, void* workspace, size_t workspace_bytes, void* stream) {
+    cfx_comp_item it = {x, base, new_base, packet};
+    return cfx_compress_batch(ctx, codec, N, C, param, flags, 1, &it, workspace, workspace_bytes, stream);
+}
+
+int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base, void* recon, int N, int C, int param, void* stream) {
+    cfx_decomp_item it = {packet, base, recon};
+    return cfx_decompress_batch(ctx, codec, N, C, param, 1, &it, stream);
+}
+
+int cfx_copy_probe(cfx_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {
+    if (!ctx || !dst || !src) return fail(ctx, CFX_ERR_NULL, "copy_probe: null");
+    if ((bytes & 15) || !AL16(dst) || !AL16(src)) return fail(ctx, CFX_ERR_ALIGN, "copy_probe: 16-byte granularity");
+    hipLaunchKernelGGL(k_copy_probe, dim3(2048), dim3(256), 0, (hipStream_t)stream, (uint4*)dst, (const uint4*)src, bytes / 16);
+    return check_launch(ctx, "copy_probe launch");
+}
+
+}  // extern "C"

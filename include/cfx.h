@@ -1,0 +1,124 @@
+/*
+ * cfx.h - C-ABI of libcfx.so: MI355X (gfx950) residual-compressed activation exchange kernels.
+ *
+ * This is the drop-in boundary for CompactFusion's compressor hot path.  The reference has no
+ * FFI (it is Python + Triton); these entry points are what a binding for that
+ * path would call, one per reference kernel wrapper:
+ *
+ *   cfx_compress[_batch]   replaces  binary_quant_fastpath   xfuser/compact/fastpath.py:124-228  (+ eager scale prologue :150-166)
+ *                                    int2_quant_fastpath     xfuser/compact/fastpath.py:584-669  (+ prologue :614-625)
+ *                                    quantize_int8 on delta  xfuser/compact/compress_quantize.py:428-471 composed with main.py:227-233
+ *                                    quantize_int4 on delta  xfuser/compact/compress_quantize.py:522-583 composed with main.py:227-233
+ *                                    topk_compress           xfuser/compact/compress_topk.py:11-105 (slowpath.py:76-79)
+ *                                    and the wire packing    xfuser/compact/main.py:149-152, slowpath.py:83
+ *   cfx_decompress[_batch] replaces  binary_dequant_fastpath xfuser/compact/fastpath.py:371-438
+ *                                    int2_dequant_fastpath   xfuser/compact/fastpath.py:745-811
+ *                                    dequantize_int8/int4    xfuser/compact/compress_quantize.py:473-484, :585-640 (+ base add main.py:376)
+ *                                    topk_decompress         xfuser/compact/compress_topk.py:108-163
+ *                                    and the wire unpacking  xfuser/compact/main.py:285-304, slowpath.py:137-169
+ *   cfx_packet_bytes       replaces  the size arithmetic of  xfuser/compact/main.py:285-293, slowpath.py:111-135
+ *
+ * Conventions
+ *   - All tensor pointers are DEVICE pointers to contiguous row-major (N, C) fp16 ("half") data.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are asynchronous.
+ *   - No torch types, no exceptions: every call returns CFX_OK (0) or a negative error code and
+ *     records a message retrievable with cfx_last_error_string().
+ *   - The library keeps no state besides the opaque cfx_ctx (device id, tuning, last error).
+ *     Workspace is caller-provided so calls can be captured in a hipGraph.
+ *
+ * Wire layouts (little endian; identical to the reference where the reference defines one)
+ *   BINARY  [ bits  N*C/8 B : bit i of byte j of row n = (x-base)[n,8j+i] >= 0 | U  N fp16 | V  C fp16 ]   main.py:149-152
+ *   INT2    [ codes N*C/4 B : 2-bit (sign<<1|mag) , element j at bits 2(j%4)   | tok N fp16 | chan C fp16 ]   main.py:149-152
+ *   INT4    [ codes N*C/2 B : byte [n/2][c] = q[n][c] | q[n+1][c]<<4           | scale C fp16 | min C fp16 ]   compress_quantize.py:566-573
+ *   INT8    [ q     N*C   B : int8                                             | scale C fp16 | zp  C int16 ]  compress_quantize.py:463-471
+ *   TOPK    [ val N*C/m fp16 | idx N*C/(2m) B : (i1<<4)|i2 per 2m-block of the flat (-1,1024) view ]           slowpath.py:76-79
+ */
+#ifndef CFX_H
+#define CFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFX_ABI_VERSION 1
+#define CFX_MAX_BATCH 16
+
+typedef struct cfx_ctx cfx_ctx;
+
+enum cfx_status {
+    CFX_OK = 0,
+    CFX_ERR_NULL = -1,       /* a required pointer is NULL */
+    CFX_ERR_SHAPE = -2,      /* N/C/param violate the codec's divisibility rules */
+    CFX_ERR_ALIGN = -3,      /* a tensor pointer is not 16-byte aligned / packet not 2-byte aligned */
+    CFX_ERR_CODEC = -4,      /* unknown codec id */
+    CFX_ERR_BATCH = -5,      /* batch < 1 or > CFX_MAX_BATCH */
+    CFX_ERR_LAUNCH = -6,     /* hipGetLastError() after a launch was not hipSuccess */
+    CFX_ERR_WORKSPACE = -7   /* workspace NULL or smaller than cfx_workspace_bytes() */
+};
+
+enum cfx_codec {
+    CFX_CODEC_BINARY = 1,    /* COMPACT_COMPRESS_TYPE.BINARY fastpath, comp_rank = -1 */
+    CFX_CODEC_INT2 = 2,      /* COMPACT_COMPRESS_TYPE.INT2 fastpath */
+    CFX_CODEC_INT4 = 3,      /* per-channel min/max 16 levels, rows paired per byte */
+    CFX_CODEC_INT8 = 4,      /* per-channel affine int8, zero point int16 */
+    CFX_CODEC_TOPK = 5       /* COMPACT_COMPRESS_TYPE.SPARSE, param = m in {1,2,4,8,16} */
+};
+
+enum cfx_flags {
+    CFX_FLAG_UPDATE_CACHE = 1, /* write new_base (compact_compress(update_cache=True)) */
+    CFX_FLAG_NO_EF = 2         /* error feedback off: new_base = x (main.py:233 `else x`) */
+};
+
+/* One tensor of a compress batch.  base may be NULL (compress_residual == 0: the codec sees x itself);
+ * new_base may alias base (in-place error-feedback update) and is ignored unless CFX_FLAG_UPDATE_CACHE. */
+typedef struct cfx_comp_item {
+    const void* x;        /* (N,C) fp16, 16-byte aligned */
+    const void* base;     /* (N,C) fp16, 16-byte aligned, or NULL */
+    void*       new_base; /* (N,C) fp16, 16-byte aligned, or NULL */
+    void*       packet;   /* cfx_packet_bytes() bytes, 2-byte aligned (16-byte aligned is faster) */
+} cfx_comp_item;
+
+/* One tensor of a decompress batch.  recon = base + decode(packet) (base NULL: recon = decode(packet)).
+ * recon may alias base (the receiver's cache update, main.py:317-319). */
+typedef struct cfx_decomp_item {
+    const void* packet;
+    const void* base;
+    void*       recon;
+} cfx_decomp_item;
+
+int         cfx_abi_version(void);
+cfx_ctx*    cfx_create(int device);
+void        cfx_destroy(cfx_ctx* ctx);
+const char* cfx_last_error_string(cfx_ctx* ctx);
+
+/* rows per workgroup tile for the streaming kernels (0 = automatic). */
+int         cfx_set_rows_per_tile(cfx_ctx* ctx, int rows);
+
+/* Size in bytes of one packet / of the scratch workspace a compress batch needs. 0 on invalid arguments. */
+size_t      cfx_packet_bytes(int codec, int N, int C, int param);
+size_t      cfx_workspace_bytes(int codec, int N, int C, int param, int batch);
+
+int cfx_compress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int flags,
+                       int batch, const cfx_comp_item* items,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+int cfx_decompress_batch(cfx_ctx* ctx, int codec, int N, int C, int param,
+                         int batch, const cfx_decomp_item* items, void* stream);
+
+/* Single-tensor conveniences (batch of one). */
+int cfx_compress(cfx_ctx* ctx, int codec, const void* x, const void* base, void* new_base, void* packet,
+                 int N, int C, int param, int flags, void* workspace, size_t workspace_bytes, void* stream);
+int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base, void* recon,
+                   int N, int C, int param, void* stream);
+
+/* Bandwidth probe: dst[i] = src[i] over `bytes` (multiple of 16) - the achievable-HBM reference
+ * against which bench.py reports roofline fractions. */
+int cfx_copy_probe(cfx_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFX_H */

@@ -1,0 +1,394 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the Python reference in the build container.
+
+This script is test infrastructure.  It runs only where /root/reference exists
+(the build container); the GPU box never runs it.  It writes *data* only
+(inputs + the reference's outputs) into tests/golden/*.npz plus MANIFEST.json.
+No reference source text is copied.
+
+Usage (from repo root):
+    TRITON_INTERPRET=1 TORCHDYNAMO_DISABLE=1 python tests/golden/make_golden.py --mode eager
+    TRITON_INTERPRET=1 python tests/golden/make_golden.py --mode compiled   # inductor numerics, small set
+
+How the reference is imported: `xfuser/__init__.py` pulls in the
+diffusers pipelines (absent here), so a stub package object whose __path__ points
+at the reference tree is registered first; the Profiler is disabled (it records
+CUDA events) and the Collector singleton is initialised disabled.
+
+Groups (SURVEY.md §8c "Golden vectors to capture"):
+  G1 binary fastpath   fastpath.py:124-228, :371-438
+  G2 int2 fastpath     fastpath.py:584-669, :745-811
+  G3 1-bit slowpath    compress_quantize.py:7-90, :154-225, sim_binary :300-335
+  G4 int8 on delta     compress_quantize.py:428-484
+  G5 int4              compress_quantize.py:522-640, sim_int4 :487-520
+  G6 int2 slowpath     compress_quantize.py:642-753, sim_int2 :338-384
+  G7 top-k 1:m         compress_topk.py:11-41, :108-125, sim_topk :221-235
+  G8 low-rank          compress_lowrank.py:14-61, slowpath.py:54-75,151-164
+  G9 state machine     main.py:169-270, :322-388 (compact_compress/compact_decompress traces)
+  G10 2-rank gloo      main.py:390-420 (compact_all_gather)
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def _import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference tree not present; golden vectors can only be generated in the build container")
+    os.environ.setdefault("TRITON_INTERPRET", "1")
+    m = types.ModuleType("xfuser")
+    m.__path__ = [os.path.join(REF, "xfuser")]
+    sys.modules["xfuser"] = m
+    from xfuser.prof import Profiler
+    Profiler.instance().disable()
+    from xfuser.collector import collector
+    collector.init(collector.Collector("/tmp/cfx_golden_collector", enabled=False))
+
+
+def sha(a):
+    import numpy as np
+    a = np.ascontiguousarray(a)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def np16(t):
+    """torch tensor -> numpy, fp16 kept as uint16 bit patterns (exact, NaN-safe)."""
+    import torch
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.float16:
+        return t.view(torch.int16).numpy().view("uint16").copy()
+    return t.numpy().copy()
+
+
+def gen_inputs(seed, N, C):
+    """The reference test recipe, tests/compact/compress_fastpath_test.py:57-58 (CPU generator)."""
+    import torch
+    torch.manual_seed(seed)
+    x = torch.randn((N, C), dtype=torch.half).contiguous()
+    base = (torch.randn_like(x) * 0.1).contiguous()
+    return x, base
+
+
+class Store:
+    def __init__(self, name, mode):
+        self.name, self.mode = name, mode
+        self.arrays = {}
+        self.manifest = {}
+
+    def put(self, key, arr, full=True):
+        import numpy as np
+        arr = np.ascontiguousarray(arr)
+        self.manifest[key] = {"sha256": sha(arr), "shape": list(arr.shape), "dtype": str(arr.dtype), "stored": bool(full)}
+        if full:
+            self.arrays[key] = arr
+
+    def save(self, manifest_all):
+        import numpy as np
+        fn = f"{self.name}_{self.mode}.npz"
+        np.savez_compressed(os.path.join(HERE, fn), **self.arrays)
+        manifest_all[fn] = self.manifest
+
+
+FAST_SHAPES = [(64, 256), (256, 1152), (128, 3072)]
+SEEDS = [42, 43, 44]
+
+
+def full_policy(shape, seed):
+    """Store complete arrays for the small shape (all seeds); for the larger shapes only the small
+    outputs (packed bits, scale vectors) are stored and the big fp16 arrays are pinned by sha256
+    (the test regenerates the inputs from the seed with the recipe of gen_inputs and checks their
+    sha256 first)."""
+    return shape == (64, 256)
+
+
+def g1_g2(mode, man):
+    import torch
+    from xfuser.compact.fastpath import (
+        binary_quant_fastpath, binary_dequant_fastpath,
+        int2_quant_fastpath, int2_dequant_fastpath,
+    )
+    st = Store("g1_binary_fastpath", mode)
+    st2 = Store("g2_int2_fastpath", mode)
+    for (N, C) in FAST_SHAPES:
+        for seed in SEEDS:
+            x, base = gen_inputs(seed, N, C)
+            full = full_policy((N, C), seed)
+            tag = f"{N}x{C}_s{seed}"
+            for s in (st, st2):
+                s.put(f"{tag}/x", np16(x), full)
+                s.put(f"{tag}/base", np16(base), full)
+            p, u, v, nb = binary_quant_fastpath(x, base, -1, True)
+            p2, u2, v2, nb2 = binary_quant_fastpath(x, base, -1, False)
+            assert nb2 is None and torch.equal(p, p2)
+            rec = binary_dequant_fastpath(p, u, v, base)
+            st.put(f"{tag}/packed", np16(p), True)
+            st.put(f"{tag}/u", np16(u), True)
+            st.put(f"{tag}/v", np16(v), True)
+            st.put(f"{tag}/new_base", np16(nb), full)
+            st.put(f"{tag}/recon", np16(rec), full)
+            p, u, v, nb = int2_quant_fastpath(x, base, True, -1)
+            rec = int2_dequant_fastpath(p, u, v, base)
+            st2.put(f"{tag}/packed", np16(p), True)
+            st2.put(f"{tag}/u", np16(u), True)
+            st2.put(f"{tag}/v", np16(v), True)
+            st2.put(f"{tag}/new_base", np16(nb), full)
+            st2.put(f"{tag}/recon", np16(rec), full)
+            print("G1/G2", tag, flush=True)
+    st.save(man)
+    st2.save(man)
+
+
+SLOW_SHAPES = [(64, 256), (256, 1152)]
+
+
+def g3_to_g6(mode, man):
+    import torch
+    from xfuser.compact.compress_quantize import (
+        quantize_1bit, dequantize_1bit, sim_binary,
+        quantize_int8, dequantize_int8,
+        quantize_int4, dequantize_int4, sim_int4,
+        quantize_int2, dequantize_int2, sim_int2, sim_int2_minmax,
+    )
+    st = Store("g3_g6_slowpath_codecs", mode)
+    for (N, C) in SLOW_SHAPES:
+        for seed in SEEDS:
+            x, base = gen_inputs(seed, N, C)
+            delta = x - base
+            full = full_policy((N, C), seed)
+            tag = f"{N}x{C}_s{seed}"
+            st.put(f"{tag}/x", np16(x), full)
+            st.put(f"{tag}/base", np16(base), full)
+            if mode == "eager":
+                # G3 (Triton kernels + eager torch; not affected by torch.compile)
+                p, u, v = quantize_1bit(delta, rank=-1)
+                r = dequantize_1bit(p, u, v)
+                st.put(f"{tag}/b1/packed", np16(p), full)
+                st.put(f"{tag}/b1/u", np16(u), True)
+                st.put(f"{tag}/b1/v", np16(v), True)
+                st.put(f"{tag}/b1/deq", np16(r), full)
+                st.put(f"{tag}/b1/sim", np16(sim_binary(delta, rank=-1)), full)
+                st.put(f"{tag}/i2mm/sim", np16(sim_int2_minmax(delta)), full)
+            # G4 int8 on delta
+            q, s, z = quantize_int8(delta)
+            r = dequantize_int8(q, s, z)
+            st.put(f"{tag}/i8/q", np16(q), full)
+            st.put(f"{tag}/i8/scale", np16(s), True)
+            st.put(f"{tag}/i8/zp", np16(z), True)
+            st.put(f"{tag}/i8/deq", np16(r), full)
+            # G5 int4
+            q, s, mn = quantize_int4(delta)
+            r = dequantize_int4(q, s, mn)
+            st.put(f"{tag}/i4/q", np16(q), full)
+            st.put(f"{tag}/i4/scale", np16(s), True)
+            st.put(f"{tag}/i4/min", np16(mn), True)
+            st.put(f"{tag}/i4/deq", np16(r), full)
+            st.put(f"{tag}/i4/sim", np16(sim_int4(delta, dim=0)), full)
+            # G6 int2 slowpath
+            q, cs, ts = quantize_int2(delta)
+            r = dequantize_int2(q, cs, ts)
+            st.put(f"{tag}/i2/q", np16(q), full)
+            st.put(f"{tag}/i2/chan", np16(cs), True)
+            st.put(f"{tag}/i2/tok", np16(ts), True)
+            st.put(f"{tag}/i2/deq", np16(r), full)
+            st.put(f"{tag}/i2/sim", np16(sim_int2(delta)), full)
+            print("G3-6", tag, flush=True)
+    st.save(man)
+
+
+def g7(mode, man):
+    import torch
+    from xfuser.compact.compress_topk import topk_compress, topk_decompress, sim_topk
+    st = Store("g7_topk", mode)
+    for (N, C) in [(64, 256), (32, 1024)]:
+        for seed in ([42, 43] if N == 64 else [42]):
+            x, base = gen_inputs(seed, N, C)
+            delta = (x - base).contiguous()
+            tag = f"{N}x{C}_s{seed}"
+            st.put(f"{tag}/x", np16(x))
+            st.put(f"{tag}/base", np16(base))
+            for m in (1, 2, 4, 8, 16):
+                val, idx = topk_compress(delta.view(-1, 1024), m)
+                dec = topk_decompress(val, idx, m).view(N, C)
+                st.put(f"{tag}/m{m}/val", np16(val))
+                st.put(f"{tag}/m{m}/idx", np16(idx))
+                st.put(f"{tag}/m{m}/dec", np16(dec))
+                st.put(f"{tag}/m{m}/sim", np16(sim_topk(delta, m)))
+            print("G7", tag, flush=True)
+    # tie-break probe: equal magnitudes inside one block -> which index wins (argmax semantics)
+    t = torch.zeros(1, 1024, dtype=torch.half)
+    t[0, 0:8] = torch.tensor([1, -1, 1, 1, 0.5, -1, 1, -1], dtype=torch.half)
+    t[0, 8:16] = torch.tensor([0, 0, 0, 0, 0, 0, 0, 0], dtype=torch.half)
+    t[0, 16:24] = torch.tensor([-2, 2, -2, 2, 1, 1, 1, 1], dtype=torch.half)
+    for m in (2, 4, 8):
+        val, idx = topk_compress(t, m)
+        st.put(f"ties/m{m}/val", np16(val))
+        st.put(f"ties/m{m}/idx", np16(idx))
+    st.put("ties/x", np16(t))
+    st.save(man)
+
+
+def g8(mode, man):
+    import torch
+    from xfuser.compact.compress_lowrank import subspace_iter
+    from xfuser.compact.slowpath import slowpath_compress, slowpath_decompress
+    from xfuser.compact.utils import COMPACT_COMPRESS_TYPE as T
+    st = Store("g8_lowrank", mode)
+    for (N, C) in [(64, 256), (256, 1152)]:
+        seed = 42
+        x, base = gen_inputs(seed, N, C)
+        delta = (x - base).contiguous()
+        tag = f"{N}x{C}_s{seed}"
+        st.put(f"{tag}/x", np16(x))
+        st.put(f"{tag}/base", np16(base))
+        for r in (8, 32):
+            g = torch.Generator().manual_seed(1000 + r)
+            q0 = torch.randn(C, r, generator=g, dtype=torch.float)
+            q0, _ = torch.linalg.qr(q0)
+            U, V, Q = subspace_iter(delta, r, 2, init_q=q0)
+            st.put(f"{tag}/r{r}/q0", q0.numpy())
+            st.put(f"{tag}/r{r}/U", np16(U))
+            st.put(f"{tag}/r{r}/V", np16(V))
+            st.put(f"{tag}/r{r}/UV", np16(torch.matmul(U, V)))
+        for ctype, name, r in ((T.LOW_RANK, "lr8", 8), (T.LOW_RANK_Q, "lrq32", 32)):
+            with torch.random.fork_rng():
+                torch.manual_seed(seed)
+                pkt = slowpath_compress(delta, ctype, rank=r)
+            dec = slowpath_decompress(pkt, (N, C), ctype, rank=r)
+            st.put(f"{tag}/{name}/packet", np16(pkt))
+            st.put(f"{tag}/{name}/dec", np16(dec))
+        print("G8", tag, flush=True)
+    st.save(man)
+
+
+def _drift_seq(seed, N, C, T):
+    """Config-1 style drift: base0 ~ N(0,1); x_t = x_{t-1} + 0.1*randn."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    xs = []
+    cur = torch.randn(N, C, generator=g).half()
+    for _ in range(T):
+        xs.append(cur.contiguous())
+        cur = (cur.float() + 0.1 * torch.randn(N, C, generator=g)).half()
+    return xs
+
+
+def g9(mode, man):
+    import torch
+    import xfuser.compact.main as cm
+    from xfuser.compact.utils import CompactConfig, COMPACT_COMPRESS_TYPE as T
+    st = Store("g9_state_machine", mode)
+    N, C = 64, 256
+    cases = {
+        # name: (config kwargs, codec type, n_warmup)
+        "binary_fast": (dict(residual=1, ef=True, fastpath=True, comp_rank=-1), T.BINARY, 1),
+        "int2_fast": (dict(residual=1, ef=True, fastpath=True, comp_rank=-1), T.INT2, 1),
+        "binary_slow_ef": (dict(residual=1, ef=True, fastpath=False, comp_rank=-1), T.BINARY, 1),
+        "binary_slow_noef": (dict(residual=1, ef=False, fastpath=False, comp_rank=-1), T.BINARY, 1),
+        "binary_slow_res0": (dict(residual=0, ef=False, fastpath=False, comp_rank=-1), T.BINARY, 0),
+        "binary_slow_res2": (dict(residual=2, ef=True, fastpath=False, comp_rank=-1, delta_decay_factor=0.5), T.BINARY, 2),
+        "int4_sim_ef": (dict(residual=1, ef=True, fastpath=False, simulate=True, comp_rank=-1), T.INT4, 1),
+        "int2_sim_ef": (dict(residual=1, ef=True, fastpath=False, simulate=True, comp_rank=-1), T.INT2, 1),
+        "sparse8_ef": (dict(residual=1, ef=True, fastpath=False, sparse_ratio=8), T.SPARSE, 1),
+    }
+    if mode == "compiled":
+        cases = {k: v for k, v in cases.items() if k in ("int4_sim_ef", "int2_sim_ef")}
+    xs = _drift_seq(7, N, C, 5)
+    for i, x in enumerate(xs):
+        st.put(f"x{i}", np16(x))
+    for name, (kw, ctype, nwarm) in cases.items():
+        cfg = CompactConfig(enabled=True, compress_func=lambda l, s: None, **kw)
+        # sender and receiver share one process: separate keys model the two sides
+        cm.compact_init(cfg)
+        skey, rkey = "0-0-k", "0-1-k"
+        for t, x in enumerate(xs):
+            x3 = x.view(1, N, C)
+            typ = T.WARMUP if t < nwarm else ctype
+            pkt = cm.compact_compress(skey, x3, typ, update_cache=True)
+            rec = cm.compact_decompress(rkey, pkt.clone(), typ, x3.shape, update_cache=True)
+            st.put(f"{name}/t{t}/packet", np16(pkt.reshape(-1)))
+            st.put(f"{name}/t{t}/recon", np16(rec.reshape(N, C)))
+            if kw.get("residual", 0) != 0:
+                st.put(f"{name}/t{t}/send_base", np16(cm.compact_cache().get_base(skey)))
+                st.put(f"{name}/t{t}/recv_base", np16(cm.compact_cache().get_base(rkey)))
+            if kw.get("residual", 0) == 2:
+                db = cm.compact_cache().get_delta_base(skey)
+                if db is not None:
+                    st.put(f"{name}/t{t}/send_dbase", np16(db))
+        print("G9", name, flush=True)
+    st.save(man)
+
+
+def _g10_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _import_reference()
+    import xfuser.compact.main as cm
+    from xfuser.compact.utils import CompactConfig, COMPACT_COMPRESS_TYPE as T
+    N, C = 32, 256
+    res = {}
+    for name, ctype in (("binary", T.BINARY), ("int2", T.INT2)):
+        cfg = CompactConfig(enabled=True, compress_func=lambda l, s: None, residual=1, ef=True, fastpath=True, comp_rank=-1)
+        cm.compact_init(cfg)
+        xs = _drift_seq(100 + rank, N, C, 4)
+        for t, x in enumerate(xs):
+            typ = T.WARMUP if t == 0 else ctype
+            outs = cm.compact_all_gather("3-k", x.view(1, N, C), typ)
+            for i, o in enumerate(outs):
+                res[f"{name}/r{rank}/t{t}/out{i}"] = np16(o.reshape(N, C))
+            res[f"{name}/r{rank}/t{t}/x"] = np16(x)
+        cm.compact_cache().check_consistency()
+        res[f"{name}/r{rank}/passed_count"] = __import__("numpy").array([cm.compact_cache().passed_count])
+    import numpy as np
+    np.savez(out + f".r{rank}.npz", **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def g10(mode, man):
+    import numpy as np
+    import torch.multiprocessing as mp
+    out = "/tmp/cfx_g10"
+    mp.spawn(_g10_worker, args=(2, 29533, out), nprocs=2, join=True)
+    st = Store("g10_allgather_2rank", mode)
+    for r in range(2):
+        d = np.load(out + f".r{r}.npz")
+        for k in d.files:
+            st.put(k, d[k])
+    st.save(man)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", choices=["eager", "compiled"], required=True)
+    ap.add_argument("--groups", default="g1,g3,g7,g8,g9,g10")
+    args = ap.parse_args()
+    if args.mode == "eager":
+        os.environ["TORCHDYNAMO_DISABLE"] = "1"
+    else:
+        os.environ.pop("TORCHDYNAMO_DISABLE", None)
+    _import_reference()
+    man_path = os.path.join(HERE, "MANIFEST.json")
+    man = json.load(open(man_path)) if os.path.exists(man_path) else {}
+    groups = args.groups.split(",")
+    if args.mode == "compiled":
+        groups = [g for g in groups if g in ("g3", "g9")]
+    fns = {"g1": g1_g2, "g3": g3_to_g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}
+    for g in groups:
+        fns[g](args.mode, man)
+    import torch
+    man["_meta"] = {"torch": torch.__version__, "generator": "tests/golden/make_golden.py",
+                    "reference": "Cobalt-27/CompactFusion snapshot 2025-09-26"}
+    json.dump(man, open(man_path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,286 @@
+"""Parity of the HIP kernels (through the C-ABI, libcfx.so) with the oracle - GPU box only (-m gpu).
+
+Bar: bit-exact for everything.  The HIP kernels and the oracle both use the exact (order-independent)
+sum for the scale reductions, so even the fp16 scale vectors and the error-feedback state are bit-identical;
+tolerances only enter where the *reference's* own fp32 accumulation order is involved
+(tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+from oracle import ref_np as R
+
+pytestmark = pytest.mark.gpu
+
+F16 = np.float16
+CODECS = [("binary", 1, 0), ("int2", 2, 0), ("int4", 3, 0), ("int8", 4, 0), ("topk", 5, 8), ("topk", 5, 2), ("topk", 5, 16), ("topk", 5, 1), ("topk", 5, 4)]
+
+
+def dev(a16):
+    return torch.from_numpy(np.ascontiguousarray(a16).view(np.int16)).view(torch.float16).cuda()
+
+
+def host_bits(t):
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def make_inputs(seed, N, C, drift=0.1):
+    rng = np.random.default_rng(seed)
+    base = rng.standard_normal((N, C)).astype(F16)
+    x = (base.astype(np.float32) + drift * rng.standard_normal((N, C)).astype(np.float32)).astype(F16)
+    return x, base
+
+
+def same_bits(a, b, what):
+    a = np.asarray(a).view(np.uint16).reshape(-1)
+    b = np.asarray(b).view(np.uint16).reshape(-1)
+    nan_a = (a & 0x7fff) > 0x7c00
+    nan_b = (b & 0x7fff) > 0x7c00
+    ok = (a == b) | (nan_a & nan_b)
+    assert ok.all(), f"{what}: {int((~ok).sum())}/{a.size} differ (first at {int(np.argmax(~ok))})"
+
+
+def run_case(name, cid, param, x, base, N, C):
+    from compactfusion_amd import codecs as K
+    pkt_ref, nb_ref = R.residual_compress(name, x, base, param)
+    xd, bd = dev(x), (None if base is None else dev(base))
+    pkt, nb = K.compress(cid, xd, bd, N, C, param, update_cache=True)
+    torch.cuda.synchronize()
+    assert pkt.numel() == pkt_ref.size
+    same_bits(host_bits(pkt), pkt_ref, f"{name} packet")
+    same_bits(host_bits(nb), R.bits(nb_ref), f"{name} new_base")
+    rec = K.decompress(cid, pkt, bd, N, C, param)
+    torch.cuda.synchronize()
+    same_bits(host_bits(rec), R.bits(nb_ref), f"{name} recon == sender state")
+    # update_cache=False writes the same packet and no state
+    pkt2, nb2 = K.compress(cid, xd, bd, N, C, param, update_cache=False)
+    torch.cuda.synchronize()
+    assert nb2 is None
+    same_bits(host_bits(pkt2), pkt_ref, f"{name} packet (no update)")
+
+
+@pytest.mark.parametrize("name,cid,param", CODECS)
+@pytest.mark.parametrize("shape", [(64, 256), (256, 1152), (544, 3072), (1024, 1152), (130, 1024), (2, 512), (34, 8192)])
+def test_codec_vs_oracle(name, cid, param, shape):
+    N, C = shape
+    if name == "topk" and (N * C) % 1024:
+        pytest.skip("SPARSE needs N*C % 1024 == 0")
+    x, base = make_inputs(1234 + N + C, N, C)
+    run_case(name, cid, param, x, base, N, C)
+
+
+@pytest.mark.parametrize("name,cid,param", CODECS[:5])
+def test_config1_shape_4096x1152(name, cid, param):
+    """BASELINE.json configs[0]: synthetic [1,4096,1152]."""
+    torch.manual_seed(1234)
+    base = torch.randn(4096, 1152).half()
+    x = (base.float() + 0.1 * torch.randn(4096, 1152)).half()
+    run_case(name, cid, param, host_bits(x).view(F16), host_bits(base).view(F16), 4096, 1152)
+
+
+@pytest.mark.parametrize("name,cid,param", CODECS[:5])
+def test_residual0_no_base(name, cid, param):
+    N, C = 64, 1024
+    x, _ = make_inputs(5, N, C)
+    run_case(name, cid, param, x, None, N, C)
+
+
+@pytest.mark.parametrize("name,cid,param", CODECS[:5])
+def test_batched_equals_single(name, cid, param):
+    from compactfusion_amd import codecs as K
+    N, C, B = 96, 1536, 7
+    xs, bs = zip(*[make_inputs(100 + i, N, C) for i in range(B)])
+    xd, bd = [dev(a) for a in xs], [dev(a) for a in bs]
+    pk = [torch.empty(K.packet_halves(cid, N, C, param), dtype=torch.float16, device="cuda") for _ in range(B)]
+    K.compress_batch(cid, xd, bd, bd, pk, N, C, param, update_cache=True)   # in place: new_base aliases base
+    recv_base = [dev(a) for a in bs]
+    K.decompress_batch(cid, pk, recv_base, recv_base, N, C, param)          # in place on the receiver
+    torch.cuda.synchronize()
+    for i in range(B):
+        pkt_ref, nb_ref = R.residual_compress(name, xs[i], bs[i], param)
+        same_bits(host_bits(pk[i]), pkt_ref, f"{name}[{i}] packet")
+        same_bits(host_bits(bd[i]), R.bits(nb_ref), f"{name}[{i}] in-place sender state")
+        same_bits(host_bits(recv_base[i]), R.bits(nb_ref), f"{name}[{i}] in-place receiver state")
+
+
+@pytest.mark.parametrize("name,cid,param", CODECS[:5])
+def test_no_ef_flag(name, cid, param):
+    from compactfusion_amd import codecs as K
+    N, C = 64, 1024
+    x, base = make_inputs(9, N, C)
+    pkt, nb = K.compress(cid, dev(x), dev(base), N, C, param, update_cache=True, ef=False)
+    torch.cuda.synchronize()
+    same_bits(host_bits(nb), R.bits(x), "ef=False stores x (main.py:233)")
+    same_bits(host_bits(pkt), R.residual_compress(name, x, base, param)[0], "packet")
+
+
+@pytest.mark.parametrize("rows", [16, 32, 64, 128])
+def test_tiling_independent(rows):
+    """Scales come from exact integer sums: any tiling gives the same bits."""
+    from compactfusion_amd import codecs as K
+    N, C = 300, 1152
+    x, base = make_inputs(77, N, C)
+    K.set_rows_per_tile(rows)
+    try:
+        for name, cid, param in CODECS[:4]:
+            run_case(name, cid, param, x, base, N, C)
+    finally:
+        K.set_rows_per_tile(0)
+
+
+def test_edge_zero_delta_and_extremes():
+    from compactfusion_amd import codecs as K
+    N, C = 32, 512
+    x, base = make_inputs(3, N, C)
+    # (a) x == base: 1-bit scales are 0/0 = NaN in the reference (no epsilon, fastpath.py:165); 2-bit has the epsilon
+    for name, cid, param in CODECS[:5]:
+        run_case(name, cid, param, base.copy(), base, N, C)
+    # (b) a constant column (min == max) and large magnitudes, signed zeros, subnormals
+    x2 = x.copy()
+    x2[:, 7] = base[:, 7] + F16(0.5)
+    x2[3, :] = F16(60000.0)
+    x2[4, :] = F16(-60000.0)
+    x2[5, ::2] = F16(-0.0)
+    base2 = base.copy()
+    base2[5, :] = F16(0.0)
+    x2[6, :] = np.float16(6e-8)
+    base2[6, :] = F16(0.0)
+    for name, cid, param in CODECS[:5]:
+        run_case(name, cid, param, x2, base2, N, C)
+
+
+GOLD_FAST = [(64, 256, 42), (64, 256, 43), (256, 1152, 42), (128, 3072, 44)]
+
+
+@pytest.mark.parametrize("N,C,seed", GOLD_FAST)
+def test_golden_binary_through_abi(N, C, seed):
+    """Committed reference vectors (G1): packed bits exact; with the reference's own U/V in the packet,
+    the dequant+add kernel reproduces the reference's new_base / recon bit for bit."""
+    from compactfusion_amd import codecs as K
+    fn = "g1_binary_fastpath_eager.npz"
+    tag = f"{N}x{C}_s{seed}"
+    x, base = G.inputs(fn, tag, seed, N, C)
+    pkt, nb = K.compress(1, dev(x.view(F16)), dev(base.view(F16)), N, C)
+    torch.cuda.synchronize()
+    words = host_bits(pkt)
+    packed, u, v = R.fastpath_unpacket(words, N, C, 8)
+    G.check(fn, f"{tag}/packed", packed, "packed")
+    gu, gv = G.get(fn, f"{tag}/u"), G.get(fn, f"{tag}/v")
+    n1, mx1 = G.ulp_diff_count(R.bits(u), gu)
+    n2, mx2 = G.ulp_diff_count(R.bits(v), gv)
+    assert mx1 <= 1 and mx2 <= 1 and G.rel_err(R.bits(u), gu.reshape(-1)) < 1e-3 and G.rel_err(R.bits(v), gv.reshape(-1)) < 1e-3
+    gpkt = R.fastpath_packet(G.get(fn, f"{tag}/packed"), gu, gv)
+    rec = K.decompress(1, dev(gpkt.view(F16)), dev(base.view(F16)), N, C)
+    torch.cuda.synchronize()
+    G.check(fn, f"{tag}/recon", host_bits(rec).reshape(N, C), "recon from golden packet")
+    G.check(fn, f"{tag}/new_base", host_bits(rec).reshape(N, C), "== reference new_base")
+
+
+@pytest.mark.parametrize("N,C,seed", GOLD_FAST)
+def test_golden_int2_through_abi(N, C, seed):
+    from compactfusion_amd import codecs as K
+    fn = "g2_int2_fastpath_eager.npz"
+    tag = f"{N}x{C}_s{seed}"
+    x, base = G.inputs(fn, tag, seed, N, C)
+    pkt, nb = K.compress(2, dev(x.view(F16)), dev(base.view(F16)), N, C)
+    torch.cuda.synchronize()
+    packed, u, v = R.fastpath_unpacket(host_bits(pkt), N, C, 4)
+    gp, gu, gv = G.get(fn, f"{tag}/packed"), G.get(fn, f"{tag}/u"), G.get(fn, f"{tag}/v")
+    assert float((packed != gp).mean()) <= 1e-3
+    assert G.ulp_diff_count(R.bits(u), gu)[1] <= 1 and G.ulp_diff_count(R.bits(v), gv)[1] <= 1
+    gpkt = R.fastpath_packet(gp, gu, gv)
+    rec = K.decompress(2, dev(gpkt.view(F16)), dev(base.view(F16)), N, C)
+    torch.cuda.synchronize()
+    G.check(fn, f"{tag}/recon", host_bits(rec).reshape(N, C), "recon from golden packet")
+    G.check(fn, f"{tag}/new_base", host_bits(rec).reshape(N, C), "== reference new_base")
+
+
+@pytest.mark.parametrize("N,C,seed", [(64, 256, 42), (256, 1152, 43)])
+def test_golden_int8_int4_through_abi(N, C, seed):
+    """G4/G5: the affine codecs have no order-dependent reduction: q, scale, zp/min all bit-exact vs the reference."""
+    from compactfusion_amd import codecs as K
+    fn = "g3_g6_slowpath_codecs_eager.npz"
+    tag = f"{N}x{C}_s{seed}"
+    x, base = G.inputs(fn, tag, seed, N, C)
+    pkt, _ = K.compress(4, dev(x.view(F16)), dev(base.view(F16)), N, C, update_cache=False)
+    torch.cuda.synchronize()
+    w = host_bits(pkt)
+    qn = N * C // 2
+    G.check(fn, f"{tag}/i8/q", w[:qn].view(np.int8).reshape(N, C), "int8 q")
+    G.check(fn, f"{tag}/i8/scale", w[qn:qn + C].reshape(1, C), "int8 scale")
+    G.check(fn, f"{tag}/i8/zp", w[qn + C:].view(np.int16).reshape(1, C), "int8 zp")
+    rec = K.decompress(4, pkt, None, N, C)
+    G.check(fn, f"{tag}/i8/deq", host_bits(rec).reshape(N, C), "int8 dequant")
+    pkt, _ = K.compress(3, dev(x.view(F16)), dev(base.view(F16)), N, C, update_cache=False)
+    torch.cuda.synchronize()
+    w = host_bits(pkt)
+    qn = N * C // 4
+    G.check(fn, f"{tag}/i4/q", w[:qn].view(np.uint8).reshape(N // 2, C), "int4 q")
+    G.check(fn, f"{tag}/i4/scale", w[qn:qn + C].reshape(1, C), "int4 scale")
+    G.check(fn, f"{tag}/i4/min", w[qn + C:].reshape(1, C), "int4 min")
+    rec = K.decompress(3, pkt, None, N, C)
+    G.check(fn, f"{tag}/i4/deq", host_bits(rec).reshape(N, C), "int4 dequant")
+
+
+@pytest.mark.parametrize("tag,N,C", [("64x256_s42", 64, 256), ("32x1024_s42", 32, 1024)])
+@pytest.mark.parametrize("m", [1, 2, 4, 8, 16])
+def test_golden_topk_through_abi(tag, N, C, m):
+    from compactfusion_amd import codecs as K
+    fn = "g7_topk_eager.npz"
+    x, base = G.get(fn, f"{tag}/x"), G.get(fn, f"{tag}/base")
+    pkt, _ = K.compress(5, dev(x.view(F16)), dev(base.view(F16)), N, C, m, update_cache=False)
+    torch.cuda.synchronize()
+    w = host_bits(pkt)
+    vn = N * C // m
+    G.check(fn, f"{tag}/m{m}/val", w[:vn].reshape(-1, 1024 // m), "topk val")
+    G.check(fn, f"{tag}/m{m}/idx", w[vn:].view(np.uint8).reshape(-1, 512 // m), "topk idx")
+    rec = K.decompress(5, pkt, None, N, C, m)
+    G.check(fn, f"{tag}/m{m}/dec", host_bits(rec).reshape(N, C), "topk decompress")
+
+
+@pytest.mark.parametrize("name,cid,param,shape", [("binary", 1, 0, (544, 3072)), ("int2", 2, 0, (544, 3072)),
+                                                  ("int4", 3, 0, (4448, 3072)), ("int8", 4, 0, (4096, 1152)),
+                                                  ("topk", 5, 8, (512, 1536))])
+def test_full_size_ef_round_trip(name, cid, param, shape):
+    """BASELINE.json full sizes, size-independent properties: over T drifting steps the sender's error-feedback
+    state and the receiver's reconstruction stay bit-identical, and the reconstruction error stays bounded
+    (error feedback does not accumulate)."""
+    from compactfusion_amd import codecs as K
+    N, C = shape
+    g = torch.Generator(device="cpu").manual_seed(42)
+    cur = torch.randn(N, C, generator=g).half()
+    send_base = cur.clone().cuda()       # WARMUP step: both sides hold x_0
+    recv_base = cur.clone().cuda()
+    pkt = torch.empty(K.packet_halves(cid, N, C, param), dtype=torch.float16, device="cuda")
+    errs = []
+    for t in range(6):
+        cur = (cur.float() + 0.1 * torch.randn(N, C, generator=g)).half()
+        xd = cur.cuda()
+        K.compress_batch(cid, [xd], [send_base], [send_base], [pkt], N, C, param, update_cache=True)
+        K.decompress_batch(cid, [pkt], [recv_base], [recv_base], N, C, param)
+        torch.cuda.synchronize()
+        assert torch.equal(send_base.view(torch.int16), recv_base.view(torch.int16)), f"state diverged at step {t}"
+        errs.append(float((recv_base.float() - xd.float()).norm() / xd.float().norm()))
+    assert all(np.isfinite(errs))
+    assert errs[-1] < 0.2 and errs[-1] < 2.5 * errs[0] + 1e-3, errs
+
+
+def test_error_codes():
+    from compactfusion_amd import codecs as K
+    from compactfusion_amd._lib import CfxError
+    x = torch.zeros(8, 20, dtype=torch.float16, device="cuda")
+    with pytest.raises(ValueError):
+        K.packet_bytes(1, 8, 20)                      # C % 8 != 0
+    with pytest.raises(ValueError):
+        K.packet_bytes(3, 7, 64)                      # int4 needs even N
+    with pytest.raises(ValueError):
+        K.packet_bytes(5, 8, 64, 8)                   # topk needs N*C % 1024 == 0
+    with pytest.raises(ValueError):
+        K.packet_bytes(9, 8, 64)                      # unknown codec
+    with pytest.raises(CfxError):
+        K.compress(1, torch.zeros(8, 64, dtype=torch.float16), None, 8, 64)   # CPU tensor: no fallback
+    big = torch.zeros(8 * 64 + 8, dtype=torch.float16, device="cuda")
+    mis = big[1:1 + 8 * 64].view(8, 64)               # 2-byte aligned only
+    with pytest.raises(CfxError):
+        K.compress(1, mis, None, 8, 64)
