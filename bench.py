@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""bench.py - residual-compressed activation exchange, FLUX.1-dev 1024^2 ring-8 per-rank workload.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per
+GPU with torch.distributed.run.  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[2], SURVEY.md §8d "Config 3"): one denoise step of FLUX.1-dev 1024^2 under
+ring-attention sequence parallelism of logical degree 8 with the 1-bit residual codec, as seen by ONE rank:
+57 attention layers x {K, V}, shard (N, C) = (544, 3072) fp16.  Per layer the rank
+  1. compresses its own K and V against its error-feedback state (one batched launch sequence),
+  2. exchanges packets (N live ranks all-gather over RCCL on a side stream; the 8-N missing logical peers are
+     looped back from the rank's own packet, so the per-GPU codec work is IDENTICAL for every N = weak scaling;
+     at N = 8 this is exactly the real exchange, at N = 1 it is the codec path alone),
+  3. applies 16 packets in ONE batched dequant+add launch: its own K,V packets onto its own state (the error-feedback
+     update of step 1, deferred into this launch) and the 7 peers' K,V onto their state arenas.
+Inputs are synthetic and already resident in HBM; the state arenas (3.0 GB) + inputs (0.76 GB) dwarf the 256 MB
+Infinity Cache, so every step streams from HBM (cold numbers).
+
+value = whole-job fp16 activation bytes compressed + reconstructed per second (GB/s), i.e.
+        n_gpus * 57 * (2 + 14) * 544*3072*2 B / step time.
+roofline = the dominant kernel (k_binary_dequant on 16 tensors): algorithmic bytes 4.125 B/element
+         x 16*544*3072 elements per launch / average launch duration from hipEvents recorded
+        on the launch stream inside the timed region (native hooks in libcfx.so).
+cpu_baseline = the C oracle (oracle/cfx_oracle.c, OpenMP) timed on this box's host cores on one layer of the same
+        workload; reported baseline only.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+L_LAYERS, N_TOK, C_CH, W_LOGICAL = 57, 544, 3072, 8
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s float4-copy achievable)
+ALG_BYTES_PER_EL = {"compress": 6.125, "decompress": 4.125}   # 1-bit, SURVEY.md §8d
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--layers", type=int, default=L_LAYERS, help="debug only; the judged workload uses 57")
+    ap.add_argument("--rows", type=int, default=0, help="rows per tile override (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--event-stride", type=int, default=8,
+                    help="bracket every k-th launch of the dominant kernel with hipEvents (an event pair costs a few us of stream time)")
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds: float):
+    """C oracle on the host cores: one layer of the workload = 2 compress + 14 decompress at (544, 3072)."""
+    import numpy as np
+    from oracle import c_oracle as CO
+    N, C = N_TOK, C_CH
+    rng = np.random.default_rng(0)
+    base = rng.standard_normal((N, C)).astype(np.float16)
+    xs = [(base.astype(np.float32) + 0.1 * rng.standard_normal((N, C)).astype(np.float32)).astype(np.float16) for _ in range(2)]
+    own = [base.copy().view(np.uint16) for _ in range(2)]
+    peers = [base.copy().view(np.uint16) for _ in range(14)]
+    pk = [np.zeros(CO.load().oracle_packet_bytes(1, N, C, 0) // 2, dtype=np.uint16) for _ in range(2)]
+    CO.compress("binary", xs[0], own[0], N, C, packet=pk[0], new_base=own[0])   # warm up (tables, threads)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        for i in range(2):
+            CO.compress("binary", xs[i], own[i], N, C, packet=pk[i], new_base=own[i])
+        for j in range(14):
+            CO.decompress("binary", pk[j % 2], peers[j], N, C, out=peers[j])
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or reps >= 200:
+            break
+    act_bytes = reps * 16 * N * C * 2
+    return {"value": round(act_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": int(CO.num_threads()), "kind": "port",
+            "sample": f"{reps} x one layer of the workload (2 compress + 14 decompress, 1-bit, (544,3072) fp16) in {dt:.1f} s, "
+                      f"C oracle oracle/cfx_oracle.c with OpenMP"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    live = world                       # live ranks in the logical ring of 8
+    assert live <= W_LOGICAL
+
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    ctx = K.context(local_rank)
+    if args.rows:
+        K.set_rows_per_tile(args.rows, local_rank)
+
+    L, N, C = args.layers, N_TOK, C_CH
+    CODEC = int(K.Codec.BINARY)
+    pkt_bytes = K.packet_bytes(CODEC, N, C)
+    slot = (pkt_bytes + 255) // 256 * 256          # per-tensor slot in the exchange buffer, 256-B aligned
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+
+    # ---- resident state and inputs --------------------------------------------------------------------------
+    x0 = torch.randn(L, 2, N, C, generator=g, device=dev, dtype=torch.float32).half()
+    xs = [(x0.float() + 0.1 * torch.randn(L, 2, N, C, generator=g, device=dev)).half() for _ in range(2)]
+    own_base = x0.clone()                                                   # [L,2,N,C] sender EF state (after WARMUP)
+    peer_base = x0.unsqueeze(1).repeat(1, W_LOGICAL - 1, 1, 1, 1).contiguous()   # [L,7,2,N,C] receiver states
+    del x0
+    send = torch.zeros(L, 2, slot, dtype=torch.uint8, device=dev)           # own packets (K,V) per layer
+    recv = torch.zeros(L, live, 2, slot, dtype=torch.uint8, device=dev) if live > 1 else None
+    ws_bytes = lib.cfx_workspace_bytes(CODEC, N, C, 0, 2)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+
+    # ---- native plans (one per input set): per layer op 2l = compress K,V ; op 2l+1 = one dequant+add launch over 16
+    #      tensors = the sender's own error-feedback update (its K,V packets applied to its own state, which is exactly
+    #      what compact_compress(update_cache=True) does, fastpath.py:88-120) + the 7 peers' K,V ---------------------------
+    plans = []
+    for s in range(2):
+        plan = lib.cfx_plan_create(ctx)
+        for l in range(L):
+            carr = (_lib.CompItem * 2)()
+            for kv in range(2):
+                carr[kv] = _lib.CompItem(xs[s][l, kv].data_ptr(), own_base[l, kv].data_ptr(), None, send[l, kv].data_ptr())
+            rc = lib.cfx_plan_add_compress(plan, CODEC, N, C, 0, 0, 2, carr, ws.data_ptr(), ws_bytes)
+            assert rc == 2 * l, (rc, lib.cfx_last_error_string(ctx))
+            darr = (_lib.DecompItem * 16)()
+            for kv in range(2):
+                darr[kv] = _lib.DecompItem(send[l, kv].data_ptr(), own_base[l, kv].data_ptr(), own_base[l, kv].data_ptr())
+            i = 2
+            for p in range(W_LOGICAL - 1):
+                # logical peer p: the first live-1 are real ranks (packets from the all-gather), the rest loop back our own packet
+                for kv in range(2):
+                    if live > 1 and p < live - 1:
+                        pk_ptr = recv[l, (rank + 1 + p) % live, kv].data_ptr()
+                    else:
+                        pk_ptr = send[l, kv].data_ptr()
+                    darr[i] = _lib.DecompItem(pk_ptr, peer_base[l, p, kv].data_ptr(), peer_base[l, p, kv].data_ptr())
+                    i += 1
+            rc = lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, 16, darr)
+            assert rc == 2 * l + 1, (rc, lib.cfx_last_error_string(ctx))
+        plans.append(plan)
+
+    compute = torch.cuda.current_stream(dev)
+    comm = torch.cuda.Stream(dev) if live > 1 else None
+    sh = compute.cuda_stream
+
+    def check(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: rc={rc} {lib.cfx_last_error_string(ctx)}")
+
+    def one_step(step):
+        plan = plans[step & 1]
+        if live == 1:
+            check(lib.cfx_plan_run(plan, 0, 2 * L, sh), "plan_run")     # the whole step from native code
+            return
+        # software pipeline: gather(l) on the side stream overlaps compress(l+1) and reconstruct(l-1)
+        works = [None] * L
+
+        def launch_gather(l):
+            ev = torch.cuda.Event()
+            ev.record(compute)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev)
+                works[l] = dist.all_gather_into_tensor(recv[l].view(-1), send[l].view(-1), async_op=True)
+        check(lib.cfx_plan_run(plan, 0, 1, sh), "compress")
+        launch_gather(0)
+        for l in range(L):
+            if l + 1 < L:
+                check(lib.cfx_plan_run(plan, 2 * (l + 1), 1, sh), "compress")
+                launch_gather(l + 1)
+            works[l].wait()          # compute stream waits for gather(l)
+            check(lib.cfx_plan_run(plan, 2 * l + 1, 1, sh), "reconstruct")
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if live > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    # ---- warmup -----------------------------------------------------------------------------------------------
+    for i in range(args.warmup):
+        one_step(i)
+    sync_all()
+
+    # ---- timed region -------------------------------------------------------------------------------------------
+    KID_DEQ = 4
+    if not args.no_kernel_events:
+        check(lib.cfx_profile_enable(ctx, args.steps * L + 8, 1 << KID_DEQ, args.event_stride), "profile_enable")
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    sync_all()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if live > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = None
+    if not args.no_kernel_events:
+        cap = args.steps * L + 8
+        ids = (ctypes.c_int * cap)()
+        ms = (ctypes.c_float * cap)()
+        n = lib.cfx_profile_read(ctx, ids, ms, cap)
+        vals = [ms[i] for i in range(n) if ids[i] == KID_DEQ and ms[i] > 0]
+        n_samples = len(vals)
+        if vals:
+            kern_ms = sum(vals) / len(vals)
+        lib.cfx_profile_enable(ctx, 0, 0, 1)
+
+    # ---- state sanity: sender state == what a receiver holds for the loop-back peers (bit-exact EF consistency) --
+    torch.cuda.synchronize(dev)
+    if live == 1:
+        assert torch.equal(own_base[0, 0].view(torch.int16), peer_base[0, 0, 0].view(torch.int16)), "EF state diverged"
+
+    # ---- uncompressed RCCL all-gather of the same K/V shards (the north-star comparison), N > 1 only ---------------
+    raw_ms = None
+    if live > 1:
+        try:
+            raw_in = xs[0]
+            raw_out = torch.empty(live, 2, N, C, dtype=torch.float16, device=dev)
+            for _ in range(2):
+                for l in range(L):
+                    dist.all_gather_into_tensor(raw_out.view(-1), raw_in[l].reshape(-1))
+            sync_all()
+            tr0 = time.perf_counter()
+            reps = max(3, min(args.steps, 10))
+            for _ in range(reps):
+                for l in range(L):
+                    dist.all_gather_into_tensor(raw_out.view(-1), raw_in[l].reshape(-1))
+            sync_all()
+            raw_ms = (time.perf_counter() - tr0) / reps * 1e3
+            t = torch.tensor([raw_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            raw_ms = float(t.item())
+        except Exception as e:  # pragma: no cover
+            raw_ms = None
+            print(f"[bench] raw all-gather baseline failed: {e}", file=sys.stderr)
+
+    ms_per_step = elapsed / args.steps * 1e3
+    act_bytes_rank = L * 16 * N * C * 2
+    value = live * act_bytes_rank / (elapsed / args.steps) / 1e9
+
+    out = {
+        "metric": "residual_compressed_activation_exchange_throughput",
+        "value": round(value, 3),
+        "unit": "GB/s",
+        "n_gpus": live,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f16",
+        "data": "synthetic",
+        "config": {
+            "workload": "FLUX.1-dev 1024x1024 ring-attention SP degree 8 (logical), 1-bit residual + error feedback: per rank per step "
+                        f"{L} layers x (compress K,V + reconstruct 7 peers' K,V), shard (544,3072) fp16; {live} live rank(s), "
+                        f"{W_LOGICAL - live} peer(s) looped back",
+            "codec": "BINARY(1-bit, comp_rank=-1)", "layers": L, "shard": [N, C], "logical_ring": W_LOGICAL,
+            "packet_bytes": pkt_bytes, "raw_bytes": N * C * 2,
+        },
+        "exchange_ms_per_step": round(ms_per_step, 4),
+        "raw_allgather_ms_per_step": None if raw_ms is None else round(raw_ms, 4),
+        "speedup_vs_raw_allgather": None if raw_ms is None else round(raw_ms / ms_per_step, 3),
+    }
+    if kern_ms is not None:
+        alg = ALG_BYTES_PER_EL["decompress"] * 16 * N * C
+        ach = alg / (kern_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_binary_dequant (16 tensors x (544,3072) per launch: own K,V error-feedback update + 7 peers' K,V)",
+                           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                           "traffic": None, "avg_launch_us": round(kern_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(alg),
+                           "event_samples": n_samples, "event_stride": args.event_stride}
+        prof = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(prof):
+            try:
+                out["roofline"]["traffic"] = json.load(open(prof)).get("k_binary_dequant_bytes_per_launch")
+            except Exception:
+                pass
+    else:
+        out["roofline"] = None
+    if rank == 0 and live == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        except Exception as e:  # pragma: no cover
+            out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if live > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,6 +44,17 @@ SYMBOLS = [
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_decompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    ("cfx_profile_enable", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_int]),
+    ("cfx_profile_read", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
+    ("cfx_kernel_name", ctypes.c_char_p, [ctypes.c_int]),
+    ("cfx_plan_create", ctypes.c_void_p, [ctypes.c_void_p]),
+    ("cfx_plan_destroy", None, [ctypes.c_void_p]),
+    ("cfx_plan_add_compress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_void_p, ctypes.c_size_t]),
+    ("cfx_plan_add_decompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.POINTER(DecompItem)]),
+    ("cfx_plan_size", ctypes.c_int, [ctypes.c_void_p]),
+    ("cfx_plan_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     ("cfx_copy_probe", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 ]
 

@@ -37,7 +37,8 @@ typedef unsigned long long u64;
 #define TILE_C 512      // channels per wave-row = 64 lanes x 8 halves
 #define WAVES 4         // waves per workgroup
 #define NTHR (WAVES * 64)
-#define UNROLL 4        // rows in flight per wave
+#define UNROLL 2        // rows in flight per wave, apply / dequant kernels (measured best with R = 8: tools/kbench.hip)
+#define UNROLL_S 4      // rows in flight per wave, statistics kernels (one exposure of HBM latency per tile of 16 rows)
 
 struct BatchC { cfx_comp_item it[CFX_MAX_BATCH]; };
 struct BatchD { cfx_decomp_item it[CFX_MAX_BATCH]; };
@@ -50,6 +51,10 @@ __device__ __forceinline__ h16 hfrom(u16 v) { return __builtin_bit_cast(h16, v);
 
 __device__ __forceinline__ h16x8 ld8(const h16* p) { return *reinterpret_cast<const h16x8*>(p); }
 __device__ __forceinline__ void st8(h16* p, h16x8 v) { *reinterpret_cast<h16x8*>(p) = v; }
+
+// Streaming (non-temporal) forms for data touched once per launch: measured +10 % on the dequant stream (tools/kbench.hip).
+__device__ __forceinline__ h16x8 ld8nt(const h16* p) { return __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(p)); }
+__device__ __forceinline__ void st8nt(h16* p, h16x8 v) { __builtin_nontemporal_store(v, reinterpret_cast<h16x8*>(p)); }
 
 // 8 halves from an address that is only guaranteed 2-byte aligned (packet tail sections).
 __device__ __forceinline__ h16x8 ld8_tail(const h16* p, bool al16) {
@@ -107,6 +112,25 @@ __device__ __forceinline__ TileCoord tile_coord(int N, int C, int R) {
 //   colpart[p][c]   = sum over the tile's R rows
 //   EMIT_BITS: also write bit i of byte j = (x-base)[n,8j+i] >= 0        (fastpath.py:58-85)
 // ---------------------------------------------------------------------------------------------------
+// Row sums of UNROLL_S rows at once: a butterfly that halves the number of live values per step
+// (xor 32: 4 -> 2 values, xor 16: 2 -> 1, then 4 single-value steps) = 7 u64 shuffles instead of 24.
+// Returns, in lanes 0/16/32/48, the wave-wide sums of rows 0/1/2/3 respectively.
+__device__ __forceinline__ u64 wave_sum4_u64(const u64 (&v)[4], int lane) {
+    const bool hi32 = lane & 32, hi16 = lane & 16;
+    // step 1: lanes < 32 keep rows {0,1}, lanes >= 32 keep rows {2,3}
+    u64 a0 = hi32 ? v[2] : v[0], a1 = hi32 ? v[3] : v[1];
+    const u64 s0 = hi32 ? v[0] : v[2], s1 = hi32 ? v[1] : v[3];
+    a0 += __shfl_xor(s0, 32, 64);
+    a1 += __shfl_xor(s1, 32, 64);
+    // step 2: within each half, lanes with bit4 = 0 keep the first row, bit4 = 1 the second
+    u64 b = hi16 ? a1 : a0;
+    const u64 sb = hi16 ? a0 : a1;
+    b += __shfl_xor(sb, 16, 64);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
+    return b;   // lane 0: row 0, lane 16: row 1, lane 32: row 2, lane 48: row 3
+}
+
 template <bool EMIT_BITS>
 __global__ __launch_bounds__(NTHR) void k_absmean_stats(BatchC batch, int N, int C, int R, u64* ws, size_t ws_stride) {
     const cfx_comp_item it = batch.it[blockIdx.z];
@@ -123,38 +147,41 @@ __global__ __launch_bounds__(NTHR) void k_absmean_stats(BatchC batch, int N, int
 #pragma unroll
     for (int i = 0; i < 8; ++i) col[i] = 0;
 
-    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL) {
-        h16x8 xv[UNROLL], bv[UNROLL];
+    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL_S) {
+        h16x8 xv[UNROLL_S], bv[UNROLL_S];
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) {
+        for (int j = 0; j < UNROLL_S; ++j) {
             const int rr = r + WAVES * j;
             xv[j] = (h16x8)(h16)0;
             bv[j] = (h16x8)(h16)0;
             if (rr < t.r1 && t.act) {
-                xv[j] = ld8(x + (size_t)rr * C + t.c);
+                // 1-bit: x is not needed again (the EF pass works from the packed bits) -> streaming load
+                xv[j] = EMIT_BITS ? ld8nt(x + (size_t)rr * C + t.c) : ld8(x + (size_t)rr * C + t.c);
                 if (base) bv[j] = ld8(base + (size_t)rr * C + t.c);
             }
         }
+        u64 rs[UNROLL_S];
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) {
+        for (int j = 0; j < UNROLL_S; ++j) {
             const int rr = r + WAVES * j;
-            if (rr < t.r1) {
-                u64 rs = 0;
-                if (t.act) {
-                    const h16x8 d = xv[j] - bv[j];
-                    unsigned byte = 0;
+            rs[j] = 0;
+            if (rr < t.r1 && t.act) {
+                const h16x8 d = xv[j] - bv[j];
+                unsigned byte = 0;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        byte |= (d[i] >= (h16)0 ? 1u : 0u) << i;
-                        const u64 u = habs_units(hbits(d[i]));
-                        col[i] += u;
-                        rs += u;
-                    }
-                    if (EMIT_BITS) bitsout[(size_t)rr * C8 + (t.c >> 3)] = (unsigned char)byte;
+                for (int i = 0; i < 8; ++i) {
+                    byte |= (d[i] >= (h16)0 ? 1u : 0u) << i;
+                    const u64 u = habs_units(hbits(d[i]));
+                    col[i] += u;
+                    rs[j] += u;
                 }
-                rs = wave_sum_u64(rs);
-                if (t.lane == 0) rowpart[(size_t)rr * CB + cb] = rs;
+                if (EMIT_BITS) bitsout[(size_t)rr * C8 + (t.c >> 3)] = (unsigned char)byte;
             }
+        }
+        const u64 tot = wave_sum4_u64(rs, t.lane);
+        if ((t.lane & 15) == 0) {
+            const int rr = r + WAVES * (t.lane >> 4);
+            if (rr < t.r1) rowpart[(size_t)rr * CB + cb] = tot;
         }
     }
     __shared__ u64 sm[WAVES][TILE_C];
@@ -171,8 +198,8 @@ __global__ __launch_bounds__(NTHR) void k_absmean_stats(BatchC batch, int N, int
 // finalize: U[n] = rowmean/mean(rowmean) (1-bit, fastpath.py:164-165) or rowmean/(mean+1e-6) (2-bit, :619-622);
 //           V[c] = colmean (fastpath.py:160,166 / :618).  Written straight into the packet tail (replaces the
 //           torch.cat of main.py:149-152).  grid = (1 + ceil(C/256), batch).
-__global__ __launch_bounds__(256) void k_absmean_finalize(BatchC batch, int N, int C, int CB, int P, int per_byte,
-                                                          int eps_mode, const u64* ws, size_t ws_stride) {
+__global__ __launch_bounds__(1024) void k_absmean_finalize(BatchC batch, int N, int C, int CB, int P, int per_byte,
+                                                           int eps_mode, const u64* ws, size_t ws_stride) {
     const cfx_comp_item it = batch.it[blockIdx.y];
     const u64* rowpart = ws + (size_t)blockIdx.y * ws_stride;
     const u64* colpart = rowpart + (size_t)N * CB;
@@ -180,33 +207,45 @@ __global__ __launch_bounds__(256) void k_absmean_finalize(BatchC batch, int N, i
     h16* V = U + N;
     const int tid = threadIdx.x;
     if (blockIdx.x == 0) {
-        __shared__ u64 red[256];
+        // rows: one thread per row (all CB partial loads independent), exact sum of the fp16 row means, then divide
+        __shared__ u64 red[1024];
+        __shared__ h16 mu_s;
         u64 acc = 0;
-        for (int n = tid; n < N; n += 256) {
+        for (int n = tid; n < N; n += 1024) {
             u64 s = 0;
+#pragma unroll 8
             for (int k = 0; k < CB; ++k) s += rowpart[(size_t)n * CB + k];
             acc += habs_units(hbits(mean16(s, C)));
         }
         red[tid] = acc;
         __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
+        for (int o = 512; o > 0; o >>= 1) {
             if (tid < o) red[tid] += red[tid + o];
             __syncthreads();
         }
-        const h16 mu = mean16(red[0], N);
+        if (tid == 0) mu_s = mean16(red[0], N);
+        __syncthreads();
+        const h16 mu = mu_s;
         const float den = eps_mode ? (float)(h16)((float)mu + 1e-6f) : (float)mu;
-        for (int n = tid; n < N; n += 256) {
+        for (int n = tid; n < N; n += 1024) {
             u64 s = 0;
+#pragma unroll 8
             for (int k = 0; k < CB; ++k) s += rowpart[(size_t)n * CB + k];
             U[n] = (h16)((float)mean16(s, C) / den);
         }
     } else {
-        const int c = (blockIdx.x - 1) * 256 + tid;
+        // columns: 256 columns per block, 4 threads per column split the P partials (loads in flight together)
+        __shared__ u64 cs[4][256];
+        const int cl = tid & 255, q = tid >> 8;
+        const int c = (blockIdx.x - 1) * 256 + cl;
+        u64 s = 0;
         if (c < C) {
-            u64 s = 0;
-            for (int p = 0; p < P; ++p) s += colpart[(size_t)p * C + c];
-            V[c] = mean16(s, N);
+#pragma unroll 4
+            for (int p = q; p < P; p += 4) s += colpart[(size_t)p * C + c];
         }
+        cs[q][cl] = s;
+        __syncthreads();
+        if (q == 0 && c < C) V[c] = mean16(cs[0][cl] + cs[1][cl] + cs[2][cl] + cs[3][cl], N);
     }
 }
 
@@ -238,7 +277,7 @@ __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, in
             by[j] = 0;
             u[j] = (h16)0;
             if (rr < t.r1 && t.act) {
-                if (base) bv[j] = ld8(base + (size_t)rr * C + t.c);
+                if (base) bv[j] = ld8nt(base + (size_t)rr * C + t.c);
                 by[j] = pk[(size_t)rr * C8 + (t.c >> 3)];
                 u[j] = U[rr];
             }
@@ -252,7 +291,7 @@ __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, in
 #pragma unroll
                 for (int i = 0; i < 8; ++i) sb[i] ^= ((by[j] >> i) & 1u) ? (u16)0 : (u16)0x8000;   // (2b-1)*s
                 const h16x8 recv = __builtin_bit_cast(h16x8, sb);
-                st8(out + (size_t)rr * C + t.c, base ? (bv[j] + recv) : recv);
+                st8nt(out + (size_t)rr * C + t.c, base ? (bv[j] + recv) : recv);
             }
         }
     }
@@ -296,8 +335,8 @@ __global__ __launch_bounds__(NTHR) void k_int2_quant(BatchC batch, int N, int C,
             const int rr = r + WAVES * j;
             xv[j] = (h16x8)(h16)0; bv[j] = (h16x8)(h16)0; tk[j] = (h16)0;
             if (rr < t.r1 && t.act) {
-                xv[j] = ld8(x + (size_t)rr * C + t.c);
-                if (base) bv[j] = ld8(base + (size_t)rr * C + t.c);
+                xv[j] = ld8nt(x + (size_t)rr * C + t.c);
+                if (base) bv[j] = ld8nt(base + (size_t)rr * C + t.c);
                 tk[j] = TOK[rr];
             }
         }
@@ -324,7 +363,7 @@ __global__ __launch_bounds__(NTHR) void k_int2_quant(BatchC batch, int N, int C,
                     } else {
                         o = xv[j];
                     }
-                    st8(nb + (size_t)rr * C + t.c, o);
+                    st8nt(nb + (size_t)rr * C + t.c, o);
                 }
             }
         }
@@ -354,7 +393,7 @@ __global__ __launch_bounds__(NTHR) void k_int2_dequant(BatchD batch, int N, int 
             const int rr = r + WAVES * j;
             bv[j] = (h16x8)(h16)0; cd[j] = 0; tk[j] = (h16)0;
             if (rr < t.r1 && t.act) {
-                if (base) bv[j] = ld8(base + (size_t)rr * C + t.c);
+                if (base) bv[j] = ld8nt(base + (size_t)rr * C + t.c);
                 cd[j] = *reinterpret_cast<const u16*>(pk + (size_t)rr * C4 + (t.c >> 2));
                 tk[j] = TOK[rr];
             }
@@ -365,7 +404,7 @@ __global__ __launch_bounds__(NTHR) void k_int2_dequant(BatchD batch, int N, int 
             if (rr < t.r1 && t.act) {
                 const h16x8 thr = ch8 * tk[j];
                 const h16x8 recv = int2_recv(cd[j], thr);
-                st8(out + (size_t)rr * C + t.c, base ? (bv[j] + recv) : recv);
+                st8nt(out + (size_t)rr * C + t.c, base ? (bv[j] + recv) : recv);
             }
         }
     }
@@ -384,10 +423,10 @@ __global__ __launch_bounds__(NTHR) void k_minmax_stats(BatchC batch, int N, int 
     h16x8 mn = (h16x8)(h16)65504.0f, mx = (h16x8)(h16)-65504.0f;
     mn = (h16x8)hfrom(0x7c00);   // +inf
     mx = (h16x8)hfrom(0xfc00);   // -inf
-    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL) {
-        h16x8 xv[UNROLL], bv[UNROLL];
+    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL_S) {
+        h16x8 xv[UNROLL_S], bv[UNROLL_S];
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) {
+        for (int j = 0; j < UNROLL_S; ++j) {
             const int rr = r + WAVES * j;
             xv[j] = (h16x8)(h16)0; bv[j] = (h16x8)(h16)0;
             if (rr < t.r1 && t.act) {
@@ -396,7 +435,7 @@ __global__ __launch_bounds__(NTHR) void k_minmax_stats(BatchC batch, int N, int 
             }
         }
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) {
+        for (int j = 0; j < UNROLL_S; ++j) {
             const int rr = r + WAVES * j;
             if (rr < t.r1 && t.act) {
                 const h16x8 d = xv[j] - bv[j];
@@ -493,8 +532,8 @@ __global__ __launch_bounds__(NTHR) void k_int8_quant(BatchC batch, int N, int C,
             const int rr = r + WAVES * j;
             xv[j] = (h16x8)(h16)0; bv[j] = (h16x8)(h16)0;
             if (rr < t.r1 && t.act) {
-                xv[j] = ld8(x + (size_t)rr * C + t.c);
-                if (base) bv[j] = ld8(base + (size_t)rr * C + t.c);
+                xv[j] = ld8nt(x + (size_t)rr * C + t.c);
+                if (base) bv[j] = ld8nt(base + (size_t)rr * C + t.c);
             }
         }
 #pragma unroll
@@ -510,8 +549,9 @@ __global__ __launch_bounds__(NTHR) void k_int8_quant(BatchC batch, int N, int C,
                     if (hisnan(v)) v = (h16)0;
                     v = v < (h16)-128.0f ? (h16)-128.0f : v;
                     v = v > (h16)127.0f ? (h16)127.0f : v;
-                    qh[i] = v;
-                    outb |= (u64)(unsigned char)(signed char)(int)(float)v << (8 * i);
+                    const int qi = (int)(float)v;
+                    qh[i] = (h16)(float)qi;                                 // via int: rint(-0.3) = -0 must dequantise as +0
+                    outb |= (u64)(unsigned char)(signed char)qi << (8 * i);
                 }
                 *reinterpret_cast<u64*>(q + (size_t)rr * C + t.c) = outb;
                 if (upd) {
@@ -520,7 +560,7 @@ __global__ __launch_bounds__(NTHR) void k_int8_quant(BatchC batch, int N, int C,
                         const h16x8 recv = (qh - zp) * sc;                // (q - zp) * scale
                         o = base ? (bv[j] + recv) : recv;
                     } else o = xv[j];
-                    st8(nb + (size_t)rr * C + t.c, o);
+                    st8nt(nb + (size_t)rr * C + t.c, o);
                 }
             }
         }
@@ -548,7 +588,7 @@ __global__ __launch_bounds__(NTHR) void k_int8_dequant(BatchD batch, int N, int 
             const int rr = r + WAVES * j;
             bv[j] = (h16x8)(h16)0; qb[j] = 0;
             if (rr < t.r1 && t.act) {
-                if (base) bv[j] = ld8(base + (size_t)rr * C + t.c);
+                if (base) bv[j] = ld8nt(base + (size_t)rr * C + t.c);
                 qb[j] = *reinterpret_cast<const u64*>(q + (size_t)rr * C + t.c);
             }
         }
@@ -560,7 +600,7 @@ __global__ __launch_bounds__(NTHR) void k_int8_dequant(BatchD batch, int N, int 
 #pragma unroll
                 for (int i = 0; i < 8; ++i) qh[i] = (h16)(float)(int)(signed char)(qb[j] >> (8 * i));
                 const h16x8 recv = (qh - zp) * sc;
-                st8(out + (size_t)rr * C + t.c, base ? (bv[j] + recv) : recv);
+                st8nt(out + (size_t)rr * C + t.c, base ? (bv[j] + recv) : recv);
             }
         }
     }
@@ -584,7 +624,7 @@ __global__ __launch_bounds__(NTHR) void k_int4_quant(BatchC batch, int N, int C,
     h16x8 sc = (h16x8)(h16)1.0f, mn = (h16x8)(h16)0;
     if (t.act) { sc = ld8_tail(S + t.c, al16); mn = ld8_tail(M + t.c, al16); }
     const int k0 = t.r0 >> 1, k1 = t.r1 >> 1;
-    constexpr int U2 = UNROLL / 2;
+    constexpr int U2 = 1;   // one row PAIR per wave step
     for (int k = k0 + t.w; k < k1; k += WAVES * U2) {
         h16x8 xv[U2][2], bv[U2][2];
 #pragma unroll
@@ -594,8 +634,8 @@ __global__ __launch_bounds__(NTHR) void k_int4_quant(BatchC batch, int N, int C,
             for (int h = 0; h < 2; ++h) {
                 xv[j][h] = (h16x8)(h16)0; bv[j][h] = (h16x8)(h16)0;
                 if (kk < k1 && t.act) {
-                    xv[j][h] = ld8(x + (size_t)(2 * kk + h) * C + t.c);
-                    if (base) bv[j][h] = ld8(base + (size_t)(2 * kk + h) * C + t.c);
+                    xv[j][h] = ld8nt(x + (size_t)(2 * kk + h) * C + t.c);
+                    if (base) bv[j][h] = ld8nt(base + (size_t)(2 * kk + h) * C + t.c);
                 }
             }
         }
@@ -615,8 +655,9 @@ __global__ __launch_bounds__(NTHR) void k_int4_quant(BatchC batch, int N, int C,
                         if (hisnan(v)) v = (h16)0;
                         v = v < (h16)0 ? (h16)0 : v;
                         v = v > (h16)15.0f ? (h16)15.0f : v;
-                        qh[h][i] = v;
-                        outb |= (u64)((unsigned)(float)v & 15u) << (8 * i + 4 * h);
+                        const unsigned qi = (unsigned)(float)v & 15u;
+                        qh[h][i] = (h16)(float)qi;
+                        outb |= (u64)qi << (8 * i + 4 * h);
                     }
                 }
                 *reinterpret_cast<u64*>(q + (size_t)kk * C + t.c) = outb;
@@ -628,7 +669,7 @@ __global__ __launch_bounds__(NTHR) void k_int4_quant(BatchC batch, int N, int C,
                             const h16x8 recv = qh[h] * sc + mn;            // q*scale + min (two roundings; contraction is off)
                             o = base ? (bv[j][h] + recv) : recv;
                         } else o = xv[j][h];
-                        st8(nb + (size_t)(2 * kk + h) * C + t.c, o);
+                        st8nt(nb + (size_t)(2 * kk + h) * C + t.c, o);
                     }
                 }
             }
@@ -648,7 +689,7 @@ __global__ __launch_bounds__(NTHR) void k_int4_dequant(BatchD batch, int N, int 
     h16x8 sc = (h16x8)(h16)1.0f, mn = (h16x8)(h16)0;
     if (t.act) { sc = ld8_tail(S + t.c, al16); mn = ld8_tail(M + t.c, al16); }
     const int k0 = t.r0 >> 1, k1 = t.r1 >> 1;
-    constexpr int U2 = UNROLL / 2;
+    constexpr int U2 = 1;   // one row PAIR per wave step
     for (int k = k0 + t.w; k < k1; k += WAVES * U2) {
         h16x8 bv[U2][2];
         u64 qb[U2];
@@ -659,7 +700,7 @@ __global__ __launch_bounds__(NTHR) void k_int4_dequant(BatchD batch, int N, int 
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 bv[j][h] = (h16x8)(h16)0;
-                if (kk < k1 && t.act && base) bv[j][h] = ld8(base + (size_t)(2 * kk + h) * C + t.c);
+                if (kk < k1 && t.act && base) bv[j][h] = ld8nt(base + (size_t)(2 * kk + h) * C + t.c);
             }
             if (kk < k1 && t.act) qb[j] = *reinterpret_cast<const u64*>(q + (size_t)kk * C + t.c);
         }
@@ -673,7 +714,7 @@ __global__ __launch_bounds__(NTHR) void k_int4_dequant(BatchD batch, int N, int 
 #pragma unroll
                     for (int i = 0; i < 8; ++i) qh[i] = (h16)(float)((qb[j] >> (8 * i + 4 * h)) & 15u);
                     const h16x8 recv = qh * sc + mn;
-                    st8(out + (size_t)(2 * kk + h) * C + t.c, base ? (bv[j][h] + recv) : recv);
+                    st8nt(out + (size_t)(2 * kk + h) * C + t.c, base ? (bv[j][h] + recv) : recv);
                 }
             }
         }
@@ -696,9 +737,9 @@ __global__ __launch_bounds__(256) void k_topk_compress(BatchC batch, size_t E, i
     unsigned char* idx = (unsigned char*)(val + E / M);
     const bool upd = (flags & CFX_FLAG_UPDATE_CACHE) && nb;
     const bool ef = !(flags & CFX_FLAG_NO_EF);
-    const h16x8 xv = ld8(x + e);
+    const h16x8 xv = ld8nt(x + e);
     h16x8 bv = (h16x8)(h16)0;
-    if (base) bv = ld8(base + e);
+    if (base) bv = ld8nt(base + e);
     const h16x8 d = xv - bv;
     const h16x8 a = habs8(d);
     unsigned keep = 0;   // bit i set = element i survives
@@ -749,7 +790,7 @@ __global__ __launch_bounds__(256) void k_topk_compress(BatchC batch, size_t E, i
             for (int i = 0; i < 8; ++i) recv[i] = ((keep >> i) & 1u) ? d[i] : (h16)0;
             o = base ? (bv + recv) : recv;
         } else o = xv;
-        st8(nb + e, o);
+        st8nt(nb + e, o);
     }
 }
 
@@ -772,8 +813,8 @@ __global__ __launch_bounds__(256) void k_topk_decompress(BatchD batch, size_t E)
         recv[i] = ((unsigned)(ei % M) == sel) ? val[hb] : (h16)0;
     }
     h16x8 bv = (h16x8)(h16)0;
-    if (base) bv = ld8(base + e);
-    st8(out + e, base ? (bv + recv) : recv);
+    if (base) bv = ld8nt(base + e);
+    st8nt(out + e, base ? (bv + recv) : recv);
 }
 
 __global__ __launch_bounds__(256) void k_copy_probe(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
@@ -785,11 +826,43 @@ __global__ __launch_bounds__(256) void k_copy_probe(uint4* __restrict__ dst, con
 // ---------------------------------------------------------------------------------------------------
 // host side: C-ABI
 // ---------------------------------------------------------------------------------------------------
+enum {
+    KID_ABSMEAN_STATS_BITS = 1, KID_ABSMEAN_STATS = 2, KID_ABSMEAN_FINALIZE = 3, KID_BINARY_DEQUANT = 4,
+    KID_INT2_QUANT = 5, KID_INT2_DEQUANT = 6, KID_MINMAX_STATS = 7, KID_MINMAX_FINALIZE = 8,
+    KID_INT8_QUANT = 9, KID_INT8_DEQUANT = 10, KID_INT4_QUANT = 11, KID_INT4_DEQUANT = 12,
+    KID_TOPK_COMPRESS = 13, KID_TOPK_DECOMPRESS = 14, KID_COPY_PROBE = 15, KID_BINARY_EF = 16, KID_MAX = 17
+};
+static const char* const kid_names[KID_MAX] = {
+    "", "k_absmean_stats<bits>", "k_absmean_stats", "k_absmean_finalize", "k_binary_dequant", "k_int2_quant", "k_int2_dequant",
+    "k_minmax_stats", "k_minmax_finalize", "k_int8_quant", "k_int8_dequant", "k_int4_quant", "k_int4_dequant",
+    "k_topk_compress", "k_topk_decompress", "k_copy_probe", "k_binary_dequant(ef)"};
+
+struct ProfRec { int kid; hipEvent_t a, b; };
+
 struct cfx_ctx {
     int device;
     int rows_per_tile;
+    // native per-launch timing (hipEvents recorded on the launch stream around selected kernels)
+    ProfRec* prof;
+    int prof_cap, prof_n;
+    int prof_stride, prof_seen;     // record every prof_stride-th eligible launch
+    unsigned prof_mask;
     char err[256];
 };
+
+// RAII-free helpers: begin returns the record index or -1
+static inline int prof_begin(cfx_ctx* ctx, int kid, hipStream_t s) {
+    if (!ctx->prof_mask || !(ctx->prof_mask & (1u << kid)) || ctx->prof_n >= ctx->prof_cap) return -1;
+    if ((ctx->prof_seen++ % ctx->prof_stride) != 0) return -1;
+    const int i = ctx->prof_n++;
+    ctx->prof[i].kid = kid;
+    (void)hipEventRecord(ctx->prof[i].a, s);
+    return i;
+}
+static inline void prof_end(cfx_ctx* ctx, int i, hipStream_t s) {
+    if (i >= 0) (void)hipEventRecord(ctx->prof[i].b, s);
+}
+#define LAUNCH(ctx, kid, s, ...) do { const int _pi = prof_begin(ctx, kid, s); hipLaunchKernelGGL(__VA_ARGS__); prof_end(ctx, _pi, s); } while (0)
 
 static int fail(cfx_ctx* ctx, int code, const char* msg) {
     if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
@@ -810,18 +883,15 @@ static bool shape_ok(int codec, int N, int C, int param) {
 }
 
 static int auto_rows(const cfx_ctx* ctx, int N, int C, int batch, bool stats) {
+    (void)N; (void)C; (void)batch;
     if (ctx && ctx->rows_per_tile > 0) {
         int r = ctx->rows_per_tile;
         if (stats && r < 16) r = 16;
         return (r + 1) & ~1;
     }
-    const int CB = (C + TILE_C - 1) / TILE_C;
-    const int cands[3] = {64, 32, 16};
-    for (int i = 0; i < 3; ++i) {
-        const long tiles = (long)CB * ((N + cands[i] - 1) / cands[i]) * batch;
-        if (tiles >= 1024) return cands[i];
-    }
-    return 16;
+    // Measured on MI355X (tools/kbench.hip, tools/microbench.py): short tiles win - one or two wave steps per
+    // workgroup, thousands of workgroups - because these launches last 5-20 us and ramp/tail dominate long tiles.
+    return stats ? WAVES * UNROLL_S : WAVES * UNROLL;
 }
 
 extern "C" {
@@ -832,11 +902,61 @@ cfx_ctx* cfx_create(int device) {
     cfx_ctx* c = new cfx_ctx();
     c->device = device;
     c->rows_per_tile = 0;
+    c->prof = nullptr;
+    c->prof_cap = c->prof_n = 0;
+    c->prof_stride = 1;
+    c->prof_seen = 0;
+    c->prof_mask = 0;
     c->err[0] = 0;
     return c;
 }
 
-void cfx_destroy(cfx_ctx* ctx) { delete ctx; }
+static void prof_free(cfx_ctx* ctx) {
+    for (int i = 0; i < ctx->prof_cap; ++i) { (void)hipEventDestroy(ctx->prof[i].a); (void)hipEventDestroy(ctx->prof[i].b); }
+    delete[] ctx->prof;
+    ctx->prof = nullptr;
+    ctx->prof_cap = ctx->prof_n = 0;
+}
+
+void cfx_destroy(cfx_ctx* ctx) {
+    if (!ctx) return;
+    prof_free(ctx);
+    delete ctx;
+}
+
+int cfx_profile_enable(cfx_ctx* ctx, int capacity, unsigned kernel_mask, int stride) {
+    if (!ctx) return CFX_ERR_NULL;
+    ctx->prof_stride = stride > 0 ? stride : 1;
+    ctx->prof_seen = 0;
+    if (capacity > ctx->prof_cap) {
+        prof_free(ctx);
+        ctx->prof = new ProfRec[capacity];
+        for (int i = 0; i < capacity; ++i) {
+            if (hipEventCreate(&ctx->prof[i].a) != hipSuccess || hipEventCreate(&ctx->prof[i].b) != hipSuccess)
+                return fail(ctx, CFX_ERR_LAUNCH, "profile: hipEventCreate failed");
+        }
+        ctx->prof_cap = capacity;
+    }
+    ctx->prof_n = 0;
+    ctx->prof_mask = capacity > 0 ? kernel_mask : 0;
+    return CFX_OK;
+}
+
+int cfx_profile_read(cfx_ctx* ctx, int* kernel_ids, float* ms, int cap) {
+    if (!ctx || !kernel_ids || !ms) return CFX_ERR_NULL;
+    const int n = ctx->prof_n < cap ? ctx->prof_n : cap;
+    for (int i = 0; i < n; ++i) {
+        (void)hipEventSynchronize(ctx->prof[i].b);
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, ctx->prof[i].a, ctx->prof[i].b) != hipSuccess) t = -1.f;
+        kernel_ids[i] = ctx->prof[i].kid;
+        ms[i] = t;
+    }
+    ctx->prof_n = 0;
+    return n;
+}
+
+const char* cfx_kernel_name(int kernel_id) { return (kernel_id > 0 && kernel_id < KID_MAX) ? kid_names[kernel_id] : ""; }
 
 const char* cfx_last_error_string(cfx_ctx* ctx) { return ctx ? ctx->err : "null ctx"; }
 
@@ -903,19 +1023,19 @@ int cfx_decompress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int b
     const int R = auto_rows(ctx, N, C, batch, false);
     const dim3 grid((C + TILE_C - 1) / TILE_C, (N + R - 1) / R, batch);
     switch (codec) {
-        case CFX_CODEC_BINARY: hipLaunchKernelGGL(k_binary_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
-        case CFX_CODEC_INT2: hipLaunchKernelGGL(k_int2_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
-        case CFX_CODEC_INT4: hipLaunchKernelGGL(k_int4_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
-        case CFX_CODEC_INT8: hipLaunchKernelGGL(k_int8_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
+        case CFX_CODEC_BINARY: LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
+        case CFX_CODEC_INT2: LAUNCH(ctx, KID_INT2_DEQUANT, s, k_int2_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
+        case CFX_CODEC_INT4: LAUNCH(ctx, KID_INT4_DEQUANT, s, k_int4_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
+        case CFX_CODEC_INT8: LAUNCH(ctx, KID_INT8_DEQUANT, s, k_int8_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
         case CFX_CODEC_TOPK: {
             const size_t E = (size_t)N * C;
             const dim3 g((unsigned)((E / 8 + 255) / 256), batch);
             switch (param) {
-                case 1: hipLaunchKernelGGL(k_topk_decompress<1>, g, dim3(256), 0, s, b, E); break;
-                case 2: hipLaunchKernelGGL(k_topk_decompress<2>, g, dim3(256), 0, s, b, E); break;
-                case 4: hipLaunchKernelGGL(k_topk_decompress<4>, g, dim3(256), 0, s, b, E); break;
-                case 8: hipLaunchKernelGGL(k_topk_decompress<8>, g, dim3(256), 0, s, b, E); break;
-                default: hipLaunchKernelGGL(k_topk_decompress<16>, g, dim3(256), 0, s, b, E); break;
+                case 1: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<1>, g, dim3(256), 0, s, b, E); break;
+                case 2: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<2>, g, dim3(256), 0, s, b, E); break;
+                case 4: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<4>, g, dim3(256), 0, s, b, E); break;
+                case 8: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<8>, g, dim3(256), 0, s, b, E); break;
+                default: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<16>, g, dim3(256), 0, s, b, E); break;
             }
         } break;
     }
@@ -948,11 +1068,11 @@ int cfx_compress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int fla
         const size_t E = (size_t)N * C;
         const dim3 g((unsigned)((E / 8 + 255) / 256), batch);
         switch (param) {
-            case 1: hipLaunchKernelGGL(k_topk_compress<1>, g, dim3(256), 0, s, b, E, flags); break;
-            case 2: hipLaunchKernelGGL(k_topk_compress<2>, g, dim3(256), 0, s, b, E, flags); break;
-            case 4: hipLaunchKernelGGL(k_topk_compress<4>, g, dim3(256), 0, s, b, E, flags); break;
-            case 8: hipLaunchKernelGGL(k_topk_compress<8>, g, dim3(256), 0, s, b, E, flags); break;
-            default: hipLaunchKernelGGL(k_topk_compress<16>, g, dim3(256), 0, s, b, E, flags); break;
+            case 1: LAUNCH(ctx, KID_TOPK_COMPRESS, s, k_topk_compress<1>, g, dim3(256), 0, s, b, E, flags); break;
+            case 2: LAUNCH(ctx, KID_TOPK_COMPRESS, s, k_topk_compress<2>, g, dim3(256), 0, s, b, E, flags); break;
+            case 4: LAUNCH(ctx, KID_TOPK_COMPRESS, s, k_topk_compress<4>, g, dim3(256), 0, s, b, E, flags); break;
+            case 8: LAUNCH(ctx, KID_TOPK_COMPRESS, s, k_topk_compress<8>, g, dim3(256), 0, s, b, E, flags); break;
+            default: LAUNCH(ctx, KID_TOPK_COMPRESS, s, k_topk_compress<16>, g, dim3(256), 0, s, b, E, flags); break;
         }
         return check_launch(ctx, "topk compress launch");
     }
@@ -961,13 +1081,13 @@ int cfx_compress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int fla
     const int P = (N + R - 1) / R;
     const dim3 grid(CB, P, batch);
     if (codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT2) {
-        if (codec == CFX_CODEC_BINARY) hipLaunchKernelGGL(k_absmean_stats<true>, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
-        else hipLaunchKernelGGL(k_absmean_stats<false>, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
+        if (codec == CFX_CODEC_BINARY) LAUNCH(ctx, KID_ABSMEAN_STATS_BITS, s, k_absmean_stats<true>, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
+        else LAUNCH(ctx, KID_ABSMEAN_STATS, s, k_absmean_stats<false>, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
         const int per_byte = codec == CFX_CODEC_BINARY ? 8 : 4;
-        hipLaunchKernelGGL(k_absmean_finalize, dim3(1 + (C + 255) / 256, batch), dim3(256), 0, s, b, N, C, CB, P, per_byte,
+        LAUNCH(ctx, KID_ABSMEAN_FINALIZE, s, k_absmean_finalize, dim3(1 + (C + 255) / 256, batch), dim3(1024), 0, s, b, N, C, CB, P, per_byte,
                            codec == CFX_CODEC_INT2 ? 1 : 0, (const u64*)ws, wstride);
         if (codec == CFX_CODEC_INT2) {
-            hipLaunchKernelGGL(k_int2_quant, grid, dim3(NTHR), 0, s, b, N, C, R, flags);
+            LAUNCH(ctx, KID_INT2_QUANT, s, k_int2_quant, grid, dim3(NTHR), 0, s, b, N, C, R, flags);
         } else if (upd) {
             if (flags & CFX_FLAG_NO_EF) {
                 for (int i = 0; i < batch; ++i)
@@ -978,14 +1098,14 @@ int cfx_compress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int fla
                 BatchD d;
                 memset(&d, 0, sizeof(d));
                 for (int i = 0; i < batch; ++i) { d.it[i].packet = items[i].packet; d.it[i].base = items[i].base; d.it[i].recon = items[i].new_base; }
-                hipLaunchKernelGGL(k_binary_dequant, grid, dim3(NTHR), 0, s, d, N, C, R);
+                LAUNCH(ctx, KID_BINARY_EF, s, k_binary_dequant, grid, dim3(NTHR), 0, s, d, N, C, R);
             }
         }
     } else {
-        hipLaunchKernelGGL(k_minmax_stats, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
-        hipLaunchKernelGGL(k_minmax_finalize, dim3((C + 255) / 256, batch), dim3(256), 0, s, b, N, C, P, codec, (const u64*)ws, wstride);
-        if (codec == CFX_CODEC_INT4) hipLaunchKernelGGL(k_int4_quant, grid, dim3(NTHR), 0, s, b, N, C, R, flags);
-        else hipLaunchKernelGGL(k_int8_quant, grid, dim3(NTHR), 0, s, b, N, C, R, flags);
+        LAUNCH(ctx, KID_MINMAX_STATS, s, k_minmax_stats, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
+        LAUNCH(ctx, KID_MINMAX_FINALIZE, s, k_minmax_finalize, dim3((C + 255) / 256, batch), dim3(256), 0, s, b, N, C, P, codec, (const u64*)ws, wstride);
+        if (codec == CFX_CODEC_INT4) LAUNCH(ctx, KID_INT4_QUANT, s, k_int4_quant, grid, dim3(NTHR), 0, s, b, N, C, R, flags);
+        else LAUNCH(ctx, KID_INT8_QUANT, s, k_int8_quant, grid, dim3(NTHR), 0, s, b, N, C, R, flags);
     }
     return check_launch(ctx, "compress launch");
 }
@@ -1001,10 +1121,91 @@ int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base
     return cfx_decompress_batch(ctx, codec, N, C, param, 1, &it, stream);
 }
 
+// ---- plan: a prebuilt schedule of batch ops replayed from native code (no per-op Python marshalling) -------------
+struct PlanOp {
+    int kind;   // 0 compress, 1 decompress
+    int codec, N, C, param, flags, batch;
+    cfx_comp_item c[CFX_MAX_BATCH];
+    cfx_decomp_item d[CFX_MAX_BATCH];
+    void* ws;
+    size_t ws_bytes;
+};
+struct cfx_plan {
+    cfx_ctx* ctx;
+    PlanOp* ops;
+    int n, cap;
+};
+
+cfx_plan* cfx_plan_create(cfx_ctx* ctx) {
+    if (!ctx) return nullptr;
+    cfx_plan* p = new cfx_plan();
+    p->ctx = ctx;
+    p->ops = nullptr;
+    p->n = p->cap = 0;
+    return p;
+}
+
+void cfx_plan_destroy(cfx_plan* p) {
+    if (!p) return;
+    delete[] p->ops;
+    delete p;
+}
+
+static PlanOp* plan_push(cfx_plan* p) {
+    if (p->n == p->cap) {
+        const int ncap = p->cap ? p->cap * 2 : 64;
+        PlanOp* no = new PlanOp[ncap];
+        if (p->n) memcpy(no, p->ops, sizeof(PlanOp) * p->n);
+        delete[] p->ops;
+        p->ops = no;
+        p->cap = ncap;
+    }
+    return &p->ops[p->n++];
+}
+
+int cfx_plan_add_compress(cfx_plan* p, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                          void* workspace, size_t workspace_bytes) {
+    if (!p || !items) return CFX_ERR_NULL;
+    if (batch < 1 || batch > CFX_MAX_BATCH) return fail(p->ctx, CFX_ERR_BATCH, "plan: batch out of range");
+    if (!shape_ok(codec, N, C, param)) return fail(p->ctx, CFX_ERR_SHAPE, "plan: bad codec/shape");
+    PlanOp* o = plan_push(p);
+    memset(o, 0, sizeof(*o));
+    o->kind = 0; o->codec = codec; o->N = N; o->C = C; o->param = param; o->flags = flags; o->batch = batch;
+    memcpy(o->c, items, sizeof(cfx_comp_item) * batch);
+    o->ws = workspace; o->ws_bytes = workspace_bytes;
+    return p->n - 1;
+}
+
+int cfx_plan_add_decompress(cfx_plan* p, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items) {
+    if (!p || !items) return CFX_ERR_NULL;
+    if (batch < 1 || batch > CFX_MAX_BATCH) return fail(p->ctx, CFX_ERR_BATCH, "plan: batch out of range");
+    if (!shape_ok(codec, N, C, param)) return fail(p->ctx, CFX_ERR_SHAPE, "plan: bad codec/shape");
+    PlanOp* o = plan_push(p);
+    memset(o, 0, sizeof(*o));
+    o->kind = 1; o->codec = codec; o->N = N; o->C = C; o->param = param; o->batch = batch;
+    memcpy(o->d, items, sizeof(cfx_decomp_item) * batch);
+    return p->n - 1;
+}
+
+int cfx_plan_size(const cfx_plan* p) { return p ? p->n : CFX_ERR_NULL; }
+
+int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) {
+    if (!p) return CFX_ERR_NULL;
+    if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
+    for (int i = first_op; i < first_op + n_ops; ++i) {
+        const PlanOp* o = &p->ops[i];
+        const int rc = o->kind == 0
+            ? cfx_compress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, o->ws, o->ws_bytes, stream)
+            : cfx_decompress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->batch, o->d, stream);
+        if (rc != CFX_OK) return rc;
+    }
+    return CFX_OK;
+}
+
 int cfx_copy_probe(cfx_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {
     if (!ctx || !dst || !src) return fail(ctx, CFX_ERR_NULL, "copy_probe: null");
     if ((bytes & 15) || !AL16(dst) || !AL16(src)) return fail(ctx, CFX_ERR_ALIGN, "copy_probe: 16-byte granularity");
-    hipLaunchKernelGGL(k_copy_probe, dim3(2048), dim3(256), 0, (hipStream_t)stream, (uint4*)dst, (const uint4*)src, bytes / 16);
+    { hipStream_t s = (hipStream_t)stream; LAUNCH(ctx, KID_COPY_PROBE, s, k_copy_probe, dim3(2048), dim3(256), 0, s, (uint4*)dst, (const uint4*)src, bytes / 16); }
     return check_launch(ctx, "copy_probe launch");
 }
 

@@ -114,6 +114,32 @@ int cfx_compress(cfx_ctx* ctx, int codec, const void* x, const void* base, void*
 int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base, void* recon,
                    int N, int C, int param, void* stream);
 
+/* Native per-launch timing.  When enabled, every `stride`-th launch of a kernel whose id bit is set in kernel_mask
+ * is bracketed by hipEvents recorded on the launch stream (up to `capacity` records; capacity 0 disables).  An event
+ * pair costs ~2-5 us of stream time, hence the stride.
+ * cfx_profile_read synchronises on the recorded events, returns their count and resets the log.
+ * Kernel ids: 1 absmean_stats<bits>, 2 absmean_stats, 3 absmean_finalize, 4 binary_dequant, 5 int2_quant,
+ * 6 int2_dequant, 7 minmax_stats, 8 minmax_finalize, 9 int8_quant, 10 int8_dequant, 11 int4_quant,
+ * 12 int4_dequant, 13 topk_compress, 14 topk_decompress, 15 copy_probe, 16 binary_dequant launched as the
+ * sender's error-feedback update. */
+int         cfx_profile_enable(cfx_ctx* ctx, int capacity, unsigned kernel_mask, int stride);
+int         cfx_profile_read(cfx_ctx* ctx, int* kernel_ids, float* ms, int cap);
+const char* cfx_kernel_name(int kernel_id);
+
+/* Plan: a prebuilt schedule of batch ops (e.g. the 57 layers x {compress, reconstruct} of one denoise step) that is
+ * replayed from native code - the MI355X-native replacement for the reference's per-call Python dispatch
+ * (xfuser/compact/ring.py:188-206, main.py:169-270).  cfx_plan_add_* copy their arguments and return the op index
+ * (>= 0) or an error (< 0); cfx_plan_run launches ops [first_op, first_op + n_ops) on `stream`. */
+typedef struct cfx_plan cfx_plan;
+cfx_plan* cfx_plan_create(cfx_ctx* ctx);
+void      cfx_plan_destroy(cfx_plan* plan);
+int       cfx_plan_add_compress(cfx_plan* plan, int codec, int N, int C, int param, int flags, int batch,
+                                const cfx_comp_item* items, void* workspace, size_t workspace_bytes);
+int       cfx_plan_add_decompress(cfx_plan* plan, int codec, int N, int C, int param, int batch,
+                                  const cfx_decomp_item* items);
+int       cfx_plan_size(const cfx_plan* plan);
+int       cfx_plan_run(cfx_plan* plan, int first_op, int n_ops, void* stream);
+
 /* Bandwidth probe: dst[i] = src[i] over `bytes` (multiple of 16) - the achievable-HBM reference
  * against which bench.py reports roofline fractions. */
 int cfx_copy_probe(cfx_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream);

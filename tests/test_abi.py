@@ -1,0 +1,75 @@
+"""The C-ABI shared library loads and exports every symbol include/cfx.h declares (no compute calls: CPU only)."""
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(REPO, "include", "cfx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cfx_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported_and_bound():
+    from compactfusion_amd import _lib
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in include/cfx.h but not exported by libcfx.so"
+        assert sym in bound, f"{sym} declared in include/cfx.h but not bound in compactfusion_amd/_lib.py"
+    assert bound <= set(declared), bound - set(declared)
+    assert lib.cfx_abi_version() == 1
+
+
+def test_packet_bytes_match_oracle_and_reference_arithmetic():
+    """cfx_packet_bytes is host-only arithmetic: compare with the oracle's wire-size formulae (main.py:285-293)."""
+    from compactfusion_amd import _lib
+    from oracle import ref_np as R
+    lib = _lib.load()
+    names = {1: "binary", 2: "int2", 3: "int4", 4: "int8", 5: "topk"}
+    for (N, C) in [(544, 3072), (4096, 1152), (1024, 1152), (4448, 3072), (512, 1536), (64, 256)]:
+        for cid, name in names.items():
+            for param in ((1, 2, 4, 8, 16) if cid == 5 else (0,)):
+                if cid == 5 and (N * C) % 1024:
+                    assert lib.cfx_packet_bytes(cid, N, C, param) == 0
+                    continue
+                assert lib.cfx_packet_bytes(cid, N, C, param) == 2 * R.packet_halves(name, N, C, param), (name, N, C, param)
+    assert lib.cfx_packet_bytes(1, 544, 3072, 0) == 216128
+    assert lib.cfx_packet_bytes(4, 4096, 1152, 0) == 4723200
+    assert lib.cfx_packet_bytes(1, 8, 20, 0) == 0                    # C % 8
+    assert lib.cfx_packet_bytes(3, 7, 64, 0) == 0                    # odd N for int4
+    assert lib.cfx_packet_bytes(77, 8, 64, 0) == 0
+    assert lib.cfx_workspace_bytes(1, 544, 3072, 0, 2) > 0
+    assert lib.cfx_workspace_bytes(1, 544, 3072, 0, 17) == 0
+
+
+def test_error_paths_without_gpu():
+    """Argument validation happens before any HIP call."""
+    from compactfusion_amd import _lib
+    lib = _lib.load()
+    ctx = lib.cfx_create(0)
+    assert ctx
+    items = (_lib.CompItem * 1)()
+    assert lib.cfx_compress_batch(ctx, 1, 8, 64, 0, 0, 1, items, None, 0, None) == -1          # null x
+    assert lib.cfx_compress_batch(ctx, 1, 8, 20, 0, 0, 1, items, None, 0, None) == -2          # bad shape
+    assert lib.cfx_compress_batch(ctx, 42, 8, 64, 0, 0, 1, items, None, 0, None) == -4         # bad codec
+    assert lib.cfx_compress_batch(ctx, 1, 8, 64, 0, 0, 0, items, None, 0, None) == -5          # bad batch
+    items[0] = _lib.CompItem(0x1002, None, None, 0x2000)
+    assert lib.cfx_compress_batch(ctx, 1, 8, 64, 0, 0, 1, items, None, 0, None) == -3          # misaligned x
+    items[0] = _lib.CompItem(0x1000, None, None, 0x2000)
+    assert lib.cfx_compress_batch(ctx, 1, 8, 64, 0, 0, 1, items, None, 0, None) == -7          # workspace missing
+    assert b"workspace" in lib.cfx_last_error_string(ctx)
+    lib.cfx_destroy(ctx)
+
+
+def test_cpu_tensors_are_refused():
+    import torch
+    from compactfusion_amd import codecs as K
+    from compactfusion_amd._lib import CfxError
+    with pytest.raises(CfxError):
+        K.compress(1, torch.zeros(8, 64, dtype=torch.float16), None, 8, 64)
