@@ -1,0 +1,51 @@
+"""Block attention + running log-sum-exp merge used by the ring / gather consumers.
+
+The reference takes these from un-vendored third-party packages (`yunchang.ring.utils.update_out_and_lse`,
+`yunchang.kernels.attention.pytorch_attn_forward`, `flash_attn._flash_attn_forward`; call sites ring.py:225-263).
+They are restated here from the published ring-attention algorithm:
+    out <- out - sigmoid(lse_b - lse) * (out - out_b) ;  lse <- lse - logsigmoid(lse - lse_b)
+The attention math itself is not part of the compressed-exchange hot path; on the GPU it is PyTorch-ROCm's fused
+SDPA kernel, elsewhere an explicit fp32 softmax."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+def block_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, dropout_p: float = 0.0,
+                    softmax_scale: Optional[float] = None, causal: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """q (B, Sq, H, D), k/v (B, Sk, H, D) -> out (B, Sq, H, D) in q.dtype, lse (B, H, Sq) fp32."""
+    if softmax_scale is None:
+        softmax_scale = q.shape[-1] ** (-0.5)
+    qt, kt, vt = (t.transpose(1, 2) for t in (q, k, v))
+    if q.is_cuda and dropout_p == 0.0:
+        try:
+            res = torch.ops.aten._scaled_dot_product_flash_attention(qt, kt, vt, 0.0, causal, False, scale=softmax_scale)
+            return res[0].transpose(1, 2), res[1].float()
+        except (RuntimeError, NotImplementedError):
+            pass
+    s = torch.matmul(qt.float(), kt.float().transpose(-1, -2)) * softmax_scale
+    if causal:
+        Sq, Sk = s.shape[-2], s.shape[-1]
+        mask = torch.ones(Sq, Sk, dtype=torch.bool, device=s.device).tril(diagonal=Sk - Sq)
+        s = s.masked_fill(~mask, float("-inf"))
+    lse = torch.logsumexp(s, dim=-1)
+    p = torch.exp(s - lse.unsqueeze(-1))
+    if dropout_p > 0.0:
+        p = F.dropout(p, dropout_p)
+    out = torch.matmul(p, vt.float()).to(q.dtype)
+    return out.transpose(1, 2), lse
+
+
+def update_out_and_lse(out: Optional[torch.Tensor], lse: Optional[torch.Tensor], block_out: torch.Tensor,
+                       block_lse: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Merge one attention block into the running (out fp32 (B,S,H,D), lse fp32 (B,S,H,1))."""
+    block_out = block_out.to(torch.float32)
+    block_lse = block_lse.transpose(-2, -1).unsqueeze(-1)
+    if out is None:
+        return block_out, block_lse
+    out = out - torch.sigmoid(block_lse - lse) * (out - block_out)
+    lse = lse - F.logsigmoid(lse - block_lse)
+    return out, lse

@@ -1,0 +1,233 @@
+"""Ring-attention forward with residual-compressed K/V exchange - the hook `xFuserLongContextAttention` binds.
+
+Mirror of the reference's `xfuser/compact/ring.py` (`compact_fwd` :36-70 with the same 17-argument signature and
+(out, lse, None) return; `_compact_ring_fwd` :120-275).  Two schedules produce the same numbers:
+
+  relay  - the reference's schedule restated: each rank compresses its K and V once, the *packets* hop W-1 times
+           around the ring with batched isend/irecv (own `RingComm`, the reference uses yunchang's), every hop's
+           packet is decoded against the sender's cached state (keys "{layer}-{rank}-{k|v}"), attention blocks are
+           merged with the running log-sum-exp.
+  gather - the MI355X-native schedule (default on GPUs): xGMI is a full point-to-point mesh and a packet is ~0.2 MB,
+           so all ranks' K+V packets are exchanged with ONE `all_gather_into_tensor` on a side HIP stream while the
+           local attention block runs, then ALL peers' K and V are reconstructed with ONE batched dequant+add launch,
+           and the attention blocks are visited in the same ring order (rank-1, rank-2, ...) so the merge order - and
+           therefore the result - is identical to the relay schedule.
+Step 0 uses the exact local K/V in both (ring.py:207-208); WARMUP steps move raw fp16 (main.py:195-209).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from ..prof import Profiler
+from . import main as cm
+from .attention import block_attention, update_out_and_lse
+from .main import compact_cache, compact_compress, compact_config, compact_decompress
+from .utils import COMPACT_COMPRESS_TYPE
+
+T = COMPACT_COMPRESS_TYPE
+
+
+class RingComm:
+    """One hop of a ring: post send-to-next / receive-from-previous pairs, commit them as one batch, wait.
+    (restates the interface `yunchang.ring.utils.RingComm` offers at the call sites ring.py:172,193-195,267)"""
+
+    def __init__(self, process_group=None):
+        self._pg = process_group
+        self.rank = dist.get_rank(process_group)
+        self.world_size = dist.get_world_size(process_group)
+        nxt, prv = (self.rank + 1) % self.world_size, (self.rank - 1) % self.world_size
+        if process_group is not None:
+            nxt, prv = dist.get_global_rank(process_group, nxt), dist.get_global_rank(process_group, prv)
+        self.send_rank, self.recv_rank = nxt, prv
+        self._ops: List[dist.P2POp] = []
+        self._reqs = None
+
+    def send_recv(self, to_send: torch.Tensor, recv_tensor: Optional[torch.Tensor] = None) -> torch.Tensor:
+        res = torch.empty_like(to_send) if recv_tensor is None else recv_tensor
+        self._ops.append(dist.P2POp(dist.isend, to_send, self.send_rank, group=self._pg))
+        self._ops.append(dist.P2POp(dist.irecv, res, self.recv_rank, group=self._pg))
+        return res
+
+    def commit(self):
+        assert self._reqs is None, "commit called twice"
+        self._reqs = dist.batch_isend_irecv(self._ops)
+
+    def wait(self):
+        assert self._reqs is not None, "wait called before commit"
+        for r in self._reqs:
+            r.wait()
+        self._reqs, self._ops = None, []
+
+
+def compact_fwd(q, k, v, dropout_p=0, softmax_scale=None, causal=True, window_size=(-1, -1), alibi_slopes=None,
+                return_attn_probs=None, deterministic=False, attn_layer=None, group=None, joint_tensor_key=None,
+                joint_tensor_value=None, joint_strategy="none", mod_idx=None, current_iter=None):
+    """Dispatch: patch-gather forward when `override_with_patch_gather_fwd`, else the ring forward (ring.py:36-70)."""
+    args = (q, k, v, dropout_p, softmax_scale, causal, window_size, alibi_slopes, return_attn_probs, deterministic,
+            attn_layer, group, joint_tensor_key, joint_tensor_value, joint_strategy, mod_idx, current_iter)
+    if compact_config().override_with_patch_gather_fwd:
+        from .patchpara.fwd import patch_gather_fwd
+        return patch_gather_fwd(*args)
+    return _compact_ring_fwd(*args)
+
+
+def _joint_mode(joint_tensor_key, joint_tensor_value, joint_strategy) -> Optional[str]:
+    if (joint_tensor_key is None) != (joint_tensor_value is None):
+        raise ValueError("joint_tensor_key and joint_tensor_value should be None or not None simultaneously.")
+    if joint_tensor_key is None:
+        return None
+    if joint_strategy not in ("front", "rear"):
+        raise ValueError(f"joint_strategy: {joint_strategy} not supprted. supported joint strategy: ['front', 'rear']")
+    return joint_strategy
+
+
+def _with_joint(k, v, jk, jv, mode, step, world):
+    if mode == "front" and step == 0:
+        return torch.cat([jk, k], dim=1), torch.cat([jv, v], dim=1)
+    if mode == "rear" and step + 1 == world:
+        return torch.cat([k, jk], dim=1), torch.cat([v, jv], dim=1)
+    return k, v
+
+
+def _schedule(q: torch.Tensor) -> str:
+    s = os.environ.get("CFX_RING_SCHEDULE", "auto")
+    if s == "auto":
+        return "gather" if q.is_cuda else "relay"
+    assert s in ("gather", "relay"), "CFX_RING_SCHEDULE must be auto | gather | relay"
+    return s
+
+
+@Profiler.prof_func("compact._compact_ring_fwd")
+def _compact_ring_fwd(q, k, v, dropout_p=0, softmax_scale=None, causal=True, window_size=(-1, -1), alibi_slopes=None,
+                      return_attn_probs=None, deterministic=False, attn_layer=None, group=None, joint_tensor_key=None,
+                      joint_tensor_value=None, joint_strategy="none", mod_idx=None, current_iter=None):
+    assert alibi_slopes is None
+    if softmax_scale is None:
+        softmax_scale = q.shape[-1] ** (-0.5)
+    jmode = _joint_mode(joint_tensor_key, joint_tensor_value, joint_strategy)
+    comm = RingComm(group)
+    rank, world = comm.rank, comm.world_size
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    ctype = compact_config().compress_func(mod_idx, current_iter)
+    kshape, vshape = k.shape, v.shape
+    kkey = lambda r: f"{mod_idx}-{r % world}-k"   # noqa: E731
+    vkey = lambda r: f"{mod_idx}-{r % world}-v"   # noqa: E731
+
+    def attend(out, lse, kk, vv, step):
+        if causal and step > rank:
+            return out, lse
+        kk, vv = _with_joint(kk, vv, joint_tensor_key, joint_tensor_value, jmode, step, world)
+        bo, bl = block_attention(q, kk, vv, dropout_p, softmax_scale, causal=causal and step == 0)
+        return update_out_and_lse(out, lse, bo, bl)
+
+    out = lse = None
+    if world == 1 or _schedule(q) == "relay":
+        k_send = compact_compress(kkey(rank), k, ctype, update_cache=True)
+        v_send = compact_compress(vkey(rank), v, ctype, update_cache=True)
+        for step in range(world):
+            if step + 1 != world:
+                buf_k = comm.send_recv(k_send)
+                buf_v = comm.send_recv(v_send)
+                comm.commit()
+            if step != 0:
+                src = rank - step
+                k = compact_decompress(kkey(src), k_send, ctype, kshape, update_cache=True).contiguous()
+                v = compact_decompress(vkey(src), v_send, ctype, vshape, update_cache=True).contiguous()
+            out, lse = attend(out, lse, k, v, step)
+            if step + 1 != world:
+                with Profiler.scope("compact.ring.wait"):
+                    comm.wait()
+                k_send, v_send = buf_k, buf_v
+    else:
+        out, lse = _gather_schedule(q, k, v, ctype, mod_idx, rank, world, group, kkey, vkey, attend)
+
+    out = out.to(q.dtype)
+    lse = lse.squeeze(dim=-1).transpose(1, 2)
+    if compact_config().check_cache_consistency:
+        compact_cache().check_consistency(group=group)
+    return out, lse, None
+
+
+_xbuf = {}
+
+
+def _exchange_buffers(tag, slot_halves: int, world: int, like: torch.Tensor):
+    key = (tag, slot_halves, world, like.device)
+    b = _xbuf.get(key)
+    if b is None:
+        send = torch.empty(2 * slot_halves, dtype=torch.float16, device=like.device)
+        recv = torch.empty(world * 2 * slot_halves, dtype=torch.float16, device=like.device)
+        side = torch.cuda.Stream(like.device) if like.is_cuda else None
+        b = (send, recv, side)
+        _xbuf[key] = b
+    return b
+
+
+def _gather_schedule(q, k, v, ctype, mod_idx, rank, world, group, kkey, vkey, attend):
+    """One all-gather of [K packet | V packet] on a side stream + one batched reconstruction of all peers."""
+    from .. import codecs
+    cfg = compact_config()
+    kshape = k.shape
+    N, C = cm._nc_shape(k.shape)
+    warm = ctype == T.WARMUP
+    native = (not warm) and (not cfg.simulate_compress) and cfg.compress_residual == 1
+    if warm or not native:
+        n_half = N * C if (warm or cfg.simulate_compress) else cm._packet_halves(*cm._native(ctype), N, C)
+    else:
+        n_half = cm._packet_halves(*cm._native(ctype), N, C)
+    slot = (n_half + 127) // 128 * 128
+    send, recv, side = _exchange_buffers(("ring", mod_idx), slot, world, k)
+    if native:
+        cm.compact_bind_packet(kkey(rank), send[:n_half])
+        cm.compact_bind_packet(vkey(rank), send[slot:slot + n_half])
+    pk = compact_compress(kkey(rank), k, ctype, update_cache=True)
+    pv = compact_compress(vkey(rank), v, ctype, update_cache=True)
+    if pk.reshape(-1).data_ptr() != send.data_ptr():
+        send[:n_half].copy_(pk.reshape(-1))
+        send[slot:slot + n_half].copy_(pv.reshape(-1))
+    # exchange on the side stream, overlapped with the local attention block
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream(k.device))
+        with torch.cuda.stream(side):
+            with Profiler.scope("compact.all_gather", stream=side):
+                dist.all_gather_into_tensor(recv, send, group=group)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+    out, lse = attend(None, None, k, v, 0)
+    if side is not None:
+        torch.cuda.current_stream(k.device).wait_stream(side)
+    peers = [(rank - s) % world for s in range(1, world)]
+    slot_of = lambda r, kv: recv[(2 * r + kv) * slot:(2 * r + kv) * slot + n_half]   # noqa: E731
+    if native:
+        cid, param = cm._native(ctype)
+        bases, pkts = [], []
+        for r in peers:
+            for kv, keyf in ((0, kkey), (1, vkey)):
+                b = compact_cache().get_base(keyf(r))
+                assert b is not None, f"no cached base for key {keyf(r)}"
+                bases.append(b)
+                pkts.append(slot_of(r, kv))
+        with Profiler.scope("compact.decompress_batch"):
+            for i in range(0, len(bases), codecs.CFX_MAX_BATCH):
+                j = i + codecs.CFX_MAX_BATCH
+                if cid >= 100:
+                    for p_, b_ in zip(pkts[i:j], bases[i:j]):
+                        cm._codec_decompress(cid, param, p_, b_, b_)
+                else:
+                    codecs.decompress_batch(cid, pkts[i:j], bases[i:j], bases[i:j], N, C, param)
+        for r in peers:
+            compact_cache().put(kkey(r), compact_cache().get_base(kkey(r)), None)
+            compact_cache().put(vkey(r), compact_cache().get_base(vkey(r)), None)
+    for step, r in enumerate(peers, start=1):
+        if native:
+            kk = compact_cache().get_base(kkey(r)).view(kshape)
+            vv = compact_cache().get_base(vkey(r)).view(v.shape)
+        else:
+            kk = compact_decompress(kkey(r), slot_of(r, 0), ctype, kshape, update_cache=True).contiguous()
+            vv = compact_decompress(vkey(r), slot_of(r, 1), ctype, v.shape, update_cache=True).contiguous()
+        out, lse = attend(out, lse, kk, vv, step)
+    return out, lse

@@ -1,0 +1,68 @@
+"""Type dispatch + flat fp16 wire format of the non-fused path - mirror of `xfuser/compact/slowpath.py`
+(slowpath_compress :26-84, slowpath_decompress :86-175, sim_compress :185-239).
+
+BINARY `[codes | U(N,1) | V(1,C)]` and SPARSE `[val | idx]` are single native launches; LOW_RANK / LOW_RANK_Q are in
+`lowrank.py`.  INT2 / INT4 / INT8 / IDENTITY are not slowpath wire codecs in the reference (ValueError, :80-81);
+here INT2 / INT4 / INT8 are accepted as an extension because BASELINE.json's configs use them as residual codecs."""
+from __future__ import annotations
+
+import torch
+
+from .. import codecs
+from .compress_topk import SPARSE_LAST_DIM_SIZE  # noqa: F401
+from .utils import COMPACT_COMPRESS_TYPE as T
+
+_MAP = {T.BINARY: codecs.Codec.BINARY, T.INT2: codecs.Codec.INT2, T.INT4: codecs.Codec.INT4, T.INT8: codecs.Codec.INT8,
+        T.SPARSE: codecs.Codec.TOPK}
+
+
+def _resolve(compress_type, rank, sparse_ratio):
+    if compress_type in (T.LOW_RANK, T.LOW_RANK_Q):
+        assert rank is not None and rank >= 1, "Rank must be provided for LOW_RANK compression"
+        return None, rank
+    if compress_type not in _MAP:
+        raise ValueError(f"Invalid compress_type value: {compress_type}")
+    if compress_type == T.BINARY:
+        assert rank is not None and (rank >= 1 or rank == -1), "Rank must be >= 1 or -1 for BINARY compression"
+        if rank != -1:
+            raise NotImplementedError("BINARY with rank >= 1 is deprecated in the reference")
+    if compress_type == T.SPARSE:
+        assert sparse_ratio is not None, "sparse_ratio must be provided for SPARSE compression"
+        return int(_MAP[compress_type]), int(sparse_ratio)
+    return int(_MAP[compress_type]), 0
+
+
+def slowpath_compress(x: torch.Tensor, compress_type: T, rank: int = None, sparse_ratio: int = None):
+    assert x.dtype == torch.half, f"x.dtype: {x.dtype}"
+    assert x.dim() == 2
+    N, C = x.shape
+    cid, param = _resolve(compress_type, rank, sparse_ratio)
+    if cid is None:
+        from . import lowrank
+        return lowrank.slowpath_compress(x.contiguous(), compress_type, param)
+    pkt, _ = codecs.compress(cid, x.contiguous(), None, N, C, param, update_cache=False)
+    return pkt
+
+
+def slowpath_decompress(x: torch.Tensor, shape: tuple, compress_type: T, rank: int = None, sparse_ratio: int = None):
+    assert x.dim() == 1 and x.dtype == torch.half
+    assert len(shape) == 2
+    N, C = shape
+    cid, param = _resolve(compress_type, rank, sparse_ratio)
+    if cid is None:
+        from . import lowrank
+        return lowrank.slowpath_decompress(x, (N, C), compress_type, param)
+    assert x.numel() == codecs.packet_halves(cid, N, C, param), "packet size does not match (N, C) and the codec"
+    return codecs.decompress(cid, x, None, N, C, param)
+
+
+def sim_compress(x: torch.Tensor, compress_type: T, sparse_ratio: int = None, rank: int = None):
+    """decode(encode(x)) at full size - the reference's `simulate=True` primitive."""
+    if compress_type == T.IDENTITY:
+        return x
+    if compress_type == T.INT2_MINMAX:
+        raise NotImplementedError("INT2_MINMAX is not implemented")
+    if compress_type == T.LOW_RANK_AWL:
+        raise NotImplementedError("LOW_RANK_AWL is deprecated in the reference")
+    pkt = slowpath_compress(x.half(), compress_type, rank=rank, sparse_ratio=sparse_ratio)
+    return slowpath_decompress(pkt, tuple(x.shape), compress_type, rank=rank, sparse_ratio=sparse_ratio)

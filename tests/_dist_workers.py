@@ -1,0 +1,167 @@
+"""Worker bodies for the world_size-2 gloo tests (spawned processes; CPU tensors; kernels replaced by the oracle
+stand-in of tests/_oracle_backend.py - test infrastructure only)."""
+import os
+import sys
+import tempfile
+import traceback
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+for p in (REPO, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _setup(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import _oracle_backend as OB
+    OB.install_plain()
+    from compactfusion_amd.collector import collector
+    collector.init(collector.Collector(tempfile.mkdtemp(), enabled=False))
+
+
+def bits(t):
+    return t.detach().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def drift(seed, shape, T):
+    g = torch.Generator().manual_seed(seed)
+    cur = torch.randn(*shape, generator=g).half()
+    out = []
+    for _ in range(T):
+        out.append(cur.contiguous())
+        cur = (cur.float() + 0.1 * torch.randn(*shape, generator=g)).half()
+    return out
+
+
+def run(fn, rank, world, port, out_path, *args):
+    try:
+        _setup(rank, world, port)
+        res = fn(rank, world, *args)
+        dist.barrier()
+        if out_path:
+            np.savez(out_path + f".r{rank}.npz", **(res or {}))
+    except Exception:
+        traceback.print_exc()
+        raise
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def w_all_gather(rank, world, codec_name):
+    """compact_all_gather over `world` ranks; recipe identical to golden group G10 when codec is binary / int2."""
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
+    N, C = 32, 256
+    fast = codec_name in ("BINARY", "INT2")
+    cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: None, residual=1, ef=True, fastpath=fast, comp_rank=-1,
+                                  sparse_ratio=8))
+    res = {}
+    xs = drift(100 + rank, (N, C), 4)
+    for t, x in enumerate(xs):
+        typ = T.WARMUP if t == 0 else T[codec_name]
+        outs = cm.compact_all_gather("3-k", x.view(1, N, C), typ)
+        assert len(outs) == world and all(o.shape == (1, N, C) for o in outs)
+        for i, o in enumerate(outs):
+            res[f"t{t}/out{i}"] = bits(o).reshape(N, C).copy()
+        res[f"t{t}/x"] = bits(x)
+    cm.compact_cache().check_consistency()
+    res["passed_count"] = np.array([cm.compact_cache().passed_count])
+    return res
+
+
+def _full_attention(q, ks, vs, scale=None):
+    from compactfusion_amd.compact.attention import block_attention
+    return block_attention(q, torch.cat(ks, dim=1), torch.cat(vs, dim=1), 0.0, scale, causal=False)
+
+
+def w_ring(rank, world, schedule, codec_name, joint):
+    """Ring forward over 3 steps (WARMUP then codec); returns out/lse and the K/V every rank ended up attending to."""
+    os.environ["CFX_RING_SCHEDULE"] = schedule
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
+    from compactfusion_amd.compact.ring import compact_fwd
+    B, S, H, D = 1, 16, 4, 32
+    fast = codec_name in ("BINARY", "INT2")
+    cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T[codec_name],
+                                  residual=1, ef=True, fastpath=fast, comp_rank=-1, check_consist=True))
+    qs = drift(7 + rank, (B, S, H, D), 3)
+    ks = drift(17 + rank, (B, S, H, D), 3)
+    vs = drift(27 + rank, (B, S, H, D), 3)
+    g = torch.Generator().manual_seed(99)
+    jk = torch.randn(B, 8, H, D, generator=g).half() if joint != "none" else None
+    jv = torch.randn(B, 8, H, D, generator=g).half() if joint != "none" else None
+    res = {}
+    for step in range(3):
+        cm.compact_set_step(step)
+        out, lse, _ = compact_fwd(qs[step], ks[step], vs[step], causal=False, group=None, joint_tensor_key=jk,
+                                  joint_tensor_value=jv, joint_strategy=joint, mod_idx=5, current_iter=step)
+        assert out.shape == (B, S, H, D) and out.dtype == torch.float16 and lse.shape == (B, H, S)
+        res[f"s{step}/out"] = out.float().numpy()
+        res[f"s{step}/lse"] = lse.float().numpy()
+        # what this rank attended to: its own exact K/V + the cached reconstructions of the peers
+        kk, vv = [], []
+        order = [(rank - s) % world for s in range(world)]
+        for r in order:
+            if r == rank:
+                kk.append(ks[step]); vv.append(vs[step])
+            else:
+                kk.append(cm.compact_cache().get_base(f"5-{r}-k").view(B, S, H, D).clone())
+                vv.append(cm.compact_cache().get_base(f"5-{r}-v").view(B, S, H, D).clone())
+        if joint == "front":
+            kk.insert(0, jk); vv.insert(0, jv)
+        elif joint == "rear":
+            kk.append(jk); vv.append(jv)
+        ref_out, ref_lse = _full_attention(qs[step], kk, vv)
+        res[f"s{step}/ref_out"] = ref_out.float().numpy()
+        res[f"s{step}/ref_lse"] = ref_lse.float().numpy()
+        # peers hold exactly the state the owner holds for its own shard (error feedback keeps them in lock step)
+        res[f"s{step}/own_k_state"] = bits(cm.compact_cache().get_base(f"5-{rank}-k")).copy()
+        for r in range(world):
+            res[f"s{step}/state_k_{r}"] = bits(cm.compact_cache().get_base(f"5-{r}-k")).copy()
+        res[f"s{step}/k"] = bits(ks[step])
+    res["passed_count"] = np.array([cm.compact_cache().passed_count])
+    return res
+
+
+def w_patch(rank, world, mode):
+    """patch_gather_fwd in its three modes."""
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig, PatchConfig
+    from compactfusion_amd.compact.ring import compact_fwd
+    B, S, H, D = 1, 16, 4, 32
+    pc = {"sync": PatchConfig(False, False, 0), "async": PatchConfig(False, True, 1), "compact": PatchConfig(True, False, 1)}[mode]
+    cm.compact_init(CompactConfig(enabled=True, override_with_patch_gather_fwd=True, patch_gather_fwd_config=pc,
+                                  compress_func=(lambda l, s: T.WARMUP if s == 0 else T.INT2) if mode == "compact" else None,
+                                  residual=1 if mode == "compact" else 0, ef=mode == "compact", fastpath=mode == "compact", comp_rank=-1))
+    qs = drift(7 + rank, (B, S, H, D), 4)
+    ks = drift(17 + rank, (B, S, H, D), 4)
+    vs = drift(27 + rank, (B, S, H, D), 4)
+    allk = [drift(17 + r, (B, S, H, D), 4) for r in range(world)]
+    allv = [drift(27 + r, (B, S, H, D), 4) for r in range(world)]
+    res = {}
+    for step in range(4):
+        cm.compact_set_step(step)
+        out, lse, _ = compact_fwd(qs[step], ks[step], vs[step], causal=False, group=None, mod_idx=2, current_iter=step)
+        res[f"s{step}/out"] = out.float().numpy()
+        if mode == "sync" or (mode == "async" and step < 1) or (mode == "compact" and step == 0):
+            kk = [allk[r][step] for r in range(world)]
+            vv = [allv[r][step] for r in range(world)]
+        elif mode == "async":
+            # remote shards are one step stale, own shard is fresh (DistriFusion, fwd.py:146-159)
+            kk = [allk[r][step] if r == rank else allk[r][step - 1] for r in range(world)]
+            vv = [allv[r][step] if r == rank else allv[r][step - 1] for r in range(world)]
+        else:
+            kk = [cm.compact_cache().get_base(f"2-k-{r}").view(B, S, H, D).clone() for r in range(world)]
+            vv = [cm.compact_cache().get_base(f"2-v-{r}").view(B, S, H, D).clone() for r in range(world)]
+        ref_out, _ = _full_attention(qs[step], kk, vv)
+        res[f"s{step}/ref_out"] = ref_out.float().numpy()
+    return res

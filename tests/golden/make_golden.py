@@ -283,7 +283,7 @@ def g9(mode, man):
     import xfuser.compact.main as cm
     from xfuser.compact.utils import CompactConfig, COMPACT_COMPRESS_TYPE as T
     st = Store("g9_state_machine", mode)
-    N, C = 64, 256
+    N, C = 32, 256
     cases = {
         # name: (config kwargs, codec type, n_warmup)
         "binary_fast": (dict(residual=1, ef=True, fastpath=True, comp_rank=-1), T.BINARY, 1),
@@ -312,10 +312,10 @@ def g9(mode, man):
             pkt = cm.compact_compress(skey, x3, typ, update_cache=True)
             rec = cm.compact_decompress(rkey, pkt.clone(), typ, x3.shape, update_cache=True)
             st.put(f"{name}/t{t}/packet", np16(pkt.reshape(-1)))
-            st.put(f"{name}/t{t}/recon", np16(rec.reshape(N, C)))
+            st.put(f"{name}/t{t}/recon", np16(rec.reshape(N, C)), kw.get("residual", 0) == 0)   # sha only when a base exists
             if kw.get("residual", 0) != 0:
                 st.put(f"{name}/t{t}/send_base", np16(cm.compact_cache().get_base(skey)))
-                st.put(f"{name}/t{t}/recv_base", np16(cm.compact_cache().get_base(rkey)))
+                st.put(f"{name}/t{t}/recv_base", np16(cm.compact_cache().get_base(rkey)), False)
             if kw.get("residual", 0) == 2:
                 db = cm.compact_cache().get_delta_base(skey)
                 if db is not None:

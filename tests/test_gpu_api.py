@@ -1,0 +1,286 @@
+"""The plugin API (compactfusion_amd.compact.*) on the real HIP kernels - GPU box only (-m gpu).
+
+Part 1 replays the reference's own unit tests (tests/compact/compress_fastpath_test.py, compress_slowpath_test.py)
+against this package: same shapes, seeds, input recipe, comparisons and tolerances.
+Part 2 runs the residual / error-feedback state machine on the GPU against the oracle, bit for bit.
+Part 3 runs the exchange schedules with two processes sharing the GPU (gloo transport, real kernels, side stream)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_np as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _collector(tmp_path):
+    from compactfusion_amd.collector import collector
+    collector.init(collector.Collector(str(tmp_path), enabled=False))
+    yield
+
+
+def bits(t):
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+# ---- helpers of the reference's tests (compress_slowpath_test.py:29-51, compress_fastpath_test.py:16-36) -----------
+def assert_tensor_close(a, b, tol=1e-3, desc=""):
+    assert a.dtype == b.dtype and a.shape == b.shape, desc
+    if a.dtype == torch.uint8:
+        assert torch.equal(a, b), f"{desc}: uint8 tensors differ"
+    else:
+        na = torch.norm(a.float())
+        err = torch.norm(a.float() - b.float())
+        assert (err < tol) if na == 0 else (err / na < tol), f"{desc}: relative error {err / na}"
+
+
+def assert_tensor_approx(a, b, tol=1e-4, desc=""):
+    rel = torch.norm(a.float() - b.float()) / torch.norm(a.float())
+    assert rel < tol, f"{desc}: relative error {rel}"
+
+
+def assert_tensor_close_binary(a, b, desc="", tol=1e-3):
+    assert a.dtype == b.dtype and a.shape == b.shape
+    mism = 1.0 - float((a == b).sum()) / a.numel()
+    assert mism <= tol, f"{desc}: mismatch ratio {mism}"
+
+
+SHAPES = [(4096, 4096), (2048, 1024), (8192, 512)]
+SEEDS = [42, 43, 44]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("update_cache", [True, False])
+def test_binary_fastpath_e2e_vs_sim(shape, seed, update_cache):
+    """compress_fastpath_test.py:45-101 with rank = -1 (ranks 1 and 4 are deprecated in the reference, main.py:188-189)."""
+    from compactfusion_amd.compact.fastpath import (binary_dequant_fastpath, binary_quant_fastpath,
+                                                    sim_binary_dequant_fastpath, sim_binary_quant_fastpath)
+    torch.manual_seed(seed)
+    N, C = shape
+    x = torch.randn((N, C), dtype=torch.half, device="cuda").contiguous()
+    base = (torch.randn_like(x) * 0.1).contiguous()
+    pk, uk, vk, nbk = binary_quant_fastpath(x, base, -1, update_cache)
+    ps, us, vs, nbs = sim_binary_quant_fastpath(x, base, -1, update_cache)
+    assert_tensor_close(pk, ps, desc="Packed")
+    assert pk.shape == (N, C // 8) and uk.shape == (N, 1) and vk.shape == (C, 1)
+    assert_tensor_close(uk, us, desc="Scale U")
+    assert_tensor_close(vk, vs, desc="Scale V")
+    if update_cache:
+        assert_tensor_close(nbk, nbs, desc="New base")
+    else:
+        assert nbk is None and nbs is None
+    assert_tensor_close(binary_dequant_fastpath(pk, uk, vk, base), sim_binary_dequant_fastpath(ps, us, vs, base), desc="Recon")
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("update_cache", [True, False])
+def test_int2_fastpath_e2e_vs_sim(shape, seed, update_cache):
+    """compress_fastpath_test.py:105-162."""
+    from compactfusion_amd.compact.fastpath import (int2_dequant_fastpath, int2_quant_fastpath, sim_int2_dequant_fastpath,
+                                                    sim_int2_quant_fastpath)
+    torch.manual_seed(seed)
+    N, C = shape
+    x = torch.randn((N, C), dtype=torch.half, device="cuda").contiguous()
+    base = (torch.randn_like(x) * 0.1).contiguous()
+    pk, uk, vk, nbk = int2_quant_fastpath(x, base, update_cache, -1)
+    ps, us, vs, nbs = sim_int2_quant_fastpath(x, base, update_cache, -1)
+    assert_tensor_close_binary(pk, ps, desc="Packed", tol=1e-3)
+    assert_tensor_approx(uk, us, tol=0.02, desc="U")
+    assert_tensor_approx(vk, vs, tol=0.02, desc="V")
+    if update_cache:
+        assert_tensor_approx(nbk, nbs, tol=0.02, desc="New base")
+    assert_tensor_approx(int2_dequant_fastpath(pk, uk, vk, base), sim_int2_dequant_fastpath(ps, us, vs, base), tol=0.02)
+
+
+SLOW_SHAPES = [(1024, 2048), (512, 4096), (256, 8192)]
+
+
+@pytest.mark.parametrize("m", [2, 4, 8, 16])
+@pytest.mark.parametrize("A,B", SLOW_SHAPES)
+@pytest.mark.parametrize("seed", [42, 43])
+def test_topk_sparsify(m, A, B, seed):
+    """compress_slowpath_test.py:56-89; the simulator is checked against the oracle's first-max rule (torch.topk's tie
+    break, which the reference's simulator inherits, is unspecified)."""
+    from compactfusion_amd.compact.compress_topk import sim_topk, topk_compress, topk_decompress, topk_sparsify
+    torch.manual_seed(seed)
+    x = torch.randn((A, B), dtype=torch.half, device="cuda")
+    sim = sim_topk(x, m)
+    xv = x.view(-1, 1024).contiguous()
+    val, idx = topk_compress(xv, m)
+    assert val.dtype == torch.half and idx.dtype == torch.uint8
+    dec = topk_decompress(val, idx, m).view(A, B)
+    assert_tensor_close(dec, sim)
+    assert_tensor_close(topk_sparsify(xv, m).view(A, B), sim)
+    assert np.array_equal(bits(dec), R.bits(R.sim_topk(bits(x).view(np.float16), m)))
+
+
+@pytest.mark.parametrize("A,B", SLOW_SHAPES)
+@pytest.mark.parametrize("seed", [42, 43])
+def test_1_bit_quantization(A, B, seed):
+    """compress_slowpath_test.py:91-123 with rank = -1."""
+    from compactfusion_amd.compact.compress_quantize import dequantize_1bit, quantize_1bit, sim_binary
+    torch.manual_seed(seed)
+    x = torch.randn((A, B), dtype=torch.half, device="cuda")
+    sim = sim_binary(x, rank=-1)
+    p, u, v = quantize_1bit(x, rank=-1)
+    assert_tensor_approx(dequantize_1bit(p, u, v), sim)
+    assert np.array_equal(bits(sim), R.bits(R.sim_binary(bits(x).view(np.float16), -1)))
+
+
+@pytest.mark.parametrize("A,B", SLOW_SHAPES)
+@pytest.mark.parametrize("seed", [42, 43])
+def test_int4_and_int2_quantization(A, B, seed):
+    """compress_slowpath_test.py:218-265 (INT4_TOL 0.05, INT2_TOL 0.02) - and bit-exact against the oracle."""
+    from compactfusion_amd.compact.compress_quantize import (dequantize_int2, dequantize_int4, quantize_int2, quantize_int4,
+                                                             sim_int2, sim_int4)
+    torch.manual_seed(seed)
+    x = torch.randn((A, B), dtype=torch.half, device="cuda")
+    q, s, mn = quantize_int4(x)
+    dec = dequantize_int4(q, s, mn)
+    assert_tensor_approx(dec, sim_int4(x, dim=0), tol=0.05, desc="INT4")
+    assert np.array_equal(bits(dec), R.bits(R.sim_int4(bits(x).view(np.float16), 0)))
+    q, ch, tk = quantize_int2(x)
+    dec = dequantize_int2(q, ch, tk)
+    assert_tensor_approx(dec, sim_int2(x), tol=0.02, desc="INT2")
+    assert np.array_equal(bits(dec), R.bits(R.dequantize_int2(*R.quantize_int2(bits(x).view(np.float16)))))
+
+
+# ---- part 2: state machine on the GPU vs the oracle ------------------------------------------------------------------
+def _drift(seed, N, C, T):
+    g = torch.Generator().manual_seed(seed)
+    cur = torch.randn(N, C, generator=g).half()
+    out = []
+    for _ in range(T):
+        out.append(cur.contiguous())
+        cur = (cur.float() + 0.1 * torch.randn(N, C, generator=g)).half()
+    return out
+
+
+CASES = [
+    ("binary_fast", dict(residual=1, ef=True, fastpath=True, comp_rank=-1), "BINARY", 1, dict(codec="binary")),
+    ("int2_fast", dict(residual=1, ef=True, fastpath=True, comp_rank=-1), "INT2", 1, dict(codec="int2")),
+    ("binary_noef", dict(residual=1, ef=False, comp_rank=-1), "BINARY", 1, dict(codec="binary")),
+    ("binary_res0", dict(residual=0, ef=False, comp_rank=-1), "BINARY", 0, dict(codec="binary")),
+    ("binary_res2", dict(residual=2, ef=True, comp_rank=-1, delta_decay_factor=0.5), "BINARY", 2, dict(codec="binary")),
+    ("int8_ef", dict(residual=1, ef=True), "INT8", 1, dict(codec="int8")),
+    ("int4_ef", dict(residual=1, ef=True), "INT4", 1, dict(codec="int4")),
+    ("sparse8", dict(residual=1, ef=True, sparse_ratio=8), "SPARSE", 1, dict(codec="topk", param=8)),
+    ("int4_sim", dict(residual=1, ef=True, simulate=True), "INT4", 1, dict(codec="int4", simulate=True)),
+]
+
+
+@pytest.mark.parametrize("name,kw,tname,nwarm,okw", CASES, ids=[c[0] for c in CASES])
+def test_state_machine_on_gpu_equals_oracle(name, kw, tname, nwarm, okw):
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
+    N, C = 256, 1152
+    xs = _drift(11, N, C, 5)
+    cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: None, log_stats=(name == "binary_fast"), **kw))
+    mk = lambda: R.OracleCompact(residual=kw.get("residual", 0), ef=kw.get("ef", False), fastpath=kw.get("fastpath", False),  # noqa: E731
+                                 simulate=okw.get("simulate", False), param=okw.get("param", 0), decay=kw.get("delta_decay_factor"))
+    orc_s, orc_r = mk(), mk()
+    skey, rkey = "0-0-k", "0-1-k"
+    for t, x in enumerate(xs):
+        cm.compact_set_step(t)
+        xd = x.cuda().view(1, N, 16, C // 16)
+        warm = t < nwarm
+        typ = T.WARMUP if warm else T[tname]
+        oname = "warmup" if warm else okw["codec"]
+        pkt = cm.compact_compress(skey, xd, typ, update_cache=True)
+        want = orc_s.compress(skey, bits(x).reshape(1, N, 16, C // 16), oname, True)
+        assert np.array_equal(bits(pkt).reshape(-1), want), f"{name} step {t}: packet"
+        rec = cm.compact_decompress(rkey, pkt.clone(), typ, xd.shape, update_cache=True)
+        wrec = orc_r.decompress(rkey, want, oname, xd.shape, True)
+        assert np.array_equal(bits(rec).reshape(-1), R.bits(wrec).reshape(-1)), f"{name} step {t}: recon"
+        if kw.get("residual", 0) != 0:
+            assert np.array_equal(bits(cm.compact_cache().get_base(skey)), R.bits(orc_s.base[skey])), f"{name} step {t}: sender state"
+            assert np.array_equal(bits(cm.compact_cache().get_base(rkey)), R.bits(orc_r.base[rkey])), f"{name} step {t}: receiver state"
+    if name == "binary_fast":
+        from compactfusion_amd.compact.stats import stats_log
+        vol = stats_log().summary_compression_volume()
+        assert 15.0 < vol["ratio"] < 16.0           # 1-bit wire ratio (15.5x-15.7x)
+
+
+def test_golden_state_trace_on_gpu():
+    """G9 binary_fast trace of the reference: fed the reference's packets, the GPU receiver reproduces the reference's
+    receiver state (sha256) at every step."""
+    import _golden as G
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
+    FN = "g9_state_machine_eager.npz"
+    N, C = 32, 256
+    for name, typ in (("binary_fast", T.BINARY), ("int2_fast", T.INT2)):
+        cm.compact_init(CompactConfig(enabled=True, residual=1, ef=True, fastpath=True, comp_rank=-1))
+        for t in range(5):
+            gold = torch.from_numpy(G.get(FN, f"{name}/t{t}/packet").view(np.int16)).view(torch.float16).cuda()
+            rec = cm.compact_decompress("0-1-k", gold, T.WARMUP if t == 0 else typ, (1, N, C), update_cache=True)
+            assert G.sha(bits(cm.compact_cache().get_base("0-1-k"))) == G.entry(FN, f"{name}/t{t}/recv_base")["sha256"], (name, t)
+            assert G.sha(bits(rec).reshape(N, C)) == G.entry(FN, f"{name}/t{t}/recon")["sha256"], (name, t)
+
+
+# ---- part 3: schedules with two processes on one GPU ---------------------------------------------------------------------
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gpu_ring_worker(rank, world, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    import tempfile
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from compactfusion_amd.collector import collector
+    collector.init(collector.Collector(tempfile.mkdtemp(), enabled=False))
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
+    from compactfusion_amd.compact.ring import compact_fwd
+    import _dist_workers as W
+    B, S, H, D = 1, 64, 8, 64
+    res = {}
+    for sched in ("relay", "gather"):
+        os.environ["CFX_RING_SCHEDULE"] = sched
+        cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T.BINARY,
+                                      residual=1, ef=True, fastpath=True, comp_rank=-1, check_consist=True))
+        qs, ks, vs = (W.drift(sd + rank, (B, S, H, D), 3) for sd in (7, 17, 27))
+        for step in range(3):
+            cm.compact_set_step(step)
+            out_, lse, _ = compact_fwd(qs[step].cuda(), ks[step].cuda(), vs[step].cuda(), causal=False, group=None,
+                                       mod_idx=1, current_iter=step)
+            torch.cuda.synchronize()
+            res[f"{sched}/s{step}/out"] = out_.float().cpu().numpy()
+            for r in range(world):
+                res[f"{sched}/s{step}/state_k_{r}"] = bits(cm.compact_cache().get_base(f"1-{r}-k")).copy()
+        res[f"{sched}/passed"] = np.array([cm.compact_cache().passed_count])
+    dist.barrier()
+    np.savez(out + f".r{rank}.npz", **res)
+    dist.destroy_process_group()
+
+
+def test_ring_schedules_two_processes_one_gpu(tmp_path):
+    """Relay (reference schedule) and gather (MI355X-native schedule: side-stream all-gather + one batched
+    reconstruction) give identical outputs and identical, rank-consistent state on the real kernels."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ring")
+    mp.start_processes(_gpu_ring_worker, args=(2, _port(), out), nprocs=2, join=True, start_method="spawn")
+    res = [dict(np.load(out + f".r{r}.npz")) for r in range(2)]
+    for r in range(2):
+        assert int(res[r]["relay/passed"][0]) == 3 and int(res[r]["gather/passed"][0]) == 3
+        for s in range(3):
+            np.testing.assert_allclose(res[r][f"relay/s{s}/out"], res[r][f"gather/s{s}/out"], rtol=2e-3, atol=2e-3)
+            for q in range(2):
+                assert np.array_equal(res[r][f"relay/s{s}/state_k_{q}"], res[r][f"gather/s{s}/state_k_{q}"])
+                assert np.array_equal(res[0][f"gather/s{s}/state_k_{q}"], res[1][f"gather/s{s}/state_k_{q}"])

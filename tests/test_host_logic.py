@@ -1,0 +1,252 @@
+"""Host-side logic on CPU: config rules, enum, cache arena, (N,C) view rule, wire sizes, the residual / error-feedback
+state machine and the function-level API mirrors.  The kernels are replaced by the oracle through a TEST-ONLY
+stand-in (tests/_oracle_backend.py); the GPU tests (-m gpu) run the same API on the real kernels."""
+import numpy as np
+import pytest
+import torch
+
+import _oracle_backend as OB
+from oracle import ref_np as R
+
+
+@pytest.fixture(autouse=True)
+def _collector(tmp_path):
+    from compactfusion_amd.collector import collector
+    collector.init(collector.Collector(str(tmp_path), enabled=False))
+    yield
+
+
+@pytest.fixture
+def cpu_kernels(monkeypatch):
+    OB.install(monkeypatch)
+
+
+def bits(t):
+    return t.detach().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def test_enum_matches_reference_values():
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T
+    want = {"WARMUP": "warmup", "SPARSE": "sparse", "BINARY": "binary", "INT2": "int2", "INT2_MINMAX": "int2-minmax",
+            "INT4": "int4", "IDENTITY": "identity", "LOW_RANK": "low-rank", "LOW_RANK_Q": "low-rank-int4",
+            "LOW_RANK_AWL": "low-rank-awl"}                       # utils.py:19-28
+    for k, v in want.items():
+        assert T[k].value == v
+
+
+def test_config_rules():
+    from compactfusion_amd.compact import CompactConfig, PatchConfig
+    CompactConfig(enabled=True, residual=1, ef=True, fastpath=True, comp_rank=-1)
+    for kw in (dict(residual=0, ef=True), dict(residual=2, ef=False), dict(residual=1, ef=False, fastpath=True),
+               dict(residual=1, ef=True, fastpath=True, simulate=True), dict(residual=2, ef=True, fastpath=True),
+               dict(residual=3)):
+        with pytest.raises(AssertionError):
+            CompactConfig(enabled=True, **kw)
+    with pytest.raises(AssertionError):
+        CompactConfig(enabled=False, override_with_patch_gather_fwd=True, patch_gather_fwd_config=PatchConfig(True, False, 1))
+    with pytest.raises(AssertionError):
+        CompactConfig(enabled=True, override_with_patch_gather_fwd=True)
+    with pytest.raises(AssertionError):
+        CompactConfig(enabled=True, patch_gather_fwd_config=PatchConfig(False, False, 0))
+    with pytest.raises(AssertionError):
+        PatchConfig(use_compact=True, async_comm=True, async_warmup=1)
+    c = CompactConfig(enabled=True, compress_func=lambda l, s: __import__("compactfusion_amd").compact.COMPACT_COMPRESS_TYPE.BINARY,
+                      residual=1, ef=True)
+    assert c.get_compress_type() == "BINARY"
+    assert CompactConfig().get_compress_type() == "NO_COMPACT"
+
+
+def test_cache_arena_semantics():
+    from compactfusion_amd.compact import CompactCache
+    c = CompactCache()
+    x = torch.randn(4, 8).half()
+    c.put("0-0-k", x, None)
+    b = c.get_base("0-0-k")
+    assert torch.equal(b, x) and b.data_ptr() != x.data_ptr()        # copied into the arena
+    p0 = b.data_ptr()
+    c.put("0-0-k", torch.ones(4, 8).half(), x * 2)
+    assert c.get_base("0-0-k").data_ptr() == p0                       # stable pointer
+    assert torch.equal(c.get_delta_base("0-0-k"), x * 2)
+    c.put("0-0-k", c.get_base("0-0-k"), None)                         # handing back the arena buffer is a no-op
+    assert c.get_delta_base("0-0-k") is None and c.get_base("missing") is None
+    with pytest.raises(AssertionError):
+        CompactCache(quantize=True)
+
+
+def test_collector_must_be_initialised():
+    from compactfusion_amd.collector import collector
+    from compactfusion_amd.compact import CompactCache
+    collector.instance = None
+    with pytest.raises(ValueError):
+        CompactCache().put("0-0-k", torch.zeros(2, 8).half(), None)
+
+
+def _drift(seed, N, C, T):
+    g = torch.Generator().manual_seed(seed)
+    cur = torch.randn(N, C, generator=g).half()
+    out = []
+    for _ in range(T):
+        out.append(cur.contiguous())
+        cur = (cur.float() + 0.1 * torch.randn(N, C, generator=g)).half()
+    return out
+
+
+CASES = [
+    ("binary_fast", dict(residual=1, ef=True, fastpath=True, comp_rank=-1), "BINARY", 1, dict(codec="binary")),
+    ("int2_fast", dict(residual=1, ef=True, fastpath=True, comp_rank=-1), "INT2", 1, dict(codec="int2")),
+    ("binary_slow_noef", dict(residual=1, ef=False, comp_rank=-1), "BINARY", 1, dict(codec="binary")),
+    ("binary_res0", dict(residual=0, ef=False, comp_rank=-1), "BINARY", 0, dict(codec="binary")),
+    ("binary_res2", dict(residual=2, ef=True, comp_rank=-1, delta_decay_factor=0.5), "BINARY", 2, dict(codec="binary")),
+    ("int8_ef", dict(residual=1, ef=True), "INT8", 1, dict(codec="int8")),
+    ("int4_ef", dict(residual=1, ef=True), "INT4", 1, dict(codec="int4")),
+    ("sparse8", dict(residual=1, ef=True, sparse_ratio=8), "SPARSE", 1, dict(codec="topk", param=8)),
+    ("int4_sim", dict(residual=1, ef=True, simulate=True), "INT4", 1, dict(codec="int4", simulate=True)),
+]
+
+
+@pytest.mark.parametrize("name,kw,tname,nwarm,okw", CASES, ids=[c[0] for c in CASES])
+def test_state_machine_equals_oracle(cpu_kernels, name, kw, tname, nwarm, okw):
+    """compact_compress / compact_decompress (host state machine over the native codec boundary) follow the oracle's
+    restatement of main.py:169-270, :322-388 step by step: same packets, same sender and receiver state."""
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
+    N, C = 64, 1024
+    xs = _drift(11, N, C, 5)
+    cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: None, **kw))
+    orc_s = R.OracleCompact(residual=kw.get("residual", 0), ef=kw.get("ef", False), fastpath=kw.get("fastpath", False),
+                            simulate=okw.get("simulate", False), param=okw.get("param", 0), decay=kw.get("delta_decay_factor"))
+    orc_r = R.OracleCompact(residual=kw.get("residual", 0), ef=kw.get("ef", False), fastpath=kw.get("fastpath", False),
+                            simulate=okw.get("simulate", False), param=okw.get("param", 0), decay=kw.get("delta_decay_factor"))
+    skey, rkey = "0-0-k", "0-1-k"
+    for t, x in enumerate(xs):
+        x4 = x.view(1, N, 8, C // 8)           # >= 4-D input exercises the (N, C) view rule
+        warm = t < nwarm
+        typ = T.WARMUP if warm else T[tname]
+        pkt = cm.compact_compress(skey, x4, typ, update_cache=True)
+        want = orc_s.compress(skey, bits(x4).reshape(1, N, 8, C // 8), "warmup" if warm else okw["codec"], True)
+        assert np.array_equal(bits(pkt).reshape(-1), want), f"{name} step {t}: packet"
+        rec = cm.compact_decompress(rkey, pkt.clone(), typ, x4.shape, update_cache=True)
+        assert rec.shape == x4.shape
+        wrec = orc_r.decompress(rkey, want, "warmup" if warm else okw["codec"], x4.shape, True)
+        assert np.array_equal(bits(rec).reshape(-1), R.bits(wrec).reshape(-1)), f"{name} step {t}: recon"
+        if kw.get("residual", 0) != 0:
+            assert np.array_equal(bits(cm.compact_cache().get_base(skey)), R.bits(orc_s.base[skey])), f"{name} step {t}: sender state"
+            assert np.array_equal(bits(cm.compact_cache().get_base(rkey)), R.bits(orc_r.base[rkey])), f"{name} step {t}: receiver state"
+            if kw.get("ef", False):
+                assert np.array_equal(bits(cm.compact_cache().get_base(skey)), bits(cm.compact_cache().get_base(rkey)))
+        if kw.get("residual", 0) == 2 and t >= 1:
+            assert np.array_equal(bits(cm.compact_cache().get_delta_base(skey)), R.bits(orc_s.dbase[skey]))
+
+
+def test_fastpath_rejects_other_codecs_and_missing_warmup(cpu_kernels):
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
+    cm.compact_init(CompactConfig(enabled=True, residual=1, ef=True, fastpath=True, comp_rank=-1))
+    x = torch.randn(1, 8, 64).half()
+    with pytest.raises(AssertionError):
+        cm.compact_compress("0-0-k", x, T.INT4, update_cache=True)
+    with pytest.raises(AssertionError):
+        cm.compact_compress("0-0-k", x, T.BINARY, update_cache=True)      # no WARMUP yet -> no base
+    cm.compact_init(CompactConfig(enabled=True, residual=1, ef=True, comp_rank=4))
+    cm.compact_compress("0-0-k", x, T.WARMUP, update_cache=True)
+    with pytest.raises((AssertionError, NotImplementedError)):
+        cm.compact_compress("0-0-k", x, T.BINARY, update_cache=True)      # rank != -1 is deprecated in the reference
+    cm.compact_init(CompactConfig(enabled=True, residual=1, ef=True))
+    cm.compact_compress("0-0-k", x, T.WARMUP, update_cache=True)
+    with pytest.raises(ValueError):
+        cm.compact_compress("0-0-k", x, T.IDENTITY, update_cache=True)    # not a wire codec (slowpath.py:80-81)
+    cm.compact_init(CompactConfig(enabled=False))
+    with pytest.raises(AssertionError):
+        cm.compact_compress("0-0-k", x, T.BINARY)
+
+
+def test_reset_and_step(cpu_kernels):
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
+    cm.compact_init(CompactConfig(enabled=True, residual=1, ef=True, fastpath=True, comp_rank=-1))
+    cm.compact_set_step(3)
+    assert cm.compact_get_step() == 3
+    cm.compact_compress("5-0-v", torch.randn(2, 8, 64).half(), T.WARMUP, update_cache=True)
+    assert cm.compact_cache().get_base("5-0-v") is not None and cm.compact_get_current_cache_key() == "5-0-v"
+    cm.compact_reset()
+    assert cm.compact_cache().get_base("5-0-v") is None and cm.compact_get_step() is None
+
+
+def test_function_level_mirrors(cpu_kernels):
+    """fastpath / compress_quantize / compress_topk / slowpath signatures and return layouts (views into the packet)."""
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T
+    from compactfusion_amd.compact import compress_quantize as Q, compress_topk as TK, fastpath as F, slowpath as S
+    torch.manual_seed(42)
+    N, C = 64, 256
+    x = torch.randn(N, C).half()
+    base = torch.randn_like(x) * 0.1
+    p, u, v, nb = F.binary_quant_fastpath(x, base, -1, True)
+    assert p.shape == (N, C // 8) and p.dtype == torch.uint8 and u.shape == (N, 1) and v.shape == (C, 1) and nb.shape == (N, C)
+    op, ou, ov, onb = R.binary_quant_fastpath(bits(x), bits(base), -1, True)
+    assert np.array_equal(p.numpy(), op) and np.array_equal(bits(u), R.bits(ou)) and np.array_equal(bits(v), R.bits(ov))
+    assert np.array_equal(bits(nb), R.bits(onb))
+    assert F.binary_quant_fastpath(x, base, -1, False)[3] is None
+    rec = F.binary_dequant_fastpath(p, u, v, base)
+    assert np.array_equal(bits(rec), R.bits(onb))
+    sp, su, sv, snb = F.sim_binary_quant_fastpath(x, base, -1, True)
+    assert torch.equal(sp, p) and torch.equal(su, u) and torch.equal(sv, v) and torch.equal(snb, nb)
+    assert torch.equal(F.sim_binary_dequant_fastpath(p, u, v, base), rec)
+    p2, u2, v2, nb2 = F.int2_quant_fastpath(x, base, True, -1)
+    assert p2.shape == (N, C // 4) and torch.equal(F.int2_dequant_fastpath(p2, u2, v2, base), nb2)
+    s2 = F.sim_int2_quant_fastpath(x, base, True)
+    assert torch.equal(s2[0], p2) and torch.equal(s2[3], nb2)
+    d = x - base
+    q, s, z = Q.quantize_int8(d)
+    assert q.dtype == torch.int8 and s.shape == (1, C) and z.dtype == torch.int16
+    oq, os_, oz = R.quantize_int8(bits(d))
+    assert np.array_equal(q.numpy(), oq) and np.array_equal(z.numpy(), oz)
+    assert np.array_equal(bits(Q.dequantize_int8(q, s, z)), R.bits(R.dequantize_int8(oq, os_, oz)))
+    q4, s4, m4 = Q.quantize_int4(d)
+    assert q4.shape == (N // 2, C) and np.array_equal(bits(Q.dequantize_int4(q4, s4, m4)), R.bits(R.sim_int4(bits(d))))
+    assert np.array_equal(bits(Q.sim_int4(d, 0)), R.bits(R.sim_int4(bits(d))))
+    pk, ch, tk = Q.quantize_int2(d)
+    assert pk.shape == (N, C // 4) and ch.shape == (1, C) and tk.shape == (N, 1)
+    assert np.array_equal(bits(Q.sim_int2(d)), R.bits(R.dequantize_int2(*R.quantize_int2(bits(d)))))
+    assert np.array_equal(bits(Q.sim_binary(d, -1)), R.bits(R.sim_binary(bits(d))))
+    val, idx = TK.topk_compress(d.view(-1, 1024), 4)
+    assert val.shape == (16, 256) and idx.shape == (16, 128) and idx.dtype == torch.uint8
+    assert np.array_equal(bits(TK.topk_decompress(val, idx, 4).view(N, C)), R.bits(R.sim_topk(bits(d), 4)))
+    assert np.array_equal(bits(TK.sim_topk(d, 4)), R.bits(R.sim_topk(bits(d), 4)))
+    pkt = S.slowpath_compress(d, T.BINARY, rank=-1)
+    assert pkt.numel() == N * C // 16 + N + C
+    assert np.array_equal(bits(S.slowpath_decompress(pkt, (N, C), T.BINARY, rank=-1)), R.bits(R.sim_binary(bits(d))))
+    assert np.array_equal(bits(S.sim_compress(d, T.SPARSE, sparse_ratio=8)), R.bits(R.sim_topk(bits(d), 8)))
+    assert S.sim_compress(d, T.IDENTITY) is d
+    with pytest.raises(ValueError):
+        S.slowpath_compress(d, T.IDENTITY)
+
+
+def test_profiler_scopes_cpu():
+    import time
+    from compactfusion_amd.prof import Profiler, prof_summary
+    p = Profiler()
+    Profiler._singleton = p
+    with Profiler.scope("total", cpu=True):
+        with Profiler.scope("inner", cpu=True):
+            time.sleep(0.01)
+        with Profiler.scope("gpu-only"):       # skipped silently without a GPU
+            pass
+
+    @Profiler.prof_func("fn", cpu=True)
+    def f():
+        return 7
+    assert f() == 7 and f() == 7
+    tot, avg = p.elapsed_time("inner")
+    assert tot >= 9.0 and avg >= 9.0
+    assert p.elapsed_time("fn")[0] >= 0 and "gpu-only" not in p.events
+    p.disable()
+    with Profiler.scope("off", cpu=True):
+        pass
+    assert "off" not in p.events
+    p.enable()
+    lines = prof_summary(p, rank=0)
+    assert any("[inner]" in l for l in lines)
+    with pytest.raises(ValueError):
+        p.elapsed_time("nope")
+    p.reset()
+    assert not p.events
