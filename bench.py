@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--copy-probe", type=int, default=0,
+                    help="also launch the 96 MiB float4 copy probe this many times before the timed region "
+                         "(known byte count: calibrates FETCH_SIZE / WRITE_SIZE in PMC profiles)")
     ap.add_argument("--event-stride", type=int, default=8,
                     help="bracket every k-th launch of the dominant kernel with hipEvents (an event pair costs a few us of stream time)")
     return ap.parse_args()
@@ -193,6 +196,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    if args.copy_probe:
+        nb = 96 * 1024 * 1024
+        src = [torch.empty(nb, dtype=torch.uint8, device=dev).random_(0, 255) for _ in range(4)]
+        dst = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(4)]
+        for i in range(args.copy_probe):
+            check(lib.cfx_copy_probe(ctx, dst[i % 4].data_ptr(), src[i % 4].data_ptr(), nb, sh), "copy_probe")
+        torch.cuda.synchronize(dev)
+        del src, dst
+
     # ---- warmup -----------------------------------------------------------------------------------------------
     for i in range(args.warmup):
         one_step(i)
@@ -288,12 +300,13 @@ def main():
         ach = alg / (kern_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_binary_dequant (16 tensors x (544,3072) per launch: own K,V error-feedback update + 7 peers' K,V)",
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                           "traffic": None, "avg_launch_us": round(kern_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(alg),
+                           "traffic": None, "traffic_source": None, "avg_launch_us": round(kern_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(alg),
                            "event_samples": n_samples, "event_stride": args.event_stride}
         prof = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
             try:
                 out["roofline"]["traffic"] = json.load(open(prof)).get("k_binary_dequant_bytes_per_launch")
+                out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, round 1)"
             except Exception:
                 pass
     else:

@@ -23,6 +23,7 @@
 //
 // Reference citations are relative to /root/reference/xfuser/compact/.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -473,15 +474,29 @@ __device__ __forceinline__ bool hisnan(h16 a) { return a != a; }
 
 // finalize int4 : scale = fp16(fp16(max-min)/15.000001f), min                     compress_quantize.py:556-558
 //          int8 : scale = fp16(fp16(max-min)/255.0f), zp = clamp(-128 - round(min/scale)) -> int16   :455-463
-__global__ __launch_bounds__(256) void k_minmax_finalize(BatchC batch, int N, int C, int P, int codec, const u64* ws, size_t ws_stride) {
+__global__ __launch_bounds__(1024) void k_minmax_finalize(BatchC batch, int N, int C, int P, int codec, const u64* ws, size_t ws_stride) {
     const cfx_comp_item it = batch.it[blockIdx.y];
     const unsigned* part = (const unsigned*)(ws + (size_t)blockIdx.y * ws_stride);
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    // 256 channels per block; 4 threads per channel split the P partials so their loads are in flight together
+    __shared__ unsigned red[4][256];
+    const int cl = threadIdx.x & 255, q = threadIdx.x >> 8;
+    const int c = blockIdx.x * 256 + cl;
     h16 mn = hfrom(0x7c00), mx = hfrom(0xfc00);
-    for (int p = 0; p < P; ++p) {
-        const unsigned v = part[(size_t)p * C + c];
-        const h16 a = hfrom((u16)(v & 0xffff)), b = hfrom((u16)(v >> 16));
+    if (c < C) {
+#pragma unroll 4
+        for (int p = q; p < P; p += 4) {
+            const unsigned v = part[(size_t)p * C + c];
+            const h16 a = hfrom((u16)(v & 0xffff)), b = hfrom((u16)(v >> 16));
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+    }
+    red[q][cl] = (unsigned)hbits(mn) | ((unsigned)hbits(mx) << 16);
+    __syncthreads();
+    if (q != 0 || c >= C) return;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        const h16 a = hfrom((u16)(red[k][cl] & 0xffff)), b = hfrom((u16)(red[k][cl] >> 16));
         mn = a < mn ? a : mn;
         mx = b > mx ? b : mx;
     }
@@ -850,19 +865,21 @@ struct cfx_ctx {
     char err[256];
 };
 
-// RAII-free helpers: begin returns the record index or -1
-static inline int prof_begin(cfx_ctx* ctx, int kid, hipStream_t s) {
+// Returns the record slot for this launch or -1.  A profiled launch goes through hipExtLaunchKernelGGL, which ties the
+// two events to the dispatch packet itself: their elapsed time is the kernel's execution time (as rocprofv3 reports it),
+// not the kernel plus the command processor's event handling that a hipEventRecord bracket would add (~6 us here).
+static inline int prof_slot(cfx_ctx* ctx, int kid) {
     if (!ctx->prof_mask || !(ctx->prof_mask & (1u << kid)) || ctx->prof_n >= ctx->prof_cap) return -1;
     if ((ctx->prof_seen++ % ctx->prof_stride) != 0) return -1;
     const int i = ctx->prof_n++;
     ctx->prof[i].kid = kid;
-    (void)hipEventRecord(ctx->prof[i].a, s);
     return i;
 }
-static inline void prof_end(cfx_ctx* ctx, int i, hipStream_t s) {
-    if (i >= 0) (void)hipEventRecord(ctx->prof[i].b, s);
-}
-#define LAUNCH(ctx, kid, s, ...) do { const int _pi = prof_begin(ctx, kid, s); hipLaunchKernelGGL(__VA_ARGS__); prof_end(ctx, _pi, s); } while (0)
+#define LAUNCH(ctx, kid, s, kern, grid, block, shm, strm, ...) do { \
+        const int _pi = prof_slot(ctx, kid); \
+        if (_pi >= 0) hipExtLaunchKernelGGL(kern, grid, block, shm, strm, (ctx)->prof[_pi].a, (ctx)->prof[_pi].b, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, block, shm, strm, __VA_ARGS__); \
+    } while (0)
 
 static int fail(cfx_ctx* ctx, int code, const char* msg) {
     if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
@@ -1103,7 +1120,7 @@ int cfx_compress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int fla
         }
     } else {
         LAUNCH(ctx, KID_MINMAX_STATS, s, k_minmax_stats, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
-        LAUNCH(ctx, KID_MINMAX_FINALIZE, s, k_minmax_finalize, dim3((C + 255) / 256, batch), dim3(256), 0, s, b, N, C, P, codec, (const u64*)ws, wstride);
+        LAUNCH(ctx, KID_MINMAX_FINALIZE, s, k_minmax_finalize, dim3((C + 255) / 256, batch), dim3(1024), 0, s, b, N, C, P, codec, (const u64*)ws, wstride);
         if (codec == CFX_CODEC_INT4) LAUNCH(ctx, KID_INT4_QUANT, s, k_int4_quant, grid, dim3(NTHR), 0, s, b, N, C, R, flags);
         else LAUNCH(ctx, KID_INT8_QUANT, s, k_int8_quant, grid, dim3(NTHR), 0, s, b, N, C, R, flags);
     }

@@ -204,7 +204,7 @@ def test_state_machine_on_gpu_equals_oracle(name, kw, tname, nwarm, okw):
     if name == "binary_fast":
         from compactfusion_amd.compact.stats import stats_log
         vol = stats_log().summary_compression_volume()
-        assert 15.0 < vol["ratio"] < 16.0           # 1-bit wire ratio (15.5x-15.7x)
+        assert 14.5 < vol["ratio"] < 16.0           # 1-bit wire ratio: 14.9x at (256,1152), 15.5x at FLUX shape
 
 
 def test_golden_state_trace_on_gpu():

@@ -250,3 +250,36 @@ def test_profiler_scopes_cpu():
         p.elapsed_time("nope")
     p.reset()
     assert not p.events
+
+
+def test_alias_injection_recipe_from_integration_md(cpu_kernels):
+    """registering this package under the reference's module names lets unchanged call sites bind."""
+    import importlib
+    import sys
+    saved = {k: v for k, v in sys.modules.items() if k == "xfuser" or k.startswith("xfuser.")}
+    try:
+        import types
+        import compactfusion_amd.compact as _c
+        sys.modules["xfuser"] = types.ModuleType("xfuser")
+        sys.modules["xfuser.compact"] = _c
+        for name in ("main", "utils", "ring", "fastpath", "slowpath", "compress_quantize", "compress_topk", "stats"):
+            sys.modules[f"xfuser.compact.{name}"] = importlib.import_module(f"compactfusion_amd.compact.{name}")
+        sys.modules["xfuser.compact.patchpara.df_utils"] = importlib.import_module("compactfusion_amd.compact.patchpara.df_utils")
+        sys.modules["xfuser.prof"] = importlib.import_module("compactfusion_amd.prof")
+        from xfuser.compact.main import compact_compress, compact_config, compact_init  # noqa: F401  (reference import lines)
+        from xfuser.compact.ring import compact_fwd  # noqa: F401
+        from xfuser.compact.utils import COMPACT_COMPRESS_TYPE, CompactConfig
+        from xfuser.compact.patchpara.df_utils import PatchConfig  # noqa: F401
+        from xfuser.prof import Profiler  # noqa: F401
+        compact_init(CompactConfig(enabled=True, residual=1, ef=True, fastpath=True, comp_rank=-1,
+                                   compress_func=lambda l, s: COMPACT_COMPRESS_TYPE.BINARY))
+        assert compact_config().enabled and compact_config().get_compress_type() == "BINARY"
+        import inspect
+        sig = list(inspect.signature(compact_fwd).parameters)
+        assert sig == ["q", "k", "v", "dropout_p", "softmax_scale", "causal", "window_size", "alibi_slopes", "return_attn_probs",
+                       "deterministic", "attn_layer", "group", "joint_tensor_key", "joint_tensor_value", "joint_strategy",
+                       "mod_idx", "current_iter"]                      # ring.py:36-54
+    finally:
+        for k in [k for k in sys.modules if k == "xfuser" or k.startswith("xfuser.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
