@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="debug: 'gloo' lets several ranks share one GPU to exercise the N>1 path")
+    ap.add_argument("--same-gpu", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--copy-probe", type=int, default=0,
                     help="also launch the 96 MiB float4 copy probe this many times before the timed region "
                          "(known byte count: calibrates FETCH_SIZE / WRITE_SIZE in PMC profiles)")
@@ -98,11 +100,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     live = world                       # live ranks in the logical ring of 8
     assert live <= W_LOGICAL
@@ -117,13 +124,21 @@ def main():
     CODEC = int(K.Codec.BINARY)
     pkt_bytes = K.packet_bytes(CODEC, N, C)
     slot = (pkt_bytes + 255) // 256 * 256          # per-tensor slot in the exchange buffer, 256-B aligned
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-
     # ---- resident state and inputs --------------------------------------------------------------------------
-    x0 = torch.randn(L, 2, N, C, generator=g, device=dev, dtype=torch.float32).half()
+    def warm_state(src_rank):
+        """x_0 of rank `src_rank` (what a WARMUP step leaves in every rank's cache for that rank's shard)."""
+        gg = torch.Generator(device=dev).manual_seed(1234 + src_rank)
+        return gg, torch.randn(L, 2, N, C, generator=gg, device=dev, dtype=torch.float32).half()
+
+    g, x0 = warm_state(rank)
     xs = [(x0.float() + 0.1 * torch.randn(L, 2, N, C, generator=g, device=dev)).half() for _ in range(2)]
     own_base = x0.clone()                                                   # [L,2,N,C] sender EF state (after WARMUP)
-    peer_base = x0.unsqueeze(1).repeat(1, W_LOGICAL - 1, 1, 1, 1).contiguous()   # [L,7,2,N,C] receiver states
+    peer_base = torch.empty(L, W_LOGICAL - 1, 2, N, C, dtype=torch.float16, device=dev)   # receiver states
+    for p in range(W_LOGICAL - 1):
+        if live > 1 and p < live - 1:
+            peer_base[:, p] = warm_state((rank + 1 + p) % live)[1]          # a real peer: its own x_0
+        else:
+            peer_base[:, p] = x0                                            # looped-back logical peer
     del x0
     send = torch.zeros(L, 2, slot, dtype=torch.uint8, device=dev)           # own packets (K,V) per layer
     recv = torch.zeros(L, live, 2, slot, dtype=torch.uint8, device=dev) if live > 1 else None
@@ -238,10 +253,19 @@ def main():
             kern_ms = sum(vals) / len(vals)
         lib.cfx_profile_enable(ctx, 0, 0, 1)
 
-    # ---- state sanity: sender state == what a receiver holds for the loop-back peers (bit-exact EF consistency) --
+    # ---- state sanity (bit-exact error-feedback consistency) ---------------------------------------------------------
     torch.cuda.synchronize(dev)
     if live == 1:
         assert torch.equal(own_base[0, 0].view(torch.int16), peer_base[0, 0, 0].view(torch.int16)), "EF state diverged"
+    else:
+        # what rank r holds for its own K of the last layer must be what every peer reconstructed for rank r
+        mine = own_base[L - 1, 0].reshape(-1)[:8192].view(torch.int32).contiguous()       # int32: a dtype every backend moves
+        allm = torch.empty(live * 4096, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(allm, mine)
+        for p in range(live - 1):
+            src = (rank + 1 + p) % live
+            got = peer_base[L - 1, p, 0].reshape(-1)[:8192].view(torch.int32)
+            assert torch.equal(got, allm[src * 4096:(src + 1) * 4096]), f"rank {rank}: state of peer {src} diverged"
 
     # ---- uncompressed RCCL all-gather of the same K/V shards (the north-star comparison), N > 1 only ---------------
     raw_ms = None
