@@ -76,7 +76,13 @@ def sim_int2(input_tensor: torch.Tensor):
 
 
 def sim_int2_minmax(input_tensor: torch.Tensor):
-    raise NotImplementedError("INT2_MINMAX exists only as a simulator in the reference and is not implemented here")
+    """4-level per-channel min/max quantise-dequantise (compress_quantize.py:386-426).  Simulation-only in the reference
+    (quality studies), so this is plain tensor arithmetic on whatever device the input lives on, not a kernel."""
+    x = _nc(input_tensor)
+    lo = x.amin(dim=0, keepdim=True)
+    step = ((x.amax(dim=0, keepdim=True) - lo) / (3 + 1e-6)).to(x.dtype)
+    level = torch.clamp(torch.round((x - lo) / step), 0, 3).to(x.dtype)
+    return level * step + lo
 
 
 # ---- int8 --------------------------------------------------------------------------------------------------------

@@ -200,6 +200,9 @@ def _sim(x_nc: torch.Tensor, compress_type: T, key) -> torch.Tensor:
     """simulate=True: the 'compressed' tensor is decode(encode(x)) at full size (slowpath.py:185-239)."""
     if compress_type == T.IDENTITY:
         return x_nc
+    if compress_type == T.INT2_MINMAX:
+        from .compress_quantize import sim_int2_minmax
+        return sim_int2_minmax(x_nc)
     cid, param = _native(compress_type)
     N, C = x_nc.shape
     pkt = _buf(key, "simpkt", _packet_halves(cid, param, N, C), x_nc)

@@ -61,7 +61,8 @@ def sim_compress(x: torch.Tensor, compress_type: T, sparse_ratio: int = None, ra
     if compress_type == T.IDENTITY:
         return x
     if compress_type == T.INT2_MINMAX:
-        raise NotImplementedError("INT2_MINMAX is not implemented")
+        from .compress_quantize import sim_int2_minmax
+        return sim_int2_minmax(x)
     if compress_type == T.LOW_RANK_AWL:
         raise NotImplementedError("LOW_RANK_AWL is deprecated in the reference")
     pkt = slowpath_compress(x.half(), compress_type, rank=rank, sparse_ratio=sparse_ratio)

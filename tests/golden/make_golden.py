@@ -243,9 +243,10 @@ def g8(mode, man):
         seed = 42
         x, base = gen_inputs(seed, N, C)
         delta = (x - base).contiguous()
+        full = full_policy((N, C), seed)
         tag = f"{N}x{C}_s{seed}"
-        st.put(f"{tag}/x", np16(x))
-        st.put(f"{tag}/base", np16(base))
+        st.put(f"{tag}/x", np16(x), full)
+        st.put(f"{tag}/base", np16(base), full)
         for r in (8, 32):
             g = torch.Generator().manual_seed(1000 + r)
             q0 = torch.randn(C, r, generator=g, dtype=torch.float)
@@ -254,14 +255,20 @@ def g8(mode, man):
             st.put(f"{tag}/r{r}/q0", q0.numpy())
             st.put(f"{tag}/r{r}/U", np16(U))
             st.put(f"{tag}/r{r}/V", np16(V))
-            st.put(f"{tag}/r{r}/UV", np16(torch.matmul(U, V)))
+            st.put(f"{tag}/r{r}/UV", np16(torch.matmul(U, V)), full)
+            # LOW_RANK_Q wire produced from these factors (deterministic given U, V): slowpath.py:63-75
+            from xfuser.compact.compress_quantize import quantize_int4
+            qu, su, mu = quantize_int4(U.half())
+            qv, sv, mv = quantize_int4(V.half().t())
+            st.put(f"{tag}/r{r}/qU", np16(qu)); st.put(f"{tag}/r{r}/sU", np16(su)); st.put(f"{tag}/r{r}/mU", np16(mu))
+            st.put(f"{tag}/r{r}/qV", np16(qv)); st.put(f"{tag}/r{r}/sV", np16(sv)); st.put(f"{tag}/r{r}/mV", np16(mv))
         for ctype, name, r in ((T.LOW_RANK, "lr8", 8), (T.LOW_RANK_Q, "lrq32", 32)):
             with torch.random.fork_rng():
                 torch.manual_seed(seed)
                 pkt = slowpath_compress(delta, ctype, rank=r)
             dec = slowpath_decompress(pkt, (N, C), ctype, rank=r)
             st.put(f"{tag}/{name}/packet", np16(pkt))
-            st.put(f"{tag}/{name}/dec", np16(dec))
+            st.put(f"{tag}/{name}/dec", np16(dec), full)
         print("G8", tag, flush=True)
     st.save(man)
 

@@ -217,6 +217,7 @@ def test_function_level_mirrors(cpu_kernels):
     assert np.array_equal(bits(S.slowpath_decompress(pkt, (N, C), T.BINARY, rank=-1)), R.bits(R.sim_binary(bits(d))))
     assert np.array_equal(bits(S.sim_compress(d, T.SPARSE, sparse_ratio=8)), R.bits(R.sim_topk(bits(d), 8)))
     assert S.sim_compress(d, T.IDENTITY) is d
+    assert np.array_equal(bits(S.sim_compress(d, T.INT2_MINMAX)), R.bits(R.sim_int2_minmax(bits(d))))
     with pytest.raises(ValueError):
         S.slowpath_compress(d, T.IDENTITY)
 
