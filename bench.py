@@ -53,6 +53,12 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="debug: 'gloo' lets several ranks share one GPU to exercise the N>1 path")
     ap.add_argument("--same-gpu", action="store_true", help="debug: every rank uses cuda:0")
+    ap.add_argument("--dist-path", action="store_true",
+                    help="debug: take the N>1 code path (per-layer collectives) even with one rank, to measure its host overhead")
+    ap.add_argument("--exchange", choices=["auto", "native", "torch"], default="auto",
+                    help="N>1: who issues the per-layer all-gather - libcfx's own RCCL communicator from the native plan "
+                         "(one host call per step) or torch.distributed (one Python call per layer); auto = native, "
+                         "falling back to torch if the communicator cannot be created")
     ap.add_argument("--copy-probe", type=int, default=0,
                     help="also launch the 96 MiB float4 copy probe this many times before the timed region "
                          "(known byte count: calibrates FETCH_SIZE / WRITE_SIZE in PMC profiles)")
@@ -104,8 +110,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.dist_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -132,16 +139,23 @@ def main():
 
     g, x0 = warm_state(rank)
     xs = [(x0.float() + 0.1 * torch.randn(L, 2, N, C, generator=g, device=dev)).half() for _ in range(2)]
-    own_base = x0.clone()                                                   # [L,2,N,C] sender EF state (after WARMUP)
+    own_base = torch.empty_like(x0)                                          # [L,2,N,C] sender EF state
     peer_base = torch.empty(L, W_LOGICAL - 1, 2, N, C, dtype=torch.float16, device=dev)   # receiver states
-    for p in range(W_LOGICAL - 1):
-        if live > 1 and p < live - 1:
-            peer_base[:, p] = warm_state((rank + 1 + p) % live)[1]          # a real peer: its own x_0
-        else:
-            peer_base[:, p] = x0                                            # looped-back logical peer
     del x0
+
+    def reset_state():
+        """State as a WARMUP step leaves it: every rank holds x_0 of every shard it tracks."""
+        x0_ = warm_state(rank)[1]
+        own_base.copy_(x0_)
+        for p in range(W_LOGICAL - 1):
+            if live > 1 and p < live - 1:
+                peer_base[:, p] = warm_state((rank + 1 + p) % live)[1]      # a real peer: its own x_0
+            else:
+                peer_base[:, p] = x0_                                       # looped-back logical peer
+    reset_state()
     send = torch.zeros(L, 2, slot, dtype=torch.uint8, device=dev)           # own packets (K,V) per layer
-    recv = torch.zeros(L, live, 2, slot, dtype=torch.uint8, device=dev) if live > 1 else None
+    use_dist = live > 1 or args.dist_path
+    recv = torch.zeros(L, live, 2, slot, dtype=torch.uint8, device=dev) if use_dist else None
     ws_bytes = lib.cfx_workspace_bytes(CODEC, N, C, 0, 2)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
 
@@ -175,8 +189,55 @@ def main():
         plans.append(plan)
 
     compute = torch.cuda.current_stream(dev)
-    comm = torch.cuda.Stream(dev) if live > 1 else None
     sh = compute.cuda_stream
+
+    # ---- N > 1: the whole step as ONE native plan, the per-layer all-gather issued by libcfx's own RCCL communicator.
+    #      Default order: compress(l) -> all-gather(l) -> reconstruct(l) in order on one stream (a cross-stream event hop
+    #      costs ~10 us on this stack - more than the wire time of a 0.4 MB packet - so no side stream here) ----
+    native_comm, step_plans, exchange_mode = None, None, "none"
+    if use_dist:
+        exchange_mode = "torch"
+        if args.exchange in ("auto", "native"):
+            try:
+                from compactfusion_amd.exchange import NativeComm
+                native_comm = NativeComm(local_rank)
+                native_comm.self_test()
+                step_plans = []
+                for s in range(2):
+                    sp = lib.cfx_plan_create(ctx)
+                    src = plans[s]
+
+                    def copy_op(i):
+                        rcx = lib.cfx_plan_copy_op(sp, src, i)
+                        assert rcx >= 0, rcx
+                    gidx = [None] * L
+
+                    def add_gather(l):
+                        gidx[l] = lib.cfx_plan_add_all_gather(sp, native_comm.handle, send[l].data_ptr(), recv[l].data_ptr(), 2 * slot)
+                        assert gidx[l] >= 0, gidx[l]
+                    if os.environ.get("CFX_EXCHANGE_STREAM", "main") == "main":
+                        # in-order on one stream: compress(l) -> all-gather(l) -> reconstruct(l)
+                        for l in range(L):
+                            copy_op(2 * l)
+                            add_gather(l)
+                            copy_op(2 * l + 1)
+                    else:
+                        # side stream: gather(l+1) overlaps reconstruct(l)
+                        copy_op(0)
+                        add_gather(0)
+                        for l in range(L):
+                            if l + 1 < L:
+                                copy_op(2 * (l + 1))
+                                add_gather(l + 1)
+                            assert lib.cfx_plan_add_wait(sp, gidx[l]) >= 0
+                            copy_op(2 * l + 1)
+                    step_plans.append(sp)
+                exchange_mode = "native"
+            except Exception as e:  # pragma: no cover
+                if args.exchange == "native":
+                    raise
+                print(f"[bench] native exchange unavailable ({e}); using torch.distributed per layer", file=sys.stderr)
+                native_comm, step_plans = None, None
 
     def check(rc, what):
         if rc != 0:
@@ -184,30 +245,28 @@ def main():
 
     def one_step(step):
         plan = plans[step & 1]
-        if live == 1:
+        if not use_dist:
             check(lib.cfx_plan_run(plan, 0, 2 * L, sh), "plan_run")     # the whole step from native code
             return
-        # software pipeline: gather(l) on the side stream overlaps compress(l+1) and reconstruct(l-1)
+        if step_plans is not None:
+            sp = step_plans[step & 1]
+            check(lib.cfx_plan_run(sp, 0, lib.cfx_plan_size(sp), sh), "plan_run(exchange)")
+            return
+        # software pipeline: gather(l) runs on RCCL's own stream (async_op: it is ordered after the compute stream's
+        # tail at the call and joined back by work.wait()) and overlaps compress(l+1) and reconstruct(l-1)
         works = [None] * L
-
-        def launch_gather(l):
-            ev = torch.cuda.Event()
-            ev.record(compute)
-            with torch.cuda.stream(comm):
-                comm.wait_event(ev)
-                works[l] = dist.all_gather_into_tensor(recv[l].view(-1), send[l].view(-1), async_op=True)
         check(lib.cfx_plan_run(plan, 0, 1, sh), "compress")
-        launch_gather(0)
+        works[0] = dist.all_gather_into_tensor(recv[0].view(-1), send[0].view(-1), async_op=True)
         for l in range(L):
             if l + 1 < L:
                 check(lib.cfx_plan_run(plan, 2 * (l + 1), 1, sh), "compress")
-                launch_gather(l + 1)
+                works[l + 1] = dist.all_gather_into_tensor(recv[l + 1].view(-1), send[l + 1].view(-1), async_op=True)
             works[l].wait()          # compute stream waits for gather(l)
             check(lib.cfx_plan_run(plan, 2 * l + 1, 1, sh), "reconstruct")
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if live > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -220,10 +279,39 @@ def main():
         torch.cuda.synchronize(dev)
         del src, dst
 
-    # ---- warmup -----------------------------------------------------------------------------------------------
-    for i in range(args.warmup):
+    def states_consistent():
+        """What a rank holds for its own shard must be, bit for bit, what every peer reconstructed for that shard."""
+        torch.cuda.synchronize(dev)
+        if live == 1:
+            same = torch.equal(own_base[0, 0].view(torch.int16), peer_base[0, 0, 0].view(torch.int16))
+            return same, "EF state of the looped-back peer diverged from the sender's"
+        mine = own_base[L - 1, 0].reshape(-1)[:8192].view(torch.int32).contiguous()       # int32: a dtype every backend moves
+        allm = torch.empty(live * 4096, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(allm, mine)
+        good = torch.ones(1, dtype=torch.int32, device=dev)
+        for p in range(live - 1):
+            src = (rank + 1 + p) % live
+            got = peer_base[L - 1, p, 0].reshape(-1)[:8192].view(torch.int32)
+            if not torch.equal(got, allm[src * 4096:(src + 1) * 4096]):
+                good.zero_()
+        dist.all_reduce(good, op=dist.ReduceOp.MIN)
+        return bool(good.item()), f"rank {rank}: a peer's reconstructed state diverged from its owner's"
+
+    # ---- warmup (+ validation of the exchange path before anything is timed) ---------------------------------------------
+    for i in range(max(args.warmup, 1 if use_dist else 0)):
         one_step(i)
     sync_all()
+    if use_dist and step_plans is not None:
+        ok, why = states_consistent()
+        if not ok:
+            if args.exchange == "native":
+                raise RuntimeError("native exchange produced inconsistent state: " + why)
+            print("[bench] native exchange failed validation; falling back to torch.distributed per layer", file=sys.stderr)
+            step_plans, exchange_mode = None, "torch"
+            reset_state()
+            for i in range(max(args.warmup, 1)):
+                one_step(i)
+            sync_all()
 
     # ---- timed region -------------------------------------------------------------------------------------------
     KID_DEQ = 4
@@ -254,18 +342,8 @@ def main():
         lib.cfx_profile_enable(ctx, 0, 0, 1)
 
     # ---- state sanity (bit-exact error-feedback consistency) ---------------------------------------------------------
-    torch.cuda.synchronize(dev)
-    if live == 1:
-        assert torch.equal(own_base[0, 0].view(torch.int16), peer_base[0, 0, 0].view(torch.int16)), "EF state diverged"
-    else:
-        # what rank r holds for its own K of the last layer must be what every peer reconstructed for rank r
-        mine = own_base[L - 1, 0].reshape(-1)[:8192].view(torch.int32).contiguous()       # int32: a dtype every backend moves
-        allm = torch.empty(live * 4096, dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(allm, mine)
-        for p in range(live - 1):
-            src = (rank + 1 + p) % live
-            got = peer_base[L - 1, p, 0].reshape(-1)[:8192].view(torch.int32)
-            assert torch.equal(got, allm[src * 4096:(src + 1) * 4096]), f"rank {rank}: state of peer {src} diverged"
+    ok, why = states_consistent()
+    assert ok, why
 
     # ---- uncompressed RCCL all-gather of the same K/V shards (the north-star comparison), N > 1 only ---------------
     raw_ms = None
@@ -316,6 +394,7 @@ def main():
             "packet_bytes": pkt_bytes, "raw_bytes": N * C * 2,
         },
         "exchange_ms_per_step": round(ms_per_step, 4),
+        "exchange_issued_by": exchange_mode,
         "raw_allgather_ms_per_step": None if raw_ms is None else round(raw_ms, 4),
         "speedup_vs_raw_allgather": None if raw_ms is None else round(raw_ms / ms_per_step, 3),
     }
@@ -340,10 +419,23 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         except Exception as e:  # pragma: no cover
             out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    # tear the communicators down first and flush C stdio (RCCL prints a version banner through its own stdio buffer),
+    # so that the JSON line is the LAST thing on stdout
+    if native_comm is not None:
+        try:
+            torch.cuda.synchronize(dev)
+            native_comm.close()
+        except Exception:
+            pass
+    if use_dist:
+        dist.destroy_process_group()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if live > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

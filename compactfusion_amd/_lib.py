@@ -53,6 +53,15 @@ SYMBOLS = [
                                              ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_void_p, ctypes.c_size_t]),
     ("cfx_plan_add_decompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.POINTER(DecompItem)]),
+    ("cfx_plan_set_exchange_stream", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_plan_add_all_gather", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    ("cfx_plan_add_wait", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_rccl_load", ctypes.c_int, [ctypes.c_char_p]),
+    ("cfx_comm_unique_id", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    ("cfx_comm_create", ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    ("cfx_comm_destroy", None, [ctypes.c_void_p]),
+    ("cfx_comm_all_gather", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    ("cfx_plan_copy_op", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("cfx_plan_size", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_plan_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     ("cfx_copy_probe", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

@@ -1,0 +1,79 @@
+"""RCCL communicator owned by libcfx.so, bootstrapped through torch.distributed.
+
+The per-layer exchange of the compressed path is an all-gather of ~0.2-0.4 MB per rank; driving it through
+`torch.distributed` costs ~50 us of host time per call (measured on MI355X: 3.3 ms vs 1.8 ms per 57-layer step), more
+than the GPU work it overlaps.  `NativeComm` lets a `cfx_plan` issue the collective itself (ncclAllGather on the plan's
+side HIP stream, ordered with events), so a whole pipelined step is ONE native call.  The RCCL library instance is the
+one PyTorch-ROCm already loaded (found in /proc/self/maps), the 128-byte unique id travels over the existing process
+group."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .codecs import context
+
+
+def loaded_rccl_path() -> Optional[str]:
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "librccl" in line:
+                    return line.split()[-1]
+    except OSError:
+        pass
+    return None
+
+
+class NativeComm:
+    def __init__(self, device: int, group=None):
+        self.lib = _lib.load()
+        self.ctx = context(device)
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        path = loaded_rccl_path()
+        rc = self.lib.cfx_rccl_load(path.encode() if path else None)
+        if rc != 0:
+            raise _lib.CfxError("cannot load RCCL (librccl.so) for the native exchange")
+        uid = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            rc = self.lib.cfx_comm_unique_id(self.ctx, uid)
+            if rc != 0:
+                raise _lib.CfxError("ncclGetUniqueId failed")
+        box = [bytes(uid.raw)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self._uid = ctypes.create_string_buffer(box[0], 128)
+        torch.cuda.synchronize(device)
+        self.handle = self.lib.cfx_comm_create(self.ctx, self._uid, self.world, self.rank)
+        if not self.handle:
+            msg = self.lib.cfx_last_error_string(self.ctx)
+            raise _lib.CfxError("ncclCommInitRank failed: %s" % (msg.decode() if msg else ""))
+        self.device = device
+
+    def all_gather(self, send: torch.Tensor, recv: torch.Tensor, stream: Optional[torch.cuda.Stream] = None) -> None:
+        nbytes = send.numel() * send.element_size()
+        assert recv.numel() * recv.element_size() == nbytes * self.world
+        s = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        rc = self.lib.cfx_comm_all_gather(self.handle, send.data_ptr(), recv.data_ptr(), nbytes, s)
+        if rc != 0:
+            raise _lib.CfxError("native all-gather failed")
+
+    def self_test(self) -> None:
+        """Gather a rank-stamped pattern and check every slot (run once before trusting the communicator)."""
+        dev = torch.device("cuda", self.device)
+        send = torch.full((4096,), self.rank + 1, dtype=torch.uint8, device=dev)
+        recv = torch.zeros(4096 * self.world, dtype=torch.uint8, device=dev)
+        self.all_gather(send, recv)
+        torch.cuda.synchronize(self.device)
+        want = torch.arange(1, self.world + 1, dtype=torch.uint8, device=dev).repeat_interleave(4096)
+        if not torch.equal(recv, want):
+            raise _lib.CfxError("native all-gather self-test failed")
+
+    def close(self):
+        if self.handle:
+            self.lib.cfx_comm_destroy(self.handle)
+            self.handle = None

@@ -137,8 +137,28 @@ int       cfx_plan_add_compress(cfx_plan* plan, int codec, int N, int C, int par
                                 const cfx_comp_item* items, void* workspace, size_t workspace_bytes);
 int       cfx_plan_add_decompress(cfx_plan* plan, int codec, int N, int C, int param, int batch,
                                   const cfx_decomp_item* items);
+/* Exchange ops.  An all-gather op is ordered after everything the plan enqueued on the main stream before it (the
+ * packets are complete); with a side stream (modes 1, 2) a wait op makes the main stream wait for that gather, so
+ * "compress(l+1), gather(l+1), wait(l), reconstruct(l)" overlaps the wire with the codec; in mode 0 waits are no-ops. */
+typedef struct cfx_comm cfx_comm;
+/* where all-gather ops run: 0 = in order on the main stream (default; measured best for layer-sized work, a
+ * cross-stream event hop costs ~10 us here), 1 = side stream, 2 = prioritised side stream.  Set before adding ops. */
+int       cfx_plan_set_exchange_stream(cfx_plan* plan, int mode);
+int       cfx_plan_add_all_gather(cfx_plan* plan, cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank);
+int       cfx_plan_add_wait(cfx_plan* plan, int gather_op);
 int       cfx_plan_size(const cfx_plan* plan);
+int       cfx_plan_copy_op(cfx_plan* dst, const cfx_plan* src, int op);   /* append a copy of a (de)compress op of `src` */
 int       cfx_plan_run(cfx_plan* plan, int first_op, int n_ops, void* stream);
+
+/* RCCL communicator owned by the library (replaces yunchang's RingComm + torch.distributed P2P of the reference,
+ * xfuser/compact/ring.py:172,193-195,265-267).  RCCL is loaded at run time (cfx_rccl_load: pass the path of the
+ * librccl the process already uses, or NULL to search); rank 0 makes the 128-byte unique id (cfx_comm_unique_id),
+ * the host shares it by any means, every rank calls cfx_comm_create (collective). */
+int       cfx_rccl_load(const char* path);
+int       cfx_comm_unique_id(cfx_ctx* ctx, void* out128);
+cfx_comm* cfx_comm_create(cfx_ctx* ctx, const void* id128, int nranks, int rank);
+void      cfx_comm_destroy(cfx_comm* comm);
+int       cfx_comm_all_gather(cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
 
 /* Bandwidth probe: dst[i] = src[i] over `bytes` (multiple of 16) - the achievable-HBM reference
  * against which bench.py reports roofline fractions. */
