@@ -44,6 +44,13 @@ SYMBOLS = [
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_decompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    ("cfx_lr_packet_bytes", ctypes.c_size_t, [ctypes.c_int] * 4),
+    ("cfx_lr_workspace_bytes", ctypes.c_size_t, [ctypes.c_int] * 5),
+    ("cfx_lr_compress_batch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.POINTER(CompItem), ctypes.POINTER(ctypes.c_void_p),
+                                             ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    ("cfx_lr_decompress_batch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.POINTER(DecompItem), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_profile_enable", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_int]),
     ("cfx_profile_read", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float), ctypes.c_int]),
     ("cfx_kernel_name", ctypes.c_char_p, [ctypes.c_int]),

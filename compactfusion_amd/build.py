@@ -12,7 +12,7 @@ import sys
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG_DIR)
-SRC = [os.path.join(PKG_DIR, "csrc", "cfx_kernels.hip")]
+SRC = [os.path.join(PKG_DIR, "csrc", "cfx_kernels.hip"), os.path.join(PKG_DIR, "csrc", "cfx_lowrank.hip")]
 INC = os.path.join(REPO, "include")
 LIB = os.path.join(PKG_DIR, "libcfx.so")
 ARCH = "gfx950"
@@ -35,14 +35,14 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = SRC + [os.path.join(INC, "cfx.h")]
+    deps = SRC + [os.path.join(INC, "cfx.h"), os.path.join(PKG_DIR, "csrc", "cfx_internal.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc_path()] + HIPCC_FLAGS + [f"-I{INC}"] + SRC + ["-o", LIB + ".tmp"]
+    cmd = [hipcc_path()] + HIPCC_FLAGS + [f"-I{INC}", f"-I{os.path.join(PKG_DIR, 'csrc')}"] + SRC + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -172,3 +172,76 @@ def copy_probe(dst: torch.Tensor, src: torch.Tensor, stream: Optional[torch.cuda
     ctx = context(dev)
     rc = _lib.load().cfx_copy_probe(ctx, dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size(), _stream_handle(stream, dev))
     _check(ctx, rc, "cfx_copy_probe")
+
+
+# ---- low-rank family (cfx_lowrank.hip) -----------------------------------------------------------------------------------
+_lr_ws = {}
+
+
+def lr_rank_pad(rank: int) -> int:
+    return 8 if rank <= 8 else (16 if rank <= 16 else 32)
+
+
+def lr_packet_halves(quantized: bool, N: int, C: int, rank: int) -> int:
+    n = _lib.load().cfx_lr_packet_bytes(int(quantized), N, C, rank)
+    if n == 0:
+        raise ValueError(f"invalid shape for the low-rank codec: N={N} C={C} rank={rank} quantized={quantized} "
+                         "(rank even and <= 32; LOW_RANK_Q: N, C even and rank % 8 == 0)")
+    return n // 2
+
+
+def _lr_workspace(quantized: bool, N: int, C: int, rank: int, batch: int, device: int) -> torch.Tensor:
+    need = _lib.load().cfx_lr_workspace_bytes(int(quantized), N, C, rank, batch)
+    if need == 0:
+        raise ValueError("invalid shape for the low-rank codec")
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    w = _lr_ws.get(key)
+    if w is None or w.numel() < need:
+        w = torch.empty(need, dtype=torch.uint8, device=f"cuda:{device}")
+        _lr_ws[key] = w
+    return w
+
+
+def lr_compress_batch(quantized: bool, xs, bases, new_bases, packets, init_qs, N: int, C: int, rank: int,
+                      update_cache: bool = True, ef: bool = True, stream: Optional[torch.cuda.Stream] = None) -> None:
+    """Low-rank residual compress of a batch: packet_i, new_base_i from (x_i, base_i) and the start matrix init_q_i
+    (C x lr_rank_pad(rank) fp32, columns >= rank zero)."""
+    B = len(xs)
+    if not (1 <= B <= CFX_MAX_BATCH):
+        raise ValueError(f"batch {B} out of range 1..{CFX_MAX_BATCH}")
+    dev = _device_index(xs[0])
+    ctx = context(dev)
+    items = (CompItem * B)()
+    qptr = (ctypes.c_void_p * B)()
+    rp = lr_rank_pad(rank)
+    for i in range(B):
+        _check_nc(xs[i], N, C, "x")
+        q = init_qs[i]
+        if q.dtype != torch.float32 or tuple(q.shape) != (C, rp) or not q.is_contiguous():
+            raise ValueError(f"init_q must be a contiguous fp32 ({C}, {rp}) tensor")
+        _device_index(q)
+        items[i] = CompItem(_ptr(xs[i]), _ptr(bases[i]), _ptr(new_bases[i]) if update_cache else None, _ptr(packets[i]))
+        qptr[i] = q.data_ptr()
+    ws = _lr_workspace(quantized, N, C, rank, B, dev)
+    flags = (FLAG_UPDATE_CACHE if update_cache else 0) | (0 if ef else FLAG_NO_EF)
+    rc = _lib.load().cfx_lr_compress_batch(ctx, int(quantized), N, C, rank, flags, B, items, qptr, ws.data_ptr(), ws.numel(),
+                                           _stream_handle(stream, dev))
+    _check(ctx, rc, "cfx_lr_compress_batch")
+
+
+def lr_decompress_batch(quantized: bool, packets, bases, recons, N: int, C: int, rank: int,
+                        stream: Optional[torch.cuda.Stream] = None) -> None:
+    B = len(packets)
+    if not (1 <= B <= CFX_MAX_BATCH):
+        raise ValueError(f"batch {B} out of range 1..{CFX_MAX_BATCH}")
+    dev = _device_index(recons[0])
+    ctx = context(dev)
+    items = (DecompItem * B)()
+    for i in range(B):
+        _check_nc(recons[i], N, C, "recon")
+        _device_index(packets[i])
+        items[i] = DecompItem(_ptr(packets[i]), _ptr(bases[i]), _ptr(recons[i]))
+    ws = _lr_workspace(quantized, N, C, rank, B, dev) if quantized else None
+    rc = _lib.load().cfx_lr_decompress_batch(ctx, int(quantized), N, C, rank, B, items, _ptr(ws), 0 if ws is None else ws.numel(),
+                                             _stream_handle(stream, dev))
+    _check(ctx, rc, "cfx_lr_decompress_batch")

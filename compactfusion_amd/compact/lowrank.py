@@ -1,18 +1,18 @@
 """Low-rank residual codecs: LOW_RANK (rank-r factors) and LOW_RANK_Q (rank-r factors, int4-quantised).
 
-Restates the reference's `xfuser/compact/compress_lowrank.py` (`subspace_iter` :14-61, `svd` :5-12) and the LOW_RANK /
-LOW_RANK_Q branches of `slowpath.py` (:54-75 encode, :120-131 + :151-164 decode):
+Host side of `compactfusion_amd/csrc/cfx_lowrank.hip`, which replaces the reference's `subspace_iter`
+(`xfuser/compact/compress_lowrank.py:14-61`) and the LOW_RANK / LOW_RANK_Q branches of `slowpath.py`
+(:54-75 encode, :120-131 + :151-164 decode) by a fixed chain of gfx950 kernels (randomised subspace iteration with
+fp64 Cholesky-QR, factor emission straight into the wire packet, fused decode + residual add):
 
-    Q0 = qr(randn(C, r)) ; 2 x { Z = A^T (A Q) ; Q = qr(Z) } ; U = qr(A Q) ; V = U^T A          (all fp32)
-    LOW_RANK   wire  [ U (N,r) fp16 | V (r,C) fp16 ]                       decode  U @ V
+    LOW_RANK   wire  [ U (N,r) fp16 | V (r,C) fp16 ]                                   decode  U @ V
     LOW_RANK_Q wire  [ q4(U) (N/2,r) | sU r | mU r | q4(V^T) (C/2,r) | sV r | mV r ]   decode  deq(U) @ deq(V^T)^T
 
-Status: this row of the scope table is FUNCTIONAL, not yet MI355X-optimised - the tall-skinny
-contractions and the QR run through PyTorch-ROCm (rocBLAS / hipSOLVER) on the GPU, the int4 factor quantiser is the
-native gfx950 kernel.  A is read six times; a fused streaming kernel is the planned replacement.  The result depends on
-the random start Q0 (`init_q` pins it) and, in the last bits, on the GEMM/QR rounding order, so parity is
-tolerance-based exactly as in the reference's own tests (compress_slowpath_test.py:128-216: 1e-4 vs its simulator under
-the same seed, 0.05 for the int4 variant, 0.1 vs SVD).
+Only the random start matrix is made here (torch.randn on the device, as the reference does at compress_lowrank.py:41);
+`set_init_q` pins it for reproducible tests.  `subspace_iter` / `svd` below are the reference's function-level API
+(library GEMM / QR through PyTorch, any device) kept for callers and tests that want the factors themselves.
+Parity is tolerance-based exactly as in the reference's own tests (compress_slowpath_test.py:128-216): the result
+depends on the random start and, in the last bits, on the GEMM / QR rounding order.
 """
 from __future__ import annotations
 
@@ -25,15 +25,71 @@ from ..prof import Profiler
 from .utils import COMPACT_COMPRESS_TYPE as T
 
 LOW_RANK_ID, LOW_RANK_Q_ID = 101, 102
-_I4 = int(codecs.Codec.INT4)
+_pinned_q: Optional[torch.Tensor] = None
 
 
 def native_id(compress_type) -> int:
     return LOW_RANK_ID if compress_type == T.LOW_RANK else LOW_RANK_Q_ID
 
 
+def set_init_q(q: Optional[torch.Tensor]) -> None:
+    """Pin the (C, r) start matrix used by the next compress calls (None: back to torch.randn)."""
+    global _pinned_q
+    _pinned_q = q
+
+
+def _start(C: int, rank: int, device) -> torch.Tensor:
+    rp = codecs.lr_rank_pad(rank)
+    q = torch.zeros(C, rp, dtype=torch.float32, device=device)
+    if _pinned_q is not None:
+        assert tuple(_pinned_q.shape) == (C, rank), f"pinned init_q must be ({C}, {rank})"
+        q[:, :rank] = _pinned_q.to(device=device, dtype=torch.float32)
+    else:
+        q[:, :rank] = torch.randn(C, rank, device=device, dtype=torch.float32)
+    return q
+
+
+def packet_halves(cid: int, rank: int, N: int, C: int) -> int:
+    return codecs.lr_packet_halves(cid == LOW_RANK_Q_ID, N, C, rank)
+
+
+@Profiler.prof_func("compact.lowrank.compress")
+def compress(cid: int, rank: int, x: torch.Tensor, base: Optional[torch.Tensor], new_base: Optional[torch.Tensor],
+             packet: torch.Tensor, update: bool, ef: bool = True) -> None:
+    N, C = x.shape
+    codecs.lr_compress_batch(cid == LOW_RANK_Q_ID, [x], [base], [new_base if update else None], [packet],
+                             [_start(C, rank, x.device)], N, C, rank, update_cache=update, ef=ef)
+
+
+@Profiler.prof_func("compact.lowrank.decompress")
+def decompress(cid: int, rank: int, packet: torch.Tensor, base: Optional[torch.Tensor], out: torch.Tensor) -> None:
+    N, C = out.shape
+    codecs.lr_decompress_batch(cid == LOW_RANK_Q_ID, [packet], [base], [out], N, C, rank)
+
+
+# ---- slowpath.py-level API ----------------------------------------------------------------------------------------------
+def slowpath_compress(x: torch.Tensor, compress_type, rank: int) -> torch.Tensor:
+    cid = native_id(compress_type)
+    N, C = x.shape
+    pkt = torch.empty(packet_halves(cid, rank, N, C), dtype=torch.float16, device=x.device)
+    compress(cid, rank, x, None, None, pkt, update=False)
+    return pkt
+
+
+def slowpath_decompress(x: torch.Tensor, shape: Tuple[int, int], compress_type, rank: int) -> torch.Tensor:
+    cid = native_id(compress_type)
+    N, C = shape
+    assert x.numel() == packet_halves(cid, rank, N, C)
+    out = torch.empty((N, C), dtype=torch.float16, device=x.device)
+    if x.data_ptr() % 16:
+        x = x.clone()
+    decompress(cid, rank, x, None, out)
+    return out
+
+
+# ---- the reference's function-level API (library path, any device) ----------------------------------------------------------
 def svd(input_tensor: torch.Tensor, rank: int):
-    """Truncated SVD reference factorisation (compress_lowrank.py:5-12): returns (U S, V^T) in the input dtype."""
+    """Truncated SVD factorisation (compress_lowrank.py:5-12): returns (U S, V^T) in the input dtype."""
     U, S, Vh = torch.linalg.svd(input_tensor.float(), full_matrices=False)
     return (U[:, :rank] * S[:rank]).to(input_tensor.dtype), Vh[:rank, :].to(input_tensor.dtype)
 
@@ -53,100 +109,3 @@ def subspace_iter(A: torch.Tensor, rank: int, num_iters: int = 10, init_q: Optio
     U, _ = torch.linalg.qr(Af @ Q)
     V = U.t() @ Af
     return U.to(dtype), V.to(dtype), Q.to(dtype)
-
-
-def packet_halves(cid: int, rank: int, N: int, C: int) -> int:
-    if cid == LOW_RANK_ID:
-        return (N + C) * rank
-    assert (N * rank) % 4 == 0 and (C * rank) % 4 == 0, f"LOW_RANK_Q split error. uN: {N * rank}, vN: {C * rank}"
-    assert N % 2 == 0 and C % 2 == 0 and rank % 8 == 0, "LOW_RANK_Q needs even N, C and rank % 8 == 0 (int4 factor kernel)"
-    return N * rank // 4 + 2 * rank + C * rank // 4 + 2 * rank
-
-
-def _q4(m: torch.Tensor, out: torch.Tensor) -> None:
-    """int4-quantise the factor matrix m (rows, r) into `out` (its packet section) with the native kernel."""
-    rows, r = m.shape
-    codecs.compress_batch(_I4, [m.contiguous()], [None], [None], [out], rows, r, 0, update_cache=False)
-
-
-def _dq4(section: torch.Tensor, rows: int, r: int) -> torch.Tensor:
-    out = torch.empty((rows, r), dtype=torch.float16, device=section.device)
-    if section.data_ptr() % 16:
-        section = section.clone()
-    codecs.decompress_batch(_I4, [section], [None], [out], rows, r, 0)
-    return out
-
-
-def _sections(cid: int, rank: int, N: int, C: int):
-    if cid == LOW_RANK_ID:
-        return [("U", 0, N * rank), ("V", N * rank, C * rank)]
-    nu = N * rank // 4 + 2 * rank
-    return [("U", 0, nu), ("V", nu, C * rank // 4 + 2 * rank)]
-
-
-def encode(cid: int, rank: int, d: torch.Tensor, packet: torch.Tensor) -> torch.Tensor:
-    """d (N, C) fp16 -> writes the packet, returns decode(packet) (N, C) fp16."""
-    N, C = d.shape
-    U, V, _ = subspace_iter(d, rank, 2)
-    (_, ou, nu), (_, ov, nv) = _sections(cid, rank, N, C)
-    if cid == LOW_RANK_ID:
-        packet[ou:ou + nu].copy_(U.reshape(-1))
-        packet[ov:ov + nv].copy_(V.reshape(-1))
-        return torch.matmul(U, V)
-    su, sv = packet[ou:ou + nu], packet[ov:ov + nv]
-    if su.data_ptr() % 16 or sv.data_ptr() % 16:
-        tu, tv = torch.empty_like(su), torch.empty_like(sv)
-        _q4(U, tu)
-        _q4(V.t(), tv)
-        su.copy_(tu)
-        sv.copy_(tv)
-    else:
-        _q4(U, su)
-        _q4(V.t(), sv)
-    return torch.matmul(_dq4(su, N, rank), _dq4(sv, C, rank).t())
-
-
-def decode(cid: int, rank: int, packet: torch.Tensor, N: int, C: int) -> torch.Tensor:
-    (_, ou, nu), (_, ov, nv) = _sections(cid, rank, N, C)
-    if cid == LOW_RANK_ID:
-        return torch.matmul(packet[ou:ou + nu].view(N, rank), packet[ov:ov + nv].view(rank, C))
-    return torch.matmul(_dq4(packet[ou:ou + nu], N, rank), _dq4(packet[ov:ov + nv], C, rank).t())
-
-
-# ---- residual codec entry points used by main.py ---------------------------------------------------------------------
-def compress(cid: int, rank: int, x: torch.Tensor, base: Optional[torch.Tensor], new_base: Optional[torch.Tensor],
-             packet: torch.Tensor, update: bool, ef: bool = True) -> None:
-    d = x if base is None else x - base
-    recv = encode(cid, rank, d, packet)
-    if update and new_base is not None:
-        if not ef:
-            new_base.copy_(x)
-        elif base is None:
-            new_base.copy_(recv)
-        else:
-            torch.add(base, recv, out=new_base)
-
-
-def decompress(cid: int, rank: int, packet: torch.Tensor, base: Optional[torch.Tensor], out: torch.Tensor) -> None:
-    N, C = out.shape
-    recv = decode(cid, rank, packet, N, C)
-    if base is None:
-        out.copy_(recv)
-    else:
-        torch.add(base, recv, out=out)
-
-
-# ---- slowpath.py-level API ----------------------------------------------------------------------------------------------
-def slowpath_compress(x: torch.Tensor, compress_type, rank: int) -> torch.Tensor:
-    cid = native_id(compress_type)
-    N, C = x.shape
-    pkt = torch.empty(packet_halves(cid, rank, N, C), dtype=torch.float16, device=x.device)
-    encode(cid, rank, x, pkt)
-    return pkt
-
-
-def slowpath_decompress(x: torch.Tensor, shape: Tuple[int, int], compress_type, rank: int) -> torch.Tensor:
-    cid = native_id(compress_type)
-    N, C = shape
-    assert x.numel() == packet_halves(cid, rank, N, C)
-    return decode(cid, rank, x, N, C)

@@ -30,6 +30,7 @@
 #include <string.h>
 #include <dlfcn.h>
 #include "cfx.h"
+#include "cfx_internal.h"
 
 typedef _Float16 h16;
 typedef h16 h16x8 __attribute__((ext_vector_type(8)));
@@ -843,51 +844,6 @@ __global__ __launch_bounds__(256) void k_copy_probe(uint4* __restrict__ dst, con
 // ---------------------------------------------------------------------------------------------------
 // host side: C-ABI
 // ---------------------------------------------------------------------------------------------------
-enum {
-    KID_ABSMEAN_STATS_BITS = 1, KID_ABSMEAN_STATS = 2, KID_ABSMEAN_FINALIZE = 3, KID_BINARY_DEQUANT = 4,
-    KID_INT2_QUANT = 5, KID_INT2_DEQUANT = 6, KID_MINMAX_STATS = 7, KID_MINMAX_FINALIZE = 8,
-    KID_INT8_QUANT = 9, KID_INT8_DEQUANT = 10, KID_INT4_QUANT = 11, KID_INT4_DEQUANT = 12,
-    KID_TOPK_COMPRESS = 13, KID_TOPK_DECOMPRESS = 14, KID_COPY_PROBE = 15, KID_BINARY_EF = 16, KID_MAX = 17
-};
-static const char* const kid_names[KID_MAX] = {
-    "", "k_absmean_stats<bits>", "k_absmean_stats", "k_absmean_finalize", "k_binary_dequant", "k_int2_quant", "k_int2_dequant",
-    "k_minmax_stats", "k_minmax_finalize", "k_int8_quant", "k_int8_dequant", "k_int4_quant", "k_int4_dequant",
-    "k_topk_compress", "k_topk_decompress", "k_copy_probe", "k_binary_dequant(ef)"};
-
-struct ProfRec { int kid; hipEvent_t a, b; };
-
-struct cfx_ctx {
-    int device;
-    int rows_per_tile;
-    // native per-launch timing (hipEvents recorded on the launch stream around selected kernels)
-    ProfRec* prof;
-    int prof_cap, prof_n;
-    int prof_stride, prof_seen;     // record every prof_stride-th eligible launch
-    unsigned prof_mask;
-    char err[256];
-};
-
-// Returns the record slot for this launch or -1.  A profiled launch goes through hipExtLaunchKernelGGL, which ties the
-// two events to the dispatch packet itself: their elapsed time is the kernel's execution time (as rocprofv3 reports it),
-// not the kernel plus the command processor's event handling that a hipEventRecord bracket would add (~6 us here).
-static inline int prof_slot(cfx_ctx* ctx, int kid) {
-    if (!ctx->prof_mask || !(ctx->prof_mask & (1u << kid)) || ctx->prof_n >= ctx->prof_cap) return -1;
-    if ((ctx->prof_seen++ % ctx->prof_stride) != 0) return -1;
-    const int i = ctx->prof_n++;
-    ctx->prof[i].kid = kid;
-    return i;
-}
-#define LAUNCH(ctx, kid, s, kern, grid, block, shm, strm, ...) do { \
-        const int _pi = prof_slot(ctx, kid); \
-        if (_pi >= 0) hipExtLaunchKernelGGL(kern, grid, block, shm, strm, (ctx)->prof[_pi].a, (ctx)->prof[_pi].b, 0, __VA_ARGS__); \
-        else hipLaunchKernelGGL(kern, grid, block, shm, strm, __VA_ARGS__); \
-    } while (0)
-
-static int fail(cfx_ctx* ctx, int code, const char* msg) {
-    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
-    return code;
-}
-
 static bool shape_ok(int codec, int N, int C, int param) {
     if (N <= 0 || C <= 0 || (C % 8) != 0) return false;
     switch (codec) {
@@ -1015,17 +971,6 @@ size_t cfx_workspace_bytes(int codec, int N, int C, int param, int batch) {
     return ws_words(codec, N, C) * 8 * batch;
 }
 
-static int check_launch(cfx_ctx* ctx, const char* what) {
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        char buf[200];
-        snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
-        return fail(ctx, CFX_ERR_LAUNCH, buf);
-    }
-    return CFX_OK;
-}
-
-#define AL16(p) ((((uintptr_t)(p)) & 15) == 0)
 
 int cfx_decompress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items, void* stream) {
     if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "decompress: null ctx/items");

@@ -1,0 +1,591 @@
+// Low-rank residual codecs (LOW_RANK, LOW_RANK_Q) on gfx950 - part of libcfx.so.
+//
+// Replaces the reference's `subspace_iter` (xfuser/compact/compress_lowrank.py:14-61: randomised subspace iteration with
+// Householder QR, run through torch.compile + cuBLAS/cuSOLVER: ~10 library calls, A read 6 times) and the LOW_RANK /
+// LOW_RANK_Q branches of slowpath.py (:54-75 encode, :120-131 + :151-164 decode) with a fixed chain of small kernels:
+//
+//   D  = x - base                                   k_lr_prep     (fp16 residual, materialised once)
+//   2x { Y = D Q ; Z = D^T Y ; Q = orth(Z) }          k_lr_aq, k_lr_aty (+ partial Gram), k_lr_chol, k_lr_apply
+//   Y  = D Q ; Z' = D^T Y ; G = Q^T Z' (= Y^T Y)      k_lr_aq, k_lr_aty (+ partial Q^T Z')
+//   T  = chol(G)^-T ; U = Y T ; V = (Z' T)^T          k_lr_chol, k_lr_apply x2    (U = orth(Y), V = U^T D without re-reading D)
+//   new_base = base + fp16(U16 V16)                   k_lr_decode   (the receiver's kernel, run on the sender's packet)
+//
+// orth() is Cholesky-QR with the r x r Gram matrix accumulated and factorised in fp64 (Z = Q R, R = chol(Z^T Z)^T): the
+// subspace - hence U V, the projection of D onto it - is the one Householder QR gives; only the signs/rotations a QR leaves
+// free can differ, and fp32 rounding.  The random start is NOT orthonormalised (compress_lowrank.py:41-42 does QR(randn)):
+// span(D^T D Q0) does not depend on the basis chosen for span(Q0).
+//
+// Everything is fp32 FMA on the vector ALU: at r <= 32 a pass is 2*N*C*r <= 0.1 GFLOP (<1 us of a 157 TFLOP/s machine) over
+// a 3 MB matrix that stays in L2/MALL; the chain is bound by its ~15 launches, not by FLOPs or bytes, so no MFMA.
+// All reductions have a fixed order (no float atomics): results are reproducible run to run.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "cfx.h"
+#include "cfx_internal.h"
+
+typedef _Float16 h16;
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+
+#define LR_MAXB CFX_MAX_BATCH
+
+struct LrItem {
+    const h16* x; const h16* base; h16* new_base; void* packet;
+    const float* q0;     // C x RP fp32 start (rank columns used, the rest zero)
+    char* ws;            // this tensor's workspace
+};
+struct LrBatch { LrItem it[LR_MAXB]; };
+
+// workspace carve-up (per tensor), all offsets 256-byte aligned
+struct LrWs {
+    size_t D, Qa, Zb, Y, Gp, T, U16, V16, Uq, Vq, Vsec, total;
+};
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+static LrWs lr_layout(int N, int C, int RP) {
+    LrWs w;
+    size_t o = 0;
+    w.D = o;   o += al256((size_t)N * C * 2);
+    w.Qa = o;  o += al256((size_t)C * RP * 4);
+    w.Zb = o;  o += al256((size_t)C * RP * 4);
+    w.Y = o;   o += al256((size_t)4 * N * RP * 4);        // 4 column-group partials of Y
+    w.Gp = o;  o += al256((size_t)((C + 31) / 32) * RP * RP * 8);
+    w.T = o;   o += al256((size_t)RP * RP * 4);
+    w.U16 = o; o += al256((size_t)N * RP * 2);
+    w.V16 = o; o += al256((size_t)C * RP * 2);
+    w.Uq = o;  o += al256((size_t)N * RP * 2 + 256);
+    w.Vq = o;  o += al256((size_t)C * RP * 2 + 256);
+    w.Vsec = o; o += al256((size_t)C * RP / 2 + 4 * RP + 256);
+    w.total = o;
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// D = x - base (fp16, one rounding as torch eager); base NULL: D = x
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lr_prep(LrBatch b, size_t E, size_t offD) {
+    const LrItem it = b.it[blockIdx.y];
+    const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (e >= E) return;
+    h16x8 xv = *reinterpret_cast<const h16x8*>(it.x + e);
+    if (it.base) xv = xv - *reinterpret_cast<const h16x8*>(it.base + e);
+    *reinterpret_cast<h16x8*>((h16*)(it.ws + offD) + e) = xv;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Ypart[g] (N x RP) = D[:, cols of group g] . Q[cols of group g, :]      Y = sum of the 4 group partials (summed, in fixed
+// order, by whoever reads Y).  grid (ceil(N/8), 4, batch): a workgroup owns 8 rows x every 4th 256-column chunk.
+//   thread = (kq: RP/8 consecutive k, rp: row pair, cp: c = cp mod 8) ; the 8 c-partials are reduced through LDS
+// ---------------------------------------------------------------------------------------------------------------------
+template <int RP>
+__global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t offD, size_t offQ, size_t offY, int use_q0) {
+    constexpr int KB = RP / 8, CK = 256, LDQ = RP + 4;
+    const LrItem it = b.it[blockIdx.z];
+    const h16* D = (const h16*)(it.ws + offD);
+    const float* Q = use_q0 ? it.q0 : (const float*)(it.ws + offQ);
+    float* Y = (float*)(it.ws + offY) + (size_t)blockIdx.y * N * RP;
+    __shared__ float qs[CK * LDQ];          // 36 KB at RP = 32
+    __shared__ float ds[8][CK + 1];
+    __shared__ float red[8][8][RP];
+    const int tid = threadIdx.x, kq = tid & 7, rp = (tid >> 3) & 3, cp = tid >> 5;
+    const int n0 = blockIdx.x * 8;
+    float acc[2][KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
+    for (int c0 = blockIdx.y * CK; c0 < C; c0 += 4 * CK) {
+        const int cn = min(CK, C - c0);
+        __syncthreads();
+        for (int i = tid; i < cn * (RP / 4); i += 256) {
+            const int r = i / (RP / 4), k4 = i - r * (RP / 4);
+            *reinterpret_cast<float4*>(&qs[r * LDQ + 4 * k4]) = *reinterpret_cast<const float4*>(&Q[(size_t)(c0 + r) * RP + 4 * k4]);
+        }
+        for (int i = tid; i < 8 * CK; i += 256) {
+            const int rr = i / CK, cc = i - rr * CK;
+            ds[rr][cc] = (n0 + rr < N && cc < cn) ? (float)D[(size_t)(n0 + rr) * C + c0 + cc] : 0.f;
+        }
+        __syncthreads();
+        for (int c = cp; c < cn; c += 8) {
+            const float d0 = ds[2 * rp][c], d1 = ds[2 * rp + 1][c];
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                const float q = qs[c * LDQ + kq * KB + j];
+                acc[0][j] = fmaf(d0, q, acc[0][j]);
+                acc[1][j] = fmaf(d1, q, acc[1][j]);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < KB; ++j) red[cp][2 * rp + h][kq * KB + j] = acc[h][j];
+    __syncthreads();
+    for (int i = tid; i < 8 * RP; i += 256) {
+        const int rr = i / RP, k = i - rr * RP;
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) s += red[p][rr][k];
+        if (n0 + rr < N) Y[(size_t)(n0 + rr) * RP + k] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Z (C x RP) = D^T (C x N) . Y (N x RP)      the one GEMM-shaped step with a long inner dimension (K = N): fp32-input MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain, operands straight from L2 in the instruction's own layout, no LDS).
+//   workgroup = one 32-column tile of D x all N; its 4 waves split N, partial 32x32 tiles are summed in fixed order.
+//   lane l feeds A[i = l&31][k = l>>5] = D[n + (l>>5)][c0 + (l&31)]  and  B[k = l>>5][j = l&31] = Y[n + (l>>5)][l&31]
+//   (Y = fixed-order sum of the 4 column-group slabs k_lr_aq wrote).  Epilogue: this tile's part of the r x r Gram matrix
+//   in fp64.  gram_mode 0: Ztile^T Ztile ; 1: Qtile^T Ztile (Q = the orthonormal basis Y was formed with).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int RP>
+__global__ __launch_bounds__(256) void k_lr_aty(LrBatch b, int N, int C, size_t offD, size_t offY, size_t offZ, size_t offQ, size_t offG, int gram_mode) {
+    const LrItem it = b.it[blockIdx.y];
+    const h16* D = (const h16*)(it.ws + offD);
+    const float* Y = (const float*)(it.ws + offY);
+    float* Z = (float*)(it.ws + offZ);
+    const float* Qb = (const float*)(it.ws + offQ);
+    double* Gp = (double*)(it.ws + offG) + (size_t)blockIdx.x * RP * RP;
+    __shared__ float red[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c0 = blockIdx.x * 32;
+    const int li = lane & 31, lk = lane >> 5;
+    const int nq = (((N + 3) / 4) + 1) & ~1;            // rows per wave, even
+    const int nb = w * nq, ne = min(N, nb + nq);
+    const bool cok = c0 + li < C, kok = li < RP;
+    const size_t slab = (size_t)N * RP;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // 8 MFMAs per round: all 40 operand loads of a round are issued before the first MFMA needs one
+    for (int n = nb; n < ne; n += 16) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int nn = n + 2 * u + lk;
+            av[u] = 0.f; bv[u] = 0.f;
+            if (nn < ne) {
+                if (cok) av[u] = (float)D[(size_t)nn * C + c0 + li];
+                if (kok) {
+                    const size_t o = (size_t)nn * RP + li;
+                    bv[u] = ((Y[o] + Y[o + slab]) + Y[o + 2 * slab]) + Y[o + 3 * slab];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    // C/D layout: column j = lane & 31, row i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) red[w][(rg & 3) + 8 * (rg >> 2) + 4 * lk][li] = acc[rg];
+    __syncthreads();
+    for (int i = tid; i < 32 * 32; i += 256) {
+        const int cc = i >> 5, k = i & 31;
+        const float s = ((red[0][cc][k] + red[1][cc][k]) + red[2][cc][k]) + red[3][cc][k];
+        red[0][cc][k] = s;          // (cc, k) is read and written by this thread only
+        if (c0 + cc < C && k < RP) Z[(size_t)(c0 + cc) * RP + k] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < RP * RP; i += 256) {
+        const int a = i / RP, bb = i - a * RP;
+        double g = 0.0;
+        if (gram_mode) {
+            for (int cc = 0; cc < 32; ++cc)
+                if (c0 + cc < C) g += (double)Qb[(size_t)(c0 + cc) * RP + a] * (double)red[0][cc][bb];
+        } else {
+            for (int cc = 0; cc < 32; ++cc)
+                if (c0 + cc < C) g += (double)red[0][cc][a] * (double)red[0][cc][bb];
+        }
+        Gp[i] = g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// T (RP x RP fp32, upper triangular) = chol(G)^-T with G = sum of the partial Grams (fp64), symmetrised; rank = r <= RP.
+// A non-positive pivot (rank-deficient residual, e.g. x == base) zeroes that direction instead of producing NaNs.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int RP>
+__global__ __launch_bounds__(1024) void k_lr_chol(LrBatch b, int r, int nparts, size_t offG, size_t offT) {
+    const LrItem it = b.it[blockIdx.x];
+    const double* Gp = (const double*)(it.ws + offG);
+    float* T = (float*)(it.ws + offT);
+    __shared__ double G[RP][RP + 1], L[RP][RP + 1], X[RP][RP + 1];
+    const int tid = threadIdx.x;
+    {
+        // all 1024 threads reduce the partial Grams: element e, part group g (1024 / RP^2 groups), 8 loads in flight each
+        constexpr int E = RP * RP, GRP = 1024 / E;
+        __shared__ double part[GRP][E];
+        const int e = tid % E, g = tid / E;
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = 0.0;
+        int p = g;
+        for (; p + 7 * GRP < nparts; p += 8 * GRP) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += Gp[(size_t)(p + u * GRP) * E + e];
+        }
+        for (; p < nparts; p += GRP) a[0] += Gp[(size_t)p * E + e];
+        part[g][e] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        __syncthreads();
+        if (tid < E) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) t += part[q][tid];
+            G[tid / RP][tid % RP] = t;
+        }
+    }
+    __syncthreads();
+    double gsym = 0.0;
+    if (tid < RP * RP) gsym = 0.5 * (G[tid / RP][tid % RP] + G[tid % RP][tid / RP]);
+    __syncthreads();
+    if (tid < RP * RP) { G[tid / RP][tid % RP] = gsym; L[tid / RP][tid % RP] = 0.0; X[tid / RP][tid % RP] = 0.0; }
+    __syncthreads();
+    if (tid >= 64) return;          // the factorisation is tiny and sequential: ONE wave, barriers between its steps are cheap
+    const int i = tid;              // lane i owns row i (lanes >= r idle)
+    double gmax = 0.0;
+    for (int k = 0; k < r; ++k) gmax = fmax(gmax, G[k][k]);
+    unsigned deadmask = 0;
+    for (int j = 0; j < r; ++j) {
+        double s = 0.0;
+        if (i >= j && i < r) {
+            s = G[i][j];
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            X[i][j] = s;
+        }
+        __syncthreads();
+        const double piv = X[j][j];
+        const bool bad = !(piv > gmax * 1e-13);
+        if (bad) deadmask |= 1u << j;
+        if (i >= j && i < r) L[i][j] = bad ? ((i == j) ? 1.0 : 0.0) : ((i == j) ? sqrt(piv) : s / sqrt(piv));
+        __syncthreads();
+    }
+    for (int k = i; k < RP * RP; k += 64) X[k / RP][k % RP] = 0.0;
+    __syncthreads();
+    // X = L^-1 (lower triangular): row m from rows < m; lane i owns column i
+    for (int m = 0; m < r; ++m) {
+        if (i <= m) {
+            double s = (i == m) ? 1.0 : 0.0;
+            for (int k = i; k < m; ++k) s -= L[m][k] * X[k][i];
+            X[m][i] = s / L[m][m];
+        }
+        __syncthreads();
+    }
+    // T[k][j] = X[j][k] (k <= j): Q = Z T ; directions with a vanished pivot are dropped
+    for (int e = i; e < RP * RP; e += 64) {
+        const int k = e / RP, j = e % RP;
+        float v = 0.f;
+        if (k < r && j < r && k <= j && !((deadmask >> j) & 1u)) v = (float)X[j][k];
+        T[e] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Out = In (rows x RP fp32) . T (RP x RP)   one thread per row.
+//   mode 0: fp32 rows x RP (the next Q) ; mode 1: fp16 rows x r, row-major (U, or V^T for LOW_RANK_Q) ;
+//   mode 2: fp16 r x rows, i.e. transposed (V in the LOW_RANK wire layout)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int RP>
+__global__ __launch_bounds__(256) void k_lr_apply(LrBatch b, int rows, int r, size_t offIn, int in_slabs, size_t offT, int mode, size_t offOut,
+                                                  int out_in_packet, size_t pkt_off_halves) {
+    const LrItem it = b.it[blockIdx.y];
+    const float* In = (const float*)(it.ws + offIn);
+    const float* T = (const float*)(it.ws + offT);
+    __shared__ float ts[RP * RP];
+    for (int i = threadIdx.x; i < RP * RP; i += 256) ts[i] = T[i];
+    __syncthreads();
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float in[RP], out[RP];
+    const size_t slab = (size_t)rows * RP;
+#pragma unroll
+    for (int k = 0; k < RP; ++k) {
+        float v = In[(size_t)row * RP + k];
+        for (int p = 1; p < in_slabs; ++p) v += In[(size_t)p * slab + (size_t)row * RP + k];     // fixed order
+        in[k] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < RP; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < RP; ++k) s = fmaf(in[k], ts[k * RP + j], s);
+        out[j] = s;
+    }
+    if (mode == 0) {
+        float* O = (float*)(it.ws + offOut);
+#pragma unroll
+        for (int j = 0; j < RP; ++j) O[(size_t)row * RP + j] = out[j];
+    } else {
+        h16* O = out_in_packet ? ((h16*)it.packet + pkt_off_halves) : (h16*)(it.ws + offOut);
+#pragma unroll
+        for (int j = 0; j < RP; ++j) {
+            if (j < r) {
+                if (mode == 1) O[(size_t)row * r + j] = (h16)out[j];
+                else O[(size_t)j * rows + row] = (h16)out[j];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out = base + fp16( sum_k U16[n][k] * V16[k][c] )      decode of LOW_RANK (slowpath.py:151-154: torch.matmul(u, v), fp32
+// accumulation, fp16 result) fused with the residual add (main.py:232, :376).  VT: V given transposed (C x r) as LOW_RANK_Q
+// stores it.  Tile = 8 rows x 512 channels like the other dequant kernels; V lives in registers, U rows are broadcast loads.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LrDec { const h16* U; const h16* V; const h16* base; h16* out; };
+struct LrDecBatch { LrDec it[LR_MAXB]; };
+
+typedef h16 h16x2 __attribute__((ext_vector_type(2)));
+
+template <int RP, bool VT>
+__global__ __launch_bounds__(256) void k_lr_decode(LrDecBatch b, int N, int C, int r) {
+    const LrDec it = b.it[blockIdx.z];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = blockIdx.x * 512 + lane * 8;
+    if (c >= C) return;
+    // V as k-pairs: vp[kk][i] = (V[2kk][c+i], V[2kk+1][c+i]) so one v_dot2_f32_f16 does two MACs with an fp32 accumulator
+    h16x2 vp[RP / 2][8];
+#pragma unroll
+    for (int kk = 0; kk < RP / 2; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vp[kk][i] = (h16x2)(h16)0;
+        if (2 * kk < r) {
+            if (VT) {
+                if (r != RP) {      // generic: 4-byte gathers
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) vp[kk][i] = *reinterpret_cast<const h16x2*>(it.V + (size_t)(c + i) * r + 2 * kk);
+                }
+            } else {
+                const h16x8 lo = *reinterpret_cast<const h16x8*>(it.V + (size_t)(2 * kk) * C + c);
+                const h16x8 hi = *reinterpret_cast<const h16x8*>(it.V + (size_t)(2 * kk + 1) * C + c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { vp[kk][i][0] = lo[i]; vp[kk][i][1] = hi[i]; }
+            }
+        }
+    }
+    if (VT && r == RP) {
+        // V^T rows c .. c+7 are one contiguous block of 8 * RP halves: coalesced 16-byte loads, then pick the pairs
+        const h16x8* blk = reinterpret_cast<const h16x8*>(it.V + (size_t)c * RP);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int q = 0; q < RP / 8; ++q) {
+                const h16x8 t = blk[i * (RP / 8) + q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vp[q * 4 + e][i][0] = t[2 * e]; vp[q * 4 + e][i][1] = t[2 * e + 1]; }
+            }
+        }
+    }
+    const int r0 = blockIdx.y * 32, r1 = min(N, r0 + 32);
+    for (int rr = r0 + w; rr < r1; rr += 4) {
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        const h16x2* urow = reinterpret_cast<const h16x2*>(it.U + (size_t)rr * r);
+#pragma unroll
+        for (int kk = 0; kk < RP / 2; ++kk) {
+            if (2 * kk < r) {
+                const h16x2 u = urow[kk];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_fdot2(u, vp[kk][i], acc[i], false);
+            }
+        }
+        h16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (h16)acc[i];
+        if (it.base) o = __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(it.base + (size_t)rr * C + c)) + o;
+        __builtin_nontemporal_store(o, reinterpret_cast<h16x8*>(it.out + (size_t)rr * C + c));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+static int lr_rp(int rank) { return rank <= 8 ? 8 : (rank <= 16 ? 16 : 32); }
+
+static bool lr_shape_ok(int quantized, int N, int C, int rank) {
+    if (N <= 0 || C <= 0 || (C % 8) != 0 || rank < 2 || rank > 32 || (rank & 1)) return false;   // k-pairs: even rank
+    if (quantized && ((N % 2) || (C % 2) || (rank % 8))) return false;
+    return true;
+}
+
+#define LR_DISPATCH(RP_, CALL) do { if (RP_ == 8) { constexpr int RP = 8; CALL; } else if (RP_ == 16) { constexpr int RP = 16; CALL; } else { constexpr int RP = 32; CALL; } } while (0)
+
+extern "C" {
+
+size_t cfx_lr_packet_bytes(int quantized, int N, int C, int rank) {
+    if (!lr_shape_ok(quantized, N, C, rank)) return 0;
+    if (!quantized) return (size_t)(N + C) * rank * 2;
+    return (size_t)N * rank / 2 + 4 * rank + (size_t)C * rank / 2 + 4 * rank;
+}
+
+size_t cfx_lr_workspace_bytes(int quantized, int N, int C, int rank, int batch) {
+    if (!lr_shape_ok(quantized, N, C, rank) || batch < 1 || batch > LR_MAXB) return 0;
+    size_t per = lr_layout(N, C, lr_rp(rank)).total;
+    // the int4 factor quantiser's own scratch (min/max partials), for the larger factor
+    per += al256(cfx_workspace_bytes(CFX_CODEC_INT4, (N > C ? N : C) + ((N > C ? N : C) & 1), 32, 0, 1));
+    return per * batch;
+}
+
+static int lr_decode_launch(cfx_ctx* ctx, int N, int C, int rank, int batch, const LrDec* items, bool vt, hipStream_t s) {
+    LrDecBatch db;
+    memset(&db, 0, sizeof(db));
+    for (int i = 0; i < batch; ++i) db.it[i] = items[i];
+    const int RPv = lr_rp(rank);
+    const dim3 grid((C + 511) / 512, (N + 31) / 32, batch);
+    if (vt) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_DECODE, s, (k_lr_decode<RP, true>), grid, dim3(256), 0, s, db, N, C, rank));
+    else LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_DECODE, s, (k_lr_decode<RP, false>), grid, dim3(256), 0, s, db, N, C, rank));
+    return check_launch(ctx, "lr decode launch");
+}
+
+// init_q[i]: device pointer to a C x RP fp32 matrix (RP = 8/16/32 >= rank; columns >= rank zero) - the random start.
+int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, int flags, int batch, const cfx_comp_item* items,
+                          const void* const* init_q, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ctx || !items || !init_q) return fail(ctx, CFX_ERR_NULL, "lr compress: null ctx/items/init_q");
+    if (batch < 1 || batch > LR_MAXB) return fail(ctx, CFX_ERR_BATCH, "lr compress: batch out of range");
+    if (!lr_shape_ok(quantized, N, C, rank)) return fail(ctx, CFX_ERR_SHAPE, "lr compress: bad shape/rank");
+    const size_t need = cfx_lr_workspace_bytes(quantized, N, C, rank, batch);
+    if (!workspace || workspace_bytes < need) return fail(ctx, CFX_ERR_WORKSPACE, "lr compress: workspace too small");
+    const bool upd = flags & CFX_FLAG_UPDATE_CACHE;
+    const int RPv = lr_rp(rank);
+    const LrWs w = lr_layout(N, C, RPv);
+    const size_t per = need / batch;
+    LrBatch b;
+    memset(&b, 0, sizeof(b));
+    for (int i = 0; i < batch; ++i) {
+        if (!items[i].x || !items[i].packet || !init_q[i]) return fail(ctx, CFX_ERR_NULL, "lr compress: null x/packet/init_q");
+        if (upd && !items[i].new_base) return fail(ctx, CFX_ERR_NULL, "lr compress: UPDATE_CACHE needs new_base");
+        if (!AL16(items[i].x) || !AL16(items[i].base) || !AL16(items[i].new_base) || !AL16(items[i].packet) || !AL16(init_q[i]))
+            return fail(ctx, CFX_ERR_ALIGN, "lr compress: pointers must be 16-byte aligned");
+        b.it[i].x = (const h16*)items[i].x; b.it[i].base = (const h16*)items[i].base; b.it[i].new_base = (h16*)items[i].new_base;
+        b.it[i].packet = items[i].packet; b.it[i].q0 = (const float*)init_q[i]; b.it[i].ws = (char*)workspace + per * i;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t E = (size_t)N * C;
+    const int nparts = (C + 31) / 32;
+    LAUNCH(ctx, KID_LR_PREP, s, k_lr_prep, dim3((unsigned)((E / 8 + 255) / 256), batch), dim3(256), 0, s, b, E, w.D);
+    const dim3 g_aq((N + 7) / 8, 4, batch), g_aty(nparts, batch), g_chol(batch), g_apc((C + 255) / 256, batch), g_apn((N + 255) / 256, batch);
+    for (int iter = 0; iter < 2; ++iter) {
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, iter == 0 ? 1 : 0));
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 0));
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(1024), 0, s, b, rank, nparts, w.Gp, w.T));
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply<RP>), g_apc, dim3(256), 0, s, b, C, rank, w.Zb, 1, w.T, 0, w.Qa, 0, (size_t)0));
+    }
+    LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0));
+    LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 1));
+    LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(1024), 0, s, b, rank, nparts, w.Gp, w.T));
+    int rc = CFX_OK;
+    LrDec dec[LR_MAXB];
+    if (!quantized) {
+        // U (N x r) and V (r x C) straight into the packet: [U | V]
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply<RP>), g_apn, dim3(256), 0, s, b, N, rank, w.Y, 4, w.T, 1, (size_t)0, 1, (size_t)0));
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply<RP>), g_apc, dim3(256), 0, s, b, C, rank, w.Zb, 1, w.T, 2, (size_t)0, 1, (size_t)N * rank));
+        for (int i = 0; i < batch; ++i) {
+            dec[i].U = (const h16*)items[i].packet; dec[i].V = (const h16*)items[i].packet + (size_t)N * rank;
+            dec[i].base = (const h16*)items[i].base; dec[i].out = (h16*)items[i].new_base;
+        }
+    } else {
+        // U16 (N x r), V^T16 (C x r) -> int4 factor quantiser (the native int4 kernel) -> packet sections; then the dequantised
+        // factors (what the receiver will see) feed the error-feedback decode
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply<RP>), g_apn, dim3(256), 0, s, b, N, rank, w.Y, 4, w.T, 1, w.U16, 0, (size_t)0));
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply<RP>), g_apc, dim3(256), 0, s, b, C, rank, w.Zb, 1, w.T, 1, w.V16, 0, (size_t)0));
+        const size_t secU = (size_t)N * rank / 2 + 4 * rank, secV = (size_t)C * rank / 2 + 4 * rank;       // bytes
+        const size_t i4ws_off = w.total;
+        // one batched launch sequence per factor side (U sections are 16-byte aligned in the packet; V sections may start
+        // at an address that is only 8-byte aligned, so they are quantised into scratch and copied)
+        cfx_comp_item cu[LR_MAXB], cv[LR_MAXB];
+        cfx_decomp_item du[LR_MAXB], dv[LR_MAXB];
+        for (int i = 0; i < batch; ++i) {
+            char* wsi = (char*)workspace + per * i;
+            char* pk = (char*)items[i].packet;
+            cu[i] = {wsi + w.U16, nullptr, nullptr, pk};
+            cv[i] = {wsi + w.V16, nullptr, nullptr, wsi + w.Vsec};
+            du[i] = {pk, nullptr, wsi + w.Uq};
+            dv[i] = {wsi + w.Vsec, nullptr, wsi + w.Vq};
+            dec[i].U = (const h16*)(wsi + w.Uq);
+            dec[i].V = (const h16*)(wsi + w.Vq);
+            dec[i].base = (const h16*)items[i].base; dec[i].out = (h16*)items[i].new_base;
+        }
+        // the int4 kernels' scratch of tensor 0 .. batch-1 is contiguous when taken with stride `per`; give them one block
+        void* i4ws = (char*)workspace + i4ws_off;
+        const size_t i4bytes = per * batch - i4ws_off;
+        if (i4bytes < cfx_workspace_bytes(CFX_CODEC_INT4, N, rank, 0, batch) || i4bytes < cfx_workspace_bytes(CFX_CODEC_INT4, C, rank, 0, batch)) {
+            // not enough room for a batched call: one tensor at a time
+            for (int i = 0; i < batch; ++i) {
+                char* wsi = (char*)workspace + per * i;
+                rc = cfx_compress_batch(ctx, CFX_CODEC_INT4, N, rank, 0, 0, 1, &cu[i], wsi + i4ws_off, per - i4ws_off, stream);
+                if (rc != CFX_OK) return rc;
+                rc = cfx_compress_batch(ctx, CFX_CODEC_INT4, C, rank, 0, 0, 1, &cv[i], wsi + i4ws_off, per - i4ws_off, stream);
+                if (rc != CFX_OK) return rc;
+            }
+        } else {
+            rc = cfx_compress_batch(ctx, CFX_CODEC_INT4, N, rank, 0, 0, batch, cu, i4ws, i4bytes, stream);
+            if (rc != CFX_OK) return rc;
+            rc = cfx_compress_batch(ctx, CFX_CODEC_INT4, C, rank, 0, 0, batch, cv, i4ws, i4bytes, stream);
+            if (rc != CFX_OK) return rc;
+        }
+        for (int i = 0; i < batch; ++i)
+            (void)hipMemcpyAsync((char*)items[i].packet + secU, (char*)workspace + per * i + w.Vsec, secV, hipMemcpyDeviceToDevice, s);
+        if (upd && !(flags & CFX_FLAG_NO_EF)) {
+            rc = cfx_decompress_batch(ctx, CFX_CODEC_INT4, N, rank, 0, batch, du, stream);
+            if (rc != CFX_OK) return rc;
+            rc = cfx_decompress_batch(ctx, CFX_CODEC_INT4, C, rank, 0, batch, dv, stream);
+            if (rc != CFX_OK) return rc;
+        }
+    }
+    if (upd) {
+        if (flags & CFX_FLAG_NO_EF) {
+            for (int i = 0; i < batch; ++i)
+                if (items[i].new_base != items[i].x) (void)hipMemcpyAsync(items[i].new_base, items[i].x, E * 2, hipMemcpyDeviceToDevice, s);
+        } else {
+            rc = lr_decode_launch(ctx, N, C, rank, batch, dec, quantized != 0, s);
+            if (rc != CFX_OK) return rc;
+        }
+    }
+    return check_launch(ctx, "lr compress launch");
+}
+
+int cfx_lr_decompress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, int batch, const cfx_decomp_item* items,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "lr decompress: null ctx/items");
+    if (batch < 1 || batch > LR_MAXB) return fail(ctx, CFX_ERR_BATCH, "lr decompress: batch out of range");
+    if (!lr_shape_ok(quantized, N, C, rank)) return fail(ctx, CFX_ERR_SHAPE, "lr decompress: bad shape/rank");
+    hipStream_t s = (hipStream_t)stream;
+    LrDec dec[LR_MAXB];
+    for (int i = 0; i < batch; ++i) {
+        if (!items[i].packet || !items[i].recon) return fail(ctx, CFX_ERR_NULL, "lr decompress: null packet/recon");
+        if (!AL16(items[i].packet) || !AL16(items[i].recon) || !AL16(items[i].base)) return fail(ctx, CFX_ERR_ALIGN, "lr decompress: pointers must be 16-byte aligned");
+    }
+    if (!quantized) {
+        for (int i = 0; i < batch; ++i) {
+            dec[i].U = (const h16*)items[i].packet; dec[i].V = (const h16*)items[i].packet + (size_t)N * rank;
+            dec[i].base = (const h16*)items[i].base; dec[i].out = (h16*)items[i].recon;
+        }
+        return lr_decode_launch(ctx, N, C, rank, batch, dec, false, s);
+    }
+    const size_t need = cfx_lr_workspace_bytes(quantized, N, C, rank, batch);
+    if (!workspace || workspace_bytes < need) return fail(ctx, CFX_ERR_WORKSPACE, "lr decompress: workspace too small");
+    const LrWs w = lr_layout(N, C, lr_rp(rank));
+    const size_t per = need / batch;
+    const size_t secU = (size_t)N * rank / 2 + 4 * rank, secV = (size_t)C * rank / 2 + 4 * rank;
+    cfx_decomp_item du[LR_MAXB], dv[LR_MAXB];
+    for (int i = 0; i < batch; ++i) {
+        char* wsi = (char*)workspace + per * i;
+        const char* pk = (const char*)items[i].packet;
+        const void* vsec = pk + secU;
+        if (!AL16(vsec)) {
+            (void)hipMemcpyAsync(wsi + w.Vsec, vsec, secV, hipMemcpyDeviceToDevice, s);
+            vsec = wsi + w.Vsec;
+        }
+        du[i] = {pk, nullptr, wsi + w.Uq};
+        dv[i] = {vsec, nullptr, wsi + w.Vq};
+        dec[i].U = (const h16*)(wsi + w.Uq); dec[i].V = (const h16*)(wsi + w.Vq);
+        dec[i].base = (const h16*)items[i].base; dec[i].out = (h16*)items[i].recon;
+    }
+    int rc = cfx_decompress_batch(ctx, CFX_CODEC_INT4, N, rank, 0, batch, du, stream);
+    if (rc != CFX_OK) return rc;
+    rc = cfx_decompress_batch(ctx, CFX_CODEC_INT4, C, rank, 0, batch, dv, stream);
+    if (rc != CFX_OK) return rc;
+    return lr_decode_launch(ctx, N, C, rank, batch, dec, true, s);
+}
+
+}  // extern "C"

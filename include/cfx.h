@@ -114,6 +114,22 @@ int cfx_compress(cfx_ctx* ctx, int codec, const void* x, const void* base, void*
 int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base, void* recon,
                    int N, int C, int param, void* stream);
 
+/* Low-rank residual codecs (compactfusion_amd/csrc/cfx_lowrank.hip).
+ *   cfx_lr_compress_batch   replaces subspace_iter (xfuser/compact/compress_lowrank.py:14-61) + the LOW_RANK / LOW_RANK_Q
+ *                           encode of slowpath.py:54-75 + the residual / error-feedback flow of main.py:227-233
+ *   cfx_lr_decompress_batch replaces slowpath.py:120-131, :151-164 (torch.matmul(u, v), int4 factor dequant) + main.py:376
+ * quantized = 0: LOW_RANK   wire [ U (N,r) fp16 | V (r,C) fp16 ]
+ * quantized = 1: LOW_RANK_Q wire [ int4(U) (N/2,r) | scale r | min r | int4(V^T) (C/2,r) | scale r | min r ]   (rank % 8 == 0)
+ * rank even, <= 32.  init_q[i] -> device C x RP fp32 row-major start matrix, RP = 8/16/32 = rank rounded up, columns >= rank
+ * zero; it need not be orthonormal (the iteration only sees its span).  Workspace from cfx_lr_workspace_bytes. */
+size_t cfx_lr_packet_bytes(int quantized, int N, int C, int rank);
+size_t cfx_lr_workspace_bytes(int quantized, int N, int C, int rank, int batch);
+int    cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, int flags, int batch,
+                             const cfx_comp_item* items, const void* const* init_q,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int    cfx_lr_decompress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, int batch,
+                               const cfx_decomp_item* items, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Native per-launch timing.  When enabled, every `stride`-th launch of a kernel whose id bit is set in kernel_mask
  * is bracketed by hipEvents recorded on the launch stream (up to `capacity` records; capacity 0 disables).  An event
  * pair costs ~2-5 us of stream time, hence the stride.
@@ -121,7 +137,7 @@ int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base
  * Kernel ids: 1 absmean_stats<bits>, 2 absmean_stats, 3 absmean_finalize, 4 binary_dequant, 5 int2_quant,
  * 6 int2_dequant, 7 minmax_stats, 8 minmax_finalize, 9 int8_quant, 10 int8_dequant, 11 int4_quant,
  * 12 int4_dequant, 13 topk_compress, 14 topk_decompress, 15 copy_probe, 16 binary_dequant launched as the
- * sender's error-feedback update. */
+ * sender's error-feedback update, 17-22 low-rank chain (prep, aq, aty, chol, apply, decode). */
 int         cfx_profile_enable(cfx_ctx* ctx, int capacity, unsigned kernel_mask, int stride);
 int         cfx_profile_read(cfx_ctx* ctx, int* kernel_ids, float* ms, int cap);
 const char* cfx_kernel_name(int kernel_id);

@@ -36,10 +36,66 @@ def decompress_batch(codec, packets, bases, recons, N, C, param=0, stream=None):
         r.view(torch.int16).numpy().view(np.uint16).reshape(N, C)[:] = R.bits(rec)
 
 
+# ---- low-rank family: the reference algorithm (compress_lowrank.py:14-61, slowpath.py:54-75,151-164) in torch on CPU ----
+def _lr_sections(quantized, N, C, r):
+    if not quantized:
+        return (0, N * r), (N * r, C * r)
+    nu = N * r // 4 + 2 * r
+    return (0, nu), (nu, C * r // 4 + 2 * r)
+
+
+def _q4(m):
+    rows, r = m.shape
+    pkt, _ = R.compress("int4", _np16(m).reshape(rows, r), None)
+    return torch.from_numpy(pkt.view(np.int16).copy()).view(torch.float16)
+
+
+def _dq4(sec, rows, r):
+    rec = R.decompress("int4", _np16(sec).reshape(-1).copy(), rows, r)
+    return torch.from_numpy(R.bits(rec).view(np.int16).copy()).view(torch.float16)
+
+
+def _lr_decode(quantized, pkt, N, C, r):
+    (ou, nu), (ov, nv) = _lr_sections(quantized, N, C, r)
+    if not quantized:
+        return torch.matmul(pkt[ou:ou + nu].view(N, r).float(), pkt[ov:ov + nv].view(r, C).float()).half()
+    return torch.matmul(_dq4(pkt[ou:ou + nu], N, r).float(), _dq4(pkt[ov:ov + nv], C, r).float().t()).half()
+
+
+def lr_compress_batch(quantized, xs, bases, new_bases, packets, init_qs, N, C, rank, update_cache=True, ef=True, stream=None):
+    for x, b, nb, p, q0 in zip(xs, bases, new_bases, packets, init_qs):
+        d = x if b is None else x - b
+        Af = d.float()
+        Q = q0[:, :rank].float()
+        for _ in range(2):
+            Q, _ = torch.linalg.qr(Af.t() @ (Af @ Q))
+        U, _ = torch.linalg.qr(Af @ Q)
+        V = U.t() @ Af
+        U, V = U.half(), V.half()
+        (ou, nu), (ov, nv) = _lr_sections(quantized, N, C, rank)
+        if not quantized:
+            p[ou:ou + nu] = U.reshape(-1)
+            p[ov:ov + nv] = V.reshape(-1)
+        else:
+            p[ou:ou + nu] = _q4(U)
+            p[ov:ov + nv] = _q4(V.t().contiguous())
+        if update_cache and nb is not None:
+            recv = _lr_decode(quantized, p, N, C, rank)
+            nb.copy_(x if not ef else (recv if b is None else b + recv))
+
+
+def lr_decompress_batch(quantized, packets, bases, recons, N, C, rank, stream=None):
+    for p, b, r in zip(packets, bases, recons):
+        recv = _lr_decode(quantized, p, N, C, rank)
+        r.copy_(recv if b is None else b + recv)
+
+
 def install(monkeypatch):
     from compactfusion_amd import codecs
     monkeypatch.setattr(codecs, "compress_batch", compress_batch)
     monkeypatch.setattr(codecs, "decompress_batch", decompress_batch)
+    monkeypatch.setattr(codecs, "lr_compress_batch", lr_compress_batch)
+    monkeypatch.setattr(codecs, "lr_decompress_batch", lr_decompress_batch)
 
 
 def install_plain():
@@ -47,3 +103,5 @@ def install_plain():
     from compactfusion_amd import codecs
     codecs.compress_batch = compress_batch
     codecs.decompress_batch = decompress_batch
+    codecs.lr_compress_batch = lr_compress_batch
+    codecs.lr_decompress_batch = lr_decompress_batch

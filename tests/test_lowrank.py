@@ -69,40 +69,56 @@ def test_subspace_iter_vs_svd():
 def _check_wire(dev):
     from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T
     from compactfusion_amd.compact import lowrank as LR
+    from compactfusion_amd.compact.compress_quantize import quantize_int4
     from compactfusion_amd.compact.slowpath import sim_compress, slowpath_compress, slowpath_decompress
     N, C = 64, 256
     tag = f"{N}x{C}_s42"
     d = _delta(tag, N, C, dev)
-    # LOW_RANK: packet = [U | V], decode = U @ V
-    torch.manual_seed(42)
-    pkt = slowpath_compress(d, T.LOW_RANK, rank=8)
-    assert pkt.numel() == (N + C) * 8 == G.get(FN, f"{tag}/lr8/packet").size
-    dec = slowpath_decompress(pkt, (N, C), T.LOW_RANK, rank=8)
-    assert rel(dec, pkt[:N * 8].view(N, 8).float() @ pkt[N * 8:].view(8, C).float()) < 1e-3
-    assert 0.3 < rel(dec, d) < 1.0                       # rank 8 of a noise matrix keeps little energy; sanity only
+    for r in (8, 32):
+        # same start matrix as the reference run -> same subspace -> same projection U V (QR conventions do not matter)
+        LR.set_init_q(torch.from_numpy(G.get(FN, f"{tag}/r{r}/q0")).to(dev))
+        try:
+            pkt = slowpath_compress(d, T.LOW_RANK, rank=r)
+        finally:
+            LR.set_init_q(None)
+        assert pkt.numel() == (N + C) * r
+        U, V = pkt[:N * r].view(N, r), pkt[N * r:].view(r, C)
+        gU, gV = t16(G.get(FN, f"{tag}/r{r}/U")).to(dev), t16(G.get(FN, f"{tag}/r{r}/V")).to(dev)
+        assert rel(U.float() @ V.float(), gU.float() @ gV.float()) < 3e-3, r
+        assert torch.allclose(U.float().t() @ U.float(), torch.eye(r, device=dev), atol=5e-3)
+        dec = slowpath_decompress(pkt, (N, C), T.LOW_RANK, rank=r)
+        assert rel(dec, U.float() @ V.float()) < 1e-3            # decode = fp16(U @ V)
+        assert rel(dec, t16(G.get(FN, f"{tag}/r{r}/UV")).to(dev)) < 3e-3
+    assert G.get(FN, f"{tag}/lr8/packet").size == (N + C) * 8
     # LOW_RANK_Q: section sizes of slowpath.py:120-131 and decode of the REFERENCE's own packet
     gp = t16(G.get(FN, f"{tag}/lrq32/packet")).to(dev)
     assert gp.numel() == LR.packet_halves(LR.LOW_RANK_Q_ID, 32, N, C) == N * 32 // 4 + 64 + C * 32 // 4 + 64
     mine = slowpath_decompress(gp, (N, C), T.LOW_RANK_Q, rank=32)
     assert rel(mine, t16(G.get(FN, f"{tag}/lrq32/dec")).to(dev)) < 2e-3
-    # int4 factor quantiser on the reference's factors reproduces the reference's packet sections bit for bit
+    # the int4 factor quantiser on the reference's factors reproduces the reference's packet sections bit for bit
     gU, gV = t16(G.get(FN, f"{tag}/r32/U")).to(dev), t16(G.get(FN, f"{tag}/r32/V")).to(dev)
-    sec = torch.empty(N * 32 // 4 + 64, dtype=torch.float16, device=dev)
-    LR._q4(gU, sec)
-    want = np.concatenate([G.get(FN, f"{tag}/r32/qU").reshape(-1).view(np.uint16), G.get(FN, f"{tag}/r32/sU").reshape(-1),
-                           G.get(FN, f"{tag}/r32/mU").reshape(-1)])
-    assert np.array_equal(sec.cpu().view(torch.int16).numpy().view(np.uint16), want)
-    sec = torch.empty(C * 32 // 4 + 64, dtype=torch.float16, device=dev)
-    LR._q4(gV.t(), sec)
-    want = np.concatenate([G.get(FN, f"{tag}/r32/qV").reshape(-1).view(np.uint16), G.get(FN, f"{tag}/r32/sV").reshape(-1),
-                           G.get(FN, f"{tag}/r32/mV").reshape(-1)])
-    assert np.array_equal(sec.cpu().view(torch.int16).numpy().view(np.uint16), want)
-    # simulate == decode(encode) under the same seed (compress_slowpath_test.py:128-183, INT4_TOL = 0.05)
-    torch.manual_seed(7)
-    sim = sim_compress(d, T.LOW_RANK_Q, rank=32)
-    torch.manual_seed(7)
-    dec = slowpath_decompress(slowpath_compress(d, T.LOW_RANK_Q, rank=32), (N, C), T.LOW_RANK_Q, rank=32)
+    for mat, nm in ((gU, "U"), (gV.t().contiguous(), "V")):
+        q, s_, m_ = quantize_int4(mat)
+        assert np.array_equal(q.cpu().numpy(), G.get(FN, f"{tag}/r32/q{nm}"))
+        assert np.array_equal(s_.cpu().view(torch.int16).numpy().view(np.uint16), G.get(FN, f"{tag}/r32/s{nm}"))
+        assert np.array_equal(m_.cpu().view(torch.int16).numpy().view(np.uint16), G.get(FN, f"{tag}/r32/m{nm}"))
+    # simulate == decode(encode) under the same start (compress_slowpath_test.py:128-183, INT4_TOL = 0.05)
+    q0 = torch.randn(C, 32, generator=torch.Generator().manual_seed(5))
+    LR.set_init_q(q0)
+    try:
+        sim = sim_compress(d, T.LOW_RANK_Q, rank=32)
+        dec = slowpath_decompress(slowpath_compress(d, T.LOW_RANK_Q, rank=32), (N, C), T.LOW_RANK_Q, rank=32)
+    finally:
+        LR.set_init_q(None)
     assert rel(dec, sim) < 0.05
+    # a rank-deficient residual (rank 3 < r = 8) must not produce NaNs and is reproduced almost exactly
+    g = torch.Generator().manual_seed(9)
+    low = (torch.randn(N, 3, generator=g) @ torch.randn(3, C, generator=g)).half().to(dev)
+    dec = slowpath_decompress(slowpath_compress(low, T.LOW_RANK, rank=8), (N, C), T.LOW_RANK, rank=8)
+    assert torch.isfinite(dec.float()).all() and rel(dec, low) < 5e-3
+    zero = torch.zeros(N, C, dtype=torch.float16, device=dev)
+    dec = slowpath_decompress(slowpath_compress(zero, T.LOW_RANK, rank=8), (N, C), T.LOW_RANK, rank=8)
+    assert torch.isfinite(dec.float()).all() and float(dec.float().abs().max()) == 0.0
 
 
 def test_lowrank_wire_cpu(monkeypatch):

@@ -1,23 +1,39 @@
 #!/usr/bin/env python3
-"""Developer timing of the low-rank codec path on the GPU box."""
-import os, sys, time
+"""Developer timing of the native low-rank codec chain on the GPU box."""
+import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from compactfusion_amd.compact import lowrank as LR
+from compactfusion_amd import _lib, codecs as K
 
-def t(fn, n=20):
-    for _ in range(3): fn()
+lib = _lib.load()
+ctx = K.context(0)
+
+def t(fn, n=30):
+    for _ in range(5): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 
+def prof(fn, n=10):
+    lib.cfx_profile_enable(ctx, 4096, 0xffffffff, 1)
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    ids = (ctypes.c_int * 4096)(); ms = (ctypes.c_float * 4096)()
+    k = lib.cfx_profile_read(ctx, ids, ms, 4096)
+    lib.cfx_profile_enable(ctx, 0, 0, 1)
+    agg = {}
+    for i in range(k): agg.setdefault(lib.cfx_kernel_name(ids[i]).decode(), []).append(ms[i] * 1e3)
+    return {a: (round(sum(v) / len(v), 2), len(v) // n) for a, v in agg.items()}
+
 for (N, C) in [(544, 3072), (512, 1536), (4096, 1152)]:
-    x = torch.randn(N, C, device="cuda").half(); b = (x.float() + 0.1 * torch.randn(N, C, device="cuda")).half()
-    d = (x - b)
-    for cid, r in ((LR.LOW_RANK_ID, 8), (LR.LOW_RANK_ID, 16), (LR.LOW_RANK_Q_ID, 32)):
-        pkt = torch.empty(LR.packet_halves(cid, r, N, C), dtype=torch.float16, device="cuda")
-        out = torch.empty_like(x)
-        Af = d.float(); Q = torch.linalg.qr(torch.randn(C, r, device="cuda"))[0]
-        print(f"({N},{C}) cid {cid} r={r}: compress {t(lambda: LR.compress(cid, r, x, b, b.clone(), pkt, True)):8.1f} us | "
-              f"decompress {t(lambda: LR.decompress(cid, r, pkt, b, out)):7.1f} us | subspace_iter {t(lambda: LR.subspace_iter(d, r, 2)):8.1f} us | "
-              f"qr(C,r) {t(lambda: torch.linalg.qr(Af.t() @ (Af @ Q))):7.1f} us | A@Q {t(lambda: Af @ Q):6.1f} us | At@Y {t(lambda: Af.t() @ (Af @ Q)):6.1f} us")
+    for B in (2,):
+        xs = [torch.randn(N, C, device="cuda").half() for _ in range(B)]
+        bs = [(x.float() + 0.1 * torch.randn(N, C, device="cuda")).half() for x in xs]
+        for q, r in ((False, 8), (False, 16), (True, 32)):
+            pk = [torch.empty(K.lr_packet_halves(q, N, C, r), dtype=torch.float16, device="cuda") for _ in range(B)]
+            q0 = [torch.randn(C, K.lr_rank_pad(r), device="cuda") for _ in range(B)]
+            nb = [b.clone() for b in bs]
+            f = lambda: K.lr_compress_batch(q, xs, bs, nb, pk, q0, N, C, r, True)
+            out = [torch.empty_like(x) for x in xs] * 7
+            g = lambda: K.lr_decompress_batch(q, (pk * 7)[:14], (bs * 7)[:14], out[:14], N, C, r)
+            print(f"({N},{C}) q={int(q)} r={r} batch {B}: compress {t(f):7.1f} us | decompress(14) {t(g):7.1f} us | {prof(f)} | {prof(g)}", flush=True)
