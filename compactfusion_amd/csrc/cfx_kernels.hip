@@ -147,9 +147,12 @@ __global__ __launch_bounds__(NTHR) void k_absmean_stats(BatchC batch, int N, int
     unsigned char* bitsout = (unsigned char*)it.packet;
     const int C8 = C >> 3;
 
-    u64 col[8];
+    // Per-thread partial sums are kept in fp64: every |d| is a multiple of 2^-24 below 2^16 and a thread adds at most a few
+    // hundred of them, so the fp64 sums are EXACT (< 2^53 units) and convert losslessly to the integer unit counts below;
+    // two conversions + two fp64 adds per element cost about half the VALU time of the integer formulation.
+    double col[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) col[i] = 0;
+    for (int i = 0; i < 8; ++i) col[i] = 0.0;
 
     for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL_S) {
         h16x8 xv[UNROLL_S], bv[UNROLL_S];
@@ -171,14 +174,17 @@ __global__ __launch_bounds__(NTHR) void k_absmean_stats(BatchC batch, int N, int
             rs[j] = 0;
             if (rr < t.r1 && t.act) {
                 const h16x8 d = xv[j] - bv[j];
+                const h16x8 a = habs8(d);
                 unsigned byte = 0;
+                double rsum = 0.0;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     byte |= (d[i] >= (h16)0 ? 1u : 0u) << i;
-                    const u64 u = habs_units(hbits(d[i]));
-                    col[i] += u;
-                    rs[j] += u;
+                    const double v = (double)(float)a[i];
+                    col[i] += v;
+                    rsum += v;
                 }
+                rs[j] = (u64)(rsum * 16777216.0);
                 if (EMIT_BITS) bitsout[(size_t)rr * C8 + (t.c >> 3)] = (unsigned char)byte;
             }
         }
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(NTHR) void k_absmean_stats(BatchC batch, int N, int
     }
     __shared__ u64 sm[WAVES][TILE_C];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sm[t.w][i * 64 + t.lane] = col[i];   // [i][lane]: conflict-free
+    for (int i = 0; i < 8; ++i) sm[t.w][i * 64 + t.lane] = (u64)(col[i] * 16777216.0);   // exact; [i][lane]: conflict-free
     __syncthreads();
     for (int k = threadIdx.x; k < TILE_C; k += NTHR) {      // k = channel within the tile: coalesced global writes
         const int s = (k & 7) * 64 + (k >> 3);
@@ -858,7 +864,6 @@ static bool shape_ok(int codec, int N, int C, int param) {
 }
 
 static int auto_rows(const cfx_ctx* ctx, int N, int C, int batch, bool stats) {
-    (void)N; (void)C; (void)batch;
     if (ctx && ctx->rows_per_tile > 0) {
         int r = ctx->rows_per_tile;
         if (stats && r < 16) r = 16;
@@ -866,7 +871,14 @@ static int auto_rows(const cfx_ctx* ctx, int N, int C, int batch, bool stats) {
     }
     // Measured on MI355X (tools/kbench.hip, tools/microbench.py): short tiles win - one or two wave steps per
     // workgroup, thousands of workgroups - because these launches last 5-20 us and ramp/tail dominate long tiles.
-    return stats ? WAVES * UNROLL_S : WAVES * UNROLL;
+    if (!stats) return WAVES * UNROLL;
+    // statistics pass: every 16 rows of tile height cost one more partial per column for the finalize kernel to reduce,
+    // so tall tensors take taller tiles as long as >= 768 workgroups remain (S4 (4448,3072): R = 64, P = 70 instead of 278)
+    const int CB = (C + TILE_C - 1) / TILE_C;
+    const int cands[3] = {128, 64, 32};
+    for (int i = 0; i < 3; ++i)
+        if ((long)CB * ((N + cands[i] - 1) / cands[i]) * batch >= 768) return cands[i];
+    return WAVES * UNROLL_S;
 }
 
 extern "C" {
