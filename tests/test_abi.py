@@ -73,3 +73,39 @@ def test_cpu_tensors_are_refused():
     from compactfusion_amd._lib import CfxError
     with pytest.raises(CfxError):
         K.compress(1, torch.zeros(8, 64, dtype=torch.float16), None, 8, 64)
+
+
+def test_plan_building_without_gpu():
+    """cfx_plan_* argument handling (no launches): op indices, copy, bounds."""
+    from compactfusion_amd import _lib
+    lib = _lib.load()
+    ctx = lib.cfx_create(0)
+    plan = lib.cfx_plan_create(ctx)
+    assert plan and lib.cfx_plan_size(plan) == 0
+    c = (_lib.CompItem * 2)(_lib.CompItem(0x1000, 0x2000, None, 0x3000), _lib.CompItem(0x4000, 0x5000, None, 0x6000))
+    d = (_lib.DecompItem * 16)(*[_lib.DecompItem(0x3000, 0x7000 + 0x1000 * i, 0x7000 + 0x1000 * i) for i in range(16)])
+    assert lib.cfx_plan_add_compress(plan, 1, 544, 3072, 0, 0, 2, c, 0x9000, 1 << 20) == 0
+    assert lib.cfx_plan_add_decompress(plan, 1, 544, 3072, 0, 16, d) == 1
+    assert lib.cfx_plan_add_decompress(plan, 1, 544, 3072, 0, 17, d) == -5            # batch too large
+    assert lib.cfx_plan_add_compress(plan, 1, 544, 3077, 0, 0, 2, c, 0x9000, 1 << 20) == -2   # bad shape
+    assert lib.cfx_plan_size(plan) == 2
+    other = lib.cfx_plan_create(ctx)
+    assert lib.cfx_plan_copy_op(other, plan, 1) == 0 and lib.cfx_plan_copy_op(other, plan, 0) == 1
+    assert lib.cfx_plan_copy_op(other, plan, 5) == -5
+    assert lib.cfx_plan_add_wait(other, 0) == -5                                       # op 0 is not an all-gather
+    assert lib.cfx_plan_set_exchange_stream(other, 7) == -5
+    assert lib.cfx_plan_set_exchange_stream(other, 0) == 0
+    assert lib.cfx_plan_run(plan, 1, 5, None) == -5                                     # range out of bounds
+    lib.cfx_plan_destroy(other)
+    lib.cfx_plan_destroy(plan)
+    lib.cfx_destroy(ctx)
+
+
+def test_lowrank_sizes_without_gpu():
+    from compactfusion_amd import _lib
+    lib = _lib.load()
+    assert lib.cfx_lr_packet_bytes(0, 544, 3072, 8) == (544 + 3072) * 8 * 2            # SURVEY.md §8 a11: 57 856 B
+    assert lib.cfx_lr_packet_bytes(1, 544, 3072, 32) == 2 * (544 * 32 // 4 + 64 + 3072 * 32 // 4 + 64)
+    assert lib.cfx_lr_packet_bytes(0, 544, 3072, 7) == 0 and lib.cfx_lr_packet_bytes(1, 544, 3072, 12) == 0
+    assert lib.cfx_lr_packet_bytes(0, 544, 3072, 34) == 0
+    assert lib.cfx_lr_workspace_bytes(0, 544, 3072, 8, 2) > 2 * 544 * 3072 * 2

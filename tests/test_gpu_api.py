@@ -284,3 +284,68 @@ def test_ring_schedules_two_processes_one_gpu(tmp_path):
             for q in range(2):
                 assert np.array_equal(res[r][f"relay/s{s}/state_k_{q}"], res[r][f"gather/s{s}/state_k_{q}"])
                 assert np.array_equal(res[0][f"gather/s{s}/state_k_{q}"], res[1][f"gather/s{s}/state_k_{q}"])
+
+
+# ---- part 4: native plan executor and the library-owned RCCL communicator ------------------------------------------------------
+def test_plan_replay_equals_direct_calls():
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    ctx = K.context(0)
+    N, C, B = 96, 1024, 3
+    g = torch.Generator().manual_seed(4)
+    xs = [torch.randn(N, C, generator=g).half().cuda() for _ in range(B)]
+    bs = [(x.float() + 0.1 * torch.randn(N, C, generator=g).cuda()).half() for x in xs]
+    ref_b = [b.clone() for b in bs]
+    pk_ref = [torch.zeros(K.packet_halves(2, N, C), dtype=torch.float16, device="cuda") for _ in range(B)]
+    K.compress_batch(2, xs, ref_b, ref_b, pk_ref, N, C, update_cache=True)
+    peers_ref = [b.clone() for b in bs]
+    K.decompress_batch(2, pk_ref, peers_ref, peers_ref, N, C)
+    # the same through a plan
+    own = [b.clone() for b in bs]
+    peers = [b.clone() for b in bs]
+    pk = [torch.zeros_like(p) for p in pk_ref]
+    wsb = lib.cfx_workspace_bytes(2, N, C, 0, B)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    plan = lib.cfx_plan_create(ctx)
+    c = (_lib.CompItem * B)(*[_lib.CompItem(xs[i].data_ptr(), own[i].data_ptr(), own[i].data_ptr(), pk[i].data_ptr()) for i in range(B)])
+    d = (_lib.DecompItem * B)(*[_lib.DecompItem(pk[i].data_ptr(), peers[i].data_ptr(), peers[i].data_ptr()) for i in range(B)])
+    assert lib.cfx_plan_add_compress(plan, 2, N, C, 0, 1, B, c, ws.data_ptr(), wsb) == 0
+    assert lib.cfx_plan_add_decompress(plan, 2, N, C, 0, B, d) == 1
+    assert lib.cfx_plan_run(plan, 0, 2, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    for i in range(B):
+        assert torch.equal(pk[i].view(torch.int16), pk_ref[i].view(torch.int16))
+        assert torch.equal(own[i].view(torch.int16), ref_b[i].view(torch.int16))
+        assert torch.equal(peers[i].view(torch.int16), peers_ref[i].view(torch.int16))
+    lib.cfx_plan_destroy(plan)
+
+
+def test_native_comm_single_rank(tmp_path):
+    """libcfx's own RCCL communicator (1 rank): unique id, init, all-gather through a plan on every stream mode."""
+    import torch.distributed as dist
+    from compactfusion_amd import _lib, codecs as K
+    from compactfusion_amd.exchange import NativeComm
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method=f"file://{tmp_path}/rdv", rank=0, world_size=1)
+        created = True
+    try:
+        comm = NativeComm(0)
+        comm.self_test()
+        lib = _lib.load()
+        ctx = K.context(0)
+        send = torch.arange(4096, dtype=torch.uint8, device="cuda")
+        for mode in (0, 1, 2):
+            recv = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+            plan = lib.cfx_plan_create(ctx)
+            assert lib.cfx_plan_set_exchange_stream(plan, mode) == 0
+            g0 = lib.cfx_plan_add_all_gather(plan, comm.handle, send.data_ptr(), recv.data_ptr(), 4096)
+            assert g0 == 0 and lib.cfx_plan_add_wait(plan, g0) == 1
+            assert lib.cfx_plan_run(plan, 0, 2, torch.cuda.current_stream().cuda_stream) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(recv, send), mode
+            lib.cfx_plan_destroy(plan)
+        comm.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
