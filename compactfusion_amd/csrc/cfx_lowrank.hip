@@ -73,58 +73,77 @@ __global__ __launch_bounds__(256) void k_lr_prep(LrBatch b, size_t E, size_t off
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Ypart[g] (N x RP) = D[:, cols of group g] . Q[cols of group g, :]      Y = sum of the 4 group partials (summed, in fixed
-// order, by whoever reads Y).  grid (ceil(N/8), 4, batch): a workgroup owns 8 rows x every 4th 256-column chunk.
-//   thread = (kq: RP/8 consecutive k, rp: row pair, cp: c = cp mod 8) ; the 8 c-partials are reduced through LDS
+// order, by whoever reads Y).  grid (ceil(N/32), 4, batch): a workgroup owns 32 rows x every 4th 256-column chunk.
+// fp32-input MFMA (v_mfma_f32_32x32x2_f32 = exact fp32 FMA chain): A[i][kk] = D[n0+i][c], B[kk][j] = Q[c][j].  The D and Q
+// chunks are staged through LDS with coalesced 16-byte loads (next chunk prefetched into registers while the current one is
+// multiplied); each of the 4 waves takes 64 of the chunk's 256 columns and the 4 partial tiles are summed in fixed order.
 // ---------------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 template <int RP>
 __global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t offD, size_t offQ, size_t offY, int use_q0) {
-    constexpr int KB = RP / 8, CK = 256, LDQ = RP + 4;
+    constexpr int CK = 256, LDD = CK + 2;            // LDD/2 = 129 dwords: odd row stride -> conflict-free column reads
+    constexpr int QV = CK * RP / 4 / 256;            // float4 of Q per thread per chunk (8 at RP = 32)
     const LrItem it = b.it[blockIdx.z];
     const h16* D = (const h16*)(it.ws + offD);
     const float* Q = use_q0 ? it.q0 : (const float*)(it.ws + offQ);
     float* Y = (float*)(it.ws + offY) + (size_t)blockIdx.y * N * RP;
-    __shared__ float qs[CK * LDQ];          // 36 KB at RP = 32
-    __shared__ float ds[8][CK + 1];
-    __shared__ float red[8][8][RP];
-    const int tid = threadIdx.x, kq = tid & 7, rp = (tid >> 3) & 3, cp = tid >> 5;
-    const int n0 = blockIdx.x * 8;
-    float acc[2][KB];
+    __shared__ h16 dsm[32 * LDD];                    // 16.1 KB
+    __shared__ float qs[CK * RP > 4 * 32 * 33 ? CK * RP : 4 * 32 * 33];   // 32 KB at RP = 32; reused for the wave partials
+    float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(qs);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    f32x16 acc;
 #pragma unroll
-    for (int j = 0; j < KB; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
-    for (int c0 = blockIdx.y * CK; c0 < C; c0 += 4 * CK) {
-        const int cn = min(CK, C - c0);
-        __syncthreads();
-        for (int i = tid; i < cn * (RP / 4); i += 256) {
-            const int r = i / (RP / 4), k4 = i - r * (RP / 4);
-            *reinterpret_cast<float4*>(&qs[r * LDQ + 4 * k4]) = *reinterpret_cast<const float4*>(&Q[(size_t)(c0 + r) * RP + 4 * k4]);
-        }
-        for (int i = tid; i < 8 * CK; i += 256) {
-            const int rr = i / CK, cc = i - rr * CK;
-            ds[rr][cc] = (n0 + rr < N && cc < cn) ? (float)D[(size_t)(n0 + rr) * C + c0 + cc] : 0.f;
-        }
-        __syncthreads();
-        for (int c = cp; c < cn; c += 8) {
-            const float d0 = ds[2 * rp][c], d1 = ds[2 * rp + 1][c];
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    h16x8 dreg[4];
+    float4 qreg[QV];
+    auto load_chunk = [&](int c0) {
 #pragma unroll
-            for (int j = 0; j < KB; ++j) {
-                const float q = qs[c * LDQ + kq * KB + j];
-                acc[0][j] = fmaf(d0, q, acc[0][j]);
-                acc[1][j] = fmaf(d1, q, acc[1][j]);
-            }
+        for (int u = 0; u < 4; ++u) {                // 32 rows x 32 sixteen-byte pieces
+            const int i = tid + 256 * u, rr = i >> 5, pc = (i & 31) * 8;
+            dreg[u] = (h16x8)(h16)0;
+            if (n0 + rr < N && c0 + pc < C) dreg[u] = *reinterpret_cast<const h16x8*>(D + (size_t)(n0 + rr) * C + c0 + pc);
+        }
+#pragma unroll
+        for (int u = 0; u < QV; ++u) {
+            const int i = tid + 256 * u, rr = i / (RP / 4), k4 = i - rr * (RP / 4);
+            qreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 + rr < C) qreg[u] = *reinterpret_cast<const float4*>(Q + (size_t)(c0 + rr) * RP + 4 * k4);
+        }
+    };
+    int c0 = blockIdx.y * CK;
+    if (c0 < C) load_chunk(c0);
+    for (; c0 < C; c0 += 4 * CK) {
+        __syncthreads();                             // previous chunk fully consumed
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u, rr = i >> 5, pc = (i & 31) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dsm[rr * LDD + pc + e] = dreg[u][e];
+        }
+#pragma unroll
+        for (int u = 0; u < QV; ++u) *reinterpret_cast<float4*>(&qs[(tid + 256 * u) * 4]) = qreg[u];
+        __syncthreads();
+        if (c0 + 4 * CK < C) load_chunk(c0 + 4 * CK);   // in flight while this chunk is multiplied
+        const int cw = w * 64;                       // this wave's 64 columns of the chunk
+#pragma unroll 8
+        for (int m = 0; m < 32; ++m) {
+            const int c = cw + 2 * m + lk;
+            const float av = (float)dsm[li * LDD + c];
+            const float bv = (li < RP) ? qs[c * RP + li] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
     }
-    __syncthreads();
+    __syncthreads();                                 // every wave is done reading qs before it becomes `red`
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < KB; ++j) red[cp][2 * rp + h][kq * KB + j] = acc[h][j];
+    for (int rg = 0; rg < 16; ++rg) red[w][(rg & 3) + 8 * (rg >> 2) + 4 * lk][li] = acc[rg];
     __syncthreads();
-    for (int i = tid; i < 8 * RP; i += 256) {
+    for (int i = tid; i < 32 * RP; i += 256) {
         const int rr = i / RP, k = i - rr * RP;
-        float s = 0.f;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) s += red[p][rr][k];
-        if (n0 + rr < N) Y[(size_t)(n0 + rr) * RP + k] = s;
+        const float sum = ((red[0][rr][k] + red[1][rr][k]) + red[2][rr][k]) + red[3][rr][k];
+        if (n0 + rr < N) Y[(size_t)(n0 + rr) * RP + k] = sum;
     }
 }
 
@@ -136,44 +155,68 @@ __global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t o
 //   (Y = fixed-order sum of the 4 column-group slabs k_lr_aq wrote).  Epilogue: this tile's part of the r x r Gram matrix
 //   in fp64.  gram_mode 0: Ztile^T Ztile ; 1: Qtile^T Ztile (Q = the orthonormal basis Y was formed with).
 // ---------------------------------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 template <int RP>
 __global__ __launch_bounds__(256) void k_lr_aty(LrBatch b, int N, int C, size_t offD, size_t offY, size_t offZ, size_t offQ, size_t offG, int gram_mode) {
+    constexpr int NCH = 128;                         // rows of D / Y per chunk: each wave multiplies 32 of them (16 MFMAs)
+    constexpr int YV = NCH * RP / 4 / 256;           // float4 positions of the Y chunk per thread (4 at RP = 32)
     const LrItem it = b.it[blockIdx.y];
     const h16* D = (const h16*)(it.ws + offD);
     const float* Y = (const float*)(it.ws + offY);
     float* Z = (float*)(it.ws + offZ);
     const float* Qb = (const float*)(it.ws + offQ);
     double* Gp = (double*)(it.ws + offG) + (size_t)blockIdx.x * RP * RP;
+    __shared__ h16 dsm[NCH][34];                     // 8.5 KB; 17-dword rows: conflict-free row-pair reads
+    __shared__ float ys[NCH * RP];                   // 16 KB at RP = 32
     __shared__ float red[4][32][33];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c0 = blockIdx.x * 32;
     const int li = lane & 31, lk = lane >> 5;
-    const int nq = (((N + 3) / 4) + 1) & ~1;            // rows per wave, even
-    const int nb = w * nq, ne = min(N, nb + nq);
-    const bool cok = c0 + li < C, kok = li < RP;
     const size_t slab = (size_t)N * RP;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    // 8 MFMAs per round: all 40 operand loads of a round are issued before the first MFMA needs one
-    for (int n = nb; n < ne; n += 16) {
-        float av[8], bv[8];
+    h16x8 dreg[2];
+    float4 yreg[YV];
+    auto load_chunk = [&](int nb) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int nn = n + 2 * u + lk;
-            av[u] = 0.f; bv[u] = 0.f;
-            if (nn < ne) {
-                if (cok) av[u] = (float)D[(size_t)nn * C + c0 + li];
-                if (kok) {
-                    const size_t o = (size_t)nn * RP + li;
-                    bv[u] = ((Y[o] + Y[o + slab]) + Y[o + 2 * slab]) + Y[o + 3 * slab];
-                }
-            }
+        for (int u = 0; u < 2; ++u) {                // 128 rows x 4 sixteen-byte pieces (32 columns)
+            const int i = tid + 256 * u, rr = i >> 2, pc = (i & 3) * 8;
+            dreg[u] = (h16x8)(h16)0;
+            if (nb + rr < N && c0 + pc < C) dreg[u] = *reinterpret_cast<const h16x8*>(D + (size_t)(nb + rr) * C + c0 + pc);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        for (int u = 0; u < YV; ++u) {
+            const int i = tid + 256 * u, rr = i / (RP / 4);
+            yreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nb + rr < N) {
+                const float* yp = Y + (size_t)nb * RP + (size_t)i * 4;
+                const float4 s0 = *reinterpret_cast<const float4*>(yp), s1 = *reinterpret_cast<const float4*>(yp + slab);
+                const float4 s2 = *reinterpret_cast<const float4*>(yp + 2 * slab), s3 = *reinterpret_cast<const float4*>(yp + 3 * slab);
+                yreg[u] = make_float4(((s0.x + s1.x) + s2.x) + s3.x, ((s0.y + s1.y) + s2.y) + s3.y,
+                                      ((s0.z + s1.z) + s2.z) + s3.z, ((s0.w + s1.w) + s2.w) + s3.w);   // fixed order
+            }
+        }
+    };
+    load_chunk(0);
+    for (int nb = 0; nb < N; nb += NCH) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 256 * u, rr = i >> 2, pc = (i & 3) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dsm[rr][pc + e] = dreg[u][e];
+        }
+#pragma unroll
+        for (int u = 0; u < YV; ++u) *reinterpret_cast<float4*>(&ys[(tid + 256 * u) * 4]) = yreg[u];
+        __syncthreads();
+        if (nb + NCH < N) load_chunk(nb + NCH);      // in flight while this chunk is multiplied
+#pragma unroll 8
+        for (int m = 0; m < 16; ++m) {
+            const int rr = w * 32 + 2 * m + lk;      // rows beyond N were staged as zeros
+            const float av = (float)dsm[rr][li];
+            const float bv = (li < RP) ? ys[rr * RP + li] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
     }
     // C/D layout: column j = lane & 31, row i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -205,77 +248,118 @@ __global__ __launch_bounds__(256) void k_lr_aty(LrBatch b, int N, int C, size_t 
 // A non-positive pivot (rank-deficient residual, e.g. x == base) zeroes that direction instead of producing NaNs.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int RP>
-__global__ __launch_bounds__(1024) void k_lr_chol(LrBatch b, int r, int nparts, size_t offG, size_t offT) {
+__global__ __launch_bounds__(512) void k_lr_chol(LrBatch b, int r, int nparts, size_t offG, size_t offT) {
     const LrItem it = b.it[blockIdx.x];
     const double* Gp = (const double*)(it.ws + offG);
     float* T = (float*)(it.ws + offT);
-    __shared__ double G[RP][RP + 1], L[RP][RP + 1], X[RP][RP + 1];
+    __shared__ double G[RP][RP + 1], L[RP][RP + 1];
     const int tid = threadIdx.x;
     {
-        // all 1024 threads reduce the partial Grams: element e, part group g (1024 / RP^2 groups), 8 loads in flight each
-        constexpr int E = RP * RP, GRP = 1024 / E;
+        // 512 threads reduce the partial Grams: element e, part group g, 8 independent loads in flight each
+        // (512, not 1024, threads: the single-wave factorisation below needs > 128 registers per lane)
+        constexpr int E = RP * RP, GRP = (512 / E) > 0 ? (512 / E) : 1, EPT = (E + 511) / 512;
         __shared__ double part[GRP][E];
-        const int e = tid % E, g = tid / E;
-        double a[8];
+        {
+            constexpr int U = 12;                    // parts in flight per element
+            const int e0 = tid % (E < 512 ? E : 512), g = (E < 512) ? tid / E : 0;
+            double a[EPT][U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = 0.0;
-        int p = g;
-        for (; p + 7 * GRP < nparts; p += 8 * GRP) {
+            for (int q = 0; q < EPT; ++q)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += Gp[(size_t)(p + u * GRP) * E + e];
+                for (int u = 0; u < U; ++u) a[q][u] = 0.0;
+            if (g < GRP) {
+                int p = g;
+                for (; p + (U - 1) * GRP < nparts; p += U * GRP) {
+#pragma unroll
+                    for (int q = 0; q < EPT; ++q)
+#pragma unroll
+                        for (int u = 0; u < U; ++u) a[q][u] += Gp[(size_t)(p + u * GRP) * E + e0 + q * 512];
+                }
+                for (; p < nparts; p += GRP) {
+#pragma unroll
+                    for (int q = 0; q < EPT; ++q) a[q][0] += Gp[(size_t)p * E + e0 + q * 512];
+                }
+#pragma unroll
+                for (int q = 0; q < EPT; ++q) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) t += a[q][u];
+                    part[g][e0 + q * 512] = t;
+                }
+            }
         }
-        for (; p < nparts; p += GRP) a[0] += Gp[(size_t)p * E + e];
-        part[g][e] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         __syncthreads();
-        if (tid < E) {
+        for (int e = tid; e < E; e += 512) {
             double t = 0.0;
 #pragma unroll
-            for (int q = 0; q < GRP; ++q) t += part[q][tid];
-            G[tid / RP][tid % RP] = t;
+            for (int q = 0; q < GRP; ++q) t += part[q][e];
+            G[e / RP][e % RP] = t;
         }
     }
     __syncthreads();
-    double gsym = 0.0;
-    if (tid < RP * RP) gsym = 0.5 * (G[tid / RP][tid % RP] + G[tid % RP][tid / RP]);
+    double gsym[(RP * RP + 511) / 512];
+#pragma unroll
+    for (int q = 0; q < (RP * RP + 511) / 512; ++q) {
+        const int e = tid + q * 512;
+        gsym[q] = (e < RP * RP) ? 0.5 * (G[e / RP][e % RP] + G[e % RP][e / RP]) : 0.0;
+    }
     __syncthreads();
-    if (tid < RP * RP) { G[tid / RP][tid % RP] = gsym; L[tid / RP][tid % RP] = 0.0; X[tid / RP][tid % RP] = 0.0; }
+#pragma unroll
+    for (int q = 0; q < (RP * RP + 511) / 512; ++q) {
+        const int e = tid + q * 512;
+        if (e < RP * RP) { G[e / RP][e % RP] = gsym[q]; L[e / RP][e % RP] = 0.0; }
+    }
     __syncthreads();
-    if (tid >= 64) return;          // the factorisation is tiny and sequential: ONE wave, barriers between its steps are cheap
-    const int i = tid;              // lane i owns row i (lanes >= r idle)
+    if (tid >= 64) return;          // the factorisation is tiny and sequential: ONE wave (its barriers are cheap)
+    // Right-looking Cholesky with lane i owning row i IN REGISTERS (all indices static through full unrolling); the only
+    // traffic per step is the freshly computed column, broadcast through LDS.  Then L^-1 column by column the same way.
+    __shared__ double colv[RP];
+    __shared__ double pivs;
+    const int i = tid;
     double gmax = 0.0;
     for (int k = 0; k < r; ++k) gmax = fmax(gmax, G[k][k]);
+    double arow[RP];
+#pragma unroll
+    for (int k = 0; k < RP; ++k) arow[k] = (i < RP) ? G[i < RP ? i : 0][k] : 0.0;
     unsigned deadmask = 0;
-    for (int j = 0; j < r; ++j) {
-        double s = 0.0;
-        if (i >= j && i < r) {
-            s = G[i][j];
-            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
-            X[i][j] = s;
-        }
+#pragma unroll
+    for (int j = 0; j < RP; ++j) {
+        if (i == j) pivs = arow[j];
         __syncthreads();
-        const double piv = X[j][j];
-        const bool bad = !(piv > gmax * 1e-13);
-        if (bad) deadmask |= 1u << j;
-        if (i >= j && i < r) L[i][j] = bad ? ((i == j) ? 1.0 : 0.0) : ((i == j) ? sqrt(piv) : s / sqrt(piv));
+        const double piv = pivs;
+        const bool bad = (j >= r) || !(piv > gmax * 1e-13);
+        if (bad && j < r) deadmask |= 1u << j;
+        double lij = 0.0;
+        if (i >= j && i < r && j < r) {
+            if (bad) lij = (i == j) ? 1.0 : 0.0;
+            else lij = (i == j) ? sqrt(piv) : arow[j] / sqrt(piv);
+        }
+        if (i < RP) { colv[i] = lij; L[i][j] = lij; }
+        __syncthreads();
+#pragma unroll
+        for (int k = j + 1; k < RP; ++k)
+            if (k <= i) arow[k] -= lij * colv[k];
         __syncthreads();
     }
-    for (int k = i; k < RP * RP; k += 64) X[k / RP][k % RP] = 0.0;
     __syncthreads();
-    // X = L^-1 (lower triangular): row m from rows < m; lane i owns column i
-    for (int m = 0; m < r; ++m) {
-        if (i <= m) {
-            double s = (i == m) ? 1.0 : 0.0;
-            for (int k = i; k < m; ++k) s -= L[m][k] * X[k][i];
-            X[m][i] = s / L[m][m];
-        }
-        __syncthreads();
+    // X = L^-1: lane i computes column i (x[m] = X[m][i]) by forward substitution; L rows are broadcast LDS reads
+    double x[RP];
+#pragma unroll
+    for (int m = 0; m < RP; ++m) {
+        double sacc = (m == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < m; ++k)
+            if (k >= i) sacc -= L[m][k] * x[k];
+        x[m] = (m >= i && m < r && i < r) ? sacc / L[m][m] : 0.0;
     }
-    // T[k][j] = X[j][k] (k <= j): Q = Z T ; directions with a vanished pivot are dropped
-    for (int e = i; e < RP * RP; e += 64) {
-        const int k = e / RP, j = e % RP;
-        float v = 0.f;
-        if (k < r && j < r && k <= j && !((deadmask >> j) & 1u)) v = (float)X[j][k];
-        T[e] = v;
+    // T[k][j] = X[j][k] (k <= j): Q = Z T; lane i writes row i of T.  Directions with a vanished pivot are dropped.
+    if (i < RP) {
+#pragma unroll
+        for (int m = 0; m < RP; ++m) {
+            float v = 0.f;
+            if (i < r && m < r && m >= i && !((deadmask >> m) & 1u)) v = (float)x[m];
+            T[i * RP + m] = v;
+        }
     }
 }
 
@@ -463,16 +547,16 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
     const size_t E = (size_t)N * C;
     const int nparts = (C + 31) / 32;
     LAUNCH(ctx, KID_LR_PREP, s, k_lr_prep, dim3((unsigned)((E / 8 + 255) / 256), batch), dim3(256), 0, s, b, E, w.D);
-    const dim3 g_aq((N + 7) / 8, 4, batch), g_aty(nparts, batch), g_chol(batch), g_apc((C + 255) / 256, batch), g_apn((N + 255) / 256, batch);
+    const dim3 g_aq((N + 31) / 32, 4, batch), g_aty(nparts, batch), g_chol(batch), g_apc((C + 255) / 256, batch), g_apn((N + 255) / 256, batch);
     for (int iter = 0; iter < 2; ++iter) {
         LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, iter == 0 ? 1 : 0));
         LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 0));
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(1024), 0, s, b, rank, nparts, w.Gp, w.T));
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(512), 0, s, b, rank, nparts, w.Gp, w.T));
         LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply<RP>), g_apc, dim3(256), 0, s, b, C, rank, w.Zb, 1, w.T, 0, w.Qa, 0, (size_t)0));
     }
     LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0));
     LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 1));
-    LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(1024), 0, s, b, rank, nparts, w.Gp, w.T));
+    LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(512), 0, s, b, rank, nparts, w.Gp, w.T));
     int rc = CFX_OK;
     LrDec dec[LR_MAXB];
     if (!quantized) {
