@@ -165,3 +165,40 @@ def w_patch(rank, world, mode):
         ref_out, _ = _full_attention(qs[step], kk, vv)
         res[f"s{step}/ref_out"] = ref_out.float().numpy()
     return res
+
+
+def w_hook_layer(rank, world, ulysses, ring, compact_on):
+    """xFuserLongContextAttention over a (ulysses x ring) sequence-parallel group; compares with full attention."""
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
+    from compactfusion_amd.core import init_sequence_parallel, xFuserLongContextAttention
+    from compactfusion_amd.core import long_ctx_attention as LCA
+    LCA.reset_layer_index()
+    init_sequence_parallel(ulysses, ring)
+    if compact_on:
+        cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T.BINARY,
+                                      residual=1, ef=True, fastpath=True, comp_rank=-1))
+    else:
+        cm.compact_init(CompactConfig(enabled=False))
+    layers = [xFuserLongContextAttention(), xFuserLongContextAttention()]
+    B, S, H, D = 1, 16, 4, 32                     # per-rank shard
+    res = {}
+    allq = [drift(7 + r, (B, S, H, D), 2) for r in range(world)]
+    allk = [drift(17 + r, (B, S, H, D), 2) for r in range(world)]
+    allv = [drift(27 + r, (B, S, H, D), 2) for r in range(world)]
+    for step in range(2):
+        cm.compact_set_step(step)
+        for li, layer in enumerate(layers):
+            out = layer(None, allq[rank][step], allk[rank][step], allv[rank][step], causal=False)
+            assert out.shape == (B, S, H, D)
+            res[f"s{step}/l{li}/out"] = out.float().numpy()
+            # reference: full attention over the whole sequence (ranks in order), my query shard
+            from compactfusion_amd.compact.attention import block_attention
+            kk = torch.cat([allk[r][step] for r in range(world)], dim=1)
+            vv = torch.cat([allv[r][step] for r in range(world)], dim=1)
+            ref, _ = block_attention(allq[rank][step], kk, vv, 0.0, None, causal=False)
+            res[f"s{step}/l{li}/ref"] = ref.float().numpy()
+        assert layers[0].idx == 0 and layers[1].idx == 1
+    if compact_on:
+        res["keys"] = np.array(sorted(cm.compact_cache().base.keys()), dtype="U")
+    return res

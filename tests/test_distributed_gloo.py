@@ -102,3 +102,23 @@ def test_patch_gather_forward_2rank(tmp_path, mode):
     for r in range(2):
         for s in range(4):
             np.testing.assert_allclose(res[r][f"s{s}/out"], res[r][f"s{s}/ref_out"], rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("ulysses,ring,compact_on", [(1, 2, True), (2, 1, True), (1, 2, False), (2, 1, False)])
+def test_long_context_attention_hook_2rank(tmp_path, ulysses, ring, compact_on):
+    """The attention layer that binds compact_fwd (attn_layer.py:55-65,173-210): layer indices, Ulysses all-to-all,
+    ring / compressed-ring dispatch.  Step 0 is WARMUP (raw K/V) so it must equal full attention; step 1 is 1-bit
+    compressed for the remote shard, so it equals full attention only up to the codec error."""
+    res = _spawn(W.w_hook_layer, 2, tmp_path, ulysses, ring, compact_on)
+    for r in range(2):
+        for li in range(2):
+            np.testing.assert_allclose(res[r][f"s0/l{li}/out"], res[r][f"s0/l{li}/ref"], rtol=2e-3, atol=2e-3)
+            if not compact_on or ring == 1:
+                np.testing.assert_allclose(res[r][f"s1/l{li}/out"], res[r][f"s1/l{li}/ref"], rtol=2e-3, atol=2e-3)
+            else:
+                err = np.abs(res[r][f"s1/l{li}/out"] - res[r][f"s1/l{li}/ref"]).max()
+                assert err < 0.15, err
+        if compact_on:
+            keys = set(res[r]["keys"].tolist())
+            want = {f"{l}-{q}-{t}" for l in range(2) for q in range(ring) for t in "kv"}     # "{layer}-{ring rank}-{k|v}"
+            assert keys == want, keys
