@@ -60,20 +60,15 @@ class CompactConfig:
         delta_decay_factor: Optional[float] = None,
     ):
         assert residual in (0, 1, 2)
-        self.enabled = enabled
-        self.compress_func = compress_func          # (layer_idx, step) -> COMPACT_COMPRESS_TYPE
-        self.sparse_ratio = sparse_ratio
-        self.comp_rank = comp_rank
-        self.compress_residual = residual
-        self.error_feedback = ef
-        self.simulate_compress = simulate
-        self.log_compress_stats = log_stats
-        self.check_cache_consistency = check_consist
-        self.fastpath = fastpath
-        self.quantized_cache = quantized_cache
-        self.delta_decay_factor = delta_decay_factor
-        self.override_with_patch_gather_fwd = override_with_patch_gather_fwd
-        self.patch_gather_fwd_config = patch_gather_fwd_config
+        # public attribute names are the reference's (utils.py:62-80); keyword -> attribute
+        for attr, value in (
+            ("enabled", enabled), ("compress_func", compress_func), ("sparse_ratio", sparse_ratio), ("comp_rank", comp_rank),
+            ("compress_residual", residual), ("error_feedback", ef), ("simulate_compress", simulate),
+            ("log_compress_stats", log_stats), ("check_cache_consistency", check_consist), ("fastpath", fastpath),
+            ("quantized_cache", quantized_cache), ("delta_decay_factor", delta_decay_factor),
+            ("override_with_patch_gather_fwd", override_with_patch_gather_fwd), ("patch_gather_fwd_config", patch_gather_fwd_config),
+        ):
+            setattr(self, attr, value)      # compress_func: (layer_idx, step) -> COMPACT_COMPRESS_TYPE
 
         rules = [
             (residual == 0 and ef, "No residual does not support error feedback."),
