@@ -412,6 +412,19 @@ def main():
                 out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, round 1)"
             except Exception:
                 pass
+        # cross-reference: the committed rocprofv3 --kernel-trace --stats summary of this same command.  The HIP-event
+        # bracket of a single dispatch includes ~1.3-2 us of marker-to-kernel gap (tools/evtest.hip), so `achieved` above
+        # is the conservative figure.
+        stats_csv = os.path.join(REPO, "profiles", "r01_bench_kernel_stats.csv")
+        if os.path.exists(stats_csv):
+            try:
+                import csv
+                for row in csv.DictReader(open(stats_csv)):
+                    if row["Name"].startswith("k_binary_dequant"):
+                        out["roofline"]["avg_launch_us_rocprof"] = round(float(row["AverageNs"]) / 1e3, 3)
+                        out["roofline"]["rocprof_source"] = "profiles/r01_bench_kernel_stats.csv"
+            except Exception:
+                pass
     else:
         out["roofline"] = None
     if rank == 0 and live == 1 and not args.no_cpu_baseline:
