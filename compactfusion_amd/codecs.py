@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 from enum import IntEnum
-from typing import Optional, Sequence
+from typing import Callable, Optional, Sequence
 
 import torch
 
@@ -143,6 +143,67 @@ def decompress_batch(codec: int, packets: Sequence[torch.Tensor], bases: Sequenc
         items[i] = DecompItem(_ptr(packets[i]), _ptr(bases[i]), _ptr(recons[i]))
     rc = _lib.load().cfx_decompress_batch(ctx, int(codec), N, C, param, B, items, _stream_handle(stream, dev))
     _check(ctx, rc, "cfx_decompress_batch")
+
+
+def prepare_compress(codec: int, bases: Sequence[Optional[torch.Tensor]], new_bases: Sequence[Optional[torch.Tensor]],
+                     packets: Sequence[torch.Tensor], N: int, C: int, param: int = 0, update_cache: bool = True,
+                     ef: bool = True) -> Callable[[Sequence[torch.Tensor]], None]:
+    """`compress_batch` with the state / packet operands bound once (persistent arena and exchange buffers): the
+    returned `run(xs, stream_handle=None)` only patches the activation pointers into a cached item array - the
+    per-call host cost of the exchange hot loop.  The bound tensors are kept alive by the closure."""
+    B = len(packets)
+    if not (1 <= B <= CFX_MAX_BATCH):
+        raise ValueError(f"batch {B} out of range 1..{CFX_MAX_BATCH}")
+    dev = _device_index(packets[0])
+    ctx = context(dev)
+    items = (CompItem * B)()
+    for i in range(B):
+        if bases[i] is not None:
+            _check_nc(bases[i], N, C, "base")
+        if new_bases[i] is not None and update_cache:
+            _check_nc(new_bases[i], N, C, "new_base")
+        _device_index(packets[i])
+        items[i] = CompItem(None, _ptr(bases[i]), _ptr(new_bases[i]) if update_cache else None, _ptr(packets[i]))
+    flags = (FLAG_UPDATE_CACHE if update_cache else 0) | (0 if ef else FLAG_NO_EF)
+    ws = workspace(codec, N, C, param, B, dev)
+    fn = _lib.load().cfx_compress_batch
+    keep = (list(bases), list(new_bases), list(packets), ws)
+    ws_ptr, ws_len, codec = _ptr(ws), ws.numel(), int(codec)
+
+    def run(xs: Sequence[torch.Tensor], stream_handle: Optional[int] = None) -> None:
+        assert len(xs) == B and keep
+        for i in range(B):
+            _check_nc(xs[i], N, C, "x")
+            items[i].x = xs[i].data_ptr()
+        sh = torch.cuda.current_stream(dev).cuda_stream if stream_handle is None else stream_handle
+        _check(ctx, fn(ctx, codec, N, C, param, flags, B, items, ws_ptr, ws_len, sh), "cfx_compress_batch")
+    return run
+
+
+def prepare_decompress(codec: int, packets: Sequence[torch.Tensor], bases: Sequence[Optional[torch.Tensor]],
+                       recons: Sequence[torch.Tensor], N: int, C: int, param: int = 0) -> Callable[..., None]:
+    """`decompress_batch` with every operand bound once; `run(stream_handle=None)` is a single C call."""
+    B = len(packets)
+    if not (1 <= B <= CFX_MAX_BATCH):
+        raise ValueError(f"batch {B} out of range 1..{CFX_MAX_BATCH}")
+    dev = _device_index(recons[0])
+    ctx = context(dev)
+    items = (DecompItem * B)()
+    for i in range(B):
+        _check_nc(recons[i], N, C, "recon")
+        if bases[i] is not None:
+            _check_nc(bases[i], N, C, "base")
+        _device_index(packets[i])
+        items[i] = DecompItem(_ptr(packets[i]), _ptr(bases[i]), _ptr(recons[i]))
+    fn = _lib.load().cfx_decompress_batch
+    keep = (list(packets), list(bases), list(recons))
+    codec = int(codec)
+
+    def run(stream_handle: Optional[int] = None) -> None:
+        assert keep
+        sh = torch.cuda.current_stream(dev).cuda_stream if stream_handle is None else stream_handle
+        _check(ctx, fn(ctx, codec, N, C, param, B, items, sh), "cfx_decompress_batch")
+    return run
 
 
 def compress(codec: int, x: torch.Tensor, base: Optional[torch.Tensor], N: int, C: int, param: int = 0,

@@ -40,13 +40,16 @@ _step = None
 _allgather_cache: Optional[AllGatherCache] = None
 _current_cache_key = None
 _packets: Dict[Tuple, torch.Tensor] = {}     # persistent packet / scratch buffers keyed by (key, role, numel)
+_generation = 0                               # bumped by compact_init / compact_reset: invalidates cached pointer tables
 
 
 # ------------------------------------------------------------------------------------------------------------
 # global state (main.py:37-113)
 # ------------------------------------------------------------------------------------------------------------
 def compact_init(config: CompactConfig):
-    global _config, _cache, _step, _allgather_cache, _current_cache_key
+    global _config, _cache, _step, _allgather_cache, _current_cache_key, _generation
+    _generation += 1
+    _drop_kv_exchanges()
     _config = config
     _cache = CompactCache(quantize=config.quantized_cache)
     _step = None
@@ -58,7 +61,9 @@ def compact_init(config: CompactConfig):
 
 def compact_reset():
     """Fresh state for a new generation (main.py:93-106)."""
-    global _cache, _step, _allgather_cache, _current_cache_key
+    global _cache, _step, _allgather_cache, _current_cache_key, _generation
+    _generation += 1
+    _drop_kv_exchanges()
     _cache = CompactCache(quantize=_config.quantized_cache)
     from .stats import stats_clear
     stats_clear()
@@ -426,3 +431,146 @@ def compact_all_gather(tag, x: torch.Tensor, comp_type: COMPACT_COMPRESS_TYPE, g
         _cache.put(f"{tag}-{i}", bases[i], None)
         _current_cache_key = f"{tag}-{i}"
     return [b.view(x.shape) for b in bases]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# fused K+V gather (what patch_gather_fwd calls) and its displaced variant
+# ------------------------------------------------------------------------------------------------------------
+_kv_exchanges: Dict[Tuple, "_KVExchange"] = {}
+
+
+def _drop_kv_exchanges():
+    for ex in _kv_exchanges.values():
+        ex.drain()
+    _kv_exchanges.clear()
+
+
+class _KVExchange:
+    """Per-layer state of the fused K+V packet gather: double-buffered exchange buffers, key strings and the prepared
+    native batches (pointer tables bound once to the state arena).
+
+    sync      - compress K,V (no state update) -> ONE all-gather of [K packet | V packet] -> ONE batched reconstruction
+                of all W ranks' K and V (own shard included, as compact_all_gather does, main.py:406-419).
+    displaced - extension (the reference forbids async + compact, df_utils.py:13-16): the gather of step t is left in
+                flight and applied at the start of step t+1, so peers' K/V are one step stale (DistriFusion's
+                staleness) while every rank still applies every packet exactly once and in order - the replicated
+                states stay bit-identical across ranks; the own shard is used fresh."""
+
+    def __init__(self, tag_k, tag_v, rank, world, slot, like, group):
+        self.rank, self.world, self.slot, self.group = rank, world, slot, group
+        self.send = [torch.empty(2 * slot, dtype=torch.float16, device=like.device) for _ in range(2)]
+        self.recv = [torch.empty(world * 2 * slot, dtype=torch.float16, device=like.device) for _ in range(2)]
+        self.kkeys = [f"{tag_k}-{i}" for i in range(world)]
+        self.vkeys = [f"{tag_v}-{i}" for i in range(world)]
+        self.sig = None
+        self.comp, self.dec = [None, None], [[], []]
+        self.kviews, self.vviews = [], []
+        self.parity = 0
+        self.pending = None
+        self.cuda = like.is_cuda
+        self.device = like.device
+
+    def bind(self, sig, cid, param, N, C, n_half, shape, ef):
+        def state(key):
+            b = _cache.get_base(key)
+            assert b is not None, f"no cached base for key {key}"
+            return b
+        kb = [state(k) for k in self.kkeys]
+        vb = [state(k) for k in self.vkeys]
+        own = [kb[self.rank], vb[self.rank]]
+        bases = [t for pair in zip(kb, vb) for t in pair]
+        step = codecs.CFX_MAX_BATCH
+        for p in range(2):
+            s_, r_, sl = self.send[p], self.recv[p], self.slot
+            self.comp[p] = codecs.prepare_compress(cid, own, [None, None], [s_[:n_half], s_[sl:sl + n_half]], N, C, param,
+                                                   update_cache=False, ef=ef)
+            pkts = [r_[i * sl:i * sl + n_half] for i in range(2 * self.world)]
+            self.dec[p] = [codecs.prepare_decompress(cid, pkts[i:i + step], bases[i:i + step], bases[i:i + step], N, C, param)
+                           for i in range(0, len(bases), step)]
+        self.kviews = [b.view(shape) for b in kb]
+        self.vviews = [b.view(shape) for b in vb]
+        self.sig = sig
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream if self.cuda else None
+
+    def _apply(self, p):
+        global _current_cache_key
+        sh = self._stream()
+        with Profiler.scope("compact.decompress_batch"):
+            for run in self.dec[p]:
+                run(sh)
+        from ..collector import collector
+        if collector.instance is None or collector.instance.enabled:
+            for key in self.kkeys + self.vkeys:
+                _cache.touch(key)
+        _current_cache_key = self.vkeys[-1]
+
+    def flush(self):
+        """Apply a displaced gather that is still in flight: all states advance to the step it was issued at."""
+        if self.pending is not None:
+            handle, p = self.pending
+            self.pending = None
+            handle.wait()
+            self._apply(p)
+
+    def drain(self):
+        if self.pending is not None:
+            self.pending[0].wait()
+            self.pending = None
+
+    def step(self, k, v, displaced: bool):
+        self.flush()
+        p = self.parity
+        self.parity ^= 1
+        with Profiler.scope("compact.compress_batch"):
+            self.comp[p]((k, v), self._stream())
+        if displaced:
+            with Profiler.scope("df.all_gather"):
+                handle = dist.all_gather_into_tensor(self.recv[p], self.send[p], group=self.group, async_op=True)
+            self.pending = (handle, p)
+            ks, vs = list(self.kviews), list(self.vviews)
+            ks[self.rank], vs[self.rank] = k, v               # own shard is always fresh
+            return ks, vs
+        with Profiler.scope("compact.all_gather"):
+            dist.all_gather_into_tensor(self.recv[p], self.send[p], group=self.group)
+        self._apply(p)
+        return list(self.kviews), list(self.vviews)
+
+
+def compact_flush_displaced() -> None:
+    """Apply every displaced gather still in flight (end of a generation, or before inspecting the states)."""
+    for ex in _kv_exchanges.values():
+        ex.flush()
+
+
+def compact_all_gather_kv(tag_k, tag_v, k: torch.Tensor, v: torch.Tensor, comp_type: COMPACT_COMPRESS_TYPE, group=None,
+                          displaced: bool = False) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    """`compact_all_gather(tag_k, k)` + `compact_all_gather(tag_v, v)` as ONE exchange (one collective, one batched
+    reconstruction) whenever the codec runs natively with first-order residuals; the two separate calls otherwise.
+    `displaced=True` selects the one-step-stale variant described in `_KVExchange`."""
+    assert _config.enabled
+    cfg = _config
+    ex = _kv_exchanges.get((tag_k, tag_v))
+    fusable = (comp_type != T.WARMUP and not cfg.simulate_compress and cfg.compress_residual == 1
+               and not cfg.log_compress_stats and k.shape == v.shape and k.is_contiguous() and v.is_contiguous())
+    if fusable:
+        cid, param = _native(comp_type)
+        fusable = cid < 100
+    if not fusable:
+        if ex is not None:
+            ex.flush()
+        return (compact_all_gather(tag_k, k, comp_type, group=group), compact_all_gather(tag_v, v, comp_type, group=group))
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    N, C = _nc_shape(k.shape)
+    n_half = _packet_halves(cid, param, N, C)
+    slot = (n_half + 127) // 128 * 128
+    if ex is None or ex.slot != slot or ex.world != world or ex.device != k.device:
+        if ex is not None:
+            ex.flush()
+        ex = _kv_exchanges[(tag_k, tag_v)] = _KVExchange(tag_k, tag_v, rank, world, slot, k, group)
+    ex.flush()
+    sig = (_generation, _cache.version, cid, param, N, C, tuple(k.shape), cfg.error_feedback)
+    if ex.sig != sig:
+        ex.bind(sig, cid, param, N, C, n_half, k.shape, cfg.error_feedback)
+    return ex.step(k, v, displaced)

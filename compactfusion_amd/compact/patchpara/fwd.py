@@ -2,7 +2,9 @@
 
 Mirror of the reference's `xfuser/compact/patchpara/fwd.py` (`patch_gather_fwd` :20-236), three communication modes
 selected by `PatchConfig`:
-  compact - `compact_all_gather` of residual-compressed shards (own shard is replaced by its reconstruction too);
+  compact - `compact_all_gather` of residual-compressed shards (own shard is replaced by its reconstruction too), K and V
+            fused into one exchange (`compact_all_gather_kv`); with `PatchConfig(displaced_compact=True)` (extension) the
+            gather of step t is consumed at step t+1 - DistriFusion's staleness on top of residual compression;
   sync    - plain all-gather of raw fp16 K and V (the "Patch Parallel" baseline);
   async   - DistriFusion: consume the buffers gathered during the PREVIOUS step (own shard fresh), launch this
             step's gather asynchronously for the next one; the first `async_warmup` steps gather synchronously.
@@ -14,7 +16,7 @@ import torch.distributed as dist
 
 from ...prof import Profiler
 from ..attention import block_attention
-from ..main import allgather_cache, compact_all_gather, compact_config
+from ..main import allgather_cache, compact_all_gather_kv, compact_config
 from .df_cache import DummyHandle
 from .df_utils import PatchConfig
 
@@ -58,8 +60,8 @@ def patch_gather_fwd(q, k, v, dropout_p=0, softmax_scale=None, causal=True, wind
 
     if pc.use_compact:
         ctype = cfg.compress_func(mod_idx, current_iter)
-        ks = compact_all_gather(f"{mod_idx}-k", k, comp_type=ctype, group=group)
-        vs = compact_all_gather(f"{mod_idx}-v", v, comp_type=ctype, group=group)
+        displaced = pc.displaced_compact and current_iter >= pc.async_warmup
+        ks, vs = compact_all_gather_kv(f"{mod_idx}-k", f"{mod_idx}-v", k, v, ctype, group=group, displaced=displaced)
     elif not pc.async_comm:
         with Profiler.scope("compact.gather.all_gather_sync"):
             _, ks, vs = _gather_raw_kv(k, v, group, world, ("sync", mod_idx))

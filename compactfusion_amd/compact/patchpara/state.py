@@ -13,13 +13,18 @@ class PatchConfig:
     """use_compact: compress the gathered K/V; async_comm: DistriFusion-style displaced gather (consume the previous
     step's buffers while this step's gather is in flight); the two are mutually exclusive (df_utils.py:13-16)."""
 
-    def __init__(self, use_compact: bool, async_comm: bool, async_warmup: int) -> None:
-        if use_compact and async_comm:
+    def __init__(self, use_compact: bool, async_comm: bool, async_warmup: int, displaced_compact: bool = False) -> None:
+        # displaced_compact (extension, SURVEY.md section 8d config 5): the compressed gather of step t is consumed at
+        # step t+1 (DistriFusion staleness on top of residual compression); it is the only way to combine the two flags
+        if use_compact and async_comm and not displaced_compact:
             raise AssertionError("Compact does not support async communication" if use_compact
                                  else "Async communication does not support compact")
+        if displaced_compact and not (use_compact and async_comm):
+            raise AssertionError("displaced_compact needs use_compact=True and async_comm=True")
         self.use_compact = bool(use_compact)
         self.async_comm = bool(async_comm)
         self.async_warmup = async_warmup
+        self.displaced_compact = bool(displaced_compact)
 
 
 class DummyHandle:

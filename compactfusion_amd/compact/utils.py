@@ -83,7 +83,8 @@ class CompactConfig:
         if override_with_patch_gather_fwd:
             assert enabled, "Compact must be enabled if override_with_patch_gather_fwd is True"
             assert pc is not None, "patch_gather_fwd_config must be set if override_with_patch_gather_fwd is True"
-            assert not (pc.use_compact and pc.async_comm), "Compact does not support async communication"
+            assert not (pc.use_compact and pc.async_comm) or getattr(pc, "displaced_compact", False), \
+                "Compact does not support async communication"
         else:
             assert pc is None, "patch_gather_fwd_config must be None if override_with_patch_gather_fwd is False"
 
@@ -110,6 +111,7 @@ class CompactCache:
         self.base: Dict[str, torch.Tensor] = {}
         self.delta_base: Dict[str, Optional[torch.Tensor]] = {}
         self.passed_count = 0
+        self.version = 0        # bumped whenever a state buffer is (re)allocated: cached pointer tables key on it
 
     # -- arena ----------------------------------------------------------------------------------------------
     def arena(self, key: str, like: torch.Tensor) -> torch.Tensor:
@@ -119,24 +121,30 @@ class CompactCache:
             buf = torch.empty(like.shape, dtype=like.dtype, device=like.device)
             self.base[key] = buf
             self.delta_base.setdefault(key, None)
+            self.version += 1
         return buf
 
-    @staticmethod
-    def _store(slot: Optional[torch.Tensor], value: torch.Tensor) -> torch.Tensor:
+    def _store(self, slot: Optional[torch.Tensor], value: torch.Tensor) -> torch.Tensor:
         if slot is None or slot.shape != value.shape or slot.device != value.device or slot.dtype != value.dtype:
             slot = torch.empty(value.shape, dtype=value.dtype, device=value.device)
+            self.version += 1
         if slot.data_ptr() != value.data_ptr():
             slot.copy_(value)
         return slot
 
-    def put(self, key, base, delta_base):
+    def touch(self, key) -> None:
+        """The state of `key` was updated in place by a kernel: only the reference's `put` side effect (the collector
+        hook for K / V keys, utils.py:138-143) is left to do."""
         from .main import compact_get_step
         from ..collector.collector import collect
-        self.base[key] = self._store(self.base.get(key), base)
         if "k" in key:
             collect(self.base[key], "kbase", compact_get_step(), int(key.split("-")[0]))
         elif "v" in key:
             collect(self.base[key], "vbase", compact_get_step(), int(key.split("-")[0]))
+
+    def put(self, key, base, delta_base):
+        self.base[key] = self._store(self.base.get(key), base)
+        self.touch(key)
         if delta_base is None:
             self.delta_base[key] = None
         else:

@@ -167,6 +167,40 @@ def w_patch(rank, world, mode):
     return res
 
 
+def w_patch_displaced(rank, world):
+    """Extension: displaced (one-step-stale) compressed patch gather next to the synchronous compressed gather."""
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig, PatchConfig
+    from compactfusion_amd.compact.ring import compact_fwd
+    B, S, H, D, STEPS = 1, 16, 4, 32, 5
+    qs = drift(7 + rank, (B, S, H, D), STEPS)
+    ks = drift(17 + rank, (B, S, H, D), STEPS)
+    vs = drift(27 + rank, (B, S, H, D), STEPS)
+    res = {}
+    for mode, pc in (("sync", PatchConfig(True, False, 1)), ("disp", PatchConfig(True, True, 1, displaced_compact=True))):
+        cm.compact_init(CompactConfig(enabled=True, override_with_patch_gather_fwd=True, patch_gather_fwd_config=pc,
+                                      compress_func=lambda l, s: T.WARMUP if s == 0 else T.BINARY,
+                                      residual=1, ef=True, fastpath=True, comp_rank=-1))
+        for step in range(STEPS):
+            cm.compact_set_step(step)
+            out, lse, _ = compact_fwd(qs[step], ks[step], vs[step], causal=False, group=None, mod_idx=2, current_iter=step)
+            res[f"{mode}/s{step}/out"] = out.float().numpy()
+            for r in range(world):
+                res[f"{mode}/s{step}/state_k_{r}"] = bits(cm.compact_cache().get_base(f"2-k-{r}")).copy()
+                res[f"{mode}/s{step}/state_v_{r}"] = bits(cm.compact_cache().get_base(f"2-v-{r}")).copy()
+        cm.compact_flush_displaced()
+        for r in range(world):
+            res[f"{mode}/final/state_k_{r}"] = bits(cm.compact_cache().get_base(f"2-k-{r}")).copy()
+    # what the displaced forward must have attended to: own shard fresh, peers as of the previous step
+    sync_state = lambda t, kv, r: torch.from_numpy(res[f"sync/s{t}/state_{kv}_{r}"].view(np.int16).copy()).view(torch.float16).view(B, S, H, D)  # noqa: E731
+    for step in range(1, STEPS):
+        kk = [ks[step] if r == rank else sync_state(step - 1, "k", r) for r in range(world)]
+        vv = [vs[step] if r == rank else sync_state(step - 1, "v", r) for r in range(world)]
+        ref_out, _ = _full_attention(qs[step], kk, vv)
+        res[f"disp/s{step}/ref_out"] = ref_out.float().numpy()
+    return res
+
+
 def w_hook_layer(rank, world, ulysses, ring, compact_on):
     """xFuserLongContextAttention over a (ulysses x ring) sequence-parallel group; compares with full attention."""
     import compactfusion_amd.compact.main as cm

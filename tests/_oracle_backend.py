@@ -1,4 +1,4 @@
-"""TEST-ONLY stand-in for the HIP kernels: implements `codecs.compress_batch` / `codecs.decompress_batch` on CPU
+"""TEST-ONLY stand-in for the HIP kernels: implements `codecs.compress_batch` / `codecs.decompress_batch` (and their prepared forms) on CPU
 tensors with the oracle, so the HOST logic (state machine, wire sizes, cache, ring / gather schedules over gloo) can
 be exercised in this GPU-less container.  It is installed by monkeypatching inside tests and never shipped: the
 product (`compactfusion_amd.codecs`) has no CPU path and refuses CPU tensors."""
@@ -90,10 +90,24 @@ def lr_decompress_batch(quantized, packets, bases, recons, N, C, rank, stream=No
         r.copy_(recv if b is None else b + recv)
 
 
+def prepare_compress(codec, bases, new_bases, packets, N, C, param=0, update_cache=True, ef=True):
+    def run(xs, stream_handle=None):
+        compress_batch(codec, xs, bases, new_bases, packets, N, C, param, update_cache, ef)
+    return run
+
+
+def prepare_decompress(codec, packets, bases, recons, N, C, param=0):
+    def run(stream_handle=None):
+        decompress_batch(codec, packets, bases, recons, N, C, param)
+    return run
+
+
 def install(monkeypatch):
     from compactfusion_amd import codecs
     monkeypatch.setattr(codecs, "compress_batch", compress_batch)
     monkeypatch.setattr(codecs, "decompress_batch", decompress_batch)
+    monkeypatch.setattr(codecs, "prepare_compress", prepare_compress)
+    monkeypatch.setattr(codecs, "prepare_decompress", prepare_decompress)
     monkeypatch.setattr(codecs, "lr_compress_batch", lr_compress_batch)
     monkeypatch.setattr(codecs, "lr_decompress_batch", lr_decompress_batch)
 
@@ -103,5 +117,7 @@ def install_plain():
     from compactfusion_amd import codecs
     codecs.compress_batch = compress_batch
     codecs.decompress_batch = decompress_batch
+    codecs.prepare_compress = prepare_compress
+    codecs.prepare_decompress = prepare_decompress
     codecs.lr_compress_batch = lr_compress_batch
     codecs.lr_decompress_batch = lr_decompress_batch

@@ -104,6 +104,23 @@ def test_patch_gather_forward_2rank(tmp_path, mode):
             np.testing.assert_allclose(res[r][f"s{s}/out"], res[r][f"s{s}/ref_out"], rtol=2e-3, atol=2e-3)
 
 
+def test_displaced_compressed_patch_gather_2rank(tmp_path):
+    """Extension: with `PatchConfig(displaced_compact=True)` the packets are the
+    synchronous run's packets, applied one step later - so peers are seen one step stale, the own shard fresh, and after
+    the final flush every state equals the synchronous run's and is identical on every rank."""
+    res = _spawn(W.w_patch_displaced, 2, tmp_path)
+    for r in range(2):
+        assert np.array_equal(res[r]["disp/s0/out"], res[r]["sync/s0/out"])          # warm-up step is synchronous
+        for s in range(1, 5):
+            np.testing.assert_allclose(res[r][f"disp/s{s}/out"], res[r][f"disp/s{s}/ref_out"], rtol=2e-3, atol=2e-3)
+            for q in range(2):
+                # while step s is in flight the states are the synchronous run's of step s-1
+                assert np.array_equal(res[r][f"disp/s{s}/state_k_{q}"], res[r][f"sync/s{s - 1}/state_k_{q}"])
+        for q in range(2):
+            assert np.array_equal(res[r][f"disp/final/state_k_{q}"], res[r]["sync/final/state_k_" + str(q)])
+            assert np.array_equal(res[0][f"disp/final/state_k_{q}"], res[1][f"disp/final/state_k_{q}"])
+
+
 @pytest.mark.parametrize("ulysses,ring,compact_on", [(1, 2, True), (2, 1, True), (1, 2, False), (2, 1, False)])
 def test_long_context_attention_hook_2rank(tmp_path, ulysses, ring, compact_on):
     """The attention layer that binds compact_fwd (attn_layer.py:55-65,173-210): layer indices, Ulysses all-to-all,
