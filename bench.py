@@ -18,9 +18,14 @@ Infinity Cache, so every step streams from HBM (cold numbers).
 
 value = whole-job fp16 activation bytes compressed + reconstructed per second (GB/s), i.e.
         n_gpus * 57 * (2 + 14) * 544*3072*2 B / step time.
-roofline = the dominant kernel (k_binary_dequant on 16 tensors): algorithmic bytes 4.125 B/element
-         x 16*544*3072 elements per launch / average launch duration from hipEvents recorded
-        on the launch stream inside the timed region (native hooks in libcfx.so).
+Replay (--replay): `pipelined` (default) = cfx_plan_run_pipelined: per layer ONE fused launch k_binary_pipe =
+        [dequant+add of layer j's 16 tensors | finalize of layer j+1's scales | stats + sign bits of layer j+2's K,V], so the
+        small latency-bound compress kernels ride underneath the bandwidth-bound reconstruction; `inorder` = cfx_plan_run,
+        stats -> finalize -> dequant one after the other.  Same results bit for bit (tests/test_gpu_api.py).
+roofline = the dominant kernel: k_binary_pipe (pipelined; algorithmic bytes 4.125 B/element x (16 + 2) tensors of
+        544*3072 elements per launch) or k_binary_dequant (inorder; 4.125 B/element x 16 tensors) / average
+        launch duration from hipEvents attached to the dispatch on the launch stream inside the timed region (native
+        hooks in libcfx.so).
 cpu_baseline = the C oracle (oracle/cfx_oracle.c, OpenMP) timed on this box's host cores on one layer of the same
         workload; reported baseline only.
 """
@@ -48,6 +53,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--layers", type=int, default=L_LAYERS, help="debug only; the judged workload uses 57")
     ap.add_argument("--rows", type=int, default=0, help="rows per tile override (0 = auto)")
+    ap.add_argument("--replay", choices=["inorder", "pipelined"], default="pipelined",
+                    help="pipelined (default): cfx_plan_run_pipelined - one fused launch per layer, the statistics / finalize "
+                         "work of the next two layers rides underneath the reconstruction of the current one; "
+                         "inorder: cfx_plan_run, three launches per layer one after the other (same results, bit for bit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -245,12 +254,13 @@ def main():
 
     def one_step(step):
         plan = plans[step & 1]
+        run = lib.cfx_plan_run_pipelined if args.replay == "pipelined" else lib.cfx_plan_run
         if not use_dist:
-            check(lib.cfx_plan_run(plan, 0, 2 * L, sh), "plan_run")     # the whole step from native code
+            check(run(plan, 0, 2 * L, sh), "plan_run")     # the whole step from native code
             return
         if step_plans is not None:
             sp = step_plans[step & 1]
-            check(lib.cfx_plan_run(sp, 0, lib.cfx_plan_size(sp), sh), "plan_run(exchange)")
+            check(run(sp, 0, lib.cfx_plan_size(sp), sh), "plan_run(exchange)")
             return
         # software pipeline: gather(l) runs on RCCL's own stream (async_op: it is ordered after the compute stream's
         # tail at the call and joined back by work.wait()) and overlaps compress(l+1) and reconstruct(l-1)
@@ -314,7 +324,9 @@ def main():
             sync_all()
 
     # ---- timed region -------------------------------------------------------------------------------------------
-    KID_DEQ = 4
+    # dominant kernel: k_binary_dequant (in-order replay) or the fused k_binary_pipe (pipelined replay; the full
+    # three-group launches only - prologue / epilogue launches carry a different id)
+    KID_DEQ = 23 if args.replay == "pipelined" else 4
     if not args.no_kernel_events:
         check(lib.cfx_profile_enable(ctx, args.steps * L + 8, 1 << KID_DEQ, args.event_stride), "profile_enable")
     sync_all()
@@ -395,34 +407,45 @@ def main():
         },
         "exchange_ms_per_step": round(ms_per_step, 4),
         "exchange_issued_by": exchange_mode,
+        "replay": args.replay,
         "raw_allgather_ms_per_step": None if raw_ms is None else round(raw_ms, 4),
         "speedup_vs_raw_allgather": None if raw_ms is None else round(raw_ms / ms_per_step, 3),
     }
     if kern_ms is not None:
-        alg = ALG_BYTES_PER_EL["decompress"] * 16 * N * C
+        if args.replay == "pipelined":
+            # reconstruct 16 tensors (bits + state in, state out: 4.125 B/el) + statistics/sign-bit pass of the next-but-one
+            # layer's K,V (x + state in, bits out: 4.125 B/el); the finalize group's traffic is negligible
+            alg = ALG_BYTES_PER_EL["decompress"] * 16 * N * C + 4.125 * 2 * N * C
+            kname = ("k_binary_pipe (one launch = dequant+add of 16 tensors x (544,3072) [own K,V error-feedback update + 7 "
+                     "peers' K,V] + finalize of the next layer's K,V scales + stats/sign bits of the layer after)")
+            pmc_key, csv_prefix = "k_binary_pipe_bytes_per_launch", "k_binary_pipe"
+        else:
+            alg = ALG_BYTES_PER_EL["decompress"] * 16 * N * C
+            kname = "k_binary_dequant (16 tensors x (544,3072) per launch: own K,V error-feedback update + 7 peers' K,V)"
+            pmc_key, csv_prefix = "k_binary_dequant_bytes_per_launch", "k_binary_dequant"
         ach = alg / (kern_ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_binary_dequant (16 tensors x (544,3072) per launch: own K,V error-feedback update + 7 peers' K,V)",
+        out["roofline"] = {"bound": "hbm", "kernel": kname,
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            "traffic": None, "traffic_source": None, "avg_launch_us": round(kern_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(alg),
                            "event_samples": n_samples, "event_stride": args.event_stride}
         prof = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(prof):
             try:
-                out["roofline"]["traffic"] = json.load(open(prof)).get("k_binary_dequant_bytes_per_launch")
+                out["roofline"]["traffic"] = json.load(open(prof)).get(pmc_key)
                 out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, round 1)"
             except Exception:
                 pass
         # cross-reference: the committed rocprofv3 --kernel-trace --stats summary of this same command.  The HIP-event
         # bracket of a single dispatch includes ~1.3-2 us of marker-to-kernel gap (tools/evtest.hip), so `achieved` above
         # is the conservative figure.
-        stats_csv = os.path.join(REPO, "profiles", "r01_bench_kernel_stats.csv")
-        if os.path.exists(stats_csv):
+        trace_json = os.path.join(REPO, "profiles", "r01_bench_kernel_durations.json")
+        if os.path.exists(trace_json):
             try:
-                import csv
-                for row in csv.DictReader(open(stats_csv)):
-                    if row["Name"].startswith("k_binary_dequant"):
-                        out["roofline"]["avg_launch_us_rocprof"] = round(float(row["AverageNs"]) / 1e3, 3)
-                        out["roofline"]["rocprof_source"] = "profiles/r01_bench_kernel_stats.csv"
+                ent = json.load(open(trace_json))["kernels"].get(csv_prefix)
+                if ent:
+                    out["roofline"]["avg_launch_us_rocprof"] = ent["avg_us"]
+                    out["roofline"]["rocprof_source"] = ("profiles/r01_bench_kernel_durations.json (tools/trace_kernel_avg.py over the "
+                                                         "rocprofv3 --kernel-trace of this command; full launches only)")
             except Exception:
                 pass
     else:

@@ -71,6 +71,7 @@ SYMBOLS = [
     ("cfx_plan_copy_op", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("cfx_plan_size", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_plan_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    ("cfx_plan_run_pipelined", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     ("cfx_copy_probe", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 ]
 

@@ -99,16 +99,17 @@ struct TileCoord {
     int lane, w, c, r0, r1;
     bool act;
 };
-__device__ __forceinline__ TileCoord tile_coord(int N, int C, int R) {
+__device__ __forceinline__ TileCoord tile_coord_at(int bx, int by, int N, int C, int R) {
     TileCoord t;
     t.lane = threadIdx.x & 63;
     t.w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    t.c = blockIdx.x * TILE_C + t.lane * 8;
+    t.c = bx * TILE_C + t.lane * 8;
     t.act = t.c < C;
-    t.r0 = blockIdx.y * R;
+    t.r0 = by * R;
     t.r1 = min(N, t.r0 + R);
     return t;
 }
+__device__ __forceinline__ TileCoord tile_coord(int N, int C, int R) { return tile_coord_at(blockIdx.x, blockIdx.y, N, C, R); }
 
 // ---------------------------------------------------------------------------------------------------
 // abs-mean statistics pass (1-bit and 2-bit codecs)      replaces fastpath.py:150-166 / :614-625 (E1/E2)
@@ -135,12 +136,13 @@ __device__ __forceinline__ u64 wave_sum4_u64(const u64 (&v)[4], int lane) {
     return b;   // lane 0: row 0, lane 16: row 1, lane 32: row 2, lane 48: row 3
 }
 
-template <bool EMIT_BITS>
-__global__ __launch_bounds__(NTHR) void k_absmean_stats(BatchC batch, int N, int C, int R, u64* ws, size_t ws_stride) {
-    const cfx_comp_item it = batch.it[blockIdx.z];
-    const TileCoord t = tile_coord(N, C, R);
-    const int CB = gridDim.x, cb = blockIdx.x;
-    u64* rowpart = ws + (size_t)blockIdx.z * ws_stride;
+// The body is shared by the stand-alone kernel and the fused pipeline kernel (k_binary_pipe): (bx, by) = tile index,
+// rowpart = this tensor's workspace, sm = WAVES x TILE_C words of LDS.
+template <bool EMIT_BITS, int US>
+__device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int N, int C, int R, int CB, int bx, int by,
+                                                   u64* rowpart, u64 (*sm)[TILE_C]) {
+    const TileCoord t = tile_coord_at(bx, by, N, C, R);
+    const int cb = bx;
     u64* colpart = rowpart + (size_t)N * CB;
     const h16* x = (const h16*)it.x;
     const h16* base = (const h16*)it.base;
@@ -154,10 +156,10 @@ __global__ __launch_bounds__(NTHR) void k_absmean_stats(BatchC batch, int N, int
 #pragma unroll
     for (int i = 0; i < 8; ++i) col[i] = 0.0;
 
-    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL_S) {
-        h16x8 xv[UNROLL_S], bv[UNROLL_S];
+    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * US) {
+        h16x8 xv[US], bv[US];
 #pragma unroll
-        for (int j = 0; j < UNROLL_S; ++j) {
+        for (int j = 0; j < US; ++j) {
             const int rr = r + WAVES * j;
             xv[j] = (h16x8)(h16)0;
             bv[j] = (h16x8)(h16)0;
@@ -167,11 +169,10 @@ __global__ __launch_bounds__(NTHR) void k_absmean_stats(BatchC batch, int N, int
                 if (base) bv[j] = ld8(base + (size_t)rr * C + t.c);
             }
         }
-        u64 rs[UNROLL_S];
+        u64 rs[4] = {0, 0, 0, 0};           // the butterfly reduces 4 rows; unused ones stay 0
 #pragma unroll
-        for (int j = 0; j < UNROLL_S; ++j) {
+        for (int j = 0; j < US; ++j) {
             const int rr = r + WAVES * j;
-            rs[j] = 0;
             if (rr < t.r1 && t.act) {
                 const h16x8 d = xv[j] - bv[j];
                 const h16x8 a = habs8(d);
@@ -189,39 +190,44 @@ __global__ __launch_bounds__(NTHR) void k_absmean_stats(BatchC batch, int N, int
             }
         }
         const u64 tot = wave_sum4_u64(rs, t.lane);
-        if ((t.lane & 15) == 0) {
+        if ((t.lane & 15) == 0 && (t.lane >> 4) < US) {
             const int rr = r + WAVES * (t.lane >> 4);
             if (rr < t.r1) rowpart[(size_t)rr * CB + cb] = tot;
         }
     }
-    __shared__ u64 sm[WAVES][TILE_C];
 #pragma unroll
     for (int i = 0; i < 8; ++i) sm[t.w][i * 64 + t.lane] = (u64)(col[i] * 16777216.0);   // exact; [i][lane]: conflict-free
     __syncthreads();
     for (int k = threadIdx.x; k < TILE_C; k += NTHR) {      // k = channel within the tile: coalesced global writes
         const int s = (k & 7) * 64 + (k >> 3);
-        const int cc = blockIdx.x * TILE_C + k;
-        if (cc < C) colpart[(size_t)blockIdx.y * C + cc] = sm[0][s] + sm[1][s] + sm[2][s] + sm[3][s];
+        const int cc = bx * TILE_C + k;
+        if (cc < C) colpart[(size_t)by * C + cc] = sm[0][s] + sm[1][s] + sm[2][s] + sm[3][s];
     }
+}
+
+template <bool EMIT_BITS>
+__global__ __launch_bounds__(NTHR) void k_absmean_stats(BatchC batch, int N, int C, int R, u64* ws, size_t ws_stride) {
+    __shared__ u64 sm[WAVES][TILE_C];
+    absmean_stats_body<EMIT_BITS, UNROLL_S>(batch.it[blockIdx.z], N, C, R, gridDim.x, blockIdx.x, blockIdx.y, ws + (size_t)blockIdx.z * ws_stride, sm);
 }
 
 // finalize: U[n] = rowmean/mean(rowmean) (1-bit, fastpath.py:164-165) or rowmean/(mean+1e-6) (2-bit, :619-622);
 //           V[c] = colmean (fastpath.py:160,166 / :618).  Written straight into the packet tail (replaces the
 //           torch.cat of main.py:149-152).  grid = (1 + ceil(C/256), batch).
-__global__ __launch_bounds__(1024) void k_absmean_finalize(BatchC batch, int N, int C, int CB, int P, int per_byte,
-                                                           int eps_mode, const u64* ws, size_t ws_stride) {
-    const cfx_comp_item it = batch.it[blockIdx.y];
-    const u64* rowpart = ws + (size_t)blockIdx.y * ws_stride;
+// Body shared with k_binary_pipe; NT = threads per block, block bx = 0 does the rows, blocks 1.. do NT/4 columns each;
+// smem = NT + 1 words of LDS.  All sums are exact integers, so the result does not depend on NT.
+template <int NT>
+__device__ __forceinline__ void absmean_finalize_body(const cfx_comp_item& it, int N, int C, int CB, int P, int per_byte, int eps_mode,
+                                                      const u64* rowpart, int bx, u64* smem) {
     const u64* colpart = rowpart + (size_t)N * CB;
     h16* U = (h16*)((char*)it.packet + (size_t)N * (C / per_byte));
     h16* V = U + N;
     const int tid = threadIdx.x;
-    if (blockIdx.x == 0) {
+    if (bx == 0) {
         // rows: one thread per row (all CB partial loads independent), exact sum of the fp16 row means, then divide
-        __shared__ u64 red[1024];
-        __shared__ h16 mu_s;
+        u64* red = smem;
         u64 acc = 0;
-        for (int n = tid; n < N; n += 1024) {
+        for (int n = tid; n < N; n += NT) {
             u64 s = 0;
 #pragma unroll 8
             for (int k = 0; k < CB; ++k) s += rowpart[(size_t)n * CB + k];
@@ -229,43 +235,49 @@ __global__ __launch_bounds__(1024) void k_absmean_finalize(BatchC batch, int N, 
         }
         red[tid] = acc;
         __syncthreads();
-        for (int o = 512; o > 0; o >>= 1) {
+        for (int o = NT / 2; o > 0; o >>= 1) {
             if (tid < o) red[tid] += red[tid + o];
             __syncthreads();
         }
-        if (tid == 0) mu_s = mean16(red[0], N);
+        if (tid == 0) smem[NT] = hbits(mean16(red[0], N));
         __syncthreads();
-        const h16 mu = mu_s;
+        const h16 mu = hfrom((u16)smem[NT]);
         const float den = eps_mode ? (float)(h16)((float)mu + 1e-6f) : (float)mu;
-        for (int n = tid; n < N; n += 1024) {
+        for (int n = tid; n < N; n += NT) {
             u64 s = 0;
 #pragma unroll 8
             for (int k = 0; k < CB; ++k) s += rowpart[(size_t)n * CB + k];
             U[n] = (h16)((float)mean16(s, C) / den);
         }
     } else {
-        // columns: 256 columns per block, 4 threads per column split the P partials (loads in flight together)
-        __shared__ u64 cs[4][256];
-        const int cl = tid & 255, q = tid >> 8;
-        const int c = (blockIdx.x - 1) * 256 + cl;
+        // columns: NT/4 columns per block, 4 threads per column split the P partials (loads in flight together)
+        constexpr int COLS = NT / 4;
+        u64* cs = smem;                       // [4][COLS]
+        const int cl = tid % COLS, q = tid / COLS;
+        const int c = (bx - 1) * COLS + cl;
         u64 s = 0;
         if (c < C) {
 #pragma unroll 4
             for (int p = q; p < P; p += 4) s += colpart[(size_t)p * C + c];
         }
-        cs[q][cl] = s;
+        cs[q * COLS + cl] = s;
         __syncthreads();
-        if (q == 0 && c < C) V[c] = mean16(cs[0][cl] + cs[1][cl] + cs[2][cl] + cs[3][cl], N);
+        if (q == 0 && c < C) V[c] = mean16(cs[cl] + cs[COLS + cl] + cs[2 * COLS + cl] + cs[3 * COLS + cl], N);
     }
+}
+
+__global__ __launch_bounds__(1024) void k_absmean_finalize(BatchC batch, int N, int C, int CB, int P, int per_byte,
+                                                           int eps_mode, const u64* ws, size_t ws_stride) {
+    __shared__ u64 smem[1024 + 8];
+    absmean_finalize_body<1024>(batch.it[blockIdx.y], N, C, CB, P, per_byte, eps_mode, ws + (size_t)blockIdx.y * ws_stride, blockIdx.x, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // 1-bit dequant + base add        replaces _binary_dequant_fastpath (fastpath.py:277-367) AND the
 // UPDATE_CACHE branch of _binary_quant_fastpath (fastpath.py:88-120): out = base + (2b-1)*fp16(u[n]*v[c])
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, int C, int R) {
-    const cfx_decomp_item it = batch.it[blockIdx.z];
-    const TileCoord t = tile_coord(N, C, R);
+__device__ __forceinline__ void binary_dequant_body(const cfx_decomp_item& it, int N, int C, int R, int tile_x, int tile_y) {
+    const TileCoord t = tile_coord_at(tile_x, tile_y, N, C, R);
     const unsigned char* pk = (const unsigned char*)it.packet;
     const int C8 = C >> 3;
     const h16* U = (const h16*)(pk + (size_t)N * C8);
@@ -305,6 +317,53 @@ __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, in
             }
         }
     }
+}
+
+__global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, int C, int R) {
+    binary_dequant_body(batch.it[blockIdx.z], N, C, R, blockIdx.x, blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Software-pipelined 1-bit exchange step: ONE launch carries three independent groups of workgroups,
+//   finalize(layer j+1)  |  stats + sign bits(layer j+2)  |  dequant + add(layer j)
+// so the two small latency-bound kernels of the compress sequence run underneath the bandwidth-bound reconstruction of
+// an earlier layer instead of in front of it (cfx_plan_run_pipelined builds the schedule; each group runs exactly the
+// code of its stand-alone kernel, so results are bit-identical).  The latency-critical finalize blocks come first in
+// dispatch order.  Any group may be empty (pipeline prologue / epilogue).
+// ---------------------------------------------------------------------------------------------------
+#ifndef PIPE_US
+#define PIPE_US 2      // rows in flight per wave in the fused kernel's stats group (register budget of 8 waves / SIMD)
+#endif
+struct PipeArgs {
+    int N, C;
+    int n_fin, fin_bpi, CB, P;          // finalize: blocks in the group, blocks per tensor, stats grid that produced the partials
+    int n_st, st_R;                     // stats: blocks in the group, tile height (grid CB x P per tensor)
+    int dq_R, dq_rb;                    // dequant: tile height, row blocks per tensor
+    const u64* ws_fin;
+    u64* ws_st;
+    size_t ws_stride;
+};
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_binary_pipe(BatchD dq, BatchC fin, BatchC st, PipeArgs a) {
+    __shared__ u64 sm[WAVES][TILE_C];
+    int b = blockIdx.x;
+    if (b < a.n_fin) {
+        const int item = b / a.fin_bpi;
+        absmean_finalize_body<NTHR>(fin.it[item], a.N, a.C, a.CB, a.P, 8, 0, a.ws_fin + (size_t)item * a.ws_stride, b - item * a.fin_bpi, &sm[0][0]);
+        return;
+    }
+    b -= a.n_fin;
+    if (b < a.n_st) {
+        const int per = a.CB * a.P;
+        const int item = b / per, rem = b - item * per;
+        const int ty = rem / a.CB;
+        absmean_stats_body<true, PIPE_US>(st.it[item], a.N, a.C, a.st_R, a.CB, rem - ty * a.CB, ty, a.ws_st + (size_t)item * a.ws_stride, sm);
+        return;
+    }
+    b -= a.n_st;
+    const int per = a.CB * a.dq_rb;
+    const int item = b / per, rem = b - item * per;
+    const int ty = rem / a.CB;
+    binary_dequant_body(dq.it[item], a.N, a.C, a.dq_R, rem - ty * a.CB, ty);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1138,6 +1197,8 @@ struct cfx_plan {
     int n, cap;
     hipStream_t side;     // exchange stream (created on first all-gather op)
     int side_mode;        // 0: issue collectives on the main stream (no cross-stream events), 1: side stream, 2: prioritised side stream
+    void* ws2;            // cfx_plan_run_pipelined: second statistics workspace (stats(j+2) runs beside finalize(j+1))
+    size_t ws2_bytes;
 };
 
 cfx_plan* cfx_plan_create(cfx_ctx* ctx) {
@@ -1147,6 +1208,8 @@ cfx_plan* cfx_plan_create(cfx_ctx* ctx) {
     p->ops = nullptr;
     p->n = p->cap = 0;
     p->side = nullptr;
+    p->ws2 = nullptr;
+    p->ws2_bytes = 0;
     // Default: collectives in order on the main stream.  Measured on MI355X / ROCm 7: one cross-stream event hop costs
     // ~10 us of idle queue time, two per layer (main->side, side->main) = +1.1 ms per 57-layer step, whereas the
     // in-order exchange adds 0.1 ms; a side stream only pays when >> 20 us of independent work can overlap (attention).
@@ -1165,9 +1228,12 @@ int cfx_plan_set_exchange_stream(cfx_plan* p, int mode) {
 
 void cfx_plan_destroy(cfx_plan* p) {
     if (!p) return;
-    for (int i = 0; i < p->n; ++i)
-        if (p->ops[i].kind == 2) { (void)hipEventDestroy(p->ops[i].ev_pre); (void)hipEventDestroy(p->ops[i].ev_done); }
+    for (int i = 0; i < p->n; ++i) {
+        if (p->ops[i].ev_pre) (void)hipEventDestroy(p->ops[i].ev_pre);
+        if (p->ops[i].ev_done) (void)hipEventDestroy(p->ops[i].ev_done);
+    }
     if (p->side) (void)hipStreamDestroy(p->side);
+    if (p->ws2) (void)hipFree(p->ws2);
     delete[] p->ops;
     delete p;
 }
@@ -1217,6 +1283,7 @@ int cfx_plan_copy_op(cfx_plan* dst, const cfx_plan* src, int op) {
     const PlanOp tmp = src->ops[op];
     PlanOp* o = plan_push(dst);
     *o = tmp;
+    o->ev_pre = o->ev_done = nullptr;      // events belong to the op they were created for
     return dst->n - 1;
 }
 
@@ -1281,6 +1348,105 @@ int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) {
         if (rc != CFX_OK) return rc;
     }
     return CFX_OK;
+}
+
+// Software-pipelined replay of a 1-bit exchange step.  The op range must be a sequence of "layers"
+//     compress(j) [BINARY, no cache update]  { all-gather }*  decompress(j) [BINARY]
+// of one shape (what bench.py and the ring gather schedule build).  It is replayed on ONE stream as
+//     stats(0) | finalize(0)+stats(1) | { all-gather(j) ; [dequant(j) + finalize(j+1) + stats(j+2)] } for j = 0..L-1
+// where each bracket is ONE k_binary_pipe launch: the latency-bound stats / finalize kernels of the next layers run
+// underneath the bandwidth-bound reconstruction of layer j (measured on MI355X, FLUX step: 1.83 -> see DESIGN.md section 3;
+// a two-stream version of the same idea loses to the ~10 us cross-stream event hops and to the slowdown of the small
+// kernels under contention).  Results are bit-identical to cfx_plan_run (same device code per group).  Statistics
+// workspaces alternate between the ops' own workspace (even layers) and a plan-owned one (odd layers).  Any other op
+// sequence falls back to cfx_plan_run.
+struct PipeLayer { int comp, deq, first_mid, n_mid; };
+
+static int launch_pipe(cfx_ctx* ctx, hipStream_t s, int N, int C, const PlanOp* dq, const PlanOp* fin, const void* ws_fin,
+                       const PlanOp* st, void* ws_st) {
+    BatchD bd; BatchC bf, bs;
+    memset(&bd, 0, sizeof(bd)); memset(&bf, 0, sizeof(bf)); memset(&bs, 0, sizeof(bs));
+    PipeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = N; a.C = C;
+    a.CB = (C + TILE_C - 1) / TILE_C;
+    const int comp_batch = fin ? fin->batch : (st ? st->batch : 1);
+    a.st_R = auto_rows(ctx, N, C, comp_batch, true);
+    a.P = (N + a.st_R - 1) / a.st_R;
+    a.ws_stride = ws_words(CFX_CODEC_BINARY, N, C);
+    if (fin) {
+        for (int i = 0; i < fin->batch; ++i) bf.it[i] = fin->c[i];
+        a.fin_bpi = 1 + (C + NTHR / 4 - 1) / (NTHR / 4);
+        a.n_fin = a.fin_bpi * fin->batch;
+        a.ws_fin = (const u64*)ws_fin;
+    }
+    if (st) {
+        for (int i = 0; i < st->batch; ++i) bs.it[i] = st->c[i];
+        a.n_st = a.CB * a.P * st->batch;
+        a.ws_st = (u64*)ws_st;
+    }
+    int n_dq = 0;
+    if (dq) {
+        for (int i = 0; i < dq->batch; ++i) bd.it[i] = dq->d[i];
+        a.dq_R = auto_rows(ctx, N, C, dq->batch, false);
+        a.dq_rb = (N + a.dq_R - 1) / a.dq_R;
+        n_dq = a.CB * a.dq_rb * dq->batch;
+    }
+    const int kid = (dq && fin && st) ? KID_BINARY_PIPE : KID_BINARY_PIPE_EDGE;
+    LAUNCH(ctx, kid, s, k_binary_pipe, dim3(a.n_fin + a.n_st + n_dq), dim3(NTHR), 0, s, bd, bf, bs, a);
+    return check_launch(ctx, "pipelined launch");
+}
+
+int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
+    if (!p) return CFX_ERR_NULL;
+    if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
+    const int end = first_op + n_ops;
+    // ---- recognise the layer pattern ------------------------------------------------------------------------------------
+    PipeLayer* layers = new PipeLayer[n_ops > 0 ? n_ops : 1];
+    int L = 0, N = 0, C = 0;
+    bool ok = n_ops > 0 && p->side_mode == 0;
+    for (int i = first_op; ok && i < end;) {
+        const PlanOp* c = &p->ops[i];
+        if (c->kind != 0 || c->codec != CFX_CODEC_BINARY || (c->flags & CFX_FLAG_UPDATE_CACHE)) { ok = false; break; }
+        if (L == 0) { N = c->N; C = c->C; }
+        if (c->N != N || c->C != C) { ok = false; break; }
+        int k = i + 1;
+        while (k < end && (p->ops[k].kind == 2 || p->ops[k].kind == 3)) ++k;
+        if (k >= end || p->ops[k].kind != 1 || p->ops[k].codec != CFX_CODEC_BINARY || p->ops[k].N != N || p->ops[k].C != C) { ok = false; break; }
+        layers[L].comp = i; layers[L].first_mid = i + 1; layers[L].n_mid = k - (i + 1); layers[L].deq = k;
+        ++L;
+        i = k + 1;
+    }
+    if (!ok) { delete[] layers; return cfx_plan_run(p, first_op, n_ops, stream); }
+    for (int j = 0; j < L; ++j) {
+        const PlanOp* c = &p->ops[layers[j].comp];
+        const size_t need = cfx_workspace_bytes(CFX_CODEC_BINARY, N, C, 0, c->batch);
+        if (!c->ws || c->ws_bytes < need) { delete[] layers; return fail(p->ctx, CFX_ERR_WORKSPACE, "plan: workspace too small"); }
+        if (need > p->ws2_bytes) {
+            if (p->ws2) (void)hipFree(p->ws2);
+            p->ws2 = nullptr; p->ws2_bytes = 0;
+            if (hipMalloc(&p->ws2, need) != hipSuccess) { delete[] layers; return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot allocate the second workspace"); }
+            p->ws2_bytes = need;
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    auto ws_of = [&](int j) -> void* { return (j & 1) ? p->ws2 : p->ops[layers[j].comp].ws; };
+    auto comp = [&](int j) -> const PlanOp* { return j < L ? &p->ops[layers[j].comp] : nullptr; };
+    int rc = launch_pipe(p->ctx, s, N, C, nullptr, nullptr, nullptr, comp(0), ws_of(0));
+    if (rc == CFX_OK) rc = launch_pipe(p->ctx, s, N, C, nullptr, comp(0), ws_of(0), comp(1), L > 1 ? ws_of(1) : nullptr);
+    for (int j = 0; rc == CFX_OK && j < L; ++j) {
+        for (int m = 0; m < layers[j].n_mid; ++m) {
+            const PlanOp* o = &p->ops[layers[j].first_mid + m];
+            if (o->kind == 2 && g_rccl.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, s) != 0) {
+                delete[] layers;
+                return fail(p->ctx, CFX_ERR_LAUNCH, "ncclAllGather failed");
+            }
+        }
+        rc = launch_pipe(p->ctx, s, N, C, &p->ops[layers[j].deq], comp(j + 1), j + 1 < L ? ws_of(j + 1) : nullptr,
+                         comp(j + 2), j + 2 < L ? ws_of(j + 2) : nullptr);
+    }
+    delete[] layers;
+    return rc;
 }
 
 // ---- communicator -----------------------------------------------------------------------------------------------------

@@ -350,6 +350,74 @@ def test_prepared_batches_equal_direct_calls(codec):
         comp([xs[0][:, :512].contiguous(), xs[1]])
 
 
+@pytest.mark.parametrize("N,C,L,B", [(96, 1024, 5, 2), (544, 3072, 4, 2), (70, 520, 3, 1), (128, 512, 1, 2), (64, 1536, 2, 3)])
+def test_pipelined_plan_replay_is_bit_identical(N, C, L, B):
+    """cfx_plan_run_pipelined (fused finalize | stats | dequant launches, layers software-pipelined) == cfx_plan_run on a
+    bench-shaped plan: per layer compress(K,V) without cache update, then one reconstruction over own + peer states."""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    ctx = K.context(0)
+    PEERS = 3
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(L, B, N, C, generator=g).half().cuda()
+    base0 = (x.float() + 0.1 * torch.randn(L, B, N, C, generator=g).cuda()).half()
+    peer0 = torch.randn(L, PEERS, B, N, C, generator=g).half().cuda()
+    pb = K.packet_bytes(1, N, C)
+    slot = (pb + 255) // 256 * 256
+    wsb = lib.cfx_workspace_bytes(1, N, C, 0, B)
+    results = []
+    for mode in ("inorder", "pipelined"):
+        own, peers = base0.clone(), peer0.clone()
+        send = torch.zeros(L, B, slot, dtype=torch.uint8, device="cuda")
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        plan = lib.cfx_plan_create(ctx)
+        for l in range(L):
+            c = (_lib.CompItem * B)(*[_lib.CompItem(x[l, i].data_ptr(), own[l, i].data_ptr(), None, send[l, i].data_ptr()) for i in range(B)])
+            assert lib.cfx_plan_add_compress(plan, 1, N, C, 0, 0, B, c, ws.data_ptr(), wsb) == 2 * l
+            items = [_lib.DecompItem(send[l, i].data_ptr(), own[l, i].data_ptr(), own[l, i].data_ptr()) for i in range(B)]
+            items += [_lib.DecompItem(send[l, i].data_ptr(), peers[l, q, i].data_ptr(), peers[l, q, i].data_ptr())
+                      for q in range(PEERS) for i in range(B)]
+            d = (_lib.DecompItem * len(items))(*items)
+            assert lib.cfx_plan_add_decompress(plan, 1, N, C, 0, len(items), d) == 2 * l + 1
+        run = lib.cfx_plan_run if mode == "inorder" else lib.cfx_plan_run_pipelined
+        for _ in range(2):                                 # two steps: the second one starts from the first one's state
+            assert run(plan, 0, 2 * L, torch.cuda.current_stream().cuda_stream) == 0, lib.cfx_last_error_string(ctx)
+        torch.cuda.synchronize()
+        lib.cfx_plan_destroy(plan)
+        results.append((own, peers, send))
+    for a, b in zip(*results):
+        assert torch.equal(a.view(torch.int16) if a.dtype == torch.float16 else a, b.view(torch.int16) if b.dtype == torch.float16 else b)
+    # and the state machine property still holds: the sender's EF state is what a peer that started equal would hold
+    assert not torch.equal(results[1][0].view(torch.int16), base0.view(torch.int16))
+
+
+def test_pipelined_replay_falls_back_for_other_patterns():
+    """An op sequence that is not the 1-bit layer pattern (here: 2-bit, cache update inside the compress op) is replayed
+    in order by the same entry point."""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    ctx = K.context(0)
+    N, C, B = 96, 1024, 2
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(N, C, generator=g).half().cuda() for _ in range(B)]
+    ref_b = [(t.float() + 0.1 * torch.randn(N, C, generator=g).cuda()).half() for t in xs]
+    own = [b.clone() for b in ref_b]
+    pk_ref = [torch.zeros(K.packet_halves(2, N, C), dtype=torch.float16, device="cuda") for _ in range(B)]
+    pk = [torch.zeros_like(t) for t in pk_ref]
+    K.compress_batch(2, xs, ref_b, ref_b, pk_ref, N, C, update_cache=True)
+    wsb = lib.cfx_workspace_bytes(2, N, C, 0, B)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    plan = lib.cfx_plan_create(ctx)
+    c = (_lib.CompItem * B)(*[_lib.CompItem(xs[i].data_ptr(), own[i].data_ptr(), own[i].data_ptr(), pk[i].data_ptr()) for i in range(B)])
+    assert lib.cfx_plan_add_compress(plan, 2, N, C, 0, 1, B, c, ws.data_ptr(), wsb) == 0
+    assert lib.cfx_plan_run_pipelined(plan, 0, 1, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    for i in range(B):
+        assert torch.equal(pk[i].view(torch.int16), pk_ref[i].view(torch.int16))
+        assert torch.equal(own[i].view(torch.int16), ref_b[i].view(torch.int16))
+    lib.cfx_plan_destroy(plan)
+
+
 def test_native_comm_single_rank(tmp_path):
     """libcfx's own RCCL communicator (1 rank): unique id, init, all-gather through a plan on every stream mode."""
     import torch.distributed as dist

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Per-kernel average duration from a rocprofv3 --kernel-trace CSV, keeping for every kernel only its launches with the
+largest grid (k_binary_pipe: the full three-group launches, not the pipeline's prologue / epilogue launches).
+Usage: tools/trace_kernel_avg.py <kernel_trace.csv> <out.json>"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def main():
+    src, out = sys.argv[1:3]
+    by = defaultdict(list)
+    for r in csv.DictReader(open(src)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        grid = int(r.get("Grid_Size", 0) or 0) or (int(r.get("Grid_Size_X", 1)) * int(r.get("Grid_Size_Y", 1)) * int(r.get("Grid_Size_Z", 1)))
+        by[name].append((grid, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    res = {"source": "rocprofv3 --kernel-trace", "unit": "us", "kernels": {}}
+    for name, v in by.items():
+        if not name.startswith("k_"):
+            continue
+        top = max(g for g, _ in v)
+        d = sorted(t for g, t in v if g == top)
+        res["kernels"][name] = {"launches": len(d), "all_launches": len(v), "grid_threads": top, "avg_us": round(sum(d) / len(d), 3),
+                                "median_us": round(d[len(d) // 2], 3), "min_us": round(d[0], 3), "max_us": round(d[-1], 3)}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
