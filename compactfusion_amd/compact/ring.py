@@ -188,9 +188,15 @@ class _LayerExchange:
             assert b is not None, f"no cached base for key {key}: a WARMUP step must precede residual compression"
             return b
         own = [state(self.kkeys[self.rank]), state(self.vkeys[self.rank])]
-        self.comp = codecs.prepare_compress(cid, own, own, [self.send[:n_half], self.send[self.slot:self.slot + n_half]],
-                                            N, C, param, update_cache=True, ef=ef)
-        bases, pkts, self.peer_views = [], [], []
+        own_pkts = [self.send[:n_half], self.send[self.slot:self.slot + n_half]]
+        # the sender's error-feedback update IS the receiver's dequant+add run on its own packet (fastpath.py:88-120), so
+        # it rides in the batched reconstruction launch (own K,V + all peers' K,V = 16 tensors at W = 8) instead of a
+        # launch of its own; the compress sequence is then stats -> finalize only
+        self.comp = codecs.prepare_compress(cid, own, [None, None], own_pkts, N, C, param, update_cache=False, ef=ef)
+        bases, pkts, self.peer_views = list(own), list(own_pkts), []
+        if not ef:
+            # no error feedback: the state becomes the activation itself (main.py:240-243) - done by the caller
+            bases, pkts = [], []
         for r in self.peers:
             bk, bv = state(self.kkeys[r]), state(self.vkeys[r])
             bases += [bk, bv]
@@ -239,6 +245,9 @@ def _gather_schedule(q, k, v, ctype, mod_idx, rank, world, group, kkey, vkey, at
             ex.bind(sig, cid, param, N, C, n_half, kshape, vshape, cfg.error_feedback)
         with Profiler.scope("compact.compress_batch"):
             ex.comp((k, v), sh)
+        if not cfg.error_feedback:
+            cache.put(ex.kkeys[rank], k.view(N, C), None)
+            cache.put(ex.vkeys[rank], v.view(N, C), None)
         cm._current_cache_key = ex.vkeys[rank]
         live = _collector_live()
         if live:
