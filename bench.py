@@ -57,6 +57,9 @@ def parse():
                     help="pipelined (default): cfx_plan_run_pipelined - one fused launch per layer, the statistics / finalize "
                          "work of the next two layers rides underneath the reconstruction of the current one; "
                          "inorder: cfx_plan_run, three launches per layer one after the other (same results, bit for bit)")
+    ap.add_argument("--gather-group", type=int, default=4,
+                    help="N > 1, native exchange: layers whose packets travel in ONE all-gather (fewer, larger collectives; the "
+                         "pipelined replay looks that many layers ahead with the statistics kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -103,6 +106,17 @@ def cpu_baseline(seconds: float):
     return {"value": round(act_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": int(CO.num_threads()), "kind": "port",
             "sample": f"{reps} x one layer of the workload (2 compress + 14 decompress, 1-bit, (544,3072) fp16) in {dt:.1f} s, "
                       f"C oracle oracle/cfx_oracle.c with OpenMP"}
+
+
+def group_recv_offset(l: int, r: int, kv: int, G: int, L: int, live: int, slot: int) -> int:
+    """Byte offset of rank r's packet (kv = 0: K, 1: V) of layer l in the grouped receive buffer.
+
+    Layers travel G at a time: group g = layers [a, b) = [gG, min(L, gG + G)).  One all-gather per group sends
+    send[a:b] = [layer][K|V][slot] (contiguous, (b-a)*2*slot bytes per rank) and receives [rank][layer in group][K|V][slot];
+    the groups' receive regions follow each other, so the region of group g starts after a*live*2*slot bytes."""
+    a = (l // G) * G
+    b = min(L, a + G)
+    return (a * live * 2 + (r * (b - a) + (l - a)) * 2 + kv) * slot
 
 
 def main():
@@ -200,9 +214,11 @@ def main():
     compute = torch.cuda.current_stream(dev)
     sh = compute.cuda_stream
 
-    # ---- N > 1: the whole step as ONE native plan, the per-layer all-gather issued by libcfx's own RCCL communicator.
-    #      Default order: compress(l) -> all-gather(l) -> reconstruct(l) in order on one stream (a cross-stream event hop
-    #      costs ~10 us on this stack - more than the wire time of a 0.4 MB packet - so no side stream here) ----
+    # ---- N > 1: the whole step as ONE native plan, the all-gathers issued by libcfx's own RCCL communicator in order on
+    #      the main stream (a cross-stream event hop costs ~10 us on this stack - more than the wire time of a packet - so no
+    #      side stream here).  --gather-group layers share one all-gather (fewer, larger collectives: each call
+    #      has a fixed latency that nothing overlaps on a single stream); the pipelined replay computes the statistics that
+    #      many layers ahead so every collective's inputs are final when it is issued. ----
     native_comm, step_plans, exchange_mode = None, None, "none"
     if use_dist:
         exchange_mode = "torch"
@@ -211,35 +227,38 @@ def main():
                 from compactfusion_amd.exchange import NativeComm
                 native_comm = NativeComm(local_rank)
                 native_comm.self_test()
+                # grouped exchange buffers: group g = layers [gG, gG + nl); ONE all-gather moves the group's K,V packets of
+                # every rank: send = send[gG : gG + nl] (contiguous), recv region laid out [rank][layer in group][K|V][slot]
+                G = max(1, args.gather_group)
+                groups = [(a, min(L, a + G)) for a in range(0, L, G)]
+                grecv = torch.zeros(L * live * 2 * slot, dtype=torch.uint8, device=dev)
+
+                def grecv_ptr(l, r, kv):
+                    return grecv.data_ptr() + group_recv_offset(l, r, kv, G, L, live, slot)
                 step_plans = []
                 for s in range(2):
                     sp = lib.cfx_plan_create(ctx)
                     src = plans[s]
-
-                    def copy_op(i):
-                        rcx = lib.cfx_plan_copy_op(sp, src, i)
+                    if os.environ.get("CFX_EXCHANGE_STREAM", "main") != "main":
+                        raise RuntimeError("side-stream exchange modes are only kept in the plan API (tests); the bench issues "
+                                           "collectives in order on the main stream")
+                    for a, b in groups:
+                        for l in range(a, b):
+                            assert lib.cfx_plan_copy_op(sp, src, 2 * l) >= 0
+                        rcx = lib.cfx_plan_add_all_gather(sp, native_comm.handle, send[a].data_ptr(), grecv.data_ptr() + a * live * 2 * slot,
+                                                          (b - a) * 2 * slot)
                         assert rcx >= 0, rcx
-                    gidx = [None] * L
-
-                    def add_gather(l):
-                        gidx[l] = lib.cfx_plan_add_all_gather(sp, native_comm.handle, send[l].data_ptr(), recv[l].data_ptr(), 2 * slot)
-                        assert gidx[l] >= 0, gidx[l]
-                    if os.environ.get("CFX_EXCHANGE_STREAM", "main") == "main":
-                        # in-order on one stream: compress(l) -> all-gather(l) -> reconstruct(l)
-                        for l in range(L):
-                            copy_op(2 * l)
-                            add_gather(l)
-                            copy_op(2 * l + 1)
-                    else:
-                        # side stream: gather(l+1) overlaps reconstruct(l)
-                        copy_op(0)
-                        add_gather(0)
-                        for l in range(L):
-                            if l + 1 < L:
-                                copy_op(2 * (l + 1))
-                                add_gather(l + 1)
-                            assert lib.cfx_plan_add_wait(sp, gidx[l]) >= 0
-                            copy_op(2 * l + 1)
+                        for l in range(a, b):
+                            darr = (_lib.DecompItem * 16)()
+                            for kv in range(2):
+                                darr[kv] = _lib.DecompItem(send[l, kv].data_ptr(), own_base[l, kv].data_ptr(), own_base[l, kv].data_ptr())
+                            i = 2
+                            for p in range(W_LOGICAL - 1):
+                                for kv in range(2):
+                                    pk_ptr = grecv_ptr(l, (rank + 1 + p) % live, kv) if (live > 1 and p < live - 1) else send[l, kv].data_ptr()
+                                    darr[i] = _lib.DecompItem(pk_ptr, peer_base[l, p, kv].data_ptr(), peer_base[l, p, kv].data_ptr())
+                                    i += 1
+                            assert lib.cfx_plan_add_decompress(sp, CODEC, N, C, 0, 16, darr) >= 0
                     step_plans.append(sp)
                 exchange_mode = "native"
             except Exception as e:  # pragma: no cover
@@ -295,15 +314,18 @@ def main():
         if live == 1:
             same = torch.equal(own_base[0, 0].view(torch.int16), peer_base[0, 0, 0].view(torch.int16))
             return same, "EF state of the looped-back peer diverged from the sender's"
-        mine = own_base[L - 1, 0].reshape(-1)[:8192].view(torch.int32).contiguous()       # int32: a dtype every backend moves
-        allm = torch.empty(live * 4096, dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(allm, mine)
+        # sampled over layers that sit at different positions of an all-gather group, K and V
+        samples = sorted({(l, kv) for l in (0, 1, min(L - 1, max(1, args.gather_group) - 1), L // 2, L - 1) for kv in (0, 1) if l < L})
         good = torch.ones(1, dtype=torch.int32, device=dev)
-        for p in range(live - 1):
-            src = (rank + 1 + p) % live
-            got = peer_base[L - 1, p, 0].reshape(-1)[:8192].view(torch.int32)
-            if not torch.equal(got, allm[src * 4096:(src + 1) * 4096]):
-                good.zero_()
+        for l, kv in samples:
+            mine = own_base[l, kv].reshape(-1)[:8192].view(torch.int32).contiguous()       # int32: a dtype every backend moves
+            allm = torch.empty(live * 4096, dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(allm, mine)
+            for p in range(live - 1):
+                src = (rank + 1 + p) % live
+                got = peer_base[l, p, kv].reshape(-1)[:8192].view(torch.int32)
+                if not torch.equal(got, allm[src * 4096:(src + 1) * 4096]):
+                    good.zero_()
         dist.all_reduce(good, op=dist.ReduceOp.MIN)
         return bool(good.item()), f"rank {rank}: a peer's reconstructed state diverged from its owner's"
 
@@ -408,6 +430,7 @@ def main():
         "exchange_ms_per_step": round(ms_per_step, 4),
         "exchange_issued_by": exchange_mode,
         "replay": args.replay,
+        "layers_per_all_gather": (max(1, args.gather_group) if (use_dist and step_plans is not None) else None),
         "raw_allgather_ms_per_step": None if raw_ms is None else round(raw_ms, 4),
         "speedup_vs_raw_allgather": None if raw_ms is None else round(raw_ms / ms_per_step, 3),
     }

@@ -1350,18 +1350,18 @@ int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) {
     return CFX_OK;
 }
 
-// Software-pipelined replay of a 1-bit exchange step.  The op range must be a sequence of "layers"
-//     compress(j) [BINARY, no cache update]  { all-gather }*  decompress(j) [BINARY]
-// of one shape (what bench.py and the ring gather schedule build).  It is replayed on ONE stream as
-//     stats(0) | finalize(0)+stats(1) | { all-gather(j) ; [dequant(j) + finalize(j+1) + stats(j+2)] } for j = 0..L-1
-// where each bracket is ONE k_binary_pipe launch: the latency-bound stats / finalize kernels of the next layers run
-// underneath the bandwidth-bound reconstruction of layer j (measured on MI355X, FLUX step: 1.83 -> see DESIGN.md section 3;
+// Software-pipelined replay of a 1-bit exchange step.  The op range must be a sequence of "groups"
+//     k x compress [BINARY, no cache update]   { all-gather }*   k x decompress [BINARY]            (k >= 1, one shape)
+// i.e. layers whose packets travel in one collective (k = 1: what the ring gather schedule builds; bench.py groups
+// several layers per all-gather: fewer, larger collectives).  With L layers in program order and look-ahead
+// d = (largest k) - 1 the range is replayed on ONE stream as launch slots t = 0 .. L+1+d:
+//     { all-gathers whose last input layer b has b + 2 <= t }  ;  K_t = [dequant(t-2-d) | finalize(t-1) | stats(t)]
+// where K_t is ONE k_binary_pipe launch: the latency-bound stats / finalize kernels of later layers run underneath the
+// bandwidth-bound reconstruction of an earlier one (measured on MI355X, FLUX step: 1.82 -> 1.35 ms, DESIGN.md section 3;
 // a two-stream version of the same idea loses to the ~10 us cross-stream event hops and to the slowdown of the small
 // kernels under contention).  Results are bit-identical to cfx_plan_run (same device code per group).  Statistics
 // workspaces alternate between the ops' own workspace (even layers) and a plan-owned one (odd layers).  Any other op
 // sequence falls back to cfx_plan_run.
-struct PipeLayer { int comp, deq, first_mid, n_mid; };
-
 static int launch_pipe(cfx_ctx* ctx, hipStream_t s, int N, int C, const PlanOp* dq, const PlanOp* fin, const void* ws_fin,
                        const PlanOp* st, void* ws_st) {
     BatchD bd; BatchC bf, bs;
@@ -1401,51 +1401,67 @@ int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
     if (!p) return CFX_ERR_NULL;
     if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
     const int end = first_op + n_ops;
-    // ---- recognise the layer pattern ------------------------------------------------------------------------------------
-    PipeLayer* layers = new PipeLayer[n_ops > 0 ? n_ops : 1];
-    int L = 0, N = 0, C = 0;
+    // ---- recognise the group pattern ------------------------------------------------------------------------------------
+    const int cap = n_ops > 0 ? n_ops : 1;
+    int* comp_op = new int[cap];
+    int* deq_op = new int[cap];
+    int* ag_op = new int[cap];
+    int* ag_last = new int[cap];          // index of the last layer whose packet an all-gather carries
+    int L = 0, n_ag = 0, N = 0, C = 0, gmax = 0;
     bool ok = n_ops > 0 && p->side_mode == 0;
+    auto cleanup = [&]() { delete[] comp_op; delete[] deq_op; delete[] ag_op; delete[] ag_last; };
     for (int i = first_op; ok && i < end;) {
-        const PlanOp* c = &p->ops[i];
-        if (c->kind != 0 || c->codec != CFX_CODEC_BINARY || (c->flags & CFX_FLAG_UPDATE_CACHE)) { ok = false; break; }
-        if (L == 0) { N = c->N; C = c->C; }
-        if (c->N != N || c->C != C) { ok = false; break; }
-        int k = i + 1;
-        while (k < end && (p->ops[k].kind == 2 || p->ops[k].kind == 3)) ++k;
-        if (k >= end || p->ops[k].kind != 1 || p->ops[k].codec != CFX_CODEC_BINARY || p->ops[k].N != N || p->ops[k].C != C) { ok = false; break; }
-        layers[L].comp = i; layers[L].first_mid = i + 1; layers[L].n_mid = k - (i + 1); layers[L].deq = k;
-        ++L;
-        i = k + 1;
+        int k = 0;
+        while (i < end && p->ops[i].kind == 0) {
+            const PlanOp* c = &p->ops[i];
+            if (c->codec != CFX_CODEC_BINARY || (c->flags & CFX_FLAG_UPDATE_CACHE)) { ok = false; break; }
+            if (L + k == 0) { N = c->N; C = c->C; }
+            if (c->N != N || c->C != C) { ok = false; break; }
+            comp_op[L + k++] = i++;
+        }
+        if (!ok || k == 0) { ok = false; break; }
+        while (i < end && (p->ops[i].kind == 2 || p->ops[i].kind == 3)) {
+            if (p->ops[i].kind == 2) { ag_op[n_ag] = i; ag_last[n_ag++] = L + k - 1; }
+            ++i;
+        }
+        for (int m = 0; m < k; ++m, ++i) {
+            if (i >= end || p->ops[i].kind != 1 || p->ops[i].codec != CFX_CODEC_BINARY || p->ops[i].N != N || p->ops[i].C != C) { ok = false; break; }
+            deq_op[L + m] = i;
+        }
+        if (!ok) break;
+        L += k;
+        if (k > gmax) gmax = k;
     }
-    if (!ok) { delete[] layers; return cfx_plan_run(p, first_op, n_ops, stream); }
+    if (!ok) { cleanup(); return cfx_plan_run(p, first_op, n_ops, stream); }
     for (int j = 0; j < L; ++j) {
-        const PlanOp* c = &p->ops[layers[j].comp];
+        const PlanOp* c = &p->ops[comp_op[j]];
         const size_t need = cfx_workspace_bytes(CFX_CODEC_BINARY, N, C, 0, c->batch);
-        if (!c->ws || c->ws_bytes < need) { delete[] layers; return fail(p->ctx, CFX_ERR_WORKSPACE, "plan: workspace too small"); }
+        if (!c->ws || c->ws_bytes < need) { cleanup(); return fail(p->ctx, CFX_ERR_WORKSPACE, "plan: workspace too small"); }
         if (need > p->ws2_bytes) {
             if (p->ws2) (void)hipFree(p->ws2);
             p->ws2 = nullptr; p->ws2_bytes = 0;
-            if (hipMalloc(&p->ws2, need) != hipSuccess) { delete[] layers; return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot allocate the second workspace"); }
+            if (hipMalloc(&p->ws2, need) != hipSuccess) { cleanup(); return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot allocate the second workspace"); }
             p->ws2_bytes = need;
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    auto ws_of = [&](int j) -> void* { return (j & 1) ? p->ws2 : p->ops[layers[j].comp].ws; };
-    auto comp = [&](int j) -> const PlanOp* { return j < L ? &p->ops[layers[j].comp] : nullptr; };
-    int rc = launch_pipe(p->ctx, s, N, C, nullptr, nullptr, nullptr, comp(0), ws_of(0));
-    if (rc == CFX_OK) rc = launch_pipe(p->ctx, s, N, C, nullptr, comp(0), ws_of(0), comp(1), L > 1 ? ws_of(1) : nullptr);
-    for (int j = 0; rc == CFX_OK && j < L; ++j) {
-        for (int m = 0; m < layers[j].n_mid; ++m) {
-            const PlanOp* o = &p->ops[layers[j].first_mid + m];
-            if (o->kind == 2 && g_rccl.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, s) != 0) {
-                delete[] layers;
+    const int d = gmax - 1;
+    auto ws_of = [&](int j) -> void* { return (j < 0 || j >= L) ? nullptr : ((j & 1) ? p->ws2 : p->ops[comp_op[j]].ws); };
+    auto comp = [&](int j) -> const PlanOp* { return (j >= 0 && j < L) ? &p->ops[comp_op[j]] : nullptr; };
+    auto deq = [&](int j) -> const PlanOp* { return (j >= 0 && j < L) ? &p->ops[deq_op[j]] : nullptr; };
+    int rc = CFX_OK, next_ag = 0;
+    for (int t = 0; rc == CFX_OK && t <= L + 1 + d; ++t) {
+        while (next_ag < n_ag && ag_last[next_ag] + 2 <= t) {
+            const PlanOp* o = &p->ops[ag_op[next_ag++]];
+            if (g_rccl.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, s) != 0) {
+                cleanup();
                 return fail(p->ctx, CFX_ERR_LAUNCH, "ncclAllGather failed");
             }
         }
-        rc = launch_pipe(p->ctx, s, N, C, &p->ops[layers[j].deq], comp(j + 1), j + 1 < L ? ws_of(j + 1) : nullptr,
-                         comp(j + 2), j + 2 < L ? ws_of(j + 2) : nullptr);
+        if (!deq(t - 2 - d) && !comp(t - 1) && !comp(t)) continue;
+        rc = launch_pipe(p->ctx, s, N, C, deq(t - 2 - d), comp(t - 1), ws_of(t - 1), comp(t), ws_of(t));
     }
-    delete[] layers;
+    cleanup();
     return rc;
 }
 

@@ -165,13 +165,14 @@ int       cfx_plan_add_wait(cfx_plan* plan, int gather_op);
 int       cfx_plan_size(const cfx_plan* plan);
 int       cfx_plan_copy_op(cfx_plan* dst, const cfx_plan* src, int op);   /* append a copy of a (de)compress op of `src` */
 int       cfx_plan_run(cfx_plan* plan, int first_op, int n_ops, void* stream);
-/* Software-pipelined replay.  If ops [first_op, first_op + n_ops) are a sequence of "layers"
- *     compress (BINARY, flags without UPDATE_CACHE)  { all-gather }*  decompress (BINARY)        of one shape,
- * they are replayed on `stream` as  stats(0) | finalize(0)+stats(1) | { all-gather(j) ; [dequant(j) + finalize(j+1) +
- * stats(j+2)] }  with every bracket ONE fused launch, so the small statistics kernels of the next layers run underneath
- * the reconstruction of layer j.  Results are bit-identical to cfx_plan_run; packet / state buffers must be distinct per
- * layer within the call (the statistics workspace may be shared: the plan double-buffers it).  Any other op sequence is
- * replayed by cfx_plan_run. */
+/* Software-pipelined replay.  If ops [first_op, first_op + n_ops) are a sequence of "groups"
+ *     k x compress (BINARY, flags without UPDATE_CACHE)   { all-gather }*   k x decompress (BINARY)      of one shape,
+ * (k >= 1 layers whose packets travel in one collective) they are replayed on `stream` as launch slots
+ *     { all-gathers whose inputs are final } ; [dequant(t-1-k_max) | finalize(t-1) | stats(t)]        t = 0, 1, ...
+ * with every bracket ONE fused launch, so the small statistics kernels of later layers run underneath the
+ * reconstruction of an earlier one.  Results are bit-identical to cfx_plan_run; packet / state buffers must be distinct
+ * per layer within the call (the statistics workspace may be shared: the plan double-buffers it).  Any other op
+ * sequence is replayed by cfx_plan_run. */
 int       cfx_plan_run_pipelined(cfx_plan* plan, int first_op, int n_ops, void* stream);
 
 /* RCCL communicator owned by the library (replaces yunchang's RingComm + torch.distributed P2P of the reference,

@@ -1,6 +1,7 @@
 """Host-side logic on CPU: config rules, enum, cache arena, (N,C) view rule, wire sizes, the residual / error-feedback
 state machine and the function-level API mirrors.  The kernels are replaced by the oracle through a TEST-ONLY
 stand-in (tests/_oracle_backend.py); the GPU tests (-m gpu) run the same API on the real kernels."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -284,3 +285,33 @@ def test_alias_injection_recipe_from_integration_md(cpu_kernels):
         for k in [k for k in sys.modules if k == "xfuser" or k.startswith("xfuser.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_bench_grouped_all_gather_layout():
+    """bench.py's grouped exchange: with all-gather semantics (recv = concatenation of every rank's send buffer) the
+    offset table must point at rank r's packet of layer l for every (l, r, K|V) - for any group size, ragged tail included."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    L, slot = 11, 8
+    for live in (2, 3, 8):
+        for G in (1, 2, 4, 5, 11, 16):
+            # send[r][l][kv][slot] filled with a code identifying (r, l, kv)
+            send = np.zeros((live, L, 2, slot), dtype=np.int64)
+            for r in range(live):
+                for l in range(L):
+                    for kv in range(2):
+                        send[r, l, kv, :] = (r * 1000 + l * 10 + kv)
+            recv = np.zeros(L * live * 2 * slot, dtype=np.int64)
+            for a in range(0, L, G):
+                b = min(L, a + G)
+                per_rank = (b - a) * 2 * slot
+                region = a * live * 2 * slot
+                for r in range(live):                                  # what ncclAllGather does for this group
+                    recv[region + r * per_rank:region + (r + 1) * per_rank] = send[r, a:b].reshape(-1)
+            for l in range(L):
+                for r in range(live):
+                    for kv in range(2):
+                        o = bench.group_recv_offset(l, r, kv, G, L, live, slot)
+                        assert (recv[o:o + slot] == r * 1000 + l * 10 + kv).all(), (live, G, l, r, kv)
