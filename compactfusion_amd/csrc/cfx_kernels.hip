@@ -334,26 +334,28 @@ __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, in
 #ifndef PIPE_US
 #define PIPE_US 2      // rows in flight per wave in the fused kernel's stats group (register budget of 8 waves / SIMD)
 #endif
+#define PIPE_MAX_DQ 64     // reconstruction items per fused launch (a "unit" of up to 4 layers x 16 tensors)
+struct BatchDX { cfx_decomp_item it[PIPE_MAX_DQ]; };
 struct PipeArgs {
-    int N, C;
-    int n_fin, fin_bpi, CB, P;          // finalize: blocks in the group, blocks per tensor, stats grid that produced the partials
-    int n_st, st_R;                     // stats: blocks in the group, tile height (grid CB x P per tensor)
+    int N, C, CB;
+    int n_fin, fin_bpi, fin_P;          // finalize: blocks in the group, blocks per tensor, partials per column to reduce
+    int n_st, st_R, st_P;               // stats: blocks in the group, tile height, row blocks per tensor (grid CB x st_P)
     int dq_R, dq_rb;                    // dequant: tile height, row blocks per tensor
     const u64* ws_fin;
     u64* ws_st;
     size_t ws_stride;
 };
-__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_binary_pipe(BatchD dq, BatchC fin, BatchC st, PipeArgs a) {
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_binary_pipe(BatchDX dq, BatchC fin, BatchC st, PipeArgs a) {
     __shared__ u64 sm[WAVES][TILE_C];
     int b = blockIdx.x;
     if (b < a.n_fin) {
         const int item = b / a.fin_bpi;
-        absmean_finalize_body<NTHR>(fin.it[item], a.N, a.C, a.CB, a.P, 8, 0, a.ws_fin + (size_t)item * a.ws_stride, b - item * a.fin_bpi, &sm[0][0]);
+        absmean_finalize_body<NTHR>(fin.it[item], a.N, a.C, a.CB, a.fin_P, 8, 0, a.ws_fin + (size_t)item * a.ws_stride, b - item * a.fin_bpi, &sm[0][0]);
         return;
     }
     b -= a.n_fin;
     if (b < a.n_st) {
-        const int per = a.CB * a.P;
+        const int per = a.CB * a.st_P;
         const int item = b / per, rem = b - item * per;
         const int ty = rem / a.CB;
         absmean_stats_body<true, PIPE_US>(st.it[item], a.N, a.C, a.st_R, a.CB, rem - ty * a.CB, ty, a.ws_st + (size_t)item * a.ws_stride, sm);
@@ -1197,8 +1199,8 @@ struct cfx_plan {
     int n, cap;
     hipStream_t side;     // exchange stream (created on first all-gather op)
     int side_mode;        // 0: issue collectives on the main stream (no cross-stream events), 1: side stream, 2: prioritised side stream
-    void* ws2;            // cfx_plan_run_pipelined: second statistics workspace (stats(j+2) runs beside finalize(j+1))
-    size_t ws2_bytes;
+    void* pipe_ws;        // cfx_plan_run_pipelined: two statistics workspaces of CFX_MAX_BATCH tensors each (stats of unit
+    size_t pipe_ws_bytes; //   t runs beside the finalize of unit t-1)
 };
 
 cfx_plan* cfx_plan_create(cfx_ctx* ctx) {
@@ -1208,8 +1210,8 @@ cfx_plan* cfx_plan_create(cfx_ctx* ctx) {
     p->ops = nullptr;
     p->n = p->cap = 0;
     p->side = nullptr;
-    p->ws2 = nullptr;
-    p->ws2_bytes = 0;
+    p->pipe_ws = nullptr;
+    p->pipe_ws_bytes = 0;
     // Default: collectives in order on the main stream.  Measured on MI355X / ROCm 7: one cross-stream event hop costs
     // ~10 us of idle queue time, two per layer (main->side, side->main) = +1.1 ms per 57-layer step, whereas the
     // in-order exchange adds 0.1 ms; a side stream only pays when >> 20 us of independent work can overlap (attention).
@@ -1233,7 +1235,7 @@ void cfx_plan_destroy(cfx_plan* p) {
         if (p->ops[i].ev_done) (void)hipEventDestroy(p->ops[i].ev_done);
     }
     if (p->side) (void)hipStreamDestroy(p->side);
-    if (p->ws2) (void)hipFree(p->ws2);
+    if (p->pipe_ws) (void)hipFree(p->pipe_ws);
     delete[] p->ops;
     delete p;
 }
@@ -1353,46 +1355,68 @@ int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) {
 // Software-pipelined replay of a 1-bit exchange step.  The op range must be a sequence of "groups"
 //     k x compress [BINARY, no cache update]   { all-gather }*   k x decompress [BINARY]            (k >= 1, one shape)
 // i.e. layers whose packets travel in one collective (k = 1: what the ring gather schedule builds; bench.py groups
-// several layers per all-gather: fewer, larger collectives).  With L layers in program order and look-ahead
-// d = (largest k) - 1 the range is replayed on ONE stream as launch slots t = 0 .. L+1+d:
-//     { all-gathers whose last input layer b has b + 2 <= t }  ;  K_t = [dequant(t-2-d) | finalize(t-1) | stats(t)]
-// where K_t is ONE k_binary_pipe launch: the latency-bound stats / finalize kernels of later layers run underneath the
-// bandwidth-bound reconstruction of an earlier one (measured on MI355X, FLUX step: 1.82 -> 1.35 ms, DESIGN.md section 3;
-// a two-stream version of the same idea loses to the ~10 us cross-stream event hops and to the slowdown of the small
-// kernels under contention).  Results are bit-identical to cfx_plan_run (same device code per group).  Statistics
-// workspaces alternate between the ops' own workspace (even layers) and a plan-owned one (odd layers).  Any other op
-// sequence falls back to cfx_plan_run.
-static int launch_pipe(cfx_ctx* ctx, hipStream_t s, int N, int C, const PlanOp* dq, const PlanOp* fin, const void* ws_fin,
-                       const PlanOp* st, void* ws_st) {
-    BatchD bd; BatchC bf, bs;
-    memset(&bd, 0, sizeof(bd)); memset(&bf, 0, sizeof(bf)); memset(&bs, 0, sizeof(bs));
+// several layers per all-gather: fewer, larger collectives).  Consecutive whole groups are merged into UNITS of up to
+// 4 layers (as many as fit 64 reconstruction items and 16 compress items), and the range is replayed on ONE stream as
+// launch slots t = 0 .. U+1:
+//     { all-gathers of unit t-2 }  ;  K_t = [dequant(unit t-2) | finalize(unit t-1) | stats(unit t)]
+// where K_t is ONE k_binary_pipe launch: the latency-bound stats / finalize work of later layers runs underneath the
+// bandwidth-bound reconstruction of earlier ones, and a launch is long enough (4 layers = ~0.5 GB of traffic) to
+// amortise its ramp and tail (measured on MI355X, FLUX step: 1.82 ms in order, 1.35 ms one layer per launch, see
+// DESIGN.md section 3 for the unit size; a two-stream version of the same idea loses to the ~10 us cross-stream event hops
+// and to the slowdown of the small kernels under contention).  Results are bit-identical to cfx_plan_run (same device
+// code per group of workgroups).  The statistics workspaces are plan-owned (two, alternating by unit); the ops' own
+// workspaces are not used here.  A group too large for one unit, or any other op sequence, is replayed by cfx_plan_run.
+struct PipeUnit { int first_layer, n_layers, n_comp_items, n_dq_items; };
+
+static int launch_pipe(cfx_plan* p, hipStream_t s, int N, int C, const int* comp_op, const int* deq_op,
+                       const PipeUnit* dq, const PipeUnit* fin, const PipeUnit* st, int fin_parity, int st_parity) {
+    cfx_ctx* ctx = p->ctx;
+    BatchDX bd; BatchC bf, bs;
     PipeArgs a;
     memset(&a, 0, sizeof(a));
     a.N = N; a.C = C;
     a.CB = (C + TILE_C - 1) / TILE_C;
-    const int comp_batch = fin ? fin->batch : (st ? st->batch : 1);
-    a.st_R = auto_rows(ctx, N, C, comp_batch, true);
-    a.P = (N + a.st_R - 1) / a.st_R;
     a.ws_stride = ws_words(CFX_CODEC_BINARY, N, C);
+    u64* ws0 = (u64*)p->pipe_ws;
+    const size_t half = (size_t)CFX_MAX_BATCH * a.ws_stride;
+    auto rows_of = [&](const PipeUnit* u) { return auto_rows(ctx, N, C, u->n_comp_items, true); };
     if (fin) {
-        for (int i = 0; i < fin->batch; ++i) bf.it[i] = fin->c[i];
+        int n = 0;
+        for (int l = 0; l < fin->n_layers; ++l) {
+            const PlanOp* o = &p->ops[comp_op[fin->first_layer + l]];
+            for (int i = 0; i < o->batch; ++i) bf.it[n++] = o->c[i];
+        }
+        const int R = rows_of(fin);
+        a.fin_P = (N + R - 1) / R;
         a.fin_bpi = 1 + (C + NTHR / 4 - 1) / (NTHR / 4);
-        a.n_fin = a.fin_bpi * fin->batch;
-        a.ws_fin = (const u64*)ws_fin;
+        a.n_fin = a.fin_bpi * n;
+        a.ws_fin = ws0 + (size_t)fin_parity * half;
     }
     if (st) {
-        for (int i = 0; i < st->batch; ++i) bs.it[i] = st->c[i];
-        a.n_st = a.CB * a.P * st->batch;
-        a.ws_st = (u64*)ws_st;
+        int n = 0;
+        for (int l = 0; l < st->n_layers; ++l) {
+            const PlanOp* o = &p->ops[comp_op[st->first_layer + l]];
+            for (int i = 0; i < o->batch; ++i) bs.it[n++] = o->c[i];
+        }
+        a.st_R = rows_of(st);
+        a.st_P = (N + a.st_R - 1) / a.st_R;
+        a.n_st = a.CB * a.st_P * n;
+        a.ws_st = ws0 + (size_t)st_parity * half;
     }
     int n_dq = 0;
     if (dq) {
-        for (int i = 0; i < dq->batch; ++i) bd.it[i] = dq->d[i];
-        a.dq_R = auto_rows(ctx, N, C, dq->batch, false);
+        int n = 0;
+        for (int l = 0; l < dq->n_layers; ++l) {
+            const PlanOp* o = &p->ops[deq_op[dq->first_layer + l]];
+            for (int i = 0; i < o->batch; ++i) bd.it[n++] = o->d[i];
+        }
+        a.dq_R = auto_rows(ctx, N, C, n, false);
         a.dq_rb = (N + a.dq_R - 1) / a.dq_R;
-        n_dq = a.CB * a.dq_rb * dq->batch;
+        n_dq = a.CB * a.dq_rb * n;
     }
-    const int kid = (dq && fin && st) ? KID_BINARY_PIPE : KID_BINARY_PIPE_EDGE;
+    // profiled as "the" pipeline kernel only when all three groups carry equally sized units (steady state)
+    const bool steady = dq && fin && st && dq->n_layers == fin->n_layers && fin->n_layers == st->n_layers;
+    const int kid = steady ? KID_BINARY_PIPE : KID_BINARY_PIPE_EDGE;
     LAUNCH(ctx, kid, s, k_binary_pipe, dim3(a.n_fin + a.n_st + n_dq), dim3(NTHR), 0, s, bd, bf, bs, a);
     return check_launch(ctx, "pipelined launch");
 }
@@ -1401,65 +1425,73 @@ int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
     if (!p) return CFX_ERR_NULL;
     if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
     const int end = first_op + n_ops;
-    // ---- recognise the group pattern ------------------------------------------------------------------------------------
     const int cap = n_ops > 0 ? n_ops : 1;
     int* comp_op = new int[cap];
     int* deq_op = new int[cap];
     int* ag_op = new int[cap];
-    int* ag_last = new int[cap];          // index of the last layer whose packet an all-gather carries
-    int L = 0, n_ag = 0, N = 0, C = 0, gmax = 0;
+    int* ag_unit = new int[cap];          // unit whose packets an all-gather carries
+    PipeUnit* units = new PipeUnit[cap];
+    auto cleanup = [&]() { delete[] comp_op; delete[] deq_op; delete[] ag_op; delete[] ag_unit; delete[] units; };
+    const char* ue = getenv("CFX_PIPE_UNIT_LAYERS");
+    int unit_layers = ue ? atoi(ue) : 4;
+    if (unit_layers < 1) unit_layers = 1;
+    // ---- recognise the group pattern, merging whole groups into units -----------------------------------------------------
+    int L = 0, n_ag = 0, N = 0, C = 0, U = 0;
     bool ok = n_ops > 0 && p->side_mode == 0;
-    auto cleanup = [&]() { delete[] comp_op; delete[] deq_op; delete[] ag_op; delete[] ag_last; };
     for (int i = first_op; ok && i < end;) {
-        int k = 0;
+        int k = 0, ncomp = 0, ndq = 0;
+        const int ag0 = n_ag;
         while (i < end && p->ops[i].kind == 0) {
             const PlanOp* c = &p->ops[i];
             if (c->codec != CFX_CODEC_BINARY || (c->flags & CFX_FLAG_UPDATE_CACHE)) { ok = false; break; }
             if (L + k == 0) { N = c->N; C = c->C; }
             if (c->N != N || c->C != C) { ok = false; break; }
+            ncomp += c->batch;
             comp_op[L + k++] = i++;
         }
         if (!ok || k == 0) { ok = false; break; }
         while (i < end && (p->ops[i].kind == 2 || p->ops[i].kind == 3)) {
-            if (p->ops[i].kind == 2) { ag_op[n_ag] = i; ag_last[n_ag++] = L + k - 1; }
+            if (p->ops[i].kind == 2) ag_op[n_ag++] = i;
             ++i;
         }
         for (int m = 0; m < k; ++m, ++i) {
             if (i >= end || p->ops[i].kind != 1 || p->ops[i].codec != CFX_CODEC_BINARY || p->ops[i].N != N || p->ops[i].C != C) { ok = false; break; }
+            ndq += p->ops[i].batch;
             deq_op[L + m] = i;
         }
         if (!ok) break;
+        if (ncomp > CFX_MAX_BATCH || ndq > PIPE_MAX_DQ) { ok = false; break; }      // a group must fit one launch
+        // extend the current unit with this group if it still fits, else start a new unit
+        if (U > 0 && units[U - 1].n_layers + k <= unit_layers && units[U - 1].n_comp_items + ncomp <= CFX_MAX_BATCH &&
+            units[U - 1].n_dq_items + ndq <= PIPE_MAX_DQ) {
+            units[U - 1].n_layers += k; units[U - 1].n_comp_items += ncomp; units[U - 1].n_dq_items += ndq;
+        } else {
+            units[U].first_layer = L; units[U].n_layers = k; units[U].n_comp_items = ncomp; units[U].n_dq_items = ndq;
+            ++U;
+        }
+        for (int a = ag0; a < n_ag; ++a) ag_unit[a] = U - 1;
         L += k;
-        if (k > gmax) gmax = k;
     }
     if (!ok) { cleanup(); return cfx_plan_run(p, first_op, n_ops, stream); }
-    for (int j = 0; j < L; ++j) {
-        const PlanOp* c = &p->ops[comp_op[j]];
-        const size_t need = cfx_workspace_bytes(CFX_CODEC_BINARY, N, C, 0, c->batch);
-        if (!c->ws || c->ws_bytes < need) { cleanup(); return fail(p->ctx, CFX_ERR_WORKSPACE, "plan: workspace too small"); }
-        if (need > p->ws2_bytes) {
-            if (p->ws2) (void)hipFree(p->ws2);
-            p->ws2 = nullptr; p->ws2_bytes = 0;
-            if (hipMalloc(&p->ws2, need) != hipSuccess) { cleanup(); return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot allocate the second workspace"); }
-            p->ws2_bytes = need;
-        }
+    const size_t need = 2 * (size_t)CFX_MAX_BATCH * ws_words(CFX_CODEC_BINARY, N, C) * sizeof(u64);
+    if (need > p->pipe_ws_bytes) {
+        if (p->pipe_ws) (void)hipFree(p->pipe_ws);
+        p->pipe_ws = nullptr; p->pipe_ws_bytes = 0;
+        if (hipMalloc(&p->pipe_ws, need) != hipSuccess) { cleanup(); return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot allocate the statistics workspaces"); }
+        p->pipe_ws_bytes = need;
     }
     hipStream_t s = (hipStream_t)stream;
-    const int d = gmax - 1;
-    auto ws_of = [&](int j) -> void* { return (j < 0 || j >= L) ? nullptr : ((j & 1) ? p->ws2 : p->ops[comp_op[j]].ws); };
-    auto comp = [&](int j) -> const PlanOp* { return (j >= 0 && j < L) ? &p->ops[comp_op[j]] : nullptr; };
-    auto deq = [&](int j) -> const PlanOp* { return (j >= 0 && j < L) ? &p->ops[deq_op[j]] : nullptr; };
+    auto unit = [&](int u) -> const PipeUnit* { return (u >= 0 && u < U) ? &units[u] : nullptr; };
     int rc = CFX_OK, next_ag = 0;
-    for (int t = 0; rc == CFX_OK && t <= L + 1 + d; ++t) {
-        while (next_ag < n_ag && ag_last[next_ag] + 2 <= t) {
+    for (int t = 0; rc == CFX_OK && t <= U + 1; ++t) {
+        while (next_ag < n_ag && ag_unit[next_ag] + 2 <= t) {
             const PlanOp* o = &p->ops[ag_op[next_ag++]];
             if (g_rccl.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, s) != 0) {
                 cleanup();
                 return fail(p->ctx, CFX_ERR_LAUNCH, "ncclAllGather failed");
             }
         }
-        if (!deq(t - 2 - d) && !comp(t - 1) && !comp(t)) continue;
-        rc = launch_pipe(p->ctx, s, N, C, deq(t - 2 - d), comp(t - 1), ws_of(t - 1), comp(t), ws_of(t));
+        rc = launch_pipe(p, s, N, C, comp_op, deq_op, unit(t - 2), unit(t - 1), unit(t), (t - 1) & 1, t & 1);
     }
     cleanup();
     return rc;

@@ -167,11 +167,12 @@ int       cfx_plan_copy_op(cfx_plan* dst, const cfx_plan* src, int op);   /* app
 int       cfx_plan_run(cfx_plan* plan, int first_op, int n_ops, void* stream);
 /* Software-pipelined replay.  If ops [first_op, first_op + n_ops) are a sequence of "groups"
  *     k x compress (BINARY, flags without UPDATE_CACHE)   { all-gather }*   k x decompress (BINARY)      of one shape,
- * (k >= 1 layers whose packets travel in one collective) they are replayed on `stream` as launch slots
- *     { all-gathers whose inputs are final } ; [dequant(t-1-k_max) | finalize(t-1) | stats(t)]        t = 0, 1, ...
+ * (k >= 1 layers whose packets travel in one collective) consecutive groups are merged into units of up to 4 layers
+ * (env CFX_PIPE_UNIT_LAYERS; at most 64 reconstruction and 16 compress items per unit) and replayed on `stream` as
+ *     { all-gathers of unit t-2 } ; [dequant(unit t-2) | finalize(unit t-1) | stats(unit t)]          t = 0, 1, ...
  * with every bracket ONE fused launch, so the small statistics kernels of later layers run underneath the
- * reconstruction of an earlier one.  Results are bit-identical to cfx_plan_run; packet / state buffers must be distinct
- * per layer within the call (the statistics workspace may be shared: the plan double-buffers it).  Any other op
+ * reconstruction of earlier ones.  Results are bit-identical to cfx_plan_run; packet / state buffers must be distinct
+ * per layer within the call; the statistics workspaces are plan-owned (the ops' own are not used).  Any other op
  * sequence is replayed by cfx_plan_run. */
 int       cfx_plan_run_pipelined(cfx_plan* plan, int first_op, int n_ops, void* stream);
 
