@@ -58,6 +58,9 @@ def parse():
                     help="pipelined (default): cfx_plan_run_pipelined - one fused launch per layer, the statistics / finalize "
                          "work of the next two layers rides underneath the reconstruction of the current one; "
                          "inorder: cfx_plan_run, three launches per layer one after the other (same results, bit for bit)")
+    ap.add_argument("--exchange-stream", choices=["main", "side", "prio"], default="prio",
+                    help="N > 1, native exchange: 'main' issues every all-gather in order on the compute stream; 'side' / 'prio' "
+                         "(prioritised stream) issue it on an exchange stream one unit ahead, underneath the next fused launch")
     ap.add_argument("--gather-group", type=int, default=4,
                     help="N > 1, native exchange: layers (1..4) whose packets travel in ONE all-gather (fewer, larger collectives; "
                          "a group is replayed as one unit of the pipelined schedule)")
@@ -215,11 +218,11 @@ def main():
     compute = torch.cuda.current_stream(dev)
     sh = compute.cuda_stream
 
-    # ---- N > 1: the whole step as ONE native plan, the all-gathers issued by libcfx's own RCCL communicator in order on
-    #      the main stream (a cross-stream event hop costs ~10 us on this stack - more than the wire time of a packet - so no
-    #      side stream here).  --gather-group layers share one all-gather (fewer, larger collectives: each call
-    #      has a fixed latency that nothing overlaps on a single stream); the pipelined replay computes the statistics that
-    #      many layers ahead so every collective's inputs are final when it is issued. ----
+    # ---- N > 1: the whole step as ONE native plan, the all-gathers issued by libcfx's own RCCL communicator.
+    #      --gather-group layers share one all-gather (fewer, larger collectives) and form one unit of the pipelined replay;
+    #      --exchange-stream prio|side runs the collective of unit u on an exchange stream underneath the fused launch that
+    #      follows finalize(u) (one extra unit of look-ahead; the ~10 us cross-stream event hops hide behind an 80 us launch),
+    #      'main' keeps everything in order on one stream. ----
     native_comm, step_plans, exchange_mode = None, None, "none"
     if use_dist:
         exchange_mode = "torch"
@@ -240,9 +243,9 @@ def main():
                 for s in range(2):
                     sp = lib.cfx_plan_create(ctx)
                     src = plans[s]
-                    if os.environ.get("CFX_EXCHANGE_STREAM", "main") != "main":
-                        raise RuntimeError("side-stream exchange modes are only kept in the plan API (tests); the bench issues "
-                                           "collectives in order on the main stream")
+                    # the in-order replay has no wait ops in this plan: everything stays on the compute stream there
+                    mode = {"main": 0, "side": 1, "prio": 2}[args.exchange_stream] if args.replay == "pipelined" else 0
+                    assert lib.cfx_plan_set_exchange_stream(sp, mode) == 0
                     for a, b in groups:
                         for l in range(a, b):
                             assert lib.cfx_plan_copy_op(sp, src, 2 * l) >= 0
@@ -256,7 +259,9 @@ def main():
                             i = 2
                             for p in range(W_LOGICAL - 1):
                                 for kv in range(2):
-                                    pk_ptr = grecv_ptr(l, (rank + 1 + p) % live, kv) if (live > 1 and p < live - 1) else send[l, kv].data_ptr()
+                                    # real peers: their slot of the gathered buffer; looped-back logical peers: OUR slot of
+                                    # the gathered buffer (so the collective's result is consumed even with one live rank)
+                                    pk_ptr = grecv_ptr(l, (rank + 1 + p) % live if (live > 1 and p < live - 1) else rank, kv)
                                     darr[i] = _lib.DecompItem(pk_ptr, peer_base[l, p, kv].data_ptr(), peer_base[l, p, kv].data_ptr())
                                     i += 1
                             assert lib.cfx_plan_add_decompress(sp, CODEC, N, C, 0, 16, darr) >= 0
@@ -431,6 +436,7 @@ def main():
         "exchange_ms_per_step": round(ms_per_step, 4),
         "exchange_issued_by": exchange_mode,
         "replay": args.replay,
+        "exchange_stream": ((args.exchange_stream if args.replay == "pipelined" else "main") if (use_dist and step_plans is not None) else None),
         "layers_per_all_gather": (max(1, min(4, args.gather_group)) if (use_dist and step_plans is not None) else None),
         "raw_allgather_ms_per_step": None if raw_ms is None else round(raw_ms, 4),
         "speedup_vs_raw_allgather": None if raw_ms is None else round(raw_ms / ms_per_step, 3),

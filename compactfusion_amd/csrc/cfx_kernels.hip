@@ -1437,7 +1437,7 @@ int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
     if (unit_layers < 1) unit_layers = 1;
     // ---- recognise the group pattern, merging whole groups into units -----------------------------------------------------
     int L = 0, n_ag = 0, N = 0, C = 0, U = 0;
-    bool ok = n_ops > 0 && p->side_mode == 0;
+    bool ok = n_ops > 0;
     for (int i = first_op; ok && i < end;) {
         int k = 0, ncomp = 0, ndq = 0;
         const int ag0 = n_ag;
@@ -1482,16 +1482,39 @@ int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     auto unit = [&](int u) -> const PipeUnit* { return (u >= 0 && u < U) ? &units[u] : nullptr; };
-    int rc = CFX_OK, next_ag = 0;
-    for (int t = 0; rc == CFX_OK && t <= U + 1; ++t) {
-        while (next_ag < n_ag && ag_unit[next_ag] + 2 <= t) {
-            const PlanOp* o = &p->ops[ag_op[next_ag++]];
-            if (g_rccl.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, s) != 0) {
-                cleanup();
-                return fail(p->ctx, CFX_ERR_LAUNCH, "ncclAllGather failed");
+    // Exchange stream mode 0: collectives in order on `stream`, right before the launch that consumes them.
+    // Modes 1 / 2: one more unit of look-ahead; the collectives of unit u are issued on the exchange stream as soon as
+    // the launch holding finalize(u) is queued and run UNDERNEATH the next launch; `stream` waits for them (an event that
+    // has normally fired long before) only in front of the launch that reconstructs unit u.
+    const int d = (p->side_mode != 0 && p->side && n_ag > 0) ? 1 : 0;
+    auto all_gather = [&](const PlanOp* o, hipStream_t on) -> int {
+        if (g_rccl.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, on) != 0)
+            return fail(p->ctx, CFX_ERR_LAUNCH, "ncclAllGather failed");
+        return CFX_OK;
+    };
+    int rc = CFX_OK, next_ag = 0, next_wait = 0;
+    for (int t = 0; rc == CFX_OK && t <= U + 1 + d; ++t) {
+        if (d == 0) {
+            while (rc == CFX_OK && next_ag < n_ag && ag_unit[next_ag] + 2 <= t) rc = all_gather(&p->ops[ag_op[next_ag++]], s);
+        } else {
+            while (rc == CFX_OK && next_wait < n_ag && ag_unit[next_wait] + 3 <= t) {
+                if (hipStreamWaitEvent(s, p->ops[ag_op[next_wait++]].ev_done, 0) != hipSuccess) rc = fail(p->ctx, CFX_ERR_LAUNCH, "plan: wait failed");
             }
         }
-        rc = launch_pipe(p, s, N, C, comp_op, deq_op, unit(t - 2), unit(t - 1), unit(t), (t - 1) & 1, t & 1);
+        if (rc != CFX_OK) break;
+        if (unit(t - 2 - d) || unit(t - 1) || unit(t))
+            rc = launch_pipe(p, s, N, C, comp_op, deq_op, unit(t - 2 - d), unit(t - 1), unit(t), (t - 1) & 1, t & 1);
+        if (d == 1) {
+            while (rc == CFX_OK && next_ag < n_ag && ag_unit[next_ag] + 1 <= t) {
+                PlanOp* o = &p->ops[ag_op[next_ag++]];
+                if (hipEventRecord(o->ev_pre, s) != hipSuccess || hipStreamWaitEvent(p->side, o->ev_pre, 0) != hipSuccess) {
+                    rc = fail(p->ctx, CFX_ERR_LAUNCH, "plan: event ordering failed");
+                    break;
+                }
+                rc = all_gather(o, p->side);
+                if (rc == CFX_OK && hipEventRecord(o->ev_done, p->side) != hipSuccess) rc = fail(p->ctx, CFX_ERR_LAUNCH, "plan: event record failed");
+            }
+        }
     }
     cleanup();
     return rc;
