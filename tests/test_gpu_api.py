@@ -448,6 +448,45 @@ def test_native_comm_single_rank(tmp_path):
             torch.cuda.synchronize()
             assert torch.equal(recv, send), mode
             lib.cfx_plan_destroy(plan)
+        # pipelined replay with grouped all-gathers whose RESULT is what the reconstruction reads (1 rank: recv == send, so
+        # any mis-ordering of collective vs finalize / dequant shows up as a wrong state), on every exchange-stream mode
+        N, C, L, G, B = 96, 1024, 7, 3, 2
+        g = torch.Generator().manual_seed(21)
+        x = torch.randn(L, B, N, C, generator=g).half().cuda()
+        base0 = (x.float() + 0.1 * torch.randn(L, B, N, C, generator=g).cuda()).half()
+        slot = (K.packet_bytes(1, N, C) + 255) // 256 * 256
+        wsb = lib.cfx_workspace_bytes(1, N, C, 0, B)
+        ref = None
+        for mode, runner in ((0, "inorder"), (0, "pipelined"), (1, "pipelined"), (2, "pipelined")):
+            own, peer = base0.clone(), base0.clone()
+            snd = torch.zeros(L, B, slot, dtype=torch.uint8, device="cuda")
+            rcv = torch.zeros(L, B, slot, dtype=torch.uint8, device="cuda")
+            ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+            plan = lib.cfx_plan_create(ctx)
+            assert lib.cfx_plan_set_exchange_stream(plan, mode) == 0
+            for a in range(0, L, G):
+                b = min(L, a + G)
+                for l in range(a, b):
+                    c = (_lib.CompItem * B)(*[_lib.CompItem(x[l, i].data_ptr(), own[l, i].data_ptr(), None, snd[l, i].data_ptr()) for i in range(B)])
+                    assert lib.cfx_plan_add_compress(plan, 1, N, C, 0, 0, B, c, ws.data_ptr(), wsb) >= 0
+                assert lib.cfx_plan_add_all_gather(plan, comm.handle, snd[a].data_ptr(), rcv[a].data_ptr(), (b - a) * B * slot) >= 0
+                for l in range(a, b):
+                    items = [_lib.DecompItem(snd[l, i].data_ptr(), own[l, i].data_ptr(), own[l, i].data_ptr()) for i in range(B)]
+                    items += [_lib.DecompItem(rcv[l, i].data_ptr(), peer[l, i].data_ptr(), peer[l, i].data_ptr()) for i in range(B)]
+                    d = (_lib.DecompItem * len(items))(*items)
+                    assert lib.cfx_plan_add_decompress(plan, 1, N, C, 0, len(items), d) >= 0
+            run = lib.cfx_plan_run if runner == "inorder" else lib.cfx_plan_run_pipelined
+            for _ in range(3):
+                assert run(plan, 0, lib.cfx_plan_size(plan), torch.cuda.current_stream().cuda_stream) == 0, lib.cfx_last_error_string(ctx)
+            torch.cuda.synchronize()
+            lib.cfx_plan_destroy(plan)
+            assert torch.equal(own.view(torch.int16), peer.view(torch.int16)), (mode, runner)      # gathered packets == own packets
+            assert torch.equal(rcv, snd), (mode, runner)
+            if ref is None:
+                ref = own.clone()
+                assert not torch.equal(ref.view(torch.int16), base0.view(torch.int16))
+            else:
+                assert torch.equal(own.view(torch.int16), ref.view(torch.int16)), (mode, runner)
         comm.close()
     finally:
         if created:
