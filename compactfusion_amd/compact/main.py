@@ -401,7 +401,7 @@ def compact_all_gather(tag, x: torch.Tensor, comp_type: COMPACT_COMPRESS_TYPE, g
     to_send = compact_compress(f"{tag}-{rank}", x, comp_type, update_cache=False)
     flat = to_send.reshape(-1)
     native_batch = (comp_type != T.WARMUP and not cfg.simulate_compress and cfg.compress_residual == 1
-                    and world <= codecs.CFX_MAX_BATCH)
+                    and world <= codecs.CFX_MAX_BATCH and not _cache.quantize)
     # one contiguous receive buffer; each rank's slot starts 256-byte aligned
     slot = (flat.numel() + 127) // 128 * 128
     sendbuf = _buf(tag, "agsend", slot, flat, flat.dtype)
@@ -553,7 +553,8 @@ def compact_all_gather_kv(tag_k, tag_v, k: torch.Tensor, v: torch.Tensor, comp_t
     cfg = _config
     ex = _kv_exchanges.get((tag_k, tag_v))
     fusable = (comp_type != T.WARMUP and not cfg.simulate_compress and cfg.compress_residual == 1
-               and not cfg.log_compress_stats and k.shape == v.shape and k.is_contiguous() and v.is_contiguous())
+               and not cfg.log_compress_stats and k.shape == v.shape and k.is_contiguous() and v.is_contiguous()
+               and not _cache.quantize)
     if fusable:
         cid, param = _native(comp_type)
         fusable = cid < 100

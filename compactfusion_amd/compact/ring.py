@@ -235,7 +235,7 @@ def _gather_schedule(q, k, v, ctype, mod_idx, rank, world, group, kkey, vkey, at
     ex = _layer_exchange(mod_idx, rank, world, slot, k)
     send, recv, side = ex.send, ex.recv, ex.side
     # steady state: K and V in ONE native compress sequence straight into the send slots, in-place EF state update
-    fast = native and cid < 100 and not cfg.log_compress_stats and v.shape == k.shape
+    fast = native and cid < 100 and not cfg.log_compress_stats and v.shape == k.shape and not compact_cache().quantize
     cur = torch.cuda.current_stream(k.device) if side is not None else None
     sh = cur.cuda_stream if cur is not None else None
     if fast:
@@ -286,6 +286,8 @@ def _gather_schedule(q, k, v, ctype, mod_idx, rank, world, group, kkey, vkey, at
         for step, (kk, vv) in enumerate(ex.peer_views, start=1):
             out, lse = attend(out, lse, kk, vv, step)
         return out, lse
+    if native and compact_cache().quantize:
+        native = False           # state lives as int8 packets: go through compact_decompress (get_base / put) per tensor
     if native:
         from .. import codecs
         bases, pkts = [], []

@@ -105,13 +105,14 @@ class CompactCache:
 
     def __init__(self, quantize: bool = False):
         if quantize:
-            assert ALLOW_DEPRECATED, "quantized cache is deprecated in the reference (utils.py:128-129)"
-            raise NotImplementedError("int8-quantised cache storage is not implemented in compactfusion_amd")
+            # deprecated in the reference as well (utils.py:128-129); kept because it cuts the state memory in half
+            assert ALLOW_DEPRECATED, "quantized cache is deprecated in the reference (utils.py:128-129): set COMPACT_ALLOW_DEPRECATED=1"
         self.quantize = quantize
         self.base: Dict[str, torch.Tensor] = {}
         self.delta_base: Dict[str, Optional[torch.Tensor]] = {}
         self.passed_count = 0
         self.version = 0        # bumped whenever a state buffer is (re)allocated: cached pointer tables key on it
+        self._scratch: Dict[str, torch.Tensor] = {}      # quantize=True: per-key fp16 view handed out by get_base
 
     # -- arena ----------------------------------------------------------------------------------------------
     def arena(self, key: str, like: torch.Tensor) -> torch.Tensor:
@@ -143,7 +144,21 @@ class CompactCache:
             collect(self.base[key], "vbase", compact_get_step(), int(key.split("-")[0]))
 
     def put(self, key, base, delta_base):
-        self.base[key] = self._store(self.base.get(key), base)
+        if self.quantize:
+            # int8 storage of the base (utils.py:135-137 -> compress_quantize.py:428-468): the native INT8 codec applied to
+            # the tensor itself (no residual); `self.base[key]` holds the packet [q | scale | zero point]
+            from .. import codecs
+            N, C = base.shape
+            pkt = self.base.get(key)
+            need = codecs.packet_halves(codecs.Codec.INT8, N, C)
+            if pkt is None or pkt.numel() != need or pkt.device != base.device:
+                pkt = torch.empty(need, dtype=torch.float16, device=base.device)
+                self.base[key] = pkt
+                self.version += 1
+            codecs.compress_batch(codecs.Codec.INT8, [base.contiguous()], [None], [None], [pkt], N, C, update_cache=False)
+            self._scratch[key] = self._store(self._scratch.get(key), base)      # shape / dtype carrier, overwritten by get_base
+        else:
+            self.base[key] = self._store(self.base.get(key), base)
         self.touch(key)
         if delta_base is None:
             self.delta_base[key] = None
@@ -151,7 +166,16 @@ class CompactCache:
             self.delta_base[key] = self._store(self.delta_base.get(key), delta_base)
 
     def get_base(self, key):
-        return self.base.get(key, None)
+        if not self.quantize:
+            return self.base.get(key, None)
+        pkt = self.base.get(key)
+        if pkt is None:
+            return None
+        from .. import codecs
+        out = self._scratch[key]
+        N, C = out.shape
+        codecs.decompress_batch(codecs.Codec.INT8, [pkt], [None], [out], N, C)      # dequantize_int8 (utils.py:149-153)
+        return out
 
     def get_delta_base(self, key):
         return self.delta_base.get(key, None)

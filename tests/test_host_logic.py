@@ -70,8 +70,6 @@ def test_cache_arena_semantics():
     assert torch.equal(c.get_delta_base("0-0-k"), x * 2)
     c.put("0-0-k", c.get_base("0-0-k"), None)                         # handing back the arena buffer is a no-op
     assert c.get_delta_base("0-0-k") is None and c.get_base("missing") is None
-    with pytest.raises(AssertionError):
-        CompactCache(quantize=True)
 
 
 def test_collector_must_be_initialised():
@@ -315,3 +313,39 @@ def test_bench_grouped_all_gather_layout():
                     for kv in range(2):
                         o = bench.group_recv_offset(l, r, kv, G, L, live, slot)
                         assert (recv[o:o + slot] == r * 1000 + l * 10 + kv).all(), (live, G, l, r, kv)
+
+
+def test_quantized_cache_int8_storage(cpu_kernels, monkeypatch):
+    """CompactCache(quantize=True) (deprecated in the reference, utils.py:128-156): the base is stored as the int8 packet of
+    quantize_int8 and handed out dequantised; a 1-bit residual exchange on top of it keeps sender and receiver states
+    identical because both sides quantise the same reconstruction."""
+    from compactfusion_amd.compact import utils as U, main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
+    with pytest.raises(AssertionError):
+        U.CompactCache(quantize=True)
+    monkeypatch.setattr(U, "ALLOW_DEPRECATED", True)
+    c = U.CompactCache(quantize=True)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(64, 256, generator=g).half()
+    assert c.get_base("1-0-k") is None
+    c.put("1-0-k", x, None)
+    want = R.decompress("int8", R.compress("int8", bits(x).reshape(64, 256), None)[0], 64, 256)
+    assert np.array_equal(bits(c.get_base("1-0-k")), R.bits(want))
+    assert c.base["1-0-k"].numel() * 2 == 64 * 256 + 4 * 256            # int8 codes + fp16 scale + int16 zero point
+    # the state machine on a quantised cache: two "ranks" in one process (distinct keys), same packets
+    cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T.BINARY, comp_rank=-1,
+                                  residual=1, ef=True, fastpath=True, quantized_cache=True))
+    assert cm.compact_cache().quantize
+    xs = [torch.randn(64, 256, generator=g).half()]
+    for _ in range(3):
+        xs.append((xs[-1].float() + 0.1 * torch.randn(64, 256, generator=g)).half())
+    for step, xt in enumerate(xs):
+        cm.compact_set_step(step)
+        typ = T.WARMUP if step == 0 else T.BINARY
+        pkt = cm.compact_compress("5-0-k", xt, typ, update_cache=True)
+        rec = cm.compact_decompress("5-1-k", pkt.clone(), typ, xt.shape, update_cache=True)
+        s_state, r_state = cm.compact_cache().get_base("5-0-k").clone(), cm.compact_cache().get_base("5-1-k").clone()
+        assert np.array_equal(bits(s_state), bits(r_state)), step
+        if step:
+            assert pkt.numel() == 64 * 256 // 16 + 64 + 256
+            assert float((rec.float() - xt.float()).norm() / xt.float().norm()) < 0.2
