@@ -425,14 +425,23 @@ __global__ __launch_bounds__(256) void k_lr_decode(LrDecBatch b, int N, int C, i
     const LrDec it = b.it[blockIdx.z];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x * 512 + lane * 8;
-    if (c >= C) return;
+    const int r0 = blockIdx.y * 32, r1 = min(N, r0 + 32);
+    // The tile's U rows (32 x r halves, one contiguous block) go through LDS once: every lane of a wave needs the same
+    // u pair at the same time, which LDS serves as a broadcast read instead of a dependent global load per k-pair and row.
+    __shared__ h16x2 us[32][RP / 2];
+    {
+        const int hp = r >> 1, npairs = (r1 - r0) * hp;
+        const h16x2* src = reinterpret_cast<const h16x2*>(it.U + (size_t)r0 * r);
+        for (int i = threadIdx.x; i < npairs; i += 256) us[i / hp][i % hp] = src[i];
+    }
+    const bool act = c < C;
     // V as k-pairs: vp[kk][i] = (V[2kk][c+i], V[2kk+1][c+i]) so one v_dot2_f32_f16 does two MACs with an fp32 accumulator
     h16x2 vp[RP / 2][8];
 #pragma unroll
     for (int kk = 0; kk < RP / 2; ++kk) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) vp[kk][i] = (h16x2)(h16)0;
-        if (2 * kk < r) {
+        if (act && 2 * kk < r) {
             if (VT) {
                 if (r != RP) {      // generic: 4-byte gathers
 #pragma unroll
@@ -446,7 +455,7 @@ __global__ __launch_bounds__(256) void k_lr_decode(LrDecBatch b, int N, int C, i
             }
         }
     }
-    if (VT && r == RP) {
+    if (VT && r == RP && act) {
         // V^T rows c .. c+7 are one contiguous block of 8 * RP halves: coalesced 16-byte loads, then pick the pairs
         const h16x8* blk = reinterpret_cast<const h16x8*>(it.V + (size_t)c * RP);
 #pragma unroll
@@ -459,25 +468,139 @@ __global__ __launch_bounds__(256) void k_lr_decode(LrDecBatch b, int N, int C, i
             }
         }
     }
-    const int r0 = blockIdx.y * 32, r1 = min(N, r0 + 32);
-    for (int rr = r0 + w; rr < r1; rr += 4) {
-        float acc[8];
+    __syncthreads();
+    if (!act) return;
+    // two rows in flight per wave: both state loads are issued before the dot products
+    for (int lr = w; lr < r1 - r0; lr += 8) {
+        const int ra = r0 + lr, rb = ra + 4;
+        const bool hb = rb < r1;
+        h16x8 ba = (h16x8)(h16)0, bb = (h16x8)(h16)0;
+        if (it.base) {
+            ba = __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(it.base + (size_t)ra * C + c));
+            if (hb) bb = __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(it.base + (size_t)rb * C + c));
+        }
+        float acca[8], accb[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-        const h16x2* urow = reinterpret_cast<const h16x2*>(it.U + (size_t)rr * r);
+        for (int i = 0; i < 8; ++i) { acca[i] = 0.f; accb[i] = 0.f; }
 #pragma unroll
         for (int kk = 0; kk < RP / 2; ++kk) {
             if (2 * kk < r) {
-                const h16x2 u = urow[kk];
+                const h16x2 ua = us[lr][kk];
+                const h16x2 ub = us[hb ? lr + 4 : lr][kk];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_fdot2(u, vp[kk][i], acc[i], false);
+                for (int i = 0; i < 8; ++i) {
+                    acca[i] = __builtin_amdgcn_fdot2(ua, vp[kk][i], acca[i], false);
+                    accb[i] = __builtin_amdgcn_fdot2(ub, vp[kk][i], accb[i], false);
+                }
             }
         }
-        h16x8 o;
+        h16x8 oa, ob;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (h16)acc[i];
-        if (it.base) o = __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(it.base + (size_t)rr * C + c)) + o;
-        __builtin_nontemporal_store(o, reinterpret_cast<h16x8*>(it.out + (size_t)rr * C + c));
+        for (int i = 0; i < 8; ++i) { oa[i] = (h16)acca[i]; ob[i] = (h16)accb[i]; }
+        if (it.base) { oa = ba + oa; ob = bb + ob; }
+        __builtin_nontemporal_store(oa, reinterpret_cast<h16x8*>(it.out + (size_t)ra * C + c));
+        if (hb) __builtin_nontemporal_store(ob, reinterpret_cast<h16x8*>(it.out + (size_t)rb * C + c));
+    }
+}
+
+// MFMA form of the same product for the larger ranks, where the VALU form above runs out of issue slots and registers.
+// The product is computed transposed,
+//   out^T tile (32 cols x 32 rows) = V^T tile (32 cols x r)  @  U^T tile (r x 32 rows)      v_mfma_f32_32x32x8_f16, r/8 steps
+// (A operand = V^T: lane l holds column c + (l & 31), k = 8 ks + 4 (l >> 5) + 0..3; B operand = U^T: row r0 + (l & 31), same
+// k; D: lane l holds output row r0 + (l & 31), columns c + 8 g + 4 (l >> 5) + 0..3 in registers 4g .. 4g+3), so a lane ends
+// up with 4 consecutive columns of one row = one 8-byte LDS write.  A workgroup covers 32 rows x 512 columns (wave w: columns
+// 128 w .. 128 w + 127, four MFMA column tiles), parks the fp16 product in LDS and then runs the SAME epilogue access
+// pattern as the VALU kernel: a wave reads one full 512-column row segment (16 B per lane), adds the state, streams it out.
+// (Writing the MFMA registers straight to memory - 32 rows x 16 B per instruction - measured 5x slower than that.)
+// The V^T fragments stay in registers while the workgroup walks down rows_per_wg rows.  fp32 accumulation in MFMA order;
+// sender (error feedback) and receiver run this same kernel, so their states stay bit-identical.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+#define LR_DEC_LDS_STRIDE (512 + 4)          // halves per LDS row: +8 bytes so the 32 row-lanes of a write spread over banks
+
+template <int RP, bool VT>
+__global__ __launch_bounds__(256) void k_lr_decode_mfma(LrDecBatch b, int N, int C, int r, int rows_per_wg) {
+    const LrDec it = b.it[blockIdx.z];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, hi = lane >> 5;
+    const int cx = blockIdx.x * 512;
+    __shared__ h16 tile[32 * LR_DEC_LDS_STRIDE];
+    const bool exact = r == RP;                    // factor rows are whole 8-byte aligned k-chunks
+    h16x4 a[4][RP / 8];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int col = cx + w * 128 + ct * 32 + li;
+#pragma unroll
+        for (int ks = 0; ks < RP / 8; ++ks) {
+            a[ct][ks] = (h16x4)(h16)0;
+            const int k0 = ks * 8 + 4 * hi;
+            if (col < C) {
+                if (VT && exact) {
+                    a[ct][ks] = *reinterpret_cast<const h16x4*>(it.V + (size_t)col * r + k0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k0 + e < r) a[ct][ks][e] = VT ? it.V[(size_t)col * r + k0 + e] : it.V[(size_t)(k0 + e) * C + col];
+                }
+            }
+        }
+    }
+    const int c = cx + lane * 8;                   // epilogue: this lane's 8 columns
+    const int rbeg = blockIdx.y * rows_per_wg, rend = min(N, rbeg + rows_per_wg);
+    for (int row0 = rbeg; row0 < rend; row0 += 32) {
+        const int row = row0 + li;
+        h16x4 bq[RP / 8];
+#pragma unroll
+        for (int ks = 0; ks < RP / 8; ++ks) {
+            bq[ks] = (h16x4)(h16)0;
+            const int k0 = ks * 8 + 4 * hi;
+            if (row < rend) {
+                if (exact) {
+                    bq[ks] = *reinterpret_cast<const h16x4*>(it.U + (size_t)row * r + k0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k0 + e < r) bq[ks][e] = it.U[(size_t)row * r + k0 + e];
+                }
+            }
+        }
+        // the state rows of the epilogue are requested before the matrix work
+        h16x8 bs[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int rr = row0 + w + 4 * q;
+            bs[q] = (h16x8)(h16)0;
+            if (it.base && rr < rend && c < C) bs[q] = __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(it.base + (size_t)rr * C + c));
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            f32x16 acc = (f32x16)0.f;
+#pragma unroll
+            for (int ks = 0; ks < RP / 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x8f16(a[ct][ks], bq[ks], acc, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (h16)acc[4 * g + e];
+                *reinterpret_cast<h16x4*>(&tile[li * LR_DEC_LDS_STRIDE + w * 128 + ct * 32 + 8 * g + 4 * hi]) = o;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int lr = w + 4 * q, rr = row0 + lr;
+            if (rr < rend && c < C) {
+                // LDS rows are 8-byte aligned only (stride 1032 B): two 8-byte reads
+                const h16x4 lo = *reinterpret_cast<const h16x4*>(&tile[lr * LR_DEC_LDS_STRIDE + lane * 8]);
+                const h16x4 hi4 = *reinterpret_cast<const h16x4*>(&tile[lr * LR_DEC_LDS_STRIDE + lane * 8 + 4]);
+                h16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi4[e]; }
+                if (it.base) o = bs[q] + o;
+                __builtin_nontemporal_store(o, reinterpret_cast<h16x8*>(it.out + (size_t)rr * C + c));
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -515,6 +638,20 @@ static int lr_decode_launch(cfx_ctx* ctx, int N, int C, int rank, int batch, con
     memset(&db, 0, sizeof(db));
     for (int i = 0; i < batch; ++i) db.it[i] = items[i];
     const int RPv = lr_rp(rank);
+    // rank <= 16: the VALU form is at the HBM roofline (tools/lowrank_bench.py); rank 32: it runs out of issue slots and
+    // registers (2.8x over the roofline), the MFMA form is back at it.  CFX_LR_DECODE=valu|mfma forces one (measurements).
+    static const char* force = getenv("CFX_LR_DECODE");
+    const bool mfma = force ? !strcmp(force, "mfma") : RPv == 32;
+    if (mfma) {
+        const int CBk = (C + 511) / 512;
+        int rows = 32;
+        for (int cand = 128; cand >= 64; cand >>= 1)
+            if ((long)CBk * ((N + cand - 1) / cand) * batch >= 768) { rows = cand; break; }
+        const dim3 grid(CBk, (N + rows - 1) / rows, batch);
+        if (vt) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_DECODE, s, (k_lr_decode_mfma<RP, true>), grid, dim3(256), 0, s, db, N, C, rank, rows));
+        else LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_DECODE, s, (k_lr_decode_mfma<RP, false>), grid, dim3(256), 0, s, db, N, C, rank, rows));
+        return check_launch(ctx, "lr decode launch");
+    }
     const dim3 grid((C + 511) / 512, (N + 31) / 32, batch);
     if (vt) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_DECODE, s, (k_lr_decode<RP, true>), grid, dim3(256), 0, s, db, N, C, rank));
     else LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_DECODE, s, (k_lr_decode<RP, false>), grid, dim3(256), 0, s, db, N, C, rank));

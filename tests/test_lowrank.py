@@ -171,3 +171,38 @@ def test_lowrank_wire_gpu():
 @pytest.mark.gpu
 def test_lowrank_state_machine_gpu():
     _check_state_machine("cuda")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C", [(70, 520), (544, 3072), (33, 8), (160, 1032)])
+@pytest.mark.parametrize("rank", [2, 8, 12, 16, 18, 24, 32])
+def test_lowrank_decode_kernels_vs_matmul(N, C, rank):
+    """Both decode kernels (VALU form for rank <= 16, MFMA + LDS form for rank 17..32) against fp32 matmul on ragged shapes:
+    plain packets [U (N,r) | V (r,C)] and, where the int4 factor format allows it, packets [q4(U) | q4(V^T)] (the V^T path)."""
+    from compactfusion_amd import codecs as K
+    from compactfusion_amd.compact.compress_quantize import dequantize_int4, quantize_int4
+    g = torch.Generator().manual_seed(N * 7 + rank)
+    U = (torch.randn(N, rank, generator=g) / rank ** 0.5).half().cuda()
+    V = torch.randn(rank, C, generator=g).half().cuda()
+    bases = [torch.randn(N, C, generator=g).half().cuda() for _ in range(3)]
+    pkt = torch.cat([U.reshape(-1), V.reshape(-1)]).contiguous()
+    want = (U.float() @ V.float()).half()
+    outs = [torch.empty(N, C, dtype=torch.float16, device="cuda") for _ in range(3)]
+    K.lr_decompress_batch(False, [pkt] * 3, [None, bases[1], bases[2]], outs, N, C, rank)
+    torch.cuda.synchronize()
+    assert rel(outs[0], want) < 1e-3
+    for i in (1, 2):
+        assert rel(outs[i], bases[i] + want) < 1e-3
+    if rank % 8 == 0 and N % 2 == 0:
+        qu, su, mu = quantize_int4(U)
+        qv, sv, mv = quantize_int4(V.t().contiguous())
+        as_half = lambda t: t.contiguous().view(torch.uint8).view(torch.float16).reshape(-1)   # noqa: E731
+        qpkt = torch.cat([as_half(qu), su.reshape(-1), mu.reshape(-1), as_half(qv), sv.reshape(-1), mv.reshape(-1)]).contiguous()
+        assert qpkt.numel() == K.lr_packet_halves(True, N, C, rank)
+        U16 = dequantize_int4(qu, su, mu)
+        V16t = dequantize_int4(qv, sv, mv)
+        wantq = (U16.float() @ V16t.float().t()).half()
+        out = torch.empty(N, C, dtype=torch.float16, device="cuda")
+        K.lr_decompress_batch(True, [qpkt], [bases[0]], [out], N, C, rank)
+        torch.cuda.synchronize()
+        assert rel(out, bases[0] + wantq) < 1e-3
