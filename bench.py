@@ -381,6 +381,18 @@ def main():
             kern_ms = sum(vals) / len(vals)
         lib.cfx_profile_enable(ctx, 0, 0, 1)
 
+    # secondary figure, same K steps replayed layer by layer in order (stats -> finalize -> dequant, three launches per
+    # layer): what a caller gets when layer j+1's K,V only exist after layer j's attention.  The pipelined replay reorders
+    # work ACROSS layers, which the bench's resident synthetic inputs allow (SURVEY.md section 8d "pure exchange" protocol).
+    inorder_ms = None
+    if args.replay == "pipelined" and not use_dist:
+        sync_all()
+        ti = time.perf_counter()
+        for i in range(args.steps):
+            check(lib.cfx_plan_run(plans[(args.warmup + args.steps + i) & 1], 0, 2 * L, sh), "plan_run(inorder)")
+        sync_all()
+        inorder_ms = (time.perf_counter() - ti) * 1e3 / args.steps
+
     # ---- state sanity (bit-exact error-feedback consistency) ---------------------------------------------------------
     ok, why = states_consistent()
     assert ok, why
@@ -436,6 +448,7 @@ def main():
         "exchange_ms_per_step": round(ms_per_step, 4),
         "exchange_issued_by": exchange_mode,
         "replay": args.replay,
+        "inorder_ms_per_step": None if inorder_ms is None else round(inorder_ms, 4),
         "exchange_stream": ((args.exchange_stream if args.replay == "pipelined" else "main") if (use_dist and step_plans is not None) else None),
         "layers_per_all_gather": (max(1, min(4, args.gather_group)) if (use_dist and step_plans is not None) else None),
         "raw_allgather_ms_per_step": None if raw_ms is None else round(raw_ms, 4),
