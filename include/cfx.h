@@ -137,7 +137,8 @@ int    cfx_lr_decompress_batch(cfx_ctx* ctx, int quantized, int N, int C, int ra
  * Kernel ids: 1 absmean_stats<bits>, 2 absmean_stats, 3 absmean_finalize, 4 binary_dequant, 5 int2_quant,
  * 6 int2_dequant, 7 minmax_stats, 8 minmax_finalize, 9 int8_quant, 10 int8_dequant, 11 int4_quant,
  * 12 int4_dequant, 13 topk_compress, 14 topk_decompress, 15 copy_probe, 16 binary_dequant launched as the
- * sender's error-feedback update, 17-22 low-rank chain (prep, aq, aty, chol, apply, decode). */
+ * sender's error-feedback update, 17-22 low-rank chain (prep, aq, aty, chol, apply, decode), 23 binary_pipe (steady-state
+ * fused launch of cfx_plan_run_pipelined), 24 binary_pipe prologue / epilogue / ragged-unit launches. */
 int         cfx_profile_enable(cfx_ctx* ctx, int capacity, unsigned kernel_mask, int stride);
 int         cfx_profile_read(cfx_ctx* ctx, int* kernel_ids, float* ms, int cap);
 const char* cfx_kernel_name(int kernel_id);
@@ -158,14 +159,17 @@ int       cfx_plan_add_decompress(cfx_plan* plan, int codec, int N, int C, int p
  * "compress(l+1), gather(l+1), wait(l), reconstruct(l)" overlaps the wire with the codec; in mode 0 waits are no-ops. */
 typedef struct cfx_comm cfx_comm;
 /* where all-gather ops run: 0 = in order on the main stream (default; measured best for layer-sized work, a
- * cross-stream event hop costs ~10 us here), 1 = side stream, 2 = prioritised side stream.  Set before adding ops. */
+ * cross-stream event hop costs ~10 us here), 1 = side stream, 2 = prioritised side stream.  Set before adding ops.
+ * cfx_plan_run_pipelined with mode 1 / 2 issues the collectives of unit u on that stream underneath the fused launch that
+ * follows finalize(u) (one more unit of look-ahead; no wait ops needed). */
 int       cfx_plan_set_exchange_stream(cfx_plan* plan, int mode);
 int       cfx_plan_add_all_gather(cfx_plan* plan, cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank);
 int       cfx_plan_add_wait(cfx_plan* plan, int gather_op);
 int       cfx_plan_size(const cfx_plan* plan);
 int       cfx_plan_copy_op(cfx_plan* dst, const cfx_plan* src, int op);   /* append a copy of a (de)compress op of `src` */
 int       cfx_plan_run(cfx_plan* plan, int first_op, int n_ops, void* stream);
-/* Software-pipelined replay.  If ops [first_op, first_op + n_ops) are a sequence of "groups"
+/* Software-pipelined replay (replaces the reference's strictly sequential quantise -> cat -> send -> dequantise per layer,
+ * xfuser/compact/ring.py:188-260 with fastpath.py:124-228, 371-438).  If ops [first_op, first_op + n_ops) are a sequence of "groups"
  *     k x compress (BINARY, flags without UPDATE_CACHE)   { all-gather }*   k x decompress (BINARY)      of one shape,
  * (k >= 1 layers whose packets travel in one collective) consecutive groups are merged into units of up to 4 layers
  * (env CFX_PIPE_UNIT_LAYERS; at most 64 reconstruction and 16 compress items per unit) and replayed on `stream` as
