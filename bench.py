@@ -94,22 +94,38 @@ def cpu_baseline(seconds: float):
     own = [base.copy().view(np.uint16) for _ in range(2)]
     peers = [base.copy().view(np.uint16) for _ in range(14)]
     pk = [np.zeros(CO.load().oracle_packet_bytes(1, N, C, 0) // 2, dtype=np.uint16) for _ in range(2)]
-    CO.compress("binary", xs[0], own[0], N, C, packet=pk[0], new_base=own[0])   # warm up (tables, threads)
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
+    def one_layer():
         for i in range(2):
             CO.compress("binary", xs[i], own[i], N, C, packet=pk[i], new_base=own[i])
         for j in range(14):
             CO.decompress("binary", pk[j % 2], peers[j], N, C, out=peers[j])
+
+    one_layer()                                       # warm up (tables, threads, page faults)
+    # thread count: the box may report more hardware threads than it schedules for us; take the fastest of a short sweep
+    most = int(CO.num_threads())
+    best_t, best = most, None
+    for t in sorted({most} | {c for c in (4, 8, 16, 32, 64, 128, 256) if c <= most}):
+        CO.set_num_threads(t)
+        one_layer()
+        t0 = time.perf_counter()
+        one_layer()
+        dt1 = time.perf_counter() - t0
+        if best is None or dt1 < best:
+            best, best_t = dt1, t
+    CO.set_num_threads(best_t)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        one_layer()
         reps += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds or reps >= 200:
+        if dt >= seconds or reps >= 2000:
             break
     act_bytes = reps * 16 * N * C * 2
-    return {"value": round(act_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": int(CO.num_threads()), "kind": "port",
+    return {"value": round(act_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": best_t, "kind": "port",
             "sample": f"{reps} x one layer of the workload (2 compress + 14 decompress, 1-bit, (544,3072) fp16) in {dt:.1f} s, "
-                      f"C oracle oracle/cfx_oracle.c with OpenMP"}
+                      f"C oracle oracle/cfx_oracle.c with OpenMP ({best_t} of {most} threads: fastest of a sweep; "
+                      f"{'F16C conversions' if CO.load().oracle_uses_f16c() else 'software fp16 conversions'})"}
 
 
 def group_recv_offset(l: int, r: int, kv: int, G: int, L: int, live: int, slot: int) -> int:

@@ -7,23 +7,45 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libcfx_oracle.so")
+LIB_F16C = os.path.join(HERE, "libcfx_oracle_f16c.so")
 CODEC_ID = {"binary": 1, "int2": 2, "int4": 3, "int8": 4, "topk": 5}
 _lib = None
 
 
 def build(force=False):
     src = os.path.join(HERE, "cfx_oracle.c")
-    if force or not os.path.exists(LIB) or os.path.getmtime(src) > os.path.getmtime(LIB):
+    stale = any(not os.path.exists(p) or os.path.getmtime(src) > os.path.getmtime(p) for p in (LIB, LIB_F16C))
+    if force or stale:
         subprocess.run(["make", "-C", HERE, "-s", "-B"], check=True)
     return LIB
 
 
-def load():
+def cpu_has_f16c() -> bool:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                flags = set(line.split(":", 1)[1].split())
+                return "f16c" in flags and "avx2" in flags
+    except OSError:
+        pass
+    return False
+
+
+def load(variant=None):
+    """variant: None = hardware fp16 conversions when the CPU has them, "generic" / "f16c" to force one (tests)."""
     global _lib
+    if variant is not None:
+        build()
+        return _bind(ctypes.CDLL(LIB_F16C if variant == "f16c" else LIB))
     if _lib is None:
-        if not os.path.exists(LIB):
+        if not os.path.exists(LIB) or not os.path.exists(LIB_F16C):
             build()
-        L = ctypes.CDLL(LIB)
+        _lib = _bind(ctypes.CDLL(LIB_F16C if cpu_has_f16c() else LIB))
+    return _lib
+
+
+def _bind(L):
+    if True:
         L.oracle_packet_bytes.restype = ctypes.c_size_t
         L.oracle_packet_bytes.argtypes = [ctypes.c_int] * 4
         L.oracle_compress.restype = ctypes.c_int
@@ -31,9 +53,10 @@ def load():
         L.oracle_decompress.restype = ctypes.c_int
         L.oracle_decompress.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3
         L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_set_num_threads.argtypes = [ctypes.c_int]
+        L.oracle_uses_f16c.restype = ctypes.c_int
         L.oracle_init()
-        _lib = L
-    return _lib
+    return L
 
 
 def _p(a):
@@ -71,3 +94,7 @@ def decompress(codec, packet, base, N, C, param=0, out=None):
 
 def num_threads():
     return load().oracle_num_threads()
+
+
+def set_num_threads(n: int):
+    load().oracle_set_num_threads(int(n))

@@ -17,7 +17,9 @@
  *
  * fp16 arithmetic: every op converts to fp32, operates, rounds once to fp16 (round-to-nearest-even);
  * by Figueroa's theorem that equals correctly rounded fp16 arithmetic (= torch eager, = the HIP kernels).
- * Portable C (no F16C intrinsics) so the same .so runs on whatever CPU the GPU box has.
+ * Portable C by default, so the same .so runs on whatever CPU the GPU box has.  Built a second time with -DCFX_F16C
+ * -mf16c -mavx2 (libcfx_oracle_f16c.so) the two fp16 conversions use the hardware instructions (IEEE round-to-nearest-even,
+ * the same results, tests/test_oracle_c.py runs both); c_oracle.py loads that build when /proc/cpuinfo lists f16c + avx2.
  */
 #include <math.h>
 #include <stdint.h>
@@ -25,6 +27,9 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#endif
+#ifdef CFX_F16C
+#include <immintrin.h>
 #endif
 
 typedef uint16_t h16;
@@ -54,10 +59,17 @@ void oracle_init(void) {
     tables_ready = 1;
 }
 
+#ifdef CFX_F16C
+static inline float h2f(h16 h) { return _cvtsh_ss(h); }
+static inline h16 f2h(float f) { return _cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
+#define f2h_soft f2h_unused
+#else
 static inline float h2f(h16 h) { return H2F[h]; }
+#define f2h_soft f2h
+#endif
 
 /* fp32 -> fp16, round to nearest even, IEEE (subnormals, inf, nan) */
-static inline h16 f2h(float f) {
+static inline h16 f2h_soft(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
     const uint32_t s = (u >> 16) & 0x8000u;
@@ -361,5 +373,21 @@ int oracle_num_threads(void) {
     return omp_get_max_threads();
 #else
     return 1;
+#endif
+}
+
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+int oracle_uses_f16c(void) {
+#ifdef CFX_F16C
+    return 1;
+#else
+    return 0;
 #endif
 }

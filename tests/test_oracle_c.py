@@ -7,6 +7,20 @@ from oracle import c_oracle as CO
 from oracle import ref_np as R
 
 F16 = np.float16
+
+
+@pytest.fixture(autouse=True, params=["generic", "f16c"])
+def oracle_build(request):
+    """Every test runs on both builds of the C oracle: software fp16 conversions and the F16C instructions."""
+    if request.param == "f16c" and not CO.cpu_has_f16c():
+        pytest.skip("CPU without f16c / avx2")
+    saved = CO._lib
+    CO._lib = CO.load(request.param)
+    assert CO._lib.oracle_uses_f16c() == (1 if request.param == "f16c" else 0)
+    yield request.param
+    CO._lib = saved
+
+
 CASES = [("binary", 0), ("int2", 0), ("int4", 0), ("int8", 0), ("topk", 1), ("topk", 2), ("topk", 4), ("topk", 8), ("topk", 16)]
 
 
