@@ -266,6 +266,33 @@ def test_full_size_ef_round_trip(name, cid, param, shape):
     assert errs[-1] < 0.2 and errs[-1] < 2.5 * errs[0] + 1e-3, errs
 
 
+@pytest.mark.parametrize("name,cid,param,shape", [("binary", 1, 0, (544, 3072)), ("int8", 4, 0, (4096, 1152)), ("int4", 3, 0, (1024, 1152)),
+                                                  ("int4", 3, 0, (4448, 3072)), ("topk", 5, 8, (512, 1536)), ("int2", 2, 0, (4448, 3072))])
+def test_baseline_config_sizes_vs_c_oracle(name, cid, param, shape):
+    """Every BASELINE.json configuration at its FULL size (SURVEY.md section 8d shapes S1-S5), two drifting steps, packet and
+    error-feedback state bit for bit against the C oracle (the numpy oracle's twin, fast enough for 13.7 M elements)."""
+    from compactfusion_amd import codecs as K
+    from oracle import c_oracle as CO
+    N, C = shape
+    x, base = make_inputs(7, N, C)
+    state_c = base.copy().view(np.uint16)
+    state_g = dev(base)
+    pkt_g = torch.empty(K.packet_halves(cid, N, C, param), dtype=torch.float16, device="cuda")
+    rng = np.random.default_rng(8)
+    for step in range(2):
+        pkt_c, state_c = CO.compress(name, x, state_c, N, C, param)
+        K.compress_batch(cid, [dev(x)], [state_g], [state_g], [pkt_g], N, C, param, update_cache=True)
+        torch.cuda.synchronize()
+        same_bits(host_bits(pkt_g), pkt_c, f"{name} {shape} step {step}: packet")
+        same_bits(host_bits(state_g), state_c, f"{name} {shape} step {step}: state")
+        x = (x.astype(np.float32) + 0.1 * rng.standard_normal((N, C)).astype(np.float32)).astype(F16)
+    # and the receiver: reconstructs the sender's state from the last packet and the previous state
+    rec_c = CO.decompress(name, pkt_c, base.view(np.uint16), N, C, param)
+    rec_g = K.decompress(cid, pkt_g, dev(base), N, C, param)
+    torch.cuda.synchronize()
+    same_bits(host_bits(rec_g), rec_c, f"{name} {shape}: receiver")
+
+
 def test_error_codes():
     from compactfusion_amd import codecs as K
     from compactfusion_amd._lib import CfxError
