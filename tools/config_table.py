@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Per-BASELINE-configuration exchange-step timing on ONE MI355X (developer tool; output committed under profiles/).
+
+For each configuration of BASELINE.json (shapes from SURVEY.md section 8d) one rank's codec work of one denoise step is
+replayed layer by layer, in order, with the other ranks looped back (their packets = our packets, their states distinct
+buffers), through the C-ABI:
+  ring configs (3, 4):   per layer compress(K,V) with error-feedback update, then reconstruct (W-1) peers x {K,V}
+  gather configs (2, 5): per layer compress(K,V) without update, then reconstruct all W ranks x {K,V} (compact_all_gather)
+  config 1:              one tensor, int8 residual round trip (the reference's own CPU-runnable case)
+Reported: ms per step (wall clock over >= 20 steps, states rotating over all layers so nothing is cache-resident),
+GB/s of fp16 activations compressed + reconstructed, and the C oracle on the host cores for the same step (bounded
+sample; n/a for the low-rank codec, which has no C restatement).
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from compactfusion_amd import _lib, codecs as K
+
+CONFIGS = [
+    # name, codec id, param, (N, C), layers, tensors compressed per layer, tensors reconstructed per layer, update on compress
+    ("1 int8 residual [1,4096,1152], world 1", 4, 0, (4096, 1152), 1, 1, 1, True),
+    ("2 PixArt-a 512^2 SP2 patch-gather INT4", 3, 0, (1024, 1152), 28, 2, 4, False),
+    ("3 FLUX.1 1024^2 ring 8, 1-bit (bench.py workload, in order)", 1, 0, (544, 3072), 57, 2, 14, True),
+    ("4 CogVideoX-5B SP4 ring INT4", 3, 0, (4448, 3072), 42, 2, 6, True),
+    ("5 SD3 1024^2 SP8 patch-gather top-k 1:8", 5, 8, (512, 1536), 24, 2, 16, False),
+    ("5 SD3 1024^2 SP8 patch-gather LOW_RANK r=8", 101, 8, (512, 1536), 24, 2, 16, False),
+    ("5 SD3 1024^2 SP8 patch-gather LOW_RANK r=16", 101, 16, (512, 1536), 24, 2, 16, False),
+]
+NAMES = {1: "binary", 3: "int4", 4: "int8", 5: "topk"}
+
+
+def gpu_step(cid, param, N, C, L, ncomp, nrec, update):
+    dev = torch.device("cuda", 0)
+    lib = _lib.load()
+    ctx = K.context(0)
+    g = torch.Generator(device=dev).manual_seed(1)
+    Lb = max(L, min(64, int(2.0e9 // ((ncomp + nrec) * N * C * 2)) or 1))      # enough distinct state to defeat the 256 MB cache
+    x = [torch.randn(Lb, ncomp, N, C, generator=g, device=dev).half() for _ in range(2)]
+    own = torch.randn(Lb, ncomp, N, C, generator=g, device=dev).half()
+    peers = torch.randn(Lb, nrec, N, C, generator=g, device=dev).half()
+    lowrank = cid >= 100
+    sh = torch.cuda.current_stream().cuda_stream
+    if not lowrank:
+        slot = (K.packet_bytes(cid, N, C, param) + 255) // 256 * 256
+        pk = torch.zeros(Lb, ncomp, slot, dtype=torch.uint8, device=dev)
+        wsb = lib.cfx_workspace_bytes(cid, N, C, param, ncomp)
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        plans = []
+        for s in range(2):
+            plan = lib.cfx_plan_create(ctx)
+            for l in range(Lb):
+                c = (_lib.CompItem * ncomp)(*[_lib.CompItem(x[s][l, i].data_ptr(), own[l, i].data_ptr(), own[l, i].data_ptr() if update else None,
+                                                            pk[l, i].data_ptr()) for i in range(ncomp)])
+                assert lib.cfx_plan_add_compress(plan, cid, N, C, param, 1 if update else 0, ncomp, c, ws.data_ptr(), wsb) >= 0
+                for a in range(0, nrec, 16):
+                    n = min(16, nrec - a)
+                    d = (_lib.DecompItem * n)(*[_lib.DecompItem(pk[l, (a + j) % ncomp].data_ptr(), peers[l, a + j].data_ptr(), peers[l, a + j].data_ptr())
+                                                for j in range(n)])
+                    assert lib.cfx_plan_add_decompress(plan, cid, N, C, param, n, d) >= 0
+            plans.append(plan)
+        ops_per_layer = 1 + (nrec + 15) // 16
+
+        def step(i):
+            first = (i * L) % Lb
+            n = min(L, Lb - first)
+            assert lib.cfx_plan_run(plans[i & 1], first * ops_per_layer, n * ops_per_layer, sh) == 0
+            if n < L:
+                assert lib.cfx_plan_run(plans[i & 1], 0, (L - n) * ops_per_layer, sh) == 0
+    else:
+        q = False
+        pkh = K.lr_packet_halves(q, N, C, param)
+        pk = torch.zeros(Lb, ncomp, (pkh + 127) // 128 * 128, dtype=torch.float16, device=dev)
+        rp = K.lr_rank_pad(param)
+        q0 = [torch.randn(C, rp, generator=g, device=dev) for _ in range(ncomp)]
+
+        def step(i):
+            for k in range(L):
+                l = (i * L + k) % Lb
+                xs = [x[i & 1][l, j] for j in range(ncomp)]
+                bs = [own[l, j] for j in range(ncomp)]
+                pks = [pk[l, j, :pkh] for j in range(ncomp)]
+                K.lr_compress_batch(q, xs, bs, bs if update else [None] * ncomp, pks, q0, N, C, param, update_cache=update)
+                for a in range(0, nrec, 16):
+                    n = min(16, nrec - a)
+                    K.lr_decompress_batch(q, [pks[(a + j) % ncomp] for j in range(n)], [peers[l, a + j] for j in range(n)],
+                                          [peers[l, a + j] for j in range(n)], N, C, param)
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    steps = max(20, int(0.2 / max(1e-6, L * 40e-6)))
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(3 + i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def cpu_step(cid, param, N, C, L, ncomp, nrec, update, budget=8.0):
+    if cid >= 100:
+        return None, 0
+    from oracle import c_oracle as CO
+    name = NAMES[cid]
+    rng = np.random.default_rng(0)
+    base = rng.standard_normal((N, C)).astype(np.float16)
+    x = (base.astype(np.float32) + 0.1 * rng.standard_normal((N, C)).astype(np.float32)).astype(np.float16)
+    own = [base.copy().view(np.uint16) for _ in range(ncomp)]
+    peers = [base.copy().view(np.uint16) for _ in range(nrec)]
+    pk = [np.zeros(CO.load().oracle_packet_bytes(cid, N, C, param) // 2, dtype=np.uint16) for _ in range(ncomp)]
+
+    def layer():
+        for i in range(ncomp):
+            CO.compress(name, x, own[i], N, C, param, update=update, packet=pk[i], new_base=own[i] if update else None)
+        for j in range(nrec):
+            CO.decompress(name, pk[j % ncomp], peers[j], N, C, param, out=peers[j])
+    layer()
+    most = int(CO.num_threads())
+    best, best_t = None, most
+    for t in sorted({most} | {c for c in (8, 16, 32, 64, 128) if c <= most}):
+        CO.set_num_threads(t)
+        layer()
+        t0 = time.perf_counter()
+        layer()
+        d = time.perf_counter() - t0
+        if best is None or d < best:
+            best, best_t = d, t
+    CO.set_num_threads(best_t)
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < budget and n < 50 * L):
+        layer()
+        n += 1
+    return (time.perf_counter() - t0) / n * L * 1e3, best_t
+
+
+def main():
+    rows = []
+    for name, cid, param, (N, C), L, ncomp, nrec, update in CONFIGS:
+        ms = gpu_step(cid, param, N, C, L, ncomp, nrec, update)
+        act = L * (ncomp + nrec) * N * C * 2
+        cms, thr = cpu_step(cid, param, N, C, L, ncomp, nrec, update)
+        rows.append({"config": name, "shape": [N, C], "layers": L, "compressed_per_layer": ncomp, "reconstructed_per_layer": nrec,
+                     "gpu_ms_per_step": round(ms, 4), "gpu_GBps": round(act / ms / 1e6, 1),
+                     "cpu_ms_per_step": None if cms is None else round(cms, 2), "cpu_GBps": None if cms is None else round(act / cms / 1e6, 2),
+                     "cpu_threads": thr})
+        print(rows[-1], flush=True)
+        torch.cuda.empty_cache()
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "config_table.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    json.dump(rows, open(out, "w"), indent=1)
+    print("| BASELINE config | shard (N,C) | layers | GPU ms/step (in order) | GPU GB/s fp16 | C oracle ms/step (threads) | CPU GB/s |")
+    print("|---|---|---|---|---|---|---|")
+    for r in rows:
+        cpu = "n/a" if r["cpu_ms_per_step"] is None else f"{r['cpu_ms_per_step']} ({r['cpu_threads']})"
+        print(f"| {r['config']} | ({r['shape'][0]},{r['shape'][1]}) | {r['layers']} | {r['gpu_ms_per_step']} | {r['gpu_GBps']} | {cpu} | "
+              f"{'n/a' if r['cpu_GBps'] is None else r['cpu_GBps']} |")
+
+
+if __name__ == "__main__":
+    main()
