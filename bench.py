@@ -498,7 +498,7 @@ def main():
             kname = (f"k_binary_pipe (one launch = {ul} layers: dequant+add of {16 * ul} tensors x (544,3072) [own K,V error-feedback "
                      f"update + 7 peers' K,V per layer] + finalize of the next {ul} layers' K,V scales + stats/sign bits of the {ul} "
                      "layers after those)")
-            pmc_key, csv_prefix = "k_binary_pipe_bytes_per_launch", "k_binary_pipe"
+            pmc_key, csv_prefix = "k_binary_pipe_bytes_per_launch", "k_binary_pipe<true>"
         else:
             alg = ALG_BYTES_PER_EL["decompress"] * 16 * N * C
             kname = "k_binary_dequant (16 tensors x (544,3072) per launch: own K,V error-feedback update + 7 peers' K,V)"
@@ -525,7 +525,8 @@ def main():
                 if ent:
                     out["roofline"]["avg_launch_us_rocprof"] = ent["avg_us"]
                     out["roofline"]["rocprof_source"] = ("profiles/r01_bench_kernel_durations.json (tools/trace_kernel_avg.py over the "
-                                                         "rocprofv3 --kernel-trace of this command; full launches only)")
+                                                         "rocprofv3 --kernel-trace of this command); the same kernel's row of "
+                                                         "profiles/r01_bench_kernel_stats.csv (rocprofv3 --stats) agrees")
             except Exception:
                 pass
     else:

@@ -345,6 +345,9 @@ struct PipeArgs {
     u64* ws_st;
     size_t ws_stride;
 };
+// STEADY only names the launch for profilers: steady-state launches (three equally sized units) and the pipeline's
+// prologue / epilogue / ragged-unit launches show up as two kernels in rocprofv3 --stats, with separate averages.
+template <bool STEADY>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_binary_pipe(BatchDX dq, BatchC fin, BatchC st, PipeArgs a) {
     __shared__ u64 sm[WAVES][TILE_C];
     int b = blockIdx.x;
@@ -1416,8 +1419,8 @@ static int launch_pipe(cfx_plan* p, hipStream_t s, int N, int C, const int* comp
     }
     // profiled as "the" pipeline kernel only when all three groups carry equally sized units (steady state)
     const bool steady = dq && fin && st && dq->n_layers == fin->n_layers && fin->n_layers == st->n_layers;
-    const int kid = steady ? KID_BINARY_PIPE : KID_BINARY_PIPE_EDGE;
-    LAUNCH(ctx, kid, s, k_binary_pipe, dim3(a.n_fin + a.n_st + n_dq), dim3(NTHR), 0, s, bd, bf, bs, a);
+    if (steady) LAUNCH(ctx, KID_BINARY_PIPE, s, k_binary_pipe<true>, dim3(a.n_fin + a.n_st + n_dq), dim3(NTHR), 0, s, bd, bf, bs, a);
+    else LAUNCH(ctx, KID_BINARY_PIPE_EDGE, s, k_binary_pipe<false>, dim3(a.n_fin + a.n_st + n_dq), dim3(NTHR), 0, s, bd, bf, bs, a);
     return check_launch(ctx, "pipelined launch");
 }
 

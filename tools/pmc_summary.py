@@ -63,7 +63,7 @@ def main():
     deq = res["kernels"].get("k_binary_dequant")
     if deq and deq["hbm_bytes"]:
         res["k_binary_dequant_bytes_per_launch"] = int(deq["hbm_bytes"])
-    pipe = res["kernels"].get("k_binary_pipe")
+    pipe = res["kernels"].get("k_binary_pipe<true>") or res["kernels"].get("k_binary_pipe")
     if pipe and pipe["hbm_bytes"]:
         res["k_binary_pipe_bytes_per_launch"] = int(pipe["hbm_bytes"])
     json.dump(res, open(out, "w"), indent=1)

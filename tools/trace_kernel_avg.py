@@ -12,7 +12,7 @@ def main():
     src, out = sys.argv[1:3]
     by = defaultdict(list)
     for r in csv.DictReader(open(src)):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")          # template arguments kept: k_binary_pipe<true> = steady state
         grid = int(r.get("Grid_Size", 0) or 0) or (int(r.get("Grid_Size_X", 1)) * int(r.get("Grid_Size_Y", 1)) * int(r.get("Grid_Size_Z", 1)))
         by[name].append((grid, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     res = {"source": "rocprofv3 --kernel-trace", "unit": "us", "kernels": {}}
