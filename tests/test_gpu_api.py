@@ -423,6 +423,46 @@ def test_pipelined_replay_falls_back_for_other_patterns():
     lib.cfx_plan_destroy(plan)
 
 
+@pytest.mark.parametrize("codec", [1, 3])
+def test_codec_calls_are_graph_capturable(codec):
+    """no atomics, no library-owned allocations in the codec calls -> a compress + reconstruct sequence can be
+    captured into a HIP graph (torch.cuda.CUDAGraph on the capture stream) and replayed; results equal the eager calls."""
+    from compactfusion_amd import codecs as K
+    N, C, B = 128, 1024, 2
+    g = torch.Generator().manual_seed(13)
+    xs = [torch.randn(N, C, generator=g).half().cuda() for _ in range(B)]
+    base0 = [(x.float() + 0.1 * torch.randn(N, C, generator=g).cuda()).half() for x in xs]
+    ref_state = [b.clone() for b in base0]
+    ref_peer = [b.clone() for b in base0]
+    ref_pkt = [torch.zeros(K.packet_halves(codec, N, C), dtype=torch.float16, device="cuda") for _ in range(B)]
+    for _ in range(2):
+        K.compress_batch(codec, xs, ref_state, ref_state, ref_pkt, N, C, update_cache=True)
+        K.decompress_batch(codec, ref_pkt, ref_peer, ref_peer, N, C)
+    state = [b.clone() for b in base0]
+    peer = [b.clone() for b in base0]
+    pkt = [torch.zeros_like(p) for p in ref_pkt]
+    ws = K.workspace(codec, N, C, 0, B, 0)
+    comp = K.prepare_compress(codec, state, state, pkt, N, C, update_cache=True)
+    dec = K.prepare_decompress(codec, pkt, peer, peer, N, C)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            comp(xs, side.cuda_stream)
+            dec(side.cuda_stream)
+    # capture does not execute: the states are still the initial ones
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(state, base0)) and ws is not None
+    graph.replay()
+    graph.replay()
+    torch.cuda.synchronize()
+    for i in range(B):
+        assert torch.equal(pkt[i].view(torch.int16), ref_pkt[i].view(torch.int16))
+        assert torch.equal(state[i].view(torch.int16), ref_state[i].view(torch.int16))
+        assert torch.equal(peer[i].view(torch.int16), ref_peer[i].view(torch.int16))
+
+
 def test_native_comm_single_rank(tmp_path):
     """libcfx's own RCCL communicator (1 rank): unique id, init, all-gather through a plan on every stream mode."""
     import torch.distributed as dist
