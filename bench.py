@@ -484,6 +484,16 @@ def main():
         "raw_allgather_ms_per_step": None if raw_ms is None else round(raw_ms, 4),
         "speedup_vs_raw_allgather": None if raw_ms is None else round(raw_ms / ms_per_step, 3),
     }
+    if live > 1:
+        # wire side of the roofline pair (north star: "fraction of HBM / xGMI roofline"): packets RECEIVED per GPU per step
+        # over the step time, against the xGMI links an all-gather among `live` GPUs can use (one link per peer, 7 at most;
+        # ~153 GB/s per direction per link, MI355X_MICROARCH.md).  The exchange overlaps the codec work, so this is a lower
+        # bound of the link rate actually reached while a collective is in flight.
+        wire = (live - 1) * 2 * L * pkt_bytes
+        links = min(live - 1, 7)
+        out["xgmi"] = {"wire_bytes_per_gpu_per_step": int(wire), "achieved": round(wire / (ms_per_step * 1e-3) / 1e9, 2),
+                       "peak": 153.0 * links, "unit": "GB/s", "frac": round(wire / (ms_per_step * 1e-3) / 1e9 / (153.0 * links), 4),
+                       "links": links, "raw_bytes_per_gpu_per_step": int((live - 1) * 2 * L * N * C * 2)}
     if kern_ms is not None:
         if args.replay == "pipelined":
             # one steady-state launch = a unit of `ul` layers in each of the three groups: reconstruct 16*ul tensors (bits +
