@@ -51,6 +51,18 @@ static inline int prof_slot(cfx_ctx* ctx, int kid) {
         else hipLaunchKernelGGL(kern, grid, block, shm, strm, __VA_ARGS__); \
     } while (0)
 
+// Same, with an optional event that must fire when THIS launch has finished (used to hand work to another stream).  When
+// the launch is not being profiled the event rides on the dispatch packet itself (no marker packet on the stream: a
+// marker costs ~6 us of queue time between two kernels on this stack); otherwise it is recorded right after the launch.
+#define LAUNCH_DONE(ctx, kid, s, done_ev, kern, grid, block, shm, strm, ...) do { \
+        const int _pi = prof_slot(ctx, kid); \
+        if (_pi >= 0) { \
+            hipExtLaunchKernelGGL(kern, grid, block, shm, strm, (ctx)->prof[_pi].a, (ctx)->prof[_pi].b, 0, __VA_ARGS__); \
+            if (done_ev) (void)hipEventRecord(done_ev, strm); \
+        } else if (done_ev) hipExtLaunchKernelGGL(kern, grid, block, shm, strm, nullptr, done_ev, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, block, shm, strm, __VA_ARGS__); \
+    } while (0)
+
 static inline int fail(cfx_ctx* ctx, int code, const char* msg) {
     if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
     return code;

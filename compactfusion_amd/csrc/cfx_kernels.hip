@@ -1372,7 +1372,8 @@ int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) {
 struct PipeUnit { int first_layer, n_layers, n_comp_items, n_dq_items; };
 
 static int launch_pipe(cfx_plan* p, hipStream_t s, int N, int C, const int* comp_op, const int* deq_op,
-                       const PipeUnit* dq, const PipeUnit* fin, const PipeUnit* st, int fin_parity, int st_parity) {
+                       const PipeUnit* dq, const PipeUnit* fin, const PipeUnit* st, int fin_parity, int st_parity,
+                       hipEvent_t done_ev) {
     cfx_ctx* ctx = p->ctx;
     BatchDX bd; BatchC bf, bs;
     PipeArgs a;
@@ -1419,8 +1420,8 @@ static int launch_pipe(cfx_plan* p, hipStream_t s, int N, int C, const int* comp
     }
     // profiled as "the" pipeline kernel only when all three groups carry equally sized units (steady state)
     const bool steady = dq && fin && st && dq->n_layers == fin->n_layers && fin->n_layers == st->n_layers;
-    if (steady) LAUNCH(ctx, KID_BINARY_PIPE, s, k_binary_pipe<true>, dim3(a.n_fin + a.n_st + n_dq), dim3(NTHR), 0, s, bd, bf, bs, a);
-    else LAUNCH(ctx, KID_BINARY_PIPE_EDGE, s, k_binary_pipe<false>, dim3(a.n_fin + a.n_st + n_dq), dim3(NTHR), 0, s, bd, bf, bs, a);
+    if (steady) LAUNCH_DONE(ctx, KID_BINARY_PIPE, s, done_ev, k_binary_pipe<true>, dim3(a.n_fin + a.n_st + n_dq), dim3(NTHR), 0, s, bd, bf, bs, a);
+    else LAUNCH_DONE(ctx, KID_BINARY_PIPE_EDGE, s, done_ev, k_binary_pipe<false>, dim3(a.n_fin + a.n_st + n_dq), dim3(NTHR), 0, s, bd, bf, bs, a);
     return check_launch(ctx, "pipelined launch");
 }
 
@@ -1505,15 +1506,20 @@ int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
             }
         }
         if (rc != CFX_OK) break;
-        if (unit(t - 2 - d) || unit(t - 1) || unit(t))
-            rc = launch_pipe(p, s, N, C, comp_op, deq_op, unit(t - 2 - d), unit(t - 1), unit(t), (t - 1) & 1, t & 1);
-        if (d == 1) {
+        // overlapped mode: the collectives of unit t-1 may start when THIS launch (which holds finalize(t-1)) has finished;
+        // the first of them lends its event to the launch
+        hipEvent_t done_ev = nullptr;
+        if (d == 1 && next_ag < n_ag && ag_unit[next_ag] + 1 <= t) done_ev = p->ops[ag_op[next_ag]].ev_pre;
+        bool launched = false;
+        if (unit(t - 2 - d) || unit(t - 1) || unit(t)) {
+            rc = launch_pipe(p, s, N, C, comp_op, deq_op, unit(t - 2 - d), unit(t - 1), unit(t), (t - 1) & 1, t & 1, done_ev);
+            launched = true;
+        }
+        if (d == 1 && rc == CFX_OK && done_ev) {
+            if ((!launched && hipEventRecord(done_ev, s) != hipSuccess) || hipStreamWaitEvent(p->side, done_ev, 0) != hipSuccess)
+                rc = fail(p->ctx, CFX_ERR_LAUNCH, "plan: event ordering failed");
             while (rc == CFX_OK && next_ag < n_ag && ag_unit[next_ag] + 1 <= t) {
                 PlanOp* o = &p->ops[ag_op[next_ag++]];
-                if (hipEventRecord(o->ev_pre, s) != hipSuccess || hipStreamWaitEvent(p->side, o->ev_pre, 0) != hipSuccess) {
-                    rc = fail(p->ctx, CFX_ERR_LAUNCH, "plan: event ordering failed");
-                    break;
-                }
                 rc = all_gather(o, p->side);
                 if (rc == CFX_OK && hipEventRecord(o->ev_done, p->side) != hipSuccess) rc = fail(p->ctx, CFX_ERR_LAUNCH, "plan: event record failed");
             }
