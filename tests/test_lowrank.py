@@ -135,7 +135,7 @@ def _check_state_machine(dev):
     N, C = 128, 512
     g = torch.Generator().manual_seed(3)
     left, right = torch.randn(N, 6, generator=g), torch.randn(6, C, generator=g)
-    for typ, rank in ((T.LOW_RANK, 8), (T.LOW_RANK_Q, 32)):
+    for typ, rank in ((T.LOW_RANK, 8), (T.LOW_RANK, 12), (T.LOW_RANK, 16), (T.LOW_RANK_Q, 16), (T.LOW_RANK_Q, 32)):   # examples/configs.py:63-110
         cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: None, comp_rank=rank, residual=1, ef=True))
         cur = torch.randn(N, C, generator=g).half()
         errs = []
