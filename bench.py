@@ -20,11 +20,11 @@ value = whole-job fp16 activation bytes compressed + reconstructed per second (G
         n_gpus * 57 * (2 + 14) * 544*3072*2 B / step time.
 Replay (--replay): `pipelined` (default) = cfx_plan_run_pipelined: per layer ONE fused launch k_binary_pipe =
         [dequant+add of unit u's 16 tensors per layer | finalize of unit u+1's scales | stats + sign bits of unit u+2's K,V],
-        a unit = 4 consecutive layers, so the small latency-bound compress kernels ride underneath the bandwidth-bound
+        a unit = 7 consecutive layers, so the small latency-bound compress kernels ride underneath the bandwidth-bound
         reconstruction and a launch is long enough to amortise its ramp and tail; `inorder` = cfx_plan_run,
         stats -> finalize -> dequant one after the other.  Same results bit for bit (tests/test_gpu_api.py).
 roofline = the dominant kernel: k_binary_pipe (pipelined; algorithmic bytes 4.125 B/element x (16 + 2) tensors of
-        544*3072 elements per layer, 4 layers per launch) or k_binary_dequant (inorder; 4.125 B/element x 16 tensors) / average
+        544*3072 elements per layer, 7 layers per launch) or k_binary_dequant (inorder; 4.125 B/element x 16 tensors) / average
         launch duration from hipEvents attached to the dispatch on the launch stream inside the timed region (native
         hooks in libcfx.so).
 cpu_baseline = the C oracle (oracle/cfx_oracle.c, OpenMP) timed on this box's host cores on one layer of the same
@@ -61,8 +61,8 @@ def parse():
     ap.add_argument("--exchange-stream", choices=["main", "side", "prio"], default="prio",
                     help="N > 1, native exchange: 'main' issues every all-gather in order on the compute stream; 'side' / 'prio' "
                          "(prioritised stream) issue it on an exchange stream one unit ahead, underneath the next fused launch")
-    ap.add_argument("--gather-group", type=int, default=4,
-                    help="N > 1, native exchange: layers (1..4) whose packets travel in ONE all-gather (fewer, larger collectives; "
+    ap.add_argument("--gather-group", type=int, default=7,
+                    help="N > 1, native exchange: layers (1..7) whose packets travel in ONE all-gather (fewer, larger collectives; "
                          "a group is replayed as one unit of the pipelined schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
@@ -78,7 +78,7 @@ def parse():
     ap.add_argument("--copy-probe", type=int, default=0,
                     help="also launch the 96 MiB float4 copy probe this many times before the timed region "
                          "(known byte count: calibrates FETCH_SIZE / WRITE_SIZE in PMC profiles)")
-    ap.add_argument("--event-stride", type=int, default=8,
+    ap.add_argument("--event-stride", type=int, default=4,
                     help="bracket every k-th launch of the dominant kernel with hipEvents (an event pair costs a few us of stream time)")
     return ap.parse_args()
 
@@ -249,7 +249,7 @@ def main():
                 native_comm.self_test()
                 # grouped exchange buffers: group g = layers [gG, gG + nl); ONE all-gather moves the group's K,V packets of
                 # every rank: send = send[gG : gG + nl] (contiguous), recv region laid out [rank][layer in group][K|V][slot]
-                G = max(1, min(4, args.gather_group))      # a group must fit one fused launch (<= 4 layers x 16 tensors)
+                G = max(1, min(7, args.gather_group))      # a group must fit one fused launch (<= 7 layers x 16 tensors)
                 groups = [(a, min(L, a + G)) for a in range(0, L, G)]
                 grecv = torch.zeros(L * live * 2 * slot, dtype=torch.uint8, device=dev)
 
@@ -480,7 +480,7 @@ def main():
         "replay": args.replay,
         "inorder_ms_per_step": None if inorder_ms is None else round(inorder_ms, 4),
         "exchange_stream": (["main", "side", "prio"][stream_mode] if (use_dist and step_plans is not None) else None),
-        "layers_per_all_gather": (max(1, min(4, args.gather_group)) if (use_dist and step_plans is not None) else None),
+        "layers_per_all_gather": (max(1, min(7, args.gather_group)) if (use_dist and step_plans is not None) else None),
         "raw_allgather_ms_per_step": None if raw_ms is None else round(raw_ms, 4),
         "speedup_vs_raw_allgather": None if raw_ms is None else round(raw_ms / ms_per_step, 3),
     }
@@ -499,11 +499,11 @@ def main():
             # one steady-state launch = a unit of `ul` layers in each of the three groups: reconstruct 16*ul tensors (bits +
             # state in, state out: 4.125 B/el) + statistics/sign-bit pass of 2*ul tensors of the unit two ahead (x + state in,
             # bits out: 4.125 B/el); the finalize group's traffic is negligible
-            ul = max(1, int(os.environ.get("CFX_PIPE_UNIT_LAYERS", "4")))
+            ul = max(1, int(os.environ.get("CFX_PIPE_UNIT_LAYERS", "7")))
             if use_dist and step_plans is not None:
-                Gq = max(1, min(4, args.gather_group))
+                Gq = max(1, min(7, args.gather_group))
                 ul = max(Gq, (ul // Gq) * Gq)                   # units are whole all-gather groups
-            ul = min(ul, 4, L)
+            ul = min(ul, 7, L)
             alg = (ALG_BYTES_PER_EL["decompress"] * 16 + 4.125 * 2) * ul * N * C
             kname = (f"k_binary_pipe (one launch = {ul} layers: dequant+add of {16 * ul} tensors x (544,3072) [own K,V error-feedback "
                      f"update + 7 peers' K,V per layer] + finalize of the next {ul} layers' K,V scales + stats/sign bits of the {ul} "

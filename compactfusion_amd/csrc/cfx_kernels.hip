@@ -334,7 +334,7 @@ __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, in
 #ifndef PIPE_US
 #define PIPE_US 2      // rows in flight per wave in the fused kernel's stats group (register budget of 8 waves / SIMD)
 #endif
-#define PIPE_MAX_DQ 64     // reconstruction items per fused launch (a "unit" of up to 4 layers x 16 tensors)
+#define PIPE_MAX_DQ 112    // reconstruction items per fused launch (a "unit" of up to 7 layers x 16 tensors; kernel arguments stay below 4 KB)
 struct BatchDX { cfx_decomp_item it[PIPE_MAX_DQ]; };
 struct PipeArgs {
     int N, C, CB;
@@ -1359,11 +1359,12 @@ int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) {
 //     k x compress [BINARY, no cache update]   { all-gather }*   k x decompress [BINARY]            (k >= 1, one shape)
 // i.e. layers whose packets travel in one collective (k = 1: what the ring gather schedule builds; bench.py groups
 // several layers per all-gather: fewer, larger collectives).  Consecutive whole groups are merged into UNITS of up to
-// 4 layers (as many as fit 64 reconstruction items and 16 compress items), and the range is replayed on ONE stream as
+// 7 layers (as many as fit 112 reconstruction items and 16 compress items: < 4 KB of kernel arguments), and the range is
+// replayed on ONE stream as
 // launch slots t = 0 .. U+1:
 //     { all-gathers of unit t-2 }  ;  K_t = [dequant(unit t-2) | finalize(unit t-1) | stats(unit t)]
 // where K_t is ONE k_binary_pipe launch: the latency-bound stats / finalize work of later layers runs underneath the
-// bandwidth-bound reconstruction of earlier ones, and a launch is long enough (4 layers = ~0.5 GB of traffic) to
+// bandwidth-bound reconstruction of earlier ones, and a launch is long enough (7 layers = ~0.9 GB of traffic) to
 // amortise its ramp and tail (measured on MI355X, FLUX step: 1.82 ms in order, 1.35 ms one layer per launch, see
 // DESIGN.md section 3 for the unit size; a two-stream version of the same idea loses to the ~10 us cross-stream event hops
 // and to the slowdown of the small kernels under contention).  Results are bit-identical to cfx_plan_run (same device
@@ -1437,7 +1438,7 @@ int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
     PipeUnit* units = new PipeUnit[cap];
     auto cleanup = [&]() { delete[] comp_op; delete[] deq_op; delete[] ag_op; delete[] ag_unit; delete[] units; };
     const char* ue = getenv("CFX_PIPE_UNIT_LAYERS");
-    int unit_layers = ue ? atoi(ue) : 4;
+    int unit_layers = ue ? atoi(ue) : 7;
     if (unit_layers < 1) unit_layers = 1;
     // ---- recognise the group pattern, merging whole groups into units -----------------------------------------------------
     int L = 0, n_ag = 0, N = 0, C = 0, U = 0;

@@ -171,8 +171,8 @@ int       cfx_plan_run(cfx_plan* plan, int first_op, int n_ops, void* stream);
 /* Software-pipelined replay (replaces the reference's strictly sequential quantise -> cat -> send -> dequantise per layer,
  * xfuser/compact/ring.py:188-260 with fastpath.py:124-228, 371-438).  If ops [first_op, first_op + n_ops) are a sequence of "groups"
  *     k x compress (BINARY, flags without UPDATE_CACHE)   { all-gather }*   k x decompress (BINARY)      of one shape,
- * (k >= 1 layers whose packets travel in one collective) consecutive groups are merged into units of up to 4 layers
- * (env CFX_PIPE_UNIT_LAYERS; at most 64 reconstruction and 16 compress items per unit) and replayed on `stream` as
+ * (k >= 1 layers whose packets travel in one collective) consecutive groups are merged into units of up to 7 layers
+ * (env CFX_PIPE_UNIT_LAYERS; at most 112 reconstruction and 16 compress items per unit) and replayed on `stream` as
  *     { all-gathers of unit t-2 } ; [dequant(unit t-2) | finalize(unit t-1) | stats(unit t)]          t = 0, 1, ...
  * with every bracket ONE fused launch, so the small statistics kernels of later layers run underneath the
  * reconstruction of earlier ones.  Results are bit-identical to cfx_plan_run; packet / state buffers must be distinct
