@@ -72,6 +72,8 @@ SYMBOLS = [
     ("cfx_plan_size", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_plan_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     ("cfx_plan_run_pipelined", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    ("cfx_residual2_delta", ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p]),
+    ("cfx_residual2_update", ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_copy_probe", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 ]
 

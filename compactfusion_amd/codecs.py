@@ -228,6 +228,35 @@ def decompress(codec: int, packet: torch.Tensor, base: Optional[torch.Tensor], N
     return recon
 
 
+def residual2_delta(x: torch.Tensor, base: torch.Tensor, delta_base: torch.Tensor, out: torch.Tensor,
+                    stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+    """out = (x - base) - delta_base (second-order residual, main.py:247), elementwise fp16."""
+    dev = _device_index(x)
+    n = x.numel()
+    for t, name in ((x, "x"), (base, "base"), (delta_base, "delta_base"), (out, "out")):
+        if t.dtype != torch.float16 or not t.is_contiguous() or t.numel() != n:
+            raise ValueError(f"{name}: expected contiguous fp16 with {n} elements")
+    ctx = context(dev)
+    rc = _lib.load().cfx_residual2_delta(ctx, _ptr(x), _ptr(base), _ptr(delta_base), _ptr(out), n, _stream_handle(stream, dev))
+    _check(ctx, rc, "cfx_residual2_delta")
+    return out
+
+
+def residual2_update(base: torch.Tensor, delta_base: torch.Tensor, recv: torch.Tensor, new_base: torch.Tensor,
+                     new_delta_base: torch.Tensor, decay: float, stream: Optional[torch.cuda.Stream] = None) -> None:
+    """new_base = (base + delta_base) + recv ; new_delta_base = (delta_base + recv) * decay (main.py:250-256, 272-273).
+    new_base / new_delta_base may be base / delta_base themselves (in-place state update)."""
+    dev = _device_index(base)
+    n = base.numel()
+    for t, name in ((base, "base"), (delta_base, "delta_base"), (recv, "recv"), (new_base, "new_base"), (new_delta_base, "new_delta_base")):
+        if t.dtype != torch.float16 or not t.is_contiguous() or t.numel() != n:
+            raise ValueError(f"{name}: expected contiguous fp16 with {n} elements")
+    ctx = context(dev)
+    rc = _lib.load().cfx_residual2_update(ctx, _ptr(base), _ptr(delta_base), _ptr(recv), _ptr(new_base), _ptr(new_delta_base),
+                                          float(decay), n, _stream_handle(stream, dev))
+    _check(ctx, rc, "cfx_residual2_update")
+
+
 def copy_probe(dst: torch.Tensor, src: torch.Tensor, stream: Optional[torch.cuda.Stream] = None) -> None:
     dev = _device_index(dst)
     ctx = context(dev)

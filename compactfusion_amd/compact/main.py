@@ -17,7 +17,7 @@ Semantics kept from the reference (file:line = xfuser/compact/main.py):
   WARMUP stores the activation as the new base and sends it raw (:195-209, :351-366); residual 0 compresses the
   activation itself (:214-226, :371-372); residual 1 compresses act - base and sets base <- base + decode(packet)
   when error feedback is on, base <- act otherwise (:227-243, :373-377); residual 2 adds the decayed second-order
-  predictor (:244-266, :378-384); `simulate` ships the dequantised tensor (:117-119, :126-127); the fastpath accepts
+  predictor (:244-266, :378-384; `cfx_residual2_delta` / `cfx_residual2_update` around the codec, states in place); `simulate` ships the dequantised tensor (:117-119, :126-127); the fastpath accepts
   only BINARY / INT2 (:131, :277).
 """
 from __future__ import annotations
@@ -299,18 +299,25 @@ def compact_compress(cache_key, x: torch.Tensor, compress_type: COMPACT_COMPRESS
                 _codec_decompress(cid, param, pkt, log_base, rec)
             _log(cache_key, log_base, None, x, rec, pkt)
         return pkt
-    # residual 2: second-order predictor; the predictor arithmetic is torch glue, the codec is native
+    # residual 2: second-order predictor - two native elementwise passes around the native codec, states updated in place
     dbase = cache.get_delta_base(cache_key)
-    pred = base + dbase
-    dd = x - base - dbase
+    assert dbase is not None, f"no second-order state for key {cache_key}: residual 2 needs two WARMUP steps"
+    dd = _buf(cache_key, "dd", N * C, x).view(N, C)
+    codecs.residual2_delta(x, base, dbase, dd)
     _codec_compress(cid, param, dd, None, None, pkt, update=False)
     if update_cache or cfg.log_compress_stats:
-        recv = torch.empty_like(x)
+        recv = _buf(cache_key, "recv", N * C, x).view(N, C)
         _codec_decompress(cid, param, pkt, None, recv)
-        new_base = pred + recv
-        if update_cache:
-            cache.put(cache_key, new_base, _decay(dbase + recv))
-        _log(cache_key, base, dbase, x, new_base, pkt)
+        if update_cache and not cfg.log_compress_stats:
+            codecs.residual2_update(base, dbase, recv, base, dbase, cfg.delta_decay_factor)     # in place on the arena
+            cache.put(cache_key, base, dbase)
+        else:
+            log_base, log_dbase = base.clone(), dbase.clone()
+            new_base, new_dbase = torch.empty_like(base), torch.empty_like(dbase)
+            codecs.residual2_update(base, dbase, recv, new_base, new_dbase, cfg.delta_decay_factor)
+            if update_cache:
+                cache.put(cache_key, new_base, new_dbase)
+            _log(cache_key, log_base, log_dbase, x, new_base, pkt)
     return pkt
 
 
@@ -379,12 +386,15 @@ def compact_decompress(cache_key, compressed: torch.Tensor, compress_type: COMPA
         _codec_decompress(cid, param, compressed, base, out)
         return out.view(original_shape)
     dbase = cache.get_delta_base(cache_key)
-    recv = torch.empty((N, C), dtype=torch.float16, device=compressed.device)
+    assert dbase is not None, f"no second-order state for key {cache_key}: residual 2 needs two WARMUP steps"
+    recv = _buf(cache_key, "recv", N * C, base).view(N, C)
     _codec_decompress(cid, param, compressed, None, recv)
-    rec = base + dbase + recv
     if update_cache:
-        cache.put(cache_key, rec, _decay(dbase + recv))
-        return cache.get_base(cache_key).view(original_shape)
+        codecs.residual2_update(base, dbase, recv, base, dbase, cfg.delta_decay_factor)         # in place on the arena
+        cache.put(cache_key, base, dbase)
+        return base.view(original_shape)
+    rec = torch.empty((N, C), dtype=torch.float16, device=compressed.device)
+    codecs.residual2_update(base, dbase, recv, rec, _buf(cache_key, "ndb", N * C, base).view(N, C), cfg.delta_decay_factor)
     return rec.view(original_shape)
 
 

@@ -905,6 +905,32 @@ __global__ __launch_bounds__(256) void k_topk_decompress(BatchD batch, size_t E)
     st8nt(out + e, base ? (bv + recv) : recv);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// second-order residual (residual = 2): the predictor arithmetic around the codec       main.py:244-266, 378-384
+//   k_residual2_delta :  dd = (x - base) - delta_base                       (what gets compressed)
+//   k_residual2_update:  new_base = (base + delta_base) + recv ; new_delta_base = fp16(fp32(fp16(delta_base + recv)) * decay)
+// one fp16 rounding per reference operation; in-place allowed (new_base == base, new_delta_base == delta_base)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_residual2_delta(const h16* __restrict__ x, const h16* base, const h16* dbase, h16* dd, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const h16x8 d = ld8nt(x + i * 8) - ld8(base + i * 8);
+    st8(dd + i * 8, d - ld8(dbase + i * 8));
+}
+__global__ __launch_bounds__(256) void k_residual2_update(const h16* base, const h16* dbase, const h16* __restrict__ recv, h16* nb, h16* ndb,
+                                                          float decay, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const h16x8 b = ld8(base + i * 8), d = ld8(dbase + i * 8), r = ld8nt(recv + i * 8);
+    const h16x8 pred = b + d;
+    const h16x8 s = d + r;
+    h16x8 nd;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) nd[k] = (h16)((float)s[k] * decay);
+    st8(nb + i * 8, pred + r);
+    st8(ndb + i * 8, nd);
+}
+
 __global__ __launch_bounds__(256) void k_copy_probe(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
@@ -1588,6 +1614,30 @@ int cfx_comm_all_gather(cfx_comm* c, const void* send, void* recv, size_t bytes_
     if (!c || !send || !recv) return CFX_ERR_NULL;
     const int r = g_rccl.AllGather(send, recv, bytes_per_rank, 1, c->comm, (hipStream_t)stream);
     return r == 0 ? CFX_OK : fail(c->ctx, CFX_ERR_LAUNCH, "ncclAllGather failed");
+}
+
+int cfx_residual2_delta(cfx_ctx* ctx, const void* x, const void* base, const void* delta_base, void* dd, size_t n, void* stream) {
+    if (!ctx || !x || !base || !delta_base || !dd) return fail(ctx, CFX_ERR_NULL, "residual2_delta: null pointer");
+    if (n == 0 || (n & 7)) return fail(ctx, CFX_ERR_SHAPE, "residual2_delta: element count must be a positive multiple of 8");
+    if (!AL16(x) || !AL16(base) || !AL16(delta_base) || !AL16(dd)) return fail(ctx, CFX_ERR_ALIGN, "residual2_delta: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n8 = n / 8;
+    LAUNCH(ctx, KID_RES2_DELTA, s, k_residual2_delta, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, (const h16*)x, (const h16*)base,
+           (const h16*)delta_base, (h16*)dd, n8);
+    return check_launch(ctx, "residual2_delta launch");
+}
+
+int cfx_residual2_update(cfx_ctx* ctx, const void* base, const void* delta_base, const void* recv, void* new_base, void* new_delta_base,
+                         float decay, size_t n, void* stream) {
+    if (!ctx || !base || !delta_base || !recv || !new_base || !new_delta_base) return fail(ctx, CFX_ERR_NULL, "residual2_update: null pointer");
+    if (n == 0 || (n & 7)) return fail(ctx, CFX_ERR_SHAPE, "residual2_update: element count must be a positive multiple of 8");
+    if (!AL16(base) || !AL16(delta_base) || !AL16(recv) || !AL16(new_base) || !AL16(new_delta_base))
+        return fail(ctx, CFX_ERR_ALIGN, "residual2_update: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n8 = n / 8;
+    LAUNCH(ctx, KID_RES2_UPDATE, s, k_residual2_update, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, (const h16*)base,
+           (const h16*)delta_base, (const h16*)recv, (h16*)new_base, (h16*)new_delta_base, decay, n8);
+    return check_launch(ctx, "residual2_update launch");
 }
 
 int cfx_copy_probe(cfx_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {

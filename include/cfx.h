@@ -138,7 +138,8 @@ int    cfx_lr_decompress_batch(cfx_ctx* ctx, int quantized, int N, int C, int ra
  * 6 int2_dequant, 7 minmax_stats, 8 minmax_finalize, 9 int8_quant, 10 int8_dequant, 11 int4_quant,
  * 12 int4_dequant, 13 topk_compress, 14 topk_decompress, 15 copy_probe, 16 binary_dequant launched as the
  * sender's error-feedback update, 17-22 low-rank chain (prep, aq, aty, chol, apply, decode), 23 binary_pipe (steady-state
- * fused launch of cfx_plan_run_pipelined), 24 binary_pipe prologue / epilogue / ragged-unit launches. */
+ * fused launch of cfx_plan_run_pipelined), 24 binary_pipe prologue / epilogue / ragged-unit launches, 25 residual2_delta,
+ * 26 residual2_update. */
 int         cfx_profile_enable(cfx_ctx* ctx, int capacity, unsigned kernel_mask, int stride);
 int         cfx_profile_read(cfx_ctx* ctx, int* kernel_ids, float* ms, int cap);
 const char* cfx_kernel_name(int kernel_id);
@@ -189,6 +190,16 @@ int       cfx_comm_unique_id(cfx_ctx* ctx, void* out128);
 cfx_comm* cfx_comm_create(cfx_ctx* ctx, const void* id128, int nranks, int rank);
 void      cfx_comm_destroy(cfx_comm* comm);
 int       cfx_comm_all_gather(cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+
+/* Second-order residual (CompactConfig(residual=2), xfuser/compact/main.py:244-266 compress, :378-384 decompress): the
+ * predictor arithmetic around any codec, n fp16 elements (multiple of 8), one fp16 rounding per reference operation.
+ *   cfx_residual2_delta :  dd = (x - base) - delta_base                        -> compress dd with base = NULL
+ *   cfx_residual2_update:  new_base = (base + delta_base) + recv ; new_delta_base = fp16(fp32(fp16(delta_base + recv)) * decay)
+ * (recv = decode(packet) with base = NULL; decay = CompactConfig.delta_decay_factor, main.py:272-273).  new_base may alias
+ * base and new_delta_base may alias delta_base. */
+int cfx_residual2_delta(cfx_ctx* ctx, const void* x, const void* base, const void* delta_base, void* dd, size_t n, void* stream);
+int cfx_residual2_update(cfx_ctx* ctx, const void* base, const void* delta_base, const void* recv, void* new_base,
+                         void* new_delta_base, float decay, size_t n, void* stream);
 
 /* Bandwidth probe: dst[i] = src[i] over `bytes` (multiple of 16) - the achievable-HBM reference
  * against which bench.py reports roofline fractions. */

@@ -594,6 +594,23 @@ def slowpath_decompress_binary(packet, N, C):
 # --------------------------------------------------------------------------------------
 # state machine (main.py:169-270, :322-388) over a dict cache (utils.py:123-162)
 # --------------------------------------------------------------------------------------
+def residual2_delta(x, base, dbase):
+    """Second-order residual dd = (x - base) - delta_base, one fp16 rounding per operation (main.py:247)."""
+    with np.errstate(invalid="ignore", over="ignore"):
+        return ((np.asarray(x, F16) - np.asarray(base, F16)).astype(F16) - np.asarray(dbase, F16)).astype(F16)
+
+
+def residual2_update(base, dbase, recv, decay):
+    """(new_base, new_delta_base) of main.py:250-256 / :381-384: new_base = (base + delta_base) + recv and
+    new_delta_base = fp16(fp32(fp16(delta_base + recv)) * fp32(decay)) - torch multiplies a half tensor by a Python scalar
+    in fp32 (main.py:272-273)."""
+    with np.errstate(invalid="ignore", over="ignore"):
+        b, d, r = np.asarray(base, F16), np.asarray(dbase, F16), np.asarray(recv, F16)
+        nb = ((b + d).astype(F16) + r).astype(F16)
+        nd = ((d + r).astype(F16).astype(np.float32) * np.float32(decay)).astype(F16)
+    return nb, nd
+
+
 class OracleCompact:
     """Minimal restatement of compact_compress / compact_decompress with module-global state folded
     into an object.  `codec` strings: 'warmup' | 'binary' | 'int2' | 'int4' | 'int8' | 'topk'.
@@ -659,7 +676,7 @@ class OracleCompact:
             pkt, recv = self._comp(codec, dd)
             if update_cache:
                 self.base[key] = ((base + db).astype(F16) + recv).astype(F16)
-                self.dbase[key] = ((db + recv).astype(F16) * F16(self.decay)).astype(F16)
+                self.dbase[key] = residual2_update(base, db, recv, self.decay)[1]
         return pkt
 
     def decompress(self, key, pkt, codec, shape, update_cache=True):
@@ -695,5 +712,5 @@ class OracleCompact:
             rec = ((base + db).astype(F16) + recv).astype(F16)
             if update_cache:
                 self.base[key] = rec
-                self.dbase[key] = ((db + recv).astype(F16) * F16(self.decay)).astype(F16)
+                self.dbase[key] = residual2_update(base, db, recv, self.decay)[1]
         return rec.reshape(shape)

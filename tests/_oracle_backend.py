@@ -102,10 +102,25 @@ def prepare_decompress(codec, packets, bases, recons, N, C, param=0):
     return run
 
 
+def residual2_delta(x, base, delta_base, out, stream=None):
+    out.view(torch.int16).numpy().view(np.uint16).reshape(-1)[:] = R.bits(R.residual2_delta(
+        _np16(x).view(np.float16).reshape(-1), _np16(base).view(np.float16).reshape(-1), _np16(delta_base).view(np.float16).reshape(-1)))
+    return out
+
+
+def residual2_update(base, delta_base, recv, new_base, new_delta_base, decay, stream=None):
+    nb, nd = R.residual2_update(_np16(base).view(np.float16).reshape(-1).copy(), _np16(delta_base).view(np.float16).reshape(-1).copy(),
+                                _np16(recv).view(np.float16).reshape(-1).copy(), decay)
+    new_base.view(torch.int16).numpy().view(np.uint16).reshape(-1)[:] = R.bits(nb)
+    new_delta_base.view(torch.int16).numpy().view(np.uint16).reshape(-1)[:] = R.bits(nd)
+
+
 def install(monkeypatch):
     from compactfusion_amd import codecs
     monkeypatch.setattr(codecs, "compress_batch", compress_batch)
     monkeypatch.setattr(codecs, "decompress_batch", decompress_batch)
+    monkeypatch.setattr(codecs, "residual2_delta", residual2_delta)
+    monkeypatch.setattr(codecs, "residual2_update", residual2_update)
     monkeypatch.setattr(codecs, "prepare_compress", prepare_compress)
     monkeypatch.setattr(codecs, "prepare_decompress", prepare_decompress)
     monkeypatch.setattr(codecs, "lr_compress_batch", lr_compress_batch)
@@ -117,6 +132,8 @@ def install_plain():
     from compactfusion_amd import codecs
     codecs.compress_batch = compress_batch
     codecs.decompress_batch = decompress_batch
+    codecs.residual2_delta = residual2_delta
+    codecs.residual2_update = residual2_update
     codecs.prepare_compress = prepare_compress
     codecs.prepare_decompress = prepare_decompress
     codecs.lr_compress_batch = lr_compress_batch

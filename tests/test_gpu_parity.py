@@ -293,6 +293,35 @@ def test_baseline_config_sizes_vs_c_oracle(name, cid, param, shape):
     same_bits(host_bits(rec_g), rec_c, f"{name} {shape}: receiver")
 
 
+@pytest.mark.parametrize("decay", [0.5, 0.3, 1.0])
+@pytest.mark.parametrize("shape", [(64, 256), (130, 1024), (544, 3072)])
+def test_residual2_kernels_vs_oracle(shape, decay):
+    """cfx_residual2_delta / cfx_residual2_update (second-order residual, main.py:244-266) bit for bit against the oracle,
+    out of place and in place; decay 0.3 is not an fp16 number (torch multiplies by the fp32 scalar)."""
+    from compactfusion_amd import codecs as K
+    N, C = shape
+    rng = np.random.default_rng(N + int(decay * 10))
+    x = rng.standard_normal((N, C)).astype(F16)
+    base = (x.astype(np.float32) + 0.1 * rng.standard_normal((N, C)).astype(np.float32)).astype(F16)
+    dbase = (0.05 * rng.standard_normal((N, C))).astype(F16)
+    recv = (0.05 * rng.standard_normal((N, C))).astype(F16)
+    dd = torch.empty(N, C, dtype=torch.float16, device="cuda")
+    K.residual2_delta(dev(x), dev(base), dev(dbase), dd)
+    same_bits(host_bits(dd), R.bits(R.residual2_delta(x, base, dbase)), "residual2 delta")
+    want_nb, want_nd = R.residual2_update(base, dbase, recv, decay)
+    nb, nd = torch.empty_like(dd), torch.empty_like(dd)
+    K.residual2_update(dev(base), dev(dbase), dev(recv), nb, nd, decay)
+    same_bits(host_bits(nb), R.bits(want_nb), "residual2 new_base")
+    same_bits(host_bits(nd), R.bits(want_nd), "residual2 new_delta_base")
+    b_, d_ = dev(base), dev(dbase)
+    K.residual2_update(b_, d_, dev(recv), b_, d_, decay)                 # in place
+    torch.cuda.synchronize()
+    same_bits(host_bits(b_), R.bits(want_nb), "residual2 new_base (in place)")
+    same_bits(host_bits(d_), R.bits(want_nd), "residual2 new_delta_base (in place)")
+    with pytest.raises(ValueError):
+        K.residual2_delta(dev(x)[:, :C // 2].contiguous(), dev(base), dev(dbase), dd)
+
+
 def test_error_codes():
     from compactfusion_amd import codecs as K
     from compactfusion_amd._lib import CfxError
