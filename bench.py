@@ -8,8 +8,8 @@ Workload (BASELINE.json configs[2], SURVEY.md §8d "Config 3"): one denoise step
 ring-attention sequence parallelism of logical degree 8 with the 1-bit residual codec, as seen by ONE rank:
 57 attention layers x {K, V}, shard (N, C) = (544, 3072) fp16.  Per layer the rank
   1. compresses its own K and V against its error-feedback state (one batched launch sequence),
-  2. exchanges packets (N live ranks all-gather over RCCL on a side stream; the 8-N missing logical peers are
-     looped back from the rank's own packet, so the per-GPU codec work is IDENTICAL for every N = weak scaling;
+  2. exchanges packets (N live ranks all-gather over RCCL, --gather-group layers per collective, issued natively on an
+     exchange stream underneath the next fused launch; the 8-N missing logical peers are looped back from the rank's own packet, so the per-GPU codec work is IDENTICAL for every N = weak scaling;
      at N = 8 this is exactly the real exchange, at N = 1 it is the codec path alone),
   3. applies 16 packets in ONE batched dequant+add launch: its own K,V packets onto its own state (the error-feedback
      update of step 1, deferred into this launch) and the 7 peers' K,V onto their state arenas.
@@ -18,11 +18,12 @@ Infinity Cache, so every step streams from HBM (cold numbers).
 
 value = whole-job fp16 activation bytes compressed + reconstructed per second (GB/s), i.e.
         n_gpus * 57 * (2 + 14) * 544*3072*2 B / step time.
-Replay (--replay): `pipelined` (default) = cfx_plan_run_pipelined: per layer ONE fused launch k_binary_pipe =
+Replay (--replay): `pipelined` (default) = cfx_plan_run_pipelined: per UNIT of layers ONE fused launch k_binary_pipe =
         [dequant+add of unit u's 16 tensors per layer | finalize of unit u+1's scales | stats + sign bits of unit u+2's K,V],
         a unit = 7 consecutive layers, so the small latency-bound compress kernels ride underneath the bandwidth-bound
         reconstruction and a launch is long enough to amortise its ramp and tail; `inorder` = cfx_plan_run,
-        stats -> finalize -> dequant one after the other.  Same results bit for bit (tests/test_gpu_api.py).
+        stats -> finalize -> dequant one after the other.  Same results bit for bit (tests/test_gpu_api.py).  The pipelined
+        replay reorders work across layers (legal with resident synthetic inputs); the JSON also carries the in-order time.
 roofline = the dominant kernel: k_binary_pipe (pipelined; algorithmic bytes 4.125 B/element x (16 + 2) tensors of
         544*3072 elements per layer, 7 layers per launch) or k_binary_dequant (inorder; 4.125 B/element x 16 tensors) / average
         launch duration from hipEvents attached to the dispatch on the launch stream inside the timed region (native
