@@ -547,6 +547,26 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         except Exception as e:  # pragma: no cover
             out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        if not use_dist:
+            # the oracle as the checker of what was just timed: replay every step this process ran (warm-up + timed +
+            # in-order) for two tensors on the host and compare the error-feedback states bit for bit - fails loudly
+            from oracle import c_oracle as CO
+            import numpy as np
+            steps_run = args.warmup + args.steps + (args.steps if inorder_ms is not None else 0)
+            x0_host = warm_state(rank)[1]
+            checked = []
+            for l, kv in ((0, 0), (L - 1, 1)):
+                state = x0_host[l, kv].cpu().numpy().view(np.uint16).copy()
+                pk = np.zeros(pkt_bytes // 2, dtype=np.uint16)
+                ins = [xs[s][l, kv].cpu().numpy() for s in range(2)]
+                for t in range(steps_run):
+                    CO.compress("binary", ins[t & 1], state, N, C, packet=pk, new_base=state)
+                for name, got in (("sender state", own_base[l, kv]), ("looped-back peer state", peer_base[l, W_LOGICAL - 2, kv])):
+                    if not np.array_equal(got.cpu().numpy().view(np.uint16), state):
+                        raise RuntimeError(f"parity spot check failed: layer {l} {'KV'[kv]} {name} differs from the C oracle after {steps_run} steps")
+                checked.append(f"layer {l} {'KV'[kv]}")
+            out["cpu_baseline"]["parity_spot_check"] = (f"error-feedback states of {', '.join(checked)} (sender and a looped-back peer) after all "
+                                                       f"{steps_run} steps of this run == C oracle replay, bit for bit")
     # tear the communicators down first and flush C stdio (RCCL prints a version banner through its own stdio buffer),
     # so that the JSON line is the LAST thing on stdout
     if native_comm is not None:
