@@ -224,43 +224,62 @@ __device__ __forceinline__ void absmean_finalize_body(const cfx_comp_item& it, i
     h16* V = U + N;
     const int tid = threadIdx.x;
     if (bx == 0) {
-        // rows: one thread per row (all CB partial loads independent), exact sum of the fp16 row means, then divide
-        u64* red = smem;
+        // rows: one thread per row (all CB partial loads independent); the row sums of a thread's first KEEP rows stay in
+        // registers for the second pass (N <= KEEP * NT: no reload at all); exact sum of the fp16 row means: wave shuffles,
+        // then one LDS round over the NT / 64 waves
+        constexpr int KEEP = 3;
+        u64 srow[KEEP];
         u64 acc = 0;
-        for (int n = tid; n < N; n += NT) {
+        int it_n = 0;
+        for (int n = tid; n < N; n += NT, ++it_n) {
             u64 s = 0;
 #pragma unroll 8
             for (int k = 0; k < CB; ++k) s += rowpart[(size_t)n * CB + k];
+#pragma unroll
+            for (int q = 0; q < KEEP; ++q)
+                if (it_n == q) srow[q] = s;
             acc += habs_units(hbits(mean16(s, C)));
         }
-        red[tid] = acc;
+        acc = wave_sum_u64(acc);
+        if ((tid & 63) == 0) smem[tid >> 6] = acc;
         __syncthreads();
-        for (int o = NT / 2; o > 0; o >>= 1) {
-            if (tid < o) red[tid] += red[tid + o];
-            __syncthreads();
+        if (tid == 0) {
+            u64 tot = 0;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) tot += smem[w];
+            smem[NT] = hbits(mean16(tot, N));
         }
-        if (tid == 0) smem[NT] = hbits(mean16(red[0], N));
         __syncthreads();
         const h16 mu = hfrom((u16)smem[NT]);
         const float den = eps_mode ? (float)(h16)((float)mu + 1e-6f) : (float)mu;
-        for (int n = tid; n < N; n += NT) {
+        it_n = 0;
+        for (int n = tid; n < N; n += NT, ++it_n) {
             u64 s = 0;
+            if (it_n < KEEP) {
+#pragma unroll
+                for (int q = 0; q < KEEP; ++q)
+                    if (it_n == q) s = srow[q];
+            } else {
 #pragma unroll 8
-            for (int k = 0; k < CB; ++k) s += rowpart[(size_t)n * CB + k];
+                for (int k = 0; k < CB; ++k) s += rowpart[(size_t)n * CB + k];
+            }
             U[n] = (h16)((float)mean16(s, C) / den);
         }
     } else {
-        // columns: NT/4 columns per block, 4 threads per column split the P partials (loads in flight together)
+        // columns: NT/4 columns per block, 4 threads per column split the P partials; two accumulators and a deep unroll keep
+        // all of a thread's loads in flight together
         constexpr int COLS = NT / 4;
         u64* cs = smem;                       // [4][COLS]
         const int cl = tid % COLS, q = tid / COLS;
         const int c = (bx - 1) * COLS + cl;
-        u64 s = 0;
+        u64 s0 = 0, s1 = 0;
         if (c < C) {
-#pragma unroll 4
-            for (int p = q; p < P; p += 4) s += colpart[(size_t)p * C + c];
+            int p = q;
+#pragma unroll 6
+            for (; p + 4 < P; p += 8) { s0 += colpart[(size_t)p * C + c]; s1 += colpart[(size_t)(p + 4) * C + c]; }
+            if (p < P) s0 += colpart[(size_t)p * C + c];
         }
-        cs[q * COLS + cl] = s;
+        cs[q * COLS + cl] = s0 + s1;
         __syncthreads();
         if (q == 0 && c < C) V[c] = mean16(cs[cl] + cs[COLS + cl] + cs[2 * COLS + cl] + cs[3 * COLS + cl], N);
     }
