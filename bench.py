@@ -6,28 +6,30 @@ GPU with torch.distributed.run.  Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json configs[2], SURVEY.md §8d "Config 3"): one denoise step of FLUX.1-dev 1024^2 under
 ring-attention sequence parallelism of logical degree 8 with the 1-bit residual codec, as seen by ONE rank:
-57 attention layers x {K, V}, shard (N, C) = (544, 3072) fp16.  Per layer the rank
-  1. compresses its own K and V against its error-feedback state (one batched launch sequence),
-  2. exchanges packets (N live ranks all-gather over RCCL, --gather-group layers per collective, issued natively on an
-     exchange stream underneath the next fused launch; the 8-N missing logical peers are looped back from the rank's own packet, so the per-GPU codec work is IDENTICAL for every N = weak scaling;
-     at N = 8 this is exactly the real exchange, at N = 1 it is the codec path alone),
-  3. applies 16 packets in ONE batched dequant+add launch: its own K,V packets onto its own state (the error-feedback
-     update of step 1, deferred into this launch) and the 7 peers' K,V onto their state arenas.
+57 attention layers x {K, V}, shard (N, C) = (544, 3072) fp16.  The step is replayed LAYER BY LAYER IN ORDER, the way a
+model runs it (layer l+1's K,V only exist after layer l's attention, reference xfuser/compact/ring.py:188-206): per layer
+  A. ONE launch compresses the rank's K and V against its error-feedback state: statistics + sign bits + in-launch
+     finalize of the scales (k_absmean_compress); the PREVIOUS layer's own error-feedback update (own packets applied to own
+     state) rides in the same launch - nothing reads that state before the next denoise step (the local attention block uses
+     the uncompressed K,V, ring.py:207-209), and it is bandwidth work that fills the reduction's latency,
+  X. exchanges the packets (N live ranks all-gather over RCCL, one collective per layer, issued natively in order; the 8-N
+     missing logical peers are looped back from the rank's own packet, so the per-GPU codec work is IDENTICAL for every
+     N = weak scaling; at N = 8 this is exactly the real exchange, at N = 1 it is the codec path alone),
+  B. ONE launch reconstructs the 7 peers' K,V (14 tensors, k_binary_dequant) onto their state arenas (the last layer's
+     launch also carries that layer's own error-feedback update).
+Launch B(l) cannot start before A(l) has finished and A(l+1) not before B(l): nothing is reordered across layers.
 Inputs are synthetic and already resident in HBM; the state arenas (3.0 GB) + inputs (0.76 GB) dwarf the 256 MB
 Infinity Cache, so every step streams from HBM (cold numbers).
 
 value = whole-job fp16 activation bytes compressed + reconstructed per second (GB/s), i.e.
-        n_gpus * 57 * (2 + 14) * 544*3072*2 B / step time.
-Replay (--replay): `pipelined` (default) = cfx_plan_run_pipelined: per UNIT of layers ONE fused launch k_binary_pipe =
-        [dequant+add of unit u's 16 tensors per layer | finalize of unit u+1's scales | stats + sign bits of unit u+2's K,V],
-        a unit = 7 consecutive layers, so the small latency-bound compress kernels ride underneath the bandwidth-bound
-        reconstruction and a launch is long enough to amortise its ramp and tail; `inorder` = cfx_plan_run,
-        stats -> finalize -> dequant one after the other.  Same results bit for bit (tests/test_gpu_api.py).  The pipelined
-        replay reorders work across layers (legal with resident synthetic inputs); the JSON also carries the in-order time.
-roofline = the dominant kernel: k_binary_pipe (pipelined; algorithmic bytes 4.125 B/element x (16 + 2) tensors of
-        544*3072 elements per layer, 7 layers per launch) or k_binary_dequant (inorder; 4.125 B/element x 16 tensors) / average
-        launch duration from hipEvents attached to the dispatch on the launch stream inside the timed region (native
-        hooks in libcfx.so).
+        n_gpus * 57 * (2 + 14) * 544*3072*2 B / step time, from the in-order replay.
+`pure_exchange_upper_bound` = the same step through cfx_plan_run_pipelined, which DOES reorder across layers (statistics of
+        layers j+7.. beside the reconstruction of layers j..): only legal because the synthetic inputs of all layers are resident;
+        a model cannot run it.  Reported as a secondary figure, never as `value`.
+roofline = the dominant kernel of the in-order step, k_binary_dequant: algorithmic bytes 4.125 B/element x the
+        tensors of a launch / average launch duration from hipEvents attached to the dispatch on the launch stream inside
+        the timed region; `roofline.step` prices the WHOLE step (every launch, edge layers included) with 6.125 B/element
+        for the rank's own tensors (compress + error feedback) and 4.125 for the peers'.
 cpu_baseline = the C oracle (oracle/cfx_oracle.c, OpenMP) timed on this box's host cores on one layer of the same
         workload; reported baseline only.
 """
@@ -55,32 +57,38 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--layers", type=int, default=L_LAYERS, help="debug only; the judged workload uses 57")
     ap.add_argument("--rows", type=int, default=0, help="rows per tile override (0 = auto)")
-    ap.add_argument("--replay", choices=["inorder", "pipelined"], default="pipelined",
-                    help="pipelined (default): cfx_plan_run_pipelined - one fused launch per layer, the statistics / finalize "
-                         "work of the next two layers rides underneath the reconstruction of the current one; "
-                         "inorder: cfx_plan_run, three launches per layer one after the other (same results, bit for bit)")
+    ap.add_argument("--replay", choices=["inorder", "pipelined"], default="inorder",
+                    help="inorder (default, the deployable schedule): cfx_plan_run, two launches per layer one after the other; "
+                         "pipelined: cfx_plan_run_pipelined, reorders work ACROSS layers (resident synthetic inputs only)")
+    ap.add_argument("--own-ef", choices=["ride", "inline"], default="ride",
+                    help="inorder replay: the rank's own error-feedback update rides in the NEXT layer's compress launch (ride) or "
+                         "sits in the same layer's reconstruction launch (inline: 16 tensors per launch)")
     ap.add_argument("--exchange-stream", choices=["main", "side", "prio"], default="prio",
-                    help="N > 1, native exchange: 'main' issues every all-gather in order on the compute stream; 'side' / 'prio' "
+                    help="N > 1, pipelined replay only: 'main' issues every all-gather in order on the compute stream; 'side' / 'prio' "
                          "(prioritised stream) issue it on an exchange stream one unit ahead, underneath the next fused launch")
-    ap.add_argument("--gather-group", type=int, default=7,
-                    help="N > 1, native exchange: layers (1..7) whose packets travel in ONE all-gather (fewer, larger collectives; "
-                         "a group is replayed as one unit of the pipelined schedule)")
+    ap.add_argument("--gather-group", type=int, default=0,
+                    help="N > 1, native exchange: layers (1..7) whose packets travel in ONE all-gather; 0 = 1 for the in-order replay "
+                         "(a model has one layer's packets at a time), 7 for the pipelined replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the long run and the pipelined upper-bound leg")
+    ap.add_argument("--long-steps", type=int, default=200, help="steps of the long timed leg that follows the contract's K steps")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="debug: 'gloo' lets several ranks share one GPU to exercise the N>1 path")
     ap.add_argument("--same-gpu", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--dist-path", action="store_true",
                     help="debug: take the N>1 code path (per-layer collectives) even with one rank, to measure its host overhead")
-    ap.add_argument("--exchange", choices=["auto", "native", "torch"], default="auto",
+    ap.add_argument("--exchange", choices=["native", "torch"], default="native",
                     help="N>1: who issues the per-layer all-gather - libcfx's own RCCL communicator from the native plan "
-                         "(one host call per step) or torch.distributed (one Python call per layer); auto = native, "
-                         "falling back to torch if the communicator cannot be created")
+                         "(one host call per step) or torch.distributed (one Python call per layer)")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N>1: if the native exchange cannot be created or fails validation, fall back to torch.distributed "
+                         "instead of exiting non-zero")
     ap.add_argument("--copy-probe", type=int, default=0,
                     help="also launch the 96 MiB float4 copy probe this many times before the timed region "
                          "(known byte count: calibrates FETCH_SIZE / WRITE_SIZE in PMC profiles)")
-    ap.add_argument("--event-stride", type=int, default=4,
-                    help="bracket every k-th launch of the dominant kernel with hipEvents (an event pair costs a few us of stream time)")
+    ap.add_argument("--event-stride", type=int, default=8,
+                    help="bracket every k-th launch of the profiled kernels with hipEvents (an event pair costs a few us of stream time)")
     return ap.parse_args()
 
 
@@ -164,6 +172,9 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     live = world                       # live ranks in the logical ring of 8
     assert live <= W_LOGICAL
+    pipelined = args.replay == "pipelined"
+    G = args.gather_group if args.gather_group > 0 else (7 if pipelined else 1)
+    G = max(1, min(7, G))
 
     from compactfusion_amd import _lib, codecs as K
     lib = _lib.load()
@@ -200,124 +211,134 @@ def main():
     send = torch.zeros(L, 2, slot, dtype=torch.uint8, device=dev)           # own packets (K,V) per layer
     use_dist = live > 1 or args.dist_path
     recv = torch.zeros(L, live, 2, slot, dtype=torch.uint8, device=dev) if use_dist else None
+    grecv = torch.zeros(L * live * 2 * slot, dtype=torch.uint8, device=dev) if use_dist else None   # grouped receive regions
     ws_bytes = lib.cfx_workspace_bytes(CODEC, N, C, 0, 2)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
 
-    # ---- native plans (one per input set): per layer op 2l = compress K,V ; op 2l+1 = one dequant+add launch over 16
-    #      tensors = the sender's own error-feedback update (its K,V packets applied to its own state, which is exactly
-    #      what compact_compress(update_cache=True) does, fastpath.py:88-120) + the 7 peers' K,V ---------------------------
-    plans = []
-    for s in range(2):
-        plan = lib.cfx_plan_create(ctx)
-        for l in range(L):
-            carr = (_lib.CompItem * 2)()
-            for kv in range(2):
-                carr[kv] = _lib.CompItem(xs[s][l, kv].data_ptr(), own_base[l, kv].data_ptr(), None, send[l, kv].data_ptr())
-            rc = lib.cfx_plan_add_compress(plan, CODEC, N, C, 0, 0, 2, carr, ws.data_ptr(), ws_bytes)
-            assert rc == 2 * l, (rc, lib.cfx_last_error_string(ctx))
-            darr = (_lib.DecompItem * 16)()
-            for kv in range(2):
-                darr[kv] = _lib.DecompItem(send[l, kv].data_ptr(), own_base[l, kv].data_ptr(), own_base[l, kv].data_ptr())
-            i = 2
-            for p in range(W_LOGICAL - 1):
-                # logical peer p: the first live-1 are real ranks (packets from the all-gather), the rest loop back our own packet
-                for kv in range(2):
-                    if live > 1 and p < live - 1:
-                        pk_ptr = recv[l, (rank + 1 + p) % live, kv].data_ptr()
-                    else:
-                        pk_ptr = send[l, kv].data_ptr()
-                    darr[i] = _lib.DecompItem(pk_ptr, peer_base[l, p, kv].data_ptr(), peer_base[l, p, kv].data_ptr())
-                    i += 1
-            rc = lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, 16, darr)
-            assert rc == 2 * l + 1, (rc, lib.cfx_last_error_string(ctx))
-        plans.append(plan)
+    def peer_packet_ptr(l, p, kv, gathered):
+        """Packet of logical peer p for layer l: a real rank's slot of the gathered buffer, or (looped-back peer) our own packet
+        - taken from OUR slot of the gathered buffer when there is one, so a collective's result is consumed even with one live rank."""
+        if gathered:
+            r = (rank + 1 + p) % live if (live > 1 and p < live - 1) else rank
+            return grecv.data_ptr() + group_recv_offset(l, r, kv, G, L, live, slot)
+        if live > 1 and p < live - 1:
+            return recv[l, (rank + 1 + p) % live, kv].data_ptr()
+        return send[l, kv].data_ptr()
+
+    def comp_items(s_, l):
+        carr = (_lib.CompItem * 2)()
+        for kv in range(2):
+            carr[kv] = _lib.CompItem(xs[s_][l, kv].data_ptr(), own_base[l, kv].data_ptr(), None, send[l, kv].data_ptr())
+        return carr
+
+    def own_ef_items(l):
+        return [_lib.DecompItem(send[l, kv].data_ptr(), own_base[l, kv].data_ptr(), own_base[l, kv].data_ptr()) for kv in range(2)]
+
+    def peer_items(l, gathered):
+        return [_lib.DecompItem(peer_packet_ptr(l, p, kv, gathered), peer_base[l, p, kv].data_ptr(), peer_base[l, p, kv].data_ptr())
+                for p in range(W_LOGICAL - 1) for kv in range(2)]
+
+    def add_layer(plan, s_, l, ride, gathered, comm=None):
+        """Layer l of the in-order schedule: A = compress (+ previous layer's own EF riding along), X = all-gather, B = reconstruct."""
+        if ride and l > 0:
+            rd = (_lib.DecompItem * 2)(*own_ef_items(l - 1))
+            rc = lib.cfx_plan_add_compress_ex(plan, CODEC, N, C, 0, 0, 2, comp_items(s_, l), 2, rd, ws.data_ptr(), ws_bytes)
+        else:
+            rc = lib.cfx_plan_add_compress(plan, CODEC, N, C, 0, 0, 2, comp_items(s_, l), ws.data_ptr(), ws_bytes)
+        assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
+        if comm is not None:
+            rc = lib.cfx_plan_add_all_gather(plan, comm, send[l].data_ptr(), grecv.data_ptr() + l * live * 2 * slot, 2 * slot)
+            assert rc >= 0, rc
+        items = peer_items(l, gathered)
+        if not ride or l == L - 1:
+            items = own_ef_items(l) + items
+        darr = (_lib.DecompItem * len(items))(*items)
+        rc = lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, len(items), darr)
+        assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
+
+    ride = args.own_ef == "ride"
+    # ---- native plans without collectives (one per input set) -----------------------------------------------------------------
+    #   inorder:   per layer  A(l) [+ EF(l-1)] ; B(l)                        (ops 2l, 2l+1)
+    #   pipelined: per layer  compress(l) ; reconstruct own + peers (16)     (the op pattern cfx_plan_run_pipelined recognises)
+    def build_plans(kind):
+        built = []
+        for s_ in range(2):
+            plan = lib.cfx_plan_create(ctx)
+            for l in range(L):
+                add_layer(plan, s_, l, ride if kind == "inorder" else False, False)
+            built.append(plan)
+        return built
+    plans_inorder = build_plans("inorder")
+    plans_pipe = build_plans("pipelined")
+    plans = plans_pipe if pipelined else plans_inorder
 
     compute = torch.cuda.current_stream(dev)
     sh = compute.cuda_stream
 
-    # ---- N > 1: the whole step as ONE native plan, the all-gathers issued by libcfx's own RCCL communicator.
-    #      --gather-group layers share one all-gather (fewer, larger collectives) and form one unit of the pipelined replay;
-    #      --exchange-stream prio|side runs the collective of unit u on an exchange stream underneath the fused launch that
-    #      follows finalize(u) (one extra unit of look-ahead; the ~10 us cross-stream event hops hide behind an 80 us launch),
-    #      'main' keeps everything in order on one stream. ----
+    # ---- N > 1: the whole step as ONE native plan, the all-gathers issued by libcfx's own RCCL communicator -----------------
+    #   inorder:   A(l) ; all-gather(l) ; B(l)   layer by layer, everything in order on the compute stream
+    #   pipelined: --gather-group layers share one all-gather and form one unit of the pipelined replay; --exchange-stream
+    #              prio|side runs the collective of unit u on an exchange stream underneath the next fused launch
     native_comm, step_plans, exchange_mode, stream_mode, build_step_plans = None, None, "none", 0, None
     if use_dist:
         exchange_mode = "torch"
-        if args.exchange in ("auto", "native"):
+        if args.exchange == "native":
             try:
                 from compactfusion_amd.exchange import NativeComm
                 native_comm = NativeComm(local_rank)
                 native_comm.self_test()
-                # grouped exchange buffers: group g = layers [gG, gG + nl); ONE all-gather moves the group's K,V packets of
-                # every rank: send = send[gG : gG + nl] (contiguous), recv region laid out [rank][layer in group][K|V][slot]
-                G = max(1, min(7, args.gather_group))      # a group must fit one fused launch (<= 7 layers x 16 tensors)
                 groups = [(a, min(L, a + G)) for a in range(0, L, G)]
-                grecv = torch.zeros(L * live * 2 * slot, dtype=torch.uint8, device=dev)
 
-                def grecv_ptr(l, r, kv):
-                    return grecv.data_ptr() + group_recv_offset(l, r, kv, G, L, live, slot)
                 def build_step_plans(mode):
                     built = []
                     for s_ in range(2):
                         sp = lib.cfx_plan_create(ctx)
-                        src = plans[s_]
                         assert lib.cfx_plan_set_exchange_stream(sp, mode) == 0
-                        for a, b in groups:
-                            for l in range(a, b):
-                                assert lib.cfx_plan_copy_op(sp, src, 2 * l) >= 0
-                            rcx = lib.cfx_plan_add_all_gather(sp, native_comm.handle, send[a].data_ptr(), grecv.data_ptr() + a * live * 2 * slot,
-                                                              (b - a) * 2 * slot)
-                            assert rcx >= 0, rcx
-                            for l in range(a, b):
-                                darr = (_lib.DecompItem * 16)()
-                                for kv in range(2):
-                                    darr[kv] = _lib.DecompItem(send[l, kv].data_ptr(), own_base[l, kv].data_ptr(), own_base[l, kv].data_ptr())
-                                i = 2
-                                for p in range(W_LOGICAL - 1):
-                                    for kv in range(2):
-                                        # real peers: their slot of the gathered buffer; looped-back logical peers: OUR slot of
-                                        # the gathered buffer (so the collective's result is consumed even with one live rank)
-                                        pk_ptr = grecv_ptr(l, (rank + 1 + p) % live if (live > 1 and p < live - 1) else rank, kv)
-                                        darr[i] = _lib.DecompItem(pk_ptr, peer_base[l, p, kv].data_ptr(), peer_base[l, p, kv].data_ptr())
-                                        i += 1
-                                assert lib.cfx_plan_add_decompress(sp, CODEC, N, C, 0, 16, darr) >= 0
+                        if not pipelined:
+                            for l in range(L):
+                                add_layer(sp, s_, l, ride, True, native_comm.handle)
+                        else:
+                            for a, b in groups:
+                                for l in range(a, b):
+                                    assert lib.cfx_plan_add_compress(sp, CODEC, N, C, 0, 0, 2, comp_items(s_, l), ws.data_ptr(), ws_bytes) >= 0
+                                rcx = lib.cfx_plan_add_all_gather(sp, native_comm.handle, send[a].data_ptr(),
+                                                                  grecv.data_ptr() + a * live * 2 * slot, (b - a) * 2 * slot)
+                                assert rcx >= 0, rcx
+                                for l in range(a, b):
+                                    items = own_ef_items(l) + peer_items(l, True)
+                                    assert lib.cfx_plan_add_decompress(sp, CODEC, N, C, 0, 16, (_lib.DecompItem * 16)(*items)) >= 0
                         built.append(sp)
                     return built
-                # the in-order replay has no wait ops in this plan: everything stays on the compute stream there
-                stream_mode = {"main": 0, "side": 1, "prio": 2}[args.exchange_stream] if args.replay == "pipelined" else 0
+                stream_mode = {"main": 0, "side": 1, "prio": 2}[args.exchange_stream] if pipelined else 0
                 step_plans = build_step_plans(stream_mode)
                 exchange_mode = "native"
             except Exception as e:  # pragma: no cover
-                if args.exchange == "native":
-                    raise
-                print(f"[bench] native exchange unavailable ({e}); using torch.distributed per layer", file=sys.stderr)
+                if not args.allow_fallback:
+                    raise SystemExit(f"[bench] native exchange unavailable ({e}); pass --allow-fallback to time torch.distributed per layer instead")
+                print(f"[bench] native exchange unavailable ({e}); FALLBACK to torch.distributed per layer (--allow-fallback)", file=sys.stderr)
                 native_comm, step_plans = None, None
 
     def check(rc, what):
         if rc != 0:
             raise RuntimeError(f"{what}: rc={rc} {lib.cfx_last_error_string(ctx)}")
 
+    run_native = lib.cfx_plan_run_pipelined if pipelined else lib.cfx_plan_run
+
     def one_step(step):
         plan = plans[step & 1]
-        run = lib.cfx_plan_run_pipelined if args.replay == "pipelined" else lib.cfx_plan_run
         if not use_dist:
-            check(run(plan, 0, 2 * L, sh), "plan_run")     # the whole step from native code
+            check(run_native(plan, 0, lib.cfx_plan_size(plan), sh), "plan_run")     # the whole step from native code
             return
         if step_plans is not None:
             sp = step_plans[step & 1]
-            check(run(sp, 0, lib.cfx_plan_size(sp), sh), "plan_run(exchange)")
+            check(run_native(sp, 0, lib.cfx_plan_size(sp), sh), "plan_run(exchange)")
             return
-        # software pipeline: gather(l) runs on RCCL's own stream (async_op: it is ordered after the compute stream's
-        # tail at the call and joined back by work.wait()) and overlaps compress(l+1) and reconstruct(l-1)
-        works = [None] * L
-        check(lib.cfx_plan_run(plan, 0, 1, sh), "compress")
-        works[0] = dist.all_gather_into_tensor(recv[0].view(-1), send[0].view(-1), async_op=True)
+        # torch.distributed per layer (fallback / --exchange torch): layer by layer in order
+        pl = plans_inorder[step & 1]
         for l in range(L):
-            if l + 1 < L:
-                check(lib.cfx_plan_run(plan, 2 * (l + 1), 1, sh), "compress")
-                works[l + 1] = dist.all_gather_into_tensor(recv[l + 1].view(-1), send[l + 1].view(-1), async_op=True)
-            works[l].wait()          # compute stream waits for gather(l)
-            check(lib.cfx_plan_run(plan, 2 * l + 1, 1, sh), "reconstruct")
+            check(lib.cfx_plan_run(pl, 2 * l, 1, sh), "compress")
+            dist.all_gather_into_tensor(recv[l].view(-1), send[l].view(-1))
+            check(lib.cfx_plan_run(pl, 2 * l + 1, 1, sh), "reconstruct")
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -338,7 +359,7 @@ def main():
         """What a rank holds for its own shard must be, bit for bit, what every peer reconstructed for that shard."""
         torch.cuda.synchronize(dev)
         # sampled over layers that sit at different positions of an all-gather group, K and V
-        samples = sorted({(l, kv) for l in (0, 1, min(L - 1, max(1, args.gather_group) - 1), L // 2, L - 1) for kv in (0, 1) if l < L})
+        samples = sorted({(l, kv) for l in (0, 1, min(L - 1, G - 1), L // 2, L - 1) for kv in (0, 1) if l < L})
         if live == 1:
             same = all(torch.equal(own_base[l, kv].view(torch.int16), peer_base[l, p, kv].view(torch.int16))
                        for l, kv in samples for p in range(W_LOGICAL - 1))
@@ -356,73 +377,100 @@ def main():
         dist.all_reduce(good, op=dist.ReduceOp.MIN)
         return bool(good.item()), f"rank {rank}: a peer's reconstructed state diverged from its owner's"
 
+    steps_run = 0
     # ---- warmup (+ validation of the exchange path before anything is timed) ---------------------------------------------
-    for i in range(max(args.warmup, 1 if use_dist else 0)):
-        one_step(i)
+    n_warm = max(args.warmup, 1 if use_dist else 0)
+    for i in range(n_warm):
+        one_step(steps_run + i)
+    steps_run += n_warm
     sync_all()
     if use_dist and step_plans is not None:
         ok, why = states_consistent()
         if not ok and stream_mode != 0:
-            # the overlapped collectives did not validate on this machine: same native plan, everything in order on one stream
-            print("[bench] exchange-stream overlap failed validation; retrying with in-order collectives", file=sys.stderr)
+            if not args.allow_fallback:
+                raise SystemExit("[bench] exchange-stream overlap failed validation (" + why + "); pass --allow-fallback to retry in order")
+            print("[bench] exchange-stream overlap failed validation; FALLBACK to in-order collectives (--allow-fallback)", file=sys.stderr)
             stream_mode = 0
             step_plans = build_step_plans(0)
             reset_state()
-            for i in range(max(args.warmup, 1)):
+            for i in range(n_warm):
                 one_step(i)
+            steps_run = n_warm
             sync_all()
             ok, why = states_consistent()
         if not ok:
-            if args.exchange == "native":
-                raise RuntimeError("native exchange produced inconsistent state: " + why)
-            print("[bench] native exchange failed validation; falling back to torch.distributed per layer", file=sys.stderr)
+            if not args.allow_fallback:
+                raise SystemExit("[bench] native exchange produced inconsistent state: " + why)
+            print("[bench] native exchange failed validation; FALLBACK to torch.distributed per layer (--allow-fallback)", file=sys.stderr)
             step_plans, exchange_mode = None, "torch"
             reset_state()
-            for i in range(max(args.warmup, 1)):
+            for i in range(n_warm):
                 one_step(i)
+            steps_run = n_warm
             sync_all()
 
     # ---- timed region -------------------------------------------------------------------------------------------
-    # dominant kernel: k_binary_dequant (in-order replay) or the fused k_binary_pipe (pipelined replay; the full
-    # three-group launches only - prologue / epilogue launches carry a different id)
-    KID_DEQ = 23 if args.replay == "pipelined" else 4
+    # profiled kernels: in-order replay: k_binary_dequant (4, launch B, dominant) and k_absmean_compress<bits> (27, launch A);
+    # pipelined replay: the fused k_binary_pipe (23: full three-group launches; 24: prologue / epilogue / ragged launches)
+    KIDS = (23, 24) if pipelined else (4, 27)
+    prof_cap = (args.steps * 2 * L) // max(1, args.event_stride) + 64
     if not args.no_kernel_events:
-        check(lib.cfx_profile_enable(ctx, args.steps * L + 8, 1 << KID_DEQ, args.event_stride), "profile_enable")
+        mask = 0
+        for k in KIDS:
+            mask |= 1 << k
+        check(lib.cfx_profile_enable(ctx, prof_cap, mask, args.event_stride), "profile_enable")
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        one_step(args.warmup + i)
+        one_step(steps_run + i)
     sync_all()
     t1 = time.perf_counter()
+    steps_run += args.steps
     elapsed = t1 - t0
     if live > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kern_ms = None
+    kern_us = {}
     if not args.no_kernel_events:
-        cap = args.steps * L + 8
-        ids = (ctypes.c_int * cap)()
-        ms = (ctypes.c_float * cap)()
-        n = lib.cfx_profile_read(ctx, ids, ms, cap)
-        vals = [ms[i] for i in range(n) if ids[i] == KID_DEQ and ms[i] > 0]
-        n_samples = len(vals)
-        if vals:
-            kern_ms = sum(vals) / len(vals)
+        ids = (ctypes.c_int * prof_cap)()
+        ms = (ctypes.c_float * prof_cap)()
+        n = lib.cfx_profile_read(ctx, ids, ms, prof_cap)
+        for k in KIDS:
+            vals = [ms[i] * 1e3 for i in range(n) if ids[i] == k and ms[i] > 0]
+            if vals:
+                kern_us[k] = (sum(vals) / len(vals), len(vals))
         lib.cfx_profile_enable(ctx, 0, 0, 1)
 
-    # secondary figure, same K steps replayed layer by layer in order (stats -> finalize -> dequant, three launches per
-    # layer): what a caller gets when layer j+1's K,V only exist after layer j's attention.  The pipelined replay reorders
-    # work ACROSS layers, which the bench's resident synthetic inputs allow (SURVEY.md section 8d "pure exchange" protocol).
-    inorder_ms = None
-    if args.replay == "pipelined" and not use_dist:
+    def timed_leg(n_steps, fn):
         sync_all()
-        ti = time.perf_counter()
-        for i in range(args.steps):
-            check(lib.cfx_plan_run(plans[(args.warmup + args.steps + i) & 1], 0, 2 * L, sh), "plan_run(inorder)")
+        ta = time.perf_counter()
+        for i in range(n_steps):
+            fn(i)
         sync_all()
-        inorder_ms = (time.perf_counter() - ti) * 1e3 / args.steps
+        dt = time.perf_counter() - ta
+        if live > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt * 1e3 / n_steps
+
+    # ---- secondary legs (no events): a long run of the same replay, the other replay ------------------------------------------
+    long_ms, other_ms = None, None
+    if not args.no_secondary:
+        base_step = steps_run
+        long_ms = timed_leg(args.long_steps, lambda i: one_step(base_step + i))
+        steps_run += args.long_steps
+        if not use_dist:
+            other = plans_inorder if pipelined else plans_pipe
+            other_run = lib.cfx_plan_run if pipelined else lib.cfx_plan_run_pipelined
+            base_step = steps_run
+            for i in range(2):
+                check(other_run(other[(base_step + i) & 1], 0, lib.cfx_plan_size(other[0]), sh), "plan_run(other)")
+            base_step += 2
+            other_ms = timed_leg(args.steps, lambda i: check(other_run(other[(base_step + i) & 1], 0, lib.cfx_plan_size(other[0]), sh), "plan_run(other)"))
+            steps_run += 2 + args.steps
 
     # ---- state sanity (bit-exact error-feedback consistency) ---------------------------------------------------------
     ok, why = states_consistent()
@@ -455,6 +503,8 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     act_bytes_rank = L * 16 * N * C * 2
     value = live * act_bytes_rank / (elapsed / args.steps) / 1e9
+    inorder_ms = other_ms if pipelined else ms_per_step
+    pipe_ms = ms_per_step if pipelined else other_ms
 
     out = {
         "metric": "residual_compressed_activation_exchange_throughput",
@@ -471,88 +521,120 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "FLUX.1-dev 1024x1024 ring-attention SP degree 8 (logical), 1-bit residual + error feedback: per rank per step "
-                        f"{L} layers x (compress K,V + reconstruct 7 peers' K,V), shard (544,3072) fp16; {live} live rank(s), "
-                        f"{W_LOGICAL - live} peer(s) looped back",
+                        f"{L} layers x (compress K,V + reconstruct 7 peers' K,V), shard (544,3072) fp16, layer by layer in order; "
+                        f"{live} live rank(s), {W_LOGICAL - live} peer(s) looped back",
             "codec": "BINARY(1-bit, comp_rank=-1)", "layers": L, "shard": [N, C], "logical_ring": W_LOGICAL,
             "packet_bytes": pkt_bytes, "raw_bytes": N * C * 2,
         },
         "exchange_ms_per_step": round(ms_per_step, 4),
         "exchange_issued_by": exchange_mode,
         "replay": args.replay,
+        "schedule": ("cross-layer software pipeline (NOT deployable: needs every layer's K,V resident)" if pipelined else
+                     "layer by layer in order (deployable): per layer A = compress K,V [statistics + sign bits + in-launch finalize"
+                     + (" + previous layer's own error-feedback update riding along" if ride else "") + "], X = exchange, B = reconstruct "
+                     + ("7 peers' K,V" if ride else "own + 7 peers' K,V")),
+        "launches_per_layer": None if pipelined else 2,
         "inorder_ms_per_step": None if inorder_ms is None else round(inorder_ms, 4),
+        "pure_exchange_upper_bound": None if pipe_ms is None else {
+            "ms_per_step": round(pipe_ms, 4),
+            "what": "cfx_plan_run_pipelined: statistics / finalize of later layers run beside the reconstruction of earlier ones; "
+                    "legal only with every layer's K,V resident before the step (this bench's synthetic inputs) - a model cannot run it"},
+        "long_run": None if long_ms is None else {"steps": args.long_steps, "ms_per_step": round(long_ms, 4)},
         "exchange_stream": (["main", "side", "prio"][stream_mode] if (use_dist and step_plans is not None) else None),
-        "layers_per_all_gather": (max(1, min(7, args.gather_group)) if (use_dist and step_plans is not None) else None),
+        "layers_per_all_gather": (G if (use_dist and step_plans is not None) else None),
         "raw_allgather_ms_per_step": None if raw_ms is None else round(raw_ms, 4),
         "speedup_vs_raw_allgather": None if raw_ms is None else round(raw_ms / ms_per_step, 3),
     }
     if live > 1:
         # wire side of the roofline pair (north star: "fraction of HBM / xGMI roofline"): packets RECEIVED per GPU per step
         # over the step time, against the xGMI links an all-gather among `live` GPUs can use (one link per peer, 7 at most;
-        # ~153 GB/s per direction per link, MI355X_MICROARCH.md).  The exchange overlaps the codec work, so this is a lower
-        # bound of the link rate actually reached while a collective is in flight.
+        # ~153 GB/s per direction per link, MI355X_MICROARCH.md).  The exchange shares the step with the codec work, so this is a
+        # lower bound of the link rate actually reached while a collective is in flight.
         wire = (live - 1) * 2 * L * pkt_bytes
         links = min(live - 1, 7)
         out["xgmi"] = {"wire_bytes_per_gpu_per_step": int(wire), "achieved": round(wire / (ms_per_step * 1e-3) / 1e9, 2),
                        "peak": 153.0 * links, "unit": "GB/s", "frac": round(wire / (ms_per_step * 1e-3) / 1e9 / (153.0 * links), 4),
                        "links": links, "raw_bytes_per_gpu_per_step": int((live - 1) * 2 * L * N * C * 2)}
-    if kern_ms is not None:
-        if args.replay == "pipelined":
-            # one steady-state launch = a unit of `ul` layers in each of the three groups: reconstruct 16*ul tensors (bits +
-            # state in, state out: 4.125 B/el) + statistics/sign-bit pass of 2*ul tensors of the unit two ahead (x + state in,
-            # bits out: 4.125 B/el); the finalize group's traffic is negligible
+    # ---- roofline --------------------------------------------------------------------------------------------------------
+    # step level (every launch of the step, edge layers included), SURVEY.md §8d: own tensors compress + error feedback 6.125 B/el,
+    # peers' tensors 4.125 B/el
+    EL = N * C
+    step_alg = L * (2 * ALG_BYTES_PER_EL["compress"] + 14 * ALG_BYTES_PER_EL["decompress"]) * EL
+    step_obj = {"algorithmic_bytes": int(step_alg), "achieved": round(step_alg / (ms_per_step * 1e-3) / 1e9, 1), "unit": "GB/s",
+                "frac": round(step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "floor_ms_at_peak": round(step_alg / (HBM_PEAK_GBS * 1e9) * 1e3, 4)}
+    dom = 23 if pipelined else 4
+    if dom in kern_us:
+        us, n_samples = kern_us[dom]
+        if pipelined:
             ul = max(1, int(os.environ.get("CFX_PIPE_UNIT_LAYERS", "7")))
             if use_dist and step_plans is not None:
-                Gq = max(1, min(7, args.gather_group))
-                ul = max(Gq, (ul // Gq) * Gq)                   # units are whole all-gather groups
+                ul = max(G, (ul // G) * G)                      # units are whole all-gather groups
             ul = min(ul, 7, L)
-            alg = (ALG_BYTES_PER_EL["decompress"] * 16 + 4.125 * 2) * ul * N * C
-            kname = (f"k_binary_pipe (one launch = {ul} layers: dequant+add of {16 * ul} tensors x (544,3072) [own K,V error-feedback "
-                     f"update + 7 peers' K,V per layer] + finalize of the next {ul} layers' K,V scales + stats/sign bits of the {ul} "
-                     "layers after those)")
-            pmc_key, csv_prefix = "k_binary_pipe_bytes_per_launch", "k_binary_pipe<true>"
+            # one steady-state launch: reconstruct 14*ul peers' tensors (4.125) + own 2*ul tensors' error-feedback pass and, two units
+            # ahead, their statistics pass: together the own tensors' compress + EF = 6.125 B/el (the second read of x / state is
+            # implementation traffic)
+            alg = (ALG_BYTES_PER_EL["decompress"] * 14 + ALG_BYTES_PER_EL["compress"] * 2) * ul * EL
+            kname = (f"k_binary_pipe (one launch = {ul} layers: dequant+add of {16 * ul} tensors x (544,3072) + finalize of the next {ul} "
+                     f"layers' K,V scales + stats/sign bits of the {ul} layers after those)")
         else:
-            alg = ALG_BYTES_PER_EL["decompress"] * 16 * N * C
-            kname = "k_binary_dequant (16 tensors x (544,3072) per launch: own K,V error-feedback update + 7 peers' K,V)"
-            pmc_key, csv_prefix = "k_binary_dequant_bytes_per_launch", "k_binary_dequant"
-        ach = alg / (kern_ms * 1e-3) / 1e9
+            n_t = (14 * (L - 1) + 16) / L if ride else 16.0     # tensors per launch B, averaged over the step's launches
+            alg = ALG_BYTES_PER_EL["decompress"] * n_t * EL
+            kname = (f"k_binary_dequant (launch B: {'7 peers K,V = 14' if ride else 'own + 7 peers K,V = 16'} tensors x (544,3072) per launch"
+                     + ("; the last layer's launch carries 16" if ride else "") + ")")
+        ach = alg / (us * 1e-6) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": kname,
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                           "traffic": None, "traffic_source": None, "avg_launch_us": round(kern_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(alg),
-                           "event_samples": n_samples, "event_stride": args.event_stride}
-        prof = os.path.join(REPO, "profiles", "pmc_traffic.json")
+                           "traffic": None, "traffic_source": None, "avg_launch_us": round(us, 3), "algorithmic_bytes_per_launch": int(alg),
+                           "event_samples": n_samples, "event_stride": args.event_stride, "step": step_obj}
+        if not pipelined and 27 in kern_us:
+            usa, na = kern_us[27]
+            # launch A: the rank's own K,V - compress now, error feedback of the previous layer riding along: 6.125 B/el algorithmic
+            alga = ALG_BYTES_PER_EL["compress"] * 2 * EL if ride else 4.125 * 2 * EL
+            out["roofline"]["compress_launch"] = {
+                "kernel": "k_absmean_compress<bits> (launch A: statistics + sign bits + in-launch finalize of own K,V"
+                          + (" + previous layer's own error-feedback update" if ride else "") + ")",
+                "avg_launch_us": round(usa, 3), "event_samples": na, "algorithmic_bytes_per_launch": int(alga),
+                "achieved": round(alga / (usa * 1e-6) / 1e9, 1), "frac": round(alga / (usa * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "latency-bound: a global reduction (scales) sits between reading K,V and the packet being complete"}
+        # PMC traffic / rocprof cross-reference: only when the committed profile was taken with THIS configuration
+        prof = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+        cfg_key = {"replay": args.replay, "own_ef": args.own_ef if not pipelined else None, "layers": L, "shard": [N, C],
+                   "rows": args.rows, "n_gpus": live}
         if os.path.exists(prof):
             try:
-                out["roofline"]["traffic"] = json.load(open(prof)).get(pmc_key)
-                out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, round 1)"
+                pj = json.load(open(prof))
+                if pj.get("config") == cfg_key:
+                    pk_ = "k_binary_pipe<true>" if pipelined else "k_binary_dequant"
+                    out["roofline"]["traffic"] = pj["bytes_per_launch"].get(pk_)
+                    out["roofline"]["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                    out["roofline"]["step"]["traffic"] = pj.get("bytes_per_step")
             except Exception:
                 pass
-        # cross-reference: the committed rocprofv3 --kernel-trace --stats summary of this same command.  The HIP-event
-        # bracket of a single dispatch includes ~1.3-2 us of marker-to-kernel gap (tools/evtest.hip), so `achieved` above
-        # is the conservative figure.
-        trace_json = os.path.join(REPO, "profiles", "r01_bench_kernel_durations.json")
+        trace_json = os.path.join(REPO, "profiles", "r02_bench_kernel_durations.json")
         if os.path.exists(trace_json):
             try:
-                ent = json.load(open(trace_json))["kernels"].get(csv_prefix)
-                if ent:
-                    out["roofline"]["avg_launch_us_rocprof"] = ent["avg_us"]
-                    out["roofline"]["rocprof_source"] = ("profiles/r01_bench_kernel_durations.json (tools/trace_kernel_avg.py over the "
-                                                         "rocprofv3 --kernel-trace of this command); the same kernel's row of "
-                                                         "profiles/r01_bench_kernel_stats.csv (rocprofv3 --stats) agrees")
+                tj = json.load(open(trace_json))
+                if tj.get("config") == cfg_key:
+                    ent = tj["kernels"].get("k_binary_pipe<true>" if pipelined else "k_binary_dequant")
+                    if ent:
+                        out["roofline"]["avg_launch_us_rocprof"] = ent["avg_us"]
+                        out["roofline"]["rocprof_source"] = "profiles/r02_bench_kernel_durations.json (rocprofv3 --kernel-trace of this command)"
             except Exception:
                 pass
     else:
-        out["roofline"] = None
+        out["roofline"] = {"bound": "hbm", "kernel": None, "achieved": step_obj["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": step_obj["frac"], "traffic": None, "step": step_obj}
     if rank == 0 and live == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         except Exception as e:  # pragma: no cover
             out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         if not use_dist:
-            # the oracle as the checker of what was just timed: replay every step this process ran (warm-up + timed +
-            # in-order) for two tensors on the host and compare the error-feedback states bit for bit - fails loudly
+            # the oracle as the checker of what was just timed: replay every step this process ran (warm-up + timed + long +
+            # the other replay) for two tensors on the host and compare the error-feedback states bit for bit - fails loudly
             from oracle import c_oracle as CO
             import numpy as np
-            steps_run = args.warmup + args.steps + (args.steps if inorder_ms is not None else 0)
             x0_host = warm_state(rank)[1]
             checked = []
             for l, kv in ((0, 0), (L - 1, 1)):

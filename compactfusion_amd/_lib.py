@@ -40,6 +40,12 @@ SYMBOLS = [
                                           ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_decompress_batch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.POINTER(DecompItem), ctypes.c_void_p]),
+    ("cfx_compress_batch_ex", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_int, ctypes.POINTER(DecompItem),
+                                             ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    ("cfx_prepare", ctypes.c_int, [ctypes.c_void_p]),
+    ("cfx_set_fused_finalize", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_debug_stamps", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     ("cfx_compress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_decompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -58,6 +64,9 @@ SYMBOLS = [
     ("cfx_plan_destroy", None, [ctypes.c_void_p]),
     ("cfx_plan_add_compress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_void_p, ctypes.c_size_t]),
+    ("cfx_plan_add_compress_ex", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_int, ctypes.POINTER(DecompItem),
+                                                ctypes.c_void_p, ctypes.c_size_t]),
     ("cfx_plan_add_decompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.POINTER(DecompItem)]),
     ("cfx_plan_set_exchange_stream", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),

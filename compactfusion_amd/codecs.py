@@ -40,8 +40,18 @@ def context(device: int):
         c = lib.cfx_create(device)
         if not c:
             raise CfxError("cfx_create failed")
+        if torch.cuda.is_available():
+            rc = lib.cfx_prepare(c)          # ticket blocks of the in-launch finalize (once; keeps later calls graph-capturable)
+            if rc != 0:
+                raise CfxError("cfx_prepare failed: " + (lib.cfx_last_error_string(c) or b"").decode())
         _ctx[device] = c
     return c
+
+
+def set_fused_finalize(on: bool, device: Optional[int] = None) -> None:
+    """Compress statistics + finalize in one launch (default) or as two kernels (bit-identical; used by the tests)."""
+    device = torch.cuda.current_device() if device is None else device
+    _lib.load().cfx_set_fused_finalize(context(device), 1 if on else 0)
 
 
 def set_rows_per_tile(rows: int, device: Optional[int] = None) -> None:
@@ -168,7 +178,7 @@ def prepare_compress(codec: int, bases: Sequence[Optional[torch.Tensor]], new_ba
     ws = workspace(codec, N, C, param, B, dev)
     fn = _lib.load().cfx_compress_batch
     keep = (list(bases), list(new_bases), list(packets), ws)
-    ws_ptr, ws_len, codec = _ptr(ws), ws.numel(), int(codec)
+    ws_ptr, ws_len, codec = _ptr(ws), (0 if ws is None else ws.numel()), int(codec)
 
     def run(xs: Sequence[torch.Tensor], stream_handle: Optional[int] = None) -> None:
         assert len(xs) == B and keep

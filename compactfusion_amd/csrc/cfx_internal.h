@@ -13,14 +13,16 @@ enum {
     KID_INT8_QUANT = 9, KID_INT8_DEQUANT = 10, KID_INT4_QUANT = 11, KID_INT4_DEQUANT = 12,
     KID_TOPK_COMPRESS = 13, KID_TOPK_DECOMPRESS = 14, KID_COPY_PROBE = 15, KID_BINARY_EF = 16,
     KID_LR_PREP = 17, KID_LR_AQ = 18, KID_LR_ATY = 19, KID_LR_CHOL = 20, KID_LR_APPLY = 21, KID_LR_DECODE = 22,
-    KID_BINARY_PIPE = 23, KID_BINARY_PIPE_EDGE = 24, KID_RES2_DELTA = 25, KID_RES2_UPDATE = 26, KID_MAX = 27
+    KID_BINARY_PIPE = 23, KID_BINARY_PIPE_EDGE = 24, KID_RES2_DELTA = 25, KID_RES2_UPDATE = 26,
+    KID_ABSMEAN_COMPRESS_BITS = 27, KID_ABSMEAN_COMPRESS = 28, KID_MINMAX_COMPRESS = 29, KID_MAX = 30
 };
 static const char* const kid_names[KID_MAX] = {
     "", "k_absmean_stats<bits>", "k_absmean_stats", "k_absmean_finalize", "k_binary_dequant", "k_int2_quant", "k_int2_dequant",
     "k_minmax_stats", "k_minmax_finalize", "k_int8_quant", "k_int8_dequant", "k_int4_quant", "k_int4_dequant",
     "k_topk_compress", "k_topk_decompress", "k_copy_probe", "k_binary_dequant(ef)",
     "k_lr_prep", "k_lr_aq", "k_lr_aty", "k_lr_chol", "k_lr_apply", "k_lr_decode",
-    "k_binary_pipe", "k_binary_pipe(prologue/epilogue)", "k_residual2_delta", "k_residual2_update"};
+    "k_binary_pipe", "k_binary_pipe(prologue/epilogue)", "k_residual2_delta", "k_residual2_update",
+    "k_absmean_compress<bits>", "k_absmean_compress", "k_minmax_compress"};
 
 struct ProfRec { int kid; hipEvent_t a, b; };
 
@@ -30,8 +32,15 @@ struct cfx_ctx {
     // native per-launch timing (hipEvents recorded on the launch stream around selected kernels)
     ProfRec* prof;
     int prof_cap, prof_n;
-    int prof_stride, prof_seen;     // record every prof_stride-th eligible launch
+    int prof_stride;                // record every prof_stride-th eligible launch of each kernel id
+    int prof_seen[KID_MAX];
     unsigned prof_mask;
+    // in-launch finalize: ticket blocks (device memory, zeroed once, self-resetting) handed out round-robin, one per launch
+    unsigned* tick;
+    unsigned tick_next;
+    int fused;                      // 1 (default): compress = statistics + in-launch finalize; 0: separate finalize kernel
+    void* dbg_stamps;               // developer hook (cfx_debug_stamps)
+    int stats_rows;                 // CFX_STATS_ROWS override of the statistics tile height (experiments), 0 = automatic
     char err[256];
 };
 
@@ -40,7 +49,7 @@ struct cfx_ctx {
 // not the kernel plus the command processor's event handling that a hipEventRecord bracket would add (~6 us here).
 static inline int prof_slot(cfx_ctx* ctx, int kid) {
     if (!ctx->prof_mask || !(ctx->prof_mask & (1u << kid)) || ctx->prof_n >= ctx->prof_cap) return -1;
-    if ((ctx->prof_seen++ % ctx->prof_stride) != 0) return -1;
+    if ((ctx->prof_seen[kid]++ % ctx->prof_stride) != 0) return -1;
     const int i = ctx->prof_n++;
     ctx->prof[i].kid = kid;
     return i;

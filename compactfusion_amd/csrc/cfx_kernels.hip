@@ -89,6 +89,20 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
     return v;
 }
 
+// Inter-workgroup hand-off inside ONE launch (the in-launch finalize below).  Per-XCD L2s are not coherent with each other
+// and a CU's L1 is never refreshed by other CUs' stores, so partial sums that another workgroup will read in this launch
+// are stored WRITE-THROUGH (relaxed agent-scope atomic store = `global_store ... sc1`: the line leaves the XCD) and read
+// back with relaxed agent-scope loads (`global_load ... sc1`: bypasses the reader's L1) - no release / acquire fences,
+// which would write back / invalidate whole caches per workgroup (MI355X_MICROARCH.md, "Workgroup dispatch ... visibility").
+__device__ __forceinline__ void st_wt(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 ld_wt(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_wt(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_wt(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its outstanding global stores
+// (__syncthreads() also drains vmcnt: behind write-through stores that is a fabric round trip, ~1 us, per barrier).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ h16x8 habs8(h16x8 v) {
     u16x8 b = __builtin_bit_cast(u16x8, v);
     b &= (u16)0x7fff;
@@ -136,11 +150,14 @@ __device__ __forceinline__ u64 wave_sum4_u64(const u64 (&v)[4], int lane) {
     return b;   // lane 0: row 0, lane 16: row 1, lane 32: row 2, lane 48: row 3
 }
 
-// The body is shared by the stand-alone kernel and the fused pipeline kernel (k_binary_pipe): (bx, by) = tile index,
-// rowpart = this tensor's workspace, sm = WAVES x TILE_C words of LDS.
-template <bool EMIT_BITS, int US>
+// The body is shared by the stand-alone kernel, the single-launch compress kernel (k_absmean_compress) and the fused pipeline
+// kernel (k_binary_pipe): (bx, by) = tile index, rowpart = this tensor's workspace, NW = waves per workgroup, sm = NW x TILE_C
+// words of LDS.  Workspace: rowpart[cb][n] (a row's partials are CB strided words: the finalize reads them coalesced over n),
+// then colpart[p][c].
+template <bool EMIT_BITS, int US, bool WT = false, int NW = WAVES>
 __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int N, int C, int R, int CB, int bx, int by,
-                                                   u64* rowpart, u64 (*sm)[TILE_C]) {
+                                                   u64* rowpart, u64 (*sm)[TILE_C], u64* stamps = nullptr) {
+#define SSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
     const TileCoord t = tile_coord_at(bx, by, N, C, R);
     const int cb = bx;
     u64* colpart = rowpart + (size_t)N * CB;
@@ -156,11 +173,11 @@ __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int 
 #pragma unroll
     for (int i = 0; i < 8; ++i) col[i] = 0.0;
 
-    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * US) {
+    for (int r = t.r0 + t.w; r < t.r1; r += NW * US) {
         h16x8 xv[US], bv[US];
 #pragma unroll
         for (int j = 0; j < US; ++j) {
-            const int rr = r + WAVES * j;
+            const int rr = r + NW * j;
             xv[j] = (h16x8)(h16)0;
             bv[j] = (h16x8)(h16)0;
             if (rr < t.r1 && t.act) {
@@ -170,9 +187,10 @@ __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int 
             }
         }
         u64 rs[4] = {0, 0, 0, 0};           // the butterfly reduces 4 rows; unused ones stay 0
+        if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SSTAMP(8); }
 #pragma unroll
         for (int j = 0; j < US; ++j) {
-            const int rr = r + WAVES * j;
+            const int rr = r + NW * j;
             if (rr < t.r1 && t.act) {
                 const h16x8 d = xv[j] - bv[j];
                 const h16x8 a = habs8(d);
@@ -189,20 +207,30 @@ __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int 
                 if (EMIT_BITS) bitsout[(size_t)rr * C8 + (t.c >> 3)] = (unsigned char)byte;
             }
         }
+        SSTAMP(9);
         const u64 tot = wave_sum4_u64(rs, t.lane);
+        SSTAMP(10);
         if ((t.lane & 15) == 0 && (t.lane >> 4) < US) {
-            const int rr = r + WAVES * (t.lane >> 4);
-            if (rr < t.r1) rowpart[(size_t)rr * CB + cb] = tot;
+            const int rr = r + NW * (t.lane >> 4);
+            if (rr < t.r1) { if (WT) st_wt(&rowpart[(size_t)cb * N + rr], tot); else rowpart[(size_t)cb * N + rr] = tot; }
         }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) sm[t.w][i * 64 + t.lane] = (u64)(col[i] * 16777216.0);   // exact; [i][lane]: conflict-free
-    __syncthreads();
-    for (int k = threadIdx.x; k < TILE_C; k += NTHR) {      // k = channel within the tile: coalesced global writes
+    SSTAMP(11);
+    if (WT) lds_barrier(); else __syncthreads();
+    SSTAMP(12);
+    for (int k = threadIdx.x; k < TILE_C; k += NW * 64) {   // k = channel within the tile: coalesced global writes
         const int s = (k & 7) * 64 + (k >> 3);
         const int cc = bx * TILE_C + k;
-        if (cc < C) colpart[(size_t)by * C + cc] = sm[0][s] + sm[1][s] + sm[2][s] + sm[3][s];
+        if (cc < C) {
+            u64 v = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += sm[w][s];
+            if (WT) st_wt(&colpart[(size_t)by * C + cc], v); else colpart[(size_t)by * C + cc] = v;
+        }
     }
+#undef SSTAMP
 }
 
 template <bool EMIT_BITS>
@@ -234,7 +262,7 @@ __device__ __forceinline__ void absmean_finalize_body(const cfx_comp_item& it, i
         for (int n = tid; n < N; n += NT, ++it_n) {
             u64 s = 0;
 #pragma unroll 8
-            for (int k = 0; k < CB; ++k) s += rowpart[(size_t)n * CB + k];
+            for (int k = 0; k < CB; ++k) s += rowpart[(size_t)k * N + n];
 #pragma unroll
             for (int q = 0; q < KEEP; ++q)
                 if (it_n == q) srow[q] = s;
@@ -261,7 +289,7 @@ __device__ __forceinline__ void absmean_finalize_body(const cfx_comp_item& it, i
                     if (it_n == q) s = srow[q];
             } else {
 #pragma unroll 8
-                for (int k = 0; k < CB; ++k) s += rowpart[(size_t)n * CB + k];
+                for (int k = 0; k < CB; ++k) s += rowpart[(size_t)k * N + n];
             }
             U[n] = (h16)((float)mean16(s, C) / den);
         }
@@ -295,6 +323,7 @@ __global__ __launch_bounds__(1024) void k_absmean_finalize(BatchC batch, int N, 
 // 1-bit dequant + base add        replaces _binary_dequant_fastpath (fastpath.py:277-367) AND the
 // UPDATE_CACHE branch of _binary_quant_fastpath (fastpath.py:88-120): out = base + (2b-1)*fp16(u[n]*v[c])
 // ---------------------------------------------------------------------------------------------------
+template <int NW = WAVES>
 __device__ __forceinline__ void binary_dequant_body(const cfx_decomp_item& it, int N, int C, int R, int tile_x, int tile_y) {
     const TileCoord t = tile_coord_at(tile_x, tile_y, N, C, R);
     const unsigned char* pk = (const unsigned char*)it.packet;
@@ -307,13 +336,13 @@ __device__ __forceinline__ void binary_dequant_body(const cfx_decomp_item& it, i
     h16x8 v8 = (h16x8)(h16)0;
     if (t.act) v8 = ld8_tail(V + t.c, val16);
 
-    for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL) {
+    for (int r = t.r0 + t.w; r < t.r1; r += NW * UNROLL) {
         h16x8 bv[UNROLL];
         unsigned by[UNROLL];
         h16 u[UNROLL];
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) {
-            const int rr = r + WAVES * j;
+            const int rr = r + NW * j;
             bv[j] = (h16x8)(h16)0;
             by[j] = 0;
             u[j] = (h16)0;
@@ -325,7 +354,7 @@ __device__ __forceinline__ void binary_dequant_body(const cfx_decomp_item& it, i
         }
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) {
-            const int rr = r + WAVES * j;
+            const int rr = r + NW * j;
             if (rr < t.r1 && t.act) {
                 const h16x8 s = v8 * u[j];                       // fp16(u*v), one rounding (fastpath.py:109,328)
                 u16x8 sb = __builtin_bit_cast(u16x8, s);
@@ -339,7 +368,207 @@ __device__ __forceinline__ void binary_dequant_body(const cfx_decomp_item& it, i
 }
 
 __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, int C, int R) {
-    binary_dequant_body(batch.it[blockIdx.z], N, C, R, blockIdx.x, blockIdx.y);
+    binary_dequant_body<WAVES>(batch.it[blockIdx.z], N, C, R, blockIdx.x, blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Compress in ONE launch: statistics pass + in-launch finalize by the last-arriving workgroups (no finalize kernel, no
+// grid barrier).  Every tile workgroup publishes its partial sums write-through, drains them, and draws two tickets:
+//   tick[1 + cb] counts the P row-tiles of column block cb   -> the workgroup that draws P - 1 reduces colpart[0..P)[cb]
+//                                                                and writes V for those 512 channels
+//   tick[0]      counts all CB x P tiles of the tensor         -> the workgroup that draws CB * P - 1 reduces the row sums,
+//                                                                the grand mean and writes U
+// All sums are exact integers, so the result is bit-identical to k_absmean_stats + k_absmean_finalize for any arrival
+// order.  A ticket word is reset by the workgroup that drew its last value (nobody touches it afterwards in this launch),
+// so the ticket block - owned by the cfx_ctx, zeroed once - is reusable by the next launch.  Results never depend on
+// dispatch order or workgroup -> XCD placement: the last arriver is whoever happens to arrive last.
+// The launch can also carry `ride` reconstruction items (1-bit only): bandwidth work that does not depend on this
+// launch's statistics - the previous layer's deferred error-feedback update - streams while the reduction tail, which
+// is pure latency, completes (cfx_compress_batch_ex).
+// ---------------------------------------------------------------------------------------------------
+#define TICK_WORDS 64          // u32 ticket words per tensor: [0] all tiles, [1 + cb] column block cb  (CB <= 63)
+#define TICK_RING 256          // ticket blocks (CFX_MAX_BATCH tensors each) a context cycles through, one per launch
+
+#define FUSED_NW 8             // waves per workgroup of the single-launch compress kernel (512 threads: the last arriver of a
+#define FUSED_NT (FUSED_NW * 64)   //   column block owns one column per thread, of a tensor one row per thread)
+#define FUSED_CH 24            // partial sums a last-arriver thread keeps in flight per batch (one fabric round trip each batch)
+
+// Row sums of rows m0 and m1 from the transposed partials rowpart[k][n]: 8 column blocks (16 loads) per batch, every load
+// unconditional (clamped block index, masked value) - a remainder loop would be CB dependent round trips.
+__device__ __forceinline__ void row_sums2_wt(const u64* rowpart, int N, int CB, int m0, int m1, u64& s0, u64& s1) {
+    s0 = 0; s1 = 0;
+    for (int k0 = 0; k0 < CB; k0 += 8) {
+        u64 a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const size_t kk = (size_t)min(k0 + j, CB - 1) * N;
+            a[j] = ld_wt(&rowpart[kk + m0]);
+            b[j] = ld_wt(&rowpart[kk + m1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0 += (k0 + j < CB) ? a[j] : 0; s1 += (k0 + j < CB) ? b[j] : 0; }
+    }
+}
+
+template <bool EMIT_BITS, int US>
+__device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int N, int C, int R, int CB, int P, int bx, int by,
+                                                   u64* rowpart, unsigned* tick, int per_byte, int eps_mode, u64 (*sm)[TILE_C], int dbg,
+                                                   u64* stamps) {
+    constexpr int NT = FUSED_NT;
+    // developer hook (cfx_debug_stamps): per-workgroup phase times, 100 MHz wall clock
+#define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
+    STAMP(0);
+    if (dbg == 3) return;                      // experiments: launch cost of the empty grid
+    if (dbg == 4) {                            // experiments: the loads alone (no arithmetic, no partial sums)
+        const TileCoord t = tile_coord_at(bx, by, N, C, R);
+        h16x8 acc = (h16x8)(h16)0;
+        for (int r = t.r0 + t.w; r < t.r1; r += FUSED_NW * US) {
+            h16x8 xv[US], bv[US];
+#pragma unroll
+            for (int j = 0; j < US; ++j) {
+                const int rr = min(r + FUSED_NW * j, t.r1 - 1);
+                xv[j] = ld8nt((const h16*)it.x + (size_t)rr * C + min(t.c, C - 8));
+                bv[j] = ld8((const h16*)it.base + (size_t)rr * C + min(t.c, C - 8));
+            }
+#pragma unroll
+            for (int j = 0; j < US; ++j) acc += xv[j] - bv[j];
+        }
+        if (acc[0] == (h16)12345.0f) ((h16*)it.packet)[threadIdx.x] = acc[1];
+        return;
+    }
+    absmean_stats_body<EMIT_BITS, US, true, FUSED_NW>(it, N, C, R, CB, bx, by, rowpart, sm, stamps);
+    STAMP(1);
+    // publish: EVERY storing wave drains its write-through stores, then one lane pair draws the two tickets
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    STAMP(2);
+    if (dbg == 1) return;
+    unsigned* flag = (unsigned*)&sm[0][0];
+    if (threadIdx.x < 2) {
+        unsigned* t = threadIdx.x ? tick : tick + 1 + bx;
+        flag[threadIdx.x] = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    lds_barrier();
+    const bool last_col = flag[0] == (unsigned)(P - 1);
+    const bool last_all = flag[1] == (unsigned)(CB * P - 1);
+    STAMP(3);
+    if (stamps && threadIdx.x == 0) stamps[7] = (last_col ? 1 : 0) | (last_all ? 2 : 0);
+    if (dbg == 2) {
+        if (last_col && threadIdx.x == 0) st_wt(tick + 1 + bx, 0u);
+        if (last_all && threadIdx.x == 0) st_wt(tick, 0u);
+        return;
+    }
+    if (!last_col && !last_all) return;        // uniform per workgroup
+    lds_barrier();                             // the flags have been read: sm may be reused
+    // The last arrivers' reductions are ONE fabric round trip when N <= 2 NT and P <= FUSED_CH: every load is unconditional
+    // (clamped index, masked value) and the loads of BOTH jobs - a workgroup is often last of its column block and of the
+    // tensor - are issued before anything is consumed; a wave-uniform branch per load would serialise them into dependent
+    // round trips (cdna_hip_programming.md, ".s-level traps" (c)).
+    const int tid = threadIdx.x;
+    const u64* colpart = rowpart + (size_t)N * CB;
+    h16* U = (h16*)((char*)it.packet + (size_t)N * (C / per_byte));
+    h16* V = U + N;
+    const int c = bx * TILE_C + tid;
+    const int cc = min(c, C - 1);
+    u64 v[FUSED_CH];
+    if (last_col) {
+#pragma unroll
+        for (int j = 0; j < FUSED_CH; ++j) v[j] = ld_wt(&colpart[(size_t)min(j, P - 1) * C + cc]);
+    }
+    u64 keep0 = 0, keep1 = 0;                  // row sums of rows tid, tid + NT
+    if (last_all) row_sums2_wt(rowpart, N, CB, min(tid, N - 1), min(tid + NT, N - 1), keep0, keep1);
+    asm volatile("" ::: "memory");
+    STAMP(4);
+    // reductions first, every global store last: a barrier must not sit behind an outstanding store
+    h16 vmean = (h16)0;
+    if (last_col) {
+        // V of column block bx: one column per thread
+        u64 a = 0;
+#pragma unroll
+        for (int j = 0; j < FUSED_CH; ++j) a += (j < P) ? v[j] : 0;
+        for (int p0 = FUSED_CH; p0 < P; p0 += FUSED_CH) {
+#pragma unroll
+            for (int j = 0; j < FUSED_CH; ++j) v[j] = ld_wt(&colpart[(size_t)min(p0 + j, P - 1) * C + cc]);
+#pragma unroll
+            for (int j = 0; j < FUSED_CH; ++j) a += (p0 + j < P) ? v[j] : 0;
+        }
+        vmean = mean16(a, N);
+    }
+    STAMP(5);
+    if (last_all) {
+        // U: one thread per row, two rows per trip; the first trip's sums are already in registers
+        u64* smem = &sm[1][0];
+        u64 acc = 0;
+        if (tid < N) acc += habs_units(hbits(mean16(keep0, C)));
+        if (tid + NT < N) acc += habs_units(hbits(mean16(keep1, C)));
+        for (int n0 = tid + 2 * NT; n0 - tid < N; n0 += 2 * NT) {
+            const int n1 = n0 + NT;
+            u64 s0, s1;
+            row_sums2_wt(rowpart, N, CB, min(n0, N - 1), min(n1, N - 1), s0, s1);
+            if (n0 < N) acc += habs_units(hbits(mean16(s0, C)));
+            if (n1 < N) acc += habs_units(hbits(mean16(s1, C)));
+        }
+        STAMP(13);
+        acc = wave_sum_u64(acc);
+        STAMP(14);
+        if ((tid & 63) == 0) smem[tid >> 6] = acc;
+        lds_barrier();
+        STAMP(15);
+        u64 tot = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) tot += smem[w];           // every thread: no second barrier
+        const h16 mu = mean16(tot, N);
+        const float den = eps_mode ? (float)(h16)((float)mu + 1e-6f) : (float)mu;
+        if (tid < N) U[tid] = (h16)((float)mean16(keep0, C) / den);
+        if (tid + NT < N) U[tid + NT] = (h16)((float)mean16(keep1, C) / den);
+        for (int n0 = tid + 2 * NT; n0 - tid < N; n0 += 2 * NT) {
+            const int n1 = n0 + NT;
+            u64 s0, s1;
+            row_sums2_wt(rowpart, N, CB, min(n0, N - 1), min(n1, N - 1), s0, s1);
+            if (n0 < N) U[n0] = (h16)((float)mean16(s0, C) / den);
+            if (n1 < N) U[n1] = (h16)((float)mean16(s1, C) / den);
+        }
+        if (tid == 0) st_wt(tick, 0u);
+    }
+    if (last_col) {
+        if (c < C) V[c] = vmean;
+        if (tid == 0) st_wt(tick + 1 + bx, 0u);
+    }
+    STAMP(6);
+#undef STAMP
+}
+
+struct FusedArgs {
+    int N, C, CB, R, P;      // statistics tiles: CB x P per tensor, R rows each
+    int n_st;                // workgroups of the statistics group (CB * P * batch); the rest reconstruct `ride`
+    int dq_R, dq_rb;         // ride items: tile height, row blocks per tensor
+    int per_byte, eps_mode;
+    int dbg;                 // experiments: 1 = stop after publishing, 2 = stop after the tickets (no finalize work)
+    u64* ws;
+    size_t ws_stride;
+    unsigned* tick;
+    u64* stamps;             // developer hook: 16 words per statistics workgroup, or NULL
+};
+template <bool EMIT_BITS, int US>
+__global__ __launch_bounds__(FUSED_NT) void k_absmean_compress(BatchC batch, BatchD ride, FusedArgs a) {
+    __shared__ u64 sm[FUSED_NW][TILE_C];
+    int b = blockIdx.x;
+    if (b < a.n_st) {
+        const int per = a.CB * a.P;
+        const int z = b / per, rem = b - z * per;
+        const int by = rem / a.CB;
+        absmean_fused_body<EMIT_BITS, US>(batch.it[z], a.N, a.C, a.R, a.CB, a.P, rem - by * a.CB, by, a.ws + (size_t)z * a.ws_stride,
+                                          a.tick + z * TICK_WORDS, a.per_byte, a.eps_mode, sm, a.dbg,
+                                          a.stamps ? a.stamps + (size_t)b * 16 : nullptr);
+        return;
+    }
+    if constexpr (EMIT_BITS) {
+        b -= a.n_st;
+        const int per = a.CB * a.dq_rb;
+        const int item = b / per, rem = b - item * per;
+        const int ty = rem / a.CB;
+        binary_dequant_body<FUSED_NW>(ride.it[item], a.N, a.C, a.dq_R, rem - ty * a.CB, ty);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -387,7 +616,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const int per = a.CB * a.dq_rb;
     const int item = b / per, rem = b - item * per;
     const int ty = rem / a.CB;
-    binary_dequant_body(dq.it[item], a.N, a.C, a.dq_R, rem - ty * a.CB, ty);
+    binary_dequant_body<WAVES>(dq.it[item], a.N, a.C, a.dq_R, rem - ty * a.CB, ty);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -507,10 +736,9 @@ __global__ __launch_bounds__(NTHR) void k_int2_dequant(BatchD batch, int N, int 
 // per-channel min/max statistics pass (int4 / int8)    compress_quantize.py:452-453, :552-553
 //   part[p][c] = {min, max} of (x-base) over the tile's rows (fp16 compares are exact)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHR) void k_minmax_stats(BatchC batch, int N, int C, int R, u64* ws, size_t ws_stride) {
-    const cfx_comp_item it = batch.it[blockIdx.z];
-    const TileCoord t = tile_coord(N, C, R);
-    unsigned* part = (unsigned*)(ws + (size_t)blockIdx.z * ws_stride);   // [P][C] of {min16 | max16<<16}
+template <bool WT>
+__device__ __forceinline__ void minmax_stats_body(const cfx_comp_item& it, int N, int C, int R, int bx, int by, unsigned* part) {
+    const TileCoord t = tile_coord_at(bx, by, N, C, R);                 // part: [P][C] of {min16 | max16<<16}
     const h16* x = (const h16*)it.x;
     const h16* base = (const h16*)it.base;
     h16x8 mn = (h16x8)(h16)65504.0f, mx = (h16x8)(h16)-65504.0f;
@@ -546,7 +774,7 @@ __global__ __launch_bounds__(NTHR) void k_minmax_stats(BatchC batch, int N, int 
     __syncthreads();
     for (int k = threadIdx.x; k < TILE_C; k += NTHR) {
         const int s = (k & 7) * 64 + (k >> 3);
-        const int cc = blockIdx.x * TILE_C + k;
+        const int cc = bx * TILE_C + k;
         if (cc < C) {
             h16 a = hfrom((u16)(sm[0][s] & 0xffff)), b = hfrom((u16)(sm[0][s] >> 16));
 #pragma unroll
@@ -555,14 +783,45 @@ __global__ __launch_bounds__(NTHR) void k_minmax_stats(BatchC batch, int N, int 
                 a = a2 < a ? a2 : a;
                 b = b2 > b ? b2 : b;
             }
-            part[(size_t)blockIdx.y * C + cc] = (unsigned)hbits(a) | ((unsigned)hbits(b) << 16);
+            const unsigned v = (unsigned)hbits(a) | ((unsigned)hbits(b) << 16);
+            if (WT) st_wt(&part[(size_t)by * C + cc], v); else part[(size_t)by * C + cc] = v;
         }
     }
+}
+
+__global__ __launch_bounds__(NTHR) void k_minmax_stats(BatchC batch, int N, int C, int R, u64* ws, size_t ws_stride) {
+    minmax_stats_body<false>(batch.it[blockIdx.z], N, C, R, blockIdx.x, blockIdx.y, (unsigned*)(ws + (size_t)blockIdx.z * ws_stride));
 }
 
 __device__ __forceinline__ h16 hdiv(h16 a, h16 b) { return (h16)((float)a / (float)b); }   // correctly rounded fp16 quotient
 __device__ __forceinline__ h16 hrint(h16 a) { return __builtin_rintf16(a); }                // round half to even (torch.round)
 __device__ __forceinline__ bool hisnan(h16 a) { return a != a; }
+
+// int4 : scale = fp16(fp16(max-min)/15.000001f), min                              compress_quantize.py:556-558
+// int8 : scale = fp16(fp16(max-min)/255.0f), zp = clamp(-128 - round(min/scale)) -> int16          :455-463
+__device__ __forceinline__ void minmax_write_scales(const cfx_comp_item& it, int N, int C, int codec, int c, h16 mn, h16 mx) {
+    const h16 rng = mx - mn;
+    if (codec == CFX_CODEC_INT4) {
+        h16* S = (h16*)((char*)it.packet + (size_t)(N / 2) * C);
+        S[c] = (h16)((float)rng / 15.000001f);
+        S[C + c] = mn;
+    } else {
+        h16* S = (h16*)((char*)it.packet + (size_t)N * C);
+        short* Z = (short*)(S + C);
+        const h16 scale = (h16)((float)rng / 255.000001f);
+        const h16 r = hrint(hdiv(mn, scale));
+        h16 z = (h16)-128.0f - r;
+        short zi;
+        if (hisnan(z)) zi = 0;
+        else {
+            z = z < (h16)-128.0f ? (h16)-128.0f : z;
+            z = z > (h16)127.0f ? (h16)127.0f : z;
+            zi = (short)(float)z;
+        }
+        S[c] = scale;
+        Z[c] = zi;
+    }
+}
 
 // finalize int4 : scale = fp16(fp16(max-min)/15.000001f), min                     compress_quantize.py:556-558
 //          int8 : scale = fp16(fp16(max-min)/255.0f), zp = clamp(-128 - round(min/scale)) -> int16   :455-463
@@ -592,27 +851,50 @@ __global__ __launch_bounds__(1024) void k_minmax_finalize(BatchC batch, int N, i
         mn = a < mn ? a : mn;
         mx = b > mx ? b : mx;
     }
-    const h16 rng = mx - mn;
-    if (codec == CFX_CODEC_INT4) {
-        h16* S = (h16*)((char*)it.packet + (size_t)(N / 2) * C);
-        S[c] = (h16)((float)rng / 15.000001f);
-        S[C + c] = mn;
-    } else {
-        h16* S = (h16*)((char*)it.packet + (size_t)N * C);
-        short* Z = (short*)(S + C);
-        const h16 scale = (h16)((float)rng / 255.000001f);
-        const h16 r = hrint(hdiv(mn, scale));
-        h16 z = (h16)-128.0f - r;
-        short zi;
-        if (hisnan(z)) zi = 0;
-        else {
-            z = z < (h16)-128.0f ? (h16)-128.0f : z;
-            z = z > (h16)127.0f ? (h16)127.0f : z;
-            zi = (short)(float)z;
+    minmax_write_scales(it, N, C, codec, c, mn, mx);
+}
+
+// Compress statistics + in-launch finalize for the per-channel min/max codecs (same ticket scheme as k_absmean_compress;
+// only the column-block tickets exist here: there is no row statistic).
+__global__ __launch_bounds__(NTHR) void k_minmax_compress(BatchC batch, int N, int C, int R, int CB, int P, int codec, u64* ws, size_t ws_stride,
+                                                          unsigned* tick0) {
+    const int per = CB * P;
+    const int z = blockIdx.x / per, rem = blockIdx.x - z * per;
+    const int by = rem / CB, bx = rem - by * CB;
+    const cfx_comp_item& it = batch.it[z];
+    unsigned* part = (unsigned*)(ws + (size_t)z * ws_stride);
+    unsigned* tick = tick0 + z * TICK_WORDS;
+    minmax_stats_body<true>(it, N, C, R, bx, by, part);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ unsigned flag;
+    if (threadIdx.x == 0) flag = __hip_atomic_fetch_add(tick + 1 + bx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (flag != (unsigned)(P - 1)) return;
+    // last arriver of column block bx: two columns per thread, FUSED_CH partials of both in flight per batch (unconditional
+    // loads with clamped indices: see fused_rows_finalize)
+    const int c0 = bx * TILE_C + threadIdx.x, c1 = c0 + NTHR;
+    const int cc0 = min(c0, C - 1), cc1 = min(c1, C - 1);
+    h16 mn0 = hfrom(0x7c00), mx0 = hfrom(0xfc00), mn1 = mn0, mx1 = mx0;
+    for (int p0 = 0; p0 < P; p0 += FUSED_CH) {
+        unsigned v0[FUSED_CH], v1[FUSED_CH];
+#pragma unroll
+        for (int j = 0; j < FUSED_CH; ++j) {
+            const size_t row = (size_t)min(p0 + j, P - 1) * C;      // a repeated partial does not change a min / max
+            v0[j] = ld_wt(&part[row + cc0]);
+            v1[j] = ld_wt(&part[row + cc1]);
         }
-        S[c] = scale;
-        Z[c] = zi;
+#pragma unroll
+        for (int j = 0; j < FUSED_CH; ++j) {
+            const h16 a0 = hfrom((u16)(v0[j] & 0xffff)), b0 = hfrom((u16)(v0[j] >> 16));
+            const h16 a1 = hfrom((u16)(v1[j] & 0xffff)), b1 = hfrom((u16)(v1[j] >> 16));
+            mn0 = a0 < mn0 ? a0 : mn0; mx0 = b0 > mx0 ? b0 : mx0;
+            mn1 = a1 < mn1 ? a1 : mn1; mx1 = b1 > mx1 ? b1 : mx1;
+        }
     }
+    if (c0 < C) minmax_write_scales(it, N, C, codec, c0, mn0, mx0);
+    if (c1 < C) minmax_write_scales(it, N, C, codec, c1, mn1, mx1);
+    if (threadIdx.x == 0) st_wt(tick + 1 + bx, 0u);
 }
 
 // int8 quantise (+EF)      compress_quantize.py:465-467 ; EF = dequantize_int8 :482 + main.py:232
@@ -1001,10 +1283,50 @@ cfx_ctx* cfx_create(int device) {
     c->prof = nullptr;
     c->prof_cap = c->prof_n = 0;
     c->prof_stride = 1;
-    c->prof_seen = 0;
+    memset(c->prof_seen, 0, sizeof(c->prof_seen));
     c->prof_mask = 0;
+    c->tick = nullptr;
+    c->tick_next = 0;
+    c->dbg_stamps = nullptr;
+    c->fused = 1;
+    const char* f = getenv("CFX_FUSED_FINALIZE");
+    if (f) c->fused = atoi(f) != 0;
+    const char* sr = getenv("CFX_STATS_ROWS");
+    c->stats_rows = sr ? atoi(sr) : 0;
     c->err[0] = 0;
     return c;
+}
+
+// Ticket blocks of the in-launch finalize: device memory owned by the context, zeroed ONCE here; every ticket word is
+// reset by the workgroup that draws its final value, so a block is clean again when its launch retires.
+int cfx_prepare(cfx_ctx* ctx) {
+    if (!ctx) return CFX_ERR_NULL;
+    if (ctx->tick) return CFX_OK;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != ctx->device && hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CFX_ERR_LAUNCH, "prepare: hipSetDevice failed");
+    const size_t bytes = (size_t)TICK_RING * CFX_MAX_BATCH * TICK_WORDS * sizeof(unsigned);
+    void* p = nullptr;
+    int rc = CFX_OK;
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        if (p) (void)hipFree(p);
+        rc = fail(ctx, CFX_ERR_LAUNCH, "prepare: cannot allocate the ticket blocks");
+    } else ctx->tick = (unsigned*)p;
+    if (cur >= 0 && cur != ctx->device) (void)hipSetDevice(cur);
+    return rc;
+}
+
+int cfx_debug_stamps(cfx_ctx* ctx, void* buf) {
+    if (!ctx) return CFX_ERR_NULL;
+    ctx->dbg_stamps = buf;
+    return CFX_OK;
+}
+
+int cfx_set_fused_finalize(cfx_ctx* ctx, int on) {
+    if (!ctx) return CFX_ERR_NULL;
+    ctx->fused = on != 0;
+    return CFX_OK;
 }
 
 static void prof_free(cfx_ctx* ctx) {
@@ -1017,13 +1339,14 @@ static void prof_free(cfx_ctx* ctx) {
 void cfx_destroy(cfx_ctx* ctx) {
     if (!ctx) return;
     prof_free(ctx);
+    if (ctx->tick) (void)hipFree(ctx->tick);
     delete ctx;
 }
 
 int cfx_profile_enable(cfx_ctx* ctx, int capacity, unsigned kernel_mask, int stride) {
     if (!ctx) return CFX_ERR_NULL;
     ctx->prof_stride = stride > 0 ? stride : 1;
-    ctx->prof_seen = 0;
+    memset(ctx->prof_seen, 0, sizeof(ctx->prof_seen));
     if (capacity > ctx->prof_cap) {
         prof_free(ctx);
         ctx->prof = new ProfRec[capacity];
@@ -1127,11 +1450,25 @@ int cfx_decompress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int b
     return check_launch(ctx, "decompress launch");
 }
 
-int cfx_compress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
-                       void* workspace, size_t workspace_bytes, void* stream) {
+// statistics tile height of the fused compress launch
+static int fused_rows(const cfx_ctx* ctx, int N, int C, int batch) {
+    if (ctx->stats_rows > 0) return (ctx->stats_rows + 15) & ~15;
+    // 8 waves x 4 rows in flight = 32 rows per wave step; taller tiles (fewer partials per column for the last arriver to
+    // reduce) as long as >= 768 workgroups remain, as in auto_rows
+    const int CB = (C + TILE_C - 1) / TILE_C;
+    const int cands[2] = {128, 64};
+    for (int i = 0; i < 2; ++i)
+        if ((long)CB * ((N + cands[i] - 1) / cands[i]) * batch >= 768) return cands[i];
+    return FUSED_NW * UNROLL_S;
+}
+
+int cfx_compress_batch_ex(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                          int n_ride, const cfx_decomp_item* ride, void* workspace, size_t workspace_bytes, void* stream) {
     if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "compress: null ctx/items");
     if (batch < 1 || batch > CFX_MAX_BATCH) return fail(ctx, CFX_ERR_BATCH, "compress: batch out of range");
     if (!shape_ok(codec, N, C, param)) return fail(ctx, codec >= 1 && codec <= 5 ? CFX_ERR_SHAPE : CFX_ERR_CODEC, "compress: bad codec/shape");
+    if (n_ride < 0 || n_ride > CFX_MAX_BATCH || (n_ride && !ride)) return fail(ctx, CFX_ERR_BATCH, "compress: ride-along batch out of range");
+    if (n_ride && codec != CFX_CODEC_BINARY) return fail(ctx, CFX_ERR_CODEC, "compress: ride-along reconstruction items need the 1-bit codec");
     const bool upd = flags & CFX_FLAG_UPDATE_CACHE;
     BatchC b;
     memset(&b, 0, sizeof(b));
@@ -1141,6 +1478,13 @@ int cfx_compress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int fla
         if (!AL16(items[i].x) || !AL16(items[i].base) || !AL16(items[i].new_base) || !AL16(items[i].packet))
             return fail(ctx, CFX_ERR_ALIGN, "compress: pointers must be 16-byte aligned");
         b.it[i] = items[i];
+    }
+    BatchD rd;
+    memset(&rd, 0, sizeof(rd));
+    for (int i = 0; i < n_ride; ++i) {
+        if (!ride[i].packet || !ride[i].recon) return fail(ctx, CFX_ERR_NULL, "compress: null ride-along packet/recon");
+        if (!AL16(ride[i].packet) || !AL16(ride[i].recon) || !AL16(ride[i].base)) return fail(ctx, CFX_ERR_ALIGN, "compress: pointers must be 16-byte aligned");
+        rd.it[i] = ride[i];
     }
     const size_t need = cfx_workspace_bytes(codec, N, C, param, batch);
     if (need && (!workspace || workspace_bytes < need)) return fail(ctx, CFX_ERR_WORKSPACE, "compress: workspace too small");
@@ -1162,17 +1506,51 @@ int cfx_compress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int fla
         return check_launch(ctx, "topk compress launch");
     }
 
-    const int R = auto_rows(ctx, N, C, batch, true);
+    // statistics + finalize: ONE launch with the in-launch finalize (default), or the two-kernel sequence
+    const bool fused = ctx->fused && CB < TICK_WORDS;
+    unsigned* tick = nullptr;
+    if (fused) {
+        if (!ctx->tick && cfx_prepare(ctx) != CFX_OK) return CFX_ERR_LAUNCH;
+        tick = ctx->tick + (size_t)(ctx->tick_next++ % TICK_RING) * CFX_MAX_BATCH * TICK_WORDS;
+    }
+    const int R = fused ? fused_rows(ctx, N, C, batch) : auto_rows(ctx, N, C, batch, true);
     const int P = (N + R - 1) / R;
     const dim3 grid(CB, P, batch);
+    const int Rq = auto_rows(ctx, N, C, batch, true);       // apply passes: same tile map as the (unfused) statistics pass
+    const dim3 gridq(CB, (N + Rq - 1) / Rq, batch);
     if (codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT2) {
-        if (codec == CFX_CODEC_BINARY) LAUNCH(ctx, KID_ABSMEAN_STATS_BITS, s, k_absmean_stats<true>, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
-        else LAUNCH(ctx, KID_ABSMEAN_STATS, s, k_absmean_stats<false>, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
         const int per_byte = codec == CFX_CODEC_BINARY ? 8 : 4;
-        LAUNCH(ctx, KID_ABSMEAN_FINALIZE, s, k_absmean_finalize, dim3(1 + (C + 255) / 256, batch), dim3(1024), 0, s, b, N, C, CB, P, per_byte,
-                           codec == CFX_CODEC_INT2 ? 1 : 0, (const u64*)ws, wstride);
+        if (fused) {
+            FusedArgs a;
+            memset(&a, 0, sizeof(a));
+            a.N = N; a.C = C; a.CB = CB; a.R = R; a.P = P;
+            a.n_st = CB * P * batch;
+            a.dq_R = FUSED_NW * UNROLL;
+            a.dq_rb = (N + a.dq_R - 1) / a.dq_R;
+            a.per_byte = per_byte; a.eps_mode = codec == CFX_CODEC_INT2 ? 1 : 0;
+            a.ws = ws; a.ws_stride = wstride; a.tick = tick;
+            { static const char* dbg_env = getenv("CFX_FUSED_DBG"); a.dbg = dbg_env ? atoi(dbg_env) : 0; }
+            a.stamps = (u64*)ctx->dbg_stamps;
+            const dim3 g(a.n_st + CB * a.dq_rb * n_ride);
+            if (codec == CFX_CODEC_BINARY) {
+                if (R % 32 == 0) LAUNCH(ctx, KID_ABSMEAN_COMPRESS_BITS, s, (k_absmean_compress<true, 4>), g, dim3(FUSED_NT), 0, s, b, rd, a);
+                else LAUNCH(ctx, KID_ABSMEAN_COMPRESS_BITS, s, (k_absmean_compress<true, 2>), g, dim3(FUSED_NT), 0, s, b, rd, a);
+            } else {
+                if (R % 32 == 0) LAUNCH(ctx, KID_ABSMEAN_COMPRESS, s, (k_absmean_compress<false, 4>), g, dim3(FUSED_NT), 0, s, b, rd, a);
+                else LAUNCH(ctx, KID_ABSMEAN_COMPRESS, s, (k_absmean_compress<false, 2>), g, dim3(FUSED_NT), 0, s, b, rd, a);
+            }
+        } else {
+            if (codec == CFX_CODEC_BINARY) LAUNCH(ctx, KID_ABSMEAN_STATS_BITS, s, k_absmean_stats<true>, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
+            else LAUNCH(ctx, KID_ABSMEAN_STATS, s, k_absmean_stats<false>, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
+            LAUNCH(ctx, KID_ABSMEAN_FINALIZE, s, k_absmean_finalize, dim3(1 + (C + 255) / 256, batch), dim3(1024), 0, s, b, N, C, CB, P, per_byte,
+                               codec == CFX_CODEC_INT2 ? 1 : 0, (const u64*)ws, wstride);
+            if (n_ride) {
+                const int Rr = auto_rows(ctx, N, C, n_ride, false);
+                LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant, dim3(CB, (N + Rr - 1) / Rr, n_ride), dim3(NTHR), 0, s, rd, N, C, Rr);
+            }
+        }
         if (codec == CFX_CODEC_INT2) {
-            LAUNCH(ctx, KID_INT2_QUANT, s, k_int2_quant, grid, dim3(NTHR), 0, s, b, N, C, R, flags);
+            LAUNCH(ctx, KID_INT2_QUANT, s, k_int2_quant, gridq, dim3(NTHR), 0, s, b, N, C, Rq, flags);
         } else if (upd) {
             if (flags & CFX_FLAG_NO_EF) {
                 for (int i = 0; i < batch; ++i)
@@ -1183,16 +1561,25 @@ int cfx_compress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int fla
                 BatchD d;
                 memset(&d, 0, sizeof(d));
                 for (int i = 0; i < batch; ++i) { d.it[i].packet = items[i].packet; d.it[i].base = items[i].base; d.it[i].recon = items[i].new_base; }
-                LAUNCH(ctx, KID_BINARY_EF, s, k_binary_dequant, grid, dim3(NTHR), 0, s, d, N, C, R);
+                LAUNCH(ctx, KID_BINARY_EF, s, k_binary_dequant, gridq, dim3(NTHR), 0, s, d, N, C, Rq);
             }
         }
     } else {
-        LAUNCH(ctx, KID_MINMAX_STATS, s, k_minmax_stats, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
-        LAUNCH(ctx, KID_MINMAX_FINALIZE, s, k_minmax_finalize, dim3((C + 255) / 256, batch), dim3(1024), 0, s, b, N, C, P, codec, (const u64*)ws, wstride);
-        if (codec == CFX_CODEC_INT4) LAUNCH(ctx, KID_INT4_QUANT, s, k_int4_quant, grid, dim3(NTHR), 0, s, b, N, C, R, flags);
-        else LAUNCH(ctx, KID_INT8_QUANT, s, k_int8_quant, grid, dim3(NTHR), 0, s, b, N, C, R, flags);
+        if (fused) {
+            LAUNCH(ctx, KID_MINMAX_COMPRESS, s, k_minmax_compress, dim3(CB * P * batch), dim3(NTHR), 0, s, b, N, C, R, CB, P, codec, ws, wstride, tick);
+        } else {
+            LAUNCH(ctx, KID_MINMAX_STATS, s, k_minmax_stats, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
+            LAUNCH(ctx, KID_MINMAX_FINALIZE, s, k_minmax_finalize, dim3((C + 255) / 256, batch), dim3(1024), 0, s, b, N, C, P, codec, (const u64*)ws, wstride);
+        }
+        if (codec == CFX_CODEC_INT4) LAUNCH(ctx, KID_INT4_QUANT, s, k_int4_quant, gridq, dim3(NTHR), 0, s, b, N, C, Rq, flags);
+        else LAUNCH(ctx, KID_INT8_QUANT, s, k_int8_quant, gridq, dim3(NTHR), 0, s, b, N, C, Rq, flags);
     }
     return check_launch(ctx, "compress launch");
+}
+
+int cfx_compress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    return cfx_compress_batch_ex(ctx, codec, N, C, param, flags, batch, items, 0, nullptr, workspace, workspace_bytes, stream);
 }
 
 int cfx_compress(cfx_ctx* ctx, int codec, const void* x, const void* base, void* new_base, void* packet, int N, int C, int param,
@@ -1230,7 +1617,8 @@ struct PlanOp {
     int kind;   // 0 compress, 1 decompress, 2 all-gather on the side stream, 3 main stream waits for gather op `ref`
     int codec, N, C, param, flags, batch;
     cfx_comp_item c[CFX_MAX_BATCH];
-    cfx_decomp_item d[CFX_MAX_BATCH];
+    cfx_decomp_item d[CFX_MAX_BATCH];     // kind 1: the items; kind 0: ride-along reconstruction items (n_ride of them)
+    int n_ride;
     void* ws;
     size_t ws_bytes;
     // kind 2 / 3
@@ -1300,17 +1688,26 @@ static PlanOp* plan_push(cfx_plan* p) {
     return &p->ops[p->n++];
 }
 
-int cfx_plan_add_compress(cfx_plan* p, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
-                          void* workspace, size_t workspace_bytes) {
+int cfx_plan_add_compress_ex(cfx_plan* p, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                             int n_ride, const cfx_decomp_item* ride, void* workspace, size_t workspace_bytes) {
     if (!p || !items) return CFX_ERR_NULL;
     if (batch < 1 || batch > CFX_MAX_BATCH) return fail(p->ctx, CFX_ERR_BATCH, "plan: batch out of range");
+    if (n_ride < 0 || n_ride > CFX_MAX_BATCH || (n_ride && !ride)) return fail(p->ctx, CFX_ERR_BATCH, "plan: ride-along batch out of range");
+    if (n_ride && codec != CFX_CODEC_BINARY) return fail(p->ctx, CFX_ERR_CODEC, "plan: ride-along reconstruction items need the 1-bit codec");
     if (!shape_ok(codec, N, C, param)) return fail(p->ctx, CFX_ERR_SHAPE, "plan: bad codec/shape");
     PlanOp* o = plan_push(p);
     memset(o, 0, sizeof(*o));
     o->kind = 0; o->codec = codec; o->N = N; o->C = C; o->param = param; o->flags = flags; o->batch = batch;
     memcpy(o->c, items, sizeof(cfx_comp_item) * batch);
+    o->n_ride = n_ride;
+    if (n_ride) memcpy(o->d, ride, sizeof(cfx_decomp_item) * n_ride);
     o->ws = workspace; o->ws_bytes = workspace_bytes;
     return p->n - 1;
+}
+
+int cfx_plan_add_compress(cfx_plan* p, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                          void* workspace, size_t workspace_bytes) {
+    return cfx_plan_add_compress_ex(p, codec, N, C, param, flags, batch, items, 0, nullptr, workspace, workspace_bytes);
 }
 
 int cfx_plan_add_decompress(cfx_plan* p, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items) {
@@ -1376,7 +1773,7 @@ int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) {
         PlanOp* o = &p->ops[i];
         int rc = CFX_OK;
         switch (o->kind) {
-            case 0: rc = cfx_compress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, o->ws, o->ws_bytes, stream); break;
+            case 0: rc = cfx_compress_batch_ex(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, o->n_ride, o->d, o->ws, o->ws_bytes, stream); break;
             case 1: rc = cfx_decompress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->batch, o->d, stream); break;
             case 2: {
                 // exchange stream picks up after everything enqueued so far on the main stream (the packets are complete)
@@ -1493,7 +1890,7 @@ int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
         const int ag0 = n_ag;
         while (i < end && p->ops[i].kind == 0) {
             const PlanOp* c = &p->ops[i];
-            if (c->codec != CFX_CODEC_BINARY || (c->flags & CFX_FLAG_UPDATE_CACHE)) { ok = false; break; }
+            if (c->codec != CFX_CODEC_BINARY || (c->flags & CFX_FLAG_UPDATE_CACHE) || c->n_ride) { ok = false; break; }
             if (L + k == 0) { N = c->N; C = c->C; }
             if (c->N != N || c->C != C) { ok = false; break; }
             ncomp += c->batch;

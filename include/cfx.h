@@ -108,6 +108,28 @@ int cfx_compress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int fla
 int cfx_decompress_batch(cfx_ctx* ctx, int codec, int N, int C, int param,
                          int batch, const cfx_decomp_item* items, void* stream);
 
+/* cfx_compress_batch plus `n_ride` reconstruction items of the SAME codec and shape (1-bit codec only) that are
+ * co-scheduled in the statistics launch: bandwidth work that does not depend on this call's scales - typically the previous
+ * layer's deferred error-feedback update (own packet applied to own state; the reference does it inside
+ * _binary_quant_fastpath, fastpath.py:88-120, but nothing reads that state before the next denoise step: the local
+ * attention block uses the uncompressed K,V, ring.py:207-209) - streams while the scale reduction, which is pure
+ * latency, completes.  The ride items must not alias this call's x / base / packet operands. */
+int cfx_compress_batch_ex(cfx_ctx* ctx, int codec, int N, int C, int param, int flags,
+                          int batch, const cfx_comp_item* items, int n_ride, const cfx_decomp_item* ride,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* The statistics pass of a compress call reduces its partial sums INSIDE the launch (last-arriving workgroups, ticket
+ * counters; replaces the eager scale prologue of fastpath.py:150-166 / compress_quantize.py:452-463 and the separate
+ * finalize kernel).  The tickets live in device memory owned by the context: cfx_prepare allocates them (idempotent;
+ * otherwise the first compress call does - call it before capturing compress calls into a hipGraph).  Compress calls
+ * on one context must be stream-ordered with respect to each other (one context per stream otherwise).
+ * cfx_set_fused_finalize(ctx, 0) selects the two-kernel sequence (statistics, finalize); results are bit-identical. */
+int cfx_prepare(cfx_ctx* ctx);
+int cfx_set_fused_finalize(cfx_ctx* ctx, int on);
+/* Developer hook: when `buf` is non-NULL every statistics workgroup of a compress launch writes 8 u64 words there (phase
+ * times on the 100 MHz wall clock + its last-arriver roles): tools/fused_stamps.py.  NULL switches it off. */
+int cfx_debug_stamps(cfx_ctx* ctx, void* buf);
+
 /* Single-tensor conveniences (batch of one). */
 int cfx_compress(cfx_ctx* ctx, int codec, const void* x, const void* base, void* new_base, void* packet,
                  int N, int C, int param, int flags, void* workspace, size_t workspace_bytes, void* stream);
@@ -139,7 +161,8 @@ int    cfx_lr_decompress_batch(cfx_ctx* ctx, int quantized, int N, int C, int ra
  * 12 int4_dequant, 13 topk_compress, 14 topk_decompress, 15 copy_probe, 16 binary_dequant launched as the
  * sender's error-feedback update, 17-22 low-rank chain (prep, aq, aty, chol, apply, decode), 23 binary_pipe (steady-state
  * fused launch of cfx_plan_run_pipelined), 24 binary_pipe prologue / epilogue / ragged-unit launches, 25 residual2_delta,
- * 26 residual2_update. */
+ * 26 residual2_update, 27 absmean_compress<bits> (statistics + sign bits + in-launch finalize [+ ride-along reconstruction]),
+ * 28 absmean_compress (2-bit statistics + in-launch finalize), 29 minmax_compress (int4 / int8 statistics + in-launch finalize). */
 int         cfx_profile_enable(cfx_ctx* ctx, int capacity, unsigned kernel_mask, int stride);
 int         cfx_profile_read(cfx_ctx* ctx, int* kernel_ids, float* ms, int cap);
 const char* cfx_kernel_name(int kernel_id);
@@ -153,6 +176,9 @@ cfx_plan* cfx_plan_create(cfx_ctx* ctx);
 void      cfx_plan_destroy(cfx_plan* plan);
 int       cfx_plan_add_compress(cfx_plan* plan, int codec, int N, int C, int param, int flags, int batch,
                                 const cfx_comp_item* items, void* workspace, size_t workspace_bytes);
+int       cfx_plan_add_compress_ex(cfx_plan* plan, int codec, int N, int C, int param, int flags, int batch,
+                                   const cfx_comp_item* items, int n_ride, const cfx_decomp_item* ride,
+                                   void* workspace, size_t workspace_bytes);   /* cfx_compress_batch_ex as a plan op */
 int       cfx_plan_add_decompress(cfx_plan* plan, int codec, int N, int C, int param, int batch,
                                   const cfx_decomp_item* items);
 /* Exchange ops.  An all-gather op is ordered after everything the plan enqueued on the main stream before it (the

@@ -340,3 +340,74 @@ def test_error_codes():
     mis = big[1:1 + 8 * 64].view(8, 64)               # 2-byte aligned only
     with pytest.raises(CfxError):
         K.compress(1, mis, None, 8, 64)
+
+
+# ---- in-launch finalize (last-arriver tickets, write-through partial sums) -------------------------------------------------
+@pytest.mark.parametrize("name,cid", [("binary", 1), ("int2", 2), ("int4", 3), ("int8", 4)])
+@pytest.mark.parametrize("shape,B", [((544, 3072), 2), ((64, 256), 16), ((130, 1024), 5), ((4448, 3072), 2), ((1024, 1152), 3), ((2, 512), 1)])
+def test_fused_finalize_equals_two_kernel_sequence_under_load(name, cid, shape, B):
+    """The compress launch reduces its partial sums inside the launch (tickets + write-through partials): every word of the
+    packets must equal the two-kernel sequence's and the oracle's, launch after launch (ticket blocks are recycled), with
+    another stream hammering HBM (uneven load) and the consumer's caches warm (the same workspace is re-read every launch)."""
+    from compactfusion_amd import codecs as K
+    N, C = shape
+    ins = [make_inputs(900 + 7 * i + N, N, C) for i in range(B)]
+    xd, bd = [dev(a) for a, _ in ins], [dev(b) for _, b in ins]
+    ph = K.packet_halves(cid, N, C, 0)
+
+    def packets():
+        return [torch.full((ph,), float("nan"), dtype=torch.float16, device="cuda") for _ in range(B)]
+
+    K.set_fused_finalize(False)
+    try:
+        want = packets()
+        K.compress_batch(cid, xd, bd, [None] * B, want, N, C, 0, update_cache=False)
+        torch.cuda.synchronize()
+    finally:
+        K.set_fused_finalize(True)
+    for i in (0, B - 1):
+        same_bits(host_bits(want[i]), R.residual_compress(name, ins[i][0], ins[i][1], 0)[0], f"{name} two-kernel packet vs oracle")
+    # background load on another stream: a big copy loop
+    side = torch.cuda.Stream()
+    junk_a = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    junk_b = torch.empty_like(junk_a)
+    reps = 40
+    got = [packets() for _ in range(reps)]
+    with torch.cuda.stream(side):
+        for _ in range(60):
+            junk_b.copy_(junk_a)
+    for r in range(reps):
+        K.compress_batch(cid, xd, bd, [None] * B, got[r], N, C, 0, update_cache=False)
+    torch.cuda.synchronize()
+    for r in range(reps):
+        for i in range(B):
+            assert torch.equal(got[r][i].view(torch.int16), want[i].view(torch.int16)), f"{name} launch {r} tensor {i}: fused finalize differs"
+
+
+def test_ride_along_reconstruction_in_the_compress_launch():
+    """cfx_compress_batch_ex: the previous layer's deferred error-feedback update rides in the statistics launch."""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    N, C = 544, 3072
+    ctx = K.context(0)
+    (x0, b0), (x1, b1) = make_inputs(1, N, C), make_inputs(2, N, C)
+    xd = [dev(x0), dev(x1)]
+    state = [dev(b0), dev(b1)]
+    pk = [torch.zeros(K.packet_halves(1, N, C), dtype=torch.float16, device="cuda") for _ in range(2)]
+    ws = K.workspace(1, N, C, 0, 1, 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    # layer 0: compress only (state untouched); layer 1: compress + layer 0's error-feedback update riding along
+    c0 = (_lib.CompItem * 1)(_lib.CompItem(xd[0].data_ptr(), state[0].data_ptr(), None, pk[0].data_ptr()))
+    assert lib.cfx_compress_batch_ex(ctx, 1, N, C, 0, 0, 1, c0, 0, None, ws.data_ptr(), ws.numel(), sh) == 0
+    c1 = (_lib.CompItem * 1)(_lib.CompItem(xd[1].data_ptr(), state[1].data_ptr(), None, pk[1].data_ptr()))
+    ride = (_lib.DecompItem * 1)(_lib.DecompItem(pk[0].data_ptr(), state[0].data_ptr(), state[0].data_ptr()))
+    assert lib.cfx_compress_batch_ex(ctx, 1, N, C, 0, 0, 1, c1, 1, ride, ws.data_ptr(), ws.numel(), sh) == 0
+    torch.cuda.synchronize()
+    p0, nb0 = R.residual_compress("binary", x0, b0, 0)
+    p1, _ = R.residual_compress("binary", x1, b1, 0)
+    same_bits(host_bits(pk[0]), p0, "layer 0 packet")
+    same_bits(host_bits(pk[1]), p1, "layer 1 packet")
+    same_bits(host_bits(state[0]), R.bits(nb0), "layer 0 state after the ride-along update")
+    same_bits(host_bits(state[1]), R.bits(b1), "layer 1 state untouched")
+    # a ride item with a codec other than 1-bit is refused
+    assert lib.cfx_compress_batch_ex(ctx, 2, N, C, 0, 0, 1, c1, 1, ride, ws.data_ptr(), ws.numel(), sh) == -4
