@@ -47,7 +47,9 @@ sys.path.insert(0, REPO)
 
 L_LAYERS, N_TOK, C_CH, W_LOGICAL = 57, 544, 3072, 8
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s float4-copy achievable)
-ALG_BYTES_PER_EL = {"compress": 6.125, "decompress": 4.125}   # 1-bit, SURVEY.md §8d
+ALG_BYTES = {"binary": {"compress": 6.125, "decompress": 4.125},   # SURVEY.md §8d, bytes per element
+             "int2": {"compress": 6.25, "decompress": 4.25}}
+ALG_BYTES_PER_EL = ALG_BYTES["binary"]
 
 
 def parse():
@@ -69,6 +71,9 @@ def parse():
     ap.add_argument("--gather-group", type=int, default=0,
                     help="N > 1, native exchange: layers (1..7) whose packets travel in ONE all-gather; 0 = 1 for the in-order replay "
                          "(a model has one layer's packets at a time), 7 for the pipelined replay")
+    ap.add_argument("--codec", choices=["binary", "int2"], default="binary",
+                    help="binary (default, the judged workload: BASELINE.json configs[2]); int2 = the reference's other fused preset "
+                         "(examples/configs.py:51-61), in-order replay only, reported as a secondary line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
     ap.add_argument("--no-secondary", action="store_true", help="skip the long run and the pipelined upper-bound leg")
@@ -81,18 +86,21 @@ def parse():
     ap.add_argument("--exchange", choices=["native", "torch"], default="native",
                     help="N>1: who issues the per-layer all-gather - libcfx's own RCCL communicator from the native plan "
                          "(one host call per step) or torch.distributed (one Python call per layer)")
+    ap.add_argument("--exchange-pattern", choices=["allgather", "relay"], default="allgather",
+                    help="N>1, in-order replay: one direct all-gather per layer (default; xGMI is a point-to-point mesh) or the "
+                         "reference's ring relay (W-1 grouped send/recv hops per layer, xfuser/compact/ring.py:193-195)")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="N>1: if the native exchange cannot be created or fails validation, fall back to torch.distributed "
                          "instead of exiting non-zero")
     ap.add_argument("--copy-probe", type=int, default=0,
                     help="also launch the 96 MiB float4 copy probe this many times before the timed region "
                          "(known byte count: calibrates FETCH_SIZE / WRITE_SIZE in PMC profiles)")
-    ap.add_argument("--event-stride", type=int, default=8,
+    ap.add_argument("--event-stride", type=int, default=29,
                     help="bracket every k-th launch of the profiled kernels with hipEvents (an event pair costs a few us of stream time)")
     return ap.parse_args()
 
 
-def cpu_baseline(seconds: float):
+def cpu_baseline(seconds: float, codec: str = "binary"):
     """C oracle on the host cores: one layer of the workload = 2 compress + 14 decompress at (544, 3072)."""
     import numpy as np
     from oracle import c_oracle as CO
@@ -102,12 +110,12 @@ def cpu_baseline(seconds: float):
     xs = [(base.astype(np.float32) + 0.1 * rng.standard_normal((N, C)).astype(np.float32)).astype(np.float16) for _ in range(2)]
     own = [base.copy().view(np.uint16) for _ in range(2)]
     peers = [base.copy().view(np.uint16) for _ in range(14)]
-    pk = [np.zeros(CO.load().oracle_packet_bytes(1, N, C, 0) // 2, dtype=np.uint16) for _ in range(2)]
+    pk = [np.zeros(CO.load().oracle_packet_bytes(1 if codec == "binary" else 2, N, C, 0) // 2, dtype=np.uint16) for _ in range(2)]
     def one_layer():
         for i in range(2):
-            CO.compress("binary", xs[i], own[i], N, C, packet=pk[i], new_base=own[i])
+            CO.compress(codec, xs[i], own[i], N, C, packet=pk[i], new_base=own[i])
         for j in range(14):
-            CO.decompress("binary", pk[j % 2], peers[j], N, C, out=peers[j])
+            CO.decompress(codec, pk[j % 2], peers[j], N, C, out=peers[j])
 
     one_layer()                                       # warm up (tables, threads, page faults)
     # thread count: the box may report more hardware threads than it schedules for us; take the fastest of a short sweep
@@ -132,7 +140,7 @@ def cpu_baseline(seconds: float):
             break
     act_bytes = reps * 16 * N * C * 2
     return {"value": round(act_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": best_t, "kind": "port",
-            "sample": f"{reps} x one layer of the workload (2 compress + 14 decompress, 1-bit, (544,3072) fp16) in {dt:.1f} s, "
+            "sample": f"{reps} x one layer of the workload (2 compress + 14 decompress, {'1-bit' if codec == 'binary' else '2-bit'}, (544,3072) fp16) in {dt:.1f} s, "
                       f"C oracle oracle/cfx_oracle.c with OpenMP ({best_t} of {most} threads: fastest of a sweep; "
                       f"{'F16C conversions' if CO.load().oracle_uses_f16c() else 'software fp16 conversions'})"}
 
@@ -173,8 +181,17 @@ def main():
     live = world                       # live ranks in the logical ring of 8
     assert live <= W_LOGICAL
     pipelined = args.replay == "pipelined"
+    int2 = args.codec == "int2"
+    if int2 and pipelined:
+        raise SystemExit("--codec int2 runs the in-order replay only (the cross-layer pipeline is 1-bit only)")
+    global ALG_BYTES_PER_EL
+    ALG_BYTES_PER_EL = ALG_BYTES[args.codec]
     G = args.gather_group if args.gather_group > 0 else (7 if pipelined else 1)
     G = max(1, min(7, G))
+
+    relay = args.exchange_pattern == "relay"
+    if relay and (pipelined or G != 1):
+        raise SystemExit("--exchange-pattern relay is an in-order, one-layer-per-exchange schedule")
 
     from compactfusion_amd import _lib, codecs as K
     lib = _lib.load()
@@ -183,7 +200,7 @@ def main():
         K.set_rows_per_tile(args.rows, local_rank)
 
     L, N, C = args.layers, N_TOK, C_CH
-    CODEC = int(K.Codec.BINARY)
+    CODEC = int(K.Codec.INT2 if int2 else K.Codec.BINARY)
     pkt_bytes = K.packet_bytes(CODEC, N, C)
     slot = (pkt_bytes + 255) // 256 * 256          # per-tensor slot in the exchange buffer, 256-B aligned
     # ---- resident state and inputs --------------------------------------------------------------------------
@@ -219,7 +236,10 @@ def main():
         """Packet of logical peer p for layer l: a real rank's slot of the gathered buffer, or (looped-back peer) our own packet
         - taken from OUR slot of the gathered buffer when there is one, so a collective's result is consumed even with one live rank."""
         if gathered:
-            r = (rank + 1 + p) % live if (live > 1 and p < live - 1) else rank
+            real = live > 1 and p < live - 1
+            if relay and not real:
+                return send[l, kv].data_ptr()          # the relay never writes our own slot of the receive area
+            r = (rank + 1 + p) % live if real else rank
             return grecv.data_ptr() + group_recv_offset(l, r, kv, G, L, live, slot)
         if live > 1 and p < live - 1:
             return recv[l, (rank + 1 + p) % live, kv].data_ptr()
@@ -240,13 +260,36 @@ def main():
 
     def add_layer(plan, s_, l, ride, gathered, comm=None):
         """Layer l of the in-order schedule: A = compress (+ previous layer's own EF riding along), X = all-gather, B = reconstruct."""
+        if int2:
+            # 2-bit: the codes depend on the scales, so compress = statistics + in-launch finalize, then quantise + error feedback
+            # (in place on the rank's own state); the reconstruction launch carries the 7 peers' K,V
+            carr = comp_items(s_, l)
+            for kv in range(2):
+                carr[kv].new_base = own_base[l, kv].data_ptr()
+            rc = lib.cfx_plan_add_compress(plan, CODEC, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, carr, ws.data_ptr(), ws_bytes)
+            assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
+            if comm is not None:
+                assert lib.cfx_plan_add_all_gather(plan, comm, send[l].data_ptr(), grecv.data_ptr() + l * live * 2 * slot, 2 * slot) >= 0
+            items = peer_items(l, gathered)
+            assert lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, len(items), (_lib.DecompItem * len(items))(*items)) >= 0
+            return
         if ride and l > 0:
             rd = (_lib.DecompItem * 2)(*own_ef_items(l - 1))
             rc = lib.cfx_plan_add_compress_ex(plan, CODEC, N, C, 0, 0, 2, comp_items(s_, l), 2, rd, ws.data_ptr(), ws_bytes)
         else:
             rc = lib.cfx_plan_add_compress(plan, CODEC, N, C, 0, 0, 2, comp_items(s_, l), ws.data_ptr(), ws_bytes)
         assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
-        if comm is not None:
+        if comm is not None and relay:
+            # ring relay: hop h moves what arrived at hop h-1 (hop 0: our own packets) to rank+1; after hop h the region
+            # [rank - h - 1] of the layer's receive area holds that rank's K,V packets - the same layout an all-gather leaves
+            base_ptr = grecv.data_ptr() + l * live * 2 * slot
+            src = send[l].data_ptr()
+            for h in range(live - 1):
+                dst = base_ptr + ((rank - h - 1) % live) * 2 * slot
+                rc = lib.cfx_plan_add_ring_hop(plan, comm, src, dst, 2 * slot)
+                assert rc >= 0, rc
+                src = dst
+        elif comm is not None:
             rc = lib.cfx_plan_add_all_gather(plan, comm, send[l].data_ptr(), grecv.data_ptr() + l * live * 2 * slot, 2 * slot)
             assert rc >= 0, rc
         items = peer_items(l, gathered)
@@ -266,10 +309,11 @@ def main():
             plan = lib.cfx_plan_create(ctx)
             for l in range(L):
                 add_layer(plan, s_, l, ride if kind == "inorder" else False, False)
+            assert lib.cfx_plan_finalize(plan) == 0
             built.append(plan)
         return built
     plans_inorder = build_plans("inorder")
-    plans_pipe = build_plans("pipelined")
+    plans_pipe = None if int2 else build_plans("pipelined")
     plans = plans_pipe if pipelined else plans_inorder
 
     compute = torch.cuda.current_stream(dev)
@@ -307,6 +351,7 @@ def main():
                                 for l in range(a, b):
                                     items = own_ef_items(l) + peer_items(l, True)
                                     assert lib.cfx_plan_add_decompress(sp, CODEC, N, C, 0, 16, (_lib.DecompItem * 16)(*items)) >= 0
+                        assert lib.cfx_plan_finalize(sp) == 0
                         built.append(sp)
                     return built
                 stream_mode = {"main": 0, "side": 1, "prio": 2}[args.exchange_stream] if pipelined else 0
@@ -412,7 +457,7 @@ def main():
     # ---- timed region -------------------------------------------------------------------------------------------
     # profiled kernels: in-order replay: k_binary_dequant (4, launch B, dominant) and k_absmean_compress<bits> (27, launch A);
     # pipelined replay: the fused k_binary_pipe (23: full three-group launches; 24: prologue / epilogue / ragged launches)
-    KIDS = (23, 24) if pipelined else (4, 27)
+    KIDS = (23, 24) if pipelined else ((6, 28, 5) if int2 else (4, 27))
     prof_cap = (args.steps * 2 * L) // max(1, args.event_stride) + 64
     if not args.no_kernel_events:
         mask = 0
@@ -462,7 +507,7 @@ def main():
         base_step = steps_run
         long_ms = timed_leg(args.long_steps, lambda i: one_step(base_step + i))
         steps_run += args.long_steps
-        if not use_dist:
+        if not use_dist and not int2:
             other = plans_inorder if pipelined else plans_pipe
             other_run = lib.cfx_plan_run if pipelined else lib.cfx_plan_run_pipelined
             base_step = steps_run
@@ -520,20 +565,23 @@ def main():
         "dtype": "f16",
         "data": "synthetic",
         "config": {
-            "workload": "FLUX.1-dev 1024x1024 ring-attention SP degree 8 (logical), 1-bit residual + error feedback: per rank per step "
+            "workload": f"FLUX.1-dev 1024x1024 ring-attention SP degree 8 (logical), {'2' if int2 else '1'}-bit residual + error feedback: per rank per step "
                         f"{L} layers x (compress K,V + reconstruct 7 peers' K,V), shard (544,3072) fp16, layer by layer in order; "
                         f"{live} live rank(s), {W_LOGICAL - live} peer(s) looped back",
-            "codec": "BINARY(1-bit, comp_rank=-1)", "layers": L, "shard": [N, C], "logical_ring": W_LOGICAL,
+            "codec": "INT2(2-bit fastpath)" if int2 else "BINARY(1-bit, comp_rank=-1)", "layers": L, "shard": [N, C], "logical_ring": W_LOGICAL,
             "packet_bytes": pkt_bytes, "raw_bytes": N * C * 2,
         },
         "exchange_ms_per_step": round(ms_per_step, 4),
         "exchange_issued_by": exchange_mode,
+        "exchange_pattern": (args.exchange_pattern if use_dist else None),
         "replay": args.replay,
         "schedule": ("cross-layer software pipeline (NOT deployable: needs every layer's K,V resident)" if pipelined else
+                     ("layer by layer in order (deployable): per layer A1 = statistics + in-launch finalize of own K,V, A2 = quantise + error "
+                      "feedback, X = exchange, B = reconstruct 7 peers' K,V") if int2 else
                      "layer by layer in order (deployable): per layer A = compress K,V [statistics + sign bits + in-launch finalize"
                      + (" + previous layer's own error-feedback update riding along" if ride else "") + "], X = exchange, B = reconstruct "
                      + ("7 peers' K,V" if ride else "own + 7 peers' K,V")),
-        "launches_per_layer": None if pipelined else 2,
+        "launches_per_layer": None if pipelined else (3 if int2 else 2),
         "inorder_ms_per_step": None if inorder_ms is None else round(inorder_ms, 4),
         "pure_exchange_upper_bound": None if pipe_ms is None else {
             "ms_per_step": round(pipe_ms, 4),
@@ -563,7 +611,7 @@ def main():
     step_obj = {"algorithmic_bytes": int(step_alg), "achieved": round(step_alg / (ms_per_step * 1e-3) / 1e9, 1), "unit": "GB/s",
                 "frac": round(step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "floor_ms_at_peak": round(step_alg / (HBM_PEAK_GBS * 1e9) * 1e3, 4)}
-    dom = 23 if pipelined else 4
+    dom = 23 if pipelined else (6 if int2 else 4)
     if dom in kern_us:
         us, n_samples = kern_us[dom]
         if pipelined:
@@ -577,6 +625,9 @@ def main():
             alg = (ALG_BYTES_PER_EL["decompress"] * 14 + ALG_BYTES_PER_EL["compress"] * 2) * ul * EL
             kname = (f"k_binary_pipe (one launch = {ul} layers: dequant+add of {16 * ul} tensors x (544,3072) + finalize of the next {ul} "
                      f"layers' K,V scales + stats/sign bits of the {ul} layers after those)")
+        elif int2:
+            alg = ALG_BYTES_PER_EL["decompress"] * 14 * EL
+            kname = "k_int2_dequant (launch B: 7 peers K,V = 14 tensors x (544,3072) per launch)"
         else:
             n_t = (14 * (L - 1) + 16) / L if ride else 16.0     # tensors per launch B, averaged over the step's launches
             alg = ALG_BYTES_PER_EL["decompress"] * n_t * EL
@@ -587,6 +638,11 @@ def main():
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            "traffic": None, "traffic_source": None, "avg_launch_us": round(us, 3), "algorithmic_bytes_per_launch": int(alg),
                            "event_samples": n_samples, "event_stride": args.event_stride, "step": step_obj}
+        if int2 and 28 in kern_us and 5 in kern_us:
+            out["roofline"]["compress_launches"] = {
+                "k_absmean_compress (A1: statistics + in-launch finalize)": round(kern_us[28][0], 3),
+                "k_int2_quant (A2: codes + error feedback, own K,V)": round(kern_us[5][0], 3), "unit": "us",
+                "algorithmic_bytes_per_layer": int(ALG_BYTES_PER_EL["compress"] * 2 * EL)}
         if not pipelined and 27 in kern_us:
             usa, na = kern_us[27]
             # launch A: the rank's own K,V - compress now, error feedback of the previous layer riding along: 6.125 B/el algorithmic
@@ -599,7 +655,7 @@ def main():
                 "note": "latency-bound: a global reduction (scales) sits between reading K,V and the packet being complete"}
         # PMC traffic / rocprof cross-reference: only when the committed profile was taken with THIS configuration
         prof = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
-        cfg_key = {"replay": args.replay, "own_ef": args.own_ef if not pipelined else None, "layers": L, "shard": [N, C],
+        cfg_key = {"codec": args.codec, "replay": args.replay, "own_ef": args.own_ef if not pipelined else None, "layers": L, "shard": [N, C],
                    "rows": args.rows, "n_gpus": live}
         if os.path.exists(prof):
             try:
@@ -627,7 +683,7 @@ def main():
                            "frac": step_obj["frac"], "traffic": None, "step": step_obj}
     if rank == 0 and live == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.codec)
         except Exception as e:  # pragma: no cover
             out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         if not use_dist:
@@ -642,7 +698,7 @@ def main():
                 pk = np.zeros(pkt_bytes // 2, dtype=np.uint16)
                 ins = [xs[s][l, kv].cpu().numpy() for s in range(2)]
                 for t in range(steps_run):
-                    CO.compress("binary", ins[t & 1], state, N, C, packet=pk, new_base=state)
+                    CO.compress(args.codec, ins[t & 1], state, N, C, packet=pk, new_base=state)
                 for name, got in (("sender state", own_base[l, kv]), ("looped-back peer state", peer_base[l, W_LOGICAL - 2, kv])):
                     if not np.array_equal(got.cpu().numpy().view(np.uint16), state):
                         raise RuntimeError(f"parity spot check failed: layer {l} {'KV'[kv]} {name} differs from the C oracle after {steps_run} steps")

@@ -72,6 +72,9 @@ SYMBOLS = [
     ("cfx_plan_set_exchange_stream", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_plan_add_all_gather", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     ("cfx_plan_add_wait", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_plan_add_ring_hop", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    ("cfx_plan_set_input", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    ("cfx_comm_ring_hop", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_rccl_load", ctypes.c_int, [ctypes.c_char_p]),
     ("cfx_comm_unique_id", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     ("cfx_comm_create", ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
@@ -81,6 +84,7 @@ SYMBOLS = [
     ("cfx_plan_size", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_plan_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     ("cfx_plan_run_pipelined", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    ("cfx_plan_finalize", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_residual2_delta", ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_residual2_update", ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_copy_probe", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

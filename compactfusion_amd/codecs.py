@@ -82,11 +82,15 @@ def packet_halves(codec: int, N: int, C: int, param: int = 0) -> int:
     return b // 2
 
 
-def workspace(codec: int, N: int, C: int, param: int, batch: int, device: int) -> Optional[torch.Tensor]:
+def workspace(codec: int, N: int, C: int, param: int, batch: int, device: int,
+              stream_handle: Optional[int] = None) -> Optional[torch.Tensor]:
+    """Statistics workspace of a compress call, one per (device, stream): calls on different streams may run concurrently
+    and must not share partial sums.  `stream_handle` = the stream the call will be launched on (default: the current one)."""
     need = _lib.load().cfx_workspace_bytes(int(codec), N, C, param, batch)
     if need == 0:
         return None
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    sh = torch.cuda.current_stream(device).cuda_stream if stream_handle is None else stream_handle
+    key = (device, sh)
     w = _ws.get(key)
     if w is None or w.numel() < need:
         w = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=f"cuda:{device}")
@@ -128,10 +132,11 @@ def compress_batch(codec: int, xs: Sequence[torch.Tensor], bases: Sequence[Optio
         _device_index(packets[i])
         items[i] = CompItem(_ptr(xs[i]), _ptr(bases[i]), _ptr(new_bases[i]), _ptr(packets[i]))
     flags = (FLAG_UPDATE_CACHE if update_cache else 0) | (0 if ef else FLAG_NO_EF)
+    sh = _stream_handle(stream, dev)
     if ws is None:
-        ws = workspace(codec, N, C, param, B, dev)
+        ws = workspace(codec, N, C, param, B, dev, sh)
     rc = _lib.load().cfx_compress_batch(ctx, int(codec), N, C, param, flags, B, items,
-                                        _ptr(ws), 0 if ws is None else ws.numel(), _stream_handle(stream, dev))
+                                        _ptr(ws), 0 if ws is None else ws.numel(), sh)
     _check(ctx, rc, "cfx_compress_batch")
 
 
@@ -175,10 +180,10 @@ def prepare_compress(codec: int, bases: Sequence[Optional[torch.Tensor]], new_ba
         _device_index(packets[i])
         items[i] = CompItem(None, _ptr(bases[i]), _ptr(new_bases[i]) if update_cache else None, _ptr(packets[i]))
     flags = (FLAG_UPDATE_CACHE if update_cache else 0) | (0 if ef else FLAG_NO_EF)
-    ws = workspace(codec, N, C, param, B, dev)
     fn = _lib.load().cfx_compress_batch
-    keep = (list(bases), list(new_bases), list(packets), ws)
-    ws_ptr, ws_len, codec = _ptr(ws), (0 if ws is None else ws.numel()), int(codec)
+    keep = (list(bases), list(new_bases), list(packets))
+    codec = int(codec)
+    ws_by_stream = {}        # the workspace belongs to the stream the call is launched on, looked up at call time
 
     def run(xs: Sequence[torch.Tensor], stream_handle: Optional[int] = None) -> None:
         assert len(xs) == B and keep
@@ -186,7 +191,11 @@ def prepare_compress(codec: int, bases: Sequence[Optional[torch.Tensor]], new_ba
             _check_nc(xs[i], N, C, "x")
             items[i].x = xs[i].data_ptr()
         sh = torch.cuda.current_stream(dev).cuda_stream if stream_handle is None else stream_handle
-        _check(ctx, fn(ctx, codec, N, C, param, flags, B, items, ws_ptr, ws_len, sh), "cfx_compress_batch")
+        w = ws_by_stream.get(sh)
+        if w is None:
+            ws = workspace(codec, N, C, param, B, dev, sh)
+            w = ws_by_stream[sh] = (ws, _ptr(ws), 0 if ws is None else ws.numel())
+        _check(ctx, fn(ctx, codec, N, C, param, flags, B, items, w[1], w[2], sh), "cfx_compress_batch")
     return run
 
 

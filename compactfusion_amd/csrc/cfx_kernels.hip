@@ -1604,13 +1604,21 @@ struct RcclApi {
     int (*AllGather)(const void*, void*, size_t, int, cfx_nccl_comm, hipStream_t);
     int (*CommDestroy)(cfx_nccl_comm);
     const char* (*GetErrorString)(int);
+    int (*Send)(const void*, size_t, int, int, cfx_nccl_comm, hipStream_t);
+    int (*Recv)(void*, size_t, int, int, cfx_nccl_comm, hipStream_t);
+    int (*GroupStart)(void);
+    int (*GroupEnd)(void);
+    char path[512];
 };
-static RcclApi g_rccl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+// The ONLY process-global state besides what hangs off a cfx_ctx (documented in cfx.h): the entry points of the collective
+// library most recently loaded by cfx_rccl_load.  A communicator keeps its own copy of the table it was created with.
+static RcclApi g_rccl = {};
 
 struct cfx_comm {
     cfx_ctx* ctx;
     cfx_nccl_comm comm;
     int nranks, rank;
+    RcclApi api;
 };
 
 struct PlanOp {
@@ -1629,6 +1637,8 @@ struct PlanOp {
     hipEvent_t ev_pre, ev_done;
     int ref;
 };
+struct PipeSched;
+static void sched_free(PipeSched* sc);
 struct cfx_plan {
     cfx_ctx* ctx;
     PlanOp* ops;
@@ -1637,6 +1647,7 @@ struct cfx_plan {
     int side_mode;        // 0: issue collectives on the main stream (no cross-stream events), 1: side stream, 2: prioritised side stream
     void* pipe_ws;        // cfx_plan_run_pipelined: two statistics workspaces of CFX_MAX_BATCH tensors each (stats of unit
     size_t pipe_ws_bytes; //   t runs beside the finalize of unit t-1)
+    PipeSched* sched;          // unit schedule of the pipelined replay, built once (cfx_plan_finalize or the first replay of a range)
 };
 
 cfx_plan* cfx_plan_create(cfx_ctx* ctx) {
@@ -1648,6 +1659,7 @@ cfx_plan* cfx_plan_create(cfx_ctx* ctx) {
     p->side = nullptr;
     p->pipe_ws = nullptr;
     p->pipe_ws_bytes = 0;
+    p->sched = nullptr;
     // Default: collectives in order on the main stream.  Measured on MI355X / ROCm 7: one cross-stream event hop costs
     // ~10 us of idle queue time, two per layer (main->side, side->main) = +1.1 ms per 57-layer step, whereas the
     // in-order exchange adds 0.1 ms; a side stream only pays when >> 20 us of independent work can overlap (attention).
@@ -1672,6 +1684,7 @@ void cfx_plan_destroy(cfx_plan* p) {
     }
     if (p->side) (void)hipStreamDestroy(p->side);
     if (p->pipe_ws) (void)hipFree(p->pipe_ws);
+    sched_free(p->sched);
     delete[] p->ops;
     delete p;
 }
@@ -1734,8 +1747,21 @@ int cfx_plan_copy_op(cfx_plan* dst, const cfx_plan* src, int op) {
     return dst->n - 1;
 }
 
+static int plan_exchange_stream(cfx_plan* p);
 int cfx_plan_add_all_gather(cfx_plan* p, cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank) {
     if (!p || !comm || !send || !recv) return CFX_ERR_NULL;
+    const int rs = plan_exchange_stream(p);
+    if (rs != CFX_OK) return rs;
+    PlanOp* o = plan_push(p);
+    memset(o, 0, sizeof(*o));
+    o->kind = 2; o->comm = comm; o->send = send; o->recv = recv; o->bytes_per_rank = bytes_per_rank;
+    if (hipEventCreateWithFlags(&o->ev_pre, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&o->ev_done, hipEventDisableTiming) != hipSuccess)
+        return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot create events");
+    return p->n - 1;
+}
+
+static int plan_exchange_stream(cfx_plan* p) {
     if (!p->side && p->side_mode != 0) {
         hipError_t e;
         if (p->side_mode == 2) {
@@ -1747,22 +1773,51 @@ int cfx_plan_add_all_gather(cfx_plan* p, cfx_comm* comm, const void* send, void*
         }
         if (e != hipSuccess) return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot create the exchange stream");
     }
+    return CFX_OK;
+}
+
+int cfx_plan_add_ring_hop(cfx_plan* p, cfx_comm* comm, const void* send, void* recv, size_t bytes) {
+    if (!p || !comm || !send || !recv) return CFX_ERR_NULL;
+    const int rs = plan_exchange_stream(p);
+    if (rs != CFX_OK) return rs;
     PlanOp* o = plan_push(p);
     memset(o, 0, sizeof(*o));
-    o->kind = 2; o->comm = comm; o->send = send; o->recv = recv; o->bytes_per_rank = bytes_per_rank;
+    o->kind = 4; o->comm = comm; o->send = send; o->recv = recv; o->bytes_per_rank = bytes;
     if (hipEventCreateWithFlags(&o->ev_pre, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&o->ev_done, hipEventDisableTiming) != hipSuccess)
         return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot create events");
     return p->n - 1;
 }
 
+int cfx_plan_set_input(cfx_plan* p, int op, int item, const void* x) {
+    if (!p || !x) return CFX_ERR_NULL;
+    if (op < 0 || op >= p->n || p->ops[op].kind != 0 || item < 0 || item >= p->ops[op].batch)
+        return fail(p->ctx, CFX_ERR_BATCH, "plan: set_input needs a compress op and an item of its batch");
+    if (!AL16(x)) return fail(p->ctx, CFX_ERR_ALIGN, "plan: pointers must be 16-byte aligned");
+    p->ops[op].c[item].x = x;
+    return CFX_OK;
+}
+
 int cfx_plan_add_wait(cfx_plan* p, int gather_op) {
     if (!p) return CFX_ERR_NULL;
-    if (gather_op < 0 || gather_op >= p->n || p->ops[gather_op].kind != 2) return fail(p->ctx, CFX_ERR_BATCH, "plan: wait target is not an all-gather op");
+    if (gather_op < 0 || gather_op >= p->n || (p->ops[gather_op].kind != 2 && p->ops[gather_op].kind != 4))
+        return fail(p->ctx, CFX_ERR_BATCH, "plan: wait target is not an exchange op");
     PlanOp* o = plan_push(p);
     memset(o, 0, sizeof(*o));
     o->kind = 3; o->ref = gather_op;
     return p->n - 1;
+}
+
+// One hop of the ring relay (reference xfuser/compact/ring.py:193-195: RingComm.send_recv + commit): send `bytes` to rank+1,
+// receive `bytes` from rank-1, as one grouped pair on `s`.
+static int ring_hop(cfx_comm* c, const void* send, void* recv, size_t bytes, hipStream_t s) {
+    if (!c->api.Send || !c->api.Recv || !c->api.GroupStart || !c->api.GroupEnd) return -1;
+    const int nxt = (c->rank + 1) % c->nranks, prv = (c->rank + c->nranks - 1) % c->nranks;
+    int r = c->api.GroupStart();
+    if (r == 0) r = c->api.Send(send, bytes, /*ncclUint8*/ 1, nxt, c->comm, s);
+    if (r == 0) r = c->api.Recv(recv, bytes, 1, prv, c->comm, s);
+    const int e = c->api.GroupEnd();
+    return r ? r : e;
 }
 
 int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) {
@@ -1775,15 +1830,19 @@ int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) {
         switch (o->kind) {
             case 0: rc = cfx_compress_batch_ex(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, o->n_ride, o->d, o->ws, o->ws_bytes, stream); break;
             case 1: rc = cfx_decompress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->batch, o->d, stream); break;
-            case 2: {
+            case 2:
+            case 4: {
                 // exchange stream picks up after everything enqueued so far on the main stream (the packets are complete)
                 hipStream_t xs = p->side_mode ? p->side : main_s;
                 if (p->side_mode && (hipEventRecord(o->ev_pre, main_s) != hipSuccess || hipStreamWaitEvent(p->side, o->ev_pre, 0) != hipSuccess))
                     return fail(p->ctx, CFX_ERR_LAUNCH, "plan: event ordering failed");
-                const int r = g_rccl.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, xs);
+                int r;
+                if (o->kind == 2) r = o->comm->api.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, xs);
+                else r = ring_hop(o->comm, o->send, o->recv, o->bytes_per_rank, xs);
                 if (r != 0) {
                     char buf[200];
-                    snprintf(buf, sizeof(buf), "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
+                    snprintf(buf, sizeof(buf), "%s: %s", o->kind == 2 ? "ncclAllGather" : "ring hop (ncclSend/ncclRecv)",
+                             o->comm->api.GetErrorString ? o->comm->api.GetErrorString(r) : "error");
                     return fail(p->ctx, CFX_ERR_LAUNCH, buf);
                 }
                 if (p->side_mode && hipEventRecord(o->ev_done, p->side) != hipSuccess) return fail(p->ctx, CFX_ERR_LAUNCH, "plan: event record failed");
@@ -1813,6 +1872,20 @@ int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) {
 // code per group of workgroups).  The statistics workspaces are plan-owned (two, alternating by unit); the ops' own
 // workspaces are not used here.  A group too large for one unit, or any other op sequence, is replayed by cfx_plan_run.
 struct PipeUnit { int first_layer, n_layers, n_comp_items, n_dq_items; };
+// The recognised schedule of an op range: built once per plan and range, replayed without host allocations, environment
+// lookups or device allocations.
+struct PipeSched {
+    int first_op, n_ops, n_plan_ops;      // the range it was built for (and the plan size at that time)
+    bool ok;                              // false: the range is not a sequence of 1-bit groups -> cfx_plan_run replays it
+    int L, n_ag, N, C, U;
+    int *comp_op, *deq_op, *ag_op, *ag_unit;
+    PipeUnit* units;
+};
+static void sched_free(PipeSched* sc) {
+    if (!sc) return;
+    delete[] sc->comp_op; delete[] sc->deq_op; delete[] sc->ag_op; delete[] sc->ag_unit; delete[] sc->units;
+    delete sc;
+}
 
 static int launch_pipe(cfx_plan* p, hipStream_t s, int N, int C, const int* comp_op, const int* deq_op,
                        const PipeUnit* dq, const PipeUnit* fin, const PipeUnit* st, int fin_parity, int st_parity,
@@ -1868,21 +1941,22 @@ static int launch_pipe(cfx_plan* p, hipStream_t s, int N, int C, const int* comp
     return check_launch(ctx, "pipelined launch");
 }
 
-int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
-    if (!p) return CFX_ERR_NULL;
-    if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
+// Recognise the group pattern of ops [first_op, first_op + n_ops), merging whole groups into units, and size the plan-owned
+// statistics workspaces.  Everything that allocates or reads the environment happens HERE, once.
+static int plan_build_sched(cfx_plan* p, int first_op, int n_ops) {
+    sched_free(p->sched);
+    p->sched = nullptr;
     const int end = first_op + n_ops;
     const int cap = n_ops > 0 ? n_ops : 1;
-    int* comp_op = new int[cap];
-    int* deq_op = new int[cap];
-    int* ag_op = new int[cap];
-    int* ag_unit = new int[cap];          // unit whose packets an all-gather carries
-    PipeUnit* units = new PipeUnit[cap];
-    auto cleanup = [&]() { delete[] comp_op; delete[] deq_op; delete[] ag_op; delete[] ag_unit; delete[] units; };
+    PipeSched* sc = new PipeSched();
+    sc->first_op = first_op; sc->n_ops = n_ops; sc->n_plan_ops = p->n;
+    sc->comp_op = new int[cap]; sc->deq_op = new int[cap]; sc->ag_op = new int[cap]; sc->ag_unit = new int[cap];
+    sc->units = new PipeUnit[cap];
+    int* comp_op = sc->comp_op; int* deq_op = sc->deq_op; int* ag_op = sc->ag_op; int* ag_unit = sc->ag_unit;
+    PipeUnit* units = sc->units;
     const char* ue = getenv("CFX_PIPE_UNIT_LAYERS");
     int unit_layers = ue ? atoi(ue) : 7;
     if (unit_layers < 1) unit_layers = 1;
-    // ---- recognise the group pattern, merging whole groups into units -----------------------------------------------------
     int L = 0, n_ag = 0, N = 0, C = 0, U = 0;
     bool ok = n_ops > 0;
     for (int i = first_op; ok && i < end;) {
@@ -1901,6 +1975,7 @@ int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
             if (p->ops[i].kind == 2) ag_op[n_ag++] = i;
             ++i;
         }
+        if (i < end && p->ops[i].kind == 4) { ok = false; break; }          // relay hops: in-order replay only
         for (int m = 0; m < k; ++m, ++i) {
             if (i >= end || p->ops[i].kind != 1 || p->ops[i].codec != CFX_CODEC_BINARY || p->ops[i].N != N || p->ops[i].C != C) { ok = false; break; }
             ndq += p->ops[i].batch;
@@ -1919,14 +1994,37 @@ int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
         for (int a = ag0; a < n_ag; ++a) ag_unit[a] = U - 1;
         L += k;
     }
-    if (!ok) { cleanup(); return cfx_plan_run(p, first_op, n_ops, stream); }
+    sc->ok = ok; sc->L = L; sc->n_ag = n_ag; sc->N = N; sc->C = C; sc->U = U;
+    p->sched = sc;
+    if (!ok) return CFX_OK;
     const size_t need = 2 * (size_t)CFX_MAX_BATCH * ws_words(CFX_CODEC_BINARY, N, C) * sizeof(u64);
     if (need > p->pipe_ws_bytes) {
         if (p->pipe_ws) (void)hipFree(p->pipe_ws);
         p->pipe_ws = nullptr; p->pipe_ws_bytes = 0;
-        if (hipMalloc(&p->pipe_ws, need) != hipSuccess) { cleanup(); return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot allocate the statistics workspaces"); }
+        if (hipMalloc(&p->pipe_ws, need) != hipSuccess) { (void)hipGetLastError(); return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot allocate the statistics workspaces"); }
         p->pipe_ws_bytes = need;
     }
+    return CFX_OK;
+}
+
+int cfx_plan_finalize(cfx_plan* p) {
+    if (!p) return CFX_ERR_NULL;
+    if (cfx_prepare(p->ctx) != CFX_OK) return CFX_ERR_LAUNCH;      // ticket blocks of the in-order compress launches
+    return plan_build_sched(p, 0, p->n);
+}
+
+int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
+    if (!p) return CFX_ERR_NULL;
+    if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
+    if (!p->sched || p->sched->first_op != first_op || p->sched->n_ops != n_ops || p->sched->n_plan_ops != p->n) {
+        const int rcb = plan_build_sched(p, first_op, n_ops);     // first replay of this range (or the plan grew): build once
+        if (rcb != CFX_OK) return rcb;
+    }
+    const PipeSched* sc = p->sched;
+    if (!sc->ok) return cfx_plan_run(p, first_op, n_ops, stream);
+    const int *comp_op = sc->comp_op, *deq_op = sc->deq_op, *ag_op = sc->ag_op, *ag_unit = sc->ag_unit;
+    const PipeUnit* units = sc->units;
+    const int n_ag = sc->n_ag, N = sc->N, C = sc->C, U = sc->U;
     hipStream_t s = (hipStream_t)stream;
     auto unit = [&](int u) -> const PipeUnit* { return (u >= 0 && u < U) ? &units[u] : nullptr; };
     // Exchange stream mode 0: collectives in order on `stream`, right before the launch that consumes them.
@@ -1935,7 +2033,7 @@ int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
     // has normally fired long before) only in front of the launch that reconstructs unit u.
     const int d = (p->side_mode != 0 && p->side && n_ag > 0) ? 1 : 0;
     auto all_gather = [&](const PlanOp* o, hipStream_t on) -> int {
-        if (g_rccl.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, on) != 0)
+        if (o->comm->api.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, on) != 0)
             return fail(p->ctx, CFX_ERR_LAUNCH, "ncclAllGather failed");
         return CFX_OK;
     };
@@ -1968,27 +2066,33 @@ int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
             }
         }
     }
-    cleanup();
     return rc;
 }
 
 // ---- communicator -----------------------------------------------------------------------------------------------------
 int cfx_rccl_load(const char* path) {
-    if (g_rccl.handle) return CFX_OK;
+    if (g_rccl.handle && (!path || !path[0] || !strcmp(path, g_rccl.path))) return CFX_OK;    // already loaded (same library)
     void* h = nullptr;
     if (path && path[0]) h = dlopen(path, RTLD_NOW | RTLD_NOLOAD);
     if (!h && path && path[0]) h = dlopen(path, RTLD_NOW);
     const char* names[] = {"librccl.so", "librccl.so.1"};
-    for (int i = 0; i < 2 && !h; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
-    for (int i = 0; i < 2 && !h; ++i) h = dlopen(names[i], RTLD_NOW);
+    for (int i = 0; i < 2 && !h && !(path && path[0]); ++i) h = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
+    for (int i = 0; i < 2 && !h && !(path && path[0]); ++i) h = dlopen(names[i], RTLD_NOW);
     if (!h) return CFX_ERR_NULL;
-    g_rccl.GetUniqueId = (int (*)(cfx_nccl_uid*))dlsym(h, "ncclGetUniqueId");
-    g_rccl.CommInitRank = (int (*)(cfx_nccl_comm*, int, cfx_nccl_uid, int))dlsym(h, "ncclCommInitRank");
-    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, cfx_nccl_comm, hipStream_t))dlsym(h, "ncclAllGather");
-    g_rccl.CommDestroy = (int (*)(cfx_nccl_comm))dlsym(h, "ncclCommDestroy");
-    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) return CFX_ERR_NULL;
-    g_rccl.handle = h;
+    RcclApi a = {};
+    a.GetUniqueId = (int (*)(cfx_nccl_uid*))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (int (*)(cfx_nccl_comm*, int, cfx_nccl_uid, int))dlsym(h, "ncclCommInitRank");
+    a.AllGather = (int (*)(const void*, void*, size_t, int, cfx_nccl_comm, hipStream_t))dlsym(h, "ncclAllGather");
+    a.CommDestroy = (int (*)(cfx_nccl_comm))dlsym(h, "ncclCommDestroy");
+    a.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    a.Send = (int (*)(const void*, size_t, int, int, cfx_nccl_comm, hipStream_t))dlsym(h, "ncclSend");
+    a.Recv = (int (*)(void*, size_t, int, int, cfx_nccl_comm, hipStream_t))dlsym(h, "ncclRecv");
+    a.GroupStart = (int (*)(void))dlsym(h, "ncclGroupStart");
+    a.GroupEnd = (int (*)(void))dlsym(h, "ncclGroupEnd");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy) return CFX_ERR_NULL;
+    a.handle = h;
+    snprintf(a.path, sizeof(a.path), "%s", (path && path[0]) ? path : "");
+    g_rccl = a;          // communicators created from now on use this library; existing ones keep the table they were made with
     return CFX_OK;
 }
 
@@ -2004,12 +2108,16 @@ int cfx_comm_unique_id(cfx_ctx* ctx, void* out128) {
 
 cfx_comm* cfx_comm_create(cfx_ctx* ctx, const void* id128, int nranks, int rank) {
     if (!ctx || !id128 || !g_rccl.handle) return nullptr;
-    (void)hipSetDevice(ctx->device);
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != ctx->device) (void)hipSetDevice(ctx->device);       // ncclCommInitRank binds the communicator to the current device
     cfx_nccl_uid id;
     memcpy(&id, id128, 128);
     cfx_comm* c = new cfx_comm();
     c->ctx = ctx; c->nranks = nranks; c->rank = rank; c->comm = nullptr;
+    c->api = g_rccl;
     const int r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (cur >= 0 && cur != ctx->device) (void)hipSetDevice(cur);   // the caller's current device is left as it was
     if (r != 0) {
         char buf[200];
         snprintf(buf, sizeof(buf), "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
@@ -2022,14 +2130,20 @@ cfx_comm* cfx_comm_create(cfx_ctx* ctx, const void* id128, int nranks, int rank)
 
 void cfx_comm_destroy(cfx_comm* c) {
     if (!c) return;
-    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    if (c->comm && c->api.CommDestroy) (void)c->api.CommDestroy(c->comm);
     delete c;
 }
 
 int cfx_comm_all_gather(cfx_comm* c, const void* send, void* recv, size_t bytes_per_rank, void* stream) {
     if (!c || !send || !recv) return CFX_ERR_NULL;
-    const int r = g_rccl.AllGather(send, recv, bytes_per_rank, 1, c->comm, (hipStream_t)stream);
+    const int r = c->api.AllGather(send, recv, bytes_per_rank, 1, c->comm, (hipStream_t)stream);
     return r == 0 ? CFX_OK : fail(c->ctx, CFX_ERR_LAUNCH, "ncclAllGather failed");
+}
+
+int cfx_comm_ring_hop(cfx_comm* c, const void* send, void* recv, size_t bytes, void* stream) {
+    if (!c || !send || !recv) return CFX_ERR_NULL;
+    const int r = ring_hop(c, send, recv, bytes, (hipStream_t)stream);
+    return r == 0 ? CFX_OK : fail(c->ctx, CFX_ERR_LAUNCH, "ring hop (ncclSend / ncclRecv) failed");
 }
 
 int cfx_residual2_delta(cfx_ctx* ctx, const void* x, const void* base, const void* delta_base, void* dd, size_t n, void* stream) {

@@ -192,6 +192,13 @@ typedef struct cfx_comm cfx_comm;
 int       cfx_plan_set_exchange_stream(cfx_plan* plan, int mode);
 int       cfx_plan_add_all_gather(cfx_plan* plan, cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank);
 int       cfx_plan_add_wait(cfx_plan* plan, int gather_op);
+/* One hop of the ring relay (reference xfuser/compact/ring.py:193-195,265-269: RingComm.send_recv / commit / wait): send
+ * `bytes` to rank+1 and receive `bytes` from rank-1 as one grouped ncclSend + ncclRecv, on the exchange stream like an
+ * all-gather op (cfx_plan_add_wait applies).  W-1 hops relay every rank's packet around the ring. */
+int       cfx_plan_add_ring_hop(cfx_plan* plan, cfx_comm* comm, const void* send, void* recv, size_t bytes);
+/* Re-point the activation of item `item` of compress op `op` (the K / V tensor a layer hands over changes from call to
+ * call; state, packet and workspace operands are bound once). */
+int       cfx_plan_set_input(cfx_plan* plan, int op, int item, const void* x);
 int       cfx_plan_size(const cfx_plan* plan);
 int       cfx_plan_copy_op(cfx_plan* dst, const cfx_plan* src, int op);   /* append a copy of a (de)compress op of `src` */
 int       cfx_plan_run(cfx_plan* plan, int first_op, int n_ops, void* stream);
@@ -206,16 +213,25 @@ int       cfx_plan_run(cfx_plan* plan, int first_op, int n_ops, void* stream);
  * per layer within the call; the statistics workspaces are plan-owned (the ops' own are not used).  Any other op
  * sequence is replayed by cfx_plan_run. */
 int       cfx_plan_run_pipelined(cfx_plan* plan, int first_op, int n_ops, void* stream);
+/* Call once after the last cfx_plan_add_*: recognises the unit schedule of the whole plan for cfx_plan_run_pipelined and
+ * makes every allocation a replay needs (statistics workspaces, the context's ticket blocks), so that cfx_plan_run /
+ * cfx_plan_run_pipelined do no host allocation, environment lookup or device allocation per step (optional: the first
+ * replay of a range does the same work otherwise). */
+int       cfx_plan_finalize(cfx_plan* plan);
 
-/* RCCL communicator owned by the library (replaces yunchang's RingComm + torch.distributed P2P of the reference,
+/* Process-global state, the only one besides cfx_ctx: the table of RCCL entry points filled by cfx_rccl_load (RCCL is a
+ * process-wide library; loading it twice would give two collective runtimes).  Communicators themselves are per cfx_comm.
+ * cfx_comm_create leaves the caller's current device unchanged.
+ * RCCL communicator owned by the library (replaces yunchang's RingComm + torch.distributed P2P of the reference,
  * xfuser/compact/ring.py:172,193-195,265-267).  RCCL is loaded at run time (cfx_rccl_load: pass the path of the
  * librccl the process already uses, or NULL to search); rank 0 makes the 128-byte unique id (cfx_comm_unique_id),
  * the host shares it by any means, every rank calls cfx_comm_create (collective). */
-int       cfx_rccl_load(const char* path);
+int       cfx_rccl_load(const char* path);   /* a different explicit path replaces the table for communicators created afterwards */
 int       cfx_comm_unique_id(cfx_ctx* ctx, void* out128);
 cfx_comm* cfx_comm_create(cfx_ctx* ctx, const void* id128, int nranks, int rank);
 void      cfx_comm_destroy(cfx_comm* comm);
 int       cfx_comm_all_gather(cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+int       cfx_comm_ring_hop(cfx_comm* comm, const void* send, void* recv, size_t bytes, void* stream);
 
 /* Second-order residual (CompactConfig(residual=2), xfuser/compact/main.py:244-266 compress, :378-384 decompress): the
  * predictor arithmetic around any codec, n fp16 elements (multiple of 8), one fp16 rounding per reference operation.
