@@ -70,6 +70,7 @@ SYMBOLS = [
     ("cfx_plan_add_decompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.POINTER(DecompItem)]),
     ("cfx_plan_set_exchange_stream", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_plan_use_exchange_stream", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     ("cfx_plan_add_all_gather", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     ("cfx_plan_add_wait", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_plan_add_ring_hop", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
@@ -83,10 +84,14 @@ SYMBOLS = [
     ("cfx_plan_copy_op", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     ("cfx_plan_size", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_plan_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    ("cfx_plan_run_x", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]),
+    ("cfx_plan_run_async", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p]),
+    ("cfx_plan_join", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     ("cfx_plan_run_pipelined", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     ("cfx_plan_finalize", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_residual2_delta", ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_residual2_update", ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p]),
+    ("cfx_attn_merge", ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 + [ctypes.c_void_p]),
     ("cfx_copy_probe", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 ]
 

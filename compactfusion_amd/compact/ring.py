@@ -108,6 +108,15 @@ def _compact_ring_fwd(q, k, v, dropout_p=0, softmax_scale=None, causal=True, win
     assert alibi_slopes is None
     if softmax_scale is None:
         softmax_scale = q.shape[-1] ** (-0.5)
+    # steady-state lane: this layer's exchange is a bound native plan and nothing it was bound against has changed -> two
+    # native calls around the local attention block, no per-call bookkeeping (the reference rebuilds keys, shapes and
+    # communicator state on every call, ring.py:172-190)
+    st = _steady.get((mod_idx, id(group) if group is not None else None))
+    if st is not None and joint_tensor_key is None and joint_tensor_value is None:
+        cfg = compact_config()
+        ctype = cfg.compress_func(mod_idx, current_iter)
+        if st.matches(q, k, v, ctype, cfg, causal, dropout_p):
+            return st.run(q, k, v, softmax_scale)
     jmode = _joint_mode(joint_tensor_key, joint_tensor_value, joint_strategy)
     comm = RingComm(group)
     rank, world = comm.rank, comm.world_size
@@ -153,6 +162,56 @@ def _compact_ring_fwd(q, k, v, dropout_p=0, softmax_scale=None, causal=True, win
 
 
 _xbuf = {}
+_xstreams = {}
+_steady = {}
+
+
+class _SteadyLayer:
+    """What `_gather_schedule` established for a layer, frozen: valid while the config object, the state arena generation, the
+    codec and the tensor geometry stay what they were (any change falls back to the general path, which re-binds)."""
+
+    def __init__(self, ex, q, k, v, ctype, cfg, rank, world):
+        cache = compact_cache()
+        self.ex, self.ctype, self.cfg, self.rank, self.world = ex, ctype, cfg, rank, world
+        self.key = (tuple(q.shape), tuple(k.shape), tuple(v.shape), q.device, cm._generation, cache.version, ex.sig)
+        self.flags = (cfg.error_feedback, cfg.log_compress_stats, cfg.check_cache_consistency, cfg.simulate_compress, cfg.compress_residual)
+        self.N, self.C = cm._nc_shape(k.shape)
+        self.kk, self.vk = ex.kkeys[rank], ex.vkeys[rank]
+        self.last_key = ex.vkeys[ex.peers[-1]]
+
+    def matches(self, q, k, v, ctype, cfg, causal, dropout_p) -> bool:
+        if ctype is not self.ctype or cfg is not self.cfg or causal or dropout_p or self.ex.plan is None or cfg.check_cache_consistency:
+            return False
+        cache = compact_cache()
+        if (tuple(q.shape), tuple(k.shape), tuple(v.shape), q.device, cm._generation, cache.version, self.ex.sig) != self.key:
+            return False
+        if (cfg.error_feedback, cfg.log_compress_stats, cfg.check_cache_consistency, cfg.simulate_compress, cfg.compress_residual) != self.flags:
+            return False
+        return q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and not Profiler.instance().enabled and not _collector_live()
+
+    def run(self, q, k, v, softmax_scale):
+        ex = self.ex
+        sh = torch.cuda.current_stream(q.device).cuda_stream
+        ex.run_front(k, v, sh)
+        if not self.flags[0]:                                  # no error feedback: the state becomes the activation (main.py:240-243)
+            cache = compact_cache()
+            cache.put(self.kk, k.view(self.N, self.C), None)
+            cache.put(self.vk, v.view(self.N, self.C), None)
+        bo, bl = block_attention(q, k, v, 0.0, softmax_scale, causal=False)
+        out, lse = update_out_and_lse(None, None, bo, bl)
+        ex.run_back(sh)
+        cm._current_cache_key = self.last_key
+        for kk, vv in ex.peer_views:
+            bo, bl = block_attention(q, kk, vv, 0.0, softmax_scale, causal=False)
+            out, lse = update_out_and_lse(out, lse, bo, bl)
+        return out.to(q.dtype), lse.squeeze(dim=-1).transpose(1, 2), None
+
+
+def _exchange_stream(device) -> "torch.cuda.Stream":
+    s = _xstreams.get(device)
+    if s is None:
+        s = _xstreams[device] = torch.cuda.Stream(device, priority=int(os.environ.get("CFX_RING_EXCHANGE_PRIORITY", "-1")))
+    return s
 
 
 class _LayerExchange:
@@ -161,11 +220,13 @@ class _LayerExchange:
     batches (cached pointer tables, `codecs.prepare_*`), so the steady-state host work per layer is one compress call,
     one collective and one reconstruct call."""
 
-    def __init__(self, mod_idx, rank: int, world: int, slot: int, like: torch.Tensor):
-        self.slot, self.world, self.rank = slot, world, rank
+    def __init__(self, mod_idx, rank: int, world: int, slot: int, like: torch.Tensor, group=None):
+        self.slot, self.world, self.rank, self.group = slot, world, rank, group
+        self.plan = None             # native per-layer plan: compress, all-gather on the exchange stream | wait, reconstruct
+        self._lib = None
         self.send = torch.empty(2 * slot, dtype=torch.float16, device=like.device)
         self.recv = torch.empty(world * 2 * slot, dtype=torch.float16, device=like.device)
-        self.side = torch.cuda.Stream(like.device) if like.is_cuda else None
+        self.side = _exchange_stream(like.device) if like.is_cuda else None
         self.peers = [(rank - s) % world for s in range(1, world)]
         self.kkeys = [f"{mod_idx}-{r}-k" for r in range(world)]
         self.vkeys = [f"{mod_idx}-{r}-v" for r in range(world)]
@@ -206,13 +267,89 @@ class _LayerExchange:
         self.dec = [codecs.prepare_decompress(cid, pkts[i:i + step], bases[i:i + step], bases[i:i + step], N, C, param)
                     for i in range(0, len(bases), step)]
         self.sig = sig
+        self._bind_native(cid, param, N, C, own, own_pkts, bases, pkts, ef)
+
+    def _drop_plan(self):
+        if self.plan is not None and self._lib is not None:
+            self._lib.cfx_plan_destroy(self.plan)
+        self.plan = None
+
+    def __del__(self):
+        try:
+            self._drop_plan()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def _bind_native(self, cid, param, N, C, own, own_pkts, bases, pkts, ef):
+        """The layer's exchange as ONE native plan replayed in two host calls: [compress K,V ; all-gather on the exchange
+        stream] - local attention block - [wait ; batched reconstruction].  The collective is issued by libcfx's own
+        communicator (the reference drives torch.distributed P2P per hop, ring.py:193-195,265-269; through torch.distributed
+        the per-layer all-gather costs ~50 us of host time, more than the GPU work it overlaps)."""
+        self._drop_plan()
+        mode = os.environ.get("CFX_RING_EXCHANGE", "auto")
+        if mode == "torch" or not self.send.is_cuda or cid >= 100:
+            return
+        import ctypes
+        from .. import _lib, codecs
+        from ..exchange import native_comm_for
+        dev = self.send.device.index if self.send.device.index is not None else torch.cuda.current_device()
+        comm = native_comm_for(self.group, dev)
+        if comm is None:
+            assert mode != "native", "CFX_RING_EXCHANGE=native but the library-owned communicator cannot be created"
+            return
+        lib = self._lib = _lib.load()
+        ctx = codecs.context(dev)
+        plan = lib.cfx_plan_create(ctx)
+        # ONE exchange stream per device, shared by every layer's plan (a stream per plan would be a hardware queue per layer)
+        xmode = os.environ.get("CFX_RING_EXCHANGE_STREAM", "chain")     # chain | side | main
+        self._async = xmode == "chain"
+        if xmode == "main":
+            assert lib.cfx_plan_set_exchange_stream(plan, 0) == 0
+        else:
+            assert lib.cfx_plan_use_exchange_stream(plan, _exchange_stream(self.send.device).cuda_stream) == 0
+        ws = codecs.workspace(cid, N, C, param, 2, dev)
+        self._plan_keep = (ws, list(own), list(own_pkts), list(bases), list(pkts), comm)
+        c = (_lib.CompItem * 2)(*[_lib.CompItem(own[i].data_ptr(), own[i].data_ptr(), None, own_pkts[i].data_ptr()) for i in range(2)])
+        flags = 0 if ef else _lib.FLAG_NO_EF
+        ok = lib.cfx_plan_add_compress(plan, cid, N, C, param, flags, 2, c, None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel()) == 0
+        g0 = lib.cfx_plan_add_all_gather(plan, comm.handle, self.send.data_ptr(), self.recv.data_ptr(), 2 * self.slot * 2)
+        ok = ok and g0 == 1 and lib.cfx_plan_add_wait(plan, g0) == 2
+        step = codecs.CFX_MAX_BATCH
+        for i in range(0, len(bases), step):
+            items = [_lib.DecompItem(p_.data_ptr(), b_.data_ptr(), b_.data_ptr()) for p_, b_ in zip(pkts[i:i + step], bases[i:i + step])]
+            ok = ok and lib.cfx_plan_add_decompress(plan, cid, N, C, param, len(items), (_lib.DecompItem * len(items))(*items)) >= 0
+        ok = ok and lib.cfx_plan_finalize(plan) == 0
+        if not ok:
+            lib.cfx_plan_destroy(plan)
+            raise _lib.CfxError("building the layer's native exchange plan failed: " + (lib.cfx_last_error_string(ctx) or b"").decode())
+        self.plan, self._ctx = plan, ctx
+        self._n_ops = lib.cfx_plan_size(plan)
+        self._xs = (ctypes.c_void_p * 2)()
+
+    def run_front(self, k, v, sh):
+        self._xs[0], self._xs[1] = k.data_ptr(), v.data_ptr()
+        if self._async:
+            # the whole chain - compress, all-gather, reconstruction - on the exchange stream, beside the local attention block
+            rc = self._lib.cfx_plan_run_async(self.plan, 0, self._n_ops, self._xs, 2, sh)
+        else:
+            rc = self._lib.cfx_plan_run_x(self.plan, 0, 2, self._xs, 2, sh)
+        if rc != 0:
+            raise RuntimeError("native exchange (compress + all-gather) failed: " + (self._lib.cfx_last_error_string(self._ctx) or b"").decode())
+
+    def run_back(self, sh):
+        if self._async:
+            rc = self._lib.cfx_plan_join(self.plan, sh)
+        else:
+            rc = self._lib.cfx_plan_run(self.plan, 2, self._n_ops - 2, sh)
+        if rc != 0:
+            raise RuntimeError("native exchange (wait + reconstruct) failed: " + (self._lib.cfx_last_error_string(self._ctx) or b"").decode())
 
 
-def _layer_exchange(mod_idx, rank: int, world: int, slot: int, like: torch.Tensor) -> _LayerExchange:
-    key = (mod_idx, rank, world, slot, like.device)
+def _layer_exchange(mod_idx, rank: int, world: int, slot: int, like: torch.Tensor, group=None) -> _LayerExchange:
+    key = (mod_idx, rank, world, slot, like.device, id(group) if group is not None else None)
     ex = _xbuf.get(key)
     if ex is None:
-        ex = _xbuf[key] = _LayerExchange(mod_idx, rank, world, slot, like)
+        ex = _xbuf[key] = _LayerExchange(mod_idx, rank, world, slot, like, group)
     return ex
 
 
@@ -232,7 +369,7 @@ def _gather_schedule(q, k, v, ctype, mod_idx, rank, world, group, kkey, vkey, at
     n_half = cm._packet_halves(cid, param, N, C) if native else \
         (N * C if (warm or cfg.simulate_compress) else cm._packet_halves(*cm._native(ctype), N, C))
     slot = (n_half + 127) // 128 * 128
-    ex = _layer_exchange(mod_idx, rank, world, slot, k)
+    ex = _layer_exchange(mod_idx, rank, world, slot, k, group)
     send, recv, side = ex.send, ex.recv, ex.side
     # steady state: K and V in ONE native compress sequence straight into the send slots, in-place EF state update
     fast = native and cid < 100 and not cfg.log_compress_stats and v.shape == k.shape and not compact_cache().quantize
@@ -243,8 +380,12 @@ def _gather_schedule(q, k, v, ctype, mod_idx, rank, world, group, kkey, vkey, at
         sig = (cm._generation, cache.version, cid, param, N, C, tuple(kshape), cfg.error_feedback)
         if ex.sig != sig:
             ex.bind(sig, cid, param, N, C, n_half, kshape, vshape, cfg.error_feedback)
+        native_x = ex.plan is not None
         with Profiler.scope("compact.compress_batch"):
-            ex.comp((k, v), sh)
+            if native_x:
+                ex.run_front(k, v, sh)         # compress K,V + the all-gather on the exchange stream: one host call
+            else:
+                ex.comp((k, v), sh)
         if not cfg.error_feedback:
             cache.put(ex.kkeys[rank], k.view(N, C), None)
             cache.put(ex.vkeys[rank], v.view(N, C), None)
@@ -263,7 +404,9 @@ def _gather_schedule(q, k, v, ctype, mod_idx, rank, world, group, kkey, vkey, at
             send[:n_half].copy_(pk.reshape(-1))
             send[slot:slot + n_half].copy_(pv.reshape(-1))
     # exchange on the side stream, overlapped with the local attention block
-    if side is not None:
+    if fast and native_x:
+        pass
+    elif side is not None:
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             with Profiler.scope("compact.all_gather", stream=side):
@@ -271,13 +414,16 @@ def _gather_schedule(q, k, v, ctype, mod_idx, rank, world, group, kkey, vkey, at
     else:
         dist.all_gather_into_tensor(recv, send, group=group)
     out, lse = attend(None, None, k, v, 0)
-    if side is not None:
+    if side is not None and not (fast and native_x):
         cur.wait_stream(side)
     peers = ex.peers
     if fast:
         with Profiler.scope("compact.decompress_batch"):
-            for run in ex.dec:
-                run(sh)
+            if native_x:
+                ex.run_back(sh)                # wait for the gather + ONE batched reconstruction: one host call
+            else:
+                for run in ex.dec:
+                    run(sh)
         if live:
             for r in peers:
                 cache.touch(ex.kkeys[r])
@@ -285,6 +431,8 @@ def _gather_schedule(q, k, v, ctype, mod_idx, rank, world, group, kkey, vkey, at
         cm._current_cache_key = ex.vkeys[peers[-1]]
         for step, (kk, vv) in enumerate(ex.peer_views, start=1):
             out, lse = attend(out, lse, kk, vv, step)
+        if native_x and cfg.error_feedback is not None:
+            _steady[(mod_idx, id(group) if group is not None else None)] = _SteadyLayer(ex, q, k, v, ctype, cfg, rank, world)
         return out, lse
     if native and compact_cache().quantize:
         native = False           # state lives as int8 packets: go through compact_decompress (get_base / put) per tensor

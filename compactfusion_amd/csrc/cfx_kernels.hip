@@ -1232,6 +1232,49 @@ __global__ __launch_bounds__(256) void k_residual2_update(const h16* base, const
     st8(ndb + i * 8, nd);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Ring-attention block merge (the consumer of the reconstructed K,V; reference ring.py:263 update_out_and_lse, taken there
+// from the un-vendored yunchang package; published formula):
+//     out <- out - sigmoid(lse_b - lse) * (out - out_b) ;  lse <- lse - logsigmoid(lse - lse_b)
+// One launch instead of ~10 eager elementwise kernels per block.  out fp32 [B][S][H][D], lse fp32 [B][S][H];
+// block_out fp16 [B][H][S][D] or [B][S][H][D] (strides) and block_lse fp32 [B][H][S] as the fused SDPA kernel leaves them.
+// first != 0: out = block_out, lse = block_lse.  One thread = 8 consecutive d of one (b, s, h).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_attn_merge(float* __restrict__ out, float* __restrict__ lse, const h16* __restrict__ bo,
+                                                    const float* __restrict__ bl, int B, int S, int H, int D, int first,
+                                                    size_t bo_sb, size_t bo_ss, size_t bo_sh) {
+    const int D8 = D >> 3;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)B * S * H * D8;
+    if (i >= total) return;
+    const int d8 = (int)(i % D8);
+    size_t r = i / D8;
+    const int h = (int)(r % H); r /= H;
+    const int s_ = (int)(r % S);
+    const int b = (int)(r / S);
+    const size_t o_idx = (((size_t)b * S + s_) * H + h) * D + (size_t)d8 * 8;
+    const size_t l_idx = ((size_t)b * S + s_) * H + h;
+    const size_t bo_idx = (size_t)b * bo_sb + (size_t)s_ * bo_ss + (size_t)h * bo_sh + (size_t)d8 * 8;
+    const float lb = bl[((size_t)b * H + h) * S + s_];
+    const h16x8 ob = ld8nt(bo + bo_idx);
+    float4* op = reinterpret_cast<float4*>(out + o_idx);
+    if (first) {
+        op[0] = make_float4((float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]);
+        op[1] = make_float4((float)ob[4], (float)ob[5], (float)ob[6], (float)ob[7]);
+        if (d8 == 0) lse[l_idx] = lb;
+        return;
+    }
+    const float l = lse[l_idx];
+    const float x = lb - l;
+    const float sg = 1.0f / (1.0f + __expf(-x));                                    // sigmoid(lse_b - lse)
+    float4 a = op[0], c = op[1];
+    a.x -= sg * (a.x - (float)ob[0]); a.y -= sg * (a.y - (float)ob[1]); a.z -= sg * (a.z - (float)ob[2]); a.w -= sg * (a.w - (float)ob[3]);
+    c.x -= sg * (c.x - (float)ob[4]); c.y -= sg * (c.y - (float)ob[5]); c.z -= sg * (c.z - (float)ob[6]); c.w -= sg * (c.w - (float)ob[7]);
+    op[0] = a; op[1] = c;
+    // logsigmoid(-x) = -softplus(x) = -(max(x,0) + log1p(exp(-|x|)));  lse - logsigmoid(lse - lse_b) = lse + softplus(x)
+    if (d8 == 0) lse[l_idx] = l + (fmaxf(x, 0.0f) + log1pf(__expf(-fabsf(x))));
+}
+
 __global__ __launch_bounds__(256) void k_copy_probe(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
@@ -1643,7 +1686,9 @@ struct cfx_plan {
     cfx_ctx* ctx;
     PlanOp* ops;
     int n, cap;
-    hipStream_t side;     // exchange stream (created on first all-gather op)
+    hipStream_t side;     // exchange stream (created on first all-gather op, or the caller's: side_owned = false)
+    bool side_owned;
+    hipEvent_t ev_fork, ev_join;   // cfx_plan_run_async / cfx_plan_join
     int side_mode;        // 0: issue collectives on the main stream (no cross-stream events), 1: side stream, 2: prioritised side stream
     void* pipe_ws;        // cfx_plan_run_pipelined: two statistics workspaces of CFX_MAX_BATCH tensors each (stats of unit
     size_t pipe_ws_bytes; //   t runs beside the finalize of unit t-1)
@@ -1657,6 +1702,8 @@ cfx_plan* cfx_plan_create(cfx_ctx* ctx) {
     p->ops = nullptr;
     p->n = p->cap = 0;
     p->side = nullptr;
+    p->side_owned = true;
+    p->ev_fork = p->ev_join = nullptr;
     p->pipe_ws = nullptr;
     p->pipe_ws_bytes = 0;
     p->sched = nullptr;
@@ -1676,13 +1723,24 @@ int cfx_plan_set_exchange_stream(cfx_plan* p, int mode) {
     return CFX_OK;
 }
 
+int cfx_plan_use_exchange_stream(cfx_plan* p, void* stream) {
+    if (!p || !stream) return CFX_ERR_NULL;
+    if (p->side) return fail(p->ctx, CFX_ERR_BATCH, "plan: the exchange stream must be chosen before the first exchange op");
+    p->side = (hipStream_t)stream;
+    p->side_owned = false;
+    p->side_mode = 1;
+    return CFX_OK;
+}
+
 void cfx_plan_destroy(cfx_plan* p) {
     if (!p) return;
     for (int i = 0; i < p->n; ++i) {
         if (p->ops[i].ev_pre) (void)hipEventDestroy(p->ops[i].ev_pre);
         if (p->ops[i].ev_done) (void)hipEventDestroy(p->ops[i].ev_done);
     }
-    if (p->side) (void)hipStreamDestroy(p->side);
+    if (p->side && p->side_owned) (void)hipStreamDestroy(p->side);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->pipe_ws) (void)hipFree(p->pipe_ws);
     sched_free(p->sched);
     delete[] p->ops;
@@ -1798,6 +1856,24 @@ int cfx_plan_set_input(cfx_plan* p, int op, int item, const void* x) {
     return CFX_OK;
 }
 
+// cfx_plan_run with the activations of the range's FIRST compress op re-pointed first (one host call per layer phase)
+int cfx_plan_run_x(cfx_plan* p, int first_op, int n_ops, const void* const* xs, int n_xs, void* stream) {
+    if (!p) return CFX_ERR_NULL;
+    if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
+    if (n_xs > 0) {
+        if (!xs) return CFX_ERR_NULL;
+        int op = first_op;
+        while (op < first_op + n_ops && p->ops[op].kind != 0) ++op;
+        if (op == first_op + n_ops || p->ops[op].batch != n_xs) return fail(p->ctx, CFX_ERR_BATCH, "plan: run_x needs a compress op with n_xs items in the range");
+        for (int i = 0; i < n_xs; ++i) {
+            if (!xs[i]) return fail(p->ctx, CFX_ERR_NULL, "plan: null activation");
+            if (!AL16(xs[i])) return fail(p->ctx, CFX_ERR_ALIGN, "plan: pointers must be 16-byte aligned");
+            p->ops[op].c[i].x = xs[i];
+        }
+    }
+    return cfx_plan_run(p, first_op, n_ops, stream);
+}
+
 int cfx_plan_add_wait(cfx_plan* p, int gather_op) {
     if (!p) return CFX_ERR_NULL;
     if (gather_op < 0 || gather_op >= p->n || (p->ops[gather_op].kind != 2 && p->ops[gather_op].kind != 4))
@@ -1820,10 +1896,13 @@ static int ring_hop(cfx_comm* c, const void* send, void* recv, size_t bytes, hip
     return r ? r : e;
 }
 
-int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) {
+// `inline_exchange`: exchange ops run in order on `stream` itself whatever the plan's exchange-stream mode (cfx_plan_run_async:
+// the whole range already runs on the exchange stream).
+static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, bool inline_exchange) {
     if (!p) return CFX_ERR_NULL;
     if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
     hipStream_t main_s = (hipStream_t)stream;
+    const int side_mode = inline_exchange ? 0 : p->side_mode;
     for (int i = first_op; i < first_op + n_ops; ++i) {
         PlanOp* o = &p->ops[i];
         int rc = CFX_OK;
@@ -1833,8 +1912,8 @@ int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) {
             case 2:
             case 4: {
                 // exchange stream picks up after everything enqueued so far on the main stream (the packets are complete)
-                hipStream_t xs = p->side_mode ? p->side : main_s;
-                if (p->side_mode && (hipEventRecord(o->ev_pre, main_s) != hipSuccess || hipStreamWaitEvent(p->side, o->ev_pre, 0) != hipSuccess))
+                hipStream_t xs = side_mode ? p->side : main_s;
+                if (side_mode && (hipEventRecord(o->ev_pre, main_s) != hipSuccess || hipStreamWaitEvent(p->side, o->ev_pre, 0) != hipSuccess))
                     return fail(p->ctx, CFX_ERR_LAUNCH, "plan: event ordering failed");
                 int r;
                 if (o->kind == 2) r = o->comm->api.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, xs);
@@ -1845,15 +1924,51 @@ int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) {
                              o->comm->api.GetErrorString ? o->comm->api.GetErrorString(r) : "error");
                     return fail(p->ctx, CFX_ERR_LAUNCH, buf);
                 }
-                if (p->side_mode && hipEventRecord(o->ev_done, p->side) != hipSuccess) return fail(p->ctx, CFX_ERR_LAUNCH, "plan: event record failed");
+                if (side_mode && hipEventRecord(o->ev_done, p->side) != hipSuccess) return fail(p->ctx, CFX_ERR_LAUNCH, "plan: event record failed");
             } break;
             case 3:
-                if (p->side_mode && hipStreamWaitEvent(main_s, p->ops[o->ref].ev_done, 0) != hipSuccess) return fail(p->ctx, CFX_ERR_LAUNCH, "plan: wait failed");
+                if (side_mode && hipStreamWaitEvent(main_s, p->ops[o->ref].ev_done, 0) != hipSuccess) return fail(p->ctx, CFX_ERR_LAUNCH, "plan: wait failed");
                 break;
         }
         if (rc != CFX_OK) return rc;
     }
     return CFX_OK;
+}
+
+int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) { return plan_run_impl(p, first_op, n_ops, stream, false); }
+
+// The whole op range on the plan's EXCHANGE stream, forked off `main_stream` and joined back later: everything a layer's exchange
+// does - compress, collective, reconstruction - runs beside what the caller enqueues on `main_stream` in between (the local
+// attention block).  cfx_plan_join makes `main_stream` wait for the range.  The activations (xs, see cfx_plan_run_x) must stay
+// alive until the join.
+int cfx_plan_run_async(cfx_plan* p, int first_op, int n_ops, const void* const* xs, int n_xs, void* main_stream) {
+    if (!p) return CFX_ERR_NULL;
+    if (!p->side) return fail(p->ctx, CFX_ERR_BATCH, "plan: run_async needs an exchange stream (cfx_plan_use_exchange_stream, or mode 1 / 2 and an exchange op)");
+    if (!p->ev_fork && (hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess))
+        return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot create events");
+    if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
+    if (n_xs > 0) {
+        if (!xs) return CFX_ERR_NULL;
+        int op = first_op;
+        while (op < first_op + n_ops && p->ops[op].kind != 0) ++op;
+        if (op == first_op + n_ops || p->ops[op].batch != n_xs) return fail(p->ctx, CFX_ERR_BATCH, "plan: run_async needs a compress op with n_xs items in the range");
+        for (int i = 0; i < n_xs; ++i) {
+            if (!xs[i] || !AL16(xs[i])) return fail(p->ctx, CFX_ERR_ALIGN, "plan: activations must be non-null and 16-byte aligned");
+            p->ops[op].c[i].x = xs[i];
+        }
+    }
+    if (hipEventRecord(p->ev_fork, (hipStream_t)main_stream) != hipSuccess || hipStreamWaitEvent(p->side, p->ev_fork, 0) != hipSuccess)
+        return fail(p->ctx, CFX_ERR_LAUNCH, "plan: fork failed");
+    const int rc = plan_run_impl(p, first_op, n_ops, (void*)p->side, true);
+    if (hipEventRecord(p->ev_join, p->side) != hipSuccess) return fail(p->ctx, CFX_ERR_LAUNCH, "plan: join event failed");
+    return rc;
+}
+
+int cfx_plan_join(cfx_plan* p, void* main_stream) {
+    if (!p) return CFX_ERR_NULL;
+    if (!p->ev_join) return fail(p->ctx, CFX_ERR_BATCH, "plan: join without run_async");
+    return hipStreamWaitEvent((hipStream_t)main_stream, p->ev_join, 0) == hipSuccess ? CFX_OK : fail(p->ctx, CFX_ERR_LAUNCH, "plan: join failed");
 }
 
 // Software-pipelined replay of a 1-bit exchange step.  The op range must be a sequence of "groups"
@@ -2168,6 +2283,19 @@ int cfx_residual2_update(cfx_ctx* ctx, const void* base, const void* delta_base,
     LAUNCH(ctx, KID_RES2_UPDATE, s, k_residual2_update, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, (const h16*)base,
            (const h16*)delta_base, (const h16*)recv, (h16*)new_base, (h16*)new_delta_base, decay, n8);
     return check_launch(ctx, "residual2_update launch");
+}
+
+int cfx_attn_merge(cfx_ctx* ctx, void* out, void* lse, const void* block_out, const void* block_lse, int B, int S, int H, int D,
+                   int block_out_bshd, int first, void* stream) {
+    if (!ctx || !out || !lse || !block_out || !block_lse) return fail(ctx, CFX_ERR_NULL, "attn_merge: null pointer");
+    if (B <= 0 || S <= 0 || H <= 0 || D <= 0 || (D & 7)) return fail(ctx, CFX_ERR_SHAPE, "attn_merge: head dim must be a positive multiple of 8");
+    if (!AL16(out) || !AL16(block_out)) return fail(ctx, CFX_ERR_ALIGN, "attn_merge: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = (size_t)B * S * H * (D / 8);
+    LAUNCH(ctx, KID_ATTN_MERGE, s, k_attn_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (float*)out, (float*)lse,
+           (const h16*)block_out, (const float*)block_lse, B, S, H, D, first,
+           (size_t)S * H * D, block_out_bshd ? (size_t)H * D : (size_t)D, block_out_bshd ? (size_t)D : (size_t)S * D);
+    return check_launch(ctx, "attn_merge launch");
 }
 
 int cfx_copy_probe(cfx_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {

@@ -77,3 +77,38 @@ class NativeComm:
         if self.handle:
             self.lib.cfx_comm_destroy(self.handle)
             self.handle = None
+
+
+# ---- one communicator per (process group, device), created on first use by every rank of the group together -----------------
+_comms = {}
+_factory = None          # tests / measurement tools: callable(group, device) -> object with .handle (e.g. a fake-RCCL communicator)
+_failed = set()
+
+
+def set_comm_factory(fn) -> None:
+    """Replace how `native_comm_for` obtains a communicator (None restores the RCCL bootstrap).  Drops cached communicators."""
+    global _factory
+    _factory = fn
+    _comms.clear()
+    _failed.clear()
+
+
+def native_comm_for(group, device: int):
+    """The library-owned communicator of `group` on `device`, or None when it cannot be created (the caller then keeps the
+    collective in torch.distributed - and says so once)."""
+    key = (id(group) if group is not None else None, device)
+    c = _comms.get(key)
+    if c is not None or key in _failed:
+        return c
+    try:
+        c = _factory(group, device) if _factory is not None else NativeComm(device, group)
+        if _factory is None:
+            c.self_test()
+        _comms[key] = c
+    except Exception as e:  # noqa: BLE001
+        import warnings
+        warnings.warn(f"compactfusion_amd: native exchange unavailable for this group ({e}); the per-layer collective stays in "
+                      "torch.distributed (about 50 us of host time per call)")
+        _failed.add(key)
+        c = None
+    return c

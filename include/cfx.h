@@ -162,7 +162,7 @@ int    cfx_lr_decompress_batch(cfx_ctx* ctx, int quantized, int N, int C, int ra
  * sender's error-feedback update, 17-22 low-rank chain (prep, aq, aty, chol, apply, decode), 23 binary_pipe (steady-state
  * fused launch of cfx_plan_run_pipelined), 24 binary_pipe prologue / epilogue / ragged-unit launches, 25 residual2_delta,
  * 26 residual2_update, 27 absmean_compress<bits> (statistics + sign bits + in-launch finalize [+ ride-along reconstruction]),
- * 28 absmean_compress (2-bit statistics + in-launch finalize), 29 minmax_compress (int4 / int8 statistics + in-launch finalize). */
+ * 28 absmean_compress (2-bit statistics + in-launch finalize), 29 minmax_compress (int4 / int8 statistics + in-launch finalize), 30 attn_merge. */
 int         cfx_profile_enable(cfx_ctx* ctx, int capacity, unsigned kernel_mask, int stride);
 int         cfx_profile_read(cfx_ctx* ctx, int* kernel_ids, float* ms, int cap);
 const char* cfx_kernel_name(int kernel_id);
@@ -190,6 +190,9 @@ typedef struct cfx_comm cfx_comm;
  * cfx_plan_run_pipelined with mode 1 / 2 issues the collectives of unit u on that stream underneath the fused launch that
  * follows finalize(u) (one more unit of look-ahead; no wait ops needed). */
 int       cfx_plan_set_exchange_stream(cfx_plan* plan, int mode);
+/* Use the caller's stream as this plan's exchange stream (mode 1 semantics; the plan does not own it).  Many plans - one
+ * per layer - should share ONE exchange stream: every stream is a hardware queue to the dispatcher. */
+int       cfx_plan_use_exchange_stream(cfx_plan* plan, void* stream);
 int       cfx_plan_add_all_gather(cfx_plan* plan, cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank);
 int       cfx_plan_add_wait(cfx_plan* plan, int gather_op);
 /* One hop of the ring relay (reference xfuser/compact/ring.py:193-195,265-269: RingComm.send_recv / commit / wait): send
@@ -202,6 +205,16 @@ int       cfx_plan_set_input(cfx_plan* plan, int op, int item, const void* x);
 int       cfx_plan_size(const cfx_plan* plan);
 int       cfx_plan_copy_op(cfx_plan* dst, const cfx_plan* src, int op);   /* append a copy of a (de)compress op of `src` */
 int       cfx_plan_run(cfx_plan* plan, int first_op, int n_ops, void* stream);
+/* cfx_plan_run after re-pointing the n_xs activations of the first compress op of the range (cfx_plan_set_input + run in
+ * one host call: what a layer's K,V hand-over costs). */
+int       cfx_plan_run_x(cfx_plan* plan, int first_op, int n_ops, const void* const* xs, int n_xs, void* stream);
+/* The op range - compress, collective, reconstruction - on the plan's EXCHANGE stream, forked off `main_stream` (an event)
+ * so that it runs beside what the caller enqueues on `main_stream` next: the local attention block, which needs none of it
+ * (reference ring.py:207-209).  Exchange ops of the range run in order on that stream; wait ops are no-ops.
+ * cfx_plan_join(plan, main_stream) makes `main_stream` wait for the range (before the first peer block).  Two host calls per
+ * layer.  The activations must stay alive until the join. */
+int       cfx_plan_run_async(cfx_plan* plan, int first_op, int n_ops, const void* const* xs, int n_xs, void* main_stream);
+int       cfx_plan_join(cfx_plan* plan, void* main_stream);
 /* Software-pipelined replay (replaces the reference's strictly sequential quantise -> cat -> send -> dequantise per layer,
  * xfuser/compact/ring.py:188-260 with fastpath.py:124-228, 371-438).  If ops [first_op, first_op + n_ops) are a sequence of "groups"
  *     k x compress (BINARY, flags without UPDATE_CACHE)   { all-gather }*   k x decompress (BINARY)      of one shape,
@@ -242,6 +255,15 @@ int       cfx_comm_ring_hop(cfx_comm* comm, const void* send, void* recv, size_t
 int cfx_residual2_delta(cfx_ctx* ctx, const void* x, const void* base, const void* delta_base, void* dd, size_t n, void* stream);
 int cfx_residual2_update(cfx_ctx* ctx, const void* base, const void* delta_base, const void* recv, void* new_base,
                          void* new_delta_base, float decay, size_t n, void* stream);
+
+/* Ring-attention block merge - the consumer side of the exchange (reference xfuser/compact/ring.py:263 calls
+ * yunchang.ring.utils.update_out_and_lse, un-vendored; published formula):
+ *   out <- out - sigmoid(lse_b - lse) * (out - out_b) ;  lse <- lse - logsigmoid(lse - lse_b)         (fp32)
+ * out fp32 [B][S][H][D], lse fp32 [B][S][H]; block_out fp16 [B][H][S][D] (block_out_bshd = 0) or [B][S][H][D] (= 1), block_lse fp32 [B][H][S]
+ * (the fused SDPA kernel's own output layouts).  first != 0 initialises out / lse from the block.  D % 8 == 0.  One launch per block instead of ~10
+ * eager elementwise kernels. */
+int cfx_attn_merge(cfx_ctx* ctx, void* out, void* lse, const void* block_out, const void* block_lse, int B, int S, int H, int D,
+                   int block_out_bshd, int first, void* stream);
 
 /* Bandwidth probe: dst[i] = src[i] over `bytes` (multiple of 16) - the achievable-HBM reference
  * against which bench.py reports roofline fractions. */

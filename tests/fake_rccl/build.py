@@ -13,7 +13,7 @@ def build(force: bool = False) -> str:
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= os.path.getmtime(SRC):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", SRC, "-o", LIB + ".tmp"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-x", "hip", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", SRC, "-o", LIB + ".tmp"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("building the fake RCCL failed:\n" + r.stdout + r.stderr)

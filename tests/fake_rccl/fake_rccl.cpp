@@ -11,7 +11,7 @@
 //                        buffer into all `nranks` slots, a ring hop receives what it sends) - the "8 logical ranks looped back
 //                        on one GPU" measurement protocol of tools/overlap_bench.py.
 // Build: hipcc -O2 -fPIC -shared tests/fake_rccl/fake_rccl.cpp -o tests/fake_rccl/libcfx_fake_rccl.so  (tests/fake_rccl/build.py)
-#include <hip/hip_runtime_api.h>
+#include <hip/hip_runtime.h>
 #include <condition_variable>
 #include <map>
 #include <mutex>
@@ -19,6 +19,14 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+
+// loopback all-gather: one launch replicates the send buffer into all slots (a real ncclAllGather is one enqueue too)
+__global__ void k_replicate(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16, int copies) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    const uint4 v = src[i];
+    for (int r = 0; r < copies; ++r) dst[(size_t)r * n16 + i] = v;
+}
 
 namespace {
 struct Pending { const void* send; void* recv; size_t bytes; int peer_send, peer_recv; };
@@ -97,6 +105,11 @@ int ncclAllGather(const void* send, void* recv, size_t count, int /*datatype: by
     Comm* c = (Comm*)comm;
     Group* g = c->g;
     if (g->loopback) {
+        if ((count & 15) == 0 && (((uintptr_t)send | (uintptr_t)recv) & 15) == 0) {
+            const size_t n16 = count / 16;
+            hipLaunchKernelGGL(k_replicate, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, stream, (uint4*)recv, (const uint4*)send, n16, g->nranks);
+            return hipGetLastError() == hipSuccess ? 0 : 1;
+        }
         for (int r = 0; r < g->nranks; ++r)
             if (hipMemcpyAsync((char*)recv + (size_t)r * count, send, count, hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;
         return 0;

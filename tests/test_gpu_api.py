@@ -591,3 +591,38 @@ def test_native_comm_single_rank(tmp_path):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_native_attention_merge_equals_the_eager_formula():
+    """cfx_attn_merge (one launch per attention block) vs the published update_out_and_lse formula in eager fp32 torch
+    (what the reference gets from yunchang, ring.py:263), on the fused SDPA kernel's own output layouts."""
+    from compactfusion_amd.compact import attention as A
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, S, H, D = 2, 77, 5, 64
+    q = torch.randn(B, S, H, D, device="cuda", dtype=torch.float16, generator=g)
+    out = lse = ref_o = ref_l = None
+    for blk in range(4):
+        k = torch.randn(B, 40 + blk, H, D, device="cuda", dtype=torch.float16, generator=g) * (1 + blk)
+        v = torch.randn(B, 40 + blk, H, D, device="cuda", dtype=torch.float16, generator=g)
+        bo, bl = A.block_attention(q, k, v, 0.0, None, causal=False)
+        if blk == 2:
+            bo = bo.transpose(1, 2).contiguous().transpose(1, 2)          # the other layout the kernel accepts: (B,H,S,D) underneath
+        calls = []
+        orig = A._merge_native
+        A._merge_native = lambda *a: (calls.append(a[-1]), orig(*a))[1]
+        try:
+            out, lse = A.update_out_and_lse(out, lse, bo, bl)
+        finally:
+            A._merge_native = orig
+        assert calls == [0 if blk == 2 else 1], "the native merge launch was not taken"
+        bo32, bl4 = bo.to(torch.float32), bl.transpose(-2, -1).unsqueeze(-1)
+        if ref_o is None:
+            ref_o, ref_l = bo32, bl4
+        else:
+            ref_o = ref_o - torch.sigmoid(bl4 - ref_l) * (ref_o - bo32)
+            ref_l = ref_l - F.logsigmoid(ref_l - bl4)
+    torch.cuda.synchronize()
+    assert out.dtype == torch.float32 and tuple(out.shape) == (B, S, H, D) and tuple(lse.shape) == (B, S, H, 1)
+    torch.testing.assert_close(out, ref_o, rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(lse, ref_l, rtol=2e-6, atol=2e-6)
