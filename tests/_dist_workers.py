@@ -16,18 +16,35 @@ for p in (REPO, HERE):
         sys.path.insert(0, p)
 
 
+DEV = "cpu"      # "cuda": the same worker bodies on the real kernels (two processes share GPU 0; tests/test_gpu_schedules.py)
+
+
 def _setup(rank, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import _oracle_backend as OB
-    OB.install_plain()
+    if DEV == "cpu":
+        import _oracle_backend as OB
+        OB.install_plain()
+    else:
+        torch.cuda.set_device(0)
     from compactfusion_amd.collector import collector
     collector.init(collector.Collector(tempfile.mkdtemp(), enabled=False))
 
 
 def bits(t):
-    return t.detach().contiguous().view(torch.int16).numpy().view(np.uint16)
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def TD(t):
+    """Worker inputs live where the run does."""
+    return t if (t is None or DEV == "cpu") else t.to("cuda")
+
+
+def TH(t):
+    if DEV != "cpu":
+        torch.cuda.synchronize()
+    return t.float().cpu().numpy()
 
 
 def drift(seed, shape, T):
@@ -40,7 +57,9 @@ def drift(seed, shape, T):
     return out
 
 
-def run(fn, rank, world, port, out_path, *args):
+def run(fn, rank, world, port, out_path, *args, device="cpu"):
+    global DEV
+    DEV = device
     try:
         _setup(rank, world, port)
         res = fn(rank, world, *args)
@@ -68,7 +87,7 @@ def w_all_gather(rank, world, codec_name):
     xs = drift(100 + rank, (N, C), 4)
     for t, x in enumerate(xs):
         typ = T.WARMUP if t == 0 else T[codec_name]
-        outs = cm.compact_all_gather("3-k", x.view(1, N, C), typ)
+        outs = cm.compact_all_gather("3-k", TD(x).view(1, N, C), typ)
         assert len(outs) == world and all(o.shape == (1, N, C) for o in outs)
         for i, o in enumerate(outs):
             res[f"t{t}/out{i}"] = bits(o).reshape(N, C).copy()
@@ -89,45 +108,47 @@ def w_ring(rank, world, schedule, codec_name, joint):
     import compactfusion_amd.compact.main as cm
     from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
     from compactfusion_amd.compact.ring import compact_fwd
-    B, S, H, D = 1, 16, 4, 32
+    B, S, Hh, Dh = (1, 16, 4, 32) if DEV == "cpu" else (1, 64, 8, 64)
     fast = codec_name in ("BINARY", "INT2")
     cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T[codec_name],
-                                  residual=1, ef=True, fastpath=fast, comp_rank=-1, check_consist=True))
-    qs = drift(7 + rank, (B, S, H, D), 3)
-    ks = drift(17 + rank, (B, S, H, D), 3)
-    vs = drift(27 + rank, (B, S, H, D), 3)
+                                  residual=1, ef=True, fastpath=fast, comp_rank=-1, check_consist=True, sparse_ratio=8))
+    qs = drift(7 + rank, (B, S, Hh, Dh), 3)
+    ks = drift(17 + rank, (B, S, Hh, Dh), 3)
+    vs = drift(27 + rank, (B, S, Hh, Dh), 3)
     g = torch.Generator().manual_seed(99)
-    jk = torch.randn(B, 8, H, D, generator=g).half() if joint != "none" else None
-    jv = torch.randn(B, 8, H, D, generator=g).half() if joint != "none" else None
+    jk = torch.randn(B, 8, Hh, Dh, generator=g).half() if joint != "none" else None
+    jv = torch.randn(B, 8, Hh, Dh, generator=g).half() if joint != "none" else None
     res = {}
     for step in range(3):
         cm.compact_set_step(step)
-        out, lse, _ = compact_fwd(qs[step], ks[step], vs[step], causal=False, group=None, joint_tensor_key=jk,
-                                  joint_tensor_value=jv, joint_strategy=joint, mod_idx=5, current_iter=step)
-        assert out.shape == (B, S, H, D) and out.dtype == torch.float16 and lse.shape == (B, H, S)
-        res[f"s{step}/out"] = out.float().numpy()
-        res[f"s{step}/lse"] = lse.float().numpy()
+        out, lse, _ = compact_fwd(TD(qs[step]), TD(ks[step]), TD(vs[step]), causal=False, group=None, joint_tensor_key=TD(jk),
+                                  joint_tensor_value=TD(jv), joint_strategy=joint, mod_idx=5, current_iter=step)
+        assert out.shape == (B, S, Hh, Dh) and out.dtype == torch.float16 and lse.shape == (B, Hh, S)
+        res[f"s{step}/out"] = TH(out)
+        res[f"s{step}/lse"] = TH(lse)
         # what this rank attended to: its own exact K/V + the cached reconstructions of the peers
         kk, vv = [], []
         order = [(rank - s) % world for s in range(world)]
         for r in order:
             if r == rank:
-                kk.append(ks[step]); vv.append(vs[step])
+                kk.append(TD(ks[step])); vv.append(TD(vs[step]))
             else:
-                kk.append(cm.compact_cache().get_base(f"5-{r}-k").view(B, S, H, D).clone())
-                vv.append(cm.compact_cache().get_base(f"5-{r}-v").view(B, S, H, D).clone())
+                kk.append(cm.compact_cache().get_base(f"5-{r}-k").view(B, S, Hh, Dh).clone())
+                vv.append(cm.compact_cache().get_base(f"5-{r}-v").view(B, S, Hh, Dh).clone())
         if joint == "front":
-            kk.insert(0, jk); vv.insert(0, jv)
+            kk.insert(0, TD(jk)); vv.insert(0, TD(jv))
         elif joint == "rear":
-            kk.append(jk); vv.append(jv)
-        ref_out, ref_lse = _full_attention(qs[step], kk, vv)
-        res[f"s{step}/ref_out"] = ref_out.float().numpy()
-        res[f"s{step}/ref_lse"] = ref_lse.float().numpy()
+            kk.append(TD(jk)); vv.append(TD(jv))
+        ref_out, ref_lse = _full_attention(TD(qs[step]), kk, vv)
+        res[f"s{step}/ref_out"] = TH(ref_out)
+        res[f"s{step}/ref_lse"] = TH(ref_lse)
         # peers hold exactly the state the owner holds for its own shard (error feedback keeps them in lock step)
         res[f"s{step}/own_k_state"] = bits(cm.compact_cache().get_base(f"5-{rank}-k")).copy()
         for r in range(world):
             res[f"s{step}/state_k_{r}"] = bits(cm.compact_cache().get_base(f"5-{r}-k")).copy()
+            res[f"s{step}/state_v_{r}"] = bits(cm.compact_cache().get_base(f"5-{r}-v")).copy()
         res[f"s{step}/k"] = bits(ks[step])
+        res[f"s{step}/v"] = bits(vs[step])
     res["passed_count"] = np.array([cm.compact_cache().passed_count])
     return res
 
@@ -137,7 +158,7 @@ def w_patch(rank, world, mode):
     import compactfusion_amd.compact.main as cm
     from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig, PatchConfig
     from compactfusion_amd.compact.ring import compact_fwd
-    B, S, H, D = 1, 16, 4, 32
+    B, S, H, D = (1, 16, 4, 32) if DEV == "cpu" else (1, 64, 8, 64)
     pc = {"sync": PatchConfig(False, False, 0), "async": PatchConfig(False, True, 1), "compact": PatchConfig(True, False, 1)}[mode]
     cm.compact_init(CompactConfig(enabled=True, override_with_patch_gather_fwd=True, patch_gather_fwd_config=pc,
                                   compress_func=(lambda l, s: T.WARMUP if s == 0 else T.INT2) if mode == "compact" else None,
@@ -150,20 +171,23 @@ def w_patch(rank, world, mode):
     res = {}
     for step in range(4):
         cm.compact_set_step(step)
-        out, lse, _ = compact_fwd(qs[step], ks[step], vs[step], causal=False, group=None, mod_idx=2, current_iter=step)
-        res[f"s{step}/out"] = out.float().numpy()
+        out, lse, _ = compact_fwd(TD(qs[step]), TD(ks[step]), TD(vs[step]), causal=False, group=None, mod_idx=2, current_iter=step)
+        res[f"s{step}/out"] = TH(out)
         if mode == "sync" or (mode == "async" and step < 1) or (mode == "compact" and step == 0):
-            kk = [allk[r][step] for r in range(world)]
-            vv = [allv[r][step] for r in range(world)]
+            kk = [TD(allk[r][step]) for r in range(world)]
+            vv = [TD(allv[r][step]) for r in range(world)]
         elif mode == "async":
             # remote shards are one step stale, own shard is fresh (DistriFusion, fwd.py:146-159)
-            kk = [allk[r][step] if r == rank else allk[r][step - 1] for r in range(world)]
-            vv = [allv[r][step] if r == rank else allv[r][step - 1] for r in range(world)]
+            kk = [TD(allk[r][step] if r == rank else allk[r][step - 1]) for r in range(world)]
+            vv = [TD(allv[r][step] if r == rank else allv[r][step - 1]) for r in range(world)]
         else:
             kk = [cm.compact_cache().get_base(f"2-k-{r}").view(B, S, H, D).clone() for r in range(world)]
             vv = [cm.compact_cache().get_base(f"2-v-{r}").view(B, S, H, D).clone() for r in range(world)]
-        ref_out, _ = _full_attention(qs[step], kk, vv)
-        res[f"s{step}/ref_out"] = ref_out.float().numpy()
+            for r in range(world):
+                res[f"s{step}/state_k_{r}"] = bits(kk[r]).copy()
+        ref_out, _ = _full_attention(TD(qs[step]), kk, vv)
+        res[f"s{step}/ref_out"] = TH(ref_out)
+        res[f"s{step}/k"] = bits(ks[step])
     return res
 
 
@@ -172,7 +196,7 @@ def w_patch_displaced(rank, world):
     import compactfusion_amd.compact.main as cm
     from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig, PatchConfig
     from compactfusion_amd.compact.ring import compact_fwd
-    B, S, H, D, STEPS = 1, 16, 4, 32, 5
+    B, S, H, D, STEPS = (1, 16, 4, 32, 5) if DEV == "cpu" else (1, 64, 8, 64, 5)
     qs = drift(7 + rank, (B, S, H, D), STEPS)
     ks = drift(17 + rank, (B, S, H, D), STEPS)
     vs = drift(27 + rank, (B, S, H, D), STEPS)
@@ -183,8 +207,8 @@ def w_patch_displaced(rank, world):
                                       residual=1, ef=True, fastpath=True, comp_rank=-1))
         for step in range(STEPS):
             cm.compact_set_step(step)
-            out, lse, _ = compact_fwd(qs[step], ks[step], vs[step], causal=False, group=None, mod_idx=2, current_iter=step)
-            res[f"{mode}/s{step}/out"] = out.float().numpy()
+            out, lse, _ = compact_fwd(TD(qs[step]), TD(ks[step]), TD(vs[step]), causal=False, group=None, mod_idx=2, current_iter=step)
+            res[f"{mode}/s{step}/out"] = TH(out)
             for r in range(world):
                 res[f"{mode}/s{step}/state_k_{r}"] = bits(cm.compact_cache().get_base(f"2-k-{r}")).copy()
                 res[f"{mode}/s{step}/state_v_{r}"] = bits(cm.compact_cache().get_base(f"2-v-{r}")).copy()
@@ -192,12 +216,15 @@ def w_patch_displaced(rank, world):
         for r in range(world):
             res[f"{mode}/final/state_k_{r}"] = bits(cm.compact_cache().get_base(f"2-k-{r}")).copy()
     # what the displaced forward must have attended to: own shard fresh, peers as of the previous step
-    sync_state = lambda t, kv, r: torch.from_numpy(res[f"sync/s{t}/state_{kv}_{r}"].view(np.int16).copy()).view(torch.float16).view(B, S, H, D)  # noqa: E731
+    sync_state = lambda t, kv, r: TD(torch.from_numpy(res[f"sync/s{t}/state_{kv}_{r}"].view(np.int16).copy()).view(torch.float16).view(B, S, H, D))  # noqa: E731
     for step in range(1, STEPS):
-        kk = [ks[step] if r == rank else sync_state(step - 1, "k", r) for r in range(world)]
-        vv = [vs[step] if r == rank else sync_state(step - 1, "v", r) for r in range(world)]
-        ref_out, _ = _full_attention(qs[step], kk, vv)
-        res[f"disp/s{step}/ref_out"] = ref_out.float().numpy()
+        kk = [TD(ks[step]) if r == rank else sync_state(step - 1, "k", r) for r in range(world)]
+        vv = [TD(vs[step]) if r == rank else sync_state(step - 1, "v", r) for r in range(world)]
+        ref_out, _ = _full_attention(TD(qs[step]), kk, vv)
+        res[f"disp/s{step}/ref_out"] = TH(ref_out)
+    for step in range(STEPS):
+        res[f"s{step}/k"] = bits(ks[step])
+        res[f"s{step}/v"] = bits(vs[step])
     return res
 
 
@@ -215,7 +242,7 @@ def w_hook_layer(rank, world, ulysses, ring, compact_on):
     else:
         cm.compact_init(CompactConfig(enabled=False))
     layers = [xFuserLongContextAttention(), xFuserLongContextAttention()]
-    B, S, H, D = 1, 16, 4, 32                     # per-rank shard
+    B, S, H, D = (1, 16, 4, 32) if DEV == "cpu" else (1, 64, 8, 64)      # per-rank shard
     res = {}
     allq = [drift(7 + r, (B, S, H, D), 2) for r in range(world)]
     allk = [drift(17 + r, (B, S, H, D), 2) for r in range(world)]
@@ -223,15 +250,15 @@ def w_hook_layer(rank, world, ulysses, ring, compact_on):
     for step in range(2):
         cm.compact_set_step(step)
         for li, layer in enumerate(layers):
-            out = layer(None, allq[rank][step], allk[rank][step], allv[rank][step], causal=False)
+            out = layer(None, TD(allq[rank][step]), TD(allk[rank][step]), TD(allv[rank][step]), causal=False)
             assert out.shape == (B, S, H, D)
-            res[f"s{step}/l{li}/out"] = out.float().numpy()
+            res[f"s{step}/l{li}/out"] = TH(out)
             # reference: full attention over the whole sequence (ranks in order), my query shard
             from compactfusion_amd.compact.attention import block_attention
-            kk = torch.cat([allk[r][step] for r in range(world)], dim=1)
-            vv = torch.cat([allv[r][step] for r in range(world)], dim=1)
-            ref, _ = block_attention(allq[rank][step], kk, vv, 0.0, None, causal=False)
-            res[f"s{step}/l{li}/ref"] = ref.float().numpy()
+            kk = torch.cat([TD(allk[r][step]) for r in range(world)], dim=1)
+            vv = torch.cat([TD(allv[r][step]) for r in range(world)], dim=1)
+            ref, _ = block_attention(TD(allq[rank][step]), kk, vv, 0.0, None, causal=False)
+            res[f"s{step}/l{li}/ref"] = TH(ref)
         assert layers[0].idx == 0 and layers[1].idx == 1
     if compact_on:
         res["keys"] = np.array(sorted(cm.compact_cache().base.keys()), dtype="U")

@@ -74,7 +74,18 @@ def test_binary_fastpath_e2e_vs_sim(shape, seed, update_cache):
         assert_tensor_close(nbk, nbs, desc="New base")
     else:
         assert nbk is None and nbs is None
-    assert_tensor_close(binary_dequant_fastpath(pk, uk, vk, base), sim_binary_dequant_fastpath(ps, us, vs, base), desc="Recon")
+    rec = binary_dequant_fastpath(pk, uk, vk, base)
+    assert_tensor_close(rec, sim_binary_dequant_fastpath(ps, us, vs, base), desc="Recon")
+    # parity: the reference's test compares the fused kernel with its simulation twin; here both ARE the HIP path, so the
+    # evidence is the oracle (pinned to the reference's golden vectors): every output bit for bit
+    from oracle import c_oracle as CO
+    pkt, nb = CO.compress("binary", bits(x), bits(base), N, C, update=True)
+    q = N * C // 16
+    assert np.array_equal(pk.cpu().numpy().reshape(-1), pkt[:q].view(np.uint8)), "packed signs vs oracle"
+    assert np.array_equal(bits(uk).reshape(-1), pkt[q:q + N]) and np.array_equal(bits(vk).reshape(-1), pkt[q + N:]), "scales vs oracle"
+    if update_cache:
+        assert np.array_equal(bits(nbk), nb), "error-feedback state vs oracle"
+    assert np.array_equal(bits(rec), nb), "reconstruction vs oracle"
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -95,7 +106,16 @@ def test_int2_fastpath_e2e_vs_sim(shape, seed, update_cache):
     assert_tensor_approx(vk, vs, tol=0.02, desc="V")
     if update_cache:
         assert_tensor_approx(nbk, nbs, tol=0.02, desc="New base")
-    assert_tensor_approx(int2_dequant_fastpath(pk, uk, vk, base), sim_int2_dequant_fastpath(ps, us, vs, base), tol=0.02)
+    rec = int2_dequant_fastpath(pk, uk, vk, base)
+    assert_tensor_approx(rec, sim_int2_dequant_fastpath(ps, us, vs, base), tol=0.02)
+    from oracle import c_oracle as CO          # parity evidence: the oracle, bit for bit (see the 1-bit test above)
+    pkt, nb = CO.compress("int2", bits(x), bits(base), N, C, update=True)
+    q = N * C // 8
+    assert np.array_equal(pk.cpu().numpy().reshape(-1), pkt[:q].view(np.uint8)), "2-bit codes vs oracle"
+    assert np.array_equal(bits(uk).reshape(-1), pkt[q:q + N]) and np.array_equal(bits(vk).reshape(-1), pkt[q + N:]), "scales vs oracle"
+    if update_cache:
+        assert np.array_equal(bits(nbk), nb), "error-feedback state vs oracle"
+    assert np.array_equal(bits(rec), nb), "reconstruction vs oracle"
 
 
 SLOW_SHAPES = [(1024, 2048), (512, 4096), (256, 8192)]
@@ -271,8 +291,8 @@ def _gpu_ring_worker(rank, world, port, out):
 
 
 def test_ring_schedules_two_processes_one_gpu(tmp_path):
-    """Relay (reference schedule) and gather (MI355X-native schedule: side-stream all-gather + one batched
-    reconstruction) give identical outputs and identical, rank-consistent state on the real kernels."""
+    """CONSISTENCY check, not parity (parity vs the oracle and full attention: tests/test_gpu_schedules.py): relay (reference
+    schedule) and gather (MI355X-native schedule) give the same outputs and identical, rank-consistent state on the real kernels."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "ring")
     mp.start_processes(_gpu_ring_worker, args=(2, _port(), out), nprocs=2, join=True, start_method="spawn")
@@ -327,8 +347,8 @@ def _gpu_patch_worker(rank, world, port, out):
 
 
 def test_patch_gather_sync_and_displaced_two_processes_one_gpu(tmp_path):
-    """The fused K+V compressed gather (`compact_all_gather_kv`, prepared native batches) and its displaced variant on the
-    real kernels: states rank-consistent, the displaced run lags the synchronous one by exactly one step and ends equal."""
+    """CONSISTENCY check, not parity (parity vs the oracle: tests/test_gpu_schedules.py): the fused K+V compressed gather and its
+    displaced variant on the real kernels - states rank-consistent, the displaced run lags the synchronous one by one step."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "patch")
     mp.start_processes(_gpu_patch_worker, args=(2, _port(), out), nprocs=2, join=True, start_method="spawn")
