@@ -95,6 +95,8 @@ def parse():
     ap.add_argument("--copy-probe", type=int, default=0,
                     help="also launch the 96 MiB float4 copy probe this many times before the timed region "
                          "(known byte count: calibrates FETCH_SIZE / WRITE_SIZE in PMC profiles)")
+    ap.add_argument("--print-config-key", action="store_true",
+                    help="print the configuration key profile summaries are matched against (tools/collect_profiles.sh) and exit")
     ap.add_argument("--event-stride", type=int, default=29,
                     help="bracket every k-th launch of the profiled kernels with hipEvents (an event pair costs a few us of stream time)")
     return ap.parse_args()
@@ -156,8 +158,18 @@ def group_recv_offset(l: int, r: int, kv: int, G: int, L: int, live: int, slot: 
     return (a * live * 2 + (r * (b - a) + (l - a)) * 2 + kv) * slot
 
 
+def config_key(args, n_gpus):
+    """What a committed profile must have been taken with for its figures to be quoted beside this run's."""
+    pipelined = args.replay == "pipelined"
+    return {"codec": args.codec, "replay": args.replay, "own_ef": args.own_ef if not pipelined else None, "layers": args.layers,
+            "shard": [N_TOK, C_CH], "rows": args.rows, "n_gpus": n_gpus}
+
+
 def main():
     args = parse()
+    if args.print_config_key:
+        print(json.dumps(config_key(args, args.gpus)))
+        return
     import torch
     import torch.distributed as dist
 
@@ -655,8 +667,7 @@ def main():
                 "note": "latency-bound: a global reduction (scales) sits between reading K,V and the packet being complete"}
         # PMC traffic / rocprof cross-reference: only when the committed profile was taken with THIS configuration
         prof = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
-        cfg_key = {"codec": args.codec, "replay": args.replay, "own_ef": args.own_ef if not pipelined else None, "layers": L, "shard": [N, C],
-                   "rows": args.rows, "n_gpus": live}
+        cfg_key = config_key(args, live)
         if os.path.exists(prof):
             try:
                 pj = json.load(open(prof))

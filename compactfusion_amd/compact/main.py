@@ -492,9 +492,24 @@ class _KVExchange:
         step = codecs.CFX_MAX_BATCH
         for p in range(2):
             s_, r_, sl = self.send[p], self.recv[p], self.slot
-            self.comp[p] = codecs.prepare_compress(cid, own, [None, None], [s_[:n_half], s_[sl:sl + n_half]], N, C, param,
-                                                   update_cache=False, ef=ef)
+            own_pkts = [s_[:n_half], s_[sl:sl + n_half]]
             pkts = [r_[i * sl:i * sl + n_half] for i in range(2 * self.world)]
+            if cid >= 100:
+                # low-rank family (BASELINE config 5): the batched native chain, K and V together; the start matrices are drawn
+                # per call as the reference does (compress_lowrank.py:41)
+                from . import lowrank
+                quant = cid == lowrank.LOW_RANK_Q_ID
+
+                def comp(xs, sh, own_pkts=own_pkts):
+                    dev = xs[0].device
+                    codecs.lr_compress_batch(quant, [x.view(N, C) for x in xs], own, [None, None], own_pkts,
+                                             [lowrank._start(C, param, dev), lowrank._start(C, param, dev)], N, C, param,
+                                             update_cache=False, ef=ef)
+                self.comp[p] = comp
+                self.dec[p] = [(lambda sh, a=pkts[i:i + step], b=bases[i:i + step]: codecs.lr_decompress_batch(quant, a, b, b, N, C, param))
+                               for i in range(0, len(bases), step)]
+                continue
+            self.comp[p] = codecs.prepare_compress(cid, own, [None, None], own_pkts, N, C, param, update_cache=False, ef=ef)
             self.dec[p] = [codecs.prepare_decompress(cid, pkts[i:i + step], bases[i:i + step], bases[i:i + step], N, C, param)
                            for i in range(0, len(bases), step)]
         self.kviews = [b.view(shape) for b in kb]
@@ -567,8 +582,14 @@ def compact_all_gather_kv(tag_k, tag_v, k: torch.Tensor, v: torch.Tensor, comp_t
                and not _cache.quantize)
     if fusable:
         cid, param = _native(comp_type)
-        fusable = cid < 100
     if not fusable:
+        if displaced and comp_type != T.WARMUP:
+            # never degrade silently to a synchronous gather: the displaced exchange exists for native first-order codecs only
+            why = ("simulate_compress" if cfg.simulate_compress else "compress_residual != 1" if cfg.compress_residual != 1 else
+                   "log_compress_stats" if cfg.log_compress_stats else "quantized_cache" if _cache.quantize else
+                   "K and V of different shape or not contiguous")
+            raise NotImplementedError(f"displaced (one-step-stale) compressed gather is not available with {why}; "
+                                      "use PatchConfig(displaced_compact=False) or change that option")
         if ex is not None:
             ex.flush()
         return (compact_all_gather(tag_k, k, comp_type, group=group), compact_all_gather(tag_v, v, comp_type, group=group))

@@ -191,11 +191,14 @@ def w_patch(rank, world, mode):
     return res
 
 
-def w_patch_displaced(rank, world):
+def w_patch_displaced(rank, world, codec_name="BINARY"):
     """Extension: displaced (one-step-stale) compressed patch gather next to the synchronous compressed gather."""
     import compactfusion_amd.compact.main as cm
-    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig, PatchConfig
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig, PatchConfig, lowrank
     from compactfusion_amd.compact.ring import compact_fwd
+    lr = codec_name.startswith("LOW_RANK")
+    if lr:   # same start matrix in both runs (the reference draws a fresh one per call: the two runs could not be compared)
+        lowrank.set_init_q(torch.randn(4 * 32 if DEV == "cpu" else 8 * 64, 8, generator=torch.Generator().manual_seed(77)))
     B, S, H, D, STEPS = (1, 16, 4, 32, 5) if DEV == "cpu" else (1, 64, 8, 64, 5)
     qs = drift(7 + rank, (B, S, H, D), STEPS)
     ks = drift(17 + rank, (B, S, H, D), STEPS)
@@ -203,8 +206,8 @@ def w_patch_displaced(rank, world):
     res = {}
     for mode, pc in (("sync", PatchConfig(True, False, 1)), ("disp", PatchConfig(True, True, 1, displaced_compact=True))):
         cm.compact_init(CompactConfig(enabled=True, override_with_patch_gather_fwd=True, patch_gather_fwd_config=pc,
-                                      compress_func=lambda l, s: T.WARMUP if s == 0 else T.BINARY,
-                                      residual=1, ef=True, fastpath=True, comp_rank=-1))
+                                      compress_func=lambda l, s: T.WARMUP if s == 0 else T[codec_name],
+                                      residual=1, ef=True, fastpath=not lr, comp_rank=8 if lr else -1))
         for step in range(STEPS):
             cm.compact_set_step(step)
             out, lse, _ = compact_fwd(TD(qs[step]), TD(ks[step]), TD(vs[step]), causal=False, group=None, mod_idx=2, current_iter=step)
@@ -225,6 +228,7 @@ def w_patch_displaced(rank, world):
     for step in range(STEPS):
         res[f"s{step}/k"] = bits(ks[step])
         res[f"s{step}/v"] = bits(vs[step])
+    lowrank.set_init_q(None)
     return res
 
 

@@ -273,6 +273,39 @@ def g8(mode, man):
     st.save(man)
 
 
+def g8b(mode, man):
+    """G8 at BASELINE config 5's shard, SD3-medium 1024^2 ring 8: (N, C) = (512, 1536), every preset rank (8, 12, 16, 32;
+    examples/configs.py:63-110).  Factors and start matrices stored, the big products pinned by sha256."""
+    import torch
+    from xfuser.compact.compress_lowrank import subspace_iter
+    from xfuser.compact.compress_quantize import quantize_int4, dequantize_int4
+    st = Store("g8b_lowrank_sd3", mode)
+    N, C, seed = 512, 1536, 42
+    x, base = gen_inputs(seed, N, C)
+    delta = (x - base).contiguous()
+    tag = f"{N}x{C}_s{seed}"
+    st.put(f"{tag}/x", np16(x), False)
+    st.put(f"{tag}/base", np16(base), False)
+    for r in (8, 12, 16, 32):
+        g = torch.Generator().manual_seed(1000 + r)
+        q0 = torch.randn(C, r, generator=g, dtype=torch.float)
+        q0, _ = torch.linalg.qr(q0)
+        U, V, Q = subspace_iter(delta, r, 2, init_q=q0)
+        st.put(f"{tag}/r{r}/q0", q0.numpy())
+        st.put(f"{tag}/r{r}/U", np16(U))
+        st.put(f"{tag}/r{r}/V", np16(V))
+        st.put(f"{tag}/r{r}/UV", np16(torch.matmul(U, V)), False)
+        if r % 8 == 0 and r >= 16:
+            qu, su, mu = quantize_int4(U.half())
+            qv, sv, mv = quantize_int4(V.half().t())
+            st.put(f"{tag}/r{r}/qU", np16(qu)); st.put(f"{tag}/r{r}/sU", np16(su)); st.put(f"{tag}/r{r}/mU", np16(mu))
+            st.put(f"{tag}/r{r}/qV", np16(qv)); st.put(f"{tag}/r{r}/sV", np16(sv)); st.put(f"{tag}/r{r}/mV", np16(mv))
+            dec = torch.matmul(dequantize_int4(qu, su, mu), dequantize_int4(qv, sv, mv).t())      # slowpath.py:151-164
+            st.put(f"{tag}/r{r}/qdec", np16(dec), False)
+        print("G8b", tag, r, flush=True)
+    st.save(man)
+
+
 def _drift_seq(seed, N, C, T):
     """Config-1 style drift: base0 ~ N(0,1); x_t = x_{t-1} + 0.1*randn."""
     import torch
@@ -388,7 +421,7 @@ def main():
     groups = args.groups.split(",")
     if args.mode == "compiled":
         groups = [g for g in groups if g in ("g3", "g9")]
-    fns = {"g1": g1_g2, "g3": g3_to_g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}
+    fns = {"g1": g1_g2, "g3": g3_to_g6, "g7": g7, "g8": g8, "g8b": g8b, "g9": g9, "g10": g10}
     for g in groups:
         fns[g](args.mode, man)
     import torch

@@ -104,11 +104,12 @@ def test_patch_gather_forward_2rank(tmp_path, mode):
             np.testing.assert_allclose(res[r][f"s{s}/out"], res[r][f"s{s}/ref_out"], rtol=2e-3, atol=2e-3)
 
 
-def test_displaced_compressed_patch_gather_2rank(tmp_path):
+@pytest.mark.parametrize("codec", ["BINARY", "LOW_RANK"])
+def test_displaced_compressed_patch_gather_2rank(tmp_path, codec):
     """Extension: with `PatchConfig(displaced_compact=True)` the packets are the
     synchronous run's packets, applied one step later - so peers are seen one step stale, the own shard fresh, and after
     the final flush every state equals the synchronous run's and is identical on every rank."""
-    res = _spawn(W.w_patch_displaced, 2, tmp_path)
+    res = _spawn(W.w_patch_displaced, 2, tmp_path, codec)       # LOW_RANK: BASELINE config 5 as written (displaced + low-rank)
     for r in range(2):
         assert np.array_equal(res[r]["disp/s0/out"], res[r]["sync/s0/out"])          # warm-up step is synchronous
         for s in range(1, 5):
@@ -139,3 +140,17 @@ def test_long_context_attention_hook_2rank(tmp_path, ulysses, ring, compact_on):
             keys = set(res[r]["keys"].tolist())
             want = {f"{l}-{q}-{t}" for l in range(2) for q in range(ring) for t in "kv"}     # "{layer}-{ring rank}-{k|v}"
             assert keys == want, keys
+
+
+def test_displaced_gather_refuses_what_it_cannot_do(monkeypatch):
+    """No silent synchronous fallback: a displaced compressed gather with an option the fused exchange does not cover raises."""
+    import torch
+    import _oracle_backend as OB
+    OB.install(monkeypatch)
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
+    cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: None, residual=1, ef=True, fastpath=True, comp_rank=-1,
+                                  log_stats=True))
+    k = torch.zeros(1, 16, 4, 32, dtype=torch.float16)
+    with pytest.raises(NotImplementedError, match="log_compress_stats"):
+        cm.compact_all_gather_kv("1-k", "1-v", k, k.clone(), T.BINARY, displaced=True)

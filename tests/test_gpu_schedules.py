@@ -132,6 +132,27 @@ def test_displaced_compressed_patch_gather_on_gpu_vs_oracle(tmp_path):
             assert np.array_equal(res[r][f"disp/final/state_k_{q}"].reshape(-1), want_k[q][4].reshape(-1))
 
 
+def test_displaced_low_rank_patch_gather_on_gpu(tmp_path):
+    """BASELINE config 5 as written: DistriFusion-style displaced patch gather WITH the low-rank residual codec (the reference
+    forbids async + compact, df_utils.py:13-16: an extension).  Every rank applies every packet once and in order: states are
+    identical on both ranks, lag the synchronous run by exactly one step and end equal to it; the output is full attention over
+    own-fresh + peers-one-step-stale K,V."""
+    res = _spawn(W.w_patch_displaced, 2, tmp_path, "LOW_RANK")
+    for r in range(2):
+        for s in range(1, 5):
+            np.testing.assert_allclose(res[r][f"disp/s{s}/out"], res[r][f"disp/s{s}/ref_out"], rtol=2e-3, atol=2e-3)
+            for q in range(2):
+                assert np.array_equal(res[0][f"sync/s{s}/state_k_{q}"], res[1][f"sync/s{s}/state_k_{q}"])
+                assert np.array_equal(res[r][f"disp/s{s}/state_k_{q}"], res[r][f"sync/s{s - 1}/state_k_{q}"])
+        for q in range(2):
+            assert np.array_equal(res[r][f"disp/final/state_k_{q}"], res[r][f"sync/final/state_k_{q}"])
+            assert np.array_equal(res[0][f"disp/final/state_k_{q}"], res[1][f"disp/final/state_k_{q}"])
+        # the codec is lossy but tracks: relative error of the low-rank reconstruction of the peer's K after 4 steps
+        k4 = res[1 - r]["s4/k"].view(np.float16).astype(np.float32).reshape(-1)
+        st = res[r][f"sync/s4/state_k_{1 - r}"].view(np.float16).astype(np.float32).reshape(-1)
+        assert np.linalg.norm(k4 - st) / np.linalg.norm(k4) < 0.25
+
+
 @pytest.mark.parametrize("ulysses,ring,compact_on", [(1, 2, True), (2, 1, True), (1, 2, False)])
 def test_long_context_attention_hook_on_gpu(tmp_path, ulysses, ring, compact_on):
     res = _spawn(W.w_hook_layer, 2, tmp_path, ulysses, ring, compact_on)

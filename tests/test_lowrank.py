@@ -206,3 +206,55 @@ def test_lowrank_decode_kernels_vs_matmul(N, C, rank):
         K.lr_decompress_batch(True, [qpkt], [bases[0]], [out], N, C, rank)
         torch.cuda.synchronize()
         assert rel(out, bases[0] + wantq) < 1e-3
+
+
+FNB = "g8b_lowrank_sd3_eager.npz"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rank", [8, 12, 16, 32])
+def test_lowrank_config5_shard_vs_reference_factors(rank):
+    """BASELINE config 5 (SD3-medium 1024^2, ring 8): shard (512, 1536), the reference's factors for every preset rank
+    (golden G8b: subspace_iter(delta, r, 2, init_q) of the reference, examples/configs.py:63-110).  Given the same start matrix
+    the HIP chain must span the same subspace: U V (what the receiver adds to its state) within 3e-3 of the reference's, the
+    error-feedback state = base + fp16(U V), and for the int4-quantised presets the reference's OWN packet decodes to the same
+    reconstruction."""
+    from compactfusion_amd import codecs as K
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T
+    from compactfusion_amd.compact import lowrank as LR
+    from compactfusion_amd.compact.slowpath import slowpath_decompress
+    N, C = 512, 1536
+    tag = f"{N}x{C}_s42"
+    xb, bb = G.inputs(FNB, tag, 42, N, C)
+    x, base = t16(xb).cuda(), t16(bb).cuda()
+    gU, gV = t16(G.get(FNB, f"{tag}/r{rank}/U")).cuda(), t16(G.get(FNB, f"{tag}/r{rank}/V")).cuda()
+    want = gU.float() @ gV.float()
+    q0 = torch.zeros(C, K.lr_rank_pad(rank), dtype=torch.float32, device="cuda")
+    q0[:, :rank] = torch.from_numpy(G.get(FNB, f"{tag}/r{rank}/q0")).cuda()
+    pkt = torch.empty(K.lr_packet_halves(False, N, C, rank), dtype=torch.float16, device="cuda")
+    nb = torch.empty(N, C, dtype=torch.float16, device="cuda")
+    K.lr_compress_batch(False, [x], [base], [nb], [pkt], [q0], N, C, rank, update_cache=True, ef=True)
+    torch.cuda.synchronize()
+    U, V = pkt[:N * rank].view(N, rank), pkt[N * rank:].view(rank, C)
+    assert rel(U.float() @ V.float(), want) < 3e-3, rank
+    assert torch.allclose(U.float().t() @ U.float(), torch.eye(rank, device="cuda"), atol=5e-3)
+    assert G.sha(np.ascontiguousarray((gU.float() @ gV.float()).half().cpu().view(torch.int16).numpy().view(np.uint16))) is not None
+    # error-feedback state: base + decode(packet); within the codec tolerance of base + the reference's U V
+    rec = torch.empty(N, C, dtype=torch.float16, device="cuda")
+    K.lr_decompress_batch(False, [pkt], [base], [rec], N, C, rank)
+    torch.cuda.synchronize()
+    assert torch.equal(nb, rec), "sender state != receiver reconstruction"
+    assert rel(nb.float() - base.float(), want) < 4e-3
+    if rank in (16, 32):
+        as_half = lambda a: torch.from_numpy(np.ascontiguousarray(a)).contiguous().view(torch.uint8).view(torch.float16).reshape(-1)   # noqa: E731
+        h16 = lambda a: t16(a).reshape(-1)     # noqa: E731
+        gp = torch.cat([as_half(G.get(FNB, f"{tag}/r{rank}/qU")), h16(G.get(FNB, f"{tag}/r{rank}/sU")), h16(G.get(FNB, f"{tag}/r{rank}/mU")),
+                        as_half(G.get(FNB, f"{tag}/r{rank}/qV")), h16(G.get(FNB, f"{tag}/r{rank}/sV")), h16(G.get(FNB, f"{tag}/r{rank}/mV"))]).cuda()
+        assert gp.numel() == LR.packet_halves(LR.LOW_RANK_Q_ID, rank, N, C)
+        mine = slowpath_decompress(gp, (N, C), T.LOW_RANK_Q, rank=rank)
+        # the reference decodes with dequantize_int4 + fp16 matmul (slowpath.py:151-164): recompute it from its own sections
+        from compactfusion_amd.compact.compress_quantize import dequantize_int4
+        qu = torch.from_numpy(G.get(FNB, f"{tag}/r{rank}/qU")).cuda(); qv = torch.from_numpy(G.get(FNB, f"{tag}/r{rank}/qV")).cuda()
+        u = dequantize_int4(qu, t16(G.get(FNB, f"{tag}/r{rank}/sU")).cuda(), t16(G.get(FNB, f"{tag}/r{rank}/mU")).cuda())
+        v = dequantize_int4(qv, t16(G.get(FNB, f"{tag}/r{rank}/sV")).cuda(), t16(G.get(FNB, f"{tag}/r{rank}/mV")).cuda())
+        assert rel(mine, u.float() @ v.float().t()) < 1e-3

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel average duration from a rocprofv3 --kernel-trace CSV, keeping for every kernel only its launches with the
 largest grid (k_binary_pipe: the full three-group launches, not the pipeline's prologue / epilogue launches).
-Usage: tools/trace_kernel_avg.py <kernel_trace.csv> <out.json>"""
+Usage: tools/trace_kernel_avg.py <kernel_trace.csv> <out.json> [config-key JSON of the profiled bench command]"""
 import csv
 import json
 import sys
@@ -10,12 +10,13 @@ from collections import defaultdict
 
 def main():
     src, out = sys.argv[1:3]
+    cfg = json.loads(sys.argv[3]) if len(sys.argv) > 3 else None
     by = defaultdict(list)
     for r in csv.DictReader(open(src)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")          # template arguments kept: k_binary_pipe<true> = steady state
         grid = int(r.get("Grid_Size", 0) or 0) or (int(r.get("Grid_Size_X", 1)) * int(r.get("Grid_Size_Y", 1)) * int(r.get("Grid_Size_Z", 1)))
         by[name].append((grid, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
-    res = {"source": "rocprofv3 --kernel-trace", "unit": "us", "kernels": {}}
+    res = {"source": "rocprofv3 --kernel-trace", "unit": "us", "config": cfg, "kernels": {}}
     for name, v in by.items():
         if not name.startswith("k_"):
             continue
