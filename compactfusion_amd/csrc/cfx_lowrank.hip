@@ -310,39 +310,41 @@ __global__ __launch_bounds__(512) void k_lr_chol(LrBatch b, int r, int nparts, s
         if (e < RP * RP) { G[e / RP][e % RP] = gsym[q]; L[e / RP][e % RP] = 0.0; }
     }
     __syncthreads();
-    if (tid >= 64) return;          // the factorisation is tiny and sequential: ONE wave (its barriers are cheap)
-    // Right-looking Cholesky with lane i owning row i IN REGISTERS (all indices static through full unrolling); the only
-    // traffic per step is the freshly computed column, broadcast through LDS.  Then L^-1 column by column the same way.
+    // Right-looking Cholesky IN LDS with the whole workgroup on every step's trailing update (a step = two barriers; the
+    // single-wave register-resident form this replaces took 45 us at r = 32: one dependent LDS round trip per column and row).
     __shared__ double colv[RP];
-    __shared__ double pivs;
-    const int i = tid;
-    double gmax = 0.0;
-    for (int k = 0; k < r; ++k) gmax = fmax(gmax, G[k][k]);
-    double arow[RP];
-#pragma unroll
-    for (int k = 0; k < RP; ++k) arow[k] = (i < RP) ? G[i < RP ? i : 0][k] : 0.0;
-    unsigned deadmask = 0;
-#pragma unroll
-    for (int j = 0; j < RP; ++j) {
-        if (i == j) pivs = arow[j];
-        __syncthreads();
-        const double piv = pivs;
-        const bool bad = (j >= r) || !(piv > gmax * 1e-13);
-        if (bad && j < r) deadmask |= 1u << j;
-        double lij = 0.0;
-        if (i >= j && i < r && j < r) {
-            if (bad) lij = (i == j) ? 1.0 : 0.0;
-            else lij = (i == j) ? sqrt(piv) : arow[j] / sqrt(piv);
-        }
-        if (i < RP) { colv[i] = lij; L[i][j] = lij; }
-        __syncthreads();
-#pragma unroll
-        for (int k = j + 1; k < RP; ++k)
-            if (k <= i) arow[k] -= lij * colv[k];
-        __syncthreads();
+    __shared__ double gmax_s;
+    __shared__ unsigned dead_s;
+    if (tid == 0) {
+        double m = 0.0;
+        for (int k = 0; k < r; ++k) m = fmax(m, G[k][k]);
+        gmax_s = m; dead_s = 0;
     }
     __syncthreads();
-    // X = L^-1: lane i computes column i (x[m] = X[m][i]) by forward substitution; L rows are broadcast LDS reads
+    const double gmax = gmax_s;
+    for (int j = 0; j < RP; ++j) {
+        __syncthreads();                              // the previous step's trailing update is complete
+        const double piv = G[j][j];
+        const bool bad = (j >= r) || !(piv > gmax * 1e-13);
+        if (tid < RP) {
+            const int i = tid;
+            double l = 0.0;
+            if (i >= j && i < r && j < r) l = bad ? (i == j ? 1.0 : 0.0) : (i == j ? sqrt(piv) : G[i][j] / sqrt(piv));
+            colv[i] = l;
+            L[i][j] = l;
+            if (i == j && bad && j < r) dead_s |= 1u << j;
+        }
+        __syncthreads();
+        for (int e = tid; e < RP * RP; e += 512) {
+            const int i = e / RP, k = e % RP;
+            if (i > j && k > j && k <= i) G[i][k] -= colv[i] * colv[k];
+        }
+    }
+    __syncthreads();
+    if (tid >= RP) return;
+    // X = L^-1: thread i computes column i (x[m] = X[m][i]) by forward substitution; L rows are broadcast LDS reads
+    const int i = tid;
+    const unsigned deadmask = dead_s;
     double x[RP];
 #pragma unroll
     for (int m = 0; m < RP; ++m) {
@@ -352,14 +354,12 @@ __global__ __launch_bounds__(512) void k_lr_chol(LrBatch b, int r, int nparts, s
             if (k >= i) sacc -= L[m][k] * x[k];
         x[m] = (m >= i && m < r && i < r) ? sacc / L[m][m] : 0.0;
     }
-    // T[k][j] = X[j][k] (k <= j): Q = Z T; lane i writes row i of T.  Directions with a vanished pivot are dropped.
-    if (i < RP) {
+    // T[k][j] = X[j][k] (k <= j): Q = Z T; thread i writes row i of T.  Directions with a vanished pivot are dropped.
 #pragma unroll
-        for (int m = 0; m < RP; ++m) {
-            float v = 0.f;
-            if (i < r && m < r && m >= i && !((deadmask >> m) & 1u)) v = (float)x[m];
-            T[i * RP + m] = v;
-        }
+    for (int m = 0; m < RP; ++m) {
+        float v = 0.f;
+        if (i < r && m < r && m >= i && !((deadmask >> m) & 1u)) v = (float)x[m];
+        T[i * RP + m] = v;
     }
 }
 
