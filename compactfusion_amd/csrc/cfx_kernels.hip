@@ -79,8 +79,22 @@ __device__ __forceinline__ u64 habs_units(u16 b) {
 
 // fp16( fp32(exact_sum * 2^-24) / fp32(n) ) - oracle/ref_np.py mean16_exact
 __device__ __forceinline__ h16 mean16(u64 units, int n) {
-    const float s = (float)units * 0x1p-24f;
+    // u64 -> fp32 through fp64: exact below 2^53, then ONE rounding to fp32 = the direct conversion, in three instructions
+    // instead of the emulated 64-bit integer conversion
+    const float s = (float)(double)units * 0x1p-24f;
     return (h16)(s / (float)n);
+}
+
+// Wave-wide sum of a u32 with DPP adds (no LDS crossbar round trips): quad, half-row, row, then the two row broadcasts;
+// the total is in lane 63.  Caller guarantees the total fits 32 bits.
+__device__ __forceinline__ unsigned wave_sum_u32_dpp(unsigned v) {
+    v += __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x141, 0xf, 0xf, true);    // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x140, 0xf, 0xf, true);    // row_mirror: every lane holds its row's total
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, true);    // row_bcast15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, true);    // row_bcast31 into rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
@@ -391,22 +405,24 @@ __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, in
 
 #define FUSED_NW 8             // waves per workgroup of the single-launch compress kernel (512 threads: the last arriver of a
 #define FUSED_NT (FUSED_NW * 64)   //   column block owns one column per thread, of a tensor one row per thread)
-#define FUSED_CH 24            // partial sums a last-arriver thread keeps in flight per batch (one fabric round trip each batch)
+#define FUSED_CH 18            // partial sums a last-arriver thread keeps in flight per batch (one fabric round trip each batch;
+                               //   a last arriver reads fresh cross-CU data at ~65 GB/s, so every redundant load counts)
+#define FUSED_RCH 6            // column blocks of a row's partials per batch
 
 // Row sums of rows m0 and m1 from the transposed partials rowpart[k][n]: 8 column blocks (16 loads) per batch, every load
 // unconditional (clamped block index, masked value) - a remainder loop would be CB dependent round trips.
 __device__ __forceinline__ void row_sums2_wt(const u64* rowpart, int N, int CB, int m0, int m1, u64& s0, u64& s1) {
     s0 = 0; s1 = 0;
-    for (int k0 = 0; k0 < CB; k0 += 8) {
-        u64 a[8], b[8];
+    for (int k0 = 0; k0 < CB; k0 += FUSED_RCH) {
+        u64 a[FUSED_RCH], b[FUSED_RCH];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < FUSED_RCH; ++j) {
             const size_t kk = (size_t)min(k0 + j, CB - 1) * N;
             a[j] = ld_wt(&rowpart[kk + m0]);
             b[j] = ld_wt(&rowpart[kk + m1]);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s0 += (k0 + j < CB) ? a[j] : 0; s1 += (k0 + j < CB) ? b[j] : 0; }
+        for (int j = 0; j < FUSED_RCH; ++j) { s0 += (k0 + j < CB) ? a[j] : 0; s1 += (k0 + j < CB) ? b[j] : 0; }
     }
 }
 
@@ -479,7 +495,35 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
     if (last_all) row_sums2_wt(rowpart, N, CB, min(tid, N - 1), min(tid + NT, N - 1), keep0, keep1);
     asm volatile("" ::: "memory");
     STAMP(4);
-    // reductions first, every global store last: a barrier must not sit behind an outstanding store
+    // reductions first, every global store last: a barrier must not sit behind an outstanding store.  The tensor-wide job (U) is
+    // the longer chain, so it goes first and the column job (V) fills the wait for the other waves.
+    u64* smem = &sm[1][0];
+    float m0 = 0.f, m1 = 0.f;
+    if (last_all) {
+        // U: one thread per row, two rows per trip; the first trip's sums are already in registers
+        const h16 h0 = mean16(keep0, C), h1 = mean16(keep1, C);
+        m0 = (float)h0; m1 = (float)h1;
+        u64 acc = 0;
+        if (tid < N) acc += habs_units(hbits(h0));
+        if (tid + NT < N) acc += habs_units(hbits(h1));
+        for (int n0 = tid + 2 * NT; n0 - tid < N; n0 += 2 * NT) {
+            const int n1 = n0 + NT;
+            u64 s0, s1;
+            row_sums2_wt(rowpart, N, CB, min(n0, N - 1), min(n1, N - 1), s0, s1);
+            if (n0 < N) acc += habs_units(hbits(mean16(s0, C)));
+            if (n1 < N) acc += habs_units(hbits(mean16(s1, C)));
+        }
+        STAMP(13);
+        // a thread's acc is below 2^17 rows x 2^40 units; split at bit 24 so that both halves of the wave sum fit 32 bits
+        u64 wtot;
+        if (N <= 2 * NT) {
+            const unsigned lo = wave_sum_u32_dpp((unsigned)(acc & 0xffffffu));       // 64 x 2^24
+            const unsigned hi = wave_sum_u32_dpp((unsigned)(acc >> 24));             // 64 x 2^17 (two rows per thread)
+            wtot = ((u64)hi << 24) + lo;
+        } else wtot = wave_sum_u64(acc);
+        STAMP(14);
+        if ((tid & 63) == 0) smem[tid >> 6] = wtot;
+    }
     h16 vmean = (h16)0;
     if (last_col) {
         // V of column block bx: one column per thread
@@ -496,22 +540,6 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
     }
     STAMP(5);
     if (last_all) {
-        // U: one thread per row, two rows per trip; the first trip's sums are already in registers
-        u64* smem = &sm[1][0];
-        u64 acc = 0;
-        if (tid < N) acc += habs_units(hbits(mean16(keep0, C)));
-        if (tid + NT < N) acc += habs_units(hbits(mean16(keep1, C)));
-        for (int n0 = tid + 2 * NT; n0 - tid < N; n0 += 2 * NT) {
-            const int n1 = n0 + NT;
-            u64 s0, s1;
-            row_sums2_wt(rowpart, N, CB, min(n0, N - 1), min(n1, N - 1), s0, s1);
-            if (n0 < N) acc += habs_units(hbits(mean16(s0, C)));
-            if (n1 < N) acc += habs_units(hbits(mean16(s1, C)));
-        }
-        STAMP(13);
-        acc = wave_sum_u64(acc);
-        STAMP(14);
-        if ((tid & 63) == 0) smem[tid >> 6] = acc;
         lds_barrier();
         STAMP(15);
         u64 tot = 0;
@@ -519,8 +547,8 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
         for (int w = 0; w < NT / 64; ++w) tot += smem[w];           // every thread: no second barrier
         const h16 mu = mean16(tot, N);
         const float den = eps_mode ? (float)(h16)((float)mu + 1e-6f) : (float)mu;
-        if (tid < N) U[tid] = (h16)((float)mean16(keep0, C) / den);
-        if (tid + NT < N) U[tid + NT] = (h16)((float)mean16(keep1, C) / den);
+        if (tid < N) U[tid] = (h16)(m0 / den);
+        if (tid + NT < N) U[tid + NT] = (h16)(m1 / den);
         for (int n0 = tid + 2 * NT; n0 - tid < N; n0 += 2 * NT) {
             const int n1 = n0 + NT;
             u64 s0, s1;

@@ -411,3 +411,21 @@ def test_ride_along_reconstruction_in_the_compress_launch():
     same_bits(host_bits(state[1]), R.bits(b1), "layer 1 state untouched")
     # a ride item with a codec other than 1-bit is refused
     assert lib.cfx_compress_batch_ex(ctx, 2, N, C, 0, 0, 1, c1, 1, ride, ws.data_ptr(), ws.numel(), sh) == -4
+
+
+@pytest.mark.parametrize("name,cid", [("binary", 1), ("int2", 2)])
+def test_statistics_exact_sums_on_outliers_subnormals_and_signed_zeros(name, cid):
+    """The exact (order-independent) sums of |x - base| over a tensor that mixes ordinary rows with outliers up to the fp16
+    maximum, subnormals, exact zeros and -0.0 (whose sign bit must pack as >= 0): everything matches the oracle bit for bit."""
+    N, C = 544, 3072
+    rng = np.random.default_rng(77)
+    base = rng.standard_normal((N, C)).astype(F16)
+    x = (base.astype(np.float32) + 0.1 * rng.standard_normal((N, C)).astype(np.float32)).astype(F16)
+    x[5, 17] = F16(60000.0); x[5, 18] = F16(-65504.0)              # |d| near the fp16 maximum
+    x[100, :64] = F16(9.0) + base[100, :64]                        # just above the threshold of the fast lane
+    x[101, :64] = (base[101, :64].astype(np.float32) + 7.99).astype(F16)   # just below it
+    x[200, :] = base[200, :]                                       # exact zeros
+    x[201, ::3] = F16(-0.0); base[201, ::3] = F16(0.0)             # -0.0 - 0.0 = -0.0 >= 0 is True
+    x[300, :128] = (base[300, :128].astype(np.float32) + 6e-8).astype(F16)
+    base[301, :128] = 0; x[301, :128] = np.frombuffer(np.arange(1, 129, dtype=np.uint16).tobytes(), dtype=F16)   # subnormals
+    run_case(name, cid, 0, x, base, N, C)
