@@ -576,7 +576,8 @@ def compact_all_gather_kv(tag_k, tag_v, k: torch.Tensor, v: torch.Tensor, comp_t
     `displaced=True` selects the one-step-stale variant described in `_KVExchange`."""
     assert _config.enabled
     cfg = _config
-    ex = _kv_exchanges.get((tag_k, tag_v))
+    xkey = (tag_k, tag_v, id(group) if group is not None else None)
+    ex = _kv_exchanges.get(xkey)
     fusable = (comp_type != T.WARMUP and not cfg.simulate_compress and cfg.compress_residual == 1
                and not cfg.log_compress_stats and k.shape == v.shape and k.is_contiguous() and v.is_contiguous()
                and not _cache.quantize)
@@ -600,7 +601,7 @@ def compact_all_gather_kv(tag_k, tag_v, k: torch.Tensor, v: torch.Tensor, comp_t
     if ex is None or ex.slot != slot or ex.world != world or ex.device != k.device:
         if ex is not None:
             ex.flush()
-        ex = _kv_exchanges[(tag_k, tag_v)] = _KVExchange(tag_k, tag_v, rank, world, slot, k, group)
+        ex = _kv_exchanges[xkey] = _KVExchange(tag_k, tag_v, rank, world, slot, k, group)
     ex.flush()
     sig = (_generation, _cache.version, cid, param, N, C, tuple(k.shape), cfg.error_feedback)
     if ex.sig != sig:

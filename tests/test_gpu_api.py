@@ -400,24 +400,25 @@ def test_plan_replay_equals_direct_calls():
     lib.cfx_plan_destroy(plan)
 
 
-@pytest.mark.parametrize("codec", [1, 2, 3, 4])
+@pytest.mark.parametrize("codec", [1, 2, 3, 4, 5])
 def test_prepared_batches_equal_direct_calls(codec):
     """`codecs.prepare_compress / prepare_decompress` (cached pointer tables used by the ring gather schedule) are the
     same launches as `compress_batch / decompress_batch`, call after call, with fresh activation tensors each time."""
     from compactfusion_amd import codecs as K
     N, C, B = 128, 1024, 2
+    param = 8 if codec == 5 else 0          # SPARSE 1:8 needs no workspace (cfx_workspace_bytes == 0): the prepared form must cope
     g = torch.Generator().manual_seed(9)
     base0 = [torch.randn(N, C, generator=g).half().cuda() for _ in range(B)]
     st_a, st_b = [b.clone() for b in base0], [b.clone() for b in base0]
     peer_a, peer_b = [b.clone() for b in base0], [b.clone() for b in base0]
-    pk_a = [torch.zeros(K.packet_halves(codec, N, C), dtype=torch.float16, device="cuda") for _ in range(B)]
+    pk_a = [torch.zeros(K.packet_halves(codec, N, C, param), dtype=torch.float16, device="cuda") for _ in range(B)]
     pk_b = [torch.zeros_like(p) for p in pk_a]
-    comp = K.prepare_compress(codec, st_b, st_b, pk_b, N, C, update_cache=True, ef=True)
-    dec = K.prepare_decompress(codec, pk_b, peer_b, peer_b, N, C)
+    comp = K.prepare_compress(codec, st_b, st_b, pk_b, N, C, param, update_cache=True, ef=True)
+    dec = K.prepare_decompress(codec, pk_b, peer_b, peer_b, N, C, param)
     for step in range(3):
         xs = [(b.float() + 0.1 * (step + 1) * torch.randn(N, C, generator=g).cuda()).half() for b in base0]
-        K.compress_batch(codec, xs, st_a, st_a, pk_a, N, C, update_cache=True)
-        K.decompress_batch(codec, pk_a, peer_a, peer_a, N, C)
+        K.compress_batch(codec, xs, st_a, st_a, pk_a, N, C, param, update_cache=True)
+        K.decompress_batch(codec, pk_a, peer_a, peer_a, N, C, param)
         comp(xs)
         dec(torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
