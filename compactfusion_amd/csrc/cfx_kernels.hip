@@ -411,15 +411,20 @@ __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, in
 
 // Row sums of rows m0 and m1 from the transposed partials rowpart[k][n]: 8 column blocks (16 loads) per batch, every load
 // unconditional (clamped block index, masked value) - a remainder loop would be CB dependent round trips.
-__device__ __forceinline__ void row_sums2_wt(const u64* rowpart, int N, int CB, int m0, int m1, u64& s0, u64& s1) {
+__device__ __forceinline__ void row_sums2_wt(const u64* rowpart, int N, int CB, int m0, int m1, bool two, u64& s0, u64& s1) {
+    // `two` is wave-uniform: a wave whose second rows all lie beyond N skips that half of the batch (one branch around the
+    // batch, not one per load)
     s0 = 0; s1 = 0;
     for (int k0 = 0; k0 < CB; k0 += FUSED_RCH) {
         u64 a[FUSED_RCH], b[FUSED_RCH];
 #pragma unroll
-        for (int j = 0; j < FUSED_RCH; ++j) {
-            const size_t kk = (size_t)min(k0 + j, CB - 1) * N;
-            a[j] = ld_wt(&rowpart[kk + m0]);
-            b[j] = ld_wt(&rowpart[kk + m1]);
+        for (int j = 0; j < FUSED_RCH; ++j) a[j] = ld_wt(&rowpart[(size_t)min(k0 + j, CB - 1) * N + m0]);
+        if (two) {
+#pragma unroll
+            for (int j = 0; j < FUSED_RCH; ++j) b[j] = ld_wt(&rowpart[(size_t)min(k0 + j, CB - 1) * N + m1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < FUSED_RCH; ++j) b[j] = 0;
         }
 #pragma unroll
         for (int j = 0; j < FUSED_RCH; ++j) { s0 += (k0 + j < CB) ? a[j] : 0; s1 += (k0 + j < CB) ? b[j] : 0; }
@@ -492,7 +497,7 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
         for (int j = 0; j < FUSED_CH; ++j) v[j] = ld_wt(&colpart[(size_t)min(j, P - 1) * C + cc]);
     }
     u64 keep0 = 0, keep1 = 0;                  // row sums of rows tid, tid + NT
-    if (last_all) row_sums2_wt(rowpart, N, CB, min(tid, N - 1), min(tid + NT, N - 1), keep0, keep1);
+    if (last_all) row_sums2_wt(rowpart, N, CB, min(tid, N - 1), min(tid + NT, N - 1), (tid & ~63) + NT < N, keep0, keep1);
     asm volatile("" ::: "memory");
     STAMP(4);
     // reductions first, every global store last: a barrier must not sit behind an outstanding store.  The tensor-wide job (U) is
@@ -509,7 +514,7 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
         for (int n0 = tid + 2 * NT; n0 - tid < N; n0 += 2 * NT) {
             const int n1 = n0 + NT;
             u64 s0, s1;
-            row_sums2_wt(rowpart, N, CB, min(n0, N - 1), min(n1, N - 1), s0, s1);
+            row_sums2_wt(rowpart, N, CB, min(n0, N - 1), min(n1, N - 1), (n1 & ~63) < N, s0, s1);
             if (n0 < N) acc += habs_units(hbits(mean16(s0, C)));
             if (n1 < N) acc += habs_units(hbits(mean16(s1, C)));
         }
@@ -552,7 +557,7 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
         for (int n0 = tid + 2 * NT; n0 - tid < N; n0 += 2 * NT) {
             const int n1 = n0 + NT;
             u64 s0, s1;
-            row_sums2_wt(rowpart, N, CB, min(n0, N - 1), min(n1, N - 1), s0, s1);
+            row_sums2_wt(rowpart, N, CB, min(n0, N - 1), min(n1, N - 1), (n1 & ~63) < N, s0, s1);
             if (n0 < N) U[n0] = (h16)((float)mean16(s0, C) / den);
             if (n1 < N) U[n1] = (h16)((float)mean16(s1, C) / den);
         }
