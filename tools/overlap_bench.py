@@ -11,7 +11,8 @@ must hide under the local attention block).  Legs, all on the same inputs:
                  the local block
   torchdist      compact_fwd with the collective issued from Python (what round 1 did; the loop-back copy stands in for
                  torch.distributed.all_gather_into_tensor, whose ~50 us of host time per call is NOT included here)
-Reported: wall ms/step, host issue ms/step, exposed exchange = leg - attention, host us/layer.
+Reported: wall ms/step, host issue ms/step, exposed exchange = leg - attention, host us/layer (by difference of legs: noisy;
+and the native exchange's own host calls measured directly).
 Run on the GPU box:  python tools/overlap_bench.py [--steps K] [--json out.json]
 """
 import argparse
@@ -88,7 +89,8 @@ def attention_only(i):
         for step in range(W):
             bo, bl = block_attention(q, k, v, 0.0, None, causal=False)
             out, lse = update_out_and_lse(out, lse, bo, bl)
-        out = out.to(q.dtype)
+        out = out.to(q.dtype)                          # the epilogue every ring forward has (ring.py:271-272)
+        lse = lse.squeeze(dim=-1).transpose(1, 2)
 
 
 def fwd(i):
@@ -131,6 +133,27 @@ res["attention"] = timed(attention_only, 0)
 init("native", "chain")
 native_used = all(ex.plan is not None for ex in ring._xbuf.values() if ex.sig is not None)
 res["native"] = timed(fwd, 3)
+# host cost of the exchange itself, measured directly (the difference of two ~13 ms host-issue legs is noise): the two native
+# calls of a layer and the steady-state lane's checks, each into an empty queue
+def _host_us(fn, n=200):
+    tot = 0.0
+    for _ in range(n):
+        torch.cuda.synchronize()
+        th = time.perf_counter(); fn(); tot += time.perf_counter() - th
+    return tot / n * 1e6
+
+
+_ex = [e for e in ring._xbuf.values() if e.sig is not None and e.plan is not None][0]
+_st = next(iter(ring._steady.values()))
+_sh = torch.cuda.current_stream().cuda_stream
+_cfg = cm.compact_config()
+direct = {"run_front (fork + compress + all-gather + reconstruct + join event, one C call)": round(_host_us(lambda: _ex.run_front(ks[0][0], vs[0][0], _sh)), 1)}
+_ex.run_front(ks[0][0], vs[0][0], _sh)
+direct["run_back (join, one C call)"] = round(_host_us(lambda: _ex.run_back(_sh)), 1)
+direct["steady-lane checks (compress_func, matches, current_stream)"] = round(_host_us(
+    lambda: (_cfg.compress_func(0, 5), _st.matches(qs[0], ks[0][0], vs[0][0], _st.ctype, _cfg, False, 0), torch.cuda.current_stream(dev).cuda_stream)), 1)
+direct["total"] = round(sum(direct.values()), 1)
+torch.cuda.synchronize()
 init("native", "side")
 res["native_gather_only_on_side"] = timed(fwd, 3)
 init("torch")
@@ -146,7 +169,8 @@ out = {
     "legs_ms_per_step": {k: {"wall": round(v[0], 3), "host_issue": round(v[1], 3)} for k, v in res.items()},
     "exposed_exchange_ms_per_step": {k: round(res[k][0] - att, 3) for k in res if k != "attention"},
     "host_us_per_layer": {k: round(res[k][1] * 1e3 / L, 1) for k in res},
-    "host_us_per_layer_exchange_only": {k: round((res[k][1] - res["attention"][1]) * 1e3 / L, 1) for k in res if k != "attention"},
+    "host_us_per_layer_exchange_only_by_difference": {k: round((res[k][1] - res["attention"][1]) * 1e3 / L, 1) for k in res if k != "attention"},
+    "native_exchange_host_us_per_layer_measured_directly": direct,
     "note": "exposed = wall(leg) - wall(attention); the collective is a loop-back device copy (no xGMI wire time); the torchdist "
             "leg excludes torch.distributed's own ~50 us/call host cost (its collective is a plain tensor copy here)",
 }
