@@ -62,9 +62,12 @@ def parse():
     ap.add_argument("--replay", choices=["inorder", "pipelined"], default="inorder",
                     help="inorder (default, the deployable schedule): cfx_plan_run, two launches per layer one after the other; "
                          "pipelined: cfx_plan_run_pipelined, reorders work ACROSS layers (resident synthetic inputs only)")
-    ap.add_argument("--own-ef", choices=["ride", "inline"], default="ride",
-                    help="inorder replay: the rank's own error-feedback update rides in the NEXT layer's compress launch (ride) or "
-                         "sits in the same layer's reconstruction launch (inline: 16 tensors per launch)")
+    ap.add_argument("--own-ef", choices=["gated", "ride", "inline"], default="gated",
+                    help="inorder replay. gated (1-bit, no collective between compress and reconstruction, i.e. N = 1): ONE launch per layer - "
+                         "the reconstruction of everything whose packet the layer's compress produces (own error feedback + looped-back peers) "
+                         "runs in the compress launch behind an arrival gate (cfx_compress_batch_gated); with a collective in between it "
+                         "behaves as ride.  ride: the own error-feedback update rides in the NEXT layer's compress launch, two launches "
+                         "per layer.  inline: it sits in the same layer's reconstruction launch (16 tensors per launch)")
     ap.add_argument("--exchange-stream", choices=["main", "side", "prio"], default="prio",
                     help="N > 1, pipelined replay only: 'main' issues every all-gather in order on the compute stream; 'side' / 'prio' "
                          "(prioritised stream) issue it on an exchange stream one unit ahead, underneath the next fused launch")
@@ -270,8 +273,16 @@ def main():
         return [_lib.DecompItem(peer_packet_ptr(l, p, kv, gathered), peer_base[l, p, kv].data_ptr(), peer_base[l, p, kv].data_ptr())
                 for p in range(W_LOGICAL - 1) for kv in range(2)]
 
-    def add_layer(plan, s_, l, ride, gathered, comm=None):
-        """Layer l of the in-order schedule: A = compress (+ previous layer's own EF riding along), X = all-gather, B = reconstruct."""
+    def add_layer(plan, s_, l, ride, gathered, comm=None, gated=False):
+        """Layer l of the in-order schedule: A = compress (+ previous layer's own EF riding along), X = all-gather, B = reconstruct;
+        gated (no X): one launch = A + the 16 reconstructions behind the arrival gate."""
+        if gated:
+            assert comm is None and not gathered and not int2
+            items = own_ef_items(l) + peer_items(l, False)
+            rc = lib.cfx_plan_add_compress_gated(plan, CODEC, N, C, 0, 0, 2, comp_items(s_, l), 0, None, len(items),
+                                                 (_lib.DecompItem * len(items))(*items), ws.data_ptr(), ws_bytes)
+            assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
+            return
         if int2:
             # 2-bit: the codes depend on the scales, so compress = statistics + in-launch finalize, then quantise + error feedback
             # (in place on the rank's own state); the reconstruction launch carries the 7 peers' K,V
@@ -311,22 +322,25 @@ def main():
         rc = lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, len(items), darr)
         assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
 
-    ride = args.own_ef == "ride"
+    ride = args.own_ef in ("ride", "gated")
+    gated = args.own_ef == "gated" and not int2 and not pipelined and not (live > 1 or args.dist_path)
     # ---- native plans without collectives (one per input set) -----------------------------------------------------------------
     #   inorder:   per layer  A(l) [+ EF(l-1)] ; B(l)                        (ops 2l, 2l+1)
     #   pipelined: per layer  compress(l) ; reconstruct own + peers (16)     (the op pattern cfx_plan_run_pipelined recognises)
+    #   gated:     per layer  ONE launch: A(l) + own EF(l) + B(l) behind the gate (op l)
     def build_plans(kind):
         built = []
         for s_ in range(2):
             plan = lib.cfx_plan_create(ctx)
             for l in range(L):
-                add_layer(plan, s_, l, ride if kind == "inorder" else False, False)
+                add_layer(plan, s_, l, ride if kind == "inorder" else False, False, gated=(kind == "gated"))
             assert lib.cfx_plan_finalize(plan) == 0
             built.append(plan)
         return built
     plans_inorder = build_plans("inorder")
     plans_pipe = None if int2 else build_plans("pipelined")
-    plans = plans_pipe if pipelined else plans_inorder
+    plans_gated = build_plans("gated") if gated else None
+    plans = plans_pipe if pipelined else (plans_gated if gated else plans_inorder)
 
     compute = torch.cuda.current_stream(dev)
     sh = compute.cuda_stream
@@ -469,7 +483,7 @@ def main():
     # ---- timed region -------------------------------------------------------------------------------------------
     # profiled kernels: in-order replay: k_binary_dequant (4, launch B, dominant) and k_absmean_compress<bits> (27, launch A);
     # pipelined replay: the fused k_binary_pipe (23: full three-group launches; 24: prologue / epilogue / ragged launches)
-    KIDS = (23, 24) if pipelined else ((6, 28, 5) if int2 else (4, 27))
+    KIDS = (23, 24) if pipelined else ((6, 28, 5) if int2 else ((31,) if gated else (4, 27)))
     prof_cap = (args.steps * 2 * L) // max(1, args.event_stride) + 64
     if not args.no_kernel_events:
         mask = 0
@@ -514,7 +528,7 @@ def main():
         return dt * 1e3 / n_steps
 
     # ---- secondary legs (no events): a long run of the same replay, the other replay ------------------------------------------
-    long_ms, other_ms = None, None
+    long_ms, other_ms, two_ms = None, None, None
     if not args.no_secondary:
         base_step = steps_run
         long_ms = timed_leg(args.long_steps, lambda i: one_step(base_step + i))
@@ -528,6 +542,19 @@ def main():
             base_step += 2
             other_ms = timed_leg(args.steps, lambda i: check(other_run(other[(base_step + i) & 1], 0, lib.cfx_plan_size(other[0]), sh), "plan_run(other)"))
             steps_run += 2 + args.steps
+        if gated:
+            base_step = steps_run
+            fn2 = lambda i: check(lib.cfx_plan_run(plans_inorder[(base_step + i) & 1], 0, lib.cfx_plan_size(plans_inorder[0]), sh), "plan_run(two launches)")
+            for i in range(2):
+                fn2(i)
+            base_step += 2
+            two_ms = timed_leg(args.steps, fn2)
+            steps_run += 2 + args.steps
+    if gated:
+        torch.cuda.synchronize(dev)
+        ge = lib.cfx_gate_errors(ctx)
+        if ge != 0:
+            raise SystemExit(f"[bench] cfx_gate_errors = {ge}: a gated launch gave up waiting for its packets")
 
     # ---- state sanity (bit-exact error-feedback consistency) ---------------------------------------------------------
     ok, why = states_consistent()
@@ -590,10 +617,17 @@ def main():
         "schedule": ("cross-layer software pipeline (NOT deployable: needs every layer's K,V resident)" if pipelined else
                      ("layer by layer in order (deployable): per layer A1 = statistics + in-launch finalize of own K,V, A2 = quantise + error "
                       "feedback, X = exchange, B = reconstruct 7 peers' K,V") if int2 else
+                     ("layer by layer in order (deployable): ONE launch per layer = compress K,V [statistics + sign bits + in-launch "
+                      "finalize] + the 16 reconstructions its packets feed (own error feedback, 7 looped-back peers' K,V): their workgroups "
+                      "pull the state tiles into registers while the scale reduction completes, wait on an arrival gate, finish from registers") if gated else
                      "layer by layer in order (deployable): per layer A = compress K,V [statistics + sign bits + in-launch finalize"
                      + (" + previous layer's own error-feedback update riding along" if ride else "") + "], X = exchange, B = reconstruct "
                      + ("7 peers' K,V" if ride else "own + 7 peers' K,V")),
-        "launches_per_layer": None if pipelined else (3 if int2 else 2),
+        "launches_per_layer": None if pipelined else (3 if int2 else (1 if gated else 2)),
+        "two_launches_per_layer": None if two_ms is None else {
+            "ms_per_step": round(two_ms, 4),
+            "what": "the same layer-ordered step as A = compress (+ previous layer's own error feedback riding along) ; B = reconstruct 7 peers - "
+                    "the schedule a collective between A and B forces (N > 1)"},
         "inorder_ms_per_step": None if inorder_ms is None else round(inorder_ms, 4),
         "pure_exchange_upper_bound": None if pipe_ms is None else {
             "ms_per_step": round(pipe_ms, 4),
@@ -623,7 +657,7 @@ def main():
     step_obj = {"algorithmic_bytes": int(step_alg), "achieved": round(step_alg / (ms_per_step * 1e-3) / 1e9, 1), "unit": "GB/s",
                 "frac": round(step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "floor_ms_at_peak": round(step_alg / (HBM_PEAK_GBS * 1e9) * 1e3, 4)}
-    dom = 23 if pipelined else (6 if int2 else 4)
+    dom = 23 if pipelined else (6 if int2 else (31 if gated else 4))
     if dom in kern_us:
         us, n_samples = kern_us[dom]
         if pipelined:
@@ -637,6 +671,11 @@ def main():
             alg = (ALG_BYTES_PER_EL["decompress"] * 14 + ALG_BYTES_PER_EL["compress"] * 2) * ul * EL
             kname = (f"k_binary_pipe (one launch = {ul} layers: dequant+add of {16 * ul} tensors x (544,3072) + finalize of the next {ul} "
                      f"layers' K,V scales + stats/sign bits of the {ul} layers after those)")
+        elif gated:
+            alg = (ALG_BYTES_PER_EL["compress"] * 2 + ALG_BYTES_PER_EL["decompress"] * 14) * EL
+            kname = ("k_absmean_compress<bits,gated> (the layer's only launch: compress + error feedback of own K,V at 6.125 B/el, "
+                     "7 looped-back peers' K,V at 4.125 B/el; a global reduction - the scales - sits between reading K,V and the first "
+                     "reconstructed byte)")
         elif int2:
             alg = ALG_BYTES_PER_EL["decompress"] * 14 * EL
             kname = "k_int2_dequant (launch B: 7 peers K,V = 14 tensors x (544,3072) per launch)"
@@ -672,8 +711,8 @@ def main():
             try:
                 pj = json.load(open(prof))
                 if pj.get("config") == cfg_key:
-                    pk_ = "k_binary_pipe<true>" if pipelined else "k_binary_dequant"
-                    out["roofline"]["traffic"] = pj["bytes_per_launch"].get(pk_)
+                    pk_ = "k_binary_pipe<true>" if pipelined else ("k_absmean_compress<true, 4, true" if gated else "k_binary_dequant")
+                    out["roofline"]["traffic"] = next((v for k_, v in pj["bytes_per_launch"].items() if k_.startswith(pk_)), None)
                     out["roofline"]["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
                     out["roofline"]["step"]["traffic"] = pj.get("bytes_per_step")
             except Exception:
@@ -683,7 +722,8 @@ def main():
             try:
                 tj = json.load(open(trace_json))
                 if tj.get("config") == cfg_key:
-                    ent = tj["kernels"].get("k_binary_pipe<true>" if pipelined else "k_binary_dequant")
+                    pk_ = "k_binary_pipe<true>" if pipelined else ("k_absmean_compress<true, 4, true" if gated else "k_binary_dequant")
+                    ent = next((v for k_, v in tj["kernels"].items() if k_.startswith(pk_)), None)
                     if ent:
                         out["roofline"]["avg_launch_us_rocprof"] = ent["avg_us"]
                         out["roofline"]["rocprof_source"] = "profiles/r02_bench_kernel_durations.json (rocprofv3 --kernel-trace of this command)"

@@ -43,6 +43,10 @@ SYMBOLS = [
     ("cfx_compress_batch_ex", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_int, ctypes.POINTER(DecompItem),
                                              ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    ("cfx_compress_batch_gated", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_int, ctypes.POINTER(DecompItem),
+                                                ctypes.c_int, ctypes.POINTER(DecompItem), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    ("cfx_gate_errors", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_prepare", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_set_fused_finalize", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_debug_stamps", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -67,6 +71,9 @@ SYMBOLS = [
     ("cfx_plan_add_compress_ex", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_int, ctypes.POINTER(DecompItem),
                                                 ctypes.c_void_p, ctypes.c_size_t]),
+    ("cfx_plan_add_compress_gated", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_int, ctypes.POINTER(DecompItem),
+                                                   ctypes.c_int, ctypes.POINTER(DecompItem), ctypes.c_void_p, ctypes.c_size_t]),
     ("cfx_plan_add_decompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.POINTER(DecompItem)]),
     ("cfx_plan_set_exchange_stream", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),

@@ -14,7 +14,8 @@ enum {
     KID_TOPK_COMPRESS = 13, KID_TOPK_DECOMPRESS = 14, KID_COPY_PROBE = 15, KID_BINARY_EF = 16,
     KID_LR_PREP = 17, KID_LR_AQ = 18, KID_LR_ATY = 19, KID_LR_CHOL = 20, KID_LR_APPLY = 21, KID_LR_DECODE = 22,
     KID_BINARY_PIPE = 23, KID_BINARY_PIPE_EDGE = 24, KID_RES2_DELTA = 25, KID_RES2_UPDATE = 26,
-    KID_ABSMEAN_COMPRESS_BITS = 27, KID_ABSMEAN_COMPRESS = 28, KID_MINMAX_COMPRESS = 29, KID_ATTN_MERGE = 30, KID_MAX = 31
+    KID_ABSMEAN_COMPRESS_BITS = 27, KID_ABSMEAN_COMPRESS = 28, KID_MINMAX_COMPRESS = 29, KID_ATTN_MERGE = 30,
+    KID_ABSMEAN_COMPRESS_GATED = 31, KID_MAX = 32
 };
 static const char* const kid_names[KID_MAX] = {
     "", "k_absmean_stats<bits>", "k_absmean_stats", "k_absmean_finalize", "k_binary_dequant", "k_int2_quant", "k_int2_dequant",
@@ -22,7 +23,7 @@ static const char* const kid_names[KID_MAX] = {
     "k_topk_compress", "k_topk_decompress", "k_copy_probe", "k_binary_dequant(ef)",
     "k_lr_prep", "k_lr_aq", "k_lr_aty", "k_lr_chol", "k_lr_apply", "k_lr_decode",
     "k_binary_pipe", "k_binary_pipe(prologue/epilogue)", "k_residual2_delta", "k_residual2_update",
-    "k_absmean_compress<bits>", "k_absmean_compress", "k_minmax_compress", "k_attn_merge"};
+    "k_absmean_compress<bits>", "k_absmean_compress", "k_minmax_compress", "k_attn_merge", "k_absmean_compress<bits,gated>"};
 
 struct ProfRec { int kid; hipEvent_t a, b; };
 
@@ -38,6 +39,11 @@ struct cfx_ctx {
     // in-launch finalize: ticket blocks (device memory, zeroed once, self-resetting) handed out round-robin, one per launch
     unsigned* tick;
     unsigned tick_next;
+    // gated reconstruction: one monotonic arrival counter per ticket-ring slot (64 B apart, after the ticket blocks), the value
+    // at which the slot's next launch opens, and one error word (a gate that never opened)
+    unsigned* gate;
+    unsigned gate_expect[256];
+    unsigned* gate_err;
     int fused;                      // 1 (default): compress = statistics + in-launch finalize; 0: separate finalize kernel
     void* dbg_stamps;               // developer hook (cfx_debug_stamps)
     int stats_rows;                 // CFX_STATS_ROWS override of the statistics tile height (experiments), 0 = automatic

@@ -112,6 +112,16 @@ __device__ __forceinline__ void st_wt(u64* p, u64 v) { __hip_atomic_store(p, v, 
 __device__ __forceinline__ u64 ld_wt(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_wt(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned ld_wt(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_wt(u16* p, u16 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u16 ld_wt(const u16* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned char ld_wt(const unsigned char* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16-byte write-through store (an agent-scope atomic store lowers to `sc1` only up to 8 bytes).  hipcc does not count an asm
+// store: the publishing wave drains it with its own `s_waitcnt vmcnt(0)`; the trailing s_nop keeps the data registers alive
+// until the store has read them (cdna_hip_programming.md 5.7).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16_wt(void* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
 
 // Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its outstanding global stores
 // (__syncthreads() also drains vmcnt: behind write-through stores that is a fabric round trip, ~1 us, per barrier).
@@ -168,7 +178,10 @@ __device__ __forceinline__ u64 wave_sum4_u64(const u64 (&v)[4], int lane) {
 // kernel (k_binary_pipe): (bx, by) = tile index, rowpart = this tensor's workspace, NW = waves per workgroup, sm = NW x TILE_C
 // words of LDS.  Workspace: rowpart[cb][n] (a row's partials are CB strided words: the finalize reads them coalesced over n),
 // then colpart[p][c].
-template <bool EMIT_BITS, int US, bool WT = false, int NW = WAVES>
+// PUB (needs C % 128 == 0): the sign bits are consumed by other workgroups of the SAME launch (gated reconstruction), so they are
+// published write-through; a lane's byte per row would be one fabric write each, so a wave transposes its US rows through LDS
+// and 4 lanes per row store 16 bytes.
+template <bool EMIT_BITS, int US, bool WT = false, int NW = WAVES, bool PUB = false>
 __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int N, int C, int R, int CB, int bx, int by,
                                                    u64* rowpart, u64 (*sm)[TILE_C], u64* stamps = nullptr) {
 #define SSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
@@ -218,7 +231,17 @@ __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int 
                     rsum += v;
                 }
                 rs[j] = (u64)(rsum * 16777216.0);
-                if (EMIT_BITS) bitsout[(size_t)rr * C8 + (t.c >> 3)] = (unsigned char)byte;
+                if (EMIT_BITS && !PUB) bitsout[(size_t)rr * C8 + (t.c >> 3)] = (unsigned char)byte;
+                if (EMIT_BITS && PUB) ((unsigned char*)&sm[t.w][0])[j * 64 + t.lane] = (unsigned char)byte;
+            }
+        }
+        if (EMIT_BITS && PUB) {
+            // same wave wrote the bytes: LDS operations of a wave execute in order, no barrier
+            const int j = t.lane >> 2, seg = t.lane & 3;
+            const int rr = r + NW * j;
+            if (t.lane < 4 * US && rr < t.r1 && bx * TILE_C + seg * 128 < C) {
+                const u32x4 v = *(const u32x4*)((const unsigned char*)&sm[t.w][0] + j * 64 + seg * 16);
+                st16_wt(bitsout + (size_t)rr * C8 + (bx * (TILE_C >> 3)) + seg * 16, v);
             }
         }
         SSTAMP(9);
@@ -385,6 +408,94 @@ __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, in
     binary_dequant_body<WAVES>(batch.it[blockIdx.z], N, C, R, blockIdx.x, blockIdx.y);
 }
 
+// Gated reconstruction: the same arithmetic for a packet that workgroups of THIS launch are still producing (the compress group
+// of k_absmean_compress).  A workgroup first pulls its whole tile of the state into registers - K rows per wave, bandwidth work
+// that does not depend on the packet and overlaps the compress group's reduction tail, which is pure latency - then one lane
+// polls the gate (relaxed, s_sleep), and the tile is finished from registers: sign bits and scales are read with agent-scope
+// loads (the producers stored them write-through), so no acquire fence.  The compress workgroups precede the gated ones in
+// dispatch order and never wait on anything, so the wait always ends; a bounded spin turns a lost arrival into an error word
+// (cfx_gate_errors) instead of a hung GPU.
+#define GATE_K 17              // rows a wave holds: tiles of up to NW * 17 rows (544 = 4 x 136)
+#define GATE_SPIN_LIMIT (1u << 21)
+#define GATE_LINE 16           // u32 words per 64-byte line
+#define GATE_STRIDE (9 * GATE_LINE)   // a slot's gate block: the arrival counter's line, then one "open" word per XCD, a line each.
+                               // Pollers never touch the counter's line: one line serves ~90 accesses per us, and a few hundred
+                               // pollers on it queue every arrival behind them (measured: the compress tail went from 12 to 24 us)
+// arrival of `inc` units; whoever completes the count opens the gate for every XCD's pollers
+__device__ __forceinline__ void gate_arrive(unsigned* gate, unsigned inc, unsigned expect) {
+    const unsigned old = __hip_atomic_fetch_add(gate, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + inc == expect) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) st_wt(gate + (1 + x) * GATE_LINE, expect);
+    }
+}
+template <int NW, int K, bool ST>
+__device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item& it, int N, int C, int R, int tile_x, int tile_y,
+                                                         const unsigned* gate, unsigned expect, unsigned* err, u64* stamps = nullptr) {
+#define GSTAMP(k) do { if (ST && stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 0) stamps[k] = wall_clock64(); } } while (0)
+    const TileCoord t = tile_coord_at(tile_x, tile_y, N, C, R);
+    if (ST && stamps && threadIdx.x == 0) { stamps[0] = wall_clock64(); stamps[7] = 4; }
+    const unsigned char* pk = (const unsigned char*)it.packet;
+    const int C8 = C >> 3;
+    const u16* U = (const u16*)(pk + (size_t)N * C8);
+    const u16* V = U + N;
+    const h16* base = (const h16*)it.base;
+    h16* out = (h16*)it.recon;
+    const int cc = min(t.c, C - 8);                       // clamped: every load unconditional
+    h16x8 bv[K];
+    if (base) {
+        // all K rows at once: holding the burst back, or thinning it to a few rows in flight, only moves the contention from the
+        // compress group's tile loads to its reduction tail (measured: no gain)
+#pragma unroll
+        for (int j = 0; j < K; ++j) bv[j] = ld8nt(base + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C + cc);
+    } else {
+#pragma unroll
+        for (int j = 0; j < K; ++j) bv[j] = (h16x8)(h16)0;
+    }
+    GSTAMP(1);
+    if (threadIdx.x == 0) {
+        unsigned n = 0;
+        const unsigned* open = gate + (1 + (blockIdx.x & 7)) * GATE_LINE;      // block b runs on XCD b % 8 (speed only)
+        while (ld_wt(open) != expect) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++n > GATE_SPIN_LIMIT) { st_wt(err, 1u); break; }
+        }
+    }
+    if (ST && stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
+    __syncthreads();
+    h16x8 v8;
+    if ((((uintptr_t)(V + cc)) & 7) == 0) {                 // uniform
+        struct { u64 a, b; } q = {ld_wt((const u64*)(V + cc)), ld_wt((const u64*)(V + cc) + 1)};
+        v8 = __builtin_bit_cast(h16x8, q);
+    } else {
+        u16x8 vb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vb[i] = ld_wt(V + cc + i);
+        v8 = __builtin_bit_cast(h16x8, vb);
+    }
+    // a row's token scale is wave-uniform: lane j fetches row j's, broadcast by readlane below
+    const u16 ul = ld_wt(U + min(t.r0 + t.w + NW * min(t.lane, K - 1), t.r1 - 1));
+    unsigned by[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) by[j] = ld_wt(pk + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C8 + (cc >> 3));
+    GSTAMP(3);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int rr = t.r0 + t.w + NW * j;
+        const h16 uj = hfrom((u16)__builtin_amdgcn_readlane((int)ul, j));
+        if (rr < t.r1 && t.act) {
+            const h16x8 s = v8 * uj;                         // fp16(u*v), one rounding (fastpath.py:109,328)
+            u16x8 sb = __builtin_bit_cast(u16x8, s);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sb[i] ^= ((by[j] >> i) & 1u) ? (u16)0 : (u16)0x8000;   // (2b-1)*s
+            const h16x8 recv = __builtin_bit_cast(h16x8, sb);
+            st8nt(out + (size_t)rr * C + t.c, base ? (bv[j] + recv) : recv);
+        }
+    }
+    GSTAMP(4);
+#undef GSTAMP
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Compress in ONE launch: statistics pass + in-launch finalize by the last-arriving workgroups (no finalize kernel, no
 // grid barrier).  Every tile workgroup publishes its partial sums write-through, drains them, and draws two tickets:
@@ -431,10 +542,14 @@ __device__ __forceinline__ void row_sums2_wt(const u64* rowpart, int N, int CB, 
     }
 }
 
-template <bool EMIT_BITS, int US>
+// GATED: workgroups of the SAME launch reconstruct from this packet (binary_dequant_gated_body), so everything that goes into
+// it is published write-through and counted on `gate`: one arrival per tile once its sign bits have drained (together with the
+// tickets: no extra round trip), one per last-arriver job once its U / V stores have drained.  The gate opens at
+// batch * (CB * P + CB + 1) arrivals.
+template <bool EMIT_BITS, int US, bool GATED = false>
 __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int N, int C, int R, int CB, int P, int bx, int by,
                                                    u64* rowpart, unsigned* tick, int per_byte, int eps_mode, u64 (*sm)[TILE_C], int dbg,
-                                                   u64* stamps) {
+                                                   u64* stamps, unsigned* gate = nullptr, unsigned gate_expect = 0) {
     constexpr int NT = FUSED_NT;
     // developer hook (cfx_debug_stamps): per-workgroup phase times, 100 MHz wall clock
 #define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
@@ -457,7 +572,7 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
         if (acc[0] == (h16)12345.0f) ((h16*)it.packet)[threadIdx.x] = acc[1];
         return;
     }
-    absmean_stats_body<EMIT_BITS, US, true, FUSED_NW>(it, N, C, R, CB, bx, by, rowpart, sm, stamps);
+    absmean_stats_body<EMIT_BITS, US, true, FUSED_NW, GATED>(it, N, C, R, CB, bx, by, rowpart, sm, stamps);
     STAMP(1);
     // publish: EVERY storing wave drains its write-through stores, then one lane pair draws the two tickets
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -469,6 +584,7 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
         unsigned* t = threadIdx.x ? tick : tick + 1 + bx;
         flag[threadIdx.x] = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (GATED && threadIdx.x == 64) gate_arrive(gate, 1u, gate_expect);   // this tile's bits are out
     lds_barrier();
     const bool last_col = flag[0] == (unsigned)(P - 1);
     const bool last_all = flag[1] == (unsigned)(CB * P - 1);
@@ -552,20 +668,28 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
         for (int w = 0; w < NT / 64; ++w) tot += smem[w];           // every thread: no second barrier
         const h16 mu = mean16(tot, N);
         const float den = eps_mode ? (float)(h16)((float)mu + 1e-6f) : (float)mu;
-        if (tid < N) U[tid] = (h16)(m0 / den);
-        if (tid + NT < N) U[tid + NT] = (h16)(m1 / den);
+#define PUT16(ptr, val) do { const h16 _v = (val); if (GATED) st_wt((u16*)(ptr), hbits(_v)); else *(ptr) = _v; } while (0)
+        if (tid < N) PUT16(&U[tid], (h16)(m0 / den));
+        if (tid + NT < N) PUT16(&U[tid + NT], (h16)(m1 / den));
         for (int n0 = tid + 2 * NT; n0 - tid < N; n0 += 2 * NT) {
             const int n1 = n0 + NT;
             u64 s0, s1;
             row_sums2_wt(rowpart, N, CB, min(n0, N - 1), min(n1, N - 1), (n1 & ~63) < N, s0, s1);
-            if (n0 < N) U[n0] = (h16)((float)mean16(s0, C) / den);
-            if (n1 < N) U[n1] = (h16)((float)mean16(s1, C) / den);
+            if (n0 < N) PUT16(&U[n0], (h16)((float)mean16(s0, C) / den));
+            if (n1 < N) PUT16(&U[n1], (h16)((float)mean16(s1, C) / den));
         }
         if (tid == 0) st_wt(tick, 0u);
     }
     if (last_col) {
-        if (c < C) V[c] = vmean;
+        if (c < C) PUT16(&V[c], vmean);
         if (tid == 0) st_wt(tick + 1 + bx, 0u);
+    }
+#undef PUT16
+    if (GATED) {
+        // the scales are out once every wave's stores have drained: one arrival per finished job
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (tid == 0) gate_arrive(gate, (last_all ? 1u : 0u) + (last_col ? 1u : 0u), gate_expect);
     }
     STAMP(6);
 #undef STAMP
@@ -581,22 +705,38 @@ struct FusedArgs {
     size_t ws_stride;
     unsigned* tick;
     u64* stamps;             // developer hook: 16 words per statistics workgroup, or NULL
+    // gated reconstruction group (GATED kernels): workgroups [n_st, n_st + n_g), tiles of g_R rows, g_rb per tensor
+    int n_g, g_R, g_rb;
+    unsigned* gate;
+    unsigned gate_expect;
+    unsigned* gate_err;
 };
-template <bool EMIT_BITS, int US>
-__global__ __launch_bounds__(FUSED_NT) void k_absmean_compress(BatchC batch, BatchD ride, FusedArgs a) {
+template <bool EMIT_BITS, int US, bool GATED = false, bool ST = false>
+__global__ __launch_bounds__(FUSED_NT, 4) void k_absmean_compress(BatchC batch, BatchD ride, BatchD gated, FusedArgs a) {
     __shared__ u64 sm[FUSED_NW][TILE_C];
     int b = blockIdx.x;
     if (b < a.n_st) {
         const int per = a.CB * a.P;
         const int z = b / per, rem = b - z * per;
         const int by = rem / a.CB;
-        absmean_fused_body<EMIT_BITS, US>(batch.it[z], a.N, a.C, a.R, a.CB, a.P, rem - by * a.CB, by, a.ws + (size_t)z * a.ws_stride,
-                                          a.tick + z * TICK_WORDS, a.per_byte, a.eps_mode, sm, a.dbg,
-                                          a.stamps ? a.stamps + (size_t)b * 16 : nullptr);
+        absmean_fused_body<EMIT_BITS, US, GATED>(batch.it[z], a.N, a.C, a.R, a.CB, a.P, rem - by * a.CB, by, a.ws + (size_t)z * a.ws_stride,
+                                                 a.tick + z * TICK_WORDS, a.per_byte, a.eps_mode, sm, a.dbg,
+                                                 a.stamps ? a.stamps + (size_t)b * 16 : nullptr, a.gate, a.gate_expect);
         return;
     }
     if constexpr (EMIT_BITS) {
         b -= a.n_st;
+        if constexpr (GATED) {
+            if (b < a.n_g) {
+                const int per = a.CB * a.g_rb;
+                const int item = b / per, rem = b - item * per;
+                const int ty = rem / a.CB;
+                binary_dequant_gated_body<FUSED_NW, GATE_K, ST>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.gate, a.gate_expect, a.gate_err,
+                                                            a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr);
+                return;
+            }
+            b -= a.n_g;
+        }
         const int per = a.CB * a.dq_rb;
         const int item = b / per, rem = b - item * per;
         const int ty = rem / a.CB;
@@ -1381,14 +1521,21 @@ int cfx_prepare(cfx_ctx* ctx) {
     int cur = -1;
     (void)hipGetDevice(&cur);
     if (cur != ctx->device && hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CFX_ERR_LAUNCH, "prepare: hipSetDevice failed");
-    const size_t bytes = (size_t)TICK_RING * CFX_MAX_BATCH * TICK_WORDS * sizeof(unsigned);
+    static_assert(TICK_RING == sizeof(((cfx_ctx*)0)->gate_expect) / sizeof(unsigned), "gate_expect has one entry per ring slot");
+    const size_t tick_words = (size_t)TICK_RING * CFX_MAX_BATCH * TICK_WORDS;
+    const size_t bytes = (tick_words + (size_t)(TICK_RING + 1) * GATE_STRIDE) * sizeof(unsigned);
     void* p = nullptr;
     int rc = CFX_OK;
     if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         (void)hipGetLastError();
         if (p) (void)hipFree(p);
         rc = fail(ctx, CFX_ERR_LAUNCH, "prepare: cannot allocate the ticket blocks");
-    } else ctx->tick = (unsigned*)p;
+    } else {
+        ctx->tick = (unsigned*)p;
+        ctx->gate = ctx->tick + tick_words;
+        ctx->gate_err = ctx->gate + (size_t)TICK_RING * GATE_STRIDE;
+        memset(ctx->gate_expect, 0, sizeof(ctx->gate_expect));
+    }
     if (cur >= 0 && cur != ctx->device) (void)hipSetDevice(cur);
     return rc;
 }
@@ -1538,9 +1685,21 @@ static int fused_rows(const cfx_ctx* ctx, int N, int C, int batch) {
     return FUSED_NW * UNROLL_S;
 }
 
-int cfx_compress_batch_ex(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
-                          int n_ride, const cfx_decomp_item* ride, void* workspace, size_t workspace_bytes, void* stream) {
+// The gated form can run as one launch when: 1-bit codec, in-launch finalize on, rows of sign bits 16-byte aligned (C % 128 == 0),
+// tiles of at most FUSED_NW * GATE_K rows cover the tensor with few enough workgroups to matter.  Otherwise the same work runs as
+// compress + one reconstruction launch (identical results).
+static bool gated_one_launch(cfx_ctx* ctx, int codec, int C, int CB) {
+    static const char* dbg_env = getenv("CFX_FUSED_DBG");
+    static const char* off_env = getenv("CFX_GATED_OFF");
+    return codec == CFX_CODEC_BINARY && ctx->fused && CB < TICK_WORDS && C % 128 == 0 && !dbg_env && !off_env;
+}
+
+static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                         int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
+                         void* workspace, size_t workspace_bytes, void* stream) {
     if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "compress: null ctx/items");
+    if (n_gated < 0 || n_gated > CFX_MAX_BATCH || (n_gated && !gated)) return fail(ctx, CFX_ERR_BATCH, "compress: gated batch out of range");
+    if (n_gated && codec != CFX_CODEC_BINARY) return fail(ctx, CFX_ERR_CODEC, "compress: gated reconstruction items need the 1-bit codec");
     if (batch < 1 || batch > CFX_MAX_BATCH) return fail(ctx, CFX_ERR_BATCH, "compress: batch out of range");
     if (!shape_ok(codec, N, C, param)) return fail(ctx, codec >= 1 && codec <= 5 ? CFX_ERR_SHAPE : CFX_ERR_CODEC, "compress: bad codec/shape");
     if (n_ride < 0 || n_ride > CFX_MAX_BATCH || (n_ride && !ride)) return fail(ctx, CFX_ERR_BATCH, "compress: ride-along batch out of range");
@@ -1562,12 +1721,20 @@ int cfx_compress_batch_ex(cfx_ctx* ctx, int codec, int N, int C, int param, int 
         if (!AL16(ride[i].packet) || !AL16(ride[i].recon) || !AL16(ride[i].base)) return fail(ctx, CFX_ERR_ALIGN, "compress: pointers must be 16-byte aligned");
         rd.it[i] = ride[i];
     }
+    BatchD gd;
+    memset(&gd, 0, sizeof(gd));
+    for (int i = 0; i < n_gated; ++i) {
+        if (!gated[i].packet || !gated[i].recon) return fail(ctx, CFX_ERR_NULL, "compress: null gated packet/recon");
+        if (!AL16(gated[i].packet) || !AL16(gated[i].recon) || !AL16(gated[i].base)) return fail(ctx, CFX_ERR_ALIGN, "compress: pointers must be 16-byte aligned");
+        gd.it[i] = gated[i];
+    }
     const size_t need = cfx_workspace_bytes(codec, N, C, param, batch);
     if (need && (!workspace || workspace_bytes < need)) return fail(ctx, CFX_ERR_WORKSPACE, "compress: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     const size_t wstride = ws_words(codec, N, C);
     u64* ws = (u64*)workspace;
     const int CB = (C + TILE_C - 1) / TILE_C;
+    const bool one_launch = n_gated && gated_one_launch(ctx, codec, C, CB);
 
     if (codec == CFX_CODEC_TOPK) {
         const size_t E = (size_t)N * C;
@@ -1607,13 +1774,29 @@ int cfx_compress_batch_ex(cfx_ctx* ctx, int codec, int N, int C, int param, int 
             a.ws = ws; a.ws_stride = wstride; a.tick = tick;
             { static const char* dbg_env = getenv("CFX_FUSED_DBG"); a.dbg = dbg_env ? atoi(dbg_env) : 0; }
             a.stamps = (u64*)ctx->dbg_stamps;
-            const dim3 g(a.n_st + CB * a.dq_rb * n_ride);
-            if (codec == CFX_CODEC_BINARY) {
-                if (R % 32 == 0) LAUNCH(ctx, KID_ABSMEAN_COMPRESS_BITS, s, (k_absmean_compress<true, 4>), g, dim3(FUSED_NT), 0, s, b, rd, a);
-                else LAUNCH(ctx, KID_ABSMEAN_COMPRESS_BITS, s, (k_absmean_compress<true, 2>), g, dim3(FUSED_NT), 0, s, b, rd, a);
+            if (one_launch) {
+                // tiles of the gated group: as few row blocks as GATE_K rows per wave allow, heights a multiple of FUSED_NW
+                a.g_rb = (N + FUSED_NW * GATE_K - 1) / (FUSED_NW * GATE_K);
+                a.g_R = ((N + a.g_rb - 1) / a.g_rb + FUSED_NW - 1) / FUSED_NW * FUSED_NW;
+                a.n_g = CB * a.g_rb * n_gated;
+                const unsigned slot = (ctx->tick_next - 1) % TICK_RING;
+                a.gate = ctx->gate + (size_t)slot * GATE_STRIDE;
+                ctx->gate_expect[slot] += (unsigned)batch * (unsigned)(CB * P + CB + 1);
+                a.gate_expect = ctx->gate_expect[slot];
+                a.gate_err = ctx->gate_err;
+            }
+            const dim3 g(a.n_st + a.n_g + CB * a.dq_rb * n_ride);
+            if (one_launch && a.stamps && R % 32 == 0) {
+                LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_absmean_compress<true, 4, true, true>), g, dim3(FUSED_NT), 0, s, b, rd, gd, a);
+            } else if (one_launch) {
+                if (R % 32 == 0) LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_absmean_compress<true, 4, true>), g, dim3(FUSED_NT), 0, s, b, rd, gd, a);
+                else LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_absmean_compress<true, 2, true>), g, dim3(FUSED_NT), 0, s, b, rd, gd, a);
+            } else if (codec == CFX_CODEC_BINARY) {
+                if (R % 32 == 0) LAUNCH(ctx, KID_ABSMEAN_COMPRESS_BITS, s, (k_absmean_compress<true, 4>), g, dim3(FUSED_NT), 0, s, b, rd, gd, a);
+                else LAUNCH(ctx, KID_ABSMEAN_COMPRESS_BITS, s, (k_absmean_compress<true, 2>), g, dim3(FUSED_NT), 0, s, b, rd, gd, a);
             } else {
-                if (R % 32 == 0) LAUNCH(ctx, KID_ABSMEAN_COMPRESS, s, (k_absmean_compress<false, 4>), g, dim3(FUSED_NT), 0, s, b, rd, a);
-                else LAUNCH(ctx, KID_ABSMEAN_COMPRESS, s, (k_absmean_compress<false, 2>), g, dim3(FUSED_NT), 0, s, b, rd, a);
+                if (R % 32 == 0) LAUNCH(ctx, KID_ABSMEAN_COMPRESS, s, (k_absmean_compress<false, 4>), g, dim3(FUSED_NT), 0, s, b, rd, gd, a);
+                else LAUNCH(ctx, KID_ABSMEAN_COMPRESS, s, (k_absmean_compress<false, 2>), g, dim3(FUSED_NT), 0, s, b, rd, gd, a);
             }
         } else {
             if (codec == CFX_CODEC_BINARY) LAUNCH(ctx, KID_ABSMEAN_STATS_BITS, s, k_absmean_stats<true>, grid, dim3(NTHR), 0, s, b, N, C, R, ws, wstride);
@@ -1640,6 +1823,10 @@ int cfx_compress_batch_ex(cfx_ctx* ctx, int codec, int N, int C, int param, int 
                 LAUNCH(ctx, KID_BINARY_EF, s, k_binary_dequant, gridq, dim3(NTHR), 0, s, d, N, C, Rq);
             }
         }
+        if (n_gated && !one_launch) {
+            const int Rg = auto_rows(ctx, N, C, n_gated, false);
+            LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant, dim3(CB, (N + Rg - 1) / Rg, n_gated), dim3(NTHR), 0, s, gd, N, C, Rg);
+        }
     } else {
         if (fused) {
             LAUNCH(ctx, KID_MINMAX_COMPRESS, s, k_minmax_compress, dim3(CB * P * batch), dim3(NTHR), 0, s, b, N, C, R, CB, P, codec, ws, wstride, tick);
@@ -1651,6 +1838,26 @@ int cfx_compress_batch_ex(cfx_ctx* ctx, int codec, int N, int C, int param, int 
         else LAUNCH(ctx, KID_INT8_QUANT, s, k_int8_quant, gridq, dim3(NTHR), 0, s, b, N, C, Rq, flags);
     }
     return check_launch(ctx, "compress launch");
+}
+
+int cfx_compress_batch_ex(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                          int n_ride, const cfx_decomp_item* ride, void* workspace, size_t workspace_bytes, void* stream) {
+    return compress_impl(ctx, codec, N, C, param, flags, batch, items, n_ride, ride, 0, nullptr, workspace, workspace_bytes, stream);
+}
+
+int cfx_compress_batch_gated(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                             int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    return compress_impl(ctx, codec, N, C, param, flags, batch, items, n_ride, ride, n_gated, gated, workspace, workspace_bytes, stream);
+}
+
+int cfx_gate_errors(cfx_ctx* ctx) {
+    if (!ctx) return CFX_ERR_NULL;
+    if (!ctx->gate_err) return 0;
+    unsigned v = 0;
+    if (hipMemcpy(&v, ctx->gate_err, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, CFX_ERR_LAUNCH, "gate errors: copy failed"); }
+    if (v) { const unsigned z = 0; (void)hipMemcpy(ctx->gate_err, &z, sizeof(z), hipMemcpyHostToDevice); }
+    return (int)v;
 }
 
 int cfx_compress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
@@ -1703,6 +1910,8 @@ struct PlanOp {
     cfx_comp_item c[CFX_MAX_BATCH];
     cfx_decomp_item d[CFX_MAX_BATCH];     // kind 1: the items; kind 0: ride-along reconstruction items (n_ride of them)
     int n_ride;
+    cfx_decomp_item g[CFX_MAX_BATCH];     // kind 0: gated reconstruction items (n_gated of them)
+    int n_gated;
     void* ws;
     size_t ws_bytes;
     // kind 2 / 3
@@ -1790,6 +1999,19 @@ static PlanOp* plan_push(cfx_plan* p) {
         p->cap = ncap;
     }
     return &p->ops[p->n++];
+}
+
+int cfx_plan_add_compress_gated(cfx_plan* p, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                                int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
+                                void* workspace, size_t workspace_bytes) {
+    if (!p) return CFX_ERR_NULL;
+    if (n_gated < 0 || n_gated > CFX_MAX_BATCH || (n_gated && !gated)) return fail(p->ctx, CFX_ERR_BATCH, "plan: gated batch out of range");
+    if (n_gated && codec != CFX_CODEC_BINARY) return fail(p->ctx, CFX_ERR_CODEC, "plan: gated reconstruction items need the 1-bit codec");
+    const int op = cfx_plan_add_compress_ex(p, codec, N, C, param, flags, batch, items, n_ride, ride, workspace, workspace_bytes);
+    if (op < 0) return op;
+    p->ops[op].n_gated = n_gated;
+    if (n_gated) memcpy(p->ops[op].g, gated, sizeof(cfx_decomp_item) * n_gated);
+    return op;
 }
 
 int cfx_plan_add_compress_ex(cfx_plan* p, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
@@ -1940,7 +2162,7 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
         PlanOp* o = &p->ops[i];
         int rc = CFX_OK;
         switch (o->kind) {
-            case 0: rc = cfx_compress_batch_ex(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, o->n_ride, o->d, o->ws, o->ws_bytes, stream); break;
+            case 0: rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, o->n_ride, o->d, o->n_gated, o->g, o->ws, o->ws_bytes, stream); break;
             case 1: rc = cfx_decompress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->batch, o->d, stream); break;
             case 2:
             case 4: {
@@ -2112,7 +2334,7 @@ static int plan_build_sched(cfx_plan* p, int first_op, int n_ops) {
         const int ag0 = n_ag;
         while (i < end && p->ops[i].kind == 0) {
             const PlanOp* c = &p->ops[i];
-            if (c->codec != CFX_CODEC_BINARY || (c->flags & CFX_FLAG_UPDATE_CACHE) || c->n_ride) { ok = false; break; }
+            if (c->codec != CFX_CODEC_BINARY || (c->flags & CFX_FLAG_UPDATE_CACHE) || c->n_ride || c->n_gated) { ok = false; break; }
             if (L + k == 0) { N = c->N; C = c->C; }
             if (c->N != N || c->C != C) { ok = false; break; }
             ncomp += c->batch;

@@ -118,6 +118,23 @@ int cfx_compress_batch_ex(cfx_ctx* ctx, int codec, int N, int C, int param, int 
                           int batch, const cfx_comp_item* items, int n_ride, const cfx_decomp_item* ride,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* cfx_compress_batch_ex plus `n_gated` reconstruction items (1-bit codec, same shape) whose PACKETS ARE PRODUCED BY THIS CALL:
+ * typically the call's own packets applied to the rank's own state (the error-feedback update, fastpath.py:88-120) and -
+ * when logical peers are looped back on one GPU - to the peers' states.  They run in the SAME launch as the compress: their
+ * workgroups first pull the state tiles into registers (bandwidth work that overlaps the scale reduction, which is pure
+ * latency), wait on an arrival counter until the packet is complete, then finish from registers.  One launch per layer instead
+ * of two, 2.125 instead of 4.125 B/el behind the dependency.  Results are identical to compress followed by
+ * cfx_decompress_batch; when the shape does not qualify (C % 128 != 0, in-launch finalize off) exactly that sequence runs.
+ * A gated item's base/recon must not alias this call's x / packet operands; recon may equal base, and a gated item may
+ * update a compress item's `base` in place (the compress group has finished reading it when the gate opens). */
+int cfx_compress_batch_gated(cfx_ctx* ctx, int codec, int N, int C, int param, int flags,
+                             int batch, const cfx_comp_item* items, int n_ride, const cfx_decomp_item* ride,
+                             int n_gated, const cfx_decomp_item* gated,
+                             void* workspace, size_t workspace_bytes, void* stream);
+/* Number of gated launches whose gate never opened since the last call (a bounded spin gives up instead of hanging the GPU;
+ * always 0 unless the library is broken), or < 0 on error.  Synchronises with the device. */
+int cfx_gate_errors(cfx_ctx* ctx);
+
 /* The statistics pass of a compress call reduces its partial sums INSIDE the launch (last-arriving workgroups, ticket
  * counters; replaces the eager scale prologue of fastpath.py:150-166 / compress_quantize.py:452-463 and the separate
  * finalize kernel).  The tickets live in device memory owned by the context: cfx_prepare allocates them (idempotent;
@@ -179,6 +196,10 @@ int       cfx_plan_add_compress(cfx_plan* plan, int codec, int N, int C, int par
 int       cfx_plan_add_compress_ex(cfx_plan* plan, int codec, int N, int C, int param, int flags, int batch,
                                    const cfx_comp_item* items, int n_ride, const cfx_decomp_item* ride,
                                    void* workspace, size_t workspace_bytes);   /* cfx_compress_batch_ex as a plan op */
+int       cfx_plan_add_compress_gated(cfx_plan* plan, int codec, int N, int C, int param, int flags, int batch,
+                                      const cfx_comp_item* items, int n_ride, const cfx_decomp_item* ride,
+                                      int n_gated, const cfx_decomp_item* gated,
+                                      void* workspace, size_t workspace_bytes);   /* cfx_compress_batch_gated as a plan op */
 int       cfx_plan_add_decompress(cfx_plan* plan, int codec, int N, int C, int param, int batch,
                                   const cfx_decomp_item* items);
 /* Exchange ops.  An all-gather op is ordered after everything the plan enqueued on the main stream before it (the

@@ -429,3 +429,87 @@ def test_statistics_exact_sums_on_outliers_subnormals_and_signed_zeros(name, cid
     x[300, :128] = (base[300, :128].astype(np.float32) + 6e-8).astype(F16)
     base[301, :128] = 0; x[301, :128] = np.frombuffer(np.arange(1, 129, dtype=np.uint16).tobytes(), dtype=F16)   # subnormals
     run_case(name, cid, 0, x, base, N, C)
+
+
+@pytest.mark.parametrize("shape,B,NG", [((544, 3072), 2, 16), ((512, 1536), 2, 16), ((256, 1152), 1, 3), ((130, 1024), 2, 5),
+                                       ((64, 256), 1, 2), ((1100, 3072), 1, 4), ((64, 264), 1, 2)])
+def test_gated_reconstruction_in_the_compress_launch(shape, B, NG):
+    """cfx_compress_batch_gated: the reconstruction of tensors whose packets THIS launch produces (own error feedback, looped-back
+    peers) runs inside the compress launch behind an arrival gate.  Packets and states equal the oracle's bit for bit on every
+    launch of a long back-to-back sequence (ticket / gate ring reuse, workgroups of consecutive launches in flight together),
+    with a bandwidth hog on a second stream for uneven load; (64, 264) does not qualify and takes the two-launch sequence."""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    N, C = shape
+    ctx = K.context(0)
+    L = 3                                                    # distinct layers cycled through
+    rng = np.random.default_rng(5)
+    xs, bs = [], []
+    for l in range(L):
+        for i in range(B):
+            x, b = make_inputs(100 + 10 * l + i, N, C)
+            xs.append(x); bs.append(b)
+    xd = [dev(x) for x in xs]
+    own = [dev(b) for b in bs]                               # the rank's own states (updated in place by gated items)
+    # gated items: the B own states (EF) first, then G - B "peers" whose states start as copies of an own state
+    src = [i % B for i in range(NG)]
+    peer = [[dev(bs[l * B + src[g]]) for g in range(B, NG)] for l in range(L)]
+    pk = [torch.zeros(K.packet_halves(1, N, C), dtype=torch.float16, device="cuda") for _ in range(L * B)]
+    ws = K.workspace(1, N, C, 0, B, 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    hog_s = torch.cuda.Stream()
+    hog = torch.empty(64 << 20, dtype=torch.float16, device="cuda")
+    comp, gated = [], []
+    for l in range(L):
+        comp.append((_lib.CompItem * B)(*[_lib.CompItem(xd[l * B + i].data_ptr(), own[l * B + i].data_ptr(), None, pk[l * B + i].data_ptr())
+                                          for i in range(B)]))
+        items = []
+        for g in range(NG):
+            st = own[l * B + g] if g < B else peer[l][g - B]
+            items.append(_lib.DecompItem(pk[l * B + src[g]].data_ptr(), st.data_ptr(), st.data_ptr()))
+        gated.append((_lib.DecompItem * NG)(*items))
+    # oracle: T rounds over the L layers (x fixed, state evolving by error feedback)
+    T = 4
+    ostate = [R.bits(b).copy() for b in bs]
+    opk = [None] * (L * B)
+    reps = 90 if N * C >= 544 * 3072 else 30                 # > 256 launches at the big shapes: the ring wraps
+    for t in range(T):
+        for l in range(L):
+            with torch.cuda.stream(hog_s):
+                hog.add_(1.0)
+            assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, 0, B, comp[l], 0, None, NG, gated[l], ws.data_ptr(), ws.numel(), sh) == 0
+            for i in range(B):
+                k = l * B + i
+                p, nb = R.residual_compress("binary", xs[k], ostate[k].view(F16), 0)
+                opk[k] = p; ostate[k] = R.bits(nb).copy()
+    torch.cuda.synchronize()
+    assert lib.cfx_gate_errors(ctx) == 0
+    for l in range(L):
+        for i in range(B):
+            same_bits(host_bits(pk[l * B + i]), opk[l * B + i], f"packet layer {l} item {i}")
+            same_bits(host_bits(own[l * B + i]), ostate[l * B + i], f"own state layer {l} item {i}")
+        for g in range(B, NG):
+            same_bits(host_bits(peer[l][g - B]), ostate[l * B + src[g]], f"looped-back peer state layer {l} item {g}")
+    # long back-to-back sequence: the states keep evolving, compare the end state with an ungated replay of the same launches
+    ref_own = [o.clone() for o in own]
+    ref_pk = [torch.zeros_like(p) for p in pk]
+    for r in range(reps):
+        l = r % L
+        assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, 0, B, comp[l], 0, None, NG, gated[l], ws.data_ptr(), ws.numel(), sh) == 0
+    torch.cuda.synchronize()
+    assert lib.cfx_gate_errors(ctx) == 0
+    for r in range(reps):
+        l = r % L
+        c = (_lib.CompItem * B)(*[_lib.CompItem(xd[l * B + i].data_ptr(), ref_own[l * B + i].data_ptr(), None, ref_pk[l * B + i].data_ptr())
+                                  for i in range(B)])
+        assert lib.cfx_compress_batch_ex(ctx, 1, N, C, 0, 0, B, c, 0, None, ws.data_ptr(), ws.numel(), sh) == 0
+        d = (_lib.DecompItem * B)(*[_lib.DecompItem(ref_pk[l * B + i].data_ptr(), ref_own[l * B + i].data_ptr(), ref_own[l * B + i].data_ptr())
+                                    for i in range(B)])
+        assert lib.cfx_decompress_batch(ctx, 1, N, C, 0, B, d, sh) == 0
+    torch.cuda.synchronize()
+    for k in range(L * B):
+        assert torch.equal(own[k].view(torch.int16), ref_own[k].view(torch.int16)), f"own state {k} after {reps} gated launches"
+        assert torch.equal(pk[k].view(torch.int16), ref_pk[k].view(torch.int16)), f"packet {k} after {reps} gated launches"
+    for l in range(L):
+        for g in range(B, NG):
+            assert torch.equal(peer[l][g - B].view(torch.int16), own[l * B + src[g]].view(torch.int16)), f"peer {g} of layer {l} diverged from its owner"
