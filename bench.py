@@ -277,9 +277,14 @@ def main():
         """Layer l of the in-order schedule: A = compress (+ previous layer's own EF riding along), X = all-gather, B = reconstruct;
         gated (no X): one launch = A + the 16 reconstructions behind the arrival gate."""
         if gated:
-            assert comm is None and not gathered and not int2
-            items = own_ef_items(l) + peer_items(l, False)
-            rc = lib.cfx_plan_add_compress_gated(plan, CODEC, N, C, 0, 0, 2, comp_items(s_, l), 0, None, len(items),
+            assert comm is None and not gathered
+            # CFX_FLAG_UPDATE_CACHE = the rank's own error feedback in the same launch (1-bit: two more gated reconstructions; 2-bit:
+            # the statistics workgroups quantise their own tiles from registers); the gated items are the 7 looped-back peers' K,V
+            carr = comp_items(s_, l)
+            for kv in range(2):
+                carr[kv].new_base = own_base[l, kv].data_ptr()
+            items = peer_items(l, False)
+            rc = lib.cfx_plan_add_compress_gated(plan, CODEC, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, carr, 0, None, len(items),
                                                  (_lib.DecompItem * len(items))(*items), ws.data_ptr(), ws_bytes)
             assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
             return
@@ -323,7 +328,7 @@ def main():
         assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
 
     ride = args.own_ef in ("ride", "gated")
-    gated = args.own_ef == "gated" and not int2 and not pipelined and not (live > 1 or args.dist_path)
+    gated = args.own_ef == "gated" and not pipelined and not (live > 1 or args.dist_path)
     # ---- native plans without collectives (one per input set) -----------------------------------------------------------------
     #   inorder:   per layer  A(l) [+ EF(l-1)] ; B(l)                        (ops 2l, 2l+1)
     #   pipelined: per layer  compress(l) ; reconstruct own + peers (16)     (the op pattern cfx_plan_run_pipelined recognises)
@@ -483,7 +488,7 @@ def main():
     # ---- timed region -------------------------------------------------------------------------------------------
     # profiled kernels: in-order replay: k_binary_dequant (4, launch B, dominant) and k_absmean_compress<bits> (27, launch A);
     # pipelined replay: the fused k_binary_pipe (23: full three-group launches; 24: prologue / epilogue / ragged launches)
-    KIDS = (23, 24) if pipelined else ((6, 28, 5) if int2 else ((31,) if gated else (4, 27)))
+    KIDS = (23, 24) if pipelined else ((31,) if gated else ((6, 28, 5) if int2 else (4, 27)))
     prof_cap = (args.steps * 2 * L) // max(1, args.event_stride) + 64
     if not args.no_kernel_events:
         mask = 0
@@ -615,6 +620,9 @@ def main():
         "exchange_pattern": (args.exchange_pattern if use_dist else None),
         "replay": args.replay,
         "schedule": ("cross-layer software pipeline (NOT deployable: needs every layer's K,V resident)" if pipelined else
+                     ("layer by layer in order (deployable): ONE launch per layer, two groups of workgroups and two arrival gates: statistics + "
+                      "in-launch finalize of own K,V, then every statistics workgroup quantises its own tile (+ error feedback) from the registers "
+                      "it loaded -> reconstruction of the 7 looped-back peers' K,V (state tiles already in registers)") if (int2 and gated) else
                      ("layer by layer in order (deployable): per layer A1 = statistics + in-launch finalize of own K,V, A2 = quantise + error "
                       "feedback, X = exchange, B = reconstruct 7 peers' K,V") if int2 else
                      ("layer by layer in order (deployable): ONE launch per layer = compress K,V [statistics + sign bits + in-launch "
@@ -623,11 +631,12 @@ def main():
                      "layer by layer in order (deployable): per layer A = compress K,V [statistics + sign bits + in-launch finalize"
                      + (" + previous layer's own error-feedback update riding along" if ride else "") + "], X = exchange, B = reconstruct "
                      + ("7 peers' K,V" if ride else "own + 7 peers' K,V")),
-        "launches_per_layer": None if pipelined else (3 if int2 else (1 if gated else 2)),
+        "launches_per_layer": None if pipelined else (1 if gated else (3 if int2 else 2)),
         "two_launches_per_layer": None if two_ms is None else {
             "ms_per_step": round(two_ms, 4),
-            "what": "the same layer-ordered step as A = compress (+ previous layer's own error feedback riding along) ; B = reconstruct 7 peers - "
-                    "the schedule a collective between A and B forces (N > 1)"},
+            "what": ("the same layer-ordered step as A1 = statistics + finalize ; A2 = quantise + error feedback ; B = reconstruct 7 peers" if int2 else
+                     "the same layer-ordered step as A = compress (+ previous layer's own error feedback riding along) ; B = reconstruct 7 peers")
+                    + " - the schedule a collective between compress and reconstruction forces (N > 1)"},
         "inorder_ms_per_step": None if inorder_ms is None else round(inorder_ms, 4),
         "pure_exchange_upper_bound": None if pipe_ms is None else {
             "ms_per_step": round(pipe_ms, 4),
@@ -657,7 +666,7 @@ def main():
     step_obj = {"algorithmic_bytes": int(step_alg), "achieved": round(step_alg / (ms_per_step * 1e-3) / 1e9, 1), "unit": "GB/s",
                 "frac": round(step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "floor_ms_at_peak": round(step_alg / (HBM_PEAK_GBS * 1e9) * 1e3, 4)}
-    dom = 23 if pipelined else (6 if int2 else (31 if gated else 4))
+    dom = 23 if pipelined else (31 if gated else (6 if int2 else 4))
     if dom in kern_us:
         us, n_samples = kern_us[dom]
         if pipelined:
@@ -673,8 +682,8 @@ def main():
                      f"layers' K,V scales + stats/sign bits of the {ul} layers after those)")
         elif gated:
             alg = (ALG_BYTES_PER_EL["compress"] * 2 + ALG_BYTES_PER_EL["decompress"] * 14) * EL
-            kname = ("k_absmean_compress<bits,gated> (the layer's only launch: compress + error feedback of own K,V at 6.125 B/el, "
-                     "7 looped-back peers' K,V at 4.125 B/el; a global reduction - the scales - sits between reading K,V and the first "
+            kname = (("k_int2_compress_gated" if int2 else "k_absmean_compress<bits,gated>") + " (the layer's only launch: compress + error feedback of own K,V at " + str(ALG_BYTES_PER_EL["compress"]) + " B/el, "
+                     "7 looped-back peers' K,V at " + str(ALG_BYTES_PER_EL["decompress"]) + " B/el; a global reduction - the scales - sits between reading K,V and the first "
                      "reconstructed byte)")
         elif int2:
             alg = ALG_BYTES_PER_EL["decompress"] * 14 * EL
@@ -711,7 +720,7 @@ def main():
             try:
                 pj = json.load(open(prof))
                 if pj.get("config") == cfg_key:
-                    pk_ = "k_binary_pipe<true>" if pipelined else ("k_absmean_compress<true, 4, true" if gated else "k_binary_dequant")
+                    pk_ = "k_binary_pipe<true>" if pipelined else (("k_int2_compress_gated" if int2 else "k_absmean_compress<true, 4, true") if gated else "k_binary_dequant")
                     out["roofline"]["traffic"] = next((v for k_, v in pj["bytes_per_launch"].items() if k_.startswith(pk_)), None)
                     out["roofline"]["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
                     out["roofline"]["step"]["traffic"] = pj.get("bytes_per_step")
@@ -722,7 +731,7 @@ def main():
             try:
                 tj = json.load(open(trace_json))
                 if tj.get("config") == cfg_key:
-                    pk_ = "k_binary_pipe<true>" if pipelined else ("k_absmean_compress<true, 4, true" if gated else "k_binary_dequant")
+                    pk_ = "k_binary_pipe<true>" if pipelined else (("k_int2_compress_gated" if int2 else "k_absmean_compress<true, 4, true") if gated else "k_binary_dequant")
                     ent = next((v for k_, v in tj["kernels"].items() if k_.startswith(pk_)), None)
                     if ent:
                         out["roofline"]["avg_launch_us_rocprof"] = ent["avg_us"]

@@ -118,7 +118,7 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         if not build_if_missing:
             raise CfxError(f"{LIB} is missing: run `python -m compactfusion_amd.build`")
         build_lib()
-    lib = ctypes.CDLL(LIB)
+    lib = ctypes.CDLL(os.environ.get("CFX_LIBCFX_PATH") or LIB)     # (developer override: A/B two builds on one box)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)     # AttributeError if the ABI lost a symbol
         fn.restype = res

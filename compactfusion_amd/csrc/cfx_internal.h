@@ -23,7 +23,8 @@ static const char* const kid_names[KID_MAX] = {
     "k_topk_compress", "k_topk_decompress", "k_copy_probe", "k_binary_dequant(ef)",
     "k_lr_prep", "k_lr_aq", "k_lr_aty", "k_lr_chol", "k_lr_apply", "k_lr_decode",
     "k_binary_pipe", "k_binary_pipe(prologue/epilogue)", "k_residual2_delta", "k_residual2_update",
-    "k_absmean_compress<bits>", "k_absmean_compress", "k_minmax_compress", "k_attn_merge", "k_absmean_compress<bits,gated>"};
+    "k_absmean_compress<bits>", "k_absmean_compress", "k_minmax_compress", "k_attn_merge",
+    "gated layer launch (k_absmean_compress<bits,gated> / k_int2_compress_gated)"};
 
 struct ProfRec { int kid; hipEvent_t a, b; };
 
@@ -42,7 +43,7 @@ struct cfx_ctx {
     // gated reconstruction: one monotonic arrival counter per ticket-ring slot (64 B apart, after the ticket blocks), the value
     // at which the slot's next launch opens, and one error word (a gate that never opened)
     unsigned* gate;
-    unsigned gate_expect[256];
+    unsigned gate_expect[2 * 256];  // two gates per slot (the 2-bit layer launch has two)
     unsigned* gate_err;
     int fused;                      // 1 (default): compress = statistics + in-launch finalize; 0: separate finalize kernel
     void* dbg_stamps;               // developer hook (cfx_debug_stamps)

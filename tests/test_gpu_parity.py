@@ -431,13 +431,16 @@ def test_statistics_exact_sums_on_outliers_subnormals_and_signed_zeros(name, cid
     run_case(name, cid, 0, x, base, N, C)
 
 
+@pytest.mark.parametrize("own_ef", ["items", "flag"])
 @pytest.mark.parametrize("shape,B,NG", [((544, 3072), 2, 16), ((512, 1536), 2, 16), ((256, 1152), 1, 3), ((130, 1024), 2, 5),
                                        ((64, 256), 1, 2), ((1100, 3072), 1, 4), ((64, 264), 1, 2)])
-def test_gated_reconstruction_in_the_compress_launch(shape, B, NG):
+def test_gated_reconstruction_in_the_compress_launch(shape, B, NG, own_ef):
     """cfx_compress_batch_gated: the reconstruction of tensors whose packets THIS launch produces (own error feedback, looped-back
     peers) runs inside the compress launch behind an arrival gate.  Packets and states equal the oracle's bit for bit on every
     launch of a long back-to-back sequence (ticket / gate ring reuse, workgroups of consecutive launches in flight together),
-    with a bandwidth hog on a second stream for uneven load; (64, 264) does not qualify and takes the two-launch sequence."""
+    with a bandwidth hog on a second stream for uneven load; (64, 264) does not qualify and takes the two-launch sequence.
+    own_ef = items: the rank's own error feedback is given as gated items too; flag: CFX_FLAG_UPDATE_CACHE - the compress
+    workgroups do it from the registers they loaded for the statistics."""
     from compactfusion_amd import _lib, codecs as K
     lib = _lib.load()
     N, C = shape
@@ -460,14 +463,18 @@ def test_gated_reconstruction_in_the_compress_launch(shape, B, NG):
     hog_s = torch.cuda.Stream()
     hog = torch.empty(64 << 20, dtype=torch.float16, device="cuda")
     comp, gated = [], []
+    flag = own_ef == "flag"
+    FL = _lib.FLAG_UPDATE_CACHE if flag else 0
+    NGI = NG - B if flag else NG                              # gated items actually passed
     for l in range(L):
-        comp.append((_lib.CompItem * B)(*[_lib.CompItem(xd[l * B + i].data_ptr(), own[l * B + i].data_ptr(), None, pk[l * B + i].data_ptr())
+        comp.append((_lib.CompItem * B)(*[_lib.CompItem(xd[l * B + i].data_ptr(), own[l * B + i].data_ptr(),
+                                                        own[l * B + i].data_ptr() if flag else None, pk[l * B + i].data_ptr())
                                           for i in range(B)]))
         items = []
-        for g in range(NG):
+        for g in range(B if flag else 0, NG):
             st = own[l * B + g] if g < B else peer[l][g - B]
             items.append(_lib.DecompItem(pk[l * B + src[g]].data_ptr(), st.data_ptr(), st.data_ptr()))
-        gated.append((_lib.DecompItem * NG)(*items))
+        gated.append((_lib.DecompItem * NGI)(*items))
     # oracle: T rounds over the L layers (x fixed, state evolving by error feedback)
     T = 4
     ostate = [R.bits(b).copy() for b in bs]
@@ -477,7 +484,7 @@ def test_gated_reconstruction_in_the_compress_launch(shape, B, NG):
         for l in range(L):
             with torch.cuda.stream(hog_s):
                 hog.add_(1.0)
-            assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, 0, B, comp[l], 0, None, NG, gated[l], ws.data_ptr(), ws.numel(), sh) == 0
+            assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, FL, B, comp[l], 0, None, NGI, gated[l], ws.data_ptr(), ws.numel(), sh) == 0
             for i in range(B):
                 k = l * B + i
                 p, nb = R.residual_compress("binary", xs[k], ostate[k].view(F16), 0)
@@ -495,7 +502,7 @@ def test_gated_reconstruction_in_the_compress_launch(shape, B, NG):
     ref_pk = [torch.zeros_like(p) for p in pk]
     for r in range(reps):
         l = r % L
-        assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, 0, B, comp[l], 0, None, NG, gated[l], ws.data_ptr(), ws.numel(), sh) == 0
+        assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, FL, B, comp[l], 0, None, NGI, gated[l], ws.data_ptr(), ws.numel(), sh) == 0
     torch.cuda.synchronize()
     assert lib.cfx_gate_errors(ctx) == 0
     for r in range(reps):
@@ -513,3 +520,77 @@ def test_gated_reconstruction_in_the_compress_launch(shape, B, NG):
     for l in range(L):
         for g in range(B, NG):
             assert torch.equal(peer[l][g - B].view(torch.int16), own[l * B + src[g]].view(torch.int16)), f"peer {g} of layer {l} diverged from its owner"
+
+
+@pytest.mark.parametrize("shape,B,NP", [((544, 3072), 2, 14), ((512, 1536), 2, 14), ((256, 1152), 1, 3), ((130, 1024), 2, 5), ((64, 264), 1, 2)])
+def test_gated_int2_layer_in_one_launch(shape, B, NP):
+    """cfx_compress_batch_gated, 2-bit codec: statistics + finalize, quantise + error feedback of the own tensors and the
+    reconstruction of NP looped-back peers in ONE launch (two arrival gates).  Packets and states equal the oracle's bit for bit
+    over several rounds, then a long back-to-back sequence equals the three-launch sequence; (64, 264) takes the fallback."""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    N, C = shape
+    ctx = K.context(0)
+    L = 3
+    xs, bs = [], []
+    for l in range(L):
+        for i in range(B):
+            x, b = make_inputs(300 + 10 * l + i, N, C)
+            xs.append(x); bs.append(b)
+    xd = [dev(x) for x in xs]
+    own = [dev(b) for b in bs]
+    src = [i % B for i in range(NP)]
+    peer = [[dev(bs[l * B + src[g]]) for g in range(NP)] for l in range(L)]
+    pk = [torch.zeros(K.packet_halves(2, N, C), dtype=torch.float16, device="cuda") for _ in range(L * B)]
+    ws = K.workspace(2, N, C, 0, B, 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    hog_s = torch.cuda.Stream()
+    hog = torch.empty(64 << 20, dtype=torch.float16, device="cuda")
+    comp, gated = [], []
+    for l in range(L):
+        comp.append((_lib.CompItem * B)(*[_lib.CompItem(xd[l * B + i].data_ptr(), own[l * B + i].data_ptr(), own[l * B + i].data_ptr(),
+                                                        pk[l * B + i].data_ptr()) for i in range(B)]))
+        gated.append((_lib.DecompItem * NP)(*[_lib.DecompItem(pk[l * B + src[g]].data_ptr(), peer[l][g].data_ptr(), peer[l][g].data_ptr())
+                                              for g in range(NP)]))
+
+    def go(l):
+        assert lib.cfx_compress_batch_gated(ctx, 2, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, comp[l], 0, None, NP, gated[l],
+                                            ws.data_ptr(), ws.numel(), sh) == 0
+    ostate = [R.bits(b).copy() for b in bs]
+    opk = [None] * (L * B)
+    for t in range(3):
+        for l in range(L):
+            with torch.cuda.stream(hog_s):
+                hog.add_(1.0)
+            go(l)
+            for i in range(B):
+                k = l * B + i
+                p, nb = R.residual_compress("int2", xs[k], ostate[k].view(F16), 0)
+                opk[k] = p; ostate[k] = R.bits(nb).copy()
+    torch.cuda.synchronize()
+    assert lib.cfx_gate_errors(ctx) == 0
+    for l in range(L):
+        for i in range(B):
+            same_bits(host_bits(pk[l * B + i]), opk[l * B + i], f"packet layer {l} item {i}")
+            same_bits(host_bits(own[l * B + i]), ostate[l * B + i], f"own state layer {l} item {i}")
+        for g in range(NP):
+            same_bits(host_bits(peer[l][g]), ostate[l * B + src[g]], f"looped-back peer state layer {l} item {g}")
+    reps = 90 if N * C >= 544 * 3072 else 30
+    ref_own = [o.clone() for o in own]
+    ref_pk = [torch.zeros_like(p) for p in pk]
+    for r in range(reps):
+        go(r % L)
+    torch.cuda.synchronize()
+    assert lib.cfx_gate_errors(ctx) == 0
+    for r in range(reps):
+        l = r % L
+        c = (_lib.CompItem * B)(*[_lib.CompItem(xd[l * B + i].data_ptr(), ref_own[l * B + i].data_ptr(), ref_own[l * B + i].data_ptr(),
+                                                ref_pk[l * B + i].data_ptr()) for i in range(B)])
+        assert lib.cfx_compress_batch_ex(ctx, 2, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, c, 0, None, ws.data_ptr(), ws.numel(), sh) == 0
+    torch.cuda.synchronize()
+    for k in range(L * B):
+        assert torch.equal(own[k].view(torch.int16), ref_own[k].view(torch.int16)), f"own state {k} after {reps} gated launches"
+        assert torch.equal(pk[k].view(torch.int16), ref_pk[k].view(torch.int16)), f"packet {k} after {reps} gated launches"
+    for l in range(L):
+        for g in range(NP):
+            assert torch.equal(peer[l][g].view(torch.int16), own[l * B + src[g]].view(torch.int16)), f"peer {g} of layer {l} diverged from its owner"

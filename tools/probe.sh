@@ -1,2 +1,4 @@
 #!/bin/bash
-for d in 0 2 3 4 6 9; do echo "== chunk=$d"; CFX_GATE_DELAY=$d timeout 300 python tools/gated_probe.py 5 2>&1 | grep "gated launch\|peers"; done
+# developer probe: phase timeline of one gated layer launch + step time of the two schedules
+timeout 300 python tools/gated_stamps.py 2>&1 | grep -v amdgpu.ids
+timeout 300 python tools/gated_probe.py 5 2>&1 | grep -v amdgpu.ids
