@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/r02
 mkdir -p "$OUT"; rm -rf "$OUT"/*
 KEY=$(python3 "$R/bench.py" --print-config-key)
 cd /tmp && export TMPDIR=/tmp
-# 1. kernel trace + stats of the default bench command (the in-order replay)
+# 1. kernel trace + stats of the default bench command (the in-order replay, one gated launch per layer)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 "$R/bench.py" --steps 20 --warmup 3 > "$OUT/bench_under_rocprof.log" 2>&1
 # 2. HBM traffic of the same command (short run + the copy probe used for calibration)
 PSTEPS=3
@@ -28,10 +28,12 @@ cp "$OUT/r02_bench_kernel_durations.json" profiles/r02_bench_kernel_durations.js
 python3 bench.py > "$OUT/r02_bench_n1.json" 2>/dev/null
 python3 bench.py --codec int2 > "$OUT/r02_bench_n1_int2.json" 2>/dev/null
 python3 bench.py --replay pipelined > "$OUT/r02_bench_n1_pipelined.json" 2>/dev/null
+python3 bench.py --own-ef ride --no-cpu-baseline > "$OUT/r02_bench_n1_two_launches.json" 2>/dev/null
 python3 bench.py --own-ef inline --no-cpu-baseline > "$OUT/r02_bench_n1_inline_ef.json" 2>/dev/null
 # 4. the deployable path with real attention (SURVEY 8d protocol 2), the compress launch's phase timeline
 python3 tools/overlap_bench.py --steps 20 --json "$OUT/r02_overlap.json" > /dev/null 2>&1
 python3 tools/fused_stamps.py 2>&1 | grep -v amdgpu.ids > "$OUT/r02_compress_timeline.txt"
+python3 tools/gated_stamps.py 2>&1 | grep -v amdgpu.ids > "$OUT/r02_gated_layer_timeline.txt"
 # 5. per-codec, per-configuration and low-rank tables
 python3 tools/codec_table.py 2>&1 | grep "^|" > "$OUT/r02_codec_table.md"
 python3 tools/config_table.py 2>&1 | grep "^|" > "$OUT/r02_config_table.md"
