@@ -720,10 +720,12 @@ __device__ __forceinline__ void own_tile_finish(const cfx_comp_item& it, int N, 
     const h16x8 ch8 = ld8_wt(CH + cc);
     const u16 ul = ld_wt(TOK + min(t.r0 + t.w + NW * min(t.lane, US - 1), t.r1 - 1));
     const bool has_base = it.base != nullptr;
+    u16 codes[US];
 #pragma unroll
     for (int j = 0; j < US; ++j) {
         const int rr = t.r0 + t.w + NW * j;
         const h16 tk = hfrom((u16)__builtin_amdgcn_readlane((int)ul, j));
+        codes[j] = 0;
         if (rr < t.r1 && t.act) {
             const h16x8 d = xk[j] - bk[j];
             const h16x8 thr = ch8 * tk;                                      // fastpath.py:536
@@ -735,21 +737,32 @@ __device__ __forceinline__ void own_tile_finish(const cfx_comp_item& it, int N, 
                 const unsigned m = a[i] > thr[i] ? 1u : 0u;                  // fastpath.py:540
                 code |= ((sg << 1) | m) << (2 * i);
             }
+            codes[j] = (u16)code;
             ((u16*)smw)[j * 64 + t.lane] = (u16)code;
-            if (upd) {
-                const h16x8 recv = int2_recv((u16)code, thr);
+        }
+    }
+    // publish the codes FIRST (the peers' workgroups wait for them; the state update below is nobody's dependency): a row of the
+    // tile is 128 bytes = 8 lanes x 16 bytes (same wave wrote the LDS words: in order)
+    {
+        const int j = t.lane >> 3, seg = t.lane & 7;
+        const int rr = t.r0 + t.w + NW * j;
+        if (t.lane < 8 * US && rr < t.r1 && bx * TILE_C + seg * 64 < C)
+            st16_wt(pk + (size_t)rr * (C >> 2) + bx * (TILE_C >> 2) + seg * 16, *(const u32x4*)(smw + j * 128 + seg * 16));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (threadIdx.x == 0) gate_arrive(gate2, 1u, expect2);
+    if (upd) {
+#pragma unroll
+        for (int j = 0; j < US; ++j) {
+            const int rr = t.r0 + t.w + NW * j;
+            const h16 tk = hfrom((u16)__builtin_amdgcn_readlane((int)ul, j));
+            if (rr < t.r1 && t.act) {
+                const h16x8 recv = int2_recv(codes[j], ch8 * tk);
                 st8nt(nb + (size_t)rr * C + t.c, ef ? (has_base ? (bk[j] + recv) : recv) : xk[j]);
             }
         }
     }
-    // publish the codes: a row of the tile is 128 bytes = 8 lanes x 16 bytes (same wave wrote the LDS words: in order)
-    const int j = t.lane >> 3, seg = t.lane & 7;
-    const int rr = t.r0 + t.w + NW * j;
-    if (t.lane < 8 * US && rr < t.r1 && bx * TILE_C + seg * 64 < C)
-        st16_wt(pk + (size_t)rr * (C >> 2) + bx * (TILE_C >> 2) + seg * 16, *(const u32x4*)(smw + j * 128 + seg * 16));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-    if (threadIdx.x == 0) gate_arrive(gate2, 1u, expect2);
 }
 
 // KEEP (the 2-bit layer launch): after the statistics and - for a last arriver - its jobs, the workgroup stays and quantises its own

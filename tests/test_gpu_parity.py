@@ -594,3 +594,29 @@ def test_gated_int2_layer_in_one_launch(shape, B, NP):
     for l in range(L):
         for g in range(NP):
             assert torch.equal(peer[l][g].view(torch.int16), own[l * B + src[g]].view(torch.int16)), f"peer {g} of layer {l} diverged from its owner"
+
+
+def test_gated_launch_argument_errors():
+    """cfx_compress_batch_gated / cfx_plan_add_compress_gated refuse what they cannot run: a codec without a gated form, too many
+    gated items, a null item list, misaligned pointers."""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    N, C = 64, 256
+    ctx = K.context(0)
+    x = torch.randn(N, C, device="cuda").half(); b = torch.zeros_like(x)
+    pk = torch.zeros(K.packet_halves(1, N, C) + 8, dtype=torch.float16, device="cuda")
+    ws = K.workspace(3, N, C, 0, 1, 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    c = (_lib.CompItem * 1)(_lib.CompItem(x.data_ptr(), b.data_ptr(), None, pk.data_ptr()))
+    g = (_lib.DecompItem * 1)(_lib.DecompItem(pk.data_ptr(), b.data_ptr(), b.data_ptr()))
+    assert lib.cfx_compress_batch_gated(ctx, 3, N, C, 0, 0, 1, c, 0, None, 1, g, ws.data_ptr(), ws.numel(), sh) == -4      # int4: no gated form
+    assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, 0, 1, c, 0, None, 17, g, ws.data_ptr(), ws.numel(), sh) == -5     # > CFX_MAX_BATCH
+    assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, 0, 1, c, 0, None, 1, None, ws.data_ptr(), ws.numel(), sh) == -5
+    bad = (_lib.DecompItem * 1)(_lib.DecompItem(pk.data_ptr() + 2, b.data_ptr(), b.data_ptr()))
+    assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, 0, 1, c, 0, None, 1, bad, ws.data_ptr(), ws.numel(), sh) == -3    # alignment
+    plan = lib.cfx_plan_create(ctx)
+    assert lib.cfx_plan_add_compress_gated(plan, 4, N, C, 0, 0, 1, c, 0, None, 1, g, ws.data_ptr(), ws.numel()) == -4
+    assert lib.cfx_plan_add_compress_gated(plan, 1, N, C, 0, 0, 1, c, 0, None, 1, g, ws.data_ptr(), ws.numel()) == 0
+    lib.cfx_plan_destroy(plan)
+    torch.cuda.synchronize()
+    assert lib.cfx_gate_errors(ctx) == 0
