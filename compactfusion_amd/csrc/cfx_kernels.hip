@@ -444,8 +444,11 @@ __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, in
                                // 1.77 - 1.91 ms per step for the all-resident forms)
 #define GATE_LDS_ROWS ((GATE_KL * FUSED_NT * 16 + TILE_C * 8 - 1) / (TILE_C * 8))   // rows of the u64[..][TILE_C] LDS array of the 2-bit layer kernel (>= FUSED_NW)
 #define GATE_SPIN_LIMIT (1u << 21)
+#ifndef GATE_LOCAL_SLEEP
+#define GATE_LOCAL_SLEEP 1        // s_sleep units between two polls of the XCD-local word (L2 hits)
+#endif
 #define GATE_LINE 16           // u32 words per 64-byte line
-#define GATE_BLOCK (9 * GATE_LINE)    // a gate block: the arrival counter's line, then one "open" word per XCD, a line each.
+#define GATE_BLOCK (25 * GATE_LINE)   // a gate block: the arrival counter's line, then per XCD an "open" word, a local word, a relay claim word, a line each.
 #define GATE_STRIDE (2 * GATE_BLOCK)  // two gate blocks per ticket-ring slot
                                // Pollers never touch the counter's line: one line serves ~90 accesses per us, and a few hundred
                                // pollers on it queue every arrival behind them (measured: the compress tail went from 12 to 24 us)
@@ -458,13 +461,40 @@ __device__ __forceinline__ void gate_arrive(unsigned* gate, unsigned inc, unsign
     }
 }
 // one lane polls this XCD's "open" word (relaxed, s_sleep), then the workgroup barrier releases everybody
-__device__ __forceinline__ void gate_wait(const unsigned* gate, unsigned expect, unsigned* err) {
+// Waiting for a gate: a few hundred workgroups polling through the fabric slow the compress group's reduction chain down (every
+// poll of a remotely written word is a fabric read; measured on some boxes: 1.68 -> 1.53 ms per step when the pollers merely
+// start 2 us later).  So only ONE workgroup per XCD - the first to claim the XCD's relay word for this launch - polls the word the
+// gate's last arriver writes for that XCD; when it opens, the relay stores a second, XCD-LOCAL word with a plain store (the line
+// stays in that XCD's L2) and everybody else on the XCD polls that one with L1-bypassing loads that the XCD's L2 serves - no
+// fabric traffic.  Every 16th poll a waiter looks at the fabric word itself, so nothing depends on the relay or on the XCD
+// number being right (a workgroup that mis-identifies its XCD just waits ~2 us longer).  One lane polls, the workgroup barrier
+// releases everybody.
+__device__ __forceinline__ unsigned ld_l2(const unsigned* p) {          // L1-bypassing, L2-served load the compiler cannot hoist
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void gate_wait(unsigned* gate, unsigned expect, unsigned* err) {
     if (threadIdx.x == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // HW_REG_XCC_ID[3:0]
+        unsigned* open = gate + (1 + xcc) * GATE_LINE;            // written by the gate's last arriver (write-through)
+        unsigned* local = gate + (9 + xcc) * GATE_LINE;           // written by this XCD's relay (plain store)
+        unsigned* claim = gate + (17 + xcc) * GATE_LINE;
+        const bool relay = __hip_atomic_exchange(claim, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != expect;
         unsigned n = 0;
-        const unsigned* open = gate + (1 + (blockIdx.x & 7)) * GATE_LINE;      // block b runs on XCD b % 8 (speed only)
-        while (ld_wt(open) != expect) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++n > GATE_SPIN_LIMIT) { st_wt(err, 1u); break; }
+        if (relay) {
+            while (ld_wt(open) != expect) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++n > GATE_SPIN_LIMIT) { st_wt(err, 1u); break; }
+            }
+            *(volatile unsigned*)local = expect;
+        } else {
+            while (ld_l2(local) != expect) {
+                if (GATE_LOCAL_SLEEP) __builtin_amdgcn_s_sleep(GATE_LOCAL_SLEEP);
+                ++n;
+                if ((n & 15u) == 0 && ld_wt(open) == expect) break;
+                if (n > GATE_SPIN_LIMIT) { st_wt(err, 1u); break; }
+            }
         }
     }
     __syncthreads();
@@ -483,7 +513,7 @@ __device__ __forceinline__ h16x8 ld8_wt(const u16* p) {
 
 template <int NW, int KR, int KL, bool ST>
 __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item& it, int N, int C, int R, int tile_x, int tile_y,
-                                                         const unsigned* gate, unsigned expect, unsigned* err, u32x4* lds, u64* stamps = nullptr) {
+                                                         unsigned* gate, unsigned expect, unsigned* err, u32x4* lds, u64* stamps = nullptr) {
     constexpr int K = KR + KL;
 #define GSTAMP(k) do { if (ST && stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 0) stamps[k] = wall_clock64(); } } while (0)
     const TileCoord t = tile_coord_at(tile_x, tile_y, N, C, R);
@@ -704,7 +734,7 @@ __device__ __forceinline__ void absmean_last_arriver_jobs(const cfx_comp_item& i
 // write-through, error feedback, one arrival on gate 2 - the arithmetic of k_int2_quant without reading x and the state again.
 template <int US>
 __device__ __forceinline__ void own_tile_finish(const cfx_comp_item& it, int N, int C, int R, int bx, int by, int flags, const h16x8* xk,
-                                                const h16x8* bk, const unsigned* gate1, unsigned expect1, unsigned* gate2, unsigned expect2,
+                                                const h16x8* bk, unsigned* gate1, unsigned expect1, unsigned* gate2, unsigned expect2,
                                                 unsigned* err, unsigned char* smw) {
     constexpr int NW = FUSED_NW;
     static_assert(US * 8 <= 64, "a wave publishes its US rows of codes with 8 lanes a row");
@@ -1038,7 +1068,7 @@ __global__ __launch_bounds__(NTHR) void k_int2_dequant(BatchD batch, int N, int 
 // ---------------------------------------------------------------------------------------------------
 template <int NW, int KR, int KL>
 __device__ __forceinline__ void int2_dequant_gated_body(const cfx_decomp_item& it, int N, int C, int R, int tile_x, int tile_y,
-                                                       const unsigned* gate, unsigned expect, unsigned* err, u32x4* lds) {
+                                                       unsigned* gate, unsigned expect, unsigned* err, u32x4* lds) {
     constexpr int K = KR + KL;
     const TileCoord t = tile_coord_at(tile_x, tile_y, N, C, R);
     const int C4 = C >> 2;

@@ -8,6 +8,7 @@ from compactfusion_amd import _lib, codecs as K
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 N, C, L, P = 544, 3072, 57, 14
 lib = _lib.load(); ctx = K.context(0)
+
 torch.manual_seed(0)
 own = torch.randn(L, 2, N, C, device="cuda").half()
 x = (own.float() + 0.1 * torch.randn(L, 2, N, C, device="cuda")).half()
