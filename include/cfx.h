@@ -126,7 +126,10 @@ int cfx_compress_batch_ex(cfx_ctx* ctx, int codec, int N, int C, int param, int 
  * of two, 2.125 instead of 4.125 B/el behind the dependency.  Results are identical to compress followed by
  * cfx_decompress_batch; when the shape does not qualify (C % 128 != 0, in-launch finalize off) exactly that sequence runs.
  * A gated item's base/recon must not alias this call's x / packet operands; recon may equal base, and a gated item may
- * update a compress item's `base` in place (the compress group has finished reading it when the gate opens). */
+ * update a compress item's `base` in place (the compress group has finished reading it when the gate opens).
+ * NOT capturable into a hipGraph: the value a gate opens at is a launch argument that advances with every launch (monotonic
+ * arrival counters, no reset, no memset node), so a replayed node would wait for a value that has already gone by.  The ungated
+ * launches (cfx_compress_batch / _ex) are capturable: their tickets reset themselves. */
 int cfx_compress_batch_gated(cfx_ctx* ctx, int codec, int N, int C, int param, int flags,
                              int batch, const cfx_comp_item* items, int n_ride, const cfx_decomp_item* ride,
                              int n_gated, const cfx_decomp_item* gated,
