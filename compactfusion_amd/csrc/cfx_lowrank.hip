@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_lr_aty(LrBatch b, int N, int C, size_t 
 // A non-positive pivot (rank-deficient residual, e.g. x == base) zeroes that direction instead of producing NaNs.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int RP>
-__global__ __launch_bounds__(512) void k_lr_chol(LrBatch b, int r, int nparts, size_t offG, size_t offT) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lr_chol(LrBatch b, int r, int nparts, size_t offG, size_t offT) {
     const LrItem it = b.it[blockIdx.x];
     const double* Gp = (const double*)(it.ws + offG);
     float* T = (float*)(it.ws + offT);
@@ -310,50 +310,64 @@ __global__ __launch_bounds__(512) void k_lr_chol(LrBatch b, int r, int nparts, s
         if (e < RP * RP) { G[e / RP][e % RP] = gsym[q]; L[e / RP][e % RP] = 0.0; }
     }
     __syncthreads();
-    // Right-looking Cholesky IN LDS with the whole workgroup on every step's trailing update (a step = two barriers; the
-    // single-wave register-resident form this replaces took 45 us at r = 32: one dependent LDS round trip per column and row).
-    __shared__ double colv[RP];
+    // Right-looking Cholesky and the triangular inverse in the REGISTERS of one wave: lane i holds row i (RP doubles); the pivot
+    // and the column entries the other lanes need travel by v_readlane (an SGPR broadcast), so a step has no LDS round trip and
+    // no barrier - ~16 cycles per trailing-update element instead of two workgroup barriers per column (r = 32: 56 -> ~15 us per
+    // call, most of what is left is the reduction of the partial Grams above).  Same operations in the same order as the
+    // LDS form it replaces (no contraction): identical factors.
     __shared__ double gmax_s;
-    __shared__ unsigned dead_s;
     if (tid == 0) {
         double m = 0.0;
         for (int k = 0; k < r; ++k) m = fmax(m, G[k][k]);
-        gmax_s = m; dead_s = 0;
+        gmax_s = m;
     }
     __syncthreads();
+    if (tid >= 64) return;
     const double gmax = gmax_s;
-    for (int j = 0; j < RP; ++j) {
-        __syncthreads();                              // the previous step's trailing update is complete
-        const double piv = G[j][j];
-        const bool bad = (j >= r) || !(piv > gmax * 1e-13);
-        if (tid < RP) {
-            const int i = tid;
-            double l = 0.0;
-            if (i >= j && i < r && j < r) l = bad ? (i == j ? 1.0 : 0.0) : (i == j ? sqrt(piv) : G[i][j] / sqrt(piv));
-            colv[i] = l;
-            L[i][j] = l;
-            if (i == j && bad && j < r) dead_s |= 1u << j;
-        }
-        __syncthreads();
-        for (int e = tid; e < RP * RP; e += 512) {
-            const int i = e / RP, k = e % RP;
-            if (i > j && k > j && k <= i) G[i][k] -= colv[i] * colv[k];
-        }
-    }
-    __syncthreads();
-    if (tid >= RP) return;
-    // X = L^-1: thread i computes column i (x[m] = X[m][i]) by forward substitution; L rows are broadcast LDS reads
     const int i = tid;
-    const unsigned deadmask = dead_s;
+    auto bcast = [](double v, int lane) -> double {          // value of lane `lane` (wave-uniform index) in every lane
+        const int2 q = __builtin_bit_cast(int2, v);
+        int2 o;
+        o.x = __builtin_amdgcn_readlane(q.x, lane);
+        o.y = __builtin_amdgcn_readlane(q.y, lane);
+        return __builtin_bit_cast(double, o);
+    };
+    double g[RP];
+#pragma unroll
+    for (int k = 0; k < RP; ++k) g[k] = (i < RP) ? G[i][k] : 0.0;
+    unsigned deadmask = 0;                                  // wave-uniform
+#pragma unroll
+    for (int j = 0; j < RP; ++j) {
+        const double piv = bcast(g[j], j);
+        const bool bad = (j >= r) || !(piv > gmax * 1e-13);
+        double l = 0.0;
+        if (i >= j && i < r && j < r) l = bad ? (i == j ? 1.0 : 0.0) : (i == j ? sqrt(piv) : g[j] / sqrt(piv));
+        if (bad && j < r) deadmask |= 1u << j;
+        g[j] = l;                                            // column j of L replaces column j of G
+#pragma unroll
+        for (int k = j + 1; k < RP; ++k) {
+            const double lk = bcast(l, k);
+            g[k] -= l * lk;      // every lane, every k > j: rows <= j have l = 0 or only touch their unused upper part, and so do the
+                                 // entries k > i - a per-(lane, k) condition would keep ~100 exec masks alive in SGPRs (1.8 k spills)
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // keep a step's broadcasts (SGPRs) from being hoisted across steps
+    }
+    // X = L^-1: lane i computes column i (x[m] = X[m][i]) by forward substitution; the rows of L go through LDS once (same wave:
+    // in order, no barrier) and are read back as broadcasts (one address for all lanes) - as SGPR broadcasts the ~500 entries
+    // were all kept alive at once (1.6 k SGPR spills)
+    if (i < RP) {
+#pragma unroll
+        for (int k = 0; k < RP; ++k) L[i][k] = g[k];
+    }
     double x[RP];
 #pragma unroll
     for (int m = 0; m < RP; ++m) {
         double sacc = (m == i) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < m; ++k)
-            if (k >= i) sacc -= L[m][k] * x[k];
+        for (int k = 0; k < m; ++k) sacc -= L[m][k] * x[k];  // x[k] = 0 for k < i: same sum without a mask per (lane, k)
         x[m] = (m >= i && m < r && i < r) ? sacc / L[m][m] : 0.0;
     }
+    if (i >= RP) return;
     // T[k][j] = X[j][k] (k <= j): Q = Z T; thread i writes row i of T.  Directions with a vanished pivot are dropped.
 #pragma unroll
     for (int m = 0; m < RP; ++m) {
