@@ -468,7 +468,8 @@ __device__ __forceinline__ void gate_arrive(unsigned* gate, unsigned inc, unsign
 // stays in that XCD's L2) and everybody else on the XCD polls that one with L1-bypassing loads that the XCD's L2 serves - no
 // fabric traffic.  Every 16th poll a waiter looks at the fabric word itself, so nothing depends on the relay or on the XCD
 // number being right (a workgroup that mis-identifies its XCD just waits ~2 us longer).  One lane polls, the workgroup barrier
-// releases everybody.
+// releases everybody.  (Letting the 8 relays poll the arrival COUNTER instead - one hop less - was far worse, 2.11 vs 1.58 ms per
+// step: reads of a line that is receiving atomics stall the arrivals, however few the readers.)
 __device__ __forceinline__ unsigned ld_l2(const unsigned* p) {          // L1-bypassing, L2-served load the compiler cannot hoist
     unsigned v;
     asm volatile("global_load_dword %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
