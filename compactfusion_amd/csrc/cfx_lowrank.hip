@@ -4,10 +4,10 @@
 // Householder QR, run through torch.compile + cuBLAS/cuSOLVER: ~10 library calls, A read 6 times) and the LOW_RANK /
 // LOW_RANK_Q branches of slowpath.py (:54-75 encode, :120-131 + :151-164 decode) with a fixed chain of small kernels:
 //
-//   D  = x - base                                   k_lr_prep     (fp16 residual, materialised once)
-//   2x { Y = D Q ; Z = D^T Y ; Q = orth(Z) }          k_lr_aq, k_lr_aty (+ partial Gram), k_lr_chol, k_lr_apply
-//   Y  = D Q ; Z' = D^T Y ; G = Q^T Z' (= Y^T Y)      k_lr_aq, k_lr_aty (+ partial Q^T Z')
-//   T  = chol(G)^-T ; U = Y T ; V = (Z' T)^T          k_lr_chol, k_lr_apply x2    (U = orth(Y), V = U^T D without re-reading D)
+//   D  = x - base ; Y = D Q0                        k_lr_aq<FROMX>  (fp16 residual, formed on the fly and materialised once)
+//   2x { Z = D^T Y ; T = chol(Z^T Z)^-T ; Q = Z T ; Y = D Q }   k_lr_aty (+ partial Gram), k_lr_chol, k_lr_apply2, k_lr_aq
+//   Z' = D^T Y ; G = Q^T Z' (= Y^T Y)                 k_lr_aty (+ partial Q^T Z')
+//   T  = chol(G)^-T ; U = Y T ; V = (Z' T)^T          k_lr_chol, k_lr_apply2      (U = orth(Y), V = U^T D without re-reading D)
 //   new_base = base + fp16(U16 V16)                   k_lr_decode   (the receiver's kernel, run on the sender's packet)
 //
 // orth() is Cholesky-QR with the r x r Gram matrix accumulated and factorised in fp64 (Z = Q R, R = chol(Z^T Z)^T): the
@@ -16,7 +16,7 @@
 // span(D^T D Q0) does not depend on the basis chosen for span(Q0).
 //
 // Everything is fp32 FMA on the vector ALU: at r <= 32 a pass is 2*N*C*r <= 0.1 GFLOP (<1 us of a 157 TFLOP/s machine) over
-// a 3 MB matrix that stays in L2/MALL; the chain is bound by its ~15 launches, not by FLOPs or bytes, so no MFMA.
+// a 3 MB matrix that stays in L2/MALL; the chain is bound by its 13 launches, not by FLOPs or bytes, so no MFMA.
 // All reductions have a fixed order (no float atomics): results are reproducible run to run.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -60,18 +60,6 @@ static LrWs lr_layout(int N, int C, int RP) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// D = x - base (fp16, one rounding as torch eager); base NULL: D = x
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lr_prep(LrBatch b, size_t E, size_t offD) {
-    const LrItem it = b.it[blockIdx.y];
-    const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    if (e >= E) return;
-    h16x8 xv = *reinterpret_cast<const h16x8*>(it.x + e);
-    if (it.base) xv = xv - *reinterpret_cast<const h16x8*>(it.base + e);
-    *reinterpret_cast<h16x8*>((h16*)(it.ws + offD) + e) = xv;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // Ypart[g] (N x RP) = D[:, cols of group g] . Q[cols of group g, :]      Y = sum of the 4 group partials (summed, in fixed
 // order, by whoever reads Y).  grid (ceil(N/32), 4, batch): a workgroup owns 32 rows x every 4th 256-column chunk.
 // fp32-input MFMA (v_mfma_f32_32x32x2_f32 = exact fp32 FMA chain): A[i][kk] = D[n0+i][c], B[kk][j] = Q[c][j].  The D and Q
@@ -80,12 +68,14 @@ __global__ __launch_bounds__(256) void k_lr_prep(LrBatch b, size_t E, size_t off
 // ---------------------------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int RP>
+// FROMX (the first product of a chain): D = x - base is formed on the fly (fp16, one rounding, as torch eager) and written to the
+//   workspace for the later passes - every element of D is read by exactly one workgroup here, so k_lr_prep is not needed.
+template <int RP, bool FROMX>
 __global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t offD, size_t offQ, size_t offY, int use_q0) {
     constexpr int CK = 256, LDD = CK + 2;            // LDD/2 = 129 dwords: odd row stride -> conflict-free column reads
     constexpr int QV = CK * RP / 4 / 256;            // float4 of Q per thread per chunk (8 at RP = 32)
     const LrItem it = b.it[blockIdx.z];
-    const h16* D = (const h16*)(it.ws + offD);
+    h16* D = (h16*)(it.ws + offD);
     const float* Q = use_q0 ? it.q0 : (const float*)(it.ws + offQ);
     float* Y = (float*)(it.ws + offY) + (size_t)blockIdx.y * N * RP;
     __shared__ h16 dsm[32 * LDD];                    // 16.1 KB
@@ -104,7 +94,15 @@ __global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t o
         for (int u = 0; u < 4; ++u) {                // 32 rows x 32 sixteen-byte pieces
             const int i = tid + 256 * u, rr = i >> 5, pc = (i & 31) * 8;
             dreg[u] = (h16x8)(h16)0;
-            if (n0 + rr < N && c0 + pc < C) dreg[u] = *reinterpret_cast<const h16x8*>(D + (size_t)(n0 + rr) * C + c0 + pc);
+            if (n0 + rr < N && c0 + pc < C) {
+                const size_t o = (size_t)(n0 + rr) * C + c0 + pc;
+                if (FROMX) {
+                    h16x8 xv = *reinterpret_cast<const h16x8*>(it.x + o);
+                    if (it.base) xv = xv - *reinterpret_cast<const h16x8*>(it.base + o);
+                    *reinterpret_cast<h16x8*>(D + o) = xv;
+                    dreg[u] = xv;
+                } else dreg[u] = *reinterpret_cast<const h16x8*>(D + o);
+            }
         }
 #pragma unroll
         for (int u = 0; u < QV; ++u) {
@@ -382,16 +380,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //   mode 0: fp32 rows x RP (the next Q) ; mode 1: fp16 rows x r, row-major (U, or V^T for LOW_RANK_Q) ;
 //   mode 2: fp16 r x rows, i.e. transposed (V in the LOW_RANK wire layout)
 // ---------------------------------------------------------------------------------------------------------------------
+struct LrApply { int rows, r, in_slabs, mode, out_in_packet; size_t offIn, offT, offOut, pkt_off_halves; };
 template <int RP>
-__global__ __launch_bounds__(256) void k_lr_apply(LrBatch b, int rows, int r, size_t offIn, int in_slabs, size_t offT, int mode, size_t offOut,
-                                                  int out_in_packet, size_t pkt_off_halves) {
-    const LrItem it = b.it[blockIdx.y];
+__device__ __forceinline__ void lr_apply_body(const LrItem& it, int bx, int rows, int r, size_t offIn, int in_slabs, size_t offT, int mode,
+                                              size_t offOut, int out_in_packet, size_t pkt_off_halves, float* ts) {
     const float* In = (const float*)(it.ws + offIn);
     const float* T = (const float*)(it.ws + offT);
-    __shared__ float ts[RP * RP];
     for (int i = threadIdx.x; i < RP * RP; i += 256) ts[i] = T[i];
     __syncthreads();
-    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int row = bx * 256 + threadIdx.x;
     if (row >= rows) return;
     float in[RP], out[RP];
     const size_t slab = (size_t)rows * RP;
@@ -422,6 +419,15 @@ __global__ __launch_bounds__(256) void k_lr_apply(LrBatch b, int rows, int r, si
             }
         }
     }
+}
+// two products by the same factor in one launch (U = Y T and V = Z' T at the end of the chain): blocks [0, nb0) do `a`, the rest `c`
+template <int RP>
+__global__ __launch_bounds__(256) void k_lr_apply2(LrBatch b, LrApply a, LrApply c, int nb0) {
+    __shared__ float ts[RP * RP];
+    const bool first = (int)blockIdx.x < nb0;
+    const LrApply& p = first ? a : c;
+    lr_apply_body<RP>(b.it[blockIdx.y], first ? blockIdx.x : blockIdx.x - nb0, p.rows, p.r, p.offIn, p.in_slabs, p.offT, p.mode, p.offOut,
+                      p.out_in_packet, p.pkt_off_halves, ts);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -697,23 +703,26 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
     hipStream_t s = (hipStream_t)stream;
     const size_t E = (size_t)N * C;
     const int nparts = (C + 31) / 32;
-    LAUNCH(ctx, KID_LR_PREP, s, k_lr_prep, dim3((unsigned)((E / 8 + 255) / 256), batch), dim3(256), 0, s, b, E, w.D);
     const dim3 g_aq((N + 31) / 32, 4, batch), g_aty(nparts, batch), g_chol(batch), g_apc((C + 255) / 256, batch), g_apn((N + 255) / 256, batch);
+    // D = x - base is formed (and stored) by the first product.  (Forming Q = orth(Z) = Z T inside the next product instead of by a
+    // launch of its own was measured slower at every rank: 17 row tiles redo the same RP x RP products per chunk.)
+    const LrApply aq_ = {C, rank, 1, 0, 0, w.Zb, w.T, w.Qa, 0};
     for (int iter = 0; iter < 2; ++iter) {
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, iter == 0 ? 1 : 0));
+        if (iter == 0) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, true>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 1));
+        else LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0));
         LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 0));
         LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(512), 0, s, b, rank, nparts, w.Gp, w.T));
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply<RP>), g_apc, dim3(256), 0, s, b, C, rank, w.Zb, 1, w.T, 0, w.Qa, 0, (size_t)0));
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), g_apc, dim3(256), 0, s, b, aq_, aq_, (int)g_apc.x));
     }
-    LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0));
+    LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0));
     LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 1));
     LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(512), 0, s, b, rank, nparts, w.Gp, w.T));
     int rc = CFX_OK;
     LrDec dec[LR_MAXB];
     if (!quantized) {
         // U (N x r) and V (r x C) straight into the packet: [U | V]
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply<RP>), g_apn, dim3(256), 0, s, b, N, rank, w.Y, 4, w.T, 1, (size_t)0, 1, (size_t)0));
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply<RP>), g_apc, dim3(256), 0, s, b, C, rank, w.Zb, 1, w.T, 2, (size_t)0, 1, (size_t)N * rank));
+        const LrApply au = {N, rank, 4, 1, 1, w.Y, w.T, 0, 0}, av = {C, rank, 1, 2, 1, w.Zb, w.T, 0, (size_t)N * rank};
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), dim3(g_apn.x + g_apc.x, batch), dim3(256), 0, s, b, au, av, (int)g_apn.x));
         for (int i = 0; i < batch; ++i) {
             dec[i].U = (const h16*)items[i].packet; dec[i].V = (const h16*)items[i].packet + (size_t)N * rank;
             dec[i].base = (const h16*)items[i].base; dec[i].out = (h16*)items[i].new_base;
@@ -721,8 +730,8 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
     } else {
         // U16 (N x r), V^T16 (C x r) -> int4 factor quantiser (the native int4 kernel) -> packet sections; then the dequantised
         // factors (what the receiver will see) feed the error-feedback decode
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply<RP>), g_apn, dim3(256), 0, s, b, N, rank, w.Y, 4, w.T, 1, w.U16, 0, (size_t)0));
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply<RP>), g_apc, dim3(256), 0, s, b, C, rank, w.Zb, 1, w.T, 1, w.V16, 0, (size_t)0));
+        const LrApply au = {N, rank, 4, 1, 0, w.Y, w.T, w.U16, 0}, av = {C, rank, 1, 1, 0, w.Zb, w.T, w.V16, 0};
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), dim3(g_apn.x + g_apc.x, batch), dim3(256), 0, s, b, au, av, (int)g_apn.x));
         const size_t secU = (size_t)N * rank / 2 + 4 * rank, secV = (size_t)C * rank / 2 + 4 * rank;       // bytes
         const size_t i4ws_off = w.total;
         // one batched launch sequence per factor side (U sections are 16-byte aligned in the packet; V sections may start
