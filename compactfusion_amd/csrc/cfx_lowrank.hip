@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr int E = RP * RP, GRP = (512 / E) > 0 ? (512 / E) : 1, EPT = (E + 511) / 512;
         __shared__ double part[GRP][E];
         {
-            constexpr int U = 12;                    // parts in flight per element
+            constexpr int U = (EPT > 1) ? 24 : 12;   // parts in flight per element (r = 32: 192 loads per thread, 8 round trips instead of 16)
             const int e0 = tid % (E < 512 ? E : 512), g = (E < 512) ? tid / E : 0;
             double a[EPT][U];
 #pragma unroll
@@ -334,13 +334,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int k = 0; k < RP; ++k) g[k] = (i < RP) ? G[i][k] : 0.0;
     unsigned deadmask = 0;                                  // wave-uniform
+    __shared__ double dinv_s[RP];                           // 1 / L[j][j]
 #pragma unroll
     for (int j = 0; j < RP; ++j) {
         const double piv = bcast(g[j], j);
         const bool bad = (j >= r) || !(piv > gmax * 1e-13);
+        // 1 / sqrt(piv) by v_rsq_f64 + two Newton steps (full fp64 accuracy) instead of a correctly rounded sqrt and a division on
+        // the critical path of every column; the factor T leaves this kernel as fp32
+        double inv = __builtin_amdgcn_rsq(bad ? 1.0 : piv);
+        inv = inv * (1.5 - 0.5 * (bad ? 1.0 : piv) * inv * inv);
+        inv = inv * (1.5 - 0.5 * (bad ? 1.0 : piv) * inv * inv);
         double l = 0.0;
-        if (i >= j && i < r && j < r) l = bad ? (i == j ? 1.0 : 0.0) : (i == j ? sqrt(piv) : g[j] / sqrt(piv));
+        if (i >= j && i < r && j < r) l = bad ? (i == j ? 1.0 : 0.0) : (i == j ? piv * inv : g[j] * inv);
         if (bad && j < r) deadmask |= 1u << j;
+        if (i == 0) dinv_s[j] = bad ? 1.0 : inv;
         g[j] = l;                                            // column j of L replaces column j of G
 #pragma unroll
         for (int k = j + 1; k < RP; ++k) {
@@ -352,7 +359,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     // X = L^-1: lane i computes column i (x[m] = X[m][i]) by forward substitution; the rows of L go through LDS once (same wave:
     // in order, no barrier) and are read back as broadcasts (one address for all lanes) - as SGPR broadcasts the ~500 entries
-    // were all kept alive at once (1.6 k SGPR spills)
+    // were all kept alive at once (1.6 k SGPR spills).  Two accumulators halve the dependent chain of a row.
     if (i < RP) {
 #pragma unroll
         for (int k = 0; k < RP; ++k) L[i][k] = g[k];
@@ -360,10 +367,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     double x[RP];
 #pragma unroll
     for (int m = 0; m < RP; ++m) {
-        double sacc = (m == i) ? 1.0 : 0.0;
+        double s0 = (m == i) ? 1.0 : 0.0, s1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < m; ++k) sacc -= L[m][k] * x[k];  // x[k] = 0 for k < i: same sum without a mask per (lane, k)
-        x[m] = (m >= i && m < r && i < r) ? sacc / L[m][m] : 0.0;
+        for (int k = 0; k + 1 < m; k += 2) { s0 -= L[m][k] * x[k]; s1 -= L[m][k + 1] * x[k + 1]; }   // x[k] = 0 for k < i: no mask per (lane, k)
+        if (m & 1) s0 -= L[m][m - 1] * x[m - 1];
+        x[m] = (m >= i && m < r && i < r) ? (s0 + s1) * dinv_s[m] : 0.0;
     }
     if (i >= RP) return;
     // T[k][j] = X[j][k] (k <= j): Q = Z T; thread i writes row i of T.  Directions with a vanished pivot are dropped.
