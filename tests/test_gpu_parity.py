@@ -433,7 +433,7 @@ def test_statistics_exact_sums_on_outliers_subnormals_and_signed_zeros(name, cid
 
 @pytest.mark.parametrize("own_ef", ["items", "flag"])
 @pytest.mark.parametrize("shape,B,NG", [((544, 3072), 2, 16), ((512, 1536), 2, 16), ((256, 1152), 1, 3), ((130, 1024), 2, 5),
-                                       ((64, 256), 1, 2), ((1100, 3072), 1, 4), ((64, 264), 1, 2)])
+                                       ((64, 256), 1, 2), ((1100, 3072), 1, 4), ((64, 264), 1, 2), ((2, 512), 1, 2), ((34, 8192), 2, 6)])
 def test_gated_reconstruction_in_the_compress_launch(shape, B, NG, own_ef):
     """cfx_compress_batch_gated: the reconstruction of tensors whose packets THIS launch produces (own error feedback, looped-back
     peers) runs inside the compress launch behind an arrival gate.  Packets and states equal the oracle's bit for bit on every
@@ -522,7 +522,8 @@ def test_gated_reconstruction_in_the_compress_launch(shape, B, NG, own_ef):
             assert torch.equal(peer[l][g - B].view(torch.int16), own[l * B + src[g]].view(torch.int16)), f"peer {g} of layer {l} diverged from its owner"
 
 
-@pytest.mark.parametrize("shape,B,NP", [((544, 3072), 2, 14), ((512, 1536), 2, 14), ((256, 1152), 1, 3), ((130, 1024), 2, 5), ((64, 264), 1, 2)])
+@pytest.mark.parametrize("shape,B,NP", [((544, 3072), 2, 14), ((512, 1536), 2, 14), ((256, 1152), 1, 3), ((130, 1024), 2, 5), ((64, 264), 1, 2),
+                                        ((2, 512), 1, 2), ((34, 8192), 2, 6)])
 def test_gated_int2_layer_in_one_launch(shape, B, NP):
     """cfx_compress_batch_gated, 2-bit codec: statistics + finalize, quantise + error feedback of the own tensors and the
     reconstruction of NP looped-back peers in ONE launch (two arrival gates).  Packets and states equal the oracle's bit for bit
@@ -620,3 +621,31 @@ def test_gated_launch_argument_errors():
     lib.cfx_plan_destroy(plan)
     torch.cuda.synchronize()
     assert lib.cfx_gate_errors(ctx) == 0
+
+
+def test_gated_item_with_a_packet_from_an_earlier_launch():
+    """A gated item whose packet was NOT produced by this launch (an older packet of the same codec and shape) is legal: it waits
+    for the gate like the others and reconstructs from the packet as it stands."""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    N, C = 544, 3072
+    ctx = K.context(0)
+    (x0, b0), (x1, b1) = make_inputs(7, N, C), make_inputs(8, N, C)
+    xd0, xd1 = dev(x0), dev(x1)
+    s0, s1 = dev(b0), dev(b1)
+    other = dev(b1)                                       # a state that receives the OLD packet (layer 0's) during layer 1's launch
+    pk0 = torch.zeros(K.packet_halves(1, N, C), dtype=torch.float16, device="cuda"); pk1 = torch.zeros_like(pk0)
+    ws = K.workspace(1, N, C, 0, 1, 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    c0 = (_lib.CompItem * 1)(_lib.CompItem(xd0.data_ptr(), s0.data_ptr(), None, pk0.data_ptr()))
+    assert lib.cfx_compress_batch_ex(ctx, 1, N, C, 0, 0, 1, c0, 0, None, ws.data_ptr(), ws.numel(), sh) == 0
+    c1 = (_lib.CompItem * 1)(_lib.CompItem(xd1.data_ptr(), s1.data_ptr(), s1.data_ptr(), pk1.data_ptr()))
+    g = (_lib.DecompItem * 1)(_lib.DecompItem(pk0.data_ptr(), other.data_ptr(), other.data_ptr()))
+    assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, _lib.FLAG_UPDATE_CACHE, 1, c1, 0, None, 1, g, ws.data_ptr(), ws.numel(), sh) == 0
+    torch.cuda.synchronize()
+    assert lib.cfx_gate_errors(ctx) == 0
+    p0, _ = R.residual_compress("binary", x0, b0, 0)
+    p1, nb1 = R.residual_compress("binary", x1, b1, 0)
+    same_bits(host_bits(pk1), p1, "layer 1 packet")
+    same_bits(host_bits(s1), R.bits(nb1), "layer 1 own state (CFX_FLAG_UPDATE_CACHE inside the gated launch)")
+    same_bits(host_bits(other), R.bits(R.residual_decompress("binary", p0, b1, N, C)), "state reconstructed from the older packet")
