@@ -2000,6 +2000,9 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
     }
     const int R = fused ? fused_rows(ctx, N, C, batch) : auto_rows(ctx, N, C, batch, true);
     const int P = (N + R - 1) / R;
+    // one launch only for explicit gated items: folding the error-feedback update of a PLAIN compress call into the launch the same
+    // way was measured slower (K,V of the FLUX shard: 20.8 vs 19.2 us 1-bit, 19.9 vs 18.6 us 2-bit) - the gate hop and the write tail
+    // cost more than the kernel boundary they replace when only two tensors wait behind the gate
     const bool one_launch = n_gated && gated_one_launch(ctx, codec, C, CB) && R == FUSED_NW * 4;   // the tile stays in registers
     const dim3 grid(CB, P, batch);
     const int Rq = auto_rows(ctx, N, C, batch, true);       // apply passes: same tile map as the (unfused) statistics pass
