@@ -435,7 +435,9 @@ __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, in
 // dispatch order and never wait on anything, so the wait always ends; a bounded spin turns a lost arrival into an error word
 // (cfx_gate_errors) instead of a hung GPU.
 #define GATE_KR 17             // rows of its tile a wave holds in registers: tiles of up to FUSED_NW * 17 rows (544 = 4 x 136) ...
-#define GATE_KL 6              // ... plus, in the 2-bit layer launch, 6 rows in LDS (16 bytes per lane and row, 48 KB a workgroup):
+#ifndef GATE_KL
+#define GATE_KL 6
+#endif                         // ... plus, in the 2-bit layer launch, 6 rows in LDS (16 bytes per lane and row, 48 KB a workgroup):
                                // there the statistics workgroups stay resident until they have quantised their tiles, so a gated
                                // workgroup that is not resident from the start only gets a slot - and pulls its tile - after the
                                // gate; with 23 rows a wave a (544, C) tensor is 3 row blocks and 204 + 14 x 6 x 3 = 456 workgroups all
@@ -1128,8 +1130,7 @@ struct Int2LayerArgs {
 };
 template <int US>
 __global__ __launch_bounds__(FUSED_NT, 4) void k_int2_compress_gated(BatchC batch, BatchD gated, Int2LayerArgs a) {
-    static_assert(GATE_LDS_ROWS >= FUSED_NW, "the statistics group needs FUSED_NW rows");
-    __shared__ u64 sm[GATE_LDS_ROWS][TILE_C];
+    __shared__ u64 sm[GATE_LDS_ROWS > FUSED_NW ? GATE_LDS_ROWS : FUSED_NW][TILE_C];      // the statistics group needs FUSED_NW rows
     int b = blockIdx.x;
     if (b < a.n_st) {
         const int per = a.CB * a.P;
