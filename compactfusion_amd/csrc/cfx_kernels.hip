@@ -167,25 +167,6 @@ __device__ __forceinline__ TileCoord tile_coord(int N, int C, int R) { return ti
 //   colpart[p][c]   = sum over the tile's R rows
 //   EMIT_BITS: also write bit i of byte j = (x-base)[n,8j+i] >= 0        (fastpath.py:58-85)
 // ---------------------------------------------------------------------------------------------------
-// Row sums of UNROLL_S rows at once: a butterfly that halves the number of live values per step
-// (xor 32: 4 -> 2 values, xor 16: 2 -> 1, then 4 single-value steps) = 7 u64 shuffles instead of 24.
-// Returns, in lanes 0/16/32/48, the wave-wide sums of rows 0/1/2/3 respectively.
-__device__ __forceinline__ u64 wave_sum4_u64(const u64 (&v)[4], int lane) {
-    const bool hi32 = lane & 32, hi16 = lane & 16;
-    // step 1: lanes < 32 keep rows {0,1}, lanes >= 32 keep rows {2,3}
-    u64 a0 = hi32 ? v[2] : v[0], a1 = hi32 ? v[3] : v[1];
-    const u64 s0 = hi32 ? v[0] : v[2], s1 = hi32 ? v[1] : v[3];
-    a0 += __shfl_xor(s0, 32, 64);
-    a1 += __shfl_xor(s1, 32, 64);
-    // step 2: within each half, lanes with bit4 = 0 keep the first row, bit4 = 1 the second
-    u64 b = hi16 ? a1 : a0;
-    const u64 sb = hi16 ? a0 : a1;
-    b += __shfl_xor(sb, 16, 64);
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
-    return b;   // lane 0: row 0, lane 16: row 1, lane 32: row 2, lane 48: row 3
-}
-
 // The body is shared by the stand-alone kernel, the single-launch compress kernel (k_absmean_compress) and the fused pipeline
 // kernel (k_binary_pipe): (bx, by) = tile index, rowpart = this tensor's workspace, NW = waves per workgroup, sm = NW x TILE_C
 // words of LDS.  Workspace: rowpart[cb][n] (a row's partials are CB strided words: the finalize reads them coalesced over n),
@@ -264,7 +245,16 @@ __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int 
             }
         }
         SSTAMP(9);
-        const u64 tot = wave_sum4_u64(rs, t.lane);
+        // wave-wide row sums by DPP adds (no LDS crossbar round trips): a lane's row sum is below 8 x 2^40 units, split at bit 24
+        // so that both halves of the wave sum fit 32 bits (64 x 2^24, 64 x 2^19); the totals are wave-uniform
+        u64 tot = 0;
+#pragma unroll
+        for (int j = 0; j < US; ++j) {
+            const unsigned lo = wave_sum_u32_dpp((unsigned)(rs[j] & 0xffffffu));
+            const unsigned hi = wave_sum_u32_dpp((unsigned)(rs[j] >> 24));
+            const u64 tj = ((u64)hi << 24) + lo;
+            if ((t.lane >> 4) == j) tot = tj;
+        }
         SSTAMP(10);
         if ((t.lane & 15) == 0 && (t.lane >> 4) < US) {
             const int rr = r + NW * (t.lane >> 4);
@@ -272,12 +262,13 @@ __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int 
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sm[t.w][i * 64 + t.lane] = (u64)(col[i] * 16777216.0);   // exact; [i][lane]: conflict-free
+    // exact; [i][lane ^ 8i]: conflict-free here AND in the column-order read below ([i][lane] made that one 8-way conflicted)
+    for (int i = 0; i < 8; ++i) sm[t.w][i * 64 + (t.lane ^ (i << 3))] = (u64)(col[i] * 16777216.0);
     SSTAMP(11);
     if (WT) lds_barrier(); else __syncthreads();
     SSTAMP(12);
     for (int k = threadIdx.x; k < TILE_C; k += NW * 64) {   // k = channel within the tile: coalesced global writes
-        const int s = (k & 7) * 64 + (k >> 3);
+        const int s = (k & 7) * 64 + ((k >> 3) ^ ((k & 7) << 3));
         const int cc = bx * TILE_C + k;
         if (cc < C) {
             u64 v = 0;
