@@ -425,16 +425,23 @@ __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, in
 // loads (the producers stored them write-through), so no acquire fence.  The compress workgroups precede the gated ones in
 // dispatch order and never wait on anything, so the wait always ends; a bounded spin turns a lost arrival into an error word
 // (cfx_gate_errors) instead of a hung GPU.
-#define GATE_KR 17             // rows of its tile a wave holds in registers: tiles of up to FUSED_NW * 17 rows (544 = 4 x 136) ...
+#ifndef GATE_KR
+#define GATE_KR 14
+#endif                         // rows of its tile a wave holds in registers, 1-bit launch: tiles of up to FUSED_NW * 14 rows - a (544, C)
+                               // tensor is 5 row blocks of 112, 480 gated workgroups for 16 tensors: 308 resident from the start,
+                               // the rest take the slots the statistics workgroups leave at ~10 us, well before the gate.  Measured
+                               // on one box: 17 rows (4 blocks, 384 workgroups) 1.53 ms per step, 14-16 rows 1.50, 12 rows and fewer
+                               // (>= 576 workgroups: some only start after the gate) 1.78-1.85
+#define GATE_KR2 17            // 2-bit launch: 17 rows in registers ...
 #ifndef GATE_KL
 #define GATE_KL 6
 #endif                         // ... plus, in the 2-bit layer launch, 6 rows in LDS (16 bytes per lane and row, 48 KB a workgroup):
                                // there the statistics workgroups stay resident until they have quantised their tiles, so a gated
                                // workgroup that is not resident from the start only gets a slot - and pulls its tile - after the
                                // gate; with 23 rows a wave a (544, C) tensor is 3 row blocks and 204 + 14 x 6 x 3 = 456 workgroups all
-                               // fit (2 / CU).  The 1-bit launch keeps 17: its statistics workgroups retire early, the ~76 gated
-                               // workgroups that take over their slots spread the preload burst, and that measured faster (1.60 vs
-                               // 1.77 - 1.91 ms per step for the all-resident forms)
+                               // fit (2 / CU).  In the 1-bit launch the statistics workgroups retire early, the gated workgroups that
+                               // take over their slots spread the preload burst, and that measured faster than the all-resident
+                               // forms (1.60 vs 1.77 - 1.91 ms per step)
 #define GATE_LDS_ROWS ((GATE_KL * FUSED_NT * 16 + TILE_C * 8 - 1) / (TILE_C * 8))   // rows of the u64[..][TILE_C] LDS array of the 2-bit layer kernel (>= FUSED_NW)
 #define GATE_SPIN_LIMIT (1u << 21)
 #ifndef GATE_LOCAL_SLEEP
@@ -865,8 +872,11 @@ struct FusedArgs {
     unsigned gate_expect;
     unsigned* gate_err;
 };
+#ifndef GATE_WPE
+#define GATE_WPE 4               // waves per SIMD the single-launch compress kernels are compiled for (2 workgroups / CU)
+#endif
 template <bool EMIT_BITS, int US, bool GATED = false, bool ST = false>
-__global__ __launch_bounds__(FUSED_NT, 4) void k_absmean_compress(BatchC batch, BatchD ride, BatchD gated, FusedArgs a) {
+__global__ __launch_bounds__(FUSED_NT, GATE_WPE) void k_absmean_compress(BatchC batch, BatchD ride, BatchD gated, FusedArgs a) {
     __shared__ u64 sm[FUSED_NW][TILE_C];
     int b = blockIdx.x;
     if (b < a.n_st) {
@@ -1136,7 +1146,7 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_int2_compress_gated(BatchC batc
     const int per = a.CB * a.g_rb;
     const int item = b / per, rem = b - item * per;
     const int ty = rem / a.CB;
-    int2_dequant_gated_body<FUSED_NW, GATE_KR, GATE_KL>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.gate2, a.expect2, a.err,
+    int2_dequant_gated_body<FUSED_NW, GATE_KR2, GATE_KL>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.gate2, a.expect2, a.err,
                                                         (u32x4*)&sm[0][0]);
 }
 
@@ -1921,7 +1931,7 @@ static int fused_rows(const cfx_ctx* ctx, int N, int C, int batch) {
 }
 
 // The gated form can run as one launch when: 1-bit codec, in-launch finalize on, rows of sign bits 16-byte aligned (C % 128 == 0),
-// tiles of at most FUSED_NW * GATE_KR (1-bit) / FUSED_NW * (GATE_KR + GATE_KL) (2-bit) rows cover the tensor with few enough workgroups to matter.  Otherwise the same work runs as
+// tiles of at most FUSED_NW * GATE_KR (1-bit) / FUSED_NW * (GATE_KR2 + GATE_KL) (2-bit) rows cover the tensor with few enough workgroups to matter.  Otherwise the same work runs as
 // compress + one reconstruction launch (identical results).
 static bool gated_one_launch(cfx_ctx* ctx, int codec, int C, int CB) {
     static const char* dbg_env = getenv("CFX_FUSED_DBG");
@@ -2006,7 +2016,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             Int2LayerArgs a;
             memset(&a, 0, sizeof(a));
             a.N = N; a.C = C; a.CB = CB; a.R = R; a.P = P; a.n_st = CB * P * batch;
-            a.g_rb = (N + FUSED_NW * (GATE_KR + GATE_KL) - 1) / (FUSED_NW * (GATE_KR + GATE_KL));
+            a.g_rb = (N + FUSED_NW * (GATE_KR2 + GATE_KL) - 1) / (FUSED_NW * (GATE_KR2 + GATE_KL));
             a.g_R = ((N + a.g_rb - 1) / a.g_rb + FUSED_NW - 1) / FUSED_NW * FUSED_NW;
             a.n_g = CB * a.g_rb * n_gated;
             a.flags = flags; a.ws = ws; a.ws_stride = wstride; a.tick = tick;
