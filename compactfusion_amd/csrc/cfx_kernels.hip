@@ -453,6 +453,11 @@ __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, in
                                // Pollers never touch the counter's line: one line serves ~90 accesses per us, and a few hundred
                                // pollers on it queue every arrival behind them (measured: the compress tail went from 12 to 24 us)
 // arrival of `inc` units; whoever completes the count opens the gate for every XCD's pollers
+// FEW arrivals (the last-arriver jobs of a launch: a dozen): nothing is returned, nobody writes "open" words - the 8 relays poll the
+// counter itself (a dozen atomics are not held up by 8 readers; hundreds of tile arrivals were, see gate_wait)
+__device__ __forceinline__ void gate_arrive_few(unsigned* gate, unsigned inc) {
+    (void)__hip_atomic_fetch_add(gate, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void gate_arrive(unsigned* gate, unsigned inc, unsigned expect) {
     const unsigned old = __hip_atomic_fetch_add(gate, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old + inc == expect) {
@@ -475,10 +480,13 @@ __device__ __forceinline__ unsigned ld_l2(const unsigned* p) {          // L1-by
     asm volatile("global_load_dword %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
+// FEW: the gate counts a dozen arrivals (gate_arrive_few) and the relay polls the counter directly - one hop less than waiting for
+// the last arriver to learn that it was last (a returned atomic) and to write the "open" words.
+template <bool FEW = false>
 __device__ __forceinline__ void gate_wait(unsigned* gate, unsigned expect, unsigned* err) {
     if (threadIdx.x == 0) {
         const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // HW_REG_XCC_ID[3:0]
-        unsigned* open = gate + (1 + xcc) * GATE_LINE;            // written by the gate's last arriver (write-through)
+        unsigned* open = FEW ? gate : gate + (1 + xcc) * GATE_LINE;   // the counter, or the word the gate's last arriver writes (write-through)
         unsigned* local = gate + (9 + xcc) * GATE_LINE;           // written by this XCD's relay (plain store)
         unsigned* claim = gate + (17 + xcc) * GATE_LINE;
         const bool relay = __hip_atomic_exchange(claim, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != expect;
@@ -493,7 +501,7 @@ __device__ __forceinline__ void gate_wait(unsigned* gate, unsigned expect, unsig
             while (ld_l2(local) != expect) {
                 if (GATE_LOCAL_SLEEP) __builtin_amdgcn_s_sleep(GATE_LOCAL_SLEEP);
                 ++n;
-                if ((n & 15u) == 0 && ld_wt(open) == expect) break;
+                if ((n & (FEW ? 255u : 15u)) == 0 && ld_wt(open) == expect) break;
                 if (n > GATE_SPIN_LIMIT) { st_wt(err, 1u); break; }
             }
         }
@@ -544,7 +552,7 @@ __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item&
         for (int j = 0; j < KR; ++j) bv[j] = (h16x8)(h16)0;
     }
     GSTAMP(1);
-    gate_wait(gate, expect, err);
+    gate_wait<true>(gate, expect, err);
     if (ST && stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
     const h16x8 v8 = ld8_wt(V + cc);
     // a row's token scale is wave-uniform: lane j fetches row j's, broadcast by readlane below
@@ -620,9 +628,9 @@ __device__ __forceinline__ void row_sums2_wt(const u64* rowpart, int N, int CB, 
 }
 
 // GATED: workgroups of the SAME launch reconstruct from this packet (binary_dequant_gated_body), so everything that goes into
-// it is published write-through and counted on `gate`: one arrival per tile once its sign bits have drained (together with the
-// tickets: no extra round trip), one per last-arriver job once its U / V stores have drained.  The gate opens at
-// batch * (CB * P + CB + 1) arrivals.
+// it is published write-through, and the gate counts the last-arriver JOBS: one arrival per job once its U / V stores have drained,
+// batch * (CB + 1) in all.  The tiles need no arrival of their own: a column block's V job only starts after the block's last
+// ticket was drawn, and every tile drains its sign bits before it draws its tickets - all jobs in implies all tiles out.
 //
 // The last arrivers' jobs: V of a column block (last_col), U of the tensor (last_all).
 template <bool GATED>
@@ -724,7 +732,7 @@ __device__ __forceinline__ void absmean_last_arriver_jobs(const cfx_comp_item& i
         // the scales are out once every wave's stores have drained: one arrival per finished job
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
-        if (tid == 0) gate_arrive(gate, (last_all ? 1u : 0u) + (last_col ? 1u : 0u), gate_expect);
+        if (tid == 0) gate_arrive_few(gate, (last_all ? 1u : 0u) + (last_col ? 1u : 0u));
     }
     STAMP(6);
 #undef STAMP
@@ -743,7 +751,7 @@ __device__ __forceinline__ void own_tile_finish(const cfx_comp_item& it, int N, 
     h16* nb = (h16*)it.new_base;
     const bool upd = (flags & CFX_FLAG_UPDATE_CACHE) && nb;
     const bool ef = !(flags & CFX_FLAG_NO_EF);
-    gate_wait(gate1, expect1, err);
+    gate_wait<true>(gate1, expect1, err);
     unsigned char* pk = (unsigned char*)it.packet;
     const u16* TOK = (const u16*)(pk + (size_t)N * (C >> 2));
     const u16* CH = TOK + N;
@@ -837,7 +845,6 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
         unsigned* t = threadIdx.x ? tick : tick + 1 + bx;
         flag[threadIdx.x] = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (GATED && threadIdx.x == 64) gate_arrive(gate, 1u, gate_expect);   // this tile's bits are out
     lds_barrier();
     const bool last_col = flag[0] == (unsigned)(P - 1);
     const bool last_all = flag[1] == (unsigned)(CB * P - 1);
@@ -2023,7 +2030,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             const unsigned slot = (ctx->tick_next - 1) % TICK_RING;
             a.gate1 = ctx->gate + (size_t)slot * GATE_STRIDE;
             a.gate2 = a.gate1 + GATE_BLOCK;
-            ctx->gate_expect[2 * slot] += (unsigned)batch * (unsigned)(CB * P + CB + 1);
+            ctx->gate_expect[2 * slot] += (unsigned)batch * (unsigned)(CB + 1);
             ctx->gate_expect[2 * slot + 1] += (unsigned)a.n_st;
             a.expect1 = ctx->gate_expect[2 * slot]; a.expect2 = ctx->gate_expect[2 * slot + 1];
             a.err = ctx->gate_err;
@@ -2061,7 +2068,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                 a.n_g = CB * a.g_rb * n_gated_k;
                 const unsigned slot = (ctx->tick_next - 1) % TICK_RING;
                 a.gate = ctx->gate + (size_t)slot * GATE_STRIDE;
-                ctx->gate_expect[2 * slot] += (unsigned)batch * (unsigned)(CB * P + CB + 1);
+                ctx->gate_expect[2 * slot] += (unsigned)batch * (unsigned)(CB + 1);
                 a.gate_expect = ctx->gate_expect[2 * slot];
                 a.gate_err = ctx->gate_err;
             }
