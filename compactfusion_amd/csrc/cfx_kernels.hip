@@ -127,6 +127,20 @@ __device__ __forceinline__ void st16_wt(void* p, u32x4 v) {
 // (__syncthreads() also drains vmcnt: behind write-through stores that is a fabric round trip, ~1 us, per barrier).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Partial sums that another workgroup of the same launch reduces (WT paths) travel as 32-bit words: a last arriver pulls fresh
+// cross-CU data at only ~65 GB/s, and for real activations every partial fits (a tile's sum of |d| would have to reach 256).
+// A sum that does not fit leaves the sentinel in the 32-bit word and the exact value in the 64-bit array the non-fused kernels
+// use; the reader follows the sentinel.  Layout per tensor: [rowpart u64 N x CB][colpart u64 ceil(N/16) x C][rowpart u32][colpart u32].
+#define PART_SAT 0xFFFFFFFFu
+__device__ __forceinline__ unsigned* part32_of(const u64* rowpart, int N, int C, int CB) {
+    return (unsigned*)(rowpart + (size_t)N * CB + (size_t)((N + 15) / 16) * C);
+}
+__device__ __forceinline__ void put_part(unsigned* p32, u64* p64, size_t i, u64 v) {
+    const bool big = v >= (u64)PART_SAT;
+    st_wt(p32 + i, big ? PART_SAT : (unsigned)v);
+    if (big) st_wt(p64 + i, v);
+}
+
 __device__ __forceinline__ h16x8 habs8(h16x8 v) {
     u16x8 b = __builtin_bit_cast(u16x8, v);
     b &= (u16)0x7fff;
@@ -258,7 +272,7 @@ __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int 
         SSTAMP(10);
         if ((t.lane & 15) == 0 && (t.lane >> 4) < US) {
             const int rr = r + NW * (t.lane >> 4);
-            if (rr < t.r1) { if (WT) st_wt(&rowpart[(size_t)cb * N + rr], tot); else rowpart[(size_t)cb * N + rr] = tot; }
+            if (rr < t.r1) { if (WT) put_part(part32_of(rowpart, N, C, CB), rowpart, (size_t)cb * N + rr, tot); else rowpart[(size_t)cb * N + rr] = tot; }
         }
     }
 #pragma unroll
@@ -274,7 +288,7 @@ __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int 
             u64 v = 0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) v += sm[w][s];
-            if (WT) st_wt(&colpart[(size_t)by * C + cc], v); else colpart[(size_t)by * C + cc] = v;
+            if (WT) put_part(part32_of(rowpart, N, C, CB) + (size_t)N * CB, colpart, (size_t)by * C + cc, v); else colpart[(size_t)by * C + cc] = v;
         }
     }
 #undef SSTAMP
@@ -607,23 +621,33 @@ __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item&
 
 // Row sums of rows m0 and m1 from the transposed partials rowpart[k][n]: 8 column blocks (16 loads) per batch, every load
 // unconditional (clamped block index, masked value) - a remainder loop would be CB dependent round trips.
-__device__ __forceinline__ void row_sums2_wt(const u64* rowpart, int N, int CB, int m0, int m1, bool two, u64& s0, u64& s1) {
+__device__ __forceinline__ void row_sums2_wt(const u64* rowpart, const unsigned* row32, int N, int CB, int m0, int m1, bool two, u64& s0, u64& s1) {
     // `two` is wave-uniform: a wave whose second rows all lie beyond N skips that half of the batch (one branch around the
     // batch, not one per load)
     s0 = 0; s1 = 0;
     for (int k0 = 0; k0 < CB; k0 += FUSED_RCH) {
-        u64 a[FUSED_RCH], b[FUSED_RCH];
+        unsigned a[FUSED_RCH], b[FUSED_RCH];
 #pragma unroll
-        for (int j = 0; j < FUSED_RCH; ++j) a[j] = ld_wt(&rowpart[(size_t)min(k0 + j, CB - 1) * N + m0]);
+        for (int j = 0; j < FUSED_RCH; ++j) a[j] = ld_wt(&row32[(size_t)min(k0 + j, CB - 1) * N + m0]);
         if (two) {
 #pragma unroll
-            for (int j = 0; j < FUSED_RCH; ++j) b[j] = ld_wt(&rowpart[(size_t)min(k0 + j, CB - 1) * N + m1]);
+            for (int j = 0; j < FUSED_RCH; ++j) b[j] = ld_wt(&row32[(size_t)min(k0 + j, CB - 1) * N + m1]);
         } else {
 #pragma unroll
             for (int j = 0; j < FUSED_RCH; ++j) b[j] = 0;
         }
+        bool sat = false;
 #pragma unroll
-        for (int j = 0; j < FUSED_RCH; ++j) { s0 += (k0 + j < CB) ? a[j] : 0; s1 += (k0 + j < CB) ? b[j] : 0; }
+        for (int j = 0; j < FUSED_RCH; ++j) {
+            s0 += (k0 + j < CB) ? a[j] : 0; s1 += (k0 + j < CB) ? b[j] : 0;
+            sat |= (a[j] == PART_SAT) | (b[j] == PART_SAT);
+        }
+        if (sat) {                               // rare: a partial that did not fit 32 bits - its exact value is in the 64-bit array
+            for (int j = 0; j < FUSED_RCH && k0 + j < CB; ++j) {
+                if (a[j] == PART_SAT) s0 += ld_wt(&rowpart[(size_t)(k0 + j) * N + m0]) - (u64)PART_SAT;
+                if (two && b[j] == PART_SAT) s1 += ld_wt(&rowpart[(size_t)(k0 + j) * N + m1]) - (u64)PART_SAT;
+            }
+        }
     }
 }
 
@@ -646,17 +670,19 @@ __device__ __forceinline__ void absmean_last_arriver_jobs(const cfx_comp_item& i
     // round trips (cdna_hip_programming.md, ".s-level traps" (c)).
     const int tid = threadIdx.x;
     const u64* colpart = rowpart + (size_t)N * CB;
+    const unsigned* row32 = part32_of(rowpart, N, C, CB);
+    const unsigned* col32 = row32 + (size_t)N * CB;
     h16* U = (h16*)((char*)it.packet + (size_t)N * (C / per_byte));
     h16* V = U + N;
     const int c = bx * TILE_C + tid;
     const int cc = min(c, C - 1);
-    u64 v[FUSED_CH];
+    unsigned v[FUSED_CH];
     if (last_col) {
 #pragma unroll
-        for (int j = 0; j < FUSED_CH; ++j) v[j] = ld_wt(&colpart[(size_t)min(j, P - 1) * C + cc]);
+        for (int j = 0; j < FUSED_CH; ++j) v[j] = ld_wt(&col32[(size_t)min(j, P - 1) * C + cc]);
     }
     u64 keep0 = 0, keep1 = 0;                  // row sums of rows tid, tid + NT
-    if (last_all) row_sums2_wt(rowpart, N, CB, min(tid, N - 1), min(tid + NT, N - 1), (tid & ~63) + NT < N, keep0, keep1);
+    if (last_all) row_sums2_wt(rowpart, row32, N, CB, min(tid, N - 1), min(tid + NT, N - 1), (tid & ~63) + NT < N, keep0, keep1);
     asm volatile("" ::: "memory");
     STAMP(4);
     // reductions first, every global store last: a barrier must not sit behind an outstanding store.  The tensor-wide job (U) is
@@ -673,7 +699,7 @@ __device__ __forceinline__ void absmean_last_arriver_jobs(const cfx_comp_item& i
         for (int n0 = tid + 2 * NT; n0 - tid < N; n0 += 2 * NT) {
             const int n1 = n0 + NT;
             u64 s0, s1;
-            row_sums2_wt(rowpart, N, CB, min(n0, N - 1), min(n1, N - 1), (n1 & ~63) < N, s0, s1);
+            row_sums2_wt(rowpart, row32, N, CB, min(n0, N - 1), min(n1, N - 1), (n1 & ~63) < N, s0, s1);
             if (n0 < N) acc += habs_units(hbits(mean16(s0, C)));
             if (n1 < N) acc += habs_units(hbits(mean16(s1, C)));
         }
@@ -692,13 +718,18 @@ __device__ __forceinline__ void absmean_last_arriver_jobs(const cfx_comp_item& i
     if (last_col) {
         // V of column block bx: one column per thread
         u64 a = 0;
+        for (int p0 = 0; p0 < P; p0 += FUSED_CH) {
+            if (p0) {
 #pragma unroll
-        for (int j = 0; j < FUSED_CH; ++j) a += (j < P) ? v[j] : 0;
-        for (int p0 = FUSED_CH; p0 < P; p0 += FUSED_CH) {
+                for (int j = 0; j < FUSED_CH; ++j) v[j] = ld_wt(&col32[(size_t)min(p0 + j, P - 1) * C + cc]);
+            }
+            bool sat = false;
 #pragma unroll
-            for (int j = 0; j < FUSED_CH; ++j) v[j] = ld_wt(&colpart[(size_t)min(p0 + j, P - 1) * C + cc]);
-#pragma unroll
-            for (int j = 0; j < FUSED_CH; ++j) a += (p0 + j < P) ? v[j] : 0;
+            for (int j = 0; j < FUSED_CH; ++j) { a += (p0 + j < P) ? v[j] : 0; sat |= v[j] == PART_SAT; }
+            if (sat) {                           // rare: see row_sums2_wt
+                for (int j = 0; j < FUSED_CH && p0 + j < P; ++j)
+                    if (v[j] == PART_SAT) a += ld_wt(&colpart[(size_t)(p0 + j) * C + cc]) - (u64)PART_SAT;
+            }
         }
         vmean = mean16(a, N);
     }
@@ -717,7 +748,7 @@ __device__ __forceinline__ void absmean_last_arriver_jobs(const cfx_comp_item& i
         for (int n0 = tid + 2 * NT; n0 - tid < N; n0 += 2 * NT) {
             const int n1 = n0 + NT;
             u64 s0, s1;
-            row_sums2_wt(rowpart, N, CB, min(n0, N - 1), min(n1, N - 1), (n1 & ~63) < N, s0, s1);
+            row_sums2_wt(rowpart, row32, N, CB, min(n0, N - 1), min(n1, N - 1), (n1 & ~63) < N, s0, s1);
             if (n0 < N) PUT16(&U[n0], (h16)((float)mean16(s0, C) / den));
             if (n1 < N) PUT16(&U[n1], (h16)((float)mean16(s1, C) / den));
         }
@@ -1878,7 +1909,7 @@ static size_t ws_words(int codec, int N, int C) {
     const size_t CB = (C + TILE_C - 1) / TILE_C, P = (N + 15) / 16;
     switch (codec) {
         case CFX_CODEC_BINARY:
-        case CFX_CODEC_INT2: return (size_t)N * CB + P * C;
+        case CFX_CODEC_INT2: return (size_t)N * CB + P * C + ((size_t)N * CB + P * C + 1) / 2;      // + the 32-bit partials of the fused path
         case CFX_CODEC_INT4:
         case CFX_CODEC_INT8: return (P * C + 1) / 2;
         default: return 0;
