@@ -649,3 +649,14 @@ def test_gated_item_with_a_packet_from_an_earlier_launch():
     same_bits(host_bits(pk1), p1, "layer 1 packet")
     same_bits(host_bits(s1), R.bits(nb1), "layer 1 own state (CFX_FLAG_UPDATE_CACHE inside the gated launch)")
     same_bits(host_bits(other), R.bits(R.residual_decompress("binary", p0, b1, N, C)), "state reconstructed from the older packet")
+
+
+@pytest.mark.parametrize("name,cid", [("binary", 1), ("int2", 2)])
+@pytest.mark.parametrize("shape,drift", [((544, 3072), 50.0), ((130, 1024), 400.0), ((544, 3072), 1.5)])
+def test_statistics_partials_beyond_32_bits(name, cid, shape, drift):
+    """The fused paths hand their partial sums from workgroup to workgroup as 32-bit words with a sentinel + 64-bit side channel for
+    sums that do not fit: residuals large enough that every row partial, every column partial (drift 50, 400) or only the row
+    partials (drift 1.5: 512 channels x 1.2 > 256) take the side channel still match the oracle bit for bit."""
+    N, C = shape
+    x, base = make_inputs(900 + int(drift), N, C, drift=drift)
+    run_case(name, cid, 0, x, base, N, C)
