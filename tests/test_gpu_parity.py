@@ -660,3 +660,49 @@ def test_statistics_partials_beyond_32_bits(name, cid, shape, drift):
     N, C = shape
     x, base = make_inputs(900 + int(drift), N, C, drift=drift)
     run_case(name, cid, 0, x, base, N, C)
+
+
+def test_gated_launches_on_two_streams_at_once():
+    """Two independent sequences of gated launches issued alternately on two streams (own workspaces, one context): their
+    workgroups share the chip, each launch has its own ticket / gate slot, nobody waits on the other sequence - both end states
+    equal an ungated replay of the same launches."""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    N, C, B, NP = 544, 3072, 2, 6
+    ctx = K.context(0)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    seqs = []
+    for q in range(2):
+        xs = [make_inputs(700 + 10 * q + i, N, C) for i in range(B)]
+        xd = [dev(x) for x, _ in xs]
+        own = [dev(b) for _, b in xs]
+        peer = [dev(xs[g % B][1]) for g in range(NP)]
+        pk = [torch.zeros(K.packet_halves(1, N, C), dtype=torch.float16, device="cuda") for _ in range(B)]
+        ws = K.workspace(1, N, C, 0, B, 0, streams[q].cuda_stream)
+        comp = (_lib.CompItem * B)(*[_lib.CompItem(xd[i].data_ptr(), own[i].data_ptr(), own[i].data_ptr(), pk[i].data_ptr()) for i in range(B)])
+        gated = (_lib.DecompItem * NP)(*[_lib.DecompItem(pk[g % B].data_ptr(), peer[g].data_ptr(), peer[g].data_ptr()) for g in range(NP)])
+        seqs.append(dict(xs=xs, xd=xd, own=own, peer=peer, pk=pk, ws=ws, comp=comp, gated=gated))
+    torch.cuda.synchronize()
+    reps = 40
+    for r in range(reps):
+        for q in range(2):
+            sq = seqs[q]
+            assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, sq["comp"], 0, None, NP, sq["gated"],
+                                                sq["ws"].data_ptr(), sq["ws"].numel(), streams[q].cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert lib.cfx_gate_errors(ctx) == 0
+    sh = torch.cuda.current_stream().cuda_stream
+    ws = K.workspace(1, N, C, 0, B, 0)
+    for q in range(2):
+        sq = seqs[q]
+        ref_own = [dev(b) for _, b in sq["xs"]]
+        ref_pk = [torch.zeros_like(p) for p in sq["pk"]]
+        c = (_lib.CompItem * B)(*[_lib.CompItem(sq["xd"][i].data_ptr(), ref_own[i].data_ptr(), ref_own[i].data_ptr(), ref_pk[i].data_ptr()) for i in range(B)])
+        for r in range(reps):
+            assert lib.cfx_compress_batch_ex(ctx, 1, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, c, 0, None, ws.data_ptr(), ws.numel(), sh) == 0
+        torch.cuda.synchronize()
+        for i in range(B):
+            assert torch.equal(sq["own"][i].view(torch.int16), ref_own[i].view(torch.int16)), f"sequence {q}: own state {i}"
+            assert torch.equal(sq["pk"][i].view(torch.int16), ref_pk[i].view(torch.int16)), f"sequence {q}: packet {i}"
+        for g in range(NP):
+            assert torch.equal(sq["peer"][g].view(torch.int16), sq["own"][g % B].view(torch.int16)), f"sequence {q}: peer {g} diverged from its owner"
