@@ -610,7 +610,9 @@ __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item&
 // launch's statistics - the previous layer's deferred error-feedback update - streams while the reduction tail, which
 // is pure latency, completes (cfx_compress_batch_ex).
 // ---------------------------------------------------------------------------------------------------
-#define TICK_WORDS 64          // u32 ticket words per tensor: [0] all tiles, [1 + cb] column block cb  (CB <= 63)
+#define TICK_WORDS 64          // u32 ticket words per tensor: [1 + cb] column block cb (CB <= 46), [TICK_ALL] all tiles - on a line of its
+#define TICK_ALL 48            //   own: in the stand-alone launch that word is POLLED, and polls of a line stall the atomics arriving on it
+#define TICK_MAX_CB 46
 #define TICK_RING 256          // ticket blocks (CFX_MAX_BATCH tensors each) a context cycles through, one per launch
 
 #define FUSED_NW 8             // waves per workgroup of the single-launch compress kernel (512 threads: the last arriver of a
@@ -752,7 +754,7 @@ __device__ __forceinline__ void absmean_last_arriver_jobs(const cfx_comp_item& i
             if (n0 < N) PUT16(&U[n0], (h16)((float)mean16(s0, C) / den));
             if (n1 < N) PUT16(&U[n1], (h16)((float)mean16(s1, C) / den));
         }
-        if (tid == 0) st_wt(tick, 0u);
+        if (tid == 0) st_wt(tick + TICK_ALL, 0u);
     }
     if (last_col) {
         if (c < C) PUT16(&V[c], vmean);
@@ -871,23 +873,50 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
     __syncthreads();
     STAMP(2);
     if (dbg == 1) return;
+    // Who does what: the column ticket (a returned atomic) elects the workgroup that reduces column block bx (V).  The tensor-wide
+    // job (U):
+    //  * gated launches: a second returned ticket elects the last tile of all, as before;
+    //  * stand-alone launches (UPOLL): that workgroup is always also the last of its column block and would read both jobs'
+    //    partials at the ~65 GB/s a single workgroup gets from other CUs - so the job goes to a FIXED workgroup, tile (0, 0):
+    //    every tile counts itself on tick[TICK_ALL] without waiting for the result, and tile (0, 0), once done with its own work,
+    //    polls that word (one reader on a line of its own) and reads only the row partials: -0.9 us on the launch.  Under a
+    //    gated launch's preload burst a poll round trip costs more than the returned ticket, there it measured +1 us.
+    constexpr bool UPOLL = !GATED;
     unsigned* flag = (unsigned*)&sm[0][0];
-    if (threadIdx.x < 2) {
-        unsigned* t = threadIdx.x ? tick : tick + 1 + bx;
-        flag[threadIdx.x] = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) flag[0] = __hip_atomic_fetch_add(tick + 1 + bx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 64) {
+        if (UPOLL) (void)__hip_atomic_fetch_add(tick + TICK_ALL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else flag[1] = __hip_atomic_fetch_add(tick + TICK_ALL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     lds_barrier();
     const bool last_col = flag[0] == (unsigned)(P - 1);
-    const bool last_all = flag[1] == (unsigned)(CB * P - 1);
+    const bool u_wg = UPOLL ? (bx == 0 && by == 0) : (flag[1] == (unsigned)(CB * P - 1));
     STAMP(3);
-    if (stamps && threadIdx.x == 0) stamps[7] = (last_col ? 1 : 0) | (last_all ? 2 : 0);
+    if (stamps && threadIdx.x == 0) stamps[7] = (last_col ? 1 : 0) | (u_wg ? 2 : 0);
     if (dbg == 2) {
         if (last_col && threadIdx.x == 0) st_wt(tick + 1 + bx, 0u);
-        if (last_all && threadIdx.x == 0) st_wt(tick, 0u);
+        if (u_wg && threadIdx.x == 0) {
+            if (UPOLL) while (ld_wt(tick + TICK_ALL) != (unsigned)(CB * P)) __builtin_amdgcn_s_sleep(1);
+            st_wt(tick + TICK_ALL, 0u);
+        }
         return;
     }
-    if (last_col || last_all)                  // uniform per workgroup
-        absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, last_col, last_all, stamps, gate, gate_expect);
+    if (UPOLL) {
+        if (last_col)                          // uniform per workgroup
+            absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, true, false, stamps, gate, gate_expect);
+        if (u_wg) {
+            if (threadIdx.x == 0) {
+                unsigned n = 0;
+                while (ld_wt(tick + TICK_ALL) != (unsigned)(CB * P)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++n > GATE_SPIN_LIMIT) { if (err) st_wt(err, 1u); break; }
+                }
+            }
+            __syncthreads();
+            absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, false, true, stamps, gate, gate_expect);
+        }
+    } else if (last_col || u_wg)
+        absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, last_col, u_wg, stamps, gate, gate_expect);
     if constexpr (KEEP)
         own_tile_finish<US>(it, N, C, R, bx, by, flags, xk, bk, gate, gate_expect, gate2, expect2, err,
                                        (unsigned char*)&sm[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0]);
@@ -923,7 +952,7 @@ __global__ __launch_bounds__(FUSED_NT, GATE_WPE) void k_absmean_compress(BatchC 
         const int by = rem / a.CB;
         absmean_fused_body<EMIT_BITS, US, GATED>(batch.it[z], a.N, a.C, a.R, a.CB, a.P, rem - by * a.CB, by, a.ws + (size_t)z * a.ws_stride,
                                                  a.tick + z * TICK_WORDS, a.per_byte, a.eps_mode, sm, a.dbg,
-                                                 a.stamps ? a.stamps + (size_t)b * 16 : nullptr, a.gate, a.gate_expect);
+                                                 a.stamps ? a.stamps + (size_t)b * 16 : nullptr, a.gate, a.gate_expect, 0, nullptr, 0u, a.gate_err);
         return;
     }
     if constexpr (EMIT_BITS) {
@@ -1974,7 +2003,7 @@ static int fused_rows(const cfx_ctx* ctx, int N, int C, int batch) {
 static bool gated_one_launch(cfx_ctx* ctx, int codec, int C, int CB) {
     static const char* dbg_env = getenv("CFX_FUSED_DBG");
     static const char* off_env = getenv("CFX_GATED_OFF");
-    return (codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT2) && ctx->fused && CB < TICK_WORDS && C % 128 == 0 && !dbg_env && !off_env;
+    return (codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT2) && ctx->fused && CB <= TICK_MAX_CB && C % 128 == 0 && !dbg_env && !off_env;
 }
 
 static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
@@ -2033,7 +2062,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
     }
 
     // statistics + finalize: ONE launch with the in-launch finalize (default), or the two-kernel sequence
-    const bool fused = ctx->fused && CB < TICK_WORDS;
+    const bool fused = ctx->fused && CB <= TICK_MAX_CB;
     unsigned* tick = nullptr;
     if (fused) {
         if (!ctx->tick && cfx_prepare(ctx) != CFX_OK) return CFX_ERR_LAUNCH;
@@ -2101,8 +2130,8 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                 a.gate = ctx->gate + (size_t)slot * GATE_STRIDE;
                 ctx->gate_expect[2 * slot] += (unsigned)batch * (unsigned)(CB + 1);
                 a.gate_expect = ctx->gate_expect[2 * slot];
-                a.gate_err = ctx->gate_err;
             }
+            a.gate_err = ctx->gate_err;
             const dim3 g(a.n_st + a.n_g + CB * a.dq_rb * n_ride);
             if (one_launch_1bit && a.stamps && R % 32 == 0) {
                 LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_absmean_compress<true, 4, true, true>), g, dim3(FUSED_NT), 0, s, b, rd, gd, a);
