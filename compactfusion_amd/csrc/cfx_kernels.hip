@@ -1255,10 +1255,11 @@ __device__ __forceinline__ void minmax_stats_body(const cfx_comp_item& it, int N
     }
     __shared__ unsigned sm[WAVES][TILE_C];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sm[t.w][i * 64 + t.lane] = (unsigned)hbits(mn[i]) | ((unsigned)hbits(mx[i]) << 16);
+    // [i][lane ^ 8i]: conflict-free here and in the column-order read below (see absmean_stats_body)
+    for (int i = 0; i < 8; ++i) sm[t.w][i * 64 + (t.lane ^ (i << 3))] = (unsigned)hbits(mn[i]) | ((unsigned)hbits(mx[i]) << 16);
     __syncthreads();
     for (int k = threadIdx.x; k < TILE_C; k += NTHR) {
-        const int s = (k & 7) * 64 + (k >> 3);
+        const int s = (k & 7) * 64 + ((k >> 3) ^ ((k & 7) << 3));
         const int cc = bx * TILE_C + k;
         if (cc < C) {
             h16 a = hfrom((u16)(sm[0][s] & 0xffff)), b = hfrom((u16)(sm[0][s] >> 16));
