@@ -7,17 +7,21 @@ GPU with torch.distributed.run.  Rank 0 prints ONE JSON line.
 Workload (BASELINE.json configs[2], SURVEY.md §8d "Config 3"): one denoise step of FLUX.1-dev 1024^2 under
 ring-attention sequence parallelism of logical degree 8 with the 1-bit residual codec, as seen by ONE rank:
 57 attention layers x {K, V}, shard (N, C) = (544, 3072) fp16.  The step is replayed LAYER BY LAYER IN ORDER, the way a
-model runs it (layer l+1's K,V only exist after layer l's attention, reference xfuser/compact/ring.py:188-206): per layer
-  A. ONE launch compresses the rank's K and V against its error-feedback state: statistics + sign bits + in-launch
-     finalize of the scales (k_absmean_compress); the PREVIOUS layer's own error-feedback update (own packets applied to own
-     state) rides in the same launch - nothing reads that state before the next denoise step (the local attention block uses
-     the uncompressed K,V, ring.py:207-209), and it is bandwidth work that fills the reduction's latency,
-  X. exchanges the packets (N live ranks all-gather over RCCL, one collective per layer, issued natively in order; the 8-N
+model runs it (layer l+1's K,V only exist after layer l's attention, reference xfuser/compact/ring.py:188-206): layer l+1's
+compress cannot start before layer l's reconstruction has finished (a kernel boundary), nothing is reordered across layers.
+Per layer, at N = 1 (default --own-ef gated), ONE launch (cfx_compress_batch_gated):
+  * compress the rank's K and V against its error-feedback state: statistics + sign bits + in-launch finalize of the scales;
+  * in the same launch, behind an in-launch arrival gate, everything the layer's packets feed on this rank: the own
+    error-feedback update and the 7 looped-back logical peers' K,V (16 tensors) - their workgroups pull the state tiles into
+    registers while the scale reduction (pure latency) completes, wait for the gate, finish from registers.
+With a collective between compress and reconstruction (N > 1; --own-ef ride at N = 1) a layer is two launches:
+  A. compress K,V (k_absmean_compress); the PREVIOUS layer's own error-feedback update rides in the same launch - nothing reads
+     that state before the next denoise step (the local attention block uses the uncompressed K,V, ring.py:207-209),
+  X. exchange the packets (N live ranks all-gather over RCCL, one collective per layer, issued natively in order; the 8-N
      missing logical peers are looped back from the rank's own packet, so the per-GPU codec work is IDENTICAL for every
      N = weak scaling; at N = 8 this is exactly the real exchange, at N = 1 it is the codec path alone),
   B. ONE launch reconstructs the 7 peers' K,V (14 tensors, k_binary_dequant) onto their state arenas (the last layer's
      launch also carries that layer's own error-feedback update).
-Launch B(l) cannot start before A(l) has finished and A(l+1) not before B(l): nothing is reordered across layers.
 Inputs are synthetic and already resident in HBM; the state arenas (3.0 GB) + inputs (0.76 GB) dwarf the 256 MB
 Infinity Cache, so every step streams from HBM (cold numbers).
 
@@ -26,10 +30,11 @@ value = whole-job fp16 activation bytes compressed + reconstructed per second (G
 `pure_exchange_upper_bound` = the same step through cfx_plan_run_pipelined, which DOES reorder across layers (statistics of
         layers j+7.. beside the reconstruction of layers j..): only legal because the synthetic inputs of all layers are resident;
         a model cannot run it.  Reported as a secondary figure, never as `value`.
-roofline = the dominant kernel of the in-order step, k_binary_dequant: algorithmic bytes 4.125 B/element x the
-        tensors of a launch / average launch duration from hipEvents attached to the dispatch on the launch stream inside
-        the timed region; `roofline.step` prices the WHOLE step (every launch, edge layers included) with 6.125 B/element
-        for the rank's own tensors (compress + error feedback) and 4.125 for the peers'.
+roofline = the dominant kernel of the in-order step - the layer's one launch (2 x 6.125 + 14 x 4.125 B/element, SURVEY.md §8d;
+        with two launches per layer: k_binary_dequant, 4.125 B/element x the tensors of a launch) / average launch duration from
+        hipEvents attached to the dispatch on the launch stream inside the timed region; `roofline.step` prices the WHOLE step
+        with 6.125 B/element for the rank's own tensors (compress + error feedback) and 4.125 for the peers'.
+`two_launches_per_layer` = the same layer-ordered step as A ; B (what a collective in between forces), a secondary figure.
 cpu_baseline = the C oracle (oracle/cfx_oracle.c, OpenMP) timed on this box's host cores on one layer of the same
         workload; reported baseline only.
 """
