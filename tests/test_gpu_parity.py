@@ -433,7 +433,8 @@ def test_statistics_exact_sums_on_outliers_subnormals_and_signed_zeros(name, cid
 
 @pytest.mark.parametrize("own_ef", ["items", "flag"])
 @pytest.mark.parametrize("shape,B,NG", [((544, 3072), 2, 16), ((512, 1536), 2, 16), ((256, 1152), 1, 3), ((130, 1024), 2, 5),
-                                       ((64, 256), 1, 2), ((1100, 3072), 1, 4), ((64, 264), 1, 2), ((2, 512), 1, 2), ((34, 8192), 2, 6)])
+                                       ((64, 256), 1, 2), ((1100, 3072), 1, 4), ((64, 264), 1, 2), ((2, 512), 1, 2), ((34, 8192), 2, 6),
+                                       ((1024, 1152), 2, 4), ((4096, 1152), 1, 2)])
 def test_gated_reconstruction_in_the_compress_launch(shape, B, NG, own_ef):
     """cfx_compress_batch_gated: the reconstruction of tensors whose packets THIS launch produces (own error feedback, looped-back
     peers) runs inside the compress launch behind an arrival gate.  Packets and states equal the oracle's bit for bit on every
@@ -523,7 +524,7 @@ def test_gated_reconstruction_in_the_compress_launch(shape, B, NG, own_ef):
 
 
 @pytest.mark.parametrize("shape,B,NP", [((544, 3072), 2, 14), ((512, 1536), 2, 14), ((256, 1152), 1, 3), ((130, 1024), 2, 5), ((64, 264), 1, 2),
-                                        ((2, 512), 1, 2), ((34, 8192), 2, 6)])
+                                        ((2, 512), 1, 2), ((34, 8192), 2, 6), ((1024, 1152), 2, 4)])
 def test_gated_int2_layer_in_one_launch(shape, B, NP):
     """cfx_compress_batch_gated, 2-bit codec: statistics + finalize, quantise + error feedback of the own tensors and the
     reconstruction of NP looped-back peers in ONE launch (two arrival gates).  Packets and states equal the oracle's bit for bit
