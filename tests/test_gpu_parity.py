@@ -707,3 +707,35 @@ def test_gated_launches_on_two_streams_at_once():
             assert torch.equal(sq["pk"][i].view(torch.int16), ref_pk[i].view(torch.int16)), f"sequence {q}: packet {i}"
         for g in range(NP):
             assert torch.equal(sq["peer"][g].view(torch.int16), sq["own"][g % B].view(torch.int16)), f"sequence {q}: peer {g} diverged from its owner"
+
+
+def test_gated_and_ride_along_items_in_one_launch():
+    """One launch carrying all three groups: compress (layer 1), gated reconstructions fed by layer 1's packet, and an ungated
+    ride-along reconstruction fed by layer 0's (already complete) packet."""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    N, C = 544, 3072
+    ctx = K.context(0)
+    (x0, b0), (x1, b1) = make_inputs(21, N, C), make_inputs(22, N, C)
+    xd0, xd1, s0, s1 = dev(x0), dev(x1), dev(b0), dev(b1)
+    peers = [dev(b1) for _ in range(3)]
+    pk0 = torch.zeros(K.packet_halves(1, N, C), dtype=torch.float16, device="cuda"); pk1 = torch.zeros_like(pk0)
+    ws = K.workspace(1, N, C, 0, 1, 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    c0 = (_lib.CompItem * 1)(_lib.CompItem(xd0.data_ptr(), s0.data_ptr(), None, pk0.data_ptr()))
+    assert lib.cfx_compress_batch_ex(ctx, 1, N, C, 0, 0, 1, c0, 0, None, ws.data_ptr(), ws.numel(), sh) == 0
+    c1 = (_lib.CompItem * 1)(_lib.CompItem(xd1.data_ptr(), s1.data_ptr(), None, pk1.data_ptr()))
+    ride = (_lib.DecompItem * 1)(_lib.DecompItem(pk0.data_ptr(), s0.data_ptr(), s0.data_ptr()))
+    items = [_lib.DecompItem(pk1.data_ptr(), s1.data_ptr(), s1.data_ptr())] + [_lib.DecompItem(pk1.data_ptr(), p.data_ptr(), p.data_ptr()) for p in peers]
+    gated = (_lib.DecompItem * len(items))(*items)
+    for _ in range(1):
+        assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, 0, 1, c1, 1, ride, len(items), gated, ws.data_ptr(), ws.numel(), sh) == 0
+    torch.cuda.synchronize()
+    assert lib.cfx_gate_errors(ctx) == 0
+    p0, nb0 = R.residual_compress("binary", x0, b0, 0)
+    p1, nb1 = R.residual_compress("binary", x1, b1, 0)
+    same_bits(host_bits(pk1), p1, "layer 1 packet")
+    same_bits(host_bits(s0), R.bits(nb0), "layer 0 state (ride-along)")
+    same_bits(host_bits(s1), R.bits(nb1), "layer 1 state (gated)")
+    for i, p in enumerate(peers):
+        same_bits(host_bits(p), R.bits(nb1), f"peer {i} (gated)")
