@@ -703,6 +703,10 @@ def main():
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            "traffic": None, "traffic_source": None, "avg_launch_us": round(us, 3), "algorithmic_bytes_per_launch": int(alg),
                            "event_samples": n_samples, "event_stride": args.event_stride, "step": step_obj}
+        if gated:
+            # one launch per layer: the step time divided by the launches is an upper bound of the launch duration (it contains the
+            # kernel boundaries); a dispatch that carries profiling events runs ~1.5 us longer than that on this kernel
+            out["roofline"]["step_time_per_launch_us"] = round(ms_per_step * 1e3 / L, 3)
         if int2 and 28 in kern_us and 5 in kern_us:
             out["roofline"]["compress_launches"] = {
                 "k_absmean_compress (A1: statistics + in-launch finalize)": round(kern_us[28][0], 3),
