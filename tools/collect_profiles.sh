@@ -32,6 +32,10 @@ python3 bench.py --own-ef ride --no-cpu-baseline > "$OUT/r02_bench_n1_two_launch
 python3 bench.py --own-ef inline --no-cpu-baseline > "$OUT/r02_bench_n1_inline_ef.json" 2>/dev/null
 # 4. the deployable path with real attention (SURVEY 8d protocol 2), the compress launch's phase timeline
 python3 tools/overlap_bench.py --steps 20 --json "$OUT/r02_overlap.json" > /dev/null 2>&1
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/ovtrace" -o ov -- python3 "$R/tools/overlap_bench.py" --steps 3 --json /tmp/ov_prof.json > /dev/null 2>&1)
+OVT=$(find "$OUT/ovtrace" -name "*kernel_trace.csv" | head -1)
+[ -n "$OVT" ] && python3 tools/overlap_trace.py "$OVT" "$OUT/r02_overlap_trace.json" > /dev/null 2>&1
+rm -rf "$OUT/ovtrace"
 python3 tools/fused_stamps.py 2>&1 | grep -v amdgpu.ids > "$OUT/r02_compress_timeline.txt"
 python3 tools/gated_stamps.py 2>&1 | grep -v amdgpu.ids > "$OUT/r02_gated_layer_timeline.txt"
 # 5. per-codec, per-configuration and low-rank tables
