@@ -96,4 +96,88 @@ static inline int check_launch(cfx_ctx* ctx, const char* what) {
 }
 
 #define AL16(p) ((((uintptr_t)(p)) & 15) == 0)
+
+// ---------------------------------------------------------------------------------------------------
+// Plan / communicator internals, shared by cfx_kernels.hip (the fused pipeline launch) and cfx_plan.hip (everything else)
+// ---------------------------------------------------------------------------------------------------
+// ---- plan: a prebuilt schedule of batch ops replayed from native code (no per-op Python marshalling) -------------
+// ---- RCCL, loaded at run time (the same library instance PyTorch-ROCm uses; no link-time dependency) ----------------
+typedef struct { char internal[128]; } cfx_nccl_uid;
+typedef void* cfx_nccl_comm;
+struct RcclApi {
+    void* handle;
+    int (*GetUniqueId)(cfx_nccl_uid*);
+    int (*CommInitRank)(cfx_nccl_comm*, int, cfx_nccl_uid, int);
+    int (*AllGather)(const void*, void*, size_t, int, cfx_nccl_comm, hipStream_t);
+    int (*CommDestroy)(cfx_nccl_comm);
+    const char* (*GetErrorString)(int);
+    int (*Send)(const void*, size_t, int, int, cfx_nccl_comm, hipStream_t);
+    int (*Recv)(void*, size_t, int, int, cfx_nccl_comm, hipStream_t);
+    int (*GroupStart)(void);
+    int (*GroupEnd)(void);
+    char path[512];
+};
+
+struct cfx_comm {
+    cfx_ctx* ctx;
+    cfx_nccl_comm comm;
+    int nranks, rank;
+    RcclApi api;
+};
+
+struct PlanOp {
+    int kind;   // 0 compress, 1 decompress, 2 all-gather on the side stream, 3 main stream waits for gather op `ref`
+    int codec, N, C, param, flags, batch;
+    cfx_comp_item c[CFX_MAX_BATCH];
+    cfx_decomp_item d[CFX_MAX_BATCH];     // kind 1: the items; kind 0: ride-along reconstruction items (n_ride of them)
+    int n_ride;
+    cfx_decomp_item g[CFX_MAX_BATCH];     // kind 0: gated reconstruction items (n_gated of them)
+    int n_gated;
+    void* ws;
+    size_t ws_bytes;
+    // kind 2 / 3
+    cfx_comm* comm;
+    const void* send;
+    void* recv;
+    size_t bytes_per_rank;
+    hipEvent_t ev_pre, ev_done;
+    int ref;
+};
+struct PipeSched;
+struct cfx_plan {
+    cfx_ctx* ctx;
+    PlanOp* ops;
+    int n, cap;
+    hipStream_t side;     // exchange stream (created on first all-gather op, or the caller's: side_owned = false)
+    bool side_owned;
+    hipEvent_t ev_fork, ev_join;   // cfx_plan_run_async / cfx_plan_join
+    int side_mode;        // 0: issue collectives on the main stream (no cross-stream events), 1: side stream, 2: prioritised side stream
+    void* pipe_ws;        // cfx_plan_run_pipelined: two statistics workspaces of CFX_MAX_BATCH tensors each (stats of unit
+    size_t pipe_ws_bytes; //   t runs beside the finalize of unit t-1)
+    PipeSched* sched;          // unit schedule of the pipelined replay, built once (cfx_plan_finalize or the first replay of a range)
+};
+
+
+#define CFX_PIPE_MAX_DQ 112    // reconstruction items per fused launch (a "unit" of up to 7 layers x 16 tensors; kernel arguments stay below 4 KB)
+struct PipeUnit { int first_layer, n_layers, n_comp_items, n_dq_items; };
+// The recognised schedule of an op range: built once per plan and range, replayed without host allocations, environment
+// lookups or device allocations.
+struct PipeSched {
+    int first_op, n_ops, n_plan_ops;      // the range it was built for (and the plan size at that time)
+    bool ok;                              // false: the range is not a sequence of 1-bit groups -> cfx_plan_run replays it
+    int L, n_ag, N, C, U;
+    int *comp_op, *deq_op, *ag_op, *ag_unit;
+    PipeUnit* units;
+};
+
+// cfx_kernels.hip, for cfx_plan.hip (hidden: not part of the ABI)
+#define CFX_HIDDEN __attribute__((visibility("hidden")))
+CFX_HIDDEN bool cfx_i_shape_ok(int codec, int N, int C, int param);
+CFX_HIDDEN size_t cfx_i_ws_words(int codec, int N, int C);
+CFX_HIDDEN int cfx_i_compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                                   int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+CFX_HIDDEN int cfx_i_launch_pipe(cfx_plan* p, hipStream_t s, int N, int C, const int* comp_op, const int* deq_op,
+                                 const PipeUnit* dq, const PipeUnit* fin, const PipeUnit* st, int fin_parity, int st_parity,
+                                 hipEvent_t done_ev);
 #endif

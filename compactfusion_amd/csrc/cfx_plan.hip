@@ -1,0 +1,544 @@
+// libcfx.so - plan replay, library-owned RCCL communicator and the flag-synchronised exchange lane (host side of the C-ABI of
+// include/cfx.h; the streaming kernels are in cfx_kernels.hip, the low-rank chain in cfx_lowrank.hip).
+//
+// Reference citations are relative to /root/reference/xfuser/compact/.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <dlfcn.h>
+#include "cfx.h"
+#include "cfx_internal.h"
+
+typedef unsigned long long u64;
+#define shape_ok cfx_i_shape_ok
+#define ws_words cfx_i_ws_words
+#define compress_impl cfx_i_compress_impl
+#define launch_pipe cfx_i_launch_pipe
+#define PIPE_MAX_DQ CFX_PIPE_MAX_DQ
+
+// The ONLY process-global state besides what hangs off a cfx_ctx (documented in cfx.h): the entry points of the collective
+// library most recently loaded by cfx_rccl_load.  A communicator keeps its own copy of the table it was created with.
+static RcclApi g_rccl = {};
+
+static void sched_free(PipeSched* sc) {
+    if (!sc) return;
+    delete[] sc->comp_op; delete[] sc->deq_op; delete[] sc->ag_op; delete[] sc->ag_unit; delete[] sc->units;
+    delete sc;
+}
+
+extern "C" {
+
+cfx_plan* cfx_plan_create(cfx_ctx* ctx) {
+    if (!ctx) return nullptr;
+    cfx_plan* p = new cfx_plan();
+    p->ctx = ctx;
+    p->ops = nullptr;
+    p->n = p->cap = 0;
+    p->side = nullptr;
+    p->side_owned = true;
+    p->ev_fork = p->ev_join = nullptr;
+    p->pipe_ws = nullptr;
+    p->pipe_ws_bytes = 0;
+    p->sched = nullptr;
+    // Default: collectives in order on the main stream.  Measured on MI355X / ROCm 7: one cross-stream event hop costs
+    // ~10 us of idle queue time, two per layer (main->side, side->main) = +1.1 ms per 57-layer step, whereas the
+    // in-order exchange adds 0.1 ms; a side stream only pays when >> 20 us of independent work can overlap (attention).
+    p->side_mode = 0;
+    const char* m = getenv("CFX_EXCHANGE_STREAM");
+    if (m) p->side_mode = !strcmp(m, "main") ? 0 : (!strcmp(m, "side") ? 1 : 2);
+    return p;
+}
+
+int cfx_plan_set_exchange_stream(cfx_plan* p, int mode) {
+    if (!p) return CFX_ERR_NULL;
+    if (mode < 0 || mode > 2 || p->side) return fail(p->ctx, CFX_ERR_BATCH, "plan: exchange stream mode must be 0..2 and set before the first all-gather op");
+    p->side_mode = mode;
+    return CFX_OK;
+}
+
+int cfx_plan_use_exchange_stream(cfx_plan* p, void* stream) {
+    if (!p || !stream) return CFX_ERR_NULL;
+    if (p->side) return fail(p->ctx, CFX_ERR_BATCH, "plan: the exchange stream must be chosen before the first exchange op");
+    p->side = (hipStream_t)stream;
+    p->side_owned = false;
+    p->side_mode = 1;
+    return CFX_OK;
+}
+
+void cfx_plan_destroy(cfx_plan* p) {
+    if (!p) return;
+    for (int i = 0; i < p->n; ++i) {
+        if (p->ops[i].ev_pre) (void)hipEventDestroy(p->ops[i].ev_pre);
+        if (p->ops[i].ev_done) (void)hipEventDestroy(p->ops[i].ev_done);
+    }
+    if (p->side && p->side_owned) (void)hipStreamDestroy(p->side);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    if (p->pipe_ws) (void)hipFree(p->pipe_ws);
+    sched_free(p->sched);
+    delete[] p->ops;
+    delete p;
+}
+
+static PlanOp* plan_push(cfx_plan* p) {
+    if (p->n == p->cap) {
+        const int ncap = p->cap ? p->cap * 2 : 64;
+        PlanOp* no = new PlanOp[ncap];
+        if (p->n) memcpy(no, p->ops, sizeof(PlanOp) * p->n);
+        delete[] p->ops;
+        p->ops = no;
+        p->cap = ncap;
+    }
+    return &p->ops[p->n++];
+}
+
+int cfx_plan_add_compress_gated(cfx_plan* p, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                                int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
+                                void* workspace, size_t workspace_bytes) {
+    if (!p) return CFX_ERR_NULL;
+    if (n_gated < 0 || n_gated > CFX_MAX_BATCH || (n_gated && !gated)) return fail(p->ctx, CFX_ERR_BATCH, "plan: gated batch out of range");
+    if (n_gated && codec != CFX_CODEC_BINARY && codec != CFX_CODEC_INT2)
+        return fail(p->ctx, CFX_ERR_CODEC, "plan: gated reconstruction items need the 1-bit or the 2-bit codec");
+    const int op = cfx_plan_add_compress_ex(p, codec, N, C, param, flags, batch, items, n_ride, ride, workspace, workspace_bytes);
+    if (op < 0) return op;
+    p->ops[op].n_gated = n_gated;
+    if (n_gated) memcpy(p->ops[op].g, gated, sizeof(cfx_decomp_item) * n_gated);
+    return op;
+}
+
+int cfx_plan_add_compress_ex(cfx_plan* p, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                             int n_ride, const cfx_decomp_item* ride, void* workspace, size_t workspace_bytes) {
+    if (!p || !items) return CFX_ERR_NULL;
+    if (batch < 1 || batch > CFX_MAX_BATCH) return fail(p->ctx, CFX_ERR_BATCH, "plan: batch out of range");
+    if (n_ride < 0 || n_ride > CFX_MAX_BATCH || (n_ride && !ride)) return fail(p->ctx, CFX_ERR_BATCH, "plan: ride-along batch out of range");
+    if (n_ride && codec != CFX_CODEC_BINARY) return fail(p->ctx, CFX_ERR_CODEC, "plan: ride-along reconstruction items need the 1-bit codec");
+    if (!shape_ok(codec, N, C, param)) return fail(p->ctx, CFX_ERR_SHAPE, "plan: bad codec/shape");
+    PlanOp* o = plan_push(p);
+    memset(o, 0, sizeof(*o));
+    o->kind = 0; o->codec = codec; o->N = N; o->C = C; o->param = param; o->flags = flags; o->batch = batch;
+    memcpy(o->c, items, sizeof(cfx_comp_item) * batch);
+    o->n_ride = n_ride;
+    if (n_ride) memcpy(o->d, ride, sizeof(cfx_decomp_item) * n_ride);
+    o->ws = workspace; o->ws_bytes = workspace_bytes;
+    return p->n - 1;
+}
+
+int cfx_plan_add_compress(cfx_plan* p, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                          void* workspace, size_t workspace_bytes) {
+    return cfx_plan_add_compress_ex(p, codec, N, C, param, flags, batch, items, 0, nullptr, workspace, workspace_bytes);
+}
+
+int cfx_plan_add_decompress(cfx_plan* p, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items) {
+    if (!p || !items) return CFX_ERR_NULL;
+    if (batch < 1 || batch > CFX_MAX_BATCH) return fail(p->ctx, CFX_ERR_BATCH, "plan: batch out of range");
+    if (!shape_ok(codec, N, C, param)) return fail(p->ctx, CFX_ERR_SHAPE, "plan: bad codec/shape");
+    PlanOp* o = plan_push(p);
+    memset(o, 0, sizeof(*o));
+    o->kind = 1; o->codec = codec; o->N = N; o->C = C; o->param = param; o->batch = batch;
+    memcpy(o->d, items, sizeof(cfx_decomp_item) * batch);
+    return p->n - 1;
+}
+
+int cfx_plan_size(const cfx_plan* p) { return p ? p->n : CFX_ERR_NULL; }
+
+// append a copy of a compress / decompress op of another plan (to build differently ordered schedules from one op set)
+int cfx_plan_copy_op(cfx_plan* dst, const cfx_plan* src, int op) {
+    if (!dst || !src) return CFX_ERR_NULL;
+    if (op < 0 || op >= src->n || src->ops[op].kind > 1) return fail(dst->ctx, CFX_ERR_BATCH, "plan: op to copy must be a compress/decompress op");
+    const PlanOp tmp = src->ops[op];
+    PlanOp* o = plan_push(dst);
+    *o = tmp;
+    o->ev_pre = o->ev_done = nullptr;      // events belong to the op they were created for
+    return dst->n - 1;
+}
+
+static int plan_exchange_stream(cfx_plan* p);
+int cfx_plan_add_all_gather(cfx_plan* p, cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank) {
+    if (!p || !comm || !send || !recv) return CFX_ERR_NULL;
+    const int rs = plan_exchange_stream(p);
+    if (rs != CFX_OK) return rs;
+    PlanOp* o = plan_push(p);
+    memset(o, 0, sizeof(*o));
+    o->kind = 2; o->comm = comm; o->send = send; o->recv = recv; o->bytes_per_rank = bytes_per_rank;
+    if (hipEventCreateWithFlags(&o->ev_pre, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&o->ev_done, hipEventDisableTiming) != hipSuccess)
+        return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot create events");
+    return p->n - 1;
+}
+
+static int plan_exchange_stream(cfx_plan* p) {
+    if (!p->side && p->side_mode != 0) {
+        hipError_t e;
+        if (p->side_mode == 2) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            e = hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, hi);   // a prioritised stream gets its own HW queue
+        } else {
+            e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+        }
+        if (e != hipSuccess) return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot create the exchange stream");
+    }
+    return CFX_OK;
+}
+
+int cfx_plan_add_ring_hop(cfx_plan* p, cfx_comm* comm, const void* send, void* recv, size_t bytes) {
+    if (!p || !comm || !send || !recv) return CFX_ERR_NULL;
+    const int rs = plan_exchange_stream(p);
+    if (rs != CFX_OK) return rs;
+    PlanOp* o = plan_push(p);
+    memset(o, 0, sizeof(*o));
+    o->kind = 4; o->comm = comm; o->send = send; o->recv = recv; o->bytes_per_rank = bytes;
+    if (hipEventCreateWithFlags(&o->ev_pre, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&o->ev_done, hipEventDisableTiming) != hipSuccess)
+        return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot create events");
+    return p->n - 1;
+}
+
+int cfx_plan_set_input(cfx_plan* p, int op, int item, const void* x) {
+    if (!p || !x) return CFX_ERR_NULL;
+    if (op < 0 || op >= p->n || p->ops[op].kind != 0 || item < 0 || item >= p->ops[op].batch)
+        return fail(p->ctx, CFX_ERR_BATCH, "plan: set_input needs a compress op and an item of its batch");
+    if (!AL16(x)) return fail(p->ctx, CFX_ERR_ALIGN, "plan: pointers must be 16-byte aligned");
+    p->ops[op].c[item].x = x;
+    return CFX_OK;
+}
+
+// cfx_plan_run with the activations of the range's FIRST compress op re-pointed first (one host call per layer phase)
+int cfx_plan_run_x(cfx_plan* p, int first_op, int n_ops, const void* const* xs, int n_xs, void* stream) {
+    if (!p) return CFX_ERR_NULL;
+    if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
+    if (n_xs > 0) {
+        if (!xs) return CFX_ERR_NULL;
+        int op = first_op;
+        while (op < first_op + n_ops && p->ops[op].kind != 0) ++op;
+        if (op == first_op + n_ops || p->ops[op].batch != n_xs) return fail(p->ctx, CFX_ERR_BATCH, "plan: run_x needs a compress op with n_xs items in the range");
+        for (int i = 0; i < n_xs; ++i) {
+            if (!xs[i]) return fail(p->ctx, CFX_ERR_NULL, "plan: null activation");
+            if (!AL16(xs[i])) return fail(p->ctx, CFX_ERR_ALIGN, "plan: pointers must be 16-byte aligned");
+            p->ops[op].c[i].x = xs[i];
+        }
+    }
+    return cfx_plan_run(p, first_op, n_ops, stream);
+}
+
+int cfx_plan_add_wait(cfx_plan* p, int gather_op) {
+    if (!p) return CFX_ERR_NULL;
+    if (gather_op < 0 || gather_op >= p->n || (p->ops[gather_op].kind != 2 && p->ops[gather_op].kind != 4))
+        return fail(p->ctx, CFX_ERR_BATCH, "plan: wait target is not an exchange op");
+    PlanOp* o = plan_push(p);
+    memset(o, 0, sizeof(*o));
+    o->kind = 3; o->ref = gather_op;
+    return p->n - 1;
+}
+
+// One hop of the ring relay (reference xfuser/compact/ring.py:193-195: RingComm.send_recv + commit): send `bytes` to rank+1,
+// receive `bytes` from rank-1, as one grouped pair on `s`.
+static int ring_hop(cfx_comm* c, const void* send, void* recv, size_t bytes, hipStream_t s) {
+    if (!c->api.Send || !c->api.Recv || !c->api.GroupStart || !c->api.GroupEnd) return -1;
+    const int nxt = (c->rank + 1) % c->nranks, prv = (c->rank + c->nranks - 1) % c->nranks;
+    int r = c->api.GroupStart();
+    if (r == 0) r = c->api.Send(send, bytes, /*ncclUint8*/ 1, nxt, c->comm, s);
+    if (r == 0) r = c->api.Recv(recv, bytes, 1, prv, c->comm, s);
+    const int e = c->api.GroupEnd();
+    return r ? r : e;
+}
+
+// `inline_exchange`: exchange ops run in order on `stream` itself whatever the plan's exchange-stream mode (cfx_plan_run_async:
+// the whole range already runs on the exchange stream).
+static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, bool inline_exchange) {
+    if (!p) return CFX_ERR_NULL;
+    if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
+    hipStream_t main_s = (hipStream_t)stream;
+    const int side_mode = inline_exchange ? 0 : p->side_mode;
+    for (int i = first_op; i < first_op + n_ops; ++i) {
+        PlanOp* o = &p->ops[i];
+        int rc = CFX_OK;
+        switch (o->kind) {
+            case 0: rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, o->n_ride, o->d, o->n_gated, o->g, o->ws, o->ws_bytes, stream); break;
+            case 1: rc = cfx_decompress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->batch, o->d, stream); break;
+            case 2:
+            case 4: {
+                // exchange stream picks up after everything enqueued so far on the main stream (the packets are complete)
+                hipStream_t xs = side_mode ? p->side : main_s;
+                if (side_mode && (hipEventRecord(o->ev_pre, main_s) != hipSuccess || hipStreamWaitEvent(p->side, o->ev_pre, 0) != hipSuccess))
+                    return fail(p->ctx, CFX_ERR_LAUNCH, "plan: event ordering failed");
+                int r;
+                if (o->kind == 2) r = o->comm->api.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, xs);
+                else r = ring_hop(o->comm, o->send, o->recv, o->bytes_per_rank, xs);
+                if (r != 0) {
+                    char buf[200];
+                    snprintf(buf, sizeof(buf), "%s: %s", o->kind == 2 ? "ncclAllGather" : "ring hop (ncclSend/ncclRecv)",
+                             o->comm->api.GetErrorString ? o->comm->api.GetErrorString(r) : "error");
+                    return fail(p->ctx, CFX_ERR_LAUNCH, buf);
+                }
+                if (side_mode && hipEventRecord(o->ev_done, p->side) != hipSuccess) return fail(p->ctx, CFX_ERR_LAUNCH, "plan: event record failed");
+            } break;
+            case 3:
+                if (side_mode && hipStreamWaitEvent(main_s, p->ops[o->ref].ev_done, 0) != hipSuccess) return fail(p->ctx, CFX_ERR_LAUNCH, "plan: wait failed");
+                break;
+        }
+        if (rc != CFX_OK) return rc;
+    }
+    return CFX_OK;
+}
+
+int cfx_plan_run(cfx_plan* p, int first_op, int n_ops, void* stream) { return plan_run_impl(p, first_op, n_ops, stream, false); }
+
+// The whole op range on the plan's EXCHANGE stream, forked off `main_stream` and joined back later: everything a layer's exchange
+// does - compress, collective, reconstruction - runs beside what the caller enqueues on `main_stream` in between (the local
+// attention block).  cfx_plan_join makes `main_stream` wait for the range.  The activations (xs, see cfx_plan_run_x) must stay
+// alive until the join.
+int cfx_plan_run_async(cfx_plan* p, int first_op, int n_ops, const void* const* xs, int n_xs, void* main_stream) {
+    if (!p) return CFX_ERR_NULL;
+    if (!p->side) return fail(p->ctx, CFX_ERR_BATCH, "plan: run_async needs an exchange stream (cfx_plan_use_exchange_stream, or mode 1 / 2 and an exchange op)");
+    if (!p->ev_fork && (hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess))
+        return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot create events");
+    if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
+    if (n_xs > 0) {
+        if (!xs) return CFX_ERR_NULL;
+        int op = first_op;
+        while (op < first_op + n_ops && p->ops[op].kind != 0) ++op;
+        if (op == first_op + n_ops || p->ops[op].batch != n_xs) return fail(p->ctx, CFX_ERR_BATCH, "plan: run_async needs a compress op with n_xs items in the range");
+        for (int i = 0; i < n_xs; ++i) {
+            if (!xs[i] || !AL16(xs[i])) return fail(p->ctx, CFX_ERR_ALIGN, "plan: activations must be non-null and 16-byte aligned");
+            p->ops[op].c[i].x = xs[i];
+        }
+    }
+    if (hipEventRecord(p->ev_fork, (hipStream_t)main_stream) != hipSuccess || hipStreamWaitEvent(p->side, p->ev_fork, 0) != hipSuccess)
+        return fail(p->ctx, CFX_ERR_LAUNCH, "plan: fork failed");
+    const int rc = plan_run_impl(p, first_op, n_ops, (void*)p->side, true);
+    if (hipEventRecord(p->ev_join, p->side) != hipSuccess) return fail(p->ctx, CFX_ERR_LAUNCH, "plan: join event failed");
+    return rc;
+}
+
+int cfx_plan_join(cfx_plan* p, void* main_stream) {
+    if (!p) return CFX_ERR_NULL;
+    if (!p->ev_join) return fail(p->ctx, CFX_ERR_BATCH, "plan: join without run_async");
+    return hipStreamWaitEvent((hipStream_t)main_stream, p->ev_join, 0) == hipSuccess ? CFX_OK : fail(p->ctx, CFX_ERR_LAUNCH, "plan: join failed");
+}
+
+// Software-pipelined replay of a 1-bit exchange step.  The op range must be a sequence of "groups"
+//     k x compress [BINARY, no cache update]   { all-gather }*   k x decompress [BINARY]            (k >= 1, one shape)
+// i.e. layers whose packets travel in one collective (k = 1: what the ring gather schedule builds; bench.py groups
+// several layers per all-gather: fewer, larger collectives).  Consecutive whole groups are merged into UNITS of up to
+// 7 layers (as many as fit 112 reconstruction items and 16 compress items: < 4 KB of kernel arguments), and the range is
+// replayed on ONE stream as
+// launch slots t = 0 .. U+1:
+//     { all-gathers of unit t-2 }  ;  K_t = [dequant(unit t-2) | finalize(unit t-1) | stats(unit t)]
+// where K_t is ONE k_binary_pipe launch: the latency-bound stats / finalize work of later layers runs underneath the
+// bandwidth-bound reconstruction of earlier ones, and a launch is long enough (7 layers = ~0.9 GB of traffic) to
+// amortise its ramp and tail (measured on MI355X, FLUX step: 1.82 ms in order, 1.35 ms one layer per launch, see
+// DESIGN.md section 3 for the unit size; a two-stream version of the same idea loses to the ~10 us cross-stream event hops
+// and to the slowdown of the small kernels under contention).  Results are bit-identical to cfx_plan_run (same device
+// code per group of workgroups).  The statistics workspaces are plan-owned (two, alternating by unit); the ops' own
+// workspaces are not used here.  A group too large for one unit, or any other op sequence, is replayed by cfx_plan_run.
+// Recognise the group pattern of ops [first_op, first_op + n_ops), merging whole groups into units, and size the plan-owned
+// statistics workspaces.  Everything that allocates or reads the environment happens HERE, once.
+static int plan_build_sched(cfx_plan* p, int first_op, int n_ops) {
+    sched_free(p->sched);
+    p->sched = nullptr;
+    const int end = first_op + n_ops;
+    const int cap = n_ops > 0 ? n_ops : 1;
+    PipeSched* sc = new PipeSched();
+    sc->first_op = first_op; sc->n_ops = n_ops; sc->n_plan_ops = p->n;
+    sc->comp_op = new int[cap]; sc->deq_op = new int[cap]; sc->ag_op = new int[cap]; sc->ag_unit = new int[cap];
+    sc->units = new PipeUnit[cap];
+    int* comp_op = sc->comp_op; int* deq_op = sc->deq_op; int* ag_op = sc->ag_op; int* ag_unit = sc->ag_unit;
+    PipeUnit* units = sc->units;
+    const char* ue = getenv("CFX_PIPE_UNIT_LAYERS");
+    int unit_layers = ue ? atoi(ue) : 7;
+    if (unit_layers < 1) unit_layers = 1;
+    int L = 0, n_ag = 0, N = 0, C = 0, U = 0;
+    bool ok = n_ops > 0;
+    for (int i = first_op; ok && i < end;) {
+        int k = 0, ncomp = 0, ndq = 0;
+        const int ag0 = n_ag;
+        while (i < end && p->ops[i].kind == 0) {
+            const PlanOp* c = &p->ops[i];
+            if (c->codec != CFX_CODEC_BINARY || (c->flags & CFX_FLAG_UPDATE_CACHE) || c->n_ride || c->n_gated) { ok = false; break; }
+            if (L + k == 0) { N = c->N; C = c->C; }
+            if (c->N != N || c->C != C) { ok = false; break; }
+            ncomp += c->batch;
+            comp_op[L + k++] = i++;
+        }
+        if (!ok || k == 0) { ok = false; break; }
+        while (i < end && (p->ops[i].kind == 2 || p->ops[i].kind == 3)) {
+            if (p->ops[i].kind == 2) ag_op[n_ag++] = i;
+            ++i;
+        }
+        if (i < end && p->ops[i].kind == 4) { ok = false; break; }          // relay hops: in-order replay only
+        for (int m = 0; m < k; ++m, ++i) {
+            if (i >= end || p->ops[i].kind != 1 || p->ops[i].codec != CFX_CODEC_BINARY || p->ops[i].N != N || p->ops[i].C != C) { ok = false; break; }
+            ndq += p->ops[i].batch;
+            deq_op[L + m] = i;
+        }
+        if (!ok) break;
+        if (ncomp > CFX_MAX_BATCH || ndq > PIPE_MAX_DQ) { ok = false; break; }      // a group must fit one launch
+        // extend the current unit with this group if it still fits, else start a new unit
+        if (U > 0 && units[U - 1].n_layers + k <= unit_layers && units[U - 1].n_comp_items + ncomp <= CFX_MAX_BATCH &&
+            units[U - 1].n_dq_items + ndq <= PIPE_MAX_DQ) {
+            units[U - 1].n_layers += k; units[U - 1].n_comp_items += ncomp; units[U - 1].n_dq_items += ndq;
+        } else {
+            units[U].first_layer = L; units[U].n_layers = k; units[U].n_comp_items = ncomp; units[U].n_dq_items = ndq;
+            ++U;
+        }
+        for (int a = ag0; a < n_ag; ++a) ag_unit[a] = U - 1;
+        L += k;
+    }
+    sc->ok = ok; sc->L = L; sc->n_ag = n_ag; sc->N = N; sc->C = C; sc->U = U;
+    p->sched = sc;
+    if (!ok) return CFX_OK;
+    const size_t need = 2 * (size_t)CFX_MAX_BATCH * ws_words(CFX_CODEC_BINARY, N, C) * sizeof(u64);
+    if (need > p->pipe_ws_bytes) {
+        if (p->pipe_ws) (void)hipFree(p->pipe_ws);
+        p->pipe_ws = nullptr; p->pipe_ws_bytes = 0;
+        if (hipMalloc(&p->pipe_ws, need) != hipSuccess) { (void)hipGetLastError(); return fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot allocate the statistics workspaces"); }
+        p->pipe_ws_bytes = need;
+    }
+    return CFX_OK;
+}
+
+int cfx_plan_finalize(cfx_plan* p) {
+    if (!p) return CFX_ERR_NULL;
+    if (cfx_prepare(p->ctx) != CFX_OK) return CFX_ERR_LAUNCH;      // ticket blocks of the in-order compress launches
+    return plan_build_sched(p, 0, p->n);
+}
+
+int cfx_plan_run_pipelined(cfx_plan* p, int first_op, int n_ops, void* stream) {
+    if (!p) return CFX_ERR_NULL;
+    if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
+    if (!p->sched || p->sched->first_op != first_op || p->sched->n_ops != n_ops || p->sched->n_plan_ops != p->n) {
+        const int rcb = plan_build_sched(p, first_op, n_ops);     // first replay of this range (or the plan grew): build once
+        if (rcb != CFX_OK) return rcb;
+    }
+    const PipeSched* sc = p->sched;
+    if (!sc->ok) return cfx_plan_run(p, first_op, n_ops, stream);
+    const int *comp_op = sc->comp_op, *deq_op = sc->deq_op, *ag_op = sc->ag_op, *ag_unit = sc->ag_unit;
+    const PipeUnit* units = sc->units;
+    const int n_ag = sc->n_ag, N = sc->N, C = sc->C, U = sc->U;
+    hipStream_t s = (hipStream_t)stream;
+    auto unit = [&](int u) -> const PipeUnit* { return (u >= 0 && u < U) ? &units[u] : nullptr; };
+    // Exchange stream mode 0: collectives in order on `stream`, right before the launch that consumes them.
+    // Modes 1 / 2: one more unit of look-ahead; the collectives of unit u are issued on the exchange stream as soon as
+    // the launch holding finalize(u) is queued and run UNDERNEATH the next launch; `stream` waits for them (an event that
+    // has normally fired long before) only in front of the launch that reconstructs unit u.
+    const int d = (p->side_mode != 0 && p->side && n_ag > 0) ? 1 : 0;
+    auto all_gather = [&](const PlanOp* o, hipStream_t on) -> int {
+        if (o->comm->api.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, on) != 0)
+            return fail(p->ctx, CFX_ERR_LAUNCH, "ncclAllGather failed");
+        return CFX_OK;
+    };
+    int rc = CFX_OK, next_ag = 0, next_wait = 0;
+    for (int t = 0; rc == CFX_OK && t <= U + 1 + d; ++t) {
+        if (d == 0) {
+            while (rc == CFX_OK && next_ag < n_ag && ag_unit[next_ag] + 2 <= t) rc = all_gather(&p->ops[ag_op[next_ag++]], s);
+        } else {
+            while (rc == CFX_OK && next_wait < n_ag && ag_unit[next_wait] + 3 <= t) {
+                if (hipStreamWaitEvent(s, p->ops[ag_op[next_wait++]].ev_done, 0) != hipSuccess) rc = fail(p->ctx, CFX_ERR_LAUNCH, "plan: wait failed");
+            }
+        }
+        if (rc != CFX_OK) break;
+        // overlapped mode: the collectives of unit t-1 may start when THIS launch (which holds finalize(t-1)) has finished;
+        // the first of them lends its event to the launch
+        hipEvent_t done_ev = nullptr;
+        if (d == 1 && next_ag < n_ag && ag_unit[next_ag] + 1 <= t) done_ev = p->ops[ag_op[next_ag]].ev_pre;
+        bool launched = false;
+        if (unit(t - 2 - d) || unit(t - 1) || unit(t)) {
+            rc = launch_pipe(p, s, N, C, comp_op, deq_op, unit(t - 2 - d), unit(t - 1), unit(t), (t - 1) & 1, t & 1, done_ev);
+            launched = true;
+        }
+        if (d == 1 && rc == CFX_OK && done_ev) {
+            if ((!launched && hipEventRecord(done_ev, s) != hipSuccess) || hipStreamWaitEvent(p->side, done_ev, 0) != hipSuccess)
+                rc = fail(p->ctx, CFX_ERR_LAUNCH, "plan: event ordering failed");
+            while (rc == CFX_OK && next_ag < n_ag && ag_unit[next_ag] + 1 <= t) {
+                PlanOp* o = &p->ops[ag_op[next_ag++]];
+                rc = all_gather(o, p->side);
+                if (rc == CFX_OK && hipEventRecord(o->ev_done, p->side) != hipSuccess) rc = fail(p->ctx, CFX_ERR_LAUNCH, "plan: event record failed");
+            }
+        }
+    }
+    return rc;
+}
+
+// ---- communicator -----------------------------------------------------------------------------------------------------
+int cfx_rccl_load(const char* path) {
+    if (g_rccl.handle && (!path || !path[0] || !strcmp(path, g_rccl.path))) return CFX_OK;    // already loaded (same library)
+    void* h = nullptr;
+    if (path && path[0]) h = dlopen(path, RTLD_NOW | RTLD_NOLOAD);
+    if (!h && path && path[0]) h = dlopen(path, RTLD_NOW);
+    const char* names[] = {"librccl.so", "librccl.so.1"};
+    for (int i = 0; i < 2 && !h && !(path && path[0]); ++i) h = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
+    for (int i = 0; i < 2 && !h && !(path && path[0]); ++i) h = dlopen(names[i], RTLD_NOW);
+    if (!h) return CFX_ERR_NULL;
+    RcclApi a = {};
+    a.GetUniqueId = (int (*)(cfx_nccl_uid*))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (int (*)(cfx_nccl_comm*, int, cfx_nccl_uid, int))dlsym(h, "ncclCommInitRank");
+    a.AllGather = (int (*)(const void*, void*, size_t, int, cfx_nccl_comm, hipStream_t))dlsym(h, "ncclAllGather");
+    a.CommDestroy = (int (*)(cfx_nccl_comm))dlsym(h, "ncclCommDestroy");
+    a.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    a.Send = (int (*)(const void*, size_t, int, int, cfx_nccl_comm, hipStream_t))dlsym(h, "ncclSend");
+    a.Recv = (int (*)(void*, size_t, int, int, cfx_nccl_comm, hipStream_t))dlsym(h, "ncclRecv");
+    a.GroupStart = (int (*)(void))dlsym(h, "ncclGroupStart");
+    a.GroupEnd = (int (*)(void))dlsym(h, "ncclGroupEnd");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy) return CFX_ERR_NULL;
+    a.handle = h;
+    snprintf(a.path, sizeof(a.path), "%s", (path && path[0]) ? path : "");
+    g_rccl = a;          // communicators created from now on use this library; existing ones keep the table they were made with
+    return CFX_OK;
+}
+
+int cfx_comm_unique_id(cfx_ctx* ctx, void* out128) {
+    if (!ctx || !out128) return CFX_ERR_NULL;
+    if (!g_rccl.handle) return fail(ctx, CFX_ERR_NULL, "RCCL not loaded: call cfx_rccl_load first");
+    cfx_nccl_uid id;
+    const int r = g_rccl.GetUniqueId(&id);
+    if (r != 0) return fail(ctx, CFX_ERR_LAUNCH, "ncclGetUniqueId failed");
+    memcpy(out128, &id, 128);
+    return CFX_OK;
+}
+
+cfx_comm* cfx_comm_create(cfx_ctx* ctx, const void* id128, int nranks, int rank) {
+    if (!ctx || !id128 || !g_rccl.handle) return nullptr;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != ctx->device) (void)hipSetDevice(ctx->device);       // ncclCommInitRank binds the communicator to the current device
+    cfx_nccl_uid id;
+    memcpy(&id, id128, 128);
+    cfx_comm* c = new cfx_comm();
+    c->ctx = ctx; c->nranks = nranks; c->rank = rank; c->comm = nullptr;
+    c->api = g_rccl;
+    const int r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (cur >= 0 && cur != ctx->device) (void)hipSetDevice(cur);   // the caller's current device is left as it was
+    if (r != 0) {
+        char buf[200];
+        snprintf(buf, sizeof(buf), "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
+        fail(ctx, CFX_ERR_LAUNCH, buf);
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void cfx_comm_destroy(cfx_comm* c) {
+    if (!c) return;
+    if (c->comm && c->api.CommDestroy) (void)c->api.CommDestroy(c->comm);
+    delete c;
+}
+
+int cfx_comm_all_gather(cfx_comm* c, const void* send, void* recv, size_t bytes_per_rank, void* stream) {
+    if (!c || !send || !recv) return CFX_ERR_NULL;
+    const int r = c->api.AllGather(send, recv, bytes_per_rank, 1, c->comm, (hipStream_t)stream);
+    return r == 0 ? CFX_OK : fail(c->ctx, CFX_ERR_LAUNCH, "ncclAllGather failed");
+}
+
+int cfx_comm_ring_hop(cfx_comm* c, const void* send, void* recv, size_t bytes, void* stream) {
+    if (!c || !send || !recv) return CFX_ERR_NULL;
+    const int r = ring_hop(c, send, recv, bytes, (hipStream_t)stream);
+    return r == 0 ? CFX_OK : fail(c->ctx, CFX_ERR_LAUNCH, "ring hop (ncclSend / ncclRecv) failed");
+}
+
+}  // extern "C"

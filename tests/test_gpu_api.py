@@ -614,13 +614,16 @@ def test_native_comm_single_rank(tmp_path):
             dist.destroy_process_group()
 
 
-def test_native_attention_merge_equals_the_eager_formula():
+@pytest.mark.parametrize("D", [64, 72, 96, 128, 160])
+def test_native_attention_merge_equals_the_eager_formula(D):
     """cfx_attn_merge (one launch per attention block) vs the published update_out_and_lse formula in eager fp32 torch
-    (what the reference gets from yunchang, ring.py:263), on the fused SDPA kernel's own output layouts."""
+    (what the reference gets from yunchang, ring.py:263), on the fused SDPA kernel's own output layouts.  Head dims whose D/8
+    threads do not divide a wave (72: PixArt, 96, 160) are the cases where a row's lse must not be rewritten before every thread of
+    the row has read it."""
     from compactfusion_amd.compact import attention as A
     import torch.nn.functional as F
     g = torch.Generator(device="cuda").manual_seed(3)
-    B, S, H, D = 2, 77, 5, 64
+    B, S, H = 2, 77, 5
     q = torch.randn(B, S, H, D, device="cuda", dtype=torch.float16, generator=g)
     out = lse = ref_o = ref_l = None
     for blk in range(4):
@@ -636,7 +639,7 @@ def test_native_attention_merge_equals_the_eager_formula():
             out, lse = A.update_out_and_lse(out, lse, bo, bl)
         finally:
             A._merge_native = orig
-        assert calls == [0 if blk == 2 else 1], "the native merge launch was not taken"
+        assert len(calls) == 1 and (blk != 2 or calls == [0]), "the native merge launch was not taken"
         bo32, bl4 = bo.to(torch.float32), bl.transpose(-2, -1).unsqueeze(-1)
         if ref_o is None:
             ref_o, ref_l = bo32, bl4
