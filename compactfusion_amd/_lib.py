@@ -12,7 +12,7 @@ CFX_MAX_BATCH = 16
 CFX_OK = 0
 ERR_NAMES = {
     -1: "CFX_ERR_NULL", -2: "CFX_ERR_SHAPE", -3: "CFX_ERR_ALIGN", -4: "CFX_ERR_CODEC",
-    -5: "CFX_ERR_BATCH", -6: "CFX_ERR_LAUNCH", -7: "CFX_ERR_WORKSPACE",
+    -5: "CFX_ERR_BATCH", -6: "CFX_ERR_LAUNCH", -7: "CFX_ERR_WORKSPACE", -8: "CFX_ERR_GATE",
 }
 
 FLAG_UPDATE_CACHE = 1
@@ -100,6 +100,19 @@ SYMBOLS = [
     ("cfx_residual2_update", ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_attn_merge", ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 + [ctypes.c_void_p]),
     ("cfx_copy_probe", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    ("cfx_plan_flags", ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_plan_add_flag_wait", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_plan_add_flag_set", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_plan_epoch", ctypes.c_uint, [ctypes.c_void_p]),
+    ("cfx_plan_run_lane", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]),
+    ("cfx_flag_set", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]),
+    ("cfx_flag_wait", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]),
+    ("cfx_stream_create_masked", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    ("cfx_stream_destroy", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    ("cfx_set_gate_timeout_ms", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_attn_merge_wait", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]),
 ]
 
 _lib = None

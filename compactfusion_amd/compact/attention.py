@@ -40,29 +40,46 @@ def block_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, dropout_p
 
 
 def update_out_and_lse(out: Optional[torch.Tensor], lse: Optional[torch.Tensor], block_out: torch.Tensor,
-                       block_lse: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+                       block_lse: torch.Tensor, wait=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Merge one attention block into the running (out fp32 (B,S,H,D), lse fp32 (B,S,H,1)).  On the GPU this is ONE native
     launch (`cfx_attn_merge`) that reads the SDPA kernel's own (B,H,S,D) / (B,H,S) outputs and updates out / lse in place;
-    elsewhere (CPU tests of the host logic) the same formula in eager torch."""
-    if block_out.is_cuda and block_out.dtype == torch.float16 and block_lse.dtype == torch.float32 and block_out.shape[-1] % 8 == 0:
+    elsewhere (CPU tests of the host logic) the same formula in eager torch.
+    `wait` = (flag device address, epoch): the exchange lane's "next peer reconstructed" flag - the merge launch also waits for
+    it (`cfx_attn_merge_wait`), so the attention block that follows finds the peer's K,V complete without a stream event."""
+    if block_out.is_cuda and block_out.dtype == torch.float16 and block_lse.dtype == torch.float32 and block_out.shape[-1] % 8 == 0 \
+            and block_out.shape[-1] <= 512 and (out is None or (out.is_contiguous() and lse.is_contiguous() and out.dtype == torch.float32)):
         if block_lse.is_contiguous() and block_out.data_ptr() % 16 == 0:
             if block_out.is_contiguous():                  # the fused SDPA output, (B,S,H,D) contiguous underneath
-                return _merge_native(out, lse, block_out, block_lse, 1)
+                return _merge_native(out, lse, block_out, block_lse, 1, wait)
             if block_out.transpose(1, 2).is_contiguous():  # ... or (B,H,S,D)
-                return _merge_native(out, lse, block_out, block_lse, 0)
+                return _merge_native(out, lse, block_out, block_lse, 0, wait)
     block_out = block_out.to(torch.float32)
     block_lse = block_lse.transpose(-2, -1).unsqueeze(-1)
-    if out is None:
-        return block_out, block_lse
-    out = out - torch.sigmoid(block_lse - lse) * (out - block_out)
-    lse = lse - F.logsigmoid(lse - block_lse)
+    if out is not None:
+        out = out - torch.sigmoid(block_lse - lse) * (out - block_out)
+        lse = lse - F.logsigmoid(lse - block_lse)
+    else:
+        out, lse = block_out, block_lse
+    if wait is not None:
+        flag_wait(wait, block_out.device)
     return out, lse
+
+
+def flag_wait(wait, device) -> None:
+    """A stand-alone wait launch on the current stream for (flag address, epoch) - what `update_out_and_lse(wait=...)` folds into
+    its merge launch when it can."""
+    from .. import _lib, codecs
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    ctx = codecs.context(dev)
+    rc = _lib.load().cfx_flag_wait(ctx, wait[0], wait[1], torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        codecs._check(ctx, rc, "cfx_flag_wait")
 
 
 _merge_fn = None
 
 
-def _merge_native(out, lse, bo, bl, bshd):
+def _merge_native(out, lse, bo, bl, bshd, wait=None):
     global _merge_fn
     from .. import _lib, codecs
     B, S, H, D = bo.shape
@@ -71,12 +88,11 @@ def _merge_native(out, lse, bo, bl, bshd):
     if first:
         out = torch.empty((B, S, H, D), dtype=torch.float32, device=bo.device)
         lse = torch.empty((B, S, H, 1), dtype=torch.float32, device=bo.device)
-    elif not (out.is_contiguous() and lse.is_contiguous() and out.dtype == torch.float32):
-        raise ValueError("update_out_and_lse: the running out / lse must be the contiguous fp32 tensors a previous merge returned")
     if _merge_fn is None:
-        _merge_fn = _lib.load().cfx_attn_merge
+        _merge_fn = _lib.load().cfx_attn_merge_wait
     ctx = codecs.context(dev)
     rc = _merge_fn(ctx, out.data_ptr(), lse.data_ptr(), bo.data_ptr(), bl.data_ptr(), B, S, H, D, bshd, 1 if first else 0,
+                   wait[0] if wait is not None else None, wait[1] if wait is not None else 0,
                    torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
         codecs._check(ctx, rc, "cfx_attn_merge")

@@ -192,8 +192,20 @@ class _SteadyLayer:
     def run(self, q, k, v, softmax_scale):
         ex = self.ex
         sh = torch.cuda.current_stream(q.device).cuda_stream
+        if ex.lane:
+            # exchange lane: ONE native call issues the layer's whole chain on the exchange stream; the compute stream never sees
+            # an event - the merge launch of block s also waits (in-kernel, on a flag) for peer s+1's reconstruction
+            epoch = ex.run_lane(k, v, sh)
+            cm._current_cache_key = self.last_key
+            bo, bl = block_attention(q, k, v, 0.0, softmax_scale, causal=False)
+            out, lse = update_out_and_lse(None, None, bo, bl, wait=(ex.flag_ptr(1), epoch))
+            last = self.world - 1
+            for s, (kk, vv) in enumerate(ex.peer_views, start=1):
+                bo, bl = block_attention(q, kk, vv, 0.0, softmax_scale, causal=False)
+                out, lse = update_out_and_lse(out, lse, bo, bl, wait=None if s == last else (ex.flag_ptr(s + 1), epoch))
+            return out.to(q.dtype), lse.squeeze(dim=-1).transpose(1, 2), None
         ex.run_front(k, v, sh)
-        if not self.flags[0]:                                  # no error feedback: the state becomes the activation (main.py:240-243)
+        if not self.flags[0] and not ex.plan_updates_state:    # no error feedback: the state becomes the activation (main.py:240-243)
             cache = compact_cache()
             cache.put(self.kk, k.view(self.N, self.C), None)
             cache.put(self.vk, v.view(self.N, self.C), None)
@@ -223,6 +235,8 @@ class _LayerExchange:
     def __init__(self, mod_idx, rank: int, world: int, slot: int, like: torch.Tensor, group=None):
         self.slot, self.world, self.rank, self.group = slot, world, rank, group
         self.plan = None             # native per-layer plan: compress, all-gather on the exchange stream | wait, reconstruct
+        self.lane = False            # plan built for the flag-synchronised exchange lane (cfx_plan_run_lane)
+        self.plan_updates_state = False   # error feedback off: the plan itself copies the activation into the state, in stream order
         self._lib = None
         self.send = torch.empty(2 * slot, dtype=torch.float16, device=like.device)
         self.recv = torch.empty(world * 2 * slot, dtype=torch.float16, device=like.device)
@@ -286,6 +300,8 @@ class _LayerExchange:
         communicator (the reference drives torch.distributed P2P per hop, ring.py:193-195,265-269; through torch.distributed
         the per-layer all-gather costs ~50 us of host time, more than the GPU work it overlaps)."""
         self._drop_plan()
+        self.lane = False
+        self.plan_updates_state = False
         mode = os.environ.get("CFX_RING_EXCHANGE", "auto")
         if mode == "torch" or not self.send.is_cuda or cid >= 100:
             return
@@ -301,23 +317,59 @@ class _LayerExchange:
         ctx = codecs.context(dev)
         plan = lib.cfx_plan_create(ctx)
         # ONE exchange stream per device, shared by every layer's plan (a stream per plan would be a hardware queue per layer)
-        xmode = os.environ.get("CFX_RING_EXCHANGE_STREAM", "chain")     # chain | side | main
+        xmode = os.environ.get("CFX_RING_EXCHANGE_STREAM", "lane")     # lane | chain | side | main
+        assert xmode in ("lane", "chain", "side", "main"), "CFX_RING_EXCHANGE_STREAM must be lane | chain | side | main"
         self._async = xmode == "chain"
+        self.lane = xmode == "lane"
+        xs_handle = None
         if xmode == "main":
             assert lib.cfx_plan_set_exchange_stream(plan, 0) == 0
         else:
-            assert lib.cfx_plan_use_exchange_stream(plan, _exchange_stream(self.send.device).cuda_stream) == 0
-        ws = codecs.workspace(cid, N, C, param, 2, dev)
+            from .. import lanes
+            # the CU-masked exchange stream when the model runs on the lane's compute stream (disjoint CU sets), else an unmasked one
+            xstream = lanes.exchange_stream(dev) if (self.lane and lanes.on_compute_stream(dev)) else _exchange_stream(self.send.device)
+            xs_handle = xstream.cuda_stream
+            assert lib.cfx_plan_use_exchange_stream(plan, xs_handle) == 0
+        # the compress launches run on the exchange stream in the lane / chain modes: their statistics workspace belongs to THAT stream
+        ws = codecs.workspace(cid, N, C, param, 2, dev, stream_handle=xs_handle if (self.lane or self._async) else None)
         self._plan_keep = (ws, list(own), list(own_pkts), list(bases), list(pkts), comm)
-        c = (_lib.CompItem * 2)(*[_lib.CompItem(own[i].data_ptr(), own[i].data_ptr(), None, own_pkts[i].data_ptr()) for i in range(2)])
-        flags = 0 if ef else _lib.FLAG_NO_EF
-        ok = lib.cfx_plan_add_compress(plan, cid, N, C, param, flags, 2, c, None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel()) == 0
-        g0 = lib.cfx_plan_add_all_gather(plan, comm.handle, self.send.data_ptr(), self.recv.data_ptr(), 2 * self.slot * 2)
-        ok = ok and g0 == 1 and lib.cfx_plan_add_wait(plan, g0) == 2
+        # error feedback off: the state becomes the activation (main.py:240-243) - done by the compress op itself, in stream order
+        # behind the statistics pass that reads the old state (a copy issued from Python on another stream would race with it)
+        self.plan_updates_state = not ef
+        flags = 0 if ef else (_lib.FLAG_NO_EF | _lib.FLAG_UPDATE_CACHE)
+        c = (_lib.CompItem * 2)(*[_lib.CompItem(own[i].data_ptr(), own[i].data_ptr(), None if ef else own[i].data_ptr(), own_pkts[i].data_ptr())
+                                  for i in range(2)])
+        wsp, wsn = (None, 0) if ws is None else (ws.data_ptr(), ws.numel())
         step = codecs.CFX_MAX_BATCH
-        for i in range(0, len(bases), step):
-            items = [_lib.DecompItem(p_.data_ptr(), b_.data_ptr(), b_.data_ptr()) for p_, b_ in zip(pkts[i:i + step], bases[i:i + step])]
-            ok = ok and lib.cfx_plan_add_decompress(plan, cid, N, C, param, len(items), (_lib.DecompItem * len(items))(*items)) >= 0
+
+        def dec_items(lo, hi):
+            return [_lib.DecompItem(p_.data_ptr(), b_.data_ptr(), b_.data_ptr()) for p_, b_ in zip(pkts[lo:hi], bases[lo:hi])]
+        if self.lane:
+            # flags: 0 = the activations exist (set on the compute stream), s = 1..W-1 = peer of ring step s reconstructed, W = chain done
+            W = self.world
+            self._flags = lib.cfx_plan_flags(plan, W + 1)
+            ok = bool(self._flags)
+            ok = ok and lib.cfx_plan_add_flag_wait(plan, 0) == 0
+            ok = ok and lib.cfx_plan_add_compress(plan, cid, N, C, param, flags, 2, c, wsp, wsn) == 1
+            ok = ok and lib.cfx_plan_add_all_gather(plan, comm.handle, self.send.data_ptr(), self.recv.data_ptr(), 2 * self.slot * 2) == 2
+            n_own = 2 if ef else 0                 # bases / pkts start with the rank's own K,V when error feedback is on
+            for s_ in range(1, W):                 # just in time: peer s's K,V, then its flag, in the order the attention blocks visit them
+                lo = n_own + 2 * (s_ - 1)
+                it = dec_items(lo, lo + 2)
+                ok = ok and lib.cfx_plan_add_decompress(plan, cid, N, C, param, 2, (_lib.DecompItem * 2)(*it)) >= 0
+                ok = ok and lib.cfx_plan_add_flag_set(plan, s_) >= 0
+            if ef:                                 # the rank's own error-feedback update: nobody waits for it before the next step
+                it = dec_items(0, 2)
+                ok = ok and lib.cfx_plan_add_decompress(plan, cid, N, C, param, 2, (_lib.DecompItem * 2)(*it)) >= 0
+            ok = ok and lib.cfx_plan_add_flag_set(plan, W) >= 0
+            self._epoch = ctypes.c_uint(0)
+        else:
+            ok = lib.cfx_plan_add_compress(plan, cid, N, C, param, flags, 2, c, wsp, wsn) == 0
+            g0 = lib.cfx_plan_add_all_gather(plan, comm.handle, self.send.data_ptr(), self.recv.data_ptr(), 2 * self.slot * 2)
+            ok = ok and g0 == 1 and lib.cfx_plan_add_wait(plan, g0) == 2
+            for i in range(0, len(bases), step):
+                items = dec_items(i, i + step)
+                ok = ok and lib.cfx_plan_add_decompress(plan, cid, N, C, param, len(items), (_lib.DecompItem * len(items))(*items)) >= 0
         ok = ok and lib.cfx_plan_finalize(plan) == 0
         if not ok:
             lib.cfx_plan_destroy(plan)
@@ -326,7 +378,21 @@ class _LayerExchange:
         self._n_ops = lib.cfx_plan_size(plan)
         self._xs = (ctypes.c_void_p * 2)()
 
+    def flag_ptr(self, i: int) -> int:
+        return self._flags + 64 * i
+
+    def run_lane(self, k, v, sh) -> int:
+        """The layer's whole chain on the exchange lane, one host call; returns the epoch its flags will carry."""
+        self._xs[0], self._xs[1] = k.data_ptr(), v.data_ptr()
+        rc = self._lib.cfx_plan_run_lane(self.plan, 0, self._n_ops, self._xs, 2, 0, sh, self._epoch)
+        if rc != 0:
+            raise RuntimeError("native exchange lane failed: " + (self._lib.cfx_last_error_string(self._ctx) or b"").decode())
+        return self._epoch.value
+
     def run_front(self, k, v, sh):
+        if self.lane:
+            self._last_epoch = self.run_lane(k, v, sh)
+            return
         self._xs[0], self._xs[1] = k.data_ptr(), v.data_ptr()
         if self._async:
             # the whole chain - compress, all-gather, reconstruction - on the exchange stream, beside the local attention block
@@ -337,6 +403,11 @@ class _LayerExchange:
             raise RuntimeError("native exchange (compress + all-gather) failed: " + (self._lib.cfx_last_error_string(self._ctx) or b"").decode())
 
     def run_back(self, sh):
+        if self.lane:
+            # general path: one wait for the whole chain (the steady-state lane waits per peer, inside the merge launches)
+            from .attention import flag_wait
+            flag_wait((self.flag_ptr(self.world), self._last_epoch), self.send.device)
+            return
         if self._async:
             rc = self._lib.cfx_plan_join(self.plan, sh)
         else:
@@ -386,7 +457,7 @@ def _gather_schedule(q, k, v, ctype, mod_idx, rank, world, group, kkey, vkey, at
                 ex.run_front(k, v, sh)         # compress K,V + the all-gather on the exchange stream: one host call
             else:
                 ex.comp((k, v), sh)
-        if not cfg.error_feedback:
+        if not cfg.error_feedback and not (native_x and ex.plan_updates_state):
             cache.put(ex.kkeys[rank], k.view(N, C), None)
             cache.put(ex.vkeys[rank], v.view(N, C), None)
         cm._current_cache_key = ex.vkeys[rank]

@@ -27,6 +27,7 @@ static const char* const kid_names[KID_MAX] = {
     "gated layer launch (k_absmean_compress<bits,gated> / k_int2_compress_gated)"};
 
 struct ProfRec { int kid; hipEvent_t a, b; };
+#define CFX_RING_STREAMS 4       // ticket / gate rings of a context: one per stream that issues compress launches
 
 struct cfx_ctx {
     int device;
@@ -39,12 +40,16 @@ struct cfx_ctx {
     unsigned prof_mask;
     // in-launch finalize: ticket blocks (device memory, zeroed once, self-resetting) handed out round-robin, one per launch
     unsigned* tick;
-    unsigned tick_next;
+    unsigned tick_next[CFX_RING_STREAMS];
+    void* ring_stream[CFX_RING_STREAMS];   // the stream each ring serves
+    int n_ring_streams;
+    int ring_cus[CFX_RING_STREAMS];        // CUs the stream's queue may use (CU-masked streams: fewer than the device has)
     // gated reconstruction: one monotonic arrival counter per ticket-ring slot (64 B apart, after the ticket blocks), the value
     // at which the slot's next launch opens, and one error word (a gate that never opened)
     unsigned* gate;
-    unsigned gate_expect[2 * 256];  // two gates per slot (the 2-bit layer launch has two)
-    unsigned* gate_err;
+    unsigned gate_expect[2 * 256 * CFX_RING_STREAMS];  // two gates per slot (the 2-bit layer launch has two)
+    unsigned* gate_err;             // pinned HOST word (device-visible): waits that timed out since the last cfx_gate_errors
+    long long gate_timeout;         // ticks of the 100 MHz wall clock a flag wait may last
     int fused;                      // 1 (default): compress = statistics + in-launch finalize; 0: separate finalize kernel
     void* dbg_stamps;               // developer hook (cfx_debug_stamps)
     int stats_rows;                 // CFX_STATS_ROWS override of the statistics tile height (experiments), 0 = automatic
@@ -126,7 +131,8 @@ struct cfx_comm {
 };
 
 struct PlanOp {
-    int kind;   // 0 compress, 1 decompress, 2 all-gather on the side stream, 3 main stream waits for gather op `ref`
+    int kind;   // 0 compress, 1 decompress, 2 all-gather on the side stream, 3 main stream waits for gather op `ref`, 4 ring hop,
+                // 5 wait until flag `ref` has reached the plan's epoch, 6 set flag `ref` to the epoch
     int codec, N, C, param, flags, batch;
     cfx_comp_item c[CFX_MAX_BATCH];
     cfx_decomp_item d[CFX_MAX_BATCH];     // kind 1: the items; kind 0: ride-along reconstruction items (n_ride of them)
@@ -155,6 +161,9 @@ struct cfx_plan {
     void* pipe_ws;        // cfx_plan_run_pipelined: two statistics workspaces of CFX_MAX_BATCH tensors each (stats of unit
     size_t pipe_ws_bytes; //   t runs beside the finalize of unit t-1)
     PipeSched* sched;          // unit schedule of the pipelined replay, built once (cfx_plan_finalize or the first replay of a range)
+    unsigned* flags;      // exchange lane: n_flags flag words, a 64-byte line each (cfx_plan_flags)
+    int n_flags;
+    unsigned epoch;       // value the lane's flags take in the current replay (cfx_plan_run_lane advances it)
 };
 
 

@@ -127,6 +127,21 @@ __device__ __forceinline__ void st16_wt(void* p, u32x4 v) {
 // (__syncthreads() also drains vmcnt: behind write-through stores that is a fabric round trip, ~1 us, per barrier).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// A failed wait (bounded spin) is counted in the context's error word, which lives in pinned HOST memory: the next native call
+// on the context reports it without a device synchronisation (cfx_gate_errors, CFX_ERR_GATE).
+__device__ __forceinline__ void gate_fail(unsigned* err) {
+    if (err) (void)__hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// One lane waits until *flag has reached `value` (monotonic epochs: signed distance), polling with L1-bypassing loads; gives
+// up after `timeout` ticks of the 100 MHz wall clock.
+__device__ __forceinline__ void flag_spin(const unsigned* flag, unsigned value, unsigned* err, long long timeout) {
+    const long long t0 = wall_clock64();
+    while ((int)(ld_wt(flag) - value) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > timeout) { gate_fail(err); break; }
+    }
+}
+
 // Partial sums that another workgroup of the same launch reduces (WT paths) travel as 32-bit words: a last arriver pulls fresh
 // cross-CU data at only ~65 GB/s, and for real activations every partial fits (a tile's sum of |d| would have to reach 256).
 // A sum that does not fit leaves the sentinel in the 32-bit word and the exact value in the 64-bit array the non-fused kernels
@@ -508,7 +523,7 @@ __device__ __forceinline__ void gate_wait(unsigned* gate, unsigned expect, unsig
         if (relay) {
             while (ld_wt(open) != expect) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++n > GATE_SPIN_LIMIT) { st_wt(err, 1u); break; }
+                if (++n > GATE_SPIN_LIMIT) { gate_fail(err); break; }
             }
             *(volatile unsigned*)local = expect;
         } else {
@@ -516,7 +531,7 @@ __device__ __forceinline__ void gate_wait(unsigned* gate, unsigned expect, unsig
                 if (GATE_LOCAL_SLEEP) __builtin_amdgcn_s_sleep(GATE_LOCAL_SLEEP);
                 ++n;
                 if ((n & (FEW ? 255u : 15u)) == 0 && ld_wt(open) == expect) break;
-                if (n > GATE_SPIN_LIMIT) { st_wt(err, 1u); break; }
+                if (n > GATE_SPIN_LIMIT) { gate_fail(err); break; }
             }
         }
     }
@@ -909,7 +924,7 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
                 unsigned n = 0;
                 while (ld_wt(tick + TICK_ALL) != (unsigned)(CB * P)) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++n > GATE_SPIN_LIMIT) { if (err) st_wt(err, 1u); break; }
+                    if (++n > GATE_SPIN_LIMIT) { gate_fail(err); break; }
                 }
             }
             __syncthreads();
@@ -1728,9 +1743,9 @@ __global__ __launch_bounds__(256) void k_residual2_update(const h16* base, const
 // read lse[row] and one of them rewrites it in place, so a row's threads must sit in ONE wave (its load instruction then
 // precedes its store instruction for every lane): a row takes G = the power of two >= D/8 lanes (G <= 64), lanes d8 >= D/8 idle.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_attn_merge(float* __restrict__ out, float* __restrict__ lse, const h16* __restrict__ bo,
-                                                    const float* __restrict__ bl, int B, int S, int H, int D, int first,
-                                                    size_t bo_sb, size_t bo_ss, size_t bo_sh, int lg) {
+__device__ __forceinline__ void attn_merge_body(float* __restrict__ out, float* __restrict__ lse, const h16* __restrict__ bo,
+                                                const float* __restrict__ bl, int B, int S, int H, int D, int first,
+                                                size_t bo_sb, size_t bo_ss, size_t bo_sh, int lg) {
     const int D8 = D >> 3;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t rows = (size_t)B * S * H;
@@ -1764,6 +1779,17 @@ __global__ __launch_bounds__(256) void k_attn_merge(float* __restrict__ out, flo
     op[0] = a; op[1] = c;
     // logsigmoid(-x) = -softplus(x) = -(max(x,0) + log1p(exp(-|x|)));  lse - logsigmoid(lse - lse_b) = lse + softplus(x)
     if (d8 == 0) lse[l_idx] = l + (fmaxf(x, 0.0f) + log1pf(__expf(-fabsf(x))));
+}
+
+// wflag != NULL: the launch ALSO waits (one lane of workgroup 0, after its own merge work) until *wflag has reached wval - the
+// exchange lane's "peer r reconstructed" flag (cfx_plan_run_lane) - so that the next attention block, which follows this launch
+// in the compute stream, finds the peer's K,V complete without any cross-stream event.
+__global__ __launch_bounds__(256) void k_attn_merge(float* __restrict__ out, float* __restrict__ lse, const h16* __restrict__ bo,
+                                                    const float* __restrict__ bl, int B, int S, int H, int D, int first,
+                                                    size_t bo_sb, size_t bo_ss, size_t bo_sh, int lg,
+                                                    const unsigned* wflag, unsigned wval, unsigned* err, long long timeout) {
+    attn_merge_body(out, lse, bo, bl, B, S, H, D, first, bo_sb, bo_ss, bo_sh, lg);
+    if (wflag && blockIdx.x == 0 && threadIdx.x == 0) flag_spin(wflag, wval, err, timeout);
 }
 
 __global__ __launch_bounds__(256) void k_copy_probe(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
@@ -1820,8 +1846,12 @@ cfx_ctx* cfx_create(int device) {
     memset(c->prof_seen, 0, sizeof(c->prof_seen));
     c->prof_mask = 0;
     c->tick = nullptr;
-    c->tick_next = 0;
+    memset(c->tick_next, 0, sizeof(c->tick_next));
+    c->n_ring_streams = 0;
     c->dbg_stamps = nullptr;
+    c->gate = nullptr;
+    c->gate_err = nullptr;
+    c->gate_timeout = 500000000LL;     // 5 s of the 100 MHz wall clock
     c->fused = 1;
     const char* f = getenv("CFX_FUSED_FINALIZE");
     if (f) c->fused = atoi(f) != 0;
@@ -1839,9 +1869,9 @@ int cfx_prepare(cfx_ctx* ctx) {
     int cur = -1;
     (void)hipGetDevice(&cur);
     if (cur != ctx->device && hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CFX_ERR_LAUNCH, "prepare: hipSetDevice failed");
-    static_assert(2 * TICK_RING == sizeof(((cfx_ctx*)0)->gate_expect) / sizeof(unsigned), "gate_expect has two entries per ring slot");
-    const size_t tick_words = (size_t)TICK_RING * CFX_MAX_BATCH * TICK_WORDS;
-    const size_t bytes = (tick_words + (size_t)(TICK_RING + 1) * GATE_STRIDE) * sizeof(unsigned);
+    static_assert(2 * TICK_RING * CFX_RING_STREAMS == sizeof(((cfx_ctx*)0)->gate_expect) / sizeof(unsigned), "gate_expect has two entries per ring slot");
+    const size_t tick_words = (size_t)CFX_RING_STREAMS * TICK_RING * CFX_MAX_BATCH * TICK_WORDS;
+    const size_t bytes = (tick_words + (size_t)(CFX_RING_STREAMS * TICK_RING + 1) * GATE_STRIDE) * sizeof(unsigned);
     void* p = nullptr;
     int rc = CFX_OK;
     if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
@@ -1851,7 +1881,10 @@ int cfx_prepare(cfx_ctx* ctx) {
     } else {
         ctx->tick = (unsigned*)p;
         ctx->gate = ctx->tick + tick_words;
-        ctx->gate_err = ctx->gate + (size_t)TICK_RING * GATE_STRIDE;
+        // the error word: pinned, device-visible HOST memory - a timed-out wait is reported by the next native call, no device sync
+        void* e = nullptr;
+        if (hipHostMalloc(&e, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); ctx->tick = nullptr; rc = fail(ctx, CFX_ERR_LAUNCH, "prepare: cannot allocate the error word"); }
+        else { memset(e, 0, 64); ctx->gate_err = (unsigned*)e; }
         memset(ctx->gate_expect, 0, sizeof(ctx->gate_expect));
     }
     if (cur >= 0 && cur != ctx->device) (void)hipSetDevice(cur);
@@ -1881,6 +1914,7 @@ void cfx_destroy(cfx_ctx* ctx) {
     if (!ctx) return;
     prof_free(ctx);
     if (ctx->tick) (void)hipFree(ctx->tick);
+    if (ctx->gate_err) (void)hipHostFree(ctx->gate_err);
     delete ctx;
 }
 
@@ -2069,17 +2103,57 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
 
     // statistics + finalize: ONE launch with the in-launch finalize (default), or the two-kernel sequence
     const bool fused = ctx->fused && CB <= TICK_MAX_CB;
+    // Ticket / gate blocks are handed out round-robin from a ring PER STREAM (launches of one stream are in order, so a ring slot is
+    // never shared by two launches in flight; one ring for every stream would let a stalled stream's launch meet a slot that another
+    // stream has cycled back to)
     unsigned* tick = nullptr;
+    unsigned slot = 0;
+    int stream_cus = 0;
     if (fused) {
         if (!ctx->tick && cfx_prepare(ctx) != CFX_OK) return CFX_ERR_LAUNCH;
-        tick = ctx->tick + (size_t)(ctx->tick_next++ % TICK_RING) * CFX_MAX_BATCH * TICK_WORDS;
+        int ring = -1;
+        for (int i = 0; i < ctx->n_ring_streams; ++i)
+            if (ctx->ring_stream[i] == stream) { ring = i; break; }
+        if (ring < 0) {
+            if (ctx->n_ring_streams == CFX_RING_STREAMS)
+                return fail(ctx, CFX_ERR_BATCH, "compress: a context serves at most 4 streams (create one cfx_ctx per further stream)");
+            ring = ctx->n_ring_streams++;
+            ctx->ring_stream[ring] = stream;
+            // CUs this stream's queue may use (hipExtStreamCreateWithCUMask): bounds what a launch can keep co-resident
+            uint32_t m[16] = {0};
+            int cus = 0;
+            if (stream && hipExtStreamGetCUMask((hipStream_t)stream, 16, m) == hipSuccess)
+                for (int i = 0; i < 16; ++i) cus += __builtin_popcount(m[i]);
+            else (void)hipGetLastError();
+            int total = 0;
+            (void)hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, ctx->device);
+            ctx->ring_cus[ring] = (cus > 0 && cus < total) ? cus : total;
+        }
+        stream_cus = ctx->ring_cus[ring];
+        slot = (unsigned)ring * TICK_RING + (ctx->tick_next[ring]++ % TICK_RING);
+        tick = ctx->tick + (size_t)slot * CFX_MAX_BATCH * TICK_WORDS;
     }
+    if (ctx->gate_err && *(volatile unsigned*)ctx->gate_err)
+        return fail(ctx, CFX_ERR_GATE, "compress: an earlier gate / flag wait on this context timed out (cfx_gate_errors reads and clears the count)");
     const int R = fused ? fused_rows(ctx, N, C, batch) : auto_rows(ctx, N, C, batch, true);
     const int P = (N + R - 1) / R;
     // one launch only for explicit gated items: folding the error-feedback update of a PLAIN compress call into the launch the same
     // way was measured slower (K,V of the FLUX shard: 20.8 vs 19.2 us 1-bit, 19.9 vs 18.6 us 2-bit) - the gate hop and the write tail
     // cost more than the kernel boundary they replace when only two tensors wait behind the gate
-    const bool one_launch = n_gated && gated_one_launch(ctx, codec, C, CB) && R == FUSED_NW * 4;   // the tile stays in registers
+    bool one_launch = n_gated && gated_one_launch(ctx, codec, C, CB) && R == FUSED_NW * 4;   // the tile stays in registers
+    if (one_launch && codec == CFX_CODEC_INT2) {
+        // the 2-bit layer launch needs every statistics workgroup CO-RESIDENT (each waits at gate 1 for all the others' partial sums
+        // while holding its tile in registers): only when they fit the CUs this stream may use, otherwise the multi-launch form
+        static int per_cu = 0;
+        if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_int2_compress_gated<4>, FUSED_NT, 0) != hipSuccess || per_cu < 1)) {
+            (void)hipGetLastError();
+            per_cu = 1;
+        }
+        if ((long)CB * P * batch > (long)per_cu * stream_cus - 8) one_launch = false;
+    }
+    // the 1-bit layer launch needs no co-residency (its statistics workgroups never wait), but its gated workgroups spin on slots the
+    // statistics group needs when the stream has few CUs: a CU-masked lane runs the multi-launch form
+    if (one_launch && stream_cus < 128) one_launch = false;
     const dim3 grid(CB, P, batch);
     const int Rq = auto_rows(ctx, N, C, batch, true);       // apply passes: same tile map as the (unfused) statistics pass
     const dim3 gridq(CB, (N + Rq - 1) / Rq, batch);
@@ -2093,7 +2167,6 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             a.g_R = ((N + a.g_rb - 1) / a.g_rb + FUSED_NW - 1) / FUSED_NW * FUSED_NW;
             a.n_g = CB * a.g_rb * n_gated;
             a.flags = flags; a.ws = ws; a.ws_stride = wstride; a.tick = tick;
-            const unsigned slot = (ctx->tick_next - 1) % TICK_RING;
             a.gate1 = ctx->gate + (size_t)slot * GATE_STRIDE;
             a.gate2 = a.gate1 + GATE_BLOCK;
             ctx->gate_expect[2 * slot] += (unsigned)batch * (unsigned)(CB + 1);
@@ -2132,8 +2205,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                 a.g_rb = (N + FUSED_NW * GATE_KR - 1) / (FUSED_NW * GATE_KR);
                 a.g_R = ((N + a.g_rb - 1) / a.g_rb + FUSED_NW - 1) / FUSED_NW * FUSED_NW;
                 a.n_g = CB * a.g_rb * n_gated_k;
-                const unsigned slot = (ctx->tick_next - 1) % TICK_RING;
-                a.gate = ctx->gate + (size_t)slot * GATE_STRIDE;
+                    a.gate = ctx->gate + (size_t)slot * GATE_STRIDE;
                 ctx->gate_expect[2 * slot] += (unsigned)batch * (unsigned)(CB + 1);
                 a.gate_expect = ctx->gate_expect[2 * slot];
             }
@@ -2207,10 +2279,15 @@ int cfx_compress_batch_gated(cfx_ctx* ctx, int codec, int N, int C, int param, i
 int cfx_gate_errors(cfx_ctx* ctx) {
     if (!ctx) return CFX_ERR_NULL;
     if (!ctx->gate_err) return 0;
-    unsigned v = 0;
-    if (hipMemcpy(&v, ctx->gate_err, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, CFX_ERR_LAUNCH, "gate errors: copy failed"); }
-    if (v) { const unsigned z = 0; (void)hipMemcpy(ctx->gate_err, &z, sizeof(z), hipMemcpyHostToDevice); }
+    const unsigned v = __atomic_exchange_n(ctx->gate_err, 0u, __ATOMIC_RELAXED);      // pinned host memory: no device synchronisation
     return (int)v;
+}
+
+int cfx_set_gate_timeout_ms(cfx_ctx* ctx, int ms) {
+    if (!ctx) return CFX_ERR_NULL;
+    if (ms <= 0) return fail(ctx, CFX_ERR_BATCH, "gate timeout must be positive");
+    ctx->gate_timeout = (long long)ms * 100000LL;
+    return CFX_OK;
 }
 
 int cfx_compress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
@@ -2320,19 +2397,27 @@ int cfx_residual2_update(cfx_ctx* ctx, const void* base, const void* delta_base,
     return check_launch(ctx, "residual2_update launch");
 }
 
-int cfx_attn_merge(cfx_ctx* ctx, void* out, void* lse, const void* block_out, const void* block_lse, int B, int S, int H, int D,
-                   int block_out_bshd, int first, void* stream) {
+int cfx_attn_merge_wait(cfx_ctx* ctx, void* out, void* lse, const void* block_out, const void* block_lse, int B, int S, int H, int D,
+                        int block_out_bshd, int first, const void* wait_flag, unsigned wait_value, void* stream) {
     if (!ctx || !out || !lse || !block_out || !block_lse) return fail(ctx, CFX_ERR_NULL, "attn_merge: null pointer");
     if (B <= 0 || S <= 0 || H <= 0 || D <= 0 || (D & 7) || D > 512) return fail(ctx, CFX_ERR_SHAPE, "attn_merge: head dim must be a positive multiple of 8, at most 512");
     if (!AL16(out) || !AL16(block_out)) return fail(ctx, CFX_ERR_ALIGN, "attn_merge: pointers must be 16-byte aligned");
+    if (wait_flag && !ctx->gate_err && cfx_prepare(ctx) != CFX_OK) return CFX_ERR_LAUNCH;
+    if (ctx->gate_err && *(volatile unsigned*)ctx->gate_err) return fail(ctx, CFX_ERR_GATE, "attn_merge: an earlier flag / gate wait on this context timed out (cfx_gate_errors)");
     hipStream_t s = (hipStream_t)stream;
     int lg = 0;
     while ((1 << lg) < D / 8) ++lg;          // a row's D/8 threads in 2^lg lanes of one wave
     const size_t total = ((size_t)B * S * H) << lg;
     LAUNCH(ctx, KID_ATTN_MERGE, s, k_attn_merge, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (float*)out, (float*)lse,
            (const h16*)block_out, (const float*)block_lse, B, S, H, D, first,
-           (size_t)S * H * D, block_out_bshd ? (size_t)H * D : (size_t)D, block_out_bshd ? (size_t)D : (size_t)S * D, lg);
+           (size_t)S * H * D, block_out_bshd ? (size_t)H * D : (size_t)D, block_out_bshd ? (size_t)D : (size_t)S * D, lg,
+           (const unsigned*)wait_flag, wait_value, ctx->gate_err, ctx->gate_timeout);
     return check_launch(ctx, "attn_merge launch");
+}
+
+int cfx_attn_merge(cfx_ctx* ctx, void* out, void* lse, const void* block_out, const void* block_lse, int B, int S, int H, int D,
+                   int block_out_bshd, int first, void* stream) {
+    return cfx_attn_merge_wait(ctx, out, lse, block_out, block_lse, B, S, H, D, block_out_bshd, first, nullptr, 0u, stream);
 }
 
 int cfx_copy_probe(cfx_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {

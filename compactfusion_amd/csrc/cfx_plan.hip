@@ -29,6 +29,44 @@ static void sched_free(PipeSched* sc) {
     delete sc;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Exchange lane: cross-stream ordering by in-memory flags instead of events.
+// Measured on MI355X / ROCm 7.2 (tools/lane_probe.hip): an event hop between two streams (record + stream-wait) costs ~14 us of
+// idle queue time per hop, a hipStreamWriteValue32 / WaitValue32 pair ~6 us, a flag written by one stream's kernel and polled by
+// the other stream's kernel ~1.7 us (plus the 1.5 us any dependent tiny kernel costs in its stream).  So the layer's exchange
+// chain runs on its own (CU-masked) stream and talks to the compute stream only through flag words:
+//     compute stream:   k_flag_set(ready, e) ; attention(own K,V) ; merge + wait(peer1 >= e) ; attention(peer 1) ; merge + wait(peer2 >= e) ...
+//     exchange stream:  k_flag_wait(ready >= e) ; compress ; all-gather ; reconstruct peer 1 ; k_flag_set(peer1, e) ; reconstruct peer 2 ; ...
+// Flags hold monotonic epochs (one per replay of the plan), one 64-byte line each, never reset.  A set kernel runs after the
+// kernel in front of it has finished and released its stores (in-order stream), a waiting kernel's successor starts with an
+// acquire: the data behind a flag needs no fences of its own.
+// ---------------------------------------------------------------------------------------------------
+#define FLAG_WORDS 16      // u32 words per flag: a 64-byte line each
+__global__ void k_flag_set(unsigned* flag, unsigned v) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_flag_wait(const unsigned* flag, unsigned v, unsigned* err, long long timeout) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > timeout) {
+            if (err) (void)__hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+}
+
+static int gate_check(cfx_ctx* ctx, const char* what) {
+    if (ctx->gate_err && *(volatile unsigned*)ctx->gate_err) {
+        char buf[200];
+        snprintf(buf, sizeof(buf), "%s: an earlier gate / flag wait on this context timed out (cfx_gate_errors reads and clears the count)", what);
+        return fail(ctx, CFX_ERR_GATE, buf);
+    }
+    return CFX_OK;
+}
+
 extern "C" {
 
 cfx_plan* cfx_plan_create(cfx_ctx* ctx) {
@@ -43,6 +81,9 @@ cfx_plan* cfx_plan_create(cfx_ctx* ctx) {
     p->pipe_ws = nullptr;
     p->pipe_ws_bytes = 0;
     p->sched = nullptr;
+    p->flags = nullptr;
+    p->n_flags = 0;
+    p->epoch = 0;
     // Default: collectives in order on the main stream.  Measured on MI355X / ROCm 7: one cross-stream event hop costs
     // ~10 us of idle queue time, two per layer (main->side, side->main) = +1.1 ms per 57-layer step, whereas the
     // in-order exchange adds 0.1 ms; a side stream only pays when >> 20 us of independent work can overlap (attention).
@@ -78,6 +119,7 @@ void cfx_plan_destroy(cfx_plan* p) {
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->pipe_ws) (void)hipFree(p->pipe_ws);
+    if (p->flags) (void)hipFree(p->flags);
     sched_free(p->sched);
     delete[] p->ops;
     delete p;
@@ -252,6 +294,7 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
     if (!p) return CFX_ERR_NULL;
     if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
     hipStream_t main_s = (hipStream_t)stream;
+    { const int ge = gate_check(p->ctx, "plan run"); if (ge != CFX_OK) return ge; }
     const int side_mode = inline_exchange ? 0 : p->side_mode;
     for (int i = first_op; i < first_op + n_ops; ++i) {
         PlanOp* o = &p->ops[i];
@@ -278,6 +321,15 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
             } break;
             case 3:
                 if (side_mode && hipStreamWaitEvent(main_s, p->ops[o->ref].ev_done, 0) != hipSuccess) return fail(p->ctx, CFX_ERR_LAUNCH, "plan: wait failed");
+                break;
+            case 5:
+                hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, main_s, (const unsigned*)(p->flags + (size_t)o->ref * FLAG_WORDS), p->epoch,
+                                   p->ctx->gate_err, p->ctx->gate_timeout);
+                rc = check_launch(p->ctx, "flag wait launch");
+                break;
+            case 6:
+                hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, main_s, p->flags + (size_t)o->ref * FLAG_WORDS, p->epoch);
+                rc = check_launch(p->ctx, "flag set launch");
                 break;
         }
         if (rc != CFX_OK) return rc;
@@ -319,6 +371,105 @@ int cfx_plan_join(cfx_plan* p, void* main_stream) {
     if (!p) return CFX_ERR_NULL;
     if (!p->ev_join) return fail(p->ctx, CFX_ERR_BATCH, "plan: join without run_async");
     return hipStreamWaitEvent((hipStream_t)main_stream, p->ev_join, 0) == hipSuccess ? CFX_OK : fail(p->ctx, CFX_ERR_LAUNCH, "plan: join failed");
+}
+
+// ---- exchange lane (see the flag kernels above) -------------------------------------------------------------------------
+void* cfx_plan_flags(cfx_plan* p, int n) {
+    if (!p || n < 1 || n > 4096) return nullptr;
+    if (p->flags) return p->n_flags >= n ? (void*)p->flags : nullptr;          // one block per plan, sized once
+    if (cfx_prepare(p->ctx) != CFX_OK) return nullptr;                         // the error word the waits report to
+    void* m = nullptr;
+    if (hipMalloc(&m, (size_t)n * FLAG_WORDS * sizeof(unsigned)) != hipSuccess || hipMemset(m, 0, (size_t)n * FLAG_WORDS * sizeof(unsigned)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        if (m) (void)hipFree(m);
+        fail(p->ctx, CFX_ERR_LAUNCH, "plan: cannot allocate the flag block");
+        return nullptr;
+    }
+    p->flags = (unsigned*)m;
+    p->n_flags = n;
+    return m;
+}
+
+static int plan_add_flag_op(cfx_plan* p, int kind, int flag) {
+    if (!p) return CFX_ERR_NULL;
+    if (!p->flags || flag < 0 || flag >= p->n_flags) return fail(p->ctx, CFX_ERR_BATCH, "plan: flag index out of range (cfx_plan_flags first)");
+    PlanOp* o = plan_push(p);
+    memset(o, 0, sizeof(*o));
+    o->kind = kind; o->ref = flag;
+    return p->n - 1;
+}
+int cfx_plan_add_flag_wait(cfx_plan* p, int flag) { return plan_add_flag_op(p, 5, flag); }
+int cfx_plan_add_flag_set(cfx_plan* p, int flag) { return plan_add_flag_op(p, 6, flag); }
+
+unsigned cfx_plan_epoch(const cfx_plan* p) { return p ? p->epoch : 0u; }
+
+int cfx_plan_run_lane(cfx_plan* p, int first_op, int n_ops, const void* const* xs, int n_xs, int ready_flag, void* compute_stream,
+                      unsigned* epoch_out) {
+    if (!p) return CFX_ERR_NULL;
+    if (!p->side) return fail(p->ctx, CFX_ERR_BATCH, "plan: run_lane needs an exchange stream (cfx_plan_use_exchange_stream)");
+    if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
+    if (!p->flags || ready_flag < 0 || ready_flag >= p->n_flags) return fail(p->ctx, CFX_ERR_BATCH, "plan: ready flag index out of range");
+    if (n_xs > 0) {
+        if (!xs) return CFX_ERR_NULL;
+        int op = first_op;
+        while (op < first_op + n_ops && p->ops[op].kind != 0) ++op;
+        if (op == first_op + n_ops || p->ops[op].batch != n_xs) return fail(p->ctx, CFX_ERR_BATCH, "plan: run_lane needs a compress op with n_xs items in the range");
+        for (int i = 0; i < n_xs; ++i) {
+            if (!xs[i] || !AL16(xs[i])) return fail(p->ctx, CFX_ERR_ALIGN, "plan: activations must be non-null and 16-byte aligned");
+            p->ops[op].c[i].x = xs[i];
+        }
+    }
+    ++p->epoch;
+    if (epoch_out) *epoch_out = p->epoch;
+    // "the activations exist": behind whatever the caller enqueued on the compute stream so far (the kernels that produce K, V)
+    hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, (hipStream_t)compute_stream, p->flags + (size_t)ready_flag * FLAG_WORDS, p->epoch);
+    const int rl = check_launch(p->ctx, "ready flag launch");
+    if (rl != CFX_OK) return rl;
+    return plan_run_impl(p, first_op, n_ops, (void*)p->side, true);
+}
+
+int cfx_flag_set(cfx_ctx* ctx, void* flag, unsigned value, void* stream) {
+    if (!ctx || !flag) return fail(ctx, CFX_ERR_NULL, "flag_set: null");
+    hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned*)flag, value);
+    return check_launch(ctx, "flag set launch");
+}
+
+int cfx_flag_wait(cfx_ctx* ctx, const void* flag, unsigned value, void* stream) {
+    if (!ctx || !flag) return fail(ctx, CFX_ERR_NULL, "flag_wait: null");
+    if (!ctx->gate_err && cfx_prepare(ctx) != CFX_OK) return CFX_ERR_LAUNCH;
+    const int ge = gate_check(ctx, "flag wait");
+    if (ge != CFX_OK) return ge;
+    hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned*)flag, value, ctx->gate_err, ctx->gate_timeout);
+    return check_launch(ctx, "flag wait launch");
+}
+
+// A stream whose kernels may only use CU-mask bits [first_cu, first_cu + n_cus).  On MI355X (8 XCDs x 32 CUs) bit i selects CU
+// i / 8 of XCD i % 8, consecutive CUs of an XCD alternating over its shader engines (tools/lane_probe.hip): a contiguous bit range
+// is the same number of CUs on every XCD, i.e. an even share of every L2 and of the fabric.
+int cfx_stream_create_masked(cfx_ctx* ctx, int first_cu, int n_cus, void** stream) {
+    if (!ctx || !stream) return fail(ctx, CFX_ERR_NULL, "stream_create_masked: null");
+    int total = 0;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != ctx->device && hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CFX_ERR_LAUNCH, "stream_create_masked: hipSetDevice failed");
+    (void)hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    int rc = CFX_OK;
+    if (total <= 0 || total > 512 || first_cu < 0 || n_cus < 1 || first_cu + n_cus > total) rc = fail(ctx, CFX_ERR_BATCH, "stream_create_masked: CU range outside the device");
+    else {
+        uint32_t mask[16] = {0};
+        for (int b = first_cu; b < first_cu + n_cus; ++b) mask[b >> 5] |= 1u << (b & 31);
+        hipStream_t s = nullptr;
+        if (hipExtStreamCreateWithCUMask(&s, (uint32_t)((total + 31) / 32), mask) != hipSuccess) { (void)hipGetLastError(); rc = fail(ctx, CFX_ERR_LAUNCH, "hipExtStreamCreateWithCUMask failed"); }
+        else *stream = (void*)s;
+    }
+    if (cur >= 0 && cur != ctx->device) (void)hipSetDevice(cur);
+    return rc;
+}
+
+int cfx_stream_destroy(cfx_ctx* ctx, void* stream) {
+    if (!ctx || !stream) return fail(ctx, CFX_ERR_NULL, "stream_destroy: null");
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? CFX_OK : fail(ctx, CFX_ERR_LAUNCH, "hipStreamDestroy failed");
 }
 
 // Software-pipelined replay of a 1-bit exchange step.  The op range must be a sequence of "groups"

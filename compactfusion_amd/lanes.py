@@ -1,0 +1,72 @@
+"""Exchange lane: two CU-masked HIP streams per device with disjoint CU sets.
+
+The reference overlaps the K,V exchange with the local attention block on NCCL's own stream and decompresses on the compute
+stream (xfuser/compact/ring.py:191-269).  Here the layer's whole chain - compress, collective, per-peer reconstruction - runs
+on an EXCHANGE stream restricted to a few CUs of every XCD, and the model (attention, projections) on a COMPUTE stream
+restricted to the rest, so that the chain's workgroups never share a CU with an attention workgroup (measured on MI355X,
+tools/sdpa_mask_probe.py: one SDPA block at the FLUX ring shape 37 us alone, 38 us beside a saturating copy on 32 other CUs,
+93 us when the two share CUs; 224 CUs are as fast as 256 for it, 192 are not).  The two streams are ordered only through flag
+words in device memory (`cfx_plan_run_lane`, `cfx_attn_merge_wait`; include/cfx.h).
+
+Use:
+    from compactfusion_amd import lanes
+    with torch.cuda.stream(lanes.compute_stream()):        # the model runs on the lane's compute stream
+        ... pipeline(...) ...
+`compact_fwd` takes the masked exchange stream whenever the current stream is the lane's compute stream; on any other stream
+it keeps an unmasked exchange stream (same flags, no CU partition).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .codecs import context
+
+
+class Lane:
+    def __init__(self, device: int, exchange_cus: int):
+        lib = _lib.load()
+        self.device = device
+        self.ctx = context(device)
+        total = torch.cuda.get_device_properties(device).multi_processor_count
+        if not (8 <= exchange_cus <= total - 8):
+            raise ValueError(f"exchange CUs must be between 8 and {total - 8}")
+        self.exchange_cus, self.compute_cus = exchange_cus, total - exchange_cus
+        ex, co = ctypes.c_void_p(), ctypes.c_void_p()
+        for (first, n, out) in ((0, exchange_cus, ex), (exchange_cus, total - exchange_cus, co)):
+            rc = lib.cfx_stream_create_masked(self.ctx, first, n, ctypes.byref(out))
+            if rc != 0:
+                raise _lib.CfxError("cannot create a CU-masked stream: " + (lib.cfx_last_error_string(self.ctx) or b"").decode())
+        self.exchange = torch.cuda.ExternalStream(ex.value, device=torch.device("cuda", device))
+        self.compute = torch.cuda.ExternalStream(co.value, device=torch.device("cuda", device))
+
+
+_lanes: Dict[int, Lane] = {}
+
+
+def lane(device: Optional[int] = None) -> Lane:
+    if device is None:
+        device = torch.cuda.current_device()
+    ln = _lanes.get(device)
+    if ln is None:
+        ln = _lanes[device] = Lane(device, int(os.environ.get("CFX_LANE_EXCHANGE_CUS", "32")))
+    return ln
+
+
+def compute_stream(device: Optional[int] = None) -> "torch.cuda.Stream":
+    """The stream to run the model on (CU-masked to everything the exchange lane does not use)."""
+    return lane(device).compute
+
+
+def exchange_stream(device: Optional[int] = None) -> "torch.cuda.Stream":
+    return lane(device).exchange
+
+
+def on_compute_stream(device: int) -> bool:
+    """True when the CURRENT stream of `device` is the lane's compute stream (a lane exists and the caller opted in)."""
+    ln = _lanes.get(device)
+    return ln is not None and torch.cuda.current_stream(device).cuda_stream == ln.compute.cuda_stream

@@ -56,7 +56,8 @@ enum cfx_status {
     CFX_ERR_CODEC = -4,      /* unknown codec id */
     CFX_ERR_BATCH = -5,      /* batch < 1 or > CFX_MAX_BATCH */
     CFX_ERR_LAUNCH = -6,     /* hipGetLastError() after a launch was not hipSuccess */
-    CFX_ERR_WORKSPACE = -7   /* workspace NULL or smaller than cfx_workspace_bytes() */
+    CFX_ERR_WORKSPACE = -7,  /* workspace NULL or smaller than cfx_workspace_bytes() */
+    CFX_ERR_GATE = -8        /* an in-launch gate / lane flag wait of an EARLIER launch on this context timed out (cfx_gate_errors) */
 };
 
 enum cfx_codec {
@@ -137,15 +138,17 @@ int cfx_compress_batch_gated(cfx_ctx* ctx, int codec, int N, int C, int param, i
                              int batch, const cfx_comp_item* items, int n_ride, const cfx_decomp_item* ride,
                              int n_gated, const cfx_decomp_item* gated,
                              void* workspace, size_t workspace_bytes, void* stream);
-/* Number of gated launches whose gate never opened since the last call (a bounded spin gives up instead of hanging the GPU;
- * always 0 unless the library is broken), or < 0 on error.  Synchronises with the device. */
+/* Number of in-launch gate / lane flag waits that timed out since the last call (a bounded spin gives up instead of hanging the GPU;
+ * always 0 unless the library is broken or a stream was starved), or < 0 on error.  Reads and clears a pinned host word: no device
+ * synchronisation (a complete count needs the streams drained first).  While the count is non-zero every compress / plan / merge
+ * call on the context returns CFX_ERR_GATE. */
 int cfx_gate_errors(cfx_ctx* ctx);
 
 /* The statistics pass of a compress call reduces its partial sums INSIDE the launch (last-arriving workgroups, ticket
  * counters; replaces the eager scale prologue of fastpath.py:150-166 / compress_quantize.py:452-463 and the separate
  * finalize kernel).  The tickets live in device memory owned by the context: cfx_prepare allocates them (idempotent;
  * otherwise the first compress call does - call it before capturing compress calls into a hipGraph).  Compress calls
- * on one context must be stream-ordered with respect to each other (one context per stream otherwise).
+ * on one context may come from up to 4 streams (a ticket ring per stream; launches of one stream are in order).
  * cfx_set_fused_finalize(ctx, 0) selects the two-kernel sequence (statistics, finalize); results are bit-identical. */
 int cfx_prepare(cfx_ctx* ctx);
 int cfx_set_fused_finalize(cfx_ctx* ctx, int on);
@@ -242,6 +245,42 @@ int       cfx_plan_run_x(cfx_plan* plan, int first_op, int n_ops, const void* co
  * layer.  The activations must stay alive until the join. */
 int       cfx_plan_run_async(cfx_plan* plan, int first_op, int n_ops, const void* const* xs, int n_xs, void* main_stream);
 int       cfx_plan_join(cfx_plan* plan, void* main_stream);
+/* Exchange lane: the layer's chain (compress, collective, per-peer reconstruction) on its own - normally CU-masked - stream, ordered
+ * with the compute stream ONLY through flag words in device memory (no events: a cross-stream event hop costs ~14 us of idle queue
+ * time on MI355X / ROCm 7.2, a flag written by one stream's kernel and polled by the other's ~1.7 us; tools/lane_probe.hip).
+ * Replaces the reference's fork / join of the K,V exchange around the local attention block (xfuser/compact/ring.py:191-269:
+ * RingComm.send_recv + commit before the block, wait after it, decompress on the compute stream).
+ *   cfx_plan_flags(plan, n)       allocates the plan's n flag words (64 bytes apart, zeroed; once per plan) and returns the device
+ *                                 address of flag 0, or NULL.  Flags hold monotonic EPOCHS: one per cfx_plan_run_lane call.
+ *   cfx_plan_add_flag_wait / _set plan ops: wait until flag i has reached the current epoch / set flag i to it.  A set op makes
+ *                                 everything the ops before it wrote visible to whoever waits (kernel boundary in an in-order stream).
+ *   cfx_plan_run_lane             advances the epoch, launches "set flag `ready_flag`" on `compute_stream` (behind the kernels that
+ *                                 produce the activations xs, see cfx_plan_run_x) and replays the op range on the plan's exchange
+ *                                 stream (cfx_plan_use_exchange_stream); the range normally starts with a wait op on `ready_flag`.
+ *                                 *epoch_out receives the epoch the range's set ops will publish.  One host call per layer.
+ *   cfx_attn_merge_wait           cfx_attn_merge whose launch also waits (one lane, after its merge work) until *wait_flag has
+ *                                 reached wait_value: the attention block that follows it in the compute stream then finds the
+ *                                 peer's reconstructed K,V complete.  wait_flag NULL = cfx_attn_merge.
+ *   cfx_flag_set / cfx_flag_wait  the same two tiny kernels for callers that order other work (flag = any 4-byte-aligned device word).
+ * A wait gives up after the context's gate timeout (default 5 s, cfx_set_gate_timeout_ms) and counts the failure in a pinned host
+ * word: the next plan / compress / merge call on the context returns CFX_ERR_GATE, cfx_gate_errors reads and clears the count
+ * without synchronising the device.
+ *   cfx_stream_create_masked      a stream restricted to CU-mask bits [first_cu, first_cu + n_cus) (hipExtStreamCreateWithCUMask; on
+ *                                 MI355X bit i = CU i/8 of XCD i%8, so a contiguous range is the same share of every XCD).  The lane
+ *                                 uses two with DISJOINT ranges - e.g. 32 CUs for the exchange, 224 for the compute stream the
+ *                                 attention kernels run on - so that neither slows the other's workgroups (tools/sdpa_mask_probe.py:
+ *                                 SDPA 37 us alone, 38 us beside a saturating copy on the other 32 CUs, 93 us when it shares them). */
+void*     cfx_plan_flags(cfx_plan* plan, int n);
+int       cfx_plan_add_flag_wait(cfx_plan* plan, int flag);
+int       cfx_plan_add_flag_set(cfx_plan* plan, int flag);
+unsigned  cfx_plan_epoch(const cfx_plan* plan);
+int       cfx_plan_run_lane(cfx_plan* plan, int first_op, int n_ops, const void* const* xs, int n_xs, int ready_flag,
+                            void* compute_stream, unsigned* epoch_out);
+int       cfx_flag_set(cfx_ctx* ctx, void* flag, unsigned value, void* stream);
+int       cfx_flag_wait(cfx_ctx* ctx, const void* flag, unsigned value, void* stream);
+int       cfx_stream_create_masked(cfx_ctx* ctx, int first_cu, int n_cus, void** stream);
+int       cfx_stream_destroy(cfx_ctx* ctx, void* stream);
+int       cfx_set_gate_timeout_ms(cfx_ctx* ctx, int ms);
 /* Software-pipelined replay (replaces the reference's strictly sequential quantise -> cat -> send -> dequantise per layer,
  * xfuser/compact/ring.py:188-260 with fastpath.py:124-228, 371-438).  If ops [first_op, first_op + n_ops) are a sequence of "groups"
  *     k x compress (BINARY, flags without UPDATE_CACHE)   { all-gather }*   k x decompress (BINARY)      of one shape,
@@ -291,6 +330,8 @@ int cfx_residual2_update(cfx_ctx* ctx, const void* base, const void* delta_base,
  * eager elementwise kernels. */
 int cfx_attn_merge(cfx_ctx* ctx, void* out, void* lse, const void* block_out, const void* block_lse, int B, int S, int H, int D,
                    int block_out_bshd, int first, void* stream);
+int cfx_attn_merge_wait(cfx_ctx* ctx, void* out, void* lse, const void* block_out, const void* block_lse, int B, int S, int H, int D,
+                        int block_out_bshd, int first, const void* wait_flag, unsigned wait_value, void* stream);
 
 /* Bandwidth probe: dst[i] = src[i] over `bytes` (multiple of 16) - the achievable-HBM reference
  * against which bench.py reports roofline fractions. */

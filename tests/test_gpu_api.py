@@ -634,7 +634,7 @@ def test_native_attention_merge_equals_the_eager_formula(D):
             bo = bo.transpose(1, 2).contiguous().transpose(1, 2)          # the other layout the kernel accepts: (B,H,S,D) underneath
         calls = []
         orig = A._merge_native
-        A._merge_native = lambda *a: (calls.append(a[-1]), orig(*a))[1]
+        A._merge_native = lambda *a: (calls.append(a[4]), orig(*a))[1]
         try:
             out, lse = A.update_out_and_lse(out, lse, bo, bl)
         finally:

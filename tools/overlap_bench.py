@@ -5,8 +5,11 @@ logical ranks are looped back: every peer's packet is this rank's own packet (te
 RCCL - same stream-ordered all-gather, device copies instead of xGMI; with real peers the collective's wire time adds to what
 must hide under the local attention block).  Legs, all on the same inputs:
   attention      the 8 attention blocks + merges of every layer on resident K,V (no exchange at all)
-  native         compact_fwd with the layer's WHOLE exchange chain (compress, all-gather, reconstruction) issued by libcfx on the
-                 exchange stream beside the local attention block (cfx_plan_run_async + cfx_plan_join: two host calls per layer)
+  lane           compact_fwd on the EXCHANGE LANE (the default): the model on the lane's CU-masked compute stream (224 CUs), the layer's
+                 whole chain - compress, all-gather, per-peer reconstruction - on the CU-masked exchange stream (32 CUs), ordered only
+                 by flags in device memory (cfx_plan_run_lane + cfx_attn_merge_wait: one host call per layer for the exchange)
+  lane_unmasked  the same flags, but the model on an ordinary stream and the chain on an unmasked exchange stream
+  native         round 2's schedule: the chain on the exchange stream, forked and joined with EVENTS (cfx_plan_run_async + cfx_plan_join)
   native_gather_only_on_side   as round 1 scheduled it: compress and reconstruction on the compute stream, only the collective beside
                  the local block
   torchdist      compact_fwd with the collective issued from Python (what round 1 did; the loop-back copy stands in for
@@ -30,6 +33,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--layers", type=int, default=57)
 ap.add_argument("--json", default=None)
+ap.add_argument("--quick", action="store_true", help="only the attention, lane and event-fork legs")
+ap.add_argument("--legs", default=None, help="comma-separated subset of the legs (for kernel traces); default all")
 args = ap.parse_args()
 
 os.environ["CFX_FAKE_RCCL_MODE"] = "loopback"
@@ -79,6 +84,7 @@ v0 = [torch.randn(1, N, H, D, device=dev, dtype=torch.float16, generator=g) for 
 drift = [[0.1 * torch.randn(1, N, H, D, device=dev, dtype=torch.float16, generator=g) for _ in range(L)] for _ in range(2)]
 ks = [[(k0[l] + drift[s][l]) for l in range(L)] for s in range(2)]
 vs = [[(v0[l] - drift[s][l]) for l in range(L)] for s in range(2)]
+torch.cuda.synchronize()
 
 
 def attention_only(i):
@@ -104,6 +110,7 @@ def init(mode, xstream="chain"):
     os.environ["CFX_RING_EXCHANGE_STREAM"] = xstream
     exchange.set_comm_factory(LoopComm if mode != "torch" else None)
     ring._xbuf.clear()
+    ring._steady.clear()
     cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T.BINARY, comp_rank=-1,
                                   residual=1, ef=True, fastpath=True))
     fwd(0); fwd(1); fwd(2)
@@ -127,14 +134,46 @@ def timed(fn, first):
     return wall / args.steps * 1e3, host / args.steps * 1e3
 
 
+from compactfusion_amd import lanes
+comp_stream = lanes.compute_stream(0)
+ALL = ["attention_on_compute_lane", "lane", "attention", "lane_unmasked", "native", "native_gather_only_on_side", "torchdist"]
+legs = [x for x in (args.legs.split(",") if args.legs else ALL) if x]
+assert all(x in ALL for x in legs), f"legs must be among {ALL}"
+if args.quick:
+    legs = [x for x in legs if x not in ("native_gather_only_on_side", "torchdist")]
 res = {}
-attention_only(0); torch.cuda.synchronize()
-res["attention"] = timed(attention_only, 0)
-init("native", "chain")
-native_used = all(ex.plan is not None for ex in ring._xbuf.values() if ex.sig is not None)
-res["native"] = timed(fwd, 3)
-# host cost of the exchange itself, measured directly (the difference of two ~13 ms host-issue legs is noise): the two native
-# calls of a layer and the steady-state lane's checks, each into an empty queue
+lane_used = native_used = None
+for leg in legs:
+    if leg == "attention_on_compute_lane":
+        with torch.cuda.stream(comp_stream):
+            attention_only(0); torch.cuda.synchronize()
+            res[leg] = timed(attention_only, 0)
+    elif leg == "lane":
+        with torch.cuda.stream(comp_stream):
+            init("native", "lane")
+            lane_used = all(ex.plan is not None and ex.lane for ex in ring._xbuf.values() if ex.sig is not None)
+            res[leg] = timed(fwd, 3)
+    elif leg == "attention":
+        attention_only(0); torch.cuda.synchronize()
+        res[leg] = timed(attention_only, 0)
+    elif leg == "lane_unmasked":
+        init("native", "lane")
+        res[leg] = timed(fwd, 3)
+    elif leg == "native":
+        init("native", "chain")
+        native_used = all(ex.plan is not None for ex in ring._xbuf.values() if ex.sig is not None)
+        res[leg] = timed(fwd, 3)
+    elif leg == "native_gather_only_on_side":
+        init("native", "side")
+        res[leg] = timed(fwd, 3)
+    elif leg == "torchdist":
+        init("torch")
+        res[leg] = timed(fwd, 3)
+    torch.cuda.synchronize()
+
+
+# host cost of the exchange itself, measured directly (the difference of two ~13 ms host-issue legs is noise): the native
+# call of a layer and the steady-state lane's checks, each into an empty queue
 def _host_us(fn, n=200):
     tot = 0.0
     for _ in range(n):
@@ -143,36 +182,33 @@ def _host_us(fn, n=200):
     return tot / n * 1e6
 
 
-_ex = [e for e in ring._xbuf.values() if e.sig is not None and e.plan is not None][0]
-_st = next(iter(ring._steady.values()))
-_sh = torch.cuda.current_stream().cuda_stream
-_cfg = cm.compact_config()
-direct = {"run_front (fork + compress + all-gather + reconstruct + join event, one C call)": round(_host_us(lambda: _ex.run_front(ks[0][0], vs[0][0], _sh)), 1)}
-_ex.run_front(ks[0][0], vs[0][0], _sh)
-direct["run_back (join, one C call)"] = round(_host_us(lambda: _ex.run_back(_sh)), 1)
-direct["steady-lane checks (compress_func, matches, current_stream)"] = round(_host_us(
-    lambda: (_cfg.compress_func(0, 5), _st.matches(qs[0], ks[0][0], vs[0][0], _st.ctype, _cfg, False, 0), torch.cuda.current_stream(dev).cuda_stream)), 1)
-direct["total"] = round(sum(direct.values()), 1)
-torch.cuda.synchronize()
-init("native", "side")
-res["native_gather_only_on_side"] = timed(fwd, 3)
-init("torch")
-res["torchdist"] = timed(fwd, 3)
-# states of the two exchange legs are the same function of the same inputs: spot check a layer against each other is not
-# parity (tests/ do that against the oracle); here only the timing matters
-att = res["attention"][0]
+direct = None
+if not args.legs:
+    init("native", "lane")
+    _ex = [e for e in ring._xbuf.values() if e.sig is not None and e.plan is not None][0]
+    _st = next(iter(ring._steady.values()))
+    _sh = torch.cuda.current_stream().cuda_stream
+    _cfg = cm.compact_config()
+    direct = {"run_lane (ready flag + wait + compress + all-gather + 7 x (reconstruct, flag) + own EF, one C call)": round(_host_us(lambda: _ex.run_lane(ks[0][0], vs[0][0], _sh)), 1)}
+    direct["steady-lane checks (compress_func, matches, current_stream)"] = round(_host_us(
+        lambda: (_cfg.compress_func(0, 5), _st.matches(qs[0], ks[0][0], vs[0][0], _st.ctype, _cfg, False, 0), torch.cuda.current_stream(dev).cuda_stream)), 1)
+    direct["total"] = round(sum(direct.values()), 1)
+    torch.cuda.synchronize()
+att = res["attention"][0] if "attention" in res else None
+att_lane = res["attention_on_compute_lane"][0] if "attention_on_compute_lane" in res else None
+base_of = lambda k: att_lane if k == "lane" else att                      # noqa: E731   each leg against attention on ITS compute stream
 out = {
     "protocol": "SURVEY.md 8d(2): compact_fwd (gather schedule) with PyTorch-ROCm SDPA, one MI355X, 8 logical ranks looped back",
     "shape": {"q_k_v": [1, N, H, D], "layers": L, "ring": W, "codec": "BINARY 1-bit residual + EF"},
     "steps": args.steps,
-    "native_plan_used": bool(native_used),
+    "lane": {"exchange_cus": lanes.lane(0).exchange_cus, "compute_cus": lanes.lane(0).compute_cus, "lane_plan_used": lane_used},
+    "native_plan_used": native_used,
     "legs_ms_per_step": {k: {"wall": round(v[0], 3), "host_issue": round(v[1], 3)} for k, v in res.items()},
-    "exposed_exchange_ms_per_step": {k: round(res[k][0] - att, 3) for k in res if k != "attention"},
+    "exposed_exchange_ms_per_step": {k: round(res[k][0] - base_of(k), 3) for k in res if not k.startswith("attention") and base_of(k) is not None},
     "host_us_per_layer": {k: round(res[k][1] * 1e3 / L, 1) for k in res},
-    "host_us_per_layer_exchange_only_by_difference": {k: round((res[k][1] - res["attention"][1]) * 1e3 / L, 1) for k in res if k != "attention"},
     "native_exchange_host_us_per_layer_measured_directly": direct,
-    "note": "exposed = wall(leg) - wall(attention); the collective is a loop-back device copy (no xGMI wire time); the torchdist "
-            "leg excludes torch.distributed's own ~50 us/call host cost (its collective is a plain tensor copy here)",
+    "note": "exposed = wall(leg) - wall(attention on the same compute stream); the collective is a loop-back device copy (no xGMI wire "
+            "time); the torchdist leg excludes torch.distributed's own ~50 us/call host cost (its collective is a plain tensor copy here)",
 }
 print(json.dumps(out))
 if args.json:
