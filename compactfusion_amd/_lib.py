@@ -103,6 +103,7 @@ SYMBOLS = [
     ("cfx_plan_flags", ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_plan_add_flag_wait", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_plan_add_flag_set", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_plan_set_pre_flag", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     ("cfx_plan_epoch", ctypes.c_uint, [ctypes.c_void_p]),
     ("cfx_plan_run_lane", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]),

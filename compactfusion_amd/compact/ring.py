@@ -353,14 +353,17 @@ class _LayerExchange:
             ok = ok and lib.cfx_plan_add_compress(plan, cid, N, C, param, flags, 2, c, wsp, wsn) == 1
             ok = ok and lib.cfx_plan_add_all_gather(plan, comm.handle, self.send.data_ptr(), self.recv.data_ptr(), 2 * self.slot * 2) == 2
             n_own = 2 if ef else 0                 # bases / pkts start with the rank's own K,V when error feedback is on
-            for s_ in range(1, W):                 # just in time: peer s's K,V, then its flag, in the order the attention blocks visit them
-                lo = n_own + 2 * (s_ - 1)
+            for s_ in range(1, W):                 # just in time: peer s's K,V in the order the attention blocks visit them; its flag is
+                lo = n_own + 2 * (s_ - 1)          # published by the NEXT launch of the chain as the first thing it does (no launch of its own)
                 it = dec_items(lo, lo + 2)
-                ok = ok and lib.cfx_plan_add_decompress(plan, cid, N, C, param, 2, (_lib.DecompItem * 2)(*it)) >= 0
-                ok = ok and lib.cfx_plan_add_flag_set(plan, s_) >= 0
+                op = lib.cfx_plan_add_decompress(plan, cid, N, C, param, 2, (_lib.DecompItem * 2)(*it))
+                ok = ok and op >= 0 and (s_ == 1 or lib.cfx_plan_set_pre_flag(plan, op, s_ - 1) == 0)
             if ef:                                 # the rank's own error-feedback update: nobody waits for it before the next step
                 it = dec_items(0, 2)
-                ok = ok and lib.cfx_plan_add_decompress(plan, cid, N, C, param, 2, (_lib.DecompItem * 2)(*it)) >= 0
+                op = lib.cfx_plan_add_decompress(plan, cid, N, C, param, 2, (_lib.DecompItem * 2)(*it))
+                ok = ok and op >= 0 and lib.cfx_plan_set_pre_flag(plan, op, W - 1) == 0
+            else:
+                ok = ok and lib.cfx_plan_add_flag_set(plan, W - 1) >= 0
             ok = ok and lib.cfx_plan_add_flag_set(plan, W) >= 0
             self._epoch = ctypes.c_uint(0)
         else:

@@ -27,7 +27,7 @@ static const char* const kid_names[KID_MAX] = {
     "gated layer launch (k_absmean_compress<bits,gated> / k_int2_compress_gated)"};
 
 struct ProfRec { int kid; hipEvent_t a, b; };
-#define CFX_RING_STREAMS 4       // ticket / gate rings of a context: one per stream that issues compress launches
+#define CFX_RING_STREAMS 8       // ticket / gate rings of a context: one per stream that issues compress launches
 
 struct cfx_ctx {
     int device;
@@ -43,6 +43,7 @@ struct cfx_ctx {
     unsigned tick_next[CFX_RING_STREAMS];
     void* ring_stream[CFX_RING_STREAMS];   // the stream each ring serves
     int n_ring_streams;
+    unsigned long long ring_used[CFX_RING_STREAMS], ring_clock;   // least recently used ring changes hands when all are taken
     int ring_cus[CFX_RING_STREAMS];        // CUs the stream's queue may use (CU-masked streams: fewer than the device has)
     // gated reconstruction: one monotonic arrival counter per ticket-ring slot (64 B apart, after the ticket blocks), the value
     // at which the slot's next launch opens, and one error word (a gate that never opened)
@@ -148,6 +149,7 @@ struct PlanOp {
     size_t bytes_per_rank;
     hipEvent_t ev_pre, ev_done;
     int ref;
+    int pre_flag;         // kind 1: flag this reconstruction launch publishes FIRST (the epoch), or -1
 };
 struct PipeSched;
 struct cfx_plan {
@@ -183,6 +185,8 @@ struct PipeSched {
 #define CFX_HIDDEN __attribute__((visibility("hidden")))
 CFX_HIDDEN bool cfx_i_shape_ok(int codec, int N, int C, int param);
 CFX_HIDDEN size_t cfx_i_ws_words(int codec, int N, int C);
+CFX_HIDDEN int cfx_i_decompress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items, void* stream,
+                                     unsigned* pre, unsigned pre_val);
 CFX_HIDDEN int cfx_i_compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                                    int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
                                    void* workspace, size_t workspace_bytes, void* stream);

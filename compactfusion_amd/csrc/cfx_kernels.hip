@@ -443,7 +443,9 @@ __device__ __forceinline__ void binary_dequant_body(const cfx_decomp_item& it, i
     }
 }
 
-__global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, int C, int R) {
+__global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, int C, int R, unsigned* pre, unsigned pre_val) {
+    // lane: publish `pre` first - the launch in front of this one in the stream (the previous peer's reconstruction) has finished
+    if (pre && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) st_wt(pre, pre_val);
     binary_dequant_body<WAVES>(batch.it[blockIdx.z], N, C, R, blockIdx.x, blockIdx.y);
 }
 
@@ -1103,7 +1105,9 @@ __global__ __launch_bounds__(NTHR) void k_int2_quant(BatchC batch, int N, int C,
 }
 
 // 2-bit dequant + base add        replaces _int2_dequant_fastpath (fastpath.py:672-741)
-__global__ __launch_bounds__(NTHR) void k_int2_dequant(BatchD batch, int N, int C, int R) {
+__global__ __launch_bounds__(NTHR) void k_int2_dequant(BatchD batch, int N, int C, int R, unsigned* pre, unsigned pre_val) {
+    // lane: publish `pre` first - the launch in front of this one in the stream (the previous peer's reconstruction) has finished
+    if (pre && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) st_wt(pre, pre_val);
     const cfx_decomp_item it = batch.it[blockIdx.z];
     const TileCoord t = tile_coord(N, C, R);
     const int C4 = C >> 2;
@@ -1457,7 +1461,9 @@ __global__ __launch_bounds__(NTHR) void k_int8_quant(BatchC batch, int N, int C,
     }
 }
 
-__global__ __launch_bounds__(NTHR) void k_int8_dequant(BatchD batch, int N, int C, int R) {
+__global__ __launch_bounds__(NTHR) void k_int8_dequant(BatchD batch, int N, int C, int R, unsigned* pre, unsigned pre_val) {
+    // lane: publish `pre` first - the launch in front of this one in the stream (the previous peer's reconstruction) has finished
+    if (pre && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) st_wt(pre, pre_val);
     const cfx_decomp_item it = batch.it[blockIdx.z];
     const TileCoord t = tile_coord(N, C, R);
     const signed char* q = (const signed char*)it.packet;
@@ -1567,7 +1573,9 @@ __global__ __launch_bounds__(NTHR) void k_int4_quant(BatchC batch, int N, int C,
     }
 }
 
-__global__ __launch_bounds__(NTHR) void k_int4_dequant(BatchD batch, int N, int C, int R) {
+__global__ __launch_bounds__(NTHR) void k_int4_dequant(BatchD batch, int N, int C, int R, unsigned* pre, unsigned pre_val) {
+    // lane: publish `pre` first - the launch in front of this one in the stream (the previous peer's reconstruction) has finished
+    if (pre && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) st_wt(pre, pre_val);
     const cfx_decomp_item it = batch.it[blockIdx.z];
     const TileCoord t = tile_coord(N, C, R);
     const unsigned char* q = (const unsigned char*)it.packet;
@@ -1685,7 +1693,9 @@ __global__ __launch_bounds__(256) void k_topk_compress(BatchC batch, size_t E, i
 }
 
 template <int M>
-__global__ __launch_bounds__(256) void k_topk_decompress(BatchD batch, size_t E) {
+__global__ __launch_bounds__(256) void k_topk_decompress(BatchD batch, size_t E, unsigned* pre, unsigned pre_val) {
+    // lane: publish `pre` first - the launch in front of this one in the stream (the previous peer's reconstruction) has finished
+    if (pre && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) st_wt(pre, pre_val);
     const cfx_decomp_item it = batch.it[blockIdx.y];
     const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (e >= E) return;
@@ -1848,6 +1858,8 @@ cfx_ctx* cfx_create(int device) {
     c->tick = nullptr;
     memset(c->tick_next, 0, sizeof(c->tick_next));
     c->n_ring_streams = 0;
+    c->ring_clock = 0;
+    memset(c->ring_used, 0, sizeof(c->ring_used));
     c->dbg_stamps = nullptr;
     c->gate = nullptr;
     c->gate_err = nullptr;
@@ -1991,7 +2003,9 @@ size_t cfx_workspace_bytes(int codec, int N, int C, int param, int batch) {
 }
 
 
-int cfx_decompress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items, void* stream) {
+// pre != NULL: the launch first publishes pre_val at *pre (exchange lane: "the reconstruction in front of this one is complete")
+static int decompress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items, void* stream,
+                           unsigned* pre, unsigned pre_val) {
     if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "decompress: null ctx/items");
     if (batch < 1 || batch > CFX_MAX_BATCH) return fail(ctx, CFX_ERR_BATCH, "decompress: batch out of range");
     if (!shape_ok(codec, N, C, param)) return fail(ctx, codec >= 1 && codec <= 5 ? CFX_ERR_SHAPE : CFX_ERR_CODEC, "decompress: bad codec/shape");
@@ -2006,23 +2020,27 @@ int cfx_decompress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int b
     const int R = auto_rows(ctx, N, C, batch, false);
     const dim3 grid((C + TILE_C - 1) / TILE_C, (N + R - 1) / R, batch);
     switch (codec) {
-        case CFX_CODEC_BINARY: LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
-        case CFX_CODEC_INT2: LAUNCH(ctx, KID_INT2_DEQUANT, s, k_int2_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
-        case CFX_CODEC_INT4: LAUNCH(ctx, KID_INT4_DEQUANT, s, k_int4_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
-        case CFX_CODEC_INT8: LAUNCH(ctx, KID_INT8_DEQUANT, s, k_int8_dequant, grid, dim3(NTHR), 0, s, b, N, C, R); break;
+        case CFX_CODEC_BINARY: LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant, grid, dim3(NTHR), 0, s, b, N, C, R, pre, pre_val); break;
+        case CFX_CODEC_INT2: LAUNCH(ctx, KID_INT2_DEQUANT, s, k_int2_dequant, grid, dim3(NTHR), 0, s, b, N, C, R, pre, pre_val); break;
+        case CFX_CODEC_INT4: LAUNCH(ctx, KID_INT4_DEQUANT, s, k_int4_dequant, grid, dim3(NTHR), 0, s, b, N, C, R, pre, pre_val); break;
+        case CFX_CODEC_INT8: LAUNCH(ctx, KID_INT8_DEQUANT, s, k_int8_dequant, grid, dim3(NTHR), 0, s, b, N, C, R, pre, pre_val); break;
         case CFX_CODEC_TOPK: {
             const size_t E = (size_t)N * C;
             const dim3 g((unsigned)((E / 8 + 255) / 256), batch);
             switch (param) {
-                case 1: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<1>, g, dim3(256), 0, s, b, E); break;
-                case 2: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<2>, g, dim3(256), 0, s, b, E); break;
-                case 4: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<4>, g, dim3(256), 0, s, b, E); break;
-                case 8: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<8>, g, dim3(256), 0, s, b, E); break;
-                default: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<16>, g, dim3(256), 0, s, b, E); break;
+                case 1: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<1>, g, dim3(256), 0, s, b, E, pre, pre_val); break;
+                case 2: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<2>, g, dim3(256), 0, s, b, E, pre, pre_val); break;
+                case 4: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<4>, g, dim3(256), 0, s, b, E, pre, pre_val); break;
+                case 8: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<8>, g, dim3(256), 0, s, b, E, pre, pre_val); break;
+                default: LAUNCH(ctx, KID_TOPK_DECOMPRESS, s, k_topk_decompress<16>, g, dim3(256), 0, s, b, E, pre, pre_val); break;
             }
         } break;
     }
     return check_launch(ctx, "decompress launch");
+}
+
+int cfx_decompress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items, void* stream) {
+    return decompress_impl(ctx, codec, N, C, param, batch, items, stream, nullptr, 0u);
 }
 
 // statistics tile height of the fused compress launch
@@ -2115,9 +2133,14 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
         for (int i = 0; i < ctx->n_ring_streams; ++i)
             if (ctx->ring_stream[i] == stream) { ring = i; break; }
         if (ring < 0) {
-            if (ctx->n_ring_streams == CFX_RING_STREAMS)
-                return fail(ctx, CFX_ERR_BATCH, "compress: a context serves at most 4 streams (create one cfx_ctx per further stream)");
-            ring = ctx->n_ring_streams++;
+            if (ctx->n_ring_streams < CFX_RING_STREAMS) ring = ctx->n_ring_streams++;
+            else {
+                // every ring is taken: the least recently used one changes hands.  The new owner continues at the ring's next slot, a
+                // full turn (256 launches) away from whatever its previous owner may still have in flight
+                ring = 0;
+                for (int i = 1; i < CFX_RING_STREAMS; ++i)
+                    if (ctx->ring_used[i] < ctx->ring_used[ring]) ring = i;
+            }
             ctx->ring_stream[ring] = stream;
             // CUs this stream's queue may use (hipExtStreamCreateWithCUMask): bounds what a launch can keep co-resident
             uint32_t m[16] = {0};
@@ -2130,6 +2153,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             ctx->ring_cus[ring] = (cus > 0 && cus < total) ? cus : total;
         }
         stream_cus = ctx->ring_cus[ring];
+        ctx->ring_used[ring] = ++ctx->ring_clock;
         slot = (unsigned)ring * TICK_RING + (ctx->tick_next[ring]++ % TICK_RING);
         tick = ctx->tick + (size_t)slot * CFX_MAX_BATCH * TICK_WORDS;
     }
@@ -2229,7 +2253,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                                codec == CFX_CODEC_INT2 ? 1 : 0, (const u64*)ws, wstride);
             if (n_ride) {
                 const int Rr = auto_rows(ctx, N, C, n_ride, false);
-                LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant, dim3(CB, (N + Rr - 1) / Rr, n_ride), dim3(NTHR), 0, s, rd, N, C, Rr);
+                LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant, dim3(CB, (N + Rr - 1) / Rr, n_ride), dim3(NTHR), 0, s, rd, N, C, Rr, (unsigned*)nullptr, 0u);
             }
         }
         if (codec == CFX_CODEC_INT2) {
@@ -2244,13 +2268,13 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                 BatchD d;
                 memset(&d, 0, sizeof(d));
                 for (int i = 0; i < batch; ++i) { d.it[i].packet = items[i].packet; d.it[i].base = items[i].base; d.it[i].recon = items[i].new_base; }
-                LAUNCH(ctx, KID_BINARY_EF, s, k_binary_dequant, gridq, dim3(NTHR), 0, s, d, N, C, Rq);
+                LAUNCH(ctx, KID_BINARY_EF, s, k_binary_dequant, gridq, dim3(NTHR), 0, s, d, N, C, Rq, (unsigned*)nullptr, 0u);
             }
         }
         if (n_gated && !(one_launch_1bit || (one_launch && codec == CFX_CODEC_INT2))) {
             const int Rg = auto_rows(ctx, N, C, n_gated, false);
-            if (codec == CFX_CODEC_BINARY) LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant, dim3(CB, (N + Rg - 1) / Rg, n_gated), dim3(NTHR), 0, s, gd, N, C, Rg);
-            else LAUNCH(ctx, KID_INT2_DEQUANT, s, k_int2_dequant, dim3(CB, (N + Rg - 1) / Rg, n_gated), dim3(NTHR), 0, s, gd, N, C, Rg);
+            if (codec == CFX_CODEC_BINARY) LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant, dim3(CB, (N + Rg - 1) / Rg, n_gated), dim3(NTHR), 0, s, gd, N, C, Rg, (unsigned*)nullptr, 0u);
+            else LAUNCH(ctx, KID_INT2_DEQUANT, s, k_int2_dequant, dim3(CB, (N + Rg - 1) / Rg, n_gated), dim3(NTHR), 0, s, gd, N, C, Rg, (unsigned*)nullptr, 0u);
         }
     } else {
         if (fused) {
@@ -2310,6 +2334,10 @@ int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base
 // ---- entry points for cfx_plan.hip (plan replay, exchange lane) ------------------------------------------------------------
 }  // extern "C"
 bool cfx_i_shape_ok(int codec, int N, int C, int param) { return shape_ok(codec, N, C, param); }
+int cfx_i_decompress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items, void* stream,
+                          unsigned* pre, unsigned pre_val) {
+    return decompress_impl(ctx, codec, N, C, param, batch, items, stream, pre, pre_val);
+}
 size_t cfx_i_ws_words(int codec, int N, int C) { return ws_words(codec, N, C); }
 int cfx_i_compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                         int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,

@@ -180,6 +180,7 @@ int cfx_plan_add_decompress(cfx_plan* p, int codec, int N, int C, int param, int
     PlanOp* o = plan_push(p);
     memset(o, 0, sizeof(*o));
     o->kind = 1; o->codec = codec; o->N = N; o->C = C; o->param = param; o->batch = batch;
+    o->pre_flag = -1;
     memcpy(o->d, items, sizeof(cfx_decomp_item) * batch);
     return p->n - 1;
 }
@@ -194,6 +195,7 @@ int cfx_plan_copy_op(cfx_plan* dst, const cfx_plan* src, int op) {
     PlanOp* o = plan_push(dst);
     *o = tmp;
     o->ev_pre = o->ev_done = nullptr;      // events belong to the op they were created for
+    o->pre_flag = -1;                      // ... and flags to the plan
     return dst->n - 1;
 }
 
@@ -301,7 +303,10 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
         int rc = CFX_OK;
         switch (o->kind) {
             case 0: rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, o->n_ride, o->d, o->n_gated, o->g, o->ws, o->ws_bytes, stream); break;
-            case 1: rc = cfx_decompress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->batch, o->d, stream); break;
+            case 1:
+                rc = cfx_i_decompress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->batch, o->d, stream,
+                                           o->pre_flag >= 0 ? p->flags + (size_t)o->pre_flag * FLAG_WORDS : nullptr, p->epoch);
+                break;
             case 2:
             case 4: {
                 // exchange stream picks up after everything enqueued so far on the main stream (the packets are complete)
@@ -398,6 +403,15 @@ static int plan_add_flag_op(cfx_plan* p, int kind, int flag) {
     memset(o, 0, sizeof(*o));
     o->kind = kind; o->ref = flag;
     return p->n - 1;
+}
+// The reconstruction op `op` publishes flag `flag` as the FIRST thing its launch does: the launch in front of it in the stream has
+// finished by then (in-order stream), so this is "set flag after the previous op" without a launch of its own.
+int cfx_plan_set_pre_flag(cfx_plan* p, int op, int flag) {
+    if (!p) return CFX_ERR_NULL;
+    if (op < 0 || op >= p->n || p->ops[op].kind != 1) return fail(p->ctx, CFX_ERR_BATCH, "plan: a pre-flag belongs to a reconstruction op");
+    if (!p->flags || flag < 0 || flag >= p->n_flags) return fail(p->ctx, CFX_ERR_BATCH, "plan: flag index out of range (cfx_plan_flags first)");
+    p->ops[op].pre_flag = flag;
+    return CFX_OK;
 }
 int cfx_plan_add_flag_wait(cfx_plan* p, int flag) { return plan_add_flag_op(p, 5, flag); }
 int cfx_plan_add_flag_set(cfx_plan* p, int flag) { return plan_add_flag_op(p, 6, flag); }

@@ -148,7 +148,8 @@ int cfx_gate_errors(cfx_ctx* ctx);
  * counters; replaces the eager scale prologue of fastpath.py:150-166 / compress_quantize.py:452-463 and the separate
  * finalize kernel).  The tickets live in device memory owned by the context: cfx_prepare allocates them (idempotent;
  * otherwise the first compress call does - call it before capturing compress calls into a hipGraph).  Compress calls
- * on one context may come from up to 4 streams (a ticket ring per stream; launches of one stream are in order).
+ * on one context may come from several streams (a ticket ring per stream, 8 rings, the least recently used one is reassigned;
+ * launches of one stream are in order).
  * cfx_set_fused_finalize(ctx, 0) selects the two-kernel sequence (statistics, finalize); results are bit-identical. */
 int cfx_prepare(cfx_ctx* ctx);
 int cfx_set_fused_finalize(cfx_ctx* ctx, int on);
@@ -273,6 +274,8 @@ int       cfx_plan_join(cfx_plan* plan, void* main_stream);
 void*     cfx_plan_flags(cfx_plan* plan, int n);
 int       cfx_plan_add_flag_wait(cfx_plan* plan, int flag);
 int       cfx_plan_add_flag_set(cfx_plan* plan, int flag);
+int       cfx_plan_set_pre_flag(cfx_plan* plan, int op, int flag);   /* reconstruction op `op` sets `flag` as the first thing its launch
+                                                                       * does (= after the op in front of it, without a launch of its own) */
 unsigned  cfx_plan_epoch(const cfx_plan* plan);
 int       cfx_plan_run_lane(cfx_plan* plan, int first_op, int n_ops, const void* const* xs, int n_xs, int ready_flag,
                             void* compute_stream, unsigned* epoch_out);
