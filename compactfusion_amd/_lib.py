@@ -107,6 +107,7 @@ SYMBOLS = [
     ("cfx_plan_epoch", ctypes.c_uint, [ctypes.c_void_p]),
     ("cfx_plan_run_lane", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]),
+    ("cfx_plan_lane_begin", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint)]),
     ("cfx_flag_set", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]),
     ("cfx_flag_wait", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]),
     ("cfx_stream_create_masked", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),

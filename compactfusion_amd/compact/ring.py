@@ -195,9 +195,10 @@ class _SteadyLayer:
         if ex.lane:
             # exchange lane: ONE native call issues the layer's whole chain on the exchange stream; the compute stream never sees
             # an event - the merge launch of block s also waits (in-kernel, on a flag) for peer s+1's reconstruction
-            epoch = ex.run_lane(k, v, sh)
+            epoch = ex.lane_begin(sh)                       # "K, V exist" on the compute stream ...
+            bo, bl = block_attention(q, k, v, 0.0, softmax_scale, causal=False)     # ... the local block behind it ...
+            ex.run_lane(k, v, None)                        # ... and the chain's dozen launches are issued while that block runs
             cm._current_cache_key = self.last_key
-            bo, bl = block_attention(q, k, v, 0.0, softmax_scale, causal=False)
             out, lse = update_out_and_lse(None, None, bo, bl, wait=(ex.flag_ptr(1), epoch))
             last = self.world - 1
             for s, (kk, vv) in enumerate(ex.peer_views, start=1):
@@ -384,8 +385,15 @@ class _LayerExchange:
     def flag_ptr(self, i: int) -> int:
         return self._flags + 64 * i
 
+    def lane_begin(self, sh) -> int:
+        rc = self._lib.cfx_plan_lane_begin(self.plan, 0, sh, self._epoch)
+        if rc != 0:
+            raise RuntimeError("native exchange lane failed: " + (self._lib.cfx_last_error_string(self._ctx) or b"").decode())
+        return self._epoch.value
+
     def run_lane(self, k, v, sh) -> int:
-        """The layer's whole chain on the exchange lane, one host call; returns the epoch its flags will carry."""
+        """The layer's whole chain on the exchange lane, one host call; returns the epoch its flags will carry.  sh = None: the
+        ready flag was already launched (`lane_begin`)."""
         self._xs[0], self._xs[1] = k.data_ptr(), v.data_ptr()
         rc = self._lib.cfx_plan_run_lane(self.plan, 0, self._n_ops, self._xs, 2, 0, sh, self._epoch)
         if rc != 0:

@@ -44,7 +44,9 @@ struct cfx_ctx {
     void* ring_stream[CFX_RING_STREAMS];   // the stream each ring serves
     int n_ring_streams;
     unsigned long long ring_used[CFX_RING_STREAMS], ring_clock;   // least recently used ring changes hands when all are taken
-    int ring_cus[CFX_RING_STREAMS];        // CUs the stream's queue may use (CU-masked streams: fewer than the device has)
+    void* cu_cache_stream[8];              // stream -> CUs its queue may use (CU-masked streams: fewer than the device has)
+    int cu_cache_n[8], n_cu_cache;
+    unsigned cu_cache_next;
     // gated reconstruction: one monotonic arrival counter per ticket-ring slot (64 B apart, after the ticket blocks), the value
     // at which the slot's next launch opens, and one error word (a gate that never opened)
     unsigned* gate;

@@ -399,7 +399,8 @@ __global__ __launch_bounds__(1024) void k_absmean_finalize(BatchC batch, int N, 
 // 1-bit dequant + base add        replaces _binary_dequant_fastpath (fastpath.py:277-367) AND the
 // UPDATE_CACHE branch of _binary_quant_fastpath (fastpath.py:88-120): out = base + (2b-1)*fp16(u[n]*v[c])
 // ---------------------------------------------------------------------------------------------------
-template <int NW = WAVES>
+// UN = rows a wave keeps in flight (2 on the whole chip; 4 on a CU-masked lane, where bytes in flight per CU bound the rate)
+template <int NW = WAVES, int UN = UNROLL>
 __device__ __forceinline__ void binary_dequant_body(const cfx_decomp_item& it, int N, int C, int R, int tile_x, int tile_y) {
     const TileCoord t = tile_coord_at(tile_x, tile_y, N, C, R);
     const unsigned char* pk = (const unsigned char*)it.packet;
@@ -412,12 +413,12 @@ __device__ __forceinline__ void binary_dequant_body(const cfx_decomp_item& it, i
     h16x8 v8 = (h16x8)(h16)0;
     if (t.act) v8 = ld8_tail(V + t.c, val16);
 
-    for (int r = t.r0 + t.w; r < t.r1; r += NW * UNROLL) {
-        h16x8 bv[UNROLL];
-        unsigned by[UNROLL];
-        h16 u[UNROLL];
+    for (int r = t.r0 + t.w; r < t.r1; r += NW * UN) {
+        h16x8 bv[UN];
+        unsigned by[UN];
+        h16 u[UN];
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) {
+        for (int j = 0; j < UN; ++j) {
             const int rr = r + NW * j;
             bv[j] = (h16x8)(h16)0;
             by[j] = 0;
@@ -429,7 +430,7 @@ __device__ __forceinline__ void binary_dequant_body(const cfx_decomp_item& it, i
             }
         }
 #pragma unroll
-        for (int j = 0; j < UNROLL; ++j) {
+        for (int j = 0; j < UN; ++j) {
             const int rr = r + NW * j;
             if (rr < t.r1 && t.act) {
                 const h16x8 s = v8 * u[j];                       // fp16(u*v), one rounding (fastpath.py:109,328)
@@ -443,10 +444,11 @@ __device__ __forceinline__ void binary_dequant_body(const cfx_decomp_item& it, i
     }
 }
 
+template <int UN>
 __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, int C, int R, unsigned* pre, unsigned pre_val) {
     // lane: publish `pre` first - the launch in front of this one in the stream (the previous peer's reconstruction) has finished
     if (pre && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) st_wt(pre, pre_val);
-    binary_dequant_body<WAVES>(batch.it[blockIdx.z], N, C, R, blockIdx.x, blockIdx.y);
+    binary_dequant_body<WAVES, UN>(batch.it[blockIdx.z], N, C, R, blockIdx.x, blockIdx.y);
 }
 
 // Gated reconstruction: the same arithmetic for a packet that workgroups of THIS launch are still producing (the compress group
@@ -1858,6 +1860,8 @@ cfx_ctx* cfx_create(int device) {
     c->tick = nullptr;
     memset(c->tick_next, 0, sizeof(c->tick_next));
     c->n_ring_streams = 0;
+    c->n_cu_cache = 0;
+    c->cu_cache_next = 0;
     c->ring_clock = 0;
     memset(c->ring_used, 0, sizeof(c->ring_used));
     c->dbg_stamps = nullptr;
@@ -2003,6 +2007,25 @@ size_t cfx_workspace_bytes(int codec, int N, int C, int param, int batch) {
 }
 
 
+// CUs the queue of `stream` may use (hipExtStreamCreateWithCUMask; an ordinary stream has them all).  Cached per stream handle:
+// tile shapes are chosen for the CUs a launch will actually get (an exchange lane has 32, not 256).
+static int stream_cu_count(cfx_ctx* ctx, void* stream) {
+    for (int i = 0; i < ctx->n_cu_cache; ++i)
+        if (ctx->cu_cache_stream[i] == stream) return ctx->cu_cache_n[i];
+    int total = 0;
+    (void)hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    int cus = 0;
+    uint32_t m[16] = {0};
+    if (stream && hipExtStreamGetCUMask((hipStream_t)stream, 16, m) == hipSuccess)
+        for (int i = 0; i < 16; ++i) cus += __builtin_popcount(m[i]);
+    else (void)hipGetLastError();
+    const int n = (cus > 0 && cus < total) ? cus : total;
+    const int slot = ctx->n_cu_cache < 8 ? ctx->n_cu_cache++ : (int)(ctx->cu_cache_next++ % 8);
+    ctx->cu_cache_stream[slot] = stream;
+    ctx->cu_cache_n[slot] = n;
+    return n;
+}
+
 // pre != NULL: the launch first publishes pre_val at *pre (exchange lane: "the reconstruction in front of this one is complete")
 static int decompress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items, void* stream,
                            unsigned* pre, unsigned pre_val) {
@@ -2020,7 +2043,13 @@ static int decompress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int
     const int R = auto_rows(ctx, N, C, batch, false);
     const dim3 grid((C + TILE_C - 1) / TILE_C, (N + R - 1) / R, batch);
     switch (codec) {
-        case CFX_CODEC_BINARY: LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant, grid, dim3(NTHR), 0, s, b, N, C, R, pre, pre_val); break;
+        case CFX_CODEC_BINARY:
+            if (stream_cu_count(ctx, stream) < 128) {
+                // a CU-masked lane is bound by the bytes each CU keeps in flight: 4 rows per wave instead of 2
+                const int R4 = WAVES * 4;
+                LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant<4>, dim3(grid.x, (N + R4 - 1) / R4, batch), dim3(NTHR), 0, s, b, N, C, R4, pre, pre_val);
+            } else LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant<UNROLL>, grid, dim3(NTHR), 0, s, b, N, C, R, pre, pre_val);
+            break;
         case CFX_CODEC_INT2: LAUNCH(ctx, KID_INT2_DEQUANT, s, k_int2_dequant, grid, dim3(NTHR), 0, s, b, N, C, R, pre, pre_val); break;
         case CFX_CODEC_INT4: LAUNCH(ctx, KID_INT4_DEQUANT, s, k_int4_dequant, grid, dim3(NTHR), 0, s, b, N, C, R, pre, pre_val); break;
         case CFX_CODEC_INT8: LAUNCH(ctx, KID_INT8_DEQUANT, s, k_int8_dequant, grid, dim3(NTHR), 0, s, b, N, C, R, pre, pre_val); break;
@@ -2044,7 +2073,7 @@ int cfx_decompress_batch(cfx_ctx* ctx, int codec, int N, int C, int param, int b
 }
 
 // statistics tile height of the fused compress launch
-static int fused_rows(const cfx_ctx* ctx, int N, int C, int batch) {
+static int fused_rows(const cfx_ctx* ctx, int N, int C, int batch, int cus) {
     if (ctx->stats_rows > 0) return (ctx->stats_rows + 15) & ~15;
     // 8 waves x 4 rows in flight = 32 rows per wave step; taller tiles (fewer partials per column for the last arriver to
     // reduce) as long as >= 768 workgroups remain, as in auto_rows
@@ -2052,6 +2081,12 @@ static int fused_rows(const cfx_ctx* ctx, int N, int C, int batch) {
     const int cands[2] = {128, 64};
     for (int i = 0; i < 2; ++i)
         if ((long)CB * ((N + cands[i] - 1) / cands[i]) * batch >= 768) return cands[i];
+    if (cus < 128) {
+        // a CU-masked lane: as many tiles as fit the lane in ONE round (3 workgroups of this kernel per CU), each a few trips of the
+        // row loop - measured on 32 CUs, K,V of the FLUX shard: 204 tiles of 32 rows = 3 rounds of latency-bound workgroups 25.7 us
+        for (int R = FUSED_NW * UNROLL_S; R <= 512; R += FUSED_NW * UNROLL_S)
+            if ((long)CB * ((N + R - 1) / R) * batch <= 3L * cus) return R;
+    }
     return FUSED_NW * UNROLL_S;
 }
 
@@ -2126,7 +2161,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
     // stream has cycled back to)
     unsigned* tick = nullptr;
     unsigned slot = 0;
-    int stream_cus = 0;
+    const int stream_cus = stream_cu_count(ctx, stream);
     if (fused) {
         if (!ctx->tick && cfx_prepare(ctx) != CFX_OK) return CFX_ERR_LAUNCH;
         int ring = -1;
@@ -2142,24 +2177,14 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                     if (ctx->ring_used[i] < ctx->ring_used[ring]) ring = i;
             }
             ctx->ring_stream[ring] = stream;
-            // CUs this stream's queue may use (hipExtStreamCreateWithCUMask): bounds what a launch can keep co-resident
-            uint32_t m[16] = {0};
-            int cus = 0;
-            if (stream && hipExtStreamGetCUMask((hipStream_t)stream, 16, m) == hipSuccess)
-                for (int i = 0; i < 16; ++i) cus += __builtin_popcount(m[i]);
-            else (void)hipGetLastError();
-            int total = 0;
-            (void)hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, ctx->device);
-            ctx->ring_cus[ring] = (cus > 0 && cus < total) ? cus : total;
         }
-        stream_cus = ctx->ring_cus[ring];
         ctx->ring_used[ring] = ++ctx->ring_clock;
         slot = (unsigned)ring * TICK_RING + (ctx->tick_next[ring]++ % TICK_RING);
         tick = ctx->tick + (size_t)slot * CFX_MAX_BATCH * TICK_WORDS;
     }
     if (ctx->gate_err && *(volatile unsigned*)ctx->gate_err)
         return fail(ctx, CFX_ERR_GATE, "compress: an earlier gate / flag wait on this context timed out (cfx_gate_errors reads and clears the count)");
-    const int R = fused ? fused_rows(ctx, N, C, batch) : auto_rows(ctx, N, C, batch, true);
+    const int R = fused ? fused_rows(ctx, N, C, batch, stream_cus) : auto_rows(ctx, N, C, batch, true);
     const int P = (N + R - 1) / R;
     // one launch only for explicit gated items: folding the error-feedback update of a PLAIN compress call into the launch the same
     // way was measured slower (K,V of the FLUX shard: 20.8 vs 19.2 us 1-bit, 19.9 vs 18.6 us 2-bit) - the gate hop and the write tail
@@ -2253,7 +2278,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                                codec == CFX_CODEC_INT2 ? 1 : 0, (const u64*)ws, wstride);
             if (n_ride) {
                 const int Rr = auto_rows(ctx, N, C, n_ride, false);
-                LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant, dim3(CB, (N + Rr - 1) / Rr, n_ride), dim3(NTHR), 0, s, rd, N, C, Rr, (unsigned*)nullptr, 0u);
+                LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant<UNROLL>, dim3(CB, (N + Rr - 1) / Rr, n_ride), dim3(NTHR), 0, s, rd, N, C, Rr, (unsigned*)nullptr, 0u);
             }
         }
         if (codec == CFX_CODEC_INT2) {
@@ -2268,12 +2293,12 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                 BatchD d;
                 memset(&d, 0, sizeof(d));
                 for (int i = 0; i < batch; ++i) { d.it[i].packet = items[i].packet; d.it[i].base = items[i].base; d.it[i].recon = items[i].new_base; }
-                LAUNCH(ctx, KID_BINARY_EF, s, k_binary_dequant, gridq, dim3(NTHR), 0, s, d, N, C, Rq, (unsigned*)nullptr, 0u);
+                LAUNCH(ctx, KID_BINARY_EF, s, k_binary_dequant<UNROLL>, gridq, dim3(NTHR), 0, s, d, N, C, Rq, (unsigned*)nullptr, 0u);
             }
         }
         if (n_gated && !(one_launch_1bit || (one_launch && codec == CFX_CODEC_INT2))) {
             const int Rg = auto_rows(ctx, N, C, n_gated, false);
-            if (codec == CFX_CODEC_BINARY) LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant, dim3(CB, (N + Rg - 1) / Rg, n_gated), dim3(NTHR), 0, s, gd, N, C, Rg, (unsigned*)nullptr, 0u);
+            if (codec == CFX_CODEC_BINARY) LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_dequant<UNROLL>, dim3(CB, (N + Rg - 1) / Rg, n_gated), dim3(NTHR), 0, s, gd, N, C, Rg, (unsigned*)nullptr, 0u);
             else LAUNCH(ctx, KID_INT2_DEQUANT, s, k_int2_dequant, dim3(CB, (N + Rg - 1) / Rg, n_gated), dim3(NTHR), 0, s, gd, N, C, Rg, (unsigned*)nullptr, 0u);
         }
     } else {

@@ -418,6 +418,18 @@ int cfx_plan_add_flag_set(cfx_plan* p, int flag) { return plan_add_flag_op(p, 6,
 
 unsigned cfx_plan_epoch(const cfx_plan* p) { return p ? p->epoch : 0u; }
 
+// Advance the epoch and publish "the activations exist" (flag `ready_flag`) behind whatever the caller has enqueued on the compute
+// stream so far - the kernels that produce K, V.  Split from cfx_plan_run_lane so that the caller can enqueue the local attention
+// block BETWEEN the two: the chain's host issue (a dozen launches) then overlaps GPU work instead of delaying it.
+int cfx_plan_lane_begin(cfx_plan* p, int ready_flag, void* compute_stream, unsigned* epoch_out) {
+    if (!p) return CFX_ERR_NULL;
+    if (!p->flags || ready_flag < 0 || ready_flag >= p->n_flags) return fail(p->ctx, CFX_ERR_BATCH, "plan: ready flag index out of range");
+    ++p->epoch;
+    if (epoch_out) *epoch_out = p->epoch;
+    hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, (hipStream_t)compute_stream, p->flags + (size_t)ready_flag * FLAG_WORDS, p->epoch);
+    return check_launch(p->ctx, "ready flag launch");
+}
+
 int cfx_plan_run_lane(cfx_plan* p, int first_op, int n_ops, const void* const* xs, int n_xs, int ready_flag, void* compute_stream,
                       unsigned* epoch_out) {
     if (!p) return CFX_ERR_NULL;
@@ -434,12 +446,10 @@ int cfx_plan_run_lane(cfx_plan* p, int first_op, int n_ops, const void* const* x
             p->ops[op].c[i].x = xs[i];
         }
     }
-    ++p->epoch;
-    if (epoch_out) *epoch_out = p->epoch;
-    // "the activations exist": behind whatever the caller enqueued on the compute stream so far (the kernels that produce K, V)
-    hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, (hipStream_t)compute_stream, p->flags + (size_t)ready_flag * FLAG_WORDS, p->epoch);
-    const int rl = check_launch(p->ctx, "ready flag launch");
-    if (rl != CFX_OK) return rl;
+    if (compute_stream) {
+        const int rb = cfx_plan_lane_begin(p, ready_flag, compute_stream, epoch_out);
+        if (rb != CFX_OK) return rb;
+    } else if (epoch_out) *epoch_out = p->epoch;       // cfx_plan_lane_begin was called separately
     return plan_run_impl(p, first_op, n_ops, (void*)p->side, true);
 }
 

@@ -279,6 +279,10 @@ int       cfx_plan_set_pre_flag(cfx_plan* plan, int op, int flag);   /* reconstr
 unsigned  cfx_plan_epoch(const cfx_plan* plan);
 int       cfx_plan_run_lane(cfx_plan* plan, int first_op, int n_ops, const void* const* xs, int n_xs, int ready_flag,
                             void* compute_stream, unsigned* epoch_out);
+/* cfx_plan_run_lane's first half on its own: advance the epoch and launch "set flag `ready_flag`" on `compute_stream`.  A later
+ * cfx_plan_run_lane with compute_stream = NULL then only replays the op range (same epoch): the caller enqueues the local attention
+ * block in between, so the chain's host issue overlaps GPU work. */
+int       cfx_plan_lane_begin(cfx_plan* plan, int ready_flag, void* compute_stream, unsigned* epoch_out);
 int       cfx_flag_set(cfx_ctx* ctx, void* flag, unsigned value, void* stream);
 int       cfx_flag_wait(cfx_ctx* ctx, const void* flag, unsigned value, void* stream);
 int       cfx_stream_create_masked(cfx_ctx* ctx, int first_cu, int n_cus, void** stream);
