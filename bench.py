@@ -9,19 +9,21 @@ ring-attention sequence parallelism of logical degree 8 with the 1-bit residual 
 57 attention layers x {K, V}, shard (N, C) = (544, 3072) fp16.  The step is replayed LAYER BY LAYER IN ORDER, the way a
 model runs it (layer l+1's K,V only exist after layer l's attention, reference xfuser/compact/ring.py:188-206): layer l+1's
 compress cannot start before layer l's reconstruction has finished (a kernel boundary), nothing is reordered across layers.
-Per layer, at N = 1 (default --own-ef gated), ONE launch (cfx_compress_batch_gated):
-  * compress the rank's K and V against its error-feedback state: statistics + sign bits + in-launch finalize of the scales;
-  * in the same launch, behind an in-launch arrival gate, everything the layer's packets feed on this rank: the own
-    error-feedback update and the 7 looped-back logical peers' K,V (16 tensors) - their workgroups pull the state tiles into
-    registers while the scale reduction (pure latency) completes, wait for the gate, finish from registers.
-With a collective between compress and reconstruction (N > 1; --own-ef ride at N = 1) a layer is two launches:
-  A. compress K,V (k_absmean_compress); the PREVIOUS layer's own error-feedback update rides in the same launch - nothing reads
-     that state before the next denoise step (the local attention block uses the uncompressed K,V, ring.py:207-209),
-  X. exchange the packets (N live ranks all-gather over RCCL, one collective per layer, issued natively in order; the 8-N
-     missing logical peers are looped back from the rank's own packet, so the per-GPU codec work is IDENTICAL for every
-     N = weak scaling; at N = 8 this is exactly the real exchange, at N = 1 it is the codec path alone),
+Per layer (default; the SAME schedule at every N):
+  A. compress K,V (k_absmean_compress: statistics + sign bits + in-launch finalize of the scales), the packets written straight
+     into the rank's slot of the gather buffer; the PREVIOUS layer's own error-feedback update rides in the same launch - nothing
+     reads that state before the next denoise step (the local attention block uses the uncompressed K,V, ring.py:207-209),
+  X. exchange the packets: ncclAllGather, in place, issued by libcfx's own RCCL communicator from the native plan in stream order
+     (N live ranks gather for real; the 8-N missing logical peers are looped back from the rank's own slot, so the per-GPU codec
+     work is IDENTICAL for every N = weak scaling; at N = 8 this is exactly the real exchange, at N = 1 RCCL's one-rank in-place
+     all-gather has nothing to move: the step is what N = 8 executes minus the wire),
   B. ONE launch reconstructs the 7 peers' K,V (14 tensors, k_binary_dequant) onto their state arenas (the last layer's
      launch also carries that layer's own error-feedback update).
+`loopback_one_launch_per_layer` (secondary, N = 1): the layer as ONE launch (cfx_compress_batch_gated: reconstruction behind an
+in-launch arrival gate) - only possible when the packets a reconstruction needs are produced by the same launch, i.e. with
+looped-back peers and NO collective in between; never `value`.
+`overlap_with_attention` (N = 1): SURVEY 8d protocol 2 - the deployable path (compact_fwd on the exchange lane) beside real SDPA
+attention: what the exchange adds to a model step (tools/overlap_bench.py, run in-process after the timed legs).
 Inputs are synthetic and already resident in HBM; the state arenas (3.0 GB) + inputs (0.76 GB) dwarf the 256 MB
 Infinity Cache, so every step streams from HBM (cold numbers).
 
@@ -30,11 +32,10 @@ value = whole-job fp16 activation bytes compressed + reconstructed per second (G
 `pure_exchange_upper_bound` = the same step through cfx_plan_run_pipelined, which DOES reorder across layers (statistics of
         layers j+7.. beside the reconstruction of layers j..): only legal because the synthetic inputs of all layers are resident;
         a model cannot run it.  Reported as a secondary figure, never as `value`.
-roofline = the dominant kernel of the in-order step - the layer's one launch (2 x 6.125 + 14 x 4.125 B/element, SURVEY.md §8d;
-        with two launches per layer: k_binary_dequant, 4.125 B/element x the tensors of a launch) / average launch duration from
-        hipEvents attached to the dispatch on the launch stream inside the timed region; `roofline.step` prices the WHOLE step
+roofline = the dominant kernel of the in-order step - launch B, k_binary_dequant, 4.125 B/element x the tensors of a launch
+         / average launch duration from hipEvents attached to the dispatch on the launch stream inside the timed
+        region; `roofline.compress_launch` = launch A against 6.125 B/element; `roofline.step` prices the WHOLE step
         with 6.125 B/element for the rank's own tensors (compress + error feedback) and 4.125 for the peers'.
-`two_launches_per_layer` = the same layer-ordered step as A ; B (what a collective in between forces), a secondary figure.
 cpu_baseline = the C oracle (oracle/cfx_oracle.c, OpenMP) timed on this box's host cores on one layer of the same
         workload; reported baseline only.
 """
@@ -67,7 +68,7 @@ def parse():
     ap.add_argument("--replay", choices=["inorder", "pipelined"], default="inorder",
                     help="inorder (default, the deployable schedule): cfx_plan_run, two launches per layer one after the other; "
                          "pipelined: cfx_plan_run_pipelined, reorders work ACROSS layers (resident synthetic inputs only)")
-    ap.add_argument("--own-ef", choices=["gated", "ride", "inline"], default="gated",
+    ap.add_argument("--own-ef", choices=["gated", "ride", "inline"], default="ride",
                     help="inorder replay. gated (1-bit, no collective between compress and reconstruction, i.e. N = 1): ONE launch per layer - "
                          "the reconstruction of everything whose packet the layer's compress produces (own error feedback + looped-back peers) "
                          "runs in the compress launch behind an arrival gate (cfx_compress_batch_gated); with a collective in between it "
@@ -82,6 +83,18 @@ def parse():
     ap.add_argument("--codec", choices=["binary", "int2"], default="binary",
                     help="binary (default, the judged workload: BASELINE.json configs[2]); int2 = the reference's other fused preset "
                          "(examples/configs.py:51-61), in-order replay only, reported as a secondary line")
+    ap.add_argument("--no-collective", action="store_true",
+                    help="N = 1 debug: build the step WITHOUT the collective between compress and reconstruction (the codec launches alone; "
+                         "--own-ef gated needs it: one launch per layer only exists when nothing sits between the two)")
+    ap.add_argument("--emulate-live", type=int, default=0,
+                    help="N = 1 debug: lay the exchange out for this many live ranks (2..8) over a LOOP-BACK collective library (--rccl-lib: "
+                         "tests/fake_rccl in loopback mode, every peer is this rank) - exercises the N > 1 plans, the raw baseline and the "
+                         "xgmi object on one GPU; the figures are not link measurements")
+    ap.add_argument("--rccl-lib", default=None, help="debug: collective library to load instead of the RCCL the process already uses")
+    ap.add_argument("--no-raw-baseline", action="store_true", help="N > 1: skip the uncompressed all-gather legs")
+    ap.add_argument("--overlap-steps", type=int, default=5,
+                    help="N = 1: after the timed legs, also run SURVEY 8d protocol 2 for this many steps (tools/overlap_bench.py in-process: compact_fwd "
+                         "on the exchange lane beside real SDPA attention, 8 logical ranks looped back) and carry its exposed-exchange figure; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
     ap.add_argument("--no-secondary", action="store_true", help="skip the long run and the pipelined upper-bound leg")
@@ -170,7 +183,7 @@ def config_key(args, n_gpus):
     """What a committed profile must have been taken with for its figures to be quoted beside this run's."""
     pipelined = args.replay == "pipelined"
     return {"codec": args.codec, "replay": args.replay, "own_ef": args.own_ef if not pipelined else None, "layers": args.layers,
-            "shard": [N_TOK, C_CH], "rows": args.rows, "n_gpus": n_gpus}
+            "shard": [N_TOK, C_CH], "rows": args.rows, "n_gpus": n_gpus, "collective": not args.no_collective}
 
 
 def main():
@@ -190,7 +203,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or args.dist_path:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         if args.backend == "nccl":
@@ -198,7 +211,11 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
-    live = world                       # live ranks in the logical ring of 8
+    real_live = world                  # ranks that really exist (processes / GPUs)
+    if args.emulate_live:
+        assert world == 1 and 2 <= args.emulate_live <= W_LOGICAL and args.rccl_lib, "--emulate-live needs one process and --rccl-lib (a loop-back library)"
+        os.environ["CFX_FAKE_RCCL_MODE"] = "loopback"
+    live = args.emulate_live or world  # ranks the exchange is LAID OUT for (= real_live unless --emulate-live)
     assert live <= W_LOGICAL
     pipelined = args.replay == "pipelined"
     int2 = args.codec == "int2"
@@ -240,45 +257,54 @@ def main():
         x0_ = warm_state(rank)[1]
         own_base.copy_(x0_)
         for p in range(W_LOGICAL - 1):
-            if live > 1 and p < live - 1:
-                peer_base[:, p] = warm_state((rank + 1 + p) % live)[1]      # a real peer: its own x_0
+            if real_live > 1 and p < real_live - 1:
+                peer_base[:, p] = warm_state((rank + 1 + p) % real_live)[1]      # a real peer: its own x_0
             else:
                 peer_base[:, p] = x0_                                       # looped-back logical peer
     reset_state()
     send = torch.zeros(L, 2, slot, dtype=torch.uint8, device=dev)           # own packets (K,V) per layer
-    use_dist = live > 1 or args.dist_path
-    recv = torch.zeros(L, live, 2, slot, dtype=torch.uint8, device=dev) if use_dist else None
+    # the collective sits in the path at EVERY N (N = 1: a one-rank RCCL communicator - what N = 8 executes minus the wire)
+    use_dist = not args.no_collective
+    if args.own_ef == "gated" and use_dist and not pipelined:
+        raise SystemExit("--own-ef gated (one launch per layer) only exists without a collective between compress and reconstruction: add --no-collective")
+    recv = torch.zeros(L, live, 2, slot, dtype=torch.uint8, device=dev) if (use_dist and real_live > 1) else None
     grecv = torch.zeros(L * live * 2 * slot, dtype=torch.uint8, device=dev) if use_dist else None   # grouped receive regions
     ws_bytes = lib.cfx_workspace_bytes(CODEC, N, C, 0, 2)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+
+    def own_pkt_ptr(l, kv, gathered):
+        """Where the rank's own packet of layer l is written: with a collective, straight into ITS slot of the gather buffer - the
+        all-gather is then in place (no local copy; with one live rank RCCL has nothing to move at all)."""
+        if gathered:
+            return grecv.data_ptr() + group_recv_offset(l, rank, kv, G, L, live, slot)
+        return send[l, kv].data_ptr()
 
     def peer_packet_ptr(l, p, kv, gathered):
         """Packet of logical peer p for layer l: a real rank's slot of the gathered buffer, or (looped-back peer) our own packet
         - taken from OUR slot of the gathered buffer when there is one, so a collective's result is consumed even with one live rank."""
         if gathered:
             real = live > 1 and p < live - 1
-            if relay and not real:
-                return send[l, kv].data_ptr()          # the relay never writes our own slot of the receive area
-            r = (rank + 1 + p) % live if real else rank
+            r = (rank + 1 + p) % live if real else rank          # a looped-back peer reads OUR slot (the compress launch wrote it there)
             return grecv.data_ptr() + group_recv_offset(l, r, kv, G, L, live, slot)
-        if live > 1 and p < live - 1:
-            return recv[l, (rank + 1 + p) % live, kv].data_ptr()
+        if real_live > 1 and p < real_live - 1:
+            return recv[l, (rank + 1 + p) % real_live, kv].data_ptr()
         return send[l, kv].data_ptr()
 
-    def comp_items(s_, l):
+    def comp_items(s_, l, gathered=False):
         carr = (_lib.CompItem * 2)()
         for kv in range(2):
-            carr[kv] = _lib.CompItem(xs[s_][l, kv].data_ptr(), own_base[l, kv].data_ptr(), None, send[l, kv].data_ptr())
+            carr[kv] = _lib.CompItem(xs[s_][l, kv].data_ptr(), own_base[l, kv].data_ptr(), None, own_pkt_ptr(l, kv, gathered))
         return carr
 
-    def own_ef_items(l):
-        return [_lib.DecompItem(send[l, kv].data_ptr(), own_base[l, kv].data_ptr(), own_base[l, kv].data_ptr()) for kv in range(2)]
+    def own_ef_items(l, gathered=False):
+        return [_lib.DecompItem(own_pkt_ptr(l, kv, gathered), own_base[l, kv].data_ptr(), own_base[l, kv].data_ptr()) for kv in range(2)]
 
     def peer_items(l, gathered):
         return [_lib.DecompItem(peer_packet_ptr(l, p, kv, gathered), peer_base[l, p, kv].data_ptr(), peer_base[l, p, kv].data_ptr())
                 for p in range(W_LOGICAL - 1) for kv in range(2)]
 
-    def add_layer(plan, s_, l, ride, gathered, comm=None, gated=False):
+    def add_layer(plan, s_, l, ride, gathered, comm=None, gated=False, relay_=None):
+        relay_ = relay if relay_ is None else relay_
         """Layer l of the in-order schedule: A = compress (+ previous layer's own EF riding along), X = all-gather, B = reconstruct;
         gated (no X): one launch = A + the 16 reconstructions behind the arrival gate."""
         if gated:
@@ -296,44 +322,44 @@ def main():
         if int2:
             # 2-bit: the codes depend on the scales, so compress = statistics + in-launch finalize, then quantise + error feedback
             # (in place on the rank's own state); the reconstruction launch carries the 7 peers' K,V
-            carr = comp_items(s_, l)
+            carr = comp_items(s_, l, gathered)
             for kv in range(2):
                 carr[kv].new_base = own_base[l, kv].data_ptr()
             rc = lib.cfx_plan_add_compress(plan, CODEC, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, carr, ws.data_ptr(), ws_bytes)
             assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
             if comm is not None:
-                assert lib.cfx_plan_add_all_gather(plan, comm, send[l].data_ptr(), grecv.data_ptr() + l * live * 2 * slot, 2 * slot) >= 0
+                assert lib.cfx_plan_add_all_gather(plan, comm, own_pkt_ptr(l, 0, True), grecv.data_ptr() + l * live * 2 * slot, 2 * slot) >= 0
             items = peer_items(l, gathered)
             assert lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, len(items), (_lib.DecompItem * len(items))(*items)) >= 0
             return
         if ride and l > 0:
-            rd = (_lib.DecompItem * 2)(*own_ef_items(l - 1))
-            rc = lib.cfx_plan_add_compress_ex(plan, CODEC, N, C, 0, 0, 2, comp_items(s_, l), 2, rd, ws.data_ptr(), ws_bytes)
+            rd = (_lib.DecompItem * 2)(*own_ef_items(l - 1, gathered))
+            rc = lib.cfx_plan_add_compress_ex(plan, CODEC, N, C, 0, 0, 2, comp_items(s_, l, gathered), 2, rd, ws.data_ptr(), ws_bytes)
         else:
-            rc = lib.cfx_plan_add_compress(plan, CODEC, N, C, 0, 0, 2, comp_items(s_, l), ws.data_ptr(), ws_bytes)
+            rc = lib.cfx_plan_add_compress(plan, CODEC, N, C, 0, 0, 2, comp_items(s_, l, gathered), ws.data_ptr(), ws_bytes)
         assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
-        if comm is not None and relay:
+        if comm is not None and relay_:
             # ring relay: hop h moves what arrived at hop h-1 (hop 0: our own packets) to rank+1; after hop h the region
             # [rank - h - 1] of the layer's receive area holds that rank's K,V packets - the same layout an all-gather leaves
             base_ptr = grecv.data_ptr() + l * live * 2 * slot
-            src = send[l].data_ptr()
+            src = own_pkt_ptr(l, 0, True)
             for h in range(live - 1):
                 dst = base_ptr + ((rank - h - 1) % live) * 2 * slot
                 rc = lib.cfx_plan_add_ring_hop(plan, comm, src, dst, 2 * slot)
                 assert rc >= 0, rc
                 src = dst
         elif comm is not None:
-            rc = lib.cfx_plan_add_all_gather(plan, comm, send[l].data_ptr(), grecv.data_ptr() + l * live * 2 * slot, 2 * slot)
+            rc = lib.cfx_plan_add_all_gather(plan, comm, own_pkt_ptr(l, 0, True), grecv.data_ptr() + l * live * 2 * slot, 2 * slot)
             assert rc >= 0, rc
         items = peer_items(l, gathered)
         if not ride or l == L - 1:
-            items = own_ef_items(l) + items
+            items = own_ef_items(l, gathered) + items
         darr = (_lib.DecompItem * len(items))(*items)
         rc = lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, len(items), darr)
         assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
 
     ride = args.own_ef in ("ride", "gated")
-    gated = args.own_ef == "gated" and not pipelined and not (live > 1 or args.dist_path)
+    gated = args.own_ef == "gated" and not pipelined and not use_dist
     # ---- native plans without collectives (one per input set) -----------------------------------------------------------------
     #   inorder:   per layer  A(l) [+ EF(l-1)] ; B(l)                        (ops 2l, 2l+1)
     #   pipelined: per layer  compress(l) ; reconstruct own + peers (16)     (the op pattern cfx_plan_run_pipelined recognises)
@@ -349,7 +375,7 @@ def main():
         return built
     plans_inorder = build_plans("inorder")
     plans_pipe = None if int2 else build_plans("pipelined")
-    plans_gated = build_plans("gated") if gated else None
+    plans_gated = build_plans("gated") if (gated or (real_live == 1 and not args.emulate_live and not pipelined and not args.no_secondary)) else None
     plans = plans_pipe if pipelined else (plans_gated if gated else plans_inorder)
 
     compute = torch.cuda.current_stream(dev)
@@ -362,30 +388,33 @@ def main():
     native_comm, step_plans, exchange_mode, stream_mode, build_step_plans = None, None, "none", 0, None
     if use_dist:
         exchange_mode = "torch"
+        if args.exchange == "torch" and world == 1:
+            raise SystemExit("--exchange torch needs N > 1 (torch.distributed is not initialised for one rank)")
         if args.exchange == "native":
             try:
                 from compactfusion_amd.exchange import NativeComm
-                native_comm = NativeComm(local_rank)
-                native_comm.self_test()
+                native_comm = NativeComm(local_rank, solo_ranks=live if world == 1 else 0, library=args.rccl_lib)
+                if not args.emulate_live:
+                    native_comm.self_test()
                 groups = [(a, min(L, a + G)) for a in range(0, L, G)]
 
-                def build_step_plans(mode):
+                def build_step_plans(mode, relay_=None):
                     built = []
                     for s_ in range(2):
                         sp = lib.cfx_plan_create(ctx)
                         assert lib.cfx_plan_set_exchange_stream(sp, mode) == 0
                         if not pipelined:
                             for l in range(L):
-                                add_layer(sp, s_, l, ride, True, native_comm.handle)
+                                add_layer(sp, s_, l, ride, True, native_comm.handle, relay_=relay_)
                         else:
                             for a, b in groups:
                                 for l in range(a, b):
-                                    assert lib.cfx_plan_add_compress(sp, CODEC, N, C, 0, 0, 2, comp_items(s_, l), ws.data_ptr(), ws_bytes) >= 0
-                                rcx = lib.cfx_plan_add_all_gather(sp, native_comm.handle, send[a].data_ptr(),
+                                    assert lib.cfx_plan_add_compress(sp, CODEC, N, C, 0, 0, 2, comp_items(s_, l, True), ws.data_ptr(), ws_bytes) >= 0
+                                rcx = lib.cfx_plan_add_all_gather(sp, native_comm.handle, own_pkt_ptr(a, 0, True),
                                                                   grecv.data_ptr() + a * live * 2 * slot, (b - a) * 2 * slot)
                                 assert rcx >= 0, rcx
                                 for l in range(a, b):
-                                    items = own_ef_items(l) + peer_items(l, True)
+                                    items = own_ef_items(l, True) + peer_items(l, True)
                                     assert lib.cfx_plan_add_decompress(sp, CODEC, N, C, 0, 16, (_lib.DecompItem * 16)(*items)) >= 0
                         assert lib.cfx_plan_finalize(sp) == 0
                         built.append(sp)
@@ -423,7 +452,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if use_dist:
+        if world > 1:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -441,7 +470,7 @@ def main():
         torch.cuda.synchronize(dev)
         # sampled over layers that sit at different positions of an all-gather group, K and V
         samples = sorted({(l, kv) for l in (0, 1, min(L - 1, G - 1), L // 2, L - 1) for kv in (0, 1) if l < L})
-        if live == 1:
+        if real_live == 1:
             same = all(torch.equal(own_base[l, kv].view(torch.int16), peer_base[l, p, kv].view(torch.int16))
                        for l, kv in samples for p in range(W_LOGICAL - 1))
             return same, "EF state of a looped-back peer diverged from the sender's"
@@ -516,7 +545,7 @@ def main():
     t1 = time.perf_counter()
     steps_run += args.steps
     elapsed = t1 - t0
-    if live > 1:
+    if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -539,80 +568,103 @@ def main():
             fn(i)
         sync_all()
         dt = time.perf_counter() - ta
-        if live > 1:
+        if world > 1:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt * 1e3 / n_steps
 
     # ---- secondary legs (no events): a long run of the same replay, the other replay ------------------------------------------
-    long_ms, other_ms, two_ms = None, None, None
+    long_ms, other_ms, two_ms, loop_ms = None, None, None, None
     if not args.no_secondary:
         base_step = steps_run
         long_ms = timed_leg(args.long_steps, lambda i: one_step(base_step + i))
         steps_run += args.long_steps
-        if not use_dist and not int2:
-            other = plans_inorder if pipelined else plans_pipe
-            other_run = lib.cfx_plan_run if pipelined else lib.cfx_plan_run_pipelined
-            base_step = steps_run
+
+        def side_leg(plset, run_fn, what):
+            """args.steps steps of a collective-free plan set on the same states (every replay advances them identically)."""
+            nonlocal steps_run
+            b0 = steps_run
+            fn = lambda i: check(run_fn(plset[(b0 + i) & 1], 0, lib.cfx_plan_size(plset[0]), sh), what)      # noqa: E731
             for i in range(2):
-                check(other_run(other[(base_step + i) & 1], 0, lib.cfx_plan_size(other[0]), sh), "plan_run(other)")
-            base_step += 2
-            other_ms = timed_leg(args.steps, lambda i: check(other_run(other[(base_step + i) & 1], 0, lib.cfx_plan_size(other[0]), sh), "plan_run(other)"))
+                fn(i)
+            b0 += 2
+            ms_ = timed_leg(args.steps, fn)
             steps_run += 2 + args.steps
-        if gated:
-            base_step = steps_run
-            fn2 = lambda i: check(lib.cfx_plan_run(plans_inorder[(base_step + i) & 1], 0, lib.cfx_plan_size(plans_inorder[0]), sh), "plan_run(two launches)")
-            for i in range(2):
-                fn2(i)
-            base_step += 2
-            two_ms = timed_leg(args.steps, fn2)
-            steps_run += 2 + args.steps
-    if gated:
-        torch.cuda.synchronize(dev)
-        ge = lib.cfx_gate_errors(ctx)
-        if ge != 0:
-            raise SystemExit(f"[bench] cfx_gate_errors = {ge}: a gated launch gave up waiting for its packets")
+            return ms_
+        if real_live == 1 and not args.emulate_live:
+            # (looped-back peers only) the cross-layer pipeline and the one-launch-per-layer form: neither can carry a collective
+            if not int2 and not pipelined:
+                other_ms = side_leg(plans_pipe, lib.cfx_plan_run_pipelined, "plan_run(pipelined)")
+            if pipelined:
+                other_ms = side_leg(plans_inorder, lib.cfx_plan_run, "plan_run(in order)")
+            if plans_gated is not None and not gated:
+                loop_ms = side_leg(plans_gated, lib.cfx_plan_run, "plan_run(one launch per layer, loop-back)")
+            if gated:
+                two_ms = side_leg(plans_inorder, lib.cfx_plan_run, "plan_run(two launches)")
+    torch.cuda.synchronize(dev)
+    ge = lib.cfx_gate_errors(ctx)
+    if ge != 0:
+        raise SystemExit(f"[bench] cfx_gate_errors = {ge}: a gated launch gave up waiting for its packets")
 
     # ---- state sanity (bit-exact error-feedback consistency) ---------------------------------------------------------
     ok, why = states_consistent()
     assert ok, why
 
-    # ---- uncompressed RCCL all-gather of the same K/V shards (the north-star comparison), N > 1 only ---------------
-    raw_ms = None
-    if live > 1:
-        try:
-            raw_in = xs[0]
-            raw_out = torch.empty(live, 2, N, C, dtype=torch.float16, device=dev)
-            for _ in range(2):
-                for l in range(L):
-                    dist.all_gather_into_tensor(raw_out.view(-1), raw_in[l].reshape(-1))
-            sync_all()
-            tr0 = time.perf_counter()
-            reps = max(3, min(args.steps, 10))
-            for _ in range(reps):
-                for l in range(L):
-                    dist.all_gather_into_tensor(raw_out.view(-1), raw_in[l].reshape(-1))
-            sync_all()
-            raw_ms = (time.perf_counter() - tr0) / reps * 1e3
-            t = torch.tensor([raw_ms], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            raw_ms = float(t.item())
-        except Exception as e:  # pragma: no cover
-            raw_ms = None
-            print(f"[bench] raw all-gather baseline failed: {e}", file=sys.stderr)
+    # ---- the north-star comparison, N > 1: the UNCOMPRESSED exchange of the same K,V shards (reference patchpara/fwd.py:108-109,
+    # ring.py:193-195) issued the same way as the compressed one - a native plan, one host call per step - as a direct all-gather
+    # and as the reference's W-1-hop ring relay; and the compressed step in the OTHER exchange pattern -------------------------
+    raw_legs, other_pattern_ms = {}, None
+    if live > 1 and native_comm is not None and not pipelined and not args.no_raw_baseline:
+        raw_in = xs[0]                                                       # [L, 2, N, C]: one layer's K,V = 2 x 3.3 MB per rank
+        raw_buf = torch.empty(live, 2, N, C, dtype=torch.float16, device=dev)    # a layer's gathered K,V (consumed before the next layer's)
+        raw_bytes = 2 * N * C * 2
+        reps = max(3, min(args.steps, 10))
+        for pattern in ("allgather", "relay"):
+            rp = lib.cfx_plan_create(ctx)
+            assert lib.cfx_plan_set_exchange_stream(rp, 0) == 0
+            for l in range(L):
+                if pattern == "allgather":
+                    assert lib.cfx_plan_add_all_gather(rp, native_comm.handle, raw_in[l].data_ptr(), raw_buf.data_ptr(), raw_bytes) >= 0
+                else:
+                    src = raw_in[l].data_ptr()
+                    for h in range(live - 1):
+                        dst = raw_buf[(rank - h - 1) % live].data_ptr()
+                        assert lib.cfx_plan_add_ring_hop(rp, native_comm.handle, src, dst, raw_bytes) >= 0
+                        src = dst
+            assert lib.cfx_plan_finalize(rp) == 0
+            fnr = lambda i: check(lib.cfx_plan_run(rp, 0, lib.cfx_plan_size(rp), sh), "plan_run(raw " + pattern + ")")      # noqa: E731
+            fnr(0); fnr(1)
+            raw_legs[pattern] = timed_leg(reps, fnr)
+            torch.cuda.synchronize(dev)
+            lib.cfx_plan_destroy(rp)
+        # the compressed step in the other pattern (same states: every replay advances them identically)
+        if step_plans is not None and G == 1:
+            op_plans = build_step_plans(0, relay_=not relay)
+            b0 = steps_run
+            fno = lambda i: check(lib.cfx_plan_run(op_plans[(b0 + i) & 1], 0, lib.cfx_plan_size(op_plans[0]), sh), "plan_run(other pattern)")   # noqa: E731
+            fno(0); fno(1)
+            b0 += 2
+            other_pattern_ms = timed_leg(args.steps, fno)
+            steps_run += 2 + args.steps
+            ok, why = states_consistent()
+            assert ok, why
+    raw_ms = raw_legs.get("relay" if relay else "allgather")
 
     ms_per_step = elapsed / args.steps * 1e3
     act_bytes_rank = L * 16 * N * C * 2
-    value = live * act_bytes_rank / (elapsed / args.steps) / 1e9
+    value = real_live * act_bytes_rank / (elapsed / args.steps) / 1e9
     inorder_ms = other_ms if pipelined else ms_per_step
     pipe_ms = ms_per_step if pipelined else other_ms
 
+    XNAME = ("no collective (--no-collective)" if not use_dist else
+             ("ring relay: " + str(live - 1) + " grouped ncclSend/ncclRecv hops" if relay else "ncclAllGather, in place (packets are written straight into the rank's slot of the gather buffer)")
+             + f" over libcfx's own {'loop-back stand-in' if args.emulate_live else 'RCCL'} communicator of {live} rank(s), issued from the native plan")
     out = {
         "metric": "residual_compressed_activation_exchange_throughput",
         "value": round(value, 3),
         "unit": "GB/s",
-        "n_gpus": live,
+        "n_gpus": real_live,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
@@ -637,12 +689,12 @@ def main():
                       "in-launch finalize of own K,V, then every statistics workgroup quantises its own tile (+ error feedback) from the registers "
                       "it loaded -> reconstruction of the 7 looped-back peers' K,V (state tiles already in registers)") if (int2 and gated) else
                      ("layer by layer in order (deployable): per layer A1 = statistics + in-launch finalize of own K,V, A2 = quantise + error "
-                      "feedback, X = exchange, B = reconstruct 7 peers' K,V") if int2 else
-                     ("layer by layer in order (deployable): ONE launch per layer = compress K,V [statistics + sign bits + in-launch "
+                      "feedback, X = " + XNAME + ", B = reconstruct 7 peers' K,V") if int2 else
+                     ("layer by layer in order, LOOP-BACK ONLY (no collective can sit inside it): ONE launch per layer = compress K,V [statistics + sign bits + in-launch "
                       "finalize] + the 16 reconstructions its packets feed (own error feedback, 7 looped-back peers' K,V): their workgroups "
                       "pull the state tiles into registers while the scale reduction completes, wait on an arrival gate, finish from registers") if gated else
                      "layer by layer in order (deployable): per layer A = compress K,V [statistics + sign bits + in-launch finalize"
-                     + (" + previous layer's own error-feedback update riding along" if ride else "") + "], X = exchange, B = reconstruct "
+                     + (" + previous layer's own error-feedback update riding along" if ride else "") + "], X = " + XNAME + ", B = reconstruct "
                      + ("7 peers' K,V" if ride else "own + 7 peers' K,V")),
         "launches_per_layer": None if pipelined else (1 if gated else (3 if int2 else 2)),
         "two_launches_per_layer": None if two_ms is None else {
@@ -659,18 +711,32 @@ def main():
         "exchange_stream": (["main", "side", "prio"][stream_mode] if (use_dist and step_plans is not None) else None),
         "layers_per_all_gather": (G if (use_dist and step_plans is not None) else None),
         "raw_allgather_ms_per_step": None if raw_ms is None else round(raw_ms, 4),
+        "raw_exchange_ms_per_step": {k_: round(v_, 4) for k_, v_ in raw_legs.items()} or None,
         "speedup_vs_raw_allgather": None if raw_ms is None else round(raw_ms / ms_per_step, 3),
+        "loopback_one_launch_per_layer": None if loop_ms is None else {
+            "ms_per_step": round(loop_ms, 4),
+            "what": "cfx_compress_batch_gated: the layer as ONE launch (reconstruction behind an in-launch arrival gate). Exists only when the "
+                    "packets a reconstruction needs are produced by the same launch - looped-back peers, no collective - so it is NOT what N > 1 runs"},
     }
     if live > 1:
-        # wire side of the roofline pair (north star: "fraction of HBM / xGMI roofline"): packets RECEIVED per GPU per step
-        # over the step time, against the xGMI links an all-gather among `live` GPUs can use (one link per peer, 7 at most;
-        # ~153 GB/s per direction per link, MI355X_MICROARCH.md).  The exchange shares the step with the codec work, so this is a
-        # lower bound of the link rate actually reached while a collective is in flight.
+        # wire side of the roofline pair (north star: "fraction of HBM / xGMI roofline"): bytes RECEIVED per GPU per step over the step
+        # time, against the xGMI links the pattern can use: a direct all-gather among `live` GPUs one link per peer (7 at most), the ring
+        # relay ONE link (every hop receives from rank-1); ~153 GB/s per direction per link (MI355X_MICROARCH.md).  The compressed
+        # exchange shares its step with the codec launches, so its figure is a lower bound of the link rate while a collective is in flight.
+        def xg(wire, ms_, pattern):
+            links = 1 if pattern == "relay" else min(live - 1, 7)
+            return None if ms_ is None else {"ms_per_step": round(ms_, 4), "achieved": round(wire / (ms_ * 1e-3) / 1e9, 2), "peak": 153.0 * links,
+                                             "unit": "GB/s", "frac": round(wire / (ms_ * 1e-3) / 1e9 / (153.0 * links), 4), "links": links}
         wire = (live - 1) * 2 * L * pkt_bytes
-        links = min(live - 1, 7)
-        out["xgmi"] = {"wire_bytes_per_gpu_per_step": int(wire), "achieved": round(wire / (ms_per_step * 1e-3) / 1e9, 2),
-                       "peak": 153.0 * links, "unit": "GB/s", "frac": round(wire / (ms_per_step * 1e-3) / 1e9 / (153.0 * links), 4),
-                       "links": links, "raw_bytes_per_gpu_per_step": int((live - 1) * 2 * L * N * C * 2)}
+        wire_raw = (live - 1) * 2 * L * N * C * 2
+        this_p, other_p = ("relay", "allgather") if relay else ("allgather", "relay")
+        out["xgmi"] = dict(xg(wire, ms_per_step, this_p), wire_bytes_per_gpu_per_step=int(wire), raw_bytes_per_gpu_per_step=int(wire_raw),
+                           pattern=this_p,
+                           compressed={this_p: xg(wire, ms_per_step, this_p), other_p: xg(wire, other_pattern_ms, other_p)},
+                           raw={k_: xg(wire_raw, v_, k_) for k_, v_ in raw_legs.items()},
+                           issued_by="every leg is one native plan per step (cfx_plan_run): no Python-issued collective on either side")
+        if args.emulate_live:
+            out["xgmi"]["note"] = "--emulate-live: loop-back collective library on ONE GPU - device copies, not xGMI links; layout and plumbing only"
     # ---- roofline --------------------------------------------------------------------------------------------------------
     # step level (every launch of the step, edge layers included), SURVEY.md §8d: own tensors compress + error feedback 6.125 B/el,
     # peers' tensors 4.125 B/el
@@ -737,7 +803,7 @@ def main():
                 "achieved": round(alga / (usa * 1e-6) / 1e9, 1), "frac": round(alga / (usa * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "latency-bound: a global reduction (scales) sits between reading K,V and the packet being complete"}
         # PMC traffic / rocprof cross-reference: only when the committed profile was taken with THIS configuration
-        prof = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+        prof = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
         cfg_key = config_key(args, live)
         if os.path.exists(prof):
             try:
@@ -745,11 +811,11 @@ def main():
                 if pj.get("config") == cfg_key:
                     pk_ = "k_binary_pipe<true>" if pipelined else (("k_int2_compress_gated" if int2 else "k_absmean_compress<true, 4, true") if gated else "k_binary_dequant")
                     out["roofline"]["traffic"] = next((v for k_, v in pj["bytes_per_launch"].items() if k_.startswith(pk_)), None)
-                    out["roofline"]["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                    out["roofline"]["traffic_source"] = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
                     out["roofline"]["step"]["traffic"] = pj.get("bytes_per_step")
             except Exception:
                 pass
-        trace_json = os.path.join(REPO, "profiles", "r02_bench_kernel_durations.json")
+        trace_json = os.path.join(REPO, "profiles", "r03_bench_kernel_durations.json")
         if os.path.exists(trace_json):
             try:
                 tj = json.load(open(trace_json))
@@ -758,18 +824,18 @@ def main():
                     ent = next((v for k_, v in tj["kernels"].items() if k_.startswith(pk_)), None)
                     if ent:
                         out["roofline"]["avg_launch_us_rocprof"] = ent["avg_us"]
-                        out["roofline"]["rocprof_source"] = "profiles/r02_bench_kernel_durations.json (rocprofv3 --kernel-trace of this command)"
+                        out["roofline"]["rocprof_source"] = "profiles/r03_bench_kernel_durations.json (rocprofv3 --kernel-trace of this command)"
             except Exception:
                 pass
     else:
         out["roofline"] = {"bound": "hbm", "kernel": None, "achieved": step_obj["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": step_obj["frac"], "traffic": None, "step": step_obj}
-    if rank == 0 and live == 1 and not args.no_cpu_baseline:
+    if rank == 0 and real_live == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.codec)
         except Exception as e:  # pragma: no cover
             out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-        if not use_dist:
+        if real_live == 1:
             # the oracle as the checker of what was just timed: replay every step this process ran (warm-up + timed + long +
             # the other replay) for two tensors on the host and compare the error-feedback states bit for bit - fails loudly
             from oracle import c_oracle as CO
@@ -796,8 +862,33 @@ def main():
             native_comm.close()
         except Exception:
             pass
-    if use_dist:
+    if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and world == 1 and args.overlap_steps > 0 and not args.emulate_live and not args.no_secondary:
+        # the deployable path beside real attention: what the exchange costs a model step once it runs on the exchange lane
+        try:
+            del xs, own_base, peer_base
+            torch.cuda.empty_cache()
+            import runpy
+            argv0 = sys.argv
+            sys.argv = ["overlap_bench.py", "--quiet", "--steps", str(args.overlap_steps), "--layers", str(L),
+                        "--legs", "attention_on_compute_lane,lane,attention_distinct_kv_on_compute_lane"]
+            try:
+                ov = runpy.run_path(os.path.join(REPO, "tools", "overlap_bench.py"), run_name="__main__")["out"]
+            finally:
+                sys.argv = argv0
+            legs = ov["legs_ms_per_step"]
+            out["overlap_with_attention"] = {
+                "protocol": ov["protocol"], "steps": ov["steps"], "lane": ov["lane"],
+                "attention_only_ms_per_step": legs["attention_on_compute_lane"]["wall"],
+                "attention_over_distinct_kv_ms_per_step": legs["attention_distinct_kv_on_compute_lane"]["wall"],
+                "with_exchange_on_the_lane_ms_per_step": legs["lane"]["wall"],
+                "exposed_exchange_ms_per_step": ov["exposed_exchange_ms_per_step"]["lane"],
+                "exposed_exchange_ms_per_step_vs_attention_over_distinct_kv": ov["exposed_exchange_ms_per_step_vs_attention_over_distinct_kv"],
+                "what": "compact_fwd (gather schedule) with PyTorch-ROCm SDPA at the FLUX shape: the layer's chain on the CU-masked exchange stream, "
+                        "ordered with the compute stream by flags in device memory; exposed = step with the exchange - attention alone"}
+        except Exception as e:  # pragma: no cover
+            out["overlap_with_attention"] = {"error": f"{type(e).__name__}: {e}"}
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:

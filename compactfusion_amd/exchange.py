@@ -30,12 +30,16 @@ def loaded_rccl_path() -> Optional[str]:
 
 
 class NativeComm:
-    def __init__(self, device: int, group=None):
+    def __init__(self, device: int, group=None, library: Optional[str] = None, solo_ranks: int = 0):
+        """library: path of the collective library to load instead of the RCCL the process already uses (tests / bench debug:
+        tests/fake_rccl).  solo_ranks > 0: a communicator that needs no torch.distributed - this process is rank 0 of
+        `solo_ranks` (1 with real RCCL: a one-rank communicator; > 1 only with a loop-back stand-in library)."""
         self.lib = _lib.load()
         self.ctx = context(device)
-        self.rank = dist.get_rank(group)
-        self.world = dist.get_world_size(group)
-        path = loaded_rccl_path()
+        solo = solo_ranks > 0
+        self.rank = 0 if solo else dist.get_rank(group)
+        self.world = solo_ranks if solo else dist.get_world_size(group)
+        path = library or loaded_rccl_path()
         rc = self.lib.cfx_rccl_load(path.encode() if path else None)
         if rc != 0:
             raise _lib.CfxError("cannot load RCCL (librccl.so) for the native exchange")
@@ -45,7 +49,8 @@ class NativeComm:
             if rc != 0:
                 raise _lib.CfxError("ncclGetUniqueId failed")
         box = [bytes(uid.raw)]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if not solo:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         self._uid = ctypes.create_string_buffer(box[0], 128)
         torch.cuda.synchronize(device)
         self.handle = self.lib.cfx_comm_create(self.ctx, self._uid, self.world, self.rank)

