@@ -267,3 +267,45 @@ def w_hook_layer(rank, world, ulysses, ring, compact_on):
     if compact_on:
         res["keys"] = np.array(sorted(cm.compact_cache().base.keys()), dtype="U")
     return res
+
+
+def w_stack(rank, world, codec_name):
+    """Golden group G13's 4-layer attention stack over two ranks through `compact_fwd` (tests/golden/make_golden_stack.py holds the
+    seeded recipe): the stack's final output per step with the compressed exchange and with the exact K,V exchanged (every step
+    WARMUP = raw fp16 through the same ring path)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_stack", os.path.join(HERE, "golden", "make_golden_stack.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
+    from compactfusion_amd.compact.ring import compact_fwd
+    W = [[TD(w) for w in lw] for lw in G.weights()]
+    xs = [TD(x) for x in G.inputs(rank)]
+    res = {}
+
+    def qkv(h, Wl):
+        return [(h.float() @ w).half().view(G.B, G.S, G.H, G.D).contiguous() for w in Wl]
+
+    def nxt(h, o):
+        y = h.float() + o.float().reshape(G.B, G.S, G.C)
+        return (y / y.pow(2).mean(dim=-1, keepdim=True).sqrt()).half()
+
+    finals = {}
+    for mode in ("exact", codec_name):
+        cm.compact_init(CompactConfig(enabled=True, compress_func=(lambda l, s: T.WARMUP) if mode == "exact" else
+                                      (lambda l, s: T.WARMUP if s == 0 else T[codec_name]),
+                                      residual=1, ef=True, fastpath=True, comp_rank=-1))
+        outs = []
+        for t in range(G.STEPS):
+            cm.compact_set_step(t)
+            h = xs[t]
+            for l in range(G.LAYERS):
+                q, k, v = qkv(h, W[l])
+                o, _, _ = compact_fwd(q, k, v, causal=False, group=None, mod_idx=l, current_iter=t)
+                h = nxt(h, o)
+            outs.append(h)
+        finals[mode] = outs
+    res["psnr"] = np.array([G.psnr(finals["exact"][t].cpu(), finals[codec_name][t].cpu()) for t in range(G.STEPS)])
+    res["exact_final"] = bits(finals["exact"][-1])
+    return res

@@ -1,0 +1,159 @@
+"""Golden group G13 - error compounding across LAYERS and RANKS (run in the BUILD container only: imports /root/reference).
+
+A stand-in for BASELINE.json's "images at matched quality" that needs no model weights: a seeded 4-layer attention stack over
+two sequence-parallel ranks (gloo), 8 denoise-like steps.  Every layer's q, k, v are seeded linear maps of the layer's input
+(the previous layer's output), so an error the compressed K,V exchange makes in layer l changes the K,V of layers l+1.. on BOTH
+ranks, and the error-feedback state carries it to the next step - the two ways the reference's compression error compounds in a
+diffusion transformer (xfuser/compact/ring.py:120-275 under a model).
+
+The exchange is the reference's own: `compact_compress` on the rank's K and V (cache keys "{layer}-{rank}-k|v"), an all-gather of
+the packets, `compact_decompress` against the peer's cached state (xfuser/compact/main.py:169-388); step 0 is WARMUP.  The
+reference's ring.py itself cannot be imported here (yunchang / flash_attn are absent), so the attention is
+an fp32 softmax over [own exact K,V ; peer reconstructed K,V] - what its ring forward computes block-wise (ring.py:207-263).
+Stored per codec (BINARY, INT2 fastpath presets, examples/configs.py:39-61) and rank: the PSNR per step of the stack's final
+output against the SAME stack with the exact K,V exchanged.  tests/test_gpu_stack.py runs the HIP path through `compact_fwd` on the
+same seeds and holds it to these PSNRs within 0.1 dB.
+
+usage: TORCHDYNAMO_DISABLE=1 TRITON_INTERPRET=1 python tests/golden/make_golden_stack.py
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+WORLD, LAYERS, STEPS = 2, 4, 8
+B, S, H, D = 1, 64, 8, 64          # per-rank shard
+C = H * D
+SEED = 31337
+CODECS = {"binary": "BINARY", "int2": "INT2"}
+
+
+def weights():
+    """Per layer Wq, Wk, Wv (C x C fp32, N(0, 1/C)): shared by the ranks."""
+    g = torch.Generator().manual_seed(SEED)
+    return [[torch.randn(C, C, generator=g) / C ** 0.5 for _ in range(3)] for _ in range(LAYERS)]
+
+
+def inputs(rank):
+    """The stack's input of `rank` over the steps: x_0 ~ N(0,1), x_t = x_{t-1} + 0.1 N(0,1) (BASELINE.md section 2 drift recipe)."""
+    g = torch.Generator().manual_seed(SEED + 1 + rank)
+    cur = torch.randn(B, S, C, generator=g)
+    out = []
+    for _ in range(STEPS):
+        out.append(cur.half())
+        cur = cur + 0.1 * torch.randn(B, S, C, generator=g)
+    return out
+
+
+def qkv(h, W):
+    """h (B,S,C) fp16 -> q,k,v (B,S,H,D) fp16."""
+    return [(h.float() @ w).half().view(B, S, H, D).contiguous() for w in W]
+
+
+def attention(q, ks, vs):
+    """fp32 softmax attention of q over the concatenation of the K,V blocks, (B,S,H,D) layout -> (B,S,H,D) fp32."""
+    k, v = torch.cat(ks, dim=1), torch.cat(vs, dim=1)
+    qt, kt, vt = (t.transpose(1, 2).float() for t in (q, k, v))
+    s = torch.matmul(qt, kt.transpose(-1, -2)) * D ** -0.5
+    return torch.matmul(torch.softmax(s, dim=-1), vt).transpose(1, 2)
+
+
+def next_input(h, attn_out):
+    """Residual + RMS normalisation (keeps the activations at unit scale through the stack), fp16 like a model's hidden state."""
+    y = h.float() + attn_out.reshape(B, S, C)
+    return (y / y.pow(2).mean(dim=-1, keepdim=True).sqrt()).half()
+
+
+def psnr(ref, got):
+    mse = float(((ref.float() - got.float()) ** 2).mean())
+    return float(20 * np.log10(float(ref.float().abs().max())) - 10 * np.log10(max(mse, 1e-30)))
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("TRITON_INTERPRET", "1")
+    os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+    m = types.ModuleType("xfuser")
+    m.__path__ = [os.path.join(REF, "xfuser")]
+    sys.modules["xfuser"] = m
+    from xfuser.prof import Profiler
+    Profiler.instance().disable()
+    from xfuser.collector import collector
+    collector.init(collector.Collector("/tmp/cfx_golden_collector", enabled=False))
+    import xfuser.compact.main as cm
+    from xfuser.compact.utils import CompactConfig, COMPACT_COMPRESS_TYPE as T
+    W, xs = weights(), inputs(rank)
+    peer = 1 - rank
+    res = {}
+
+    def exchange_exact(k, v):
+        got = [torch.empty_like(k) for _ in range(world)], [torch.empty_like(v) for _ in range(world)]
+        dist.all_gather(got[0], k)
+        dist.all_gather(got[1], v)
+        return got[0][peer], got[1][peer]
+
+    # the stack with the exact K,V exchanged
+    exact = []
+    for t in range(STEPS):
+        h = xs[t]
+        for l in range(LAYERS):
+            q, k, v = qkv(h, W[l])
+            pk, pv = exchange_exact(k, v)
+            h = next_input(h, attention(q, [k, pk], [v, pv]))
+        exact.append(h)
+    for name, tname in CODECS.items():
+        cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: None, residual=1, ef=True, fastpath=True, comp_rank=-1))
+        rows = []
+        for t in range(STEPS):
+            typ = T.WARMUP if t == 0 else T[tname]
+            h = xs[t]
+            for l in range(LAYERS):
+                q, k, v = qkv(h, W[l])
+                rec = []
+                for kv, x in (("k", k), ("v", v)):
+                    pkt = cm.compact_compress(f"{l}-{rank}-{kv}", x, typ, update_cache=True)
+                    pkts = [torch.empty_like(pkt) for _ in range(world)]
+                    dist.all_gather(pkts, pkt.contiguous())
+                    rec.append(cm.compact_decompress(f"{l}-{peer}-{kv}", pkts[peer], typ, (B, S, H, D), update_cache=True).clone())
+                h = next_input(h, attention(q, [k, rec[0]], [v, rec[1]]))
+            rows.append(psnr(exact[t], h))
+            print(f"G13 rank {rank} {name} step {t}: final-output PSNR {rows[-1]:.3f} dB", flush=True)
+        res[f"{name}/r{rank}/psnr"] = np.array(rows)
+        res[f"{name}/r{rank}/final_sha"] = np.frombuffer(hashlib.sha256(h.contiguous().view(torch.int16).numpy().tobytes()).digest(), dtype=np.uint8)
+    res[f"exact/r{rank}/final_sha"] = np.frombuffer(hashlib.sha256(exact[-1].contiguous().view(torch.int16).numpy().tobytes()).digest(), dtype=np.uint8)
+    np.savez(out + f".r{rank}.npz", **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    import torch.multiprocessing as mp
+    out = "/tmp/cfx_g13"
+    mp.spawn(_worker, args=(WORLD, 29541, out), nprocs=WORLD, join=True)
+    res = {}
+    for r in range(WORLD):
+        d = np.load(out + f".r{r}.npz")
+        for k in d.files:
+            res[k] = d[k]
+    np.savez_compressed(os.path.join(HERE, "g13_stack.npz"), **res)
+    sha = lambda t: hashlib.sha256(t.contiguous().view(torch.int16).numpy().tobytes()).hexdigest()   # noqa: E731
+    meta = {"world": WORLD, "layers": LAYERS, "steps": STEPS, "shard": [B, S, H, D], "seed": SEED,
+            "sha_input_last": [sha(inputs(r)[-1]) for r in range(WORLD)], "sha_w_last": sha(weights()[-1][-1].half())}
+    with open(os.path.join(HERE, "g13_stack_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    for k in sorted(res):
+        if k.endswith("psnr"):
+            print(k, np.round(res[k], 3))
+
+
+if __name__ == "__main__":
+    main()

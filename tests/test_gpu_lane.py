@@ -184,8 +184,10 @@ def test_flag_set_wait_order_two_streams():
     for e in range(1, E + 1):
         with torch.cuda.stream(b):          # consumer: waits for epoch e, reads, acknowledges
             assert lib.cfx_flag_wait(ctx, ready, e, b.cuda_stream) == 0
-            seen[e, 0] = src[0]
-            seen[e, 1] = src[-1]
+            # the consumer must be a KERNEL (what a flag orders is kernels: the attention blocks).  A device-to-device memcpy - what
+            # `seen[e, 0] = src[0]` is - was observed reading the previous epoch here (it does not take the kernel path's acquire)
+            torch.add(src[0:1], 0, out=seen[e, 0:1])
+            torch.add(src[-1:], 0, out=seen[e, 1:2])
             assert lib.cfx_flag_set(ctx, ack, e, b.cuda_stream) == 0
         with torch.cuda.stream(a):          # producer: waits until epoch e-1 was consumed, overwrites, publishes
             assert lib.cfx_flag_wait(ctx, ack, e - 1, a.cuda_stream) == 0

@@ -1,0 +1,45 @@
+"""N1 stand-in (-m gpu): error compounding across layers AND ranks.  Golden group G13 (tests/golden/make_golden_stack.py) ran the
+REFERENCE's compact_compress / compact_decompress through a seeded 4-layer attention stack over two gloo ranks for 8 steps and stored
+the PSNR of the stack's final output against the same stack with the exact K,V exchanged.  Here the HIP path runs the same stack
+through `compact_fwd` (two processes sharing GPU 0) and must reproduce those PSNRs within 0.1 dB, per rank and step."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import _dist_workers as W
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "g13_stack.npz")
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _entry(rank, fn_name, world, port, out, args):
+    W.run(getattr(W, fn_name), rank, world, port, out, *args, device="cuda")
+
+
+@pytest.mark.parametrize("codec", ["BINARY", "INT2"])
+def test_stack_psnr_matches_the_reference(tmp_path, codec):
+    if not os.path.exists(GOLD):
+        pytest.skip("G13 golden vectors not generated")
+    gold = np.load(GOLD)
+    out = str(tmp_path / "res")
+    mp.start_processes(_entry, args=("w_stack", 2, _port(), out, (codec,)), nprocs=2, join=True, start_method="spawn")
+    for r in range(2):
+        got = np.load(out + f".r{r}.npz")["psnr"]
+        want = gold[f"{codec.lower()}/r{r}/psnr"]
+        assert got.shape == want.shape
+        assert got[0] > 100 and want[0] > 100, "step 0 is WARMUP: the exchange is exact"
+        d = np.abs(got[1:] - want[1:])
+        assert d.max() < 0.1, f"{codec} rank {r}: final-output PSNR departs from the reference by {d.max():.3f} dB (step {1 + int(d.argmax())}): {got} vs {want}"
+        assert np.all(want[1:] < 80), "the compressed run must differ from the exact one"
