@@ -12,7 +12,7 @@ import sys
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG_DIR)
-SRC = [os.path.join(PKG_DIR, "csrc", f) for f in ("cfx_kernels.hip", "cfx_plan.hip", "cfx_lowrank.hip")]
+SRC = [os.path.join(PKG_DIR, "csrc", f) for f in ("cfx_kernels.hip", "cfx_plan.hip", "cfx_lowrank.hip", "cfx_lrgram.hip")]
 INC = os.path.join(REPO, "include")
 LIB = os.path.join(PKG_DIR, "libcfx.so")
 ARCH = "gfx950"
@@ -35,7 +35,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = SRC + [os.path.join(INC, "cfx.h"), os.path.join(PKG_DIR, "csrc", "cfx_internal.h")]
+    deps = SRC + [os.path.join(INC, "cfx.h"), os.path.join(PKG_DIR, "csrc", "cfx_internal.h"), os.path.join(PKG_DIR, "csrc", "cfx_lr.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -187,6 +187,8 @@ struct PipeSched {
 #define CFX_HIDDEN __attribute__((visibility("hidden")))
 CFX_HIDDEN bool cfx_i_shape_ok(int codec, int N, int C, int param);
 CFX_HIDDEN size_t cfx_i_ws_words(int codec, int N, int C);
+// a zeroed block of CFX_MAX_BATCH * 64 u32 ticket words for ONE launch on `stream`; whoever draws a word's final value resets it to 0
+CFX_HIDDEN unsigned* cfx_i_ticket_block(cfx_ctx* ctx, void* stream);
 CFX_HIDDEN int cfx_i_decompress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items, void* stream,
                                      unsigned* pre, unsigned pre_val);
 CFX_HIDDEN int cfx_i_compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,

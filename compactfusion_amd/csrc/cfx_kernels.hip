@@ -2099,6 +2099,30 @@ static bool gated_one_launch(cfx_ctx* ctx, int codec, int C, int CB) {
     return (codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT2) && ctx->fused && CB <= TICK_MAX_CB && C % 128 == 0 && !dbg_env && !off_env;
 }
 
+// Ticket / gate blocks are handed out round-robin from a ring PER STREAM (launches of one stream are in order, so a ring slot is never
+// shared by two launches in flight; one ring for every stream would let a stalled stream's launch meet a slot that another stream has
+// cycled back to).  Needs cfx_prepare.
+static unsigned ticket_slot(cfx_ctx* ctx, void* stream) {
+    unsigned slot;
+    int ring = -1;
+    for (int i = 0; i < ctx->n_ring_streams; ++i)
+        if (ctx->ring_stream[i] == stream) { ring = i; break; }
+    if (ring < 0) {
+        if (ctx->n_ring_streams < CFX_RING_STREAMS) ring = ctx->n_ring_streams++;
+        else {
+            // every ring is taken: the least recently used one changes hands.  The new owner continues at the ring's next slot, a
+            // full turn (256 launches) away from whatever its previous owner may still have in flight
+            ring = 0;
+            for (int i = 1; i < CFX_RING_STREAMS; ++i)
+                if (ctx->ring_used[i] < ctx->ring_used[ring]) ring = i;
+        }
+        ctx->ring_stream[ring] = stream;
+    }
+    ctx->ring_used[ring] = ++ctx->ring_clock;
+    slot = (unsigned)ring * TICK_RING + (ctx->tick_next[ring]++ % TICK_RING);
+    return slot;
+}
+
 static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                          int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
                          void* workspace, size_t workspace_bytes, void* stream) {
@@ -2164,22 +2188,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
     const int stream_cus = stream_cu_count(ctx, stream);
     if (fused) {
         if (!ctx->tick && cfx_prepare(ctx) != CFX_OK) return CFX_ERR_LAUNCH;
-        int ring = -1;
-        for (int i = 0; i < ctx->n_ring_streams; ++i)
-            if (ctx->ring_stream[i] == stream) { ring = i; break; }
-        if (ring < 0) {
-            if (ctx->n_ring_streams < CFX_RING_STREAMS) ring = ctx->n_ring_streams++;
-            else {
-                // every ring is taken: the least recently used one changes hands.  The new owner continues at the ring's next slot, a
-                // full turn (256 launches) away from whatever its previous owner may still have in flight
-                ring = 0;
-                for (int i = 1; i < CFX_RING_STREAMS; ++i)
-                    if (ctx->ring_used[i] < ctx->ring_used[ring]) ring = i;
-            }
-            ctx->ring_stream[ring] = stream;
-        }
-        ctx->ring_used[ring] = ++ctx->ring_clock;
-        slot = (unsigned)ring * TICK_RING + (ctx->tick_next[ring]++ % TICK_RING);
+        slot = ticket_slot(ctx, stream);
         tick = ctx->tick + (size_t)slot * CFX_MAX_BATCH * TICK_WORDS;
     }
     if (ctx->gate_err && *(volatile unsigned*)ctx->gate_err)
@@ -2287,7 +2296,9 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             if (flags & CFX_FLAG_NO_EF) {
                 for (int i = 0; i < batch; ++i)
                     if (items[i].new_base != items[i].x)
-                        (void)hipMemcpyAsync(items[i].new_base, items[i].x, (size_t)N * C * 2, hipMemcpyDeviceToDevice, s);
+                        // a copy KERNEL, not hipMemcpyAsync: x may have been produced on another stream and handed over by a flag (exchange
+                        // lane), and only kernels take the acquire that makes such a hand-off visible (tools/flag_coherence_probe.hip)
+                        hipLaunchKernelGGL(k_copy_probe, dim3(2048), dim3(256), 0, s, (uint4*)items[i].new_base, (const uint4*)items[i].x, (size_t)N * C * 2 / 16);
             } else {
                 // error-feedback update == the receiver's dequant+add on our own packet
                 BatchD d;
@@ -2359,6 +2370,10 @@ int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base
 // ---- entry points for cfx_plan.hip (plan replay, exchange lane) ------------------------------------------------------------
 }  // extern "C"
 bool cfx_i_shape_ok(int codec, int N, int C, int param) { return shape_ok(codec, N, C, param); }
+unsigned* cfx_i_ticket_block(cfx_ctx* ctx, void* stream) {
+    if (!ctx->tick && cfx_prepare(ctx) != CFX_OK) return nullptr;
+    return ctx->tick + (size_t)ticket_slot(ctx, stream) * CFX_MAX_BATCH * TICK_WORDS;
+}
 int cfx_i_decompress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items, void* stream,
                           unsigned* pre, unsigned pre_val) {
     return decompress_impl(ctx, codec, N, C, param, batch, items, stream, pre, pre_val);

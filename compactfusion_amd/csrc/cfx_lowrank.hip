@@ -23,24 +23,12 @@
 #include <string.h>
 #include "cfx.h"
 #include "cfx_internal.h"
-
-typedef _Float16 h16;
-typedef h16 h16x8 __attribute__((ext_vector_type(8)));
-
-#define LR_MAXB CFX_MAX_BATCH
-
-struct LrItem {
-    const h16* x; const h16* base; h16* new_base; void* packet;
-    const float* q0;     // C x RP fp32 start (rank columns used, the rest zero)
-    char* ws;            // this tensor's workspace
-};
-struct LrBatch { LrItem it[LR_MAXB]; };
+#include "cfx_lr.h"
 
 // workspace carve-up (per tensor), all offsets 256-byte aligned
 struct LrWs {
-    size_t D, Qa, Zb, Y, Gp, T, U16, V16, Uq, Vq, Vsec, total;
+    size_t D, Qa, Zb, Y, Gp, T, U16, V16, Uq, Vq, Vsec, gram, total;
 };
-static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static LrWs lr_layout(int N, int C, int RP) {
     LrWs w;
     size_t o = 0;
@@ -55,6 +43,7 @@ static LrWs lr_layout(int N, int C, int RP) {
     w.Uq = o;  o += al256((size_t)N * RP * 2 + 256);
     w.Vq = o;  o += al256((size_t)C * RP * 2 + 256);
     w.Vsec = o; o += al256((size_t)C * RP / 2 + 4 * RP + 256);
+    w.gram = o; o += cfx_i_lrg_extra_bytes(N, C, RP);       // the N-space chain's Gram matrix, N x r intermediates (0 when it does not apply)
     w.total = o;
     return w;
 }
@@ -66,8 +55,6 @@ static LrWs lr_layout(int N, int C, int RP) {
 // chunks are staged through LDS with coalesced 16-byte loads (next chunk prefetched into registers while the current one is
 // multiplied); each of the 4 waves takes 64 of the chunk's 256 columns and the 4 partial tiles are summed in fixed order.
 // ---------------------------------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 // FROMX (the first product of a chain): D = x - base is formed on the fly (fp16, one rounding, as torch eager) and written to the
 //   workspace for the later passes - every element of D is read by exactly one workgroup here, so k_lr_prep is not needed.
 template <int RP, bool FROMX>
@@ -295,92 +282,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     __syncthreads();
-    double gsym[(RP * RP + 511) / 512];
-#pragma unroll
-    for (int q = 0; q < (RP * RP + 511) / 512; ++q) {
-        const int e = tid + q * 512;
-        gsym[q] = (e < RP * RP) ? 0.5 * (G[e / RP][e % RP] + G[e % RP][e / RP]) : 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < (RP * RP + 511) / 512; ++q) {
-        const int e = tid + q * 512;
-        if (e < RP * RP) { G[e / RP][e % RP] = gsym[q]; L[e / RP][e % RP] = 0.0; }
-    }
-    __syncthreads();
-    // Right-looking Cholesky and the triangular inverse in the REGISTERS of one wave: lane i holds row i (RP doubles); the pivot
-    // and the column entries the other lanes need travel by v_readlane (an SGPR broadcast), so a step has no LDS round trip and
-    // no barrier - ~16 cycles per trailing-update element instead of two workgroup barriers per column (r = 32: 56 -> ~15 us per
-    // call, most of what is left is the reduction of the partial Grams above).  Same operations in the same order as the
-    // LDS form it replaces (no contraction): identical factors.
     __shared__ double gmax_s;
-    if (tid == 0) {
-        double m = 0.0;
-        for (int k = 0; k < r; ++k) m = fmax(m, G[k][k]);
-        gmax_s = m;
-    }
-    __syncthreads();
-    if (tid >= 64) return;
-    const double gmax = gmax_s;
-    const int i = tid;
-    auto bcast = [](double v, int lane) -> double {          // value of lane `lane` (wave-uniform index) in every lane
-        const int2 q = __builtin_bit_cast(int2, v);
-        int2 o;
-        o.x = __builtin_amdgcn_readlane(q.x, lane);
-        o.y = __builtin_amdgcn_readlane(q.y, lane);
-        return __builtin_bit_cast(double, o);
-    };
-    double g[RP];
-#pragma unroll
-    for (int k = 0; k < RP; ++k) g[k] = (i < RP) ? G[i][k] : 0.0;
-    unsigned deadmask = 0;                                  // wave-uniform
     __shared__ double dinv_s[RP];                           // 1 / L[j][j]
-#pragma unroll
-    for (int j = 0; j < RP; ++j) {
-        const double piv = bcast(g[j], j);
-        const bool bad = (j >= r) || !(piv > gmax * 1e-13);
-        // 1 / sqrt(piv) by v_rsq_f64 + two Newton steps (full fp64 accuracy) instead of a correctly rounded sqrt and a division on
-        // the critical path of every column; the factor T leaves this kernel as fp32
-        double inv = __builtin_amdgcn_rsq(bad ? 1.0 : piv);
-        inv = inv * (1.5 - 0.5 * (bad ? 1.0 : piv) * inv * inv);
-        inv = inv * (1.5 - 0.5 * (bad ? 1.0 : piv) * inv * inv);
-        double l = 0.0;
-        if (i >= j && i < r && j < r) l = bad ? (i == j ? 1.0 : 0.0) : (i == j ? piv * inv : g[j] * inv);
-        if (bad && j < r) deadmask |= 1u << j;
-        if (i == 0) dinv_s[j] = bad ? 1.0 : inv;
-        g[j] = l;                                            // column j of L replaces column j of G
-#pragma unroll
-        for (int k = j + 1; k < RP; ++k) {
-            const double lk = bcast(l, k);
-            g[k] -= l * lk;      // every lane, every k > j: rows <= j have l = 0 or only touch their unused upper part, and so do the
-                                 // entries k > i - a per-(lane, k) condition would keep ~100 exec masks alive in SGPRs (1.8 k spills)
-        }
-        __builtin_amdgcn_sched_barrier(0);                   // keep a step's broadcasts (SGPRs) from being hoisted across steps
-    }
-    // X = L^-1: lane i computes column i (x[m] = X[m][i]) by forward substitution; the rows of L go through LDS once (same wave:
-    // in order, no barrier) and are read back as broadcasts (one address for all lanes) - as SGPR broadcasts the ~500 entries
-    // were all kept alive at once (1.6 k SGPR spills).  Two accumulators halve the dependent chain of a row.
-    if (i < RP) {
-#pragma unroll
-        for (int k = 0; k < RP; ++k) L[i][k] = g[k];
-    }
-    double x[RP];
-#pragma unroll
-    for (int m = 0; m < RP; ++m) {
-        double s0 = (m == i) ? 1.0 : 0.0, s1 = 0.0;
-#pragma unroll
-        for (int k = 0; k + 1 < m; k += 2) { s0 -= L[m][k] * x[k]; s1 -= L[m][k + 1] * x[k + 1]; }   // x[k] = 0 for k < i: no mask per (lane, k)
-        if (m & 1) s0 -= L[m][m - 1] * x[m - 1];
-        x[m] = (m >= i && m < r && i < r) ? (s0 + s1) * dinv_s[m] : 0.0;
-    }
-    if (i >= RP) return;
-    // T[k][j] = X[j][k] (k <= j): Q = Z T; thread i writes row i of T.  Directions with a vanished pivot are dropped.
-#pragma unroll
-    for (int m = 0; m < RP; ++m) {
-        float v = 0.f;
-        if (i < r && m < r && m >= i && !((deadmask >> m) & 1u)) v = (float)x[m];
-        T[i * RP + m] = v;
-    }
+    lr_chol_T<RP, 512>(G, L, r, T, &gmax_s, dinv_s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -443,10 +347,6 @@ __global__ __launch_bounds__(256) void k_lr_apply2(LrBatch b, LrApply a, LrApply
 // accumulation, fp16 result) fused with the residual add (main.py:232, :376).  VT: V given transposed (C x r) as LOW_RANK_Q
 // stores it.  Tile = 8 rows x 512 channels like the other dequant kernels; V lives in registers, U rows are broadcast loads.
 // ---------------------------------------------------------------------------------------------------------------------
-struct LrDec { const h16* U; const h16* V; const h16* base; h16* out; };
-struct LrDecBatch { LrDec it[LR_MAXB]; };
-
-typedef h16 h16x2 __attribute__((ext_vector_type(2)));
 
 template <int RP, bool VT>
 __global__ __launch_bounds__(256) void k_lr_decode(LrDecBatch b, int N, int C, int r) {
@@ -542,8 +442,6 @@ __global__ __launch_bounds__(256) void k_lr_decode(LrDecBatch b, int N, int C, i
 // (Writing the MFMA registers straight to memory - 32 rows x 16 B per instruction - measured 5x slower than that.)
 // The V^T fragments stay in registers while the workgroup walks down rows_per_wg rows.  fp32 accumulation in MFMA order;
 // sender (error feedback) and receiver run this same kernel, so their states stay bit-identical.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef h16 h16x4 __attribute__((ext_vector_type(4)));
 #define LR_DEC_LDS_STRIDE (512 + 4)          // halves per LDS row: +8 bytes so the 32 row-lanes of a write spread over banks
 
 template <int RP, bool VT>
@@ -635,7 +533,6 @@ __global__ __launch_bounds__(256) void k_lr_decode_mfma(LrDecBatch b, int N, int
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-static int lr_rp(int rank) { return rank <= 8 ? 8 : (rank <= 16 ? 16 : 32); }
 
 static bool lr_shape_ok(int quantized, int N, int C, int rank) {
     if (N <= 0 || C <= 0 || (C % 8) != 0 || rank < 2 || rank > 32 || (rank & 1)) return false;   // k-pairs: even rank
@@ -661,7 +558,7 @@ size_t cfx_lr_workspace_bytes(int quantized, int N, int C, int rank, int batch) 
     return per * batch;
 }
 
-static int lr_decode_launch(cfx_ctx* ctx, int N, int C, int rank, int batch, const LrDec* items, bool vt, hipStream_t s) {
+int cfx_i_lr_decode_launch(cfx_ctx* ctx, int N, int C, int rank, int batch, const LrDec* items, bool vt, hipStream_t s) {
     LrDecBatch db;
     memset(&db, 0, sizeof(db));
     for (int i = 0; i < batch; ++i) db.it[i] = items[i];
@@ -712,25 +609,33 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
     const size_t E = (size_t)N * C;
     const int nparts = (C + 31) / 32;
     const dim3 g_aq((N + 31) / 32, 4, batch), g_aty(nparts, batch), g_chol(batch), g_apc((C + 255) / 256, batch), g_apn((N + 255) / 256, batch);
-    // D = x - base is formed (and stored) by the first product.  (Forming Q = orth(Z) = Z T inside the next product instead of by a
-    // launch of its own was measured slower at every rank: 17 row tiles redo the same RP x RP products per chunk.)
-    const LrApply aq_ = {C, rank, 1, 0, 0, w.Zb, w.T, w.Qa, 0};
-    for (int iter = 0; iter < 2; ++iter) {
-        if (iter == 0) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, true>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 1));
-        else LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0));
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 0));
+    // The N-space chain (cfx_lrgram.hip: 5 launches up to the factors) for shards whose Gram matrix is small, else the C-space chain.
+    static const char* chain_env = getenv("CFX_LR_CHAIN");
+    const bool gram = cfx_i_lrg_ok(N, C) && !(chain_env && !strcmp(chain_env, "cspace"));
+    if (gram) {
+        const int rg = cfx_i_lrg_factors(ctx, quantized, N, C, rank, batch, b, w.D, w.U16, w.V16, w.gram, s);
+        if (rg != CFX_OK) return rg;
+    } else {
+        // D = x - base is formed (and stored) by the first product.  (Forming Q = orth(Z) = Z T inside the next product instead of by a
+        // launch of its own was measured slower at every rank: 17 row tiles redo the same RP x RP products per chunk.)
+        const LrApply aq_ = {C, rank, 1, 0, 0, w.Zb, w.T, w.Qa, 0};
+        for (int iter = 0; iter < 2; ++iter) {
+            if (iter == 0) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, true>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 1));
+            else LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0));
+            LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 0));
+            LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(512), 0, s, b, rank, nparts, w.Gp, w.T));
+            LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), g_apc, dim3(256), 0, s, b, aq_, aq_, (int)g_apc.x));
+        }
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0));
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 1));
         LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(512), 0, s, b, rank, nparts, w.Gp, w.T));
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), g_apc, dim3(256), 0, s, b, aq_, aq_, (int)g_apc.x));
     }
-    LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0));
-    LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 1));
-    LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(512), 0, s, b, rank, nparts, w.Gp, w.T));
     int rc = CFX_OK;
     LrDec dec[LR_MAXB];
     if (!quantized) {
         // U (N x r) and V (r x C) straight into the packet: [U | V]
         const LrApply au = {N, rank, 4, 1, 1, w.Y, w.T, 0, 0}, av = {C, rank, 1, 2, 1, w.Zb, w.T, 0, (size_t)N * rank};
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), dim3(g_apn.x + g_apc.x, batch), dim3(256), 0, s, b, au, av, (int)g_apn.x));
+        if (!gram) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), dim3(g_apn.x + g_apc.x, batch), dim3(256), 0, s, b, au, av, (int)g_apn.x));
         for (int i = 0; i < batch; ++i) {
             dec[i].U = (const h16*)items[i].packet; dec[i].V = (const h16*)items[i].packet + (size_t)N * rank;
             dec[i].base = (const h16*)items[i].base; dec[i].out = (h16*)items[i].new_base;
@@ -739,7 +644,7 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
         // U16 (N x r), V^T16 (C x r) -> int4 factor quantiser (the native int4 kernel) -> packet sections; then the dequantised
         // factors (what the receiver will see) feed the error-feedback decode
         const LrApply au = {N, rank, 4, 1, 0, w.Y, w.T, w.U16, 0}, av = {C, rank, 1, 1, 0, w.Zb, w.T, w.V16, 0};
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), dim3(g_apn.x + g_apc.x, batch), dim3(256), 0, s, b, au, av, (int)g_apn.x));
+        if (!gram) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), dim3(g_apn.x + g_apc.x, batch), dim3(256), 0, s, b, au, av, (int)g_apn.x));
         const size_t secU = (size_t)N * rank / 2 + 4 * rank, secV = (size_t)C * rank / 2 + 4 * rank;       // bytes
         const size_t i4ws_off = w.total;
         // one batched launch sequence per factor side (U sections are 16-byte aligned in the packet; V sections may start
@@ -789,7 +694,7 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
             for (int i = 0; i < batch; ++i)
                 if (items[i].new_base != items[i].x) (void)hipMemcpyAsync(items[i].new_base, items[i].x, E * 2, hipMemcpyDeviceToDevice, s);
         } else {
-            rc = lr_decode_launch(ctx, N, C, rank, batch, dec, quantized != 0, s);
+            rc = cfx_i_lr_decode_launch(ctx, N, C, rank, batch, dec, quantized != 0, s);
             if (rc != CFX_OK) return rc;
         }
     }
@@ -812,7 +717,7 @@ int cfx_lr_decompress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank,
             dec[i].U = (const h16*)items[i].packet; dec[i].V = (const h16*)items[i].packet + (size_t)N * rank;
             dec[i].base = (const h16*)items[i].base; dec[i].out = (h16*)items[i].recon;
         }
-        return lr_decode_launch(ctx, N, C, rank, batch, dec, false, s);
+        return cfx_i_lr_decode_launch(ctx, N, C, rank, batch, dec, false, s);
     }
     const size_t need = cfx_lr_workspace_bytes(quantized, N, C, rank, batch);
     if (!workspace || workspace_bytes < need) return fail(ctx, CFX_ERR_WORKSPACE, "lr decompress: workspace too small");
@@ -837,7 +742,7 @@ int cfx_lr_decompress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank,
     if (rc != CFX_OK) return rc;
     rc = cfx_decompress_batch(ctx, CFX_CODEC_INT4, C, rank, 0, batch, dv, stream);
     if (rc != CFX_OK) return rc;
-    return lr_decode_launch(ctx, N, C, rank, batch, dec, true, s);
+    return cfx_i_lr_decode_launch(ctx, N, C, rank, batch, dec, true, s);
 }
 
 }  // extern "C"

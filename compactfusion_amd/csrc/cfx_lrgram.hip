@@ -1,0 +1,560 @@
+// Low-rank residual codecs, N-space ("Gram") form of the factorisation chain - part of libcfx.so.
+//
+// The reference's subspace_iter (xfuser/compact/compress_lowrank.py:14-61) is, for A = x - base (N x C, N << C):
+//     Q <- orth(A^T (A Q))  twice ;  U = orth(A Q) ;  V = U^T A
+// The C-space chain of cfx_lowrank.hip follows it product by product: 13 launches, each 5-35 us for a few microseconds of
+// traffic.  Here the same iteration runs in N-space.  With G = A A^T (N x N) and Y0 = A Q0:
+//     W1 = G Y0        M1 = Y0^T W1 (= Z1^T Z1, Z1 = A^T Y0)     T1 = chol(M1)^-T     Y1 = W1 T1   (= A orth(Z1))
+//     W2 = G Y1        M2 = Y1^T W2 (= Z2^T Z2)                  T2 = chol(M2)^-T     Y2 = W2 T2   (= A orth(Z2))
+//     M3 = Y2^T Y2 = T2^T (W2^T W2) T2                           T3 = chol(M3)^-T     U  = Y2 T3   (= orth(A Q2))
+//     V  = U^T A
+// - identical in exact arithmetic, orthonormalisation after every multiplication included (without it the result drifts from the
+// reference by up to 3e-3 on fast-decaying spectra; with it 1e-5 .. 6e-5, measured in numpy).  A is touched by three passes
+// instead of seven, two of them pure fp16-input MFMA work with no range issue (A is fp16; Q0 and U are split hi + lo), and
+// everything between is N x r sized.  Launches (r x r factorisations run in the LAST-ARRIVING workgroup of the launch that
+// produced their input: ticket counter, write-through partials - the in-launch finalize of cfx_kernels.hip):
+//     k_lrg_prep   D = x - base                                                      (materialised once, 3.3 MB at the FLUX shard)
+//     k_lrg_gram   G = D D^T (64 x 64 tiles, upper triangle + mirror, 2 column slabs), Y0 = D Q0       v_mfma_f32_32x32x16_f16
+//     k_lrg_gy<0>  W1 = G Y0, M1 partials; last arriver: T1                                           v_mfma_f32_32x32x2_f32
+//     k_lrg_gy<1>  Y1 = W1 T1 (every workgroup, N x r x r), W2 = G Y1, M2 and W2^T W2 partials; last arriver: T2, T3, U
+//     k_lrg_v      V = U^T D                                                                           v_mfma_f32_32x32x16_f16
+//     (decode / int4 factor quantisation: the kernels the C-space chain ends with)
+// All reductions have a fixed order (no float atomics): results are reproducible run to run.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "cfx_lr.h"
+
+#define LRG_LD 72          // halves per LDS row of a 64-column chunk: 144 B, 16-byte aligned, rows spread over the banks
+
+__device__ __forceinline__ h16x8 lrg_ld8(const h16* p) { return *reinterpret_cast<const h16x8*>(p); }
+__device__ __forceinline__ void lrg_st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float lrg_ld_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lrg_st_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double lrg_ld_wt(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct LrgArgs {
+    int N, C, NP, TN, npair, kslab, r, batch;
+    int per_tensor;          // workgroups per tensor of the launch
+    int xcd_group;           // 8 / batch when that divides: a tensor's workgroups stay on ITS XCDs (block b runs on XCD b % 8), so its
+                             // D (3.3 MB at the FLUX shard) stays resident in their L2s; 0: plain tensor-major order
+    size_t offD, offG, offY0, offW1, offW2, offMp, offPp, offT, offUf, offU16, offV16;
+    int u_in_packet;         // LOW_RANK: U (N x r) and V (r x C) straight into the packet; LOW_RANK_Q: fp16 U (N x r), V^T (C x r) to the workspace
+    unsigned* tick;
+};
+
+__device__ __forceinline__ bool lrg_block(const LrgArgs& a, int& z, int& idx) {
+    const int bid = blockIdx.x;
+    if (a.xcd_group) { z = (bid & 7) / a.xcd_group; idx = (bid >> 3) * a.xcd_group + (bid & 7) % a.xcd_group; }
+    else { z = bid / a.per_tensor; idx = bid - z * a.per_tensor; }
+    return z < a.batch && idx < a.per_tensor;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lrg_prep(LrBatch b, size_t n8, size_t offD) {
+    const LrItem it = b.it[blockIdx.y];
+    h16* D = (h16*)(it.ws + offD);
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n8; i += stride) {
+        h16x8 v = lrg_ld8(it.x + i * 8);
+        if (it.base) v = v - lrg_ld8(it.base + i * 8);                 // fp16, one rounding (torch eager: x - base)
+        *reinterpret_cast<h16x8*>(D + i * 8) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// G slab ks (NP x NP fp32) = D[:, slab] D[:, slab]^T ; Y0 slab ks (NP x RP fp32) = D[:, slab] Q0[slab, :]
+// Workgroups of a tensor: [pairs (ti <= tj) of 64-row tiles x 2 slabs | 64-row tiles x 2 slabs for Y0].  A 64-column chunk of both
+// row tiles goes through LDS with coalesced 16-byte loads (the next chunk is in flight while this one is multiplied); wave w owns
+// the 32 x 32 sub-tile (w & 1, w >> 1).  Operand layout of v_mfma_f32_32x32x16_f16: lane l holds row (A) / column (B) l & 31 and
+// the 8 consecutive k = 8 (l >> 5) .. + 7 - the same k-set for A and B, which is all a dot product needs.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int RP>
+__global__ __launch_bounds__(256) void k_lrg_gram(LrBatch b, LrgArgs a) {
+    int z, idx;
+    if (!lrg_block(a, z, idx)) return;
+    const LrItem it = b.it[z];
+    const h16* D = (const h16*)(it.ws + a.offD);
+    const int ks = idx & 1, u = idx >> 1;
+    const int k0 = ks * a.kslab, k1 = min(a.C, k0 + a.kslab);
+    const int N = a.N, C = a.C, NP = a.NP;
+    __shared__ h16 As[64 * LRG_LD];
+    __shared__ h16 Bs[64 * LRG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (u < a.npair) {
+        int ti = 0, rem = u;
+        while (rem >= a.TN - ti) { rem -= a.TN - ti; ++ti; }
+        const int tj = ti + rem;
+        const int i0 = ti * 64, j0 = tj * 64;
+        const bool diag = ti == tj;
+        const int si = w & 1, sj = w >> 1;
+        h16x8 ra[2], rb[2];
+        auto load = [&](int c0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int p = tid + 256 * q, row = p >> 3, c8 = (p & 7) * 8;
+                ra[q] = (h16x8)(h16)0;
+                rb[q] = (h16x8)(h16)0;
+                if (i0 + row < N) ra[q] = lrg_ld8(D + (size_t)(i0 + row) * C + c0 + c8);
+                if (diag) rb[q] = ra[q];
+                else if (j0 + row < N) rb[q] = lrg_ld8(D + (size_t)(j0 + row) * C + c0 + c8);
+            }
+        };
+        load(k0);
+        for (int c0 = k0; c0 < k1; c0 += 64) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int p = tid + 256 * q, row = p >> 3, c8 = (p & 7) * 8;
+                *reinterpret_cast<h16x8*>(&As[row * LRG_LD + c8]) = ra[q];
+                *reinterpret_cast<h16x8*>(&Bs[row * LRG_LD + c8]) = rb[q];
+            }
+            __syncthreads();
+            if (c0 + 64 < k1) load(c0 + 64);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const h16x8 av = *reinterpret_cast<const h16x8*>(&As[(si * 32 + li) * LRG_LD + kk * 16 + lh * 8]);
+                const h16x8 bv = *reinterpret_cast<const h16x8*>(&Bs[(sj * 32 + li) * LRG_LD + kk * 16 + lh * 8]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+            }
+        }
+        // C/D layout: column j = lane & 31, row i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        float* G = (float*)(it.ws + a.offG) + (size_t)ks * NP * NP;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int gi = i0 + si * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * lh, gj = j0 + sj * 32 + li;
+            G[(size_t)gi * NP + gj] = acc[rg];
+            if (!diag) G[(size_t)gj * NP + gi] = acc[rg];
+        }
+        return;
+    }
+    // ---- Y0 slab: 64 rows x RP, Q0 as hi + lo fp16 (the product is then exact to 2^-22 of an fp32 product) ----
+    const int ti = u - a.npair, i0 = ti * 64;
+    const int si = w & 1, part = w >> 1;                              // waves 0, 1: hi ; 2, 3: lo
+    h16* Qh = Bs;                                                     // [32][LRG_LD]: row n = column of Q0, k along the row
+    h16* Ql = Bs + 32 * LRG_LD;
+    for (int i = tid; i < 64 * LRG_LD; i += 256) Bs[i] = (h16)0;      // rows n >= RP stay zero
+    constexpr int QV = 64 * RP / 256;                                 // floats of the Q0 chunk per thread
+    h16x8 ra[2];
+    float rq[QV];
+    auto load = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = tid + 256 * q, row = p >> 3, c8 = (p & 7) * 8;
+            ra[q] = (h16x8)(h16)0;
+            if (i0 + row < N) ra[q] = lrg_ld8(D + (size_t)(i0 + row) * C + c0 + c8);
+        }
+#pragma unroll
+        for (int q = 0; q < QV; ++q) {
+            const int e = tid + 256 * q;                             // e = kk * RP + n
+            rq[q] = it.q0[(size_t)c0 * RP + e];
+        }
+    };
+    load(k0);
+    for (int c0 = k0; c0 < k1; c0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = tid + 256 * q, row = p >> 3, c8 = (p & 7) * 8;
+            *reinterpret_cast<h16x8*>(&As[row * LRG_LD + c8]) = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < QV; ++q) {
+            const int e = tid + 256 * q, kk = e / RP, n = e - kk * RP;
+            const h16 hi = (h16)rq[q];
+            Qh[n * LRG_LD + kk] = hi;
+            Ql[n * LRG_LD + kk] = (h16)(rq[q] - (float)hi);
+        }
+        __syncthreads();
+        if (c0 + 64 < k1) load(c0 + 64);
+        const h16* Qp = part ? Ql : Qh;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const h16x8 av = *reinterpret_cast<const h16x8*>(&As[(si * 32 + li) * LRG_LD + kk * 16 + lh * 8]);
+            const h16x8 bv = *reinterpret_cast<const h16x8*>(&Qp[li * LRG_LD + kk * 16 + lh * 8]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(As);   // 2 x 32 x 33 floats = 8448 B <= 9216 B
+    if (part) {
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) red[si][(rg & 3) + 8 * (rg >> 2) + 4 * lh][li] = acc[rg];
+    }
+    __syncthreads();
+    if (!part) {
+        float* Y0 = (float*)(it.ws + a.offY0) + (size_t)ks * NP * RP;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int row = (rg & 3) + 8 * (rg >> 2) + 4 * lh;
+            if (li < RP) Y0[(size_t)(i0 + si * 32 + row) * RP + li] = acc[rg] + red[si][row][li];      // hi + lo
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// W (32-row tile) = G Y with Y = Y0 (MODE 0: the two slabs summed) or W1 T1 (MODE 1), G = the two slabs summed.
+// fp32-input MFMA (v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain): A[i][k] = G[i0 + i][j], B[k][n] = Y[j][n]; a 64-column chunk
+// of the G rows is staged through LDS (coalesced), all of Y sits in LDS; the 4 waves take 16 columns of the chunk each and their
+// partial tiles are summed in fixed order.  Epilogue: partial M = Y_tile^T W_tile (fp64; MODE 1 also P = W_tile^T W_tile), then the
+// ticket - the last workgroup of the tensor to arrive factorises:
+//   MODE 0:  T1 = chol(sum M)^-T                                   -> T[0]
+//   MODE 1:  T2 = chol(sum M)^-T ; M3 = T2^T (sum P) T2 ; T3 = chol(M3)^-T ; U = W2 (T2 T3)      -> Uf (fp32), U fp16 (packet / workspace)
+// Dynamic LDS: Ys[NP * RP] floats | Gs[32 * 65] | red[4][32][33] | Ts[RP * RP] | doubles Gd[RP][RP+1], Ld[RP][RP+1], Sd[RP][RP+1], misc
+// ---------------------------------------------------------------------------------------------------------------------
+template <int RP, int MODE>
+__global__ __launch_bounds__(256) void k_lrg_gy(LrBatch b, LrgArgs a) {
+    int z, idx;
+    if (!lrg_block(a, z, idx)) return;
+    const LrItem it = b.it[z];
+    const int N = a.N, NP = a.NP, r = a.r;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int i0 = idx * 32, ntiles = a.per_tensor;
+    extern __shared__ double lrg_smem[];
+    double (*Gd)[RP + 1] = reinterpret_cast<double (*)[RP + 1]>(lrg_smem);
+    double (*Ld)[RP + 1] = Gd + RP;
+    double (*Sd)[RP + 1] = Ld + RP;
+    double* misc = reinterpret_cast<double*>(Sd + RP);                // [0] gmax, [1 .. RP] dinv
+    float* Ts = reinterpret_cast<float*>(misc + RP + 2);             // RP * RP
+    float* T2s = Ts + RP * RP;                                        // RP * RP (MODE 1 finalize)
+    float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(T2s + RP * RP);
+    float* Gs = reinterpret_cast<float*>(red + 4);                    // 32 x 65
+    float* Ys = Gs + 32 * 65;                                         // NP x RP
+    __shared__ unsigned last_flag;
+    const float* G0 = (const float*)(it.ws + a.offG);
+    const float* G1 = G0 + (size_t)NP * NP;
+    float* W = (float*)(it.ws + (MODE ? a.offW2 : a.offW1));
+    float* Tg = (float*)(it.ws + a.offT);                             // T1 | T2 | T3, RP * RP each
+
+    // ---- Y into LDS ----
+    if (MODE == 0) {
+        const float* Ya = (const float*)(it.ws + a.offY0);
+        const float* Yb = Ya + (size_t)NP * RP;
+        for (int i = tid; i < NP * RP; i += 256) Ys[i] = (i / RP < N) ? (Ya[i] + Yb[i]) : 0.f;
+    } else {
+        for (int i = tid; i < RP * RP; i += 256) Ts[i] = Tg[i];
+        __syncthreads();
+        const float* W1 = (const float*)(it.ws + a.offW1);
+        for (int j = tid; j < NP; j += 256) {
+            float in[RP], out[RP];
+#pragma unroll
+            for (int k = 0; k < RP; ++k) in[k] = (j < N) ? W1[(size_t)j * RP + k] : 0.f;
+#pragma unroll
+            for (int n = 0; n < RP; ++n) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < RP; ++k) s = fmaf(in[k], Ts[k * RP + n], s);
+                out[n] = s;
+            }
+#pragma unroll
+            for (int n = 0; n < RP; ++n) Ys[j * RP + n] = out[n];
+        }
+    }
+    // ---- W tile = G rows x Y ----
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float4 g0[2], g1[2];
+    auto load = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = tid + 256 * q, row = p >> 4, c4 = (p & 15) * 4;                        // 32 rows x 16 float4
+            const size_t o = (size_t)(i0 + row) * NP + c0 + c4;
+            g0[q] = *reinterpret_cast<const float4*>(G0 + o);
+            g1[q] = *reinterpret_cast<const float4*>(G1 + o);
+        }
+    };
+    load(0);
+    for (int c0 = 0; c0 < NP; c0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = tid + 256 * q, row = p >> 4, c4 = (p & 15) * 4;
+            float* d = &Gs[row * 65 + c4];
+            d[0] = g0[q].x + g1[q].x; d[1] = g0[q].y + g1[q].y; d[2] = g0[q].z + g1[q].z; d[3] = g0[q].w + g1[q].w;
+        }
+        __syncthreads();
+        if (c0 + 64 < NP) load(c0 + 64);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int jc = w * 16 + 2 * m + lh;                      // column of the chunk
+            const float av = Gs[li * 65 + jc];
+            const float bv = (li < RP) ? Ys[(c0 + jc) * RP + li] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) red[w][(rg & 3) + 8 * (rg >> 2) + 4 * lh][li] = acc[rg];
+    __syncthreads();
+    for (int i = tid; i < 32 * RP; i += 256) {
+        const int row = i / RP, n = i - row * RP;
+        const float s = ((red[0][row][n] + red[1][row][n]) + red[2][row][n]) + red[3][row][n];
+        red[0][row][n] = s;                                           // (row, n) is read and written by this thread only
+        lrg_st_wt(&W[(size_t)(i0 + row) * RP + n], s);
+    }
+    __syncthreads();
+    {
+        double* Mp = (double*)(it.ws + a.offMp) + (size_t)idx * RP * RP;
+        double* Pp = (double*)(it.ws + a.offPp) + (size_t)idx * RP * RP;
+        for (int i = tid; i < RP * RP; i += 256) {
+            const int p = i / RP, q = i - p * RP;
+            double m = 0.0, pp = 0.0;
+            for (int row = 0; row < 32; ++row) {
+                const double wv = (double)red[0][row][q];
+                m += (double)Ys[(i0 + row) * RP + p] * wv;
+                if (MODE) pp += (double)red[0][row][p] * wv;
+            }
+            lrg_st_wt(&Mp[i], m);
+            if (MODE) lrg_st_wt(&Pp[i], pp);
+        }
+    }
+    // publish: every storing wave drains its write-through stores, then one lane draws the ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.tick + z * 64 + MODE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = old == (unsigned)(ntiles - 1);
+        if (last_flag) __hip_atomic_store(a.tick + z * 64 + MODE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-resetting
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    // ---- the tensor's last workgroup: the factorisations ----
+    {
+        const double* Mp = (const double*)(it.ws + a.offMp);
+        const double* Pp = (const double*)(it.ws + a.offPp);
+        for (int i = tid; i < RP * RP; i += 256) {
+            double m = 0.0, pp = 0.0;
+            for (int t = 0; t < ntiles; ++t) {                       // fixed order
+                m += lrg_ld_wt(&Mp[(size_t)t * RP * RP + i]);
+                if (MODE) pp += lrg_ld_wt(&Pp[(size_t)t * RP * RP + i]);
+            }
+            Gd[i / RP][i % RP] = m;
+            if (MODE) Sd[i / RP][i % RP] = pp;
+        }
+    }
+    __syncthreads();
+    lr_chol_T<RP, 256>(Gd, Ld, r, MODE ? T2s : Ts, &misc[0], &misc[1]);
+    __syncthreads();
+    if (MODE == 0) {
+        for (int i = tid; i < RP * RP; i += 256) Tg[i] = Ts[i];
+        return;
+    }
+    // M3 = T2^T S T2 (S = W2^T W2 symmetric): first X = S T2 into Ld, then M3 = T2^T X into Gd
+    for (int i = tid; i < RP * RP; i += 256) {
+        const int p = i / RP, q = i - p * RP;
+        double s = 0.0;
+        for (int k = 0; k < RP; ++k) s += 0.5 * (Sd[p][k] + Sd[k][p]) * (double)T2s[k * RP + q];
+        Ld[p][q] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < RP * RP; i += 256) {
+        const int p = i / RP, q = i - p * RP;
+        double s = 0.0;
+        for (int k = 0; k < RP; ++k) s += (double)T2s[k * RP + p] * Ld[k][q];
+        Gd[p][q] = s;
+    }
+    __syncthreads();
+    lr_chol_T<RP, 256>(Gd, Ld, r, Ts, &misc[0], &misc[1]);          // T3 -> Ts
+    __syncthreads();
+    // T23 = T2 T3 (into Gs as floats, RP * RP <= 32 * 65), then U = W2 T23 for every row
+    float* T23 = Gs;
+    for (int i = tid; i < RP * RP; i += 256) {
+        const int p = i / RP, q = i - p * RP;
+        float s = 0.f;
+        for (int k = 0; k < RP; ++k) s = fmaf(T2s[p * RP + k], Ts[k * RP + q], s);
+        T23[i] = s;
+    }
+    __syncthreads();
+    float* Uf = (float*)(it.ws + a.offUf);
+    h16* U16 = a.u_in_packet ? (h16*)it.packet : (h16*)(it.ws + a.offU16);
+    for (int j = tid; j < NP; j += 256) {
+        float in[RP], out[RP];
+#pragma unroll
+        for (int k = 0; k < RP; ++k) in[k] = (j < N) ? lrg_ld_wt(&W[(size_t)j * RP + k]) : 0.f;
+#pragma unroll
+        for (int n = 0; n < RP; ++n) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < RP; ++k) s = fmaf(in[k], T23[k * RP + n], s);
+            out[n] = s;
+        }
+#pragma unroll
+        for (int n = 0; n < RP; ++n) Uf[(size_t)j * RP + n] = out[n];
+        if (j < N) {
+#pragma unroll
+            for (int n = 0; n < RP; ++n)
+                if (n < r) U16[(size_t)j * r + n] = (h16)out[n];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// V (r x 64-column block) = U^T D: fp16-input MFMA with U as hi + lo.  Both operands want 8 consecutive k = 8 consecutive ROWS of
+// D / U per lane, so a 64-row chunk of the D block and of U is TRANSPOSED into LDS ([column][row], [rank index][row]).
+// Waves: column sub-tile (w & 1) x {hi, lo} (w >> 1).  Output: LOW_RANK V (r x C) fp16 at packet + N r halves; LOW_RANK_Q V^T (C x r).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int RP>
+__global__ __launch_bounds__(256) void k_lrg_v(LrBatch b, LrgArgs a) {
+    int z, idx;
+    if (!lrg_block(a, z, idx)) return;
+    const LrItem it = b.it[z];
+    const h16* D = (const h16*)(it.ws + a.offD);
+    const float* Uf = (const float*)(it.ws + a.offUf);
+    const int N = a.N, C = a.C, r = a.r;
+    const int c0 = idx * 64;
+    __shared__ h16 Dt[64 * LRG_LD];                                   // [column][row]
+    __shared__ h16 Uh[32 * LRG_LD], Ul[32 * LRG_LD];                  // [rank index][row]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int sj = w & 1, part = w >> 1;
+    for (int i = tid; i < 32 * LRG_LD; i += 256) { Uh[i] = (h16)0; Ul[i] = (h16)0; }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    constexpr int UV = 64 * RP / 256;
+    h16x8 rd[2];
+    float ru[UV];
+    auto load = [&](int n0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = tid + 256 * q, row = p >> 3, c8 = (p & 7) * 8;
+            rd[q] = (h16x8)(h16)0;
+            if (n0 + row < N && c0 + c8 < C) rd[q] = lrg_ld8(D + (size_t)(n0 + row) * C + c0 + c8);
+        }
+#pragma unroll
+        for (int q = 0; q < UV; ++q) {
+            const int e = tid + 256 * q, row = e / RP;
+            ru[q] = (n0 + row < N) ? Uf[(size_t)n0 * RP + e] : 0.f;
+        }
+    };
+    load(0);
+    for (int n0 = 0; n0 < N; n0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = tid + 256 * q, row = p >> 3, c8 = (p & 7) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Dt[(c8 + e) * LRG_LD + row] = rd[q][e];
+        }
+#pragma unroll
+        for (int q = 0; q < UV; ++q) {
+            const int e = tid + 256 * q, row = e / RP, m = e - row * RP;
+            const h16 hi = (h16)ru[q];
+            Uh[m * LRG_LD + row] = hi;
+            Ul[m * LRG_LD + row] = (h16)(ru[q] - (float)hi);
+        }
+        __syncthreads();
+        if (n0 + 64 < N) load(n0 + 64);
+        const h16* Up = part ? Ul : Uh;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const h16x8 av = *reinterpret_cast<const h16x8*>(&Up[li * LRG_LD + kk * 16 + lh * 8]);                 // A[m = li][k = row]
+            const h16x8 bv = *reinterpret_cast<const h16x8*>(&Dt[(sj * 32 + li) * LRG_LD + kk * 16 + lh * 8]);     // B[k = row][n = column]
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(Dt);   // 2 x 32 x 33 floats = 8448 B <= 9216 B
+    if (part) {
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) red[sj][(rg & 3) + 8 * (rg >> 2) + 4 * lh][li] = acc[rg];
+    }
+    __syncthreads();
+    if (!part) {
+        const int c = c0 + sj * 32 + li;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int m = (rg & 3) + 8 * (rg >> 2) + 4 * lh;          // rank index
+            if (m < r && c < C) {
+                const h16 v = (h16)(acc[rg] + red[sj][m][li]);
+                if (a.u_in_packet) ((h16*)it.packet)[(size_t)N * r + (size_t)m * C + c] = v;
+                else ((h16*)(it.ws + a.offV16))[(size_t)c * r + m] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+static inline int lrg_np(int N) { return (N + 63) / 64 * 64; }
+
+// shapes the N-space chain covers: the Gram matrix must stay small (N <= 640: 1.6 MB per slab) and the column slabs whole chunks
+bool cfx_i_lrg_ok(int N, int C) { return N >= 32 && N <= 640 && (C % 128) == 0 && C >= 128; }
+
+// bytes the chain needs behind the C-space chain's own per-tensor layout (which provides D, U16, V16)
+size_t cfx_i_lrg_extra_bytes(int N, int C, int RP) {
+    if (!cfx_i_lrg_ok(N, C)) return 0;
+    const size_t NP = lrg_np(N), nt = (N + 31) / 32;
+    size_t o = 0;
+    o += al256(2 * NP * NP * 4);          // G, two slabs
+    o += al256(2 * NP * RP * 4);          // Y0, two slabs
+    o += al256(NP * RP * 4) * 2;          // W1, W2
+    o += al256(nt * RP * RP * 8) * 2;     // M partials, W^T W partials
+    o += al256(3 * RP * RP * 4);          // T1, T2, T3
+    o += al256(NP * RP * 4);              // U fp32
+    return o;
+}
+
+template <int RP>
+static int lrg_run(cfx_ctx* ctx, const LrBatch& b, LrgArgs a, hipStream_t s) {
+    const int N = a.N, C = a.C;
+    const size_t n8 = (size_t)N * C / 8;
+    LAUNCH(ctx, KID_LR_PREP, s, k_lrg_prep, dim3((unsigned)((n8 + 255) / 256 < 1024 ? (n8 + 255) / 256 : 1024), a.batch), dim3(256), 0, s, b, n8, a.offD);
+    auto grid_of = [&](int per_tensor) {
+        a.per_tensor = per_tensor;
+        if (a.xcd_group) return dim3((unsigned)((per_tensor + a.xcd_group - 1) / a.xcd_group * 8));
+        return dim3((unsigned)(per_tensor * a.batch));
+    };
+    dim3 g = grid_of((a.npair + a.TN) * 2);
+    LAUNCH(ctx, KID_LR_AQ, s, (k_lrg_gram<RP>), g, dim3(256), 0, s, b, a);
+    const int nt = (N + 31) / 32;
+    const size_t lds = (size_t)3 * RP * (RP + 1) * 8 + (RP + 2) * 8 + (size_t)2 * RP * RP * 4 + (size_t)4 * 32 * 33 * 4 + (size_t)32 * 65 * 4 +
+                       (size_t)a.NP * RP * 4;
+    g = grid_of(nt);
+    static bool attr_done[3] = {false, false, false};
+    const int ai = RP == 8 ? 0 : (RP == 16 ? 1 : 2);
+    if (!attr_done[ai]) {
+        (void)hipFuncSetAttribute((const void*)k_lrg_gy<RP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_lrg_gy<RP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done[ai] = true;
+    }
+    LAUNCH(ctx, KID_LR_ATY, s, (k_lrg_gy<RP, 0>), g, dim3(256), lds, s, b, a);
+    LAUNCH(ctx, KID_LR_CHOL, s, (k_lrg_gy<RP, 1>), g, dim3(256), lds, s, b, a);
+    g = grid_of((C + 63) / 64);
+    LAUNCH(ctx, KID_LR_APPLY, s, (k_lrg_v<RP>), g, dim3(256), 0, s, b, a);
+    return check_launch(ctx, "low-rank (N-space chain) launch");
+}
+
+// Factors of every tensor of the batch: LOW_RANK -> U, V straight into the packets; LOW_RANK_Q -> fp16 U (N x r) at offU16 and V^T
+// (C x r) at offV16 of each tensor's workspace (what the int4 factor quantiser of cfx_lowrank.hip takes).  `extra` = offset of
+// cfx_i_lrg_extra_bytes() bytes inside each tensor's workspace.
+int cfx_i_lrg_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int batch, const LrBatch& b, size_t offD, size_t offU16, size_t offV16,
+                      size_t extra, hipStream_t s) {
+    const int RPv = lr_rp(rank);
+    LrgArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = N; a.C = C; a.NP = lrg_np(N); a.TN = a.NP / 64; a.npair = a.TN * (a.TN + 1) / 2; a.r = rank; a.batch = batch;
+    a.kslab = (C / 2 + 63) / 64 * 64;
+    a.xcd_group = (batch <= 8 && 8 % batch == 0) ? 8 / batch : 0;
+    const size_t NP = a.NP, nt = (N + 31) / 32;
+    size_t o = extra;
+    a.offD = offD; a.offU16 = offU16; a.offV16 = offV16;
+    a.offG = o;  o += al256(2 * NP * NP * 4);
+    a.offY0 = o; o += al256(2 * NP * RPv * 4);
+    a.offW1 = o; o += al256(NP * RPv * 4);
+    a.offW2 = o; o += al256(NP * RPv * 4);
+    a.offMp = o; o += al256(nt * RPv * RPv * 8);
+    a.offPp = o; o += al256(nt * RPv * RPv * 8);
+    a.offT = o;  o += al256(3 * (size_t)RPv * RPv * 4);
+    a.offUf = o; o += al256(NP * RPv * 4);
+    a.u_in_packet = quantized ? 0 : 1;
+    a.tick = cfx_i_ticket_block(ctx, (void*)s);
+    if (!a.tick) return fail(ctx, CFX_ERR_LAUNCH, "low-rank: no ticket block");
+    if (RPv == 8) return lrg_run<8>(ctx, b, a, s);
+    if (RPv == 16) return lrg_run<16>(ctx, b, a, s);
+    return lrg_run<32>(ctx, b, a, s);
+}
