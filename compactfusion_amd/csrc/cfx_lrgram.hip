@@ -25,6 +25,7 @@
 #include <string.h>
 #include "cfx_lr.h"
 
+#define LRG_GQ 18          // float4 G operands per lane in k_lrg_gy: NP / 32 <= 18, i.e. N <= 576
 #define LRG_LD 72          // halves per LDS row of a 64-column chunk: 144 B, 16-byte aligned, rows spread over the banks
 
 __device__ __forceinline__ h16x8 lrg_ld8(const h16* p) { return *reinterpret_cast<const h16x8*>(p); }
@@ -34,11 +35,11 @@ __device__ __forceinline__ void lrg_st_wt(double* p, double v) { __hip_atomic_st
 __device__ __forceinline__ double lrg_ld_wt(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct LrgArgs {
-    int N, C, NP, TN, npair, kslab, r, batch;
+    int N, C, NP, TN, npair, kslab, KS, r, batch;
     int per_tensor;          // workgroups per tensor of the launch
     int xcd_group;           // 8 / batch when that divides: a tensor's workgroups stay on ITS XCDs (block b runs on XCD b % 8), so its
                              // D (3.3 MB at the FLUX shard) stays resident in their L2s; 0: plain tensor-major order
-    size_t offD, offG, offY0, offW1, offW2, offMp, offPp, offT, offUf, offU16, offV16;
+    size_t offD, offG, offGp, offY0, offY0p, offW1, offW2, offMp, offPp, offT, offUf, offU16, offV16;
     int u_in_packet;         // LOW_RANK: U (N x r) and V (r x C) straight into the packet; LOW_RANK_Q: fp16 U (N x r), V^T (C x r) to the workspace
     unsigned* tick;
 };
@@ -76,12 +77,15 @@ __global__ __launch_bounds__(256) void k_lrg_gram(LrBatch b, LrgArgs a) {
     if (!lrg_block(a, z, idx)) return;
     const LrItem it = b.it[z];
     const h16* D = (const h16*)(it.ws + a.offD);
-    const int ks = idx & 1, u = idx >> 1;
+    const int KS = a.KS;
+    const int ks = idx % KS, u = idx / KS;
     const int k0 = ks * a.kslab, k1 = min(a.C, k0 + a.kslab);
     const int N = a.N, C = a.C, NP = a.NP;
     __shared__ h16 As[64 * LRG_LD];
     __shared__ h16 Bs[64 * LRG_LD];
+    __shared__ unsigned last_flag;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    unsigned* tick = a.tick + z * 64 + 2 + u;                         // one ticket per tile pair / Y0 row tile (words 0, 1: k_lrg_gy)
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -92,43 +96,72 @@ __global__ __launch_bounds__(256) void k_lrg_gram(LrBatch b, LrgArgs a) {
         const int i0 = ti * 64, j0 = tj * 64;
         const bool diag = ti == tj;
         const int si = w & 1, sj = w >> 1;
-        h16x8 ra[2], rb[2];
-        auto load = [&](int c0) {
+        h16x8 ra[2][2], rb[2][2];                                     // two chunks in flight
+        auto load = [&](int c0, int slot) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int p = tid + 256 * q, row = p >> 3, c8 = (p & 7) * 8;
-                ra[q] = (h16x8)(h16)0;
-                rb[q] = (h16x8)(h16)0;
-                if (i0 + row < N) ra[q] = lrg_ld8(D + (size_t)(i0 + row) * C + c0 + c8);
-                if (diag) rb[q] = ra[q];
-                else if (j0 + row < N) rb[q] = lrg_ld8(D + (size_t)(j0 + row) * C + c0 + c8);
+                ra[slot][q] = (h16x8)(h16)0;
+                rb[slot][q] = (h16x8)(h16)0;
+                if (c0 < k1) {
+                    if (i0 + row < N) ra[slot][q] = lrg_ld8(D + (size_t)(i0 + row) * C + c0 + c8);
+                    if (diag) rb[slot][q] = ra[slot][q];
+                    else if (j0 + row < N) rb[slot][q] = lrg_ld8(D + (size_t)(j0 + row) * C + c0 + c8);
+                }
             }
         };
-        load(k0);
-        for (int c0 = k0; c0 < k1; c0 += 64) {
+        auto stage = [&](const h16x8 (&xa)[2], const h16x8 (&xb)[2]) {
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int p = tid + 256 * q, row = p >> 3, c8 = (p & 7) * 8;
-                *reinterpret_cast<h16x8*>(&As[row * LRG_LD + c8]) = ra[q];
-                *reinterpret_cast<h16x8*>(&Bs[row * LRG_LD + c8]) = rb[q];
+                *reinterpret_cast<h16x8*>(&As[row * LRG_LD + c8]) = xa[q];
+                *reinterpret_cast<h16x8*>(&Bs[row * LRG_LD + c8]) = xb[q];
             }
             __syncthreads();
-            if (c0 + 64 < k1) load(c0 + 64);
+        };
+        auto mma = [&]() {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const h16x8 av = *reinterpret_cast<const h16x8*>(&As[(si * 32 + li) * LRG_LD + kk * 16 + lh * 8]);
                 const h16x8 bv = *reinterpret_cast<const h16x8*>(&Bs[(sj * 32 + li) * LRG_LD + kk * 16 + lh * 8]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
             }
+        };
+        load(k0, 0);
+        load(k0 + 64, 1);
+        for (int c0 = k0; c0 < k1; c0 += 128) {
+            stage(ra[0], rb[0]);
+            load(c0 + 128, 0);                                        // two chunks ahead of the one being multiplied
+            mma();
+            if (c0 + 64 < k1) {
+                stage(ra[1], rb[1]);
+                load(c0 + 192, 1);
+                mma();
+            }
         }
-        // C/D layout: column j = lane & 31, row i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-        float* G = (float*)(it.ws + a.offG) + (size_t)ks * NP * NP;
+        // this slab's partial tile, write-through; C/D layout: column j = lane & 31, row i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        float* Gp = (float*)(it.ws + a.offGp) + ((size_t)u * KS + ks) * 4096;
 #pragma unroll
-        for (int rg = 0; rg < 16; ++rg) {
-            const int gi = i0 + si * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * lh, gj = j0 + sj * 32 + li;
-            G[(size_t)gi * NP + gj] = acc[rg];
-            if (!diag) G[(size_t)gj * NP + gi] = acc[rg];
+        for (int rg = 0; rg < 16; ++rg) lrg_st_wt(&Gp[(si * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * lh) * 64 + sj * 32 + li], acc[rg]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = old == (unsigned)(KS - 1);
+            if (last_flag) __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        // the pair's last slab: sum the KS partial tiles in fixed order, write the tile and its mirror image
+        float* G = (float*)(it.ws + a.offG);
+        const float* P0 = (const float*)(it.ws + a.offGp) + (size_t)u * KS * 4096;
+        for (int e = tid; e < 4096; e += 256) {
+            float sacc = 0.f;
+            for (int q = 0; q < KS; ++q) sacc += lrg_ld_wt(&P0[(size_t)q * 4096 + e]);
+            const int gi = i0 + (e >> 6), gj = j0 + (e & 63);
+            G[(size_t)gi * NP + gj] = sacc;
+            if (!diag) G[(size_t)gj * NP + gi] = sacc;
         }
         return;
     }
@@ -186,13 +219,29 @@ __global__ __launch_bounds__(256) void k_lrg_gram(LrBatch b, LrgArgs a) {
         for (int rg = 0; rg < 16; ++rg) red[si][(rg & 3) + 8 * (rg >> 2) + 4 * lh][li] = acc[rg];
     }
     __syncthreads();
+    float* Yp = (float*)(it.ws + a.offY0p) + ((size_t)ti * KS + ks) * 64 * RP;      // this slab's partial rows, write-through
     if (!part) {
-        float* Y0 = (float*)(it.ws + a.offY0) + (size_t)ks * NP * RP;
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) {
             const int row = (rg & 3) + 8 * (rg >> 2) + 4 * lh;
-            if (li < RP) Y0[(size_t)(i0 + si * 32 + row) * RP + li] = acc[rg] + red[si][row][li];      // hi + lo
+            if (li < RP) lrg_st_wt(&Yp[(si * 32 + row) * RP + li], acc[rg] + red[si][row][li]);      // hi + lo
         }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = old == (unsigned)(KS - 1);
+        if (last_flag) __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    float* Y0 = (float*)(it.ws + a.offY0);
+    const float* P0 = (const float*)(it.ws + a.offY0p) + (size_t)ti * KS * 64 * RP;
+    for (int e = tid; e < 64 * RP; e += 256) {
+        float sacc = 0.f;
+        for (int q = 0; q < KS; ++q) sacc += lrg_ld_wt(&P0[(size_t)q * 64 * RP + e]);
+        Y0[(size_t)i0 * RP + e] = sacc;
     }
 }
 
@@ -204,7 +253,7 @@ __global__ __launch_bounds__(256) void k_lrg_gram(LrBatch b, LrgArgs a) {
 // ticket - the last workgroup of the tensor to arrive factorises:
 //   MODE 0:  T1 = chol(sum M)^-T                                   -> T[0]
 //   MODE 1:  T2 = chol(sum M)^-T ; M3 = T2^T (sum P) T2 ; T3 = chol(M3)^-T ; U = W2 (T2 T3)      -> Uf (fp32), U fp16 (packet / workspace)
-// Dynamic LDS: Ys[NP * RP] floats | Gs[32 * 65] | red[4][32][33] | Ts[RP * RP] | doubles Gd[RP][RP+1], Ld[RP][RP+1], Sd[RP][RP+1], misc
+// Dynamic LDS: doubles Gd, Ld, Sd [RP][RP+1], misc | Ts, T2s [RP * RP] | red[4][32][33] | T23 [RP * RP] | Ys [NP * RP]
 // ---------------------------------------------------------------------------------------------------------------------
 template <int RP, int MODE>
 __global__ __launch_bounds__(256) void k_lrg_gy(LrBatch b, LrgArgs a) {
@@ -222,19 +271,29 @@ __global__ __launch_bounds__(256) void k_lrg_gy(LrBatch b, LrgArgs a) {
     float* Ts = reinterpret_cast<float*>(misc + RP + 2);             // RP * RP
     float* T2s = Ts + RP * RP;                                        // RP * RP (MODE 1 finalize)
     float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(T2s + RP * RP);
-    float* Gs = reinterpret_cast<float*>(red + 4);                    // 32 x 65
-    float* Ys = Gs + 32 * 65;                                         // NP x RP
+    float* T23 = reinterpret_cast<float*>(red + 4);                   // RP * RP (MODE 1 finalize)
+    float* Ys = T23 + RP * RP;                                        // NP x RP
     __shared__ unsigned last_flag;
-    const float* G0 = (const float*)(it.ws + a.offG);
-    const float* G1 = G0 + (size_t)NP * NP;
     float* W = (float*)(it.ws + (MODE ? a.offW2 : a.offW1));
     float* Tg = (float*)(it.ws + a.offT);                             // T1 | T2 | T3, RP * RP each
 
+    // ---- this wave's share of the G rows: straight from L2 into the MFMA operand layout, ALL loads in flight before anything else.
+    // Wave w takes columns [w QW, (w + 1) QW), QW = NP / 4; lane (li, lh) holds G[i0 + li][w QW + 8 q + 4 lh .. + 3] (32-byte segments
+    // of 32 rows per instruction: every byte is used).  A staged copy through LDS cost 9 dependent round trips per workgroup. ----
+    const int QW = NP >> 2, nq = QW >> 3;
+    float4 gq[LRG_GQ];
+    {
+        const float* Gr = (const float*)(it.ws + a.offG) + (size_t)(i0 + li) * NP + w * QW + 4 * lh;
+#pragma unroll
+        for (int q = 0; q < LRG_GQ; ++q) {
+            gq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < nq) gq[q] = *reinterpret_cast<const float4*>(Gr + 8 * q);
+        }
+    }
     // ---- Y into LDS ----
     if (MODE == 0) {
         const float* Ya = (const float*)(it.ws + a.offY0);
-        const float* Yb = Ya + (size_t)NP * RP;
-        for (int i = tid; i < NP * RP; i += 256) Ys[i] = (i / RP < N) ? (Ya[i] + Yb[i]) : 0.f;
+        for (int i = tid; i < NP * RP; i += 256) Ys[i] = (i / RP < N) ? Ya[i] : 0.f;
     } else {
         for (int i = tid; i < RP * RP; i += 256) Ts[i] = Tg[i];
         __syncthreads();
@@ -255,36 +314,20 @@ __global__ __launch_bounds__(256) void k_lrg_gy(LrBatch b, LrgArgs a) {
         }
     }
     // ---- W tile = G rows x Y ----
+    __syncthreads();                                                  // Ys complete
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    float4 g0[2], g1[2];
-    auto load = [&](int c0) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int p = tid + 256 * q, row = p >> 4, c4 = (p & 15) * 4;                        // 32 rows x 16 float4
-            const size_t o = (size_t)(i0 + row) * NP + c0 + c4;
-            g0[q] = *reinterpret_cast<const float4*>(G0 + o);
-            g1[q] = *reinterpret_cast<const float4*>(G1 + o);
-        }
-    };
-    load(0);
-    for (int c0 = 0; c0 < NP; c0 += 64) {
-        __syncthreads();
+    for (int q = 0; q < LRG_GQ; ++q) {
+        if (q < nq) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int p = tid + 256 * q, row = p >> 4, c4 = (p & 15) * 4;
-            float* d = &Gs[row * 65 + c4];
-            d[0] = g0[q].x + g1[q].x; d[1] = g0[q].y + g1[q].y; d[2] = g0[q].z + g1[q].z; d[3] = g0[q].w + g1[q].w;
-        }
-        __syncthreads();
-        if (c0 + 64 < NP) load(c0 + 64);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int jc = w * 16 + 2 * m + lh;                      // column of the chunk
-            const float av = Gs[li * 65 + jc];
-            const float bv = (li < RP) ? Ys[(c0 + jc) * RP + li] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+                const int col = w * QW + 8 * q + 4 * lh + e;        // k = lh of this MFMA step: the same column for A and B
+                const float av = e == 0 ? gq[q].x : (e == 1 ? gq[q].y : (e == 2 ? gq[q].z : gq[q].w));
+                const float bv = (li < RP) ? Ys[col * RP + li] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -360,8 +403,7 @@ __global__ __launch_bounds__(256) void k_lrg_gy(LrBatch b, LrgArgs a) {
     __syncthreads();
     lr_chol_T<RP, 256>(Gd, Ld, r, Ts, &misc[0], &misc[1]);          // T3 -> Ts
     __syncthreads();
-    // T23 = T2 T3 (into Gs as floats, RP * RP <= 32 * 65), then U = W2 T23 for every row
-    float* T23 = Gs;
+    // T23 = T2 T3, then U = W2 T23 for every row
     for (int i = tid; i < RP * RP; i += 256) {
         const int p = i / RP, q = i - p * RP;
         float s = 0.f;
@@ -415,45 +457,57 @@ __global__ __launch_bounds__(256) void k_lrg_v(LrBatch b, LrgArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     constexpr int UV = 64 * RP / 256;
-    h16x8 rd[2];
-    float ru[UV];
-    auto load = [&](int n0) {
+    h16x8 rd[2][2];                                                   // two 64-row chunks in flight
+    float ru[2][UV];
+    auto load = [&](int n0, int slot) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int p = tid + 256 * q, row = p >> 3, c8 = (p & 7) * 8;
-            rd[q] = (h16x8)(h16)0;
-            if (n0 + row < N && c0 + c8 < C) rd[q] = lrg_ld8(D + (size_t)(n0 + row) * C + c0 + c8);
+            rd[slot][q] = (h16x8)(h16)0;
+            if (n0 + row < N && c0 + c8 < C) rd[slot][q] = lrg_ld8(D + (size_t)(n0 + row) * C + c0 + c8);
         }
 #pragma unroll
         for (int q = 0; q < UV; ++q) {
             const int e = tid + 256 * q, row = e / RP;
-            ru[q] = (n0 + row < N) ? Uf[(size_t)n0 * RP + e] : 0.f;
+            ru[slot][q] = (n0 + row < N) ? Uf[(size_t)n0 * RP + e] : 0.f;
         }
     };
-    load(0);
-    for (int n0 = 0; n0 < N; n0 += 64) {
+    auto stage = [&](const h16x8 (&xd)[2], const float (&xu)[UV]) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int p = tid + 256 * q, row = p >> 3, c8 = (p & 7) * 8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) Dt[(c8 + e) * LRG_LD + row] = rd[q][e];
+            for (int e = 0; e < 8; ++e) Dt[(c8 + e) * LRG_LD + row] = xd[q][e];
         }
 #pragma unroll
         for (int q = 0; q < UV; ++q) {
             const int e = tid + 256 * q, row = e / RP, m = e - row * RP;
-            const h16 hi = (h16)ru[q];
+            const h16 hi = (h16)xu[q];
             Uh[m * LRG_LD + row] = hi;
-            Ul[m * LRG_LD + row] = (h16)(ru[q] - (float)hi);
+            Ul[m * LRG_LD + row] = (h16)(xu[q] - (float)hi);
         }
         __syncthreads();
-        if (n0 + 64 < N) load(n0 + 64);
-        const h16* Up = part ? Ul : Uh;
+    };
+    const h16* Up = part ? Ul : Uh;
+    auto mma = [&]() {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const h16x8 av = *reinterpret_cast<const h16x8*>(&Up[li * LRG_LD + kk * 16 + lh * 8]);                 // A[m = li][k = row]
             const h16x8 bv = *reinterpret_cast<const h16x8*>(&Dt[(sj * 32 + li) * LRG_LD + kk * 16 + lh * 8]);     // B[k = row][n = column]
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+        }
+    };
+    load(0, 0);
+    load(64, 1);
+    for (int n0 = 0; n0 < N; n0 += 128) {
+        stage(rd[0], ru[0]);
+        load(n0 + 128, 0);
+        mma();
+        if (n0 + 64 < N) {
+            stage(rd[1], ru[1]);
+            load(n0 + 192, 1);
+            mma();
         }
     }
     __syncthreads();
@@ -483,15 +537,21 @@ __global__ __launch_bounds__(256) void k_lrg_v(LrBatch b, LrgArgs a) {
 static inline int lrg_np(int N) { return (N + 63) / 64 * 64; }
 
 // shapes the N-space chain covers: the Gram matrix must stay small (N <= 640: 1.6 MB per slab) and the column slabs whole chunks
-bool cfx_i_lrg_ok(int N, int C) { return N >= 32 && N <= 640 && (C % 128) == 0 && C >= 128; }
+bool cfx_i_lrg_ok(int N, int C) { return N >= 32 && N <= 576 && (C % 128) == 0 && C >= 128; }
+// column slabs per tile pair: as many as divide the columns into whole 64-column chunks, up to 8 (more, shorter workgroups: the
+// kernel is bound by load latency, not by bytes)
+static inline int lrg_ks(int C) { return (C % 512) == 0 ? 8 : ((C % 256) == 0 ? 4 : 2); }
 
 // bytes the chain needs behind the C-space chain's own per-tensor layout (which provides D, U16, V16)
 size_t cfx_i_lrg_extra_bytes(int N, int C, int RP) {
     if (!cfx_i_lrg_ok(N, C)) return 0;
     const size_t NP = lrg_np(N), nt = (N + 31) / 32;
+    const size_t KS = lrg_ks(C), TN = NP / 64, npair = TN * (TN + 1) / 2;
     size_t o = 0;
-    o += al256(2 * NP * NP * 4);          // G, two slabs
-    o += al256(2 * NP * RP * 4);          // Y0, two slabs
+    o += al256(NP * NP * 4);              // G
+    o += al256(npair * KS * 4096 * 4);    // G partial tiles, one per column slab
+    o += al256(NP * RP * 4);              // Y0
+    o += al256(TN * KS * 64 * RP * 4);    // Y0 partial rows
     o += al256(NP * RP * 4) * 2;          // W1, W2
     o += al256(nt * RP * RP * 8) * 2;     // M partials, W^T W partials
     o += al256(3 * RP * RP * 4);          // T1, T2, T3
@@ -509,18 +569,20 @@ static int lrg_run(cfx_ctx* ctx, const LrBatch& b, LrgArgs a, hipStream_t s) {
         if (a.xcd_group) return dim3((unsigned)((per_tensor + a.xcd_group - 1) / a.xcd_group * 8));
         return dim3((unsigned)(per_tensor * a.batch));
     };
-    dim3 g = grid_of((a.npair + a.TN) * 2);
+    dim3 g = grid_of((a.npair + a.TN) * a.KS);
     LAUNCH(ctx, KID_LR_AQ, s, (k_lrg_gram<RP>), g, dim3(256), 0, s, b, a);
     const int nt = (N + 31) / 32;
-    const size_t lds = (size_t)3 * RP * (RP + 1) * 8 + (RP + 2) * 8 + (size_t)2 * RP * RP * 4 + (size_t)4 * 32 * 33 * 4 + (size_t)32 * 65 * 4 +
-                       (size_t)a.NP * RP * 4;
+    const size_t lds = (size_t)3 * RP * (RP + 1) * 8 + (RP + 2) * 8 + (size_t)3 * RP * RP * 4 + (size_t)4 * 32 * 33 * 4 + (size_t)a.NP * RP * 4;
     g = grid_of(nt);
-    static bool attr_done[3] = {false, false, false};
+    static size_t attr_bytes[3] = {0, 0, 0};                          // dynamic LDS the two kernels have been allowed so far
     const int ai = RP == 8 ? 0 : (RP == 16 ? 1 : 2);
-    if (!attr_done[ai]) {
-        (void)hipFuncSetAttribute((const void*)k_lrg_gy<RP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_lrg_gy<RP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done[ai] = true;
+    if (lds > 64 * 1024 && lds > attr_bytes[ai]) {
+        if (hipFuncSetAttribute((const void*)k_lrg_gy<RP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_lrg_gy<RP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(ctx, CFX_ERR_LAUNCH, "low-rank: the device does not grant the LDS the N-space chain needs");
+        }
+        attr_bytes[ai] = lds;
     }
     LAUNCH(ctx, KID_LR_ATY, s, (k_lrg_gy<RP, 0>), g, dim3(256), lds, s, b, a);
     LAUNCH(ctx, KID_LR_CHOL, s, (k_lrg_gy<RP, 1>), g, dim3(256), lds, s, b, a);
@@ -538,19 +600,22 @@ int cfx_i_lrg_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int b
     LrgArgs a;
     memset(&a, 0, sizeof(a));
     a.N = N; a.C = C; a.NP = lrg_np(N); a.TN = a.NP / 64; a.npair = a.TN * (a.TN + 1) / 2; a.r = rank; a.batch = batch;
-    a.kslab = (C / 2 + 63) / 64 * 64;
+    a.KS = lrg_ks(C);
+    a.kslab = C / a.KS;
     a.xcd_group = (batch <= 8 && 8 % batch == 0) ? 8 / batch : 0;
-    const size_t NP = a.NP, nt = (N + 31) / 32;
+    const size_t NP = a.NP, nt = (N + 31) / 32, KS = a.KS;
     size_t o = extra;
     a.offD = offD; a.offU16 = offU16; a.offV16 = offV16;
-    a.offG = o;  o += al256(2 * NP * NP * 4);
-    a.offY0 = o; o += al256(2 * NP * RPv * 4);
-    a.offW1 = o; o += al256(NP * RPv * 4);
-    a.offW2 = o; o += al256(NP * RPv * 4);
-    a.offMp = o; o += al256(nt * RPv * RPv * 8);
-    a.offPp = o; o += al256(nt * RPv * RPv * 8);
-    a.offT = o;  o += al256(3 * (size_t)RPv * RPv * 4);
-    a.offUf = o; o += al256(NP * RPv * 4);
+    a.offG = o;   o += al256(NP * NP * 4);
+    a.offGp = o;  o += al256((size_t)a.npair * KS * 4096 * 4);
+    a.offY0 = o;  o += al256(NP * RPv * 4);
+    a.offY0p = o; o += al256((size_t)a.TN * KS * 64 * RPv * 4);
+    a.offW1 = o;  o += al256(NP * RPv * 4);
+    a.offW2 = o;  o += al256(NP * RPv * 4);
+    a.offMp = o;  o += al256(nt * RPv * RPv * 8);
+    a.offPp = o;  o += al256(nt * RPv * RPv * 8);
+    a.offT = o;   o += al256(3 * (size_t)RPv * RPv * 4);
+    a.offUf = o;  o += al256(NP * RPv * 4);
     a.u_in_packet = quantized ? 0 : 1;
     a.tick = cfx_i_ticket_block(ctx, (void*)s);
     if (!a.tick) return fail(ctx, CFX_ERR_LAUNCH, "low-rank: no ticket block");
