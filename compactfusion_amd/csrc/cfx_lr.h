@@ -39,7 +39,8 @@ CFX_HIDDEN int cfx_i_lrg_factors(cfx_ctx* ctx, int quantized, int N, int C, int 
 // thread of a workgroup of NT threads (NT >= 64, multiple of 64); the factorisation itself runs in the registers of wave 0.  G and L
 // are scratch (RP x (RP + 1) doubles each); the caller synchronises before reading T.
 template <int RP, int NT>
-__device__ __forceinline__ void lr_chol_T(double (*G)[RP + 1], double (*L)[RP + 1], int r, float* T, double* gmax_s, double* dinv_s) {
+__device__ __forceinline__ void lr_chol_T(double (*G)[RP + 1], double (*L)[RP + 1], int r, float* T, double* gmax_s, double* dinv_s,
+                                          double pivot_tol = 1e-13) {
     const int tid = threadIdx.x;
     double gsym[(RP * RP + NT - 1) / NT];
 #pragma unroll
@@ -82,7 +83,7 @@ __device__ __forceinline__ void lr_chol_T(double (*G)[RP + 1], double (*L)[RP + 
 #pragma unroll
     for (int j = 0; j < RP; ++j) {
         const double piv = bcast(g[j], j);
-        const bool bad = (j >= r) || !(piv > gmax * 1e-13);
+        const bool bad = (j >= r) || !(piv > gmax * pivot_tol);
         // 1 / sqrt(piv) by v_rsq_f64 + two Newton steps (full fp64 accuracy) instead of a correctly rounded sqrt and a division on
         // the critical path of every column; the factor T leaves this kernel as fp32
         double inv = __builtin_amdgcn_rsq(bad ? 1.0 : piv);

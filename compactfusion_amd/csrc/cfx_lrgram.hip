@@ -25,12 +25,20 @@
 #include <string.h>
 #include "cfx_lr.h"
 
+// Pivots below this fraction of the largest are dropped.  In N-space the Gram matrix carries its fp32 accumulation error (1e-6 relative)
+// into every product, so the null directions of a rank-deficient residual surface with pivots ~1e-10 of the largest instead of ~1e-14;
+// kept, they are normalised noise that is not orthogonal to the true directions (numpy replay of this chain: projection error 3e-2 ..
+// 5e-1 on a rank-3 residual at 1e-13, 3.5e-4 at 1e-9 .. 1e-5).  1e-10 of a sigma^4-scaled pivot = singular values below 0.3 % of the largest.
+#define LRG_PIVOT_TOL 1e-10
 #define LRG_GQ 18          // float4 G operands per lane in k_lrg_gy: NP / 32 <= 18, i.e. N <= 576
 #define LRG_LD 72          // halves per LDS row of a 64-column chunk: 144 B, 16-byte aligned, rows spread over the banks
 
 __device__ __forceinline__ h16x8 lrg_ld8(const h16* p) { return *reinterpret_cast<const h16x8*>(p); }
 __device__ __forceinline__ void lrg_st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float lrg_ld_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+typedef float lrg_f4 __attribute__((ext_vector_type(4)));
+// 16 bytes another workgroup of this launch stored write-through: L1-bypassing load (sc1); the caller waits (s_waitcnt) before use
+__device__ __forceinline__ void lrg_ld16_wt_issue(lrg_f4& v, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory"); }
 __device__ __forceinline__ void lrg_st_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double lrg_ld_wt(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -156,12 +164,26 @@ __global__ __launch_bounds__(256) void k_lrg_gram(LrBatch b, LrgArgs a) {
         // the pair's last slab: sum the KS partial tiles in fixed order, write the tile and its mirror image
         float* G = (float*)(it.ws + a.offG);
         const float* P0 = (const float*)(it.ws + a.offGp) + (size_t)u * KS * 4096;
-        for (int e = tid; e < 4096; e += 256) {
-            float sacc = 0.f;
-            for (int q = 0; q < KS; ++q) sacc += lrg_ld_wt(&P0[(size_t)q * 4096 + e]);
-            const int gi = i0 + (e >> 6), gj = j0 + (e & 63);
-            G[(size_t)gi * NP + gj] = sacc;
-            if (!diag) G[(size_t)gj * NP + gi] = sacc;
+        // 1024 float4 positions, 4 per thread, KS slabs each: every load is issued before any is consumed (one fabric round trip)
+        lrg_f4 pv[4][8];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < KS) lrg_ld16_wt_issue(pv[v][q], P0 + (size_t)q * 4096 + (size_t)(tid + 256 * v) * 4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            lrg_f4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < KS) sacc += pv[v][q];                         // fixed order
+            const int e = (tid + 256 * v) * 4, gi = i0 + (e >> 6), gj = j0 + (e & 63);
+            *reinterpret_cast<lrg_f4*>(&G[(size_t)gi * NP + gj]) = sacc;
+            if (!diag) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) G[(size_t)(gj + c) * NP + gi] = sacc[c];
+            }
         }
         return;
     }
@@ -239,8 +261,12 @@ __global__ __launch_bounds__(256) void k_lrg_gram(LrBatch b, LrgArgs a) {
     float* Y0 = (float*)(it.ws + a.offY0);
     const float* P0 = (const float*)(it.ws + a.offY0p) + (size_t)ti * KS * 64 * RP;
     for (int e = tid; e < 64 * RP; e += 256) {
+        float pq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pq[q] = lrg_ld_wt(&P0[(size_t)min(q, KS - 1) * 64 * RP + e]);     // unconditional: all in flight together
         float sacc = 0.f;
-        for (int q = 0; q < KS; ++q) sacc += lrg_ld_wt(&P0[(size_t)q * 64 * RP + e]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sacc += (q < KS) ? pq[q] : 0.f;
         Y0[(size_t)i0 * RP + e] = sacc;
     }
 }
@@ -369,18 +395,27 @@ __global__ __launch_bounds__(256) void k_lrg_gy(LrBatch b, LrgArgs a) {
     {
         const double* Mp = (const double*)(it.ws + a.offMp);
         const double* Pp = (const double*)(it.ws + a.offPp);
+        // every load unconditional (clamped tile index, masked value) and issued before any is consumed: one fabric round trip per
+        // element instead of one per tile (cdna_hip_programming.md: a branch per load serialises them)
         for (int i = tid; i < RP * RP; i += 256) {
+            double mv[LRG_GQ], pv[LRG_GQ];
+#pragma unroll
+            for (int t = 0; t < LRG_GQ; ++t) {
+                mv[t] = lrg_ld_wt(&Mp[(size_t)min(t, ntiles - 1) * RP * RP + i]);
+                if (MODE) pv[t] = lrg_ld_wt(&Pp[(size_t)min(t, ntiles - 1) * RP * RP + i]);
+            }
             double m = 0.0, pp = 0.0;
-            for (int t = 0; t < ntiles; ++t) {                       // fixed order
-                m += lrg_ld_wt(&Mp[(size_t)t * RP * RP + i]);
-                if (MODE) pp += lrg_ld_wt(&Pp[(size_t)t * RP * RP + i]);
+#pragma unroll
+            for (int t = 0; t < LRG_GQ; ++t) {                       // fixed order
+                m += (t < ntiles) ? mv[t] : 0.0;
+                if (MODE) pp += (t < ntiles) ? pv[t] : 0.0;
             }
             Gd[i / RP][i % RP] = m;
             if (MODE) Sd[i / RP][i % RP] = pp;
         }
     }
     __syncthreads();
-    lr_chol_T<RP, 256>(Gd, Ld, r, MODE ? T2s : Ts, &misc[0], &misc[1]);
+    lr_chol_T<RP, 256>(Gd, Ld, r, MODE ? T2s : Ts, &misc[0], &misc[1], LRG_PIVOT_TOL);
     __syncthreads();
     if (MODE == 0) {
         for (int i = tid; i < RP * RP; i += 256) Tg[i] = Ts[i];
@@ -401,7 +436,7 @@ __global__ __launch_bounds__(256) void k_lrg_gy(LrBatch b, LrgArgs a) {
         Gd[p][q] = s;
     }
     __syncthreads();
-    lr_chol_T<RP, 256>(Gd, Ld, r, Ts, &misc[0], &misc[1]);          // T3 -> Ts
+    lr_chol_T<RP, 256>(Gd, Ld, r, Ts, &misc[0], &misc[1], LRG_PIVOT_TOL);          // T3 -> Ts
     __syncthreads();
     // T23 = T2 T3, then U = W2 T23 for every row
     for (int i = tid; i < RP * RP; i += 256) {
