@@ -611,7 +611,9 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
     const dim3 g_aq((N + 31) / 32, 4, batch), g_aty(nparts, batch), g_chol(batch), g_apc((C + 255) / 256, batch), g_apn((N + 255) / 256, batch);
     // The N-space chain (cfx_lrgram.hip: 5 launches up to the factors) for shards whose Gram matrix is small, else the C-space chain.
     static const char* chain_env = getenv("CFX_LR_CHAIN");
-    const bool gram = cfx_i_lrg_ok(N, C) && !(chain_env && !strcmp(chain_env, "cspace"));
+    // (rank > 16: the two factorisations the chain's last launch runs back to back in one wave spill at RP = 32 - measured slower than the
+    // C-space chain's separate launches)
+    const bool gram = cfx_i_lrg_ok(N, C) && RPv <= 16 && !(chain_env && !strcmp(chain_env, "cspace"));
     if (gram) {
         const int rg = cfx_i_lrg_factors(ctx, quantized, N, C, rank, batch, b, w.D, w.U16, w.V16, w.gram, s);
         if (rg != CFX_OK) return rg;

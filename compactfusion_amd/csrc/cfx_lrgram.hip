@@ -36,9 +36,10 @@
 __device__ __forceinline__ h16x8 lrg_ld8(const h16* p) { return *reinterpret_cast<const h16x8*>(p); }
 __device__ __forceinline__ void lrg_st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float lrg_ld_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-typedef float lrg_f4 __attribute__((ext_vector_type(4)));
-// 16 bytes another workgroup of this launch stored write-through: L1-bypassing load (sc1); the caller waits (s_waitcnt) before use
-__device__ __forceinline__ void lrg_ld16_wt_issue(lrg_f4& v, const float* p) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory"); }
+typedef unsigned lrg_u4 __attribute__((ext_vector_type(4)));
+// 16-byte write-through store (an agent-scope atomic store lowers to sc1 only up to 8 bytes).  hipcc does not count an asm store: the
+// publishing wave drains it with its own s_waitcnt vmcnt(0); the s_nop keeps the data registers alive until the store has read them
+__device__ __forceinline__ void lrg_st16_wt(void* p, lrg_u4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void lrg_st_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double lrg_ld_wt(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -104,48 +105,44 @@ __global__ __launch_bounds__(256) void k_lrg_gram(LrBatch b, LrgArgs a) {
         const int i0 = ti * 64, j0 = tj * 64;
         const bool diag = ti == tj;
         const int si = w & 1, sj = w >> 1;
-        h16x8 ra[2][2], rb[2][2];                                     // two chunks in flight
-        auto load = [&](int c0, int slot) {
+        // The kernel is bound by load latency, not by bytes: up to 6 chunks (the whole slab of the FLUX / SD3 shards) are requested
+        // at once - 24 x 16 bytes per thread in flight - and then staged through LDS chunk by chunk without another global wait
+        constexpr int DEPTH = 6;
+        h16x8 ra[DEPTH][2], rb[DEPTH][2];
+        for (int g0 = k0; g0 < k1; g0 += DEPTH * 64) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int p = tid + 256 * q, row = p >> 3, c8 = (p & 7) * 8;
-                ra[slot][q] = (h16x8)(h16)0;
-                rb[slot][q] = (h16x8)(h16)0;
-                if (c0 < k1) {
-                    if (i0 + row < N) ra[slot][q] = lrg_ld8(D + (size_t)(i0 + row) * C + c0 + c8);
-                    if (diag) rb[slot][q] = ra[slot][q];
-                    else if (j0 + row < N) rb[slot][q] = lrg_ld8(D + (size_t)(j0 + row) * C + c0 + c8);
+            for (int d = 0; d < DEPTH; ++d) {
+                const int c0 = g0 + d * 64;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int p = tid + 256 * q, row = p >> 3, c8 = (p & 7) * 8;
+                    ra[d][q] = (h16x8)(h16)0;
+                    rb[d][q] = (h16x8)(h16)0;
+                    if (c0 < k1) {
+                        if (i0 + row < N) ra[d][q] = lrg_ld8(D + (size_t)(i0 + row) * C + c0 + c8);
+                        if (diag) rb[d][q] = ra[d][q];
+                        else if (j0 + row < N) rb[d][q] = lrg_ld8(D + (size_t)(j0 + row) * C + c0 + c8);
+                    }
                 }
             }
-        };
-        auto stage = [&](const h16x8 (&xa)[2], const h16x8 (&xb)[2]) {
-            __syncthreads();
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int p = tid + 256 * q, row = p >> 3, c8 = (p & 7) * 8;
-                *reinterpret_cast<h16x8*>(&As[row * LRG_LD + c8]) = xa[q];
-                *reinterpret_cast<h16x8*>(&Bs[row * LRG_LD + c8]) = xb[q];
-            }
-            __syncthreads();
-        };
-        auto mma = [&]() {
+            for (int d = 0; d < DEPTH; ++d) {
+                if (g0 + d * 64 < k1) {                               // uniform
+                    __syncthreads();
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const h16x8 av = *reinterpret_cast<const h16x8*>(&As[(si * 32 + li) * LRG_LD + kk * 16 + lh * 8]);
-                const h16x8 bv = *reinterpret_cast<const h16x8*>(&Bs[(sj * 32 + li) * LRG_LD + kk * 16 + lh * 8]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
-            }
-        };
-        load(k0, 0);
-        load(k0 + 64, 1);
-        for (int c0 = k0; c0 < k1; c0 += 128) {
-            stage(ra[0], rb[0]);
-            load(c0 + 128, 0);                                        // two chunks ahead of the one being multiplied
-            mma();
-            if (c0 + 64 < k1) {
-                stage(ra[1], rb[1]);
-                load(c0 + 192, 1);
-                mma();
+                    for (int q = 0; q < 2; ++q) {
+                        const int p = tid + 256 * q, row = p >> 3, c8 = (p & 7) * 8;
+                        *reinterpret_cast<h16x8*>(&As[row * LRG_LD + c8]) = ra[d][q];
+                        *reinterpret_cast<h16x8*>(&Bs[row * LRG_LD + c8]) = rb[d][q];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const h16x8 av = *reinterpret_cast<const h16x8*>(&As[(si * 32 + li) * LRG_LD + kk * 16 + lh * 8]);
+                        const h16x8 bv = *reinterpret_cast<const h16x8*>(&Bs[(sj * 32 + li) * LRG_LD + kk * 16 + lh * 8]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc, 0, 0, 0);
+                    }
+                }
             }
         }
         // this slab's partial tile, write-through; C/D layout: column j = lane & 31, row i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -164,25 +161,29 @@ __global__ __launch_bounds__(256) void k_lrg_gram(LrBatch b, LrgArgs a) {
         // the pair's last slab: sum the KS partial tiles in fixed order, write the tile and its mirror image
         float* G = (float*)(it.ws + a.offG);
         const float* P0 = (const float*)(it.ws + a.offGp) + (size_t)u * KS * 4096;
-        // 1024 float4 positions, 4 per thread, KS slabs each: every load is issued before any is consumed (one fabric round trip)
-        lrg_f4 pv[4][8];
+        // 2048 float2 positions, 8 per thread, KS slabs each: every load is issued before any is consumed (one fabric round trip);
+        // 8-byte agent-scope loads = global_load_dwordx2 sc1, which the compiler tracks (an asm dwordx4 load it does not)
+        typedef unsigned long long u64_;
+        for (int half = 0; half < 2; ++half) {
+            u64_ pv[4][8];
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
+            for (int v = 0; v < 4; ++v)
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (q < KS) lrg_ld16_wt_issue(pv[v][q], P0 + (size_t)q * 4096 + (size_t)(tid + 256 * v) * 4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int q = 0; q < 8; ++q)
+                    pv[v][q] = __hip_atomic_load((const u64_*)(P0 + (size_t)min(q, KS - 1) * 4096) + (tid + 256 * (v + 4 * half)), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            lrg_f4 sacc = {0.f, 0.f, 0.f, 0.f};
+            for (int v = 0; v < 4; ++v) {
+                float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (q < KS) sacc += pv[v][q];                         // fixed order
-            const int e = (tid + 256 * v) * 4, gi = i0 + (e >> 6), gj = j0 + (e & 63);
-            *reinterpret_cast<lrg_f4*>(&G[(size_t)gi * NP + gj]) = sacc;
-            if (!diag) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) G[(size_t)(gj + c) * NP + gi] = sacc[c];
+                for (int q = 0; q < 8; ++q) {                         // fixed order
+                    const float2 f = __builtin_bit_cast(float2, pv[v][q]);
+                    s0 += (q < KS) ? f.x : 0.f;
+                    s1 += (q < KS) ? f.y : 0.f;
+                }
+                const int e = (tid + 256 * (v + 4 * half)) * 2, gi = i0 + (e >> 6), gj = j0 + (e & 63);
+                *reinterpret_cast<float2*>(&G[(size_t)gi * NP + gj]) = make_float2(s0, s1);
+                if (!diag) { G[(size_t)gj * NP + gi] = s0; G[(size_t)(gj + 1) * NP + gi] = s1; }
             }
         }
         return;
@@ -281,8 +282,9 @@ __global__ __launch_bounds__(256) void k_lrg_gram(LrBatch b, LrgArgs a) {
 //   MODE 1:  T2 = chol(sum M)^-T ; M3 = T2^T (sum P) T2 ; T3 = chol(M3)^-T ; U = W2 (T2 T3)      -> Uf (fp32), U fp16 (packet / workspace)
 // Dynamic LDS: doubles Gd, Ld, Sd [RP][RP+1], misc | Ts, T2s [RP * RP] | red[4][32][33] | T23 [RP * RP] | Ys [NP * RP]
 // ---------------------------------------------------------------------------------------------------------------------
+// (one wave per SIMD: the single-wave factorisation of the last arriver wants the whole register file at RP = 32)
 template <int RP, int MODE>
-__global__ __launch_bounds__(256) void k_lrg_gy(LrBatch b, LrgArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_lrg_gy(LrBatch b, LrgArgs a) {
     int z, idx;
     if (!lrg_block(a, z, idx)) return;
     const LrItem it = b.it[z];
