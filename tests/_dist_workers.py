@@ -263,6 +263,17 @@ def w_hook_layer(rank, world, ulysses, ring, compact_on):
             vv = torch.cat([TD(allv[r][step]) for r in range(world)], dim=1)
             ref, _ = block_attention(TD(allq[rank][step]), kk, vv, 0.0, None, causal=False)
             res[f"s{step}/l{li}/ref"] = TH(ref)
+            if compact_on and ring > 1 and ulysses == 1:
+                # what the compressed ring step must equal: ONE attention over what this rank holds - its own exact K,V, then the
+                # peers' cached reconstructions in ring order (the comparison w_ring makes); and the states themselves
+                order = [(rank - s_) % world for s_ in range(world)]
+                hk = [TD(allk[rank][step]) if r_ == rank else cm.compact_cache().get_base(f"{li}-{r_}-k").view(B, S, H, D).clone() for r_ in order]
+                hv = [TD(allv[rank][step]) if r_ == rank else cm.compact_cache().get_base(f"{li}-{r_}-v").view(B, S, H, D).clone() for r_ in order]
+                held, _ = block_attention(TD(allq[rank][step]), torch.cat(hk, dim=1), torch.cat(hv, dim=1), 0.0, None, causal=False)
+                res[f"s{step}/l{li}/ref_held"] = TH(held)
+                for r_ in range(world):
+                    res[f"s{step}/l{li}/state_k_{r_}"] = bits(cm.compact_cache().get_base(f"{li}-{r_}-k")).copy()
+                    res[f"s{step}/l{li}/state_v_{r_}"] = bits(cm.compact_cache().get_base(f"{li}-{r_}-v")).copy()
         assert layers[0].idx == 0 and layers[1].idx == 1
     if compact_on:
         res["keys"] = np.array(sorted(cm.compact_cache().base.keys()), dtype="U")

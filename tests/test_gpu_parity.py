@@ -739,3 +739,91 @@ def test_gated_and_ride_along_items_in_one_launch():
     same_bits(host_bits(s1), R.bits(nb1), "layer 1 state (gated)")
     for i, p in enumerate(peers):
         same_bits(host_bits(p), R.bits(nb1), f"peer {i} (gated)")
+
+
+@pytest.mark.parametrize("codec", [1, 2])
+def test_gated_layer_launches_beside_attention_kernels(codec):
+    """The one-launch layer (1-bit and 2-bit) while a COMPUTE kernel - PyTorch's SDPA, long and CU-filling - runs on another stream:
+    the gated workgroups must still get their slots behind the statistics group (forward progress rests on in-order dispatch), no
+    gate may time out, and a long back-to-back sequence must equal the multi-launch replay bit for bit."""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    N, C, B, NP = 544, 3072, 2, 14
+    ctx = K.context(0)
+    xs, bs = [], []
+    for i in range(B):
+        x, b = make_inputs(900 + i, N, C)
+        xs.append(x); bs.append(b)
+    xd = [dev(x) for x in xs]
+    own = [dev(b) for b in bs]
+    peer = [dev(bs[g % B]) for g in range(NP)]
+    pk = [torch.zeros(K.packet_halves(codec, N, C), dtype=torch.float16, device="cuda") for _ in range(B)]
+    ws = K.workspace(codec, N, C, 0, B, 0)
+    sh = torch.cuda.current_stream().cuda_stream
+    comp = (_lib.CompItem * B)(*[_lib.CompItem(xd[i].data_ptr(), own[i].data_ptr(), own[i].data_ptr(), pk[i].data_ptr()) for i in range(B)])
+    gated = (_lib.DecompItem * NP)(*[_lib.DecompItem(pk[g % B].data_ptr(), peer[g].data_ptr(), peer[g].data_ptr()) for g in range(NP)])
+    att_s = torch.cuda.Stream()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    q, k, v = (torch.randn(1, 24, 4096, 128, device="cuda", dtype=torch.float16, generator=g) for _ in range(3))
+    reps = 120
+    torch.cuda.synchronize()
+    with torch.cuda.stream(att_s):
+        for _ in range(60):                                   # ~1 ms each: attention kernels cover the whole sequence of launches
+            torch.ops.aten._scaled_dot_product_flash_attention(q, k, v, 0.0, False, False, scale=128 ** -0.5)
+    for _ in range(reps):
+        assert lib.cfx_compress_batch_gated(ctx, codec, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, comp, 0, None, NP, gated, ws.data_ptr(), ws.numel(), sh) == 0
+    torch.cuda.synchronize()
+    assert lib.cfx_gate_errors(ctx) == 0, "a gate timed out beside the attention kernels"
+    # replay without the gate machinery: compress (+ EF) then reconstruction, on fresh copies of the initial states
+    r_own = [dev(b) for b in bs]
+    r_peer = [dev(bs[g % B]) for g in range(NP)]
+    r_pk = [torch.zeros_like(p) for p in pk]
+    c2 = (_lib.CompItem * B)(*[_lib.CompItem(xd[i].data_ptr(), r_own[i].data_ptr(), r_own[i].data_ptr(), r_pk[i].data_ptr()) for i in range(B)])
+    d2 = (_lib.DecompItem * NP)(*[_lib.DecompItem(r_pk[g % B].data_ptr(), r_peer[g].data_ptr(), r_peer[g].data_ptr()) for g in range(NP)])
+    for _ in range(reps):
+        assert lib.cfx_compress_batch(ctx, codec, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, c2, ws.data_ptr(), ws.numel(), sh) == 0
+        assert lib.cfx_decompress_batch(ctx, codec, N, C, 0, NP, d2, sh) == 0
+    torch.cuda.synchronize()
+    for i in range(B):
+        assert torch.equal(own[i].view(torch.int16), r_own[i].view(torch.int16)), f"own state {i}"
+        assert torch.equal(pk[i].view(torch.int16), r_pk[i].view(torch.int16)), f"packet {i}"
+    for gi in range(NP):
+        assert torch.equal(peer[gi].view(torch.int16), r_peer[gi].view(torch.int16)), f"peer state {gi}"
+
+
+def test_gated_int2_falls_back_when_its_statistics_group_cannot_be_co_resident():
+    """The 2-bit one-launch layer needs every statistics workgroup resident at once (each waits at gate 1 for all the others).  A
+    batch with more of them than the device holds - K,V of a (2304, 3072) shard: 864 - and ANY batch on a CU-masked stream must
+    take the multi-launch form instead of spinning into the gate timeout; results equal the plain sequence bit for bit."""
+    from compactfusion_amd import _lib, codecs as K, lanes
+    lib = _lib.load()
+    ctx = K.context(0)
+    for (N, C, stream) in ((2304, 3072, torch.cuda.current_stream()), (544, 3072, lanes.exchange_stream(0))):
+        B, NP = 2, 4
+        xs, bs = [], []
+        for i in range(B):
+            x, b = make_inputs(950 + i, N, C)
+            xs.append(x); bs.append(b)
+        sh = stream.cuda_stream
+        with torch.cuda.stream(stream):
+            xd = [dev(x) for x in xs]
+            outs = []
+            for gated_call in (True, False):
+                own = [dev(b) for b in bs]
+                peer = [dev(bs[g % B]) for g in range(NP)]
+                pk = [torch.zeros(K.packet_halves(2, N, C), dtype=torch.float16, device="cuda") for _ in range(B)]
+                ws = K.workspace(2, N, C, 0, B, 0, stream_handle=sh)
+                comp = (_lib.CompItem * B)(*[_lib.CompItem(xd[i].data_ptr(), own[i].data_ptr(), own[i].data_ptr(), pk[i].data_ptr()) for i in range(B)])
+                dq = (_lib.DecompItem * NP)(*[_lib.DecompItem(pk[g % B].data_ptr(), peer[g].data_ptr(), peer[g].data_ptr()) for g in range(NP)])
+                for _ in range(3):
+                    if gated_call:
+                        assert lib.cfx_compress_batch_gated(ctx, 2, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, comp, 0, None, NP, dq, ws.data_ptr(), ws.numel(), sh) == 0
+                    else:
+                        assert lib.cfx_compress_batch(ctx, 2, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, comp, ws.data_ptr(), ws.numel(), sh) == 0
+                        assert lib.cfx_decompress_batch(ctx, 2, N, C, 0, NP, dq, sh) == 0
+                torch.cuda.synchronize()
+                outs.append((own, peer, pk))
+        assert lib.cfx_gate_errors(ctx) == 0, (N, C)
+        for a, b_ in zip(outs[0], outs[1]):
+            for t0, t1 in zip(a, b_):
+                assert torch.equal(t0.view(torch.int16), t1.view(torch.int16)), (N, C)
