@@ -100,6 +100,12 @@ SYMBOLS = [
     ("cfx_residual2_update", ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_attn_merge", ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 + [ctypes.c_void_p]),
     ("cfx_copy_probe", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    ("cfx_binary_rank_packet_bytes", ctypes.c_size_t, [ctypes.c_int] * 3),
+    ("cfx_binary_rank_workspace_bytes", ctypes.c_size_t, [ctypes.c_int] * 4),
+    ("cfx_binary_rank_compress_batch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                      ctypes.POINTER(CompItem), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    ("cfx_binary_rank_decompress_batch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                        ctypes.POINTER(DecompItem), ctypes.c_void_p]),
     ("cfx_plan_flags", ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_plan_add_flag_wait", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_plan_add_flag_set", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),

@@ -354,3 +354,56 @@ def lr_decompress_batch(quantized: bool, packets, bases, recons, N: int, C: int,
     rc = _lib.load().cfx_lr_decompress_batch(ctx, int(quantized), N, C, rank, B, items, _ptr(ws), 0 if ws is None else ws.numel(),
                                              _stream_handle(stream, dev))
     _check(ctx, rc, "cfx_lr_decompress_batch")
+
+
+# ---- 1-bit codec with rank-K scales (deprecated in the reference; main.py:188-189) ----------------------------------------
+def binary_rank_packet_halves(N: int, C: int, rank: int) -> int:
+    n = _lib.load().cfx_binary_rank_packet_bytes(N, C, rank)
+    if n == 0:
+        raise ValueError(f"invalid shape / rank for the rank-K 1-bit codec: ({N}, {C}), rank {rank} (1..8)")
+    return n // 2
+
+
+def binary_rank_compress_batch(xs, bases, new_bases, packets, init_qs, N: int, C: int, rank: int, update_cache: bool = True,
+                               ef: bool = True, stream: Optional[torch.cuda.Stream] = None) -> None:
+    """bits + rank-K scale factors of |x - base| (+ error-feedback state) for a batch; init_q_i: (C, 8) fp32, columns >= rank zero."""
+    B = len(xs)
+    if not (1 <= B <= CFX_MAX_BATCH):
+        raise ValueError(f"batch {B} out of range 1..{CFX_MAX_BATCH}")
+    dev = _device_index(xs[0])
+    ctx = context(dev)
+    lib = _lib.load()
+    items = (CompItem * B)()
+    qptr = (ctypes.c_void_p * B)()
+    for i in range(B):
+        _check_nc(xs[i], N, C, "x")
+        q = init_qs[i]
+        if q.dtype != torch.float32 or tuple(q.shape) != (C, 8) or not q.is_contiguous():
+            raise ValueError(f"init_q must be a contiguous fp32 ({C}, 8) tensor")
+        items[i] = CompItem(_ptr(xs[i]), _ptr(bases[i]), _ptr(new_bases[i]) if update_cache else None, _ptr(packets[i]))
+        qptr[i] = q.data_ptr()
+    need = lib.cfx_binary_rank_workspace_bytes(N, C, rank, B)
+    if need == 0:
+        raise ValueError("invalid shape / rank for the rank-K 1-bit codec")
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    w = _lr_ws.get(key)
+    if w is None or w.numel() < need:
+        w = _lr_ws[key] = torch.empty(need, dtype=torch.uint8, device=f"cuda:{dev}")
+    flags = (FLAG_UPDATE_CACHE if update_cache else 0) | (0 if ef else FLAG_NO_EF)
+    rc = lib.cfx_binary_rank_compress_batch(ctx, N, C, rank, flags, B, items, qptr, w.data_ptr(), w.numel(), _stream_handle(stream, dev))
+    _check(ctx, rc, "cfx_binary_rank_compress_batch")
+
+
+def binary_rank_decompress_batch(packets, bases, recons, N: int, C: int, rank: int, stream: Optional[torch.cuda.Stream] = None) -> None:
+    B = len(packets)
+    if not (1 <= B <= CFX_MAX_BATCH):
+        raise ValueError(f"batch {B} out of range 1..{CFX_MAX_BATCH}")
+    dev = _device_index(recons[0])
+    ctx = context(dev)
+    items = (DecompItem * B)()
+    for i in range(B):
+        _check_nc(recons[i], N, C, "recon")
+        _device_index(packets[i])
+        items[i] = DecompItem(_ptr(packets[i]), _ptr(bases[i]), _ptr(recons[i]))
+    rc = _lib.load().cfx_binary_rank_decompress_batch(ctx, N, C, rank, B, items, _stream_handle(stream, dev))
+    _check(ctx, rc, "cfx_binary_rank_decompress_batch")

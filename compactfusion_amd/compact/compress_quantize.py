@@ -26,13 +26,19 @@ def _cat_packet(*parts):
 
 # ---- 1 bit -------------------------------------------------------------------------------------------------------
 def quantize_1bit(input_tensor: torch.Tensor, rank):
-    """-> packed (N, C//8) uint8, scale_u (N,1), scale_v (1,C)   (rank = -1: mean scales)."""
+    """-> packed (N, C//8) uint8, scale_u (N,K), scale_v (K,C)   (rank = -1: K = 1 mean scales; rank 1..8: rank-K factors of |x|,
+    compress_quantize.py:37-49 - note V is (K, C) here and (C, K) in the fastpath wire)."""
     assert rank >= 1 or rank == -1, "Rank must be >= 1 or -1"
-    if rank != -1:
-        raise NotImplementedError("rank >= 1 scales are deprecated in the reference")
     x = _nc(input_tensor)
     N, C = x.shape
     assert C % 8 == 0, "Channel dimension C must be divisible by 8 for packing"
+    if rank != -1:
+        from . import lowrank
+        pkt = torch.empty(codecs.binary_rank_packet_halves(N, C, rank), dtype=torch.float16, device=x.device)
+        codecs.binary_rank_compress_batch([x], [None], [None], [pkt], [lowrank._start(C, rank, x.device, 8)], N, C, rank, update_cache=False)
+        qh = N * C // 16
+        return (pkt[:qh].view(torch.uint8).view(N, C // 8), pkt[qh:qh + N * rank].view(N, rank),
+                pkt[qh + N * rank:].view(C, rank).t().contiguous())
     pkt, _ = codecs.compress(K.BINARY, x, None, N, C, update_cache=False)
     qh = N * C // 16
     return pkt[:qh].view(torch.uint8).view(N, C // 8), pkt[qh:qh + N].view(N, 1), pkt[qh + N:].view(1, C)
@@ -42,7 +48,12 @@ def dequantize_1bit(packed_tensor: torch.Tensor, scale_u: torch.Tensor, scale_v:
     assert packed_tensor.dtype == torch.uint8 and scale_u.dtype == torch.half and scale_v.dtype == torch.half
     N, C8 = packed_tensor.shape
     C = C8 * 8
-    assert scale_u.shape == (N, 1) and scale_v.shape == (1, C), "only K = 1 scales are supported"
+    Kr = scale_u.shape[1]
+    assert scale_u.shape == (N, Kr) and scale_v.shape == (Kr, C)
+    if Kr > 1:
+        out = torch.empty((N, C), dtype=torch.float16, device=packed_tensor.device)
+        codecs.binary_rank_decompress_batch([_cat_packet(packed_tensor, scale_u, scale_v.t().contiguous())], [None], [out], N, C, Kr)
+        return out
     return codecs.decompress(K.BINARY, _cat_packet(packed_tensor, scale_u, scale_v), None, N, C)
 
 

@@ -43,16 +43,33 @@ def _dequant(cid, per_byte, packed, u, v, base):
 
 @Profiler.prof_func("compact.binary_quant_fastpath")
 def binary_quant_fastpath(x_tensor_nc: torch.Tensor, base_tensor_nc: torch.Tensor, rank: int, update_cache: bool):
-    """-> packed (N, C//8) uint8, scale_u (N,1), scale_v (C,1), new_base (N,C) | None.   rank must be -1."""
+    """-> packed (N, C//8) uint8, scale_u (N,K), scale_v (C,K), new_base (N,C) | None.   rank -1 (K = 1: mean scales) or 1..8."""
     assert rank >= 1 or rank == -1, "Rank must be >= 1 or -1"
-    if rank != -1:
-        raise NotImplementedError("subspace-iteration scales (rank >= 1) are deprecated in the reference (main.py:188-189)")
     _check(x_tensor_nc, base_tensor_nc)
+    if rank != -1:
+        # scales = rank-K factors of |x - base| (fastpath.py:186-200: subspace_iter on the absolute residual): -> U (N, K), V (C, K)
+        from . import lowrank
+        x, base = x_tensor_nc.contiguous(), base_tensor_nc.contiguous()
+        N, C = x.shape
+        pkt = torch.empty(codecs.binary_rank_packet_halves(N, C, rank), dtype=torch.float16, device=x.device)
+        nb = torch.empty_like(x) if update_cache else None
+        codecs.binary_rank_compress_batch([x], [base], [nb], [pkt], [lowrank._start(C, rank, x.device, 8)], N, C, rank, update_cache=update_cache)
+        qh = N * (C // 8) // 2
+        return pkt[:qh].view(torch.uint8).view(N, C // 8), pkt[qh:qh + N * rank].view(N, rank), pkt[qh + N * rank:].view(C, rank), nb
     return _quant(_BIN, 8, x_tensor_nc, base_tensor_nc, update_cache)
 
 
 @Profiler.prof_func("compact.binary_dequant_fastpath")
 def binary_dequant_fastpath(packed: torch.Tensor, scale_u_nk: torch.Tensor, scale_v_ck: torch.Tensor, base_nc: torch.Tensor):
+    K = scale_u_nk.shape[1]
+    if K > 1 or scale_v_ck.shape[1] > 1:              # rank-K scales (the rank is inferred from the scales, fastpath.py:400-404)
+        N, Cp = packed.shape
+        C = Cp * 8
+        assert scale_u_nk.shape == (N, K) and scale_v_ck.shape == (C, K) and base_nc.shape == (N, C)
+        pkt = torch.cat([packed.contiguous().view(-1).view(torch.half), scale_u_nk.reshape(-1), scale_v_ck.reshape(-1)])
+        out = torch.empty((N, C), dtype=torch.float16, device=base_nc.device)
+        codecs.binary_rank_decompress_batch([pkt], [base_nc.contiguous()], [out], N, C, K)
+        return out
     return _dequant(_BIN, 8, packed, scale_u_nk, scale_v_ck, base_nc)
 
 

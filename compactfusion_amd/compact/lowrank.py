@@ -25,6 +25,7 @@ from ..prof import Profiler
 from .utils import COMPACT_COMPRESS_TYPE as T
 
 LOW_RANK_ID, LOW_RANK_Q_ID = 101, 102
+BINARY_RANK_ID = 103          # 1-bit codec whose scales are rank-K factors of |x - base| (fastpath.py:88-120; deprecated in the reference)
 _pinned_q: Optional[torch.Tensor] = None
 
 
@@ -38,8 +39,8 @@ def set_init_q(q: Optional[torch.Tensor]) -> None:
     _pinned_q = q
 
 
-def _start(C: int, rank: int, device) -> torch.Tensor:
-    rp = codecs.lr_rank_pad(rank)
+def _start(C: int, rank: int, device, rp: Optional[int] = None) -> torch.Tensor:
+    rp = codecs.lr_rank_pad(rank) if rp is None else rp
     q = torch.zeros(C, rp, dtype=torch.float32, device=device)
     if _pinned_q is not None:
         assert tuple(_pinned_q.shape) == (C, rank), f"pinned init_q must be ({C}, {rank})"
@@ -50,6 +51,8 @@ def _start(C: int, rank: int, device) -> torch.Tensor:
 
 
 def packet_halves(cid: int, rank: int, N: int, C: int) -> int:
+    if cid == BINARY_RANK_ID:
+        return codecs.binary_rank_packet_halves(N, C, rank)
     return codecs.lr_packet_halves(cid == LOW_RANK_Q_ID, N, C, rank)
 
 
@@ -57,6 +60,10 @@ def packet_halves(cid: int, rank: int, N: int, C: int) -> int:
 def compress(cid: int, rank: int, x: torch.Tensor, base: Optional[torch.Tensor], new_base: Optional[torch.Tensor],
              packet: torch.Tensor, update: bool, ef: bool = True) -> None:
     N, C = x.shape
+    if cid == BINARY_RANK_ID:
+        codecs.binary_rank_compress_batch([x], [base], [new_base if update else None], [packet], [_start(C, rank, x.device, 8)], N, C, rank,
+                                          update_cache=update, ef=ef)
+        return
     codecs.lr_compress_batch(cid == LOW_RANK_Q_ID, [x], [base], [new_base if update else None], [packet],
                              [_start(C, rank, x.device)], N, C, rank, update_cache=update, ef=ef)
 
@@ -64,6 +71,9 @@ def compress(cid: int, rank: int, x: torch.Tensor, base: Optional[torch.Tensor],
 @Profiler.prof_func("compact.lowrank.decompress")
 def decompress(cid: int, rank: int, packet: torch.Tensor, base: Optional[torch.Tensor], out: torch.Tensor) -> None:
     N, C = out.shape
+    if cid == BINARY_RANK_ID:
+        codecs.binary_rank_decompress_batch([packet], [base], [out], N, C, rank)
+        return
     codecs.lr_decompress_batch(cid == LOW_RANK_Q_ID, [packet], [base], [out], N, C, rank)
 
 

@@ -138,9 +138,10 @@ def _native(compress_type: T) -> Tuple[int, int]:
     if compress_type == T.BINARY:
         rank = _config.comp_rank
         if rank is not None and rank != -1:
-            assert ALLOW_DEPRECATED, "Binary compression with rank != -1 is deprecated"
-            raise NotImplementedError("1-bit with subspace-iteration scales (comp_rank >= 1) is deprecated in the "
-                                      "reference (main.py:188-189) and not implemented here; use comp_rank=-1")
+            assert ALLOW_DEPRECATED, "Binary compression with rank != -1 is deprecated"      # main.py:188-189
+            assert 1 <= rank <= 8, "1-bit with subspace-iteration scales: comp_rank must be 1..8"
+            from . import lowrank
+            return lowrank.BINARY_RANK_ID, int(rank)
         return int(codecs.Codec.BINARY), 0
     if compress_type == T.INT2:
         return int(codecs.Codec.INT2), 0

@@ -328,7 +328,11 @@ class _LayerExchange:
         else:
             from .. import lanes
             # the CU-masked exchange stream when the model runs on the lane's compute stream (disjoint CU sets), else an unmasked one
-            xstream = lanes.exchange_stream(dev) if (self.lane and lanes.on_compute_stream(dev)) else _exchange_stream(self.send.device)
+            if self.lane:
+                # flags order the two streams, so the exchange stream must OWN its hardware queue (lanes.dedicated_stream)
+                xstream = lanes.exchange_stream(dev) if lanes.on_compute_stream(dev) else lanes.dedicated_stream(dev)
+            else:
+                xstream = _exchange_stream(self.send.device)
             xs_handle = xstream.cuda_stream
             assert lib.cfx_plan_use_exchange_stream(plan, xs_handle) == 0
         # the compress launches run on the exchange stream in the lane / chain modes: their statistics workspace belongs to THAT stream

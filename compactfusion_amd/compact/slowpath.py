@@ -25,7 +25,7 @@ def _resolve(compress_type, rank, sparse_ratio):
     if compress_type == T.BINARY:
         assert rank is not None and (rank >= 1 or rank == -1), "Rank must be >= 1 or -1 for BINARY compression"
         if rank != -1:
-            raise NotImplementedError("BINARY with rank >= 1 is deprecated in the reference")
+            return "binary_rank", int(rank)       # rank-K scales (deprecated in the reference, kept for its tests): wire [q | U (N,K) | V (K,C)]
     if compress_type == T.SPARSE:
         assert sparse_ratio is not None, "sparse_ratio must be provided for SPARSE compression"
         return int(_MAP[compress_type]), int(sparse_ratio)
@@ -40,6 +40,11 @@ def slowpath_compress(x: torch.Tensor, compress_type: T, rank: int = None, spars
     if cid is None:
         from . import lowrank
         return lowrank.slowpath_compress(x.contiguous(), compress_type, param)
+    if cid == "binary_rank":
+        # slowpath.py:44-53: quantize_1bit(x, rank) -> cat(q, U (N,K), V (K,C))
+        from .compress_quantize import quantize_1bit
+        q, u, v = quantize_1bit(x, param)
+        return torch.cat([q.contiguous().view(-1).view(torch.half), u.reshape(-1), v.reshape(-1)])
     pkt, _ = codecs.compress(cid, x.contiguous(), None, N, C, param, update_cache=False)
     return pkt
 
@@ -52,6 +57,11 @@ def slowpath_decompress(x: torch.Tensor, shape: tuple, compress_type: T, rank: i
     if cid is None:
         from . import lowrank
         return lowrank.slowpath_decompress(x, (N, C), compress_type, param)
+    if cid == "binary_rank":
+        from .compress_quantize import dequantize_1bit
+        qh = N * C // 16
+        assert x.numel() == qh + (N + C) * param, "packet size does not match (N, C) and the rank"
+        return dequantize_1bit(x[:qh].view(torch.uint8).view(N, C // 8), x[qh:qh + N * param].view(N, param), x[qh + N * param:].view(param, C))
     assert x.numel() == codecs.packet_halves(cid, N, C, param), "packet size does not match (N, C) and the codec"
     return codecs.decompress(cid, x, None, N, C, param)
 

@@ -32,6 +32,12 @@
 #include "cfx.h"
 #include "cfx_internal.h"
 
+// cfx_lowrank.hip (the rank-K scales of the 1-bit codec are low-rank factors of |x - base|)
+#define CFX_I_FLAG_LR_FACTORS_ONLY 0x100
+#define CFX_I_FLAG_LR_ABS 0x200
+extern "C" CFX_HIDDEN size_t cfx_i_lr_workspace_bytes_any(int N, int C, int rank, int batch);
+extern "C" CFX_HIDDEN void cfx_i_lr_factor_offsets(int N, int C, int rank, size_t* offU16, size_t* offV16, size_t* per);
+
 typedef _Float16 h16;
 typedef h16 h16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
@@ -449,6 +455,76 @@ __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, in
     // lane: publish `pre` first - the launch in front of this one in the stream (the previous peer's reconstruction) has finished
     if (pre && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) st_wt(pre, pre_val);
     binary_dequant_body<WAVES, UN>(batch.it[blockIdx.z], N, C, R, blockIdx.x, blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 1-bit codec with rank-K scales      replaces the K-loop of _binary_quant_fastpath / _binary_dequant_fastpath (fastpath.py:88-120, :330-360)
+// and quantize_1bit(rank >= 1) / dequantize_1bit (compress_quantize.py:37-49, :154-225); deprecated in the reference (main.py:188-189).
+//   scale[n, c] = fp16( sum_k fp32( fp16(U[n,k] * V[c,k]) ) )     U (N, K), V (C, K) fp16 = the rank-K factors of |x - base| (cfx_lowrank)
+//   out = base + (2 b - 1) * scale                                 wire [ bits N*C/8 | U N*K | V C*K ]   (main.py:149-152)
+// (Triton's tl.sum adds the fp16 products in fp16 in an unspecified tree order; here they are added in fp32 in index order and
+// rounded once - equal for K = 1, within an ulp otherwise; sender and receiver run this same arithmetic on the same fp16 factors.)
+// QUANT: x and the factor workspace in, bits + factors + new state out; else packet in, reconstruction out.  K <= 8.
+// ---------------------------------------------------------------------------------------------------
+struct RankFac { const h16* U[CFX_MAX_BATCH]; const h16* VT[CFX_MAX_BATCH]; };
+template <bool QUANT>
+__global__ __launch_bounds__(NTHR) void k_binary_rank(BatchC bc, BatchD bd, RankFac fac, int N, int C, int R, int K, int flags) {
+    const TileCoord t = tile_coord(N, C, R);
+    const int z = blockIdx.z;
+    const int C8 = C >> 3;
+    unsigned char* pk = QUANT ? (unsigned char*)bc.it[z].packet : (unsigned char*)bd.it[z].packet;
+    h16* Up = (h16*)(pk + (size_t)N * C8);                       // packet sections
+    h16* Vp = Up + (size_t)N * K;
+    const h16* U = QUANT ? fac.U[z] : Up;
+    const h16* VT = QUANT ? fac.VT[z] : Vp;
+    const h16* x = QUANT ? (const h16*)bc.it[z].x : nullptr;
+    const h16* base = QUANT ? (const h16*)bc.it[z].base : (const h16*)bd.it[z].base;
+    h16* out = QUANT ? (h16*)bc.it[z].new_base : (h16*)bd.it[z].recon;
+    const bool upd = QUANT ? ((flags & CFX_FLAG_UPDATE_CACHE) && out) : true;
+    const bool ef = !(flags & CFX_FLAG_NO_EF);
+    h16 v[8][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[e][k] = (t.act && k < K) ? VT[(size_t)(t.c + e) * K + k] : (h16)0;
+    if (QUANT) {
+        // the factors go into the packet as they are: V by the first row block, U by the first column block
+        if (blockIdx.y == 0 && t.act)
+            for (int e = 0; e < 8; ++e)
+                for (int k = 0; k < K; ++k) Vp[(size_t)(t.c + e) * K + k] = v[e][k];
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < (t.r1 - t.r0) * K; i += NTHR) Up[(size_t)t.r0 * K + i] = U[(size_t)t.r0 * K + i];
+    }
+    for (int r = t.r0 + t.w; r < t.r1; r += WAVES) {
+        if (!t.act) continue;
+        h16 u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k] = (k < K) ? U[(size_t)r * K + k] : (h16)0;
+        h16x8 bv = (h16x8)(h16)0, xv = (h16x8)(h16)0;
+        if (base) bv = ld8(base + (size_t)r * C + t.c);
+        unsigned byte;
+        if (QUANT) {
+            xv = ld8(x + (size_t)r * C + t.c);
+            const h16x8 d = xv - bv;
+            byte = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) byte |= (d[i] >= (h16)0 ? 1u : 0u) << i;
+            pk[(size_t)r * C8 + (t.c >> 3)] = (unsigned char)byte;
+        } else byte = pk[(size_t)r * C8 + (t.c >> 3)];
+        if (!upd) continue;
+        h16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += (float)(h16)(u[k] * v[e][k]);       // fp16 product (one rounding), fp32 sum in index order
+            const h16 sc = (h16)acc;
+            const h16 recv = ((byte >> e) & 1u) ? sc : -sc;
+            o[e] = base ? (h16)(bv[e] + recv) : recv;
+        }
+        if (QUANT && !ef) o = xv;                                   // error feedback off: the state becomes the activation (main.py:233)
+        st8(out + (size_t)r * C + t.c, o);
+    }
 }
 
 // Gated reconstruction: the same arithmetic for a packet that workgroups of THIS launch are still producing (the compress group
@@ -2440,6 +2516,76 @@ int cfx_i_launch_pipe(cfx_plan* p, hipStream_t s, int N, int C, const int* comp_
 }
 
 extern "C" {
+
+size_t cfx_binary_rank_packet_bytes(int N, int C, int rank) {
+    if (N <= 0 || C <= 0 || (C % 8) || rank < 1 || rank > 8 || (((size_t)N * (C / 8)) % 2)) return 0;
+    return (size_t)N * C / 8 + 2 * ((size_t)N + C) * rank;
+}
+
+size_t cfx_binary_rank_workspace_bytes(int N, int C, int rank, int batch) {
+    if (!cfx_binary_rank_packet_bytes(N, C, rank) || batch < 1 || batch > CFX_MAX_BATCH) return 0;
+    return cfx_i_lr_workspace_bytes_any(N, C, rank, batch);
+}
+
+int cfx_binary_rank_compress_batch(cfx_ctx* ctx, int N, int C, int rank, int flags, int batch, const cfx_comp_item* items,
+                                   const void* const* init_q, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!ctx || !items || !init_q) return fail(ctx, CFX_ERR_NULL, "binary rank-K compress: null ctx/items/init_q");
+    if (batch < 1 || batch > CFX_MAX_BATCH) return fail(ctx, CFX_ERR_BATCH, "binary rank-K compress: batch out of range");
+    if (!cfx_binary_rank_packet_bytes(N, C, rank)) return fail(ctx, CFX_ERR_SHAPE, "binary rank-K compress: bad shape / rank (1 .. 8)");
+    const size_t need = cfx_binary_rank_workspace_bytes(N, C, rank, batch);
+    if (!workspace || workspace_bytes < need) return fail(ctx, CFX_ERR_WORKSPACE, "binary rank-K compress: workspace too small");
+    const bool upd = flags & CFX_FLAG_UPDATE_CACHE;
+    BatchC b;
+    memset(&b, 0, sizeof(b));
+    for (int i = 0; i < batch; ++i) {
+        if (!items[i].x || !items[i].packet) return fail(ctx, CFX_ERR_NULL, "binary rank-K compress: null x/packet");
+        if (upd && !items[i].new_base) return fail(ctx, CFX_ERR_NULL, "binary rank-K compress: UPDATE_CACHE needs new_base");
+        if (!AL16(items[i].x) || !AL16(items[i].base) || !AL16(items[i].new_base) || !AL16(items[i].packet))
+            return fail(ctx, CFX_ERR_ALIGN, "binary rank-K compress: pointers must be 16-byte aligned");
+        b.it[i] = items[i];
+    }
+    // 1. rank-K factors of |x - base| (the low-rank chain, stopped at the fp16 factors in the workspace)
+    const int rf = cfx_lr_compress_batch(ctx, 1, N, C, rank, CFX_I_FLAG_LR_FACTORS_ONLY | CFX_I_FLAG_LR_ABS, batch, items, init_q, workspace,
+                                         workspace_bytes, stream);
+    if (rf != CFX_OK) return rf;
+    size_t offU = 0, offV = 0, per1 = 0;
+    cfx_i_lr_factor_offsets(N, C, rank, &offU, &offV, &per1);
+    const size_t per = need / batch;
+    RankFac fac;
+    memset(&fac, 0, sizeof(fac));
+    for (int i = 0; i < batch; ++i) {
+        fac.U[i] = (const h16*)((char*)workspace + per * i + offU);
+        fac.VT[i] = (const h16*)((char*)workspace + per * i + offV);
+    }
+    // 2. sign bits, factors into the packet, error-feedback state
+    hipStream_t s = (hipStream_t)stream;
+    const int R = WAVES * UNROLL;
+    BatchD dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    LAUNCH(ctx, KID_BINARY_EF, s, k_binary_rank<true>, dim3((C + TILE_C - 1) / TILE_C, (N + R - 1) / R, batch), dim3(NTHR), 0, s, b, dummy, fac, N, C, R, rank, flags);
+    return check_launch(ctx, "binary rank-K compress launch");
+}
+
+int cfx_binary_rank_decompress_batch(cfx_ctx* ctx, int N, int C, int rank, int batch, const cfx_decomp_item* items, void* stream) {
+    if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "binary rank-K decompress: null ctx/items");
+    if (batch < 1 || batch > CFX_MAX_BATCH) return fail(ctx, CFX_ERR_BATCH, "binary rank-K decompress: batch out of range");
+    if (!cfx_binary_rank_packet_bytes(N, C, rank)) return fail(ctx, CFX_ERR_SHAPE, "binary rank-K decompress: bad shape / rank (1 .. 8)");
+    BatchD b;
+    memset(&b, 0, sizeof(b));
+    for (int i = 0; i < batch; ++i) {
+        if (!items[i].packet || !items[i].recon) return fail(ctx, CFX_ERR_NULL, "binary rank-K decompress: null packet/recon");
+        if (!AL16(items[i].packet) || !AL16(items[i].recon) || !AL16(items[i].base)) return fail(ctx, CFX_ERR_ALIGN, "binary rank-K decompress: pointers must be 16-byte aligned");
+        b.it[i] = items[i];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int R = WAVES * UNROLL;
+    BatchC dummy;
+    RankFac fac;
+    memset(&dummy, 0, sizeof(dummy));
+    memset(&fac, 0, sizeof(fac));
+    LAUNCH(ctx, KID_BINARY_DEQUANT, s, k_binary_rank<false>, dim3((C + TILE_C - 1) / TILE_C, (N + R - 1) / R, batch), dim3(NTHR), 0, s, dummy, b, fac, N, C, R, rank, 0);
+    return check_launch(ctx, "binary rank-K decompress launch");
+}
 
 int cfx_residual2_delta(cfx_ctx* ctx, const void* x, const void* base, const void* delta_base, void* dd, size_t n, void* stream) {
     if (!ctx || !x || !base || !delta_base || !dd) return fail(ctx, CFX_ERR_NULL, "residual2_delta: null pointer");

@@ -58,7 +58,7 @@ static LrWs lr_layout(int N, int C, int RP) {
 // FROMX (the first product of a chain): D = x - base is formed on the fly (fp16, one rounding, as torch eager) and written to the
 //   workspace for the later passes - every element of D is read by exactly one workgroup here, so k_lr_prep is not needed.
 template <int RP, bool FROMX>
-__global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t offD, size_t offQ, size_t offY, int use_q0) {
+__global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t offD, size_t offQ, size_t offY, int use_q0, int absd) {
     constexpr int CK = 256, LDD = CK + 2;            // LDD/2 = 129 dwords: odd row stride -> conflict-free column reads
     constexpr int QV = CK * RP / 4 / 256;            // float4 of Q per thread per chunk (8 at RP = 32)
     const LrItem it = b.it[blockIdx.z];
@@ -86,6 +86,12 @@ __global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t o
                 if (FROMX) {
                     h16x8 xv = *reinterpret_cast<const h16x8*>(it.x + o);
                     if (it.base) xv = xv - *reinterpret_cast<const h16x8*>(it.base + o);
+                    if (absd) {                          // the matrix to factorise is |x - base| (rank-K scales of the 1-bit codec)
+                        typedef unsigned short u16x8_ __attribute__((ext_vector_type(8)));
+                        u16x8_ bb = __builtin_bit_cast(u16x8_, xv);
+                        bb &= (unsigned short)0x7fff;
+                        xv = __builtin_bit_cast(h16x8, bb);
+                    }
                     *reinterpret_cast<h16x8*>(D + o) = xv;
                     dreg[u] = xv;
                 } else dreg[u] = *reinterpret_cast<const h16x8*>(D + o);
@@ -552,10 +558,20 @@ size_t cfx_lr_packet_bytes(int quantized, int N, int C, int rank) {
 
 size_t cfx_lr_workspace_bytes(int quantized, int N, int C, int rank, int batch) {
     if (!lr_shape_ok(quantized, N, C, rank) || batch < 1 || batch > LR_MAXB) return 0;
+    return cfx_i_lr_workspace_bytes_any(N, C, rank, batch);
+}
+
+size_t cfx_i_lr_workspace_bytes_any(int N, int C, int rank, int batch) {
     size_t per = lr_layout(N, C, lr_rp(rank)).total;
     // the int4 factor quantiser's own scratch (min/max partials), for the larger factor
     per += al256(cfx_workspace_bytes(CFX_CODEC_INT4, (N > C ? N : C) + ((N > C ? N : C) & 1), 32, 0, 1));
     return per * batch;
+}
+
+void cfx_i_lr_factor_offsets(int N, int C, int rank, size_t* offU16, size_t* offV16, size_t* per) {
+    const LrWs w = lr_layout(N, C, lr_rp(rank));
+    *offU16 = w.U16; *offV16 = w.V16;
+    *per = cfx_i_lr_workspace_bytes_any(N, C, rank, 1);
 }
 
 int cfx_i_lr_decode_launch(cfx_ctx* ctx, int N, int C, int rank, int batch, const LrDec* items, bool vt, hipStream_t s) {
@@ -588,10 +604,15 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
                           const void* const* init_q, void* workspace, size_t workspace_bytes, void* stream) {
     if (!ctx || !items || !init_q) return fail(ctx, CFX_ERR_NULL, "lr compress: null ctx/items/init_q");
     if (batch < 1 || batch > LR_MAXB) return fail(ctx, CFX_ERR_BATCH, "lr compress: batch out of range");
-    if (!lr_shape_ok(quantized, N, C, rank)) return fail(ctx, CFX_ERR_SHAPE, "lr compress: bad shape/rank");
-    const size_t need = cfx_lr_workspace_bytes(quantized, N, C, rank, batch);
+    // internal callers (the rank-K scales of the 1-bit codec, cfx_binary_rank_*): factorise |x - base| and stop once the fp16 factors
+    // U (N x r) and V^T (C x r) are in the workspace; any rank 1 .. 32
+    const bool factors_only = flags & CFX_I_FLAG_LR_FACTORS_ONLY;
+    const int absd = (flags & CFX_I_FLAG_LR_ABS) ? 1 : 0;
+    if (factors_only ? !(N > 0 && C > 0 && C % 8 == 0 && rank >= 1 && rank <= 32 && quantized) : !lr_shape_ok(quantized, N, C, rank))
+        return fail(ctx, CFX_ERR_SHAPE, "lr compress: bad shape/rank");
+    const size_t need = cfx_i_lr_workspace_bytes_any(N, C, rank, batch);
     if (!workspace || workspace_bytes < need) return fail(ctx, CFX_ERR_WORKSPACE, "lr compress: workspace too small");
-    const bool upd = flags & CFX_FLAG_UPDATE_CACHE;
+    const bool upd = (flags & CFX_FLAG_UPDATE_CACHE) && !factors_only;
     const int RPv = lr_rp(rank);
     const LrWs w = lr_layout(N, C, RPv);
     const size_t per = need / batch;
@@ -615,20 +636,20 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
     // C-space chain's separate launches)
     const bool gram = cfx_i_lrg_ok(N, C) && RPv <= 16 && !(chain_env && !strcmp(chain_env, "cspace"));
     if (gram) {
-        const int rg = cfx_i_lrg_factors(ctx, quantized, N, C, rank, batch, b, w.D, w.U16, w.V16, w.gram, s);
+        const int rg = cfx_i_lrg_factors(ctx, quantized, N, C, rank, batch, b, w.D, w.U16, w.V16, w.gram, absd, s);
         if (rg != CFX_OK) return rg;
     } else {
         // D = x - base is formed (and stored) by the first product.  (Forming Q = orth(Z) = Z T inside the next product instead of by a
         // launch of its own was measured slower at every rank: 17 row tiles redo the same RP x RP products per chunk.)
         const LrApply aq_ = {C, rank, 1, 0, 0, w.Zb, w.T, w.Qa, 0};
         for (int iter = 0; iter < 2; ++iter) {
-            if (iter == 0) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, true>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 1));
-            else LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0));
+            if (iter == 0) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, true>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 1, absd));
+            else LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0, 0));
             LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 0));
             LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(512), 0, s, b, rank, nparts, w.Gp, w.T));
             LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), g_apc, dim3(256), 0, s, b, aq_, aq_, (int)g_apc.x));
         }
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0));
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0, 0));
         LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 1));
         LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(512), 0, s, b, rank, nparts, w.Gp, w.T));
     }
@@ -647,6 +668,7 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
         // factors (what the receiver will see) feed the error-feedback decode
         const LrApply au = {N, rank, 4, 1, 0, w.Y, w.T, w.U16, 0}, av = {C, rank, 1, 1, 0, w.Zb, w.T, w.V16, 0};
         if (!gram) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), dim3(g_apn.x + g_apc.x, batch), dim3(256), 0, s, b, au, av, (int)g_apn.x));
+        if (factors_only) return check_launch(ctx, "lr factor launch");
         const size_t secU = (size_t)N * rank / 2 + 4 * rank, secV = (size_t)C * rank / 2 + 4 * rank;       // bytes
         const size_t i4ws_off = w.total;
         // one batched launch sequence per factor side (U sections are 16-byte aligned in the packet; V sections may start

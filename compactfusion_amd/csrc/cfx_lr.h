@@ -27,12 +27,16 @@ static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 static inline int lr_rp(int rank) { return rank <= 8 ? 8 : (rank <= 16 ? 16 : 32); }
 
 // cfx_lowrank.hip
+#define CFX_I_FLAG_LR_FACTORS_ONLY 0x100     // cfx_lr_compress_batch (quantized = 1): stop when fp16 U (N x r), V^T (C x r) are in the workspace
+#define CFX_I_FLAG_LR_ABS 0x200              // ... of |x - base| instead of x - base
+extern "C" CFX_HIDDEN size_t cfx_i_lr_workspace_bytes_any(int N, int C, int rank, int batch);
+extern "C" CFX_HIDDEN void cfx_i_lr_factor_offsets(int N, int C, int rank, size_t* offU16, size_t* offV16, size_t* per);
 extern "C" CFX_HIDDEN int cfx_i_lr_decode_launch(cfx_ctx* ctx, int N, int C, int rank, int batch, const LrDec* items, bool vt, hipStream_t s);
 // cfx_lrgram.hip: the N-space ("Gram") chain
 CFX_HIDDEN bool cfx_i_lrg_ok(int N, int C);
 CFX_HIDDEN size_t cfx_i_lrg_extra_bytes(int N, int C, int RP);
 CFX_HIDDEN int cfx_i_lrg_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int batch, const LrBatch& b, size_t offD, size_t offU16,
-                                 size_t offV16, size_t extra, hipStream_t s);
+                                 size_t offV16, size_t extra, int absd, hipStream_t s);
 
 // T (RP x RP fp32, upper triangular, row-major at T[i * RP + m]) = chol(G)^-T for the symmetrised G (RP x RP fp64 in LDS); rank = r <= RP.
 // A non-positive pivot (rank-deficient residual, e.g. x == base) zeroes that direction instead of producing NaNs.  Called by EVERY

@@ -49,6 +49,7 @@ struct LrgArgs {
     int xcd_group;           // 8 / batch when that divides: a tensor's workgroups stay on ITS XCDs (block b runs on XCD b % 8), so its
                              // D (3.3 MB at the FLUX shard) stays resident in their L2s; 0: plain tensor-major order
     size_t offD, offG, offGp, offY0, offY0p, offW1, offW2, offMp, offPp, offT, offUf, offU16, offV16;
+    int absd;                // factorise |x - base|
     int u_in_packet;         // LOW_RANK: U (N x r) and V (r x C) straight into the packet; LOW_RANK_Q: fp16 U (N x r), V^T (C x r) to the workspace
     unsigned* tick;
 };
@@ -61,7 +62,7 @@ __device__ __forceinline__ bool lrg_block(const LrgArgs& a, int& z, int& idx) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lrg_prep(LrBatch b, size_t n8, size_t offD) {
+__global__ __launch_bounds__(256) void k_lrg_prep(LrBatch b, size_t n8, size_t offD, int absd) {
     const LrItem it = b.it[blockIdx.y];
     h16* D = (h16*)(it.ws + offD);
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -69,6 +70,12 @@ __global__ __launch_bounds__(256) void k_lrg_prep(LrBatch b, size_t n8, size_t o
     for (; i < n8; i += stride) {
         h16x8 v = lrg_ld8(it.x + i * 8);
         if (it.base) v = v - lrg_ld8(it.base + i * 8);                 // fp16, one rounding (torch eager: x - base)
+        if (absd) {                                                    // |x - base|: the matrix behind the 1-bit codec's rank-K scales
+            typedef unsigned short u16x8_ __attribute__((ext_vector_type(8)));
+            u16x8_ bb = __builtin_bit_cast(u16x8_, v);
+            bb &= (unsigned short)0x7fff;
+            v = __builtin_bit_cast(h16x8, bb);
+        }
         *reinterpret_cast<h16x8*>(D + i * 8) = v;
     }
 }
@@ -600,7 +607,7 @@ template <int RP>
 static int lrg_run(cfx_ctx* ctx, const LrBatch& b, LrgArgs a, hipStream_t s) {
     const int N = a.N, C = a.C;
     const size_t n8 = (size_t)N * C / 8;
-    LAUNCH(ctx, KID_LR_PREP, s, k_lrg_prep, dim3((unsigned)((n8 + 255) / 256 < 1024 ? (n8 + 255) / 256 : 1024), a.batch), dim3(256), 0, s, b, n8, a.offD);
+    LAUNCH(ctx, KID_LR_PREP, s, k_lrg_prep, dim3((unsigned)((n8 + 255) / 256 < 1024 ? (n8 + 255) / 256 : 1024), a.batch), dim3(256), 0, s, b, n8, a.offD, a.absd);
     auto grid_of = [&](int per_tensor) {
         a.per_tensor = per_tensor;
         if (a.xcd_group) return dim3((unsigned)((per_tensor + a.xcd_group - 1) / a.xcd_group * 8));
@@ -632,7 +639,7 @@ static int lrg_run(cfx_ctx* ctx, const LrBatch& b, LrgArgs a, hipStream_t s) {
 // (C x r) at offV16 of each tensor's workspace (what the int4 factor quantiser of cfx_lowrank.hip takes).  `extra` = offset of
 // cfx_i_lrg_extra_bytes() bytes inside each tensor's workspace.
 int cfx_i_lrg_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int batch, const LrBatch& b, size_t offD, size_t offU16, size_t offV16,
-                      size_t extra, hipStream_t s) {
+                      size_t extra, int absd, hipStream_t s) {
     const int RPv = lr_rp(rank);
     LrgArgs a;
     memset(&a, 0, sizeof(a));
@@ -654,6 +661,7 @@ int cfx_i_lrg_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int b
     a.offT = o;   o += al256(3 * (size_t)RPv * RPv * 4);
     a.offUf = o;  o += al256(NP * RPv * 4);
     a.u_in_packet = quantized ? 0 : 1;
+    a.absd = absd;
     a.tick = cfx_i_ticket_block(ctx, (void*)s);
     if (!a.tick) return fail(ctx, CFX_ERR_LAUNCH, "low-rank: no ticket block");
     if (RPv == 8) return lrg_run<8>(ctx, b, a, s);

@@ -46,6 +46,26 @@ class Lane:
 
 
 _lanes: Dict[int, Lane] = {}
+_dedicated: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def dedicated_stream(device: Optional[int] = None) -> "torch.cuda.Stream":
+    """An exchange stream over ALL CUs that owns its hardware queue.  Streams ordered by flags (one polls what the other sets) must not
+    share a hardware queue - the polling kernel would block the kernel it waits for until the wait times out - and HIP multiplexes
+    ordinary streams (hipStreamCreate, torch.cuda.Stream) over a small pool of queues.  A stream created with a CU mask is never
+    pooled, so this one is made by cfx_stream_create_masked with the full mask."""
+    if device is None:
+        device = torch.cuda.current_device()
+    s = _dedicated.get(device)
+    if s is None:
+        lib = _lib.load()
+        total = torch.cuda.get_device_properties(device).multi_processor_count
+        h = ctypes.c_void_p()
+        ctx = context(device)
+        if lib.cfx_stream_create_masked(ctx, 0, total, ctypes.byref(h)) != 0:
+            raise _lib.CfxError("cannot create the exchange stream: " + (lib.cfx_last_error_string(ctx) or b"").decode())
+        s = _dedicated[device] = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", device))
+    return s
 
 
 def lane(device: Optional[int] = None) -> Lane:

@@ -179,6 +179,19 @@ int    cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank
 int    cfx_lr_decompress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, int batch,
                                const cfx_decomp_item* items, void* workspace, size_t workspace_bytes, void* stream);
 
+/* 1-bit codec with rank-K scales (COMPACT_COMPRESS_TYPE.BINARY with comp_rank >= 1; deprecated in the reference, main.py:188-189):
+ *   cfx_binary_rank_compress_batch   replaces binary_quant_fastpath(rank >= 1) (xfuser/compact/fastpath.py:124-228: subspace_iter(|x - base|)
+ *                                    for the scales + the K-loop of _binary_quant_fastpath :88-120) and quantize_1bit(rank >= 1)
+ *                                    (compress_quantize.py:37-49)
+ *   cfx_binary_rank_decompress_batch replaces binary_dequant_fastpath (fastpath.py:371-438, K-loop :330-360) / dequantize_1bit
+ * scale[n, c] = fp16(sum_k fp16(U[n,k] * V[c,k])), out = base + (2 b - 1) * scale.  Wire [ bits N*C/8 | U (N,K) fp16 | V (C,K) fp16 ]
+ * (main.py:149-152).  rank 1 .. 8; init_q[i] as for cfx_lr_compress_batch (device C x 8 fp32, columns >= rank zero). */
+size_t cfx_binary_rank_packet_bytes(int N, int C, int rank);
+size_t cfx_binary_rank_workspace_bytes(int N, int C, int rank, int batch);
+int    cfx_binary_rank_compress_batch(cfx_ctx* ctx, int N, int C, int rank, int flags, int batch, const cfx_comp_item* items,
+                                      const void* const* init_q, void* workspace, size_t workspace_bytes, void* stream);
+int    cfx_binary_rank_decompress_batch(cfx_ctx* ctx, int N, int C, int rank, int batch, const cfx_decomp_item* items, void* stream);
+
 /* Native per-launch timing.  When enabled, every `stride`-th launch of a kernel whose id bit is set in kernel_mask
  * is bracketed by hipEvents recorded on the launch stream (up to `capacity` records; capacity 0 disables).  An event
  * pair costs ~2-5 us of stream time, hence the stride.
@@ -266,6 +279,9 @@ int       cfx_plan_join(cfx_plan* plan, void* main_stream);
  * A wait gives up after the context's gate timeout (default 5 s, cfx_set_gate_timeout_ms) and counts the failure in a pinned host
  * word: the next plan / compress / merge call on the context returns CFX_ERR_GATE, cfx_gate_errors reads and clears the count
  * without synchronising the device.
+ * The two streams a flag orders must NOT share a hardware queue (the polling kernel would block the kernel it waits for until the
+ * timeout): HIP multiplexes ordinary streams over a small pool of queues, a CU-masked stream owns its queue - create at least the
+ * exchange stream with cfx_stream_create_masked (a full mask, first_cu = 0, n_cus = all, is fine).
  *   cfx_stream_create_masked      a stream restricted to CU-mask bits [first_cu, first_cu + n_cus) (hipExtStreamCreateWithCUMask; on
  *                                 MI355X bit i = CU i/8 of XCD i%8, so a contiguous range is the same share of every XCD).  The lane
  *                                 uses two with DISJOINT ranges - e.g. 32 CUs for the exchange, 224 for the compute stream the

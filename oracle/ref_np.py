@@ -141,6 +141,39 @@ def binary_apply(base16, bits01, u16, v16):
         return (base16 + recv).astype(F16)
 
 
+def binary_rank_scale(u16, vt16):
+    """Rank-K scale matrix of the 1-bit codec: scale[n, c] = fp16(sum_k fp16(U[n,k] * V[c,k]))   (fastpath.py:109: tl.sum of the fp16
+    products; Triton adds them in fp16 in an unspecified tree order - here fp32 in index order, one final rounding: equal for K = 1,
+    within an ulp otherwise).  u16 (N, K), vt16 (C, K)."""
+    u16, vt16 = as_f16(u16), as_f16(vt16)
+    acc = np.zeros((u16.shape[0], vt16.shape[0]), dtype=F32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        for k in range(u16.shape[1]):
+            acc = acc + (u16[:, k:k + 1] * vt16[:, k:k + 1].T).astype(F16).astype(F32)
+        return acc.astype(F16)
+
+
+def binary_rank_apply(base16, bits01, u16, vt16):
+    """out = base + (2b-1) * scale   (fastpath.py:109-116, :328-363 with K >= 1)."""
+    with np.errstate(invalid="ignore", over="ignore"):
+        scale = binary_rank_scale(u16, vt16)
+        recv = np.where(bits01.astype(bool), scale, -scale).astype(F16)
+        return recv if base16 is None else (as_f16(base16) + recv).astype(F16)
+
+
+def binary_rank_quant_fastpath(x, base, rank, init_q, update_cache=True):
+    """binary_quant_fastpath with rank >= 1 (fastpath.py:186-200): scales = subspace_iter(|x - base|, rank, 2) -> U (N,K), V (C,K).
+    init_q: the (C, rank) start matrix (the reference draws torch.randn and orthonormalises it; only its span matters)."""
+    x = as_f16(x)
+    base = None if base is None else as_f16(base)
+    d = x if base is None else (x - base).astype(F16)
+    packed = pack_bits_1(d)
+    U, V, _ = subspace_iter(np.abs(d), rank, 2, init_q=np.linalg.qr(np.asarray(init_q, dtype=F32))[0])
+    vt = np.ascontiguousarray(V.T)
+    nb = binary_rank_apply(base, unpack_bits_1(packed), U, vt) if update_cache else None
+    return packed, U, vt, nb
+
+
 def binary_quant_fastpath(x, base, rank=-1, update_cache=True):
     """fastpath.py:124-228 (`binary_quant_fastpath`, rank == -1 only).
     Returns packed (N, C/8) u8, u (N,1) f16, v (C,1) f16, new_base (N,C) f16 | None."""

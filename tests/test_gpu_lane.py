@@ -173,8 +173,10 @@ def test_flag_set_wait_order_two_streams():
     """Producer / consumer over two streams ordered ONLY by flags (data flag + acknowledge flag): the consumer's copy of the
     payload always sees the producer's fill of the same epoch - never an older or a newer one."""
     from compactfusion_amd import _lib, codecs as K
+    from compactfusion_amd import lanes
     lib, ctx = _lib.load(), K.context(0)
-    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    # flag-ordered streams must not share a hardware queue (pool streams may): each of these owns its queue
+    a, b = lanes.exchange_stream(0), lanes.compute_stream(0)
     flags = torch.zeros(32, dtype=torch.int32, device="cuda")
     ready, ack = flags.data_ptr(), flags.data_ptr() + 64
     src = torch.zeros(1 << 20, dtype=torch.int32, device="cuda")
@@ -236,8 +238,9 @@ def test_wait_timeout_is_reported_by_the_next_call():
 
 def test_merge_wait_releases_when_the_flag_arrives():
     from compactfusion_amd import _lib, codecs as K
+    from compactfusion_amd import lanes
     lib, ctx = _lib.load(), K.context(0)
-    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    a, b = lanes.compute_stream(0), lanes.dedicated_stream(0)          # each owns its hardware queue
     flag = torch.zeros(16, dtype=torch.int32, device="cuda")
     B, S, H, D = 1, 33, 3, 64
     g = torch.Generator(device="cuda").manual_seed(5)
