@@ -189,6 +189,29 @@ class _SteadyLayer:
             return False
         return q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and not Profiler.instance().enabled and not _collector_live()
 
+    def _fast_ok(self, q) -> bool:
+        """The lean host path applies when the fused SDPA op takes this shape and returns the layouts the native merge reads
+        (decided once per layer by trying it)."""
+        ok = getattr(self, "_fast", None)
+        if ok is not None:
+            return ok
+        self._fast = False
+        try:
+            if q.dtype == torch.float16 and q.shape[-1] % 8 == 0 and q.shape[-1] <= 512 and q.dim() == 4:
+                from .. import _lib, codecs
+                sdpa = torch.ops.aten._scaled_dot_product_flash_attention
+                qt = q.transpose(1, 2)
+                r = sdpa(qt, qt, qt, 0.0, False, False, scale=1.0)
+                if (r[0].dtype == torch.float16 and r[0].transpose(1, 2).is_contiguous() and r[1].dtype == torch.float32 and r[1].is_contiguous()
+                        and r[0].data_ptr() % 16 == 0):
+                    dev = q.device.index if q.device.index is not None else torch.cuda.current_device()
+                    self._sdpa, self._merge, self._ctx = sdpa, _lib.load().cfx_attn_merge_wait, codecs.context(dev)
+                    self._peer_t = [(kk.transpose(1, 2), vv.transpose(1, 2)) for kk, vv in self.ex.peer_views]
+                    self._fast = True
+        except (RuntimeError, NotImplementedError):
+            self._fast = False
+        return self._fast
+
     def run(self, q, k, v, softmax_scale):
         ex = self.ex
         sh = torch.cuda.current_stream(q.device).cuda_stream
@@ -196,6 +219,29 @@ class _SteadyLayer:
             # exchange lane: ONE native call issues the layer's whole chain on the exchange stream; the compute stream never sees
             # an event - the merge launch of block s also waits (in-kernel, on a flag) for peer s+1's reconstruction
             epoch = ex.lane_begin(sh)                       # "K, V exist" on the compute stream ...
+            fast = self._fast_ok(q)
+            if fast:
+                # lean host path (the step is host-bound long before it is GPU-bound: 8 attention + 8 merge calls per layer): cached
+                # transposed views of the peers' states, the fused SDPA op called directly, the merge through its cached entry point
+                sdpa, merge, ctx = self._sdpa, self._merge, self._ctx
+                B, S, H, D = q.shape
+                qt = q.transpose(1, 2)
+                res = sdpa(qt, k.transpose(1, 2), v.transpose(1, 2), 0.0, False, False, scale=softmax_scale)
+                ex.run_lane(k, v, None)                    # ... the chain's dozen launches are issued while the local block runs
+                cm._current_cache_key = self.last_key
+                out = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
+                lse = torch.empty((B, S, H, 1), dtype=torch.float32, device=q.device)
+                op, lp, last = out.data_ptr(), lse.data_ptr(), self.world - 1
+                if merge(ctx, op, lp, res[0].data_ptr(), res[1].data_ptr(), B, S, H, D, 1, 1, ex.flag_ptr(1), epoch, sh) != 0:
+                    raise RuntimeError("cfx_attn_merge_wait failed: " + (ex._lib.cfx_last_error_string(ctx) or b"").decode())
+                keep = [res]
+                for s_, (kt, vt) in enumerate(self._peer_t, start=1):
+                    res = sdpa(qt, kt, vt, 0.0, False, False, scale=softmax_scale)
+                    keep.append(res)
+                    if merge(ctx, op, lp, res[0].data_ptr(), res[1].data_ptr(), B, S, H, D, 1, 0,
+                             None if s_ == last else ex.flag_ptr(s_ + 1), epoch, sh) != 0:
+                        raise RuntimeError("cfx_attn_merge_wait failed: " + (ex._lib.cfx_last_error_string(ctx) or b"").decode())
+                return out.to(q.dtype), lse.squeeze(dim=-1).transpose(1, 2), None
             bo, bl = block_attention(q, k, v, 0.0, softmax_scale, causal=False)     # ... the local block behind it ...
             ex.run_lane(k, v, None)                        # ... and the chain's dozen launches are issued while that block runs
             cm._current_cache_key = self.last_key
@@ -330,7 +376,10 @@ class _LayerExchange:
             # the CU-masked exchange stream when the model runs on the lane's compute stream (disjoint CU sets), else an unmasked one
             if self.lane:
                 # flags order the two streams, so the exchange stream must OWN its hardware queue (lanes.dedicated_stream)
-                xstream = lanes.exchange_stream(dev) if lanes.on_compute_stream(dev) else lanes.dedicated_stream(dev)
+                # (on the lane's compute stream: the CU-masked exchange stream.  Otherwise a high-priority pool stream: non-blocking, and
+                # high-priority streams do not share a hardware queue with normal-priority ones - a CU-masked stream would own its queue too,
+                # but hipExtStreamCreateWithCUMask makes BLOCKING streams, which synchronise implicitly with the null stream most models run on)
+                xstream = lanes.exchange_stream(dev) if lanes.on_compute_stream(dev) else _exchange_stream(self.send.device)
             else:
                 xstream = _exchange_stream(self.send.device)
             xs_handle = xstream.cuda_stream
