@@ -227,7 +227,7 @@ class _SteadyLayer:
                 B, S, H, D = q.shape
                 qt = q.transpose(1, 2)
                 res = sdpa(qt, k.transpose(1, 2), v.transpose(1, 2), 0.0, False, False, scale=softmax_scale)
-                ex.run_lane(k, v, None)                    # ... the chain's dozen launches are issued while the local block runs
+                ex.run_lane_head(k, v)                     # ... the chain up to the first peer's flag is issued while the local block runs
                 cm._current_cache_key = self.last_key
                 out = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
                 lse = torch.empty((B, S, H, 1), dtype=torch.float32, device=q.device)
@@ -238,6 +238,8 @@ class _SteadyLayer:
                 for s_, (kt, vt) in enumerate(self._peer_t, start=1):
                     res = sdpa(qt, kt, vt, 0.0, False, False, scale=softmax_scale)
                     keep.append(res)
+                    if s_ == 1:
+                        ex.run_lane_tail()                 # the rest of the chain, behind the first peer's block on the compute stream
                     if merge(ctx, op, lp, res[0].data_ptr(), res[1].data_ptr(), B, S, H, D, 1, 0,
                              None if s_ == last else ex.flag_ptr(s_ + 1), epoch, sh) != 0:
                         raise RuntimeError("cfx_attn_merge_wait failed: " + (ex._lib.cfx_last_error_string(ctx) or b"").decode())
@@ -443,6 +445,21 @@ class _LayerExchange:
         if rc != 0:
             raise RuntimeError("native exchange lane failed: " + (self._lib.cfx_last_error_string(self._ctx) or b"").decode())
         return self._epoch.value
+
+    def run_lane_head(self, k, v) -> None:
+        """After `lane_begin`: the chain up to the launch that publishes the first peer's flag (wait, compress, all-gather, peers 1 and
+        2) - what the first merge waits for.  `run_lane_tail` issues the rest; splitting the dozen launches lets the caller put the
+        next attention block on the compute stream in between instead of behind 50 us of host time."""
+        self._xs[0], self._xs[1] = k.data_ptr(), v.data_ptr()
+        n = min(5, self._n_ops)
+        rc = self._lib.cfx_plan_run_lane(self.plan, 0, n, self._xs, 2, 0, None, self._epoch)
+        if rc != 0:
+            raise RuntimeError("native exchange lane failed: " + (self._lib.cfx_last_error_string(self._ctx) or b"").decode())
+
+    def run_lane_tail(self) -> None:
+        n = min(5, self._n_ops)
+        if self._n_ops > n and self._lib.cfx_plan_run_lane(self.plan, n, self._n_ops - n, None, 0, 0, None, self._epoch) != 0:
+            raise RuntimeError("native exchange lane failed: " + (self._lib.cfx_last_error_string(self._ctx) or b"").decode())
 
     def run_lane(self, k, v, sh) -> int:
         """The layer's whole chain on the exchange lane, one host call; returns the epoch its flags will carry.  sh = None: the
