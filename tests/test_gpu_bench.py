@@ -1,0 +1,58 @@
+"""bench.py end to end on one GPU (-m gpu): the contract line at N = 1 (the collective in the headline schedule, roofline + cpu_baseline
+objects) and the N > 1 plumbing - plans laid out for several live ranks, both exchange patterns, the uncompressed exchange issued
+natively in both patterns, the xgmi object - over tests/fake_rccl in loop-back mode (`--emulate-live`).  Reduced layer count: the
+judged workload is the default command line, this only checks that every leg runs and the keys are there."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def _fake():
+    sys.path.insert(0, os.path.join(HERE, "fake_rccl"))
+    try:
+        import build as fake_build
+        return fake_build.build()
+    finally:
+        sys.path.pop(0)
+        sys.modules.pop("build", None)
+
+
+def _bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--layers", "6", "--steps", "3", "--warmup", "1", "--long-steps", "3",
+                        "--cpu-seconds", "0.5", "--overlap-steps", "0", *args], capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_default_line_has_the_collective_in_its_schedule():
+    d = _bench()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert "ncclAllGather" in d["schedule"] and d["exchange_issued_by"] == "native" and d["launches_per_layer"] == 2
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["peak"] == 8000.0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and "parity_spot_check" in d["cpu_baseline"]
+    assert d["loopback_one_launch_per_layer"]["ms_per_step"] > 0 and d["pure_exchange_upper_bound"]["ms_per_step"] > 0
+
+
+@pytest.mark.parametrize("live,pattern", [(2, "allgather"), (3, "relay"), (8, "allgather")])
+def test_bench_n_gt_1_plumbing_over_the_loopback_library(live, pattern):
+    d = _bench("--emulate-live", str(live), "--rccl-lib", _fake(), "--exchange-pattern", pattern, "--no-cpu-baseline")
+    assert d["n_gpus"] == 1 and d["exchange_pattern"] == pattern and d["exchange_issued_by"] == "native"
+    x = d["xgmi"]
+    assert x["pattern"] == pattern and x["links"] == (1 if pattern == "relay" else min(live - 1, 7))
+    assert set(x["compressed"]) == {"allgather", "relay"} and set(x["raw"]) == {"allgather", "relay"}
+    for leg in list(x["compressed"].values()) + list(x["raw"].values()):
+        assert leg["ms_per_step"] > 0 and leg["frac"] > 0 and leg["unit"] == "GB/s"
+    assert x["wire_bytes_per_gpu_per_step"] == (live - 1) * 2 * 6 * d["config"]["packet_bytes"]
+    assert x["raw_bytes_per_gpu_per_step"] == (live - 1) * 2 * 6 * d["config"]["raw_bytes"]
+    assert "no Python-issued collective" in x["issued_by"]
+    assert d["raw_exchange_ms_per_step"].keys() == {"allgather", "relay"} and d["speedup_vs_raw_allgather"] > 0
