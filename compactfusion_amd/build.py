@@ -39,10 +39,12 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
+def build_lib(force: bool = False, verbose: bool = False, dev_probes: bool = False) -> str:
+    """dev_probes: compile the experiment early exits of the compress kernel in (CFX_FUSED_DBG=1..4, tools/fused_probe.py); the
+    product build has none of them."""
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc_path()] + HIPCC_FLAGS + [f"-I{INC}", f"-I{os.path.join(PKG_DIR, 'csrc')}"] + SRC + ["-o", LIB + ".tmp"]
+    cmd = [hipcc_path()] + HIPCC_FLAGS + (["-DCFX_DEV_PROBES"] if dev_probes else []) + [f"-I{INC}", f"-I{os.path.join(PKG_DIR, 'csrc')}"] + SRC + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -53,4 +55,4 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_lib(force="--force" in sys.argv or "--dev-probes" in sys.argv, verbose=True, dev_probes="--dev-probes" in sys.argv))

@@ -942,6 +942,7 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
     // developer hook (cfx_debug_stamps): per-workgroup phase times, 100 MHz wall clock
 #define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
     STAMP(0);
+#ifdef CFX_DEV_PROBES                          // experiment early exits: only in a developer build (python -m compactfusion_amd.build --dev-probes)
     if (dbg == 3) return;                      // experiments: launch cost of the empty grid
     if (dbg == 4) {                            // experiments: the loads alone (no arithmetic, no partial sums)
         const TileCoord t = tile_coord_at(bx, by, N, C, R);
@@ -960,6 +961,7 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
         if (acc[0] == (h16)12345.0f) ((h16*)it.packet)[threadIdx.x] = acc[1];
         return;
     }
+#endif
     h16x8 xk[KEEP ? US : 1], bk[KEEP ? US : 1];
     absmean_stats_body<EMIT_BITS, US, true, FUSED_NW, GATED, KEEP>(it, N, C, R, CB, bx, by, rowpart, sm, stamps, xk, bk);
     STAMP(1);
@@ -967,7 +969,9 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     STAMP(2);
+#ifdef CFX_DEV_PROBES
     if (dbg == 1) return;
+#endif
     // Who does what: the column ticket (a returned atomic) elects the workgroup that reduces column block bx (V).  The tensor-wide
     // job (U):
     //  * gated launches: a second returned ticket elects the last tile of all, as before;
@@ -988,6 +992,7 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
     const bool u_wg = UPOLL ? (bx == 0 && by == 0) : (flag[1] == (unsigned)(CB * P - 1));
     STAMP(3);
     if (stamps && threadIdx.x == 0) stamps[7] = (last_col ? 1 : 0) | (u_wg ? 2 : 0);
+#ifdef CFX_DEV_PROBES
     if (dbg == 2) {
         if (last_col && threadIdx.x == 0) st_wt(tick + 1 + bx, 0u);
         if (u_wg && threadIdx.x == 0) {
@@ -996,6 +1001,7 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
         }
         return;
     }
+#endif
     if (UPOLL) {
         if (last_col)                          // uniform per workgroup
             absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, true, false, stamps, gate, gate_expect);
@@ -1023,7 +1029,7 @@ struct FusedArgs {
     int n_st;                // workgroups of the statistics group (CB * P * batch); the rest reconstruct `ride`
     int dq_R, dq_rb;         // ride items: tile height, row blocks per tensor
     int per_byte, eps_mode;
-    int dbg;                 // experiments: 1 = stop after publishing, 2 = stop after the tickets (no finalize work)
+    int dbg;                 // developer builds only (CFX_DEV_PROBES): 1 = stop after publishing, 2 = after the tickets, 3 = empty grid, 4 = loads only
     u64* ws;
     size_t ws_stride;
     unsigned* tick;
