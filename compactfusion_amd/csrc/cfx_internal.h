@@ -15,13 +15,14 @@ enum {
     KID_LR_PREP = 17, KID_LR_AQ = 18, KID_LR_ATY = 19, KID_LR_CHOL = 20, KID_LR_APPLY = 21, KID_LR_DECODE = 22,
     KID_BINARY_PIPE = 23, KID_BINARY_PIPE_EDGE = 24, KID_RES2_DELTA = 25, KID_RES2_UPDATE = 26,
     KID_ABSMEAN_COMPRESS_BITS = 27, KID_ABSMEAN_COMPRESS = 28, KID_MINMAX_COMPRESS = 29, KID_ATTN_MERGE = 30,
-    KID_ABSMEAN_COMPRESS_GATED = 31, KID_MAX = 32
+    KID_ABSMEAN_COMPRESS_GATED = 31, KID_MAX = 32,
+    KID_LR_CHAIN = KID_LR_PREP      // the single-launch chain has no separate prep launch: it takes that id (the kernel mask is 32 bits)
 };
 static const char* const kid_names[KID_MAX] = {
     "", "k_absmean_stats<bits>", "k_absmean_stats", "k_absmean_finalize", "k_binary_dequant", "k_int2_quant", "k_int2_dequant",
     "k_minmax_stats", "k_minmax_finalize", "k_int8_quant", "k_int8_dequant", "k_int4_quant", "k_int4_dequant",
     "k_topk_compress", "k_topk_decompress", "k_copy_probe", "k_binary_dequant(ef)",
-    "k_lr_prep", "k_lr_aq", "k_lr_aty", "k_lr_chol", "k_lr_apply", "k_lr_decode",
+    "k_lr_prep | k_lrp (single-launch chain)", "k_lr_aq", "k_lr_aty", "k_lr_chol", "k_lr_apply", "k_lr_decode",
     "k_binary_pipe", "k_binary_pipe(prologue/epilogue)", "k_residual2_delta", "k_residual2_update",
     "k_absmean_compress<bits>", "k_absmean_compress", "k_minmax_compress", "k_attn_merge",
     "gated layer launch (k_absmean_compress<bits,gated> / k_int2_compress_gated)"};
@@ -189,6 +190,8 @@ CFX_HIDDEN bool cfx_i_shape_ok(int codec, int N, int C, int param);
 CFX_HIDDEN size_t cfx_i_ws_words(int codec, int N, int C);
 // a zeroed block of CFX_MAX_BATCH * 64 u32 ticket words for ONE launch on `stream`; whoever draws a word's final value resets it to 0
 CFX_HIDDEN unsigned* cfx_i_ticket_block(cfx_ctx* ctx, void* stream);
+// CUs the queue of `stream` may use (a CU-masked stream: fewer than the device has)
+CFX_HIDDEN int cfx_i_stream_cus(cfx_ctx* ctx, void* stream);
 CFX_HIDDEN int cfx_i_decompress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items, void* stream,
                                      unsigned* pre, unsigned pre_val);
 CFX_HIDDEN int cfx_i_compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,

@@ -2461,6 +2461,7 @@ int cfx_i_decompress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int 
     return decompress_impl(ctx, codec, N, C, param, batch, items, stream, pre, pre_val);
 }
 size_t cfx_i_ws_words(int codec, int N, int C) { return ws_words(codec, N, C); }
+int cfx_i_stream_cus(cfx_ctx* ctx, void* stream) { return stream_cu_count(ctx, stream); }
 int cfx_i_compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                         int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
                         void* workspace, size_t workspace_bytes, void* stream) {

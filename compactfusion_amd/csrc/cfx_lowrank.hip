@@ -32,7 +32,7 @@ struct LrWs {
 static LrWs lr_layout(int N, int C, int RP) {
     LrWs w;
     size_t o = 0;
-    w.D = o;   o += al256((size_t)N * C * 2);
+    w.D = o;   o += al256((size_t)((N + 63) / 64 * 64) * C * 2);     // 64-row padded (the N-space chain reads whole tiles)
     w.Qa = o;  o += al256((size_t)C * RP * 4);
     w.Zb = o;  o += al256((size_t)C * RP * 4);
     w.Y = o;   o += al256((size_t)4 * N * RP * 4);        // 4 column-group partials of Y
@@ -635,8 +635,10 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
     // (rank > 16: the two factorisations the chain's last launch runs back to back in one wave spill at RP = 32 - measured slower than the
     // C-space chain's separate launches)
     const bool gram = cfx_i_lrg_ok(N, C) && RPv <= 16 && !(chain_env && !strcmp(chain_env, "cspace"));
+    int decoded = 0;                     // the single-launch chain also does the error-feedback update of LOW_RANK
     if (gram) {
-        const int rg = cfx_i_lrg_factors(ctx, quantized, N, C, rank, batch, b, w.D, w.U16, w.V16, w.gram, absd, s);
+        const int rg = cfx_i_lrg_factors(ctx, quantized, N, C, rank, batch, b, w.D, w.U16, w.V16, w.gram, absd,
+                                         (upd && !(flags & CFX_FLAG_NO_EF) && !factors_only) ? 1 : 0, &decoded, s);
         if (rg != CFX_OK) return rg;
     } else {
         // D = x - base is formed (and stored) by the first product.  (Forming Q = orth(Z) = Z T inside the next product instead of by a
@@ -717,7 +719,7 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
         if (flags & CFX_FLAG_NO_EF) {
             for (int i = 0; i < batch; ++i)
                 if (items[i].new_base != items[i].x) (void)hipMemcpyAsync(items[i].new_base, items[i].x, E * 2, hipMemcpyDeviceToDevice, s);
-        } else {
+        } else if (!decoded) {
             rc = cfx_i_lr_decode_launch(ctx, N, C, rank, batch, dec, quantized != 0, s);
             if (rc != CFX_OK) return rc;
         }
