@@ -12,7 +12,7 @@ import sys
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG_DIR)
-SRC = [os.path.join(PKG_DIR, "csrc", f) for f in ("cfx_kernels.hip", "cfx_plan.hip", "cfx_lowrank.hip", "cfx_lrgram.hip")]
+SRC = [os.path.join(PKG_DIR, "csrc", f) for f in ("cfx_kernels.hip", "cfx_plan.hip", "cfx_lowrank.hip", "cfx_lrgram.hip", "cfx_lrslab.hip")]
 INC = os.path.join(REPO, "include")
 LIB = os.path.join(PKG_DIR, "libcfx.so")
 ARCH = "gfx950"

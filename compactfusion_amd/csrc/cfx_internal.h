@@ -57,6 +57,14 @@ struct cfx_ctx {
     int fused;                      // 1 (default): compress = statistics + in-launch finalize; 0: separate finalize kernel
     void* dbg_stamps;               // developer hook (cfx_debug_stamps)
     int stats_rows;                 // CFX_STATS_ROWS override of the statistics tile height (experiments), 0 = automatic
+    // hand-over arenas of the slab-resident low-rank chain: one per stream that launches it (zeroed when allocated and whenever the
+    // shape it is laid out for changes: its words carry sequence tags that only make sense against what the chain itself wrote)
+    void* lrs_stream[8];
+    char* lrs_arena[8];
+    size_t lrs_bytes[8];
+    unsigned long long lrs_key[8];
+    int lrs_n;
+    unsigned lrs_next;
     char err[256];
 };
 

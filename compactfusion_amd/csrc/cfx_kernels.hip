@@ -2012,6 +2012,8 @@ void cfx_destroy(cfx_ctx* ctx) {
     if (!ctx) return;
     prof_free(ctx);
     if (ctx->tick) (void)hipFree(ctx->tick);
+    for (int i = 0; i < ctx->lrs_n; ++i)
+        if (ctx->lrs_arena[i]) (void)hipFree(ctx->lrs_arena[i]);
     if (ctx->gate_err) (void)hipHostFree(ctx->gate_err);
     delete ctx;
 }

@@ -38,6 +38,13 @@ CFX_HIDDEN size_t cfx_i_lrg_extra_bytes(int N, int C, int RP);
 CFX_HIDDEN int cfx_i_lrg_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int batch, const LrBatch& b, size_t offD, size_t offU16,
                                  size_t offV16, size_t extra, int absd, int want_decode, int* decoded, hipStream_t s);
 
+// cfx_lrslab.hip: the slab-resident chain (one persistent launch)
+CFX_HIDDEN bool cfx_i_lrs_ok(int N, int C, int RP);
+CFX_HIDDEN size_t cfx_i_lrs_extra_bytes(int N, int C, int RP);
+CFX_HIDDEN int cfx_i_lrs_fit(cfx_ctx* ctx, int N, int C, int RP, void* stream);
+CFX_HIDDEN int cfx_i_lrs_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int batch, const LrBatch& b, size_t offU16, size_t offV16,
+                                 size_t extra, int absd, int want_decode, int* decoded, hipStream_t s);
+
 // T (RP x RP fp32, upper triangular, row-major at T[i * RP + m]) = chol(G)^-T for the symmetrised G (RP x RP fp64 in LDS); rank = r <= RP.
 // A non-positive pivot (rank-deficient residual, e.g. x == base) zeroes that direction instead of producing NaNs.  Called by EVERY
 // thread of a workgroup of NT threads (NT >= 64, multiple of 64); the factorisation itself runs in the registers of wave 0.  G and L

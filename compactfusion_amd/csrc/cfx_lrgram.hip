@@ -1244,8 +1244,8 @@ static size_t lrp_extra_bytes(int N, int C, int RP) {       // the single-launch
 }
 size_t cfx_i_lrg_extra_bytes(int N, int C, int RP) {
     if (!cfx_i_lrg_ok(N, C)) return 0;
-    const size_t a = lrg5_extra_bytes(N, C, RP), b = lrp_extra_bytes(N, C, RP);
-    return a > b ? a : b;
+    const size_t a = lrg5_extra_bytes(N, C, RP), b = lrp_extra_bytes(N, C, RP), c = cfx_i_lrs_extra_bytes(N, C, RP);
+    return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 template <int RP>
@@ -1336,6 +1336,9 @@ int cfx_i_lrg_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int b
     const int RPv = lr_rp(rank);
     if (decoded) *decoded = 0;
     static const char* chain_env = getenv("CFX_LR_CHAIN");
+    // the slab-resident chain when its workgroups are co-resident on this stream's CUs (not on a CU-masked lane)
+    if (!(chain_env && (!strcmp(chain_env, "gram5") || !strcmp(chain_env, "gram1"))) && cfx_i_lrs_fit(ctx, N, C, RPv, (void*)s) >= 1)
+        return cfx_i_lrs_factors(ctx, quantized, N, C, rank, batch, b, offU16, offV16, extra, absd, want_decode, decoded, s);
     if (!(chain_env && !strcmp(chain_env, "gram5"))) {
         const size_t NP = lrg_np(N), nt = (N + 31) / 32;
         for (int first = 0; first < batch; first += 4) {               // LRP_TW words of the launch's ticket block per tensor

@@ -1,0 +1,645 @@
+// Low-rank residual codecs, slab-resident form of the factorisation chain - part of libcfx.so.
+//
+// The reference's subspace_iter (xfuser/compact/compress_lowrank.py:14-61) for A = x - base (N x C, N << C), written as in
+// cfx_lrgram.hip (orthonormalisation after every multiplication, the r x r factors by Cholesky of the Gram matrices):
+//     Y0 = A Q0
+//     W1 = A (A^T Y0)      M1 = Y0^T W1      T1 = chol(M1)^-T      Y1 = W1 T1
+//     W2 = A (A^T Y1)      M2 = Y1^T W2      T2 = chol(M2)^-T      M3 = T2^T (W2^T W2) T2      T3 = chol(M3)^-T      U = W2 T2 T3
+//     V  = U^T A           new_base = base + fp16(U V)
+// Here A is never written anywhere and A A^T is never formed.  ONE persistent launch; workgroup j of a tensor owns the 32-column
+// slab j of A for the whole chain: the slab is read from x and base exactly once (HBM: x + base in, new_base out - 6 bytes an
+// element, what the 1-bit codec moves), kept in REGISTERS in the B-operand layout of v_mfma_f32_16x16x32_f16 (a lane: 8 consecutive
+// columns of one row) and, transposed, in LDS (35 KB).  Against the slab both halves of a product are local:
+//     Z  = slab^T Y   (32 x r,  K = N)     A operand = transposed slab, B operand = Y^T as fp16 hi + lo (LDS)
+//     Wp = slab Z     (N x r,   K = 32)    A operand = Z^T as fp16 hi + lo, B operand = the slab registers
+// and what remains between two products is the sum of the N x r partials over the slabs - three such sums in the chain (Y0, W1,
+// W2).  No barrier anywhere: every fp32 word that changes hands carries a 2-bit SEQUENCE TAG in its two lowest mantissa bits (the
+// value is rounded to 22 bits of mantissa - what the fp16 hi + lo operands of the products keep anyway), the n-th sum since the
+// hand-over arena was zeroed writes tag (n + 1) mod 4, and a reader polls the words it needs (16-byte L2-bypassing loads) until all
+// carry this sum's tag: a word holds either what the previous sum left there or the new value, never anything else, because the
+// arena belongs to the context and nothing but this kernel writes to it.  A workgroup sums its 1 / nwg share of the cells over all
+// partials in fixed order (reproducible run to run), publishes the share the same way, and every workgroup polls the N x r result:
+// two memory hops per sum (~1.7 us each) instead of two grid barriers and two hops.  The count of sums lives in the arena (the last
+// workgroup of a launch moves it on): nothing depends on a host-side counter, the launch can be captured in a hipGraph.
+// Everything r x r sized - the fp64 Gram
+// matrices (v_mfma_f64_16x16x4_f64 over the fp32 values: exact products), the factorisations, Y = W T (v_mfma_f32_16x16x4_f32) - is
+// done by every workgroup redundantly: nobody waits for a broadcast.  V = U^T slab and the state update of the slab's columns come
+// from the registers the slab and base were loaded into at the start, with the arithmetic of k_lr_decode (the receiver's kernel).
+//
+// The workgroups of a launch wait for each other: the host only takes this form when C / 32 workgroups per tensor are co-resident
+// on the CUs the stream may use (one workgroup per CU: ~150 KB of LDS); otherwise the multi-launch chains run.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "cfx_lr.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef unsigned lrs_u4 __attribute__((ext_vector_type(4)));
+
+#define LRS_PIVOT_TOL 1e-10   // as the N-space chain (cfx_lrgram.hip): pivots below this fraction of the largest are dropped
+#define LRS_SW 32             // columns of a slab
+#define LRS_TQ 9              // 16-row tiles per wave: 4 waves x 9 x 16 = 576 rows at most
+#define LRS_ZH 40             // halves per LDS row of Z^T (32 + 8: 16-byte aligned rows spread over the banks)
+#define LRS_J 10              // partials / cells a thread polls at once (4 units each)
+
+struct LrsArgs {
+    int N, C, NPK, r, batch, nwg_t, zmod;
+    int absd, u_in_packet, fuse_decode;
+    size_t offU16, offV16;
+    char* arena;                     // [256 B: word 0 = launches since the arena was zeroed] then per tensor [partials of every slab | the sum]
+    size_t arena_stride, offFull;    // bytes per tensor; offset of the sum inside a tensor's part
+    unsigned* tick;                  // a zeroed ticket word: workgroups that have left
+    unsigned* err;
+    long long timeout;
+    unsigned long long* stamps;      // developer hook (cfx_debug_stamps): 16 words per workgroup, 100 MHz wall clock
+};
+
+// A word that changes hands: the fp32 value rounded to 22 bits of mantissa, its two lowest bits the sequence tag of the sum it belongs to.
+__device__ __forceinline__ unsigned lrs_pack(float v, unsigned seq) { return ((__builtin_bit_cast(unsigned, v) + 2u) & ~3u) | seq; }
+__device__ __forceinline__ float lrs_val(unsigned q) { return __builtin_bit_cast(float, q & ~3u); }
+// 16-byte write-through store / L2-bypassing load (sc1).  hipcc does not count asm memory operations: nothing ever waits for the
+// stores (the s_nop keeps the data registers alive until the store has read them), and a batch of loads is followed by lrs_wait
+__device__ __forceinline__ void lrs_st16(void* p, lrs_u4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+#define LRS_LD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
+template <int J> __device__ __forceinline__ void lrs_wait(lrs_u4 (&q)[J]) {
+    static_assert(J == 10, "operand list below");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]), "+v"(q[9])::"memory");
+}
+__device__ __forceinline__ bool lrs_tagged(lrs_u4 q, unsigned seq) { return ((q[0] & q[1] & q[2] & q[3] & 3u) == seq) && (((q[0] | q[1] | q[2] | q[3]) & 3u) == seq); }
+
+// LDS carve-up (bytes).  NPK = N rounded up to 32 (the K step of the fp16 MFMA), NPH = NPK + 8 halves per transposed row.
+template <int RP> struct LrsLds {
+    __host__ __device__ static int dt(int) { return 0; }                                        // slab^T  [32][NPH] fp16
+    __host__ __device__ static int yt(int NPK) { return 32 * (NPK + 8) * 2; }                   // Y^T hi | lo, [16][NPH] fp16 each
+    __host__ __device__ static int yt_bytes(int NPK) { const int a = 2 * 16 * (NPK + 8) * 2; return a > 16384 ? a : 16384; }     // dead: fp64 Gram partials
+    __host__ __device__ static int yf(int NPK) { return yt(NPK) + yt_bytes(NPK); }              // Y   [NPK][RP] fp32; at the end: U [NPK][RP] fp16
+    __host__ __device__ static int wf(int NPK) { return yf(NPK) + NPK * RP * 4; }               // W   [NPK][RP] fp32; dead: 8 KB of reduction scratch
+    __host__ __device__ static int wf_bytes(int NPK) { const int a = NPK * RP * 4; return a > 8192 ? a : 8192; }
+    __host__ __device__ static int zt(int NPK) { return wf(NPK) + wf_bytes(NPK); }              // Z^T hi | lo, [16][LRS_ZH] fp16 each
+    __host__ __device__ static int ch(int NPK) { return zt(NPK) + 2 * 16 * LRS_ZH * 2; }        // factorisation scratch
+    static constexpr int ch_bytes = ((3 * RP * (RP + 1) + RP + 2) * 8 + 3 * RP * RP * 4 + 15) / 16 * 16;
+    __host__ __device__ static int total(int NPK) { return ch(NPK) + ch_bytes; }
+};
+
+template <int RP>
+__global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
+    typedef LrsLds<RP> L;
+    const int bid = blockIdx.x;
+    int z, idx;
+    if (a.zmod) { z = bid % a.batch; idx = bid / a.batch; } else { z = bid / a.nwg_t; idx = bid - z * a.nwg_t; }
+    const LrItem it = b.it[z];
+    const int N = a.N, C = a.C, NPK = a.NPK, r = a.r, nwg = a.nwg_t;
+    const int NPH = NPK + 8, nmt = NPK / 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, lq = lane >> 4;
+    extern __shared__ double lrs_smem[];
+    char* sm = reinterpret_cast<char*>(lrs_smem);
+    h16* Dt = reinterpret_cast<h16*>(sm + L::dt(NPK));
+    h16* Yth = reinterpret_cast<h16*>(sm + L::yt(NPK));
+    h16* Ytl = Yth + 16 * NPH;
+    float* Yf = reinterpret_cast<float*>(sm + L::yf(NPK));
+    float* Wf = reinterpret_cast<float*>(sm + L::wf(NPK));
+    f32x4* red4 = reinterpret_cast<f32x4*>(Wf);                        // 8 KB of scratch while W is dead
+    h16* U16s = reinterpret_cast<h16*>(Yf);                            // [NPK][RP] fp16 U (the fp32 U itself is not needed)
+    h16* Zth = reinterpret_cast<h16*>(sm + L::zt(NPK));
+    h16* Ztl = Zth + 16 * LRS_ZH;
+    double (*Gd)[RP + 1] = reinterpret_cast<double (*)[RP + 1]>(sm + L::ch(NPK));
+    double (*Ld)[RP + 1] = Gd + RP;
+    double (*Sd)[RP + 1] = Ld + RP;
+    double* misc = reinterpret_cast<double*>(Sd + RP);                // [0] gmax, [1 .. RP] dinv
+    float* Ts = reinterpret_cast<float*>(misc + RP + 2);
+    float* T2s = Ts + RP * RP;
+    float* T23 = T2s + RP * RP;
+    double* scr64 = reinterpret_cast<double*>(Yth);                    // fp64 Gram partials of the waves while Y^T is dead (<= 16 KB)
+    lrs_u4* part = reinterpret_cast<lrs_u4*>(a.arena + 256 + (size_t)z * a.arena_stride);     // [nwg][NPK][RP / 4] cells of 4 tagged words
+    lrs_u4* full = reinterpret_cast<lrs_u4*>(a.arena + 256 + (size_t)z * a.arena_stride + a.offFull);      // [NPK][RP / 4]
+    const unsigned launches = __hip_atomic_load(reinterpret_cast<const unsigned*>(a.arena), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned tag0 = launches * 3u + 1u;                         // sum n since the arena was zeroed carries tag (n + 1) mod 4
+    const int c0 = idx * LRS_SW;
+#define LSTAMP(k) do { if (a.stamps && tid == 0) a.stamps[(size_t)bid * 16 + (k)] = wall_clock64(); } while (0)
+    LSTAMP(0);
+
+    // ---------------- the slab: registers (rows t * 16 + l16 of tile t = w + 4 q, columns c0 + 8 lq .. + 7) and LDS (transposed) ----------------
+    h16x8 ds[LRS_TQ], bs[LRS_TQ];
+    {
+        h16x8 xv[LRS_TQ];
+#pragma unroll
+        for (int q = 0; q < LRS_TQ; ++q) {                              // every load unconditional (clamped row): all in flight at once
+            const int row = min((w + 4 * q) * 16 + l16, N - 1);
+            const size_t o = (size_t)row * C + c0 + 8 * lq;
+            xv[q] = __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(it.x + o));
+            bs[q] = (h16x8)(h16)0;
+            if (it.base) bs[q] = __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(it.base + o));
+        }
+        // meanwhile: zero what must read as zero (rows >= RP of Y^T and Z^T, columns >= N of the transposed arrays)
+        for (int i = tid; i < (L::yf(NPK) - L::dt(NPK)) / 16; i += 256) reinterpret_cast<lrs_u4*>(sm)[i] = (lrs_u4)0u;
+        for (int i = tid; i < 2 * 16 * LRS_ZH * 2 / 16; i += 256) reinterpret_cast<lrs_u4*>(Zth)[i] = (lrs_u4)0u;
+        __syncthreads();
+        for (int e = tid; e < LRS_SW * RP; e += 256) {                  // Q0 rows of the slab -> Z^T as hi + lo
+            const int wc = e / RP, k = e - wc * RP;
+            const float v = it.q0[(size_t)(c0 + wc) * RP + k];
+            const h16 hi = (h16)v;
+            Zth[k * LRS_ZH + wc] = hi;
+            Ztl[k * LRS_ZH + wc] = (h16)(v - (float)hi);
+        }
+#pragma unroll
+        for (int q = 0; q < LRS_TQ; ++q) {
+            const int t = w + 4 * q, row = t * 16 + l16;
+            h16x8 d = xv[q] - bs[q];                                  // fp16, one rounding (torch eager: x - base); base absent: x - 0 = x
+            if (a.absd) {
+                typedef unsigned short u16x8_ __attribute__((ext_vector_type(8)));
+                u16x8_ bb = __builtin_bit_cast(u16x8_, d);
+                bb &= (unsigned short)0x7fff;
+                d = __builtin_bit_cast(h16x8, bb);
+            }
+            if (row >= N) d = (h16x8)(h16)0;
+            ds[q] = d;
+            if (t < nmt) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Dt[(8 * lq + e) * NPH + row] = d[e];
+            }
+        }
+    }
+    __syncthreads();
+    LSTAMP(1);
+
+    // Wp = slab Z as [n][RP] fp32 partial of this workgroup (write-through): D[i = rank][j = row], a lane holds 4 consecutive ranks
+    auto product_b = [&](unsigned tag) {
+        const h16x8 zh = *reinterpret_cast<const h16x8*>(&Zth[l16 * LRS_ZH + 8 * lq]);
+        const h16x8 zl = *reinterpret_cast<const h16x8*>(&Ztl[l16 * LRS_ZH + 8 * lq]);
+        lrs_u4* P = part + (size_t)idx * NPK * (RP / 4);
+        const unsigned seq = tag & 3u;
+#pragma unroll
+        for (int q = 0; q < LRS_TQ; ++q) {
+            const int t = w + 4 * q;
+            if (t < nmt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, ds[q], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl, ds[q], acc, 0, 0, 0);
+                if (4 * lq < RP) {
+                    lrs_u4 o;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) o[v] = lrs_pack(acc[v], seq);
+                    lrs_st16(&P[(size_t)(t * 16 + l16) * (RP / 4) + lq], o);
+                }
+            }
+        }
+    };
+
+    // Z = slab^T Y (32 x RP): the waves split K = N, partial tiles summed through LDS in wave order.  final_v: the result is V
+    // (fp16, into LDS [rank][column] and into the packet / the workspace); otherwise Z^T as hi + lo for product_b
+    auto product_a = [&](bool final_v) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const int nk32 = NPK / 32;
+#pragma unroll
+        for (int i = 0; i < (LRS_TQ * 2 + 3) / 4; ++i) {               // K steps of this wave, operands loaded unconditionally
+            const int ks = w + 4 * i;
+            const int n0 = min(ks, nk32 - 1) * 32 + 8 * lq;
+            const h16x8 a0 = *reinterpret_cast<const h16x8*>(&Dt[l16 * NPH + n0]);
+            const h16x8 a1 = *reinterpret_cast<const h16x8*>(&Dt[(16 + l16) * NPH + n0]);
+            h16x8 bh = *reinterpret_cast<const h16x8*>(&Yth[l16 * NPH + n0]);
+            h16x8 bl = *reinterpret_cast<const h16x8*>(&Ytl[l16 * NPH + n0]);
+            if (ks >= nk32) { bh = (h16x8)(h16)0; bl = (h16x8)(h16)0; }
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl, acc1, 0, 0, 0);
+        }
+        red4[(w * 2 + 0) * 64 + lane] = acc0;
+        red4[(w * 2 + 1) * 64 + lane] = acc1;
+        __syncthreads();
+        if (tid < 128) {
+            const int mt = tid >> 6, ln = tid & 63;
+            f32x4 s = red4[mt * 64 + ln];
+#pragma unroll
+            for (int wv = 1; wv < 4; ++wv) s += red4[(wv * 2 + mt) * 64 + ln];
+            const int rr = ln & 15, w0 = 16 * mt + 4 * (ln >> 4);      // D[i = column of the slab][j = rank]
+            if (!final_v) {
+                h16x4 hi, lo;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { hi[v] = (h16)s[v]; lo[v] = (h16)(s[v] - (float)hi[v]); }
+                *reinterpret_cast<h16x4*>(&Zth[rr * LRS_ZH + w0]) = hi;
+                *reinterpret_cast<h16x4*>(&Ztl[rr * LRS_ZH + w0]) = lo;
+            } else {
+                h16x4 v16;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) v16[v] = (rr < r) ? (h16)s[v] : (h16)0;
+                *reinterpret_cast<h16x4*>(&Zth[rr * LRS_ZH + w0]) = v16;
+                if (rr < r) {
+                    if (a.u_in_packet && ((N * r) & 3) == 0) *reinterpret_cast<h16x4*>(&((h16*)it.packet)[(size_t)N * r + (size_t)rr * C + c0 + w0]) = v16;
+                    else if (a.u_in_packet) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) ((h16*)it.packet)[(size_t)N * r + (size_t)rr * C + c0 + w0 + v] = v16[v];
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) ((h16*)(it.ws + a.offV16))[(size_t)(c0 + w0 + v) * r + rr] = v16[v];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    };
+
+    // Sum of the partials over the slabs into dst (LDS, [NPK][RP] fp32): this workgroup's share of the cells over all partials
+    // (fixed order), published; then everybody polls the whole result
+    auto allreduce = [&](unsigned tag, float* dst, bool stamp) {
+        const unsigned seq = tag & 3u;
+        const int cells = NPK * RP / 4;
+        const int cpw = (cells + nwg - 1) / nwg;
+        const int cw = cpw < 256 ? cpw : 256, subs = 256 / cw;
+        const int ci = tid % cw, sub = tid / cw;
+        for (int cb = 0; cb < cpw; cb += cw) {
+            const int cl = cb + ci, cell = idx * cpw + cl;
+            const bool act = sub < subs && cl < cpw && cell < cells;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if (act) {
+                const lrs_u4* src = part + cell;
+                for (int p0 = sub; p0 < nwg; p0 += subs * LRS_J) {
+                    lrs_u4 q[LRS_J];
+                    long long t0 = 0;
+                    for (;;) {
+#pragma unroll
+                        for (int j = 0; j < LRS_J; ++j) LRS_LD16(q[j], src + (size_t)min(p0 + subs * j, nwg - 1) * cells);     // unconditional: one round trip
+                        lrs_wait(q);
+                        bool ok = true;
+#pragma unroll
+                        for (int j = 0; j < LRS_J; ++j) ok = ok && lrs_tagged(q[j], seq);
+                        if (ok) break;
+                        const long long now = wall_clock64();
+                        if (!t0) t0 = now;
+                        else if (now - t0 > a.timeout) {
+                            if (a.err) (void)__hip_atomic_fetch_add(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            break;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < LRS_J; ++j)
+                        if (p0 + subs * j < nwg) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) s[k] += lrs_val(q[j][k]);
+                        }
+                }
+            }
+            if (sub < subs) red4[sub * cw + ci] = s;
+            __syncthreads();
+            if (sub == 0 && act) {
+                f32x4 t = red4[ci];
+                for (int s2 = 1; s2 < subs; ++s2) t += red4[s2 * cw + ci];
+                lrs_u4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = lrs_pack(t[k], seq);
+                lrs_st16(&full[cell], o);
+            }
+            __syncthreads();
+        }
+        if (stamp) LSTAMP(12);
+        f32x4* dst4 = reinterpret_cast<f32x4*>(dst);
+        for (int i0 = tid; i0 < cells; i0 += 256 * LRS_J) {
+            lrs_u4 q[LRS_J];
+            long long t0 = 0;
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < LRS_J; ++j) LRS_LD16(q[j], full + min(i0 + 256 * j, cells - 1));
+                lrs_wait(q);
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < LRS_J; ++j) ok = ok && lrs_tagged(q[j], seq);
+                if (ok) break;
+                const long long now = wall_clock64();
+                if (!t0) t0 = now;
+                else if (now - t0 > a.timeout) {
+                    if (a.err) (void)__hip_atomic_fetch_add(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < LRS_J; ++j)
+                if (i0 + 256 * j < cells) {
+                    f32x4 v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = lrs_val(q[j][k]);
+                    dst4[i0 + 256 * j] = v;
+                }
+        }
+        __syncthreads();
+    };
+
+    // Y^T as fp16 hi + lo from Y (LDS fp32 [NPK][RP])
+    auto split_y = [&]() {
+        for (int i = tid; i < NPK * RP; i += 256) {
+            const int n = i / RP, k = i - n * RP;
+            const float v = Yf[i];
+            const h16 hi = (h16)v;
+            Yth[k * NPH + n] = hi;
+            Ytl[k * NPH + n] = (h16)(v - (float)hi);
+        }
+        __syncthreads();
+    };
+
+    // fp64 Gram matrices of fp32 operands (exact products, fp64 sums): M = Y^T W into Gd, and (want_p) P = W^T W into Sd
+    auto gram64 = [&](bool want_p) {
+        f64x4 am[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, ap[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        const int nks = NPK / 4;
+        constexpr int UN = 6;                                         // K steps whose operands are in flight at once
+        for (int i0 = 0; w + 4 * i0 < nks; i0 += UN) {
+            float av[UN], bv[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int ks = w + 4 * (i0 + u);
+                const int n = min(ks, nks - 1) * 4 + lq;
+                if (RP == 8) {
+                    // one product: rows 0 .. 7 of the A operand are Y's columns, rows 8 .. 15 W's (W lies behind Y in LDS) -> M on top of P
+                    av[u] = Yf[(l16 < 8 ? 0 : NPK * RP) + n * RP + (l16 & 7)];
+                    bv[u] = Wf[n * RP + (l16 & 7)];
+                    if (l16 >= 8) bv[u] = 0.f;
+                } else {
+                    av[u] = Yf[n * RP + (l16 & (RP - 1))];
+                    bv[u] = Wf[n * RP + (l16 & (RP - 1))];
+                }
+                if (ks >= nks) { av[u] = 0.f; bv[u] = 0.f; }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                am[u & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[u], (double)bv[u], am[u & 1], 0, 0, 0);
+                if (RP == 16 && want_p) ap[u & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)bv[u], (double)bv[u], ap[u & 1], 0, 0, 0);
+            }
+        }
+        am[0] += am[1];
+        ap[0] += ap[1];
+        // D[i][j]: j = lane & 15, i = (lane >> 4) + 4 v  (the fp64 form's own map)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            scr64[(w * 64 + lane) * 4 + v] = am[0][v];
+            if (RP == 16) scr64[1024 + (w * 64 + lane) * 4 + v] = ap[0][v];
+        }
+        __syncthreads();
+        {
+            const int ln = tid & 63, v = tid >> 6;
+            const int i = (ln >> 4) + 4 * v, j = ln & 15;
+            double m = 0.0, p = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) {
+                m += scr64[(wv * 64 + ln) * 4 + v];
+                if (RP == 16) p += scr64[1024 + (wv * 64 + ln) * 4 + v];
+            }
+            if (RP == 8) {
+                if (j < 8) { if (i < 8) Gd[i][j] = m; else Sd[i - 8][j] = m; }
+            } else {
+                Gd[i & (RP - 1)][j & (RP - 1)] = m;
+                Sd[i & (RP - 1)][j & (RP - 1)] = p;
+            }
+        }
+        __syncthreads();
+    };
+
+    // dst = W T (T: RP x RP fp32, row-major T[k * RP + m]) by the fp32-input MFMA (a k-ordered fmaf chain); Y^T hi + lo beside it.
+    // as_u: the result is U - its fp16 rounding is the hi part, kept row-major for the state update and written to the packet
+    auto apply_t = [&](const float* T, bool as_u) {
+        h16* U16g = a.u_in_packet ? (h16*)it.packet : (h16*)(it.ws + a.offU16);
+        float tv[RP / 4], wv[LRS_TQ][RP / 4];
+#pragma unroll
+        for (int k = 0; k < RP / 4; ++k) tv[k] = (l16 < RP) ? T[(4 * k + lq) * RP + (l16 & (RP - 1))] : 0.f;      // A[i = m][k]
+#pragma unroll
+        for (int q = 0; q < LRS_TQ; ++q)
+#pragma unroll
+            for (int k = 0; k < RP / 4; ++k) wv[q][k] = Wf[min((w + 4 * q) * 16 + l16, NPK - 1) * RP + 4 * k + lq];   // B[k][j = row]
+#pragma unroll
+        for (int q = 0; q < LRS_TQ; ++q) {
+            const int t = w + 4 * q, n = t * 16 + l16;
+            if (t >= nmt) break;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < RP / 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[k], wv[q][k], acc, 0, 0, 0);
+            // D[i = m = 4 lq + v][j = row]; rows m >= RP of the transposed arrays are rewritten with the zeros the masked A rows give
+            // (the fp64 scratch lay over them)
+            if (4 * lq < RP && !as_u) *reinterpret_cast<f32x4*>(&Yf[n * RP + 4 * lq]) = acc;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int m = 4 * lq + v;
+                const h16 hi = (h16)acc[v];
+                Yth[m * NPH + n] = hi;
+                Ytl[m * NPH + n] = (h16)(acc[v] - (float)hi);
+                if (as_u && m < RP) {
+                    U16s[n * RP + m] = hi;
+                    if (idx == 0 && n < N && m < r) U16g[(size_t)n * r + m] = hi;
+                }
+            }
+        }
+        __syncthreads();
+    };
+
+    // ---------------- Y0 = A Q0 ----------------
+    product_b(tag0);
+    LSTAMP(2);
+    allreduce(tag0, Yf, false);
+    split_y();
+    LSTAMP(3);
+
+    // ---------------- W1 = A (A^T Y0), T1, Y1 = W1 T1 ----------------
+    product_a(false);
+    product_b(tag0 + 1);
+    LSTAMP(4);
+    allreduce(tag0 + 1, Wf, true);
+    LSTAMP(5);
+    gram64(false);
+    LSTAMP(15);
+    lr_chol_T<RP, 256>(Gd, Ld, r, Ts, &misc[0], &misc[1], LRS_PIVOT_TOL);       // T1
+    __syncthreads();
+    apply_t(Ts, false);
+    LSTAMP(6);
+
+    // ---------------- W2 = A (A^T Y1), T2, T3, U = W2 T2 T3 ----------------
+    product_a(false);
+    product_b(tag0 + 2);
+    LSTAMP(7);
+    allreduce(tag0 + 2, Wf, false);
+    LSTAMP(8);
+    gram64(true);
+    lr_chol_T<RP, 256>(Gd, Ld, r, T2s, &misc[0], &misc[1], LRS_PIVOT_TOL);      // T2
+    __syncthreads();
+    for (int i = tid; i < RP * RP; i += 256) {                        // X = sym(P) T2
+        const int p = i / RP, q = i - p * RP;
+        double s = 0.0;
+        for (int k = 0; k < RP; ++k) s += 0.5 * (Sd[p][k] + Sd[k][p]) * (double)T2s[k * RP + q];
+        Ld[p][q] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < RP * RP; i += 256) {                        // M3 = T2^T X
+        const int p = i / RP, q = i - p * RP;
+        double s = 0.0;
+        for (int k = 0; k < RP; ++k) s += (double)T2s[k * RP + p] * Ld[k][q];
+        Gd[p][q] = s;
+    }
+    __syncthreads();
+    lr_chol_T<RP, 256>(Gd, Ld, r, Ts, &misc[0], &misc[1], LRS_PIVOT_TOL);       // T3
+    __syncthreads();
+    for (int i = tid; i < RP * RP; i += 256) {
+        const int p = i / RP, q = i - p * RP;
+        float s = 0.f;
+        for (int k = 0; k < RP; ++k) s = fmaf(T2s[p * RP + k], Ts[k * RP + q], s);
+        T23[i] = s;
+    }
+    __syncthreads();
+    LSTAMP(9);
+    apply_t(T23, true);                                               // U (hi + lo transposed for V, fp16 row-major for the state update)
+    LSTAMP(10);
+
+    // ---------------- V = U^T A for the slab's columns, state update of the slab's columns ----------------
+    product_a(true);
+    if (a.fuse_decode) {
+        // new_base[:, slab] = base + fp16(U V): the arithmetic of k_lr_decode (v_dot2 chain over the k-pairs in order, one rounding
+        // to fp16, one fp16 add), from the registers base was loaded into at the start
+        h16x2 vp[RP / 2][8];
+#pragma unroll
+        for (int kk = 0; kk < RP / 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                vp[kk][i][0] = Zth[(2 * kk) * LRS_ZH + 8 * lq + i];
+                vp[kk][i][1] = Zth[(2 * kk + 1) * LRS_ZH + 8 * lq + i];
+            }
+#pragma unroll
+        for (int q = 0; q < LRS_TQ; ++q) {
+            const int row = (w + 4 * q) * 16 + l16;
+            if (row < N) {
+                float acc[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < RP / 2; ++kk) {
+                    if (2 * kk < r) {
+                        const h16x2 ua = *reinterpret_cast<const h16x2*>(&U16s[row * RP + 2 * kk]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_fdot2(ua, vp[kk][i], acc[i], false);
+                    }
+                }
+                h16x8 o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = (h16)acc[i];
+                if (it.base) o = bs[q] + o;
+                __builtin_nontemporal_store(o, reinterpret_cast<h16x8*>(it.new_base + (size_t)row * C + c0 + 8 * lq));
+            }
+        }
+    }
+    LSTAMP(11);
+#undef LSTAMP
+    // ---------------- leave: the last workgroup of the launch resets the ticket and moves the arena's launch count on ----------------
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)(nwg * a.batch) - 1) {
+            __hip_atomic_store(a.tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned*>(a.arena), launches + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+static inline int lrs_npk(int N) { return (N + 31) / 32 * 32; }
+
+bool cfx_i_lrs_ok(int N, int C, int RP) {
+    if (N < 32 || N > 16 * 4 * LRS_TQ || (C % 128) != 0 || C < 512 || RP > 16) return false;
+    const int npk = lrs_npk(N);
+    return (RP == 8 ? LrsLds<8>::total(npk) : LrsLds<16>::total(npk)) <= 160 * 1024;
+}
+
+size_t cfx_i_lrs_extra_bytes(int, int, int) { return 0; }       // nothing in the caller's workspace: the hand-over arena is the context's
+
+// bytes of one tensor's part of the arena: the partials of every slab, then the sum (4-byte tagged words)
+static size_t lrs_tensor_bytes(int N, int C, int RP, size_t* off_full) {
+    const size_t npk = lrs_npk(N);
+    const size_t part = al256((size_t)(C / LRS_SW) * npk * RP * 4);
+    if (off_full) *off_full = part;
+    return part + al256(npk * RP * 4);
+}
+
+// The arena of `stream` laid out for this shape (allocated / zeroed as needed; the zeroing is stream-ordered before the launch).
+static char* lrs_arena(cfx_ctx* ctx, void* stream, int N, int C, int RP, int nb, size_t* stride, size_t* off_full) {
+    *stride = lrs_tensor_bytes(N, C, RP, off_full);
+    const size_t need = 256 + *stride * nb;
+    const unsigned long long key = ((unsigned long long)N << 40) ^ ((unsigned long long)C << 16) ^ ((unsigned long long)RP << 8) ^ (unsigned long long)nb;
+    int slot = -1;
+    for (int i = 0; i < ctx->lrs_n; ++i)
+        if (ctx->lrs_stream[i] == stream) { slot = i; break; }
+    if (slot < 0) {
+        slot = ctx->lrs_n < 8 ? ctx->lrs_n++ : (int)(ctx->lrs_next++ % 8);      // every slot taken: the oldest changes hands
+        ctx->lrs_stream[slot] = stream;
+        ctx->lrs_key[slot] = ~0ull;
+    }
+    if (ctx->lrs_bytes[slot] < need) {
+        if (ctx->lrs_arena[slot]) { (void)hipDeviceSynchronize(); (void)hipFree(ctx->lrs_arena[slot]); }
+        ctx->lrs_arena[slot] = nullptr;
+        ctx->lrs_bytes[slot] = 0;
+        void* p = nullptr;
+        if (hipMalloc(&p, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        ctx->lrs_arena[slot] = (char*)p;
+        ctx->lrs_bytes[slot] = need;
+        ctx->lrs_key[slot] = ~0ull;
+    }
+    if (ctx->lrs_key[slot] != key) {
+        // another layout: what the words hold no longer says anything about the tags - start again from zero (tag 0, count 0)
+        if (hipMemsetAsync(ctx->lrs_arena[slot], 0, need, (hipStream_t)stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        ctx->lrs_key[slot] = key;
+    }
+    return ctx->lrs_arena[slot];
+}
+
+template <int RP>
+static int lrs_run(cfx_ctx* ctx, const LrBatch& b, LrsArgs a, hipStream_t s) {
+    const size_t lds = (size_t)LrsLds<RP>::total(a.NPK);
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) {
+        if (hipFuncSetAttribute((const void*)k_lrs<RP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(ctx, CFX_ERR_LAUNCH, "low-rank: the device does not grant the LDS the slab-resident chain needs");
+        }
+        attr_bytes = lds;
+    }
+    a.zmod = (a.batch <= 8 && 8 % a.batch == 0) ? 1 : 0;
+    LAUNCH(ctx, KID_LR_CHAIN, s, (k_lrs<RP>), dim3((unsigned)(a.nwg_t * a.batch)), dim3(256), lds, s, b, a);
+    return check_launch(ctx, "low-rank (slab-resident chain)");
+}
+
+// Tensors of a batch one launch can take: every workgroup must be resident at once (one per CU: the LDS), so C / 32 per tensor
+// out of the CUs the stream's queue may use; 0: this stream cannot run the form at all.
+int cfx_i_lrs_fit(cfx_ctx* ctx, int N, int C, int RP, void* stream) {
+    if (!cfx_i_lrs_ok(N, C, RP)) return 0;
+    const int cap = cfx_i_stream_cus(ctx, stream) - 2;                // a little room for whatever else is on the device
+    const int nb = cap / (C / LRS_SW);
+    return nb > LR_MAXB ? LR_MAXB : nb;
+}
+
+// Factors of every tensor of the batch (see cfx_i_lrg_factors) by the slab-resident chain.  `extra` = offset of
+// cfx_i_lrs_extra_bytes() bytes inside each tensor's workspace.
+int cfx_i_lrs_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int batch, const LrBatch& b, size_t offU16, size_t offV16,
+                      size_t extra, int absd, int want_decode, int* decoded, hipStream_t s) {
+    const int RPv = lr_rp(rank);
+    if (decoded) *decoded = 0;
+    const int fit = cfx_i_lrs_fit(ctx, N, C, RPv, (void*)s);
+    if (fit < 1) return fail(ctx, CFX_ERR_LAUNCH, "low-rank: the slab-resident chain does not fit the stream's CUs");
+    const size_t npk = lrs_npk(N);
+    (void)extra;
+    for (int first = 0; first < batch; first += fit) {
+        const int nb = batch - first < fit ? batch - first : fit;
+        LrBatch bb;
+        memset(&bb, 0, sizeof(bb));
+        for (int i = 0; i < nb; ++i) bb.it[i] = b.it[first + i];
+        LrsArgs a;
+        memset(&a, 0, sizeof(a));
+        a.N = N; a.C = C; a.NPK = (int)npk; a.r = rank; a.batch = nb; a.nwg_t = C / LRS_SW;
+        a.absd = absd; a.u_in_packet = quantized ? 0 : 1;
+        a.fuse_decode = (want_decode && !quantized) ? 1 : 0;
+        a.offU16 = offU16; a.offV16 = offV16;
+        a.arena = lrs_arena(ctx, (void*)s, N, C, RPv, nb, &a.arena_stride, &a.offFull);
+        a.tick = cfx_i_ticket_block(ctx, (void*)s);
+        if (!a.arena || !a.tick) return fail(ctx, CFX_ERR_LAUNCH, "low-rank: cannot set up the hand-over arena");
+        a.err = ctx->gate_err;
+        a.timeout = ctx->gate_timeout;
+        a.stamps = (unsigned long long*)ctx->dbg_stamps;
+        const int rc = RPv == 8 ? lrs_run<8>(ctx, bb, a, s) : lrs_run<16>(ctx, bb, a, s);
+        if (rc != CFX_OK) return rc;
+    }
+    if (decoded) *decoded = (want_decode && !quantized) ? 1 : 0;
+    return CFX_OK;
+}
