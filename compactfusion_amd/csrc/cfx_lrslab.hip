@@ -4,7 +4,8 @@
 // cfx_lrgram.hip (orthonormalisation after every multiplication, the r x r factors by Cholesky of the Gram matrices):
 //     Y0 = A Q0
 //     W1 = A (A^T Y0)      M1 = Y0^T W1      T1 = chol(M1)^-T      Y1 = W1 T1
-//     W2 = A (A^T Y1)      M2 = Y1^T W2      T2 = chol(M2)^-T      M3 = T2^T (W2^T W2) T2      T3 = chol(M3)^-T      U = W2 T2 T3
+//     W2 = A (A^T Y1)      U = W2 chol(W2^T W2)^-T        (= W2 T2 T3 of the N-space chain: T2 T3 is upper triangular and makes
+//                                                           W2 orthonormal, so it IS the inverse Cholesky factor of W2^T W2)
 //     V  = U^T A           new_base = base + fp16(U V)
 // Here A is never written anywhere and A A^T is never formed.  ONE persistent launch; workgroup j of a tensor owns the 32-column
 // slab j of A for the whole chain: the slab is read from x and base exactly once (HBM: x + base in, new_base out - 6 bytes an
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
     const LrItem it = b.it[z];
     const int N = a.N, C = a.C, NPK = a.NPK, r = a.r, nwg = a.nwg_t;
     const int NPH = NPK + 8, nmt = NPK / 16;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, lq = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, lq = lane >> 4;     // w: scalar (uniform branches)
     extern __shared__ double lrs_smem[];
     char* sm = reinterpret_cast<char*>(lrs_smem);
     h16* Dt = reinterpret_cast<h16*>(sm + L::dt(NPK));
@@ -336,11 +337,11 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
         __syncthreads();
     };
 
-    // fp64 Gram matrices of fp32 operands (exact products, fp64 sums): M = Y^T W into Gd, and (want_p) P = W^T W into Sd
+    // fp64 Gram matrices of fp32 operands (exact products, fp64 sums): M = Y^T W into Gd, or (want_p) P = W^T W into Sd
     auto gram64 = [&](bool want_p) {
         f64x4 am[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, ap[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
         const int nks = NPK / 4;
-        constexpr int UN = 6;                                         // K steps whose operands are in flight at once
+        constexpr int UN = 9;                                         // K steps whose operands are in flight at once
         for (int i0 = 0; w + 4 * i0 < nks; i0 += UN) {
             float av[UN], bv[UN];
 #pragma unroll
@@ -360,8 +361,8 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                am[u & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[u], (double)bv[u], am[u & 1], 0, 0, 0);
                 if (RP == 16 && want_p) ap[u & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)bv[u], (double)bv[u], ap[u & 1], 0, 0, 0);
+                else am[u & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[u], (double)bv[u], am[u & 1], 0, 0, 0);
             }
         }
         am[0] += am[1];
@@ -392,40 +393,46 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
         __syncthreads();
     };
 
-    // dst = W T (T: RP x RP fp32, row-major T[k * RP + m]) by the fp32-input MFMA (a k-ordered fmaf chain); Y^T hi + lo beside it.
-    // as_u: the result is U - its fp16 rounding is the hi part, kept row-major for the state update and written to the packet
+    // Y = W T (T: RP x RP fp32, row-major T[k * RP + m]) by the fp32-input MFMA (a k-ordered fmaf chain), D[i = row][j = m]: a lane
+    // holds 4 consecutive rows of one column, i.e. 8 bytes of a row of Y^T (hi, lo).  Rows m >= RP of Y^T are rewritten with the zeros
+    // the masked B columns give (the fp64 scratch lay over them).  as_u: the result is U - its fp16 rounding is the hi part, kept
+    // row-major for the state update (and written to the packet by workgroup 0); otherwise Y (fp32, row-major) for the next Gram matrix
     auto apply_t = [&](const float* T, bool as_u) {
-        h16* U16g = a.u_in_packet ? (h16*)it.packet : (h16*)(it.ws + a.offU16);
         float tv[RP / 4], wv[LRS_TQ][RP / 4];
 #pragma unroll
-        for (int k = 0; k < RP / 4; ++k) tv[k] = (l16 < RP) ? T[(4 * k + lq) * RP + (l16 & (RP - 1))] : 0.f;      // A[i = m][k]
+        for (int k = 0; k < RP / 4; ++k) tv[k] = (l16 < RP) ? T[(4 * k + lq) * RP + (l16 & (RP - 1))] : 0.f;      // B[k][j = m]
 #pragma unroll
         for (int q = 0; q < LRS_TQ; ++q)
 #pragma unroll
-            for (int k = 0; k < RP / 4; ++k) wv[q][k] = Wf[min((w + 4 * q) * 16 + l16, NPK - 1) * RP + 4 * k + lq];   // B[k][j = row]
+            for (int k = 0; k < RP / 4; ++k) wv[q][k] = Wf[min((w + 4 * q) * 16 + l16, NPK - 1) * RP + 4 * k + lq];   // A[i = row][k]
 #pragma unroll
         for (int q = 0; q < LRS_TQ; ++q) {
-            const int t = w + 4 * q, n = t * 16 + l16;
-            if (t >= nmt) break;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int t = w + 4 * q, n0 = t * 16 + 4 * lq;
+            if (t < nmt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < RP / 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(tv[k], wv[q][k], acc, 0, 0, 0);
-            // D[i = m = 4 lq + v][j = row]; rows m >= RP of the transposed arrays are rewritten with the zeros the masked A rows give
-            // (the fp64 scratch lay over them)
-            if (4 * lq < RP && !as_u) *reinterpret_cast<f32x4*>(&Yf[n * RP + 4 * lq]) = acc;
+                for (int k = 0; k < RP / 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][k], tv[k], acc, 0, 0, 0);
+                h16x4 hi, lo;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int m = 4 * lq + v;
-                const h16 hi = (h16)acc[v];
-                Yth[m * NPH + n] = hi;
-                Ytl[m * NPH + n] = (h16)(acc[v] - (float)hi);
-                if (as_u && m < RP) {
-                    U16s[n * RP + m] = hi;
-                    if (idx == 0 && n < N && m < r) U16g[(size_t)n * r + m] = hi;
+                for (int v = 0; v < 4; ++v) { hi[v] = (h16)acc[v]; lo[v] = (h16)(acc[v] - (float)hi[v]); }
+                *reinterpret_cast<h16x4*>(&Yth[l16 * NPH + n0]) = hi;
+                *reinterpret_cast<h16x4*>(&Ytl[l16 * NPH + n0]) = lo;
+                if (l16 < RP) {
+                    if (as_u) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) U16s[(n0 + v) * RP + l16] = hi[v];
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) Yf[(n0 + v) * RP + l16] = acc[v];
+                    }
                 }
             }
         }
         __syncthreads();
+        if (as_u && idx == 0) {
+            h16* U16g = a.u_in_packet ? (h16*)it.packet : (h16*)(it.ws + a.offU16);
+            for (int i = tid; i < N * r; i += 256) { const int n = i / r, m = i - n * r; U16g[i] = U16s[n * RP + m]; }
+        }
     };
 
     // ---------------- Y0 = A Q0 ----------------
@@ -454,31 +461,12 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
     LSTAMP(7);
     allreduce(tag0 + 2, Wf, false);
     LSTAMP(8);
+    // T2 T3 = chol(W2^T W2)^-T: the product of the two upper triangular factors is itself the (unique) inverse Cholesky factor of
+    // P = W2^T W2 - one factorisation instead of chol(Y1^T W2), T2^T P T2, chol of that
     gram64(true);
-    lr_chol_T<RP, 256>(Gd, Ld, r, T2s, &misc[0], &misc[1], LRS_PIVOT_TOL);      // T2
+    for (int i = tid; i < RP * RP; i += 256) Gd[i / RP][i % RP] = Sd[i / RP][i % RP];
     __syncthreads();
-    for (int i = tid; i < RP * RP; i += 256) {                        // X = sym(P) T2
-        const int p = i / RP, q = i - p * RP;
-        double s = 0.0;
-        for (int k = 0; k < RP; ++k) s += 0.5 * (Sd[p][k] + Sd[k][p]) * (double)T2s[k * RP + q];
-        Ld[p][q] = s;
-    }
-    __syncthreads();
-    for (int i = tid; i < RP * RP; i += 256) {                        // M3 = T2^T X
-        const int p = i / RP, q = i - p * RP;
-        double s = 0.0;
-        for (int k = 0; k < RP; ++k) s += (double)T2s[k * RP + p] * Ld[k][q];
-        Gd[p][q] = s;
-    }
-    __syncthreads();
-    lr_chol_T<RP, 256>(Gd, Ld, r, Ts, &misc[0], &misc[1], LRS_PIVOT_TOL);       // T3
-    __syncthreads();
-    for (int i = tid; i < RP * RP; i += 256) {
-        const int p = i / RP, q = i - p * RP;
-        float s = 0.f;
-        for (int k = 0; k < RP; ++k) s = fmaf(T2s[p * RP + k], Ts[k * RP + q], s);
-        T23[i] = s;
-    }
+    lr_chol_T<RP, 256>(Gd, Ld, r, T23, &misc[0], &misc[1], LRS_PIVOT_TOL);
     __syncthreads();
     LSTAMP(9);
     apply_t(T23, true);                                               // U (hi + lo transposed for V, fp16 row-major for the state update)
