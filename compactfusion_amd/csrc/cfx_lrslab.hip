@@ -40,9 +40,11 @@ typedef unsigned lrs_u4 __attribute__((ext_vector_type(4)));
 
 #define LRS_PIVOT_TOL 1e-10   // as the N-space chain (cfx_lrgram.hip): pivots below this fraction of the largest are dropped
 #define LRS_SW 32             // columns of a slab
-#define LRS_TQ 9              // 16-row tiles per wave: 4 waves x 9 x 16 = 576 rows at most
+#define LRS_NW 8              // waves of a workgroup (two per SIMD: one hides the other's LDS / MFMA latencies)
+#define LRS_NT (64 * LRS_NW)
+#define LRS_TQ 5              // 16-row tiles per wave: 8 waves x 5 x 16 = 640 rows at most (the LDS allows ~576)
 #define LRS_ZH 40             // halves per LDS row of Z^T (32 + 8: 16-byte aligned rows spread over the banks)
-#define LRS_J 10              // partials / cells a thread polls at once (4 units each)
+#define LRS_J 6               // partials / cells (16 bytes each) a thread polls at once
 
 struct LrsArgs {
     int N, C, NPK, r, batch, nwg_t, zmod;
@@ -64,8 +66,8 @@ __device__ __forceinline__ float lrs_val(unsigned q) { return __builtin_bit_cast
 __device__ __forceinline__ void lrs_st16(void* p, lrs_u4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
 #define LRS_LD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
 template <int J> __device__ __forceinline__ void lrs_wait(lrs_u4 (&q)[J]) {
-    static_assert(J == 10, "operand list below");
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]), "+v"(q[9])::"memory");
+    static_assert(J == 6, "operand list below");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5])::"memory");
 }
 __device__ __forceinline__ bool lrs_tagged(lrs_u4 q, unsigned seq) { return ((q[0] & q[1] & q[2] & q[3] & 3u) == seq) && (((q[0] | q[1] | q[2] | q[3]) & 3u) == seq); }
 
@@ -75,8 +77,8 @@ template <int RP> struct LrsLds {
     __host__ __device__ static int yt(int NPK) { return 32 * (NPK + 8) * 2; }                   // Y^T hi | lo, [16][NPH] fp16 each
     __host__ __device__ static int yt_bytes(int NPK) { const int a = 2 * 16 * (NPK + 8) * 2; return a > 16384 ? a : 16384; }     // dead: fp64 Gram partials
     __host__ __device__ static int yf(int NPK) { return yt(NPK) + yt_bytes(NPK); }              // Y   [NPK][RP] fp32; at the end: U [NPK][RP] fp16
-    __host__ __device__ static int wf(int NPK) { return yf(NPK) + NPK * RP * 4; }               // W   [NPK][RP] fp32; dead: 8 KB of reduction scratch
-    __host__ __device__ static int wf_bytes(int NPK) { const int a = NPK * RP * 4; return a > 8192 ? a : 8192; }
+    __host__ __device__ static int wf(int NPK) { return yf(NPK) + NPK * RP * 4; }               // W   [NPK][RP] fp32; dead: 16 KB of reduction scratch
+    __host__ __device__ static int wf_bytes(int NPK) { const int a = NPK * RP * 4; return a > 16384 ? a : 16384; }
     __host__ __device__ static int zt(int NPK) { return wf(NPK) + wf_bytes(NPK); }              // Z^T hi | lo, [16][LRS_ZH] fp16 each
     __host__ __device__ static int ch(int NPK) { return zt(NPK) + 2 * 16 * LRS_ZH * 2; }        // factorisation scratch
     static constexpr int ch_bytes = ((3 * RP * (RP + 1) + RP + 2) * 8 + 3 * RP * RP * 4 + 15) / 16 * 16;
@@ -84,7 +86,7 @@ template <int RP> struct LrsLds {
 };
 
 template <int RP>
-__global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
+__global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     typedef LrsLds<RP> L;
     const int bid = blockIdx.x;
     int z, idx;
@@ -120,23 +122,23 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
 #define LSTAMP(k) do { if (a.stamps && tid == 0) a.stamps[(size_t)bid * 16 + (k)] = wall_clock64(); } while (0)
     LSTAMP(0);
 
-    // ---------------- the slab: registers (rows t * 16 + l16 of tile t = w + 4 q, columns c0 + 8 lq .. + 7) and LDS (transposed) ----------------
+    // ---------------- the slab: registers (rows t * 16 + l16 of tile t = w + LRS_NW q, columns c0 + 8 lq .. + 7) and LDS (transposed) ----------------
     h16x8 ds[LRS_TQ], bs[LRS_TQ];
     {
         h16x8 xv[LRS_TQ];
 #pragma unroll
         for (int q = 0; q < LRS_TQ; ++q) {                              // every load unconditional (clamped row): all in flight at once
-            const int row = min((w + 4 * q) * 16 + l16, N - 1);
+            const int row = min((w + LRS_NW * q) * 16 + l16, N - 1);
             const size_t o = (size_t)row * C + c0 + 8 * lq;
             xv[q] = __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(it.x + o));
             bs[q] = (h16x8)(h16)0;
             if (it.base) bs[q] = __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(it.base + o));
         }
         // meanwhile: zero what must read as zero (rows >= RP of Y^T and Z^T, columns >= N of the transposed arrays)
-        for (int i = tid; i < (L::yf(NPK) - L::dt(NPK)) / 16; i += 256) reinterpret_cast<lrs_u4*>(sm)[i] = (lrs_u4)0u;
-        for (int i = tid; i < 2 * 16 * LRS_ZH * 2 / 16; i += 256) reinterpret_cast<lrs_u4*>(Zth)[i] = (lrs_u4)0u;
+        for (int i = tid; i < (L::yf(NPK) - L::dt(NPK)) / 16; i += LRS_NT) reinterpret_cast<lrs_u4*>(sm)[i] = (lrs_u4)0u;
+        for (int i = tid; i < 2 * 16 * LRS_ZH * 2 / 16; i += LRS_NT) reinterpret_cast<lrs_u4*>(Zth)[i] = (lrs_u4)0u;
         __syncthreads();
-        for (int e = tid; e < LRS_SW * RP; e += 256) {                  // Q0 rows of the slab -> Z^T as hi + lo
+        for (int e = tid; e < LRS_SW * RP; e += LRS_NT) {                  // Q0 rows of the slab -> Z^T as hi + lo
             const int wc = e / RP, k = e - wc * RP;
             const float v = it.q0[(size_t)(c0 + wc) * RP + k];
             const h16 hi = (h16)v;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < LRS_TQ; ++q) {
-            const int t = w + 4 * q, row = t * 16 + l16;
+            const int t = w + LRS_NW * q, row = t * 16 + l16;
             h16x8 d = xv[q] - bs[q];                                  // fp16, one rounding (torch eager: x - base); base absent: x - 0 = x
             if (a.absd) {
                 typedef unsigned short u16x8_ __attribute__((ext_vector_type(8)));
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
         const unsigned seq = tag & 3u;
 #pragma unroll
         for (int q = 0; q < LRS_TQ; ++q) {
-            const int t = w + 4 * q;
+            const int t = w + LRS_NW * q;
             if (t < nmt) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, ds[q], acc, 0, 0, 0);
@@ -193,8 +195,8 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         const int nk32 = NPK / 32;
 #pragma unroll
-        for (int i = 0; i < (LRS_TQ * 2 + 3) / 4; ++i) {               // K steps of this wave, operands loaded unconditionally
-            const int ks = w + 4 * i;
+        for (int i = 0; i < (LRS_TQ * LRS_NW / 2 + LRS_NW - 1) / LRS_NW; ++i) {      // K steps of this wave, operands loaded unconditionally
+            const int ks = w + LRS_NW * i;
             const int n0 = min(ks, nk32 - 1) * 32 + 8 * lq;
             const h16x8 a0 = *reinterpret_cast<const h16x8*>(&Dt[l16 * NPH + n0]);
             const h16x8 a1 = *reinterpret_cast<const h16x8*>(&Dt[(16 + l16) * NPH + n0]);
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
             const int mt = tid >> 6, ln = tid & 63;
             f32x4 s = red4[mt * 64 + ln];
 #pragma unroll
-            for (int wv = 1; wv < 4; ++wv) s += red4[(wv * 2 + mt) * 64 + ln];
+            for (int wv = 1; wv < LRS_NW; ++wv) s += red4[(wv * 2 + mt) * 64 + ln];
             const int rr = ln & 15, w0 = 16 * mt + 4 * (ln >> 4);      // D[i = column of the slab][j = rank]
             if (!final_v) {
                 h16x4 hi, lo;
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
         const unsigned seq = tag & 3u;
         const int cells = NPK * RP / 4;
         const int cpw = (cells + nwg - 1) / nwg;
-        const int cw = cpw < 256 ? cpw : 256, subs = 256 / cw;
+        const int cw = cpw < LRS_NT ? cpw : LRS_NT, subs = LRS_NT / cw;
         const int ci = tid % cw, sub = tid / cw;
         for (int cb = 0; cb < cpw; cb += cw) {
             const int cl = cb + ci, cell = idx * cpw + cl;
@@ -295,12 +297,12 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
         }
         if (stamp) LSTAMP(12);
         f32x4* dst4 = reinterpret_cast<f32x4*>(dst);
-        for (int i0 = tid; i0 < cells; i0 += 256 * LRS_J) {
+        for (int i0 = tid; i0 < cells; i0 += LRS_NT * LRS_J) {
             lrs_u4 q[LRS_J];
             long long t0 = 0;
             for (;;) {
 #pragma unroll
-                for (int j = 0; j < LRS_J; ++j) LRS_LD16(q[j], full + min(i0 + 256 * j, cells - 1));
+                for (int j = 0; j < LRS_J; ++j) LRS_LD16(q[j], full + min(i0 + LRS_NT * j, cells - 1));
                 lrs_wait(q);
                 bool ok = true;
 #pragma unroll
@@ -315,11 +317,11 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < LRS_J; ++j)
-                if (i0 + 256 * j < cells) {
+                if (i0 + LRS_NT * j < cells) {
                     f32x4 v;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = lrs_val(q[j][k]);
-                    dst4[i0 + 256 * j] = v;
+                    dst4[i0 + LRS_NT * j] = v;
                 }
         }
         __syncthreads();
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
 
     // Y^T as fp16 hi + lo from Y (LDS fp32 [NPK][RP])
     auto split_y = [&]() {
-        for (int i = tid; i < NPK * RP; i += 256) {
+        for (int i = tid; i < NPK * RP; i += LRS_NT) {
             const int n = i / RP, k = i - n * RP;
             const float v = Yf[i];
             const h16 hi = (h16)v;
@@ -342,11 +344,11 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
         f64x4 am[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, ap[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
         const int nks = NPK / 4;
         constexpr int UN = 9;                                         // K steps whose operands are in flight at once
-        for (int i0 = 0; w + 4 * i0 < nks; i0 += UN) {
+        for (int i0 = 0; w + LRS_NW * i0 < nks; i0 += UN) {
             float av[UN], bv[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int ks = w + 4 * (i0 + u);
+                const int ks = w + LRS_NW * (i0 + u);
                 const int n = min(ks, nks - 1) * 4 + lq;
                 if (RP == 8) {
                     // one product: rows 0 .. 7 of the A operand are Y's columns, rows 8 .. 15 W's (W lies behind Y in LDS) -> M on top of P
@@ -367,28 +369,21 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
         }
         am[0] += am[1];
         ap[0] += ap[1];
+        const f64x4 res = (RP == 16 && want_p) ? ap[0] : am[0];
         // D[i][j]: j = lane & 15, i = (lane >> 4) + 4 v  (the fp64 form's own map)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            scr64[(w * 64 + lane) * 4 + v] = am[0][v];
-            if (RP == 16) scr64[1024 + (w * 64 + lane) * 4 + v] = ap[0][v];
-        }
+        for (int v = 0; v < 4; ++v) scr64[(w * 64 + lane) * 4 + v] = res[v];
         __syncthreads();
-        {
+        if (tid < 256) {
             const int ln = tid & 63, v = tid >> 6;
             const int i = (ln >> 4) + 4 * v, j = ln & 15;
-            double m = 0.0, p = 0.0;
+            double m = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < 4; ++wv) {
-                m += scr64[(wv * 64 + ln) * 4 + v];
-                if (RP == 16) p += scr64[1024 + (wv * 64 + ln) * 4 + v];
-            }
+            for (int wv = 0; wv < LRS_NW; ++wv) m += scr64[(wv * 64 + ln) * 4 + v];
             if (RP == 8) {
                 if (j < 8) { if (i < 8) Gd[i][j] = m; else Sd[i - 8][j] = m; }
-            } else {
-                Gd[i & (RP - 1)][j & (RP - 1)] = m;
-                Sd[i & (RP - 1)][j & (RP - 1)] = p;
-            }
+            } else if (want_p) Sd[i & (RP - 1)][j & (RP - 1)] = m;
+            else Gd[i & (RP - 1)][j & (RP - 1)] = m;
         }
         __syncthreads();
     };
@@ -404,10 +399,10 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
 #pragma unroll
         for (int q = 0; q < LRS_TQ; ++q)
 #pragma unroll
-            for (int k = 0; k < RP / 4; ++k) wv[q][k] = Wf[min((w + 4 * q) * 16 + l16, NPK - 1) * RP + 4 * k + lq];   // A[i = row][k]
+            for (int k = 0; k < RP / 4; ++k) wv[q][k] = Wf[min((w + LRS_NW * q) * 16 + l16, NPK - 1) * RP + 4 * k + lq];   // A[i = row][k]
 #pragma unroll
         for (int q = 0; q < LRS_TQ; ++q) {
-            const int t = w + 4 * q, n0 = t * 16 + 4 * lq;
+            const int t = w + LRS_NW * q, n0 = t * 16 + 4 * lq;
             if (t < nmt) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -431,7 +426,7 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
         __syncthreads();
         if (as_u && idx == 0) {
             h16* U16g = a.u_in_packet ? (h16*)it.packet : (h16*)(it.ws + a.offU16);
-            for (int i = tid; i < N * r; i += 256) { const int n = i / r, m = i - n * r; U16g[i] = U16s[n * RP + m]; }
+            for (int i = tid; i < N * r; i += LRS_NT) { const int n = i / r, m = i - n * r; U16g[i] = U16s[n * RP + m]; }
         }
     };
 
@@ -450,7 +445,7 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
     LSTAMP(5);
     gram64(false);
     LSTAMP(15);
-    lr_chol_T<RP, 256>(Gd, Ld, r, Ts, &misc[0], &misc[1], LRS_PIVOT_TOL);       // T1
+    lr_chol_T<RP, LRS_NT>(Gd, Ld, r, Ts, &misc[0], &misc[1], LRS_PIVOT_TOL);       // T1
     __syncthreads();
     apply_t(Ts, false);
     LSTAMP(6);
@@ -464,9 +459,9 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
     // T2 T3 = chol(W2^T W2)^-T: the product of the two upper triangular factors is itself the (unique) inverse Cholesky factor of
     // P = W2^T W2 - one factorisation instead of chol(Y1^T W2), T2^T P T2, chol of that
     gram64(true);
-    for (int i = tid; i < RP * RP; i += 256) Gd[i / RP][i % RP] = Sd[i / RP][i % RP];
+    for (int i = tid; i < RP * RP; i += LRS_NT) Gd[i / RP][i % RP] = Sd[i / RP][i % RP];
     __syncthreads();
-    lr_chol_T<RP, 256>(Gd, Ld, r, T23, &misc[0], &misc[1], LRS_PIVOT_TOL);
+    lr_chol_T<RP, LRS_NT>(Gd, Ld, r, T23, &misc[0], &misc[1], LRS_PIVOT_TOL);
     __syncthreads();
     LSTAMP(9);
     apply_t(T23, true);                                               // U (hi + lo transposed for V, fp16 row-major for the state update)
@@ -487,7 +482,7 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
             }
 #pragma unroll
         for (int q = 0; q < LRS_TQ; ++q) {
-            const int row = (w + 4 * q) * 16 + l16;
+            const int row = (w + LRS_NW * q) * 16 + l16;
             if (row < N) {
                 float acc[8];
 #pragma unroll
@@ -527,7 +522,7 @@ __global__ __launch_bounds__(256) void k_lrs(LrBatch b, LrsArgs a) {
 static inline int lrs_npk(int N) { return (N + 31) / 32 * 32; }
 
 bool cfx_i_lrs_ok(int N, int C, int RP) {
-    if (N < 32 || N > 16 * 4 * LRS_TQ || (C % 128) != 0 || C < 512 || RP > 16) return false;
+    if (N < 32 || N > 16 * LRS_NW * LRS_TQ || (C % 128) != 0 || C < 512 || RP > 16) return false;
     const int npk = lrs_npk(N);
     return (RP == 8 ? LrsLds<8>::total(npk) : LrsLds<16>::total(npk)) <= 160 * 1024;
 }
@@ -585,7 +580,7 @@ static int lrs_run(cfx_ctx* ctx, const LrBatch& b, LrsArgs a, hipStream_t s) {
         attr_bytes = lds;
     }
     a.zmod = (a.batch <= 8 && 8 % a.batch == 0) ? 1 : 0;
-    LAUNCH(ctx, KID_LR_CHAIN, s, (k_lrs<RP>), dim3((unsigned)(a.nwg_t * a.batch)), dim3(256), lds, s, b, a);
+    LAUNCH(ctx, KID_LR_CHAIN, s, (k_lrs<RP>), dim3((unsigned)(a.nwg_t * a.batch)), dim3(LRS_NT), lds, s, b, a);
     return check_launch(ctx, "low-rank (slab-resident chain)");
 }
 
