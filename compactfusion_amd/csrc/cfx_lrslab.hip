@@ -71,6 +71,54 @@ template <int J> __device__ __forceinline__ void lrs_wait(lrs_u4 (&q)[J]) {
 }
 __device__ __forceinline__ bool lrs_tagged(lrs_u4 q, unsigned seq) { return ((q[0] & q[1] & q[2] & q[3] & 3u) == seq) && (((q[0] | q[1] | q[2] | q[3]) & 3u) == seq); }
 
+// Cholesky factor of the symmetrised G (RP x RP fp64 in LDS) in the registers of ONE wave: lane i holds row i, the pivot and the
+// column entries the other lanes need travel by v_readlane.  Out (LDS, fp32): L row-major (zero above the diagonal), 1 / L[j][j], and
+// the mask of directions whose pivot is not above tol x the largest diagonal entry (rank-deficient residual, e.g. x == base): their
+// column of L is the unit vector, the caller zeroes them.  No triangular inverse: the caller solves Y L^T = W row by row.
+template <int RP>
+__device__ __forceinline__ void lrs_chol_L(const double (*G)[RP + 1], int r, float* Lf, float* dinvf, unsigned* deadw, double tol) {
+    const int i = threadIdx.x & 63, ii = i < RP ? i : 0;
+    auto bcast = [](double v, int lane) -> double {          // value of lane `lane` (a constant) in every lane
+        const int2 q = __builtin_bit_cast(int2, v);
+        int2 o;
+        o.x = __builtin_amdgcn_readlane(q.x, lane);
+        o.y = __builtin_amdgcn_readlane(q.y, lane);
+        return __builtin_bit_cast(double, o);
+    };
+    double g[RP], gmax = 0.0;
+#pragma unroll
+    for (int k = 0; k < RP; ++k) g[k] = 0.5 * (G[ii][k] + G[k][ii]);
+#pragma unroll
+    for (int k = 0; k < RP; ++k) gmax = (k < r) ? fmax(gmax, G[k][k]) : gmax;
+    const double thr = gmax * tol;
+    unsigned dead = 0;
+    double myinv = 1.0;
+#pragma unroll
+    for (int j = 0; j < RP; ++j) {
+        const double piv = bcast(g[j], j);
+        const bool ok = (j < r) && (piv > thr);
+        const double pv = ok ? piv : 1.0;
+        // 1 / sqrt(piv) by v_rsq_f64 + two Newton steps (full fp64 accuracy): no correctly rounded sqrt and division on the chain
+        double inv = __builtin_amdgcn_rsq(pv);
+        inv = inv * (1.5 - 0.5 * pv * inv * inv);
+        inv = inv * (1.5 - 0.5 * pv * inv * inv);
+        double l = ok ? g[j] * inv : (i == j ? 1.0 : 0.0);           // lane j: piv * inv = sqrt(piv)
+        l = (i >= j && i < r) ? l : 0.0;
+        myinv = (i == j && ok) ? inv : myinv;
+        dead |= (ok || j >= r) ? 0u : (1u << j);
+        g[j] = l;
+#pragma unroll
+        for (int k = j + 1; k < RP; ++k) g[k] -= l * bcast(l, k);    // every lane, every k > j: rows above the diagonal have l = 0
+        __builtin_amdgcn_sched_barrier(0);                           // keep a step's broadcasts (SGPRs) from being hoisted across steps
+    }
+    if (i < RP) {
+#pragma unroll
+        for (int k = 0; k < RP; ++k) Lf[i * RP + k] = (float)g[k];
+        dinvf[i] = (float)myinv;
+    }
+    if (i == 0) *deadw = dead;
+}
+
 // LDS carve-up (bytes).  NPK = N rounded up to 32 (the K step of the fp16 MFMA), NPH = NPK + 8 halves per transposed row.
 template <int RP> struct LrsLds {
     __host__ __device__ static int dt(int) { return 0; }                                        // slab^T  [32][NPH] fp16
@@ -110,9 +158,9 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     double (*Ld)[RP + 1] = Gd + RP;
     double (*Sd)[RP + 1] = Ld + RP;
     double* misc = reinterpret_cast<double*>(Sd + RP);                // [0] gmax, [1 .. RP] dinv
-    float* Ts = reinterpret_cast<float*>(misc + RP + 2);
-    float* T2s = Ts + RP * RP;
-    float* T23 = T2s + RP * RP;
+    float* Lf = reinterpret_cast<float*>(misc + RP + 2);            // Cholesky factor (fp32, row-major), 1 / diagonal, dead directions
+    float* dinvf = Lf + RP * RP;
+    unsigned* deadw = reinterpret_cast<unsigned*>(dinvf + RP);
     double* scr64 = reinterpret_cast<double*>(Yth);                    // fp64 Gram partials of the waves while Y^T is dead (<= 16 KB)
     lrs_u4* part = reinterpret_cast<lrs_u4*>(a.arena + 256 + (size_t)z * a.arena_stride);     // [nwg][NPK][RP / 4] cells of 4 tagged words
     lrs_u4* full = reinterpret_cast<lrs_u4*>(a.arena + 256 + (size_t)z * a.arena_stride + a.offFull);      // [NPK][RP / 4]
@@ -388,39 +436,43 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
         __syncthreads();
     };
 
-    // Y = W T (T: RP x RP fp32, row-major T[k * RP + m]) by the fp32-input MFMA (a k-ordered fmaf chain), D[i = row][j = m]: a lane
-    // holds 4 consecutive rows of one column, i.e. 8 bytes of a row of Y^T (hi, lo).  Rows m >= RP of Y^T are rewritten with the zeros
-    // the masked B columns give (the fp64 scratch lay over them).  as_u: the result is U - its fp16 rounding is the hi part, kept
-    // row-major for the state update (and written to the packet by workgroup 0); otherwise Y (fp32, row-major) for the next Gram matrix
-    auto apply_t = [&](const float* T, bool as_u) {
-        float tv[RP / 4], wv[LRS_TQ][RP / 4];
+    // Y = W L^-T, one row per thread by forward substitution (fp32; the factor's entries are LDS broadcasts): Y^T as fp16 hi + lo for
+    // the next product (rows >= RP rewritten with zeros: the fp64 scratch lay over them), and Y itself (fp32, row-major) for the next
+    // Gram matrix - or, as_u: the result is U, its fp16 rounding (= the hi part) kept row-major for the state update and written to
+    // the packet by workgroup 0
+    auto apply_l = [&](bool as_u) {
+        const unsigned dead = *deadw;
+        for (int n = tid; n < NPK; n += LRS_NT) {
+            float wv[RP], y[RP];
 #pragma unroll
-        for (int k = 0; k < RP / 4; ++k) tv[k] = (l16 < RP) ? T[(4 * k + lq) * RP + (l16 & (RP - 1))] : 0.f;      // B[k][j = m]
+            for (int c = 0; c < RP / 4; ++c) *reinterpret_cast<f32x4*>(&wv[4 * c]) = *reinterpret_cast<const f32x4*>(&Wf[n * RP + 4 * c]);
 #pragma unroll
-        for (int q = 0; q < LRS_TQ; ++q)
+            for (int j = 0; j < RP; ++j) {
+                float sacc = wv[j];
 #pragma unroll
-            for (int k = 0; k < RP / 4; ++k) wv[q][k] = Wf[min((w + LRS_NW * q) * 16 + l16, NPK - 1) * RP + 4 * k + lq];   // A[i = row][k]
+                for (int k = 0; k < j; ++k) sacc = fmaf(-y[k], Lf[j * RP + k], sacc);
+                y[j] = ((dead >> j) & 1u) ? 0.f : sacc * dinvf[j];
+            }
+            h16 hi[RP];
 #pragma unroll
-        for (int q = 0; q < LRS_TQ; ++q) {
-            const int t = w + LRS_NW * q, n0 = t * 16 + 4 * lq;
-            if (t < nmt) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < RP; ++m) {
+                hi[m] = (h16)y[m];
+                Yth[m * NPH + n] = hi[m];
+                Ytl[m * NPH + n] = (h16)(y[m] - (float)hi[m]);
+            }
 #pragma unroll
-                for (int k = 0; k < RP / 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q][k], tv[k], acc, 0, 0, 0);
-                h16x4 hi, lo;
+            for (int m = RP; m < 16; ++m) { Yth[m * NPH + n] = (h16)0; Ytl[m * NPH + n] = (h16)0; }
+            if (as_u) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) { hi[v] = (h16)acc[v]; lo[v] = (h16)(acc[v] - (float)hi[v]); }
-                *reinterpret_cast<h16x4*>(&Yth[l16 * NPH + n0]) = hi;
-                *reinterpret_cast<h16x4*>(&Ytl[l16 * NPH + n0]) = lo;
-                if (l16 < RP) {
-                    if (as_u) {
+                for (int c = 0; c < RP / 8; ++c) {
+                    h16x8 u8;
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) U16s[(n0 + v) * RP + l16] = hi[v];
-                    } else {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) Yf[(n0 + v) * RP + l16] = acc[v];
-                    }
+                    for (int e = 0; e < 8; ++e) u8[e] = hi[8 * c + e];
+                    *reinterpret_cast<h16x8*>(&U16s[n * RP + 8 * c]) = u8;
                 }
+            } else {
+#pragma unroll
+                for (int c = 0; c < RP / 4; ++c) *reinterpret_cast<f32x4*>(&Yf[n * RP + 4 * c]) = *reinterpret_cast<const f32x4*>(&y[4 * c]);
             }
         }
         __syncthreads();
@@ -445,9 +497,9 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     LSTAMP(5);
     gram64(false);
     LSTAMP(15);
-    lr_chol_T<RP, LRS_NT>(Gd, Ld, r, Ts, &misc[0], &misc[1], LRS_PIVOT_TOL);       // T1
+    if (w == 0) lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_TOL);        // chol(M1)
     __syncthreads();
-    apply_t(Ts, false);
+    apply_l(false);                                                   // Y1 = W1 chol(M1)^-T
     LSTAMP(6);
 
     // ---------------- W2 = A (A^T Y1), T2, T3, U = W2 T2 T3 ----------------
@@ -459,12 +511,10 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     // T2 T3 = chol(W2^T W2)^-T: the product of the two upper triangular factors is itself the (unique) inverse Cholesky factor of
     // P = W2^T W2 - one factorisation instead of chol(Y1^T W2), T2^T P T2, chol of that
     gram64(true);
-    for (int i = tid; i < RP * RP; i += LRS_NT) Gd[i / RP][i % RP] = Sd[i / RP][i % RP];
-    __syncthreads();
-    lr_chol_T<RP, LRS_NT>(Gd, Ld, r, T23, &misc[0], &misc[1], LRS_PIVOT_TOL);
+    if (w == 0) lrs_chol_L<RP>(Sd, r, Lf, dinvf, deadw, LRS_PIVOT_TOL);
     __syncthreads();
     LSTAMP(9);
-    apply_t(T23, true);                                               // U (hi + lo transposed for V, fp16 row-major for the state update)
+    apply_l(true);                                                    // U (hi + lo transposed for V, fp16 row-major for the state update)
     LSTAMP(10);
 
     // ---------------- V = U^T A for the slab's columns, state update of the slab's columns ----------------
