@@ -166,7 +166,12 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     lrs_u4* full = reinterpret_cast<lrs_u4*>(a.arena + 256 + (size_t)z * a.arena_stride + a.offFull);      // [NPK][RP / 4]
     const unsigned launches = __hip_atomic_load(reinterpret_cast<const unsigned*>(a.arena), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned tag0 = launches * 3u + 1u;                         // sum n since the arena was zeroed carries tag (n + 1) mod 4
-    const int c0 = idx * LRS_SW;
+    // the slab of this workgroup: with the round-robin dispatch of workgroups over the 8 XCDs, the workgroups of tensor z sit on the
+    // XCDs = z mod batch; neighbouring slabs go to ONE of them, so that the two 64-byte halves of a 128-byte line of x and base are
+    // asked for by the same L2 (a hint only: nothing depends on where a workgroup really runs)
+    int slab = idx;
+    if (a.zmod && (8 % a.batch) == 0 && nwg % (8 / a.batch) == 0) { const int nx = 8 / a.batch; slab = (idx % nx) * (nwg / nx) + idx / nx; }
+    const int c0 = slab * LRS_SW;
 #define LSTAMP(k) do { if (a.stamps && tid == 0) a.stamps[(size_t)bid * 16 + (k)] = wall_clock64(); } while (0)
     LSTAMP(0);
 
@@ -442,17 +447,28 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     // the packet by workgroup 0
     auto apply_l = [&](bool as_u) {
         const unsigned dead = *deadw;
-        for (int n = tid; n < NPK; n += LRS_NT) {
-            float wv[RP], y[RP];
+        // rows tid and tid + LRS_NT in ONE pass (NPK <= 2 LRS_NT): the factor's rows are read once for both
+        const int n0 = tid, n1 = tid + LRS_NT;
+        const bool h0 = n0 < NPK, h1 = n1 < NPK;
+        float wa[RP], wb[RP], ya[RP], yb[RP];
 #pragma unroll
-            for (int c = 0; c < RP / 4; ++c) *reinterpret_cast<f32x4*>(&wv[4 * c]) = *reinterpret_cast<const f32x4*>(&Wf[n * RP + 4 * c]);
+        for (int c = 0; c < RP / 4; ++c) {
+            *reinterpret_cast<f32x4*>(&wa[4 * c]) = *reinterpret_cast<const f32x4*>(&Wf[(h0 ? n0 : 0) * RP + 4 * c]);
+            *reinterpret_cast<f32x4*>(&wb[4 * c]) = *reinterpret_cast<const f32x4*>(&Wf[(h1 ? n1 : 0) * RP + 4 * c]);
+        }
 #pragma unroll
-            for (int j = 0; j < RP; ++j) {
-                float sacc = wv[j];
+        for (int j = 0; j < RP; ++j) {
+            float lrow[(RP + 3) / 4 * 4];
 #pragma unroll
-                for (int k = 0; k < j; ++k) sacc = fmaf(-y[k], Lf[j * RP + k], sacc);
-                y[j] = ((dead >> j) & 1u) ? 0.f : sacc * dinvf[j];
-            }
+            for (int c = 0; c < (j + 3) / 4; ++c) *reinterpret_cast<f32x4*>(&lrow[4 * c]) = *reinterpret_cast<const f32x4*>(&Lf[j * RP + 4 * c]);
+            const float dj = ((dead >> j) & 1u) ? 0.f : dinvf[j];     // a dropped direction: zero column
+            float sa = wa[j], sb = wb[j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) { sa = fmaf(-ya[k], lrow[k], sa); sb = fmaf(-yb[k], lrow[k], sb); }
+            ya[j] = sa * dj;
+            yb[j] = sb * dj;
+        }
+        auto put = [&](int n, const float (&y)[RP]) {
             h16 hi[RP];
 #pragma unroll
             for (int m = 0; m < RP; ++m) {
@@ -474,7 +490,9 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
 #pragma unroll
                 for (int c = 0; c < RP / 4; ++c) *reinterpret_cast<f32x4*>(&Yf[n * RP + 4 * c]) = *reinterpret_cast<const f32x4*>(&y[4 * c]);
             }
-        }
+        };
+        if (h0) put(n0, ya);
+        if (h1) put(n1, yb);
         __syncthreads();
         if (as_u && idx == 0) {
             h16* U16g = a.u_in_packet ? (h16*)it.packet : (h16*)(it.ws + a.offU16);
