@@ -64,6 +64,16 @@ __device__ __forceinline__ float lrs_val(unsigned q) { return __builtin_bit_cast
 // 16-byte write-through store / L2-bypassing load (sc1).  hipcc does not count asm memory operations: nothing ever waits for the
 // stores (the s_nop keeps the data registers alive until the store has read them), and a batch of loads is followed by lrs_wait
 __device__ __forceinline__ void lrs_st16(void* p, lrs_u4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+typedef unsigned lrs_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lrs_st8(void* p, lrs_u2 v) { asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+// an fp64 value as two tagged words (hi, lo: ~44 bits of mantissa between them)
+__device__ __forceinline__ lrs_u2 lrs_pack64(double d, unsigned seq) {
+    lrs_u2 o;
+    o[0] = lrs_pack((float)d, seq);
+    o[1] = lrs_pack((float)(d - (double)__builtin_bit_cast(float, o[0] & ~3u)), seq);
+    return o;
+}
+__device__ __forceinline__ double lrs_val64(unsigned hi, unsigned lo) { return (double)__builtin_bit_cast(float, hi & ~3u) + (double)__builtin_bit_cast(float, lo & ~3u); }
 #define LRS_LD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
 template <int J> __device__ __forceinline__ void lrs_wait(lrs_u4 (&q)[J]) {
     static_assert(J == 6, "operand list below");
@@ -98,17 +108,17 @@ __device__ __forceinline__ void lrs_chol_L(const double (*G)[RP + 1], int r, flo
         const double piv = bcast(g[j], j);
         const bool ok = (j < r) && (piv > thr);
         const double pv = ok ? piv : 1.0;
-        // 1 / sqrt(piv) by v_rsq_f64 + two Newton steps (full fp64 accuracy): no correctly rounded sqrt and division on the chain
+        // 1 / sqrt(piv) by v_rsq_f64 (~26 bits) + one Newton step (~51 bits; the factor leaves as fp32): no correctly rounded sqrt and
+        // no division on the chain from one pivot to the next
         double inv = __builtin_amdgcn_rsq(pv);
-        inv = inv * (1.5 - 0.5 * pv * inv * inv);
-        inv = inv * (1.5 - 0.5 * pv * inv * inv);
+        inv = inv * __builtin_fma(pv * inv, -0.5 * inv, 1.5);
         double l = ok ? g[j] * inv : (i == j ? 1.0 : 0.0);           // lane j: piv * inv = sqrt(piv)
         l = (i >= j && i < r) ? l : 0.0;
         myinv = (i == j && ok) ? inv : myinv;
         dead |= (ok || j >= r) ? 0u : (1u << j);
         g[j] = l;
 #pragma unroll
-        for (int k = j + 1; k < RP; ++k) g[k] -= l * bcast(l, k);    // every lane, every k > j: rows above the diagonal have l = 0
+        for (int k = j + 1; k < RP; ++k) g[k] = __builtin_fma(-l, bcast(l, k), g[k]);     // every lane, every k > j: rows above the diagonal have l = 0
         __builtin_amdgcn_sched_barrier(0);                           // keep a step's broadcasts (SGPRs) from being hoisted across steps
     }
     if (i < RP) {
@@ -128,7 +138,8 @@ template <int RP> struct LrsLds {
     __host__ __device__ static int wf(int NPK) { return yf(NPK) + NPK * RP * 4; }               // W   [NPK][RP] fp32; dead: 16 KB of reduction scratch
     __host__ __device__ static int wf_bytes(int NPK) { const int a = NPK * RP * 4; return a > 16384 ? a : 16384; }
     __host__ __device__ static int zt(int NPK) { return wf(NPK) + wf_bytes(NPK); }              // Z^T hi | lo, [16][LRS_ZH] fp16 each
-    __host__ __device__ static int ch(int NPK) { return zt(NPK) + 2 * 16 * LRS_ZH * 2; }        // factorisation scratch
+    __host__ __device__ static int zf(int NPK) { return zt(NPK) + 2 * 16 * LRS_ZH * 2; }        // Z [32][16] fp32 (for its Gram matrix)
+    __host__ __device__ static int ch(int NPK) { return zf(NPK) + 32 * 16 * 4; }                // factorisation scratch
     static constexpr int ch_bytes = ((3 * RP * (RP + 1) + RP + 2) * 8 + 3 * RP * RP * 4 + 15) / 16 * 16;
     __host__ __device__ static int total(int NPK) { return ch(NPK) + ch_bytes; }
 };
@@ -154,6 +165,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     h16* U16s = reinterpret_cast<h16*>(Yf);                            // [NPK][RP] fp16 U (the fp32 U itself is not needed)
     h16* Zth = reinterpret_cast<h16*>(sm + L::zt(NPK));
     h16* Ztl = Zth + 16 * LRS_ZH;
+    float* Zf = reinterpret_cast<float*>(sm + L::zf(NPK));
     double (*Gd)[RP + 1] = reinterpret_cast<double (*)[RP + 1]>(sm + L::ch(NPK));
     double (*Ld)[RP + 1] = Gd + RP;
     double (*Sd)[RP + 1] = Ld + RP;
@@ -165,7 +177,8 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     lrs_u4* part = reinterpret_cast<lrs_u4*>(a.arena + 256 + (size_t)z * a.arena_stride);     // [nwg][NPK][RP / 4] cells of 4 tagged words
     lrs_u4* full = reinterpret_cast<lrs_u4*>(a.arena + 256 + (size_t)z * a.arena_stride + a.offFull);      // [NPK][RP / 4]
     const unsigned launches = __hip_atomic_load(reinterpret_cast<const unsigned*>(a.arena), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned tag0 = launches * 3u + 1u;                         // sum n since the arena was zeroed carries tag (n + 1) mod 4
+    const unsigned tag0 = launches * 3u + 1u;
+    const int cells = NPK * RP / 4, gcells = RP * RP / 2, pcells = cells + gcells;      // cells (4 words) of a partial: the N x r values | an r x r fp64 matrix as word pairs                         // sum n since the arena was zeroed carries tag (n + 1) mod 4
     // the slab of this workgroup: with the round-robin dispatch of workgroups over the 8 XCDs, the workgroups of tensor z sit on the
     // XCDs = z mod batch; neighbouring slabs go to ONE of them, so that the two 64-byte halves of a 128-byte line of x and base are
     // asked for by the same L2 (a hint only: nothing depends on where a workgroup really runs)
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     auto product_b = [&](unsigned tag) {
         const h16x8 zh = *reinterpret_cast<const h16x8*>(&Zth[l16 * LRS_ZH + 8 * lq]);
         const h16x8 zl = *reinterpret_cast<const h16x8*>(&Ztl[l16 * LRS_ZH + 8 * lq]);
-        lrs_u4* P = part + (size_t)idx * NPK * (RP / 4);
+        lrs_u4* P = part + (size_t)idx * pcells;
         const unsigned seq = tag & 3u;
 #pragma unroll
         for (int q = 0; q < LRS_TQ; ++q) {
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
 
     // Z = slab^T Y (32 x RP): the waves split K = N, partial tiles summed through LDS in wave order.  final_v: the result is V
     // (fp16, into LDS [rank][column] and into the packet / the workspace); otherwise Z^T as hi + lo for product_b
-    auto product_a = [&](bool final_v) {
+    auto product_a = [&](bool final_v, bool want_gram, unsigned tag) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         const int nk32 = NPK / 32;
 #pragma unroll
@@ -276,6 +289,10 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
                 for (int v = 0; v < 4; ++v) { hi[v] = (h16)s[v]; lo[v] = (h16)(s[v] - (float)hi[v]); }
                 *reinterpret_cast<h16x4*>(&Zth[rr * LRS_ZH + w0]) = hi;
                 *reinterpret_cast<h16x4*>(&Ztl[rr * LRS_ZH + w0]) = lo;
+                if (want_gram) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) Zf[(w0 + v) * 16 + rr] = s[v];
+                }
             } else {
                 h16x4 v16;
 #pragma unroll
@@ -294,20 +311,38 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             }
         }
         __syncthreads();
+        if (want_gram && w == LRS_NW - 1) {
+            // this slab's share of Z^T Z (= Y^T W of the sum that follows: W = A Z, Z = A^T Y), fp64 from the fp32 Z: exact products.
+            // It travels behind the partial, every entry as a (hi, lo) pair of tagged words
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            double zv[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) zv[ks] = (double)Zf[(4 * ks + lq) * 16 + l16];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[ks], zv[ks], acc, 0, 0, 0);
+            unsigned* G2 = reinterpret_cast<unsigned*>(part + (size_t)idx * pcells + cells);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int gi = lq + 4 * v;                            // D[i = lq + 4 v][j = l16]
+                if (gi < RP && l16 < RP) lrs_st8(&G2[2 * (gi * RP + l16)], lrs_pack64(acc[v], tag & 3u));
+            }
+        }
     };
 
     // Sum of the partials over the slabs into dst (LDS, [NPK][RP] fp32): this workgroup's share of the cells over all partials
     // (fixed order), published; then everybody polls the whole result
-    auto allreduce = [&](unsigned tag, float* dst, bool stamp) {
+    auto allreduce = [&](unsigned tag, float* dst, bool with_gram) {
         const unsigned seq = tag & 3u;
-        const int cells = NPK * RP / 4;
-        const int cpw = (cells + nwg - 1) / nwg;
+        const int tcells = with_gram ? pcells : cells;                // with_gram: the r x r fp64 matrix behind the values is summed (in fp64) too -> Gd
+        const int cpw = (tcells + nwg - 1) / nwg;
         const int cw = cpw < LRS_NT ? cpw : LRS_NT, subs = LRS_NT / cw;
         const int ci = tid % cw, sub = tid / cw;
         for (int cb = 0; cb < cpw; cb += cw) {
             const int cl = cb + ci, cell = idx * cpw + cl;
-            const bool act = sub < subs && cl < cpw && cell < cells;
+            const bool act = sub < subs && cl < cpw && cell < tcells;
+            const bool dbl = cell >= cells;                           // a cell of the fp64 matrix: two (hi, lo) pairs
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            double d0 = 0.0, d1 = 0.0;
             if (act) {
                 const lrs_u4* src = part + cell;
                 for (int p0 = sub; p0 < nwg; p0 += subs * LRS_J) {
@@ -315,7 +350,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
                     long long t0 = 0;
                     for (;;) {
 #pragma unroll
-                        for (int j = 0; j < LRS_J; ++j) LRS_LD16(q[j], src + (size_t)min(p0 + subs * j, nwg - 1) * cells);     // unconditional: one round trip
+                        for (int j = 0; j < LRS_J; ++j) LRS_LD16(q[j], src + (size_t)min(p0 + subs * j, nwg - 1) * pcells);     // unconditional: one round trip
                         lrs_wait(q);
                         bool ok = true;
 #pragma unroll
@@ -331,31 +366,47 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
 #pragma unroll
                     for (int j = 0; j < LRS_J; ++j)
                         if (p0 + subs * j < nwg) {
+                            if (dbl) { d0 += lrs_val64(q[j][0], q[j][1]); d1 += lrs_val64(q[j][2], q[j][3]); }
+                            else {
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) s[k] += lrs_val(q[j][k]);
+                                for (int k = 0; k < 4; ++k) s[k] += lrs_val(q[j][k]);
+                            }
                         }
                 }
             }
+            if (dbl) { const double dd[2] = {d0, d1}; s = __builtin_bit_cast(f32x4, dd); }
             if (sub < subs) red4[sub * cw + ci] = s;
             __syncthreads();
             if (sub == 0 && act) {
-                f32x4 t = red4[ci];
-                for (int s2 = 1; s2 < subs; ++s2) t += red4[s2 * cw + ci];
                 lrs_u4 o;
+                if (dbl) {
+                    double t0d = 0.0, t1d = 0.0;
+                    for (int s2 = 0; s2 < subs; ++s2) {
+                        const f32x4 rv = red4[s2 * cw + ci];
+                        double dd[2];
+                        __builtin_memcpy(dd, &rv, 16);
+                        t0d += dd[0]; t1d += dd[1];
+                    }
+                    const lrs_u2 a0 = lrs_pack64(t0d, seq), a1 = lrs_pack64(t1d, seq);
+                    o[0] = a0[0]; o[1] = a0[1]; o[2] = a1[0]; o[3] = a1[1];
+                } else {
+                    f32x4 t = red4[ci];
+                    for (int s2 = 1; s2 < subs; ++s2) t += red4[s2 * cw + ci];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = lrs_pack(t[k], seq);
+                    for (int k = 0; k < 4; ++k) o[k] = lrs_pack(t[k], seq);
+                }
                 lrs_st16(&full[cell], o);
             }
             __syncthreads();
         }
-        if (stamp) LSTAMP(12);
+        if (with_gram) LSTAMP(12);
         f32x4* dst4 = reinterpret_cast<f32x4*>(dst);
-        for (int i0 = tid; i0 < cells; i0 += LRS_NT * LRS_J) {
+        for (int i0 = tid; i0 < tcells; i0 += LRS_NT * LRS_J) {
             lrs_u4 q[LRS_J];
             long long t0 = 0;
             for (;;) {
 #pragma unroll
-                for (int j = 0; j < LRS_J; ++j) LRS_LD16(q[j], full + min(i0 + LRS_NT * j, cells - 1));
+                for (int j = 0; j < LRS_J; ++j) LRS_LD16(q[j], full + min(i0 + LRS_NT * j, tcells - 1));
                 lrs_wait(q);
                 bool ok = true;
 #pragma unroll
@@ -369,13 +420,19 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
                 }
             }
 #pragma unroll
-            for (int j = 0; j < LRS_J; ++j)
-                if (i0 + LRS_NT * j < cells) {
+            for (int j = 0; j < LRS_J; ++j) {
+                const int c = i0 + LRS_NT * j;
+                if (c < cells) {
                     f32x4 v;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = lrs_val(q[j][k]);
-                    dst4[i0 + LRS_NT * j] = v;
+                    dst4[c] = v;
+                } else if (c < tcells) {
+                    const int e = 2 * (c - cells);
+                    Gd[e / RP][e % RP] = lrs_val64(q[j][0], q[j][1]);
+                    Gd[(e + 1) / RP][(e + 1) % RP] = lrs_val64(q[j][2], q[j][3]);
                 }
+            }
         }
         __syncthreads();
     };
@@ -508,12 +565,11 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     LSTAMP(3);
 
     // ---------------- W1 = A (A^T Y0), T1, Y1 = W1 T1 ----------------
-    product_a(false);
+    product_a(false, true, tag0 + 1);                                 // also: this slab's share of M1 = Z1^T Z1 (= Y0^T W1), behind the partial
     product_b(tag0 + 1);
     LSTAMP(4);
-    allreduce(tag0 + 1, Wf, true);
+    allreduce(tag0 + 1, Wf, true);                                    // W1 and M1
     LSTAMP(5);
-    gram64(false);
     LSTAMP(15);
     if (w == 0) lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_TOL);        // chol(M1)
     __syncthreads();
@@ -521,7 +577,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     LSTAMP(6);
 
     // ---------------- W2 = A (A^T Y1), T2, T3, U = W2 T2 T3 ----------------
-    product_a(false);
+    product_a(false, false, 0u);
     product_b(tag0 + 2);
     LSTAMP(7);
     allreduce(tag0 + 2, Wf, false);
@@ -536,7 +592,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     LSTAMP(10);
 
     // ---------------- V = U^T A for the slab's columns, state update of the slab's columns ----------------
-    product_a(true);
+    product_a(true, false, 0u);
     if (a.fuse_decode) {
         // new_base[:, slab] = base + fp16(U V): the arithmetic of k_lr_decode (v_dot2 chain over the k-pairs in order, one rounding
         // to fp16, one fp16 add), from the registers base was loaded into at the start
@@ -600,9 +656,10 @@ size_t cfx_i_lrs_extra_bytes(int, int, int) { return 0; }       // nothing in th
 // bytes of one tensor's part of the arena: the partials of every slab, then the sum (4-byte tagged words)
 static size_t lrs_tensor_bytes(int N, int C, int RP, size_t* off_full) {
     const size_t npk = lrs_npk(N);
-    const size_t part = al256((size_t)(C / LRS_SW) * npk * RP * 4);
+    const size_t pbytes = npk * RP * 4 + (size_t)RP * RP * 8;           // a partial: the N x r values, then an r x r fp64 matrix as word pairs
+    const size_t part = al256((size_t)(C / LRS_SW) * pbytes);
     if (off_full) *off_full = part;
-    return part + al256(npk * RP * 4);
+    return part + al256(pbytes);
 }
 
 // The arena of `stream` laid out for this shape (allocated / zeroed as needed; the zeroing is stream-ordered before the launch).
