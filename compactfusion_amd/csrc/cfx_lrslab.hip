@@ -4,8 +4,7 @@
 // cfx_lrgram.hip (orthonormalisation after every multiplication, the r x r factors by Cholesky of the Gram matrices):
 //     Y0 = A Q0
 //     W1 = A (A^T Y0)      M1 = Y0^T W1      T1 = chol(M1)^-T      Y1 = W1 T1
-//     W2 = A (A^T Y1)      U = W2 chol(W2^T W2)^-T        (= W2 T2 T3 of the N-space chain: T2 T3 is upper triangular and makes
-//                                                           W2 orthonormal, so it IS the inverse Cholesky factor of W2^T W2)
+//     W2 = A (A^T Y1)      U = W2 chol(W2^T W2)^-T        (= W2 T2 T3 of the N-space chain, whose T2 T3 is this inverse factor)
 //     V  = U^T A           new_base = base + fp16(U V)
 // Here A is never written anywhere and A A^T is never formed.  ONE persistent launch; workgroup j of a tensor owns the 32-column
 // slab j of A for the whole chain: the slab is read from x and base exactly once (HBM: x + base in, new_base out - 6 bytes an
@@ -38,7 +37,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef unsigned lrs_u4 __attribute__((ext_vector_type(4)));
 
-#define LRS_PIVOT_TOL 1e-10   // as the N-space chain (cfx_lrgram.hip): pivots below this fraction of the largest are dropped
+#define LRS_PIVOT_TOL 1e-10   // first factorisation, as the N-space chain (cfx_lrgram.hip): pivots below this fraction of the largest are dropped
+#define LRS_PIVOT_REL 1e-9    // last factorisation: pivots below this fraction of their own diagonal entry are dropped
 #define LRS_SW 32             // columns of a slab
 #define LRS_NW 8              // waves of a workgroup (two per SIMD: one hides the other's LDS / MFMA latencies)
 #define LRS_NT (64 * LRS_NW)
@@ -86,7 +86,7 @@ __device__ __forceinline__ bool lrs_tagged(lrs_u4 q, unsigned seq) { return ((q[
 // the mask of directions whose pivot is not above tol x the largest diagonal entry (rank-deficient residual, e.g. x == base): their
 // column of L is the unit vector, the caller zeroes them.  No triangular inverse: the caller solves Y L^T = W row by row.
 template <int RP>
-__device__ __forceinline__ void lrs_chol_L(const double (*G)[RP + 1], int r, float* Lf, float* dinvf, unsigned* deadw, double tol) {
+__device__ __forceinline__ unsigned lrs_chol_rows(const double (*G)[RP + 1], int r, double tol, bool own_diag, double (&g)[RP], double& myinv) {
     const int i = threadIdx.x & 63, ii = i < RP ? i : 0;
     auto bcast = [](double v, int lane) -> double {          // value of lane `lane` (a constant) in every lane
         const int2 q = __builtin_bit_cast(int2, v);
@@ -95,21 +95,24 @@ __device__ __forceinline__ void lrs_chol_L(const double (*G)[RP + 1], int r, flo
         o.y = __builtin_amdgcn_readlane(q.y, lane);
         return __builtin_bit_cast(double, o);
     };
-    double g[RP], gmax = 0.0;
+    double gmax = 0.0;
 #pragma unroll
     for (int k = 0; k < RP; ++k) g[k] = 0.5 * (G[ii][k] + G[k][ii]);
 #pragma unroll
     for (int k = 0; k < RP; ++k) gmax = (k < r) ? fmax(gmax, G[k][k]) : gmax;
     const double thr = gmax * tol;
     unsigned dead = 0;
-    double myinv = 1.0;
+    myinv = 1.0;
 #pragma unroll
     for (int j = 0; j < RP; ++j) {
         const double piv = bcast(g[j], j);
-        const bool ok = (j < r) && (piv > thr);
+        // a direction is dropped when its pivot is not above tol x the largest diagonal entry - or, own_diag, x ITS OWN diagonal entry
+        // (what is left of the column after the earlier ones, relative to the column: the test for graded columns, whose small
+        // diagonal entries are legitimate)
+        const bool ok = (j < r) && (piv > (own_diag ? G[j][j] * tol : thr));
         const double pv = ok ? piv : 1.0;
-        // 1 / sqrt(piv) by v_rsq_f64 (~26 bits) + one Newton step (~51 bits; the factor leaves as fp32): no correctly rounded sqrt and
-        // no division on the chain from one pivot to the next
+        // 1 / sqrt(piv) by v_rsq_f64 (~26 bits) + one Newton step (~51 bits): no correctly rounded sqrt and no division on the chain
+        // from one pivot to the next
         double inv = __builtin_amdgcn_rsq(pv);
         inv = inv * __builtin_fma(pv * inv, -0.5 * inv, 1.5);
         double l = ok ? g[j] * inv : (i == j ? 1.0 : 0.0);           // lane j: piv * inv = sqrt(piv)
@@ -121,6 +124,15 @@ __device__ __forceinline__ void lrs_chol_L(const double (*G)[RP + 1], int r, flo
         for (int k = j + 1; k < RP; ++k) g[k] = __builtin_fma(-l, bcast(l, k), g[k]);     // every lane, every k > j: rows above the diagonal have l = 0
         __builtin_amdgcn_sched_barrier(0);                           // keep a step's broadcasts (SGPRs) from being hoisted across steps
     }
+    return dead;
+}
+
+// chol(G) for the caller's substitution: L (fp32, row-major), 1 / diagonal, dead directions.  One wave.
+template <int RP>
+__device__ __forceinline__ void lrs_chol_L(const double (*G)[RP + 1], int r, float* Lf, float* dinvf, unsigned* deadw, double tol, bool own_diag) {
+    const int i = threadIdx.x & 63;
+    double g[RP], myinv;
+    const unsigned dead = lrs_chol_rows<RP>(G, r, tol, own_diag, g, myinv);
     if (i < RP) {
 #pragma unroll
         for (int k = 0; k < RP; ++k) Lf[i * RP + k] = (float)g[k];
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     auto product_b = [&](unsigned tag) {
         const h16x8 zh = *reinterpret_cast<const h16x8*>(&Zth[l16 * LRS_ZH + 8 * lq]);
         const h16x8 zl = *reinterpret_cast<const h16x8*>(&Ztl[l16 * LRS_ZH + 8 * lq]);
-        lrs_u4* P = part + (size_t)idx * pcells;
+        lrs_u4* P = part + (size_t)slab * pcells;
         const unsigned seq = tag & 3u;
 #pragma unroll
         for (int q = 0; q < LRS_TQ; ++q) {
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             for (int ks = 0; ks < 8; ++ks) zv[ks] = (double)Zf[(4 * ks + lq) * 16 + l16];
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[ks], zv[ks], acc, 0, 0, 0);
-            unsigned* G2 = reinterpret_cast<unsigned*>(part + (size_t)idx * pcells + cells);
+            unsigned* G2 = reinterpret_cast<unsigned*>(part + (size_t)slab * pcells + cells);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int gi = lq + 4 * v;                            // D[i = lq + 4 v][j = l16]
@@ -345,7 +357,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             double d0 = 0.0, d1 = 0.0;
             if (act) {
                 const lrs_u4* src = part + cell;
-                for (int p0 = sub; p0 < nwg; p0 += subs * LRS_J) {
+                for (int p0 = sub; p0 < nwg; p0 += subs * LRS_J) {    // slab order: the result does not depend on the batch
                     lrs_u4 q[LRS_J];
                     long long t0 = 0;
                     for (;;) {
@@ -453,12 +465,13 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     auto gram64 = [&](bool want_p) {
         f64x4 am[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, ap[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
         const int nks = NPK / 4;
-        constexpr int UN = 9;                                         // K steps whose operands are in flight at once
-        for (int i0 = 0; w + LRS_NW * i0 < nks; i0 += UN) {
+        const int nwv = LRS_NW, wk = w;
+        constexpr int UN = 10;                                        // K steps whose operands are in flight at once
+        for (int i0 = 0; wk >= 0 && wk + nwv * i0 < nks; i0 += UN) {
             float av[UN], bv[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int ks = w + LRS_NW * (i0 + u);
+                const int ks = wk + nwv * (i0 + u);
                 const int n = min(ks, nks - 1) * 4 + lq;
                 if (RP == 8) {
                     // one product: rows 0 .. 7 of the A operand are Y's columns, rows 8 .. 15 W's (W lies behind Y in LDS) -> M on top of P
@@ -491,7 +504,8 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
 #pragma unroll
             for (int wv = 0; wv < LRS_NW; ++wv) m += scr64[(wv * 64 + ln) * 4 + v];
             if (RP == 8) {
-                if (j < 8) { if (i < 8) Gd[i][j] = m; else Sd[i - 8][j] = m; }
+                if (j < 8 && !want_p && i < 8) Gd[i][j] = m;
+                if (j < 8 && want_p && i >= 8) Sd[i - 8][j] = m;
             } else if (want_p) Sd[i & (RP - 1)][j & (RP - 1)] = m;
             else Gd[i & (RP - 1)][j & (RP - 1)] = m;
         }
@@ -504,27 +518,6 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     // the packet by workgroup 0
     auto apply_l = [&](bool as_u) {
         const unsigned dead = *deadw;
-        // rows tid and tid + LRS_NT in ONE pass (NPK <= 2 LRS_NT): the factor's rows are read once for both
-        const int n0 = tid, n1 = tid + LRS_NT;
-        const bool h0 = n0 < NPK, h1 = n1 < NPK;
-        float wa[RP], wb[RP], ya[RP], yb[RP];
-#pragma unroll
-        for (int c = 0; c < RP / 4; ++c) {
-            *reinterpret_cast<f32x4*>(&wa[4 * c]) = *reinterpret_cast<const f32x4*>(&Wf[(h0 ? n0 : 0) * RP + 4 * c]);
-            *reinterpret_cast<f32x4*>(&wb[4 * c]) = *reinterpret_cast<const f32x4*>(&Wf[(h1 ? n1 : 0) * RP + 4 * c]);
-        }
-#pragma unroll
-        for (int j = 0; j < RP; ++j) {
-            float lrow[(RP + 3) / 4 * 4];
-#pragma unroll
-            for (int c = 0; c < (j + 3) / 4; ++c) *reinterpret_cast<f32x4*>(&lrow[4 * c]) = *reinterpret_cast<const f32x4*>(&Lf[j * RP + 4 * c]);
-            const float dj = ((dead >> j) & 1u) ? 0.f : dinvf[j];     // a dropped direction: zero column
-            float sa = wa[j], sb = wb[j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) { sa = fmaf(-ya[k], lrow[k], sa); sb = fmaf(-yb[k], lrow[k], sb); }
-            ya[j] = sa * dj;
-            yb[j] = sb * dj;
-        }
         auto put = [&](int n, const float (&y)[RP]) {
             h16 hi[RP];
 #pragma unroll
@@ -548,8 +541,52 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
                 for (int c = 0; c < RP / 4; ++c) *reinterpret_cast<f32x4*>(&Yf[n * RP + 4 * c]) = *reinterpret_cast<const f32x4*>(&y[4 * c]);
             }
         };
-        if (h0) put(n0, ya);
-        if (h1) put(n1, yb);
+        if (RP <= 8) {
+            // rows tid and tid + LRS_NT in ONE pass (NPK <= 2 LRS_NT): the factor's rows are read once for both
+            const int n0 = tid, n1 = tid + LRS_NT;
+            const bool h0 = n0 < NPK, h1 = n1 < NPK;
+            float wa[RP], wb[RP], ya[RP], yb[RP];
+#pragma unroll
+            for (int c = 0; c < RP / 4; ++c) {
+                *reinterpret_cast<f32x4*>(&wa[4 * c]) = *reinterpret_cast<const f32x4*>(&Wf[(h0 ? n0 : 0) * RP + 4 * c]);
+                *reinterpret_cast<f32x4*>(&wb[4 * c]) = *reinterpret_cast<const f32x4*>(&Wf[(h1 ? n1 : 0) * RP + 4 * c]);
+            }
+#pragma unroll
+            for (int j = 0; j < RP; ++j) {
+                float lrow[(RP + 3) / 4 * 4];
+#pragma unroll
+                for (int c = 0; c < (j + 3) / 4; ++c) *reinterpret_cast<f32x4*>(&lrow[4 * c]) = *reinterpret_cast<const f32x4*>(&Lf[j * RP + 4 * c]);
+                const float dj = ((dead >> j) & 1u) ? 0.f : dinvf[j];     // a dropped direction: zero column
+                float sa = wa[j], sb = wb[j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) { sa = fmaf(-ya[k], lrow[k], sa); sb = fmaf(-yb[k], lrow[k], sb); }
+                ya[j] = sa * dj;
+                yb[j] = sb * dj;
+            }
+            if (h0) put(n0, ya);
+            if (h1) put(n1, yb);
+        } else {
+            // rank 16: one row at a time (two rows' values and the factor's 136 entries do not fit the registers of 8 waves); the second
+            // pass - rows >= LRS_NT - only exists in wave 0
+            for (int n = tid; n < NPK; n += LRS_NT) {
+                float wa[RP], ya[RP];
+#pragma unroll
+                for (int c = 0; c < RP / 4; ++c) *reinterpret_cast<f32x4*>(&wa[4 * c]) = *reinterpret_cast<const f32x4*>(&Wf[n * RP + 4 * c]);
+#pragma unroll
+                for (int j = 0; j < RP; ++j) {
+                    float lrow[(RP + 3) / 4 * 4];
+#pragma unroll
+                    for (int c = 0; c < (j + 3) / 4; ++c) *reinterpret_cast<f32x4*>(&lrow[4 * c]) = *reinterpret_cast<const f32x4*>(&Lf[j * RP + 4 * c]);
+                    const float dj = ((dead >> j) & 1u) ? 0.f : dinvf[j];
+                    float sa = wa[j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) sa = fmaf(-ya[k], lrow[k], sa);
+                    ya[j] = sa * dj;
+                    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four rows of the factor in flight at a time
+                }
+                put(n, ya);
+            }
+        }
         __syncthreads();
         if (as_u && idx == 0) {
             h16* U16g = a.u_in_packet ? (h16*)it.packet : (h16*)(it.ws + a.offU16);
@@ -571,21 +608,25 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     allreduce(tag0 + 1, Wf, true);                                    // W1 and M1
     LSTAMP(5);
     LSTAMP(15);
-    if (w == 0) lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_TOL);        // chol(M1)
+    if (w == 0) lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_TOL, false);     // chol(M1)
     __syncthreads();
     apply_l(false);                                                   // Y1 = W1 chol(M1)^-T
     LSTAMP(6);
 
-    // ---------------- W2 = A (A^T Y1), T2, T3, U = W2 T2 T3 ----------------
+    // ---------------- W2 = A (A^T Y1), U = W2 chol(W2^T W2)^-T ----------------
     product_a(false, false, 0u);
     product_b(tag0 + 2);
     LSTAMP(7);
     allreduce(tag0 + 2, Wf, false);
     LSTAMP(8);
-    // T2 T3 = chol(W2^T W2)^-T: the product of the two upper triangular factors is itself the (unique) inverse Cholesky factor of
-    // P = W2^T W2 - one factorisation instead of chol(Y1^T W2), T2^T P T2, chol of that
+    // The N-space chain's T2 T3 (T2 = chol(Y1^T W2)^-T, T3 = chol(T2^T P T2)^-T, P = W2^T W2) is upper triangular and makes W2
+    // orthonormal, so it IS the inverse Cholesky factor of P: one factorisation.  W2's columns are graded (norms ~ sigma^3), P's
+    // pivots span ~ sigma^6 - Cholesky without pivoting does not mind (its error goes with the condition of the matrix scaled to unit
+    // diagonal: orthogonality of U 1e-9 .. 1e-5 for sigma_r / sigma_1 down to 3e-5, checked in fp64), but "small against the largest
+    // diagonal entry" is the wrong test for a dead direction here: a pivot is compared with its OWN diagonal entry (legitimate
+    // directions: > 1e-8 of it; the null directions of a rank-deficient residual: < 1e-10)
     gram64(true);
-    if (w == 0) lrs_chol_L<RP>(Sd, r, Lf, dinvf, deadw, LRS_PIVOT_TOL);
+    if (w == 0) lrs_chol_L<RP>(Sd, r, Lf, dinvf, deadw, LRS_PIVOT_REL, true);
     __syncthreads();
     LSTAMP(9);
     apply_l(true);                                                    // U (hi + lo transposed for V, fp16 row-major for the state update)

@@ -1,0 +1,182 @@
+"""The slab-resident low-rank chain (csrc/cfx_lrslab.hip, one persistent launch, rank <= 16, N <= 576): what the launch
+structure could break - ragged shapes, rank-deficient residuals, sub-batching, reuse of the hand-over arena across shapes,
+run-to-run reproducibility, hipGraph capture - checked against an fp64 replay of the reference's iteration
+(xfuser/compact/compress_lowrank.py:14-61, Householder QR) with the same start matrix, and against the receiver's kernel."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def subspace_iter_fp64(D, Q0, iters=2):
+    """compress_lowrank.py:45-61 in fp64: Q <- qr(A^T (A Q)) twice, U = qr(A Q), V = U^T A."""
+    A = D.double()
+    Q = Q0.double()
+    for _ in range(iters):
+        Q, _ = torch.linalg.qr(A.t() @ (A @ Q))
+    U, _ = torch.linalg.qr(A @ Q)
+    return U, U.t() @ A
+
+
+def make(N, C, rank, seed, decay=0.7, resid_rank=None):
+    """x, base with a residual of decaying spectrum (sigma_k = decay^k) over `resid_rank` directions (default min(N, 48)) plus a
+    little noise, and the start matrix."""
+    from compactfusion_amd import codecs as K
+    g = torch.Generator().manual_seed(seed)
+    k = resid_rank or min(N, 48)
+    L = torch.linalg.qr(torch.randn(N, k, generator=g))[0]
+    R = torch.linalg.qr(torch.randn(C, k, generator=g))[0]
+    s = decay ** torch.arange(k, dtype=torch.float32)
+    D = (L * s) @ R.t() * (N * C) ** 0.5 * 0.05
+    if resid_rank is None:
+        D = D + 1e-3 * torch.randn(N, C, generator=g)
+    base = torch.randn(N, C, generator=g).half()
+    x = (base.float() + D).half()
+    q0 = torch.zeros(C, K.lr_rank_pad(rank))
+    q0[:, :rank] = torch.linalg.qr(torch.randn(C, rank, generator=g))[0]
+    return x.cuda(), base.cuda(), q0.cuda()
+
+
+def run(xs, bases, q0s, N, C, rank, ef=True):
+    from compactfusion_amd import codecs as K
+    B = len(xs)
+    pk = [torch.empty(K.lr_packet_halves(False, N, C, rank), dtype=torch.float16, device="cuda") for _ in range(B)]
+    nb = [torch.empty(N, C, dtype=torch.float16, device="cuda") for _ in range(B)]
+    K.lr_compress_batch(False, xs, bases, nb, pk, q0s, N, C, rank, update_cache=True, ef=ef)
+    torch.cuda.synchronize()
+    return pk, nb
+
+
+def check(x, base, q0, pkt, nb, N, C, rank, tol=3e-3):
+    from compactfusion_amd import codecs as K
+    U, V = pkt[:N * rank].view(N, rank).float(), pkt[N * rank:].view(rank, C).float()
+    D = x - base                                                  # fp16, one rounding: what the kernel factorises
+    Ur, Vr = subspace_iter_fp64(D.float(), q0[:, :rank])
+    assert torch.isfinite(pkt.float()).all()
+    assert rel(U @ V, (Ur @ Vr).float()) < tol
+    assert torch.allclose(U.t() @ U, torch.eye(rank, device="cuda"), atol=5e-3)
+    rec = torch.empty(N, C, dtype=torch.float16, device="cuda")
+    K.lr_decompress_batch(False, [pkt], [base], [rec], N, C, rank)
+    torch.cuda.synchronize()
+    assert torch.equal(nb, rec), "sender state != receiver reconstruction"
+
+
+def slab_chain_taken(N, C, rank):
+    """the chain under test only runs when its workgroups fit the device (C / 32 per tensor, one per CU)"""
+    return 32 <= N <= 576 and C % 128 == 0 and C >= 512 and rank <= 16 and C // 32 <= 250
+
+
+@pytest.mark.parametrize("N,C", [(544, 3072), (512, 1536), (100, 512), (33, 640), (576, 1024), (256, 6144)])
+@pytest.mark.parametrize("rank", [2, 8, 12, 16])
+def test_projection_and_states(N, C, rank):
+    if (N, C, rank) == (576, 1024, 16) or (N, C, rank) == (576, 1024, 12):
+        pytest.skip("LDS: this shape runs the multi-launch chain (covered by test_lowrank.py)")
+    assert slab_chain_taken(N, C, rank)
+    x, base, q0 = make(N, C, rank, seed=N + C + rank)
+    pk, nb = run([x], [base], [q0], N, C, rank)
+    check(x, base, q0, pk[0], nb[0], N, C, rank)
+
+
+def test_rank_deficient_residual_and_zero_residual():
+    N, C, rank = 544, 3072, 8
+    x, base, q0 = make(N, C, rank, seed=5, resid_rank=3, decay=0.5)
+    pk, nb = run([x], [base], [q0], N, C, rank)
+    U, V = pk[0][:N * rank].view(N, rank).float(), pk[0][N * rank:].view(rank, C).float()
+    D = (x - base).float()
+    assert torch.isfinite(pk[0].float()).all()
+    # a rank-3 residual (up to its fp16 rounding): the projection keeps it
+    assert rel(U @ V, D) < 2e-2
+    # x == base: nothing to send, the state stays
+    pk, nb = run([base.clone()], [base], [q0], N, C, rank)
+    assert torch.isfinite(pk[0].float()).all()
+    assert float(pk[0].float().abs().max()) == 0.0
+    assert torch.equal(nb[0], base)
+
+
+def test_batches_bigger_than_one_launch_and_reproducible():
+    """C = 3072: 96 workgroups per tensor, two tensors per launch - a batch of 5 is three launches on the same arena"""
+    N, C, rank = 544, 3072, 8
+    data = [make(N, C, rank, seed=100 + i) for i in range(5)]
+    xs, bs, qs = [d[0] for d in data], [d[1] for d in data], [d[2] for d in data]
+    pk, nb = run(xs, bs, qs, N, C, rank)
+    for i in range(5):
+        check(xs[i], bs[i], qs[i], pk[i], nb[i], N, C, rank)
+    pk2, nb2 = run(xs, bs, qs, N, C, rank)
+    for i in range(5):
+        assert torch.equal(pk[i], pk2[i]) and torch.equal(nb[i], nb2[i]), "not reproducible run to run"
+    # one at a time: the same bits as in the batch (the sums have a fixed order that does not depend on the launch's batch)
+    for i in (0, 4):
+        p1, n1 = run([xs[i]], [bs[i]], [qs[i]], N, C, rank)
+        assert torch.equal(p1[0], pk[i]) and torch.equal(n1[0], nb[i])
+
+
+def test_arena_survives_changing_shapes():
+    """the hand-over arena is re-laid-out (and zeroed) when the shape changes; stale tagged words of another layout must never
+    be taken for this launch's"""
+    a = (544, 3072, 8)
+    b = (512, 1536, 16)
+    da, db = make(*a, seed=1), make(*b, seed=2)
+    ref_a = run([da[0]], [da[1]], [da[2]], *a)
+    ref_b = run([db[0]], [db[1]], [db[2]], *b)
+    for _ in range(3):
+        ra = run([da[0]], [da[1]], [da[2]], *a)
+        rb = run([db[0]], [db[1]], [db[2]], *b)
+        assert torch.equal(ra[0][0], ref_a[0][0]) and torch.equal(ra[1][0], ref_a[1][0])
+        assert torch.equal(rb[0][0], ref_b[0][0]) and torch.equal(rb[1][0], ref_b[1][0])
+    # many launches on one layout: the 2-bit sequence tags wrap around every four sums
+    for _ in range(9):
+        ra = run([da[0]], [da[1]], [da[2]], *a)
+    assert torch.equal(ra[0][0], ref_a[0][0]) and torch.equal(ra[1][0], ref_a[1][0])
+
+
+def test_no_error_feedback_and_no_base():
+    from compactfusion_amd import codecs as K
+    N, C, rank = 512, 1536, 8
+    x, base, q0 = make(N, C, rank, seed=9)
+    pk, nb = run([x], [base], [q0], N, C, rank, ef=False)
+    assert torch.equal(nb[0], x), "error feedback off: the state is the activation itself"
+    pk2, _ = run([x], [base], [q0], N, C, rank, ef=True)
+    assert torch.equal(pk[0], pk2[0])
+    # no base (first step): the residual is x
+    pkt = torch.empty(K.lr_packet_halves(False, N, C, rank), dtype=torch.float16, device="cuda")
+    nbn = torch.empty(N, C, dtype=torch.float16, device="cuda")
+    K.lr_compress_batch(False, [x], [None], [nbn], [pkt], [q0], N, C, rank, update_cache=True, ef=True)
+    torch.cuda.synchronize()
+    U, V = pkt[:N * rank].view(N, rank).float(), pkt[N * rank:].view(rank, C).float()
+    Ur, Vr = subspace_iter_fp64(x.float(), q0[:, :rank])
+    assert rel(U @ V, (Ur @ Vr).float()) < 3e-3
+    rec = torch.empty(N, C, dtype=torch.float16, device="cuda")
+    K.lr_decompress_batch(False, [pkt], [None], [rec], N, C, rank)
+    torch.cuda.synchronize()
+    assert torch.equal(nbn, rec)
+
+
+def test_capturable_in_a_hip_graph():
+    """nothing in the launch depends on a host-side counter: captured once, replayed, it keeps producing the eager result"""
+    from compactfusion_amd import codecs as K
+    N, C, rank = 544, 3072, 8
+    data = [make(N, C, rank, seed=40 + i) for i in range(2)]
+    xs, bs, qs = [d[0] for d in data], [d[1] for d in data], [d[2] for d in data]
+    s = torch.cuda.Stream()
+    pk = [torch.empty(K.lr_packet_halves(False, N, C, rank), dtype=torch.float16, device="cuda") for _ in range(2)]
+    nb = [torch.empty(N, C, dtype=torch.float16, device="cuda") for _ in range(2)]
+    with torch.cuda.stream(s):
+        K.lr_compress_batch(False, xs, bs, nb, pk, qs, N, C, rank, update_cache=True, ef=True)     # warm-up: arena, attributes
+        s.synchronize()
+        want_p, want_n = [p.clone() for p in pk], [n.clone() for n in nb]
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            K.lr_compress_batch(False, xs, bs, nb, pk, qs, N, C, rank, update_cache=True, ef=True)
+    for _ in range(5):
+        for t in pk + nb:
+            t.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for i in range(2):
+            assert torch.equal(pk[i], want_p[i]) and torch.equal(nb[i], want_n[i])
