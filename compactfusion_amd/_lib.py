@@ -76,6 +76,11 @@ SYMBOLS = [
                                                    ctypes.c_int, ctypes.POINTER(DecompItem), ctypes.c_void_p, ctypes.c_size_t]),
     ("cfx_plan_add_decompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.POINTER(DecompItem)]),
+    ("cfx_plan_add_lr_compress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.POINTER(CompItem), ctypes.POINTER(ctypes.c_void_p),
+                                                ctypes.c_void_p, ctypes.c_size_t]),
+    ("cfx_plan_add_lr_decompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.POINTER(DecompItem), ctypes.c_void_p, ctypes.c_size_t]),
     ("cfx_plan_set_exchange_stream", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_plan_use_exchange_stream", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     ("cfx_plan_add_all_gather", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),

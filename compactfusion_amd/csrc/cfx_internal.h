@@ -22,7 +22,7 @@ static const char* const kid_names[KID_MAX] = {
     "", "k_absmean_stats<bits>", "k_absmean_stats", "k_absmean_finalize", "k_binary_dequant", "k_int2_quant", "k_int2_dequant",
     "k_minmax_stats", "k_minmax_finalize", "k_int8_quant", "k_int8_dequant", "k_int4_quant", "k_int4_dequant",
     "k_topk_compress", "k_topk_decompress", "k_copy_probe", "k_binary_dequant(ef)",
-    "k_lr_prep | k_lrp (single-launch chain)", "k_lr_aq", "k_lr_aty", "k_lr_chol", "k_lr_apply", "k_lr_decode",
+    "k_lr_prep | k_lrs (slab-resident chain, one launch)", "k_lr_aq", "k_lr_aty", "k_lr_chol", "k_lr_apply", "k_lr_decode",
     "k_binary_pipe", "k_binary_pipe(prologue/epilogue)", "k_residual2_delta", "k_residual2_update",
     "k_absmean_compress<bits>", "k_absmean_compress", "k_minmax_compress", "k_attn_merge",
     "gated layer launch (k_absmean_compress<bits,gated> / k_int2_compress_gated)"};
@@ -144,7 +144,8 @@ struct cfx_comm {
 
 struct PlanOp {
     int kind;   // 0 compress, 1 decompress, 2 all-gather on the side stream, 3 main stream waits for gather op `ref`, 4 ring hop,
-                // 5 wait until flag `ref` has reached the plan's epoch, 6 set flag `ref` to the epoch
+                // 5 wait until flag `ref` has reached the plan's epoch, 6 set flag `ref` to the epoch,
+                // 7 low-rank compress (codec = quantized, param = rank), 8 low-rank decompress
     int codec, N, C, param, flags, batch;
     cfx_comp_item c[CFX_MAX_BATCH];
     cfx_decomp_item d[CFX_MAX_BATCH];     // kind 1: the items; kind 0: ride-along reconstruction items (n_ride of them)
@@ -153,6 +154,7 @@ struct PlanOp {
     int n_gated;
     void* ws;
     size_t ws_bytes;
+    const void* q0[CFX_MAX_BATCH];        // kind 7: the start matrices
     // kind 2 / 3
     cfx_comm* comm;
     const void* send;

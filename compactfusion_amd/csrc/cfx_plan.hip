@@ -185,6 +185,35 @@ int cfx_plan_add_decompress(cfx_plan* p, int codec, int N, int C, int param, int
     return p->n - 1;
 }
 
+int cfx_plan_add_lr_compress(cfx_plan* p, int quantized, int N, int C, int rank, int flags, int batch, const cfx_comp_item* items,
+                             const void* const* init_q, void* workspace, size_t workspace_bytes) {
+    if (!p || !items || !init_q) return CFX_ERR_NULL;
+    if (batch < 1 || batch > CFX_MAX_BATCH) return fail(p->ctx, CFX_ERR_BATCH, "plan: batch out of range");
+    if (!cfx_lr_packet_bytes(quantized, N, C, rank)) return fail(p->ctx, CFX_ERR_SHAPE, "plan: bad low-rank shape");
+    PlanOp* o = plan_push(p);
+    memset(o, 0, sizeof(*o));
+    o->kind = 7; o->codec = quantized; o->N = N; o->C = C; o->param = rank; o->flags = flags; o->batch = batch;
+    o->pre_flag = -1;
+    memcpy(o->c, items, sizeof(cfx_comp_item) * batch);
+    for (int i = 0; i < batch; ++i) o->q0[i] = init_q[i];
+    o->ws = workspace; o->ws_bytes = workspace_bytes;
+    return p->n - 1;
+}
+
+int cfx_plan_add_lr_decompress(cfx_plan* p, int quantized, int N, int C, int rank, int batch, const cfx_decomp_item* items,
+                               void* workspace, size_t workspace_bytes) {
+    if (!p || !items) return CFX_ERR_NULL;
+    if (batch < 1 || batch > CFX_MAX_BATCH) return fail(p->ctx, CFX_ERR_BATCH, "plan: batch out of range");
+    if (!cfx_lr_packet_bytes(quantized, N, C, rank)) return fail(p->ctx, CFX_ERR_SHAPE, "plan: bad low-rank shape");
+    PlanOp* o = plan_push(p);
+    memset(o, 0, sizeof(*o));
+    o->kind = 8; o->codec = quantized; o->N = N; o->C = C; o->param = rank; o->batch = batch;
+    o->pre_flag = -1;
+    memcpy(o->d, items, sizeof(cfx_decomp_item) * batch);
+    o->ws = workspace; o->ws_bytes = workspace_bytes;
+    return p->n - 1;
+}
+
 int cfx_plan_size(const cfx_plan* p) { return p ? p->n : CFX_ERR_NULL; }
 
 // append a copy of a compress / decompress op of another plan (to build differently ordered schedules from one op set)
@@ -243,7 +272,7 @@ int cfx_plan_add_ring_hop(cfx_plan* p, cfx_comm* comm, const void* send, void* r
 
 int cfx_plan_set_input(cfx_plan* p, int op, int item, const void* x) {
     if (!p || !x) return CFX_ERR_NULL;
-    if (op < 0 || op >= p->n || p->ops[op].kind != 0 || item < 0 || item >= p->ops[op].batch)
+    if (op < 0 || op >= p->n || (p->ops[op].kind != 0 && p->ops[op].kind != 7) || item < 0 || item >= p->ops[op].batch)
         return fail(p->ctx, CFX_ERR_BATCH, "plan: set_input needs a compress op and an item of its batch");
     if (!AL16(x)) return fail(p->ctx, CFX_ERR_ALIGN, "plan: pointers must be 16-byte aligned");
     p->ops[op].c[item].x = x;
@@ -336,6 +365,8 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                 hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, main_s, p->flags + (size_t)o->ref * FLAG_WORDS, p->epoch);
                 rc = check_launch(p->ctx, "flag set launch");
                 break;
+            case 7: rc = cfx_lr_compress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, o->q0, o->ws, o->ws_bytes, stream); break;
+            case 8: rc = cfx_lr_decompress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->batch, o->d, o->ws, o->ws_bytes, stream); break;
         }
         if (rc != CFX_OK) return rc;
     }

@@ -225,6 +225,13 @@ int       cfx_plan_add_compress_gated(cfx_plan* plan, int codec, int N, int C, i
                                       void* workspace, size_t workspace_bytes);   /* cfx_compress_batch_gated as a plan op */
 int       cfx_plan_add_decompress(cfx_plan* plan, int codec, int N, int C, int param, int batch,
                                   const cfx_decomp_item* items);
+/* cfx_lr_compress_batch / cfx_lr_decompress_batch as plan ops (a LOW_RANK / LOW_RANK_Q layer replayed without per-op marshalling:
+ * slowpath.py:54-75, :120-131, :151-164 once per layer of patchpara/fwd.py:108-131).  Pointers (items, init_q, workspace) must stay
+ * valid while the plan is replayed. */
+int       cfx_plan_add_lr_compress(cfx_plan* plan, int quantized, int N, int C, int rank, int flags, int batch,
+                                   const cfx_comp_item* items, const void* const* init_q, void* workspace, size_t workspace_bytes);
+int       cfx_plan_add_lr_decompress(cfx_plan* plan, int quantized, int N, int C, int rank, int batch,
+                                     const cfx_decomp_item* items, void* workspace, size_t workspace_bytes);
 /* Exchange ops.  An all-gather op is ordered after everything the plan enqueued on the main stream before it (the
  * packets are complete); with a side stream (modes 1, 2) a wait op makes the main stream wait for that gather, so
  * "compress(l+1), gather(l+1), wait(l), reconstruct(l)" overlaps the wire with the codec; in mode 0 waits are no-ops. */

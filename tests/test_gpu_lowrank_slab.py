@@ -180,3 +180,42 @@ def test_capturable_in_a_hip_graph():
         torch.cuda.synchronize()
         for i in range(2):
             assert torch.equal(pk[i], want_p[i]) and torch.equal(nb[i], want_n[i])
+
+
+def test_plan_ops_equal_direct_calls():
+    """cfx_plan_add_lr_compress / cfx_plan_add_lr_decompress: a LOW_RANK layer replayed from a native plan gives the bits of the
+    direct calls (sender state, packets, receiver states)"""
+    import ctypes
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    ctx = K.context(0)
+    N, C, rank, B, R = 512, 1536, 8, 2, 6
+    data = [make(N, C, rank, seed=70 + i) for i in range(B)]
+    xs, bs, qs = [d[0] for d in data], [d[1] for d in data], [d[2] for d in data]
+    peers = [torch.randn(N, C, device="cuda").half() for _ in range(R)]
+    # direct
+    pk, nb = run(xs, bs, qs, N, C, rank)
+    rec = [torch.empty(N, C, dtype=torch.float16, device="cuda") for _ in range(R)]
+    K.lr_decompress_batch(False, [pk[j % B] for j in range(R)], peers, rec, N, C, rank)
+    torch.cuda.synchronize()
+    # plan
+    pk2 = [torch.zeros_like(p) for p in pk]
+    nb2 = [torch.zeros_like(n) for n in nb]
+    rec2 = [torch.zeros_like(r_) for r_ in rec]
+    wsb = lib.cfx_lr_workspace_bytes(0, N, C, rank, 16)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+    plan = lib.cfx_plan_create(ctx)
+    c = (_lib.CompItem * B)(*[_lib.CompItem(xs[i].data_ptr(), bs[i].data_ptr(), nb2[i].data_ptr(), pk2[i].data_ptr()) for i in range(B)])
+    qp = (ctypes.c_void_p * B)(*[q.data_ptr() for q in qs])
+    assert lib.cfx_plan_add_lr_compress(plan, 0, N, C, rank, _lib.FLAG_UPDATE_CACHE, B, c, qp, ws.data_ptr(), wsb) == 0
+    d = (_lib.DecompItem * R)(*[_lib.DecompItem(pk2[j % B].data_ptr(), peers[j].data_ptr(), rec2[j].data_ptr()) for j in range(R)])
+    assert lib.cfx_plan_add_lr_decompress(plan, 0, N, C, rank, R, d, ws.data_ptr(), wsb) == 1
+    assert lib.cfx_plan_add_lr_compress(plan, 0, N, C, 7, 0, B, c, qp, ws.data_ptr(), wsb) < 0, "odd rank must be refused"
+    for _ in range(2):
+        assert lib.cfx_plan_run(plan, 0, 2, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    lib.cfx_plan_destroy(plan)
+    for i in range(B):
+        assert torch.equal(pk[i], pk2[i]) and torch.equal(nb[i], nb2[i])
+    for j in range(R):
+        assert torch.equal(rec[j], rec2[j])

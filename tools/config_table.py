@@ -14,6 +14,7 @@ sample; n/a for the low-rank codec, which has no C restatement).
 import json
 import os
 import sys
+import ctypes
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -73,23 +74,36 @@ def gpu_step(cid, param, N, C, L, ncomp, nrec, update):
             if n < L:
                 assert lib.cfx_plan_run(plans[i & 1], 0, (L - n) * ops_per_layer, sh) == 0
     else:
+        # the low-rank layer as plan ops too (cfx_plan_add_lr_compress / _decompress): replayed natively like the other rows
         q = False
         pkh = K.lr_packet_halves(q, N, C, param)
         pk = torch.zeros(Lb, ncomp, (pkh + 127) // 128 * 128, dtype=torch.float16, device=dev)
         rp = K.lr_rank_pad(param)
         q0 = [torch.randn(C, rp, generator=g, device=dev) for _ in range(ncomp)]
-
-        def step(i):
-            for k in range(L):
-                l = (i * L + k) % Lb
-                xs = [x[i & 1][l, j] for j in range(ncomp)]
-                bs = [own[l, j] for j in range(ncomp)]
-                pks = [pk[l, j, :pkh] for j in range(ncomp)]
-                K.lr_compress_batch(q, xs, bs, bs if update else [None] * ncomp, pks, q0, N, C, param, update_cache=update)
+        wsb = lib.cfx_lr_workspace_bytes(int(q), N, C, param, max(ncomp, 16))
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+        qp = (ctypes.c_void_p * ncomp)(*[t.data_ptr() for t in q0])
+        plans = []
+        for s in range(2):
+            plan = lib.cfx_plan_create(ctx)
+            for l in range(Lb):
+                c = (_lib.CompItem * ncomp)(*[_lib.CompItem(x[s][l, i].data_ptr(), own[l, i].data_ptr(), own[l, i].data_ptr() if update else None,
+                                                            pk[l, i].data_ptr()) for i in range(ncomp)])
+                assert lib.cfx_plan_add_lr_compress(plan, int(q), N, C, param, 1 if update else 0, ncomp, c, qp, ws.data_ptr(), wsb) >= 0
                 for a in range(0, nrec, 16):
                     n = min(16, nrec - a)
-                    K.lr_decompress_batch(q, [pks[(a + j) % ncomp] for j in range(n)], [peers[l, a + j] for j in range(n)],
-                                          [peers[l, a + j] for j in range(n)], N, C, param)
+                    d = (_lib.DecompItem * n)(*[_lib.DecompItem(pk[l, (a + j) % ncomp].data_ptr(), peers[l, a + j].data_ptr(), peers[l, a + j].data_ptr())
+                                                for j in range(n)])
+                    assert lib.cfx_plan_add_lr_decompress(plan, int(q), N, C, param, n, d, ws.data_ptr(), wsb) >= 0
+            plans.append(plan)
+        ops_per_layer = 1 + (nrec + 15) // 16
+
+        def step(i):
+            first = (i * L) % Lb
+            n = min(L, Lb - first)
+            assert lib.cfx_plan_run(plans[i & 1], first * ops_per_layer, n * ops_per_layer, sh) == 0
+            if n < L:
+                assert lib.cfx_plan_run(plans[i & 1], 0, (L - n) * ops_per_layer, sh) == 0
     for i in range(3):
         step(i)
     torch.cuda.synchronize()
