@@ -243,7 +243,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const LrItem it = b.it[blockIdx.x];
     const double* Gp = (const double*)(it.ws + offG);
     float* T = (float*)(it.ws + offT);
-    __shared__ double G[RP][RP + 1], L[RP][RP + 1];
+    __shared__ double G[RP][RP + 1];
     const int tid = threadIdx.x;
     {
         // 512 threads reduce the partial Grams: element e, part group g, 8 independent loads in flight each
@@ -288,13 +288,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     __syncthreads();
-    __shared__ double gmax_s;
-    __shared__ double dinv_s[RP];                           // 1 / L[j][j]
-    lr_chol_T<RP, 512>(G, L, r, T, &gmax_s, dinv_s);
+    // The factor only (one wave, branch-free: cfx_lr.h), no triangular inverse: k_lr_apply2 solves Out L^T = In row by row.  What it
+    // reads from T: L row-major with 1 / L[j][j] ON the diagonal (0 for a dropped direction: its column of the result is zero).
+    // (The routine with the explicit inverse took 25 of this kernel's 36 us at r = 32.)
+    if (tid < 64) {
+        double g[RP], myinv;
+        const unsigned dead = lr_chol_rows<RP>(G, r, 1e-13, false, g, myinv);
+        if (tid < RP) {
+#pragma unroll
+            for (int k = 0; k < RP; ++k) T[tid * RP + k] = (k == tid) ? (((dead >> tid) & 1u) ? 0.f : (float)myinv) : (float)g[k];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Out = In (rows x RP fp32) . T (RP x RP)   one thread per row.
+// Out = In (rows x RP fp32) . chol(G)^-T   one thread per row (the factor from k_lr_chol).
 //   mode 0: fp32 rows x RP (the next Q) ; mode 1: fp16 rows x r, row-major (U, or V^T for LOW_RANK_Q) ;
 //   mode 2: fp16 r x rows, i.e. transposed (V in the LOW_RANK wire layout)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -316,12 +324,17 @@ __device__ __forceinline__ void lr_apply_body(const LrItem& it, int bx, int rows
         for (int p = 1; p < in_slabs; ++p) v += In[(size_t)p * slab + (size_t)row * RP + k];     // fixed order
         in[k] = v;
     }
+    // Out = In L^-T by forward substitution (ts: L with 1 / diagonal on the diagonal, k_lr_chol); a row of L is read as 16-byte broadcasts
 #pragma unroll
     for (int j = 0; j < RP; ++j) {
-        float s = 0.f;
+        float lrow[RP];
 #pragma unroll
-        for (int k = 0; k < RP; ++k) s = fmaf(in[k], ts[k * RP + j], s);
-        out[j] = s;
+        for (int c = 0; c < (j + 4) / 4; ++c) *reinterpret_cast<float4*>(&lrow[4 * c]) = *reinterpret_cast<const float4*>(&ts[j * RP + 4 * c]);
+        float s = in[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s = fmaf(-out[k], lrow[k], s);
+        out[j] = s * lrow[j];
+        if (RP > 16 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four rows of the factor in flight at a time (registers)
     }
     if (mode == 0) {
         float* O = (float*)(it.ws + offOut);
@@ -341,7 +354,7 @@ __device__ __forceinline__ void lr_apply_body(const LrItem& it, int bx, int rows
 // two products by the same factor in one launch (U = Y T and V = Z' T at the end of the chain): blocks [0, nb0) do `a`, the rest `c`
 template <int RP>
 __global__ __launch_bounds__(256) void k_lr_apply2(LrBatch b, LrApply a, LrApply c, int nb0) {
-    __shared__ float ts[RP * RP];
+    __shared__ __attribute__((aligned(16))) float ts[RP * RP];
     const bool first = (int)blockIdx.x < nb0;
     const LrApply& p = first ? a : c;
     lr_apply_body<RP>(b.it[blockIdx.y], first ? blockIdx.x : blockIdx.x - nb0, p.rows, p.r, p.offIn, p.in_slabs, p.offT, p.mode, p.offOut,

@@ -140,4 +140,50 @@ __device__ __forceinline__ void lr_chol_T(double (*G)[RP + 1], double (*L)[RP + 
     }
     }
 }
+// Cholesky factor of the symmetrised G (RP x RP fp64 in LDS) in the registers of ONE wave: lane i holds row i, the pivot and the
+// column entries the other lanes need travel by v_readlane.  Out (LDS, fp32): L row-major (zero above the diagonal), 1 / L[j][j], and
+// the mask of directions whose pivot is not above tol x the largest diagonal entry (rank-deficient residual, e.g. x == base): their
+// column of L is the unit vector, the caller zeroes them.  No triangular inverse: the caller solves Y L^T = W row by row.
+template <int RP>
+__device__ __forceinline__ unsigned lr_chol_rows(const double (*G)[RP + 1], int r, double tol, bool own_diag, double (&g)[RP], double& myinv) {
+    const int i = threadIdx.x & 63, ii = i < RP ? i : 0;
+    auto bcast = [](double v, int lane) -> double {          // value of lane `lane` (a constant) in every lane
+        const int2 q = __builtin_bit_cast(int2, v);
+        int2 o;
+        o.x = __builtin_amdgcn_readlane(q.x, lane);
+        o.y = __builtin_amdgcn_readlane(q.y, lane);
+        return __builtin_bit_cast(double, o);
+    };
+    double gmax = 0.0;
+#pragma unroll
+    for (int k = 0; k < RP; ++k) g[k] = 0.5 * (G[ii][k] + G[k][ii]);
+#pragma unroll
+    for (int k = 0; k < RP; ++k) gmax = (k < r) ? fmax(gmax, G[k][k]) : gmax;
+    const double thr = gmax * tol;
+    unsigned dead = 0;
+    myinv = 1.0;
+#pragma unroll
+    for (int j = 0; j < RP; ++j) {
+        const double piv = bcast(g[j], j);
+        // a direction is dropped when its pivot is not above tol x the largest diagonal entry - or, own_diag, x ITS OWN diagonal entry
+        // (what is left of the column after the earlier ones, relative to the column: the test for graded columns, whose small
+        // diagonal entries are legitimate)
+        const bool ok = (j < r) && (piv > (own_diag ? G[j][j] * tol : thr));
+        const double pv = ok ? piv : 1.0;
+        // 1 / sqrt(piv) by v_rsq_f64 (~26 bits) + one Newton step (~51 bits): no correctly rounded sqrt and no division on the chain
+        // from one pivot to the next
+        double inv = __builtin_amdgcn_rsq(pv);
+        inv = inv * __builtin_fma(pv * inv, -0.5 * inv, 1.5);
+        double l = ok ? g[j] * inv : (i == j ? 1.0 : 0.0);           // lane j: piv * inv = sqrt(piv)
+        l = (i >= j && i < r) ? l : 0.0;
+        myinv = (i == j && ok) ? inv : myinv;
+        dead |= (ok || j >= r) ? 0u : (1u << j);
+        g[j] = l;
+#pragma unroll
+        for (int k = j + 1; k < RP; ++k) g[k] = __builtin_fma(-l, bcast(l, k), g[k]);     // every lane, every k > j: rows above the diagonal have l = 0
+        __builtin_amdgcn_sched_barrier(0);                           // keep a step's broadcasts (SGPRs) from being hoisted across steps
+    }
+    return dead;
+}
+
 #endif
