@@ -666,7 +666,11 @@ static char* lrs_arena(cfx_ctx* ctx, void* stream, int N, int C, int RP, int nb,
     for (int i = 0; i < ctx->lrs_n; ++i)
         if (ctx->lrs_stream[i] == stream) { slot = i; break; }
     if (slot < 0) {
-        slot = ctx->lrs_n < 8 ? ctx->lrs_n++ : (int)(ctx->lrs_next++ % 8);      // every slot taken: the oldest changes hands
+        if (ctx->lrs_n < 8) slot = ctx->lrs_n++;
+        else {
+            slot = (int)(ctx->lrs_next++ % 8);                         // every slot taken: the oldest changes hands - once whatever its
+            (void)hipDeviceSynchronize();                              // previous owner had in flight on it has finished
+        }
         ctx->lrs_stream[slot] = stream;
         ctx->lrs_key[slot] = ~0ull;
     }

@@ -170,7 +170,11 @@ int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base
  * quantized = 0: LOW_RANK   wire [ U (N,r) fp16 | V (r,C) fp16 ]
  * quantized = 1: LOW_RANK_Q wire [ int4(U) (N/2,r) | scale r | min r | int4(V^T) (C/2,r) | scale r | min r ]   (rank % 8 == 0)
  * rank even, <= 32.  init_q[i] -> device C x RP fp32 row-major start matrix, RP = 8/16/32 = rank rounded up, columns >= rank
- * zero; it need not be orthonormal (the iteration only sees its span).  Workspace from cfx_lr_workspace_bytes. */
+ * zero; it need not be orthonormal (the iteration only sees its span).  Workspace from cfx_lr_workspace_bytes.
+ * rank <= 16 on a shard of at most 576 tokens: ONE persistent launch (csrc/cfx_lrslab.hip) whose workgroups wait for each other - taken
+ * only where C / 32 workgroups per tensor fit the CUs of `stream` (otherwise a multi-launch chain runs; same results within the codec's
+ * tolerance).  It hands its partial sums over through an arena the context owns (allocated on the first call of a stream, zeroed when
+ * the shape changes): make one call before capturing the stream into a hipGraph; the launch itself is capturable. */
 size_t cfx_lr_packet_bytes(int quantized, int N, int C, int rank);
 size_t cfx_lr_workspace_bytes(int quantized, int N, int C, int rank, int batch);
 int    cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, int flags, int batch,

@@ -219,3 +219,24 @@ def test_plan_ops_equal_direct_calls():
         assert torch.equal(pk[i], pk2[i]) and torch.equal(nb[i], nb2[i])
     for j in range(R):
         assert torch.equal(rec[j], rec2[j])
+
+
+def test_cu_masked_lane_runs_the_multi_launch_chain():
+    """a 32-CU exchange lane cannot hold C / 32 co-resident workgroups: the call must take the six-launch chain there (no wait
+    that never ends) and give the same projection"""
+    from compactfusion_amd import codecs as K, lanes
+    N, C, rank = 544, 3072, 8
+    x, base, q0 = make(N, C, rank, seed=21)
+    want_p, want_n = run([x], [base], [q0], N, C, rank)
+    s = lanes.exchange_stream(0)
+    pkt = torch.empty(K.lr_packet_halves(False, N, C, rank), dtype=torch.float16, device="cuda")
+    nb = torch.empty(N, C, dtype=torch.float16, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        K.lr_compress_batch(False, [x], [base], [nb], [pkt], [q0], N, C, rank, update_cache=True, ef=True, stream=s)
+    s.synchronize()
+    assert K.gate_errors(0) == 0 if hasattr(K, "gate_errors") else True
+    check(x, base, q0, pkt, nb, N, C, rank)
+    U0, V0 = want_p[0][:N * rank].view(N, rank).float(), want_p[0][N * rank:].view(rank, C).float()
+    U1, V1 = pkt[:N * rank].view(N, rank).float(), pkt[N * rank:].view(rank, C).float()
+    assert rel(U1 @ V1, U0 @ V0) < 3e-3
