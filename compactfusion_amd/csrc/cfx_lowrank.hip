@@ -647,7 +647,9 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
     static const char* chain_env = getenv("CFX_LR_CHAIN");
     // (rank > 16: the two factorisations the chain's last launch runs back to back in one wave spill at RP = 32 - measured slower than the
     // C-space chain's separate launches)
-    const bool gram = cfx_i_lrg_ok(N, C) && RPv <= 16 && !(chain_env && !strcmp(chain_env, "cspace"));
+    // rank 32: only the slab-resident form of the N-space chain takes it (where its workgroups fit the stream's CUs)
+    const bool slab32 = RPv == 32 && !(chain_env && !strcmp(chain_env, "gram5")) && cfx_i_lrs_fit(ctx, N, C, RPv, (void*)s) >= 1;
+    const bool gram = cfx_i_lrg_ok(N, C) && (RPv <= 16 || slab32) && !(chain_env && !strcmp(chain_env, "cspace"));
     int decoded = 0;                     // the single-launch chain also does the error-feedback update of LOW_RANK
     if (gram) {
         const int rg = cfx_i_lrg_factors(ctx, quantized, N, C, rank, batch, b, w.D, w.U16, w.V16, w.gram, absd,

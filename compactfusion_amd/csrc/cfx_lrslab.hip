@@ -90,61 +90,58 @@ __device__ __forceinline__ void lrs_chol_L(const double (*G)[RP + 1], int r, flo
     if (i < RP) {
 #pragma unroll
         for (int k = 0; k < RP; ++k) Lf[i * RP + k] = (float)g[k];
-        dinvf[i] = (float)myinv;
+        dinvf[i] = ((dead >> i) & 1u) ? 0.f : (float)myinv;         // a dropped direction: zero column of the result
     }
     if (i == 0) *deadw = dead;
 }
 
-// LDS carve-up (bytes).  NPK = N rounded up to 32 (the K step of the fp16 MFMA), NPH = NPK + 8 halves per transposed row.
+// LDS carve-up (bytes).  NPK = N rounded up to 32 (the K step of the fp16 MFMA); RR = RP rounded up to 16 (the rank groups of the MFMA
+// tiles).  ONE N x r matrix lives in LDS at a time (Y0, W1, Y1, W2, U in turn, in place), fp32, transposed [rank][row]: the operand of
+// the slab product reads 8 consecutive rows of a rank and splits them into fp16 hi + lo on the way; the fp64 Gram matrix, the
+// substitution and the state update read it as it is.
 template <int RP> struct LrsLds {
-    __host__ __device__ static int dt(int) { return 0; }                                        // slab^T  [32][NPH] fp16
-    __host__ __device__ static int yt(int NPK) { return 32 * (NPK + 8) * 2; }                   // Y^T hi | lo, [16][NPH] fp16 each
-    __host__ __device__ static int yt_bytes(int NPK) { const int a = 2 * 16 * (NPK + 8) * 2; return a > 16384 ? a : 16384; }     // dead: fp64 Gram partials
-    __host__ __device__ static int yf(int NPK) { return yt(NPK) + yt_bytes(NPK); }              // Y   [NPK][RP] fp32; at the end: U [NPK][RP] fp16
-    __host__ __device__ static int wf(int NPK) { return yf(NPK) + NPK * RP * 4; }               // W   [NPK][RP] fp32; dead: 16 KB of reduction scratch
-    __host__ __device__ static int wf_bytes(int NPK) { const int a = NPK * RP * 4; return a > 16384 ? a : 16384; }
-    __host__ __device__ static int zt(int NPK) { return wf(NPK) + wf_bytes(NPK); }              // Z^T hi | lo, [16][LRS_ZH] fp16 each
-    __host__ __device__ static int zf(int NPK) { return zt(NPK) + 2 * 16 * LRS_ZH * 2; }        // Z [32][16] fp32 (for its Gram matrix)
-    __host__ __device__ static int ch(int NPK) { return zf(NPK) + 32 * 16 * 4; }                // factorisation scratch
-    static constexpr int ch_bytes = ((3 * RP * (RP + 1) + RP + 2) * 8 + 3 * RP * RP * 4 + 15) / 16 * 16;
+    static constexpr int RR = (RP + 15) / 16 * 16;
+    __host__ __device__ static int nps(int NPK) { return NPK + 4; }                             // floats per row of the N x r matrix (banks)
+    __host__ __device__ static int dt(int) { return 0; }                                        // slab^T  [32][NPK + 8] fp16
+    __host__ __device__ static int yt(int NPK) { return 32 * (NPK + 8) * 2; }                   // the N x r matrix [RR][NPS] fp32
+    __host__ __device__ static int sc(int NPK) { return yt(NPK) + RR * nps(NPK) * 4; }          // 16 KB of scratch: wave partials of the products
+    __host__ __device__ static int zt(int NPK) { return sc(NPK) + 16384; }                      // Z^T hi | lo, [RR][LRS_ZH] fp16 each
+    __host__ __device__ static int zf(int NPK) { return zt(NPK) + 2 * RR * LRS_ZH * 2; }        // Z [32][RR] fp32 (for its Gram matrix)
+    __host__ __device__ static int ch(int NPK) { return zf(NPK) + 32 * RR * 4; }                // factorisation: G fp64, L fp32, 1 / diagonal, dead mask
+    static constexpr int ch_bytes = (RP * (RP + 1) * 8 + RP * RP * 4 + RP * 4 + 16 + 15) / 16 * 16;
     __host__ __device__ static int total(int NPK) { return ch(NPK) + ch_bytes; }
 };
 
 template <int RP>
 __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     typedef LrsLds<RP> L;
+    constexpr int RR = L::RR, RG = RR / 16;                           // rank groups of 16 (the N dimension of an MFMA tile)
     const int bid = blockIdx.x;
     int z, idx;
     if (a.zmod) { z = bid % a.batch; idx = bid / a.batch; } else { z = bid / a.nwg_t; idx = bid - z * a.nwg_t; }
     const LrItem it = b.it[z];
     const int N = a.N, C = a.C, NPK = a.NPK, r = a.r, nwg = a.nwg_t;
-    const int NPH = NPK + 8, nmt = NPK / 16;
+    const int NPH = NPK + 8, NPS = NPK + 4, nmt = NPK / 16;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, lq = lane >> 4;     // w: scalar (uniform branches)
     extern __shared__ double lrs_smem[];
     char* sm = reinterpret_cast<char*>(lrs_smem);
     h16* Dt = reinterpret_cast<h16*>(sm + L::dt(NPK));
-    h16* Yth = reinterpret_cast<h16*>(sm + L::yt(NPK));
-    h16* Ytl = Yth + 16 * NPH;
-    float* Yf = reinterpret_cast<float*>(sm + L::yf(NPK));
-    float* Wf = reinterpret_cast<float*>(sm + L::wf(NPK));
-    f32x4* red4 = reinterpret_cast<f32x4*>(Wf);                        // 8 KB of scratch while W is dead
-    h16* U16s = reinterpret_cast<h16*>(Yf);                            // [NPK][RP] fp16 U (the fp32 U itself is not needed)
+    float* Yt = reinterpret_cast<float*>(sm + L::yt(NPK));            // [RR][NPS]
+    f32x4* red4 = reinterpret_cast<f32x4*>(sm + L::sc(NPK));
+    double* scr64 = reinterpret_cast<double*>(sm + L::sc(NPK));
     h16* Zth = reinterpret_cast<h16*>(sm + L::zt(NPK));
-    h16* Ztl = Zth + 16 * LRS_ZH;
+    h16* Ztl = Zth + RR * LRS_ZH;
     float* Zf = reinterpret_cast<float*>(sm + L::zf(NPK));
     double (*Gd)[RP + 1] = reinterpret_cast<double (*)[RP + 1]>(sm + L::ch(NPK));
-    double (*Ld)[RP + 1] = Gd + RP;
-    double (*Sd)[RP + 1] = Ld + RP;
-    double* misc = reinterpret_cast<double*>(Sd + RP);                // [0] gmax, [1 .. RP] dinv
-    float* Lf = reinterpret_cast<float*>(misc + RP + 2);            // Cholesky factor (fp32, row-major), 1 / diagonal, dead directions
+    float* Lf = reinterpret_cast<float*>(Gd + RP);                    // Cholesky factor (fp32, row-major), 1 / diagonal, dead directions
     float* dinvf = Lf + RP * RP;
     unsigned* deadw = reinterpret_cast<unsigned*>(dinvf + RP);
-    double* scr64 = reinterpret_cast<double*>(Yth);                    // fp64 Gram partials of the waves while Y^T is dead (<= 16 KB)
-    lrs_u4* part = reinterpret_cast<lrs_u4*>(a.arena + 256 + (size_t)z * a.arena_stride);     // [nwg][NPK][RP / 4] cells of 4 tagged words
-    lrs_u4* full = reinterpret_cast<lrs_u4*>(a.arena + 256 + (size_t)z * a.arena_stride + a.offFull);      // [NPK][RP / 4]
+    lrs_u4* part = reinterpret_cast<lrs_u4*>(a.arena + 256 + (size_t)z * a.arena_stride);     // [slab][pcells] cells of 4 tagged words
+    lrs_u4* full = reinterpret_cast<lrs_u4*>(a.arena + 256 + (size_t)z * a.arena_stride + a.offFull);      // [pcells]
     const unsigned launches = __hip_atomic_load(reinterpret_cast<const unsigned*>(a.arena), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned tag0 = launches * 3u + 1u;
-    const int cells = NPK * RP / 4, gcells = RP * RP / 2, pcells = cells + gcells;      // cells (4 words) of a partial: the N x r values | an r x r fp64 matrix as word pairs                         // sum n since the arena was zeroed carries tag (n + 1) mod 4
+    const unsigned tag0 = launches * 3u + 1u;                         // sum n since the arena was zeroed carries tag (n + 1) mod 4
+    // cells (4 words) of a partial: the N x r values row by row, then an r x r fp64 matrix as (hi, lo) word pairs
+    const int cells = NPK * RP / 4, gcells = RP * RP / 2, pcells = cells + gcells;
     // the slab of this workgroup: with the round-robin dispatch of workgroups over the 8 XCDs, the workgroups of tensor z sit on the
     // XCDs = z mod batch; neighbouring slabs go to ONE of them, so that the two 64-byte halves of a 128-byte line of x and base are
     // asked for by the same L2 (a hint only: nothing depends on where a workgroup really runs)
@@ -166,11 +163,11 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             bs[q] = (h16x8)(h16)0;
             if (it.base) bs[q] = __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(it.base + o));
         }
-        // meanwhile: zero what must read as zero (rows >= RP of Y^T and Z^T, columns >= N of the transposed arrays)
-        for (int i = tid; i < (L::yf(NPK) - L::dt(NPK)) / 16; i += LRS_NT) reinterpret_cast<lrs_u4*>(sm)[i] = (lrs_u4)0u;
-        for (int i = tid; i < 2 * 16 * LRS_ZH * 2 / 16; i += LRS_NT) reinterpret_cast<lrs_u4*>(Zth)[i] = (lrs_u4)0u;
+        // meanwhile: zero what must read as zero (ranks >= RP of the N x r matrix and of Z^T, rows >= N of the transposed arrays)
+        for (int i = tid; i < (L::sc(NPK) - L::dt(NPK)) / 16; i += LRS_NT) reinterpret_cast<lrs_u4*>(sm)[i] = (lrs_u4)0u;
+        for (int i = tid; i < 2 * RR * LRS_ZH * 2 / 16; i += LRS_NT) reinterpret_cast<lrs_u4*>(Zth)[i] = (lrs_u4)0u;
         __syncthreads();
-        for (int e = tid; e < LRS_SW * RP; e += LRS_NT) {                  // Q0 rows of the slab -> Z^T as hi + lo
+        for (int e = tid; e < LRS_SW * RP; e += LRS_NT) {               // Q0 rows of the slab -> Z^T as hi + lo
             const int wc = e / RP, k = e - wc * RP;
             const float v = it.q0[(size_t)(c0 + wc) * RP + k];
             const h16 hi = (h16)v;
@@ -200,55 +197,68 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
 
     // Wp = slab Z as [n][RP] fp32 partial of this workgroup (write-through): D[i = rank][j = row], a lane holds 4 consecutive ranks
     auto product_b = [&](unsigned tag) {
-        const h16x8 zh = *reinterpret_cast<const h16x8*>(&Zth[l16 * LRS_ZH + 8 * lq]);
-        const h16x8 zl = *reinterpret_cast<const h16x8*>(&Ztl[l16 * LRS_ZH + 8 * lq]);
+        h16x8 zh[RG], zl[RG];
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            zh[g] = *reinterpret_cast<const h16x8*>(&Zth[(16 * g + l16) * LRS_ZH + 8 * lq]);
+            zl[g] = *reinterpret_cast<const h16x8*>(&Ztl[(16 * g + l16) * LRS_ZH + 8 * lq]);
+        }
         lrs_u4* P = part + (size_t)slab * pcells;
         const unsigned seq = tag & 3u;
 #pragma unroll
         for (int q = 0; q < LRS_TQ; ++q) {
             const int t = w + LRS_NW * q;
             if (t < nmt) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh, ds[q], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl, ds[q], acc, 0, 0, 0);
-                if (4 * lq < RP) {
-                    lrs_u4 o;
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) o[v] = lrs_pack(acc[v], seq);
-                    lrs_st16(&P[(size_t)(t * 16 + l16) * (RP / 4) + lq], o);
+                for (int g = 0; g < RG; ++g) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh[g], ds[q], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl[g], ds[q], acc, 0, 0, 0);
+                    if (16 * g + 4 * lq < RP) {
+                        lrs_u4 o;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) o[v] = lrs_pack(acc[v], seq);
+                        lrs_st16(&P[(size_t)(t * 16 + l16) * (RP / 4) + 4 * g + lq], o);
+                    }
                 }
             }
         }
     };
 
-    // Z = slab^T Y (32 x RP): the waves split K = N, partial tiles summed through LDS in wave order.  final_v: the result is V
-    // (fp16, into LDS [rank][column] and into the packet / the workspace); otherwise Z^T as hi + lo for product_b
+    // Z = slab^T Y (32 x RP): 2 RG output tiles (16 columns of the slab x 16 ranks), each wave one tile over its share of K = N; the
+    // shares are summed through LDS in wave order.  The B operand - 8 consecutive rows of a rank - is split into fp16 hi + lo on the
+    // way from the fp32 matrix.  final_v: the result is V (fp16, into LDS [rank][column] and into the packet / the workspace);
+    // otherwise Z^T as hi + lo for product_b, and - want_gram - this slab's share of Z^T Z behind its partial
     auto product_a = [&](bool final_v, bool want_gram, unsigned tag) {
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        constexpr int T = 2 * RG, KS = LRS_NW / T;                     // tiles, K shares per tile
+        const int tile = w % T, mt = tile & 1, g = tile >> 1, ksh = w / T;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int nk32 = NPK / 32;
 #pragma unroll
-        for (int i = 0; i < (LRS_TQ * LRS_NW / 2 + LRS_NW - 1) / LRS_NW; ++i) {      // K steps of this wave, operands loaded unconditionally
-            const int ks = w + LRS_NW * i;
+        for (int i = 0; i < (LRS_TQ * LRS_NW / 2 + KS - 1) / KS; ++i) {      // K steps of this wave, operands loaded unconditionally
+            const int ks = ksh + KS * i;
             const int n0 = min(ks, nk32 - 1) * 32 + 8 * lq;
-            const h16x8 a0 = *reinterpret_cast<const h16x8*>(&Dt[l16 * NPH + n0]);
-            const h16x8 a1 = *reinterpret_cast<const h16x8*>(&Dt[(16 + l16) * NPH + n0]);
-            h16x8 bh = *reinterpret_cast<const h16x8*>(&Yth[l16 * NPH + n0]);
-            h16x8 bl = *reinterpret_cast<const h16x8*>(&Ytl[l16 * NPH + n0]);
-            if (ks >= nk32) { bh = (h16x8)(h16)0; bl = (h16x8)(h16)0; }
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl, acc1, 0, 0, 0);
-        }
-        red4[(w * 2 + 0) * 64 + lane] = acc0;
-        red4[(w * 2 + 1) * 64 + lane] = acc1;
-        __syncthreads();
-        if (tid < 128) {
-            const int mt = tid >> 6, ln = tid & 63;
-            f32x4 s = red4[mt * 64 + ln];
+            const h16x8 av = *reinterpret_cast<const h16x8*>(&Dt[(16 * mt + l16) * NPH + n0]);
+            const f32x4 y0 = *reinterpret_cast<const f32x4*>(&Yt[(16 * g + l16) * NPS + n0]);
+            const f32x4 y1 = *reinterpret_cast<const f32x4*>(&Yt[(16 * g + l16) * NPS + n0 + 4]);
+            h16x8 bh, bl;
 #pragma unroll
-            for (int wv = 1; wv < LRS_NW; ++wv) s += red4[(wv * 2 + mt) * 64 + ln];
-            const int rr = ln & 15, w0 = 16 * mt + 4 * (ln >> 4);      // D[i = column of the slab][j = rank]
+            for (int e = 0; e < 4; ++e) {
+                bh[e] = (h16)y0[e]; bl[e] = (h16)(y0[e] - (float)bh[e]);
+                bh[4 + e] = (h16)y1[e]; bl[4 + e] = (h16)(y1[e] - (float)bh[4 + e]);
+            }
+            if (ks >= nk32) { bh = (h16x8)(h16)0; bl = (h16x8)(h16)0; }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bl, acc, 0, 0, 0);
+        }
+        red4[w * 64 + lane] = acc;
+        __syncthreads();
+        if (tid < 64 * T) {
+            const int tl = tid >> 6, ln = tid & 63, mt2 = tl & 1, g2 = tl >> 1;
+            f32x4 s = red4[tl * 64 + ln];
+#pragma unroll
+            for (int k = 1; k < KS; ++k) s += red4[(k * T + tl) * 64 + ln];
+            const int rr = 16 * g2 + (ln & 15), w0 = 16 * mt2 + 4 * (ln >> 4);      // D[i = column of the slab][j = rank]
             if (!final_v) {
                 h16x4 hi, lo;
 #pragma unroll
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
                 *reinterpret_cast<h16x4*>(&Ztl[rr * LRS_ZH + w0]) = lo;
                 if (want_gram) {
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) Zf[(w0 + v) * 16 + rr] = s[v];
+                    for (int v = 0; v < 4; ++v) Zf[(w0 + v) * RR + rr] = s[v];
                 }
             } else {
                 h16x4 v16;
@@ -277,27 +287,28 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             }
         }
         __syncthreads();
-        if (want_gram && w == LRS_NW - 1) {
-            // this slab's share of Z^T Z (= Y^T W of the sum that follows: W = A Z, Z = A^T Y), fp64 from the fp32 Z: exact products.
-            // It travels behind the partial, every entry as a (hi, lo) pair of tagged words
-            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-            double zv[8];
+        if (want_gram && w >= LRS_NW - RG * RG) {
+            // this slab's share of Z^T Z (= Y^T W of the sum that follows: W = A Z, Z = A^T Y), fp64 from the fp32 Z: exact products; one
+            // 16 x 16 tile a wave.  It travels behind the partial, every entry as a (hi, lo) pair of tagged words
+            const int tg = LRS_NW - 1 - w, gi = tg / RG, gj = tg - gi * RG;
+            f64x4 acc2 = {0.0, 0.0, 0.0, 0.0};
+            double za[8], zb[8];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) zv[ks] = (double)Zf[(4 * ks + lq) * 16 + l16];
+            for (int ks = 0; ks < 8; ++ks) { za[ks] = (double)Zf[(4 * ks + lq) * RR + 16 * gi + l16]; zb[ks] = (double)Zf[(4 * ks + lq) * RR + 16 * gj + l16]; }
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(zv[ks], zv[ks], acc, 0, 0, 0);
+            for (int ks = 0; ks < 8; ++ks) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(za[ks], zb[ks], acc2, 0, 0, 0);
             unsigned* G2 = reinterpret_cast<unsigned*>(part + (size_t)slab * pcells + cells);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int gi = lq + 4 * v;                            // D[i = lq + 4 v][j = l16]
-                if (gi < RP && l16 < RP) lrs_st8(&G2[2 * (gi * RP + l16)], lrs_pack64(acc[v], tag & 3u));
+                const int ri = 16 * gi + lq + 4 * v, rj = 16 * gj + l16;      // D[i = lq + 4 v][j = l16]
+                if (ri < RP && rj < RP) lrs_st8(&G2[2 * (ri * RP + rj)], lrs_pack64(acc2[v], tag & 3u));
             }
         }
     };
 
-    // Sum of the partials over the slabs into dst (LDS, [NPK][RP] fp32): this workgroup's share of the cells over all partials
-    // (fixed order), published; then everybody polls the whole result
-    auto allreduce = [&](unsigned tag, float* dst, bool with_gram) {
+    // Sum of the partials over the slabs into the N x r matrix (LDS, [rank][row] fp32): this workgroup's share of the cells over all
+    // partials (fixed order), published; then everybody polls the whole result
+    auto allreduce = [&](unsigned tag, bool with_gram) {
         const unsigned seq = tag & 3u;
         const int tcells = with_gram ? pcells : cells;                // with_gram: the r x r fp64 matrix behind the values is summed (in fp64) too -> Gd
         const int cpw = (tcells + nwg - 1) / nwg;
@@ -366,7 +377,6 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             __syncthreads();
         }
         if (with_gram) LSTAMP(12);
-        f32x4* dst4 = reinterpret_cast<f32x4*>(dst);
         for (int i0 = tid; i0 < tcells; i0 += LRS_NT * LRS_J) {
             lrs_u4 q[LRS_J];
             long long t0 = 0;
@@ -389,10 +399,9 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             for (int j = 0; j < LRS_J; ++j) {
                 const int c = i0 + LRS_NT * j;
                 if (c < cells) {
-                    f32x4 v;
+                    const int n = c / (RP / 4), rq = c - n * (RP / 4);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = lrs_val(q[j][k]);
-                    dst4[c] = v;
+                    for (int k = 0; k < 4; ++k) Yt[(4 * rq + k) * NPS + n] = lrs_val(q[j][k]);
                 } else if (c < tcells) {
                     const int e = 2 * (c - cells);
                     Gd[e / RP][e % RP] = lrs_val64(q[j][0], q[j][1]);
@@ -403,175 +412,122 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
         __syncthreads();
     };
 
-    // Y^T as fp16 hi + lo from Y (LDS fp32 [NPK][RP])
-    auto split_y = [&]() {
-        for (int i = tid; i < NPK * RP; i += LRS_NT) {
-            const int n = i / RP, k = i - n * RP;
-            const float v = Yf[i];
-            const h16 hi = (h16)v;
-            Yth[k * NPH + n] = hi;
-            Ytl[k * NPH + n] = (h16)(v - (float)hi);
-        }
-        __syncthreads();
-    };
-
-    // fp64 Gram matrices of fp32 operands (exact products, fp64 sums): M = Y^T W into Gd, or (want_p) P = W^T W into Sd
-    auto gram64 = [&](bool want_p) {
-        f64x4 am[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, ap[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    // P = W^T W into Gd: fp64 from the fp32 values (exact products, fp64 sums), RG x RG tiles of 16 x 16, each wave one tile over its
+    // share of K = N; the shares are summed through LDS in wave order
+    auto gram64 = [&]() {
+        constexpr int T2 = RG * RG, KS2 = LRS_NW / T2;
+        const int tile = w % T2, gi = tile / RG, gj = tile - gi * RG, ksh = w / T2;
+        f64x4 am[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
         const int nks = NPK / 4;
-        const int nwv = LRS_NW, wk = w;
         constexpr int UN = 10;                                        // K steps whose operands are in flight at once
-        for (int i0 = 0; wk >= 0 && wk + nwv * i0 < nks; i0 += UN) {
+        for (int i0 = 0; ksh + KS2 * i0 < nks; i0 += UN) {
             float av[UN], bv[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int ks = wk + nwv * (i0 + u);
+                const int ks = ksh + KS2 * (i0 + u);
                 const int n = min(ks, nks - 1) * 4 + lq;
-                if (RP == 8) {
-                    // one product: rows 0 .. 7 of the A operand are Y's columns, rows 8 .. 15 W's (W lies behind Y in LDS) -> M on top of P
-                    av[u] = Yf[(l16 < 8 ? 0 : NPK * RP) + n * RP + (l16 & 7)];
-                    bv[u] = Wf[n * RP + (l16 & 7)];
-                    if (l16 >= 8) bv[u] = 0.f;
-                } else {
-                    av[u] = Yf[n * RP + (l16 & (RP - 1))];
-                    bv[u] = Wf[n * RP + (l16 & (RP - 1))];
-                }
+                av[u] = Yt[(16 * gi + l16) * NPS + n];
+                bv[u] = Yt[(16 * gj + l16) * NPS + n];
                 if (ks >= nks) { av[u] = 0.f; bv[u] = 0.f; }
             }
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                if (RP == 16 && want_p) ap[u & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)bv[u], (double)bv[u], ap[u & 1], 0, 0, 0);
-                else am[u & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[u], (double)bv[u], am[u & 1], 0, 0, 0);
-            }
+            for (int u = 0; u < UN; ++u) am[u & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[u], (double)bv[u], am[u & 1], 0, 0, 0);
         }
         am[0] += am[1];
-        ap[0] += ap[1];
-        const f64x4 res = (RP == 16 && want_p) ? ap[0] : am[0];
         // D[i][j]: j = lane & 15, i = (lane >> 4) + 4 v  (the fp64 form's own map)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) scr64[(w * 64 + lane) * 4 + v] = res[v];
+        for (int v = 0; v < 4; ++v) scr64[(w * 64 + lane) * 4 + v] = am[0][v];
         __syncthreads();
-        if (tid < 256) {
-            const int ln = tid & 63, v = tid >> 6;
-            const int i = (ln >> 4) + 4 * v, j = ln & 15;
+        for (int o = tid; o < T2 * 256; o += LRS_NT) {
+            const int tl = o >> 8, ln = o & 63, v = (o >> 6) & 3;
+            const int i = 16 * (tl / RG) + (ln >> 4) + 4 * v, j = 16 * (tl % RG) + (ln & 15);
             double m = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < LRS_NW; ++wv) m += scr64[(wv * 64 + ln) * 4 + v];
-            if (RP == 8) {
-                if (j < 8 && !want_p && i < 8) Gd[i][j] = m;
-                if (j < 8 && want_p && i >= 8) Sd[i - 8][j] = m;
-            } else if (want_p) Sd[i & (RP - 1)][j & (RP - 1)] = m;
-            else Gd[i & (RP - 1)][j & (RP - 1)] = m;
+            for (int k = 0; k < KS2; ++k) m += scr64[((k * T2 + tl) * 64 + ln) * 4 + v];
+            if (i < RP && j < RP) Gd[i][j] = m;
         }
         __syncthreads();
     };
 
-    // Y = W L^-T, one row per thread by forward substitution (fp32; the factor's entries are LDS broadcasts): Y^T as fp16 hi + lo for
-    // the next product (rows >= RP rewritten with zeros: the fp64 scratch lay over them), and Y itself (fp32, row-major) for the next
-    // Gram matrix - or, as_u: the result is U, its fp16 rounding (= the hi part) kept row-major for the state update and written to
-    // the packet by workgroup 0
-    auto apply_l = [&](bool as_u) {
-        const unsigned dead = *deadw;
-        auto put = [&](int n, const float (&y)[RP]) {
-            h16 hi[RP];
-#pragma unroll
-            for (int m = 0; m < RP; ++m) {
-                hi[m] = (h16)y[m];
-                Yth[m * NPH + n] = hi[m];
-                Ytl[m * NPH + n] = (h16)(y[m] - (float)hi[m]);
-            }
-#pragma unroll
-            for (int m = RP; m < 16; ++m) { Yth[m * NPH + n] = (h16)0; Ytl[m * NPH + n] = (h16)0; }
-            if (as_u) {
-#pragma unroll
-                for (int c = 0; c < RP / 8; ++c) {
-                    h16x8 u8;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) u8[e] = hi[8 * c + e];
-                    *reinterpret_cast<h16x8*>(&U16s[n * RP + 8 * c]) = u8;
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < RP / 4; ++c) *reinterpret_cast<f32x4*>(&Yf[n * RP + 4 * c]) = *reinterpret_cast<const f32x4*>(&y[4 * c]);
-            }
-        };
+    // Y = W L^-T in place, one row per thread by forward substitution (fp32; the factor's entries are LDS broadcasts, a row of the
+    // factor read once as 16-byte pieces)
+    auto apply_l = [&]() {
         if (RP <= 8) {
             // rows tid and tid + LRS_NT in ONE pass (NPK <= 2 LRS_NT): the factor's rows are read once for both
             const int n0 = tid, n1 = tid + LRS_NT;
             const bool h0 = n0 < NPK, h1 = n1 < NPK;
             float wa[RP], wb[RP], ya[RP], yb[RP];
 #pragma unroll
-            for (int c = 0; c < RP / 4; ++c) {
-                *reinterpret_cast<f32x4*>(&wa[4 * c]) = *reinterpret_cast<const f32x4*>(&Wf[(h0 ? n0 : 0) * RP + 4 * c]);
-                *reinterpret_cast<f32x4*>(&wb[4 * c]) = *reinterpret_cast<const f32x4*>(&Wf[(h1 ? n1 : 0) * RP + 4 * c]);
-            }
+            for (int k = 0; k < RP; ++k) { wa[k] = Yt[k * NPS + (h0 ? n0 : 0)]; wb[k] = Yt[k * NPS + (h1 ? n1 : 0)]; }
 #pragma unroll
             for (int j = 0; j < RP; ++j) {
                 float lrow[(RP + 3) / 4 * 4];
 #pragma unroll
                 for (int c = 0; c < (j + 3) / 4; ++c) *reinterpret_cast<f32x4*>(&lrow[4 * c]) = *reinterpret_cast<const f32x4*>(&Lf[j * RP + 4 * c]);
-                const float dj = ((dead >> j) & 1u) ? 0.f : dinvf[j];     // a dropped direction: zero column
+                const float dj = dinvf[j];                                // (0 for a dropped direction: zero column)
                 float sa = wa[j], sb = wb[j];
 #pragma unroll
                 for (int k = 0; k < j; ++k) { sa = fmaf(-ya[k], lrow[k], sa); sb = fmaf(-yb[k], lrow[k], sb); }
                 ya[j] = sa * dj;
                 yb[j] = sb * dj;
             }
-            if (h0) put(n0, ya);
-            if (h1) put(n1, yb);
+#pragma unroll
+            for (int k = 0; k < RP; ++k) {
+                if (h0) Yt[k * NPS + n0] = ya[k];
+                if (h1) Yt[k * NPS + n1] = yb[k];
+            }
         } else {
-            // rank 16: one row at a time (two rows' values and the factor's 136 entries do not fit the registers of 8 waves); the second
+            // rank 16 / 32: one row at a time (two rows' values and the factor's entries do not fit the registers of 8 waves); the second
             // pass - rows >= LRS_NT - only exists in wave 0
             for (int n = tid; n < NPK; n += LRS_NT) {
-                float wa[RP], ya[RP];
+                float y[RP];                                          // W's row, replaced entry by entry
+                // (the row stride is a run-time value: walking a pointer keeps ONE address in registers - computed up front, the RP
+                // addresses were spilled at rank 32)
+                const float* rp = Yt + n;
 #pragma unroll
-                for (int c = 0; c < RP / 4; ++c) *reinterpret_cast<f32x4*>(&wa[4 * c]) = *reinterpret_cast<const f32x4*>(&Wf[n * RP + 4 * c]);
+                for (int k = 0; k < RP; ++k) { y[k] = *rp; rp += NPS; asm volatile("" : "+v"(rp)); }
 #pragma unroll
                 for (int j = 0; j < RP; ++j) {
                     float lrow[(RP + 3) / 4 * 4];
 #pragma unroll
                     for (int c = 0; c < (j + 3) / 4; ++c) *reinterpret_cast<f32x4*>(&lrow[4 * c]) = *reinterpret_cast<const f32x4*>(&Lf[j * RP + 4 * c]);
-                    const float dj = ((dead >> j) & 1u) ? 0.f : dinvf[j];
-                    float sa = wa[j];
+                    float sa = y[j];
 #pragma unroll
-                    for (int k = 0; k < j; ++k) sa = fmaf(-ya[k], lrow[k], sa);
-                    ya[j] = sa * dj;
-                    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four rows of the factor in flight at a time
+                    for (int k = 0; k < j; ++k) sa = fmaf(-y[k], lrow[k], sa);
+                    y[j] = sa * dinvf[j];
+                    if (RP > 16 || (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // the factor's rows in flight: four (rank 16), one (rank 32)
                 }
-                put(n, ya);
+                float* wp = Yt + n;
+#pragma unroll
+                for (int k = 0; k < RP; ++k) { *wp = y[k]; wp += NPS; asm volatile("" : "+v"(wp)); }
             }
         }
         __syncthreads();
-        if (as_u && idx == 0) {
-            h16* U16g = a.u_in_packet ? (h16*)it.packet : (h16*)(it.ws + a.offU16);
-            for (int i = tid; i < N * r; i += LRS_NT) { const int n = i / r, m = i - n * r; U16g[i] = U16s[n * RP + m]; }
-        }
     };
 
     // ---------------- Y0 = A Q0 ----------------
     product_b(tag0);
     LSTAMP(2);
-    allreduce(tag0, Yf, false);
-    split_y();
+    allreduce(tag0, false);
     LSTAMP(3);
 
-    // ---------------- W1 = A (A^T Y0), T1, Y1 = W1 T1 ----------------
+    // ---------------- W1 = A (A^T Y0), Y1 = W1 chol(M1)^-T ----------------
     product_a(false, true, tag0 + 1);                                 // also: this slab's share of M1 = Z1^T Z1 (= Y0^T W1), behind the partial
     product_b(tag0 + 1);
     LSTAMP(4);
-    allreduce(tag0 + 1, Wf, true);                                    // W1 and M1
+    allreduce(tag0 + 1, true);                                        // W1 and M1
     LSTAMP(5);
     LSTAMP(15);
     if (w == 0) lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_TOL, false);     // chol(M1)
     __syncthreads();
-    apply_l(false);                                                   // Y1 = W1 chol(M1)^-T
+    apply_l();                                                        // Y1 = W1 chol(M1)^-T
     LSTAMP(6);
 
     // ---------------- W2 = A (A^T Y1), U = W2 chol(W2^T W2)^-T ----------------
     product_a(false, false, 0u);
     product_b(tag0 + 2);
     LSTAMP(7);
-    allreduce(tag0 + 2, Wf, false);
+    allreduce(tag0 + 2, false);
     LSTAMP(8);
     // The N-space chain's T2 T3 (T2 = chol(Y1^T W2)^-T, T3 = chol(T2^T P T2)^-T, P = W2^T W2) is upper triangular and makes W2
     // orthonormal, so it IS the inverse Cholesky factor of P: one factorisation.  W2's columns are graded (norms ~ sigma^3), P's
@@ -579,44 +535,63 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     // diagonal: orthogonality of U 1e-9 .. 1e-5 for sigma_r / sigma_1 down to 3e-5, checked in fp64), but "small against the largest
     // diagonal entry" is the wrong test for a dead direction here: a pivot is compared with its OWN diagonal entry (legitimate
     // directions: > 1e-8 of it; the null directions of a rank-deficient residual: < 1e-10)
-    gram64(true);
-    if (w == 0) lrs_chol_L<RP>(Sd, r, Lf, dinvf, deadw, LRS_PIVOT_REL, true);
+    gram64();
+    if (w == 0) lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_REL, true);
     __syncthreads();
     LSTAMP(9);
-    apply_l(true);                                                    // U (hi + lo transposed for V, fp16 row-major for the state update)
+    apply_l();                                                        // U, fp32 in place: its fp16 rounding is what the packet carries
+    if (idx == 0) {
+        h16* U16g = a.u_in_packet ? (h16*)it.packet : (h16*)(it.ws + a.offU16);
+        for (int i = tid; i < N * r; i += LRS_NT) { const int n = i / r, m = i - n * r; U16g[i] = (h16)Yt[m * NPS + n]; }
+    }
     LSTAMP(10);
 
     // ---------------- V = U^T A for the slab's columns, state update of the slab's columns ----------------
     product_a(true, false, 0u);
     if (a.fuse_decode) {
         // new_base[:, slab] = base + fp16(U V): the arithmetic of k_lr_decode (v_dot2 chain over the k-pairs in order, one rounding
-        // to fp16, one fp16 add), from the registers base was loaded into at the start
-        h16x2 vp[RP / 2][8];
+        // to fp16, one fp16 add), from the registers base was loaded into at the start; 8 k-pairs at a time (registers)
+        float acc[LRS_TQ][8];
 #pragma unroll
-        for (int kk = 0; kk < RP / 2; ++kk)
+        for (int q = 0; q < LRS_TQ; ++q)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                vp[kk][i][0] = Zth[(2 * kk) * LRS_ZH + 8 * lq + i];
-                vp[kk][i][1] = Zth[(2 * kk + 1) * LRS_ZH + 8 * lq + i];
+            for (int i = 0; i < 8; ++i) acc[q][i] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < (RP / 2 + 7) / 8; ++kh) {
+            h16x2 vp[8][8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k2 = 8 * kh + kk;
+                    vp[kk][i][0] = (2 * k2 < RR) ? Zth[(2 * k2) * LRS_ZH + 8 * lq + i] : (h16)0;
+                    vp[kk][i][1] = (2 * k2 + 1 < RR) ? Zth[(2 * k2 + 1) * LRS_ZH + 8 * lq + i] : (h16)0;
+                }
+#pragma unroll
+            for (int q = 0; q < LRS_TQ; ++q) {
+                const int row = (w + LRS_NW * q) * 16 + l16;
+                if (row < N) {
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const int k2 = 8 * kh + kk;
+                        if (2 * k2 < r && 2 * k2 < RP) {
+                            h16x2 ua;
+                            ua[0] = (h16)Yt[(2 * k2) * NPS + row];
+                            ua[1] = (h16)Yt[(2 * k2 + 1) * NPS + row];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) acc[q][i] = __builtin_amdgcn_fdot2(ua, vp[kk][i], acc[q][i], false);
+                        }
+                    }
+                }
             }
+        }
 #pragma unroll
         for (int q = 0; q < LRS_TQ; ++q) {
             const int row = (w + LRS_NW * q) * 16 + l16;
             if (row < N) {
-                float acc[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < RP / 2; ++kk) {
-                    if (2 * kk < r) {
-                        const h16x2 ua = *reinterpret_cast<const h16x2*>(&U16s[row * RP + 2 * kk]);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_fdot2(ua, vp[kk][i], acc[i], false);
-                    }
-                }
                 h16x8 o;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = (h16)acc[i];
+                for (int i = 0; i < 8; ++i) o[i] = (h16)acc[q][i];
                 if (it.base) o = bs[q] + o;
                 __builtin_nontemporal_store(o, reinterpret_cast<h16x8*>(it.new_base + (size_t)row * C + c0 + 8 * lq));
             }
@@ -641,9 +616,9 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
 static inline int lrs_npk(int N) { return (N + 31) / 32 * 32; }
 
 bool cfx_i_lrs_ok(int N, int C, int RP) {
-    if (N < 32 || N > 16 * LRS_NW * LRS_TQ || (C % 128) != 0 || C < 512 || RP > 16) return false;
+    if (N < 32 || N > 16 * LRS_NW * LRS_TQ || (C % 128) != 0 || C < 512 || RP > 32) return false;
     const int npk = lrs_npk(N);
-    return (RP == 8 ? LrsLds<8>::total(npk) : LrsLds<16>::total(npk)) <= 160 * 1024;
+    return (RP == 8 ? LrsLds<8>::total(npk) : (RP == 16 ? LrsLds<16>::total(npk) : LrsLds<32>::total(npk))) <= 160 * 1024;
 }
 
 size_t cfx_i_lrs_extra_bytes(int, int, int) { return 0; }       // nothing in the caller's workspace: the hand-over arena is the context's
@@ -736,7 +711,7 @@ int cfx_i_lrs_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int b
         memset(&a, 0, sizeof(a));
         a.N = N; a.C = C; a.NPK = (int)npk; a.r = rank; a.batch = nb; a.nwg_t = C / LRS_SW;
         a.absd = absd; a.u_in_packet = quantized ? 0 : 1;
-        a.fuse_decode = (want_decode && !quantized) ? 1 : 0;
+        a.fuse_decode = (want_decode && !quantized && RPv <= 16) ? 1 : 0;      // (rank 32: the receiver's kernel is the MFMA form - the caller runs it)
         a.offU16 = offU16; a.offV16 = offV16;
         a.arena = lrs_arena(ctx, (void*)s, N, C, RPv, nb, &a.arena_stride, &a.offFull);
         a.tick = cfx_i_ticket_block(ctx, (void*)s);
@@ -744,9 +719,9 @@ int cfx_i_lrs_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int b
         a.err = ctx->gate_err;
         a.timeout = ctx->gate_timeout;
         a.stamps = (unsigned long long*)ctx->dbg_stamps;
-        const int rc = RPv == 8 ? lrs_run<8>(ctx, bb, a, s) : lrs_run<16>(ctx, bb, a, s);
+        const int rc = RPv == 8 ? lrs_run<8>(ctx, bb, a, s) : (RPv == 16 ? lrs_run<16>(ctx, bb, a, s) : lrs_run<32>(ctx, bb, a, s));
         if (rc != CFX_OK) return rc;
     }
-    if (decoded) *decoded = (want_decode && !quantized) ? 1 : 0;
+    if (decoded) *decoded = (want_decode && !quantized && RPv <= 16) ? 1 : 0;
     return CFX_OK;
 }
