@@ -351,6 +351,109 @@ __device__ __forceinline__ void lr_apply_body(const LrItem& it, int bx, int rows
         }
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// LOW_RANK_Q: the int4 quantiser of BOTH factors in one launch (quantize_int4 of u and of v.t(), slowpath.py:62-67, i.e.
+// compress_quantize.py:552-573: per column min / max over the rows, scale = fp16(fp16(max - min) / 15.000001), codes
+// round((x - min) / scale) clamped to 0 .. 15, two ROWS per byte) and - want_dq - the factors the receiver will see
+// (q * scale + min, two fp16 roundings: compress_quantize.py:626-636) for the error-feedback decode.  The arithmetic of
+// k_minmax_compress / k_int4_quant / k_int4_dequant applied to a rows x r matrix (bit-identical: tests), without their nine launches and
+// copies for matrices of 17 K and 98 K elements.  grid.x: block 0 = U (N x r), blocks 1 .. LRQ_VS = V^T (C x r) in row shares; every
+// block finds the column statistics of its whole matrix itself (32 columns: cheaper than waiting for each other).
+// ---------------------------------------------------------------------------------------------------------------------
+#define LRQ_VS 6
+struct LrQ4 { const h16* U; const h16* V; unsigned char* secU; unsigned char* secV; h16* Uq; h16* Vq; };
+struct LrQ4Batch { LrQ4 it[LR_MAXB]; };
+__global__ __launch_bounds__(1024) void k_lr_q4(LrQ4Batch b, int N, int C, int r, int want_dq) {
+    const LrQ4 it = b.it[blockIdx.y];
+    const bool isu = blockIdx.x == 0;
+    const int R = isu ? N : C, share = isu ? 0 : (int)blockIdx.x - 1, ns = isu ? 1 : LRQ_VS;
+    const h16* X = isu ? it.U : it.V;
+    unsigned char* sec = isu ? it.secU : it.secV;
+    h16* Xq = isu ? it.Uq : it.Vq;
+    // a thread: 8 consecutive columns (16 bytes) of a row; r / 8 threads a row, 1024 / (r / 8) rows a pass
+    const int tid = threadIdx.x, oc = r >> 3, cq = tid % oc, rw = tid / oc, rpass = 1024 / oc;
+    __shared__ h16x8 smn[1024], smx[1024];                    // [row of the pass][column octet]
+    __shared__ h16 s2mn[32][33], s2mx[32][33];
+    __shared__ h16 scs[32], mns[32];
+    const h16 pinf = __builtin_bit_cast(h16, (unsigned short)0x7c00), ninf = __builtin_bit_cast(h16, (unsigned short)0xfc00);
+    h16x8 mn = (h16x8)pinf, mx = (h16x8)ninf;
+    if (rw < rpass) {
+        for (int row0 = rw; row0 < R; row0 += 4 * rpass) {           // four rows in flight (clamped: a repeated row changes nothing)
+            h16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const h16x8*>(X + (size_t)min(row0 + u * rpass, R - 1) * r + 8 * cq);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { mn[e] = v[u][e] < mn[e] ? v[u][e] : mn[e]; mx[e] = v[u][e] > mx[e] ? v[u][e] : mx[e]; }
+        }
+    }
+    smn[tid] = mn; smx[tid] = mx;
+    __syncthreads();
+    {
+        // columns c < r, 32 row groups: group g takes rows g, g + 32, .. of the pass
+        const int c = tid & 31, g = tid >> 5;
+        h16 a = pinf, bb = ninf;
+        if (c < r) {
+            const h16* pm = reinterpret_cast<const h16*>(smn);
+            const h16* px = reinterpret_cast<const h16*>(smx);
+            for (int k = g; k < rpass; k += 32) {
+                const h16 u = pm[(k * oc + (c >> 3)) * 8 + (c & 7)], v = px[(k * oc + (c >> 3)) * 8 + (c & 7)];
+                a = u < a ? u : a;
+                bb = v > bb ? v : bb;
+            }
+        }
+        s2mn[g][c] = a; s2mx[g][c] = bb;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        h16 a = pinf, bb = ninf;
+        for (int k = 0; k < 32; ++k) {
+            const h16 u = s2mn[k][tid], v = s2mx[k][tid];
+            a = u < a ? u : a;
+            bb = v > bb ? v : bb;
+        }
+        const h16 rng = bb - a;
+        const h16 sc = (h16)((float)rng / 15.000001f);
+        scs[tid] = sc; mns[tid] = a;
+        if (share == 0 && tid < r) {
+            h16* S = (h16*)(sec + (size_t)(R / 2) * r);
+            S[tid] = sc;
+            S[r + tid] = a;
+        }
+    }
+    __syncthreads();
+    h16x8 sc8, m8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc8[e] = scs[8 * cq + e]; m8[e] = mns[8 * cq + e]; }
+    const int pairs = R / 2, p0 = (int)((long)pairs * share / ns), p1 = (int)((long)pairs * (share + 1) / ns);
+    if (rw < rpass) {
+        for (int kk = p0 + rw; kk < p1; kk += rpass) {
+            h16x8 x[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) x[h] = *reinterpret_cast<const h16x8*>(X + (size_t)(2 * kk + h) * r + 8 * cq);
+            unsigned long long outb = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const h16x8 dm = x[h] - m8;
+                h16x8 dq;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    h16 v = __builtin_rintf16((h16)((float)dm[e] / (float)sc8[e]));      // round half to even (torch.round) of the fp16 quotient
+                    if (v != v) v = (h16)0;
+                    v = v < (h16)0 ? (h16)0 : v;
+                    v = v > (h16)15.0f ? (h16)15.0f : v;
+                    const unsigned qi = (unsigned)(float)v & 15u;
+                    outb |= (unsigned long long)qi << (8 * e + 4 * h);
+                    dq[e] = (h16)(float)qi;
+                }
+                if (want_dq) *reinterpret_cast<h16x8*>(Xq + (size_t)(2 * kk + h) * r + 8 * cq) = dq * sc8 + m8;      // two roundings (contraction is off)
+            }
+            *reinterpret_cast<unsigned long long*>(sec + (size_t)kk * r + 8 * cq) = outb;
+        }
+    }
+}
+
 // two products by the same factor in one launch (U = Y T and V = Z' T at the end of the chain): blocks [0, nb0) do `a`, the rest `c`
 template <int RP>
 __global__ __launch_bounds__(256) void k_lr_apply2(LrBatch b, LrApply a, LrApply c, int nb0) {
@@ -688,47 +791,20 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
         if (factors_only) return check_launch(ctx, "lr factor launch");
         const size_t secU = (size_t)N * rank / 2 + 4 * rank, secV = (size_t)C * rank / 2 + 4 * rank;       // bytes
         const size_t i4ws_off = w.total;
-        // one batched launch sequence per factor side (U sections are 16-byte aligned in the packet; V sections may start
-        // at an address that is only 8-byte aligned, so they are quantised into scratch and copied)
-        cfx_comp_item cu[LR_MAXB], cv[LR_MAXB];
-        cfx_decomp_item du[LR_MAXB], dv[LR_MAXB];
+        // both factors of every tensor through the int4 quantiser in ONE launch, straight into the packet sections; with error
+        // feedback also the dequantised factors (what the receiver will see) for the decode below
+        LrQ4Batch qb;
+        memset(&qb, 0, sizeof(qb));
         for (int i = 0; i < batch; ++i) {
             char* wsi = (char*)workspace + per * i;
             char* pk = (char*)items[i].packet;
-            cu[i] = {wsi + w.U16, nullptr, nullptr, pk};
-            cv[i] = {wsi + w.V16, nullptr, nullptr, wsi + w.Vsec};
-            du[i] = {pk, nullptr, wsi + w.Uq};
-            dv[i] = {wsi + w.Vsec, nullptr, wsi + w.Vq};
+            qb.it[i] = {(const h16*)(wsi + w.U16), (const h16*)(wsi + w.V16), (unsigned char*)pk, (unsigned char*)pk + secU, (h16*)(wsi + w.Uq), (h16*)(wsi + w.Vq)};
             dec[i].U = (const h16*)(wsi + w.Uq);
             dec[i].V = (const h16*)(wsi + w.Vq);
             dec[i].base = (const h16*)items[i].base; dec[i].out = (h16*)items[i].new_base;
         }
-        // the int4 kernels' scratch of tensor 0 .. batch-1 is contiguous when taken with stride `per`; give them one block
-        void* i4ws = (char*)workspace + i4ws_off;
-        const size_t i4bytes = per * batch - i4ws_off;
-        if (i4bytes < cfx_workspace_bytes(CFX_CODEC_INT4, N, rank, 0, batch) || i4bytes < cfx_workspace_bytes(CFX_CODEC_INT4, C, rank, 0, batch)) {
-            // not enough room for a batched call: one tensor at a time
-            for (int i = 0; i < batch; ++i) {
-                char* wsi = (char*)workspace + per * i;
-                rc = cfx_compress_batch(ctx, CFX_CODEC_INT4, N, rank, 0, 0, 1, &cu[i], wsi + i4ws_off, per - i4ws_off, stream);
-                if (rc != CFX_OK) return rc;
-                rc = cfx_compress_batch(ctx, CFX_CODEC_INT4, C, rank, 0, 0, 1, &cv[i], wsi + i4ws_off, per - i4ws_off, stream);
-                if (rc != CFX_OK) return rc;
-            }
-        } else {
-            rc = cfx_compress_batch(ctx, CFX_CODEC_INT4, N, rank, 0, 0, batch, cu, i4ws, i4bytes, stream);
-            if (rc != CFX_OK) return rc;
-            rc = cfx_compress_batch(ctx, CFX_CODEC_INT4, C, rank, 0, 0, batch, cv, i4ws, i4bytes, stream);
-            if (rc != CFX_OK) return rc;
-        }
-        for (int i = 0; i < batch; ++i)
-            (void)hipMemcpyAsync((char*)items[i].packet + secU, (char*)workspace + per * i + w.Vsec, secV, hipMemcpyDeviceToDevice, s);
-        if (upd && !(flags & CFX_FLAG_NO_EF)) {
-            rc = cfx_decompress_batch(ctx, CFX_CODEC_INT4, N, rank, 0, batch, du, stream);
-            if (rc != CFX_OK) return rc;
-            rc = cfx_decompress_batch(ctx, CFX_CODEC_INT4, C, rank, 0, batch, dv, stream);
-            if (rc != CFX_OK) return rc;
-        }
+        (void)secV; (void)i4ws_off;
+        LAUNCH(ctx, KID_INT4_QUANT, s, k_lr_q4, dim3(1 + LRQ_VS, batch), dim3(1024), 0, s, qb, N, C, rank, (upd && !(flags & CFX_FLAG_NO_EF)) ? 1 : 0);
     }
     if (upd) {
         if (flags & CFX_FLAG_NO_EF) {
