@@ -240,3 +240,43 @@ def test_cu_masked_lane_runs_the_multi_launch_chain():
     U0, V0 = want_p[0][:N * rank].view(N, rank).float(), want_p[0][N * rank:].view(rank, C).float()
     U1, V1 = pkt[:N * rank].view(N, rank).float(), pkt[N * rank:].view(rank, C).float()
     assert rel(U1 @ V1, U0 @ V0) < 3e-3
+
+
+def test_hand_over_under_load_and_soak():
+    """the tagged hand-over must not depend on timing: 600 back-to-back launches (rank 8 and 32 alternating shapes every 100) while
+    another stream saturates the memory system with copies, every result equal to the quiet run's bits; no wait may time out"""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    ctx = K.context(0)
+    cfgs = [(544, 3072, 8, False), (512, 1536, 32, True)]
+    data, ref = [], []
+    for (N, C, rank, q) in cfgs:
+        d = [make(N, C, rank, seed=300 + i) for i in range(2)]
+        xs, bs, qs = [t[0] for t in d], [t[1] for t in d], [t[2] for t in d]
+        pk = [torch.empty(K.lr_packet_halves(q, N, C, rank), dtype=torch.float16, device="cuda") for _ in range(2)]
+        nb = [torch.empty(N, C, dtype=torch.float16, device="cuda") for _ in range(2)]
+        K.lr_compress_batch(q, xs, bs, nb, pk, qs, N, C, rank, update_cache=True, ef=True)
+        torch.cuda.synchronize()
+        data.append((xs, bs, qs, pk, nb))
+        ref.append(([p.clone() for p in pk], [n.clone() for n in nb]))
+    hog = torch.cuda.Stream()
+    src = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(src)
+    stop = False
+    for rnd in range(6):
+        (N, C, rank, q), (xs, bs, qs, pk, nb), (rp, rn) = cfgs[rnd & 1], data[rnd & 1], ref[rnd & 1]
+        with torch.cuda.stream(hog):
+            for _ in range(40):
+                dst.copy_(src, non_blocking=True)
+        for it in range(100):
+            K.lr_compress_batch(q, xs, bs, nb, pk, qs, N, C, rank, update_cache=True, ef=True)
+            if it % 25 == 24:
+                torch.cuda.synchronize()
+                for i in range(2):
+                    # bit patterns (a LOW_RANK_Q packet's codes, seen as fp16, contain NaNs)
+                    assert torch.equal(pk[i].view(torch.int16), rp[i].view(torch.int16)) and torch.equal(nb[i], rn[i]), (rnd, it, i)
+                with torch.cuda.stream(hog):
+                    for _ in range(40):
+                        dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    assert lib.cfx_gate_errors(ctx) == 0
