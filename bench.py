@@ -22,6 +22,8 @@ Per layer (default; the SAME schedule at every N):
 `loopback_one_launch_per_layer` (secondary, N = 1): the layer as ONE launch (cfx_compress_batch_gated: reconstruction behind an
 in-launch arrival gate) - only possible when the packets a reconstruction needs are produced by the same launch, i.e. with
 looped-back peers and NO collective in between; never `value`.
+`low_rank_presets` (N = 1): compress time per K,V pair of the reference's LOW_RANK / LOW_RANK_Q presets on the same shard (one persistent
+launch each, csrc/cfx_lrslab.hip).
 `overlap_with_attention` (N = 1): SURVEY 8d protocol 2 - the deployable path (compact_fwd on the exchange lane) beside real SDPA
 attention: what the exchange adds to a model step (tools/overlap_bench.py, run in-process after the timed legs).
 Inputs are synthetic and already resident in HBM; the state arenas (3.0 GB) + inputs (0.76 GB) dwarf the 256 MB
@@ -889,6 +891,37 @@ def main():
                         "ordered with the compute stream by flags in device memory; exposed = step with the exchange - attention alone"}
         except Exception as e:  # pragma: no cover
             out["overlap_with_attention"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and world == 1 and not args.emulate_live and not args.no_secondary:
+        # the low-rank presets of the reference (examples/configs.py:63-110) on the same shard: one K,V pair per call, distinct pairs
+        # in turn (cold caches), event-timed through the Python API (compress = factors + state update; LOW_RANK_Q also quantises them)
+        try:
+            lr = {}
+            Lr = 24
+            g2 = torch.Generator(device=dev).manual_seed(5)
+            xl = torch.randn(Lr, 2, N, C, generator=g2, device=dev).half()
+            sl = (xl.float() + 0.1 * torch.randn(Lr, 2, N, C, generator=g2, device=dev)).half()
+            for name, q_, r_ in (("LOW_RANK r=8", False, 8), ("LOW_RANK r=16", False, 16), ("LOW_RANK_Q r=32", True, 32)):
+                pkl = [torch.empty(K.lr_packet_halves(q_, N, C, r_), dtype=torch.float16, device=dev) for _ in range(2)]
+                q0 = [torch.randn(C, K.lr_rank_pad(r_), generator=g2, device=dev) for _ in range(2)]
+
+                def lay(l):
+                    K.lr_compress_batch(q_, [xl[l, 0], xl[l, 1]], [sl[l, 0], sl[l, 1]], [sl[l, 0], sl[l, 1]], pkl, q0, N, C, r_, True)
+                for l in range(4):
+                    lay(l)
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    for l in range(Lr):
+                        lay(l)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                lr[name] = round(e0.elapsed_time(e1) / (3 * Lr) * 1e3, 1)
+            out["low_rank_presets"] = {"us_per_kv_pair_compress": lr, "shard": [N, C],
+                                       "what": "cfx_lr_compress_batch, one persistent launch per K,V pair (csrc/cfx_lrslab.hip) + the int4 factor quantiser "
+                                               "for LOW_RANK_Q; profiles/r03_lowrank_*"}
+        except Exception as e:  # pragma: no cover
+            out["low_rank_presets"] = {"error": f"{type(e).__name__}: {e}"}
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:
