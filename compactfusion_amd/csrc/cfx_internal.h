@@ -65,6 +65,8 @@ struct cfx_ctx {
     unsigned long long lrs_key[8];
     int lrs_n;
     unsigned lrs_next;
+    void* lrs_last_stream;          // the stream of the last slab-resident launch (launches of two streams must not be in flight together)
+    hipEvent_t lrs_ev;
     char err[256];
 };
 

@@ -2014,6 +2014,7 @@ void cfx_destroy(cfx_ctx* ctx) {
     if (ctx->tick) (void)hipFree(ctx->tick);
     for (int i = 0; i < ctx->lrs_n; ++i)
         if (ctx->lrs_arena[i]) (void)hipFree(ctx->lrs_arena[i]);
+    if (ctx->lrs_ev) (void)hipEventDestroy(ctx->lrs_ev);
     if (ctx->gate_err) (void)hipHostFree(ctx->gate_err);
     delete ctx;
 }

@@ -679,6 +679,18 @@ static int lrs_run(cfx_ctx* ctx, const LrBatch& b, LrsArgs a, hipStream_t s) {
         attr_bytes = lds;
     }
     a.zmod = (a.batch <= 8 && 8 % a.batch == 0) ? 1 : 0;
+    // Two of these launches in flight at once - from two streams - could each hold only a part of the CUs and wait for workgroups
+    // that find no room.  Launches of ONE stream are in order; when the stream changes, the new one first waits for everything the
+    // previous one has been given so far (an event recorded there now: nothing is paid while a context keeps to one stream).
+    if (ctx->lrs_last_stream != (void*)s) {
+        if (ctx->lrs_last_stream || ctx->lrs_ev) {
+            if (!ctx->lrs_ev && hipEventCreateWithFlags(&ctx->lrs_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->lrs_ev = nullptr; }
+            if (ctx->lrs_ev && (hipEventRecord(ctx->lrs_ev, (hipStream_t)ctx->lrs_last_stream) != hipSuccess ||
+                                hipStreamWaitEvent(s, ctx->lrs_ev, 0) != hipSuccess))
+                (void)hipGetLastError();       // (a capturing stream cannot wait for an event outside its graph: the caller serialises)
+        } else if (!ctx->lrs_ev && hipEventCreateWithFlags(&ctx->lrs_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->lrs_ev = nullptr; }
+        ctx->lrs_last_stream = (void*)s;
+    }
     LAUNCH(ctx, KID_LR_CHAIN, s, (k_lrs<RP>), dim3((unsigned)(a.nwg_t * a.batch)), dim3(LRS_NT), lds, s, b, a);
     return check_launch(ctx, "low-rank (slab-resident chain)");
 }

@@ -280,3 +280,32 @@ def test_hand_over_under_load_and_soak():
                         dst.copy_(src, non_blocking=True)
     torch.cuda.synchronize()
     assert lib.cfx_gate_errors(ctx) == 0
+
+
+def test_two_streams_do_not_starve_each_other():
+    """two streams issuing the persistent launch back to back: a launch of one must never share the CUs with a launch of the other
+    (each would wait for workgroups that find no room) - the library orders them; results equal the single-stream bits"""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    N, C, rank = 544, 3072, 8
+    sets = []
+    for si in range(2):
+        d = [make(N, C, rank, seed=500 + 2 * si + i) for i in range(2)]
+        xs, bs, qs = [t[0] for t in d], [t[1] for t in d], [t[2] for t in d]
+        pk, nb = run(xs, bs, qs, N, C, rank)
+        sets.append((xs, bs, qs, [p.clone() for p in pk], [n.clone() for n in nb]))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for si in range(2):
+        outs.append(([torch.empty_like(p) for p in sets[si][3]], [torch.empty_like(n) for n in sets[si][4]]))
+    torch.cuda.synchronize()
+    for it in range(60):
+        for si in range(2):
+            xs, bs, qs, _, _ = sets[si]
+            with torch.cuda.stream(streams[si]):
+                K.lr_compress_batch(False, xs, bs, outs[si][1], outs[si][0], qs, N, C, rank, update_cache=True, ef=True, stream=streams[si])
+    torch.cuda.synchronize()
+    assert lib.cfx_gate_errors(K.context(0)) == 0
+    for si in range(2):
+        for i in range(2):
+            assert torch.equal(outs[si][0][i], sets[si][3][i]) and torch.equal(outs[si][1][i], sets[si][4][i])
