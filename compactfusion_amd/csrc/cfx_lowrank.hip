@@ -454,6 +454,37 @@ __global__ __launch_bounds__(1024) void k_lr_q4(LrQ4Batch b, int N, int C, int r
     }
 }
 
+// The receiver's side of k_lr_q4: both int4 factors of every tensor back to fp16 (q * scale + min, two roundings:
+// compress_quantize.py:626-636; the arithmetic of k_int4_dequant) in one launch.  Sections may start at addresses that are only 8-byte
+// aligned: the codes are read 8 bytes at a time.  grid.x: block 0 = U (N x r), blocks 1 .. LRQ_VS = V^T (C x r) in row shares.
+struct LrDq4 { const unsigned char* secU; const unsigned char* secV; h16* Uq; h16* Vq; };
+struct LrDq4Batch { LrDq4 it[LR_MAXB]; };
+__global__ __launch_bounds__(1024) void k_lr_dq4(LrDq4Batch b, int N, int C, int r) {
+    const LrDq4 it = b.it[blockIdx.y];
+    const bool isu = blockIdx.x == 0;
+    const int R = isu ? N : C, share = isu ? 0 : (int)blockIdx.x - 1, ns = isu ? 1 : LRQ_VS;
+    const unsigned char* sec = isu ? it.secU : it.secV;
+    h16* Xq = isu ? it.Uq : it.Vq;
+    const int tid = threadIdx.x, oc = r >> 3, cq = tid % oc, rw = tid / oc, rpass = 1024 / oc;
+    const h16* S = (const h16*)(sec + (size_t)(R / 2) * r);
+    h16x8 sc8, m8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc8[e] = S[8 * cq + e]; m8[e] = S[r + 8 * cq + e]; }
+    const int pairs = R / 2, p0 = (int)((long)pairs * share / ns), p1 = (int)((long)pairs * (share + 1) / ns);
+    if (rw < rpass) {
+        for (int kk = p0 + rw; kk < p1; kk += rpass) {
+            const unsigned long long by = *reinterpret_cast<const unsigned long long*>(sec + (size_t)kk * r + 8 * cq);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                h16x8 dq;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dq[e] = (h16)(float)((unsigned)(by >> (8 * e + 4 * h)) & 15u);
+                *reinterpret_cast<h16x8*>(Xq + (size_t)(2 * kk + h) * r + 8 * cq) = dq * sc8 + m8;      // two roundings (contraction is off)
+            }
+        }
+    }
+}
+
 // two products by the same factor in one launch (U = Y T and V = Z' T at the end of the chain): blocks [0, nb0) do `a`, the rest `c`
 template <int RP>
 __global__ __launch_bounds__(256) void k_lr_apply2(LrBatch b, LrApply a, LrApply c, int nb0) {
@@ -841,24 +872,17 @@ int cfx_lr_decompress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank,
     const LrWs w = lr_layout(N, C, lr_rp(rank));
     const size_t per = need / batch;
     const size_t secU = (size_t)N * rank / 2 + 4 * rank, secV = (size_t)C * rank / 2 + 4 * rank;
-    cfx_decomp_item du[LR_MAXB], dv[LR_MAXB];
+    LrDq4Batch qb;
+    memset(&qb, 0, sizeof(qb));
+    (void)secV;
     for (int i = 0; i < batch; ++i) {
         char* wsi = (char*)workspace + per * i;
-        const char* pk = (const char*)items[i].packet;
-        const void* vsec = pk + secU;
-        if (!AL16(vsec)) {
-            (void)hipMemcpyAsync(wsi + w.Vsec, vsec, secV, hipMemcpyDeviceToDevice, s);
-            vsec = wsi + w.Vsec;
-        }
-        du[i] = {pk, nullptr, wsi + w.Uq};
-        dv[i] = {vsec, nullptr, wsi + w.Vq};
+        const unsigned char* pk = (const unsigned char*)items[i].packet;
+        qb.it[i] = {pk, pk + secU, (h16*)(wsi + w.Uq), (h16*)(wsi + w.Vq)};
         dec[i].U = (const h16*)(wsi + w.Uq); dec[i].V = (const h16*)(wsi + w.Vq);
         dec[i].base = (const h16*)items[i].base; dec[i].out = (h16*)items[i].recon;
     }
-    int rc = cfx_decompress_batch(ctx, CFX_CODEC_INT4, N, rank, 0, batch, du, stream);
-    if (rc != CFX_OK) return rc;
-    rc = cfx_decompress_batch(ctx, CFX_CODEC_INT4, C, rank, 0, batch, dv, stream);
-    if (rc != CFX_OK) return rc;
+    LAUNCH(ctx, KID_INT4_DEQUANT, s, k_lr_dq4, dim3(1 + LRQ_VS, batch), dim3(1024), 0, s, qb, N, C, rank);
     return cfx_i_lr_decode_launch(ctx, N, C, rank, batch, dec, true, s);
 }
 
