@@ -1,4 +1,4 @@
-"""The slab-resident low-rank chain (csrc/cfx_lrslab.hip, one persistent launch, rank <= 16, N <= 576): what the launch
+"""The slab-resident low-rank chain (csrc/cfx_lrslab.hip, one persistent launch, rank <= 32, N <= 576): what the launch
 structure could break - ragged shapes, rank-deficient residuals, sub-batching, reuse of the hand-over arena across shapes,
 run-to-run reproducibility, hipGraph capture - checked against an fp64 replay of the reference's iteration
 (xfuser/compact/compress_lowrank.py:14-61, Householder QR) with the same start matrix, and against the receiver's kernel."""
@@ -69,16 +69,16 @@ def check(x, base, q0, pkt, nb, N, C, rank, tol=3e-3):
 
 def slab_chain_taken(N, C, rank):
     """the chain under test only runs when its workgroups fit the device (C / 32 per tensor, one per CU)"""
-    return 32 <= N <= 576 and C % 128 == 0 and C >= 512 and rank <= 16 and C // 32 <= 250
+    return 32 <= N <= 576 and C % 128 == 0 and C >= 512 and rank <= 32 and C // 32 <= 250
 
 
 @pytest.mark.parametrize("N,C", [(544, 3072), (512, 1536), (100, 512), (33, 640), (576, 1024), (256, 6144)])
-@pytest.mark.parametrize("rank", [2, 8, 12, 16])
+@pytest.mark.parametrize("rank", [2, 8, 12, 16, 24, 32])
 def test_projection_and_states(N, C, rank):
-    if (N, C, rank) == (576, 1024, 16) or (N, C, rank) == (576, 1024, 12):
-        pytest.skip("LDS: this shape runs the multi-launch chain (covered by test_lowrank.py)")
     assert slab_chain_taken(N, C, rank)
-    x, base, q0 = make(N, C, rank, seed=N + C + rank)
+    # sigma_k = 0.7^k down to rank 16 (sigma_16 / sigma_1 = 5e-3); beyond that 0.85^k: 0.7^31 = 1.6e-5 is below what fp32 products
+    # resolve at all (the reference's own fp32 iteration is off by more than the tolerance there)
+    x, base, q0 = make(N, C, rank, seed=N + C + rank, decay=0.7 if rank <= 16 else 0.85)
     pk, nb = run([x], [base], [q0], N, C, rank)
     check(x, base, q0, pk[0], nb[0], N, C, rank)
 

@@ -8,8 +8,8 @@ from compactfusion_amd import _lib, codecs as K
 
 lib = _lib.load(); ctx = K.context(0)
 N, C = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (544, 3072)
-names = ["start", "slab in registers + LDS", "Y0 partial written", "Y0 summed, split", "W1 partial written", "W1 summed", "T1, Y1",
-         "W2 partial written", "W2 summed", "T2, T3", "U", "V + state done", "W1: share summed + published", "-", "-", "M1 (fp64 Gram)"]
+names = ["start", "slab in registers + LDS", "Y0 partial written", "Y0 summed", "W1 + M1 partial written", "W1 + M1 summed", "factor of M1, Y1",
+         "W2 partial written", "W2 summed", "P = W2^T W2, its factor", "U", "V + state done", "W1: share summed + published"]
 for r in (8, 16, 32):
     B = 2
     xs = [torch.randn(N, C, device="cuda").half() for _ in range(B)]
