@@ -412,41 +412,56 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
         __syncthreads();
     };
 
-    // P = W^T W into Gd: fp64 from the fp32 values (exact products, fp64 sums), RG x RG tiles of 16 x 16, each wave one tile over its
-    // share of K = N; the shares are summed through LDS in wave order
+    // P = W^T W into Gd: fp64 from the fp32 values (exact products, fp64 sums).  The waves split K = N; a wave loads its rows of the
+    // RG rank groups once and feeds the RG (RG + 1) / 2 tiles of the upper triangle (16 x 16 each) from them; the waves' shares are
+    // summed through LDS in wave order, a tile at a time (the scratch holds one tile of every wave), the lower triangle is the mirror
     auto gram64 = [&]() {
-        constexpr int T2 = RG * RG, KS2 = LRS_NW / T2;
-        const int tile = w % T2, gi = tile / RG, gj = tile - gi * RG, ksh = w / T2;
-        f64x4 am[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+        constexpr int NTL = RG * (RG + 1) / 2;
+        f64x4 am[NTL];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) am[t] = f64x4{0.0, 0.0, 0.0, 0.0};
         const int nks = NPK / 4;
-        constexpr int UN = 10;                                        // K steps whose operands are in flight at once
-        for (int i0 = 0; ksh + KS2 * i0 < nks; i0 += UN) {
-            float av[UN], bv[UN];
+        constexpr int UN = RG == 1 ? 10 : 6;                          // K steps whose operands are in flight at once
+        for (int i0 = 0; w + LRS_NW * i0 < nks; i0 += UN) {
+            float av[UN][RG];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int ks = ksh + KS2 * (i0 + u);
+                const int ks = w + LRS_NW * (i0 + u);
                 const int n = min(ks, nks - 1) * 4 + lq;
-                av[u] = Yt[(16 * gi + l16) * NPS + n];
-                bv[u] = Yt[(16 * gj + l16) * NPS + n];
-                if (ks >= nks) { av[u] = 0.f; bv[u] = 0.f; }
+#pragma unroll
+                for (int g = 0; g < RG; ++g) av[u][g] = (ks < nks) ? Yt[(16 * g + l16) * NPS + n] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < UN; ++u) am[u & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[u], (double)bv[u], am[u & 1], 0, 0, 0);
-        }
-        am[0] += am[1];
-        // D[i][j]: j = lane & 15, i = (lane >> 4) + 4 v  (the fp64 form's own map)
+            for (int u = 0; u < UN; ++u) {
+                int t = 0;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) scr64[(w * 64 + lane) * 4 + v] = am[0][v];
-        __syncthreads();
-        for (int o = tid; o < T2 * 256; o += LRS_NT) {
-            const int tl = o >> 8, ln = o & 63, v = (o >> 6) & 3;
-            const int i = 16 * (tl / RG) + (ln >> 4) + 4 * v, j = 16 * (tl % RG) + (ln & 15);
-            double m = 0.0;
+                for (int gi = 0; gi < RG; ++gi)
 #pragma unroll
-            for (int k = 0; k < KS2; ++k) m += scr64[((k * T2 + tl) * 64 + ln) * 4 + v];
-            if (i < RP && j < RP) Gd[i][j] = m;
+                    for (int gj = gi; gj < RG; ++gj, ++t)
+                        am[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[u][gi], (double)av[u][gj], am[t], 0, 0, 0);
+            }
         }
-        __syncthreads();
+        {
+            int t = 0;
+#pragma unroll
+            for (int gi = 0; gi < RG; ++gi)
+#pragma unroll
+                for (int gj = gi; gj < RG; ++gj, ++t) {
+                    // D[i][j]: j = lane & 15, i = (lane >> 4) + 4 v  (the fp64 form's own map)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) scr64[(w * 64 + lane) * 4 + v] = am[t][v];
+                    __syncthreads();
+                    if (tid < 256) {
+                        const int ln = tid & 63, v = tid >> 6;
+                        const int i = 16 * gi + (ln >> 4) + 4 * v, jj = 16 * gj + (ln & 15);
+                        double m = 0.0;
+#pragma unroll
+                        for (int k = 0; k < LRS_NW; ++k) m += scr64[(k * 64 + ln) * 4 + v];
+                        if (i < RP && jj < RP) { Gd[i][jj] = m; if (gi != gj) Gd[jj][i] = m; }
+                    }
+                    __syncthreads();
+                }
+        }
     };
 
     // Y = W L^-T in place, one row per thread by forward substitution (fp32; the factor's entries are LDS broadcasts, a row of the
@@ -517,9 +532,9 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     LSTAMP(4);
     allreduce(tag0 + 1, true);                                        // W1 and M1
     LSTAMP(5);
-    LSTAMP(15);
     if (w == 0) lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_TOL, false);     // chol(M1)
     __syncthreads();
+    LSTAMP(14);
     apply_l();                                                        // Y1 = W1 chol(M1)^-T
     LSTAMP(6);
 
@@ -536,6 +551,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     // diagonal entry" is the wrong test for a dead direction here: a pivot is compared with its OWN diagonal entry (legitimate
     // directions: > 1e-8 of it; the null directions of a rank-deficient residual: < 1e-10)
     gram64();
+    LSTAMP(13);
     if (w == 0) lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_REL, true);
     __syncthreads();
     LSTAMP(9);

@@ -9,7 +9,7 @@ from compactfusion_amd import _lib, codecs as K
 lib = _lib.load(); ctx = K.context(0)
 N, C = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (544, 3072)
 names = ["start", "slab in registers + LDS", "Y0 partial written", "Y0 summed", "W1 + M1 partial written", "W1 + M1 summed", "factor of M1, Y1",
-         "W2 partial written", "W2 summed", "P = W2^T W2, its factor", "U", "V + state done", "W1: share summed + published"]
+         "W2 partial written", "W2 summed", "P = W2^T W2, its factor", "U", "V + state done", "W1: share summed + published", "P = W2^T W2 formed", "factor of M1"]
 for r in (8, 16, 32):
     B = 2
     xs = [torch.randn(N, C, device="cuda").half() for _ in range(B)]
