@@ -89,6 +89,17 @@ def test_plan_building_without_gpu():
     assert lib.cfx_plan_add_decompress(plan, 1, 544, 3072, 0, 17, d) == -5            # batch too large
     assert lib.cfx_plan_add_compress(plan, 1, 544, 3077, 0, 0, 2, c, 0x9000, 1 << 20) == -2   # bad shape
     assert lib.cfx_plan_size(plan) == 2
+    # low-rank layer as plan ops
+    import ctypes
+    q0 = (ctypes.c_void_p * 2)(0xa000, 0xb000)
+    assert lib.cfx_plan_add_lr_compress(plan, 0, 544, 3072, 8, 1, 2, c, q0, 0x9000, 1 << 20) == 2
+    assert lib.cfx_plan_add_lr_decompress(plan, 0, 544, 3072, 8, 14, d, 0x9000, 1 << 20) == 3
+    assert lib.cfx_plan_add_lr_compress(plan, 0, 544, 3072, 7, 1, 2, c, q0, 0x9000, 1 << 20) == -2      # odd rank
+    assert lib.cfx_plan_add_lr_compress(plan, 1, 544, 3072, 12, 1, 2, c, q0, 0x9000, 1 << 20) == -2     # LOW_RANK_Q: rank % 8
+    assert lib.cfx_plan_add_lr_decompress(plan, 0, 544, 3072, 8, 17, d, 0x9000, 1 << 20) == -5           # batch too large
+    assert lib.cfx_plan_add_lr_compress(plan, 0, 544, 3072, 8, 1, 2, c, None, 0x9000, 1 << 20) == -1     # no start matrices
+    assert lib.cfx_plan_set_input(plan, 2, 1, 0xc000) == 0 and lib.cfx_plan_set_input(plan, 3, 0, 0xc000) == -5
+    assert lib.cfx_plan_size(plan) == 4
     other = lib.cfx_plan_create(ctx)
     assert lib.cfx_plan_copy_op(other, plan, 1) == 0 and lib.cfx_plan_copy_op(other, plan, 0) == 1
     assert lib.cfx_plan_copy_op(other, plan, 5) == -5
