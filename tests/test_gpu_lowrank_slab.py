@@ -309,3 +309,17 @@ def test_two_streams_do_not_starve_each_other():
     for si in range(2):
         for i in range(2):
             assert torch.equal(outs[si][0][i], sets[si][3][i]) and torch.equal(outs[si][1][i], sets[si][4][i])
+
+
+@pytest.mark.parametrize("B", [3, 4, 5])
+def test_several_tensors_in_one_launch(B):
+    """C = 1536: 48 workgroups per tensor, up to five tensors co-resident in ONE launch (tensor-major and XCD-interleaved block
+    orders); every tensor's bits equal its single-tensor run"""
+    N, C, rank = 512, 1536, 8
+    data = [make(N, C, rank, seed=700 + i) for i in range(B)]
+    xs, bs, qs = [d[0] for d in data], [d[1] for d in data], [d[2] for d in data]
+    pk, nb = run(xs, bs, qs, N, C, rank)
+    for i in range(B):
+        check(xs[i], bs[i], qs[i], pk[i], nb[i], N, C, rank)
+        p1, n1 = run([xs[i]], [bs[i]], [qs[i]], N, C, rank)
+        assert torch.equal(p1[0], pk[i]) and torch.equal(n1[0], nb[i])
