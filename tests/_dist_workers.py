@@ -303,10 +303,14 @@ def w_stack(rank, world, codec_name):
         return (y / y.pow(2).mean(dim=-1, keepdim=True).sqrt()).half()
 
     finals = {}
+    tname, crank, fast = G.CODECS[codec_name.lower()] if codec_name.lower() in G.CODECS else (codec_name, -1, True)
+    if crank > 0:       # the low-rank presets: the start of every subspace iteration pinned to the golden run's seeded matrix
+        from compactfusion_amd.compact import lowrank
+        lowrank.set_init_q(G.start_matrix(crank))
     for mode in ("exact", codec_name):
         cm.compact_init(CompactConfig(enabled=True, compress_func=(lambda l, s: T.WARMUP) if mode == "exact" else
-                                      (lambda l, s: T.WARMUP if s == 0 else T[codec_name]),
-                                      residual=1, ef=True, fastpath=True, comp_rank=-1))
+                                      (lambda l, s: T.WARMUP if s == 0 else T[tname]),
+                                      residual=1, ef=True, fastpath=fast, comp_rank=crank))
         outs = []
         for t in range(G.STEPS):
             cm.compact_set_step(t)
@@ -317,6 +321,8 @@ def w_stack(rank, world, codec_name):
                 h = nxt(h, o)
             outs.append(h)
         finals[mode] = outs
+    if crank > 0:
+        lowrank.set_init_q(None)
     res["psnr"] = np.array([G.psnr(finals["exact"][t].cpu(), finals[codec_name][t].cpu()) for t in range(G.STEPS)])
     res["exact_final"] = bits(finals["exact"][-1])
     return res

@@ -10,11 +10,13 @@ The exchange is the reference's own: `compact_compress` on the rank's K and V (c
 the packets, `compact_decompress` against the peer's cached state (xfuser/compact/main.py:169-388); step 0 is WARMUP.  The
 reference's ring.py itself cannot be imported here (yunchang / flash_attn are absent), so the attention is
 an fp32 softmax over [own exact K,V ; peer reconstructed K,V] - what its ring forward computes block-wise (ring.py:207-263).
-Stored per codec (BINARY, INT2 fastpath presets, examples/configs.py:39-61) and rank: the PSNR per step of the stack's final
+Stored per codec (BINARY, INT2 fastpath presets, LOW_RANK r = 8 and LOW_RANK_Q r = 32 slow-path presets, examples/configs.py:39-110)
+and rank: the PSNR per step of the stack's final
 output against the SAME stack with the exact K,V exchanged.  tests/test_gpu_stack.py runs the HIP path through `compact_fwd` on the
 same seeds and holds it to these PSNRs within 0.1 dB.
 
 usage: TORCHDYNAMO_DISABLE=1 TRITON_INTERPRET=1 python tests/golden/make_golden_stack.py
+       (G13_ONLY=lowrank8,lowrankq32 adds / refreshes only those codecs in the committed file)
 """
 import hashlib
 import json
@@ -31,7 +33,16 @@ WORLD, LAYERS, STEPS = 2, 4, 8
 B, S, H, D = 1, 64, 8, 64          # per-rank shard
 C = H * D
 SEED = 31337
-CODECS = {"binary": "BINARY", "int2": "INT2"}
+# name -> (COMPACT_COMPRESS_TYPE, comp_rank, fastpath): the fused presets and the low-rank presets (examples/configs.py:39-110)
+CODECS = {"binary": ("BINARY", -1, True), "int2": ("INT2", -1, True), "lowrank8": ("LOW_RANK", 8, False), "lowrankq32": ("LOW_RANK_Q", 32, False)}
+
+
+def start_matrix(rank):
+    """The (C, rank) start of every subspace iteration of the low-rank runs.  The reference draws torch.randn per call
+    (compress_lowrank.py:41); here - and in tests/test_gpu_stack.py - the draw is pinned to ONE seeded matrix, so that both sides
+    iterate from the same subspace (as golden group G12 does)."""
+    g = torch.Generator().manual_seed(SEED + 77 + rank)
+    return torch.randn(C, rank, generator=g)
 
 
 def weights():
@@ -110,8 +121,18 @@ def _worker(rank, world, port, out):
             pk, pv = exchange_exact(k, v)
             h = next_input(h, attention(q, [k, pk], [v, pv]))
         exact.append(h)
-    for name, tname in CODECS.items():
-        cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: None, residual=1, ef=True, fastpath=True, comp_rank=-1))
+    only = os.environ.get("G13_ONLY")
+    import xfuser.compact.slowpath as sp
+    ref_subspace_iter = sp.subspace_iter
+    for name, (tname, crank, fast) in CODECS.items():
+        if only and name not in only.split(","):
+            continue
+        if crank > 0:
+            q0 = start_matrix(crank)
+            sp.subspace_iter = lambda A, rank, num_iters=10, init_q=None, _q=q0: ref_subspace_iter(A, rank, num_iters, init_q=_q)     # pinned draw
+        else:
+            sp.subspace_iter = ref_subspace_iter
+        cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: None, residual=1, ef=True, fastpath=fast, comp_rank=crank))
         rows = []
         for t in range(STEPS):
             typ = T.WARMUP if t == 0 else T[tname]
@@ -140,6 +161,10 @@ def main():
     out = "/tmp/cfx_g13"
     mp.spawn(_worker, args=(WORLD, 29541, out), nprocs=WORLD, join=True)
     res = {}
+    dst = os.path.join(HERE, "g13_stack.npz")
+    if os.environ.get("G13_ONLY") and os.path.exists(dst):      # add / refresh some codecs, keep the others as generated before
+        old = np.load(dst)
+        res = {k: old[k] for k in old.files}
     for r in range(WORLD):
         d = np.load(out + f".r{r}.npz")
         for k in d.files:

@@ -28,11 +28,17 @@ def _entry(rank, fn_name, world, port, out, args):
     W.run(getattr(W, fn_name), rank, world, port, out, *args, device="cuda")
 
 
-@pytest.mark.parametrize("codec", ["BINARY", "INT2"])
-def test_stack_psnr_matches_the_reference(tmp_path, codec):
+@pytest.mark.parametrize("codec,tol", [("BINARY", 0.1), ("INT2", 0.1), ("lowrank8", 0.1), ("lowrankq32", 0.5)])
+def test_stack_psnr_matches_the_reference(tmp_path, codec, tol):
+    """lowrank8 / lowrankq32: the reference's LOW_RANK r = 8 and LOW_RANK_Q r = 32 presets (slow path), both sides iterating from
+    the same pinned start matrix; q32 wider: the int4 re-quantisation of the factors turns last-bit differences between Cholesky-QR
+    and Householder QR into whole quantisation levels (as in the single-layer trace G12): per step within 0.5 dB (measured: up to 0.38,
+    either sign), averaged over the steps within 0.15 dB"""
     if not os.path.exists(GOLD):
         pytest.skip("G13 golden vectors not generated")
     gold = np.load(GOLD)
+    if f"{codec.lower()}/r0/psnr" not in gold.files:
+        pytest.skip(f"G13 has no {codec} run")
     out = str(tmp_path / "res")
     mp.start_processes(_entry, args=("w_stack", 2, _port(), out, (codec,)), nprocs=2, join=True, start_method="spawn")
     for r in range(2):
@@ -41,5 +47,6 @@ def test_stack_psnr_matches_the_reference(tmp_path, codec):
         assert got.shape == want.shape
         assert got[0] > 100 and want[0] > 100, "step 0 is WARMUP: the exchange is exact"
         d = np.abs(got[1:] - want[1:])
-        assert d.max() < 0.1, f"{codec} rank {r}: final-output PSNR departs from the reference by {d.max():.3f} dB (step {1 + int(d.argmax())}): {got} vs {want}"
+        assert d.max() < tol, f"{codec} rank {r}: final-output PSNR departs from the reference by {d.max():.3f} dB (step {1 + int(d.argmax())}): {got} vs {want}"
         assert np.all(want[1:] < 80), "the compressed run must differ from the exact one"
+        assert abs(float(got[1:].mean() - want[1:].mean())) < 0.15, f"{codec} rank {r}: mean PSNR {got[1:].mean():.3f} vs {want[1:].mean():.3f}"
