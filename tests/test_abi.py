@@ -120,3 +120,16 @@ def test_lowrank_sizes_without_gpu():
     assert lib.cfx_lr_packet_bytes(0, 544, 3072, 7) == 0 and lib.cfx_lr_packet_bytes(1, 544, 3072, 12) == 0
     assert lib.cfx_lr_packet_bytes(0, 544, 3072, 34) == 0
     assert lib.cfx_lr_workspace_bytes(0, 544, 3072, 8, 2) > 2 * 544 * 3072 * 2
+
+
+def test_header_is_plain_c():
+    """include/cfx.h is the drop-in boundary: it must compile as C99 on its own (no C++ constructs, no torch / HIP types)"""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        import pytest
+        pytest.skip("no gcc")
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "cfx.h")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
