@@ -225,6 +225,31 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
         }
     };
 
+    // The iteration does not care about the scale of Y (every factor renormalises), but the fp16 operands do: Y0 = A Q0 grows with
+    // sigma, Z = A^T Y with sigma^2 - a residual with entries of a few units at the FLUX shard puts Z past 65504.  Before a product the
+    // N x r matrix is therefore scaled by the power of two that brings its largest entry into [0.5, 1) - exact, the same in every
+    // workgroup (all hold the same matrix), and folded into the operand conversion below.  |Z| <= N max|A| then: in range for any
+    // residual with entries below ~100.
+    float ysc = 1.f;
+    auto norm_scale = [&]() {
+        float m = 0.f;
+        for (int i = tid; i < RR * NPS / 4; i += LRS_NT) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(&Yt[4 * i]);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float* mx = reinterpret_cast<float*>(red4);
+        if (lane == 0) mx[w] = m;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < LRS_NW; ++k) m = fmaxf(m, mx[k]);
+        __syncthreads();
+        int e = 0;
+        (void)frexpf(m, &e);
+        ysc = (m > 0.f && m < 3.0e38f) ? ldexpf(1.f, -e) : 1.f;
+    };
+
     // Z = slab^T Y (32 x RP): 2 RG output tiles (16 columns of the slab x 16 ranks), each wave one tile over its share of K = N; the
     // shares are summed through LDS in wave order.  The B operand - 8 consecutive rows of a rank - is split into fp16 hi + lo on the
     // way from the fp32 matrix.  final_v: the result is V (fp16, into LDS [rank][column] and into the packet / the workspace);
@@ -239,8 +264,8 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             const int ks = ksh + KS * i;
             const int n0 = min(ks, nk32 - 1) * 32 + 8 * lq;
             const h16x8 av = *reinterpret_cast<const h16x8*>(&Dt[(16 * mt + l16) * NPH + n0]);
-            const f32x4 y0 = *reinterpret_cast<const f32x4*>(&Yt[(16 * g + l16) * NPS + n0]);
-            const f32x4 y1 = *reinterpret_cast<const f32x4*>(&Yt[(16 * g + l16) * NPS + n0 + 4]);
+            const f32x4 y0 = *reinterpret_cast<const f32x4*>(&Yt[(16 * g + l16) * NPS + n0]) * ysc;
+            const f32x4 y1 = *reinterpret_cast<const f32x4*>(&Yt[(16 * g + l16) * NPS + n0 + 4]) * ysc;
             h16x8 bh, bl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -524,6 +549,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     product_b(tag0);
     LSTAMP(2);
     allreduce(tag0, false);
+    norm_scale();
     LSTAMP(3);
 
     // ---------------- W1 = A (A^T Y0), Y1 = W1 chol(M1)^-T ----------------
@@ -536,6 +562,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     __syncthreads();
     LSTAMP(14);
     apply_l();                                                        // Y1 = W1 chol(M1)^-T
+    norm_scale();
     LSTAMP(6);
 
     // ---------------- W2 = A (A^T Y1), U = W2 chol(W2^T W2)^-T ----------------
@@ -556,6 +583,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     __syncthreads();
     LSTAMP(9);
     apply_l();                                                        // U, fp32 in place: its fp16 rounding is what the packet carries
+    ysc = 1.f;                                                        // (orthonormal columns: no scale - V = U^T A is wanted as it is)
     if (idx == 0) {
         h16* U16g = a.u_in_packet ? (h16*)it.packet : (h16*)(it.ws + a.offU16);
         for (int i = tid; i < N * r; i += LRS_NT) { const int n = i / r, m = i - n * r; U16g[i] = (h16)Yt[m * NPS + n]; }

@@ -99,6 +99,44 @@ def test_rank_deficient_residual_and_zero_residual():
     assert torch.equal(nb[0], base)
 
 
+@pytest.mark.parametrize("N,C,rank", [(544, 3072, 8), (544, 3072, 16), (512, 1536, 8), (512, 1536, 32)])
+@pytest.mark.parametrize("amp", [0.02, 40.0, 300.0])
+def test_residual_magnitude(N, C, rank, amp):
+    """The iteration is scale-free but its fp16 MFMA operands are not: Y = A Q grows with sigma, A^T Y with sigma^2.  The kernel
+    rescales the N x r matrix by a power of two before every product; residual entries from 1e-3 up to ~100 must give the same
+    projection (relative) and finite packets."""
+    from compactfusion_amd import codecs as K
+    g = torch.Generator().manual_seed(7 + rank)
+    k = 48
+    L = torch.linalg.qr(torch.randn(N, k, generator=g))[0]
+    R = torch.linalg.qr(torch.randn(C, k, generator=g))[0]
+    s = (0.7 if rank <= 16 else 0.85) ** torch.arange(k, dtype=torch.float32)
+    D = ((L * s) @ R.t() * (N * C) ** 0.5 * 0.05 + 1e-3 * torch.randn(N, C, generator=g)) * amp
+    assert float(D.abs().max()) < 6.0e4
+    x = D.half().cuda()
+    base = torch.zeros(N, C, dtype=torch.float16, device="cuda")
+    q0 = torch.zeros(C, K.lr_rank_pad(rank))
+    q0[:, :rank] = torch.linalg.qr(torch.randn(C, rank, generator=g))[0]
+    q0 = q0.cuda()
+    pk, nb = run([x], [base], [q0], N, C, rank)
+    check(x, base, q0, pk[0], nb[0], N, C, rank)
+
+
+def test_exactly_low_rank_large_entries_no_base():
+    """a rank-3 matrix with entries of a few units and no state behind it (the first step of a layer), through the plugin-level
+    entry: used to overflow the fp16 operands of the second product"""
+    from compactfusion_amd.compact.slowpath import slowpath_compress, slowpath_decompress
+    from compactfusion_amd.compact.utils import COMPACT_COMPRESS_TYPE as T
+    g = torch.Generator().manual_seed(3)
+    for (N, C) in ((544, 3072), (512, 1536)):
+        low = (torch.randn(N, 3, generator=g) @ torch.randn(3, C, generator=g)).half().cuda()
+        for rank in (8, 16):
+            pkt = slowpath_compress(low, T.LOW_RANK, rank=rank)
+            assert torch.isfinite(pkt.float()).all()
+            out = slowpath_decompress(pkt, (N, C), T.LOW_RANK, rank=rank)
+            assert rel(out, low) < 2e-3
+
+
 def test_batches_bigger_than_one_launch_and_reproducible():
     """C = 3072: 96 workgroups per tensor, two tensors per launch - a batch of 5 is three launches on the same arena"""
     N, C, rank = 544, 3072, 8
