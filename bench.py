@@ -9,16 +9,20 @@ ring-attention sequence parallelism of logical degree 8 with the 1-bit residual 
 57 attention layers x {K, V}, shard (N, C) = (544, 3072) fp16.  The step is replayed LAYER BY LAYER IN ORDER, the way a
 model runs it (layer l+1's K,V only exist after layer l's attention, reference xfuser/compact/ring.py:188-206): layer l+1's
 compress cannot start before layer l's reconstruction has finished (a kernel boundary), nothing is reordered across layers.
-Per layer (default; the SAME schedule at every N):
+Per layer, the collective in the path at every N:
   A. compress K,V (k_absmean_compress: statistics + sign bits + in-launch finalize of the scales), the packets written straight
-     into the rank's slot of the gather buffer; the PREVIOUS layer's own error-feedback update rides in the same launch - nothing
-     reads that state before the next denoise step (the local attention block uses the uncompressed K,V, ring.py:207-209),
-  X. exchange the packets: ncclAllGather, in place, issued by libcfx's own RCCL communicator from the native plan in stream order
+     into the rank's slot of the gather buffer,
+  X. exchange the packets: ncclAllGather, in place, issued by libcfx's own RCCL communicator from the native plan
      (N live ranks gather for real; the 8-N missing logical peers are looped back from the rank's own slot, so the per-GPU codec
-     work is IDENTICAL for every N = weak scaling; at N = 8 this is exactly the real exchange, at N = 1 RCCL's one-rank in-place
-     all-gather has nothing to move: the step is what N = 8 executes minus the wire),
-  B. ONE launch reconstructs the 7 peers' K,V (14 tensors, k_binary_dequant) onto their state arenas (the last layer's
-     launch also carries that layer's own error-feedback update).
+     work is IDENTICAL for every N = weak scaling; at N = 1 RCCL's one-rank in-place all-gather has nothing to move),
+  B. reconstruct the 7 peers' K,V (14 tensors) onto their state arenas, and the rank's own error-feedback update.
+N = 1 (default, --own-ef xgate): A and B are ONE launch on the run stream (cfx_plan_add_exchange_layer): B's workgroups are launched
+with A's, pull their state tiles into registers while the scale reduction and the collective run, and wait for a gate word; the
+exchange stream runs  flag-wait kernel (A's packets complete) ; ncclAllGather ; flag-set kernel (opens the gate).
+N > 1 (and `two_launches_per_layer` at N = 1): A ; X ; B as two codec launches in stream order, the previous layer's own
+error-feedback update riding in A (nothing reads that state before the next denoise step, ring.py:207-209) - a collective KERNEL finds
+no room beside the waiting workgroups of the one-launch form unless CUs are set aside for it, and setting them aside costs more than
+the hidden preload gains (`with_cu_partition`).
 `loopback_one_launch_per_layer` (secondary, N = 1): the layer as ONE launch (cfx_compress_batch_gated: reconstruction behind an
 in-launch arrival gate) - only possible when the packets a reconstruction needs are produced by the same launch, i.e. with
 looped-back peers and NO collective in between; never `value`.
@@ -50,6 +54,10 @@ import os
 import sys
 import time
 
+# HIP multiplexes streams over a pool of hardware queues; with the variable unset, a stream created after RCCL has initialised can end up
+# time-sliced against the CU-masked exchange stream's queue (measured: the flag-ordered layer launch 24.6 -> 50 us).  Any explicit value
+# restores one queue per stream; must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
@@ -70,8 +78,11 @@ def parse():
     ap.add_argument("--replay", choices=["inorder", "pipelined"], default="inorder",
                     help="inorder (default, the deployable schedule): cfx_plan_run, two launches per layer one after the other; "
                          "pipelined: cfx_plan_run_pipelined, reorders work ACROSS layers (resident synthetic inputs only)")
-    ap.add_argument("--own-ef", choices=["gated", "ride", "inline"], default="ride",
-                    help="inorder replay. gated (1-bit, no collective between compress and reconstruction, i.e. N = 1): ONE launch per layer - "
+    ap.add_argument("--own-ef", choices=["gated", "ride", "inline", "xgate"], default="xgate",
+                    help="inorder replay. xgate (default; 1-bit, all-gather pattern, native exchange - otherwise it behaves as ride): ONE launch per "
+                         "layer with the collective IN the path - the reconstruction workgroups are launched with the compress group, pull their "
+                         "state tiles into registers and wait for a gate the exchange stream sets after ncclAllGather "
+                         "(cfx_plan_add_exchange_layer).  gated (1-bit, no collective between compress and reconstruction, i.e. N = 1): ONE launch per layer - "
                          "the reconstruction of everything whose packet the layer's compress produces (own error feedback + looped-back peers) "
                          "runs in the compress launch behind an arrival gate (cfx_compress_batch_gated); with a collective in between it "
                          "behaves as ride.  ride: the own error-feedback update rides in the NEXT layer's compress launch, two launches "
@@ -184,7 +195,11 @@ def group_recv_offset(l: int, r: int, kv: int, G: int, L: int, live: int, slot: 
 def config_key(args, n_gpus):
     """What a committed profile must have been taken with for its figures to be quoted beside this run's."""
     pipelined = args.replay == "pipelined"
-    return {"codec": args.codec, "replay": args.replay, "own_ef": args.own_ef if not pipelined else None, "layers": args.layers,
+    own_ef = args.own_ef
+    if own_ef == "xgate" and (args.codec != "binary" or args.no_collective or args.exchange != "native" or args.exchange_pattern == "relay"
+                              or n_gpus > 1 or args.emulate_live):
+        own_ef = "ride"
+    return {"codec": args.codec, "replay": args.replay, "own_ef": own_ef if not pipelined else None, "layers": args.layers,
             "shard": [N_TOK, C_CH], "rows": args.rows, "n_gpus": n_gpus, "collective": not args.no_collective}
 
 
@@ -305,8 +320,20 @@ def main():
         return [_lib.DecompItem(peer_packet_ptr(l, p, kv, gathered), peer_base[l, p, kv].data_ptr(), peer_base[l, p, kv].data_ptr())
                 for p in range(W_LOGICAL - 1) for kv in range(2)]
 
-    def add_layer(plan, s_, l, ride, gathered, comm=None, gated=False, relay_=None):
+    def add_layer(plan, s_, l, ride, gathered, comm=None, gated=False, relay_=None, xlayer=False):
         relay_ = relay if relay_ is None else relay_
+        if xlayer:
+            # ONE op: compress + own EF ; all-gather ; reconstruct 14 - the reconstruction group launched with the compress group,
+            # gated on the collective's arrival (cfx_plan_add_exchange_layer)
+            assert gathered and not int2
+            carr = comp_items(s_, l, True)
+            for kv in range(2):
+                carr[kv].new_base = own_base[l, kv].data_ptr()
+            items = peer_items(l, True)
+            rc = lib.cfx_plan_add_exchange_layer(plan, CODEC, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, carr, len(items), (_lib.DecompItem * len(items))(*items),
+                                                 comm, own_pkt_ptr(l, 0, True), grecv.data_ptr() + l * live * 2 * slot, 2 * slot, ws.data_ptr(), ws_bytes)
+            assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
+            return
         """Layer l of the in-order schedule: A = compress (+ previous layer's own EF riding along), X = all-gather, B = reconstruct;
         gated (no X): one launch = A + the 16 reconstructions behind the arrival gate."""
         if gated:
@@ -360,8 +387,15 @@ def main():
         rc = lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, len(items), darr)
         assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
 
+    # more than one live rank: the collective is a KERNEL (rcclGenericKernel: 256 threads x ~280 VGPRs) that finds no room beside the
+    # waiting reconstruction workgroups of a flag-ordered layer launch unless CUs are set aside for it, and a CU-masked run stream costs
+    # the layer launch more than the hidden state preload gains (`with_cu_partition` below): those runs keep two launches per layer
+    xgate = (args.own_ef == "xgate" and not pipelined and not int2 and use_dist and not relay and args.exchange == "native" and live == 1)
+    if args.own_ef == "xgate" and not xgate:
+        args.own_ef = "ride"
     ride = args.own_ef in ("ride", "gated")
     gated = args.own_ef == "gated" and not pipelined and not use_dist
+    one_launch = gated or xgate
     # ---- native plans without collectives (one per input set) -----------------------------------------------------------------
     #   inorder:   per layer  A(l) [+ EF(l-1)] ; B(l)                        (ops 2l, 2l+1)
     #   pipelined: per layer  compress(l) ; reconstruct own + peers (16)     (the op pattern cfx_plan_run_pipelined recognises)
@@ -380,6 +414,14 @@ def main():
     plans_gated = build_plans("gated") if (gated or (real_live == 1 and not args.emulate_live and not pipelined and not args.no_secondary)) else None
     plans = plans_pipe if pipelined else (plans_gated if gated else plans_inorder)
 
+    xside = None
+    if xgate:
+        # the exchange-layer op orders its two streams by flag words: the run stream must not be the legacy NULL stream (it serialises
+        # with every blocking stream, the CU-masked exchange stream included)
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
+        hx = ctypes.c_void_p()
+        assert lib.cfx_stream_create_masked(ctx, 0, 256, ctypes.byref(hx)) == 0      # ONE exchange stream for every plan: each stream is a hardware queue
+        xside = hx.value
     compute = torch.cuda.current_stream(dev)
     sh = compute.cuda_stream
 
@@ -400,14 +442,20 @@ def main():
                     native_comm.self_test()
                 groups = [(a, min(L, a + G)) for a in range(0, L, G)]
 
-                def build_step_plans(mode, relay_=None):
+                def build_step_plans(mode, relay_=None, xlayer=None, comm_=True, side_=None):
+                    xlayer = (xgate if xlayer is None else xlayer) and not (relay if relay_ is None else relay_)
+                    side_ = side_ or xside
                     built = []
                     for s_ in range(2):
                         sp = lib.cfx_plan_create(ctx)
-                        assert lib.cfx_plan_set_exchange_stream(sp, mode) == 0
+                        if xlayer and side_:
+                            assert lib.cfx_plan_use_exchange_stream(sp, side_) == 0
+                        elif not xlayer:
+                            assert lib.cfx_plan_set_exchange_stream(sp, mode) == 0
                         if not pipelined:
                             for l in range(L):
-                                add_layer(sp, s_, l, ride, True, native_comm.handle, relay_=relay_)
+                                add_layer(sp, s_, l, ride or xgate, True, native_comm.handle if comm_ else None, relay_=relay_,
+                                          xlayer=xlayer)
                         else:
                             for a, b in groups:
                                 for l in range(a, b):
@@ -524,7 +572,7 @@ def main():
     # ---- timed region -------------------------------------------------------------------------------------------
     # profiled kernels: in-order replay: k_binary_dequant (4, launch B, dominant) and k_absmean_compress<bits> (27, launch A);
     # pipelined replay: the fused k_binary_pipe (23: full three-group launches; 24: prologue / epilogue / ragged launches)
-    KIDS = (23, 24) if pipelined else ((31,) if gated else ((6, 28, 5) if int2 else (4, 27)))
+    KIDS = (23, 24) if pipelined else ((31,) if one_launch else ((6, 28, 5) if int2 else (4, 27)))
     prof_cap = (args.steps * 2 * L) // max(1, args.event_stride) + 64
     if not args.no_kernel_events:
         mask = 0
@@ -535,7 +583,7 @@ def main():
     step_events = []          # gated schedule: hipEvents on the launch stream around every 4th step (every launch of a step is the
     t0 = time.perf_counter()  # same kernel, so elapsed / layers = its average duration with the kernel boundaries in)
     for i in range(args.steps):
-        if gated and not args.no_kernel_events and i % 4 == 1:
+        if one_launch and not args.no_kernel_events and i % 4 == 1:
             ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ea.record(compute)
             one_step(steps_run + i)
@@ -577,7 +625,7 @@ def main():
         return dt * 1e3 / n_steps
 
     # ---- secondary legs (no events): a long run of the same replay, the other replay ------------------------------------------
-    long_ms, other_ms, two_ms, loop_ms = None, None, None, None
+    long_ms, other_ms, two_ms, loop_ms, relay_ms, part_ms = None, None, None, None, None, None
     if not args.no_secondary:
         base_step = steps_run
         long_ms = timed_leg(args.long_steps, lambda i: one_step(base_step + i))
@@ -604,6 +652,30 @@ def main():
                 loop_ms = side_leg(plans_gated, lib.cfx_plan_run, "plan_run(one launch per layer, loop-back)")
             if gated:
                 two_ms = side_leg(plans_inorder, lib.cfx_plan_run, "plan_run(two launches)")
+            if xgate and build_step_plans is not None:
+                def step_leg(plset, what, stream_handle=sh):
+                    nonlocal steps_run
+                    b0 = steps_run
+                    fn = lambda i: check(lib.cfx_plan_run(plset[(b0 + i) & 1], 0, lib.cfx_plan_size(plset[0]), stream_handle), what)      # noqa: E731
+                    for i in range(2):
+                        fn(i)
+                    b0 += 2
+                    ms_ = timed_leg(args.steps, fn)
+                    steps_run += 2 + args.steps
+                    for pl_ in plset:
+                        lib.cfx_plan_destroy(pl_)
+                    return ms_
+                # the same step, collective in the path, as two launches per layer in stream order (round 2's deployable schedule)
+                two_ms = step_leg(build_step_plans(0, xlayer=False), "plan_run(two launches, collective in the path)")
+                # no communicator: the exchange stream only relays the flag (one kernel instead of wait ; ncclAllGather ; set)
+                relay_ms = step_leg(build_step_plans(0, comm_=False), "plan_run(exchange layer, flag relay)")
+                # the configuration a run with MORE than one rank uses: run stream on CUs [0, 224), exchange stream on the other 32
+                hm, hx = ctypes.c_void_p(), ctypes.c_void_p()
+                assert lib.cfx_stream_create_masked(ctx, 0, 224, ctypes.byref(hm)) == 0 and lib.cfx_stream_create_masked(ctx, 224, 32, ctypes.byref(hx)) == 0
+                torch.cuda.synchronize(dev)
+                part_ms = step_leg(build_step_plans(0, side_=hx.value), "plan_run(exchange layer, CU partition)", hm.value)
+                torch.cuda.synchronize(dev)
+                lib.cfx_stream_destroy(ctx, hm); lib.cfx_stream_destroy(ctx, hx)
     torch.cuda.synchronize(dev)
     ge = lib.cfx_gate_errors(ctx)
     if ge != 0:
@@ -695,15 +767,33 @@ def main():
                      ("layer by layer in order, LOOP-BACK ONLY (no collective can sit inside it): ONE launch per layer = compress K,V [statistics + sign bits + in-launch "
                       "finalize] + the 16 reconstructions its packets feed (own error feedback, 7 looped-back peers' K,V): their workgroups "
                       "pull the state tiles into registers while the scale reduction completes, wait on an arrival gate, finish from registers") if gated else
+                     ("layer by layer in order (deployable), the collective in the path: per layer ONE codec launch on the run stream = compress K,V "
+                      "[statistics + sign bits + in-launch finalize; packets written straight into the rank's slot of the gather buffer] + own "
+                      "error-feedback update + reconstruction of the 7 peers' K,V, whose workgroups pull their state tiles into registers and "
+                      "then wait for a gate word; on the exchange stream: flag-wait kernel (this launch's packets complete) ; X = " + XNAME +
+                      " ; flag-set kernel (opens the gate).  " +
+                      "One live rank: the collective enqueues no kernel, so no CUs are set aside for one.  Runs with more than one rank keep "
+                      "`two_launches_per_layer` (an RCCL kernel finds no room beside the waiting workgroups without a CU partition, and "
+                      "`with_cu_partition` is slower than two launches)") if xgate else
                      "layer by layer in order (deployable): per layer A = compress K,V [statistics + sign bits + in-launch finalize"
                      + (" + previous layer's own error-feedback update riding along" if ride else "") + "], X = " + XNAME + ", B = reconstruct "
                      + ("7 peers' K,V" if ride else "own + 7 peers' K,V")),
-        "launches_per_layer": None if pipelined else (1 if gated else (3 if int2 else 2)),
+        "launches_per_layer": None if pipelined else (1 if one_launch else (3 if int2 else 2)),
         "two_launches_per_layer": None if two_ms is None else {
             "ms_per_step": round(two_ms, 4),
             "what": ("the same layer-ordered step as A1 = statistics + finalize ; A2 = quantise + error feedback ; B = reconstruct 7 peers" if int2 else
                      "the same layer-ordered step as A = compress (+ previous layer's own error feedback riding along) ; B = reconstruct 7 peers")
-                    + " - the schedule a collective between compress and reconstruction forces (N > 1)"},
+                    + (" ; the collective between them, everything in stream order - what runs with more than one rank execute, minus the wire" if xgate else
+                       " - the schedule a collective between compress and reconstruction forces (N > 1)")},
+        "flag_relay_no_communicator": None if relay_ms is None else {
+            "ms_per_step": round(relay_ms, 4),
+            "what": "the same exchange-layer plans built WITHOUT a communicator: the exchange stream runs one relay kernel per layer (wait + set) instead of "
+                    "flag-wait kernel ; ncclAllGather ; flag-set kernel - what the two kernel boundaries around the collective cost"},
+        "with_cu_partition": None if part_ms is None else {
+            "ms_per_step": round(part_ms, 4),
+            "what": "the same exchange-layer plans with the run stream masked to CUs [0, 224) and the exchange stream to [224, 256) - what it would take for "
+                    "RCCL's kernel (256 threads x ~280 VGPRs) to always find room beside the waiting workgroups at N > 1; slower than two launches "
+                    "per layer (any partial CU mask costs this launch ~5 us), so N > 1 runs use two launches"},
         "inorder_ms_per_step": None if inorder_ms is None else round(inorder_ms, 4),
         "pure_exchange_upper_bound": None if pipe_ms is None else {
             "ms_per_step": round(pipe_ms, 4),
@@ -747,7 +837,7 @@ def main():
     step_obj = {"algorithmic_bytes": int(step_alg), "achieved": round(step_alg / (ms_per_step * 1e-3) / 1e9, 1), "unit": "GB/s",
                 "frac": round(step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "floor_ms_at_peak": round(step_alg / (HBM_PEAK_GBS * 1e9) * 1e3, 4)}
-    dom = 23 if pipelined else (31 if gated else (6 if int2 else 4))
+    dom = 23 if pipelined else (31 if one_launch else (6 if int2 else 4))
     if dom in kern_us:
         us, n_samples = kern_us[dom]
         if pipelined:
@@ -761,6 +851,11 @@ def main():
             alg = (ALG_BYTES_PER_EL["decompress"] * 14 + ALG_BYTES_PER_EL["compress"] * 2) * ul * EL
             kname = (f"k_binary_pipe (one launch = {ul} layers: dequant+add of {16 * ul} tensors x (544,3072) + finalize of the next {ul} "
                      f"layers' K,V scales + stats/sign bits of the {ul} layers after those)")
+        elif xgate:
+            alg = (ALG_BYTES_PER_EL["compress"] * 2 + ALG_BYTES_PER_EL["decompress"] * 14) * EL
+            kname = ("k_absmean_compress<bits,gated> (the layer's only codec launch: compress + error feedback of own K,V at " + str(ALG_BYTES_PER_EL["compress"]) +
+                     " B/el, 7 peers' K,V at " + str(ALG_BYTES_PER_EL["decompress"]) + " B/el; between reading K,V and the first reconstructed byte sit a global "
+                     "reduction - the scales - and the collective's arrival)")
         elif gated:
             alg = (ALG_BYTES_PER_EL["compress"] * 2 + ALG_BYTES_PER_EL["decompress"] * 14) * EL
             kname = (("k_int2_compress_gated" if int2 else "k_absmean_compress<bits,gated>") + " (the layer's only launch: compress + error feedback of own K,V at " + str(ALG_BYTES_PER_EL["compress"]) + " B/el, "
@@ -779,7 +874,7 @@ def main():
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            "traffic": None, "traffic_source": None, "avg_launch_us": round(us, 3), "algorithmic_bytes_per_launch": int(alg),
                            "event_samples": n_samples, "event_stride": args.event_stride, "step": step_obj}
-        if gated and step_events:
+        if one_launch and step_events:
             # one launch per layer: hipEvents around whole steps / the launches of a step = the launch duration with the kernel
             # boundaries in (what rocprofv3's per-kernel durations add up to); a dispatch that itself carries profiling events runs
             # ~1.5 us longer on this kernel, so the roofline uses the step-bracketing events and keeps the other figure beside it
@@ -811,7 +906,7 @@ def main():
             try:
                 pj = json.load(open(prof))
                 if pj.get("config") == cfg_key:
-                    pk_ = "k_binary_pipe<true>" if pipelined else (("k_int2_compress_gated" if int2 else "k_absmean_compress<true, 4, true") if gated else "k_binary_dequant")
+                    pk_ = "k_binary_pipe<true>" if pipelined else (("k_int2_compress_gated" if int2 else "k_absmean_compress<true, 4, true") if one_launch else "k_binary_dequant")
                     out["roofline"]["traffic"] = next((v for k_, v in pj["bytes_per_launch"].items() if k_.startswith(pk_)), None)
                     out["roofline"]["traffic_source"] = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
                     out["roofline"]["step"]["traffic"] = pj.get("bytes_per_step")
@@ -822,7 +917,7 @@ def main():
             try:
                 tj = json.load(open(trace_json))
                 if tj.get("config") == cfg_key:
-                    pk_ = "k_binary_pipe<true>" if pipelined else (("k_int2_compress_gated" if int2 else "k_absmean_compress<true, 4, true") if gated else "k_binary_dequant")
+                    pk_ = "k_binary_pipe<true>" if pipelined else (("k_int2_compress_gated" if int2 else "k_absmean_compress<true, 4, true") if one_launch else "k_binary_dequant")
                     ent = next((v for k_, v in tj["kernels"].items() if k_.startswith(pk_)), None)
                     if ent:
                         out["roofline"]["avg_launch_us_rocprof"] = ent["avg_us"]

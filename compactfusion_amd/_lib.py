@@ -83,6 +83,10 @@ SYMBOLS = [
                                                   ctypes.POINTER(DecompItem), ctypes.c_void_p, ctypes.c_size_t]),
     ("cfx_plan_set_exchange_stream", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_plan_use_exchange_stream", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    ("cfx_plan_add_exchange_layer", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_int, ctypes.POINTER(DecompItem),
+                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                                   ctypes.c_void_p, ctypes.c_size_t]),
     ("cfx_plan_add_all_gather", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     ("cfx_plan_add_wait", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_plan_add_ring_hop", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),

@@ -144,10 +144,15 @@ struct cfx_comm {
     RcclApi api;
 };
 
+// what an exchange-layer launch tells its caller: the packets of the launch are complete once counter *p_gate has reached p_expect;
+// the gated reconstruction group proceeds once *f_gate == f_expect
+struct CfxXGate { int taken; unsigned* p_gate; unsigned p_expect; unsigned* f_gate; unsigned f_expect; };
 struct PlanOp {
     int kind;   // 0 compress, 1 decompress, 2 all-gather on the side stream, 3 main stream waits for gather op `ref`, 4 ring hop,
                 // 5 wait until flag `ref` has reached the plan's epoch, 6 set flag `ref` to the epoch,
-                // 7 low-rank compress (codec = quantized, param = rank), 8 low-rank decompress
+                // 7 low-rank compress (codec = quantized, param = rank), 8 low-rank decompress,
+                // 9 exchange layer: compress (c) ; all-gather (comm, send, recv; comm NULL = none) ; reconstruct (g) - one launch on the
+                //   main stream whose reconstruction group preloads its state and waits for the collective's arrival
     int codec, N, C, param, flags, batch;
     cfx_comp_item c[CFX_MAX_BATCH];
     cfx_decomp_item d[CFX_MAX_BATCH];     // kind 1: the items; kind 0: ride-along reconstruction items (n_ride of them)
@@ -206,9 +211,11 @@ CFX_HIDDEN unsigned* cfx_i_ticket_block(cfx_ctx* ctx, void* stream);
 CFX_HIDDEN int cfx_i_stream_cus(cfx_ctx* ctx, void* stream);
 CFX_HIDDEN int cfx_i_decompress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items, void* stream,
                                      unsigned* pre, unsigned pre_val);
+// `xg` != NULL: the gated items wait on an EXTERNAL gate (their packets are delivered by a collective behind this launch), see
+// compress_impl in cfx_kernels.hip; xg->taken == 0 on return: only the compress part was launched
 CFX_HIDDEN int cfx_i_compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                                    int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
-                                   void* workspace, size_t workspace_bytes, void* stream);
+                                   void* workspace, size_t workspace_bytes, void* stream, CfxXGate* xg = nullptr);
 CFX_HIDDEN int cfx_i_launch_pipe(cfx_plan* p, hipStream_t s, int N, int C, const int* comp_op, const int* deq_op,
                                  const PipeUnit* dq, const PipeUnit* fin, const PipeUnit* st, int fin_parity, int st_parity,
                                  hipEvent_t done_ev);

@@ -1039,6 +1039,10 @@ struct FusedArgs {
     unsigned* gate;
     unsigned gate_expect;
     unsigned* gate_err;
+    // external gate (exchange-layer op, cfx_plan_add_exchange_layer): the gated group waits for this word instead of the arrival
+    // counter - whoever moves the packets (a collective on the exchange stream) sets it once they have arrived.  NULL: wait on `gate`.
+    unsigned* xgate;
+    unsigned xexpect;
 };
 #ifndef GATE_WPE
 #define GATE_WPE 4               // waves per SIMD the single-launch compress kernels are compiled for (2 workgroups / CU)
@@ -1063,7 +1067,8 @@ __global__ __launch_bounds__(FUSED_NT, GATE_WPE) void k_absmean_compress(BatchC 
                 const int per = a.CB * a.g_rb;
                 const int item = b / per, rem = b - item * per;
                 const int ty = rem / a.CB;
-                binary_dequant_gated_body<FUSED_NW, GATE_KR, 0, ST>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.gate, a.gate_expect, a.gate_err,
+                binary_dequant_gated_body<FUSED_NW, GATE_KR, 0, ST>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.xgate ? a.xgate : a.gate,
+                                                            a.xgate ? a.xexpect : a.gate_expect, a.gate_err,
                                                             nullptr,
                                                             a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr);
                 return;
@@ -2208,9 +2213,14 @@ static unsigned ticket_slot(cfx_ctx* ctx, void* stream) {
     return slot;
 }
 
+// `xg` (exchange-layer op): the gated items' packets are NOT produced by this call but delivered by somebody else (a collective) once
+// this call's packets are complete.  If the one-launch form is possible, the gated group waits on an external gate word and *xg
+// says what to wait for (packets complete: counter p_gate has reached p_expect) and what to set afterwards (f_gate = f_expect);
+// otherwise only the compress part is launched, xg->taken stays false and the caller reconstructs after its collective.
 static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                          int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
-                         void* workspace, size_t workspace_bytes, void* stream) {
+                         void* workspace, size_t workspace_bytes, void* stream, CfxXGate* xg = nullptr) {
+    if (xg) memset(xg, 0, sizeof(*xg));
     if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "compress: null ctx/items");
     if (n_gated < 0 || n_gated > CFX_MAX_BATCH || (n_gated && !gated)) return fail(ctx, CFX_ERR_BATCH, "compress: gated batch out of range");
     if (n_gated && codec != CFX_CODEC_BINARY && codec != CFX_CODEC_INT2)
@@ -2297,6 +2307,10 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
     // the 1-bit layer launch needs no co-residency (its statistics workgroups never wait), but its gated workgroups spin on slots the
     // statistics group needs when the stream has few CUs: a CU-masked lane runs the multi-launch form
     if (one_launch && stream_cus < 128) one_launch = false;
+    if (xg && !(one_launch && fused && codec == CFX_CODEC_BINARY && (!upd || (!(flags & CFX_FLAG_NO_EF) && n_gated + batch <= CFX_MAX_BATCH)))) {
+        n_gated = 0;            // compress only: the caller runs its collective and the reconstruction behind this launch
+        one_launch = false;
+    }
     const dim3 grid(CB, P, batch);
     const int Rq = auto_rows(ctx, N, C, batch, true);       // apply passes: same tile map as the (unfused) statistics pass
     const dim3 gridq(CB, (N + Rq - 1) / Rq, batch);
@@ -2351,6 +2365,13 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                     a.gate = ctx->gate + (size_t)slot * GATE_STRIDE;
                 ctx->gate_expect[2 * slot] += (unsigned)batch * (unsigned)(CB + 1);
                 a.gate_expect = ctx->gate_expect[2 * slot];
+                if (xg) {
+                    a.xgate = a.gate + GATE_BLOCK;                    // the slot's second gate block (the 2-bit layer launch's gate 2)
+                    a.xexpect = ++ctx->gate_expect[2 * slot + 1];
+                    xg->taken = 1;
+                    xg->p_gate = a.gate; xg->p_expect = a.gate_expect;
+                    xg->f_gate = a.xgate; xg->f_expect = a.xexpect;
+                }
             }
             a.gate_err = ctx->gate_err;
             const dim3 g(a.n_st + a.n_g + CB * a.dq_rb * n_ride);
@@ -2467,8 +2488,8 @@ size_t cfx_i_ws_words(int codec, int N, int C) { return ws_words(codec, N, C); }
 int cfx_i_stream_cus(cfx_ctx* ctx, void* stream) { return stream_cu_count(ctx, stream); }
 int cfx_i_compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                         int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
-                        void* workspace, size_t workspace_bytes, void* stream) {
-    return compress_impl(ctx, codec, N, C, param, flags, batch, items, n_ride, ride, n_gated, gated, workspace, workspace_bytes, stream);
+                        void* workspace, size_t workspace_bytes, void* stream, CfxXGate* xg) {
+    return compress_impl(ctx, codec, N, C, param, flags, batch, items, n_ride, ride, n_gated, gated, workspace, workspace_bytes, stream, xg);
 }
 // One fused launch of the software-pipelined replay (cfx_plan_run_pipelined, cfx_plan.hip): [dequant(dq) | finalize(fin) | stats(st)]
 int cfx_i_launch_pipe(cfx_plan* p, hipStream_t s, int N, int C, const int* comp_op, const int* deq_op,

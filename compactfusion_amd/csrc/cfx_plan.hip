@@ -58,6 +58,20 @@ __global__ void k_flag_wait(const unsigned* flag, unsigned v, unsigned* err, lon
     }
 }
 
+// wait + set in one launch: what sits between "packets complete" and "packets arrived" when no collective kernel does
+__global__ void k_flag_relay(const unsigned* wait, unsigned wv, unsigned* set, unsigned sv, unsigned* err, long long timeout) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - wv) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > timeout) {
+            if (err) (void)__hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+    __hip_atomic_store(set, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 static int gate_check(cfx_ctx* ctx, const char* what) {
     if (ctx->gate_err && *(volatile unsigned*)ctx->gate_err) {
         char buf[200];
@@ -214,6 +228,38 @@ int cfx_plan_add_lr_decompress(cfx_plan* p, int quantized, int N, int C, int ran
     return p->n - 1;
 }
 
+// Exchange layer: compress ; all-gather ; reconstruct as ONE op (the in-order layer of the ring / patch gather schedules, reference
+// ring.py:188-206 + 265-269, patchpara/fwd.py:108-137).  The reconstruction workgroups are launched WITH the compress group: they pull
+// their state tiles into registers while the statistics chain and the collective run, and continue when the exchange stream - which
+// waits for the launch's packets, issues the collective and then sets the launch's external gate - says the packets have arrived.
+int cfx_plan_add_exchange_layer(cfx_plan* p, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                                int n_recon, const cfx_decomp_item* recon, cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank,
+                                void* workspace, size_t workspace_bytes) {
+    if (!p) return CFX_ERR_NULL;
+    if (n_recon < 1 || n_recon > CFX_MAX_BATCH || !recon) return fail(p->ctx, CFX_ERR_BATCH, "plan: exchange layer needs 1..CFX_MAX_BATCH reconstruction items");
+    if (codec != CFX_CODEC_BINARY) return fail(p->ctx, CFX_ERR_CODEC, "plan: the exchange layer op is built for the 1-bit codec");
+    if (comm && (!send || !recv)) return fail(p->ctx, CFX_ERR_NULL, "plan: exchange layer: null send/recv");
+    if (!p->side) {
+        // the flag kernels poll: they need a hardware queue of their own (cfx.h, exchange lane) - a CU-masked stream has one
+        void* xs = nullptr;
+        int total = 0;
+        (void)hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, p->ctx->device);
+        const int rc = cfx_stream_create_masked(p->ctx, 0, total, &xs);
+        if (rc != CFX_OK) return rc;
+        p->side = (hipStream_t)xs;
+        p->side_owned = true;
+        if (p->side_mode == 0) p->side_mode = 1;
+    }
+    const int op = cfx_plan_add_compress(p, codec, N, C, param, flags, batch, items, workspace, workspace_bytes);
+    if (op < 0) return op;
+    PlanOp* o = &p->ops[op];
+    o->kind = 9;
+    o->n_gated = n_recon;
+    memcpy(o->g, recon, sizeof(cfx_decomp_item) * n_recon);
+    o->comm = comm; o->send = send; o->recv = recv; o->bytes_per_rank = bytes_per_rank;
+    return op;
+}
+
 int cfx_plan_size(const cfx_plan* p) { return p ? p->n : CFX_ERR_NULL; }
 
 // append a copy of a compress / decompress op of another plan (to build differently ordered schedules from one op set)
@@ -367,6 +413,57 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                 break;
             case 7: rc = cfx_lr_compress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, o->q0, o->ws, o->ws_bytes, stream); break;
             case 8: rc = cfx_lr_decompress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->batch, o->d, o->ws, o->ws_bytes, stream); break;
+            case 9: {
+                CfxXGate xg;
+                memset(&xg, 0, sizeof(xg));
+                // (the legacy NULL stream serialises with the CU-masked exchange stream: a flag kernel there would wait for the very launch
+                // it is meant to release - run in order instead)
+                const bool own_stream = p->side && stream != nullptr && (hipStream_t)stream != p->side && !inline_exchange;
+                if (!own_stream && o->comm) {
+                    // in order on the run stream: compress ; all-gather ; reconstruct
+                    rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, 0, nullptr, 0, nullptr, o->ws, o->ws_bytes, stream);
+                    if (rc != CFX_OK) break;
+                    const int r = o->comm->api.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, main_s);
+                    if (r != 0) return fail(p->ctx, CFX_ERR_LAUNCH, "ncclAllGather failed (exchange layer, in order)");
+                    rc = cfx_i_decompress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->n_gated, o->g, stream, nullptr, 0u);
+                    break;
+                }
+                rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, 0, nullptr, o->n_gated, o->g, o->ws, o->ws_bytes, stream,
+                                   own_stream ? &xg : nullptr);
+                if (rc != CFX_OK || !own_stream) break;       // (no exchange stream, no collective: the ordinary gated launch)
+                hipStream_t xs = xg.taken ? p->side : main_s;
+                // with a communicator: wait kernel ; ncclAllGather ; set kernel - the same three enqueues at every world size (a one-rank
+                // in-place all-gather enqueues nothing; CFX_XGATE_FUSE_ONE_RANK=1, developer: treat it like "no communicator")
+                static const bool fuse_one = getenv("CFX_XGATE_FUSE_ONE_RANK") != nullptr;
+                const bool moves = o->comm && !(fuse_one && o->comm->nranks == 1);
+                if (xg.taken) {
+                    if (!moves) {
+                        hipLaunchKernelGGL(k_flag_relay, dim3(1), dim3(64), 0, xs, (const unsigned*)xg.p_gate, xg.p_expect, xg.f_gate, xg.f_expect,
+                                           p->ctx->gate_err, p->ctx->gate_timeout);
+                    } else {
+                        hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, xs, (const unsigned*)xg.p_gate, xg.p_expect, p->ctx->gate_err, p->ctx->gate_timeout);
+                    }
+                    rc = check_launch(p->ctx, "exchange layer: flag launch");
+                    if (rc != CFX_OK) break;
+                }
+                if (o->comm && (moves || !xg.taken)) {
+                    const int r = o->comm->api.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, xs);
+                    if (r != 0) {
+                        char buf[200];
+                        snprintf(buf, sizeof(buf), "ncclAllGather: %s", o->comm->api.GetErrorString ? o->comm->api.GetErrorString(r) : "error");
+                        return fail(p->ctx, CFX_ERR_LAUNCH, buf);
+                    }
+                }
+                if (xg.taken) {
+                    if (moves) {
+                        hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, xs, xg.f_gate, xg.f_expect);
+                        rc = check_launch(p->ctx, "exchange layer: flag set launch");
+                    }
+                } else {
+                    // the launch could not carry the reconstruction (shape / stream without the one-launch form): in order on the main stream
+                    rc = cfx_i_decompress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->n_gated, o->g, stream, nullptr, 0u);
+                }
+            } break;
         }
         if (rc != CFX_OK) return rc;
     }

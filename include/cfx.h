@@ -250,6 +250,22 @@ int       cfx_plan_set_exchange_stream(cfx_plan* plan, int mode);
 int       cfx_plan_use_exchange_stream(cfx_plan* plan, void* stream);
 int       cfx_plan_add_all_gather(cfx_plan* plan, cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank);
 int       cfx_plan_add_wait(cfx_plan* plan, int gather_op);
+/* Exchange layer: compress ; all-gather ; reconstruct as ONE op - the in-order layer of the gather schedules (reference
+ * xfuser/compact/ring.py:188-206 + 265-269, patchpara/fwd.py:108-137: quantise, exchange, dequantise every peer's shard onto its
+ * state).  The reconstruction workgroups are launched WITH the compress group on the stream cfx_plan_run is given: they pull their
+ * state tiles into registers while the statistics chain and the collective run, and continue when the plan's exchange stream - which
+ * waits (a flag kernel) until the launch's packets are complete, issues ncclAllGather(send, recv, bytes_per_rank) and then sets the
+ * launch's external gate - says the packets have arrived.  `recon` items read their packets from wherever the collective leaves them
+ * (or from this op's own packet operands: with CFX_FLAG_UPDATE_CACHE the rank's own error-feedback update joins them).  comm NULL or
+ * a one-rank communicator: nothing moves, the exchange stream only relays the flag.  1-bit codec.  When the one-launch form is not
+ * available (shape without it, a run stream masked below 128 CUs, cfx_plan_run_async / _lane) the op runs as compress ; all-gather ;
+ * reconstruct in order - same results.  The exchange stream must own a hardware queue (see "Exchange lane" below): the plan creates a
+ * CU-masked one unless cfx_plan_use_exchange_stream supplied it.  A gate that never opens times out like any flag wait
+ * (CFX_ERR_GATE at the next call).  Returns the op index. */
+int       cfx_plan_add_exchange_layer(cfx_plan* plan, int codec, int N, int C, int param, int flags, int batch,
+                                      const cfx_comp_item* items, int n_recon, const cfx_decomp_item* recon,
+                                      cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank,
+                                      void* workspace, size_t workspace_bytes);
 /* One hop of the ring relay (reference xfuser/compact/ring.py:193-195,265-269: RingComm.send_recv / commit / wait): send
  * `bytes` to rank+1 and receive `bytes` from rank-1 as one grouped ncclSend + ncclRecv, on the exchange stream like an
  * all-gather op (cfx_plan_add_wait applies).  W-1 hops relay every rank's packet around the ring. */

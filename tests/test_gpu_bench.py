@@ -31,13 +31,23 @@ def _bench(*args):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def test_bench_two_launch_schedule_still_selectable():
+    d = _bench("--own-ef", "ride", "--no-cpu-baseline")
+    assert "ncclAllGather" in d["schedule"] and d["launches_per_layer"] == 2 and "k_binary_dequant" in d["roofline"]["kernel"]
+
+
 def test_bench_default_line_has_the_collective_in_its_schedule():
     d = _bench()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"]
-    assert "ncclAllGather" in d["schedule"] and d["exchange_issued_by"] == "native" and d["launches_per_layer"] == 2
+    # N = 1: the layer is ONE codec launch gated on the collective's arrival (exchange-layer op); the two-launch form, the flag relay and
+    # the CU-partitioned configuration ride along as secondary legs
+    assert "ncclAllGather" in d["schedule"] and "flag-wait kernel" in d["schedule"] and d["exchange_issued_by"] == "native" and d["launches_per_layer"] == 1
+    for k in ("two_launches_per_layer", "flag_relay_no_communicator", "with_cu_partition"):
+        assert d[k]["ms_per_step"] > 0, k
+    assert "k_absmean_compress<bits,gated>" in d["roofline"]["kernel"]
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["peak"] == 8000.0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and "parity_spot_check" in d["cpu_baseline"]
     assert d["loopback_one_launch_per_layer"]["ms_per_step"] > 0 and d["pure_exchange_upper_bound"]["ms_per_step"] > 0
@@ -47,6 +57,7 @@ def test_bench_default_line_has_the_collective_in_its_schedule():
 def test_bench_n_gt_1_plumbing_over_the_loopback_library(live, pattern):
     d = _bench("--emulate-live", str(live), "--rccl-lib", _fake(), "--exchange-pattern", pattern, "--no-cpu-baseline")
     assert d["n_gpus"] == 1 and d["exchange_pattern"] == pattern and d["exchange_issued_by"] == "native"
+    assert d["launches_per_layer"] == 2          # more than one live rank: two codec launches per layer around the collective
     x = d["xgmi"]
     assert x["pattern"] == pattern and x["links"] == (1 if pattern == "relay" else min(live - 1, 7))
     assert set(x["compressed"]) == {"allgather", "relay"} and set(x["raw"]) == {"allgather", "relay"}

@@ -94,6 +94,18 @@ int main() {
         where(nm, sm, d_out, nblk);
         CK(hipStreamDestroy(sm));
     }
+    {   // whole XCDs taken out (bit i = CU i/8 of XCD i%8: XCD x is bit x of every byte), and one single CU taken out
+        const uint32_t pats[4] = {0x7f7f7f7fu, 0xfefefefeu, 0x3f3f3f3fu, 0xffffffffu};
+        const char* nms[4] = {"all but XCD 7", "all but XCD 0", "all but XCD 6,7", "all but bit 255"};
+        for (int t = 0; t < 4; ++t) {
+            uint32_t mask[8];
+            for (int i = 0; i < 8; ++i) mask[i] = pats[t];
+            if (t == 3) mask[7] = 0x7fffffffu;
+            hipStream_t sm;
+            if (hipExtStreamCreateWithCUMask(&sm, 8, mask) == hipSuccess) { where(nms[t], sm, d_out, nblk); CK(hipStreamDestroy(sm)); }
+            else printf("%s: mask rejected\n", nms[t]);
+        }
+    }
     {   // the complement of the low 64 bits
         uint32_t mask[8];
         for (int i = 0; i < 8; ++i) mask[i] = i < 2 ? 0u : 0xffffffffu;
