@@ -908,7 +908,10 @@ def main():
                 if pj.get("config") == cfg_key:
                     pk_ = "k_binary_pipe<true>" if pipelined else (("k_int2_compress_gated" if int2 else "k_absmean_compress<true, 4, true") if one_launch else "k_binary_dequant")
                     out["roofline"]["traffic"] = next((v for k_, v in pj["bytes_per_launch"].items() if k_.startswith(pk_)), None)
-                    out["roofline"]["traffic_source"] = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                    out["roofline"]["traffic_source"] = ("profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes" +
+                                                         ("; " + pj["measured_with"] + ")" if pj.get("measured_with") else " of this command)"))
+                    if pj.get("measured_with"):
+                        out["roofline"]["step"]["traffic_source"] = "the same counter passes (loop-back form of the step: no flag kernels, no collective call)"
                     out["roofline"]["step"]["traffic"] = pj.get("bytes_per_step")
             except Exception:
                 pass
@@ -953,6 +956,12 @@ def main():
                                                        f"{steps_run} steps of this run == C oracle replay, bit for bit")
     # tear the communicators down first and flush C stdio (RCCL prints a version banner through its own stdio buffer),
     # so that the JSON line is the LAST thing on stdout
+    torch.cuda.synchronize(dev)
+    for plset in (step_plans, plans_inorder, plans_pipe, plans_gated):
+        for pl_ in (plset or []):
+            lib.cfx_plan_destroy(pl_)
+    if xside:
+        lib.cfx_stream_destroy(ctx, ctypes.c_void_p(xside))
     if native_comm is not None:
         try:
             torch.cuda.synchronize(dev)

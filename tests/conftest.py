@@ -3,9 +3,6 @@ import sys
 
 import pytest
 
-# flag-ordered streams (exchange lane, exchange-layer op): one hardware queue per stream even after RCCL has initialised - see bench.py;
-# must be in the environment before the HIP runtime starts
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)

@@ -10,15 +10,34 @@ mkdir -p "$OUT"; rm -rf "$OUT"/*
 KEY=$(python3 "$R/bench.py" --print-config-key)
 FAKE=$R/tests/fake_rccl/libcfx_fake_rccl.so
 cd /tmp && export TMPDIR=/tmp
-# 1. kernel trace + stats of the default bench command's headline schedule (A ; in-place all-gather ; B, layer by layer).  --overlap-steps 0
-#    and --no-secondary keep the other legs' kernels (the exchange lane runs the same compress kernel on 32 CUs) out of the averages.
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-secondary --overlap-steps 0 > "$OUT/bench_under_rocprof.log" 2>&1
-# 2. HBM traffic of the same schedule (short run + the copy probe used for calibration)
+export GPU_MAX_HW_QUEUES=8
+# 1. kernel trace + stats of the default bench command's headline schedule (one codec launch per layer gated on the collective's arrival; flag
+#    kernels + in-place all-gather on the exchange stream).  --overlap-steps 0 and --no-secondary keep the other legs' kernels out of the averages.
+#    Every profiled command runs under `timeout`: a profiler that serialises dispatches would leave the flag-ordered launch waiting for a kernel
+#    that cannot start.
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-secondary --overlap-steps 0 > "$OUT/bench_under_rocprof.log" 2>&1 < /dev/null
+# 1b. the same trace of the two-launch schedule (what runs with more than one rank execute)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace2" -o bench -- python3 "$R/bench.py" --own-ef ride --steps 20 --warmup 3 --no-secondary --overlap-steps 0 > "$OUT/bench2_under_rocprof.log" 2>&1 < /dev/null
+ST2=$(find "$OUT/trace2" -name "*kernel_stats.csv" 2>/dev/null | head -1)
+[ -n "$ST2" ] && cp "$ST2" "$OUT/r03_bench_two_launch_kernel_stats.csv"
+rm -rf "$OUT/trace2"
+# 2. HBM traffic (short run + the copy probe used for calibration).  Counter collection SERIALISES dispatches, which the flag-ordered launch cannot
+#    survive (its flag kernels would queue behind it), so the counters are taken on the loop-back form of the SAME kernel
+#    (k_absmean_compress<bits,gated> with its in-launch gate: identical loads and stores, one stream) and the file says so.
 PSTEPS=3
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --overlap-steps 0 --copy-probe 8 > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --overlap-steps 0 --copy-probe 8 > "$OUT/pmc_write.log" 2>&1
+PNOTE="counter passes serialise dispatches: taken on --no-collective --own-ef gated, the same kernel (k_absmean_compress<true, 4, true>) with its in-launch gate instead of the exchange stream's flag - identical loads and stores"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 "$R/bench.py" --no-collective --own-ef gated --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --overlap-steps 0 --copy-probe 8 > "$OUT/pmc_fetch.log" 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 "$R/bench.py" --no-collective --own-ef gated --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --overlap-steps 0 --copy-probe 8 > "$OUT/pmc_write.log" 2>&1 < /dev/null
 cd "$R"
-python3 tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/r03_pmc_traffic.json" "$KEY" $PSTEPS > /dev/null
+python3 tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/r03_pmc_traffic.json" "$KEY" $PSTEPS "$PNOTE" > /dev/null
+# 2b. the same counters for the two-launch schedule
+cd /tmp
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch2" -o pmc -- python3 "$R/bench.py" --own-ef ride --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --overlap-steps 0 --copy-probe 8 > "$OUT/pmc_fetch2.log" 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write2" -o pmc -- python3 "$R/bench.py" --own-ef ride --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --overlap-steps 0 --copy-probe 8 > "$OUT/pmc_write2.log" 2>&1 < /dev/null
+cd "$R"
+KEY2=$(python3 "$R/bench.py" --own-ef ride --print-config-key)
+python3 tools/pmc_summary.py "$OUT/pmc_fetch2" "$OUT/pmc_write2" "$OUT/r03_pmc_traffic_two_launch.json" "$KEY2" $PSTEPS > /dev/null
+rm -rf "$OUT/pmc_fetch2" "$OUT/pmc_write2"
 TR=$(find "$OUT/trace" -name "*kernel_trace.csv" | head -1)
 ST=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)
 [ -n "$TR" ] && python3 tools/trace_kernel_avg.py "$TR" "$OUT/r03_bench_kernel_durations.json" "$KEY" > /dev/null
@@ -31,6 +50,7 @@ cp "$OUT/r03_bench_kernel_durations.json" profiles/r03_bench_kernel_durations.js
 python3 bench.py > "$OUT/r03_bench_n1.json" 2>/dev/null
 python3 bench.py --codec int2 --overlap-steps 0 > "$OUT/r03_bench_n1_int2.json" 2>/dev/null
 python3 bench.py --no-collective --own-ef gated --overlap-steps 0 --no-cpu-baseline > "$OUT/r03_bench_n1_loopback_one_launch.json" 2>/dev/null
+python3 bench.py --own-ef ride --overlap-steps 0 --no-cpu-baseline > "$OUT/r03_bench_n1_two_launch.json" 2>/dev/null
 python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --no-cpu-baseline --long-steps 20 > "$OUT/r03_bench_emulated_live8.json" 2>/dev/null
 python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --exchange-pattern relay --no-cpu-baseline --long-steps 20 > "$OUT/r03_bench_emulated_live8_relay.json" 2>/dev/null
 # 4. the deployable path with real attention (SURVEY 8d protocol 2): all legs, then kernel traces of the lane leg and of attention alone

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc counter CSVs into per-kernel HBM traffic per launch (developer tool).
 
-Usage: tools/pmc_summary.py <fetch_dir> <write_dir> <out.json> [config-key JSON of the profiled bench command] [steps profiled]
+Usage: tools/pmc_summary.py <fetch_dir> <write_dir> <out.json> [config-key JSON of the profiled bench command] [steps profiled] [note]
 Each dir holds the *_counter_collection.csv of ONE --pmc pass (FETCH_SIZE and WRITE_SIZE do not fit one pass,
 MI355X_MICROARCH.md §rocprofv3 PMC slots).  Units and corrections follow MI355X_MICROARCH.md §HBM:
   * FETCH_SIZE / WRITE_SIZE are reported in KiB;
@@ -41,6 +41,7 @@ def main():
     fdir, wdir, out = sys.argv[1:4]
     cfg = json.loads(sys.argv[4]) if len(sys.argv) > 4 else None
     steps = int(sys.argv[5]) if len(sys.argv) > 5 else None
+    note = sys.argv[6] if len(sys.argv) > 6 else None
     fetch, write = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
     probe_bytes = 96 * 1024 * 1024
     res = {"unit": "bytes per launch", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)", "kernels": {}}
@@ -71,6 +72,8 @@ def main():
     # what bench.py matches against: the configuration the counters were taken with, bytes per launch of every libcfx kernel
     # and the bytes one denoise step moves (all libcfx launches of the profiled run / steps profiled)
     res["config"] = cfg
+    if note:
+        res["measured_with"] = note
     res["bytes_per_launch"] = {k: int(v["hbm_bytes"]) for k, v in res["kernels"].items() if k.startswith("k_") and v["hbm_bytes"]}
     if steps:
         tot = sum(v["hbm_bytes"] * v["launches"] for k, v in res["kernels"].items()
