@@ -108,7 +108,7 @@ template <int RP> struct LrsLds {
     __host__ __device__ static int zt(int NPK) { return sc(NPK) + 16384; }                      // Z^T hi | lo, [RR][LRS_ZH] fp16 each
     __host__ __device__ static int zf(int NPK) { return zt(NPK) + 2 * RR * LRS_ZH * 2; }        // Z [32][RR] fp32 (for its Gram matrix)
     __host__ __device__ static int ch(int NPK) { return zf(NPK) + 32 * RR * 4; }                // factorisation: G fp64, L fp32, 1 / diagonal, dead mask
-    static constexpr int ch_bytes = (RP * (RP + 1) * 8 + RP * RP * 4 + RP * 4 + 16 + 15) / 16 * 16;
+    static constexpr int ch_bytes = (RP * (RP + 1) * 8 + RP * RP * 4 + RP * 4 + 16 + 15) / 16 * 16 + 64;    // (+ 2 x 8 wave maxima, norm_scale)
     __host__ __device__ static int total(int NPK) { return ch(NPK) + ch_bytes; }
 };
 
@@ -230,21 +230,18 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     // N x r matrix is therefore scaled by the power of two that brings its largest entry into [0.5, 1) - exact, the same in every
     // workgroup (all hold the same matrix), and folded into the operand conversion below.  |Z| <= N max|A| then: in range for any
     // residual with entries below ~100.
-    float ysc = 1.f;
-    auto norm_scale = [&]() {
-        float m = 0.f;
-        for (int i = tid; i < RR * NPS / 4; i += LRS_NT) {
-            const f32x4 y = *reinterpret_cast<const f32x4*>(&Yt[4 * i]);
-            m = fmaxf(fmaxf(m, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
-        }
+    // The largest entry is tracked by whoever writes the matrix (the gather of a sum, the substitution): run_max is each thread's share.
+    float ysc = 1.f, run_max = 0.f;
+    float* mxs = reinterpret_cast<float*>(sm + L::ch(NPK) + L::ch_bytes - 64);
+    auto norm_scale = [&](int which) {
+        float m = run_max;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        float* mx = reinterpret_cast<float*>(red4);
+        float* mx = mxs + which * LRS_NW;                             // its own words per call site: nothing to wait for afterwards
         if (lane == 0) mx[w] = m;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < LRS_NW; ++k) m = fmaxf(m, mx[k]);
-        __syncthreads();
         int e = 0;
         (void)frexpf(m, &e);
         ysc = (m > 0.f && m < 3.0e38f) ? ldexpf(1.f, -e) : 1.f;
@@ -426,7 +423,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
                 if (c < cells) {
                     const int n = c / (RP / 4), rq = c - n * (RP / 4);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) Yt[(4 * rq + k) * NPS + n] = lrs_val(q[j][k]);
+                    for (int k = 0; k < 4; ++k) { const float v = lrs_val(q[j][k]); Yt[(4 * rq + k) * NPS + n] = v; run_max = fmaxf(run_max, fabsf(v)); }
                 } else if (c < tcells) {
                     const int e = 2 * (c - cells);
                     Gd[e / RP][e % RP] = lrs_val64(q[j][0], q[j][1]);
@@ -492,6 +489,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     // Y = W L^-T in place, one row per thread by forward substitution (fp32; the factor's entries are LDS broadcasts, a row of the
     // factor read once as 16-byte pieces)
     auto apply_l = [&]() {
+        run_max = 0.f;
         if (RP <= 8) {
             // rows tid and tid + LRS_NT in ONE pass (NPK <= 2 LRS_NT): the factor's rows are read once for both
             const int n0 = tid, n1 = tid + LRS_NT;
@@ -513,8 +511,8 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             }
 #pragma unroll
             for (int k = 0; k < RP; ++k) {
-                if (h0) Yt[k * NPS + n0] = ya[k];
-                if (h1) Yt[k * NPS + n1] = yb[k];
+                if (h0) { Yt[k * NPS + n0] = ya[k]; run_max = fmaxf(run_max, fabsf(ya[k])); }
+                if (h1) { Yt[k * NPS + n1] = yb[k]; run_max = fmaxf(run_max, fabsf(yb[k])); }
             }
         } else {
             // rank 16 / 32: one row at a time (two rows' values and the factor's entries do not fit the registers of 8 waves); the second
@@ -539,7 +537,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
                 }
                 float* wp = Yt + n;
 #pragma unroll
-                for (int k = 0; k < RP; ++k) { *wp = y[k]; wp += NPS; asm volatile("" : "+v"(wp)); }
+                for (int k = 0; k < RP; ++k) { *wp = y[k]; run_max = fmaxf(run_max, fabsf(y[k])); wp += NPS; asm volatile("" : "+v"(wp)); }
             }
         }
         __syncthreads();
@@ -548,8 +546,9 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     // ---------------- Y0 = A Q0 ----------------
     product_b(tag0);
     LSTAMP(2);
+    run_max = 0.f;
     allreduce(tag0, false);
-    norm_scale();
+    norm_scale(0);
     LSTAMP(3);
 
     // ---------------- W1 = A (A^T Y0), Y1 = W1 chol(M1)^-T ----------------
@@ -562,7 +561,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     __syncthreads();
     LSTAMP(14);
     apply_l();                                                        // Y1 = W1 chol(M1)^-T
-    norm_scale();
+    norm_scale(1);
     LSTAMP(6);
 
     // ---------------- W2 = A (A^T Y1), U = W2 chol(W2^T W2)^-T ----------------
