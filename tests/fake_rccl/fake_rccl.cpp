@@ -28,6 +28,25 @@ __global__ void k_replicate(uint4* __restrict__ dst, const uint4* __restrict__ s
     for (int r = 0; r < copies; ++r) dst[(size_t)r * n16 + i] = v;
 }
 
+// the same copy with the register footprint of RCCL's kernel on gfx950 (rcclGenericKernel: 256 threads, 261-280 VGPRs - read from
+// librccl's code object): CFX_FAKE_RCCL_FAT=1.  What matters to the tests is WHERE such a workgroup can be placed, not what it does.
+__global__ __launch_bounds__(256) void k_replicate_fat(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16, int copies) {
+    asm volatile("v_mov_b32 v247, 0\n\tv_accvgpr_write_b32 a31, 0" ::: "v247", "a31");       // 248 VGPRs + 32 AGPRs
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    const uint4 v = src[i];
+    for (int r = 0; r < copies; ++r) dst[(size_t)r * n16 + i] = v;
+}
+
+// CFX_FAKE_RCCL_FAT=2: a whole SIMD's register file per wave (512): such a workgroup only fits a CU that holds nothing else
+__global__ __launch_bounds__(256) void k_replicate_huge(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16, int copies) {
+    asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255");
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    const uint4 v = src[i];
+    for (int r = 0; r < copies; ++r) dst[(size_t)r * n16 + i] = v;
+}
+
 namespace {
 struct Pending { const void* send; void* recv; size_t bytes; int peer_send, peer_recv; };
 struct Group {
@@ -107,7 +126,13 @@ int ncclAllGather(const void* send, void* recv, size_t count, int /*datatype: by
     if (g->loopback) {
         if ((count & 15) == 0 && (((uintptr_t)send | (uintptr_t)recv) & 15) == 0) {
             const size_t n16 = count / 16;
-            hipLaunchKernelGGL(k_replicate, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, stream, (uint4*)recv, (const uint4*)send, n16, g->nranks);
+            const char* fat = getenv("CFX_FAKE_RCCL_FAT");
+            if (fat && fat[0] == '2')
+                hipLaunchKernelGGL(k_replicate_huge, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, stream, (uint4*)recv, (const uint4*)send, n16, g->nranks);
+            else if (fat && fat[0] == '1')
+                hipLaunchKernelGGL(k_replicate_fat, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, stream, (uint4*)recv, (const uint4*)send, n16, g->nranks);
+            else
+                hipLaunchKernelGGL(k_replicate, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, stream, (uint4*)recv, (const uint4*)send, n16, g->nranks);
             return hipGetLastError() == hipSuccess ? 0 : 1;
         }
         for (int r = 0; r < g->nranks; ++r)

@@ -160,6 +160,53 @@ def test_collective_kernel_on_the_exchange_stream(partition):
         lib.cfx_comm_destroy(comm)
 
 
+@pytest.mark.parametrize("fat", ["1", "2"])
+def test_collective_kernels_that_need_room(fat):
+    """The collective's kernel has to be placed while the layer launch's reconstruction workgroups wait for it.
+    fat = 1: a kernel with the register footprint of RCCL's on gfx950 (rcclGenericKernel: 256 threads x 280 VGPRs, read from librccl's
+    code object) - it finds CUs with a single waiting workgroup and the plans run unpartitioned (observed, not guaranteed: bench.py
+    validates its first step with a short gate timeout and falls back to two launches).
+    fat = 2: a kernel that needs an EMPTY CU (512 VGPRs per wave) - it cannot be placed, the gate never opens: the launch gives up after
+    the context's gate timeout - no hang - and the NEXT call on the context reports CFX_ERR_GATE.  With the run stream on CUs [0, 224)
+    and the exchange stream on [224, 256) the same plans run and leave the states of compress ; all-gather ; reconstruct."""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    os.environ["CFX_FAKE_RCCL_MODE"] = "loopback"
+    os.environ["CFX_FAKE_RCCL_FAT"] = fat
+    ctx = lib.cfx_create(0)
+    try:
+        assert lib.cfx_prepare(ctx) == 0 and lib.cfx_set_gate_timeout_ms(ctx, 150) == 0
+        assert lib.cfx_rccl_load(_fake_path().encode()) == 0
+        uid = ctypes.create_string_buffer(128)
+        assert lib.cfx_comm_unique_id(ctx, uid) == 0
+        comm = lib.cfx_comm_create(ctx, uid, 4, 0)
+        assert comm
+        W = Layers(2, 544, 3072, 7, seed=9, live=4)
+        ref = _reference(lib, _lib, ctx, W, 2, comm=comm)
+        W.reset()
+        run = torch.cuda.Stream()
+        if fat == "1":
+            _run(lib, ctx, _plans(lib, _lib, ctx, W, "xlayer", comm=comm), run.cuda_stream, 2)
+            assert torch.equal(W.own, ref[0]) and torch.equal(W.peer, ref[1])
+        else:
+            plans = _plans(lib, _lib, ctx, W, "xlayer", comm=comm)
+            assert lib.cfx_plan_run(plans[0], 0, 1, run.cuda_stream) == 0
+            torch.cuda.synchronize()
+            assert lib.cfx_plan_run(plans[0], 1, 1, run.cuda_stream) == -8, "a gate that never opened must surface as CFX_ERR_GATE at the next call"
+            assert lib.cfx_gate_errors(ctx) > 0 and lib.cfx_gate_errors(ctx) == 0
+            for p in plans:
+                lib.cfx_plan_destroy(p)
+            # CU partition: the collective always finds its CUs
+            W.reset()
+            runm, side = _masked(lib, ctx, 0, 224), _masked(lib, ctx, 224, 32)
+            _run(lib, ctx, _plans(lib, _lib, ctx, W, "xlayer", comm=comm, side=side), runm, 2)
+            assert torch.equal(W.own, ref[0]) and torch.equal(W.peer, ref[1])
+        lib.cfx_comm_destroy(comm)
+    finally:
+        os.environ.pop("CFX_FAKE_RCCL_FAT", None)
+        lib.cfx_destroy(ctx)
+
+
 def test_two_rank_threads_exchange_for_real():
     """W = 2 ranks as threads on one GPU, each on its own half of the CUs (a waiting layer launch of one rank must not hold the CUs the
     other rank's compress group needs), real all-gathers through tests/fake_rccl: every rank's reconstruction of the other rank's shard
