@@ -31,17 +31,6 @@ def _bench(*args):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
-def test_bench_falls_back_when_the_collective_cannot_be_placed():
-    """a collective kernel that needs an empty CU (CFX_FAKE_RCCL_FAT=2) never runs beside the waiting layer launch: the warm-up step times
-    out (300 ms gates), every rank switches to two launches per layer, the line says so"""
-    os.environ["CFX_FAKE_RCCL_FAT"] = "2"
-    try:
-        d = _bench("--emulate-live", "2", "--rccl-lib", _fake(), "--no-cpu-baseline", "--no-raw-baseline", "--layers", "3")
-    finally:
-        os.environ.pop("CFX_FAKE_RCCL_FAT", None)
-    assert d["launches_per_layer"] == 2 and "timed out" in d["schedule_fallback"]
-
-
 def test_bench_two_launch_schedule_still_selectable():
     d = _bench("--own-ef", "ride", "--no-cpu-baseline")
     assert "ncclAllGather" in d["schedule"] and d["launches_per_layer"] == 2 and "k_binary_dequant" in d["roofline"]["kernel"]
@@ -68,8 +57,7 @@ def test_bench_default_line_has_the_collective_in_its_schedule():
 def test_bench_n_gt_1_plumbing_over_the_loopback_library(live, pattern):
     d = _bench("--emulate-live", str(live), "--rccl-lib", _fake(), "--exchange-pattern", pattern, "--no-cpu-baseline")
     assert d["n_gpus"] == 1 and d["exchange_pattern"] == pattern and d["exchange_issued_by"] == "native"
-    # all-gather pattern: the exchange-layer op at every N (validated in warm-up, no fallback needed here); the relay pattern keeps two launches
-    assert d["launches_per_layer"] == (1 if pattern == "allgather" else 2) and d["schedule_fallback"] is None
+    assert d["launches_per_layer"] == 2          # more than one live rank: two codec launches per layer around the collective
     x = d["xgmi"]
     assert x["pattern"] == pattern and x["links"] == (1 if pattern == "relay" else min(live - 1, 7))
     assert set(x["compressed"]) == {"allgather", "relay"} and set(x["raw"]) == {"allgather", "relay"}

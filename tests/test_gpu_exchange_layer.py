@@ -162,13 +162,15 @@ def test_collective_kernel_on_the_exchange_stream(partition):
 
 @pytest.mark.parametrize("fat", ["1", "2"])
 def test_collective_kernels_that_need_room(fat):
-    """The collective's kernel has to be placed while the layer launch's reconstruction workgroups wait for it.
+    """The collective's kernel has to be placed while the layer launch's reconstruction workgroups wait for it (why bench.py keeps two
+    launches per layer with more than one rank).
     fat = 1: a kernel with the register footprint of RCCL's on gfx950 (rcclGenericKernel: 256 threads x 280 VGPRs, read from librccl's
-    code object) - it finds CUs with a single waiting workgroup and the plans run unpartitioned (observed, not guaranteed: bench.py
-    validates its first step with a short gate timeout and falls back to two launches).
-    fat = 2: a kernel that needs an EMPTY CU (512 VGPRs per wave) - it cannot be placed, the gate never opens: the launch gives up after
-    the context's gate timeout - no hang - and the NEXT call on the context reports CFX_ERR_GATE.  With the run stream on CUs [0, 224)
-    and the exchange stream on [224, 256) the same plans run and leave the states of compress ; all-gather ; reconstruct."""
+    code object).  Unpartitioned it is placed in most runs (CUs with a single waiting workgroup exist) and not in others: nothing is
+    asserted about that leg except that it never hangs and that a gate which did not open is REPORTED.
+    fat = 2: a kernel that needs an empty CU (512 VGPRs per wave): never placed - the launch gives up after the context's gate
+    timeout and the NEXT call on the context reports CFX_ERR_GATE.
+    Both: with the run stream on CUs [0, 224) and the exchange stream on [224, 256) the same plans run and leave the states of
+    compress ; all-gather ; reconstruct."""
     from compactfusion_amd import _lib, codecs as K
     lib = _lib.load()
     os.environ["CFX_FAKE_RCCL_MODE"] = "loopback"
@@ -185,22 +187,23 @@ def test_collective_kernels_that_need_room(fat):
         ref = _reference(lib, _lib, ctx, W, 2, comm=comm)
         W.reset()
         run = torch.cuda.Stream()
-        if fat == "1":
-            _run(lib, ctx, _plans(lib, _lib, ctx, W, "xlayer", comm=comm), run.cuda_stream, 2)
-            assert torch.equal(W.own, ref[0]) and torch.equal(W.peer, ref[1])
-        else:
-            plans = _plans(lib, _lib, ctx, W, "xlayer", comm=comm)
-            assert lib.cfx_plan_run(plans[0], 0, 1, run.cuda_stream) == 0
-            torch.cuda.synchronize()
-            assert lib.cfx_plan_run(plans[0], 1, 1, run.cuda_stream) == -8, "a gate that never opened must surface as CFX_ERR_GATE at the next call"
-            assert lib.cfx_gate_errors(ctx) > 0 and lib.cfx_gate_errors(ctx) == 0
-            for p in plans:
-                lib.cfx_plan_destroy(p)
-            # CU partition: the collective always finds its CUs
-            W.reset()
-            runm, side = _masked(lib, ctx, 0, 224), _masked(lib, ctx, 224, 32)
-            _run(lib, ctx, _plans(lib, _lib, ctx, W, "xlayer", comm=comm, side=side), runm, 2)
-            assert torch.equal(W.own, ref[0]) and torch.equal(W.peer, ref[1])
+        plans = _plans(lib, _lib, ctx, W, "xlayer", comm=comm)
+        assert lib.cfx_plan_run(plans[0], 0, 1, run.cuda_stream) == 0
+        torch.cuda.synchronize()                                      # returns: a gate that cannot open costs its timeout, not the GPU
+        rc = lib.cfx_plan_run(plans[0], 1, 1, run.cuda_stream)
+        torch.cuda.synchronize()
+        errs = lib.cfx_gate_errors(ctx)
+        assert (rc == -8) == (errs > 0) or rc == 0, (rc, errs)        # a timeout of the first launch surfaces at the next call
+        if fat == "2":
+            assert rc == -8 and errs > 0, "a gate that never opened must surface as CFX_ERR_GATE at the next call"
+        assert lib.cfx_gate_errors(ctx) == 0                          # read-and-clear
+        for p in plans:
+            lib.cfx_plan_destroy(p)
+        # CU partition: the collective always finds its CUs
+        W.reset()
+        runm, side = _masked(lib, ctx, 0, 224), _masked(lib, ctx, 224, 32)
+        _run(lib, ctx, _plans(lib, _lib, ctx, W, "xlayer", comm=comm, side=side), runm, 2)
+        assert torch.equal(W.own, ref[0]) and torch.equal(W.peer, ref[1])
         lib.cfx_comm_destroy(comm)
     finally:
         os.environ.pop("CFX_FAKE_RCCL_FAT", None)
