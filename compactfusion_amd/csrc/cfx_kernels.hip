@@ -1034,8 +1034,9 @@ struct FusedArgs {
     size_t ws_stride;
     unsigned* tick;
     u64* stamps;             // developer hook: 16 words per statistics workgroup, or NULL
-    // gated reconstruction group (GATED kernels): workgroups [n_st, n_st + n_g), tiles of g_R rows, g_rb per tensor
-    int n_g, g_R, g_rb;
+    // gated reconstruction group (GATED kernels): workgroups [n_st, n_st + n_g), tiles of g_R rows, g_rb per tensor; n_gt tiles in all:
+    // n_g == n_gt, one tile per workgroup, or n_g < n_gt: a PERSISTENT group, workgroup g takes tiles g, g + n_g, ...
+    int n_g, g_R, g_rb, n_gt;
     unsigned* gate;
     unsigned gate_expect;
     unsigned* gate_err;
@@ -1065,12 +1066,14 @@ __global__ __launch_bounds__(FUSED_NT, GATE_WPE) void k_absmean_compress(BatchC 
         if constexpr (GATED) {
             if (b < a.n_g) {
                 const int per = a.CB * a.g_rb;
-                const int item = b / per, rem = b - item * per;
-                const int ty = rem / a.CB;
-                binary_dequant_gated_body<FUSED_NW, GATE_KR, 0, ST>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.xgate ? a.xgate : a.gate,
-                                                            a.xgate ? a.xexpect : a.gate_expect, a.gate_err,
-                                                            nullptr,
-                                                            a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr);
+                for (int t = b; t < a.n_gt; t += a.n_g) {             // (one trip unless the group is persistent)
+                    const int item = t / per, rem = t - item * per;
+                    const int ty = rem / a.CB;
+                    binary_dequant_gated_body<FUSED_NW, GATE_KR, 0, ST>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.xgate ? a.xgate : a.gate,
+                                                                a.xgate ? a.xexpect : a.gate_expect, a.gate_err,
+                                                                nullptr,
+                                                                a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr);
+                }
                 return;
             }
             b -= a.n_g;
@@ -2220,7 +2223,7 @@ static unsigned ticket_slot(cfx_ctx* ctx, void* stream) {
 static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                          int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
                          void* workspace, size_t workspace_bytes, void* stream, CfxXGate* xg = nullptr) {
-    if (xg) memset(xg, 0, sizeof(*xg));
+    if (xg) { const int pers = xg->persistent; memset(xg, 0, sizeof(*xg)); xg->persistent = pers; }
     if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "compress: null ctx/items");
     if (n_gated < 0 || n_gated > CFX_MAX_BATCH || (n_gated && !gated)) return fail(ctx, CFX_ERR_BATCH, "compress: gated batch out of range");
     if (n_gated && codec != CFX_CODEC_BINARY && codec != CFX_CODEC_INT2)
@@ -2361,7 +2364,20 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                 // tiles of the gated group: as few row blocks as GATE_KR rows per wave allow, heights a multiple of FUSED_NW
                 a.g_rb = (N + FUSED_NW * GATE_KR - 1) / (FUSED_NW * GATE_KR);
                 a.g_R = ((N + a.g_rb - 1) / a.g_rb + FUSED_NW - 1) / FUSED_NW * FUSED_NW;
-                a.n_g = CB * a.g_rb * n_gated_k;
+                a.n_gt = a.n_g = CB * a.g_rb * n_gated_k;
+                if (xg && xg->persistent) {
+                    // a collective KERNEL will need CUs while this group waits: launch only as many reconstruction workgroups as are resident
+                    // TOGETHER with the compress group (nothing is ever pending, so the slots the compress group frees stay free: at least
+                    // (CUs - n_g / 2) CUs then hold a single workgroup of this launch and 320 free VGPRs per SIMD); the rest of the tiles
+                    // are taken in turn after the gate
+                    static int per_cu = 0;
+                    if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_absmean_compress<true, 4, true>, FUSED_NT, 0) != hipSuccess || per_cu < 1)) {
+                        (void)hipGetLastError();
+                        per_cu = 1;
+                    }
+                    const int cap = per_cu * stream_cus - a.n_st;
+                    if (cap >= stream_cus / 2 && cap < a.n_g) a.n_g = cap;
+                }
                     a.gate = ctx->gate + (size_t)slot * GATE_STRIDE;
                 ctx->gate_expect[2 * slot] += (unsigned)batch * (unsigned)(CB + 1);
                 a.gate_expect = ctx->gate_expect[2 * slot];

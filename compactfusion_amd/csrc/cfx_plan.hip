@@ -416,6 +416,10 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
             case 9: {
                 CfxXGate xg;
                 memset(&xg, 0, sizeof(xg));
+                // CFX_XGATE_PERSISTENT=1 (developer): a reconstruction group small enough that nothing of the launch is ever pending - it
+                // guarantees a collective KERNEL its CUs, and measured slower than two launches, so it is off
+                static const char* pers_env = getenv("CFX_XGATE_PERSISTENT");
+                xg.persistent = pers_env ? atoi(pers_env) : 0;
                 // (the legacy NULL stream serialises with the CU-masked exchange stream: a flag kernel there would wait for the very launch
                 // it is meant to release - run in order instead)
                 const bool own_stream = p->side && stream != nullptr && (hipStream_t)stream != p->side && !inline_exchange;
