@@ -256,12 +256,16 @@ int       cfx_plan_add_wait(cfx_plan* plan, int gather_op);
  * state tiles into registers while the statistics chain and the collective run, and continue when the plan's exchange stream - which
  * waits (a flag kernel) until the launch's packets are complete, issues ncclAllGather(send, recv, bytes_per_rank) and then sets the
  * launch's external gate - says the packets have arrived.  `recon` items read their packets from wherever the collective leaves them
- * (or from this op's own packet operands: with CFX_FLAG_UPDATE_CACHE the rank's own error-feedback update joins them).  comm NULL or
- * a one-rank communicator: nothing moves, the exchange stream only relays the flag.  1-bit codec.  When the one-launch form is not
- * available (shape without it, a run stream masked below 128 CUs, cfx_plan_run_async / _lane) the op runs as compress ; all-gather ;
+ * (or from this op's own packet operands: with CFX_FLAG_UPDATE_CACHE the rank's own error-feedback update joins them).  comm NULL:
+ * nothing moves, the exchange stream runs one relay kernel (wait + set).  1-bit codec.  When the one-launch form is not available (shape
+ * without it, a run stream masked below 128 CUs, the legacy NULL stream, cfx_plan_run_async / _lane) the op runs as compress ; all-gather ;
  * reconstruct in order - same results.  The exchange stream must own a hardware queue (see "Exchange lane" below): the plan creates a
- * CU-masked one unless cfx_plan_use_exchange_stream supplied it.  A gate that never opens times out like any flag wait
- * (CFX_ERR_GATE at the next call).  Returns the op index. */
+ * CU-masked one unless cfx_plan_use_exchange_stream supplied it (one stream should serve all plans).  A gate that never opens times
+ * out like any flag wait (CFX_ERR_GATE at the next call).
+ * With more than one rank the collective is a KERNEL that has to be placed while the reconstruction workgroups hold their CUs: RCCL's
+ * (256 threads x ~280 VGPRs on gfx950) only fits CUs with a single waiting workgroup, which exist in most launches and not in all
+ * (DESIGN.md section 3).  Either give the two streams disjoint CU ranges (cfx_stream_create_masked; costs this launch ~5 us) or use
+ * cfx_plan_add_compress_ex ; cfx_plan_add_all_gather ; cfx_plan_add_decompress there, as bench.py does.  Returns the op index. */
 int       cfx_plan_add_exchange_layer(cfx_plan* plan, int codec, int N, int C, int param, int flags, int batch,
                                       const cfx_comp_item* items, int n_recon, const cfx_decomp_item* recon,
                                       cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank,
