@@ -107,6 +107,17 @@ def test_plan_building_without_gpu():
     assert lib.cfx_plan_set_exchange_stream(other, 7) == -5
     assert lib.cfx_plan_set_exchange_stream(other, 0) == 0
     assert lib.cfx_plan_run(plan, 1, 5, None) == -5                                     # range out of bounds
+    # exchange layer (compress ; all-gather ; reconstruct as one op): argument checks come before anything touches a device
+    assert lib.cfx_plan_add_exchange_layer(plan, 3, 544, 3072, 0, 1, 2, c, 14, d, None, None, None, 0, 0x9000, 1 << 20) == -4     # 1-bit codec only
+    assert lib.cfx_plan_add_exchange_layer(plan, 1, 544, 3072, 0, 1, 2, c, 0, d, None, None, None, 0, 0x9000, 1 << 20) == -5      # nothing to reconstruct
+    assert lib.cfx_plan_add_exchange_layer(plan, 1, 544, 3072, 0, 1, 2, c, 17, d, None, None, None, 0, 0x9000, 1 << 20) == -5     # batch too large
+    assert lib.cfx_plan_add_exchange_layer(plan, 1, 544, 3072, 0, 1, 2, c, 14, d, 0x1234, None, None, 0, 0x9000, 1 << 20) == -1   # communicator without buffers
+    xl = lib.cfx_plan_create(ctx)
+    assert lib.cfx_plan_use_exchange_stream(xl, 0x5678) == 0                            # (a caller's stream: nothing is created here)
+    assert lib.cfx_plan_add_exchange_layer(xl, 1, 544, 3072, 0, 1, 2, c, 14, d, None, None, None, 0, 0x9000, 1 << 20) == 0
+    assert lib.cfx_plan_add_exchange_layer(xl, 1, 544, 3077, 0, 1, 2, c, 14, d, None, None, None, 0, 0x9000, 1 << 20) == -2      # bad shape
+    assert lib.cfx_plan_size(xl) == 1
+    lib.cfx_plan_destroy(xl)
     lib.cfx_plan_destroy(other)
     lib.cfx_plan_destroy(plan)
     lib.cfx_destroy(ctx)
