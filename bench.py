@@ -71,8 +71,8 @@ ALG_BYTES_PER_EL = ALG_BYTES["binary"]
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)      # 100 x ~1.5 ms: a timed region of ~150 ms (20 steps were a 30 ms sample, clocks still settling)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--layers", type=int, default=L_LAYERS, help="debug only; the judged workload uses 57")
     ap.add_argument("--rows", type=int, default=0, help="rows per tile override (0 = auto)")
     ap.add_argument("--replay", choices=["inorder", "pipelined"], default="inorder",
