@@ -16,13 +16,16 @@ Per layer, the collective in the path at every N:
      (N live ranks gather for real; the 8-N missing logical peers are looped back from the rank's own slot, so the per-GPU codec
      work is IDENTICAL for every N = weak scaling; at N = 1 RCCL's one-rank in-place all-gather has nothing to move),
   B. reconstruct the 7 peers' K,V (14 tensors) onto their state arenas, and the rank's own error-feedback update.
-N = 1 (default, --own-ef xgate): A and B are ONE launch on the run stream (cfx_plan_add_exchange_layer): B's workgroups are launched
-with A's, pull their state tiles into registers while the scale reduction and the collective run, and wait for a gate word; the
-exchange stream runs  flag-wait kernel (A's packets complete) ; ncclAllGather ; flag-set kernel (opens the gate).
-N > 1 (and `two_launches_per_layer` at N = 1): A ; X ; B as two codec launches in stream order, the previous layer's own
-error-feedback update riding in A (nothing reads that state before the next denoise step, ring.py:207-209) - a collective KERNEL finds
-no room beside the waiting workgroups of the one-launch form unless CUs are set aside for it, and setting them aside costs more than
-the hidden preload gains (`with_cu_partition`).
+Default (--own-ef xgate), the same at every N: A and B are ONE launch on the run stream (cfx_plan_add_exchange_layer): B's workgroups are
+launched with A's, pull their state tiles into registers while the scale reduction and the collective run, and wait for a gate word;
+the exchange stream runs  flag-wait kernel (A's packets complete) ; ncclAllGather ; flag-set kernel (opens the gate).  With more than
+one live rank the collective is a kernel that must be placed beside the waiting workgroups (the library takes the one-launch form only
+if they leave it CUs); the first step runs with a 300 ms gate timeout and if a gate did not open on any rank every rank switches to
+the two-launch schedule (`schedule_fallback` says so).
+`two_launches_per_layer` (secondary at N = 1; --own-ef ride): A ; X ; B as two codec launches in stream order, the previous layer's
+own error-feedback update riding in A (nothing reads that state before the next denoise step, ring.py:207-209).
+`with_cu_partition` (secondary at N = 1): the default with the run stream masked to CUs [0, 224) and the exchange stream to [224, 256):
+any partial CU mask costs the layer launch ~5 us, so the streams are not partitioned.
 `loopback_one_launch_per_layer` (secondary, N = 1): the layer as ONE launch (cfx_compress_batch_gated: reconstruction behind an
 in-launch arrival gate) - only possible when the packets a reconstruction needs are produced by the same launch, i.e. with
 looped-back peers and NO collective in between; never `value`.
@@ -197,7 +200,7 @@ def config_key(args, n_gpus):
     pipelined = args.replay == "pipelined"
     own_ef = args.own_ef
     if own_ef == "xgate" and (args.codec != "binary" or args.no_collective or args.exchange != "native" or args.exchange_pattern == "relay"
-                              or ((n_gpus > 1 or args.emulate_live) and os.environ.get("CFX_BENCH_XGATE_ANY_N") != "1")):
+                              ):
         own_ef = "ride"
     return {"codec": args.codec, "replay": args.replay, "own_ef": own_ef if not pipelined else None, "layers": args.layers,
             "shard": [N_TOK, C_CH], "rows": args.rows, "n_gpus": n_gpus, "collective": not args.no_collective}
@@ -387,11 +390,7 @@ def main():
         rc = lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, len(items), darr)
         assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
 
-    # more than one live rank: the collective is a KERNEL (rcclGenericKernel: 256 threads x ~280 VGPRs) that finds no room beside the
-    # waiting reconstruction workgroups of a flag-ordered layer launch unless CUs are set aside for it, and a CU-masked run stream costs
-    # the layer launch more than the hidden state preload gains (`with_cu_partition` below): those runs keep two launches per layer
-    xgate = (args.own_ef == "xgate" and not pipelined and not int2 and use_dist and not relay and args.exchange == "native"
-             and (live == 1 or os.environ.get("CFX_BENCH_XGATE_ANY_N") == "1"))     # (developer: the op beside a collective KERNEL, unpartitioned)
+    xgate = (args.own_ef == "xgate" and not pipelined and not int2 and use_dist and not relay and args.exchange == "native")
     if args.own_ef == "xgate" and not xgate:
         args.own_ef = "ride"
     ride = args.own_ef in ("ride", "gated")
@@ -541,6 +540,32 @@ def main():
     steps_run = 0
     # ---- warmup (+ validation of the exchange path before anything is timed) ---------------------------------------------
     n_warm = max(args.warmup, 1 if use_dist else 0)
+    schedule_fallback = None
+    if xgate and live > 1:
+        # More than one live rank: the collective is a KERNEL that has to be placed while the layer launch's reconstruction workgroups hold
+        # their CUs.  The library only takes the one-launch form when that group leaves workgroup slots free (csrc: needs_room), and a kernel
+        # of RCCL's register footprint is then placed every time on this hardware (tools/xlayer_room_loop.py) - but RCCL itself has never run
+        # here beside it on more than one GPU.  So the first step runs with a short gate timeout, and a gate that did not open on ANY rank
+        # sends every rank to two launches per layer (the launches that gave up ran on garbage: the states are reset either way).
+        lib.cfx_set_gate_timeout_ms(ctx, 300)
+        one_step(0)
+        sync_all()
+        bad = torch.tensor([lib.cfx_gate_errors(ctx)], device=dev, dtype=torch.int32)
+        if world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        lib.cfx_set_gate_timeout_ms(ctx, 5000)
+        if int(bad.item()) != 0:
+            print("[bench] exchange-layer launches timed out waiting for the collective; running compress ; all-gather ; reconstruct in stream order", file=sys.stderr)
+            schedule_fallback = ("the exchange-layer op timed out in the validation step (the collective's kernel was not placed beside the waiting "
+                                 "workgroups); two launches per layer in stream order instead")
+            xgate = one_launch = False
+            args.own_ef = "ride"
+            ride = True
+            for pl_ in step_plans:
+                lib.cfx_plan_destroy(pl_)
+            step_plans = build_step_plans(0, xlayer=False)
+        reset_state()
+        sync_all()
     for i in range(n_warm):
         one_step(steps_run + i)
     steps_run += n_warm
@@ -773,18 +798,19 @@ def main():
                       "error-feedback update + reconstruction of the 7 peers' K,V, whose workgroups pull their state tiles into registers and "
                       "then wait for a gate word; on the exchange stream: flag-wait kernel (this launch's packets complete) ; X = " + XNAME +
                       " ; flag-set kernel (opens the gate).  " +
-                      "One live rank: the collective enqueues no kernel, so no CUs are set aside for one.  Runs with more than one rank keep "
-                      "`two_launches_per_layer` (an RCCL kernel finds no room beside the waiting workgroups without a CU partition, and "
-                      "`with_cu_partition` is slower than two launches)") if xgate else
+                      ("One live rank: the collective enqueues no kernel." if live == 1 else
+                       "More than one live rank: the collective is a kernel that is placed beside the waiting workgroups (the reconstruction "
+                       "group leaves >= 32 workgroup slots free); the first step was validated with a 300 ms gate timeout")) if xgate else
                      "layer by layer in order (deployable): per layer A = compress K,V [statistics + sign bits + in-launch finalize"
                      + (" + previous layer's own error-feedback update riding along" if ride else "") + "], X = " + XNAME + ", B = reconstruct "
                      + ("7 peers' K,V" if ride else "own + 7 peers' K,V")),
+        "schedule_fallback": schedule_fallback,
         "launches_per_layer": None if pipelined else (1 if one_launch else (3 if int2 else 2)),
         "two_launches_per_layer": None if two_ms is None else {
             "ms_per_step": round(two_ms, 4),
             "what": ("the same layer-ordered step as A1 = statistics + finalize ; A2 = quantise + error feedback ; B = reconstruct 7 peers" if int2 else
                      "the same layer-ordered step as A = compress (+ previous layer's own error feedback riding along) ; B = reconstruct 7 peers")
-                    + (" ; the collective between them, everything in stream order - what runs with more than one rank execute, minus the wire" if xgate else
+                    + (" ; the collective between them, everything in stream order (the fall-back schedule)" if xgate else
                        " - the schedule a collective between compress and reconstruction forces (N > 1)")},
         "flag_relay_no_communicator": None if relay_ms is None else {
             "ms_per_step": round(relay_ms, 4),
@@ -792,9 +818,9 @@ def main():
                     "flag-wait kernel ; ncclAllGather ; flag-set kernel - what the two kernel boundaries around the collective cost"},
         "with_cu_partition": None if part_ms is None else {
             "ms_per_step": round(part_ms, 4),
-            "what": "the same exchange-layer plans with the run stream masked to CUs [0, 224) and the exchange stream to [224, 256) - what it would take for "
-                    "RCCL's kernel (256 threads x ~280 VGPRs) to always find room beside the waiting workgroups at N > 1; slower than two launches "
-                    "per layer (any partial CU mask costs this launch ~5 us), so N > 1 runs use two launches"},
+            "what": "the same exchange-layer plans with the run stream masked to CUs [0, 224) and the exchange stream to [224, 256): CUs of its own for a "
+                    "collective kernel whatever the shape; any partial CU mask costs this launch ~5 us, so the streams are not partitioned (the "
+                    "reconstruction group of this shape leaves 32 workgroup slots free, which is room enough)"},
         "inorder_ms_per_step": None if inorder_ms is None else round(inorder_ms, 4),
         "pure_exchange_upper_bound": None if pipe_ms is None else {
             "ms_per_step": round(pipe_ms, 4),

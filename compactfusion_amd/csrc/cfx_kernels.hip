@@ -2223,7 +2223,7 @@ static unsigned ticket_slot(cfx_ctx* ctx, void* stream) {
 static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                          int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
                          void* workspace, size_t workspace_bytes, void* stream, CfxXGate* xg = nullptr) {
-    if (xg) { const int pers = xg->persistent; memset(xg, 0, sizeof(*xg)); xg->persistent = pers; }
+    if (xg) { const int pers = xg->persistent, room = xg->needs_room; memset(xg, 0, sizeof(*xg)); xg->persistent = pers; xg->needs_room = room; }
     if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "compress: null ctx/items");
     if (n_gated < 0 || n_gated > CFX_MAX_BATCH || (n_gated && !gated)) return fail(ctx, CFX_ERR_BATCH, "compress: gated batch out of range");
     if (n_gated && codec != CFX_CODEC_BINARY && codec != CFX_CODEC_INT2)
@@ -2313,6 +2313,22 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
     if (xg && !(one_launch && fused && codec == CFX_CODEC_BINARY && (!upd || (!(flags & CFX_FLAG_NO_EF) && n_gated + batch <= CFX_MAX_BATCH)))) {
         n_gated = 0;            // compress only: the caller runs its collective and the reconstruction behind this launch
         one_launch = false;
+    }
+    if (xg && xg->needs_room && one_launch) {
+        // A collective KERNEL has to be placed while the reconstruction group waits for it.  Once the compress group has gone, the group's
+        // n_g workgroups are all that is left of this launch; if they leave 32 workgroup slots of the stream's CUs free, at least 16 CUs
+        // hold at most one of them - 320 free VGPRs per SIMD and 128 KB of LDS there, room for a workgroup of RCCL's kernel (256 threads x
+        // 280 VGPRs, 20 KB) - and nothing of the launch is pending that could take those slots.  Otherwise: two launches.
+        static int per_cu = 0;
+        if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_absmean_compress<true, 4, true>, FUSED_NT, 0) != hipSuccess || per_cu < 1)) {
+            (void)hipGetLastError();
+            per_cu = 1;
+        }
+        const long n_g_all = (long)CB * ((N + FUSED_NW * GATE_KR - 1) / (FUSED_NW * GATE_KR)) * (n_gated + (upd ? batch : 0));
+        if (n_g_all + 32 > (long)per_cu * stream_cus) {
+            n_gated = 0;
+            one_launch = false;
+        }
     }
     const dim3 grid(CB, P, batch);
     const int Rq = auto_rows(ctx, N, C, batch, true);       // apply passes: same tile map as the (unfused) statistics pass

@@ -420,6 +420,7 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                 // guarantees a collective KERNEL its CUs, and measured slower than two launches, so it is off
                 static const char* pers_env = getenv("CFX_XGATE_PERSISTENT");
                 xg.persistent = pers_env ? atoi(pers_env) : 0;
+                xg.needs_room = o->comm && o->comm->nranks > 1;
                 // (the legacy NULL stream serialises with the CU-masked exchange stream: a flag kernel there would wait for the very launch
                 // it is meant to release - run in order instead)
                 const bool own_stream = p->side && stream != nullptr && (hipStream_t)stream != p->side && !inline_exchange;

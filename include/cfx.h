@@ -262,10 +262,9 @@ int       cfx_plan_add_wait(cfx_plan* plan, int gather_op);
  * reconstruct in order - same results.  The exchange stream must own a hardware queue (see "Exchange lane" below): the plan creates a
  * CU-masked one unless cfx_plan_use_exchange_stream supplied it (one stream should serve all plans).  A gate that never opens times
  * out like any flag wait (CFX_ERR_GATE at the next call).
- * With more than one rank the collective is a KERNEL that has to be placed while the reconstruction workgroups hold their CUs: RCCL's
- * (256 threads x ~280 VGPRs on gfx950) only fits CUs with a single waiting workgroup, which exist in most launches and not in all
- * (DESIGN.md section 3).  Either give the two streams disjoint CU ranges (cfx_stream_create_masked; costs this launch ~5 us) or use
- * cfx_plan_add_compress_ex ; cfx_plan_add_all_gather ; cfx_plan_add_decompress there, as bench.py does.  Returns the op index. */
+ * With more than one rank the collective is a KERNEL that has to be placed while the reconstruction workgroups hold their CUs: the
+ * one-launch form is then taken only if that group leaves 32 workgroup slots of the run stream's CUs free (room for RCCL's workgroups:
+ * 256 threads x ~280 VGPRs on gfx950), otherwise the op runs in order.  Returns the op index. */
 int       cfx_plan_add_exchange_layer(cfx_plan* plan, int codec, int N, int C, int param, int flags, int batch,
                                       const cfx_comp_item* items, int n_recon, const cfx_decomp_item* recon,
                                       cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank,

@@ -31,6 +31,28 @@ def _bench(*args):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def test_bench_falls_back_when_the_collective_cannot_be_placed():
+    """a collective kernel that needs an EMPTY CU (CFX_FAKE_RCCL_FAT=2) never runs beside the waiting layer launch: the validation step times
+    out (300 ms gates), every rank switches to two launches per layer, the line says so and the states are still consistent"""
+    os.environ["CFX_FAKE_RCCL_FAT"] = "2"
+    try:
+        d = _bench("--emulate-live", "2", "--rccl-lib", _fake(), "--no-cpu-baseline", "--no-raw-baseline", "--layers", "3")
+    finally:
+        os.environ.pop("CFX_FAKE_RCCL_FAT", None)
+    assert d["launches_per_layer"] == 2 and "timed out" in d["schedule_fallback"]
+
+
+def test_bench_with_a_collective_kernel_of_rccl_footprint():
+    """CFX_FAKE_RCCL_FAT=1: the loop-back collective as a kernel of 256 threads x 280 VGPRs (rcclGenericKernel on gfx950) - placed beside
+    the waiting reconstruction group (which leaves 32 workgroup slots free), no fall-back"""
+    os.environ["CFX_FAKE_RCCL_FAT"] = "1"
+    try:
+        d = _bench("--emulate-live", "8", "--rccl-lib", _fake(), "--no-cpu-baseline", "--no-raw-baseline")
+    finally:
+        os.environ.pop("CFX_FAKE_RCCL_FAT", None)
+    assert d["launches_per_layer"] == 1 and d["schedule_fallback"] is None
+
+
 def test_bench_two_launch_schedule_still_selectable():
     d = _bench("--own-ef", "ride", "--no-cpu-baseline")
     assert "ncclAllGather" in d["schedule"] and d["launches_per_layer"] == 2 and "k_binary_dequant" in d["roofline"]["kernel"]
@@ -57,7 +79,8 @@ def test_bench_default_line_has_the_collective_in_its_schedule():
 def test_bench_n_gt_1_plumbing_over_the_loopback_library(live, pattern):
     d = _bench("--emulate-live", str(live), "--rccl-lib", _fake(), "--exchange-pattern", pattern, "--no-cpu-baseline")
     assert d["n_gpus"] == 1 and d["exchange_pattern"] == pattern and d["exchange_issued_by"] == "native"
-    assert d["launches_per_layer"] == 2          # more than one live rank: two codec launches per layer around the collective
+    # all-gather pattern: the exchange-layer op at every N (first step validated, no fall-back needed here); the relay pattern keeps two launches
+    assert d["launches_per_layer"] == (1 if pattern == "allgather" else 2) and d["schedule_fallback"] is None
     x = d["xgmi"]
     assert x["pattern"] == pattern and x["links"] == (1 if pattern == "relay" else min(live - 1, 7))
     assert set(x["compressed"]) == {"allgather", "relay"} and set(x["raw"]) == {"allgather", "relay"}

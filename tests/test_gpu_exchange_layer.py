@@ -210,6 +210,36 @@ def test_collective_kernels_that_need_room(fat):
         lib.cfx_destroy(ctx)
 
 
+def test_one_launch_form_only_when_the_group_leaves_room_for_a_collective_kernel():
+    """a communicator with more than one rank means a collective KERNEL runs while the reconstruction group waits: the library takes the
+    one-launch form only if that group leaves >= 32 workgroup slots of the stream's CUs free (7 peers x K,V + own = 480 workgroups of 512 at
+    the FLUX shard: yes; 15 tensors' worth more at a taller shard: no -> compress ; all-gather ; reconstruct in order, same states)"""
+    from compactfusion_amd import _lib, codecs as K
+    lib, ctx = _lib.load(), K.context(0)
+    os.environ["CFX_FAKE_RCCL_MODE"] = "loopback"
+    assert lib.cfx_rccl_load(_fake_path().encode()) == 0
+    uid = ctypes.create_string_buffer(128)
+    assert lib.cfx_comm_unique_id(ctx, uid) == 0
+    comm = lib.cfx_comm_create(ctx, uid, 4, 0)
+    assert comm
+    try:
+        for (N, C, P, want_one) in ((544, 3072, 7, True), (1024, 3072, 7, False)):
+            W = Layers(2, N, C, P, seed=N, live=4)
+            ref = _reference(lib, _lib, ctx, W, 2, comm=comm)
+            W.reset()
+            run = torch.cuda.Stream()
+            lib.cfx_profile_enable(ctx, 256, 0xffffffff, 1)
+            _run(lib, ctx, _plans(lib, _lib, ctx, W, "xlayer", comm=comm), run.cuda_stream, 2)
+            ids = (ctypes.c_int * 256)(); ms = (ctypes.c_float * 256)()
+            k = lib.cfx_profile_read(ctx, ids, ms, 256)
+            lib.cfx_profile_enable(ctx, 0, 0, 1)
+            names = {lib.cfx_kernel_name(ids[i]).decode() for i in range(k)}
+            assert any("gated layer launch" in n for n in names) == want_one, (N, names)
+            assert torch.equal(W.own, ref[0]) and torch.equal(W.peer, ref[1])
+    finally:
+        lib.cfx_comm_destroy(comm)
+
+
 def test_two_rank_threads_exchange_for_real():
     """W = 2 ranks as threads on one GPU, each on its own half of the CUs (a waiting layer launch of one rank must not hold the CUs the
     other rank's compress group needs), real all-gathers through tests/fake_rccl: every rank's reconstruction of the other rank's shard

@@ -52,6 +52,9 @@ python3 bench.py --codec int2 --overlap-steps 0 > "$OUT/r03_bench_n1_int2.json" 
 python3 bench.py --no-collective --own-ef gated --overlap-steps 0 --no-cpu-baseline > "$OUT/r03_bench_n1_loopback_one_launch.json" 2>/dev/null
 python3 bench.py --own-ef ride --overlap-steps 0 --no-cpu-baseline > "$OUT/r03_bench_n1_two_launch.json" 2>/dev/null
 python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --no-cpu-baseline --long-steps 20 > "$OUT/r03_bench_emulated_live8.json" 2>/dev/null
+CFX_FAKE_RCCL_FAT=1 python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --no-cpu-baseline --long-steps 20 > "$OUT/r03_bench_emulated_live8_fat.json" 2>/dev/null
+python3 tools/xlayer_room_loop.py 2>&1 | grep -v amdgpu.ids > "$OUT/r03_xlayer_room_loop.txt"
+SHARE=0 python3 tools/xlayer_room_loop.py 2>&1 | grep -v amdgpu.ids > "$OUT/r03_xlayer_room_loop_stream_churn.txt"
 python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --exchange-pattern relay --no-cpu-baseline --long-steps 20 > "$OUT/r03_bench_emulated_live8_relay.json" 2>/dev/null
 # 4. the deployable path with real attention (SURVEY 8d protocol 2): all legs, then kernel traces of the lane leg and of attention alone
 python3 tools/overlap_bench.py --steps 20 --json "$OUT/r03_overlap.json" > /dev/null 2>&1
