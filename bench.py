@@ -951,6 +951,7 @@ def main():
                     ent = next((v for k_, v in tj["kernels"].items() if k_.startswith(pk_)), None)
                     if ent:
                         out["roofline"]["avg_launch_us_rocprof"] = ent["avg_us"]
+                        out["roofline"]["median_launch_us_rocprof"] = ent.get("median_us")
                         out["roofline"]["rocprof_source"] = "profiles/r03_bench_kernel_durations.json (rocprofv3 --kernel-trace of this command)"
             except Exception:
                 pass

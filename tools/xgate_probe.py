@@ -41,6 +41,15 @@ if os.environ.get("COMM"):
 def state():
     return x0.clone(), x0.unsqueeze(1).repeat(1, P, 1, 1, 1).contiguous()
 
+extra = []
+for _ in range(int(os.environ.get("EXTRA_MASKED", 0))):        # idle CU-masked streams: each is a hardware queue of its own
+    hh = ctypes.c_void_p()
+    assert lib.cfx_stream_create_masked(ctx, 0, 256, ctypes.byref(hh)) == 0
+    extra.append(hh.value)
+    if os.environ.get("EXTRA_USED"):                              # (touch it once: a queue only exists once something was launched on it)
+        torch.zeros(1, device=dev)
+        lib.cfx_flag_set(ctx, torch.zeros(16, dtype=torch.int32, device=dev).data_ptr(), 1, hh.value)
+torch.cuda.synchronize()
 shared_side = None
 if os.environ.get("SIDE") == "shared":
     hs = ctypes.c_void_p()

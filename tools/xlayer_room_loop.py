@@ -6,7 +6,7 @@ stream and one exchange stream for every repetition; SHARE=0: a fresh pair per r
 import ctypes, os, sys, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 os.environ["GPU_MAX_HW_QUEUES"] = "8"
-import test_gpu_exchange_layer as T
+import xlayer_cases as T
 from compactfusion_amd import _lib, codecs as K
 lib = _lib.load()
 os.environ["CFX_FAKE_RCCL_MODE"] = "loopback"; os.environ.setdefault("CFX_FAKE_RCCL_FAT", "1")
