@@ -153,6 +153,7 @@ struct PlanOp {
     int kind;   // 0 compress, 1 decompress, 2 all-gather on the side stream, 3 main stream waits for gather op `ref`, 4 ring hop,
                 // 5 wait until flag `ref` has reached the plan's epoch, 6 set flag `ref` to the epoch,
                 // 7 low-rank compress (codec = quantized, param = rank), 8 low-rank decompress,
+                // 10 = 9 without a collective (peers' packets read in place, one published word per rank and layer),
                 // 9 exchange layer: compress (c) ; all-gather (comm, send, recv; comm NULL = none) ; reconstruct (g) - one launch on the
                 //   main stream whose reconstruction group preloads its state and waits for the collective's arrival
     int codec, N, C, param, flags, batch;
@@ -172,6 +173,11 @@ struct PlanOp {
     hipEvent_t ev_pre, ev_done;
     int ref;
     int pre_flag;         // kind 1: flag this reconstruction launch publishes FIRST (the epoch), or -1
+    // kind 10 (exchange layer without a collective: peers' packets read in place through IPC mappings)
+    unsigned* own_flag;                              // this rank's "packets of this layer complete" word (in memory the peers have mapped)
+    const unsigned* peer_flag[CFX_P2P_MAX_PEERS];    // the peers' words
+    int n_peers;
+    unsigned runs;                                   // executions so far = the epoch published next
 };
 struct PipeSched;
 struct cfx_plan {
@@ -188,6 +194,7 @@ struct cfx_plan {
     unsigned* flags;      // exchange lane: n_flags flag words, a 64-byte line each (cfx_plan_flags)
     int n_flags;
     unsigned epoch;       // value the lane's flags take in the current replay (cfx_plan_run_lane advances it)
+    unsigned* p2p_sink;   // a device word nobody reads: where the in-order form of a p2p exchange layer "opens its gate"
 };
 
 

@@ -72,6 +72,36 @@ __global__ void k_flag_relay(const unsigned* wait, unsigned wv, unsigned* set, u
     __hip_atomic_store(set, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Peer-to-peer exchange without a collective (cfx_plan_add_exchange_layer_p2p): every rank's packets stay in ITS memory, mapped into
+// the peers (cfx_ipc_*); the reconstruction workgroups of a peer read them from there.  What travels is one word per rank and layer:
+//   wait until this rank's launch has completed its packets  ->  publish (own_pub = epoch, visible to the peers)
+//   wait until every peer has published the epoch            ->  open this launch's gate
+// One wave: lane 0 does the local steps, lane p polls peer p's word (system-scope loads: the word lives in another GPU's memory).
+struct PeerFlags { const unsigned* pub[CFX_P2P_MAX_PEERS]; };
+__global__ void k_flag_exchange(const unsigned* p_gate, unsigned p_expect, unsigned* own_pub, unsigned epoch, PeerFlags peers, int n_peers,
+                                unsigned* f_gate, unsigned f_expect, unsigned* err, long long timeout) {
+    const int lane = threadIdx.x;
+    const long long t0 = wall_clock64();
+    bool gave_up = false;
+    if (lane == 0) {
+        while ((int)(__hip_atomic_load(p_gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p_expect) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > timeout) { gave_up = true; break; }
+        }
+        // the packets were stored write-through and their stores had completed before the last arrival was counted: publishing after
+        // having SEEN the count orders them before the word for anybody who reads the word first
+        __hip_atomic_store(own_pub, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (lane < n_peers) {
+        while ((int)(__hip_atomic_load(peers.pub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > timeout) { gave_up = true; break; }
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(gave_up) != 0 && lane == 0 && err) (void)__hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 0) __hip_atomic_store(f_gate, f_expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 static int gate_check(cfx_ctx* ctx, const char* what) {
     if (ctx->gate_err && *(volatile unsigned*)ctx->gate_err) {
         char buf[200];
@@ -98,6 +128,7 @@ cfx_plan* cfx_plan_create(cfx_ctx* ctx) {
     p->flags = nullptr;
     p->n_flags = 0;
     p->epoch = 0;
+    p->p2p_sink = nullptr;
     // Default: collectives in order on the main stream.  Measured on MI355X / ROCm 7: one cross-stream event hop costs
     // ~10 us of idle queue time, two per layer (main->side, side->main) = +1.1 ms per 57-layer step, whereas the
     // in-order exchange adds 0.1 ms; a side stream only pays when >> 20 us of independent work can overlap (attention).
@@ -134,6 +165,7 @@ void cfx_plan_destroy(cfx_plan* p) {
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->pipe_ws) (void)hipFree(p->pipe_ws);
     if (p->flags) (void)hipFree(p->flags);
+    if (p->p2p_sink) (void)hipFree(p->p2p_sink);
     sched_free(p->sched);
     delete[] p->ops;
     delete p;
@@ -258,6 +290,73 @@ int cfx_plan_add_exchange_layer(cfx_plan* p, int codec, int N, int C, int param,
     memcpy(o->g, recon, sizeof(cfx_decomp_item) * n_recon);
     o->comm = comm; o->send = send; o->recv = recv; o->bytes_per_rank = bytes_per_rank;
     return op;
+}
+
+// The exchange layer without a collective: the peers' packets are READ IN PLACE from the peers' memory (recon items point into buffers
+// opened with cfx_ipc_open), and one word per rank and layer says when they are complete (k_flag_exchange above).  Nothing but two tiny
+// kernels ever runs on the exchange stream: there is no collective kernel that would have to find CUs beside the waiting workgroups.
+int cfx_plan_add_exchange_layer_p2p(cfx_plan* p, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                                    int n_recon, const cfx_decomp_item* recon, void* own_flag, int n_peers, const void* const* peer_flags,
+                                    void* workspace, size_t workspace_bytes) {
+    if (!p) return CFX_ERR_NULL;
+    if (n_peers < 0 || n_peers > CFX_P2P_MAX_PEERS || (n_peers && !peer_flags) || !own_flag)
+        return fail(p->ctx, CFX_ERR_BATCH, "plan: p2p exchange layer needs an own flag and 0..CFX_P2P_MAX_PEERS peer flags");
+    for (int i = 0; i < n_peers; ++i)
+        if (!peer_flags[i] || ((uintptr_t)peer_flags[i] & 3)) return fail(p->ctx, CFX_ERR_NULL, "plan: p2p exchange layer: null / misaligned peer flag");
+    const int op = cfx_plan_add_exchange_layer(p, codec, N, C, param, flags, batch, items, n_recon, recon, nullptr, nullptr, nullptr, 0, workspace, workspace_bytes);
+    if (op < 0) return op;
+    PlanOp* o = &p->ops[op];
+    o->kind = 10;
+    o->own_flag = (unsigned*)own_flag;
+    o->n_peers = n_peers;
+    for (int i = 0; i < n_peers; ++i) o->peer_flag[i] = (const unsigned*)peer_flags[i];
+    o->runs = 0;
+    if (!p->p2p_sink && hipMalloc((void**)&p->p2p_sink, 64) != hipSuccess) {
+        (void)hipGetLastError();
+        p->p2p_sink = nullptr;
+        return fail(p->ctx, CFX_ERR_LAUNCH, "plan: p2p exchange layer: hipMalloc failed");
+    }
+    return op;
+}
+
+// ---- device memory shared between the processes of a node (dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0) ---------------------------------
+int cfx_ipc_alloc(cfx_ctx* ctx, size_t bytes, void** ptr, void* handle64) {
+    if (!ctx || !ptr || !handle64 || !bytes) return fail(ctx, CFX_ERR_NULL, "ipc_alloc: null");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the C-ABI hands IPC handles around as 64 bytes");
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != ctx->device && hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CFX_ERR_LAUNCH, "ipc_alloc: hipSetDevice failed");
+    int rc = CFX_OK;
+    void* d = nullptr;
+    hipIpcMemHandle_t h;
+    if (hipMalloc(&d, bytes) != hipSuccess) { (void)hipGetLastError(); rc = fail(ctx, CFX_ERR_LAUNCH, "ipc_alloc: hipMalloc failed"); }
+    else if (hipMemset(d, 0, bytes) != hipSuccess || hipIpcGetMemHandle(&h, d) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(d);
+        rc = fail(ctx, CFX_ERR_LAUNCH, "ipc_alloc: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 is needed on hosts with dmabuf IPC only)");
+    } else { *ptr = d; memcpy(handle64, &h, 64); }
+    if (cur >= 0 && cur != ctx->device) (void)hipSetDevice(cur);
+    return rc;
+}
+int cfx_ipc_open(cfx_ctx* ctx, const void* handle64, void** ptr) {
+    if (!ctx || !ptr || !handle64) return fail(ctx, CFX_ERR_NULL, "ipc_open: null");
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != ctx->device && hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CFX_ERR_LAUNCH, "ipc_open: hipSetDevice failed");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, 64);
+    int rc = CFX_OK;
+    if (hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); rc = fail(ctx, CFX_ERR_LAUNCH, "ipc_open: hipIpcOpenMemHandle failed"); }
+    if (cur >= 0 && cur != ctx->device) (void)hipSetDevice(cur);
+    return rc;
+}
+int cfx_ipc_close(cfx_ctx* ctx, void* ptr) {
+    if (!ctx || !ptr) return fail(ctx, CFX_ERR_NULL, "ipc_close: null");
+    return hipIpcCloseMemHandle(ptr) == hipSuccess ? CFX_OK : fail(ctx, CFX_ERR_LAUNCH, "hipIpcCloseMemHandle failed");
+}
+int cfx_ipc_free(cfx_ctx* ctx, void* ptr) {
+    if (!ctx || !ptr) return fail(ctx, CFX_ERR_NULL, "ipc_free: null");
+    return hipFree(ptr) == hipSuccess ? CFX_OK : fail(ctx, CFX_ERR_LAUNCH, "hipFree failed");
 }
 
 int cfx_plan_size(const cfx_plan* p) { return p ? p->n : CFX_ERR_NULL; }
@@ -413,7 +512,8 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                 break;
             case 7: rc = cfx_lr_compress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, o->q0, o->ws, o->ws_bytes, stream); break;
             case 8: rc = cfx_lr_decompress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->batch, o->d, o->ws, o->ws_bytes, stream); break;
-            case 9: {
+            case 9:
+            case 10: {
                 CfxXGate xg;
                 memset(&xg, 0, sizeof(xg));
                 // CFX_XGATE_PERSISTENT=1 (developer): a reconstruction group small enough that nothing of the launch is ever pending - it
@@ -424,6 +524,20 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                 // (the legacy NULL stream serialises with the CU-masked exchange stream: a flag kernel there would wait for the very launch
                 // it is meant to release - run in order instead)
                 const bool own_stream = p->side && stream != nullptr && (hipStream_t)stream != p->side && !inline_exchange;
+                if (!own_stream && o->kind == 10) {
+                    // in order on the run stream: compress ; publish + wait for the peers ; reconstruct
+                    rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, 0, nullptr, 0, nullptr, o->ws, o->ws_bytes, stream);
+                    if (rc != CFX_OK) break;
+                    const unsigned epoch = ++o->runs;
+                    PeerFlags pf;
+                    memset(&pf, 0, sizeof(pf));
+                    for (int q = 0; q < o->n_peers; ++q) pf.pub[q] = o->peer_flag[q];
+                    hipLaunchKernelGGL(k_flag_exchange, dim3(1), dim3(64), 0, main_s, (const unsigned*)o->own_flag, 0u, o->own_flag, epoch, pf, o->n_peers,
+                                       p->p2p_sink, epoch, p->ctx->gate_err, p->ctx->gate_timeout);
+                    rc = check_launch(p->ctx, "p2p exchange layer: flag exchange launch (in order)");
+                    if (rc == CFX_OK) rc = cfx_i_decompress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->n_gated, o->g, stream, nullptr, 0u);
+                    break;
+                }
                 if (!own_stream && o->comm) {
                     // in order on the run stream: compress ; all-gather ; reconstruct
                     rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, 0, nullptr, 0, nullptr, o->ws, o->ws_bytes, stream);
@@ -437,6 +551,26 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                                    own_stream ? &xg : nullptr);
                 if (rc != CFX_OK || !own_stream) break;       // (no exchange stream, no collective: the ordinary gated launch)
                 hipStream_t xs = xg.taken ? p->side : main_s;
+                if (o->kind == 10) {
+                    // the epoch every rank publishes for this execution of the op: all ranks replay the same plans the same number of times
+                    const unsigned epoch = ++o->runs;
+                    PeerFlags pf;
+                    memset(&pf, 0, sizeof(pf));
+                    for (int q = 0; q < o->n_peers; ++q) pf.pub[q] = o->peer_flag[q];
+                    if (xg.taken) {
+                        hipLaunchKernelGGL(k_flag_exchange, dim3(1), dim3(64), 0, xs, (const unsigned*)xg.p_gate, xg.p_expect, o->own_flag, epoch, pf, o->n_peers,
+                                           xg.f_gate, xg.f_expect, p->ctx->gate_err, p->ctx->gate_timeout);
+                        rc = check_launch(p->ctx, "p2p exchange layer: flag exchange launch");
+                    } else {
+                        // no one-launch form here: compress has been launched on the run stream; publish and wait in stream order, then reconstruct
+                        // (the gate words are not used: the kernel's p_gate / f_gate point at a scratch word that already holds the values)
+                        hipLaunchKernelGGL(k_flag_exchange, dim3(1), dim3(64), 0, main_s, (const unsigned*)o->own_flag, 0u, o->own_flag, epoch, pf, o->n_peers,
+                                           p->p2p_sink, epoch, p->ctx->gate_err, p->ctx->gate_timeout);
+                        rc = check_launch(p->ctx, "p2p exchange layer: flag exchange launch (in order)");
+                        if (rc == CFX_OK) rc = cfx_i_decompress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->n_gated, o->g, stream, nullptr, 0u);
+                    }
+                    break;
+                }
                 // with a communicator: wait kernel ; ncclAllGather ; set kernel - the same three enqueues at every world size (a one-rank
                 // in-place all-gather enqueues nothing; CFX_XGATE_FUSE_ONE_RANK=1, developer: treat it like "no communicator")
                 static const bool fuse_one = getenv("CFX_XGATE_FUSE_ONE_RANK") != nullptr;

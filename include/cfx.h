@@ -269,6 +269,27 @@ int       cfx_plan_add_exchange_layer(cfx_plan* plan, int codec, int N, int C, i
                                       const cfx_comp_item* items, int n_recon, const cfx_decomp_item* recon,
                                       cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank,
                                       void* workspace, size_t workspace_bytes);
+/* The exchange layer WITHOUT a collective, for the GPUs of one node: every rank's packets stay where the compress launch wrote them - in
+ * a buffer from cfx_ipc_alloc that the peers have opened with cfx_ipc_open - and a peer's reconstruction workgroups read them from
+ * there over xGMI (`recon` items point into the opened mappings).  What is exchanged is one 4-byte word per rank and layer: the
+ * exchange stream's kernel waits for this launch's packets, sets *own_flag to the op's execution count (1, 2, ...: every rank replays
+ * the same plans equally often), waits until every peer_flags[i] has reached that count and opens the launch's gate.  No collective
+ * kernel runs, so nothing has to find CUs beside the waiting workgroups.  own_flag and the peers' flags live in cfx_ipc_alloc memory
+ * (zero-initialised), one word per op and plan; a plan must have at least two such ops per replay (a rank rewrites a layer's packets
+ * only after its peers have moved past that layer).  Replaces the all-gather of ring.py:188-206 / patchpara/fwd.py:108-109 on a
+ * single node.  Same fall-backs and timeouts as cfx_plan_add_exchange_layer. */
+#define CFX_P2P_MAX_PEERS 15
+int       cfx_plan_add_exchange_layer_p2p(cfx_plan* plan, int codec, int N, int C, int param, int flags, int batch,
+                                          const cfx_comp_item* items, int n_recon, const cfx_decomp_item* recon,
+                                          void* own_flag, int n_peers, const void* const* peer_flags,
+                                          void* workspace, size_t workspace_bytes);
+/* Device memory shared between the processes of a node (hipIpcGetMemHandle / hipIpcOpenMemHandle; on hosts with dmabuf IPC only the
+ * processes need HSA_ENABLE_IPC_MODE_LEGACY=0).  cfx_ipc_alloc: zeroed device memory + its 64-byte handle (send it to the peers by any
+ * means); cfx_ipc_open: map a peer's allocation; close / free when done. */
+int       cfx_ipc_alloc(cfx_ctx* ctx, size_t bytes, void** ptr, void* handle64);
+int       cfx_ipc_open(cfx_ctx* ctx, const void* handle64, void** ptr);
+int       cfx_ipc_close(cfx_ctx* ctx, void* ptr);
+int       cfx_ipc_free(cfx_ctx* ctx, void* ptr);
 /* One hop of the ring relay (reference xfuser/compact/ring.py:193-195,265-269: RingComm.send_recv / commit / wait): send
  * `bytes` to rank+1 and receive `bytes` from rank-1 as one grouped ncclSend + ncclRecv, on the exchange stream like an
  * all-gather op (cfx_plan_add_wait applies).  W-1 hops relay every rank's packet around the ring. */

@@ -340,3 +340,98 @@ def test_two_rank_threads_exchange_for_real():
             _made.remove(m)
         for c in ctxs:
             lib.cfx_destroy(c)
+
+
+# ---- the exchange layer without a collective: peers' packets read in place through IPC mappings --------------------------------------
+def _p2p_worker(r, W, tmp, L, N, C, steps, masked):
+    import time
+    import numpy as np
+    from compactfusion_amd import _lib, codecs as K
+    torch.cuda.set_device(0)
+    lib = _lib.load()
+    ctx = lib.cfx_create(0)
+    assert lib.cfx_prepare(ctx) == 0 and lib.cfx_set_gate_timeout_ms(ctx, 4000) == 0
+    slot = (K.packet_bytes(1, N, C) + 255) // 256 * 256
+    flags_off = L * 2 * slot
+    nbytes = flags_off + 2 * L * 64
+    ptr, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+    assert lib.cfx_ipc_alloc(ctx, nbytes, ctypes.byref(ptr), handle) == 0, lib.cfx_last_error_string(ctx)
+    with open(os.path.join(tmp, f"h{r}.tmp"), "wb") as f:
+        f.write(handle.raw)
+    os.replace(os.path.join(tmp, f"h{r}.tmp"), os.path.join(tmp, f"h{r}.bin"))
+    peers = {}
+    for q in range(W):
+        if q == r:
+            continue
+        fn = os.path.join(tmp, f"h{q}.bin")
+        t0 = time.time()
+        while not os.path.exists(fn):
+            assert time.time() - t0 < 60, "peer never published its handle"
+            time.sleep(0.01)
+        pp = ctypes.c_void_p()
+        assert lib.cfx_ipc_open(ctx, open(fn, "rb").read(), ctypes.byref(pp)) == 0, lib.cfx_last_error_string(ctx)
+        peers[q] = pp.value
+    g = torch.Generator(device="cuda").manual_seed(77)
+    x0 = torch.randn(W, L, 2, N, C, generator=g, device="cuda").half()                 # the same in every process
+    xs = [(x0.float() + 0.1 * (s + 1) * torch.randn(W, L, 2, N, C, generator=g, device="cuda")).half() for s in range(2)]
+    own = x0[r].clone()
+    peer = {q: x0[q].clone() for q in peers}
+    wsb = lib.cfx_workspace_bytes(1, N, C, 0, 2)
+    ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    run = _masked(lib, ctx, (256 // W) * r, 256 // W) if masked else None              # each rank its share of the CUs: a waiting launch of
+    keep = None                                                                       # one rank must not hold what the other's compress needs
+    if run is None:
+        keep = torch.cuda.Stream()
+        run = keep.cuda_stream
+    torch.cuda.synchronize()
+    plans = []
+    for s in range(2):
+        plan = lib.cfx_plan_create(ctx)
+        for l in range(L):
+            c = (_lib.CompItem * 2)(*[_lib.CompItem(xs[s][r, l, b].data_ptr(), own[l, b].data_ptr(), own[l, b].data_ptr(), ptr.value + (l * 2 + b) * slot)
+                                      for b in range(2)])
+            items = [_lib.DecompItem(peers[q] + (l * 2 + b) * slot, peer[q][l, b].data_ptr(), peer[q][l, b].data_ptr()) for q in peers for b in range(2)]
+            d = (_lib.DecompItem * len(items))(*items)
+            pf = (ctypes.c_void_p * len(peers))(*[peers[q] + flags_off + (s * L + l) * 64 for q in peers])
+            rc = lib.cfx_plan_add_exchange_layer_p2p(plan, 1, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, c, len(items), d,
+                                                     ptr.value + flags_off + (s * L + l) * 64, len(peers), pf, ws.data_ptr(), wsb)
+            assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
+        plans.append(plan)
+    for i in range(steps):
+        rc = lib.cfx_plan_run(plans[i & 1], 0, L, run)
+        assert rc == 0, (rc, lib.cfx_last_error_string(ctx))
+    torch.cuda.synchronize()
+    ge = lib.cfx_gate_errors(ctx)
+    np.save(os.path.join(tmp, f"own{r}.npy"), own.cpu().numpy().view(np.uint16))
+    for q in peer:
+        np.save(os.path.join(tmp, f"peer{r}_{q}.npy"), peer[q].cpu().numpy().view(np.uint16))
+    np.save(os.path.join(tmp, f"x0_{r}.npy"), x0[r].cpu().numpy().view(np.uint16))
+    # everybody done reading everybody's packets before anything is unmapped
+    open(os.path.join(tmp, f"done{r}"), "w").close()
+    t0 = time.time()
+    while not all(os.path.exists(os.path.join(tmp, f"done{q}")) for q in range(W)):
+        assert time.time() - t0 < 60
+        time.sleep(0.01)
+    for p in plans:
+        lib.cfx_plan_destroy(p)
+    for q in peers:
+        lib.cfx_ipc_close(ctx, ctypes.c_void_p(peers[q]))
+    lib.cfx_ipc_free(ctx, ptr)
+    assert ge == 0, f"rank {r}: {ge} gate errors"
+
+
+@pytest.mark.parametrize("N,C,masked", [(544, 3072, True), (96, 1024, True), (128, 1088, False)])
+def test_p2p_exchange_two_processes_one_gpu(tmp_path, N, C, masked):
+    """cfx_plan_add_exchange_layer_p2p: two rank PROCESSES on one GPU, each with its packets in cfx_ipc_alloc memory the other has opened;
+    no collective library at all.  Every rank's reconstruction of the other's shard must equal that rank's own error-feedback state, bit
+    for bit, over several steps (the packets are read in place from the other process's allocation, ordered by one published word per
+    layer).  (128, 1088): a shape without the one-launch form -> compress ; publish + wait ; reconstruct in stream order."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    W, L, steps = 2, 4, 4
+    mp.start_processes(_p2p_worker, args=(W, str(tmp_path), L, N, C, steps, masked), nprocs=W, join=True, start_method="spawn")
+    for r in range(W):
+        own = np.load(tmp_path / f"own{r}.npy")
+        assert not np.array_equal(own, np.load(tmp_path / f"x0_{r}.npy"))
+        got = np.load(tmp_path / f"peer{1 - r}_{r}.npy")
+        assert np.array_equal(got, own), f"rank {1 - r}: reconstruction of rank {r}'s shard differs from rank {r}'s own state"
