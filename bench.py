@@ -118,6 +118,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="debug: 'gloo' lets several ranks share one GPU to exercise the N>1 path")
     ap.add_argument("--same-gpu", action="store_true", help="debug: every rank uses cuda:0")
+    ap.add_argument("--p2p", choices=["auto", "off"], default="auto",
+                    help="N > 1, --own-ef xgate: auto = no collective at all - every rank's packets stay in IPC-shared memory and the peers' reconstruction "
+                         "workgroups read them in place (cfx_plan_add_exchange_layer_p2p; single node); off = ncclAllGather on the exchange stream")
     ap.add_argument("--dist-path", action="store_true",
                     help="debug: take the N>1 code path (per-layer collectives) even with one rank, to measure its host overhead")
     ap.add_argument("--exchange", choices=["native", "torch"], default="native",
@@ -418,7 +421,14 @@ def main():
     if xgate:
         # the exchange-layer op orders its two streams by flag words: the run stream must not be the legacy NULL stream (it serialises
         # with every blocking stream, the CU-masked exchange stream included)
-        torch.cuda.set_stream(torch.cuda.Stream(dev))
+        if args.same_gpu and world > 1:
+            # debug: the ranks share one GPU - a waiting layer launch of one rank must not hold the CUs another rank's compress group needs
+            hm = ctypes.c_void_p()
+            share = 256 // world
+            assert lib.cfx_stream_create_masked(ctx, share * rank, share, ctypes.byref(hm)) == 0
+            torch.cuda.set_stream(torch.cuda.ExternalStream(hm.value, device=dev))
+        else:
+            torch.cuda.set_stream(torch.cuda.Stream(dev))
         hx = ctypes.c_void_p()
         assert lib.cfx_stream_create_masked(ctx, 0, 256, ctypes.byref(hx)) == 0      # ONE exchange stream for every plan: each stream is a hardware queue
         xside = hx.value
@@ -430,6 +440,7 @@ def main():
     #   pipelined: --gather-group layers share one all-gather and form one unit of the pipelined replay; --exchange-stream
     #              prio|side runs the collective of unit u on an exchange stream underneath the next fused launch
     native_comm, step_plans, exchange_mode, stream_mode, build_step_plans = None, None, "none", 0, None
+    p2p_ptr, p2p_peer = None, {}
     if use_dist:
         exchange_mode = "torch"
         if args.exchange == "torch" and world == 1:
@@ -437,9 +448,17 @@ def main():
         if args.exchange == "native":
             try:
                 from compactfusion_amd.exchange import NativeComm
-                native_comm = NativeComm(local_rank, solo_ranks=live if world == 1 else 0, library=args.rccl_lib)
-                if not args.emulate_live:
-                    native_comm.self_test()
+                try:
+                    native_comm = NativeComm(local_rank, solo_ranks=live if world == 1 else 0, library=args.rccl_lib)
+                    if not args.emulate_live:
+                        native_comm.self_test()
+                except Exception as e_comm:
+                    # --same-gpu (debug): RCCL refuses two ranks on one device; the peer-to-peer exchange needs no collective library
+                    if not (args.same_gpu and world > 1 and xgate and args.p2p == "auto"):
+                        raise
+                    native_comm = None
+                    if rank == 0:
+                        print(f"[bench] no collective library here ({e_comm}); peer-to-peer exchange only, raw-exchange legs skipped", file=sys.stderr)
                 groups = [(a, min(L, a + G)) for a in range(0, L, G)]
 
                 def build_step_plans(mode, relay_=None, xlayer=None, comm_=True, side_=None):
@@ -470,8 +489,61 @@ def main():
                         built.append(sp)
                     return built
                 stream_mode = {"main": 0, "side": 1, "prio": 2}[args.exchange_stream] if pipelined else 0
-                step_plans = build_step_plans(stream_mode)
-                exchange_mode = "native"
+                if native_comm is not None:
+                    step_plans = build_step_plans(stream_mode)
+                    exchange_mode = "native"
+                if xgate and world > 1 and args.p2p == "auto":
+                    # ---- no collective at all: packets stay in IPC-shared memory, the peers read them in place ---------------------------
+                    flags_off = L * 2 * slot
+                    p2p_ptr, p2p_handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+                    check_rc = lib.cfx_ipc_alloc(ctx, flags_off + 2 * L * 64, ctypes.byref(p2p_ptr), p2p_handle)
+                    ok_all = torch.tensor([1 if check_rc == 0 else 0], device=dev, dtype=torch.int32)
+                    dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+                    if int(ok_all.item()) == 1:
+                        handles = [None] * world
+                        dist.all_gather_object(handles, bytes(p2p_handle.raw))
+                        p2p_peer = {}
+                        opened = 1
+                        for q in range(world):
+                            if q != rank:
+                                pq = ctypes.c_void_p()
+                                if lib.cfx_ipc_open(ctx, handles[q], ctypes.byref(pq)) != 0:
+                                    opened = 0
+                                    break
+                                p2p_peer[q] = pq.value
+                        ok_all = torch.tensor([opened], device=dev, dtype=torch.int32)
+                        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+                    if int(ok_all.item()) == 1:
+                        def build_p2p_plans():
+                            built = []
+                            for s_ in range(2):
+                                sp = lib.cfx_plan_create(ctx)
+                                assert lib.cfx_plan_use_exchange_stream(sp, xside) == 0
+                                for l in range(L):
+                                    carr = (_lib.CompItem * 2)()
+                                    for kv in range(2):
+                                        carr[kv] = _lib.CompItem(xs[s_][l, kv].data_ptr(), own_base[l, kv].data_ptr(), own_base[l, kv].data_ptr(),
+                                                                 p2p_ptr.value + (l * 2 + kv) * slot)
+                                    items = []
+                                    for p in range(W_LOGICAL - 1):
+                                        real = p < world - 1
+                                        src = p2p_peer[(rank + 1 + p) % world] if real else p2p_ptr.value        # a looped-back logical peer reads OUR packets
+                                        for kv in range(2):
+                                            items.append(_lib.DecompItem(src + (l * 2 + kv) * slot, peer_base[l, p, kv].data_ptr(), peer_base[l, p, kv].data_ptr()))
+                                    pf = (ctypes.c_void_p * (world - 1))(*[p2p_peer[q] + flags_off + (s_ * L + l) * 64 for q in sorted(p2p_peer)])
+                                    rc_ = lib.cfx_plan_add_exchange_layer_p2p(sp, CODEC, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, carr, len(items),
+                                                                              (_lib.DecompItem * len(items))(*items), p2p_ptr.value + flags_off + (s_ * L + l) * 64,
+                                                                              world - 1, pf, ws.data_ptr(), ws_bytes)
+                                    assert rc_ >= 0, (rc_, lib.cfx_last_error_string(ctx))
+                                assert lib.cfx_plan_finalize(sp) == 0
+                                built.append(sp)
+                            return built
+                        for pl_ in (step_plans or []):
+                            lib.cfx_plan_destroy(pl_)
+                        step_plans = build_p2p_plans()
+                        exchange_mode = "p2p"
+                    elif rank == 0:
+                        print("[bench] IPC-shared packet buffers unavailable; the collective stays in the path (ncclAllGather on the exchange stream)", file=sys.stderr)
             except Exception as e:  # pragma: no cover
                 if not args.allow_fallback:
                     raise SystemExit(f"[bench] native exchange unavailable ({e}); pass --allow-fallback to time torch.distributed per layer instead")
@@ -547,17 +619,26 @@ def main():
         # of RCCL's register footprint is then placed every time on this hardware (tools/xlayer_room_loop.py) - but RCCL itself has never run
         # here beside it on more than one GPU.  So the first step runs with a short gate timeout, and a gate that did not open on ANY rank
         # sends every rank to two launches per layer (the launches that gave up ran on garbage: the states are reset either way).
+        sync_all()                                   # (the ranks enter the validated step together: its waits are short)
         lib.cfx_set_gate_timeout_ms(ctx, 300)
         one_step(0)
         sync_all()
-        bad = torch.tensor([lib.cfx_gate_errors(ctx)], device=dev, dtype=torch.int32)
+        n_bad = lib.cfx_gate_errors(ctx)
+        if n_bad == 0 and exchange_mode == "p2p":
+            n_bad = 0 if states_consistent()[0] else 1      # packets read in place from the peers' memory: the states must agree
+        bad = torch.tensor([n_bad], device=dev, dtype=torch.int32)
         if world > 1:
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         lib.cfx_set_gate_timeout_ms(ctx, 5000)
         if int(bad.item()) != 0:
-            print("[bench] exchange-layer launches timed out waiting for the collective; running compress ; all-gather ; reconstruct in stream order", file=sys.stderr)
-            schedule_fallback = ("the exchange-layer op timed out in the validation step (the collective's kernel was not placed beside the waiting "
-                                 "workgroups); two launches per layer in stream order instead")
+            print("[bench] exchange-layer launches failed their validation step; running compress ; all-gather ; reconstruct in stream order", file=sys.stderr)
+            schedule_fallback = ("the exchange-layer op failed its validation step (" + ("peer-to-peer packet reads: gate timeout or inconsistent states"
+                                 if exchange_mode == "p2p" else "the collective's kernel was not placed beside the waiting workgroups") +
+                                 "); two launches per layer around ncclAllGather in stream order instead")
+            if native_comm is None:
+                raise SystemExit("[bench] the peer-to-peer exchange failed its validation step and there is no collective library to fall back to")
+            if exchange_mode == "p2p":
+                exchange_mode = "native"
             xgate = one_launch = False
             args.own_ef = "ride"
             ride = True
@@ -757,6 +838,7 @@ def main():
     inorder_ms = other_ms if pipelined else ms_per_step
     pipe_ms = ms_per_step if pipelined else other_ms
 
+    P2P = exchange_mode == "p2p"
     XNAME = ("no collective (--no-collective)" if not use_dist else
              ("ring relay: " + str(live - 1) + " grouped ncclSend/ncclRecv hops" if relay else "ncclAllGather, in place (packets are written straight into the rank's slot of the gather buffer)")
              + f" over libcfx's own {'loop-back stand-in' if args.emulate_live else 'RCCL'} communicator of {live} rank(s), issued from the native plan")
@@ -793,6 +875,12 @@ def main():
                      ("layer by layer in order, LOOP-BACK ONLY (no collective can sit inside it): ONE launch per layer = compress K,V [statistics + sign bits + in-launch "
                       "finalize] + the 16 reconstructions its packets feed (own error feedback, 7 looped-back peers' K,V): their workgroups "
                       "pull the state tiles into registers while the scale reduction completes, wait on an arrival gate, finish from registers") if gated else
+                     ("layer by layer in order (deployable), NO collective: every rank's packets stay in IPC-shared memory of its own GPU, the peers' "
+                      "reconstruction workgroups read them in place over xGMI.  Per layer ONE codec launch on the run stream = compress K,V [statistics + "
+                      "sign bits + in-launch finalize] + own error-feedback update + reconstruction of the 7 peers' K,V, whose workgroups pull their state "
+                      "tiles into registers and then wait for a gate word; on the exchange stream ONE small kernel: wait for this launch's packets, publish "
+                      f"a word the {live - 1} live peer(s) have mapped, wait for their words, open the gate (cfx_plan_add_exchange_layer_p2p).  The first "
+                      "step was validated (gate timeouts, state consistency across ranks)") if (xgate and P2P) else
                      ("layer by layer in order (deployable), the collective in the path: per layer ONE codec launch on the run stream = compress K,V "
                       "[statistics + sign bits + in-launch finalize; packets written straight into the rank's slot of the gather buffer] + own "
                       "error-feedback update + reconstruction of the 7 peers' K,V, whose workgroups pull their state tiles into registers and "
@@ -985,6 +1073,12 @@ def main():
     # tear the communicators down first and flush C stdio (RCCL prints a version banner through its own stdio buffer),
     # so that the JSON line is the LAST thing on stdout
     torch.cuda.synchronize(dev)
+    if p2p_ptr is not None and p2p_ptr.value:
+        sync_all()                                   # nobody unmaps or frees while a peer may still read
+        for q_, pq_ in p2p_peer.items():
+            lib.cfx_ipc_close(ctx, ctypes.c_void_p(pq_))
+        sync_all()
+        lib.cfx_ipc_free(ctx, p2p_ptr)
     for plset in (step_plans, plans_inorder, plans_pipe, plans_gated):
         for pl_ in (plset or []):
             lib.cfx_plan_destroy(pl_)

@@ -39,7 +39,7 @@ def test_bench_falls_back_when_the_collective_cannot_be_placed():
         d = _bench("--emulate-live", "2", "--rccl-lib", _fake(), "--no-cpu-baseline", "--no-raw-baseline", "--layers", "3")
     finally:
         os.environ.pop("CFX_FAKE_RCCL_FAT", None)
-    assert d["launches_per_layer"] == 2 and "timed out" in d["schedule_fallback"]
+    assert d["launches_per_layer"] == 2 and "validation step" in d["schedule_fallback"]
 
 
 def test_bench_with_a_collective_kernel_of_rccl_footprint():
@@ -90,3 +90,20 @@ def test_bench_n_gt_1_plumbing_over_the_loopback_library(live, pattern):
     assert x["raw_bytes_per_gpu_per_step"] == (live - 1) * 2 * 6 * d["config"]["raw_bytes"]
     assert "no Python-issued collective" in x["issued_by"]
     assert d["raw_exchange_ms_per_step"].keys() == {"allgather", "relay"} and d["speedup_vs_raw_allgather"] > 0
+
+
+def test_bench_two_rank_processes_exchange_peer_to_peer():
+    """N = 2 as the driver launches it (torch.distributed.run, one process per rank) - on ONE GPU here (--same-gpu --backend gloo; RCCL refuses
+    two ranks on a device, so there is no collective library at all): the packets stay in each process's IPC-shared buffer, the other
+    process's reconstruction workgroups read them in place, one published word per rank and layer (cfx_plan_add_exchange_layer_p2p).  The
+    bench validates its first step (gate timeouts, state consistency across the ranks) and checks the states again at the end."""
+    env = dict(os.environ)
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29613", os.path.join(REPO, "bench.py"), "--gpus", "2", "--same-gpu", "--backend", "gloo", "--layers", "6",
+                        "--steps", "4", "--warmup", "1", "--long-steps", "4", "--overlap-steps", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stderr[-2500:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["exchange_issued_by"] == "p2p" and d["launches_per_layer"] == 1 and d["schedule_fallback"] is None
+    assert "NO collective" in d["schedule"] and d["scaling"] == "weak"
