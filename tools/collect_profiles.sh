@@ -53,6 +53,7 @@ python3 bench.py --no-collective --own-ef gated --overlap-steps 0 --no-cpu-basel
 python3 bench.py --own-ef ride --overlap-steps 0 --no-cpu-baseline > "$OUT/r03_bench_n1_two_launch.json" 2>/dev/null
 python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --no-cpu-baseline --long-steps 20 > "$OUT/r03_bench_emulated_live8.json" 2>/dev/null
 CFX_FAKE_RCCL_FAT=1 python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --no-cpu-baseline --long-steps 20 > "$OUT/r03_bench_emulated_live8_fat.json" 2>/dev/null
+timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29617 bench.py --gpus 2 --same-gpu --backend gloo --no-cpu-baseline --overlap-steps 0 --steps 20 --warmup 3 --long-steps 20 2>/dev/null | tail -1 > "$OUT/r03_bench_p2p_two_processes_one_gpu.json"
 python3 tools/xlayer_room_loop.py 2>&1 | grep -v amdgpu.ids > "$OUT/r03_xlayer_room_loop.txt"
 SHARE=0 python3 tools/xlayer_room_loop.py 2>&1 | grep -v amdgpu.ids > "$OUT/r03_xlayer_room_loop_stream_churn.txt"
 python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --exchange-pattern relay --no-cpu-baseline --long-steps 20 > "$OUT/r03_bench_emulated_live8_relay.json" 2>/dev/null
