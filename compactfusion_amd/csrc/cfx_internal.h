@@ -148,7 +148,8 @@ struct cfx_comm {
 // the gated reconstruction group proceeds once *f_gate == f_expect
 // persistent (in): size the reconstruction group so that nothing of the launch is ever pending (a collective kernel needs CUs meanwhile)
 // needs_room (in): a collective kernel will run while the reconstruction group waits - take the one-launch form only if the group leaves it CUs
-struct CfxXGate { int taken; unsigned* p_gate; unsigned p_expect; unsigned* f_gate; unsigned f_expect; int persistent; int needs_room; };
+struct CfxXGate { int taken; unsigned* p_gate; unsigned p_expect; unsigned* f_gate; unsigned f_expect; int persistent; int needs_room;
+                  int remote; };    // remote (in): the reconstruction items' packets may sit in a peer GPU's memory
 struct PlanOp {
     int kind;   // 0 compress, 1 decompress, 2 all-gather on the side stream, 3 main stream waits for gather op `ref`, 4 ring hop,
                 // 5 wait until flag `ref` has reached the plan's epoch, 6 set flag `ref` to the epoch,

@@ -121,6 +121,10 @@ __device__ __forceinline__ unsigned ld_wt(const unsigned* p) { return __hip_atom
 __device__ __forceinline__ void st_wt(u16* p, u16 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u16 ld_wt(const u16* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned char ld_wt(const unsigned char* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// system scope: the word may live in ANOTHER GPU's memory (packets read in place through an IPC mapping, cfx_plan_add_exchange_layer_p2p)
+__device__ __forceinline__ u64 ld_sys(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ u16 ld_sys(const u16* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned char ld_sys(const unsigned char* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 // 16-byte write-through store (an agent-scope atomic store lowers to `sc1` only up to 8 bytes).  hipcc does not count an asm
 // store: the publishing wave drains it with its own `s_waitcnt vmcnt(0)`; the trailing s_nop keeps the data registers alive
 // until the store has read them (cdna_hip_programming.md 5.7).
@@ -631,7 +635,8 @@ __device__ __forceinline__ h16x8 ld8_wt(const u16* p) {
 
 template <int NW, int KR, int KL, bool ST>
 __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item& it, int N, int C, int R, int tile_x, int tile_y,
-                                                         unsigned* gate, unsigned expect, unsigned* err, u32x4* lds, u64* stamps = nullptr) {
+                                                         unsigned* gate, unsigned expect, unsigned* err, u32x4* lds, u64* stamps = nullptr,
+                                                         bool remote = false) {
     constexpr int K = KR + KL;
 #define GSTAMP(k) do { if (ST && stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 0) stamps[k] = wall_clock64(); } } while (0)
     const TileCoord t = tile_coord_at(tile_x, tile_y, N, C, R);
@@ -663,12 +668,24 @@ __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item&
     GSTAMP(1);
     gate_wait<true>(gate, expect, err);
     if (ST && stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
-    const h16x8 v8 = ld8_wt(V + cc);
-    // a row's token scale is wave-uniform: lane j fetches row j's, broadcast by readlane below
-    const u16 ul = ld_wt(U + min(t.r0 + t.w + NW * min(t.lane, K - 1), t.r1 - 1));
+    h16x8 v8;
+    u16 ul;
     unsigned by[K];
+    if (remote) {                                            // (uniform) the packet sits in a peer GPU's memory: system-scope loads
+        u16x8 vb;
 #pragma unroll
-    for (int j = 0; j < K; ++j) by[j] = ld_wt(pk + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C8 + (cc >> 3));
+        for (int i = 0; i < 8; ++i) vb[i] = ld_sys(V + cc + i);
+        v8 = __builtin_bit_cast(h16x8, vb);
+        ul = ld_sys(U + min(t.r0 + t.w + NW * min(t.lane, K - 1), t.r1 - 1));
+#pragma unroll
+        for (int j = 0; j < K; ++j) by[j] = ld_sys(pk + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C8 + (cc >> 3));
+    } else {
+        v8 = ld8_wt(V + cc);
+        // a row's token scale is wave-uniform: lane j fetches row j's, broadcast by readlane below
+        ul = ld_wt(U + min(t.r0 + t.w + NW * min(t.lane, K - 1), t.r1 - 1));
+#pragma unroll
+        for (int j = 0; j < K; ++j) by[j] = ld_wt(pk + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C8 + (cc >> 3));
+    }
     GSTAMP(3);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
@@ -1044,6 +1061,7 @@ struct FusedArgs {
     // counter - whoever moves the packets (a collective on the exchange stream) sets it once they have arrived.  NULL: wait on `gate`.
     unsigned* xgate;
     unsigned xexpect;
+    int remote;              // the gated items' packets may sit in a peer GPU's memory (read with system-scope loads)
 };
 #ifndef GATE_WPE
 #define GATE_WPE 4               // waves per SIMD the single-launch compress kernels are compiled for (2 workgroups / CU)
@@ -1072,7 +1090,7 @@ __global__ __launch_bounds__(FUSED_NT, GATE_WPE) void k_absmean_compress(BatchC 
                     binary_dequant_gated_body<FUSED_NW, GATE_KR, 0, ST>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.xgate ? a.xgate : a.gate,
                                                                 a.xgate ? a.xexpect : a.gate_expect, a.gate_err,
                                                                 nullptr,
-                                                                a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr);
+                                                                a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr, a.remote != 0);
                 }
                 return;
             }
@@ -2223,7 +2241,7 @@ static unsigned ticket_slot(cfx_ctx* ctx, void* stream) {
 static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                          int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
                          void* workspace, size_t workspace_bytes, void* stream, CfxXGate* xg = nullptr) {
-    if (xg) { const int pers = xg->persistent, room = xg->needs_room; memset(xg, 0, sizeof(*xg)); xg->persistent = pers; xg->needs_room = room; }
+    if (xg) { const int pers = xg->persistent, room = xg->needs_room, rem = xg->remote; memset(xg, 0, sizeof(*xg)); xg->persistent = pers; xg->needs_room = room; xg->remote = rem; }
     if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "compress: null ctx/items");
     if (n_gated < 0 || n_gated > CFX_MAX_BATCH || (n_gated && !gated)) return fail(ctx, CFX_ERR_BATCH, "compress: gated batch out of range");
     if (n_gated && codec != CFX_CODEC_BINARY && codec != CFX_CODEC_INT2)
@@ -2400,6 +2418,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                 if (xg) {
                     a.xgate = a.gate + GATE_BLOCK;                    // the slot's second gate block (the 2-bit layer launch's gate 2)
                     a.xexpect = ++ctx->gate_expect[2 * slot + 1];
+                    a.remote = xg->remote;
                     xg->taken = 1;
                     xg->p_gate = a.gate; xg->p_expect = a.gate_expect;
                     xg->f_gate = a.xgate; xg->f_expect = a.xexpect;

@@ -521,6 +521,7 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                 static const char* pers_env = getenv("CFX_XGATE_PERSISTENT");
                 xg.persistent = pers_env ? atoi(pers_env) : 0;
                 xg.needs_room = o->comm && o->comm->nranks > 1;
+                xg.remote = o->kind == 10 && o->n_peers > 0;
                 // (the legacy NULL stream serialises with the CU-masked exchange stream: a flag kernel there would wait for the very launch
                 // it is meant to release - run in order instead)
                 const bool own_stream = p->side && stream != nullptr && (hipStream_t)stream != p->side && !inline_exchange;
