@@ -117,6 +117,13 @@ def test_plan_building_without_gpu():
     assert lib.cfx_plan_add_exchange_layer(xl, 1, 544, 3072, 0, 1, 2, c, 14, d, None, None, None, 0, 0x9000, 1 << 20) == 0
     assert lib.cfx_plan_add_exchange_layer(xl, 1, 544, 3077, 0, 1, 2, c, 14, d, None, None, None, 0, 0x9000, 1 << 20) == -2      # bad shape
     assert lib.cfx_plan_size(xl) == 1
+    # ... and its collective-free form: flags are checked before anything is allocated
+    pf = (ctypes.c_void_p * 2)(0xd000, 0xd040)
+    assert lib.cfx_plan_add_exchange_layer_p2p(xl, 1, 544, 3072, 0, 1, 2, c, 14, d, None, 2, pf, 0x9000, 1 << 20) == -5          # no own flag
+    assert lib.cfx_plan_add_exchange_layer_p2p(xl, 1, 544, 3072, 0, 1, 2, c, 14, d, 0xe000, 16, pf, 0x9000, 1 << 20) == -5       # too many peers
+    bad = (ctypes.c_void_p * 2)(0xd000, 0xd042)
+    assert lib.cfx_plan_add_exchange_layer_p2p(xl, 1, 544, 3072, 0, 1, 2, c, 14, d, 0xe000, 2, bad, 0x9000, 1 << 20) == -1       # misaligned peer flag
+    assert lib.cfx_ipc_open(ctx, None, None) == -1 and lib.cfx_ipc_close(ctx, None) == -1 and lib.cfx_ipc_free(ctx, None) == -1
     lib.cfx_plan_destroy(xl)
     lib.cfx_plan_destroy(other)
     lib.cfx_plan_destroy(plan)
