@@ -32,7 +32,7 @@ looped-back peers and NO collective in between; never `value`.
 `low_rank_presets` (N = 1): compress time per K,V pair of the reference's LOW_RANK / LOW_RANK_Q presets on the same shard (one persistent
 launch each, csrc/cfx_lrslab.hip).
 `overlap_with_attention` (N = 1): SURVEY 8d protocol 2 - the deployable path (compact_fwd on the exchange lane) beside real SDPA
-attention: what the exchange adds to a model step (tools/overlap_bench.py, run in-process after the timed legs).
+attention: what the exchange adds to a model step (tools/overlap_bench.py, run as a child process after the timed legs).
 Inputs are synthetic and already resident in HBM; the state arenas (3.0 GB) + inputs (0.76 GB) dwarf the 256 MB
 Infinity Cache, so every step streams from HBM (cold numbers).
 
@@ -1097,14 +1097,19 @@ def main():
         try:
             del xs, own_base, peer_base
             torch.cuda.empty_cache()
-            import runpy
-            argv0 = sys.argv
-            sys.argv = ["overlap_bench.py", "--quiet", "--steps", str(args.overlap_steps), "--layers", str(L),
-                        "--legs", "attention_on_compute_lane,lane,attention_distinct_kv_on_compute_lane"]
-            try:
-                ov = runpy.run_path(os.path.join(REPO, "tools", "overlap_bench.py"), run_name="__main__")["out"]
-            finally:
-                sys.argv = argv0
+            # a process of its own: this one has had RCCL, the exchange stream and half a dozen plan sets in it, and the lane's figure is
+            # about two flag-ordered streams beside attention kernels, nothing else (in-process it read 0.15 ms/step higher, same box)
+            import subprocess
+            import tempfile
+            torch.cuda.synchronize(dev)
+            with tempfile.TemporaryDirectory() as td:
+                jpath = os.path.join(td, "overlap.json")
+                r_ov = subprocess.run([sys.executable, os.path.join(REPO, "tools", "overlap_bench.py"), "--quiet", "--steps", str(args.overlap_steps),
+                                       "--layers", str(L), "--legs", "attention_on_compute_lane,lane,attention_distinct_kv_on_compute_lane",
+                                       "--json", jpath], capture_output=True, text=True, timeout=900, cwd=REPO)
+                if r_ov.returncode != 0:
+                    raise RuntimeError("tools/overlap_bench.py failed: " + r_ov.stderr[-400:])
+                ov = json.load(open(jpath))
             legs = ov["legs_ms_per_step"]
             out["overlap_with_attention"] = {
                 "protocol": ov["protocol"], "steps": ov["steps"], "lane": ov["lane"],

@@ -34,7 +34,7 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--layers", type=int, default=57)
 ap.add_argument("--json", default=None)
 ap.add_argument("--quick", action="store_true", help="only the attention, lane and event-fork legs")
-ap.add_argument("--quiet", action="store_true", help="do not print the JSON (bench.py runs this file in-process and reads `out`)")
+ap.add_argument("--quiet", action="store_true", help="do not print the JSON (bench.py runs this file as a child process and reads --json)")
 ap.add_argument("--legs", default=None, help="comma-separated subset of the legs (for kernel traces); default all")
 args = ap.parse_args()
 
