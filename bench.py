@@ -108,7 +108,7 @@ def parse():
                          "xgmi object on one GPU; the figures are not link measurements")
     ap.add_argument("--rccl-lib", default=None, help="debug: collective library to load instead of the RCCL the process already uses")
     ap.add_argument("--no-raw-baseline", action="store_true", help="N > 1: skip the uncompressed all-gather legs")
-    ap.add_argument("--overlap-steps", type=int, default=5,
+    ap.add_argument("--overlap-steps", type=int, default=12,
                     help="N = 1: after the timed legs, also run SURVEY 8d protocol 2 for this many steps (tools/overlap_bench.py in-process: compact_fwd "
                          "on the exchange lane beside real SDPA attention, 8 logical ranks looped back) and carry its exposed-exchange figure; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
