@@ -417,7 +417,8 @@ int cfx_plan_add_ring_hop(cfx_plan* p, cfx_comm* comm, const void* send, void* r
 
 int cfx_plan_set_input(cfx_plan* p, int op, int item, const void* x) {
     if (!p || !x) return CFX_ERR_NULL;
-    if (op < 0 || op >= p->n || (p->ops[op].kind != 0 && p->ops[op].kind != 7) || item < 0 || item >= p->ops[op].batch)
+    const int kind = (op >= 0 && op < p->n) ? p->ops[op].kind : -1;
+    if ((kind != 0 && kind != 7 && kind != 9 && kind != 10) || item < 0 || item >= p->ops[op].batch)
         return fail(p->ctx, CFX_ERR_BATCH, "plan: set_input needs a compress op and an item of its batch");
     if (!AL16(x)) return fail(p->ctx, CFX_ERR_ALIGN, "plan: pointers must be 16-byte aligned");
     p->ops[op].c[item].x = x;

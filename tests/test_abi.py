@@ -117,6 +117,7 @@ def test_plan_building_without_gpu():
     assert lib.cfx_plan_add_exchange_layer(xl, 1, 544, 3072, 0, 1, 2, c, 14, d, None, None, None, 0, 0x9000, 1 << 20) == 0
     assert lib.cfx_plan_add_exchange_layer(xl, 1, 544, 3077, 0, 1, 2, c, 14, d, None, None, None, 0, 0x9000, 1 << 20) == -2      # bad shape
     assert lib.cfx_plan_size(xl) == 1
+    assert lib.cfx_plan_set_input(xl, 0, 1, 0xc000) == 0 and lib.cfx_plan_set_input(xl, 0, 2, 0xc000) == -5     # activations re-pointed per call
     # ... and its collective-free form: flags are checked before anything is allocated
     pf = (ctypes.c_void_p * 2)(0xd000, 0xd040)
     assert lib.cfx_plan_add_exchange_layer_p2p(xl, 1, 544, 3072, 0, 1, 2, c, 14, d, None, 2, pf, 0x9000, 1 << 20) == -5          # no own flag
