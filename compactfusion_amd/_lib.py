@@ -90,6 +90,7 @@ SYMBOLS = [
     ("cfx_plan_add_exchange_layer_p2p", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                        ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_int, ctypes.POINTER(DecompItem),
                                                        ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_size_t]),
+    ("cfx_plan_add_p2p_sync", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
     ("cfx_ipc_alloc", ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     ("cfx_ipc_open", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     ("cfx_ipc_close", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

@@ -154,6 +154,7 @@ struct PlanOp {
     int kind;   // 0 compress, 1 decompress, 2 all-gather on the side stream, 3 main stream waits for gather op `ref`, 4 ring hop,
                 // 5 wait until flag `ref` has reached the plan's epoch, 6 set flag `ref` to the epoch,
                 // 7 low-rank compress (codec = quantized, param = rank), 8 low-rank decompress,
+                // 11 p2p sync: publish this rank's word, wait for the peers' (in stream order),
                 // 10 = 9 without a collective (peers' packets read in place, one published word per rank and layer),
                 // 9 exchange layer: compress (c) ; all-gather (comm, send, recv; comm NULL = none) ; reconstruct (g) - one launch on the
                 //   main stream whose reconstruction group preloads its state and waits for the collective's arrival

@@ -319,6 +319,31 @@ int cfx_plan_add_exchange_layer_p2p(cfx_plan* p, int codec, int N, int C, int pa
     return op;
 }
 
+// Publish-and-wait as an op of its own (what the p2p exchange layer does between compress and reconstruction, for chains that keep
+// their own launches: compress ; p2p_sync ; reconstruct peer 1 ; reconstruct peer 2 ; ... - the lane plan of compact_fwd): in stream order
+// on the stream the range runs on.  Everything the ops BEFORE it wrote is complete when the word is published (kernel boundary), and
+// the ops behind it start after every peer has published (their packets can be read in place through the IPC mappings).
+int cfx_plan_add_p2p_sync(cfx_plan* p, void* own_flag, int n_peers, const void* const* peer_flags) {
+    if (!p) return CFX_ERR_NULL;
+    if (n_peers < 0 || n_peers > CFX_P2P_MAX_PEERS || (n_peers && !peer_flags) || !own_flag)
+        return fail(p->ctx, CFX_ERR_BATCH, "plan: p2p sync needs an own flag and 0..CFX_P2P_MAX_PEERS peer flags");
+    for (int i = 0; i < n_peers; ++i)
+        if (!peer_flags[i] || ((uintptr_t)peer_flags[i] & 3)) return fail(p->ctx, CFX_ERR_NULL, "plan: p2p sync: null / misaligned peer flag");
+    if (!p->p2p_sink && hipMalloc((void**)&p->p2p_sink, 64) != hipSuccess) {
+        (void)hipGetLastError();
+        p->p2p_sink = nullptr;
+        return fail(p->ctx, CFX_ERR_LAUNCH, "plan: p2p sync: hipMalloc failed");
+    }
+    PlanOp* o = plan_push(p);
+    memset(o, 0, sizeof(*o));
+    o->kind = 11;
+    o->pre_flag = -1;
+    o->own_flag = (unsigned*)own_flag;
+    o->n_peers = n_peers;
+    for (int i = 0; i < n_peers; ++i) o->peer_flag[i] = (const unsigned*)peer_flags[i];
+    return p->n - 1;
+}
+
 // ---- device memory shared between the processes of a node (dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0) ---------------------------------
 int cfx_ipc_alloc(cfx_ctx* ctx, size_t bytes, void** ptr, void* handle64) {
     if (!ctx || !ptr || !handle64 || !bytes) return fail(ctx, CFX_ERR_NULL, "ipc_alloc: null");
@@ -513,6 +538,15 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                 break;
             case 7: rc = cfx_lr_compress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, o->q0, o->ws, o->ws_bytes, stream); break;
             case 8: rc = cfx_lr_decompress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->batch, o->d, o->ws, o->ws_bytes, stream); break;
+            case 11: {
+                const unsigned epoch = ++o->runs;
+                PeerFlags pf;
+                memset(&pf, 0, sizeof(pf));
+                for (int q = 0; q < o->n_peers; ++q) pf.pub[q] = o->peer_flag[q];
+                hipLaunchKernelGGL(k_flag_exchange, dim3(1), dim3(64), 0, main_s, (const unsigned*)o->own_flag, 0u, o->own_flag, epoch, pf, o->n_peers,
+                                   p->p2p_sink, epoch, p->ctx->gate_err, p->ctx->gate_timeout);
+                rc = check_launch(p->ctx, "p2p sync launch");
+            } break;
             case 9:
             case 10: {
                 CfxXGate xg;

@@ -283,6 +283,11 @@ int       cfx_plan_add_exchange_layer_p2p(cfx_plan* plan, int codec, int N, int 
                                           const cfx_comp_item* items, int n_recon, const cfx_decomp_item* recon,
                                           void* own_flag, int n_peers, const void* const* peer_flags,
                                           void* workspace, size_t workspace_bytes);
+/* The publish-and-wait step of the p2p exchange as an op of its own, for chains that keep separate launches (compress ; p2p_sync ;
+ * reconstruct peer 1 ; reconstruct peer 2 ; ... - the lane plan of compact_fwd): runs in stream order where the op range runs; what
+ * the ops before it wrote is complete when *own_flag is published, the ops behind it start after every peer has published.  Flags
+ * as in cfx_plan_add_exchange_layer_p2p (one word per op and plan, cfx_ipc_alloc memory, execution count as the epoch). */
+int       cfx_plan_add_p2p_sync(cfx_plan* plan, void* own_flag, int n_peers, const void* const* peer_flags);
 /* Device memory shared between the processes of a node (hipIpcGetMemHandle / hipIpcOpenMemHandle; on hosts with dmabuf IPC only the
  * processes need HSA_ENABLE_IPC_MODE_LEGACY=0).  cfx_ipc_alloc: zeroed device memory + its 64-byte handle (send it to the peers by any
  * means); cfx_ipc_open: map a peer's allocation; close / free when done. */

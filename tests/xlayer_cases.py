@@ -420,6 +420,86 @@ def _p2p_worker(r, W, tmp, L, N, C, steps, masked):
     assert ge == 0, f"rank {r}: {ge} gate errors"
 
 
+def _p2p_chain_worker(r, W, tmp, L, N, C, steps, codec):
+    """compress ; p2p_sync ; one reconstruction launch per peer tensor pair - the launch structure of compact_fwd's lane plan"""
+    import time
+    import numpy as np
+    from compactfusion_amd import _lib, codecs as K
+    torch.cuda.set_device(0)
+    lib = _lib.load()
+    ctx = lib.cfx_create(0)
+    assert lib.cfx_prepare(ctx) == 0 and lib.cfx_set_gate_timeout_ms(ctx, 4000) == 0
+    slot = (K.packet_bytes(codec, N, C, 0 if codec != 5 else 8) + 255) // 256 * 256
+    flags_off = L * 2 * slot
+    ptr, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+    assert lib.cfx_ipc_alloc(ctx, flags_off + 2 * L * 64, ctypes.byref(ptr), handle) == 0, lib.cfx_last_error_string(ctx)
+    with open(os.path.join(tmp, f"h{r}.tmp"), "wb") as f:
+        f.write(handle.raw)
+    os.replace(os.path.join(tmp, f"h{r}.tmp"), os.path.join(tmp, f"h{r}.bin"))
+    q = 1 - r
+    fn = os.path.join(tmp, f"h{q}.bin")
+    t0 = time.time()
+    while not os.path.exists(fn):
+        assert time.time() - t0 < 60
+        time.sleep(0.01)
+    pp = ctypes.c_void_p()
+    assert lib.cfx_ipc_open(ctx, open(fn, "rb").read(), ctypes.byref(pp)) == 0, lib.cfx_last_error_string(ctx)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x0 = torch.randn(W, L, 2, N, C, generator=g, device="cuda").half()
+    xs = [(x0.float() + 0.1 * (s + 1) * torch.randn(W, L, 2, N, C, generator=g, device="cuda")).half() for s in range(2)]
+    own, peer = x0[r].clone(), x0[q].clone()
+    param = 0 if codec != 5 else 8
+    wsb = lib.cfx_workspace_bytes(codec, N, C, param, 2)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+    run = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    plans = []
+    for s in range(2):
+        plan = lib.cfx_plan_create(ctx)
+        for l in range(L):
+            c = (_lib.CompItem * 2)(*[_lib.CompItem(xs[s][r, l, b].data_ptr(), own[l, b].data_ptr(), own[l, b].data_ptr(), ptr.value + (l * 2 + b) * slot)
+                                      for b in range(2)])
+            assert lib.cfx_plan_add_compress(plan, codec, N, C, param, _lib.FLAG_UPDATE_CACHE, 2, c, ws.data_ptr(), wsb) >= 0
+            pf = (ctypes.c_void_p * 1)(pp.value + flags_off + (s * L + l) * 64)
+            assert lib.cfx_plan_add_p2p_sync(plan, ptr.value + flags_off + (s * L + l) * 64, 1, pf) >= 0, lib.cfx_last_error_string(ctx)
+            for b in range(2):
+                d = (_lib.DecompItem * 1)(_lib.DecompItem(pp.value + (l * 2 + b) * slot, peer[l, b].data_ptr(), peer[l, b].data_ptr()))
+                assert lib.cfx_plan_add_decompress(plan, codec, N, C, param, 1, d) >= 0
+        plans.append(plan)
+    for i in range(steps):
+        rc = lib.cfx_plan_run(plans[i & 1], 0, lib.cfx_plan_size(plans[i & 1]), run.cuda_stream)
+        assert rc == 0, (rc, lib.cfx_last_error_string(ctx))
+    torch.cuda.synchronize()
+    ge = lib.cfx_gate_errors(ctx)
+    np.save(os.path.join(tmp, f"own{r}.npy"), own.cpu().numpy().view(np.uint16))
+    np.save(os.path.join(tmp, f"peer{r}_{q}.npy"), peer.cpu().numpy().view(np.uint16))
+    np.save(os.path.join(tmp, f"x0_{r}.npy"), x0[r].cpu().numpy().view(np.uint16))
+    open(os.path.join(tmp, f"done{r}"), "w").close()
+    t0 = time.time()
+    while not os.path.exists(os.path.join(tmp, f"done{q}")):
+        assert time.time() - t0 < 60
+        time.sleep(0.01)
+    for p in plans:
+        lib.cfx_plan_destroy(p)
+    lib.cfx_ipc_close(ctx, pp)
+    lib.cfx_ipc_free(ctx, ptr)
+    assert ge == 0, f"rank {r}: {ge} gate errors"
+
+
+@pytest.mark.parametrize("codec,N,C", [(1, 544, 3072), (3, 96, 1024), (4, 128, 1152), (5, 64, 512)])
+def test_p2p_sync_chain_two_processes_one_gpu(tmp_path, codec, N, C):
+    """cfx_plan_add_p2p_sync: compress ; publish-and-wait ; per-peer reconstruction launches reading the other PROCESS's packets in place -
+    the launch structure of compact_fwd's lane plan without a collective, for the 1-bit, int8, int4 and top-k codecs: every rank's
+    reconstruction of the other's shard equals that rank's own error-feedback state bit for bit."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    mp.start_processes(_p2p_chain_worker, args=(2, str(tmp_path), 3, N, C, 4, codec), nprocs=2, join=True, start_method="spawn")
+    for r in range(2):
+        own = np.load(tmp_path / f"own{r}.npy")
+        assert not np.array_equal(own, np.load(tmp_path / f"x0_{r}.npy"))
+        assert np.array_equal(np.load(tmp_path / f"peer{1 - r}_{r}.npy"), own), f"rank {1 - r}: reconstruction of rank {r}'s shard differs"
+
+
 @pytest.mark.parametrize("N,C,masked", [(544, 3072, True), (96, 1024, True), (128, 1088, False)])
 def test_p2p_exchange_two_processes_one_gpu(tmp_path, N, C, masked):
     """cfx_plan_add_exchange_layer_p2p: two rank PROCESSES on one GPU, each with its packets in cfx_ipc_alloc memory the other has opened;
