@@ -275,6 +275,17 @@ def _exchange_stream(device) -> "torch.cuda.Stream":
     return s
 
 
+class _RawHalves:
+    """fp16 view of device memory that torch did not allocate (cfx_ipc_alloc / cfx_ipc_open), through the CUDA array interface"""
+
+    def __init__(self, ptr: int, n_halves: int):
+        self.__cuda_array_interface__ = {"shape": (n_halves,), "typestr": "<f2", "data": (ptr, False), "version": 2}
+
+
+def _raw_halves(ptr: int, n_halves: int, device) -> torch.Tensor:
+    return torch.as_tensor(_RawHalves(ptr, n_halves), device=device)
+
+
 class _LayerExchange:
     """Everything about one layer's packet exchange that does not change from step to step: the exchange buffers, the
     side stream, key strings, the peers' packet views and - once the state arena is populated - the prepared native
@@ -297,6 +308,48 @@ class _LayerExchange:
         self.comp = None
         self.dec = []
         self.peer_views = []
+        self._p2p = None             # CFX_RING_P2P: {"send": own packets in IPC memory, "peer": {rank: its packets, mapped}, "flag": ptr, "peer_flag": {rank: ptr}}
+        self._p2p_tried = False
+
+    def _p2p_setup(self):
+        """CFX_RING_P2P=1 (ranks of ONE node): the packets stay in cfx_ipc_alloc memory of the rank that produced them and the peers'
+        reconstruction launches read them in place; the all-gather of the layer's plan becomes a publish-and-wait op
+        (cfx_plan_add_p2p_sync).  Collective over the group (the handles travel once); all ranks or none."""
+        self._p2p_tried = True
+        if os.environ.get("CFX_RING_P2P", "0") not in ("1", "on", "auto") or self.world < 2 or not self.send.is_cuda or self.world - 1 > 15:
+            return
+        import ctypes
+        from .. import _lib, codecs
+        lib = _lib.load()
+        dev = self.send.device.index if self.send.device.index is not None else torch.cuda.current_device()
+        ctx = codecs.context(dev)
+        halves = 2 * self.slot
+        nbytes = halves * 2 + 128                                       # [K packet | V packet] + two flag words on lines of their own
+        ptr, handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+        mine = bytes(handle.raw) if lib.cfx_ipc_alloc(ctx, nbytes, ctypes.byref(ptr), handle) == 0 else None
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine, group=self.group)
+        opened, good = {}, all(h is not None for h in handles)
+        if good:
+            for r in range(self.world):
+                if r != self.rank:
+                    pq = ctypes.c_void_p()
+                    if lib.cfx_ipc_open(ctx, handles[r], ctypes.byref(pq)) != 0:
+                        good = False
+                        break
+                    opened[r] = pq.value
+        votes = [None] * self.world
+        dist.all_gather_object(votes, bool(good), group=self.group)
+        if not all(votes):
+            for pq in opened.values():
+                lib.cfx_ipc_close(ctx, ctypes.c_void_p(pq))
+            if mine is not None:
+                lib.cfx_ipc_free(ctx, ptr)
+            return
+        d = self.send.device
+        self._p2p = {"ptr": ptr.value, "send": _raw_halves(ptr.value, halves, d),
+                     "peer": {r: _raw_halves(pq, halves, d) for r, pq in opened.items()},
+                     "flag": ptr.value + halves * 2, "peer_flag": {r: pq + halves * 2 for r, pq in opened.items()}}
 
     def packet(self, r: int, kv: int, n_half: int) -> torch.Tensor:
         o = (2 * r + kv) * self.slot
@@ -312,7 +365,11 @@ class _LayerExchange:
             assert b is not None, f"no cached base for key {key}: a WARMUP step must precede residual compression"
             return b
         own = [state(self.kkeys[self.rank]), state(self.vkeys[self.rank])]
-        own_pkts = [self.send[:n_half], self.send[self.slot:self.slot + n_half]]
+        if not self._p2p_tried:
+            self._p2p_setup()
+        p2p = self._p2p
+        own_src = p2p["send"] if p2p else self.send
+        own_pkts = [own_src[:n_half], own_src[self.slot:self.slot + n_half]]
         # the sender's error-feedback update IS the receiver's dequant+add run on its own packet (fastpath.py:88-120), so
         # it rides in the batched reconstruction launch (own K,V + all peers' K,V = 16 tensors at W = 8) instead of a
         # launch of its own; the compress sequence is then stats -> finalize only
@@ -324,7 +381,10 @@ class _LayerExchange:
         for r in self.peers:
             bk, bv = state(self.kkeys[r]), state(self.vkeys[r])
             bases += [bk, bv]
-            pkts += [self.packet(r, 0, n_half), self.packet(r, 1, n_half)]
+            if p2p:                 # read in place from the peer's own buffer
+                pkts += [p2p["peer"][r][:n_half], p2p["peer"][r][self.slot:self.slot + n_half]]
+            else:
+                pkts += [self.packet(r, 0, n_half), self.packet(r, 1, n_half)]
             self.peer_views.append((bk.view(kshape), bv.view(vshape)))
         step = codecs.CFX_MAX_BATCH
         self.dec = [codecs.prepare_decompress(cid, pkts[i:i + step], bases[i:i + step], bases[i:i + step], N, C, param)
@@ -358,8 +418,9 @@ class _LayerExchange:
         from .. import _lib, codecs
         from ..exchange import native_comm_for
         dev = self.send.device.index if self.send.device.index is not None else torch.cuda.current_device()
-        comm = native_comm_for(self.group, dev)
-        if comm is None:
+        p2p = self._p2p
+        comm = None if p2p else native_comm_for(self.group, dev)
+        if comm is None and not p2p:
             assert mode != "native", "CFX_RING_EXCHANGE=native but the library-owned communicator cannot be created"
             return
         lib = self._lib = _lib.load()
@@ -400,6 +461,20 @@ class _LayerExchange:
 
         def dec_items(lo, hi):
             return [_lib.DecompItem(p_.data_ptr(), b_.data_ptr(), b_.data_ptr()) for p_, b_ in zip(pkts[lo:hi], bases[lo:hi])]
+
+        def exchange_op():
+            """the op between compress and reconstruction: ncclAllGather, or (p2p) publish this rank's word and wait for the peers'"""
+            if not p2p:
+                return lib.cfx_plan_add_all_gather(plan, comm.handle, self.send.data_ptr(), self.recv.data_ptr(), 2 * self.slot * 2)
+            pf = (ctypes.c_void_p * (self.world - 1))(*[p2p["peer_flag"][r] for r in sorted(p2p["peer_flag"])])
+            return lib.cfx_plan_add_p2p_sync(plan, p2p["flag"], self.world - 1, pf)
+
+        def done_op():
+            """p2p: nobody rewrites its packets before every peer has finished reading them (a second word per rank)"""
+            if not p2p:
+                return 0
+            pf = (ctypes.c_void_p * (self.world - 1))(*[p2p["peer_flag"][r] + 64 for r in sorted(p2p["peer_flag"])])
+            return lib.cfx_plan_add_p2p_sync(plan, p2p["flag"] + 64, self.world - 1, pf)
         if self.lane:
             # flags: 0 = the activations exist (set on the compute stream), s = 1..W-1 = peer of ring step s reconstructed, W = chain done
             W = self.world
@@ -407,7 +482,7 @@ class _LayerExchange:
             ok = bool(self._flags)
             ok = ok and lib.cfx_plan_add_flag_wait(plan, 0) == 0
             ok = ok and lib.cfx_plan_add_compress(plan, cid, N, C, param, flags, 2, c, wsp, wsn) == 1
-            ok = ok and lib.cfx_plan_add_all_gather(plan, comm.handle, self.send.data_ptr(), self.recv.data_ptr(), 2 * self.slot * 2) == 2
+            ok = ok and exchange_op() == 2
             n_own = 2 if ef else 0                 # bases / pkts start with the rank's own K,V when error feedback is on
             for s_ in range(1, W):                 # just in time: peer s's K,V in the order the attention blocks visit them; its flag is
                 lo = n_own + 2 * (s_ - 1)          # published by the NEXT launch of the chain as the first thing it does (no launch of its own)
@@ -421,14 +496,18 @@ class _LayerExchange:
             else:
                 ok = ok and lib.cfx_plan_add_flag_set(plan, W - 1) >= 0
             ok = ok and lib.cfx_plan_add_flag_set(plan, W) >= 0
+            ok = ok and done_op() >= 0
             self._epoch = ctypes.c_uint(0)
         else:
             ok = lib.cfx_plan_add_compress(plan, cid, N, C, param, flags, 2, c, wsp, wsn) == 0
-            g0 = lib.cfx_plan_add_all_gather(plan, comm.handle, self.send.data_ptr(), self.recv.data_ptr(), 2 * self.slot * 2)
-            ok = ok and g0 == 1 and lib.cfx_plan_add_wait(plan, g0) == 2
+            g0 = exchange_op()
+            # (front = ops [0, 2), back = the rest: with the collective the wait op is op 2; the publish-and-wait op needs none, and
+            # run_back then starts at the first reconstruction - a no-op flag set keeps the indices the same)
+            ok = ok and g0 == 1 and (lib.cfx_plan_add_wait(plan, g0) if not p2p else lib.cfx_plan_add_p2p_sync(plan, p2p["flag"] + 96, 0, None)) == 2
             for i in range(0, len(bases), step):
                 items = dec_items(i, i + step)
                 ok = ok and lib.cfx_plan_add_decompress(plan, cid, N, C, param, len(items), (_lib.DecompItem * len(items))(*items)) >= 0
+            ok = ok and done_op() >= 0
         ok = ok and lib.cfx_plan_finalize(plan) == 0
         if not ok:
             lib.cfx_plan_destroy(plan)

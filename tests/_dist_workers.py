@@ -150,6 +150,8 @@ def w_ring(rank, world, schedule, codec_name, joint):
         res[f"s{step}/k"] = bits(ks[step])
         res[f"s{step}/v"] = bits(vs[step])
     res["passed_count"] = np.array([cm.compact_cache().passed_count])
+    import compactfusion_amd.compact.ring as ring_mod
+    res["p2p"] = np.array([int(any(getattr(ex, "_p2p", None) is not None for ex in ring_mod._xbuf.values()))])
     return res
 
 

@@ -101,6 +101,30 @@ def test_ring_forward_on_gpu_vs_oracle_and_full_attention(tmp_path, codec, joint
             np.testing.assert_allclose(relay[r][f"s{s}/out"], gather[r][f"s{s}/out"], rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("codec", ["BINARY", "INT8", "SPARSE"])
+def test_ring_gather_peer_to_peer_on_gpu_vs_oracle(tmp_path, codec):
+    """CFX_RING_P2P=1: the gather schedule of compact_fwd with NO collective - every rank's packets stay in cfx_ipc_alloc memory, the other
+    process's per-peer reconstruction launches read them in place behind a publish-and-wait op (cfx_plan_add_p2p_sync).  Two processes on
+    one GPU: the states every rank holds for every shard equal the oracle's replay, and the attention equals one attention over them."""
+    os.environ["CFX_RING_P2P"] = "1"
+    try:
+        res = _spawn(W.w_ring, 2, tmp_path, "gather", codec, "none")
+    finally:
+        os.environ.pop("CFX_RING_P2P", None)
+    shape = (1, 64, 8, 64)
+    want_k = [_chain(codec, W.drift(17 + q, shape, 3)) for q in range(2)]
+    want_v = [_chain(codec, W.drift(27 + q, shape, 3)) for q in range(2)]
+    for r in range(2):
+        assert int(res[r]["p2p"][0]) == 1, "the peer-to-peer exchange was not taken"
+        assert int(res[r]["passed_count"][0]) == 3
+        for s in range(3):
+            for q in range(2):
+                assert np.array_equal(res[r][f"s{s}/state_k_{q}"].reshape(-1), want_k[q][s].reshape(-1)), (r, s, q, "k")
+                assert np.array_equal(res[r][f"s{s}/state_v_{q}"].reshape(-1), want_v[q][s].reshape(-1)), (r, s, q, "v")
+            np.testing.assert_allclose(res[r][f"s{s}/out"], res[r][f"s{s}/ref_out"], rtol=2e-3, atol=2e-3)
+            np.testing.assert_allclose(res[r][f"s{s}/lse"], res[r][f"s{s}/ref_lse"], rtol=1e-3, atol=1e-3)
+
+
 @pytest.mark.parametrize("mode", ["sync", "async", "compact"])
 def test_patch_gather_forward_on_gpu(tmp_path, mode):
     res = _spawn(W.w_patch, 2, tmp_path, mode)
