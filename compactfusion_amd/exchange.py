@@ -116,4 +116,19 @@ def native_comm_for(group, device: int):
                       "torch.distributed (about 50 us of host time per call)")
         _failed.add(key)
         c = None
+    # every rank of the group takes the same path: a rank that failed would issue torch.distributed's all-gather while its peers sit in
+    # the library's - all or none (the stand-in factories of the tests are per-process by design and skip the vote)
+    if _factory is None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        votes = [None] * dist.get_world_size(group)
+        dist.all_gather_object(votes, c is not None, group=group)
+        if not all(votes) and c is not None:
+            import warnings
+            warnings.warn("compactfusion_amd: a peer could not create the native communicator; this group keeps its collective in torch.distributed")
+            try:
+                c.close()
+            except Exception:  # noqa: BLE001
+                pass
+            _comms.pop(key, None)
+            _failed.add(key)
+            c = None
     return c
