@@ -903,7 +903,8 @@ def main():
         "flag_relay_no_communicator": None if relay_ms is None else {
             "ms_per_step": round(relay_ms, 4),
             "what": "the same exchange-layer plans built WITHOUT a communicator: the exchange stream runs one relay kernel per layer (wait + set) instead of "
-                    "flag-wait kernel ; ncclAllGather ; flag-set kernel - what the two kernel boundaries around the collective cost"},
+                    "flag-wait kernel ; ncclAllGather ; flag-set kernel - what the two kernel boundaries around the collective cost, and the launch "
+                    "structure of the peer-to-peer exchange layer runs with N > 1 use (there the one kernel also publishes a word and waits for the peers')"},
         "with_cu_partition": None if part_ms is None else {
             "ms_per_step": round(part_ms, 4),
             "what": "the same exchange-layer plans with the run stream masked to CUs [0, 224) and the exchange stream to [224, 256): CUs of its own for a "
