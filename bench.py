@@ -16,12 +16,15 @@ Per layer, the collective in the path at every N:
      (N live ranks gather for real; the 8-N missing logical peers are looped back from the rank's own slot, so the per-GPU codec
      work is IDENTICAL for every N = weak scaling; at N = 1 RCCL's one-rank in-place all-gather has nothing to move),
   B. reconstruct the 7 peers' K,V (14 tensors) onto their state arenas, and the rank's own error-feedback update.
-Default (--own-ef xgate), the same at every N: A and B are ONE launch on the run stream (cfx_plan_add_exchange_layer): B's workgroups are
-launched with A's, pull their state tiles into registers while the scale reduction and the collective run, and wait for a gate word;
-the exchange stream runs  flag-wait kernel (A's packets complete) ; ncclAllGather ; flag-set kernel (opens the gate).  With more than
-one live rank the collective is a kernel that must be placed beside the waiting workgroups (the library takes the one-launch form only
-if they leave it CUs); the first step runs with a 300 ms gate timeout and if a gate did not open on any rank every rank switches to
-the two-launch schedule (`schedule_fallback` says so).
+Default (--own-ef xgate --p2p auto), the same at every N: A and B are ONE launch on the run stream (the exchange-layer op): B's workgroups
+are launched with A's, pull their state tiles into registers while the scale reduction runs, and wait for a gate word.  X is NOT a
+collective: every rank's packets stay in IPC-shared memory of its own GPU (cfx_ipc_alloc), the peers' reconstruction workgroups read
+them in place over xGMI, and ONE small kernel per layer on the exchange stream waits for A's packets, publishes a word the live peers
+have mapped, waits for theirs and opens the gate (cfx_plan_add_exchange_layer_p2p).  At N = 1 there is no live peer: the same op,
+launches and kernels minus the remote reads and the waiting.  At N > 1 the first step is validated (gate timeouts, state consistency
+across ranks); on failure every rank switches to two launches around ncclAllGather (`schedule_fallback`).
+`collective_in_the_path` (secondary at N = 1; --p2p off): the same launch with flag-wait kernel ; ncclAllGather (libcfx's own RCCL
+communicator, in place) ; flag-set kernel on the exchange stream.
 `two_launches_per_layer` (secondary at N = 1; --own-ef ride): A ; X ; B as two codec launches in stream order, the previous layer's
 own error-feedback update riding in A (nothing reads that state before the next denoise step, ring.py:207-209).
 `with_cu_partition` (secondary at N = 1): the default with the run stream masked to CUs [0, 224) and the exchange stream to [224, 256):
@@ -206,7 +209,8 @@ def config_key(args, n_gpus):
                               ):
         own_ef = "ride"
     return {"codec": args.codec, "replay": args.replay, "own_ef": own_ef if not pipelined else None, "layers": args.layers,
-            "shard": [N_TOK, C_CH], "rows": args.rows, "n_gpus": n_gpus, "collective": not args.no_collective}
+            "shard": [N_TOK, C_CH], "rows": args.rows, "n_gpus": n_gpus, "collective": not args.no_collective,
+            "p2p": (args.p2p if (own_ef == "xgate" and not args.emulate_live) else None)}
 
 
 def main():
@@ -492,16 +496,19 @@ def main():
                 if native_comm is not None:
                     step_plans = build_step_plans(stream_mode)
                     exchange_mode = "native"
-                if xgate and world > 1 and args.p2p == "auto":
+                if xgate and args.p2p == "auto" and not args.emulate_live:
                     # ---- no collective at all: packets stay in IPC-shared memory, the peers read them in place ---------------------------
                     flags_off = L * 2 * slot
                     p2p_ptr, p2p_handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
                     check_rc = lib.cfx_ipc_alloc(ctx, flags_off + 2 * L * 64, ctypes.byref(p2p_ptr), p2p_handle)
                     ok_all = torch.tensor([1 if check_rc == 0 else 0], device=dev, dtype=torch.int32)
-                    dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+                    if world > 1:
+                        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
                     if int(ok_all.item()) == 1:
-                        handles = [None] * world
-                        dist.all_gather_object(handles, bytes(p2p_handle.raw))
+                        handles = [bytes(p2p_handle.raw)]
+                        if world > 1:
+                            handles = [None] * world
+                            dist.all_gather_object(handles, bytes(p2p_handle.raw))
                         p2p_peer = {}
                         opened = 1
                         for q in range(world):
@@ -512,7 +519,8 @@ def main():
                                     break
                                 p2p_peer[q] = pq.value
                         ok_all = torch.tensor([opened], device=dev, dtype=torch.int32)
-                        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+                        if world > 1:
+                            dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
                     if int(ok_all.item()) == 1:
                         def build_p2p_plans():
                             built = []
@@ -530,7 +538,7 @@ def main():
                                         src = p2p_peer[(rank + 1 + p) % world] if real else p2p_ptr.value        # a looped-back logical peer reads OUR packets
                                         for kv in range(2):
                                             items.append(_lib.DecompItem(src + (l * 2 + kv) * slot, peer_base[l, p, kv].data_ptr(), peer_base[l, p, kv].data_ptr()))
-                                    pf = (ctypes.c_void_p * (world - 1))(*[p2p_peer[q] + flags_off + (s_ * L + l) * 64 for q in sorted(p2p_peer)])
+                                    pf = (ctypes.c_void_p * max(1, world - 1))(*[p2p_peer[q] + flags_off + (s_ * L + l) * 64 for q in sorted(p2p_peer)])
                                     rc_ = lib.cfx_plan_add_exchange_layer_p2p(sp, CODEC, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, carr, len(items),
                                                                               (_lib.DecompItem * len(items))(*items), p2p_ptr.value + flags_off + (s_ * L + l) * 64,
                                                                               world - 1, pf, ws.data_ptr(), ws_bytes)
@@ -732,7 +740,7 @@ def main():
         return dt * 1e3 / n_steps
 
     # ---- secondary legs (no events): a long run of the same replay, the other replay ------------------------------------------
-    long_ms, other_ms, two_ms, loop_ms, relay_ms, part_ms = None, None, None, None, None, None
+    long_ms, other_ms, two_ms, loop_ms, relay_ms, part_ms, coll_ms = None, None, None, None, None, None, None
     if not args.no_secondary:
         base_step = steps_run
         long_ms = timed_leg(args.long_steps, lambda i: one_step(base_step + i))
@@ -772,6 +780,9 @@ def main():
                     for pl_ in plset:
                         lib.cfx_plan_destroy(pl_)
                     return ms_
+                # the same exchange-layer launch with ncclAllGather in the path (flag-wait kernel ; ncclAllGather ; flag-set kernel on the exchange stream)
+                if exchange_mode == "p2p" and native_comm is not None:
+                    coll_ms = step_leg(build_step_plans(0), "plan_run(exchange layer, ncclAllGather in the path)")
                 # the same step, collective in the path, as two launches per layer in stream order (round 2's deployable schedule)
                 two_ms = step_leg(build_step_plans(0, xlayer=False), "plan_run(two launches, collective in the path)")
                 # no communicator: the exchange stream only relays the flag (one kernel instead of wait ; ncclAllGather ; set)
@@ -879,8 +890,10 @@ def main():
                       "reconstruction workgroups read them in place over xGMI.  Per layer ONE codec launch on the run stream = compress K,V [statistics + "
                       "sign bits + in-launch finalize] + own error-feedback update + reconstruction of the 7 peers' K,V, whose workgroups pull their state "
                       "tiles into registers and then wait for a gate word; on the exchange stream ONE small kernel: wait for this launch's packets, publish "
-                      f"a word the {live - 1} live peer(s) have mapped, wait for their words, open the gate (cfx_plan_add_exchange_layer_p2p).  The first "
-                      "step was validated (gate timeouts, state consistency across ranks)") if (xgate and P2P) else
+                      f"a word the {live - 1} live peer(s) have mapped, wait for their words, open the gate (cfx_plan_add_exchange_layer_p2p).  " +
+                      ("One live rank: no peer to read from or to wait for - the same op, launches and kernels as any N, minus the remote reads "
+                       "(`collective_in_the_path`: the same launch around ncclAllGather)" if live == 1 else
+                       "The first step was validated (gate timeouts, state consistency across ranks)")) if (xgate and P2P) else
                      ("layer by layer in order (deployable), the collective in the path: per layer ONE codec launch on the run stream = compress K,V "
                       "[statistics + sign bits + in-launch finalize; packets written straight into the rank's slot of the gather buffer] + own "
                       "error-feedback update + reconstruction of the 7 peers' K,V, whose workgroups pull their state tiles into registers and "
@@ -900,6 +913,10 @@ def main():
                      "the same layer-ordered step as A = compress (+ previous layer's own error feedback riding along) ; B = reconstruct 7 peers")
                     + (" ; the collective between them, everything in stream order (the fall-back schedule)" if xgate else
                        " - the schedule a collective between compress and reconstruction forces (N > 1)")},
+        "collective_in_the_path": None if coll_ms is None else {
+            "ms_per_step": round(coll_ms, 4),
+            "what": "the same exchange-layer launch with a collective library in the path: flag-wait kernel ; ncclAllGather (in place, libcfx's own RCCL "
+                    "communicator of this many ranks) ; flag-set kernel on the exchange stream - round 3's earlier default, `--p2p off`"},
         "flag_relay_no_communicator": None if relay_ms is None else {
             "ms_per_step": round(relay_ms, 4),
             "what": "the same exchange-layer plans built WITHOUT a communicator: the exchange stream runs one relay kernel per layer (wait + set) instead of "

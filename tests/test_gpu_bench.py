@@ -53,6 +53,11 @@ def test_bench_with_a_collective_kernel_of_rccl_footprint():
     assert d["launches_per_layer"] == 1 and d["schedule_fallback"] is None
 
 
+def test_bench_collective_in_the_path_still_selectable():
+    d = _bench("--p2p", "off", "--no-cpu-baseline")
+    assert "ncclAllGather" in d["schedule"] and "flag-wait kernel" in d["schedule"] and d["exchange_issued_by"] == "native" and d["launches_per_layer"] == 1
+
+
 def test_bench_two_launch_schedule_still_selectable():
     d = _bench("--own-ef", "ride", "--no-cpu-baseline")
     assert "ncclAllGather" in d["schedule"] and d["launches_per_layer"] == 2 and "k_binary_dequant" in d["roofline"]["kernel"]
@@ -66,8 +71,8 @@ def test_bench_default_line_has_the_collective_in_its_schedule():
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"]
     # N = 1: the layer is ONE codec launch gated on the collective's arrival (exchange-layer op); the two-launch form, the flag relay and
     # the CU-partitioned configuration ride along as secondary legs
-    assert "ncclAllGather" in d["schedule"] and "flag-wait kernel" in d["schedule"] and d["exchange_issued_by"] == "native" and d["launches_per_layer"] == 1
-    for k in ("two_launches_per_layer", "flag_relay_no_communicator", "with_cu_partition"):
+    assert "NO collective" in d["schedule"] and "cfx_plan_add_exchange_layer_p2p" in d["schedule"] and d["exchange_issued_by"] == "p2p" and d["launches_per_layer"] == 1
+    for k in ("collective_in_the_path", "two_launches_per_layer", "flag_relay_no_communicator", "with_cu_partition"):
         assert d[k]["ms_per_step"] > 0, k
     assert "k_absmean_compress<bits,gated>" in d["roofline"]["kernel"]
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["peak"] == 8000.0
