@@ -11,8 +11,8 @@ KEY=$(python3 "$R/bench.py" --print-config-key)
 FAKE=$R/tests/fake_rccl/libcfx_fake_rccl.so
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8
-# 1. kernel trace + stats of the default bench command's headline schedule (one codec launch per layer gated on the collective's arrival; flag
-#    kernels + in-place all-gather on the exchange stream).  --overlap-steps 0 and --no-secondary keep the other legs' kernels out of the averages.
+# 1. kernel trace + stats of the default bench command's headline schedule (one codec launch per layer gated on the packets' arrival; one
+#    exchange kernel per layer on the exchange stream, no collective).  --overlap-steps 0 and --no-secondary keep the other legs' kernels out of the averages.
 #    Every profiled command runs under `timeout`: a profiler that serialises dispatches would leave the flag-ordered launch waiting for a kernel
 #    that cannot start.
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 "$R/bench.py" --steps 20 --warmup 3 --no-secondary --overlap-steps 0 > "$OUT/bench_under_rocprof.log" 2>&1 < /dev/null
@@ -51,6 +51,7 @@ python3 bench.py > "$OUT/r03_bench_n1.json" 2>/dev/null
 python3 bench.py --codec int2 --overlap-steps 0 > "$OUT/r03_bench_n1_int2.json" 2>/dev/null
 python3 bench.py --no-collective --own-ef gated --overlap-steps 0 --no-cpu-baseline > "$OUT/r03_bench_n1_loopback_one_launch.json" 2>/dev/null
 python3 bench.py --own-ef ride --overlap-steps 0 --no-cpu-baseline > "$OUT/r03_bench_n1_two_launch.json" 2>/dev/null
+python3 bench.py --p2p off --overlap-steps 0 --no-cpu-baseline > "$OUT/r03_bench_n1_collective_in_path.json" 2>/dev/null
 python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --no-cpu-baseline --long-steps 20 > "$OUT/r03_bench_emulated_live8.json" 2>/dev/null
 CFX_FAKE_RCCL_FAT=1 python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --no-cpu-baseline --long-steps 20 > "$OUT/r03_bench_emulated_live8_fat.json" 2>/dev/null
 timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29617 bench.py --gpus 2 --same-gpu --backend gloo --no-cpu-baseline --overlap-steps 0 --steps 20 --warmup 3 --long-steps 20 2>/dev/null | tail -1 > "$OUT/r03_bench_p2p_two_processes_one_gpu.json"
