@@ -122,8 +122,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="debug: 'gloo' lets several ranks share one GPU to exercise the N>1 path")
     ap.add_argument("--same-gpu", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--p2p", choices=["auto", "off"], default="auto",
-                    help="N > 1, --own-ef xgate: auto = no collective at all - every rank's packets stay in IPC-shared memory and the peers' reconstruction "
-                         "workgroups read them in place (cfx_plan_add_exchange_layer_p2p; single node); off = ncclAllGather on the exchange stream")
+                    help="--own-ef xgate, every N: auto (default) = no collective at all - every rank's packets stay in IPC-shared memory and the peers' "
+                         "reconstruction workgroups read them in place (cfx_plan_add_exchange_layer_p2p; single node; no live peer at N = 1); "
+                         "off = ncclAllGather between a flag-wait and a flag-set kernel on the exchange stream")
     ap.add_argument("--dist-path", action="store_true",
                     help="debug: take the N>1 code path (per-layer collectives) even with one rank, to measure its host overhead")
     ap.add_argument("--exchange", choices=["native", "torch"], default="native",
