@@ -975,7 +975,7 @@ def main():
     if dom in kern_us:
         us, n_samples = kern_us[dom]
         if pipelined:
-            ul = max(1, int(os.environ.get("CFX_PIPE_UNIT_LAYERS", "7")))
+            ul = 7                                              # cfx_plan_set_pipe_unit_layers default
             if use_dist and step_plans is not None:
                 ul = max(G, (ul // G) * G)                      # units are whole all-gather groups
             ul = min(ul, 7, L)

@@ -12,7 +12,7 @@ CFX_MAX_BATCH = 16
 CFX_OK = 0
 ERR_NAMES = {
     -1: "CFX_ERR_NULL", -2: "CFX_ERR_SHAPE", -3: "CFX_ERR_ALIGN", -4: "CFX_ERR_CODEC",
-    -5: "CFX_ERR_BATCH", -6: "CFX_ERR_LAUNCH", -7: "CFX_ERR_WORKSPACE", -8: "CFX_ERR_GATE",
+    -5: "CFX_ERR_BATCH", -6: "CFX_ERR_LAUNCH", -7: "CFX_ERR_WORKSPACE", -8: "CFX_ERR_GATE", -9: "CFX_ERR_QUEUES",
 }
 
 FLAG_UPDATE_CACHE = 1
@@ -50,6 +50,15 @@ SYMBOLS = [
     ("cfx_prepare", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_set_fused_finalize", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_debug_stamps", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    ("cfx_set_stats_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_set_gated_launch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_set_lr_chain", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_set_lr_decode", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_set_dev_probe", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_hw_queues_ok", ctypes.c_int, []),
+    ("cfx_set_allow_shared_queues", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    ("cfx_ipc_memory_kind", ctypes.c_int, [ctypes.c_void_p]),
+    ("cfx_plan_set_pipe_unit_layers", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_compress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_decompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

@@ -480,6 +480,9 @@ class _KVExchange:
         self.pending = None
         self.cuda = like.is_cuda
         self.device = like.device
+        self.tags = (tag_k, tag_v)
+        self.xop = None              # the synchronous exchange as ONE native op per layer (xlayer.LayerOp)
+        self._xop_args = None
 
     def bind(self, sig, cid, param, N, C, n_half, shape, ef):
         def state(key):
@@ -516,6 +519,19 @@ class _KVExchange:
         self.kviews = [b.view(shape) for b in kb]
         self.vviews = [b.view(shape) for b in vb]
         self.sig = sig
+        # sync steps: compress ; exchange ; reconstruct all W shards (the own shard is replaced by its reconstruction too, main.py:406-419)
+        # as ONE native call (built on first use)
+        from . import xlayer
+        self._drop_xop()
+        if xlayer.usable(cid, self.world, self.cuda):
+            peers = [(r, kb[r], vb[r]) for r in range(self.world) if r != self.rank]
+            self._xop_args = (("gather",) + self.tags + (id(self.group) if self.group is not None else None,), cid, param, N, C,
+                              self.rank, self.world, self.group, self.device, own, peers)
+
+    def _drop_xop(self):
+        if self.xop is not None:
+            self.xop.close()
+        self.xop, self._xop_args = None, None
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream if self.cuda else None
@@ -544,9 +560,23 @@ class _KVExchange:
         if self.pending is not None:
             self.pending[0].wait()
             self.pending = None
+        self._drop_xop()
 
     def step(self, k, v, displaced: bool):
         self.flush()
+        if not displaced and self._xop_args is not None:
+            global _current_cache_key
+            if self.xop is None:
+                from . import xlayer
+                self.xop = xlayer.LayerOp(*self._xop_args, own_update="ef")
+            with Profiler.scope("compact.exchange_layer"):
+                self.xop.run(k, v, self._stream())
+            from ..collector import collector
+            if collector.instance is None or collector.instance.enabled:
+                for key in self.kkeys + self.vkeys:
+                    _cache.touch(key)
+            _current_cache_key = self.vkeys[-1]
+            return list(self.kviews), list(self.vviews)
         p = self.parity
         self.parity ^= 1
         with Profiler.scope("compact.compress_batch"):

@@ -180,7 +180,7 @@ class _SteadyLayer:
         self.last_key = ex.vkeys[ex.peers[-1]]
 
     def matches(self, q, k, v, ctype, cfg, causal, dropout_p) -> bool:
-        if ctype is not self.ctype or cfg is not self.cfg or causal or dropout_p or self.ex.plan is None or cfg.check_cache_consistency:
+        if ctype is not self.ctype or cfg is not self.cfg or causal or dropout_p or (self.ex.plan is None and self.ex.xop is None) or cfg.check_cache_consistency:
             return False
         cache = compact_cache()
         if (tuple(q.shape), tuple(k.shape), tuple(v.shape), q.device, cm._generation, cache.version, self.ex.sig) != self.key:
@@ -215,6 +215,32 @@ class _SteadyLayer:
     def run(self, q, k, v, softmax_scale):
         ex = self.ex
         sh = torch.cuda.current_stream(q.device).cuda_stream
+        if ex.xop is not None:
+            # ONE native call: the layer's whole exchange on this stream, then the blocks over own K,V and the peers' states
+            ex.xop.run(k, v, sh)
+            cm._current_cache_key = self.last_key
+            if self._fast_ok(q):
+                sdpa, merge, ctx = self._sdpa, self._merge, self._ctx
+                B, S, H, D = q.shape
+                qt = q.transpose(1, 2)
+                res = sdpa(qt, k.transpose(1, 2), v.transpose(1, 2), 0.0, False, False, scale=softmax_scale)
+                out = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
+                lse = torch.empty((B, S, H, 1), dtype=torch.float32, device=q.device)
+                op, lp = out.data_ptr(), lse.data_ptr()
+                first = 1
+                for kt, vt in [(None, None)] + self._peer_t:
+                    if kt is not None:
+                        res = sdpa(qt, kt, vt, 0.0, False, False, scale=softmax_scale)
+                    if merge(ctx, op, lp, res[0].data_ptr(), res[1].data_ptr(), B, S, H, D, 1, first, None, 0, sh) != 0:
+                        raise RuntimeError("cfx_attn_merge failed: " + (ex.xop.lib.cfx_last_error_string(ctx) or b"").decode())
+                    first = 0
+                return out.to(q.dtype), lse.squeeze(dim=-1).transpose(1, 2), None
+            bo, bl = block_attention(q, k, v, 0.0, softmax_scale, causal=False)
+            out, lse = update_out_and_lse(None, None, bo, bl)
+            for kk, vv in ex.peer_views:
+                bo, bl = block_attention(q, kk, vv, 0.0, softmax_scale, causal=False)
+                out, lse = update_out_and_lse(out, lse, bo, bl)
+            return out.to(q.dtype), lse.squeeze(dim=-1).transpose(1, 2), None
         if ex.lane:
             # exchange lane: ONE native call issues the layer's whole chain on the exchange stream; the compute stream never sees
             # an event - the merge launch of block s also waits (in-kernel, on a flag) for peer s+1's reconstruction
@@ -308,6 +334,7 @@ class _LayerExchange:
         self.comp = None
         self.dec = []
         self.peer_views = []
+        self.xop = None              # the layer's exchange as ONE native op (xlayer.LayerOp): the default off the exchange lane
         self._p2p = None             # CFX_RING_P2P: {"send": own packets in IPC memory, "peer": {rank: its packets, mapped}, "flag": ptr, "peer_flag": {rank: ptr}}
         self._p2p_tried = False
 
@@ -347,7 +374,8 @@ class _LayerExchange:
                 lib.cfx_ipc_free(ctx, ptr)
             return
         d = self.send.device
-        self._p2p = {"ptr": ptr.value, "send": _raw_halves(ptr.value, halves, d),
+        self._lib = lib
+        self._p2p = {"ptr": ptr.value, "peer_ptr": dict(opened), "send": _raw_halves(ptr.value, halves, d),
                      "peer": {r: _raw_halves(pq, halves, d) for r, pq in opened.items()},
                      "flag": ptr.value + halves * 2, "peer_flag": {r: pq + halves * 2 for r, pq in opened.items()}}
 
@@ -365,6 +393,23 @@ class _LayerExchange:
             assert b is not None, f"no cached base for key {key}: a WARMUP step must precede residual compression"
             return b
         own = [state(self.kkeys[self.rank]), state(self.vkeys[self.rank])]
+        self._drop_xop()
+        if self._xop_wanted(cid):
+            # ONE native op per layer (xlayer.LayerOp): compress ; exchange ; reconstruct all peers - on the caller's stream, in front of
+            # the local attention block.  The states are updated in place; the consumer reads them as the peers' K,V.
+            from . import xlayer
+            self._drop_plan()
+            self.lane, self.plan_updates_state = False, not ef
+            peers, self.peer_views = [], []
+            for r in self.peers:
+                bk, bv = state(self.kkeys[r]), state(self.vkeys[r])
+                peers.append((r, bk, bv))
+                self.peer_views.append((bk.view(kshape), bv.view(vshape)))
+            self.xop = xlayer.LayerOp(("ring", self.kkeys[self.rank], id(self.group) if self.group is not None else None), cid, param, N, C,
+                                      self.rank, self.world, self.group, self.send.device, own, peers, own_update="ef" if ef else "x")
+            self.comp, self.dec = None, []
+            self.sig = sig
+            return
         if not self._p2p_tried:
             self._p2p_setup()
         p2p = self._p2p
@@ -397,9 +442,40 @@ class _LayerExchange:
             self._lib.cfx_plan_destroy(self.plan)
         self.plan = None
 
+    def _drop_xop(self):
+        if self.xop is not None:
+            self.xop.close()
+        self.xop = None
+
+    def _xop_wanted(self, cid) -> bool:
+        """The layer's exchange as one native op on the caller's stream - unless the caller runs on the exchange lane's compute stream
+        (then the chain runs beside the attention blocks on the CU-masked exchange stream) or asked for one of the multi-launch forms."""
+        from . import xlayer
+        from .. import lanes
+        xmode = os.environ.get("CFX_RING_EXCHANGE_STREAM", "auto")     # auto | xlayer | lane | chain | side | main
+        if xmode not in ("auto", "xlayer") or not xlayer.usable(cid, self.world, self.send.is_cuda):
+            return False
+        dev = self.send.device.index if self.send.device.index is not None else torch.cuda.current_device()
+        return xmode == "xlayer" or not lanes.on_compute_stream(dev)
+
+    def close(self):
+        """Release what the layer holds outside torch's allocator: native plans and (legacy CFX_RING_P2P chain) its IPC buffer + mappings."""
+        self._drop_plan()
+        self._drop_xop()
+        p2p, self._p2p = self._p2p, None
+        if p2p is not None and self._lib is not None:
+            import ctypes
+            from .. import codecs
+            dev = self.send.device.index if self.send.device.index is not None else torch.cuda.current_device()
+            ctx = codecs.context(dev)
+            torch.cuda.synchronize(dev)
+            for pq in p2p["peer_ptr"].values():
+                self._lib.cfx_ipc_close(ctx, ctypes.c_void_p(pq))
+            self._lib.cfx_ipc_free(ctx, ctypes.c_void_p(p2p["ptr"]))
+
     def __del__(self):
         try:
-            self._drop_plan()
+            self.close()
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 
@@ -427,8 +503,10 @@ class _LayerExchange:
         ctx = codecs.context(dev)
         plan = lib.cfx_plan_create(ctx)
         # ONE exchange stream per device, shared by every layer's plan (a stream per plan would be a hardware queue per layer)
-        xmode = os.environ.get("CFX_RING_EXCHANGE_STREAM", "lane")     # lane | chain | side | main
-        assert xmode in ("lane", "chain", "side", "main"), "CFX_RING_EXCHANGE_STREAM must be lane | chain | side | main"
+        xmode = os.environ.get("CFX_RING_EXCHANGE_STREAM", "auto")     # auto | xlayer | lane | chain | side | main
+        if xmode in ("auto", "xlayer"):
+            xmode = "lane"           # (here: the caller is on the lane's compute stream, or the shape has no layer op)
+        assert xmode in ("lane", "chain", "side", "main"), "CFX_RING_EXCHANGE_STREAM must be auto | xlayer | lane | chain | side | main"
         self._async = xmode == "chain"
         self.lane = xmode == "lane"
         xs_handle = None
@@ -550,8 +628,15 @@ class _LayerExchange:
         return self._epoch.value
 
     def run_front(self, k, v, sh):
+        if self.xop is not None:
+            self.xop.run(k, v, sh)
+            return
         if self.lane:
-            self._last_epoch = self.run_lane(k, v, sh)
+            # (two calls: cfx_plan_run_lane takes compute_stream = NULL to mean "cfx_plan_lane_begin was already called", and the
+            # legacy default stream IS the NULL handle - the ready flag would never be launched and the chain's wait would compare
+            # against a stale epoch: K,V read before the compute stream has produced them)
+            self.lane_begin(sh)
+            self._last_epoch = self.run_lane(k, v, None)
             return
         self._xs[0], self._xs[1] = k.data_ptr(), v.data_ptr()
         if self._async:
@@ -563,6 +648,8 @@ class _LayerExchange:
             raise RuntimeError("native exchange (compress + all-gather) failed: " + (self._lib.cfx_last_error_string(self._ctx) or b"").decode())
 
     def run_back(self, sh):
+        if self.xop is not None:
+            return                    # (the layer op reconstructed every peer in front of the local block, in stream order)
         if self.lane:
             # general path: one wait for the whole chain (the steady-state lane waits per peer, inside the merge launches)
             from .attention import flag_wait
@@ -611,7 +698,7 @@ def _gather_schedule(q, k, v, ctype, mod_idx, rank, world, group, kkey, vkey, at
         sig = (cm._generation, cache.version, cid, param, N, C, tuple(kshape), cfg.error_feedback)
         if ex.sig != sig:
             ex.bind(sig, cid, param, N, C, n_half, kshape, vshape, cfg.error_feedback)
-        native_x = ex.plan is not None
+        native_x = ex.plan is not None or ex.xop is not None
         with Profiler.scope("compact.compress_batch"):
             if native_x:
                 ex.run_front(k, v, sh)         # compress K,V + the all-gather on the exchange stream: one host call

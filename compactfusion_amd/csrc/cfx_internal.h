@@ -56,7 +56,12 @@ struct cfx_ctx {
     long long gate_timeout;         // ticks of the 100 MHz wall clock a flag wait may last
     int fused;                      // 1 (default): compress = statistics + in-launch finalize; 0: separate finalize kernel
     void* dbg_stamps;               // developer hook (cfx_debug_stamps)
-    int stats_rows;                 // CFX_STATS_ROWS override of the statistics tile height (experiments), 0 = automatic
+    int stats_rows;                 // cfx_set_stats_rows: override of the statistics tile height (experiments), 0 = automatic
+    int gated_on;                   // cfx_set_gated_launch: 1 (default) the one-launch gated / exchange-layer forms where they qualify
+    int lr_chain, lr_decode;        // cfx_set_lr_chain / cfx_set_lr_decode (0 = automatic)
+    int dev_probe;                  // cfx_set_dev_probe (developer builds)
+    int allow_shared_queues;        // cfx_set_allow_shared_queues: flag-ordered streams even when cfx_hw_queues_ok() == 0
+    int ipc_kind;                   // what the last cfx_ipc_alloc returned: 2 uncached, 1 fine-grained, 0 ordinary device memory
     // hand-over arenas of the slab-resident low-rank chain: one per stream that launches it (zeroed when allocated and whenever the
     // shape it is laid out for changes: its words carry sequence tags that only make sense against what the chain itself wrote)
     void* lrs_stream[8];
@@ -146,9 +151,8 @@ struct cfx_comm {
 
 // what an exchange-layer launch tells its caller: the packets of the launch are complete once counter *p_gate has reached p_expect;
 // the gated reconstruction group proceeds once *f_gate == f_expect
-// persistent (in): size the reconstruction group so that nothing of the launch is ever pending (a collective kernel needs CUs meanwhile)
 // needs_room (in): a collective kernel will run while the reconstruction group waits - take the one-launch form only if the group leaves it CUs
-struct CfxXGate { int taken; unsigned* p_gate; unsigned p_expect; unsigned* f_gate; unsigned f_expect; int persistent; int needs_room;
+struct CfxXGate { int taken; unsigned* p_gate; unsigned p_expect; unsigned* f_gate; unsigned f_expect; int needs_room;
                   int remote; };    // remote (in): the reconstruction items' packets may sit in a peer GPU's memory
 struct PlanOp {
     int kind;   // 0 compress, 1 decompress, 2 all-gather on the side stream, 3 main stream waits for gather op `ref`, 4 ring hop,
@@ -179,7 +183,6 @@ struct PlanOp {
     unsigned* own_flag;                              // this rank's "packets of this layer complete" word (in memory the peers have mapped)
     const unsigned* peer_flag[CFX_P2P_MAX_PEERS];    // the peers' words
     int n_peers;
-    unsigned runs;                                   // executions so far = the epoch published next
 };
 struct PipeSched;
 struct cfx_plan {
@@ -197,6 +200,7 @@ struct cfx_plan {
     int n_flags;
     unsigned epoch;       // value the lane's flags take in the current replay (cfx_plan_run_lane advances it)
     unsigned* p2p_sink;   // a device word nobody reads: where the in-order form of a p2p exchange layer "opens its gate"
+    int pipe_unit_layers; // cfx_plan_set_pipe_unit_layers: layers per unit of the pipelined replay (default 7)
 };
 
 
@@ -220,6 +224,8 @@ CFX_HIDDEN size_t cfx_i_ws_words(int codec, int N, int C);
 CFX_HIDDEN unsigned* cfx_i_ticket_block(cfx_ctx* ctx, void* stream);
 // CUs the queue of `stream` may use (a CU-masked stream: fewer than the device has)
 CFX_HIDDEN int cfx_i_stream_cus(cfx_ctx* ctx, void* stream);
+// 1: the codec has a one-launch exchange-layer form (reconstruction group gated on an external word)
+CFX_HIDDEN bool cfx_i_has_xlayer_form(int codec);
 CFX_HIDDEN int cfx_i_decompress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items, void* stream,
                                      unsigned* pre, unsigned pre_val);
 // `xg` != NULL: the gated items wait on an EXTERNAL gate (their packets are delivered by a collective behind this launch), see

@@ -1977,10 +1977,12 @@ cfx_ctx* cfx_create(int device) {
     c->gate_err = nullptr;
     c->gate_timeout = 500000000LL;     // 5 s of the 100 MHz wall clock
     c->fused = 1;
-    const char* f = getenv("CFX_FUSED_FINALIZE");
-    if (f) c->fused = atoi(f) != 0;
-    const char* sr = getenv("CFX_STATS_ROWS");
-    c->stats_rows = sr ? atoi(sr) : 0;
+    c->stats_rows = 0;
+    c->gated_on = 1;
+    c->lr_chain = c->lr_decode = 0;
+    c->dev_probe = 0;
+    c->allow_shared_queues = 0;
+    c->ipc_kind = 0;
     c->err[0] = 0;
     return c;
 }
@@ -2025,6 +2027,61 @@ int cfx_set_fused_finalize(cfx_ctx* ctx, int on) {
     if (!ctx) return CFX_ERR_NULL;
     ctx->fused = on != 0;
     return CFX_OK;
+}
+
+int cfx_set_stats_rows(cfx_ctx* ctx, int rows) {
+    if (!ctx) return CFX_ERR_NULL;
+    if (rows < 0 || rows > 4096) return fail(ctx, CFX_ERR_BATCH, "stats rows must be 0 (automatic) .. 4096");
+    ctx->stats_rows = rows;
+    return CFX_OK;
+}
+
+int cfx_set_gated_launch(cfx_ctx* ctx, int on) {
+    if (!ctx) return CFX_ERR_NULL;
+    ctx->gated_on = on != 0;
+    return CFX_OK;
+}
+
+int cfx_set_lr_chain(cfx_ctx* ctx, int chain) {
+    if (!ctx) return CFX_ERR_NULL;
+    if (chain < 0 || chain > 2) return fail(ctx, CFX_ERR_BATCH, "lr chain must be 0 (automatic), 1 (no single launch) or 2 (C-space chain)");
+    ctx->lr_chain = chain;
+    return CFX_OK;
+}
+
+int cfx_set_lr_decode(cfx_ctx* ctx, int mode) {
+    if (!ctx) return CFX_ERR_NULL;
+    if (mode < 0 || mode > 2) return fail(ctx, CFX_ERR_BATCH, "lr decode must be 0 (automatic), 1 (VALU) or 2 (MFMA)");
+    ctx->lr_decode = mode;
+    return CFX_OK;
+}
+
+int cfx_set_dev_probe(cfx_ctx* ctx, int mode) {
+    if (!ctx) return CFX_ERR_NULL;
+#ifdef CFX_DEV_PROBES
+    if (mode < 0 || mode > 4) return fail(ctx, CFX_ERR_BATCH, "dev probe must be 0..4");
+    ctx->dev_probe = mode;
+    return CFX_OK;
+#else
+    if (mode != 0) return fail(ctx, CFX_ERR_BATCH, "this build has no developer probes (python -m compactfusion_amd.build --dev-probes)");
+    return CFX_OK;
+#endif
+}
+
+int cfx_set_allow_shared_queues(cfx_ctx* ctx, int on) {
+    if (!ctx) return CFX_ERR_NULL;
+    ctx->allow_shared_queues = on != 0;
+    return CFX_OK;
+}
+
+// The one environment variable the library looks at - and it is the HIP runtime's, not ours: see cfx.h.
+int cfx_hw_queues_ok(void) {
+    static int ok = -1;
+    if (ok < 0) {
+        const char* v = getenv("GPU_MAX_HW_QUEUES");
+        ok = (v && atoi(v) >= 2) ? 1 : 0;
+    }
+    return ok;
 }
 
 static void prof_free(cfx_ctx* ctx) {
@@ -2205,9 +2262,7 @@ static int fused_rows(const cfx_ctx* ctx, int N, int C, int batch, int cus) {
 // tiles of at most FUSED_NW * GATE_KR (1-bit) / FUSED_NW * (GATE_KR2 + GATE_KL) (2-bit) rows cover the tensor with few enough workgroups to matter.  Otherwise the same work runs as
 // compress + one reconstruction launch (identical results).
 static bool gated_one_launch(cfx_ctx* ctx, int codec, int C, int CB) {
-    static const char* dbg_env = getenv("CFX_FUSED_DBG");
-    static const char* off_env = getenv("CFX_GATED_OFF");
-    return (codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT2) && ctx->fused && CB <= TICK_MAX_CB && C % 128 == 0 && !dbg_env && !off_env;
+    return (codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT2) && ctx->fused && CB <= TICK_MAX_CB && C % 128 == 0 && !ctx->dev_probe && ctx->gated_on;
 }
 
 // Ticket / gate blocks are handed out round-robin from a ring PER STREAM (launches of one stream are in order, so a ring slot is never
@@ -2241,7 +2296,7 @@ static unsigned ticket_slot(cfx_ctx* ctx, void* stream) {
 static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                          int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
                          void* workspace, size_t workspace_bytes, void* stream, CfxXGate* xg = nullptr) {
-    if (xg) { const int pers = xg->persistent, room = xg->needs_room, rem = xg->remote; memset(xg, 0, sizeof(*xg)); xg->persistent = pers; xg->needs_room = room; xg->remote = rem; }
+    if (xg) { const int room = xg->needs_room, rem = xg->remote; memset(xg, 0, sizeof(*xg)); xg->needs_room = room; xg->remote = rem; }
     if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "compress: null ctx/items");
     if (n_gated < 0 || n_gated > CFX_MAX_BATCH || (n_gated && !gated)) return fail(ctx, CFX_ERR_BATCH, "compress: gated batch out of range");
     if (n_gated && codec != CFX_CODEC_BINARY && codec != CFX_CODEC_INT2)
@@ -2392,27 +2447,14 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             a.dq_rb = (N + a.dq_R - 1) / a.dq_R;
             a.per_byte = per_byte; a.eps_mode = codec == CFX_CODEC_INT2 ? 1 : 0;
             a.ws = ws; a.ws_stride = wstride; a.tick = tick;
-            { static const char* dbg_env = getenv("CFX_FUSED_DBG"); a.dbg = dbg_env ? atoi(dbg_env) : 0; }
+            a.dbg = ctx->dev_probe;
             a.stamps = (u64*)ctx->dbg_stamps;
             if (one_launch_1bit) {
                 // tiles of the gated group: as few row blocks as GATE_KR rows per wave allow, heights a multiple of FUSED_NW
                 a.g_rb = (N + FUSED_NW * GATE_KR - 1) / (FUSED_NW * GATE_KR);
                 a.g_R = ((N + a.g_rb - 1) / a.g_rb + FUSED_NW - 1) / FUSED_NW * FUSED_NW;
                 a.n_gt = a.n_g = CB * a.g_rb * n_gated_k;
-                if (xg && xg->persistent) {
-                    // a collective KERNEL will need CUs while this group waits: launch only as many reconstruction workgroups as are resident
-                    // TOGETHER with the compress group (nothing is ever pending, so the slots the compress group frees stay free: at least
-                    // (CUs - n_g / 2) CUs then hold a single workgroup of this launch and 320 free VGPRs per SIMD); the rest of the tiles
-                    // are taken in turn after the gate
-                    static int per_cu = 0;
-                    if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_absmean_compress<true, 4, true>, FUSED_NT, 0) != hipSuccess || per_cu < 1)) {
-                        (void)hipGetLastError();
-                        per_cu = 1;
-                    }
-                    const int cap = per_cu * stream_cus - a.n_st;
-                    if (cap >= stream_cus / 2 && cap < a.n_g) a.n_g = cap;
-                }
-                    a.gate = ctx->gate + (size_t)slot * GATE_STRIDE;
+                a.gate = ctx->gate + (size_t)slot * GATE_STRIDE;
                 ctx->gate_expect[2 * slot] += (unsigned)batch * (unsigned)(CB + 1);
                 a.gate_expect = ctx->gate_expect[2 * slot];
                 if (xg) {
@@ -2527,6 +2569,7 @@ int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base
 // ---- entry points for cfx_plan.hip (plan replay, exchange lane) ------------------------------------------------------------
 }  // extern "C"
 bool cfx_i_shape_ok(int codec, int N, int C, int param) { return shape_ok(codec, N, C, param); }
+bool cfx_i_has_xlayer_form(int codec) { return codec == CFX_CODEC_BINARY; }
 unsigned* cfx_i_ticket_block(cfx_ctx* ctx, void* stream) {
     if (!ctx->tick && cfx_prepare(ctx) != CFX_OK) return nullptr;
     return ctx->tick + (size_t)ticket_slot(ctx, stream) * CFX_MAX_BATCH * TICK_WORDS;

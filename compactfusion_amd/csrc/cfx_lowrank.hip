@@ -727,9 +727,8 @@ int cfx_i_lr_decode_launch(cfx_ctx* ctx, int N, int C, int rank, int batch, cons
     for (int i = 0; i < batch; ++i) db.it[i] = items[i];
     const int RPv = lr_rp(rank);
     // rank <= 16: the VALU form is at the HBM roofline (tools/lowrank_bench.py); rank 32: it runs out of issue slots and
-    // registers (2.8x over the roofline), the MFMA form is back at it.  CFX_LR_DECODE=valu|mfma forces one (measurements).
-    static const char* force = getenv("CFX_LR_DECODE");
-    const bool mfma = force ? !strcmp(force, "mfma") : RPv == 32;
+    // registers (2.8x over the roofline), the MFMA form is back at it.  cfx_set_lr_decode forces one (measurements).
+    const bool mfma = ctx->lr_decode ? ctx->lr_decode == 2 : RPv == 32;
     if (mfma) {
         const int CBk = (C + 511) / 512;
         int rows = 32;
@@ -778,12 +777,11 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
     const int nparts = (C + 31) / 32;
     const dim3 g_aq((N + 31) / 32, 4, batch), g_aty(nparts, batch), g_chol(batch), g_apc((C + 255) / 256, batch), g_apn((N + 255) / 256, batch);
     // The N-space chain (cfx_lrgram.hip: 5 launches up to the factors) for shards whose Gram matrix is small, else the C-space chain.
-    static const char* chain_env = getenv("CFX_LR_CHAIN");
     // (rank > 16: the two factorisations the chain's last launch runs back to back in one wave spill at RP = 32 - measured slower than the
     // C-space chain's separate launches)
     // rank 32: only the slab-resident form of the N-space chain takes it (where its workgroups fit the stream's CUs)
-    const bool slab32 = RPv == 32 && !(chain_env && !strcmp(chain_env, "gram5")) && cfx_i_lrs_fit(ctx, N, C, RPv, (void*)s) >= 1;
-    const bool gram = cfx_i_lrg_ok(N, C) && (RPv <= 16 || slab32) && !(chain_env && !strcmp(chain_env, "cspace"));
+    const bool slab32 = RPv == 32 && ctx->lr_chain == 0 && cfx_i_lrs_fit(ctx, N, C, RPv, (void*)s) >= 1;
+    const bool gram = cfx_i_lrg_ok(N, C) && (RPv <= 16 || slab32) && ctx->lr_chain != 2;
     int decoded = 0;                     // the single-launch chain also does the error-feedback update of LOW_RANK
     if (gram) {
         const int rg = cfx_i_lrg_factors(ctx, quantized, N, C, rank, batch, b, w.D, w.U16, w.V16, w.gram, absd,

@@ -653,10 +653,9 @@ int cfx_i_lrg_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int b
                       size_t extra, int absd, int want_decode, int* decoded, hipStream_t s) {
     const int RPv = lr_rp(rank);
     if (decoded) *decoded = 0;
-    static const char* chain_env = getenv("CFX_LR_CHAIN");
     // the slab-resident chain (cfx_lrslab.hip: one persistent launch) when its workgroups are co-resident on this stream's CUs - not on
     // a CU-masked lane, whose 32 CUs cannot hold C / 32 workgroups: there the six launches below run
-    if (!(chain_env && !strcmp(chain_env, "gram5")) && cfx_i_lrs_fit(ctx, N, C, RPv, (void*)s) >= 1)
+    if (ctx->lr_chain == 0 && cfx_i_lrs_fit(ctx, N, C, RPv, (void*)s) >= 1)
         return cfx_i_lrs_factors(ctx, quantized, N, C, rank, batch, b, offU16, offV16, extra, absd, want_decode, decoded, s);
     LrgArgs a;
     memset(&a, 0, sizeof(a));
@@ -683,5 +682,7 @@ int cfx_i_lrg_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int b
     if (!a.tick) return fail(ctx, CFX_ERR_LAUNCH, "low-rank: no ticket block");
     if (RPv == 8) return lrg_run<8>(ctx, b, a, s);
     if (RPv == 16) return lrg_run<16>(ctx, b, a, s);
-    return lrg_run<32>(ctx, b, a, s);
+    // rank 32 is only ever taken by the slab-resident launch (the six-launch form's two back-to-back factorisations spilled at RP = 32
+    // and measured slower than the C-space chain: not built)
+    return fail(ctx, CFX_ERR_SHAPE, "low-rank: the six-launch N-space chain is built for ranks up to 16");
 }

@@ -78,20 +78,30 @@ __global__ void k_flag_relay(const unsigned* wait, unsigned wv, unsigned* set, u
 //   wait until every peer has published the epoch            ->  open this launch's gate
 // One wave: lane 0 does the local steps, lane p polls peer p's word (system-scope loads: the word lives in another GPU's memory).
 struct PeerFlags { const unsigned* pub[CFX_P2P_MAX_PEERS]; };
-__global__ void k_flag_exchange(const unsigned* p_gate, unsigned p_expect, unsigned* own_pub, unsigned epoch, PeerFlags peers, int n_peers,
+// The epoch a rank publishes is (its own word) + 1, taken on the DEVICE: every rank executes an op equally often, so the n-th execution
+// publishes n on every rank whatever the host rebuilt in between (a plan that is rebuilt - compact_reset, a new state arena - keeps
+// counting where the words stand; a host-side counter restarted at 0 there and every wait of the next generation passed at once).  Only
+// this rank's flag kernels of this op write the word, one at a time (stream order, or behind the launch whose packets they wait for).
+// p_gate NULL: nothing to wait for locally (the in-order forms: the packets are complete by stream order).
+__global__ void k_flag_exchange(const unsigned* p_gate, unsigned p_expect, unsigned* own_pub, PeerFlags peers, int n_peers,
                                 unsigned* f_gate, unsigned f_expect, unsigned* err, long long timeout) {
     const int lane = threadIdx.x;
     const long long t0 = wall_clock64();
     bool gave_up = false;
+    unsigned epoch = 0;
     if (lane == 0) {
-        while ((int)(__hip_atomic_load(p_gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p_expect) < 0) {
-            __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > timeout) { gave_up = true; break; }
+        if (p_gate) {
+            while ((int)(__hip_atomic_load(p_gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p_expect) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > timeout) { gave_up = true; break; }
+            }
         }
+        epoch = __hip_atomic_load(own_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
         // the packets were stored write-through and their stores had completed before the last arrival was counted: publishing after
         // having SEEN the count orders them before the word for anybody who reads the word first
         __hip_atomic_store(own_pub, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    epoch = (unsigned)__builtin_amdgcn_readfirstlane((int)epoch);
     if (lane < n_peers) {
         while ((int)(__hip_atomic_load(peers.pub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
             __builtin_amdgcn_s_sleep(2);
@@ -133,8 +143,7 @@ cfx_plan* cfx_plan_create(cfx_ctx* ctx) {
     // ~10 us of idle queue time, two per layer (main->side, side->main) = +1.1 ms per 57-layer step, whereas the
     // in-order exchange adds 0.1 ms; a side stream only pays when >> 20 us of independent work can overlap (attention).
     p->side_mode = 0;
-    const char* m = getenv("CFX_EXCHANGE_STREAM");
-    if (m) p->side_mode = !strcmp(m, "main") ? 0 : (!strcmp(m, "side") ? 1 : 2);
+    p->pipe_unit_layers = 7;
     return p;
 }
 
@@ -142,6 +151,15 @@ int cfx_plan_set_exchange_stream(cfx_plan* p, int mode) {
     if (!p) return CFX_ERR_NULL;
     if (mode < 0 || mode > 2 || p->side) return fail(p->ctx, CFX_ERR_BATCH, "plan: exchange stream mode must be 0..2 and set before the first all-gather op");
     p->side_mode = mode;
+    return CFX_OK;
+}
+
+int cfx_plan_set_pipe_unit_layers(cfx_plan* p, int layers) {
+    if (!p) return CFX_ERR_NULL;
+    if (layers < 1 || layers > 7) return fail(p->ctx, CFX_ERR_BATCH, "plan: a unit of the pipelined replay holds 1..7 layers");
+    p->pipe_unit_layers = layers;
+    sched_free(p->sched);
+    p->sched = nullptr;
     return CFX_OK;
 }
 
@@ -170,6 +188,9 @@ void cfx_plan_destroy(cfx_plan* p) {
     delete[] p->ops;
     delete p;
 }
+
+// op kinds whose items' x operands are the activations a run re-points (cfx_plan_run_x): the 1-bit .. top-k compress, the exchange layers
+static inline bool takes_activations(int kind) { return kind == 0 || kind == 9 || kind == 10; }
 
 static PlanOp* plan_push(cfx_plan* p) {
     if (p->n == p->cap) {
@@ -269,7 +290,7 @@ int cfx_plan_add_exchange_layer(cfx_plan* p, int codec, int N, int C, int param,
                                 void* workspace, size_t workspace_bytes) {
     if (!p) return CFX_ERR_NULL;
     if (n_recon < 1 || n_recon > CFX_MAX_BATCH || !recon) return fail(p->ctx, CFX_ERR_BATCH, "plan: exchange layer needs 1..CFX_MAX_BATCH reconstruction items");
-    if (codec != CFX_CODEC_BINARY) return fail(p->ctx, CFX_ERR_CODEC, "plan: the exchange layer op is built for the 1-bit codec");
+    if (codec < CFX_CODEC_BINARY || codec > CFX_CODEC_TOPK) return fail(p->ctx, CFX_ERR_CODEC, "plan: exchange layer: unknown codec");
     if (comm && (!send || !recv)) return fail(p->ctx, CFX_ERR_NULL, "plan: exchange layer: null send/recv");
     if (!p->side) {
         // the flag kernels poll: they need a hardware queue of their own (cfx.h, exchange lane) - a CU-masked stream has one
@@ -310,7 +331,6 @@ int cfx_plan_add_exchange_layer_p2p(cfx_plan* p, int codec, int N, int C, int pa
     o->own_flag = (unsigned*)own_flag;
     o->n_peers = n_peers;
     for (int i = 0; i < n_peers; ++i) o->peer_flag[i] = (const unsigned*)peer_flags[i];
-    o->runs = 0;
     if (!p->p2p_sink && hipMalloc((void**)&p->p2p_sink, 64) != hipSuccess) {
         (void)hipGetLastError();
         p->p2p_sink = nullptr;
@@ -354,15 +374,25 @@ int cfx_ipc_alloc(cfx_ctx* ctx, size_t bytes, void** ptr, void* handle64) {
     int rc = CFX_OK;
     void* d = nullptr;
     hipIpcMemHandle_t h;
-    if (hipMalloc(&d, bytes) != hipSuccess) { (void)hipGetLastError(); rc = fail(ctx, CFX_ERR_LAUNCH, "ipc_alloc: hipMalloc failed"); }
-    else if (hipMemset(d, 0, bytes) != hipSuccess || hipIpcGetMemHandle(&h, d) != hipSuccess) {
+    // Peers poll flag words in this memory and read packets from it WHILE the producing kernel is still running, and the same addresses
+    // are rewritten every step.  Ordinary (coarse-grained) device memory is only promised coherent across devices at kernel boundaries:
+    // a reader's L2 may keep last step's lines.  So the buffer is UNCACHED device memory (what RCCL allocates for the buffers its kernels
+    // exchange through on gfx94x / gfx950), else fine-grained, else - with a note in the context - ordinary memory; the device code
+    // uses write-through stores on the producer and system-scope loads on the readers whatever the kind.
+    int kind = 2;
+    hipError_t e = hipExtMallocWithFlags(&d, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); d = nullptr; kind = 1; e = hipExtMallocWithFlags(&d, bytes, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) { (void)hipGetLastError(); d = nullptr; kind = 0; e = hipMalloc(&d, bytes); }
+    if (e != hipSuccess) { (void)hipGetLastError(); rc = fail(ctx, CFX_ERR_LAUNCH, "ipc_alloc: device allocation failed"); }
+    else if (hipMemset(d, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipIpcGetMemHandle(&h, d) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(d);
         rc = fail(ctx, CFX_ERR_LAUNCH, "ipc_alloc: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 is needed on hosts with dmabuf IPC only)");
-    } else { *ptr = d; memcpy(handle64, &h, 64); }
+    } else { *ptr = d; memcpy(handle64, &h, 64); ctx->ipc_kind = kind; }
     if (cur >= 0 && cur != ctx->device) (void)hipSetDevice(cur);
     return rc;
 }
+int cfx_ipc_memory_kind(cfx_ctx* ctx) { return ctx ? ctx->ipc_kind : CFX_ERR_NULL; }
 int cfx_ipc_open(cfx_ctx* ctx, const void* handle64, void** ptr) {
     if (!ctx || !ptr || !handle64) return fail(ctx, CFX_ERR_NULL, "ipc_open: null");
     int cur = -1;
@@ -457,7 +487,7 @@ int cfx_plan_run_x(cfx_plan* p, int first_op, int n_ops, const void* const* xs, 
     if (n_xs > 0) {
         if (!xs) return CFX_ERR_NULL;
         int op = first_op;
-        while (op < first_op + n_ops && p->ops[op].kind != 0) ++op;
+        while (op < first_op + n_ops && !takes_activations(p->ops[op].kind)) ++op;
         if (op == first_op + n_ops || p->ops[op].batch != n_xs) return fail(p->ctx, CFX_ERR_BATCH, "plan: run_x needs a compress op with n_xs items in the range");
         for (int i = 0; i < n_xs; ++i) {
             if (!xs[i]) return fail(p->ctx, CFX_ERR_NULL, "plan: null activation");
@@ -488,6 +518,18 @@ static int ring_hop(cfx_comm* c, const void* send, void* recv, size_t bytes, hip
     if (r == 0) r = c->api.Recv(recv, bytes, 1, prv, c->comm, s);
     const int e = c->api.GroupEnd();
     return r ? r : e;
+}
+
+// publish this rank's word for op `o`, wait for the peers' (k_flag_exchange) on `s`; p_gate != NULL: first wait until *p_gate has reached
+// p_expect (the launch's packets are complete); afterwards *f_gate = f_expect
+static int launch_flag_exchange(cfx_plan* p, const PlanOp* o, hipStream_t s, const unsigned* p_gate, unsigned p_expect, unsigned* f_gate,
+                                unsigned f_expect, const char* what) {
+    PeerFlags pf;
+    memset(&pf, 0, sizeof(pf));
+    for (int q = 0; q < o->n_peers; ++q) pf.pub[q] = o->peer_flag[q];
+    hipLaunchKernelGGL(k_flag_exchange, dim3(1), dim3(64), 0, s, p_gate, p_expect, o->own_flag, pf, o->n_peers, f_gate, f_expect,
+                       p->ctx->gate_err, p->ctx->gate_timeout);
+    return check_launch(p->ctx, what);
 }
 
 // `inline_exchange`: exchange ops run in order on `stream` itself whatever the plan's exchange-stream mode (cfx_plan_run_async:
@@ -538,105 +580,72 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                 break;
             case 7: rc = cfx_lr_compress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, o->q0, o->ws, o->ws_bytes, stream); break;
             case 8: rc = cfx_lr_decompress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->batch, o->d, o->ws, o->ws_bytes, stream); break;
-            case 11: {
-                const unsigned epoch = ++o->runs;
-                PeerFlags pf;
-                memset(&pf, 0, sizeof(pf));
-                for (int q = 0; q < o->n_peers; ++q) pf.pub[q] = o->peer_flag[q];
-                hipLaunchKernelGGL(k_flag_exchange, dim3(1), dim3(64), 0, main_s, (const unsigned*)o->own_flag, 0u, o->own_flag, epoch, pf, o->n_peers,
-                                   p->p2p_sink, epoch, p->ctx->gate_err, p->ctx->gate_timeout);
-                rc = check_launch(p->ctx, "p2p sync launch");
-            } break;
+            case 11:
+                rc = launch_flag_exchange(p, o, main_s, nullptr, 0u, p->p2p_sink, 1u, "p2p sync launch");
+                break;
             case 9:
             case 10: {
+                // Which form: ONE launch (the reconstruction group launched with the compress group, gated on a word the exchange stream
+                // sets) needs a codec that has it, an exchange stream that is not the run stream, and hardware queues of their own for the
+                // two (cfx_hw_queues_ok).  The legacy NULL stream serialises with every BLOCKING stream - a CU-masked exchange stream is one:
+                // its flag kernel would wait for the very launch it is meant to release - so beside the NULL stream only a non-blocking
+                // exchange stream will do.  Everything else runs the same work in order on the run stream: compress ; exchange ; reconstruct.
+                bool own_stream = p->side && (hipStream_t)stream != p->side && !inline_exchange && cfx_i_has_xlayer_form(o->codec) &&
+                                  (cfx_hw_queues_ok() || p->ctx->allow_shared_queues);
+                if (own_stream && stream == nullptr) {
+                    unsigned sf = 0;
+                    if (hipStreamGetFlags(p->side, &sf) != hipSuccess) { (void)hipGetLastError(); sf = 0; }
+                    own_stream = (sf & hipStreamNonBlocking) != 0;
+                }
                 CfxXGate xg;
                 memset(&xg, 0, sizeof(xg));
-                // CFX_XGATE_PERSISTENT=1 (developer): a reconstruction group small enough that nothing of the launch is ever pending - it
-                // guarantees a collective KERNEL its CUs, and measured slower than two launches, so it is off
-                static const char* pers_env = getenv("CFX_XGATE_PERSISTENT");
-                xg.persistent = pers_env ? atoi(pers_env) : 0;
                 xg.needs_room = o->comm && o->comm->nranks > 1;
                 xg.remote = o->kind == 10 && o->n_peers > 0;
-                // (the legacy NULL stream serialises with the CU-masked exchange stream: a flag kernel there would wait for the very launch
-                // it is meant to release - run in order instead)
-                const bool own_stream = p->side && stream != nullptr && (hipStream_t)stream != p->side && !inline_exchange;
-                if (!own_stream && o->kind == 10) {
-                    // in order on the run stream: compress ; publish + wait for the peers ; reconstruct
+                if (own_stream) {
+                    rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, 0, nullptr, o->n_gated, o->g, o->ws, o->ws_bytes, stream, &xg);
+                } else if (o->kind == 9 && !o->comm && (o->codec == CFX_CODEC_BINARY || o->codec == CFX_CODEC_INT2)) {
+                    // nothing moves and nobody else publishes: the reconstruction items' packets are this launch's own - the ordinary gated launch
+                    rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, 0, nullptr, o->n_gated, o->g, o->ws, o->ws_bytes, stream);
+                    break;
+                } else {
                     rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, 0, nullptr, 0, nullptr, o->ws, o->ws_bytes, stream);
-                    if (rc != CFX_OK) break;
-                    const unsigned epoch = ++o->runs;
-                    PeerFlags pf;
-                    memset(&pf, 0, sizeof(pf));
-                    for (int q = 0; q < o->n_peers; ++q) pf.pub[q] = o->peer_flag[q];
-                    hipLaunchKernelGGL(k_flag_exchange, dim3(1), dim3(64), 0, main_s, (const unsigned*)o->own_flag, 0u, o->own_flag, epoch, pf, o->n_peers,
-                                       p->p2p_sink, epoch, p->ctx->gate_err, p->ctx->gate_timeout);
-                    rc = check_launch(p->ctx, "p2p exchange layer: flag exchange launch (in order)");
+                }
+                if (rc != CFX_OK) break;
+                if (!xg.taken) {
+                    // in order on the run stream (also: a shape / stream without the one-launch form - compress_impl launched the compress only)
+                    if (o->kind == 10) rc = launch_flag_exchange(p, o, main_s, nullptr, 0u, p->p2p_sink, 1u, "p2p exchange layer: flag exchange launch (in order)");
+                    else if (o->comm) {
+                        const int r = o->comm->api.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, main_s);
+                        if (r != 0) {
+                            char buf[200];
+                            snprintf(buf, sizeof(buf), "ncclAllGather (exchange layer, in order): %s", o->comm->api.GetErrorString ? o->comm->api.GetErrorString(r) : "error");
+                            return fail(p->ctx, CFX_ERR_LAUNCH, buf);
+                        }
+                    }
                     if (rc == CFX_OK) rc = cfx_i_decompress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->n_gated, o->g, stream, nullptr, 0u);
                     break;
                 }
-                if (!own_stream && o->comm) {
-                    // in order on the run stream: compress ; all-gather ; reconstruct
-                    rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, 0, nullptr, 0, nullptr, o->ws, o->ws_bytes, stream);
-                    if (rc != CFX_OK) break;
-                    const int r = o->comm->api.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, main_s);
-                    if (r != 0) return fail(p->ctx, CFX_ERR_LAUNCH, "ncclAllGather failed (exchange layer, in order)");
-                    rc = cfx_i_decompress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->n_gated, o->g, stream, nullptr, 0u);
-                    break;
-                }
-                rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, 0, nullptr, o->n_gated, o->g, o->ws, o->ws_bytes, stream,
-                                   own_stream ? &xg : nullptr);
-                if (rc != CFX_OK || !own_stream) break;       // (no exchange stream, no collective: the ordinary gated launch)
-                hipStream_t xs = xg.taken ? p->side : main_s;
+                // one launch: what sits on the exchange stream between "packets complete" and "packets arrived"
                 if (o->kind == 10) {
-                    // the epoch every rank publishes for this execution of the op: all ranks replay the same plans the same number of times
-                    const unsigned epoch = ++o->runs;
-                    PeerFlags pf;
-                    memset(&pf, 0, sizeof(pf));
-                    for (int q = 0; q < o->n_peers; ++q) pf.pub[q] = o->peer_flag[q];
-                    if (xg.taken) {
-                        hipLaunchKernelGGL(k_flag_exchange, dim3(1), dim3(64), 0, xs, (const unsigned*)xg.p_gate, xg.p_expect, o->own_flag, epoch, pf, o->n_peers,
-                                           xg.f_gate, xg.f_expect, p->ctx->gate_err, p->ctx->gate_timeout);
-                        rc = check_launch(p->ctx, "p2p exchange layer: flag exchange launch");
-                    } else {
-                        // no one-launch form here: compress has been launched on the run stream; publish and wait in stream order, then reconstruct
-                        // (the gate words are not used: the kernel's p_gate / f_gate point at a scratch word that already holds the values)
-                        hipLaunchKernelGGL(k_flag_exchange, dim3(1), dim3(64), 0, main_s, (const unsigned*)o->own_flag, 0u, o->own_flag, epoch, pf, o->n_peers,
-                                           p->p2p_sink, epoch, p->ctx->gate_err, p->ctx->gate_timeout);
-                        rc = check_launch(p->ctx, "p2p exchange layer: flag exchange launch (in order)");
-                        if (rc == CFX_OK) rc = cfx_i_decompress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->n_gated, o->g, stream, nullptr, 0u);
-                    }
-                    break;
-                }
-                // with a communicator: wait kernel ; ncclAllGather ; set kernel - the same three enqueues at every world size (a one-rank
-                // in-place all-gather enqueues nothing; CFX_XGATE_FUSE_ONE_RANK=1, developer: treat it like "no communicator")
-                static const bool fuse_one = getenv("CFX_XGATE_FUSE_ONE_RANK") != nullptr;
-                const bool moves = o->comm && !(fuse_one && o->comm->nranks == 1);
-                if (xg.taken) {
-                    if (!moves) {
-                        hipLaunchKernelGGL(k_flag_relay, dim3(1), dim3(64), 0, xs, (const unsigned*)xg.p_gate, xg.p_expect, xg.f_gate, xg.f_expect,
-                                           p->ctx->gate_err, p->ctx->gate_timeout);
-                    } else {
-                        hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, xs, (const unsigned*)xg.p_gate, xg.p_expect, p->ctx->gate_err, p->ctx->gate_timeout);
-                    }
-                    rc = check_launch(p->ctx, "exchange layer: flag launch");
+                    rc = launch_flag_exchange(p, o, p->side, xg.p_gate, xg.p_expect, xg.f_gate, xg.f_expect, "p2p exchange layer: flag exchange launch");
+                } else if (!o->comm) {
+                    hipLaunchKernelGGL(k_flag_relay, dim3(1), dim3(64), 0, p->side, (const unsigned*)xg.p_gate, xg.p_expect, xg.f_gate, xg.f_expect,
+                                       p->ctx->gate_err, p->ctx->gate_timeout);
+                    rc = check_launch(p->ctx, "exchange layer: flag relay launch");
+                } else {
+                    // with a communicator: wait kernel ; ncclAllGather ; set kernel - the same three enqueues at every world size (a one-rank
+                    // in-place all-gather enqueues nothing)
+                    hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, p->side, (const unsigned*)xg.p_gate, xg.p_expect, p->ctx->gate_err, p->ctx->gate_timeout);
+                    rc = check_launch(p->ctx, "exchange layer: flag wait launch");
                     if (rc != CFX_OK) break;
-                }
-                if (o->comm && (moves || !xg.taken)) {
-                    const int r = o->comm->api.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, xs);
+                    const int r = o->comm->api.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, p->side);
                     if (r != 0) {
                         char buf[200];
                         snprintf(buf, sizeof(buf), "ncclAllGather: %s", o->comm->api.GetErrorString ? o->comm->api.GetErrorString(r) : "error");
                         return fail(p->ctx, CFX_ERR_LAUNCH, buf);
                     }
-                }
-                if (xg.taken) {
-                    if (moves) {
-                        hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, xs, xg.f_gate, xg.f_expect);
-                        rc = check_launch(p->ctx, "exchange layer: flag set launch");
-                    }
-                } else {
-                    // the launch could not carry the reconstruction (shape / stream without the one-launch form): in order on the main stream
-                    rc = cfx_i_decompress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->n_gated, o->g, stream, nullptr, 0u);
+                    hipLaunchKernelGGL(k_flag_set, dim3(1), dim3(64), 0, p->side, xg.f_gate, xg.f_expect);
+                    rc = check_launch(p->ctx, "exchange layer: flag set launch");
                 }
             } break;
         }
@@ -661,7 +670,7 @@ int cfx_plan_run_async(cfx_plan* p, int first_op, int n_ops, const void* const* 
     if (n_xs > 0) {
         if (!xs) return CFX_ERR_NULL;
         int op = first_op;
-        while (op < first_op + n_ops && p->ops[op].kind != 0) ++op;
+        while (op < first_op + n_ops && !takes_activations(p->ops[op].kind)) ++op;
         if (op == first_op + n_ops || p->ops[op].batch != n_xs) return fail(p->ctx, CFX_ERR_BATCH, "plan: run_async needs a compress op with n_xs items in the range");
         for (int i = 0; i < n_xs; ++i) {
             if (!xs[i] || !AL16(xs[i])) return fail(p->ctx, CFX_ERR_ALIGN, "plan: activations must be non-null and 16-byte aligned");
@@ -724,8 +733,17 @@ unsigned cfx_plan_epoch(const cfx_plan* p) { return p ? p->epoch : 0u; }
 // Advance the epoch and publish "the activations exist" (flag `ready_flag`) behind whatever the caller has enqueued on the compute
 // stream so far - the kernels that produce K, V.  Split from cfx_plan_run_lane so that the caller can enqueue the local attention
 // block BETWEEN the two: the chain's host issue (a dozen launches) then overlaps GPU work instead of delaying it.
+static int queues_check(cfx_ctx* ctx, const char* what) {
+    if (cfx_hw_queues_ok() || ctx->allow_shared_queues) return CFX_OK;
+    char buf[240];
+    snprintf(buf, sizeof(buf), "%s: flag-ordered streams need hardware queues of their own - set GPU_MAX_HW_QUEUES (e.g. 8) before HIP "
+             "initialises, or cfx_set_allow_shared_queues", what);
+    return fail(ctx, CFX_ERR_QUEUES, buf);
+}
+
 int cfx_plan_lane_begin(cfx_plan* p, int ready_flag, void* compute_stream, unsigned* epoch_out) {
     if (!p) return CFX_ERR_NULL;
+    { const int qc = queues_check(p->ctx, "plan: exchange lane"); if (qc != CFX_OK) return qc; }
     if (!p->flags || ready_flag < 0 || ready_flag >= p->n_flags) return fail(p->ctx, CFX_ERR_BATCH, "plan: ready flag index out of range");
     ++p->epoch;
     if (epoch_out) *epoch_out = p->epoch;
@@ -737,12 +755,13 @@ int cfx_plan_run_lane(cfx_plan* p, int first_op, int n_ops, const void* const* x
                       unsigned* epoch_out) {
     if (!p) return CFX_ERR_NULL;
     if (!p->side) return fail(p->ctx, CFX_ERR_BATCH, "plan: run_lane needs an exchange stream (cfx_plan_use_exchange_stream)");
+    { const int qc = queues_check(p->ctx, "plan: exchange lane"); if (qc != CFX_OK) return qc; }
     if (first_op < 0 || n_ops < 0 || first_op + n_ops > p->n) return fail(p->ctx, CFX_ERR_BATCH, "plan: op range out of bounds");
     if (!p->flags || ready_flag < 0 || ready_flag >= p->n_flags) return fail(p->ctx, CFX_ERR_BATCH, "plan: ready flag index out of range");
     if (n_xs > 0) {
         if (!xs) return CFX_ERR_NULL;
         int op = first_op;
-        while (op < first_op + n_ops && p->ops[op].kind != 0) ++op;
+        while (op < first_op + n_ops && !takes_activations(p->ops[op].kind)) ++op;
         if (op == first_op + n_ops || p->ops[op].batch != n_xs) return fail(p->ctx, CFX_ERR_BATCH, "plan: run_lane needs a compress op with n_xs items in the range");
         for (int i = 0; i < n_xs; ++i) {
             if (!xs[i] || !AL16(xs[i])) return fail(p->ctx, CFX_ERR_ALIGN, "plan: activations must be non-null and 16-byte aligned");
@@ -827,9 +846,7 @@ static int plan_build_sched(cfx_plan* p, int first_op, int n_ops) {
     sc->units = new PipeUnit[cap];
     int* comp_op = sc->comp_op; int* deq_op = sc->deq_op; int* ag_op = sc->ag_op; int* ag_unit = sc->ag_unit;
     PipeUnit* units = sc->units;
-    const char* ue = getenv("CFX_PIPE_UNIT_LAYERS");
-    int unit_layers = ue ? atoi(ue) : 7;
-    if (unit_layers < 1) unit_layers = 1;
+    const int unit_layers = p->pipe_unit_layers;
     int L = 0, n_ag = 0, N = 0, C = 0, U = 0;
     bool ok = n_ops > 0;
     for (int i = first_op; ok && i < end;) {

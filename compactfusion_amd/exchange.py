@@ -40,14 +40,22 @@ class NativeComm:
         self.rank = 0 if solo else dist.get_rank(group)
         self.world = solo_ranks if solo else dist.get_world_size(group)
         path = library or loaded_rccl_path()
-        rc = self.lib.cfx_rccl_load(path.encode() if path else None)
-        if rc != 0:
-            raise _lib.CfxError("cannot load RCCL (librccl.so) for the native exchange")
+        # Everything that can fail on ONE rank alone (loading the library, making the unique id) happens before the first collective of
+        # this bootstrap, and the ranks vote on it: a rank that failed here used to leave its peers inside broadcast_object_list /
+        # ncclCommInitRank while it was already in the caller's own all-or-none vote - mismatched collectives, a hang instead of a fall-back.
+        err = None
+        if self.lib.cfx_rccl_load(path.encode() if path else None) != 0:
+            err = "cannot load RCCL (librccl.so) for the native exchange"
         uid = ctypes.create_string_buffer(128)
-        if self.rank == 0:
-            rc = self.lib.cfx_comm_unique_id(self.ctx, uid)
-            if rc != 0:
-                raise _lib.CfxError("ncclGetUniqueId failed")
+        if err is None and self.rank == 0 and self.lib.cfx_comm_unique_id(self.ctx, uid) != 0:
+            err = "ncclGetUniqueId failed"
+        if not solo and self.world > 1:
+            votes = [None] * self.world
+            dist.all_gather_object(votes, err is None, group=group)
+            if err is None and not all(votes):
+                err = "a peer could not load RCCL / make the unique id"
+        if err is not None:
+            raise _lib.CfxError(err)
         box = [bytes(uid.raw)]
         if not solo:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)

@@ -57,7 +57,9 @@ enum cfx_status {
     CFX_ERR_BATCH = -5,      /* batch < 1 or > CFX_MAX_BATCH */
     CFX_ERR_LAUNCH = -6,     /* hipGetLastError() after a launch was not hipSuccess */
     CFX_ERR_WORKSPACE = -7,  /* workspace NULL or smaller than cfx_workspace_bytes() */
-    CFX_ERR_GATE = -8        /* an in-launch gate / lane flag wait of an EARLIER launch on this context timed out (cfx_gate_errors) */
+    CFX_ERR_GATE = -8,       /* an in-launch gate / lane flag wait of an EARLIER launch on this context timed out (cfx_gate_errors) */
+    CFX_ERR_QUEUES = -9      /* flag-ordered streams asked for, but the process did not give HIP's streams hardware queues of their own
+                              * (GPU_MAX_HW_QUEUES unset: cfx_hw_queues_ok) */
 };
 
 enum cfx_codec {
@@ -156,6 +158,31 @@ int cfx_set_fused_finalize(cfx_ctx* ctx, int on);
 /* Developer hook: when `buf` is non-NULL every statistics workgroup of a compress launch writes 8 u64 words there (phase
  * times on the 100 MHz wall clock + its last-arriver roles): tools/fused_stamps.py.  NULL switches it off. */
 int cfx_debug_stamps(cfx_ctx* ctx, void* buf);
+/* Tuning / measurement switches of a context.  The library reads NO environment variable for its behaviour (the one variable it looks
+ * at, GPU_MAX_HW_QUEUES, belongs to the HIP runtime: see cfx_prepare below); what earlier builds read from the environment is set here:
+ *   cfx_set_stats_rows    statistics tile height of the one-launch compress (multiple of 16; 0 = automatic)
+ *   cfx_set_gated_launch  0: the gated / exchange-layer ops always run as compress ; exchange ; reconstruct in stream order (1 = default:
+ *                         the one-launch forms where they qualify)
+ *   cfx_set_lr_chain      low-rank factor chain: 0 = automatic (slab-resident single launch where its workgroups fit the stream, else
+ *                         the six-launch N-space chain, else the C-space chain), 1 = never the single launch, 2 = C-space chain only
+ *   cfx_set_lr_decode     low-rank reconstruction kernel: 0 = automatic (MFMA form at rank 32), 1 = VALU form, 2 = MFMA form
+ *   cfx_set_dev_probe     developer builds only (-DCFX_DEV_PROBES): early exits of the compress kernel (tools/fused_probe.py); the product
+ *                         build accepts 0 only */
+int cfx_set_stats_rows(cfx_ctx* ctx, int rows);
+int cfx_set_gated_launch(cfx_ctx* ctx, int on);
+int cfx_set_lr_chain(cfx_ctx* ctx, int chain);
+int cfx_set_lr_decode(cfx_ctx* ctx, int mode);
+int cfx_set_dev_probe(cfx_ctx* ctx, int mode);
+/* Flag-ordered launches (the exchange-layer ops, the exchange lane) need the streams they order to sit on hardware queues of their own:
+ * a polling kernel is never scheduled out for the kernel it waits for.  HIP multiplexes streams over a pool of hardware queues; with
+ * GPU_MAX_HW_QUEUES unset a stream created after a collective library initialised can be time-sliced against the exchange stream's
+ * queue (measured: the layer launch 25 -> 50-100 us, and gate time-outs under stream churn).  cfx_hw_queues_ok() returns 1 when the
+ * process set the variable to >= 2 before HIP started (any explicit value restores one queue per stream), 0 otherwise.  With 0 the
+ * plan ops that would order two streams by flags (cfx_plan_add_exchange_layer[_p2p] in their one-launch form, cfx_plan_run_lane) are
+ * refused with CFX_ERR_QUEUES - the exchange-layer ops then run in stream order on one stream (same results) - unless
+ * cfx_set_allow_shared_queues(ctx, 1) says the caller knows better. */
+int cfx_hw_queues_ok(void);
+int cfx_set_allow_shared_queues(cfx_ctx* ctx, int on);
 
 /* Single-tensor conveniences (batch of one). */
 int cfx_compress(cfx_ctx* ctx, int codec, const void* x, const void* base, void* new_base, void* packet,
@@ -248,6 +275,8 @@ int       cfx_plan_set_exchange_stream(cfx_plan* plan, int mode);
 /* Use the caller's stream as this plan's exchange stream (mode 1 semantics; the plan does not own it).  Many plans - one
  * per layer - should share ONE exchange stream: every stream is a hardware queue to the dispatcher. */
 int       cfx_plan_use_exchange_stream(cfx_plan* plan, void* stream);
+/* layers (1..7, default 7) per unit of cfx_plan_run_pipelined; set before the first replay */
+int       cfx_plan_set_pipe_unit_layers(cfx_plan* plan, int layers);
 int       cfx_plan_add_all_gather(cfx_plan* plan, cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank);
 int       cfx_plan_add_wait(cfx_plan* plan, int gather_op);
 /* Exchange layer: compress ; all-gather ; reconstruct as ONE op - the in-order layer of the gather schedules (reference
@@ -257,9 +286,10 @@ int       cfx_plan_add_wait(cfx_plan* plan, int gather_op);
  * waits (a flag kernel) until the launch's packets are complete, issues ncclAllGather(send, recv, bytes_per_rank) and then sets the
  * launch's external gate - says the packets have arrived.  `recon` items read their packets from wherever the collective leaves them
  * (or from this op's own packet operands: with CFX_FLAG_UPDATE_CACHE the rank's own error-feedback update joins them).  comm NULL:
- * nothing moves, the exchange stream runs one relay kernel (wait + set).  1-bit codec.  When the one-launch form is not available (shape
- * without it, a run stream masked below 128 CUs, the legacy NULL stream, cfx_plan_run_async / _lane) the op runs as compress ; all-gather ;
- * reconstruct in order - same results.  The exchange stream must own a hardware queue (see "Exchange lane" below): the plan creates a
+ * nothing moves, the exchange stream runs one relay kernel (wait + set).  Any codec; the one-launch form exists for the 1-bit codec.
+ * When the one-launch form is not available (codec or shape
+ * without it, a run stream masked below 128 CUs, the legacy NULL stream beside a BLOCKING exchange stream - every CU-masked stream is
+ * one -, cfx_hw_queues_ok() == 0, cfx_plan_run_async / _lane) the op runs as compress ; all-gather ; reconstruct in order - same results.  The exchange stream must own a hardware queue (see "Exchange lane" below): the plan creates a
  * CU-masked one unless cfx_plan_use_exchange_stream supplied it (one stream should serve all plans).  A gate that never opens times
  * out like any flag wait (CFX_ERR_GATE at the next call).
  * With more than one rank the collective is a KERNEL that has to be placed while the reconstruction workgroups hold their CUs: the
@@ -272,8 +302,9 @@ int       cfx_plan_add_exchange_layer(cfx_plan* plan, int codec, int N, int C, i
 /* The exchange layer WITHOUT a collective, for the GPUs of one node: every rank's packets stay where the compress launch wrote them - in
  * a buffer from cfx_ipc_alloc that the peers have opened with cfx_ipc_open - and a peer's reconstruction workgroups read them from
  * there over xGMI (`recon` items point into the opened mappings).  What is exchanged is one 4-byte word per rank and layer: the
- * exchange stream's kernel waits for this launch's packets, sets *own_flag to the op's execution count (1, 2, ...: every rank replays
- * the same plans equally often), waits until every peer_flags[i] has reached that count and opens the launch's gate.  No collective
+ * exchange stream's kernel waits for this launch's packets, advances *own_flag by one (the op's execution count 1, 2, ... - taken from
+ * the word itself on the device, so a rebuilt plan keeps counting where the words stand; every rank executes the same ops equally
+ * often), waits until every peer_flags[i] has reached that count and opens the launch's gate.  No collective
  * kernel runs, so nothing has to find CUs beside the waiting workgroups.  own_flag and the peers' flags live in cfx_ipc_alloc memory
  * (zero-initialised), one word per op and plan; a plan must have at least two such ops per replay (a rank rewrites a layer's packets
  * only after its peers have moved past that layer).  Replaces the all-gather of ring.py:188-206 / patchpara/fwd.py:108-109 on a
@@ -290,8 +321,12 @@ int       cfx_plan_add_exchange_layer_p2p(cfx_plan* plan, int codec, int N, int 
 int       cfx_plan_add_p2p_sync(cfx_plan* plan, void* own_flag, int n_peers, const void* const* peer_flags);
 /* Device memory shared between the processes of a node (hipIpcGetMemHandle / hipIpcOpenMemHandle; on hosts with dmabuf IPC only the
  * processes need HSA_ENABLE_IPC_MODE_LEGACY=0).  cfx_ipc_alloc: zeroed device memory + its 64-byte handle (send it to the peers by any
- * means); cfx_ipc_open: map a peer's allocation; close / free when done. */
+ * means); cfx_ipc_open: map a peer's allocation; close / free when done.
+ * The memory is UNCACHED device memory (hipExtMallocWithFlags(hipDeviceMallocUncached); fine-grained, then ordinary memory as fall-backs,
+ * cfx_ipc_memory_kind says which): peers poll words in it and read packets from it while the producing kernel is still running, and the
+ * same addresses are rewritten every step - ordinary device memory is only promised coherent across devices at kernel boundaries. */
 int       cfx_ipc_alloc(cfx_ctx* ctx, size_t bytes, void** ptr, void* handle64);
+int       cfx_ipc_memory_kind(cfx_ctx* ctx);   /* what the last cfx_ipc_alloc of the context returned: 2 uncached, 1 fine-grained, 0 ordinary */
 int       cfx_ipc_open(cfx_ctx* ctx, const void* handle64, void** ptr);
 int       cfx_ipc_close(cfx_ctx* ctx, void* ptr);
 int       cfx_ipc_free(cfx_ctx* ctx, void* ptr);
@@ -364,7 +399,7 @@ int       cfx_set_gate_timeout_ms(cfx_ctx* ctx, int ms);
  * xfuser/compact/ring.py:188-260 with fastpath.py:124-228, 371-438).  If ops [first_op, first_op + n_ops) are a sequence of "groups"
  *     k x compress (BINARY, flags without UPDATE_CACHE)   { all-gather }*   k x decompress (BINARY)      of one shape,
  * (k >= 1 layers whose packets travel in one collective) consecutive groups are merged into units of up to 7 layers
- * (env CFX_PIPE_UNIT_LAYERS; at most 112 reconstruction and 16 compress items per unit) and replayed on `stream` as
+ * (cfx_plan_set_pipe_unit_layers; at most 112 reconstruction and 16 compress items per unit) and replayed on `stream` as
  *     { all-gathers of unit t-2 } ; [dequant(unit t-2) | finalize(unit t-1) | stats(unit t)]          t = 0, 1, ...
  * with every bracket ONE fused launch, so the small statistics kernels of later layers run underneath the
  * reconstruction of earlier ones.  Results are bit-identical to cfx_plan_run; packet / state buffers must be distinct

@@ -151,7 +151,8 @@ def w_ring(rank, world, schedule, codec_name, joint):
         res[f"s{step}/v"] = bits(vs[step])
     res["passed_count"] = np.array([cm.compact_cache().passed_count])
     import compactfusion_amd.compact.ring as ring_mod
-    res["p2p"] = np.array([int(any(getattr(ex, "_p2p", None) is not None for ex in ring_mod._xbuf.values()))])
+    res["p2p"] = np.array([int(any(getattr(ex, "_p2p", None) is not None or (ex.xop is not None and ex.xop.transport == "p2p")
+                                   for ex in ring_mod._xbuf.values()))])
     return res
 
 
@@ -327,4 +328,56 @@ def w_stack(rank, world, codec_name):
         lowrank.set_init_q(None)
     res["psnr"] = np.array([G.psnr(finals["exact"][t].cpu(), finals[codec_name][t].cpu()) for t in range(G.STEPS)])
     res["exact_final"] = bits(finals["exact"][-1])
+    return res
+
+
+def w_xlayer(rank, world, codec_name, mode, poison, gens):
+    """The product path of the gather schedules - ONE native op per layer (compact/xlayer.py) - over `gens` generations with
+    compact_reset in between: `mode` = "ring" (compact_fwd, gather schedule) or "gather" (compact_all_gather_kv, what patch_gather_fwd
+    calls).  poison >= 0: rank 1 corrupts a peer's reconstruction right before its validated p2p execution `poison` - every rank must
+    fall back to the next transport together and the states must come out as if nothing had happened."""
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig, PatchConfig, xlayer
+    from compactfusion_amd.compact import ring as ring_mod
+    from compactfusion_amd.compact.ring import compact_fwd
+    L, STEPS = 3, 4
+    B, S, Hh, Dh = (1, 16, 4, 32) if DEV == "cpu" else (1, 64, 8, 64)
+    if poison >= 0:
+        xlayer._TEST_POISON = (1, poison)
+    fast = codec_name in ("BINARY", "INT2")
+    kw = dict(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T[codec_name], residual=1, ef=True, fastpath=fast,
+              comp_rank=-1, sparse_ratio=8)
+    if mode == "gather":
+        kw.update(override_with_patch_gather_fwd=True, patch_gather_fwd_config=PatchConfig(True, False, 1))
+    cm.compact_init(CompactConfig(**kw))
+    res = {}
+    free = []
+    for gen in range(gens):
+        if gen:
+            cm.compact_reset()
+        qs = [drift(1000 * gen + 7 + 10 * l + rank, (B, S, Hh, Dh), STEPS) for l in range(L)]
+        ks = [drift(1000 * gen + 17 + 10 * l + rank, (B, S, Hh, Dh), STEPS) for l in range(L)]
+        vs = [drift(1000 * gen + 27 + 10 * l + rank, (B, S, Hh, Dh), STEPS) for l in range(L)]
+        for step in range(STEPS):
+            cm.compact_set_step(step)
+            for l in range(L):
+                out, lse, _ = compact_fwd(TD(qs[l][step]), TD(ks[l][step]), TD(vs[l][step]), causal=False, group=None, mod_idx=l, current_iter=step)
+                assert out.shape == (B, S, Hh, Dh)
+            if gens <= 2:
+                for l in range(L):
+                    for r in range(world):
+                        kk, vk = (f"{l}-{r}-k", f"{l}-{r}-v") if mode == "ring" else (f"{l}-k-{r}", f"{l}-v-{r}")
+                        res[f"g{gen}/s{step}/l{l}/k{r}"] = bits(cm.compact_cache().get_base(kk)).copy()
+                        res[f"g{gen}/s{step}/l{l}/v{r}"] = bits(cm.compact_cache().get_base(vk)).copy()
+        if DEV != "cpu":
+            torch.cuda.synchronize()
+            free.append(torch.cuda.mem_get_info()[0])
+    ops = [e.xop for e in ring_mod._xbuf.values() if e.xop is not None] + [e.xop for e in cm._kv_exchanges.values() if e.xop is not None]
+    res["n_ops"] = np.array([len(ops)])
+    res["p2p"] = np.array([sum(1 for o in ops if o.transport == "p2p")])
+    res["fell_back"] = np.array([sum(1 for o in ops if o.fallback_reason is not None)])
+    res["validated"] = np.array([min([o.region.validated for o in ops if o.region is not None] or [-1])])
+    res["free"] = np.array(free, dtype=np.int64)
+    dist.barrier()
+    xlayer.release()
     return res

@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+# flag-ordered streams need hardware queues of their own (include/cfx.h: cfx_hw_queues_ok); before HIP initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)

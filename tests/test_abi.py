@@ -108,7 +108,7 @@ def test_plan_building_without_gpu():
     assert lib.cfx_plan_set_exchange_stream(other, 0) == 0
     assert lib.cfx_plan_run(plan, 1, 5, None) == -5                                     # range out of bounds
     # exchange layer (compress ; all-gather ; reconstruct as one op): argument checks come before anything touches a device
-    assert lib.cfx_plan_add_exchange_layer(plan, 3, 544, 3072, 0, 1, 2, c, 14, d, None, None, None, 0, 0x9000, 1 << 20) == -4     # 1-bit codec only
+    assert lib.cfx_plan_add_exchange_layer(plan, 9, 544, 3072, 0, 1, 2, c, 14, d, None, None, None, 0, 0x9000, 1 << 20) == -4     # unknown codec
     assert lib.cfx_plan_add_exchange_layer(plan, 1, 544, 3072, 0, 1, 2, c, 0, d, None, None, None, 0, 0x9000, 1 << 20) == -5      # nothing to reconstruct
     assert lib.cfx_plan_add_exchange_layer(plan, 1, 544, 3072, 0, 1, 2, c, 17, d, None, None, None, 0, 0x9000, 1 << 20) == -5     # batch too large
     assert lib.cfx_plan_add_exchange_layer(plan, 1, 544, 3072, 0, 1, 2, c, 14, d, 0x1234, None, None, 0, 0x9000, 1 << 20) == -1   # communicator without buffers
@@ -117,6 +117,8 @@ def test_plan_building_without_gpu():
     assert lib.cfx_plan_add_exchange_layer(xl, 1, 544, 3072, 0, 1, 2, c, 14, d, None, None, None, 0, 0x9000, 1 << 20) == 0
     assert lib.cfx_plan_add_exchange_layer(xl, 1, 544, 3077, 0, 1, 2, c, 14, d, None, None, None, 0, 0x9000, 1 << 20) == -2      # bad shape
     assert lib.cfx_plan_size(xl) == 1
+    assert lib.cfx_plan_add_exchange_layer(xl, 3, 544, 3072, 0, 1, 2, c, 14, d, None, None, None, 0, 0x9000, 1 << 20) == 1       # any codec (in-order form)
+    assert lib.cfx_plan_add_exchange_layer(xl, 3, 543, 3072, 0, 1, 2, c, 14, d, None, None, None, 0, 0x9000, 1 << 20) == -2      # int4: N even
     assert lib.cfx_plan_set_input(xl, 0, 1, 0xc000) == 0 and lib.cfx_plan_set_input(xl, 0, 2, 0xc000) == -5     # activations re-pointed per call
     # ... and its collective-free form: flags are checked before anything is allocated
     pf = (ctypes.c_void_p * 2)(0xd000, 0xd040)
@@ -129,6 +131,31 @@ def test_plan_building_without_gpu():
     lib.cfx_plan_destroy(other)
     lib.cfx_plan_destroy(plan)
     lib.cfx_destroy(ctx)
+
+
+def test_context_setters_replace_the_environment_switches():
+    """every behaviour switch of the library is a setter on the context (include/cfx.h); the one environment variable it reads is HIP's"""
+    import glob
+    from compactfusion_amd import _lib
+    lib = _lib.load()
+    ctx = lib.cfx_create(0)
+    assert lib.cfx_set_stats_rows(ctx, 64) == 0 and lib.cfx_set_stats_rows(ctx, -1) == -5 and lib.cfx_set_stats_rows(ctx, 0) == 0
+    assert lib.cfx_set_gated_launch(ctx, 0) == 0 and lib.cfx_set_gated_launch(ctx, 1) == 0
+    assert lib.cfx_set_lr_chain(ctx, 1) == 0 and lib.cfx_set_lr_chain(ctx, 3) == -5 and lib.cfx_set_lr_chain(ctx, 0) == 0
+    assert lib.cfx_set_lr_decode(ctx, 2) == 0 and lib.cfx_set_lr_decode(ctx, 3) == -5 and lib.cfx_set_lr_decode(ctx, 0) == 0
+    assert lib.cfx_set_dev_probe(ctx, 0) == 0 and lib.cfx_set_dev_probe(ctx, 1) == -5          # the product build has no probes
+    assert b"dev-probes" in lib.cfx_last_error_string(ctx)
+    assert lib.cfx_set_allow_shared_queues(ctx, 1) == 0 and lib.cfx_set_allow_shared_queues(ctx, 0) == 0
+    assert lib.cfx_set_fused_finalize(ctx, 0) == 0 and lib.cfx_set_fused_finalize(ctx, 1) == 0
+    assert lib.cfx_ipc_memory_kind(ctx) == 0 and lib.cfx_ipc_memory_kind(None) == -1
+    assert lib.cfx_hw_queues_ok() in (0, 1)
+    plan = lib.cfx_plan_create(ctx)
+    assert lib.cfx_plan_set_pipe_unit_layers(plan, 3) == 0 and lib.cfx_plan_set_pipe_unit_layers(plan, 8) == -5
+    lib.cfx_plan_destroy(plan)
+    lib.cfx_destroy(ctx)
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "compactfusion_amd", "csrc")
+    n = sum(open(f).read().count("getenv(") for f in glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")))
+    assert n == 1, "libcfx reads exactly one environment variable (GPU_MAX_HW_QUEUES, the HIP runtime's)"
 
 
 def test_lowrank_sizes_without_gpu():

@@ -1,0 +1,197 @@
+"""The PRODUCT path of the gather schedules on the GPU (-m gpu): `compact_fwd` (ring gather schedule, reference xfuser/compact/ring.py:188-206
++ 265-269) and `compact_all_gather_kv` (what `patch_gather_fwd` calls; reference main.py:390-420, patchpara/fwd.py:88-102) issue ONE native
+op per layer - `cfx_plan_add_exchange_layer[_p2p]` through compact/xlayer.py - and for the 1-bit codec that op is ONE codec launch (kernel
+id 31, the gated layer launch) with no separate reconstruction launch.  Asserted through `cfx_profile_read` kernel ids, with every state
+against the oracle's replay bit for bit:
+  * 8 logical ranks looped back in one process (packets in the uncached IPC arena, every logical peer reads this rank's packets), on a
+    side stream and on the legacy default stream;
+  * two rank PROCESSES on one GPU (packets read in place through IPC mappings, first two executions validated across the ranks), two
+    generations with compact_reset in between, a poisoned reconstruction that must send every rank to the next transport, and 20 resets
+    that must leave the device memory flat."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _dist_workers as W
+from oracle import ref_np as R
+from test_gpu_schedules import ONAME, _chain, _spawn
+
+pytestmark = pytest.mark.gpu
+WL = 8
+
+
+def bits(t):
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+@pytest.fixture
+def loop8(monkeypatch):
+    """An 8-rank group whose peers are all this rank; torch.distributed is not initialised."""
+    from compactfusion_amd.compact import ring, main as cm, xlayer
+    from compactfusion_amd.collector import collector
+    from compactfusion_amd.prof import Profiler
+    monkeypatch.setenv("CFX_RING_SCHEDULE", "gather")
+    monkeypatch.delenv("CFX_RING_EXCHANGE_STREAM", raising=False)
+    monkeypatch.delenv("CFX_RING_EXCHANGE", raising=False)
+    monkeypatch.setattr(ring.dist, "get_rank", lambda g=None: 0)
+    monkeypatch.setattr(ring.dist, "get_world_size", lambda g=None: WL)
+    monkeypatch.setattr(ring.dist, "all_gather_into_tensor",            # WARMUP steps gather raw fp16 through torch.distributed
+                        lambda recv, send, group=None: recv.view(WL, -1).copy_(send.view(1, -1).expand(WL, -1)))
+    xlayer.set_p2p_loopback(True)
+    Profiler.instance().disable()
+    collector.init(collector.Collector("/tmp/none", enabled=False))
+    ring._xbuf.clear()
+    ring._steady.clear()
+    yield ring, cm, xlayer
+    cm._drop_kv_exchanges()
+    for e in ring._xbuf.values():
+        e.close()
+    ring._xbuf.clear()
+    ring._steady.clear()
+    xlayer.set_p2p_loopback(False)
+
+
+def _replay(codec, seqs, N, C, ef=True):
+    name, param = ONAME[codec]
+    st = seqs[0].numpy().reshape(N, C).copy()
+    out = [R.bits(st).copy()]
+    for x in seqs[1:]:
+        _, st = R.residual_compress(name, x.numpy().reshape(N, C), st, param, ef=ef)
+        out.append(R.bits(st).copy())
+    return out
+
+
+def _kernel_ids(lib, ctx):
+    ids = (ctypes.c_int * 8192)()
+    ms = (ctypes.c_float * 8192)()
+    n = lib.cfx_profile_read(ctx, ids, ms, 8192)
+    return [ids[i] for i in range(n)]
+
+
+@pytest.mark.parametrize("api,stream_kind", [("ring", "side"), ("ring", "default"), ("gather", "side"), ("gather", "default")])
+def test_plugin_call_issues_the_gated_layer_launch(loop8, api, stream_kind):
+    ring, cm, xlayer = loop8
+    from compactfusion_amd import _lib, codecs as K
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig, PatchConfig
+    lib, ctx = _lib.load(), K.context(0)
+    assert lib.cfx_hw_queues_ok() == 1, "tests/conftest.py sets GPU_MAX_HW_QUEUES before HIP starts"
+    L, STEPS = 3, 5
+    shape, N, C = (1, 64, 8, 64), 64, 512
+    kw = dict(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T.BINARY, comp_rank=-1, residual=1, ef=True, fastpath=True)
+    if api == "gather":
+        kw.update(override_with_patch_gather_fwd=True, patch_gather_fwd_config=PatchConfig(True, False, 1))
+    cm.compact_init(CompactConfig(**kw))
+    qs = [W.drift(7 + l, shape, STEPS) for l in range(L)]
+    ks = [W.drift(17 + l, shape, STEPS) for l in range(L)]
+    vs = [W.drift(27 + l, shape, STEPS) for l in range(L)]
+    want = {(l, n): _replay("BINARY", seq[l], N, C) for l in range(L) for n, seq in (("k", ks), ("v", vs))}
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.Stream(dev) if stream_kind == "side" else torch.cuda.default_stream(dev)
+    MASK = (1 << 31) | (1 << 4) | (1 << 16) | (1 << 27)
+    with torch.cuda.stream(stream):
+        dq, dk, dv = ([[t.to(dev) for t in seq[l]] for l in range(L)] for seq in (qs, ks, vs))
+        for s in range(STEPS):
+            cm.compact_set_step(s)
+            torch.cuda.synchronize()
+            assert lib.cfx_profile_enable(ctx, 8192, MASK, 1) == 0
+            for l in range(L):
+                ring.compact_fwd(dq[l][s], dk[l][s], dv[l][s], causal=False, mod_idx=l, current_iter=s)
+            torch.cuda.synchronize()
+            got = _kernel_ids(lib, ctx)
+            lib.cfx_profile_enable(ctx, 0, 0, 1)
+            if s > 0:
+                # ONE codec launch per layer: the gated layer launch (31); no reconstruction (4), error-feedback (16) or plain compress (27) launch
+                assert got.count(31) == L and got.count(4) == 0 and got.count(16) == 0 and got.count(27) == 0, (api, stream_kind, s, got)
+            cache = cm.compact_cache()
+            for l in range(L):
+                for n in ("k", "v"):
+                    for r in range(WL):
+                        key = f"{l}-{r}-{n}" if api == "ring" else f"{l}-{n}-{r}"
+                        assert np.array_equal(bits(cache.get_base(key)).reshape(N, C), want[(l, n)][s].reshape(N, C)), (api, s, l, n, r)
+    ops = [e.xop for e in ring._xbuf.values() if e.xop is not None] + [e.xop for e in cm._kv_exchanges.values() if e.xop is not None]
+    assert len(ops) == L and all(o.transport == "p2p" for o in ops), "the layer op / the IPC arena was not used"
+    arena = next(iter(xlayer._arenas.values()))
+    assert arena.kind == 2, "the packet arena is uncached device memory (hipExtMallocWithFlags(hipDeviceMallocUncached))"
+    assert lib.cfx_gate_errors(ctx) == 0
+
+
+@pytest.mark.parametrize("codec", ["INT2", "INT4", "INT8", "SPARSE"])
+@pytest.mark.parametrize("api", ["ring", "gather"])
+def test_plugin_call_other_codecs_one_native_op(loop8, api, codec):
+    """The other streaming codecs through the same one-op-per-layer path (they run compress ; exchange ; reconstruct in stream order inside it)."""
+    ring, cm, xlayer = loop8
+    from compactfusion_amd import _lib, codecs as K
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig, PatchConfig
+    lib, ctx = _lib.load(), K.context(0)
+    L, STEPS = 2, 4
+    shape, N, C = (1, 64, 16, 64), 64, 1024
+    fast = codec == "INT2"
+    kw = dict(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T[codec], comp_rank=-1, residual=1, ef=True, fastpath=fast, sparse_ratio=8)
+    if api == "gather":
+        kw.update(override_with_patch_gather_fwd=True, patch_gather_fwd_config=PatchConfig(True, False, 1))
+    cm.compact_init(CompactConfig(**kw))
+    qs = [W.drift(7 + l, shape, STEPS) for l in range(L)]
+    ks = [W.drift(17 + l, shape, STEPS) for l in range(L)]
+    vs = [W.drift(27 + l, shape, STEPS) for l in range(L)]
+    want = {(l, n): _replay(codec, seq[l], N, C) for l in range(L) for n, seq in (("k", ks), ("v", vs))}
+    dev = torch.device("cuda:0")
+    with torch.cuda.stream(torch.cuda.Stream(dev)):
+        for s in range(STEPS):
+            cm.compact_set_step(s)
+            for l in range(L):
+                ring.compact_fwd(qs[l][s].to(dev), ks[l][s].to(dev), vs[l][s].to(dev), causal=False, mod_idx=l, current_iter=s)
+            torch.cuda.synchronize()
+            cache = cm.compact_cache()
+            for l in range(L):
+                for n in ("k", "v"):
+                    for r in range(WL):
+                        key = f"{l}-{r}-{n}" if api == "ring" else f"{l}-{n}-{r}"
+                        assert np.array_equal(bits(cache.get_base(key)).reshape(N, C), want[(l, n)][s].reshape(N, C)), (api, codec, s, l, n, r)
+    ops = [e.xop for e in ring._xbuf.values() if e.xop is not None] + [e.xop for e in cm._kv_exchanges.values() if e.xop is not None]
+    assert len(ops) == L and all(o.transport == "p2p" for o in ops)
+    assert lib.cfx_gate_errors(ctx) == 0
+
+
+def _check_states(res, codec, mode, world, gens, L=3, STEPS=4, shape=(1, 64, 8, 64)):
+    for gen in range(gens):
+        for l in range(L):
+            want_k = [_chain(codec, W.drift(1000 * gen + 17 + 10 * l + q, shape, STEPS)) for q in range(world)]
+            want_v = [_chain(codec, W.drift(1000 * gen + 27 + 10 * l + q, shape, STEPS)) for q in range(world)]
+            for r in range(world):
+                for s in range(STEPS):
+                    for q in range(world):
+                        assert np.array_equal(res[r][f"g{gen}/s{s}/l{l}/k{q}"].reshape(-1), want_k[q][s].reshape(-1)), (mode, gen, l, r, s, q, "k")
+                        assert np.array_equal(res[r][f"g{gen}/s{s}/l{l}/v{q}"].reshape(-1), want_v[q][s].reshape(-1)), (mode, gen, l, r, s, q, "v")
+
+
+@pytest.mark.parametrize("mode,codec", [("ring", "BINARY"), ("gather", "BINARY"), ("ring", "INT4"), ("gather", "INT8")])
+def test_two_processes_two_generations_peer_to_peer(tmp_path, mode, codec):
+    """Two rank processes on one GPU, packets read in place through IPC mappings; compact_reset between two generations: the flag words
+    keep counting on the device (a host-side epoch restarted at 0 and every wait of the second generation passed at once)."""
+    res = _spawn(W.w_xlayer, 2, tmp_path, codec, mode, -1, 2)
+    for r in range(2):
+        assert int(res[r]["n_ops"][0]) == 3 and int(res[r]["p2p"][0]) == 3 and int(res[r]["fell_back"][0]) == 0, "the peer-to-peer layer op was not taken"
+        assert int(res[r]["validated"][0]) == 2, "the first two executions of every layer are validated across the ranks"
+    _check_states(res, codec, mode, 2, 2)
+
+
+@pytest.mark.parametrize("poison", [0, 1])
+def test_poisoned_reconstruction_sends_every_rank_to_the_next_transport(tmp_path, poison):
+    """A reconstruction that differs from its owner's state (what a stale cache line would produce - from the SECOND use of an address on)
+    fails the validation on every rank together: states restored, the arena marked bad, the execution repeated on the next transport
+    (here torch.distributed over gloo: RCCL refuses two ranks on one device) - and nothing of it shows in the states."""
+    res = _spawn(W.w_xlayer, 2, tmp_path, "BINARY", "ring", poison, 1)
+    for r in range(2):
+        assert int(res[r]["p2p"][0]) == 0 and int(res[r]["fell_back"][0]) >= 1, (r, res[r]["p2p"], res[r]["fell_back"])
+    _check_states(res, "BINARY", "ring", 2, 1)
+
+
+def test_twenty_resets_leave_device_memory_flat(tmp_path):
+    res = _spawn(W.w_xlayer, 2, tmp_path, "BINARY", "ring", -1, 22)
+    for r in range(2):
+        free = res[r]["free"]
+        assert int(res[r]["p2p"][0]) == 3
+        assert abs(int(free[-1]) - int(free[1])) <= (8 << 20), f"device memory moved by {int(free[1]) - int(free[-1])} B over 20 compact_reset()s"

@@ -74,7 +74,7 @@ python3 tools/fused_stamps.py 2>&1 | grep -v amdgpu.ids > "$OUT/r03_compress_tim
 python3 tools/codec_table.py 2>&1 | grep "^|" > "$OUT/r03_codec_table.md"
 python3 tools/config_table.py 2>&1 | grep "^|" > "$OUT/r03_config_table.md"
 python3 tools/lowrank_bench.py 2>&1 | grep -v amdgpu.ids > "$OUT/r03_lowrank_bench.txt"
-CFX_LR_CHAIN=cspace python3 tools/lowrank_bench.py 2>&1 | grep -v amdgpu.ids | head -6 > "$OUT/r03_lowrank_bench_cspace_chain.txt"
-CFX_LR_CHAIN=gram5 python3 tools/lowrank_bench.py 2>&1 | grep -v amdgpu.ids | head -6 > "$OUT/r03_lowrank_bench_six_launch_chain.txt"
+LR_CHAIN=2 python3 tools/lowrank_bench.py 2>&1 | grep -v amdgpu.ids | head -6 > "$OUT/r03_lowrank_bench_cspace_chain.txt"
+LR_CHAIN=1 python3 tools/lowrank_bench.py 2>&1 | grep -v amdgpu.ids | head -6 > "$OUT/r03_lowrank_bench_six_launch_chain.txt"
 python3 tools/lrs_stamps.py 2>&1 | grep -v amdgpu.ids > "$OUT/r03_lowrank_slab_timeline.txt"
 tail -c 800 "$OUT/r03_bench_n1.json"

@@ -17,7 +17,10 @@ sh = torch.cuda.current_stream().cuda_stream
 items = []
 for l in range(L):
     items.append((_lib.CompItem * B)(*[_lib.CompItem(x[l, i].data_ptr(), base[l, i].data_ptr(), None, pk[l, i].data_ptr()) for i in range(B)]))
-for fused in ([1, 0] if os.environ.get("CFX_FUSED_DBG") is None else [1]):
+dbg = int(os.environ.get("DBG", "0"))     # developer build (python -m compactfusion_amd.build --dev-probes): early exits 1..4 of the compress kernel
+if dbg:
+    assert lib.cfx_set_dev_probe(ctx, dbg) == 0, "DBG needs a --dev-probes build"
+for fused in ([1, 0] if not dbg else [1]):
     lib.cfx_set_fused_finalize(ctx, fused)
     for r in range(reps):
         l = r % L

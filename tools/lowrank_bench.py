@@ -7,6 +7,8 @@ from compactfusion_amd import _lib, codecs as K
 
 lib = _lib.load()
 ctx = K.context(0)
+if os.environ.get("LR_CHAIN"):          # 1 = never the single launch (six-launch N-space chain), 2 = C-space chain only
+    assert lib.cfx_set_lr_chain(ctx, int(os.environ["LR_CHAIN"])) == 0
 
 def t(fn, n=30):
     for _ in range(5): fn()
