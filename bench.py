@@ -114,6 +114,10 @@ def parse():
     ap.add_argument("--overlap-steps", type=int, default=12,
                     help="N = 1: after the timed legs, also run SURVEY 8d protocol 2 for this many steps (tools/overlap_bench.py in-process: compact_fwd "
                          "on the exchange lane beside real SDPA attention, 8 logical ranks looped back) and carry its exposed-exchange figure; 0 = skip")
+    ap.add_argument("--plugin-steps", type=int, default=40,
+                    help="N = 1: steps of the plugin_path leg (tools/plugin_path_bench.py as a child process: the same step through compact_all_gather_kv / "
+                         "compact_fwd with a no-op attention); 0 = skip")
+    ap.add_argument("--no-config-table", action="store_true", help="N = 1: skip the per-BASELINE-configuration table (`configs`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
     ap.add_argument("--no-secondary", action="store_true", help="skip the long run and the pipelined upper-bound leg")
@@ -134,8 +138,11 @@ def parse():
                     help="N>1, in-order replay: one direct all-gather per layer (default; xGMI is a point-to-point mesh) or the "
                          "reference's ring relay (W-1 grouped send/recv hops per layer, xfuser/compact/ring.py:193-195)")
     ap.add_argument("--allow-fallback", action="store_true",
-                    help="N>1: if the native exchange cannot be created or fails validation, fall back to torch.distributed "
-                         "instead of exiting non-zero")
+                    help="(kept for old command lines; a multi-rank run now ALWAYS falls back in-process - p2p -> ncclAllGather in stream order -> "
+                         "torch.distributed per layer - instead of exiting non-zero, and records it in `schedule_fallback`)")
+    ap.add_argument("--poison-after-step", type=int, default=-1,
+                    help="debug (N > 1, p2p): after this step rank 0 corrupts one reconstructed state - what a stale cache line would leave - to "
+                         "exercise validate-then-fall-back")
     ap.add_argument("--copy-probe", type=int, default=0,
                     help="also launch the 96 MiB float4 copy probe this many times before the timed region "
                          "(known byte count: calibrates FETCH_SIZE / WRITE_SIZE in PMC profiles)")
@@ -164,10 +171,25 @@ def cpu_baseline(seconds: float, codec: str = "binary"):
             CO.decompress(codec, pk[j % 2], peers[j], N, C, out=peers[j])
 
     one_layer()                                       # warm up (tables, threads, page faults)
-    # thread count: the box may report more hardware threads than it schedules for us; take the fastest of a short sweep
+    # "on all host cores" - the figure with every hardware thread the box reports is the baseline (`value`); the box may report
+    # more threads than it schedules for us, so the fastest of a short sweep is carried beside it (`best_of_sweep`), never instead of it
     most = int(CO.num_threads())
+
+    def timed_run(threads, budget):
+        CO.set_num_threads(threads)
+        one_layer()
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            one_layer()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget or reps >= 2000:
+                break
+        return reps, dt
+    reps, dt = timed_run(most, seconds * 0.6)
     best_t, best = most, None
-    for t in sorted({most} | {c for c in (4, 8, 16, 32, 64, 128, 256) if c <= most}):
+    for t in sorted({c for c in (4, 8, 16, 32, 64, 128, 256) if c < most}):
         CO.set_num_threads(t)
         one_layer()
         t0 = time.perf_counter()
@@ -175,20 +197,16 @@ def cpu_baseline(seconds: float, codec: str = "binary"):
         dt1 = time.perf_counter() - t0
         if best is None or dt1 < best:
             best, best_t = dt1, t
-    CO.set_num_threads(best_t)
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        one_layer()
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or reps >= 2000:
-            break
+    sweep = None
+    if best is not None and best < dt / reps:
+        r2, d2 = timed_run(best_t, seconds * 0.4)
+        sweep = {"value": round(r2 * 16 * N * C * 2 / d2 / 1e9, 4), "cores": best_t}
+    CO.set_num_threads(most)
     act_bytes = reps * 16 * N * C * 2
-    return {"value": round(act_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": best_t, "kind": "port",
+    return {"value": round(act_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": most, "kind": "port", "best_of_sweep": sweep,
             "sample": f"{reps} x one layer of the workload (2 compress + 14 decompress, {'1-bit' if codec == 'binary' else '2-bit'}, (544,3072) fp16) in {dt:.1f} s, "
-                      f"C oracle oracle/cfx_oracle.c with OpenMP ({best_t} of {most} threads: fastest of a sweep; "
-                      f"{'F16C conversions' if CO.load().oracle_uses_f16c() else 'software fp16 conversions'})"}
+                      f"C oracle oracle/cfx_oracle.c with OpenMP on all {most} hardware threads the box reports "
+                      f"({'F16C conversions' if CO.load().oracle_uses_f16c() else 'software fp16 conversions'}); best_of_sweep = the fastest thread count of a short sweep, if faster"}
 
 
 def group_recv_offset(l: int, r: int, kv: int, G: int, L: int, live: int, slot: int) -> int:
@@ -445,6 +463,7 @@ def main():
     #   pipelined: --gather-group layers share one all-gather and form one unit of the pipelined replay; --exchange-stream
     #              prio|side runs the collective of unit u on an exchange stream underneath the next fused launch
     native_comm, step_plans, exchange_mode, stream_mode, build_step_plans = None, None, "none", 0, None
+    setup_fallback = None
     p2p_ptr, p2p_peer = None, {}
     if use_dist:
         exchange_mode = "torch"
@@ -554,10 +573,12 @@ def main():
                     elif rank == 0:
                         print("[bench] IPC-shared packet buffers unavailable; the collective stays in the path (ncclAllGather on the exchange stream)", file=sys.stderr)
             except Exception as e:  # pragma: no cover
-                if not args.allow_fallback:
-                    raise SystemExit(f"[bench] native exchange unavailable ({e}); pass --allow-fallback to time torch.distributed per layer instead")
-                print(f"[bench] native exchange unavailable ({e}); FALLBACK to torch.distributed per layer (--allow-fallback)", file=sys.stderr)
-                native_comm, step_plans = None, None
+                if world == 1:
+                    raise SystemExit(f"[bench] native exchange unavailable ({e})")
+                # never end a multi-rank run while a collective fall-back exists: torch.distributed per layer (the line says so)
+                print(f"[bench] native exchange unavailable ({e}); FALLBACK to torch.distributed per layer", file=sys.stderr)
+                native_comm, step_plans, exchange_mode = None, None, "torch"
+                setup_fallback = f"the native exchange could not be set up ({e}); torch.distributed per layer instead"
 
     def check(rc, what):
         if rc != 0:
@@ -619,98 +640,130 @@ def main():
         return bool(good.item()), f"rank {rank}: a peer's reconstructed state diverged from its owner's"
 
     steps_run = 0
-    # ---- warmup (+ validation of the exchange path before anything is timed) ---------------------------------------------
+    # ---- warm-up, validation, timed region, validation - and, on ANY inconsistency, an in-process fall-back to the next schedule ----------
+    # N > 1: packets are read in place from the peers' memory (p2p) or delivered by a collective kernel that has to find CUs beside the
+    # waiting reconstruction workgroups; neither has ever run here on more than one GPU.  So the run is validated AFTER the warm-up steps
+    # and AGAIN after the timed region (a stale cache line only shows from the second use of an address on): gate time-outs, and every
+    # rank's reconstruction of a shard against its owner's state.  A failed check never ends the run: every rank (the verdict is
+    # all-reduced) resets its states, rebuilds the step as compress ; ncclAllGather ; reconstruct in stream order (libcfx's communicator;
+    # torch.distributed per layer if there is none), and warm-up + timed region run again.  `schedule_fallback` records which check tripped.
     n_warm = max(args.warmup, 1 if use_dist else 0)
-    schedule_fallback = None
-    if xgate and live > 1:
-        # More than one live rank: the collective is a KERNEL that has to be placed while the layer launch's reconstruction workgroups hold
-        # their CUs.  The library only takes the one-launch form when that group leaves workgroup slots free (csrc: needs_room), and a kernel
-        # of RCCL's register footprint is then placed every time on this hardware (tools/xlayer_room_loop.py) - but RCCL itself has never run
-        # here beside it on more than one GPU.  So the first step runs with a short gate timeout, and a gate that did not open on ANY rank
-        # sends every rank to two launches per layer (the launches that gave up ran on garbage: the states are reset either way).
-        sync_all()                                   # (the ranks enter the validated step together: its waits are short)
-        lib.cfx_set_gate_timeout_ms(ctx, 300)
-        one_step(0)
-        sync_all()
-        n_bad = lib.cfx_gate_errors(ctx)
-        if n_bad == 0 and exchange_mode == "p2p":
-            n_bad = 0 if states_consistent()[0] else 1      # packets read in place from the peers' memory: the states must agree
-        bad = torch.tensor([n_bad], device=dev, dtype=torch.int32)
+    schedule_fallback = setup_fallback
+    if exchange_mode == "torch":
+        xgate = one_launch = False
+        args.own_ef = "ride"
+        ride = True
+    KIDS, prof_cap = (), 0
+    poisoned = [False]
+
+    def maybe_poison(step_no):
+        """--poison-after-step (debug): what a stale line in a reader's cache would leave behind - a reconstruction that differs from its
+        owner's state - planted once, while the peer-to-peer schedule runs."""
+        if args.poison_after_step >= 0 and not poisoned[0] and exchange_mode == "p2p" and step_no == args.poison_after_step and rank == 0:
+            torch.cuda.synchronize(dev)
+            peer_base[0, 0, 0].view(torch.int16)[0, :8] += 1
+            poisoned[0] = True
+
+    def validate(label):
+        """None when this rank AND every other rank is fine, else what tripped (the same answer on every rank)."""
+        if not use_dist:
+            return None
+        torch.cuda.synchronize(dev)
+        ge = lib.cfx_gate_errors(ctx)                    # reads and clears the count
+        ok, why = states_consistent()
+        bad = torch.tensor([2 if ge else (0 if ok else 1)], device=dev, dtype=torch.int32)
         if world > 1:
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        lib.cfx_set_gate_timeout_ms(ctx, 5000)
-        if int(bad.item()) != 0:
-            print("[bench] exchange-layer launches failed their validation step; running compress ; all-gather ; reconstruct in stream order", file=sys.stderr)
-            schedule_fallback = ("the exchange-layer op failed its validation step (" + ("peer-to-peer packet reads: gate timeout or inconsistent states"
-                                 if exchange_mode == "p2p" else "the collective's kernel was not placed beside the waiting workgroups") +
-                                 "); two launches per layer around ncclAllGather in stream order instead")
-            if native_comm is None:
-                raise SystemExit("[bench] the peer-to-peer exchange failed its validation step and there is no collective library to fall back to")
-            if exchange_mode == "p2p":
-                exchange_mode = "native"
+        code = int(bad.item())
+        if code == 0:
+            return None
+        return label + ": " + ("a gate / flag wait timed out (the packets did not arrive in time)" if code == 2 else
+                               "a reconstructed state differs from its owner's (" + why + ")")
+
+    def fall_back(reason):
+        """Every rank together: the next schedule down.  one launch per layer (p2p or collective in the path) -> two launches per layer around
+        ncclAllGather in stream order -> torch.distributed per layer."""
+        nonlocal schedule_fallback, exchange_mode, xgate, one_launch, ride, step_plans, stream_mode
+        was = ("the peer-to-peer exchange layer (packets read in place through IPC mappings)" if exchange_mode == "p2p" else
+               "the exchange-layer launch around ncclAllGather" if xgate else
+               "two launches per layer around ncclAllGather" if step_plans is not None else "torch.distributed per layer")
+        if rank == 0:
+            print(f"[bench] {was} failed validation ({reason}); falling back in-process", file=sys.stderr)
+        for pl_ in (step_plans or []):
+            lib.cfx_plan_destroy(pl_)
+        step_plans = None
+        if (exchange_mode == "p2p" or xgate or stream_mode != 0) and native_comm is not None:
+            exchange_mode, stream_mode = "native", 0
             xgate = one_launch = False
             args.own_ef = "ride"
             ride = True
-            for pl_ in step_plans:
-                lib.cfx_plan_destroy(pl_)
             step_plans = build_step_plans(0, xlayer=False)
-        reset_state()
-        sync_all()
-    for i in range(n_warm):
-        one_step(steps_run + i)
-    steps_run += n_warm
-    sync_all()
-    if use_dist and step_plans is not None:
-        ok, why = states_consistent()
-        if not ok and stream_mode != 0:
-            if not args.allow_fallback:
-                raise SystemExit("[bench] exchange-stream overlap failed validation (" + why + "); pass --allow-fallback to retry in order")
-            print("[bench] exchange-stream overlap failed validation; FALLBACK to in-order collectives (--allow-fallback)", file=sys.stderr)
-            stream_mode = 0
-            step_plans = build_step_plans(0)
-            reset_state()
-            for i in range(n_warm):
-                one_step(i)
-            steps_run = n_warm
-            sync_all()
-            ok, why = states_consistent()
-        if not ok:
-            if not args.allow_fallback:
-                raise SystemExit("[bench] native exchange produced inconsistent state: " + why)
-            print("[bench] native exchange failed validation; FALLBACK to torch.distributed per layer (--allow-fallback)", file=sys.stderr)
-            step_plans, exchange_mode = None, "torch"
-            reset_state()
-            for i in range(n_warm):
-                one_step(i)
-            steps_run = n_warm
-            sync_all()
-
-    # ---- timed region -------------------------------------------------------------------------------------------
-    # profiled kernels: in-order replay: k_binary_dequant (4, launch B, dominant) and k_absmean_compress<bits> (27, launch A);
-    # pipelined replay: the fused k_binary_pipe (23: full three-group launches; 24: prologue / epilogue / ragged launches)
-    KIDS = (23, 24) if pipelined else ((31,) if one_launch else ((6, 28, 5) if int2 else (4, 27)))
-    prof_cap = (args.steps * 2 * L) // max(1, args.event_stride) + 64
-    if not args.no_kernel_events:
-        mask = 0
-        for k in KIDS:
-            mask |= 1 << k
-        check(lib.cfx_profile_enable(ctx, prof_cap, mask, args.event_stride), "profile_enable")
-    sync_all()
-    step_events = []          # gated schedule: hipEvents on the launch stream around every 4th step (every launch of a step is the
-    t0 = time.perf_counter()  # same kernel, so elapsed / layers = its average duration with the kernel boundaries in)
-    for i in range(args.steps):
-        if one_launch and not args.no_kernel_events and i % 4 == 1:
-            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ea.record(compute)
-            one_step(steps_run + i)
-            eb.record(compute)
-            step_events.append((ea, eb))
+            now = "compress ; ncclAllGather ; reconstruct, two launches per layer in stream order (libcfx's own RCCL communicator)"
+        elif exchange_mode != "torch" and world > 1:
+            exchange_mode = "torch"
+            xgate = one_launch = False
+            args.own_ef = "ride"
+            ride = True
+            now = "compress ; torch.distributed.all_gather_into_tensor ; reconstruct, issued per layer from Python"
         else:
-            one_step(steps_run + i)
-    sync_all()
-    t1 = time.perf_counter()
-    steps_run += args.steps
-    elapsed = t1 - t0
+            raise SystemExit(f"[bench] {was} failed validation ({reason}) and no schedule is left to fall back to")
+        schedule_fallback = ((schedule_fallback + " ; then " if schedule_fallback else "") + was + " failed validation - " + reason + " - and the run continued as: " + now)
+
+    while True:
+        reset_state()
+        steps_run = 0
+        sync_all()
+        first_short = xgate and live > 1
+        if first_short:
+            lib.cfx_set_gate_timeout_ms(ctx, 300)         # (the ranks enter the first step together: a gate that cannot open gives up quickly)
+        for i in range(n_warm):
+            one_step(i)
+            maybe_poison(i)
+            if i == 0 and first_short:
+                sync_all()
+                lib.cfx_set_gate_timeout_ms(ctx, 5000)
+        steps_run = n_warm
+        sync_all()
+        why_bad = validate("after the warm-up steps")
+        if why_bad is not None:
+            fall_back(why_bad)
+            continue
+        # profiled kernels: in-order replay: k_binary_dequant (4, launch B, dominant) and k_absmean_compress<bits> (27, launch A);
+        # pipelined replay: the fused k_binary_pipe (23: full three-group launches; 24: prologue / epilogue / ragged launches)
+        KIDS = (23, 24) if pipelined else ((31,) if one_launch else ((6, 28, 5) if int2 else (4, 27)))
+        prof_cap = (args.steps * 2 * L) // max(1, args.event_stride) + 64
+        if not args.no_kernel_events:
+            mask = 0
+            for k in KIDS:
+                mask |= 1 << k
+            check(lib.cfx_profile_enable(ctx, prof_cap, mask, args.event_stride), "profile_enable")
+        sync_all()
+        step_events = []          # gated schedule: hipEvents on the launch stream around every 4th step (every launch of a step is the
+        t0 = time.perf_counter()  # same kernel, so elapsed / layers = its average duration with the kernel boundaries in)
+        for i in range(args.steps):
+            if one_launch and not args.no_kernel_events and i % 4 == 1:
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(compute)
+                one_step(steps_run + i)
+                eb.record(compute)
+                step_events.append((ea, eb))
+            else:
+                one_step(steps_run + i)
+            maybe_poison(steps_run + i)
+        sync_all()
+        t1 = time.perf_counter()
+        steps_run += args.steps
+        elapsed = t1 - t0
+        why_bad = validate("after the timed region")
+        if why_bad is not None:
+            if not args.no_kernel_events:
+                ids_ = (ctypes.c_int * prof_cap)()
+                ms_ = (ctypes.c_float * prof_cap)()
+                lib.cfx_profile_read(ctx, ids_, ms_, prof_cap)
+                lib.cfx_profile_enable(ctx, 0, 0, 1)
+            fall_back(why_bad)
+            continue
+        break
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -894,7 +947,7 @@ def main():
                       f"a word the {live - 1} live peer(s) have mapped, wait for their words, open the gate (cfx_plan_add_exchange_layer_p2p).  " +
                       ("One live rank: no peer to read from or to wait for - the same op, launches and kernels as any N, minus the remote reads "
                        "(`collective_in_the_path`: the same launch around ncclAllGather)" if live == 1 else
-                       "The first step was validated (gate timeouts, state consistency across ranks)")) if (xgate and P2P) else
+                       "Validated after the warm-up steps and again after the timed region (gate time-outs, every rank's reconstruction of a shard against its owner's state)")) if (xgate and P2P) else
                      ("layer by layer in order (deployable), the collective in the path: per layer ONE codec launch on the run stream = compress K,V "
                       "[statistics + sign bits + in-launch finalize; packets written straight into the rank's slot of the gather buffer] + own "
                       "error-feedback update + reconstruction of the 7 peers' K,V, whose workgroups pull their state tiles into registers and "
@@ -902,7 +955,7 @@ def main():
                       " ; flag-set kernel (opens the gate).  " +
                       ("One live rank: the collective enqueues no kernel." if live == 1 else
                        "More than one live rank: the collective is a kernel that is placed beside the waiting workgroups (the reconstruction "
-                       "group leaves >= 32 workgroup slots free); the first step was validated with a 300 ms gate timeout")) if xgate else
+                       "group leaves >= 32 workgroup slots free); validated after the warm-up steps (first step: 300 ms gate timeout) and after the timed region")) if xgate else
                      "layer by layer in order (deployable): per layer A = compress K,V [statistics + sign bits + in-launch finalize"
                      + (" + previous layer's own error-feedback update riding along" if ride else "") + "], X = " + XNAME + ", B = reconstruct "
                      + ("7 peers' K,V" if ride else "own + 7 peers' K,V")),
@@ -1139,8 +1192,49 @@ def main():
                 "exposed_exchange_ms_per_step_vs_attention_over_distinct_kv": ov["exposed_exchange_ms_per_step_vs_attention_over_distinct_kv"],
                 "what": "compact_fwd (gather schedule) with PyTorch-ROCm SDPA at the FLUX shape: the layer's chain on the CU-masked exchange stream, "
                         "ordered with the compute stream by flags in device memory; exposed = step with the exchange - attention alone"}
+            out["exposed_exchange_ms_per_step"] = ov["exposed_exchange_ms_per_step"]["lane"]
         except Exception as e:  # pragma: no cover
             out["overlap_with_attention"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and world == 1 and not args.emulate_live and not args.no_secondary and args.plugin_steps > 0:
+        # protocol 1 THROUGH THE PLUGIN API (compact_all_gather_kv / compact_fwd with a no-op attention): what the product path - one native
+        # op per layer, compact/xlayer.py - takes for the same 57-layer step, host issue included.  A process of its own (it loops the 8
+        # logical ranks back by patching torch.distributed's rank / world queries)
+        try:
+            import subprocess
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                jpath = os.path.join(td, "plugin.json")
+                r_pp = subprocess.run([sys.executable, os.path.join(REPO, "tools", "plugin_path_bench.py"), "--quiet", "--steps", str(args.plugin_steps),
+                                       "--layers", str(L), "--json", jpath], capture_output=True, text=True, timeout=600, cwd=REPO)
+                if r_pp.returncode != 0:
+                    raise RuntimeError("tools/plugin_path_bench.py failed: " + r_pp.stderr[-400:])
+                pp = json.load(open(jpath))
+            out["plugin_path"] = {"ms_per_step": pp["ms_per_step"], "host_us_per_layer": pp["host_us_per_layer"], "legs": pp["legs"],
+                                  "ipc_memory": pp.get("ipc_memory_kind"),
+                                  "what": "the same step issued through the plugin API, attention replaced by a no-op: compact_all_gather_kv (what patch_gather_fwd "
+                                          "calls) and compact_fwd (gather schedule), ONE native op per layer (cfx_plan_add_exchange_layer_p2p through "
+                                          "compact/xlayer.py); `ms_per_step` / `host_us_per_layer` = compact_all_gather_kv on a side stream; 8 logical ranks looped back"}
+            out["plugin_path_ms_per_step"] = pp["ms_per_step"]
+        except Exception as e:  # pragma: no cover
+            out["plugin_path"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0 and world == 1 and not args.emulate_live and not args.no_secondary and not args.no_config_table:
+        # every BASELINE.json configuration, one rank's codec work of one denoise step replayed layer by layer in order, peers looped back
+        # (tools/config_table.py; SURVEY 8d shapes): ms per step, algorithmic bytes, fraction of the 8 TB/s HBM roofline
+        try:
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            import config_table as CT
+            torch.cuda.empty_cache()
+            cfgs = {}
+            for name, cid_, param_, (n_, c_), l_, ncomp, nrec, upd in CT.CONFIGS:
+                ms_ = CT.gpu_step(cid_, param_, n_, c_, l_, ncomp, nrec, upd, min_steps=8, budget_s=0.05)
+                ab = CT.alg_bytes(cid_, n_, c_, l_, ncomp, nrec, upd)
+                cfgs[name.split()[0] + (" " + " ".join(name.split()[-2:]) if name.startswith("5") else "")] = {
+                    "workload": name, "shard": [n_, c_], "layers": l_, "ms_per_step": round(ms_, 4), "alg_bytes": ab,
+                    "frac": round(ab / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                torch.cuda.empty_cache()
+            out["configs"] = cfgs
+        except Exception as e:  # pragma: no cover
+            out["configs"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.emulate_live and not args.no_secondary:
         # the low-rank presets of the reference (examples/configs.py:63-110) on the same shard: one K,V pair per call, distinct pairs
         # in turn (cold caches), event-timed through the Python API (compress = factors + state update; LOW_RANK_Q also quantises them)

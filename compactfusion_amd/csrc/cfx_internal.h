@@ -25,7 +25,7 @@ static const char* const kid_names[KID_MAX] = {
     "k_lr_prep | k_lrs (slab-resident chain, one launch)", "k_lr_aq", "k_lr_aty", "k_lr_chol", "k_lr_apply", "k_lr_decode",
     "k_binary_pipe", "k_binary_pipe(prologue/epilogue)", "k_residual2_delta", "k_residual2_update",
     "k_absmean_compress<bits>", "k_absmean_compress", "k_minmax_compress", "k_attn_merge",
-    "gated layer launch (k_absmean_compress<bits,gated> / k_int2_compress_gated)"};
+    "gated layer launch (k_absmean_compress<bits,gated> / k_int2_compress_gated / k_minmax_layer)"};
 
 struct ProfRec { int kid; hipEvent_t a, b; };
 #define CFX_RING_STREAMS 8       // ticket / gate rings of a context: one per stream that issues compress launches
@@ -52,6 +52,8 @@ struct cfx_ctx {
     // at which the slot's next launch opens, and one error word (a gate that never opened)
     unsigned* gate;
     unsigned gate_expect[2 * 256 * CFX_RING_STREAMS];  // two gates per slot (the 2-bit layer launch has two)
+    unsigned* colgate;              // column gates of the min/max layer launch: per ring [CFX_MAX_BATCH][TICK_MAX_CB + 2] words, a 64-byte line each
+    unsigned colgate_seq[CFX_RING_STREAMS];   // launch sequence number per ring: the value a launch's column gates are raised to
     unsigned* gate_err;             // pinned HOST word (device-visible): waits that timed out since the last cfx_gate_errors
     long long gate_timeout;         // ticks of the 100 MHz wall clock a flag wait may last
     int fused;                      // 1 (default): compress = statistics + in-launch finalize; 0: separate finalize kernel

@@ -1512,6 +1512,327 @@ __global__ __launch_bounds__(NTHR) void k_minmax_compress(BatchC batch, int N, i
     if (threadIdx.x == 0) st_wt(tick + 1 + bx, 0u);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The min/max codecs' layer in ONE launch (cfx_compress_batch_gated / the exchange-layer ops, codecs INT4 and INT8) - what the 1-bit and
+// 2-bit codecs have had: the statistics tile stays in REGISTERS, the scales are finalised inside the launch, every statistics workgroup
+// then quantises its own tile from those registers (x and the state are read ONCE: 6.5 / 7.0 B per element is what moves), and the
+// reconstruction of the peers' tensors waits in the same launch, state tiles preloaded, for the packets.
+//   S  tile (32 rows x 512 channels, 8 waves): load x, state -> d = x - state -> per-channel {min, max} partial of the tile, published
+//      write-through -> ticket of the column block; the block's last arriver reduces the P partials, writes scale / min (int4) or scale /
+//      zero point (int8) into the packet (compress_quantize.py:452-463, :552-558) and raises the block's COLUMN GATE.  The scales of a
+//      tile depend on its column block only (there is no tensor-wide statistic), so a tile waits for the P tiles of its own block, not
+//      for the launch.  Then: codes from registers (arithmetic of k_int4_quant / k_int8_quant), published as 16-byte write-through
+//      stores through an LDS transpose, one arrival on the codes gate, error-feedback state last (nobody waits for it).
+//   D  tile (112 rows x 512 channels): state rows into registers, wait for the gate (the launch's own codes gate, or the external word an
+//      exchange stream sets once the peers' packets have arrived), codes + scales through L2-bypassing loads, finish from registers.
+// S workgroups precede D in dispatch order and wait only for each other: all of them must be CO-RESIDENT (the host checks; otherwise the
+// multi-launch forms run).  Column gates hold a per-stream launch sequence number (monotonic, raised with atomic max: never reset).
+// ---------------------------------------------------------------------------------------------------
+#define MML_NW FUSED_NW
+#define MML_ROWS 32            // rows of an S tile: 4 per wave
+#define MML_KC 14              // rows of a D tile a wave holds in registers (int4: 7 row pairs)
+#define COLGATE_LINES (TICK_MAX_CB + 2)     // column gates per tensor, a 64-byte line each
+struct MinMaxLayerArgs {
+    int N, C, CB, P, n_st;            // group S: CB x P tiles of MML_ROWS rows per own tensor
+    int g_R, g_rb, n_g;               // group D: tiles of g_R rows, g_rb per tensor
+    int codec, flags;
+    u64* ws; size_t ws_stride;
+    unsigned* tick;
+    unsigned* colgate; unsigned seq;  // column gates of this stream's ring, the launch's sequence number
+    unsigned* gate2; unsigned expect2;     // codes gate: one arrival per S tile
+    unsigned* xgate; unsigned xexpect;     // external gate for group D (NULL: group D waits on gate2)
+    unsigned* err;
+    int remote;
+};
+// codes of 8 channels of one row (int8) / one row pair (int4), exactly as k_int8_quant / k_int4_quant compute them
+__device__ __forceinline__ u64 int8_codes(h16x8 d, h16x8 sc, h16x8 zp, h16x8& qh) {
+    u64 outb = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h16 v = hrint(hdiv(d[i], sc[i]) + zp[i]);
+        if (hisnan(v)) v = (h16)0;
+        v = v < (h16)-128.0f ? (h16)-128.0f : v;
+        v = v > (h16)127.0f ? (h16)127.0f : v;
+        const int qi = (int)(float)v;
+        qh[i] = (h16)(float)qi;
+        outb |= (u64)(unsigned char)(signed char)qi << (8 * i);
+    }
+    return outb;
+}
+__device__ __forceinline__ u64 int4_codes(h16x8 d0, h16x8 d1, h16x8 sc, h16x8 mn, h16x8* qh) {
+    u64 outb = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const h16x8 dm = (h ? d1 : d0) - mn;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            h16 v = hrint(hdiv(dm[i], sc[i]));
+            if (hisnan(v)) v = (h16)0;
+            v = v < (h16)0 ? (h16)0 : v;
+            v = v > (h16)15.0f ? (h16)15.0f : v;
+            const unsigned qi = (unsigned)(float)v & 15u;
+            qh[h][i] = (h16)(float)qi;
+            outb |= (u64)qi << (8 * i + 4 * h);
+        }
+    }
+    return outb;
+}
+__device__ __forceinline__ u64 ld_wt_or_sys(const u64* p, bool remote) { return remote ? ld_sys(p) : ld_wt(p); }
+__device__ __forceinline__ h16x8 ld8_pub(const u16* p, bool remote) {
+    if (!remote) return ld8_wt(p);
+    u16x8 vb;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vb[i] = ld_sys(p + i);
+    return __builtin_bit_cast(h16x8, vb);
+}
+// scale vectors of 8 channels out of a packet other workgroups (or another GPU) published; int8: zp as fp16 values
+template <bool INT4>
+__device__ __forceinline__ void minmax_ld_scales(const unsigned char* pk, int N, int C, int cc, bool remote, h16x8& sc, h16x8& mz) {
+    if (INT4) {
+        const u16* S = (const u16*)(pk + (size_t)(N / 2) * C);
+        sc = ld8_pub(S + cc, remote);
+        mz = ld8_pub(S + C + cc, remote);
+    } else {
+        const u16* S = (const u16*)(pk + (size_t)N * C);
+        sc = ld8_pub(S + cc, remote);
+        const u16x8 zb = __builtin_bit_cast(u16x8, ld8_pub(S + C + cc, remote));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mz[i] = (h16)(float)(short)zb[i];
+    }
+}
+// as minmax_write_scales, published write-through (consumers inside this launch / on another GPU)
+__device__ __forceinline__ void minmax_write_scales_wt(const cfx_comp_item& it, int N, int C, int codec, int c, h16 mn, h16 mx) {
+    const h16 rng = mx - mn;
+    if (codec == CFX_CODEC_INT4) {
+        u16* S = (u16*)((char*)it.packet + (size_t)(N / 2) * C);
+        st_wt(S + c, hbits((h16)((float)rng / 15.000001f)));
+        st_wt(S + C + c, hbits(mn));
+    } else {
+        u16* S = (u16*)((char*)it.packet + (size_t)N * C);
+        const h16 scale = (h16)((float)rng / 255.000001f);
+        const h16 r = hrint(hdiv(mn, scale));
+        h16 z = (h16)-128.0f - r;
+        short zi;
+        if (hisnan(z)) zi = 0;
+        else {
+            z = z < (h16)-128.0f ? (h16)-128.0f : z;
+            z = z > (h16)127.0f ? (h16)127.0f : z;
+            zi = (short)(float)z;
+        }
+        st_wt(S + c, hbits(scale));
+        st_wt(S + C + c, (u16)zi);
+    }
+}
+
+template <bool INT4>
+__device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, const MinMaxLayerArgs& a, int z, int bx, int by, unsigned (*sm)[TILE_C]) {
+    constexpr int NW = MML_NW;
+    constexpr int RPC = INT4 ? 2 : 1;          // rows per code row
+    constexpr int CR = 4 / RPC;                // code rows a wave holds
+    const int N = a.N, C = a.C;
+    const TileCoord t = tile_coord_at(bx, by, N, C, MML_ROWS);
+    const h16* x = (const h16*)it.x;
+    const h16* base = (const h16*)it.base;
+    const int cc = min(t.c, C - 8);
+    // ---- the tile into registers (every load unconditional: clamped row, masked use) ----
+    h16x8 xk[4], bk[4];
+    bool rv[4];
+#pragma unroll
+    for (int j = 0; j < CR; ++j)
+#pragma unroll
+        for (int h = 0; h < RPC; ++h) {
+            const int row = t.r0 + (t.w + NW * j) * RPC + h;
+            rv[j * RPC + h] = row < t.r1 && t.act;
+            const size_t off = (size_t)min(row, N - 1) * C + cc;
+            xk[j * RPC + h] = ld8nt(x + off);
+            bk[j * RPC + h] = base ? ld8nt(base + off) : (h16x8)(h16)0;
+        }
+    h16x8 mn = (h16x8)hfrom(0x7c00), mx = (h16x8)hfrom(0xfc00);
+    h16x8 d[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        d[q] = xk[q] - bk[q];
+        if (rv[q]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                mn[i] = d[q][i] < mn[i] ? d[q][i] : mn[i];
+                mx[i] = d[q][i] > mx[i] ? d[q][i] : mx[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm[t.w][i * 64 + (t.lane ^ (i << 3))] = (unsigned)hbits(mn[i]) | ((unsigned)hbits(mx[i]) << 16);
+    lds_barrier();
+    unsigned* part = (unsigned*)(a.ws + (size_t)z * a.ws_stride);
+    {
+        const int k = threadIdx.x;              // 512 threads: one channel of the tile each
+        const int sidx = (k & 7) * 64 + ((k >> 3) ^ ((k & 7) << 3));
+        const int ch = bx * TILE_C + k;
+        if (ch < C) {
+            h16 lo = hfrom((u16)(sm[0][sidx] & 0xffff)), hi = hfrom((u16)(sm[0][sidx] >> 16));
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const h16 a2 = hfrom((u16)(sm[w][sidx] & 0xffff)), b2 = hfrom((u16)(sm[w][sidx] >> 16));
+                lo = a2 < lo ? a2 : lo;
+                hi = b2 > hi ? b2 : hi;
+            }
+            st_wt(&part[(size_t)by * C + ch], (unsigned)hbits(lo) | ((unsigned)hbits(hi) << 16));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* tick = a.tick + z * TICK_WORDS;
+    unsigned* flag = &sm[0][0];
+    if (threadIdx.x == 0) flag[0] = __hip_atomic_fetch_add(tick + 1 + bx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lds_barrier();
+    const bool last = flag[0] == (unsigned)(a.P - 1);
+    unsigned* cgate = a.colgate + ((size_t)z * COLGATE_LINES + bx) * GATE_LINE;
+    if (last) {
+        // the column block's scales: one channel per thread, FUSED_CH partials in flight per batch (unconditional loads, clamped index)
+        const int ch = bx * TILE_C + threadIdx.x;
+        const int chc = min(ch, C - 1);
+        h16 lo = hfrom(0x7c00), hi = hfrom(0xfc00);
+        for (int p0 = 0; p0 < a.P; p0 += FUSED_CH) {
+            unsigned v[FUSED_CH];
+#pragma unroll
+            for (int j = 0; j < FUSED_CH; ++j) v[j] = ld_wt(&part[(size_t)min(p0 + j, a.P - 1) * C + chc]);   // a repeated partial does not change a min / max
+#pragma unroll
+            for (int j = 0; j < FUSED_CH; ++j) {
+                const h16 a0 = hfrom((u16)(v[j] & 0xffff)), b0 = hfrom((u16)(v[j] >> 16));
+                lo = a0 < lo ? a0 : lo;
+                hi = b0 > hi ? b0 : hi;
+            }
+        }
+        if (ch < C) minmax_write_scales_wt(it, N, C, a.codec, ch, lo, hi);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (threadIdx.x == 0) {
+            st_wt(tick + 1 + bx, 0u);
+            (void)__hip_atomic_fetch_max(cgate, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (threadIdx.x == 0) {
+        unsigned n = 0;
+        while ((int)(ld_wt(cgate) - a.seq) < 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++n > GATE_SPIN_LIMIT) { gate_fail(a.err); break; }
+        }
+    }
+    __syncthreads();
+    // ---- own tile: codes from registers ----
+    unsigned char* pk = (unsigned char*)it.packet;
+    h16x8 sc, mz;
+    minmax_ld_scales<INT4>(pk, N, C, cc, false, sc, mz);
+    h16* nb = (h16*)it.new_base;
+    const bool upd = (a.flags & CFX_FLAG_UPDATE_CACHE) && nb;
+    const bool ef = !(a.flags & CFX_FLAG_NO_EF);
+    h16x8 qh[4];
+    u64* stage = (u64*)&sm[0][0] + (size_t)t.w * CR * 64;        // this wave's CR code rows x 64 lanes x 8 bytes (same wave writes and reads: in order)
+#pragma unroll
+    for (int j = 0; j < CR; ++j) {
+        u64 codes;
+        if (INT4) codes = int4_codes(d[2 * j], d[2 * j + 1], sc, mz, &qh[2 * j]);
+        else codes = int8_codes(d[j], sc, mz, qh[j]);
+        stage[j * 64 + t.lane] = codes;
+    }
+    {
+        // a code row of the tile is 512 bytes = 32 lanes x 16 bytes; the wave's CR code rows: lanes [0, 32) rows 0.., lanes [32, 64) the odd ones
+        const int crows = INT4 ? N / 2 : N;
+        const size_t crow_bytes = (size_t)C;
+#pragma unroll
+        for (int jj = 0; jj < CR; jj += 2) {
+            const int j = jj + (t.lane >> 5), seg = t.lane & 31;
+            const int cr = (t.r0 / RPC) + t.w + NW * j;
+            if (j < CR && cr < crows && cr * RPC < t.r1 && bx * TILE_C + seg * 16 < C)
+                st16_wt(pk + (size_t)cr * crow_bytes + (size_t)bx * TILE_C + seg * 16, *(const u32x4*)((const unsigned char*)(stage + j * 64) + seg * 16));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (threadIdx.x == 0) gate_arrive(a.gate2, 1u, a.expect2);
+    if (upd) {
+#pragma unroll
+        for (int j = 0; j < CR; ++j)
+#pragma unroll
+            for (int h = 0; h < RPC; ++h) {
+                const int q = j * RPC + h;
+                const int row = t.r0 + (t.w + NW * j) * RPC + h;
+                if (rv[q]) {
+                    h16x8 o;
+                    if (ef) {
+                        const h16x8 recv = INT4 ? (qh[q] * sc + mz) : ((qh[q] - mz) * sc);
+                        o = base ? (bk[q] + recv) : recv;
+                    } else o = xk[q];
+                    st8nt(nb + (size_t)row * C + t.c, o);
+                }
+            }
+    }
+}
+
+template <bool INT4>
+__device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, const MinMaxLayerArgs& a, int bx, int by) {
+    constexpr int NW = MML_NW;
+    constexpr int RPC = INT4 ? 2 : 1;
+    constexpr int KC = MML_KC / RPC;           // code rows a wave holds
+    const int N = a.N, C = a.C;
+    const TileCoord t = tile_coord_at(bx, by, N, C, a.g_R);
+    const unsigned char* pk = (const unsigned char*)it.packet;
+    const h16* base = (const h16*)it.base;
+    h16* out = (h16*)it.recon;
+    const int cc = min(t.c, C - 8);
+    h16x8 bv[MML_KC];
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+        for (int h = 0; h < RPC; ++h) {
+            const int row = t.r0 + (t.w + NW * j) * RPC + h;
+            bv[j * RPC + h] = base ? ld8nt(base + (size_t)min(row, N - 1) * C + cc) : (h16x8)(h16)0;
+        }
+    if (a.xgate) gate_wait<true>(a.xgate, a.xexpect, a.err);
+    else gate_wait<false>(a.gate2, a.expect2, a.err);
+    const bool remote = a.remote != 0;
+    h16x8 sc, mz;
+    minmax_ld_scales<INT4>(pk, N, C, cc, remote, sc, mz);
+    const int crows = INT4 ? N / 2 : N;
+    u64 qb[KC];
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+        const int cr = min((t.r0 / RPC) + t.w + NW * j, crows - 1);
+        qb[j] = ld_wt_or_sys((const u64*)(pk + (size_t)cr * C + cc), remote);
+    }
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+#pragma unroll
+        for (int h = 0; h < RPC; ++h) {
+            const int row = t.r0 + (t.w + NW * j) * RPC + h;
+            if (row < t.r1 && t.act) {
+                h16x8 qh;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    qh[i] = INT4 ? (h16)(float)((qb[j] >> (8 * i + 4 * h)) & 15u) : (h16)(float)(int)(signed char)(qb[j] >> (8 * i));
+                const h16x8 recv = INT4 ? (qh * sc + mz) : ((qh - mz) * sc);
+                st8nt(out + (size_t)row * C + t.c, base ? (bv[j * RPC + h] + recv) : recv);
+            }
+        }
+}
+
+template <bool INT4>
+__global__ __launch_bounds__(FUSED_NT, 4) void k_minmax_layer(BatchC batch, BatchD gated, MinMaxLayerArgs a) {
+    __shared__ unsigned sm[MML_NW][TILE_C];
+    int b = blockIdx.x;
+    if (b < a.n_st) {
+        const int per = a.CB * a.P;
+        const int z = b / per, rem = b - z * per;
+        const int by = rem / a.CB;
+        minmax_layer_s_tile<INT4>(batch.it[z], a, z, rem - by * a.CB, by, sm);
+        return;
+    }
+    b -= a.n_st;
+    const int per = a.CB * a.g_rb;
+    const int item = b / per, rem = b - item * per;
+    const int ty = rem / a.CB;
+    minmax_layer_d_tile<INT4>(gated.it[item], a, rem - ty * a.CB, ty);
+}
+
 // int8 quantise (+EF)      compress_quantize.py:465-467 ; EF = dequantize_int8 :482 + main.py:232
 __global__ __launch_bounds__(NTHR) void k_int8_quant(BatchC batch, int N, int C, int R, int flags) {
     const cfx_comp_item it = batch.it[blockIdx.z];
@@ -1997,7 +2318,9 @@ int cfx_prepare(cfx_ctx* ctx) {
     if (cur != ctx->device && hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CFX_ERR_LAUNCH, "prepare: hipSetDevice failed");
     static_assert(2 * TICK_RING * CFX_RING_STREAMS == sizeof(((cfx_ctx*)0)->gate_expect) / sizeof(unsigned), "gate_expect has two entries per ring slot");
     const size_t tick_words = (size_t)CFX_RING_STREAMS * TICK_RING * CFX_MAX_BATCH * TICK_WORDS;
-    const size_t bytes = (tick_words + (size_t)(CFX_RING_STREAMS * TICK_RING + 1) * GATE_STRIDE) * sizeof(unsigned);
+    const size_t gate_words = (size_t)(CFX_RING_STREAMS * TICK_RING + 1) * GATE_STRIDE;
+    const size_t colgate_words = (size_t)CFX_RING_STREAMS * CFX_MAX_BATCH * COLGATE_LINES * GATE_LINE;     // column gates of the min/max layer launch, per ring
+    const size_t bytes = (tick_words + gate_words + colgate_words) * sizeof(unsigned);
     void* p = nullptr;
     int rc = CFX_OK;
     if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
@@ -2007,6 +2330,8 @@ int cfx_prepare(cfx_ctx* ctx) {
     } else {
         ctx->tick = (unsigned*)p;
         ctx->gate = ctx->tick + tick_words;
+        ctx->colgate = ctx->gate + gate_words;
+        memset(ctx->colgate_seq, 0, sizeof(ctx->colgate_seq));
         // the error word: pinned, device-visible HOST memory - a timed-out wait is reported by the next native call, no device sync
         void* e = nullptr;
         if (hipHostMalloc(&e, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); ctx->tick = nullptr; rc = fail(ctx, CFX_ERR_LAUNCH, "prepare: cannot allocate the error word"); }
@@ -2299,8 +2624,8 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
     if (xg) { const int room = xg->needs_room, rem = xg->remote; memset(xg, 0, sizeof(*xg)); xg->needs_room = room; xg->remote = rem; }
     if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "compress: null ctx/items");
     if (n_gated < 0 || n_gated > CFX_MAX_BATCH || (n_gated && !gated)) return fail(ctx, CFX_ERR_BATCH, "compress: gated batch out of range");
-    if (n_gated && codec != CFX_CODEC_BINARY && codec != CFX_CODEC_INT2)
-        return fail(ctx, CFX_ERR_CODEC, "compress: gated reconstruction items need the 1-bit or the 2-bit codec");
+    if (n_gated && codec == CFX_CODEC_TOPK)
+        return fail(ctx, CFX_ERR_CODEC, "compress: gated reconstruction items need one of the quantising codecs (1-bit, 2-bit, int4, int8)");
     if (batch < 1 || batch > CFX_MAX_BATCH) return fail(ctx, CFX_ERR_BATCH, "compress: batch out of range");
     if (!shape_ok(codec, N, C, param)) return fail(ctx, codec >= 1 && codec <= 5 ? CFX_ERR_SHAPE : CFX_ERR_CODEC, "compress: bad codec/shape");
     if (n_ride < 0 || n_ride > CFX_MAX_BATCH || (n_ride && !ride)) return fail(ctx, CFX_ERR_BATCH, "compress: ride-along batch out of range");
@@ -2512,6 +2837,57 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             else LAUNCH(ctx, KID_INT2_DEQUANT, s, k_int2_dequant, dim3(CB, (N + Rg - 1) / Rg, n_gated), dim3(NTHR), 0, s, gd, N, C, Rg, (unsigned*)nullptr, 0u);
         }
     } else {
+        // ---- the min/max codecs' layer in ONE launch (k_minmax_layer): statistics tile in registers, in-launch scales, codes from registers,
+        // gated reconstruction.  Needs every statistics workgroup CO-RESIDENT on the stream's CUs (each waits for its column block's scales
+        // holding its tile); otherwise - tall tensors - the multi-launch forms below run (identical results). ----
+        const bool int4 = codec == CFX_CODEC_INT4;
+        const int P32 = (N + MML_ROWS - 1) / MML_ROWS;
+        const int g_rb = (N + FUSED_NW * MML_KC - 1) / (FUSED_NW * MML_KC);
+        const int g_R = ((N + g_rb - 1) / g_rb + 15) / 16 * 16;
+        const long n_st = (long)CB * P32 * batch, n_g = (long)CB * g_rb * n_gated;
+        bool layer = fused && ctx->gated_on && !ctx->dev_probe && C % 16 == 0 && stream_cus >= 128 && ctx->stats_rows == 0;
+        if (layer) {
+            static int per_cu4 = 0, per_cu8 = 0;
+            int& per_cu = int4 ? per_cu4 : per_cu8;
+            if (!per_cu) {
+                const hipError_t oe = int4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_minmax_layer<true>, FUSED_NT, 0)
+                                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_minmax_layer<false>, FUSED_NT, 0);
+                if (oe != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+            }
+            const long slots = (long)per_cu * stream_cus;
+            if (n_st > slots - 8) layer = false;
+            // a collective KERNEL has to find CUs while group D waits (see the 1-bit exchange layer): 32 workgroup slots left free
+            if (layer && xg && xg->needs_room && n_g + 32 > slots) layer = false;
+        }
+        if (xg && !layer) n_gated = 0;      // compress only: the caller runs its exchange and the reconstruction behind this call
+        if (layer) {
+            MinMaxLayerArgs a;
+            memset(&a, 0, sizeof(a));
+            a.N = N; a.C = C; a.CB = CB; a.P = P32; a.n_st = (int)n_st;
+            a.g_R = g_R; a.g_rb = g_rb; a.n_g = (int)n_g;
+            a.codec = codec; a.flags = flags;
+            a.ws = ws; a.ws_stride = wstride; a.tick = tick;
+            const unsigned ring = slot / TICK_RING;
+            a.colgate = ctx->colgate + (size_t)ring * CFX_MAX_BATCH * COLGATE_LINES * GATE_LINE;
+            a.seq = ++ctx->colgate_seq[ring];
+            a.gate2 = ctx->gate + (size_t)slot * GATE_STRIDE;
+            ctx->gate_expect[2 * slot] += (unsigned)n_st;
+            a.expect2 = ctx->gate_expect[2 * slot];
+            a.err = ctx->gate_err;
+            if (xg && n_gated) {
+                a.xgate = a.gate2 + GATE_BLOCK;
+                a.xexpect = ++ctx->gate_expect[2 * slot + 1];
+                a.remote = xg->remote;
+                xg->taken = 1;
+                xg->p_gate = a.gate2 + 1 * GATE_LINE;      // the word the codes gate's last arriver writes for XCD 0: no poller on the counter's line
+                xg->p_expect = a.expect2;
+                xg->f_gate = a.xgate; xg->f_expect = a.xexpect;
+            }
+            const dim3 g((unsigned)(n_st + n_g));
+            if (int4) LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_minmax_layer<true>), g, dim3(FUSED_NT), 0, s, b, gd, a);
+            else LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_minmax_layer<false>), g, dim3(FUSED_NT), 0, s, b, gd, a);
+            return check_launch(ctx, "min/max layer launch");
+        }
         if (fused) {
             LAUNCH(ctx, KID_MINMAX_COMPRESS, s, k_minmax_compress, dim3(CB * P * batch), dim3(NTHR), 0, s, b, N, C, R, CB, P, codec, ws, wstride, tick);
         } else {
@@ -2520,6 +2896,10 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
         }
         if (codec == CFX_CODEC_INT4) LAUNCH(ctx, KID_INT4_QUANT, s, k_int4_quant, gridq, dim3(NTHR), 0, s, b, N, C, Rq, flags);
         else LAUNCH(ctx, KID_INT8_QUANT, s, k_int8_quant, gridq, dim3(NTHR), 0, s, b, N, C, Rq, flags);
+        if (n_gated) {
+            const int rcg = decompress_impl(ctx, codec, N, C, param, n_gated, gated, stream, nullptr, 0u);
+            if (rcg != CFX_OK) return rcg;
+        }
     }
     return check_launch(ctx, "compress launch");
 }
@@ -2569,7 +2949,7 @@ int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base
 // ---- entry points for cfx_plan.hip (plan replay, exchange lane) ------------------------------------------------------------
 }  // extern "C"
 bool cfx_i_shape_ok(int codec, int N, int C, int param) { return shape_ok(codec, N, C, param); }
-bool cfx_i_has_xlayer_form(int codec) { return codec == CFX_CODEC_BINARY; }
+bool cfx_i_has_xlayer_form(int codec) { return codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT4 || codec == CFX_CODEC_INT8; }
 unsigned* cfx_i_ticket_block(cfx_ctx* ctx, void* stream) {
     if (!ctx->tick && cfx_prepare(ctx) != CFX_OK) return nullptr;
     return ctx->tick + (size_t)ticket_slot(ctx, stream) * CFX_MAX_BATCH * TICK_WORDS;

@@ -34,9 +34,18 @@ CONFIGS = [
     ("5 SD3 1024^2 SP8 patch-gather LOW_RANK r=16", 101, 16, (512, 1536), 24, 2, 16, False),
 ]
 NAMES = {1: "binary", 3: "int4", 4: "int8", 5: "topk"}
+# algorithmic bytes per element (compress + error feedback, reconstruct); low-rank: x + state in, state out (6), state in / out (4)
+ALG = {1: (6.125, 4.125), 2: (6.25, 4.25), 3: (6.5, 4.5), 4: (7.0, 5.0), 5: (6 + 2.5 / 8, 4 + 2.5 / 8), 101: (6.0, 4.0)}
 
 
-def gpu_step(cid, param, N, C, L, ncomp, nrec, update):
+def alg_bytes(cid, N, C, L, ncomp, nrec, update):
+    """Algorithmic HBM bytes of one step: `ncomp` tensors compressed (+ error feedback when the compress updates the state; a compress
+    that does not - gather mode - reads x and the state and writes the packet only: 2 B/el less) and `nrec` reconstructed, per layer."""
+    c, d = ALG[cid]
+    return int(L * N * C * (ncomp * (c if update else c - 2.0) + nrec * d))
+
+
+def gpu_step(cid, param, N, C, L, ncomp, nrec, update, min_steps=20, budget_s=0.2):
     dev = torch.device("cuda", 0)
     lib = _lib.load()
     ctx = K.context(0)
@@ -107,12 +116,15 @@ def gpu_step(cid, param, N, C, L, ncomp, nrec, update):
     for i in range(3):
         step(i)
     torch.cuda.synchronize()
-    steps = max(20, int(0.2 / max(1e-6, L * 40e-6)))
+    steps = max(min_steps, int(budget_s / max(1e-6, L * 40e-6)))
     t0 = time.perf_counter()
     for i in range(steps):
         step(3 + i)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    for plan in plans:
+        lib.cfx_plan_destroy(plan)
+    return ms
 
 
 def cpu_step(cid, param, N, C, L, ncomp, nrec, update, budget=8.0):
