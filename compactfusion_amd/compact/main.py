@@ -28,6 +28,7 @@ import torch
 import torch.distributed as dist
 
 from .. import codecs
+from ..collector import collector as _collector_mod
 from ..prof import Profiler
 from .patchpara.df_cache import AllGatherCache
 from .utils import ALLOW_DEPRECATED, COMPACT_COMPRESS_TYPE, CompactCache, CompactConfig
@@ -483,6 +484,7 @@ class _KVExchange:
         self.tags = (tag_k, tag_v)
         self.xop = None              # the synchronous exchange as ONE native op per layer (xlayer.LayerOp)
         self._xop_args = None
+        self.steady = None           # (codec type, config, shape, generation, arena version, device) the bound op is valid for
 
     def bind(self, sig, cid, param, N, C, n_half, shape, ef):
         def state(key):
@@ -531,7 +533,18 @@ class _KVExchange:
     def _drop_xop(self):
         if self.xop is not None:
             self.xop.close()
-        self.xop, self._xop_args = None, None
+        self.xop, self._xop_args, self.steady = None, None, None
+
+    def step_steady(self, k, v):
+        """`step` of the synchronous exchange with nothing to re-check: one native call."""
+        global _current_cache_key
+        self.xop.run(k, v, torch.cuda.current_stream(self.device).cuda_stream)
+        inst = _collector_mod.instance
+        if inst is None or inst.enabled:
+            for key in self.kkeys + self.vkeys:
+                _cache.touch(key)
+        _current_cache_key = self.vkeys[-1]
+        return self.kviews[:], self.vviews[:]
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream if self.cuda else None
@@ -609,6 +622,12 @@ def compact_all_gather_kv(tag_k, tag_v, k: torch.Tensor, v: torch.Tensor, comp_t
     cfg = _config
     xkey = (tag_k, tag_v, id(group) if group is not None else None)
     ex = _kv_exchanges.get(xkey)
+    # steady state of the synchronous exchange: the layer is bound to ONE native op and nothing it was bound against has changed - straight to it
+    if ex is not None and not displaced:
+        st = ex.steady
+        if (st is not None and st[0] is comp_type and st[1] is cfg and k.shape == st[2] and v.shape == st[2] and _generation == st[3]
+                and _cache.version == st[4] and k.device == st[5] and not cfg.log_compress_stats and k.is_contiguous() and v.is_contiguous()):
+            return ex.step_steady(k, v)
     fusable = (comp_type != T.WARMUP and not cfg.simulate_compress and cfg.compress_residual == 1
                and not cfg.log_compress_stats and k.shape == v.shape and k.is_contiguous() and v.is_contiguous()
                and not _cache.quantize)
@@ -637,4 +656,7 @@ def compact_all_gather_kv(tag_k, tag_v, k: torch.Tensor, v: torch.Tensor, comp_t
     sig = (_generation, _cache.version, cid, param, N, C, tuple(k.shape), cfg.error_feedback)
     if ex.sig != sig:
         ex.bind(sig, cid, param, N, C, n_half, k.shape, cfg.error_feedback)
-    return ex.step(k, v, displaced)
+    out = ex.step(k, v, displaced)
+    if not displaced and ex.xop is not None and ex.pending is None and not cfg.simulate_compress and cfg.compress_residual == 1:
+        ex.steady = (comp_type, cfg, k.shape, _generation, _cache.version, k.device)
+    return out

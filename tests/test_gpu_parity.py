@@ -523,16 +523,19 @@ def test_gated_reconstruction_in_the_compress_launch(shape, B, NG, own_ef):
             assert torch.equal(peer[l][g - B].view(torch.int16), own[l * B + src[g]].view(torch.int16)), f"peer {g} of layer {l} diverged from its owner"
 
 
+@pytest.mark.parametrize("name,cid", [("int2", 2), ("int4", 3), ("int8", 4)])
 @pytest.mark.parametrize("shape,B,NP", [((544, 3072), 2, 14), ((512, 1536), 2, 14), ((256, 1152), 1, 3), ((130, 1024), 2, 5), ((64, 264), 1, 2),
-                                        ((2, 512), 1, 2), ((34, 8192), 2, 6), ((1024, 1152), 2, 4)])
-def test_gated_int2_layer_in_one_launch(shape, B, NP):
-    """cfx_compress_batch_gated, 2-bit codec: statistics + finalize, quantise + error feedback of the own tensors and the
-    reconstruction of NP looped-back peers in ONE launch (two arrival gates).  Packets and states equal the oracle's bit for bit
-    over several rounds, then a long back-to-back sequence equals the three-launch sequence; (64, 264) takes the fallback."""
+                                        ((2, 512), 1, 2), ((34, 8192), 2, 6), ((1024, 1152), 2, 4), ((4096, 1152), 1, 1)])
+def test_gated_int2_layer_in_one_launch(shape, B, NP, name, cid):
+    """cfx_compress_batch_gated, 2-bit / int4 / int8 codec: statistics + finalize, quantise + error feedback of the own tensors (from the
+    registers the statistics pass loaded) and the reconstruction of NP looped-back peers in ONE launch (two gates).  Packets and states
+    equal the oracle's bit for bit over several rounds, then a long back-to-back sequence equals the multi-launch sequence; (64, 264)
+    takes the fallback.  The co-resident shapes of the min/max codecs must issue the layer launch (kernel id 31) and nothing else."""
     from compactfusion_amd import _lib, codecs as K
     lib = _lib.load()
     N, C = shape
     ctx = K.context(0)
+    CID = cid
     L = 3
     xs, bs = [], []
     for l in range(L):
@@ -543,8 +546,8 @@ def test_gated_int2_layer_in_one_launch(shape, B, NP):
     own = [dev(b) for b in bs]
     src = [i % B for i in range(NP)]
     peer = [[dev(bs[l * B + src[g]]) for g in range(NP)] for l in range(L)]
-    pk = [torch.zeros(K.packet_halves(2, N, C), dtype=torch.float16, device="cuda") for _ in range(L * B)]
-    ws = K.workspace(2, N, C, 0, B, 0)
+    pk = [torch.zeros(K.packet_halves(CID, N, C), dtype=torch.float16, device="cuda") for _ in range(L * B)]
+    ws = K.workspace(CID, N, C, 0, B, 0)
     sh = torch.cuda.current_stream().cuda_stream
     hog_s = torch.cuda.Stream()
     hog = torch.empty(64 << 20, dtype=torch.float16, device="cuda")
@@ -556,8 +559,25 @@ def test_gated_int2_layer_in_one_launch(shape, B, NP):
                                               for g in range(NP)]))
 
     def go(l):
-        assert lib.cfx_compress_batch_gated(ctx, 2, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, comp[l], 0, None, NP, gated[l],
+        assert lib.cfx_compress_batch_gated(ctx, CID, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, comp[l], 0, None, NP, gated[l],
                                             ws.data_ptr(), ws.numel(), sh) == 0
+    if cid in (3, 4) and C % 16 == 0 and ((N + 31) // 32) * ((C + 511) // 512) * B <= 500:
+        # the layer launch itself: one kernel (id 31), no statistics / quantise / reconstruction launch beside it
+        import ctypes as _ct
+        torch.cuda.synchronize()
+        assert lib.cfx_profile_enable(ctx, 64, 0xffffffff, 1) == 0
+        keep_own, keep_peer = [o.clone() for o in own], [[p.clone() for p in pl] for pl in peer]
+        go(0)
+        torch.cuda.synchronize()
+        ids, ms = (_ct.c_int * 64)(), (_ct.c_float * 64)()
+        n_ids = lib.cfx_profile_read(ctx, ids, ms, 64)
+        lib.cfx_profile_enable(ctx, 0, 0, 1)
+        assert [ids[i] for i in range(n_ids)] == [31], [ids[i] for i in range(n_ids)]
+        for o, k_ in zip(own, keep_own):
+            o.copy_(k_)
+        for pl, kl in zip(peer, keep_peer):
+            for p_, k_ in zip(pl, kl):
+                p_.copy_(k_)
     ostate = [R.bits(b).copy() for b in bs]
     opk = [None] * (L * B)
     for t in range(3):
@@ -567,7 +587,7 @@ def test_gated_int2_layer_in_one_launch(shape, B, NP):
             go(l)
             for i in range(B):
                 k = l * B + i
-                p, nb = R.residual_compress("int2", xs[k], ostate[k].view(F16), 0)
+                p, nb = R.residual_compress(name, xs[k], ostate[k].view(F16), 0)
                 opk[k] = p; ostate[k] = R.bits(nb).copy()
     torch.cuda.synchronize()
     assert lib.cfx_gate_errors(ctx) == 0
@@ -588,7 +608,7 @@ def test_gated_int2_layer_in_one_launch(shape, B, NP):
         l = r % L
         c = (_lib.CompItem * B)(*[_lib.CompItem(xd[l * B + i].data_ptr(), ref_own[l * B + i].data_ptr(), ref_own[l * B + i].data_ptr(),
                                                 ref_pk[l * B + i].data_ptr()) for i in range(B)])
-        assert lib.cfx_compress_batch_ex(ctx, 2, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, c, 0, None, ws.data_ptr(), ws.numel(), sh) == 0
+        assert lib.cfx_compress_batch_ex(ctx, CID, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, c, 0, None, ws.data_ptr(), ws.numel(), sh) == 0
     torch.cuda.synchronize()
     for k in range(L * B):
         assert torch.equal(own[k].view(torch.int16), ref_own[k].view(torch.int16)), f"own state {k} after {reps} gated launches"
@@ -611,13 +631,13 @@ def test_gated_launch_argument_errors():
     sh = torch.cuda.current_stream().cuda_stream
     c = (_lib.CompItem * 1)(_lib.CompItem(x.data_ptr(), b.data_ptr(), None, pk.data_ptr()))
     g = (_lib.DecompItem * 1)(_lib.DecompItem(pk.data_ptr(), b.data_ptr(), b.data_ptr()))
-    assert lib.cfx_compress_batch_gated(ctx, 3, N, C, 0, 0, 1, c, 0, None, 1, g, ws.data_ptr(), ws.numel(), sh) == -4      # int4: no gated form
+    assert lib.cfx_compress_batch_gated(ctx, 5, 64, 256, 8, 0, 1, c, 0, None, 1, g, ws.data_ptr(), ws.numel(), sh) == -4      # top-k: no gated form
     assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, 0, 1, c, 0, None, 17, g, ws.data_ptr(), ws.numel(), sh) == -5     # > CFX_MAX_BATCH
     assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, 0, 1, c, 0, None, 1, None, ws.data_ptr(), ws.numel(), sh) == -5
     bad = (_lib.DecompItem * 1)(_lib.DecompItem(pk.data_ptr() + 2, b.data_ptr(), b.data_ptr()))
     assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, 0, 1, c, 0, None, 1, bad, ws.data_ptr(), ws.numel(), sh) == -3    # alignment
     plan = lib.cfx_plan_create(ctx)
-    assert lib.cfx_plan_add_compress_gated(plan, 4, N, C, 0, 0, 1, c, 0, None, 1, g, ws.data_ptr(), ws.numel()) == -4
+    assert lib.cfx_plan_add_compress_gated(plan, 5, N, C, 8, 0, 1, c, 0, None, 1, g, ws.data_ptr(), ws.numel()) == -4
     assert lib.cfx_plan_add_compress_gated(plan, 1, N, C, 0, 0, 1, c, 0, None, 1, g, ws.data_ptr(), ws.numel()) == 0
     lib.cfx_plan_destroy(plan)
     torch.cuda.synchronize()

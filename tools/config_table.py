@@ -17,6 +17,7 @@ import sys
 import ctypes
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -45,6 +46,19 @@ def alg_bytes(cid, N, C, L, ncomp, nrec, update):
     return int(L * N * C * (ncomp * (c if update else c - 2.0) + nrec * d))
 
 
+_STREAMS = []
+
+
+def _streams(ctx, lib):
+    """(run stream, exchange stream handle): the exchange-layer ops order two streams by flags - a run stream that is not the legacy NULL
+    stream and ONE CU-masked (full mask) exchange stream for every plan."""
+    if not _STREAMS:
+        hx = ctypes.c_void_p()
+        assert lib.cfx_stream_create_masked(ctx, 0, torch.cuda.get_device_properties(0).multi_processor_count, ctypes.byref(hx)) == 0
+        _STREAMS.extend([torch.cuda.Stream(), hx.value])
+    return _STREAMS
+
+
 def gpu_step(cid, param, N, C, L, ncomp, nrec, update, min_steps=20, budget_s=0.2):
     dev = torch.device("cuda", 0)
     lib = _lib.load()
@@ -55,18 +69,29 @@ def gpu_step(cid, param, N, C, L, ncomp, nrec, update, min_steps=20, budget_s=0.
     own = torch.randn(Lb, ncomp, N, C, generator=g, device=dev).half()
     peers = torch.randn(Lb, nrec, N, C, generator=g, device=dev).half()
     lowrank = cid >= 100
-    sh = torch.cuda.current_stream().cuda_stream
+    run_stream = _streams(ctx, lib)[0]
+    sh = run_stream.cuda_stream
     if not lowrank:
         slot = (K.packet_bytes(cid, N, C, param) + 255) // 256 * 256
         pk = torch.zeros(Lb, ncomp, slot, dtype=torch.uint8, device=dev)
         wsb = lib.cfx_workspace_bytes(cid, N, C, param, ncomp)
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         plans = []
+        # ONE exchange-layer op per layer (cfx_plan_add_exchange_layer, no communicator: the exchange stream relays the gate - the launch
+        # structure of the peer-to-peer exchange at any N): compress + the reconstruction of every tensor whose packet it feeds
+        one_op = nrec <= 16
         for s in range(2):
             plan = lib.cfx_plan_create(ctx)
+            assert lib.cfx_plan_use_exchange_stream(plan, _streams(ctx, lib)[1]) == 0
             for l in range(Lb):
                 c = (_lib.CompItem * ncomp)(*[_lib.CompItem(x[s][l, i].data_ptr(), own[l, i].data_ptr(), own[l, i].data_ptr() if update else None,
                                                             pk[l, i].data_ptr()) for i in range(ncomp)])
+                if one_op:
+                    d = (_lib.DecompItem * nrec)(*[_lib.DecompItem(pk[l, j % ncomp].data_ptr(), peers[l, j].data_ptr(), peers[l, j].data_ptr())
+                                                   for j in range(nrec)])
+                    rc = lib.cfx_plan_add_exchange_layer(plan, cid, N, C, param, 1 if update else 0, ncomp, c, nrec, d, None, None, None, 0, ws.data_ptr(), wsb)
+                    assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
+                    continue
                 assert lib.cfx_plan_add_compress(plan, cid, N, C, param, 1 if update else 0, ncomp, c, ws.data_ptr(), wsb) >= 0
                 for a in range(0, nrec, 16):
                     n = min(16, nrec - a)
@@ -74,7 +99,7 @@ def gpu_step(cid, param, N, C, L, ncomp, nrec, update, min_steps=20, budget_s=0.
                                                 for j in range(n)])
                     assert lib.cfx_plan_add_decompress(plan, cid, N, C, param, n, d) >= 0
             plans.append(plan)
-        ops_per_layer = 1 + (nrec + 15) // 16
+        ops_per_layer = 1 if one_op else 1 + (nrec + 15) // 16
 
         def step(i):
             first = (i * L) % Lb
@@ -113,9 +138,11 @@ def gpu_step(cid, param, N, C, L, ncomp, nrec, update, min_steps=20, budget_s=0.
             assert lib.cfx_plan_run(plans[i & 1], first * ops_per_layer, n * ops_per_layer, sh) == 0
             if n < L:
                 assert lib.cfx_plan_run(plans[i & 1], 0, (L - n) * ops_per_layer, sh) == 0
+    torch.cuda.synchronize()          # (the inputs were made on the default stream, the steps run on the run stream)
     for i in range(3):
         step(i)
     torch.cuda.synchronize()
+    assert lib.cfx_gate_errors(ctx) == 0
     steps = max(min_steps, int(budget_s / max(1e-6, L * 40e-6)))
     t0 = time.perf_counter()
     for i in range(steps):

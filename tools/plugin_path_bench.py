@@ -122,7 +122,9 @@ def timed(fn, first, steps):
 
 res = {"workload": f"FLUX.1-dev 1024^2, logical ring 8 looped back on one GPU, {args.codec} residual + error feedback, {L} layers, shard (544,3072), "
                    "attention replaced by a no-op", "steps": args.steps, "legs": {}}
-for sname, stream in (("side_stream", torch.cuda.Stream(dev)), ("default_stream", torch.cuda.default_stream(dev))):
+# (the default-stream legs first: the legacy NULL stream serialises with every BLOCKING stream of the process, and the side-stream legs create
+# one - the CU-masked exchange stream; a model that runs on the default stream never has it: its exchange stream is a non-blocking one)
+for sname, stream in (("default_stream", torch.cuda.default_stream(dev)), ("side_stream", torch.cuda.Stream(dev))):
     with torch.cuda.stream(stream):
         for name, fn in (("compact_all_gather_kv", gather), ("compact_fwd_noop_attention", fwd)):
             init()
