@@ -2708,7 +2708,8 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
     // the 1-bit layer launch needs no co-residency (its statistics workgroups never wait), but its gated workgroups spin on slots the
     // statistics group needs when the stream has few CUs: a CU-masked lane runs the multi-launch form
     if (one_launch && stream_cus < 128) one_launch = false;
-    if (xg && !(one_launch && fused && codec == CFX_CODEC_BINARY && (!upd || (!(flags & CFX_FLAG_NO_EF) && n_gated + batch <= CFX_MAX_BATCH)))) {
+    const bool absmean_codec = codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT2;     // (the min/max codecs decide in their own branch below)
+    if (xg && absmean_codec && !(one_launch && fused && codec == CFX_CODEC_BINARY && (!upd || (!(flags & CFX_FLAG_NO_EF) && n_gated + batch <= CFX_MAX_BATCH)))) {
         n_gated = 0;            // compress only: the caller runs its collective and the reconstruction behind this launch
         one_launch = false;
     }

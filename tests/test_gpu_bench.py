@@ -39,7 +39,7 @@ def test_bench_falls_back_when_the_collective_cannot_be_placed():
         d = _bench("--emulate-live", "2", "--rccl-lib", _fake(), "--no-cpu-baseline", "--no-raw-baseline", "--layers", "3")
     finally:
         os.environ.pop("CFX_FAKE_RCCL_FAT", None)
-    assert d["launches_per_layer"] == 2 and "validation step" in d["schedule_fallback"]
+    assert d["launches_per_layer"] == 2 and "failed validation" in d["schedule_fallback"] and "gate" in d["schedule_fallback"]
 
 
 def test_bench_with_a_collective_kernel_of_rccl_footprint():
@@ -112,3 +112,23 @@ def test_bench_two_rank_processes_exchange_peer_to_peer():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["exchange_issued_by"] == "p2p" and d["launches_per_layer"] == 1 and d["schedule_fallback"] is None
     assert "NO collective" in d["schedule"] and d["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("poison_step", [1, 3])
+def test_bench_poisoned_peer_state_falls_back_instead_of_dying(poison_step):
+    """N = 2 (two rank processes on one GPU, no collective library): after step 1 (warm-up) / step 3 (inside the timed region) rank 0
+    corrupts one reconstructed state - what a stale cache line in a reader's L2 would leave from the SECOND use of an address on.  The
+    validation after the warm-up steps / after the timed region trips on every rank together, the run continues in-process on the next
+    schedule (here torch.distributed per layer: RCCL refuses two ranks on a device), exits 0 and says which check tripped."""
+    env = dict(os.environ)
+    env.setdefault("GPU_MAX_HW_QUEUES", "4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29620 + poison_step), os.path.join(REPO, "bench.py"), "--gpus", "2", "--same-gpu", "--backend", "gloo",
+                        "--layers", "6", "--steps", "4", "--warmup", "2", "--long-steps", "4", "--overlap-steps", "0", "--no-cpu-baseline",
+                        "--poison-after-step", str(poison_step)],
+                       capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stderr[-2500:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    fb = d["schedule_fallback"]
+    assert d["n_gpus"] == 2 and d["exchange_issued_by"] == "torch" and d["launches_per_layer"] == 2, d
+    assert fb and "peer-to-peer" in fb and "differs from its owner" in fb and ("after the warm-up steps" if poison_step == 1 else "after the timed region") in fb, fb
