@@ -224,8 +224,7 @@ def config_key(args, n_gpus):
     """What a committed profile must have been taken with for its figures to be quoted beside this run's."""
     pipelined = args.replay == "pipelined"
     own_ef = args.own_ef
-    if own_ef == "xgate" and (args.codec != "binary" or args.no_collective or args.exchange != "native" or args.exchange_pattern == "relay"
-                              ):
+    if own_ef == "xgate" and (args.no_collective or args.exchange != "native" or args.exchange_pattern == "relay"):
         own_ef = "ride"
     return {"codec": args.codec, "replay": args.replay, "own_ef": own_ef if not pipelined else None, "layers": args.layers,
             "shard": [N_TOK, C_CH], "rows": args.rows, "n_gpus": n_gpus, "collective": not args.no_collective,
@@ -354,7 +353,7 @@ def main():
         if xlayer:
             # ONE op: compress + own EF ; all-gather ; reconstruct 14 - the reconstruction group launched with the compress group,
             # gated on the collective's arrival (cfx_plan_add_exchange_layer)
-            assert gathered and not int2
+            assert gathered
             carr = comp_items(s_, l, True)
             for kv in range(2):
                 carr[kv].new_base = own_base[l, kv].data_ptr()
@@ -416,7 +415,7 @@ def main():
         rc = lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, len(items), darr)
         assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
 
-    xgate = (args.own_ef == "xgate" and not pipelined and not int2 and use_dist and not relay and args.exchange == "native")
+    xgate = (args.own_ef == "xgate" and not pipelined and use_dist and not relay and args.exchange == "native")
     if args.own_ef == "xgate" and not xgate:
         args.own_ef = "ride"
     ride = args.own_ef in ("ride", "gated")
@@ -1040,7 +1039,7 @@ def main():
                      f"layers' K,V scales + stats/sign bits of the {ul} layers after those)")
         elif xgate:
             alg = (ALG_BYTES_PER_EL["compress"] * 2 + ALG_BYTES_PER_EL["decompress"] * 14) * EL
-            kname = ("k_absmean_compress<bits,gated> (the layer's only codec launch: compress + error feedback of own K,V at " + str(ALG_BYTES_PER_EL["compress"]) +
+            kname = (("k_int2_compress_gated" if int2 else "k_absmean_compress<bits,gated>") + " (the layer's only codec launch: compress + error feedback of own K,V at " + str(ALG_BYTES_PER_EL["compress"]) +
                      " B/el, 7 peers' K,V at " + str(ALG_BYTES_PER_EL["decompress"]) + " B/el; between reading K,V and the first reconstructed byte sit a global "
                      "reduction - the scales - and the collective's arrival)")
         elif gated:

@@ -63,6 +63,7 @@ SYMBOLS = [
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_decompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    ("cfx_int2_quantize", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_void_p]),
     ("cfx_lr_packet_bytes", ctypes.c_size_t, [ctypes.c_int] * 4),
     ("cfx_lr_workspace_bytes", ctypes.c_size_t, [ctypes.c_int] * 5),
     ("cfx_lr_compress_batch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -51,7 +51,7 @@ struct cfx_ctx {
     // gated reconstruction: one monotonic arrival counter per ticket-ring slot (64 B apart, after the ticket blocks), the value
     // at which the slot's next launch opens, and one error word (a gate that never opened)
     unsigned* gate;
-    unsigned gate_expect[2 * 256 * CFX_RING_STREAMS];  // two gates per slot (the 2-bit layer launch has two)
+    unsigned gate_expect[3 * 256 * CFX_RING_STREAMS];  // three gates per slot (the 2-bit exchange layer has three)
     unsigned* colgate;              // column gates of the min/max layer launch: per ring [CFX_MAX_BATCH][TICK_MAX_CB + 2] words, a 64-byte line each
     unsigned colgate_seq[CFX_RING_STREAMS];   // launch sequence number per ring: the value a launch's column gates are raised to
     unsigned* gate_err;             // pinned HOST word (device-visible): waits that timed out since the last cfx_gate_errors

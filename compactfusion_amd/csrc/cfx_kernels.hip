@@ -562,7 +562,7 @@ __global__ __launch_bounds__(NTHR) void k_binary_rank(BatchC bc, BatchD bd, Rank
 #endif
 #define GATE_LINE 16           // u32 words per 64-byte line
 #define GATE_BLOCK (25 * GATE_LINE)   // a gate block: the arrival counter's line, then per XCD an "open" word, a local word, a relay claim word, a line each.
-#define GATE_STRIDE (2 * GATE_BLOCK)  // two gate blocks per ticket-ring slot
+#define GATE_STRIDE (3 * GATE_BLOCK)  // three gate blocks per ticket-ring slot (the 2-bit exchange layer: scales gate, codes gate, external gate)
                                // Pollers never touch the counter's line: one line serves ~90 accesses per us, and a few hundred
                                // pollers on it queue every arrival behind them (measured: the compress tail went from 12 to 24 us)
 // arrival of `inc` units; whoever completes the count opens the gate for every XCD's pollers
@@ -1269,7 +1269,8 @@ __global__ __launch_bounds__(NTHR) void k_int2_dequant(BatchD batch, int N, int 
 // ---------------------------------------------------------------------------------------------------
 template <int NW, int KR, int KL>
 __device__ __forceinline__ void int2_dequant_gated_body(const cfx_decomp_item& it, int N, int C, int R, int tile_x, int tile_y,
-                                                       unsigned* gate, unsigned expect, unsigned* err, u32x4* lds) {
+                                                       unsigned* gate, unsigned expect, unsigned* err, u32x4* lds,
+                                                       unsigned* xgate = nullptr, unsigned xexpect = 0, bool remote = false) {
     constexpr int K = KR + KL;
     const TileCoord t = tile_coord_at(tile_x, tile_y, N, C, R);
     const int C4 = C >> 2;
@@ -1294,12 +1295,25 @@ __device__ __forceinline__ void int2_dequant_gated_body(const cfx_decomp_item& i
 #pragma unroll
         for (int j = 0; j < KR; ++j) bv[j] = (h16x8)(h16)0;
     }
-    gate_wait(gate, expect, err);
-    const h16x8 ch8 = ld8_wt(CH + cc);
-    const u16 ul = ld_wt(TOK + min(t.r0 + t.w + NW * min(t.lane, K - 1), t.r1 - 1));
+    if (xgate) gate_wait<true>(xgate, xexpect, err);
+    else gate_wait(gate, expect, err);
+    h16x8 ch8;
+    u16 ul;
     u16 cd[K];
+    if (remote) {                                            // (uniform) the packet sits in a peer GPU's memory: system-scope loads
+        u16x8 vb;
 #pragma unroll
-    for (int j = 0; j < K; ++j) cd[j] = ld_wt((const u16*)(pk + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C4) + (cc >> 3));
+        for (int i = 0; i < 8; ++i) vb[i] = ld_sys(CH + cc + i);
+        ch8 = __builtin_bit_cast(h16x8, vb);
+        ul = ld_sys(TOK + min(t.r0 + t.w + NW * min(t.lane, K - 1), t.r1 - 1));
+#pragma unroll
+        for (int j = 0; j < K; ++j) cd[j] = ld_sys((const u16*)(pk + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C4) + (cc >> 3));
+    } else {
+        ch8 = ld8_wt(CH + cc);
+        ul = ld_wt(TOK + min(t.r0 + t.w + NW * min(t.lane, K - 1), t.r1 - 1));
+#pragma unroll
+        for (int j = 0; j < K; ++j) cd[j] = ld_wt((const u16*)(pk + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C4) + (cc >> 3));
+    }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         const int rr = t.r0 + t.w + NW * j;
@@ -1325,6 +1339,8 @@ struct Int2LayerArgs {
     unsigned* gate1; unsigned expect1;
     unsigned* gate2; unsigned expect2;
     unsigned* err;
+    unsigned* xgate; unsigned xexpect;     // external gate for group D (exchange-layer op): NULL = group D waits on gate2
+    int remote;                            // group D's packets may sit in a peer GPU's memory
 };
 template <int US>
 __global__ __launch_bounds__(FUSED_NT, 4) void k_int2_compress_gated(BatchC batch, BatchD gated, Int2LayerArgs a) {
@@ -1343,7 +1359,7 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_int2_compress_gated(BatchC batc
     const int item = b / per, rem = b - item * per;
     const int ty = rem / a.CB;
     int2_dequant_gated_body<FUSED_NW, GATE_KR2, GATE_KL>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.gate2, a.expect2, a.err,
-                                                        (u32x4*)&sm[0][0]);
+                                                        (u32x4*)&sm[0][0], a.xgate, a.xexpect, a.remote != 0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2316,7 +2332,7 @@ int cfx_prepare(cfx_ctx* ctx) {
     int cur = -1;
     (void)hipGetDevice(&cur);
     if (cur != ctx->device && hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CFX_ERR_LAUNCH, "prepare: hipSetDevice failed");
-    static_assert(2 * TICK_RING * CFX_RING_STREAMS == sizeof(((cfx_ctx*)0)->gate_expect) / sizeof(unsigned), "gate_expect has two entries per ring slot");
+    static_assert(3 * TICK_RING * CFX_RING_STREAMS == sizeof(((cfx_ctx*)0)->gate_expect) / sizeof(unsigned), "gate_expect has three entries per ring slot");
     const size_t tick_words = (size_t)CFX_RING_STREAMS * TICK_RING * CFX_MAX_BATCH * TICK_WORDS;
     const size_t gate_words = (size_t)(CFX_RING_STREAMS * TICK_RING + 1) * GATE_STRIDE;
     const size_t colgate_words = (size_t)CFX_RING_STREAMS * CFX_MAX_BATCH * COLGATE_LINES * GATE_LINE;     // column gates of the min/max layer launch, per ring
@@ -2709,7 +2725,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
     // statistics group needs when the stream has few CUs: a CU-masked lane runs the multi-launch form
     if (one_launch && stream_cus < 128) one_launch = false;
     const bool absmean_codec = codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT2;     // (the min/max codecs decide in their own branch below)
-    if (xg && absmean_codec && !(one_launch && fused && codec == CFX_CODEC_BINARY && (!upd || (!(flags & CFX_FLAG_NO_EF) && n_gated + batch <= CFX_MAX_BATCH)))) {
+    if (xg && absmean_codec && !(one_launch && fused && (codec == CFX_CODEC_INT2 || !upd || (!(flags & CFX_FLAG_NO_EF) && n_gated + batch <= CFX_MAX_BATCH)))) {
         n_gated = 0;            // compress only: the caller runs its collective and the reconstruction behind this launch
         one_launch = false;
     }
@@ -2744,10 +2760,19 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             a.flags = flags; a.ws = ws; a.ws_stride = wstride; a.tick = tick;
             a.gate1 = ctx->gate + (size_t)slot * GATE_STRIDE;
             a.gate2 = a.gate1 + GATE_BLOCK;
-            ctx->gate_expect[2 * slot] += (unsigned)batch * (unsigned)(CB + 1);
-            ctx->gate_expect[2 * slot + 1] += (unsigned)a.n_st;
-            a.expect1 = ctx->gate_expect[2 * slot]; a.expect2 = ctx->gate_expect[2 * slot + 1];
+            ctx->gate_expect[3 * slot] += (unsigned)batch * (unsigned)(CB + 1);
+            ctx->gate_expect[3 * slot + 1] += (unsigned)a.n_st;
+            a.expect1 = ctx->gate_expect[3 * slot]; a.expect2 = ctx->gate_expect[3 * slot + 1];
             a.err = ctx->gate_err;
+            if (xg) {
+                a.xgate = a.gate1 + 2 * GATE_BLOCK;
+                a.xexpect = ++ctx->gate_expect[3 * slot + 2];
+                a.remote = xg->remote;
+                xg->taken = 1;
+                xg->p_gate = a.gate2 + 1 * GATE_LINE;      // the word the codes gate's last arriver writes for XCD 0
+                xg->p_expect = a.expect2;
+                xg->f_gate = a.xgate; xg->f_expect = a.xexpect;
+            }
             const dim3 g(a.n_st + a.n_g);
             LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_int2_compress_gated<4>), g, dim3(FUSED_NT), 0, s, b, gd, a);
             return check_launch(ctx, "2-bit layer launch");
@@ -2781,11 +2806,11 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                 a.g_R = ((N + a.g_rb - 1) / a.g_rb + FUSED_NW - 1) / FUSED_NW * FUSED_NW;
                 a.n_gt = a.n_g = CB * a.g_rb * n_gated_k;
                 a.gate = ctx->gate + (size_t)slot * GATE_STRIDE;
-                ctx->gate_expect[2 * slot] += (unsigned)batch * (unsigned)(CB + 1);
-                a.gate_expect = ctx->gate_expect[2 * slot];
+                ctx->gate_expect[3 * slot] += (unsigned)batch * (unsigned)(CB + 1);
+                a.gate_expect = ctx->gate_expect[3 * slot];
                 if (xg) {
                     a.xgate = a.gate + GATE_BLOCK;                    // the slot's second gate block (the 2-bit layer launch's gate 2)
-                    a.xexpect = ++ctx->gate_expect[2 * slot + 1];
+                    a.xexpect = ++ctx->gate_expect[3 * slot + 1];
                     a.remote = xg->remote;
                     xg->taken = 1;
                     xg->p_gate = a.gate; xg->p_expect = a.gate_expect;
@@ -2872,12 +2897,12 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             a.colgate = ctx->colgate + (size_t)ring * CFX_MAX_BATCH * COLGATE_LINES * GATE_LINE;
             a.seq = ++ctx->colgate_seq[ring];
             a.gate2 = ctx->gate + (size_t)slot * GATE_STRIDE;
-            ctx->gate_expect[2 * slot] += (unsigned)n_st;
-            a.expect2 = ctx->gate_expect[2 * slot];
+            ctx->gate_expect[3 * slot] += (unsigned)n_st;
+            a.expect2 = ctx->gate_expect[3 * slot];
             a.err = ctx->gate_err;
             if (xg && n_gated) {
                 a.xgate = a.gate2 + GATE_BLOCK;
-                a.xexpect = ++ctx->gate_expect[2 * slot + 1];
+                a.xexpect = ++ctx->gate_expect[3 * slot + 1];
                 a.remote = xg->remote;
                 xg->taken = 1;
                 xg->p_gate = a.gate2 + 1 * GATE_LINE;      // the word the codes gate's last arriver writes for XCD 0: no poller on the counter's line
@@ -2941,6 +2966,28 @@ int cfx_compress(cfx_ctx* ctx, int codec, const void* x, const void* base, void*
     return cfx_compress_batch(ctx, codec, N, C, param, flags, 1, &it, workspace, workspace_bytes, stream);
 }
 
+// The 2-bit quantise kernel ALONE, scales given: the packet tail already holds tok (N halves) and chan (C halves) - the Triton kernel
+// _int2_quant_fastpath (fastpath.py:486-580) as the reference launches it after its eager scale prologue.
+int cfx_int2_quantize(cfx_ctx* ctx, int N, int C, int flags, int batch, const cfx_comp_item* items, void* stream) {
+    if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "int2_quantize: null ctx/items");
+    if (batch < 1 || batch > CFX_MAX_BATCH) return fail(ctx, CFX_ERR_BATCH, "int2_quantize: batch out of range");
+    if (!shape_ok(CFX_CODEC_INT2, N, C, 0)) return fail(ctx, CFX_ERR_SHAPE, "int2_quantize: bad shape");
+    const bool upd = flags & CFX_FLAG_UPDATE_CACHE;
+    BatchC b;
+    memset(&b, 0, sizeof(b));
+    for (int i = 0; i < batch; ++i) {
+        if (!items[i].x || !items[i].packet) return fail(ctx, CFX_ERR_NULL, "int2_quantize: null x/packet");
+        if (upd && !items[i].new_base) return fail(ctx, CFX_ERR_NULL, "int2_quantize: UPDATE_CACHE needs new_base");
+        if (!AL16(items[i].x) || !AL16(items[i].base) || !AL16(items[i].new_base) || !AL16(items[i].packet))
+            return fail(ctx, CFX_ERR_ALIGN, "int2_quantize: pointers must be 16-byte aligned");
+        b.it[i] = items[i];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int Rq = auto_rows(ctx, N, C, batch, true);
+    LAUNCH(ctx, KID_INT2_QUANT, s, k_int2_quant, dim3((C + TILE_C - 1) / TILE_C, (N + Rq - 1) / Rq, batch), dim3(NTHR), 0, s, b, N, C, Rq, flags);
+    return check_launch(ctx, "int2 quantise launch");
+}
+
 int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base, void* recon, int N, int C, int param, void* stream) {
     cfx_decomp_item it = {packet, base, recon};
     return cfx_decompress_batch(ctx, codec, N, C, param, 1, &it, stream);
@@ -2950,7 +2997,7 @@ int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base
 // ---- entry points for cfx_plan.hip (plan replay, exchange lane) ------------------------------------------------------------
 }  // extern "C"
 bool cfx_i_shape_ok(int codec, int N, int C, int param) { return shape_ok(codec, N, C, param); }
-bool cfx_i_has_xlayer_form(int codec) { return codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT4 || codec == CFX_CODEC_INT8; }
+bool cfx_i_has_xlayer_form(int codec) { return codec >= CFX_CODEC_BINARY && codec <= CFX_CODEC_INT8; }
 unsigned* cfx_i_ticket_block(cfx_ctx* ctx, void* stream) {
     if (!ctx->tick && cfx_prepare(ctx) != CFX_OK) return nullptr;
     return ctx->tick + (size_t)ticket_slot(ctx, stream) * CFX_MAX_BATCH * TICK_WORDS;

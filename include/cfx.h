@@ -190,6 +190,12 @@ int cfx_compress(cfx_ctx* ctx, int codec, const void* x, const void* base, void*
 int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base, void* recon,
                    int N, int C, int param, void* stream);
 
+/* The 2-bit quantise kernel alone, SCALES GIVEN: each item's packet tail already holds tok (N fp16, after the N*C/4 code bytes) and chan
+ * (C fp16); codes (+ error-feedback state with CFX_FLAG_UPDATE_CACHE) are written.  Replaces the Triton kernel _int2_quant_fastpath
+ * (xfuser/compact/fastpath.py:486-580) as the reference launches it behind its eager scale prologue (:614-625) - what a parity test
+ * needs to compare codes bit for bit given the reference's own scale vectors. */
+int cfx_int2_quantize(cfx_ctx* ctx, int N, int C, int flags, int batch, const cfx_comp_item* items, void* stream);
+
 /* Low-rank residual codecs (compactfusion_amd/csrc/cfx_lowrank.hip).
  *   cfx_lr_compress_batch   replaces subspace_iter (xfuser/compact/compress_lowrank.py:14-61) + the LOW_RANK / LOW_RANK_Q
  *                           encode of slowpath.py:54-75 + the residual / error-feedback flow of main.py:227-233

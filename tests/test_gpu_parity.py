@@ -196,6 +196,31 @@ def test_golden_int2_through_abi(N, C, seed):
     G.check(fn, f"{tag}/new_base", host_bits(rec).reshape(N, C), "== reference new_base")
 
 
+@pytest.mark.parametrize("N,C,seed", GOLD_FAST)
+def test_golden_int2_codes_exact_given_the_reference_scales(N, C, seed):
+    """k_int2_quant ALONE with the reference's own tok / chan vectors planted in the packet (cfx_int2_quantize = the Triton kernel
+    _int2_quant_fastpath behind the reference's eager prologue, fastpath.py:486-580): codes == G2 `packed` and the error-feedback state
+    == G2 `new_base`, bit for bit - the 2-bit codes only ever differ from the reference through <= 1-ulp flips of the scale vectors
+    (reference test tests/compact/compress_fastpath_test.py:105-162)."""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    fn = "g2_int2_fastpath_eager.npz"
+    tag = f"{N}x{C}_s{seed}"
+    x, base = G.inputs(fn, tag, seed, N, C)
+    gp, gu, gv = G.get(fn, f"{tag}/packed"), G.get(fn, f"{tag}/u"), G.get(fn, f"{tag}/v")
+    pkt_host = R.fastpath_packet(np.zeros_like(gp), gu, gv)                    # [codes = 0 | tok | chan]
+    pkt = dev(pkt_host.view(F16))
+    xd, bd = dev(x.view(F16)), dev(base.view(F16))
+    nb = torch.empty_like(bd)
+    it = (_lib.CompItem * 1)(_lib.CompItem(xd.data_ptr(), bd.data_ptr(), nb.data_ptr(), pkt.data_ptr()))
+    assert lib.cfx_int2_quantize(K.context(0), N, C, _lib.FLAG_UPDATE_CACHE, 1, it, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    packed, u, v = R.fastpath_unpacket(host_bits(pkt), N, C, 4)
+    assert np.array_equal(R.bits(u).reshape(-1), np.asarray(gu).view(np.uint16).reshape(-1)) and np.array_equal(R.bits(v).reshape(-1), np.asarray(gv).view(np.uint16).reshape(-1))
+    G.check(fn, f"{tag}/packed", packed, "k_int2_quant codes | the reference's scales")
+    G.check(fn, f"{tag}/new_base", host_bits(nb).reshape(N, C), "k_int2_quant error-feedback state | the reference's scales")
+
+
 @pytest.mark.parametrize("N,C,seed", [(64, 256, 42), (256, 1152, 43)])
 def test_golden_int8_int4_through_abi(N, C, seed):
     """G4/G5: the affine codecs have no order-dependent reduction: q, scale, zp/min all bit-exact vs the reference."""

@@ -406,6 +406,8 @@ def _p2p_worker(r, W, tmp, L, N, C, steps, masked):
     for q in peer:
         np.save(os.path.join(tmp, f"peer{r}_{q}.npy"), peer[q].cpu().numpy().view(np.uint16))
     np.save(os.path.join(tmp, f"x0_{r}.npy"), x0[r].cpu().numpy().view(np.uint16))
+    for s_ in range(2):
+        np.save(os.path.join(tmp, f"xs{s_}_{r}.npy"), xs[s_][r].cpu().numpy().view(np.uint16))
     # everybody done reading everybody's packets before anything is unmapped
     open(os.path.join(tmp, f"done{r}"), "w").close()
     t0 = time.time()
@@ -474,6 +476,8 @@ def _p2p_chain_worker(r, W, tmp, L, N, C, steps, codec):
     np.save(os.path.join(tmp, f"own{r}.npy"), own.cpu().numpy().view(np.uint16))
     np.save(os.path.join(tmp, f"peer{r}_{q}.npy"), peer.cpu().numpy().view(np.uint16))
     np.save(os.path.join(tmp, f"x0_{r}.npy"), x0[r].cpu().numpy().view(np.uint16))
+    for s_ in range(2):
+        np.save(os.path.join(tmp, f"xs{s_}_{r}.npy"), xs[s_][r].cpu().numpy().view(np.uint16))
     open(os.path.join(tmp, f"done{r}"), "w").close()
     t0 = time.time()
     while not os.path.exists(os.path.join(tmp, f"done{q}")):
@@ -484,6 +488,25 @@ def _p2p_chain_worker(r, W, tmp, L, N, C, steps, codec):
     lib.cfx_ipc_close(ctx, pp)
     lib.cfx_ipc_free(ctx, ptr)
     assert ge == 0, f"rank {r}: {ge} gate errors"
+
+
+def _oracle_replay(tmp_path, r, codec, N, C, steps):
+    """The C oracle's replay of rank r's error-feedback states: x_0, then `steps` residual-compress steps alternating its two input sets
+    (what every tensor of the worker went through) -> uint16 bit patterns shaped like the worker's `own`."""
+    import numpy as np
+    from oracle import c_oracle as CO
+    name = {1: "binary", 3: "int4", 4: "int8", 5: "topk"}[codec]
+    param = 8 if codec == 5 else 0
+    state = np.load(tmp_path / f"x0_{r}.npy").copy()
+    xs = [np.load(tmp_path / f"xs{s}_{r}.npy") for s in range(2)]
+    L = state.shape[0]
+    for l in range(L):
+        for b in range(2):
+            st = np.ascontiguousarray(state[l, b])
+            for i in range(steps):
+                CO.compress(name, np.ascontiguousarray(xs[i & 1][l, b]).view(np.float16), st, N, C, param, new_base=st)
+            state[l, b] = st
+    return state
 
 
 @pytest.mark.parametrize("codec,N,C", [(1, 544, 3072), (3, 96, 1024), (4, 128, 1152), (5, 64, 512)])
@@ -498,6 +521,7 @@ def test_p2p_sync_chain_two_processes_one_gpu(tmp_path, codec, N, C):
         own = np.load(tmp_path / f"own{r}.npy")
         assert not np.array_equal(own, np.load(tmp_path / f"x0_{r}.npy"))
         assert np.array_equal(np.load(tmp_path / f"peer{1 - r}_{r}.npy"), own), f"rank {1 - r}: reconstruction of rank {r}'s shard differs"
+        assert np.array_equal(own, _oracle_replay(tmp_path, r, codec, N, C, 4)), f"rank {r}: error-feedback states differ from the oracle's replay"
 
 
 @pytest.mark.parametrize("N,C,masked", [(544, 3072, True), (96, 1024, True), (128, 1088, False)])
@@ -515,3 +539,4 @@ def test_p2p_exchange_two_processes_one_gpu(tmp_path, N, C, masked):
         assert not np.array_equal(own, np.load(tmp_path / f"x0_{r}.npy"))
         got = np.load(tmp_path / f"peer{1 - r}_{r}.npy")
         assert np.array_equal(got, own), f"rank {1 - r}: reconstruction of rank {r}'s shard differs from rank {r}'s own state"
+        assert np.array_equal(own, _oracle_replay(tmp_path, r, 1, N, C, steps)), f"rank {r}: error-feedback states differ from the oracle's replay"

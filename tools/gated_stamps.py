@@ -34,6 +34,15 @@ for rep in range(4):
     torch.cuda.synchronize()
     lib.cfx_debug_stamps(ctx, None)
 a = st.cpu().numpy().reshape(nwg, 16)
+# per own tensor (K = item 0, V = item 1): compress workgroup b belongs to tensor b // (CB * P)
+CBP = ((C + 511) // 512) * ((N + 31) // 32)
+t00 = a[a[:, 0] > 0][:, 0].min()
+for z, nm in ((0, "K"), (1, "V")):
+    blk = a[z * CBP:(z + 1) * CBP]
+    uj = blk[(blk[:, 7] & 2) != 0]
+    vj = blk[(blk[:, 7] & 1) != 0]
+    print(f"tensor {nm}: tiles done p50 {(np.median(blk[:, 1]) - t00) / 100:.2f} max {(blk[:, 1].max() - t00) / 100:.2f}; V jobs end max {(vj[:, 6].max() - t00) / 100:.2f}; "
+          f"U job end {(uj[:, 6].max() - t00) / 100:.2f} us (tail loads back {(uj[:, 4].max() - t00) / 100:.2f})")
 a = a[a[:, 0] > 0]
 t0 = a[:, 0].min()
 A = a[a[:, 7] != 4]; G = a[a[:, 7] == 4]
