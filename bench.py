@@ -224,7 +224,7 @@ def config_key(args, n_gpus):
     """What a committed profile must have been taken with for its figures to be quoted beside this run's."""
     pipelined = args.replay == "pipelined"
     own_ef = args.own_ef
-    if own_ef == "xgate" and (args.no_collective or args.exchange != "native" or args.exchange_pattern == "relay"):
+    if own_ef == "xgate" and (args.codec != "binary" or args.no_collective or args.exchange != "native" or args.exchange_pattern == "relay"):
         own_ef = "ride"
     return {"codec": args.codec, "replay": args.replay, "own_ef": own_ef if not pipelined else None, "layers": args.layers,
             "shard": [N_TOK, C_CH], "rows": args.rows, "n_gpus": n_gpus, "collective": not args.no_collective,
@@ -415,7 +415,7 @@ def main():
         rc = lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, len(items), darr)
         assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
 
-    xgate = (args.own_ef == "xgate" and not pipelined and use_dist and not relay and args.exchange == "native")
+    xgate = (args.own_ef == "xgate" and not pipelined and not int2 and use_dist and not relay and args.exchange == "native")
     if args.own_ef == "xgate" and not xgate:
         args.own_ef = "ride"
     ride = args.own_ef in ("ride", "gated")

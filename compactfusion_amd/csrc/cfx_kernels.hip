@@ -2997,7 +2997,10 @@ int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base
 // ---- entry points for cfx_plan.hip (plan replay, exchange lane) ------------------------------------------------------------
 }  // extern "C"
 bool cfx_i_shape_ok(int codec, int N, int C, int param) { return shape_ok(codec, N, C, param); }
-bool cfx_i_has_xlayer_form(int codec) { return codec >= CFX_CODEC_BINARY && codec <= CFX_CODEC_INT8; }
+// (the 2-bit layer launch CAN wait on an external gate too - k_int2_compress_gated's group D takes one - but measured 2.44 ms per FLUX step
+// against 2.03 for its three launches in stream order: 18.7 us instead of 11 between the gate and the end of the launch; until that is
+// understood the 2-bit exchange layer runs in stream order)
+bool cfx_i_has_xlayer_form(int codec) { return codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT4 || codec == CFX_CODEC_INT8; }
 unsigned* cfx_i_ticket_block(cfx_ctx* ctx, void* stream) {
     if (!ctx->tick && cfx_prepare(ctx) != CFX_OK) return nullptr;
     return ctx->tick + (size_t)ticket_slot(ctx, stream) * CFX_MAX_BATCH * TICK_WORDS;

@@ -97,9 +97,16 @@ __global__ void k_flag_exchange(const unsigned* p_gate, unsigned p_expect, unsig
             }
         }
         epoch = __hip_atomic_load(own_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
-        // the packets were stored write-through and their stores had completed before the last arrival was counted: publishing after
-        // having SEEN the count orders them before the word for anybody who reads the word first
-        __hip_atomic_store(own_pub, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p_gate) {
+            // one-launch form: the packets were stored WRITE-THROUGH and their stores had completed before the last arrival was counted:
+            // publishing after having SEEN the count orders them before the word for anybody who reads the word first - no release fence
+            // (a system-scope release writes back this XCD's whole L2, and the launch's state updates are streaming through it right
+            // now: measured +7 us per layer on the 2-bit exchange layer, whose workgroups store their state right after the arrival)
+            __hip_atomic_store(own_pub, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            // in-order forms: the packets were written by the kernels in front of this one in the stream, with plain stores
+            __hip_atomic_store(own_pub, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     epoch = (unsigned)__builtin_amdgcn_readfirstlane((int)epoch);
     if (lane < n_peers) {
