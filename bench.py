@@ -81,6 +81,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--layers", type=int, default=L_LAYERS, help="debug only; the judged workload uses 57")
     ap.add_argument("--rows", type=int, default=0, help="rows per tile override (0 = auto)")
+    ap.add_argument("--stats-rows", type=int, default=0, help="debug: statistics tile height of the compress launches (cfx_set_stats_rows; 0 = auto)")
     ap.add_argument("--replay", choices=["inorder", "pipelined"], default="inorder",
                     help="inorder (default, the deployable schedule): cfx_plan_run, two launches per layer one after the other; "
                          "pipelined: cfx_plan_run_pipelined, reorders work ACROSS layers (resident synthetic inputs only)")
@@ -280,6 +281,8 @@ def main():
     ctx = K.context(local_rank)
     if args.rows:
         K.set_rows_per_tile(args.rows, local_rank)
+    if args.stats_rows:
+        assert lib.cfx_set_stats_rows(ctx, args.stats_rows) == 0
 
     L, N, C = args.layers, N_TOK, C_CH
     CODEC = int(K.Codec.INT2 if int2 else K.Codec.BINARY)

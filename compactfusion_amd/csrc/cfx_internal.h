@@ -52,8 +52,8 @@ struct cfx_ctx {
     // at which the slot's next launch opens, and one error word (a gate that never opened)
     unsigned* gate;
     unsigned gate_expect[3 * 256 * CFX_RING_STREAMS];  // three gates per slot (the 2-bit exchange layer has three)
-    unsigned* colgate;              // column gates of the min/max layer launch: per ring [CFX_MAX_BATCH][TICK_MAX_CB + 2] words, a 64-byte line each
-    unsigned colgate_seq[CFX_RING_STREAMS];   // launch sequence number per ring: the value a launch's column gates are raised to
+    unsigned* colgate;              // tile flags of the min/max layer launch: per ring 2 x 2048 words ("partial published", "codes published")
+    unsigned colgate_seq[CFX_RING_STREAMS];   // launch sequence number per ring: the value a launch's tile flags are set to
     unsigned* gate_err;             // pinned HOST word (device-visible): waits that timed out since the last cfx_gate_errors
     long long gate_timeout;         // ticks of the 100 MHz wall clock a flag wait may last
     int fused;                      // 1 (default): compress = statistics + in-launch finalize; 0: separate finalize kernel
@@ -154,7 +154,8 @@ struct cfx_comm {
 // what an exchange-layer launch tells its caller: the packets of the launch are complete once counter *p_gate has reached p_expect;
 // the gated reconstruction group proceeds once *f_gate == f_expect
 // needs_room (in): a collective kernel will run while the reconstruction group waits - take the one-launch form only if the group leaves it CUs
-struct CfxXGate { int taken; unsigned* p_gate; unsigned p_expect; unsigned* f_gate; unsigned f_expect; int needs_room;
+// p_count: the packets are complete once the p_count CONSECUTIVE words at p_gate have all reached p_expect (1: one counter word)
+struct CfxXGate { int taken; unsigned* p_gate; unsigned p_expect; int p_count; unsigned* f_gate; unsigned f_expect; int needs_room;
                   int remote; };    // remote (in): the reconstruction items' packets may sit in a peer GPU's memory
 struct PlanOp {
     int kind;   // 0 compress, 1 decompress, 2 all-gather on the side stream, 3 main stream waits for gather op `ref`, 4 ring hop,

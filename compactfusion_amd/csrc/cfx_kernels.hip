@@ -1545,23 +1545,23 @@ __global__ __launch_bounds__(NTHR) void k_minmax_compress(BatchC batch, int N, i
 // multi-launch forms run).  Column gates hold a per-stream launch sequence number (monotonic, raised with atomic max: never reset).
 // ---------------------------------------------------------------------------------------------------
 #define MML_NW FUSED_NW
-#define MML_ROWS 32            // rows of an S tile: 4 per wave
 #define MML_KC 14              // rows of a D tile a wave holds in registers (int4: 7 row pairs)
-#define COLGATE_LINES (TICK_MAX_CB + 2)     // column gates per tensor, a 64-byte line each
+#define MML_MAX_P 64           // row tiles per column block (one poll load per lane of a wave)
+#define MML_MAX_TILES 2048     // statistics tiles of one launch = flag words per ring and kind
 struct MinMaxLayerArgs {
-    int N, C, CB, P, n_st;            // group S: CB x P tiles of MML_ROWS rows per own tensor
+    int N, C, CB, P, R, n_st;         // group S: CB x P tiles of R rows (32 or 64) per own tensor
     int g_R, g_rb, n_g;               // group D: tiles of g_R rows, g_rb per tensor
     int codec, flags;
     u64* ws; size_t ws_stride;
-    unsigned* tick;
-    unsigned* colgate; unsigned seq;  // column gates of this stream's ring, the launch's sequence number
-    unsigned* gate2; unsigned expect2;     // codes gate: one arrival per S tile
-    unsigned* xgate; unsigned xexpect;     // external gate for group D (NULL: group D waits on gate2)
+    unsigned* statdone; unsigned* codedone; unsigned seq;   // one flag word per S tile, index (z * CB + bx) * P + by: "partial published" /
+                                                            // "codes (and, tile by == 0, the scales) published" = the launch's sequence number
+    unsigned* xgate; unsigned xexpect;     // external gate for group D (NULL: a D tile waits for the S tiles whose codes it reads)
     unsigned* err;
     int remote;
+    signed char src[CFX_MAX_BATCH];   // gated item -> the own tensor whose packet it reads (loop-back forms)
 };
 // codes of 8 channels of one row (int8) / one row pair (int4), exactly as k_int8_quant / k_int4_quant compute them
-__device__ __forceinline__ u64 int8_codes(h16x8 d, h16x8 sc, h16x8 zp, h16x8& qh) {
+__device__ __forceinline__ u64 int8_codes(h16x8 d, h16x8 sc, h16x8 zp) {
     u64 outb = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1570,12 +1570,11 @@ __device__ __forceinline__ u64 int8_codes(h16x8 d, h16x8 sc, h16x8 zp, h16x8& qh
         v = v < (h16)-128.0f ? (h16)-128.0f : v;
         v = v > (h16)127.0f ? (h16)127.0f : v;
         const int qi = (int)(float)v;
-        qh[i] = (h16)(float)qi;
         outb |= (u64)(unsigned char)(signed char)qi << (8 * i);
     }
     return outb;
 }
-__device__ __forceinline__ u64 int4_codes(h16x8 d0, h16x8 d1, h16x8 sc, h16x8 mn, h16x8* qh) {
+__device__ __forceinline__ u64 int4_codes(h16x8 d0, h16x8 d1, h16x8 sc, h16x8 mn) {
     u64 outb = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1587,11 +1586,19 @@ __device__ __forceinline__ u64 int4_codes(h16x8 d0, h16x8 d1, h16x8 sc, h16x8 mn
             v = v < (h16)0 ? (h16)0 : v;
             v = v > (h16)15.0f ? (h16)15.0f : v;
             const unsigned qi = (unsigned)(float)v & 15u;
-            qh[h][i] = (h16)(float)qi;
             outb |= (u64)qi << (8 * i + 4 * h);
         }
     }
     return outb;
+}
+// received values of 8 channels of row h of a code row (int8: h = 0): k_int8_dequant / k_int4_dequant arithmetic
+template <bool INT4>
+__device__ __forceinline__ h16x8 minmax_recv(u64 codes, int h, h16x8 sc, h16x8 mz) {
+    h16x8 qh;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        qh[i] = INT4 ? (h16)(float)((codes >> (8 * i + 4 * h)) & 15u) : (h16)(float)(int)(signed char)(codes >> (8 * i));
+    return INT4 ? (qh * sc + mz) : ((qh - mz) * sc);
 }
 __device__ __forceinline__ u64 ld_wt_or_sys(const u64* p, bool remote) { return remote ? ld_sys(p) : ld_wt(p); }
 __device__ __forceinline__ h16x8 ld8_pub(const u16* p, bool remote) {
@@ -1616,16 +1623,15 @@ __device__ __forceinline__ void minmax_ld_scales(const unsigned char* pk, int N,
         for (int i = 0; i < 8; ++i) mz[i] = (h16)(float)(short)zb[i];
     }
 }
-// as minmax_write_scales, published write-through (consumers inside this launch / on another GPU)
-__device__ __forceinline__ void minmax_write_scales_wt(const cfx_comp_item& it, int N, int C, int codec, int c, h16 mn, h16 mx) {
+// scale and min (int4) / scale and zero point (int8) of one channel from its {min, max}: compress_quantize.py:556-558 / :455-463
+template <bool INT4>
+__device__ __forceinline__ void minmax_scale_of(h16 mn, h16 mx, h16& scale, u16& second) {
     const h16 rng = mx - mn;
-    if (codec == CFX_CODEC_INT4) {
-        u16* S = (u16*)((char*)it.packet + (size_t)(N / 2) * C);
-        st_wt(S + c, hbits((h16)((float)rng / 15.000001f)));
-        st_wt(S + C + c, hbits(mn));
+    if (INT4) {
+        scale = (h16)((float)rng / 15.000001f);
+        second = hbits(mn);
     } else {
-        u16* S = (u16*)((char*)it.packet + (size_t)N * C);
-        const h16 scale = (h16)((float)rng / 255.000001f);
+        scale = (h16)((float)rng / 255.000001f);
         const h16 r = hrint(hdiv(mn, scale));
         h16 z = (h16)-128.0f - r;
         short zi;
@@ -1635,24 +1641,38 @@ __device__ __forceinline__ void minmax_write_scales_wt(const cfx_comp_item& it, 
             z = z > (h16)127.0f ? (h16)127.0f : z;
             zi = (short)(float)z;
         }
-        st_wt(S + c, hbits(scale));
-        st_wt(S + C + c, (u16)zi);
+        second = (u16)zi;
+    }
+}
+#ifndef MML_POLL_SLEEP
+#define MML_POLL_SLEEP 2
+#endif
+// one wave: wait until the `n` (<= 64) flag words f[0 .. n) have all reached `seq`
+__device__ __forceinline__ void wave_wait_flags(const unsigned* f, int n, unsigned seq, unsigned* err) {
+    const int lane = threadIdx.x & 63;
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned v = lane < n ? ld_wt(f + lane) : seq;
+        if (__builtin_amdgcn_ballot_w64((int)(v - seq) < 0) == 0) break;
+        __builtin_amdgcn_s_sleep(MML_POLL_SLEEP);
+        if (++spins > GATE_SPIN_LIMIT) { if (lane == 0) gate_fail(err); break; }
     }
 }
 
-template <bool INT4>
-__device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, const MinMaxLayerArgs& a, int z, int bx, int by, unsigned (*sm)[TILE_C]) {
+// RW = rows a wave holds: 4 (tiles of 32 rows) or 8 (tiles of 64 rows: tall tensors, fewer partials per channel)
+template <bool INT4, int RW>
+__device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, const MinMaxLayerArgs& a, int z, int bx, int by, u64 (*sm)[TILE_C]) {
     constexpr int NW = MML_NW;
     constexpr int RPC = INT4 ? 2 : 1;          // rows per code row
-    constexpr int CR = 4 / RPC;                // code rows a wave holds
+    constexpr int CR = RW / RPC;               // code rows a wave holds
     const int N = a.N, C = a.C;
-    const TileCoord t = tile_coord_at(bx, by, N, C, MML_ROWS);
+    const TileCoord t = tile_coord_at(bx, by, N, C, a.R);
     const h16* x = (const h16*)it.x;
     const h16* base = (const h16*)it.base;
     const int cc = min(t.c, C - 8);
     // ---- the tile into registers (every load unconditional: clamped row, masked use) ----
-    h16x8 xk[4], bk[4];
-    bool rv[4];
+    h16x8 xk[RW], bk[RW];
+    bool rv[RW];
 #pragma unroll
     for (int j = 0; j < CR; ++j)
 #pragma unroll
@@ -1664,108 +1684,107 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
             bk[j * RPC + h] = base ? ld8nt(base + off) : (h16x8)(h16)0;
         }
     h16x8 mn = (h16x8)hfrom(0x7c00), mx = (h16x8)hfrom(0xfc00);
-    h16x8 d[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        d[q] = xk[q] - bk[q];
+    for (int q = 0; q < RW; ++q) {
+        const h16x8 d = xk[q] - bk[q];
         if (rv[q]) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                mn[i] = d[q][i] < mn[i] ? d[q][i] : mn[i];
-                mx[i] = d[q][i] > mx[i] ? d[q][i] : mx[i];
+                mn[i] = d[i] < mn[i] ? d[i] : mn[i];
+                mx[i] = d[i] > mx[i] ? d[i] : mx[i];
             }
         }
     }
+    unsigned* sm32 = (unsigned*)&sm[0][0];                 // [NW][TILE_C] words
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sm[t.w][i * 64 + (t.lane ^ (i << 3))] = (unsigned)hbits(mn[i]) | ((unsigned)hbits(mx[i]) << 16);
+    for (int i = 0; i < 8; ++i) sm32[t.w * TILE_C + i * 64 + (t.lane ^ (i << 3))] = (unsigned)hbits(mn[i]) | ((unsigned)hbits(mx[i]) << 16);
     lds_barrier();
     unsigned* part = (unsigned*)(a.ws + (size_t)z * a.ws_stride);
+    const int k = threadIdx.x;                              // 512 threads: one channel of the tile each
+    const int ch = bx * TILE_C + k, chc = min(ch, C - 1);
     {
-        const int k = threadIdx.x;              // 512 threads: one channel of the tile each
         const int sidx = (k & 7) * 64 + ((k >> 3) ^ ((k & 7) << 3));
-        const int ch = bx * TILE_C + k;
-        if (ch < C) {
-            h16 lo = hfrom((u16)(sm[0][sidx] & 0xffff)), hi = hfrom((u16)(sm[0][sidx] >> 16));
+        h16 lo = hfrom((u16)(sm32[sidx] & 0xffff)), hi = hfrom((u16)(sm32[sidx] >> 16));
 #pragma unroll
-            for (int w = 1; w < NW; ++w) {
-                const h16 a2 = hfrom((u16)(sm[w][sidx] & 0xffff)), b2 = hfrom((u16)(sm[w][sidx] >> 16));
-                lo = a2 < lo ? a2 : lo;
-                hi = b2 > hi ? b2 : hi;
-            }
-            st_wt(&part[(size_t)by * C + ch], (unsigned)hbits(lo) | ((unsigned)hbits(hi) << 16));
+        for (int w = 1; w < NW; ++w) {
+            const unsigned v = sm32[w * TILE_C + sidx];
+            const h16 a2 = hfrom((u16)(v & 0xffff)), b2 = hfrom((u16)(v >> 16));
+            lo = a2 < lo ? a2 : lo;
+            hi = b2 > hi ? b2 : hi;
         }
+        if (ch < C) st_wt(&part[(size_t)by * C + ch], (unsigned)hbits(lo) | ((unsigned)hbits(hi) << 16));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    unsigned* tick = a.tick + z * TICK_WORDS;
-    unsigned* flag = &sm[0][0];
-    if (threadIdx.x == 0) flag[0] = __hip_atomic_fetch_add(tick + 1 + bx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    lds_barrier();
-    const bool last = flag[0] == (unsigned)(a.P - 1);
-    unsigned* cgate = a.colgate + ((size_t)z * COLGATE_LINES + bx) * GATE_LINE;
-    if (last) {
-        // the column block's scales: one channel per thread, FUSED_CH partials in flight per batch (unconditional loads, clamped index)
-        const int ch = bx * TILE_C + threadIdx.x;
-        const int chc = min(ch, C - 1);
-        h16 lo = hfrom(0x7c00), hi = hfrom(0xfc00);
-        for (int p0 = 0; p0 < a.P; p0 += FUSED_CH) {
-            unsigned v[FUSED_CH];
+    const size_t fbase = ((size_t)z * a.CB + bx) * a.P;
+    if (k == 0) st_wt(a.statdone + fbase + by, a.seq);
+    // ---- every tile of the column block reduces the block's P partials itself: no last arriver, no second hand-over ----
+    if (t.w == 0) wave_wait_flags(a.statdone + fbase, a.P, a.seq, a.err);
+    __syncthreads();
+    h16 lo = hfrom(0x7c00), hi = hfrom(0xfc00);
+    for (int p0 = 0; p0 < a.P; p0 += 16) {
+        unsigned v[16];
 #pragma unroll
-            for (int j = 0; j < FUSED_CH; ++j) v[j] = ld_wt(&part[(size_t)min(p0 + j, a.P - 1) * C + chc]);   // a repeated partial does not change a min / max
+        for (int j = 0; j < 16; ++j) v[j] = ld_wt(&part[(size_t)min(p0 + j, a.P - 1) * C + chc]);   // a repeated partial does not change a min / max
 #pragma unroll
-            for (int j = 0; j < FUSED_CH; ++j) {
-                const h16 a0 = hfrom((u16)(v[j] & 0xffff)), b0 = hfrom((u16)(v[j] >> 16));
-                lo = a0 < lo ? a0 : lo;
-                hi = b0 > hi ? b0 : hi;
-            }
+        for (int j = 0; j < 16; ++j) {
+            const h16 a0 = hfrom((u16)(v[j] & 0xffff)), b0 = hfrom((u16)(v[j] >> 16));
+            lo = a0 < lo ? a0 : lo;
+            hi = b0 > hi ? b0 : hi;
         }
-        if (ch < C) minmax_write_scales_wt(it, N, C, a.codec, ch, lo, hi);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier();
-        if (threadIdx.x == 0) {
-            st_wt(tick + 1 + bx, 0u);
-            (void)__hip_atomic_fetch_max(cgate, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    } else if (threadIdx.x == 0) {
-        unsigned n = 0;
-        while ((int)(ld_wt(cgate) - a.seq) < 0) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++n > GATE_SPIN_LIMIT) { gate_fail(a.err); break; }
+    }
+    h16 scale;
+    u16 second;
+    minmax_scale_of<INT4>(lo, hi, scale, second);
+    unsigned char* pk = (unsigned char*)it.packet;
+    if (by == 0 && ch < C) {                               // the block's scales into the packet: once
+        u16* S = (u16*)(pk + (INT4 ? (size_t)(N / 2) * C : (size_t)N * C));
+        st_wt(S + ch, hbits(scale));
+        st_wt(S + C + ch, second);
+    }
+    // a lane's 8 channels from the 512 per-thread values: through LDS
+    u16* sl = (u16*)&sm[0][0];                              // [2][TILE_C] halves (the min / max words are consumed)
+    __syncthreads();
+    sl[k] = hbits(scale);
+    sl[TILE_C + k] = second;
+    __syncthreads();
+    h16x8 sc, mz;
+    {
+        const u16x8 s8 = *(const u16x8*)(sl + t.lane * 8), m8 = *(const u16x8*)(sl + TILE_C + t.lane * 8);
+        sc = __builtin_bit_cast(h16x8, s8);
+        if (INT4) mz = __builtin_bit_cast(h16x8, m8);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mz[i] = (h16)(float)(short)m8[i];
         }
     }
     __syncthreads();
     // ---- own tile: codes from registers ----
-    unsigned char* pk = (unsigned char*)it.packet;
-    h16x8 sc, mz;
-    minmax_ld_scales<INT4>(pk, N, C, cc, false, sc, mz);
-    h16* nb = (h16*)it.new_base;
-    const bool upd = (a.flags & CFX_FLAG_UPDATE_CACHE) && nb;
-    const bool ef = !(a.flags & CFX_FLAG_NO_EF);
-    h16x8 qh[4];
-    u64* stage = (u64*)&sm[0][0] + (size_t)t.w * CR * 64;        // this wave's CR code rows x 64 lanes x 8 bytes (same wave writes and reads: in order)
+    u64* stage = &sm[0][0] + (size_t)t.w * CR * 64;         // this wave's CR code rows x 64 lanes x 8 bytes (same wave writes and reads: in order)
 #pragma unroll
     for (int j = 0; j < CR; ++j) {
-        u64 codes;
-        if (INT4) codes = int4_codes(d[2 * j], d[2 * j + 1], sc, mz, &qh[2 * j]);
-        else codes = int8_codes(d[j], sc, mz, qh[j]);
-        stage[j * 64 + t.lane] = codes;
+        u64 cj;
+        if (INT4) cj = int4_codes(xk[2 * j] - bk[2 * j], xk[2 * j + 1] - bk[2 * j + 1], sc, mz);
+        else cj = int8_codes(xk[j] - bk[j], sc, mz);
+        stage[j * 64 + t.lane] = cj;                        // (kept there for the error-feedback pass too: nothing else uses the LDS afterwards)
     }
     {
-        // a code row of the tile is 512 bytes = 32 lanes x 16 bytes; the wave's CR code rows: lanes [0, 32) rows 0.., lanes [32, 64) the odd ones
+        // a code row of the tile is 512 bytes = 32 lanes x 16 bytes; lanes [0, 32) take the even code rows of the wave, [32, 64) the odd ones
         const int crows = INT4 ? N / 2 : N;
-        const size_t crow_bytes = (size_t)C;
 #pragma unroll
         for (int jj = 0; jj < CR; jj += 2) {
             const int j = jj + (t.lane >> 5), seg = t.lane & 31;
             const int cr = (t.r0 / RPC) + t.w + NW * j;
             if (j < CR && cr < crows && cr * RPC < t.r1 && bx * TILE_C + seg * 16 < C)
-                st16_wt(pk + (size_t)cr * crow_bytes + (size_t)bx * TILE_C + seg * 16, *(const u32x4*)((const unsigned char*)(stage + j * 64) + seg * 16));
+                st16_wt(pk + (size_t)cr * C + (size_t)bx * TILE_C + seg * 16, *(const u32x4*)((const unsigned char*)(stage + j * 64) + seg * 16));
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-    if (threadIdx.x == 0) gate_arrive(a.gate2, 1u, a.expect2);
-    if (upd) {
+    __syncthreads();
+    if (k == 0) st_wt(a.codedone + fbase + by, a.seq);
+    h16* nb = (h16*)it.new_base;
+    if ((a.flags & CFX_FLAG_UPDATE_CACHE) && nb) {
+        const bool ef = !(a.flags & CFX_FLAG_NO_EF);
 #pragma unroll
         for (int j = 0; j < CR; ++j)
 #pragma unroll
@@ -1775,7 +1794,7 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
                 if (rv[q]) {
                     h16x8 o;
                     if (ef) {
-                        const h16x8 recv = INT4 ? (qh[q] * sc + mz) : ((qh[q] - mz) * sc);
+                        const h16x8 recv = minmax_recv<INT4>(stage[j * 64 + t.lane], h, sc, mz);
                         o = base ? (bk[q] + recv) : recv;
                     } else o = xk[q];
                     st8nt(nb + (size_t)row * C + t.c, o);
@@ -1785,7 +1804,7 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
 }
 
 template <bool INT4>
-__device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, const MinMaxLayerArgs& a, int bx, int by) {
+__device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, const MinMaxLayerArgs& a, int item, int bx, int by) {
     constexpr int NW = MML_NW;
     constexpr int RPC = INT4 ? 2 : 1;
     constexpr int KC = MML_KC / RPC;           // code rows a wave holds
@@ -1804,7 +1823,23 @@ __device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, c
             bv[j * RPC + h] = base ? ld8nt(base + (size_t)min(row, N - 1) * C + cc) : (h16x8)(h16)0;
         }
     if (a.xgate) gate_wait<true>(a.xgate, a.xexpect, a.err);
-    else gate_wait<false>(a.gate2, a.expect2, a.err);
+    else {
+        // the S tiles whose codes this tile reads (same column block, the row tiles its rows fall into) - and tile 0, which wrote the scales
+        if (t.w == 0) {
+            const unsigned* f = a.codedone + ((size_t)a.src[item] * a.CB + bx) * a.P;
+            const int by0 = t.r0 / a.R, by1 = (t.r1 - 1) / a.R;
+            const int lane = threadIdx.x & 63;
+            unsigned spins = 0;
+            for (;;) {
+                const int idx = lane == 0 ? 0 : by0 + lane - 1;
+                const unsigned v = (lane == 0 || idx <= by1) ? ld_wt(f + min(idx, a.P - 1)) : a.seq;
+                if (__builtin_amdgcn_ballot_w64((int)(v - a.seq) < 0) == 0) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > GATE_SPIN_LIMIT) { if (lane == 0) gate_fail(a.err); break; }
+            }
+        }
+        __syncthreads();
+    }
     const bool remote = a.remote != 0;
     h16x8 sc, mz;
     minmax_ld_scales<INT4>(pk, N, C, cc, remote, sc, mz);
@@ -1821,32 +1856,28 @@ __device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, c
         for (int h = 0; h < RPC; ++h) {
             const int row = t.r0 + (t.w + NW * j) * RPC + h;
             if (row < t.r1 && t.act) {
-                h16x8 qh;
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    qh[i] = INT4 ? (h16)(float)((qb[j] >> (8 * i + 4 * h)) & 15u) : (h16)(float)(int)(signed char)(qb[j] >> (8 * i));
-                const h16x8 recv = INT4 ? (qh * sc + mz) : ((qh - mz) * sc);
+                const h16x8 recv = minmax_recv<INT4>(qb[j], h, sc, mz);
                 st8nt(out + (size_t)row * C + t.c, base ? (bv[j * RPC + h] + recv) : recv);
             }
         }
 }
 
-template <bool INT4>
+template <bool INT4, int RW>
 __global__ __launch_bounds__(FUSED_NT, 4) void k_minmax_layer(BatchC batch, BatchD gated, MinMaxLayerArgs a) {
-    __shared__ unsigned sm[MML_NW][TILE_C];
+    __shared__ u64 sm[MML_NW][TILE_C];
     int b = blockIdx.x;
     if (b < a.n_st) {
         const int per = a.CB * a.P;
         const int z = b / per, rem = b - z * per;
         const int by = rem / a.CB;
-        minmax_layer_s_tile<INT4>(batch.it[z], a, z, rem - by * a.CB, by, sm);
+        minmax_layer_s_tile<INT4, RW>(batch.it[z], a, z, rem - by * a.CB, by, sm);
         return;
     }
     b -= a.n_st;
     const int per = a.CB * a.g_rb;
     const int item = b / per, rem = b - item * per;
     const int ty = rem / a.CB;
-    minmax_layer_d_tile<INT4>(gated.it[item], a, rem - ty * a.CB, ty);
+    minmax_layer_d_tile<INT4>(gated.it[item], a, item, rem - ty * a.CB, ty);
 }
 
 // int8 quantise (+EF)      compress_quantize.py:465-467 ; EF = dequantize_int8 :482 + main.py:232
@@ -2335,7 +2366,7 @@ int cfx_prepare(cfx_ctx* ctx) {
     static_assert(3 * TICK_RING * CFX_RING_STREAMS == sizeof(((cfx_ctx*)0)->gate_expect) / sizeof(unsigned), "gate_expect has three entries per ring slot");
     const size_t tick_words = (size_t)CFX_RING_STREAMS * TICK_RING * CFX_MAX_BATCH * TICK_WORDS;
     const size_t gate_words = (size_t)(CFX_RING_STREAMS * TICK_RING + 1) * GATE_STRIDE;
-    const size_t colgate_words = (size_t)CFX_RING_STREAMS * CFX_MAX_BATCH * COLGATE_LINES * GATE_LINE;     // column gates of the min/max layer launch, per ring
+    const size_t colgate_words = (size_t)CFX_RING_STREAMS * 2 * MML_MAX_TILES;     // tile flags of the min/max layer launch ("partial published", "codes published"), per ring
     const size_t bytes = (tick_words + gate_words + colgate_words) * sizeof(unsigned);
     void* p = nullptr;
     int rc = CFX_OK;
@@ -2637,7 +2668,7 @@ static unsigned ticket_slot(cfx_ctx* ctx, void* stream) {
 static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                          int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
                          void* workspace, size_t workspace_bytes, void* stream, CfxXGate* xg = nullptr) {
-    if (xg) { const int room = xg->needs_room, rem = xg->remote; memset(xg, 0, sizeof(*xg)); xg->needs_room = room; xg->remote = rem; }
+    if (xg) { const int room = xg->needs_room, rem = xg->remote; memset(xg, 0, sizeof(*xg)); xg->needs_room = room; xg->remote = rem; xg->p_count = 1; }
     if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "compress: null ctx/items");
     if (n_gated < 0 || n_gated > CFX_MAX_BATCH || (n_gated && !gated)) return fail(ctx, CFX_ERR_BATCH, "compress: gated batch out of range");
     if (n_gated && codec == CFX_CODEC_TOPK)
@@ -2710,7 +2741,8 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
     // one launch only for explicit gated items: folding the error-feedback update of a PLAIN compress call into the launch the same
     // way was measured slower (K,V of the FLUX shard: 20.8 vs 19.2 us 1-bit, 19.9 vs 18.6 us 2-bit) - the gate hop and the write tail
     // cost more than the kernel boundary they replace when only two tensors wait behind the gate
-    bool one_launch = n_gated && gated_one_launch(ctx, codec, C, CB) && R == FUSED_NW * 4;   // the tile stays in registers
+    // (2-bit: the tile stays in registers - exactly one trip of the row loop; 1-bit: any whole number of trips)
+    bool one_launch = n_gated && gated_one_launch(ctx, codec, C, CB) && (R == FUSED_NW * 4 || (codec == CFX_CODEC_BINARY && R % (FUSED_NW * 4) == 0));
     if (one_launch && codec == CFX_CODEC_INT2) {
         // the 2-bit layer launch needs every statistics workgroup CO-RESIDENT (each waits at gate 1 for all the others' partial sums
         // while holding its tile in registers): only when they fit the CUs this stream may use, otherwise the multi-launch form
@@ -2867,17 +2899,31 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
         // gated reconstruction.  Needs every statistics workgroup CO-RESIDENT on the stream's CUs (each waits for its column block's scales
         // holding its tile); otherwise - tall tensors - the multi-launch forms below run (identical results). ----
         const bool int4 = codec == CFX_CODEC_INT4;
-        const int P32 = (N + MML_ROWS - 1) / MML_ROWS;
+        const int RL = (N + 31) / 32 <= MML_MAX_P / 2 ? 32 : 64;       // S tile height: 32 rows; 64 where that keeps the partials per channel <= MML_MAX_P
+        const int PL = (N + RL - 1) / RL;
         const int g_rb = (N + FUSED_NW * MML_KC - 1) / (FUSED_NW * MML_KC);
         const int g_R = ((N + g_rb - 1) / g_rb + 15) / 16 * 16;
-        const long n_st = (long)CB * P32 * batch, n_g = (long)CB * g_rb * n_gated;
-        bool layer = fused && ctx->gated_on && !ctx->dev_probe && C % 16 == 0 && stream_cus >= 128 && ctx->stats_rows == 0;
+        const long n_st = (long)CB * PL * batch, n_g = (long)CB * g_rb * n_gated;
+        bool layer = fused && ctx->gated_on && !ctx->dev_probe && C % 16 == 0 && stream_cus >= 128 && ctx->stats_rows == 0 && PL <= MML_MAX_P &&
+                     n_st <= MML_MAX_TILES;
+        signed char src[CFX_MAX_BATCH];
+        memset(src, 0, sizeof(src));
+        if (layer && n_gated && !xg) {
+            // loop-back: a gated item waits for the S tiles of the own tensor whose packet it reads
+            for (int g_ = 0; g_ < n_gated && layer; ++g_) {
+                int m = -1;
+                for (int i = 0; i < batch; ++i)
+                    if (gated[g_].packet == items[i].packet) m = i;
+                if (m < 0) layer = false;
+                src[g_] = (signed char)m;
+            }
+        }
         if (layer) {
             static int per_cu4 = 0, per_cu8 = 0;
             int& per_cu = int4 ? per_cu4 : per_cu8;
             if (!per_cu) {
-                const hipError_t oe = int4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_minmax_layer<true>, FUSED_NT, 0)
-                                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_minmax_layer<false>, FUSED_NT, 0);
+                const hipError_t oe = int4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_minmax_layer<true, 8>, FUSED_NT, 0)
+                                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_minmax_layer<false, 8>, FUSED_NT, 0);
                 if (oe != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
             }
             const long slots = (long)per_cu * stream_cus;
@@ -2889,29 +2935,32 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
         if (layer) {
             MinMaxLayerArgs a;
             memset(&a, 0, sizeof(a));
-            a.N = N; a.C = C; a.CB = CB; a.P = P32; a.n_st = (int)n_st;
+            a.N = N; a.C = C; a.CB = CB; a.P = PL; a.R = RL; a.n_st = (int)n_st;
             a.g_R = g_R; a.g_rb = g_rb; a.n_g = (int)n_g;
             a.codec = codec; a.flags = flags;
-            a.ws = ws; a.ws_stride = wstride; a.tick = tick;
+            a.ws = ws; a.ws_stride = wstride;
             const unsigned ring = slot / TICK_RING;
-            a.colgate = ctx->colgate + (size_t)ring * CFX_MAX_BATCH * COLGATE_LINES * GATE_LINE;
+            a.statdone = ctx->colgate + (size_t)ring * 2 * MML_MAX_TILES;
+            a.codedone = a.statdone + MML_MAX_TILES;
             a.seq = ++ctx->colgate_seq[ring];
-            a.gate2 = ctx->gate + (size_t)slot * GATE_STRIDE;
-            ctx->gate_expect[3 * slot] += (unsigned)n_st;
-            a.expect2 = ctx->gate_expect[3 * slot];
             a.err = ctx->gate_err;
+            memcpy(a.src, src, sizeof(src));
             if (xg && n_gated) {
-                a.xgate = a.gate2 + GATE_BLOCK;
+                a.xgate = ctx->gate + (size_t)slot * GATE_STRIDE + GATE_BLOCK;
                 a.xexpect = ++ctx->gate_expect[3 * slot + 1];
                 a.remote = xg->remote;
                 xg->taken = 1;
-                xg->p_gate = a.gate2 + 1 * GATE_LINE;      // the word the codes gate's last arriver writes for XCD 0: no poller on the counter's line
-                xg->p_expect = a.expect2;
+                xg->p_gate = a.codedone; xg->p_expect = a.seq; xg->p_count = (int)n_st;      // "packets complete" = every S tile's codes flag
                 xg->f_gate = a.xgate; xg->f_expect = a.xexpect;
             }
             const dim3 g((unsigned)(n_st + n_g));
-            if (int4) LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_minmax_layer<true>), g, dim3(FUSED_NT), 0, s, b, gd, a);
-            else LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_minmax_layer<false>), g, dim3(FUSED_NT), 0, s, b, gd, a);
+            if (RL == 32) {
+                if (int4) LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_minmax_layer<true, 4>), g, dim3(FUSED_NT), 0, s, b, gd, a);
+                else LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_minmax_layer<false, 4>), g, dim3(FUSED_NT), 0, s, b, gd, a);
+            } else {
+                if (int4) LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_minmax_layer<true, 8>), g, dim3(FUSED_NT), 0, s, b, gd, a);
+                else LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_minmax_layer<false, 8>), g, dim3(FUSED_NT), 0, s, b, gd, a);
+            }
             return check_launch(ctx, "min/max layer launch");
         }
         if (fused) {

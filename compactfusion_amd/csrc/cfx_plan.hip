@@ -46,29 +46,38 @@ static void sched_free(PipeSched* sc) {
 __global__ void k_flag_set(unsigned* flag, unsigned v) {
     if (threadIdx.x == 0) __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void k_flag_wait(const unsigned* flag, unsigned v, unsigned* err, long long timeout) {
-    if (threadIdx.x != 0) return;
-    const long long t0 = wall_clock64();
-    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
-        __builtin_amdgcn_s_sleep(2);
-        if (wall_clock64() - t0 > timeout) {
-            if (err) (void)__hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
+// one wave: wait until the `count` consecutive words at `flag` have all reached v (count 1: lane 0 polls one word); true = gave up
+__device__ __forceinline__ bool wave_wait_words(const unsigned* flag, unsigned v, int count, long long t0, long long timeout) {
+    const int lane = threadIdx.x;
+    if (count <= 1) {
+        bool gave_up = false;
+        if (lane == 0) {
+            while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > timeout) { gave_up = true; break; }
+            }
         }
+        return __builtin_amdgcn_ballot_w64(gave_up) != 0;
     }
+    for (;;) {
+        bool behind = false;
+        for (int i = lane; i < count; i += 64)
+            behind |= (int)(__hip_atomic_load(flag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - v) < 0;
+        if (__builtin_amdgcn_ballot_w64(behind) == 0) return false;
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > timeout) return true;
+    }
+}
+__global__ void k_flag_wait(const unsigned* flag, unsigned v, int count, unsigned* err, long long timeout) {
+    const bool gave_up = wave_wait_words(flag, v, count, wall_clock64(), timeout);
+    if (gave_up && threadIdx.x == 0 && err) (void)__hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // wait + set in one launch: what sits between "packets complete" and "packets arrived" when no collective kernel does
-__global__ void k_flag_relay(const unsigned* wait, unsigned wv, unsigned* set, unsigned sv, unsigned* err, long long timeout) {
+__global__ void k_flag_relay(const unsigned* wait, unsigned wv, int count, unsigned* set, unsigned sv, unsigned* err, long long timeout) {
+    const bool gave_up = wave_wait_words(wait, wv, count, wall_clock64(), timeout);
     if (threadIdx.x != 0) return;
-    const long long t0 = wall_clock64();
-    while ((int)(__hip_atomic_load(wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - wv) < 0) {
-        __builtin_amdgcn_s_sleep(1);
-        if (wall_clock64() - t0 > timeout) {
-            if (err) (void)__hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
-        }
-    }
+    if (gave_up && err) (void)__hip_atomic_fetch_add(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(set, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -83,25 +92,19 @@ struct PeerFlags { const unsigned* pub[CFX_P2P_MAX_PEERS]; };
 // counting where the words stand; a host-side counter restarted at 0 there and every wait of the next generation passed at once).  Only
 // this rank's flag kernels of this op write the word, one at a time (stream order, or behind the launch whose packets they wait for).
 // p_gate NULL: nothing to wait for locally (the in-order forms: the packets are complete by stream order).
-__global__ void k_flag_exchange(const unsigned* p_gate, unsigned p_expect, unsigned* own_pub, PeerFlags peers, int n_peers,
+__global__ void k_flag_exchange(const unsigned* p_gate, unsigned p_expect, int p_count, unsigned* own_pub, PeerFlags peers, int n_peers,
                                 unsigned* f_gate, unsigned f_expect, unsigned* err, long long timeout) {
     const int lane = threadIdx.x;
     const long long t0 = wall_clock64();
     bool gave_up = false;
     unsigned epoch = 0;
+    if (p_gate) gave_up = wave_wait_words(p_gate, p_expect, p_count, t0, timeout);
     if (lane == 0) {
-        if (p_gate) {
-            while ((int)(__hip_atomic_load(p_gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p_expect) < 0) {
-                __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > timeout) { gave_up = true; break; }
-            }
-        }
         epoch = __hip_atomic_load(own_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
         if (p_gate) {
             // one-launch form: the packets were stored WRITE-THROUGH and their stores had completed before the last arrival was counted:
             // publishing after having SEEN the count orders them before the word for anybody who reads the word first - no release fence
-            // (a system-scope release writes back this XCD's whole L2, and the launch's state updates are streaming through it right
-            // now: measured +7 us per layer on the 2-bit exchange layer, whose workgroups store their state right after the arrival)
+            // (a system-scope release writes back this XCD's whole L2 while the launch's state updates are streaming through it)
             __hip_atomic_store(own_pub, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else {
             // in-order forms: the packets were written by the kernels in front of this one in the stream, with plain stores
@@ -529,12 +532,12 @@ static int ring_hop(cfx_comm* c, const void* send, void* recv, size_t bytes, hip
 
 // publish this rank's word for op `o`, wait for the peers' (k_flag_exchange) on `s`; p_gate != NULL: first wait until *p_gate has reached
 // p_expect (the launch's packets are complete); afterwards *f_gate = f_expect
-static int launch_flag_exchange(cfx_plan* p, const PlanOp* o, hipStream_t s, const unsigned* p_gate, unsigned p_expect, unsigned* f_gate,
+static int launch_flag_exchange(cfx_plan* p, const PlanOp* o, hipStream_t s, const unsigned* p_gate, unsigned p_expect, int p_count, unsigned* f_gate,
                                 unsigned f_expect, const char* what) {
     PeerFlags pf;
     memset(&pf, 0, sizeof(pf));
     for (int q = 0; q < o->n_peers; ++q) pf.pub[q] = o->peer_flag[q];
-    hipLaunchKernelGGL(k_flag_exchange, dim3(1), dim3(64), 0, s, p_gate, p_expect, o->own_flag, pf, o->n_peers, f_gate, f_expect,
+    hipLaunchKernelGGL(k_flag_exchange, dim3(1), dim3(64), 0, s, p_gate, p_expect, p_count, o->own_flag, pf, o->n_peers, f_gate, f_expect,
                        p->ctx->gate_err, p->ctx->gate_timeout);
     return check_launch(p->ctx, what);
 }
@@ -577,7 +580,7 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                 if (side_mode && hipStreamWaitEvent(main_s, p->ops[o->ref].ev_done, 0) != hipSuccess) return fail(p->ctx, CFX_ERR_LAUNCH, "plan: wait failed");
                 break;
             case 5:
-                hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, main_s, (const unsigned*)(p->flags + (size_t)o->ref * FLAG_WORDS), p->epoch,
+                hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, main_s, (const unsigned*)(p->flags + (size_t)o->ref * FLAG_WORDS), p->epoch, 1,
                                    p->ctx->gate_err, p->ctx->gate_timeout);
                 rc = check_launch(p->ctx, "flag wait launch");
                 break;
@@ -588,7 +591,7 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
             case 7: rc = cfx_lr_compress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, o->q0, o->ws, o->ws_bytes, stream); break;
             case 8: rc = cfx_lr_decompress_batch(p->ctx, o->codec, o->N, o->C, o->param, o->batch, o->d, o->ws, o->ws_bytes, stream); break;
             case 11:
-                rc = launch_flag_exchange(p, o, main_s, nullptr, 0u, p->p2p_sink, 1u, "p2p sync launch");
+                rc = launch_flag_exchange(p, o, main_s, nullptr, 0u, 1, p->p2p_sink, 1u, "p2p sync launch");
                 break;
             case 9:
             case 10: {
@@ -620,7 +623,7 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                 if (rc != CFX_OK) break;
                 if (!xg.taken) {
                     // in order on the run stream (also: a shape / stream without the one-launch form - compress_impl launched the compress only)
-                    if (o->kind == 10) rc = launch_flag_exchange(p, o, main_s, nullptr, 0u, p->p2p_sink, 1u, "p2p exchange layer: flag exchange launch (in order)");
+                    if (o->kind == 10) rc = launch_flag_exchange(p, o, main_s, nullptr, 0u, 1, p->p2p_sink, 1u, "p2p exchange layer: flag exchange launch (in order)");
                     else if (o->comm) {
                         const int r = o->comm->api.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, main_s);
                         if (r != 0) {
@@ -634,15 +637,15 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                 }
                 // one launch: what sits on the exchange stream between "packets complete" and "packets arrived"
                 if (o->kind == 10) {
-                    rc = launch_flag_exchange(p, o, p->side, xg.p_gate, xg.p_expect, xg.f_gate, xg.f_expect, "p2p exchange layer: flag exchange launch");
+                    rc = launch_flag_exchange(p, o, p->side, xg.p_gate, xg.p_expect, xg.p_count, xg.f_gate, xg.f_expect, "p2p exchange layer: flag exchange launch");
                 } else if (!o->comm) {
-                    hipLaunchKernelGGL(k_flag_relay, dim3(1), dim3(64), 0, p->side, (const unsigned*)xg.p_gate, xg.p_expect, xg.f_gate, xg.f_expect,
+                    hipLaunchKernelGGL(k_flag_relay, dim3(1), dim3(64), 0, p->side, (const unsigned*)xg.p_gate, xg.p_expect, xg.p_count, xg.f_gate, xg.f_expect,
                                        p->ctx->gate_err, p->ctx->gate_timeout);
                     rc = check_launch(p->ctx, "exchange layer: flag relay launch");
                 } else {
                     // with a communicator: wait kernel ; ncclAllGather ; set kernel - the same three enqueues at every world size (a one-rank
                     // in-place all-gather enqueues nothing)
-                    hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, p->side, (const unsigned*)xg.p_gate, xg.p_expect, p->ctx->gate_err, p->ctx->gate_timeout);
+                    hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, p->side, (const unsigned*)xg.p_gate, xg.p_expect, xg.p_count, p->ctx->gate_err, p->ctx->gate_timeout);
                     rc = check_launch(p->ctx, "exchange layer: flag wait launch");
                     if (rc != CFX_OK) break;
                     const int r = o->comm->api.AllGather(o->send, o->recv, o->bytes_per_rank, /*ncclUint8*/ 1, o->comm->comm, p->side);
@@ -793,7 +796,7 @@ int cfx_flag_wait(cfx_ctx* ctx, const void* flag, unsigned value, void* stream) 
     if (!ctx->gate_err && cfx_prepare(ctx) != CFX_OK) return CFX_ERR_LAUNCH;
     const int ge = gate_check(ctx, "flag wait");
     if (ge != CFX_OK) return ge;
-    hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned*)flag, value, ctx->gate_err, ctx->gate_timeout);
+    hipLaunchKernelGGL(k_flag_wait, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned*)flag, value, 1, ctx->gate_err, ctx->gate_timeout);
     return check_launch(ctx, "flag wait launch");
 }
 

@@ -193,7 +193,13 @@ def cpu_step(cid, param, N, C, L, ncomp, nrec, update, budget=8.0):
 
 def main():
     rows = []
+    only = os.environ.get("ONLY")              # e.g. ONLY=2: one configuration (for kernel traces), GPU side only
     for name, cid, param, (N, C), L, ncomp, nrec, update in CONFIGS:
+        if only and not name.startswith(only):
+            continue
+        if only:
+            print(name, gpu_step(cid, param, N, C, L, ncomp, nrec, update), "ms/step")
+            continue
         ms = gpu_step(cid, param, N, C, L, ncomp, nrec, update)
         act = L * (ncomp + nrec) * N * C * 2
         cms, thr = cpu_step(cid, param, N, C, L, ncomp, nrec, update)

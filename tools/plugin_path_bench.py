@@ -6,8 +6,9 @@
                           `update_out_and_lse` replaced by no-ops
 Both go through compact/xlayer.py: ONE native op per layer (cfx_plan_add_exchange_layer_p2p), which for the 1-bit codec is ONE codec launch.
 One GPU: the 8 logical ranks are looped back (every logical peer reads this rank's packets from the uncached IPC arena) - the same op,
-launches and kernels as any N minus the remote reads and the waiting.  Reported per leg: wall ms/step, host issue us/layer, and the
-kernel ids one step issued (cfx_profile_read: 31 = the gated layer launch).
+launches and kernels as any N minus the remote reads and the waiting.  Reported per leg: wall ms/step (back-to-back steps), host issue
+us/layer (median of single steps issued into an idle queue; and of the back-to-back loop, where it contains the waiting for queue space),
+and the kernel ids one step issued (cfx_profile_read: 31 = the gated layer launch).
 Run on the GPU box:  python tools/plugin_path_bench.py [--steps K] [--json out.json]"""
 import argparse
 import ctypes
@@ -117,7 +118,18 @@ def timed(fn, first, steps):
         host += time.perf_counter() - h0
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    return {"ms_per_step": round(wall / steps * 1e3, 4), "host_us_per_layer": round(host / steps / L * 1e6, 2)}
+    # host cost proper: ONE step issued into an idle queue (in the back-to-back loop above the host runs ahead of the GPU - 25 us of kernel per
+    # layer - until the hardware queue is full, and its issue time then contains the waiting)
+    idle = []
+    for i in range(9):
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        fn(first + 2 + steps + i)
+        idle.append(time.perf_counter() - h0)
+    torch.cuda.synchronize()
+    idle.sort()
+    return {"ms_per_step": round(wall / steps * 1e3, 4), "host_us_per_layer": round(idle[len(idle) // 2] / L * 1e6, 2),
+            "host_us_per_layer_back_to_back": round(host / steps / L * 1e6, 2)}
 
 
 res = {"workload": f"FLUX.1-dev 1024^2, logical ring 8 looped back on one GPU, {args.codec} residual + error feedback, {L} layers, shard (544,3072), "
