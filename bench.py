@@ -9,33 +9,37 @@ ring-attention sequence parallelism of logical degree 8 with the 1-bit residual 
 57 attention layers x {K, V}, shard (N, C) = (544, 3072) fp16.  The step is replayed LAYER BY LAYER IN ORDER, the way a
 model runs it (layer l+1's K,V only exist after layer l's attention, reference xfuser/compact/ring.py:188-206): layer l+1's
 compress cannot start before layer l's reconstruction has finished (a kernel boundary), nothing is reordered across layers.
-Per layer, the collective in the path at every N:
-  A. compress K,V (k_absmean_compress: statistics + sign bits + in-launch finalize of the scales), the packets written straight
-     into the rank's slot of the gather buffer,
-  X. exchange the packets: ncclAllGather, in place, issued by libcfx's own RCCL communicator from the native plan
-     (N live ranks gather for real; the 8-N missing logical peers are looped back from the rank's own slot, so the per-GPU codec
-     work is IDENTICAL for every N = weak scaling; at N = 1 RCCL's one-rank in-place all-gather has nothing to move),
+Per layer:
+  A. compress K,V (k_absmean_compress: statistics + sign bits + in-launch finalize of the scales),
+  X. exchange the packets (N live ranks exchange for real; the 8-N missing logical peers are looped back from the rank's own packets, so the
+     per-GPU codec work is IDENTICAL for every N = weak scaling),
   B. reconstruct the 7 peers' K,V (14 tensors) onto their state arenas, and the rank's own error-feedback update.
-Default (--own-ef xgate --p2p auto), the same at every N: A and B are ONE launch on the run stream (the exchange-layer op): B's workgroups
-are launched with A's, pull their state tiles into registers while the scale reduction runs, and wait for a gate word.  X is NOT a
-collective: every rank's packets stay in IPC-shared memory of its own GPU (cfx_ipc_alloc), the peers' reconstruction workgroups read
-them in place over xGMI, and ONE small kernel per layer on the exchange stream waits for A's packets, publishes a word the live peers
-have mapped, waits for theirs and opens the gate (cfx_plan_add_exchange_layer_p2p).  At N = 1 there is no live peer: the same op,
-launches and kernels minus the remote reads and the waiting.  At N > 1 the first step is validated (gate timeouts, state consistency
-across ranks); on failure every rank switches to two launches around ncclAllGather (`schedule_fallback`).
+Default (--own-ef xgate --p2p auto) = WHAT THE PLUGIN API RUNS (compactfusion_amd/compact/xlayer.py: compact_fwd's gather schedule and
+compact_all_gather_kv issue this op, one native call per layer; `plugin_path` times the same step through that API): A and B are ONE launch on
+the run stream (the exchange-layer op, cfx_plan_add_exchange_layer_p2p): B's workgroups are launched with A's, pull their state tiles into
+registers while the scale reduction runs, and wait for a gate word.  X is NOT a collective: every rank's packets stay in UNCACHED IPC device
+memory of its own GPU (cfx_ipc_alloc), the peers' reconstruction workgroups read them in place over xGMI, and ONE one-wave kernel per layer on
+the exchange stream waits for A's packets, publishes a word the live peers have mapped, waits for theirs and opens the gate.  At N = 1 there is
+no live peer: the same op, launches and kernels minus the remote reads and the waiting - `value` at N = 1 prices the launch structure every N
+executes, not a wire.  At N > 1 the run is VALIDATED after the warm-up steps and again after the timed region (gate time-outs; every rank's
+reconstruction of a shard against its owner's state); on any failure every rank falls back IN-PROCESS - p2p -> compress ; ncclAllGather ;
+reconstruct in stream order -> torch.distributed per layer - re-runs warm-up and timed region, and `schedule_fallback` says which check tripped.
 `collective_in_the_path` (secondary at N = 1; --p2p off): the same launch with flag-wait kernel ; ncclAllGather (libcfx's own RCCL
 communicator, in place) ; flag-set kernel on the exchange stream.
 `two_launches_per_layer` (secondary at N = 1; --own-ef ride): A ; X ; B as two codec launches in stream order, the previous layer's
-own error-feedback update riding in A (nothing reads that state before the next denoise step, ring.py:207-209).
+own error-feedback update riding in A (nothing reads that state before the next denoise step, ring.py:207-209) - the fall-back schedule.
 `with_cu_partition` (secondary at N = 1): the default with the run stream masked to CUs [0, 224) and the exchange stream to [224, 256):
 any partial CU mask costs the layer launch ~5 us, so the streams are not partitioned.
 `loopback_one_launch_per_layer` (secondary, N = 1): the layer as ONE launch (cfx_compress_batch_gated: reconstruction behind an
 in-launch arrival gate) - only possible when the packets a reconstruction needs are produced by the same launch, i.e. with
-looped-back peers and NO collective in between; never `value`.
+looped-back peers and NO exchange in between; never `value`.
+`plugin_path` (N = 1): SURVEY 8d protocol 1 THROUGH THE PLUGIN API - the same 57-layer step issued by compact_all_gather_kv (what patch_gather_fwd
+calls) and by compact_fwd with a no-op attention, one native op per layer (tools/plugin_path_bench.py as a child process).
+`configs` (N = 1): every BASELINE.json configuration's step (tools/config_table.py): ms per step, algorithmic bytes, fraction of the HBM roofline.
 `low_rank_presets` (N = 1): compress time per K,V pair of the reference's LOW_RANK / LOW_RANK_Q presets on the same shard (one persistent
 launch each, csrc/cfx_lrslab.hip).
-`overlap_with_attention` (N = 1): SURVEY 8d protocol 2 - the deployable path (compact_fwd on the exchange lane) beside real SDPA
-attention: what the exchange adds to a model step (tools/overlap_bench.py, run as a child process after the timed legs).
+`overlap_with_attention` (N = 1): SURVEY 8d protocol 2 - compact_fwd on the exchange lane beside real SDPA attention: what the exchange adds
+to a model step (tools/overlap_bench.py as a child process); `exposed_exchange_ms_per_step` carries its figure at the top level.
 Inputs are synthetic and already resident in HBM; the state arenas (3.0 GB) + inputs (0.76 GB) dwarf the 256 MB
 Infinity Cache, so every step streams from HBM (cold numbers).
 
@@ -44,12 +48,11 @@ value = whole-job fp16 activation bytes compressed + reconstructed per second (G
 `pure_exchange_upper_bound` = the same step through cfx_plan_run_pipelined, which DOES reorder across layers (statistics of
         layers j+7.. beside the reconstruction of layers j..): only legal because the synthetic inputs of all layers are resident;
         a model cannot run it.  Reported as a secondary figure, never as `value`.
-roofline = the dominant kernel of the in-order step - launch B, k_binary_dequant, 4.125 B/element x the tensors of a launch
-         / average launch duration from hipEvents attached to the dispatch on the launch stream inside the timed
-        region; `roofline.compress_launch` = launch A against 6.125 B/element; `roofline.step` prices the WHOLE step
-        with 6.125 B/element for the rank's own tensors (compress + error feedback) and 4.125 for the peers'.
-cpu_baseline = the C oracle (oracle/cfx_oracle.c, OpenMP) timed on this box's host cores on one layer of the same
-        workload; reported baseline only.
+roofline = the dominant kernel of the in-order step - the layer's only codec launch, k_absmean_compress<bits,gated>: (2 x 6.125 + 14 x 4.125)
+        B/element x 544 x 3072 / its average duration from hipEvents on the run stream around every 4th step of the timed
+        region / launches per step; with two launches per layer it is launch B, k_binary_dequant; `roofline.step` prices the WHOLE step.
+cpu_baseline = the C oracle (oracle/cfx_oracle.c, OpenMP) timed on ALL host hardware threads of this box on one layer of the same
+        workload (`best_of_sweep`: the fastest thread count of a short sweep, beside it); reported baseline only.
 """
 from __future__ import annotations
 
@@ -1089,7 +1092,7 @@ def main():
                 "achieved": round(alga / (usa * 1e-6) / 1e9, 1), "frac": round(alga / (usa * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "latency-bound: a global reduction (scales) sits between reading K,V and the packet being complete"}
         # PMC traffic / rocprof cross-reference: only when the committed profile was taken with THIS configuration
-        prof = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
+        prof = os.path.join(REPO, "profiles", "r04_pmc_traffic.json")
         cfg_key = config_key(args, live)
         if os.path.exists(prof):
             try:
@@ -1097,14 +1100,14 @@ def main():
                 if pj.get("config") == cfg_key:
                     pk_ = "k_binary_pipe<true>" if pipelined else (("k_int2_compress_gated" if int2 else "k_absmean_compress<true, 4, true") if one_launch else "k_binary_dequant")
                     out["roofline"]["traffic"] = next((v for k_, v in pj["bytes_per_launch"].items() if k_.startswith(pk_)), None)
-                    out["roofline"]["traffic_source"] = ("profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes" +
+                    out["roofline"]["traffic_source"] = ("profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes" +
                                                          ("; " + pj["measured_with"] + ")" if pj.get("measured_with") else " of this command)"))
                     if pj.get("measured_with"):
                         out["roofline"]["step"]["traffic_source"] = "the same counter passes (loop-back form of the step: no flag kernels, no collective call)"
                     out["roofline"]["step"]["traffic"] = pj.get("bytes_per_step")
             except Exception:
                 pass
-        trace_json = os.path.join(REPO, "profiles", "r03_bench_kernel_durations.json")
+        trace_json = os.path.join(REPO, "profiles", "r04_bench_kernel_durations.json")
         if os.path.exists(trace_json):
             try:
                 tj = json.load(open(trace_json))
@@ -1114,7 +1117,7 @@ def main():
                     if ent:
                         out["roofline"]["avg_launch_us_rocprof"] = ent["avg_us"]
                         out["roofline"]["median_launch_us_rocprof"] = ent.get("median_us")
-                        out["roofline"]["rocprof_source"] = "profiles/r03_bench_kernel_durations.json (rocprofv3 --kernel-trace of this command)"
+                        out["roofline"]["rocprof_source"] = "profiles/r04_bench_kernel_durations.json (rocprofv3 --kernel-trace of this command)"
             except Exception:
                 pass
     else:
@@ -1265,7 +1268,7 @@ def main():
                 lr[name] = round(e0.elapsed_time(e1) / (3 * Lr) * 1e3, 1)
             out["low_rank_presets"] = {"us_per_kv_pair_compress": lr, "shard": [N, C],
                                        "what": "cfx_lr_compress_batch, one persistent launch per K,V pair (csrc/cfx_lrslab.hip) + the int4 factor quantiser "
-                                               "for LOW_RANK_Q; profiles/r03_lowrank_*"}
+                                               "for LOW_RANK_Q; profiles/r04_lowrank_*"}
         except Exception as e:  # pragma: no cover
             out["low_rank_presets"] = {"error": f"{type(e).__name__}: {e}"}
     try:
