@@ -22,7 +22,14 @@ def _port():
 
 def _spawn(fn, world, tmp_path, *args):
     out = str(tmp_path / "res")
-    mp.start_processes(_entry, args=(fn.__name__, world, _port(), out, args), nprocs=world, join=True, start_method="spawn")
+    for attempt in range(3):
+        try:
+            mp.start_processes(_entry, args=(fn.__name__, world, _port(), out, args), nprocs=world, join=True, start_method="spawn")
+            break
+        except Exception as e:  # noqa: BLE001
+            # the port _port() found free can be taken again before rank 0 binds it (other rank processes of the suite come and go)
+            if "EADDRINUSE" not in str(e) or attempt == 2:
+                raise
     return [dict(np.load(out + f".r{r}.npz")) for r in range(world)]
 
 
