@@ -1295,8 +1295,12 @@ __device__ __forceinline__ void int2_dequant_gated_body(const cfx_decomp_item& i
 #pragma unroll
         for (int j = 0; j < KR; ++j) bv[j] = (h16x8)(h16)0;
     }
+#ifdef CFX_EXP_INT2_DWAIT
+    gate_wait(gate, expect, err);
+#else
     if (xgate) gate_wait<true>(xgate, xexpect, err);
     else gate_wait(gate, expect, err);
+#endif
     h16x8 ch8;
     u16 ul;
     u16 cd[K];
@@ -3049,7 +3053,11 @@ bool cfx_i_shape_ok(int codec, int N, int C, int param) { return shape_ok(codec,
 // (the 2-bit layer launch CAN wait on an external gate too - k_int2_compress_gated's group D takes one - but measured 2.44 ms per FLUX step
 // against 2.03 for its three launches in stream order: 18.7 us instead of 11 between the gate and the end of the launch; until that is
 // understood the 2-bit exchange layer runs in stream order)
+#ifdef CFX_EXP_INT2_XLAYER
+bool cfx_i_has_xlayer_form(int codec) { return codec >= CFX_CODEC_BINARY && codec <= CFX_CODEC_INT8; }
+#else
 bool cfx_i_has_xlayer_form(int codec) { return codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT4 || codec == CFX_CODEC_INT8; }
+#endif
 unsigned* cfx_i_ticket_block(cfx_ctx* ctx, void* stream) {
     if (!ctx->tick && cfx_prepare(ctx) != CFX_OK) return nullptr;
     return ctx->tick + (size_t)ticket_slot(ctx, stream) * CFX_MAX_BATCH * TICK_WORDS;
