@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--layers", type=int, default=L_LAYERS, help="debug only; the judged workload uses 57")
     ap.add_argument("--rows", type=int, default=0, help="rows per tile override (0 = auto)")
+    ap.add_argument("--int2-xlayer", action="store_true", help="debug: build the 2-bit step from exchange-layer ops too (the library runs them in stream "
+                    "order unless it was built with -DCFX_EXP_INT2_XLAYER)")
     ap.add_argument("--stats-rows", type=int, default=0, help="debug: statistics tile height of the compress launches (cfx_set_stats_rows; 0 = auto)")
     ap.add_argument("--replay", choices=["inorder", "pipelined"], default="inorder",
                     help="inorder (default, the deployable schedule): cfx_plan_run, two launches per layer one after the other; "
@@ -421,7 +423,7 @@ def main():
         rc = lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, len(items), darr)
         assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
 
-    xgate = (args.own_ef == "xgate" and not pipelined and not int2 and use_dist and not relay and args.exchange == "native")
+    xgate = (args.own_ef == "xgate" and not pipelined and (not int2 or args.int2_xlayer) and use_dist and not relay and args.exchange == "native")
     if args.own_ef == "xgate" and not xgate:
         args.own_ef = "ride"
     ride = args.own_ef in ("ride", "gated")

@@ -1295,12 +1295,8 @@ __device__ __forceinline__ void int2_dequant_gated_body(const cfx_decomp_item& i
 #pragma unroll
         for (int j = 0; j < KR; ++j) bv[j] = (h16x8)(h16)0;
     }
-#ifdef CFX_EXP_INT2_DWAIT
-    gate_wait(gate, expect, err);
-#else
     if (xgate) gate_wait<true>(xgate, xexpect, err);
     else gate_wait(gate, expect, err);
-#endif
     h16x8 ch8;
     u16 ul;
     u16 cd[K];
@@ -3050,9 +3046,10 @@ int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base
 // ---- entry points for cfx_plan.hip (plan replay, exchange lane) ------------------------------------------------------------
 }  // extern "C"
 bool cfx_i_shape_ok(int codec, int N, int C, int param) { return shape_ok(codec, N, C, param); }
-// (the 2-bit layer launch CAN wait on an external gate too - k_int2_compress_gated's group D takes one - but measured 2.44 ms per FLUX step
-// against 2.03 for its three launches in stream order: 18.7 us instead of 11 between the gate and the end of the launch; until that is
-// understood the 2-bit exchange layer runs in stream order)
+// (the 2-bit layer launch CAN wait on an external gate too - k_int2_compress_gated's group D takes one; build with -DCFX_EXP_INT2_XLAYER
+// and run bench.py --codec int2 --int2-xlayer - but it measured 2.41-2.46 ms per FLUX step against 2.03 for its three launches in stream
+// order and 2.01 for the loop-back one-launch form of the SAME kernel, also with group D waiting on the codes gate itself: the launch lasts
+// 42 us instead of 35 whenever the exchange stream's kernel runs beside it; not understood, so the 2-bit exchange layer runs in stream order)
 #ifdef CFX_EXP_INT2_XLAYER
 bool cfx_i_has_xlayer_form(int codec) { return codec >= CFX_CODEC_BINARY && codec <= CFX_CODEC_INT8; }
 #else
