@@ -8,6 +8,8 @@ must hide under the local attention block).  Legs, all on the same inputs:
   lane           compact_fwd on the EXCHANGE LANE (the default): the model on the lane's CU-masked compute stream (224 CUs), the layer's
                  whole chain - compress, all-gather, per-peer reconstruction - on the CU-masked exchange stream (32 CUs), ordered only
                  by flags in device memory (cfx_plan_run_lane + cfx_attn_merge_wait: one host call per layer for the exchange)
+  layer_op       the default off the lane (round 4): the layer's exchange as ONE native op (compact/xlayer.py: one codec launch gated on the
+                 packets' arrival) on the model's own stream, in front of the local attention block - nothing overlaps, one launch per layer
   lane_unmasked  the same flags, but the model on an ordinary stream and the chain on an unmasked exchange stream
   native         round 2's schedule: the chain on the exchange stream, forked and joined with EVENTS (cfx_plan_run_async + cfx_plan_join)
   native_gather_only_on_side   as round 1 scheduled it: compress and reconstruction on the compute stream, only the collective beside
@@ -154,7 +156,7 @@ def timed(fn, first):
 
 from compactfusion_amd import lanes
 comp_stream = lanes.compute_stream(0)
-ALL = ["attention_on_compute_lane", "lane", "attention_distinct_kv_on_compute_lane", "attention", "lane_unmasked", "native", "native_gather_only_on_side", "torchdist"]
+ALL = ["attention_on_compute_lane", "lane", "attention_distinct_kv_on_compute_lane", "attention", "layer_op", "lane_unmasked", "native", "native_gather_only_on_side", "torchdist"]
 legs = [x for x in (args.legs.split(",") if args.legs else ALL) if x]
 assert all(x in ALL for x in legs), f"legs must be among {ALL}"
 if args.quick:
@@ -182,6 +184,18 @@ for leg in legs:
     elif leg == "attention":
         attention_only(0); torch.cuda.synchronize()
         res[leg] = timed(attention_only, 0)
+    elif leg == "layer_op":
+        # the default OFF the lane (round 4): ONE native op per layer (compact/xlayer.py) on the model's stream, in front of the local block;
+        # packets in the uncached IPC arena, the 8 logical ranks looped back
+        from compactfusion_amd.compact import xlayer
+        xlayer.set_p2p_loopback(True)
+        init("native", "xlayer")
+        assert all(ex.xop is not None and ex.xop.transport == "p2p" for ex in ring._xbuf.values() if ex.sig is not None)
+        res[leg] = timed(fwd, 3)
+        for ex in ring._xbuf.values():
+            ex.close()
+        ring._xbuf.clear(); ring._steady.clear()
+        xlayer.set_p2p_loopback(False)
     elif leg == "lane_unmasked":
         init("native", "lane")
         res[leg] = timed(fwd, 3)
