@@ -84,8 +84,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--layers", type=int, default=L_LAYERS, help="debug only; the judged workload uses 57")
     ap.add_argument("--rows", type=int, default=0, help="rows per tile override (0 = auto)")
-    ap.add_argument("--int2-xlayer", action="store_true", help="debug: build the 2-bit step from exchange-layer ops too (the library runs them in stream "
-                    "order unless it was built with -DCFX_EXP_INT2_XLAYER)")
+    ap.add_argument("--ipc-memory", type=int, default=2, choices=[0, 1, 2],
+                    help="debug: what cfx_ipc_alloc asks for first: 2 uncached (default), 1 fine-grained, 0 ordinary device memory")
     ap.add_argument("--stats-rows", type=int, default=0, help="debug: statistics tile height of the compress launches (cfx_set_stats_rows; 0 = auto)")
     ap.add_argument("--replay", choices=["inorder", "pipelined"], default="inorder",
                     help="inorder (default, the deployable schedule): cfx_plan_run, two launches per layer one after the other; "
@@ -230,7 +230,7 @@ def config_key(args, n_gpus):
     """What a committed profile must have been taken with for its figures to be quoted beside this run's."""
     pipelined = args.replay == "pipelined"
     own_ef = args.own_ef
-    if own_ef == "xgate" and (args.codec != "binary" or args.no_collective or args.exchange != "native" or args.exchange_pattern == "relay"):
+    if own_ef == "xgate" and ((args.codec != "binary" and args.p2p != "auto") or args.no_collective or args.exchange != "native" or args.exchange_pattern == "relay"):
         own_ef = "ride"
     return {"codec": args.codec, "replay": args.replay, "own_ef": own_ef if not pipelined else None, "layers": args.layers,
             "shard": [N_TOK, C_CH], "rows": args.rows, "n_gpus": n_gpus, "collective": not args.no_collective,
@@ -288,6 +288,8 @@ def main():
         K.set_rows_per_tile(args.rows, local_rank)
     if args.stats_rows:
         assert lib.cfx_set_stats_rows(ctx, args.stats_rows) == 0
+    if args.ipc_memory != 2:
+        assert lib.cfx_set_ipc_memory_kind(ctx, args.ipc_memory) == 0
 
     L, N, C = args.layers, N_TOK, C_CH
     CODEC = int(K.Codec.INT2 if int2 else K.Codec.BINARY)
@@ -423,7 +425,9 @@ def main():
         rc = lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, len(items), darr)
         assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
 
-    xgate = (args.own_ef == "xgate" and not pipelined and (not int2 or args.int2_xlayer) and use_dist and not relay and args.exchange == "native")
+    # (2-bit: one launch per layer only in the peer-to-peer form, where the exchange runs inside the launch; beside an exchange stream's kernel
+    # its layer launch is slower than three launches in stream order)
+    xgate = (args.own_ef == "xgate" and not pipelined and (not int2 or args.p2p == "auto") and use_dist and not relay and args.exchange == "native")
     if args.own_ef == "xgate" and not xgate:
         args.own_ef = "ride"
     ride = args.own_ef in ("ride", "gated")

@@ -58,6 +58,7 @@ SYMBOLS = [
     ("cfx_hw_queues_ok", ctypes.c_int, []),
     ("cfx_set_allow_shared_queues", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_ipc_memory_kind", ctypes.c_int, [ctypes.c_void_p]),
+    ("cfx_set_ipc_memory_kind", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_plan_set_pipe_unit_layers", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_compress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

@@ -317,7 +317,7 @@ class LayerOp:
         wsp, wsn = (None, 0) if ws is None else (ws.data_ptr(), ws.numel())
         keep = [ws]
         t = self.transport
-        if t in ("p2p", "rccl"):
+        if t == "rccl":          # (the peer-to-peer form runs its exchange inside the layer launch: no second stream)
             xs = _exchange_stream(self.dev, beside_null_stream=(sh == 0))
             keep.append(xs)
             self._check(lib.cfx_plan_use_exchange_stream(plan, xs.cuda_stream) == 0, "exchange stream")
@@ -374,6 +374,10 @@ class LayerOp:
             ent = self._build(sh)
         t = self.transport
         if t == "p2p":
+            if not self.arena.ok:              # another layer of the group failed its validation: every layer leaves p2p (all ranks alike)
+                self.fallback_reason = self.arena.why
+                self._choose_transport(exclude=("p2p",))
+                return self.run(k, v, sh)
             reg = self.region
             if reg.validated < 2 and not self.arena.loopback:
                 return self._run_validated(k, v, sh)

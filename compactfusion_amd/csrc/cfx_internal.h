@@ -63,6 +63,7 @@ struct cfx_ctx {
     int lr_chain, lr_decode;        // cfx_set_lr_chain / cfx_set_lr_decode (0 = automatic)
     int dev_probe;                  // cfx_set_dev_probe (developer builds)
     int allow_shared_queues;        // cfx_set_allow_shared_queues: flag-ordered streams even when cfx_hw_queues_ok() == 0
+    int ipc_want;                   // cfx_set_ipc_memory_kind: what cfx_ipc_alloc asks for first (2 uncached - default -, 1 fine-grained, 0 ordinary)
     int ipc_kind;                   // what the last cfx_ipc_alloc returned: 2 uncached, 1 fine-grained, 0 ordinary device memory
     // hand-over arenas of the slab-resident low-rank chain: one per stream that launches it (zeroed when allocated and whenever the
     // shape it is laid out for changes: its words carry sequence tags that only make sense against what the chain itself wrote)
@@ -155,8 +156,11 @@ struct cfx_comm {
 // the gated reconstruction group proceeds once *f_gate == f_expect
 // needs_room (in): a collective kernel will run while the reconstruction group waits - take the one-launch form only if the group leaves it CUs
 // p_count: the packets are complete once the p_count CONSECUTIVE words at p_gate have all reached p_expect (1: one counter word)
+// p2p_own (in): the peer-to-peer exchange runs INSIDE the launch (workgroup 0 publishes p2p_own, awaits the p2p_n words p2p_peer[], opens the
+// gate); inline_done (out): the launch does that - nothing to launch on an exchange stream
 struct CfxXGate { int taken; unsigned* p_gate; unsigned p_expect; int p_count; unsigned* f_gate; unsigned f_expect; int needs_room;
-                  int remote; };    // remote (in): the reconstruction items' packets may sit in a peer GPU's memory
+                  int remote;      // remote (in): the reconstruction items' packets may sit in a peer GPU's memory
+                  unsigned* p2p_own; const unsigned* const* p2p_peer; int p2p_n; int inline_done; };
 struct PlanOp {
     int kind;   // 0 compress, 1 decompress, 2 all-gather on the side stream, 3 main stream waits for gather op `ref`, 4 ring hop,
                 // 5 wait until flag `ref` has reached the plan's epoch, 6 set flag `ref` to the epoch,

@@ -1041,6 +1041,48 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
 #undef STAMP
 }
 
+// The peer-to-peer exchange INSIDE the layer launch (cfx_plan_add_exchange_layer_p2p, one-launch form): workgroup 0 of the launch, once its own
+// tile work is done, waits until the launch's packets are complete, publishes this rank's word for the layer (own word + 1, taken on the
+// device), waits for the peers' words and opens the launch's external gate - what a one-wave kernel on an exchange stream did before.  No
+// second launch, no second stream, no hardware-queue requirement; and a resident polling kernel on another queue - harmless to the 1-bit
+// launch - cost the 2-bit layer launch 4 us per layer (tools/xgate_probe.py: gated 2.02 ms per step, the same beside a poller 2.27).
+struct P2PInline {
+    unsigned* own;                               // NULL: no in-launch exchange
+    const unsigned* peer[CFX_P2P_MAX_PEERS];
+    int n_peers;
+    long long timeout;
+};
+__device__ __forceinline__ unsigned ld_sys32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// p_count consecutive words at p_gate must all have reached p_expect (1: one counter / "open" word)
+__device__ __forceinline__ void p2p_exchange_inline(const unsigned* p_gate, unsigned p_expect, int p_count, const P2PInline& p,
+                                                    unsigned* f_gate, unsigned f_expect, unsigned* err) {
+    if ((threadIdx.x >> 6) != 0) return;        // one wave
+    const int lane = threadIdx.x & 63;
+    const long long t0 = wall_clock64();
+    unsigned epoch = 0;
+    if (lane == 0) epoch = ld_sys32(p.own) + 1u;                 // (read before the wait: only this launch writes it)
+    bool gave_up = false;
+    for (;;) {
+        bool behind = false;
+        for (int i = lane; i < p_count; i += 64) behind |= (int)(ld_wt(p_gate + i) - p_expect) < 0;
+        if (__builtin_amdgcn_ballot_w64(behind) == 0) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > p.timeout) { gave_up = true; break; }
+    }
+    // the packets were stored write-through and drained before they were counted complete: publishing after having SEEN that orders them
+    // before the word for anybody who reads the word first
+    if (lane == 0) __hip_atomic_store(p.own, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    epoch = (unsigned)__builtin_amdgcn_readfirstlane((int)epoch);
+    if (lane < p.n_peers) {
+        while ((int)(ld_sys32(p.peer[lane]) - epoch) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > p.timeout) { gave_up = true; break; }
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(gave_up) != 0 && lane == 0) gate_fail(err);
+    if (lane == 0) st_wt(f_gate, f_expect);
+}
+
 struct FusedArgs {
     int N, C, CB, R, P;      // statistics tiles: CB x P per tensor, R rows each
     int n_st;                // workgroups of the statistics group (CB * P * batch); the rest reconstruct `ride`
@@ -1062,6 +1104,7 @@ struct FusedArgs {
     unsigned* xgate;
     unsigned xexpect;
     int remote;              // the gated items' packets may sit in a peer GPU's memory (read with system-scope loads)
+    P2PInline p2p;           // own != NULL: workgroup 0 runs the peer-to-peer exchange and opens xgate itself
 };
 #ifndef GATE_WPE
 #define GATE_WPE 4               // waves per SIMD the single-launch compress kernels are compiled for (2 workgroups / CU)
@@ -1077,6 +1120,9 @@ __global__ __launch_bounds__(FUSED_NT, GATE_WPE) void k_absmean_compress(BatchC 
         absmean_fused_body<EMIT_BITS, US, GATED>(batch.it[z], a.N, a.C, a.R, a.CB, a.P, rem - by * a.CB, by, a.ws + (size_t)z * a.ws_stride,
                                                  a.tick + z * TICK_WORDS, a.per_byte, a.eps_mode, sm, a.dbg,
                                                  a.stamps ? a.stamps + (size_t)b * 16 : nullptr, a.gate, a.gate_expect, 0, nullptr, 0u, a.gate_err);
+        if constexpr (GATED) {
+            if (b == 0 && a.p2p.own) p2p_exchange_inline(a.gate, a.gate_expect, 1, a.p2p, a.xgate, a.xexpect, a.gate_err);
+        }
         return;
     }
     if constexpr (EMIT_BITS) {
@@ -1341,6 +1387,7 @@ struct Int2LayerArgs {
     unsigned* err;
     unsigned* xgate; unsigned xexpect;     // external gate for group D (exchange-layer op): NULL = group D waits on gate2
     int remote;                            // group D's packets may sit in a peer GPU's memory
+    P2PInline p2p;                         // own != NULL: workgroup 0 runs the peer-to-peer exchange and opens xgate itself
 };
 template <int US>
 __global__ __launch_bounds__(FUSED_NT, 4) void k_int2_compress_gated(BatchC batch, BatchD gated, Int2LayerArgs a) {
@@ -1352,6 +1399,8 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_int2_compress_gated(BatchC batc
         const int by = rem / a.CB;
         absmean_fused_body<false, US, true, true>(batch.it[z], a.N, a.C, a.R, a.CB, a.P, rem - by * a.CB, by, a.ws + (size_t)z * a.ws_stride,
                                                   a.tick + z * TICK_WORDS, 4, 1, sm, 0, nullptr, a.gate1, a.expect1, a.flags, a.gate2, a.expect2, a.err);
+        // (packets complete = the codes gate's last arriver has written the "open" words: XCD 0's)
+        if (b == 0 && a.p2p.own) p2p_exchange_inline(a.gate2 + 1 * GATE_LINE, a.expect2, 1, a.p2p, a.xgate, a.xexpect, a.err);
         return;
     }
     b -= a.n_st;
@@ -1559,6 +1608,7 @@ struct MinMaxLayerArgs {
     unsigned* err;
     int remote;
     signed char src[CFX_MAX_BATCH];   // gated item -> the own tensor whose packet it reads (loop-back forms)
+    P2PInline p2p;                    // own != NULL: workgroup 0 runs the peer-to-peer exchange and opens xgate itself
 };
 // codes of 8 channels of one row (int8) / one row pair (int4), exactly as k_int8_quant / k_int4_quant compute them
 __device__ __forceinline__ u64 int8_codes(h16x8 d, h16x8 sc, h16x8 zp) {
@@ -1871,6 +1921,7 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_minmax_layer(BatchC batch, Batc
         const int z = b / per, rem = b - z * per;
         const int by = rem / a.CB;
         minmax_layer_s_tile<INT4, RW>(batch.it[z], a, z, rem - by * a.CB, by, sm);
+        if (b == 0 && a.p2p.own) p2p_exchange_inline(a.codedone, a.seq, a.n_st, a.p2p, a.xgate, a.xexpect, a.err);     // packets complete = every S tile's codes flag
         return;
     }
     b -= a.n_st;
@@ -2351,6 +2402,7 @@ cfx_ctx* cfx_create(int device) {
     c->dev_probe = 0;
     c->allow_shared_queues = 0;
     c->ipc_kind = 0;
+    c->ipc_want = 2;
     c->err[0] = 0;
     return c;
 }
@@ -2665,10 +2717,21 @@ static unsigned ticket_slot(cfx_ctx* ctx, void* stream) {
 // this call's packets are complete.  If the one-launch form is possible, the gated group waits on an external gate word and *xg
 // says what to wait for (packets complete: counter p_gate has reached p_expect) and what to set afterwards (f_gate = f_expect);
 // otherwise only the compress part is launched, xg->taken stays false and the caller reconstructs after its collective.
+// peer-to-peer exchange layer: the launch itself publishes / awaits the flag words (P2PInline) - the caller launches nothing else
+static void fill_p2p(cfx_ctx* ctx, CfxXGate* xg, P2PInline& p) {
+    memset(&p, 0, sizeof(p));
+    if (!xg->p2p_own) return;
+    p.own = xg->p2p_own;
+    p.n_peers = xg->p2p_n;
+    for (int i = 0; i < xg->p2p_n; ++i) p.peer[i] = xg->p2p_peer[i];
+    p.timeout = ctx->gate_timeout;
+    xg->inline_done = 1;
+}
+
 static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                          int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
                          void* workspace, size_t workspace_bytes, void* stream, CfxXGate* xg = nullptr) {
-    if (xg) { const int room = xg->needs_room, rem = xg->remote; memset(xg, 0, sizeof(*xg)); xg->needs_room = room; xg->remote = rem; xg->p_count = 1; }
+    if (xg) { xg->taken = 0; xg->inline_done = 0; xg->p_gate = xg->f_gate = nullptr; xg->p_expect = xg->f_expect = 0; xg->p_count = 1; }
     if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "compress: null ctx/items");
     if (n_gated < 0 || n_gated > CFX_MAX_BATCH || (n_gated && !gated)) return fail(ctx, CFX_ERR_BATCH, "compress: gated batch out of range");
     if (n_gated && codec == CFX_CODEC_TOPK)
@@ -2800,6 +2863,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                 a.xgate = a.gate1 + 2 * GATE_BLOCK;
                 a.xexpect = ++ctx->gate_expect[3 * slot + 2];
                 a.remote = xg->remote;
+                fill_p2p(ctx, xg, a.p2p);
                 xg->taken = 1;
                 xg->p_gate = a.gate2 + 1 * GATE_LINE;      // the word the codes gate's last arriver writes for XCD 0
                 xg->p_expect = a.expect2;
@@ -2844,6 +2908,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                     a.xgate = a.gate + GATE_BLOCK;                    // the slot's second gate block (the 2-bit layer launch's gate 2)
                     a.xexpect = ++ctx->gate_expect[3 * slot + 1];
                     a.remote = xg->remote;
+                    fill_p2p(ctx, xg, a.p2p);
                     xg->taken = 1;
                     xg->p_gate = a.gate; xg->p_expect = a.gate_expect;
                     xg->f_gate = a.xgate; xg->f_expect = a.xexpect;
@@ -2949,6 +3014,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                 a.xgate = ctx->gate + (size_t)slot * GATE_STRIDE + GATE_BLOCK;
                 a.xexpect = ++ctx->gate_expect[3 * slot + 1];
                 a.remote = xg->remote;
+                fill_p2p(ctx, xg, a.p2p);
                 xg->taken = 1;
                 xg->p_gate = a.codedone; xg->p_expect = a.seq; xg->p_count = (int)n_st;      // "packets complete" = every S tile's codes flag
                 xg->f_gate = a.xgate; xg->f_expect = a.xexpect;
@@ -3046,15 +3112,10 @@ int cfx_decompress(cfx_ctx* ctx, int codec, const void* packet, const void* base
 // ---- entry points for cfx_plan.hip (plan replay, exchange lane) ------------------------------------------------------------
 }  // extern "C"
 bool cfx_i_shape_ok(int codec, int N, int C, int param) { return shape_ok(codec, N, C, param); }
-// (the 2-bit layer launch CAN wait on an external gate too - k_int2_compress_gated's group D takes one; build with -DCFX_EXP_INT2_XLAYER
-// and run bench.py --codec int2 --int2-xlayer - but it measured 2.41-2.46 ms per FLUX step against 2.03 for its three launches in stream
-// order and 2.01 for the loop-back one-launch form of the SAME kernel, also with group D waiting on the codes gate itself: the launch lasts
-// 42 us instead of 35 whenever the exchange stream's kernel runs beside it; not understood, so the 2-bit exchange layer runs in stream order)
-#ifdef CFX_EXP_INT2_XLAYER
+// The 2-bit layer launch takes the external gate too (k_int2_compress_gated's group D).  With the exchange as a one-wave kernel on an exchange
+// stream it measured 2.40-2.46 ms per FLUX step against 2.03 for three launches in stream order - a resident polling kernel on another queue
+// alone costs that launch 4 us per layer (tools/xgate_probe.py, kind gated+poller) -; with the exchange INSIDE the launch (P2PInline) 2.11.
 bool cfx_i_has_xlayer_form(int codec) { return codec >= CFX_CODEC_BINARY && codec <= CFX_CODEC_INT8; }
-#else
-bool cfx_i_has_xlayer_form(int codec) { return codec == CFX_CODEC_BINARY || codec == CFX_CODEC_INT4 || codec == CFX_CODEC_INT8; }
-#endif
 unsigned* cfx_i_ticket_block(cfx_ctx* ctx, void* stream) {
     if (!ctx->tick && cfx_prepare(ctx) != CFX_OK) return nullptr;
     return ctx->tick + (size_t)ticket_slot(ctx, stream) * CFX_MAX_BATCH * TICK_WORDS;

@@ -98,9 +98,11 @@ __global__ void k_flag_exchange(const unsigned* p_gate, unsigned p_expect, int p
     const long long t0 = wall_clock64();
     bool gave_up = false;
     unsigned epoch = 0;
+    // (the own word is read BEFORE the wait: only this kernel writes it, and a system-scope load of uncached memory is a microsecond that
+    // would otherwise sit between "packets complete" and "gate open")
+    if (lane == 0) epoch = __hip_atomic_load(own_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
     if (p_gate) gave_up = wave_wait_words(p_gate, p_expect, p_count, t0, timeout);
     if (lane == 0) {
-        epoch = __hip_atomic_load(own_pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
         if (p_gate) {
             // one-launch form: the packets were stored WRITE-THROUGH and their stores had completed before the last arrival was counted:
             // publishing after having SEEN the count orders them before the word for anybody who reads the word first - no release fence
@@ -295,14 +297,24 @@ int cfx_plan_add_lr_decompress(cfx_plan* p, int quantized, int N, int C, int ran
 // ring.py:188-206 + 265-269, patchpara/fwd.py:108-137).  The reconstruction workgroups are launched WITH the compress group: they pull
 // their state tiles into registers while the statistics chain and the collective run, and continue when the exchange stream - which
 // waits for the launch's packets, issues the collective and then sets the launch's external gate - says the packets have arrived.
+static int add_exchange_layer(cfx_plan* p, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                              int n_recon, const cfx_decomp_item* recon, cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank,
+                              void* workspace, size_t workspace_bytes, bool need_side);
 int cfx_plan_add_exchange_layer(cfx_plan* p, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                                 int n_recon, const cfx_decomp_item* recon, cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank,
                                 void* workspace, size_t workspace_bytes) {
+    return add_exchange_layer(p, codec, N, C, param, flags, batch, items, n_recon, recon, comm, send, recv, bytes_per_rank, workspace, workspace_bytes, true);
+}
+// need_side: the op's exchange runs on the plan's exchange stream (a collective, or the gate relay) - the peer-to-peer form runs it inside
+// the launch and needs none
+static int add_exchange_layer(cfx_plan* p, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
+                              int n_recon, const cfx_decomp_item* recon, cfx_comm* comm, const void* send, void* recv, size_t bytes_per_rank,
+                              void* workspace, size_t workspace_bytes, bool need_side) {
     if (!p) return CFX_ERR_NULL;
     if (n_recon < 1 || n_recon > CFX_MAX_BATCH || !recon) return fail(p->ctx, CFX_ERR_BATCH, "plan: exchange layer needs 1..CFX_MAX_BATCH reconstruction items");
     if (codec < CFX_CODEC_BINARY || codec > CFX_CODEC_TOPK) return fail(p->ctx, CFX_ERR_CODEC, "plan: exchange layer: unknown codec");
     if (comm && (!send || !recv)) return fail(p->ctx, CFX_ERR_NULL, "plan: exchange layer: null send/recv");
-    if (!p->side) {
+    if (!p->side && need_side) {
         // the flag kernels poll: they need a hardware queue of their own (cfx.h, exchange lane) - a CU-masked stream has one
         void* xs = nullptr;
         int total = 0;
@@ -334,7 +346,7 @@ int cfx_plan_add_exchange_layer_p2p(cfx_plan* p, int codec, int N, int C, int pa
         return fail(p->ctx, CFX_ERR_BATCH, "plan: p2p exchange layer needs an own flag and 0..CFX_P2P_MAX_PEERS peer flags");
     for (int i = 0; i < n_peers; ++i)
         if (!peer_flags[i] || ((uintptr_t)peer_flags[i] & 3)) return fail(p->ctx, CFX_ERR_NULL, "plan: p2p exchange layer: null / misaligned peer flag");
-    const int op = cfx_plan_add_exchange_layer(p, codec, N, C, param, flags, batch, items, n_recon, recon, nullptr, nullptr, nullptr, 0, workspace, workspace_bytes);
+    const int op = add_exchange_layer(p, codec, N, C, param, flags, batch, items, n_recon, recon, nullptr, nullptr, nullptr, 0, workspace, workspace_bytes, false);
     if (op < 0) return op;
     PlanOp* o = &p->ops[op];
     o->kind = 10;
@@ -389,10 +401,11 @@ int cfx_ipc_alloc(cfx_ctx* ctx, size_t bytes, void** ptr, void* handle64) {
     // a reader's L2 may keep last step's lines.  So the buffer is UNCACHED device memory (what RCCL allocates for the buffers its kernels
     // exchange through on gfx94x / gfx950), else fine-grained, else - with a note in the context - ordinary memory; the device code
     // uses write-through stores on the producer and system-scope loads on the readers whatever the kind.
-    int kind = 2;
-    hipError_t e = hipExtMallocWithFlags(&d, bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess) { (void)hipGetLastError(); d = nullptr; kind = 1; e = hipExtMallocWithFlags(&d, bytes, hipDeviceMallocFinegrained); }
-    if (e != hipSuccess) { (void)hipGetLastError(); d = nullptr; kind = 0; e = hipMalloc(&d, bytes); }
+    int kind = ctx->ipc_want;
+    hipError_t e = hipErrorUnknown;
+    if (kind == 2) { e = hipExtMallocWithFlags(&d, bytes, hipDeviceMallocUncached); if (e != hipSuccess) { (void)hipGetLastError(); d = nullptr; kind = 1; } }
+    if (kind == 1) { e = hipExtMallocWithFlags(&d, bytes, hipDeviceMallocFinegrained); if (e != hipSuccess) { (void)hipGetLastError(); d = nullptr; kind = 0; } }
+    if (kind == 0) e = hipMalloc(&d, bytes);
     if (e != hipSuccess) { (void)hipGetLastError(); rc = fail(ctx, CFX_ERR_LAUNCH, "ipc_alloc: device allocation failed"); }
     else if (hipMemset(d, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipIpcGetMemHandle(&h, d) != hipSuccess) {
         (void)hipGetLastError();
@@ -403,6 +416,12 @@ int cfx_ipc_alloc(cfx_ctx* ctx, size_t bytes, void** ptr, void* handle64) {
     return rc;
 }
 int cfx_ipc_memory_kind(cfx_ctx* ctx) { return ctx ? ctx->ipc_kind : CFX_ERR_NULL; }
+int cfx_set_ipc_memory_kind(cfx_ctx* ctx, int kind) {
+    if (!ctx) return CFX_ERR_NULL;
+    if (kind < 0 || kind > 2) return fail(ctx, CFX_ERR_BATCH, "ipc memory kind must be 2 (uncached), 1 (fine-grained) or 0 (ordinary device memory)");
+    ctx->ipc_want = kind;
+    return CFX_OK;
+}
 int cfx_ipc_open(cfx_ctx* ctx, const void* handle64, void** ptr) {
     if (!ctx || !ptr || !handle64) return fail(ctx, CFX_ERR_NULL, "ipc_open: null");
     int cur = -1;
@@ -600,9 +619,11 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                 // two (cfx_hw_queues_ok).  The legacy NULL stream serialises with every BLOCKING stream - a CU-masked exchange stream is one:
                 // its flag kernel would wait for the very launch it is meant to release - so beside the NULL stream only a non-blocking
                 // exchange stream will do.  Everything else runs the same work in order on the run stream: compress ; exchange ; reconstruct.
-                bool own_stream = p->side && (hipStream_t)stream != p->side && !inline_exchange && cfx_i_has_xlayer_form(o->codec) &&
-                                  (cfx_hw_queues_ok() || p->ctx->allow_shared_queues);
-                if (own_stream && stream == nullptr) {
+                // (the peer-to-peer form needs NO second stream: workgroup 0 of the launch publishes / awaits the flag words itself)
+                const bool inline_p2p = o->kind == 10 && cfx_i_has_xlayer_form(o->codec);
+                bool own_stream = inline_p2p || (p->side && (hipStream_t)stream != p->side && !inline_exchange && cfx_i_has_xlayer_form(o->codec) &&
+                                                 (cfx_hw_queues_ok() || p->ctx->allow_shared_queues));
+                if (own_stream && !inline_p2p && stream == nullptr) {
                     unsigned sf = 0;
                     if (hipStreamGetFlags(p->side, &sf) != hipSuccess) { (void)hipGetLastError(); sf = 0; }
                     own_stream = (sf & hipStreamNonBlocking) != 0;
@@ -611,6 +632,7 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                 memset(&xg, 0, sizeof(xg));
                 xg.needs_room = o->comm && o->comm->nranks > 1;
                 xg.remote = o->kind == 10 && o->n_peers > 0;
+                if (inline_p2p) { xg.p2p_own = o->own_flag; xg.p2p_peer = o->peer_flag; xg.p2p_n = o->n_peers; }
                 if (own_stream) {
                     rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, 0, nullptr, o->n_gated, o->g, o->ws, o->ws_bytes, stream, &xg);
                 } else if (o->kind == 9 && !o->comm && o->codec != CFX_CODEC_TOPK) {
@@ -636,7 +658,9 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                     break;
                 }
                 // one launch: what sits on the exchange stream between "packets complete" and "packets arrived"
-                if (o->kind == 10) {
+                if (xg.inline_done) {
+                    // nothing: the launch runs the peer-to-peer exchange itself
+                } else if (o->kind == 10) {
                     rc = launch_flag_exchange(p, o, p->side, xg.p_gate, xg.p_expect, xg.p_count, xg.f_gate, xg.f_expect, "p2p exchange layer: flag exchange launch");
                 } else if (!o->comm) {
                     hipLaunchKernelGGL(k_flag_relay, dim3(1), dim3(64), 0, p->side, (const unsigned*)xg.p_gate, xg.p_expect, xg.p_count, xg.f_gate, xg.f_expect,

@@ -333,6 +333,7 @@ int       cfx_plan_add_p2p_sync(cfx_plan* plan, void* own_flag, int n_peers, con
  * same addresses are rewritten every step - ordinary device memory is only promised coherent across devices at kernel boundaries. */
 int       cfx_ipc_alloc(cfx_ctx* ctx, size_t bytes, void** ptr, void* handle64);
 int       cfx_ipc_memory_kind(cfx_ctx* ctx);   /* what the last cfx_ipc_alloc of the context returned: 2 uncached, 1 fine-grained, 0 ordinary */
+int       cfx_set_ipc_memory_kind(cfx_ctx* ctx, int kind);   /* what cfx_ipc_alloc asks for first (default 2; measurements: 1, 0) */
 int       cfx_ipc_open(cfx_ctx* ctx, const void* handle64, void** ptr);
 int       cfx_ipc_close(cfx_ctx* ctx, void* ptr);
 int       cfx_ipc_free(cfx_ctx* ctx, void* ptr);

@@ -9,6 +9,7 @@ from compactfusion_amd import _lib, codecs as K
 lib = _lib.load()
 ctx = K.context(0)
 L, N, C, P = int(os.environ.get("L", 57)), 544, 3072, 7
+CODEC = int(os.environ.get("CODEC", 1))        # 1 = 1-bit, 2 = 2-bit (its exchange-layer form needs a -DCFX_EXP_INT2_XLAYER build)
 dev = "cuda"
 if os.environ.get("MAIN") == "hexmask":
     # arbitrary CU mask (8 hex words, bit i = CU i/8 of XCD i%8), straight from the HIP runtime
@@ -28,8 +29,8 @@ torch.cuda.set_stream(main)
 g = torch.Generator(device=dev).manual_seed(1)
 x0 = torch.randn(L, 2, N, C, generator=g, device=dev).half()
 xs = [(x0.float() + 0.1 * torch.randn(L, 2, N, C, generator=g, device=dev)).half() for _ in range(2)]
-slot = (K.packet_bytes(1, N, C) + 255) // 256 * 256
-wsb = lib.cfx_workspace_bytes(1, N, C, 0, 2)
+slot = (K.packet_bytes(CODEC, N, C) + 255) // 256 * 256
+wsb = lib.cfx_workspace_bytes(CODEC, N, C, 0, 2)
 ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 
 comm = None
@@ -37,6 +38,10 @@ if os.environ.get("COMM"):
     from compactfusion_amd.exchange import NativeComm
     ncomm = NativeComm(0, solo_ranks=1)
     comm = ncomm.handle if os.environ["COMM"] != "init" else None
+
+ipc, _h = ctypes.c_void_p(), ctypes.create_string_buffer(64)
+assert lib.cfx_ipc_alloc(ctx, L * 2 * slot + 2 * L * 64, ctypes.byref(ipc), _h) == 0
+
 
 def state():
     return x0.clone(), x0.unsqueeze(1).repeat(1, P, 1, 1, 1).contiguous()
@@ -66,14 +71,21 @@ def build(kind, own, peer, send):
             c = (_lib.CompItem * 2)(*[_lib.CompItem(xs[s][l, b].data_ptr(), own[l, b].data_ptr(), own[l, b].data_ptr(), send[l, b].data_ptr()) for b in range(2)])
             items = [_lib.DecompItem(send[l, b].data_ptr(), peer[l, p, b].data_ptr(), peer[l, p, b].data_ptr()) for p in range(P) for b in range(2)]
             d = (_lib.DecompItem * len(items))(*items)
-            if kind == "xlayer":
-                rc = lib.cfx_plan_add_exchange_layer(plan, 1, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, c, len(items), d, comm, send[l].data_ptr() if comm else None, send[l].data_ptr() if comm else None, 2 * slot, ws.data_ptr(), wsb)
-            elif kind == "gated":
-                rc = lib.cfx_plan_add_compress_gated(plan, 1, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, c, 0, None, len(items), d, ws.data_ptr(), wsb)
+            if kind == "p2p":
+                # the peer-to-peer exchange layer with no live peer: packets and flag word in cfx_ipc_alloc memory, the exchange inside the launch
+                o = (l * 2) * slot
+                cp = (_lib.CompItem * 2)(*[_lib.CompItem(xs[s][l, b].data_ptr(), own[l, b].data_ptr(), own[l, b].data_ptr(), ipc.value + o + b * slot) for b in range(2)])
+                it2 = [_lib.DecompItem(ipc.value + o + b * slot, peer[l, p, b].data_ptr(), peer[l, p, b].data_ptr()) for p in range(P) for b in range(2)]
+                rc = lib.cfx_plan_add_exchange_layer_p2p(plan, CODEC, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, cp, len(it2), (_lib.DecompItem * len(it2))(*it2),
+                                                         ipc.value + L * 2 * slot + (s * L + l) * 64, 0, (ctypes.c_void_p * 1)(), ws.data_ptr(), wsb)
+            elif kind == "xlayer":
+                rc = lib.cfx_plan_add_exchange_layer(plan, CODEC, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, c, len(items), d, comm, send[l].data_ptr() if comm else None, send[l].data_ptr() if comm else None, 2 * slot, ws.data_ptr(), wsb)
+            elif kind in ("gated", "gated+poller"):
+                rc = lib.cfx_plan_add_compress_gated(plan, CODEC, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, c, 0, None, len(items), d, ws.data_ptr(), wsb)
             else:
-                rc = lib.cfx_plan_add_compress(plan, 1, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, c, ws.data_ptr(), wsb)
+                rc = lib.cfx_plan_add_compress(plan, CODEC, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, c, ws.data_ptr(), wsb)
                 assert rc >= 0
-                rc = lib.cfx_plan_add_decompress(plan, 1, N, C, 0, len(items), d)
+                rc = lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, len(items), d)
             assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
         assert lib.cfx_plan_finalize(plan) == 0
         plans.append(plan)
@@ -87,9 +99,21 @@ def run(kind, steps=20):
         rc = lib.cfx_plan_run(plans[i & 1], 0, lib.cfx_plan_size(plans[i & 1]), main.cuda_stream)
         assert rc == 0, (rc, lib.cfx_last_error_string(ctx))
     for i in range(4): step(i)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    poll = None
+    if kind == "gated+poller":
+        # the loop-back gated launches while a one-wave polling kernel sits on ANOTHER (CU-masked) stream's queue for the whole timed region
+        hp = ctypes.c_void_p()
+        assert lib.cfx_stream_create_masked(ctx, 0, 256, ctypes.byref(hp)) == 0
+        poll = (hp, torch.zeros(16, dtype=torch.int32, device=dev))
+        torch.cuda.synchronize()
+        assert lib.cfx_flag_wait(ctx, poll[1].data_ptr(), 1, hp.value) == 0
+    torch.cuda.synchronize() if poll is None else main.synchronize(); t0 = time.perf_counter()
     for i in range(4, 4 + steps): step(i)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps * 1e3
+    main.synchronize(); dt = (time.perf_counter() - t0) / steps * 1e3
+    if poll is not None:
+        assert lib.cfx_flag_set(ctx, poll[1].data_ptr(), 1, main.cuda_stream) == 0
+        torch.cuda.synchronize()
+        lib.cfx_stream_destroy(ctx, poll[0])
     # host issue time alone
     t0 = time.perf_counter(); step(0); th = (time.perf_counter() - t0) * 1e3
     torch.cuda.synchronize()
