@@ -18,9 +18,9 @@ Default (--own-ef xgate --p2p auto) = WHAT THE PLUGIN API RUNS (compactfusion_am
 compact_all_gather_kv issue this op, one native call per layer; `plugin_path` times the same step through that API): A and B are ONE launch on
 the run stream (the exchange-layer op, cfx_plan_add_exchange_layer_p2p): B's workgroups are launched with A's, pull their state tiles into
 registers while the scale reduction runs, and wait for a gate word.  X is NOT a collective: every rank's packets stay in UNCACHED IPC device
-memory of its own GPU (cfx_ipc_alloc), the peers' reconstruction workgroups read them in place over xGMI, and ONE one-wave kernel per layer on
-the exchange stream waits for A's packets, publishes a word the live peers have mapped, waits for theirs and opens the gate.  At N = 1 there is
-no live peer: the same op, launches and kernels minus the remote reads and the waiting - `value` at N = 1 prices the launch structure every N
+memory of its own GPU (cfx_ipc_alloc), the peers' reconstruction workgroups read them in place over xGMI, and workgroup 0 of the SAME launch
+waits for A's packets, publishes a word the live peers have mapped, waits for theirs and opens the gate: one launch per layer on one stream,
+nothing else.  At N = 1 there is no live peer: the same op, launch and kernel minus the remote reads and the waiting - `value` at N = 1 prices the launch structure every N
 executes, not a wire.  At N > 1 the run is VALIDATED after the warm-up steps and again after the timed region (gate time-outs; every rank's
 reconstruction of a shard against its owner's state); on any failure every rank falls back IN-PROCESS - p2p -> compress ; ncclAllGather ;
 reconstruct in stream order -> torch.distributed per layer - re-runs warm-up and timed region, and `schedule_fallback` says which check tripped.
@@ -954,9 +954,9 @@ def main():
                      ("layer by layer in order (deployable), NO collective: every rank's packets stay in IPC-shared memory of its own GPU, the peers' "
                       "reconstruction workgroups read them in place over xGMI.  Per layer ONE codec launch on the run stream = compress K,V [statistics + "
                       "sign bits + in-launch finalize] + own error-feedback update + reconstruction of the 7 peers' K,V, whose workgroups pull their state "
-                      "tiles into registers and then wait for a gate word; on the exchange stream ONE small kernel: wait for this launch's packets, publish "
-                      f"a word the {live - 1} live peer(s) have mapped, wait for their words, open the gate (cfx_plan_add_exchange_layer_p2p).  " +
-                      ("One live rank: no peer to read from or to wait for - the same op, launches and kernels as any N, minus the remote reads "
+                      "tiles into registers and then wait for a gate word; workgroup 0 of the same launch waits for the launch's packets, publishes "
+                      f"a word the {live - 1} live peer(s) have mapped, waits for their words and opens the gate (cfx_plan_add_exchange_layer_p2p): no second launch, no second stream.  " +
+                      ("One live rank: no peer to read from or to wait for - the same op, launch and kernel as any N, minus the remote reads "
                        "(`collective_in_the_path`: the same launch around ncclAllGather)" if live == 1 else
                        "Validated after the warm-up steps and again after the timed region (gate time-outs, every rank's reconstruction of a shard against its owner's state)")) if (xgate and P2P) else
                      ("layer by layer in order (deployable), the collective in the path: per layer ONE codec launch on the run stream = compress K,V "

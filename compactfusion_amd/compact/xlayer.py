@@ -3,13 +3,15 @@
 What the reference does per layer and denoise step in Python (xfuser/compact/main.py:390-420 `compact_all_gather`: compress, list
 all-gather, W decompress calls; patchpara/fwd.py:88-102; ring.py:188-206 + 265-269: compress K and V, W-1 relay hops, a
 decompress per hop) is here ONE host call into libcfx per layer: `cfx_plan_add_exchange_layer[_p2p]` replayed by `cfx_plan_run_x`
-(include/cfx.h).  For the 1-bit codec on a stream that owns its hardware queue that is ONE codec launch whose reconstruction
-workgroups wait, state tiles already in registers, for the packets' arrival; every other codec / stream runs the same
-work in stream order (compress ; exchange ; reconstruct) - same results, still one host call.
+(include/cfx.h).  For the quantising codecs (1-bit, 2-bit, int4, int8) that is ONE codec launch whose reconstruction workgroups wait, state
+tiles already in registers, for the packets' arrival - and in the peer-to-peer transport the exchange itself (publish this rank's word, await
+the peers') runs inside that launch; top-k and shapes without the one-launch form run the same work in stream order
+(compress ; exchange ; reconstruct) - same results, still one host call.
 
 Transports, tried in this order (`CFX_EXCHANGE` = auto | p2p | rccl | torch):
   p2p    ranks of ONE node: every rank's packets stay in uncached IPC device memory of its own GPU (`P2PArena`), the peers'
-         reconstruction workgroups read them in place over xGMI; what is exchanged is one word per rank and layer.  The first two
+         reconstruction workgroups read them in place over xGMI; what is exchanged is one word per rank and layer, by the launch itself
+         (no exchange stream, any run stream).  The first two
          executions of every layer are VALIDATED (gate time-outs, and every rank's reconstruction of a shard against its owner's state,
          by checksum over the process group); on any failure every rank restores the layer's states, the group's arena is marked
          bad and all its layers continue on the next transport.

@@ -307,14 +307,17 @@ int       cfx_plan_add_exchange_layer(cfx_plan* plan, int codec, int N, int C, i
                                       void* workspace, size_t workspace_bytes);
 /* The exchange layer WITHOUT a collective, for the GPUs of one node: every rank's packets stay where the compress launch wrote them - in
  * a buffer from cfx_ipc_alloc that the peers have opened with cfx_ipc_open - and a peer's reconstruction workgroups read them from
- * there over xGMI (`recon` items point into the opened mappings).  What is exchanged is one 4-byte word per rank and layer: the
- * exchange stream's kernel waits for this launch's packets, advances *own_flag by one (the op's execution count 1, 2, ... - taken from
- * the word itself on the device, so a rebuilt plan keeps counting where the words stand; every rank executes the same ops equally
- * often), waits until every peer_flags[i] has reached that count and opens the launch's gate.  No collective
- * kernel runs, so nothing has to find CUs beside the waiting workgroups.  own_flag and the peers' flags live in cfx_ipc_alloc memory
- * (zero-initialised), one word per op and plan; a plan must have at least two such ops per replay (a rank rewrites a layer's packets
- * only after its peers have moved past that layer).  Replaces the all-gather of ring.py:188-206 / patchpara/fwd.py:108-109 on a
- * single node.  Same fall-backs and timeouts as cfx_plan_add_exchange_layer. */
+ * there over xGMI (`recon` items point into the opened mappings).  What is exchanged is one 4-byte word per rank and layer, and the exchange
+ * runs INSIDE the launch: workgroup 0, once its own tile is done, waits until the launch's packets are complete, advances *own_flag by one
+ * (the op's execution count 1, 2, ... - taken from the word itself on the device, so a rebuilt plan keeps counting where the words stand;
+ * every rank executes the same ops equally often), waits until every peer_flags[i] has reached that count and opens the launch's gate.  ONE
+ * launch per layer on ONE stream: no exchange stream, no collective kernel that has to find CUs beside the waiting workgroups, no
+ * hardware-queue requirement, any run stream (the legacy NULL stream included).  own_flag and the peers' flags live in cfx_ipc_alloc memory
+ * (zero-initialised), one word per op and plan; a rank may rewrite a layer's packets only after its peers have moved past that layer: a plan
+ * has at least two such ops per replay, or the caller double-buffers packets and flag words by execution parity (compact/xlayer.py).
+ * Replaces the all-gather of ring.py:188-206 / patchpara/fwd.py:108-109 on a single node.  1-bit, 2-bit, int4, int8 (the min/max and 2-bit
+ * codecs where all their statistics workgroups are co-resident); otherwise - shape / stream without the one-launch form - compress ; a
+ * one-wave kernel that publishes and waits ; reconstruct in stream order: same results.  Time-outs as for cfx_plan_add_exchange_layer. */
 #define CFX_P2P_MAX_PEERS 15
 int       cfx_plan_add_exchange_layer_p2p(cfx_plan* plan, int codec, int N, int C, int param, int flags, int batch,
                                           const cfx_comp_item* items, int n_recon, const cfx_decomp_item* recon,
