@@ -52,8 +52,10 @@ struct cfx_ctx {
     // at which the slot's next launch opens, and one error word (a gate that never opened)
     unsigned* gate;
     unsigned gate_expect[3 * 256 * CFX_RING_STREAMS];  // three gates per slot (the 2-bit exchange layer has three)
-    unsigned* colgate;              // tile flags of the min/max layer launch: per ring 2 x 2048 words ("partial published", "codes published")
-    unsigned colgate_seq[CFX_RING_STREAMS];   // launch sequence number per ring: the value a launch's tile flags are set to
+    unsigned* colgate;              // tile flags of the min/max layer launch: per ring 2048 words ("codes published")
+    unsigned mml_seq;               // sequence number of the min/max layer launches of this context: the value of a launch's flags and the tag of its partials
+    unsigned long long* mml_arena[CFX_RING_STREAMS];        // per ring: tagged partials + scales of the min/max layer launch (zeroed at allocation, grown on demand)
+    size_t mml_arena_bytes[CFX_RING_STREAMS];
     unsigned* gate_err;             // pinned HOST word (device-visible): waits that timed out since the last cfx_gate_errors
     long long gate_timeout;         // ticks of the 100 MHz wall clock a flag wait may last
     int fused;                      // 1 (default): compress = statistics + in-launch finalize; 0: separate finalize kernel

@@ -1475,6 +1475,17 @@ __global__ __launch_bounds__(NTHR) void k_minmax_stats(BatchC batch, int N, int 
 
 __device__ __forceinline__ h16 hdiv(h16 a, h16 b) { return (h16)((float)a / (float)b); }   // correctly rounded fp16 quotient
 __device__ __forceinline__ h16 hrint(h16 a) { return __builtin_rintf16(a); }                // round half to even (torch.round)
+// hdiv(a, b) given bf = (float)b and rb = v_rcp_f32(bf) (1 ulp), 4 instructions instead of the 10 of an IEEE fp32 division: one Newton step
+// (t = a * rb; q = t + (a - t * b) * rb) leaves the fp32 quotient within 0.5 ulp for every pair of fp16 operands whatever the rcp's last bit
+// (exhaustive over the significands: tests/test_fastdiv.py), so its rounding to fp16 is the correctly rounded quotient; v_div_fixup_f32 puts
+// IEEE's results for zero / infinite / NaN operands back.  The codecs divide every element by its channel's scale: rb is per channel.
+__device__ __forceinline__ h16 hdiv_r(h16 a, float bf, float rb) {
+    const float af = (float)a;
+    const float t = af * rb;
+    const float r = __builtin_fmaf(-t, bf, af);
+    const float q = __builtin_fmaf(r, rb, t);
+    return (h16)__builtin_amdgcn_div_fixupf(q, bf, af);
+}
 __device__ __forceinline__ bool hisnan(h16 a) { return a != a; }
 
 // int4 : scale = fp16(fp16(max-min)/15.000001f), min                              compress_quantize.py:556-558
@@ -1596,20 +1607,30 @@ __global__ __launch_bounds__(NTHR) void k_minmax_compress(BatchC batch, int N, i
 #define MML_NW FUSED_NW
 #define MML_KC 14              // rows of a D tile a wave holds in registers (int4: 7 row pairs)
 #define MML_MAX_P 64           // row tiles per column block (one poll load per lane of a wave)
+#define MML_MAX_P_TALL 128     // ... of the tall form (two poll loads per lane)
+#define MML_NRED 8             // tall form: tiles 0 .. 7 of a column block reduce 64 of its 512 channels each
 #define MML_MAX_TILES 2048     // statistics tiles of one launch = flag words per ring and kind
 struct MinMaxLayerArgs {
     int N, C, CB, P, R, n_st;         // group S: CB x P tiles of R rows (32 or 64) per own tensor
     int g_R, g_rb, n_g;               // group D: tiles of g_R rows, g_rb per tensor
     int codec, flags;
-    u64* ws; size_t ws_stride;
-    unsigned* statdone; unsigned* codedone; unsigned seq;   // one flag word per S tile, index (z * CB + bx) * P + by: "partial published" /
-                                                            // "codes (and, tile by == 0, the scales) published" = the launch's sequence number
+    u64* part; size_t part_stride;    // context-owned arena (zeroed once), per own tensor [P][C] partials + [C] scales as TAGGED words:
+                                      // {fp16 pair, seq} in one 8-byte store - a reader polls the data itself, no flag, no store fence
+    unsigned* codedone; unsigned seq; // one flag word per S tile, index (z * CB + bx) * P + by: "codes (and, the tiles that computed them,
+                                      // the scales) published" = the launch's sequence number (context-wide, never reused)
     unsigned* xgate; unsigned xexpect;     // external gate for group D (NULL: a D tile waits for the S tiles whose codes it reads)
     unsigned* err;
     int remote;
     signed char src[CFX_MAX_BATCH];   // gated item -> the own tensor whose packet it reads (loop-back forms)
     P2PInline p2p;                    // own != NULL: workgroup 0 runs the peer-to-peer exchange and opens xgate itself
+    // tall != 0 (tensors whose S tiles do not fit the chip at once): S tiles ordered column block by column block (row tile fastest), so that a
+    // column block's P tiles - the only workgroups a tile waits for - are dispatched together and ahead of every later block's; tiles
+    // 0 .. MML_NRED - 1 of the block reduce 64 channels' P partials each (a wave takes every 8th partial) and publish the scales as tagged
+    // words; every tile polls the 512 scales of its block
+    int tall;
+    u64* stamps;                      // cfx_debug_stamps: 16 words per workgroup (100 MHz wall clock per phase; word 7: 1 = S tile, 4 = D tile)
 };
+#define MML_STAMP(i) do { if (st && threadIdx.x == 0) st[i] = (u64)wall_clock64(); } while (0)
 // codes of 8 channels of one row (int8) / one row pair (int4), exactly as k_int8_quant / k_int4_quant compute them
 __device__ __forceinline__ u64 int8_codes(h16x8 d, h16x8 sc, h16x8 zp) {
     u64 outb = 0;
@@ -1697,13 +1718,14 @@ __device__ __forceinline__ void minmax_scale_of(h16 mn, h16 mx, h16& scale, u16&
 #ifndef MML_POLL_SLEEP
 #define MML_POLL_SLEEP 2
 #endif
-// one wave: wait until the `n` (<= 64) flag words f[0 .. n) have all reached `seq`
+// one wave: wait until the `n` (<= 128) flag words f[0 .. n) have all reached `seq`
 __device__ __forceinline__ void wave_wait_flags(const unsigned* f, int n, unsigned seq, unsigned* err) {
     const int lane = threadIdx.x & 63;
     unsigned spins = 0;
     for (;;) {
         const unsigned v = lane < n ? ld_wt(f + lane) : seq;
-        if (__builtin_amdgcn_ballot_w64((int)(v - seq) < 0) == 0) break;
+        const unsigned v2 = lane + 64 < n ? ld_wt(f + lane + 64) : seq;
+        if (__builtin_amdgcn_ballot_w64((int)(v - seq) < 0 || (int)(v2 - seq) < 0) == 0) break;
         __builtin_amdgcn_s_sleep(MML_POLL_SLEEP);
         if (++spins > GATE_SPIN_LIMIT) { if (lane == 0) gate_fail(err); break; }
     }
@@ -1720,6 +1742,9 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
     const h16* x = (const h16*)it.x;
     const h16* base = (const h16*)it.base;
     const int cc = min(t.c, C - 8);
+    u64* st = a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr;
+    if (st && threadIdx.x == 0) st[7] = 1;
+    MML_STAMP(0);
     // ---- the tile into registers (every load unconditional: clamped row, masked use) ----
     h16x8 xk[RW], bk[RW];
     bool rv[RW];
@@ -1749,7 +1774,9 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
 #pragma unroll
     for (int i = 0; i < 8; ++i) sm32[t.w * TILE_C + i * 64 + (t.lane ^ (i << 3))] = (unsigned)hbits(mn[i]) | ((unsigned)hbits(mx[i]) << 16);
     lds_barrier();
-    unsigned* part = (unsigned*)(a.ws + (size_t)z * a.ws_stride);
+    u64* part = a.part + (size_t)z * a.part_stride;         // [P][C] tagged partials, then [C] tagged scales
+    u64* sca = part + (size_t)a.P * C;
+    const u64 tag = (u64)a.seq << 32;
     const int k = threadIdx.x;                              // 512 threads: one channel of the tile each
     const int ch = bx * TILE_C + k, chc = min(ch, C - 1);
     {
@@ -1762,36 +1789,134 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
             lo = a2 < lo ? a2 : lo;
             hi = b2 > hi ? b2 : hi;
         }
-        if (ch < C) st_wt(&part[(size_t)by * C + ch], (unsigned)hbits(lo) | ((unsigned)hbits(hi) << 16));
+        // the partial AND its "published" mark in one 8-byte store: nobody waits for a store to be acknowledged before a flag can follow
+        if (ch < C) st_wt(&part[(size_t)by * C + ch], tag | (unsigned)hbits(lo) | ((unsigned)hbits(hi) << 16));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    MML_STAMP(1);                                           // tile loaded, partial issued
     const size_t fbase = ((size_t)z * a.CB + bx) * a.P;
-    if (k == 0) st_wt(a.statdone + fbase + by, a.seq);
-    // ---- every tile of the column block reduces the block's P partials itself: no last arriver, no second hand-over ----
-    if (t.w == 0) wave_wait_flags(a.statdone + fbase, a.P, a.seq, a.err);
-    __syncthreads();
-    h16 lo = hfrom(0x7c00), hi = hfrom(0xfc00);
-    for (int p0 = 0; p0 < a.P; p0 += 16) {
-        unsigned v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = ld_wt(&part[(size_t)min(p0 + j, a.P - 1) * C + chc]);   // a repeated partial does not change a min / max
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const h16 a0 = hfrom((u16)(v[j] & 0xffff)), b0 = hfrom((u16)(v[j] >> 16));
-            lo = a0 < lo ? a0 : lo;
-            hi = b0 > hi ? b0 : hi;
-        }
-    }
+    unsigned char* pk = (unsigned char*)it.packet;
+    u16* S = (u16*)(pk + (INT4 ? (size_t)(N / 2) * C : (size_t)N * C));
     h16 scale;
     u16 second;
-    minmax_scale_of<INT4>(lo, hi, scale, second);
-    unsigned char* pk = (unsigned char*)it.packet;
-    if (by == 0 && ch < C) {                               // the block's scales into the packet: once
-        u16* S = (u16*)(pk + (INT4 ? (size_t)(N / 2) * C : (size_t)N * C));
-        st_wt(S + ch, hbits(scale));
-        st_wt(S + C + ch, second);
+    constexpr int NB = RW == 4 ? 16 : 8;                    // partials in flight per thread (registers: the tile stays live)
+    if (!a.tall || by < MML_NRED) {
+        // one wave watches ONE word per tile of the block (lane i: tile i's first channel) until all carry the tag; only then does every
+        // thread load its channel's P words (and checks their tags: a tile's 512 stores are not ordered among themselves).  Every thread
+        // polling its own words from the start is a hop shorter on an idle chip - and a storm of 8192 loads per tile and round that starves
+        // whatever shares the chip, including the tiles being waited for (measured: waits of seconds beside a copy stream)
+        if (t.w == 0) {
+            const u64* w0 = part + (size_t)bx * TILE_C;
+            unsigned spins = 0;
+            for (;;) {
+                const u64 v0 = t.lane < a.P ? ld_wt(w0 + (size_t)t.lane * C) : tag;
+                const u64 v1 = t.lane + 64 < a.P ? ld_wt(w0 + (size_t)(t.lane + 64) * C) : tag;
+                if (__builtin_amdgcn_ballot_w64((unsigned)(v0 >> 32) != a.seq || (unsigned)(v1 >> 32) != a.seq) == 0) break;
+                __builtin_amdgcn_s_sleep(MML_POLL_SLEEP);
+                if (++spins > GATE_SPIN_LIMIT) { if (t.lane == 0) gate_fail(a.err); break; }
+            }
+        }
+        __syncthreads();
     }
+    if (!a.tall) {
+        // ---- every tile of the column block reduces the block's P partials itself: no last arriver, no second hand-over ----
+        h16 lo = hfrom(0x7c00), hi = hfrom(0xfc00);
+        for (int p0 = 0; p0 < a.P; p0 += NB) {
+            u64 v[NB];
+            unsigned spins = 0;
+            for (;;) {
+                // (all loads issued, THEN the tags compared: a test per load makes the compiler wait for each load in turn)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) v[j] = ld_wt(&part[(size_t)min(p0 + j, a.P - 1) * C + chc]);   // a repeated partial does not change a min / max
+                unsigned bad = 0;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) bad |= (unsigned)(v[j] >> 32) ^ a.seq;
+                if (!bad) break;
+                __builtin_amdgcn_s_sleep(MML_POLL_SLEEP);
+                if (++spins > GATE_SPIN_LIMIT) {
+                    gate_fail(a.err);
+                    break;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const h16 a0 = hfrom((u16)(v[j] & 0xffff)), b0 = hfrom((u16)((unsigned)v[j] >> 16));
+                lo = a0 < lo ? a0 : lo;
+                hi = b0 > hi ? b0 : hi;
+            }
+        }
+        minmax_scale_of<INT4>(lo, hi, scale, second);
+        if (by == 0 && ch < C) {                               // the block's scales into the packet: once
+            st_wt(S + ch, hbits(scale));
+            st_wt(S + C + ch, second);
+        }
+    } else {
+        // ---- tall form: P x 2 KB per tile would be a second pass over a good part of the tensor - tiles 0 .. 7 reduce 64 channels each ----
+        if (by < MML_NRED) {
+            const int chr = bx * TILE_C + by * 64 + t.lane, chrc = min(chr, C - 1);
+            h16 lo = hfrom(0x7c00), hi = hfrom(0xfc00);
+            for (int p0 = t.w; p0 < a.P; p0 += NW * 8) {
+                u64 v[8];
+                unsigned spins = 0;
+                for (;;) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = ld_wt(&part[(size_t)min(p0 + NW * j, a.P - 1) * C + chrc]);
+                    unsigned bad = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bad |= (unsigned)(v[j] >> 32) ^ a.seq;
+                    if (!bad) break;
+                    __builtin_amdgcn_s_sleep(MML_POLL_SLEEP);
+                    if (++spins > GATE_SPIN_LIMIT) { gate_fail(a.err); break; }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const h16 a0 = hfrom((u16)(v[j] & 0xffff)), b0 = hfrom((u16)((unsigned)v[j] >> 16));
+                    lo = a0 < lo ? a0 : lo;
+                    hi = b0 > hi ? b0 : hi;
+                }
+            }
+            __syncthreads();                                    // (sm32: the publish above has read it)
+            sm32[t.w * 64 + t.lane] = (unsigned)hbits(lo) | ((unsigned)hbits(hi) << 16);
+            __syncthreads();
+            if (t.w == 0) {
+#pragma unroll
+                for (int w = 1; w < NW; ++w) {
+                    const unsigned u = sm32[w * 64 + t.lane];
+                    const h16 a0 = hfrom((u16)(u & 0xffff)), b0 = hfrom((u16)(u >> 16));
+                    lo = a0 < lo ? a0 : lo;
+                    hi = b0 > hi ? b0 : hi;
+                }
+                h16 sc1;
+                u16 sec1;
+                minmax_scale_of<INT4>(lo, hi, sc1, sec1);
+                if (chr < C) {
+                    st_wt(&sca[chr], tag | (unsigned)hbits(sc1) | ((unsigned)sec1 << 16));
+                    st_wt(S + chr, hbits(sc1));                 // (the packet's copy: for the receivers, behind this tile's codes flag)
+                    st_wt(S + C + chr, sec1);
+                }
+            }
+        }
+        if (t.w == 0) {                                         // (one wave watches one word per reducer tile first: see above)
+            unsigned spins = 0;
+            for (;;) {
+                const u64 v0 = t.lane < MML_NRED ? ld_wt(&sca[min(bx * TILE_C + t.lane * 64, C - 1)]) : tag;
+                if (__builtin_amdgcn_ballot_w64((unsigned)(v0 >> 32) != a.seq) == 0) break;
+                __builtin_amdgcn_s_sleep(MML_POLL_SLEEP);
+                if (++spins > GATE_SPIN_LIMIT) { if (t.lane == 0) gate_fail(a.err); break; }
+            }
+        }
+        __syncthreads();
+        unsigned spins = 0;
+        u64 v;
+        for (;;) {
+            v = ld_wt(&sca[chc]);
+            if ((unsigned)(v >> 32) == a.seq) break;
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > GATE_SPIN_LIMIT) { gate_fail(a.err); break; }
+        }
+        scale = hfrom((u16)(v & 0xffff));
+        second = (u16)((unsigned)v >> 16);
+    }
+    MML_STAMP(2);                                           // scales known
     // a lane's 8 channels from the 512 per-thread values: through LDS
     u16* sl = (u16*)&sm[0][0];                              // [2][TILE_C] halves (the min / max words are consumed)
     __syncthreads();
@@ -1811,12 +1936,38 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
     __syncthreads();
     // ---- own tile: codes from registers ----
     u64* stage = &sm[0][0] + (size_t)t.w * CR * 64;         // this wave's CR code rows x 64 lanes x 8 bytes (same wave writes and reads: in order)
+    {
+        // arithmetic of int4_codes / int8_codes (= k_int4_quant / k_int8_quant), channel by channel: the division by the channel's scale as
+        // hdiv_r with one reciprocal per channel - this loop is the kernel's instruction count (tall tensors: it ran at the VALU's pace)
+        u64 cj[CR];
 #pragma unroll
-    for (int j = 0; j < CR; ++j) {
-        u64 cj;
-        if (INT4) cj = int4_codes(xk[2 * j] - bk[2 * j], xk[2 * j + 1] - bk[2 * j + 1], sc, mz);
-        else cj = int8_codes(xk[j] - bk[j], sc, mz);
-        stage[j * 64 + t.lane] = cj;                        // (kept there for the error-feedback pass too: nothing else uses the LDS afterwards)
+        for (int j = 0; j < CR; ++j) cj[j] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float bf = (float)sc[i], rb = __builtin_amdgcn_rcpf(bf);
+#pragma unroll
+            for (int j = 0; j < CR; ++j) {
+                if (INT4) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const h16 d = xk[2 * j + h][i] - bk[2 * j + h][i];
+                        h16 v = hrint(hdiv_r(d - mz[i], bf, rb));
+                        v = __builtin_fmaxf16(v, (h16)0);              // (NaN -> 0, as the explicit test of int4_codes)
+                        v = __builtin_fminf16(v, (h16)15.0f);
+                        cj[j] |= (u64)((unsigned)(unsigned short)v & 15u) << (8 * i + 4 * h);
+                    }
+                } else {
+                    const h16 d = xk[j][i] - bk[j][i];
+                    h16 v = hrint(hdiv_r(d, bf, rb) + mz[i]);
+                    if (hisnan(v)) v = (h16)0;
+                    v = __builtin_fmaxf16(v, (h16)-128.0f);
+                    v = __builtin_fminf16(v, (h16)127.0f);
+                    cj[j] |= (u64)(unsigned char)(signed char)(short)v << (8 * i);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CR; ++j) stage[j * 64 + t.lane] = cj[j];   // (kept there for the error-feedback pass too: nothing else uses the LDS afterwards)
     }
     {
         // a code row of the tile is 512 bytes = 32 lanes x 16 bytes; lanes [0, 32) take the even code rows of the wave, [32, 64) the odd ones
@@ -1829,9 +1980,11 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
                 st16_wt(pk + (size_t)cr * C + (size_t)bx * TILE_C + seg * 16, *(const u32x4*)((const unsigned char*)(stage + j * 64) + seg * 16));
         }
     }
+    MML_STAMP(3);                                           // codes issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (k == 0) st_wt(a.codedone + fbase + by, a.seq);
+    MML_STAMP(4);                                           // codes acknowledged, flag issued
     h16* nb = (h16*)it.new_base;
     if ((a.flags & CFX_FLAG_UPDATE_CACHE) && nb) {
         const bool ef = !(a.flags & CFX_FLAG_NO_EF);
@@ -1851,6 +2004,10 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
                 }
             }
     }
+    if (st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MML_STAMP(5);                                       // state stores acknowledged
+    }
 }
 
 template <bool INT4>
@@ -1864,25 +2021,33 @@ __device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, c
     const h16* base = (const h16*)it.base;
     h16* out = (h16*)it.recon;
     const int cc = min(t.c, C - 8);
+    u64* st = a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr;
+    if (st && threadIdx.x == 0) st[7] = 4;
+    MML_STAMP(0);
+    const int kc = a.g_R / (NW * RPC);         // code rows per wave of THIS launch's tiles (<= KC; uniform)
     h16x8 bv[MML_KC];
 #pragma unroll
     for (int j = 0; j < KC; ++j)
+        if (j < kc) {
 #pragma unroll
-        for (int h = 0; h < RPC; ++h) {
-            const int row = t.r0 + (t.w + NW * j) * RPC + h;
-            bv[j * RPC + h] = base ? ld8nt(base + (size_t)min(row, N - 1) * C + cc) : (h16x8)(h16)0;
+            for (int h = 0; h < RPC; ++h) {
+                const int row = t.r0 + (t.w + NW * j) * RPC + h;
+                bv[j * RPC + h] = base ? ld8nt(base + (size_t)min(row, N - 1) * C + cc) : (h16x8)(h16)0;
+            }
         }
     if (a.xgate) gate_wait<true>(a.xgate, a.xexpect, a.err);
     else {
-        // the S tiles whose codes this tile reads (same column block, the row tiles its rows fall into) - and tile 0, which wrote the scales
+        // the S tiles whose codes this tile reads (same column block, the row tiles its rows fall into) - and the tiles that wrote the
+        // scales: tile 0, tall form tiles 0 .. MML_NRED - 1
         if (t.w == 0) {
             const unsigned* f = a.codedone + ((size_t)a.src[item] * a.CB + bx) * a.P;
             const int by0 = t.r0 / a.R, by1 = (t.r1 - 1) / a.R;
             const int lane = threadIdx.x & 63;
+            const int nsc = a.tall ? MML_NRED : 1;
             unsigned spins = 0;
             for (;;) {
-                const int idx = lane == 0 ? 0 : by0 + lane - 1;
-                const unsigned v = (lane == 0 || idx <= by1) ? ld_wt(f + min(idx, a.P - 1)) : a.seq;
+                const int idx = lane < nsc ? lane : by0 + lane - nsc;
+                const unsigned v = (lane < nsc || idx <= by1) ? ld_wt(f + min(idx, a.P - 1)) : a.seq;
                 if (__builtin_amdgcn_ballot_w64((int)(v - a.seq) < 0) == 0) break;
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > GATE_SPIN_LIMIT) { if (lane == 0) gate_fail(a.err); break; }
@@ -1890,26 +2055,38 @@ __device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, c
         }
         __syncthreads();
     }
+    if (st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MML_STAMP(1);                                       // state tile in registers AND gate seen
+    }
     const bool remote = a.remote != 0;
     h16x8 sc, mz;
     minmax_ld_scales<INT4>(pk, N, C, cc, remote, sc, mz);
     const int crows = INT4 ? N / 2 : N;
     u64 qb[KC];
 #pragma unroll
-    for (int j = 0; j < KC; ++j) {
-        const int cr = min((t.r0 / RPC) + t.w + NW * j, crows - 1);
-        qb[j] = ld_wt_or_sys((const u64*)(pk + (size_t)cr * C + cc), remote);
-    }
+    for (int j = 0; j < KC; ++j)
+        if (j < kc) {
+            const int cr = min((t.r0 / RPC) + t.w + NW * j, crows - 1);
+            qb[j] = ld_wt_or_sys((const u64*)(pk + (size_t)cr * C + cc), remote);
+        }
 #pragma unroll
     for (int j = 0; j < KC; ++j)
+        if (j < kc) {
 #pragma unroll
-        for (int h = 0; h < RPC; ++h) {
-            const int row = t.r0 + (t.w + NW * j) * RPC + h;
-            if (row < t.r1 && t.act) {
-                const h16x8 recv = minmax_recv<INT4>(qb[j], h, sc, mz);
-                st8nt(out + (size_t)row * C + t.c, base ? (bv[j * RPC + h] + recv) : recv);
+            for (int h = 0; h < RPC; ++h) {
+                const int row = t.r0 + (t.w + NW * j) * RPC + h;
+                if (row < t.r1 && t.act) {
+                    const h16x8 recv = minmax_recv<INT4>(qb[j], h, sc, mz);
+                    st8nt(out + (size_t)row * C + t.c, base ? (bv[j * RPC + h] + recv) : recv);
+                }
             }
         }
+    if (st) {
+        MML_STAMP(2);                                       // codes landed, stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MML_STAMP(3);
+    }
 }
 
 template <bool INT4, int RW>
@@ -1919,8 +2096,10 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_minmax_layer(BatchC batch, Batc
     if (b < a.n_st) {
         const int per = a.CB * a.P;
         const int z = b / per, rem = b - z * per;
-        const int by = rem / a.CB;
-        minmax_layer_s_tile<INT4, RW>(batch.it[z], a, z, rem - by * a.CB, by, sm);
+        int bx, by;
+        if (a.tall) { bx = rem / a.P; by = rem - bx * a.P; }
+        else { by = rem / a.CB; bx = rem - by * a.CB; }
+        minmax_layer_s_tile<INT4, RW>(batch.it[z], a, z, bx, by, sm);
         if (b == 0 && a.p2p.own) p2p_exchange_inline(a.codedone, a.seq, a.n_st, a.p2p, a.xgate, a.xexpect, a.err);     // packets complete = every S tile's codes flag
         return;
     }
@@ -2418,7 +2597,7 @@ int cfx_prepare(cfx_ctx* ctx) {
     static_assert(3 * TICK_RING * CFX_RING_STREAMS == sizeof(((cfx_ctx*)0)->gate_expect) / sizeof(unsigned), "gate_expect has three entries per ring slot");
     const size_t tick_words = (size_t)CFX_RING_STREAMS * TICK_RING * CFX_MAX_BATCH * TICK_WORDS;
     const size_t gate_words = (size_t)(CFX_RING_STREAMS * TICK_RING + 1) * GATE_STRIDE;
-    const size_t colgate_words = (size_t)CFX_RING_STREAMS * 2 * MML_MAX_TILES;     // tile flags of the min/max layer launch ("partial published", "codes published"), per ring
+    const size_t colgate_words = (size_t)CFX_RING_STREAMS * MML_MAX_TILES;     // tile flags of the min/max layer launch ("codes published"), per ring
     const size_t bytes = (tick_words + gate_words + colgate_words) * sizeof(unsigned);
     void* p = nullptr;
     int rc = CFX_OK;
@@ -2430,7 +2609,7 @@ int cfx_prepare(cfx_ctx* ctx) {
         ctx->tick = (unsigned*)p;
         ctx->gate = ctx->tick + tick_words;
         ctx->colgate = ctx->gate + gate_words;
-        memset(ctx->colgate_seq, 0, sizeof(ctx->colgate_seq));
+        ctx->mml_seq = 0;
         // the error word: pinned, device-visible HOST memory - a timed-out wait is reported by the next native call, no device sync
         void* e = nullptr;
         if (hipHostMalloc(&e, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); ctx->tick = nullptr; rc = fail(ctx, CFX_ERR_LAUNCH, "prepare: cannot allocate the error word"); }
@@ -2521,6 +2700,8 @@ void cfx_destroy(cfx_ctx* ctx) {
     if (ctx->tick) (void)hipFree(ctx->tick);
     for (int i = 0; i < ctx->lrs_n; ++i)
         if (ctx->lrs_arena[i]) (void)hipFree(ctx->lrs_arena[i]);
+    for (int i = 0; i < CFX_RING_STREAMS; ++i)
+        if (ctx->mml_arena[i]) (void)hipFree(ctx->mml_arena[i]);
     if (ctx->lrs_ev) (void)hipEventDestroy(ctx->lrs_ev);
     if (ctx->gate_err) (void)hipHostFree(ctx->gate_err);
     delete ctx;
@@ -2966,10 +3147,12 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
         const bool int4 = codec == CFX_CODEC_INT4;
         const int RL = (N + 31) / 32 <= MML_MAX_P / 2 ? 32 : 64;       // S tile height: 32 rows; 64 where that keeps the partials per channel <= MML_MAX_P
         const int PL = (N + RL - 1) / RL;
-        const int g_rb = (N + FUSED_NW * MML_KC - 1) / (FUSED_NW * MML_KC);
-        const int g_R = ((N + g_rb - 1) / g_rb + 15) / 16 * 16;
-        const long n_st = (long)CB * PL * batch, n_g = (long)CB * g_rb * n_gated;
-        bool layer = fused && ctx->gated_on && !ctx->dev_probe && C % 16 == 0 && stream_cus >= 128 && ctx->stats_rows == 0 && PL <= MML_MAX_P &&
+        bool tall = PL > MML_MAX_P;
+        int g_rb = (N + FUSED_NW * MML_KC - 1) / (FUSED_NW * MML_KC);
+        int g_R = ((N + g_rb - 1) / g_rb + 15) / 16 * 16;
+        const long n_st = (long)CB * PL * batch;
+        long n_g = (long)CB * g_rb * n_gated;
+        bool layer = fused && ctx->gated_on && !ctx->dev_probe && C % 16 == 0 && stream_cus >= 128 && ctx->stats_rows == 0 && PL <= MML_MAX_P_TALL &&
                      n_st <= MML_MAX_TILES;
         signed char src[CFX_MAX_BATCH];
         memset(src, 0, sizeof(src));
@@ -2992,7 +3175,21 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                 if (oe != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
             }
             const long slots = (long)per_cu * stream_cus;
-            if (n_st > slots - 8) layer = false;
+            // every S tile co-resident; or - tall form - a column block's P tiles at a time, which in-order dispatch (workgroup i on XCD
+            // i % 8, every XCD walking its share in order) guarantees as long as they fit a fraction of the slots
+            if (n_st > slots - 8) tall = true;
+            if (tall && (RL != 64 || PL * 4 > slots)) layer = false;
+            // group D's tile height: as low as keeps the group within the slots group S leaves free (small tensors: 60 workgroups of 112
+            // rows would leave most of the chip idle behind the gate - the tile's arithmetic, not HBM, is what takes the time there)
+            if (n_gated && n_st < slots) {
+                const long per_rb = (long)CB * n_gated, fit = (slots - n_st) / per_rb;      // row tiles per tensor that fit
+                if (fit > g_rb) {
+                    const int rows = (int)((N + fit - 1) / fit);
+                    g_R = std::max(16, (rows + 15) / 16 * 16);
+                    g_rb = (N + g_R - 1) / g_R;
+                    n_g = (long)CB * g_rb * n_gated;
+                }
+            }
             // a collective KERNEL has to find CUs while group D waits (see the 1-bit exchange layer): 32 workgroup slots left free
             if (layer && xg && xg->needs_room && n_g + 32 > slots) layer = false;
         }
@@ -3003,11 +3200,31 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             a.N = N; a.C = C; a.CB = CB; a.P = PL; a.R = RL; a.n_st = (int)n_st;
             a.g_R = g_R; a.g_rb = g_rb; a.n_g = (int)n_g;
             a.codec = codec; a.flags = flags;
-            a.ws = ws; a.ws_stride = wstride;
             const unsigned ring = slot / TICK_RING;
-            a.statdone = ctx->colgate + (size_t)ring * 2 * MML_MAX_TILES;
-            a.codedone = a.statdone + MML_MAX_TILES;
-            a.seq = ++ctx->colgate_seq[ring];
+            // the partials' arena of this ring (stream): context-owned because its words are TAGGED - a stale word must never carry a tag a
+            // later launch expects, so it starts zeroed and only ever takes this context's sequence numbers (which are not reused)
+            a.part_stride = (size_t)(PL + 1) * C;
+            const size_t need = a.part_stride * batch * sizeof(u64);
+            if (ctx->mml_arena_bytes[ring] < need) {
+                if (ctx->mml_arena[ring]) (void)hipFree(ctx->mml_arena[ring]);      // (synchronises the device: no launch still reads it)
+                ctx->mml_arena[ring] = nullptr;
+                ctx->mml_arena_bytes[ring] = 0;
+                const size_t cap = (std::max(need, (size_t)4 << 20) + 4095) & ~(size_t)4095;
+                void* m = nullptr;
+                // (zeroed IN the launch stream: a plain hipMemset runs on the NULL stream, which a non-blocking stream does not wait for)
+                if (hipMalloc(&m, cap) != hipSuccess || hipMemsetAsync(m, 0, cap, s) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (m) (void)hipFree(m);
+                    return fail(ctx, CFX_ERR_LAUNCH, "min/max layer launch: cannot allocate the partials' arena");
+                }
+                ctx->mml_arena[ring] = (u64*)m;
+                ctx->mml_arena_bytes[ring] = cap;
+            }
+            a.part = ctx->mml_arena[ring];
+            a.stamps = (u64*)ctx->dbg_stamps;
+            a.codedone = ctx->colgate + (size_t)ring * MML_MAX_TILES;
+            a.tall = tall ? 1 : 0;
+            a.seq = ++ctx->mml_seq;
             a.err = ctx->gate_err;
             memcpy(a.src, src, sizeof(src));
             if (xg && n_gated) {

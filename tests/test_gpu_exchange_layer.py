@@ -21,7 +21,8 @@ CASES = ['test_flag_relay_without_a_communicator',
          'test_one_launch_form_only_when_the_group_leaves_room_for_a_collective_kernel',
          'test_two_rank_threads_exchange_for_real',
          'test_p2p_exchange_two_processes_one_gpu',
-         'test_p2p_sync_chain_two_processes_one_gpu']
+         'test_p2p_sync_chain_two_processes_one_gpu',
+         'test_p2p_exchange_layer_of_the_other_codecs_in_one_launch']
 
 
 @pytest.mark.parametrize("case", CASES)

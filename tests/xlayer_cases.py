@@ -540,3 +540,76 @@ def test_p2p_exchange_two_processes_one_gpu(tmp_path, N, C, masked):
         got = np.load(tmp_path / f"peer{1 - r}_{r}.npy")
         assert np.array_equal(got, own), f"rank {1 - r}: reconstruction of rank {r}'s shard differs from rank {r}'s own state"
         assert np.array_equal(own, _oracle_replay(tmp_path, r, 1, N, C, steps)), f"rank {r}: error-feedback states differ from the oracle's replay"
+
+
+@pytest.mark.parametrize("codec,N,C,P", [(3, 1024, 1152, 1), (4, 1024, 1152, 1), (3, 4448, 3072, 3), (4, 4096, 1152, 2), (2, 544, 3072, 7), (3, 96, 1024, 3)])
+def test_p2p_exchange_layer_of_the_other_codecs_in_one_launch(codec, N, C, P):
+    """cfx_plan_add_exchange_layer_p2p with no live peer (what compact/xlayer.py issues on one GPU, and the launch structure at any N) for the
+    int4 / int8 / 2-bit codecs at BASELINE's shards - (1024, 1152) config 2, (4448, 3072) config 4 (the TALL form of the min/max layer launch:
+    its statistics tiles do not fit the chip at once), (4096, 1152) config 1's tensor: ONE kernel per layer (id 31: statistics, scales,
+    codes, error feedback, the exchange's published word and the gated reconstruction of every looped-back peer), states equal to the
+    in-order sequence compress ; reconstruct bit for bit after several steps, and to the C oracle's replay."""
+    import numpy as np
+    from compactfusion_amd import _lib, codecs as K
+    from oracle import c_oracle as CO
+    lib, ctx = _lib.load(), K.context(0)
+    L, steps = 2, 4
+    g = torch.Generator(device="cuda").manual_seed(11 + N)
+    x0 = torch.randn(L, 2, N, C, generator=g, device="cuda").half()
+    xs = [(x0.float() + 0.1 * (s + 1) * torch.randn(L, 2, N, C, generator=g, device="cuda")).half() for s in range(2)]
+    slot = (K.packet_bytes(codec, N, C, 0) + 255) // 256 * 256
+    flags_off = L * 2 * slot
+    ipc, handle = ctypes.c_void_p(), (ctypes.c_ubyte * 64)()
+    assert lib.cfx_ipc_alloc(ctx, flags_off + 2 * L * 64, ctypes.byref(ipc), handle) == 0, lib.cfx_last_error_string(ctx)
+    wsb = lib.cfx_workspace_bytes(codec, N, C, 0, 2)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+    run = torch.cuda.Stream()
+    res = {}
+    try:
+        for kind in ("inorder", "p2p"):
+            own = x0.clone()
+            peer = x0.unsqueeze(1).repeat(1, P, 1, 1, 1).contiguous()
+            plans = []
+            for s in range(2):
+                plan = lib.cfx_plan_create(ctx)
+                for l in range(L):
+                    c = (_lib.CompItem * 2)(*[_lib.CompItem(xs[s][l, b].data_ptr(), own[l, b].data_ptr(), own[l, b].data_ptr(), ipc.value + (l * 2 + b) * slot)
+                                              for b in range(2)])
+                    items = [_lib.DecompItem(ipc.value + (l * 2 + b) * slot, peer[l, p, b].data_ptr(), peer[l, p, b].data_ptr()) for p in range(P) for b in range(2)]
+                    d = (_lib.DecompItem * len(items))(*items)
+                    if kind == "p2p":
+                        rc = lib.cfx_plan_add_exchange_layer_p2p(plan, codec, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, c, len(items), d,
+                                                                 ipc.value + flags_off + (s * L + l) * 64, 0, (ctypes.c_void_p * 1)(), ws.data_ptr(), wsb)
+                        assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
+                    else:
+                        assert lib.cfx_plan_add_compress(plan, codec, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, c, ws.data_ptr(), wsb) >= 0
+                        assert lib.cfx_plan_add_decompress(plan, codec, N, C, 0, len(items), d) >= 0
+                assert lib.cfx_plan_finalize(plan) == 0
+                plans.append(plan)
+            torch.cuda.synchronize()
+            if kind == "p2p":
+                assert lib.cfx_profile_enable(ctx, 256, 0xffffffff, 1) == 0
+            for i in range(steps):
+                assert lib.cfx_plan_run(plans[i & 1], 0, lib.cfx_plan_size(plans[i & 1]), run.cuda_stream) == 0, lib.cfx_last_error_string(ctx)
+            torch.cuda.synchronize()
+            if kind == "p2p":
+                ids, ms = (ctypes.c_int * 256)(), (ctypes.c_float * 256)()
+                n_ids = lib.cfx_profile_read(ctx, ids, ms, 256)
+                lib.cfx_profile_enable(ctx, 0, 0, 1)
+                assert [ids[i] for i in range(n_ids)] == [31] * (steps * L), [ids[i] for i in range(n_ids)]
+            assert lib.cfx_gate_errors(ctx) == 0
+            res[kind] = (own.clone(), peer.clone())
+            for p_ in plans:
+                lib.cfx_plan_destroy(p_)
+        for a_, b_, what in zip(res["p2p"], res["inorder"], ("own states", "peer states")):
+            assert torch.equal(a_.view(torch.uint8), b_.view(torch.uint8)), f"{what} differ from the in-order sequence"
+        for p in range(P):
+            assert torch.equal(res["p2p"][1][:, p].view(torch.int16), res["p2p"][0].view(torch.int16)), f"looped-back peer {p} diverged from its owner"
+        # the C oracle's replay of layer 0, tensor 0
+        name = {2: "int2", 3: "int4", 4: "int8"}[codec]
+        st = np.ascontiguousarray(x0[0, 0].cpu().numpy().view(np.uint16))
+        for i in range(steps):
+            CO.compress(name, np.ascontiguousarray(xs[i & 1][0, 0].cpu().numpy()), st, N, C, 0, new_base=st)
+        assert np.array_equal(res["p2p"][0][0, 0].cpu().numpy().view(np.uint16), st), "own state differs from the C oracle's replay"
+    finally:
+        lib.cfx_ipc_free(ctx, ipc)

@@ -47,6 +47,7 @@ def alg_bytes(cid, N, C, L, ncomp, nrec, update):
 
 
 _STREAMS = []
+_IPC = []
 
 
 def _streams(ctx, lib):
@@ -73,29 +74,36 @@ def gpu_step(cid, param, N, C, L, ncomp, nrec, update, min_steps=20, budget_s=0.
     sh = run_stream.cuda_stream
     if not lowrank:
         slot = (K.packet_bytes(cid, N, C, param) + 255) // 256 * 256
-        pk = torch.zeros(Lb, ncomp, slot, dtype=torch.uint8, device=dev)
         wsb = lib.cfx_workspace_bytes(cid, N, C, param, ncomp)
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
         plans = []
-        # ONE exchange-layer op per layer (cfx_plan_add_exchange_layer, no communicator: the exchange stream relays the gate - the launch
-        # structure of the peer-to-peer exchange at any N): compress + the reconstruction of every tensor whose packet it feeds
+        # ONE exchange-layer op per layer, the product's default form (cfx_plan_add_exchange_layer_p2p; what compact/xlayer.py issues): the
+        # packets in the uncached IPC arena, compress + the exchange (no live peer here: one published word) + the reconstruction of every
+        # tensor whose packet it feeds in one launch for the codecs that have the layer form, in stream order for the others
         one_op = nrec <= 16
+        flags_off = Lb * ncomp * slot
+        ipc, handle = ctypes.c_void_p(), (ctypes.c_ubyte * 64)()
+        assert lib.cfx_ipc_alloc(ctx, flags_off + 2 * Lb * 64, ctypes.byref(ipc), handle) == 0, lib.cfx_last_error_string(ctx)
+        _IPC.append(ipc)
+
+        def pkp(l, i):
+            return ipc.value + (l * ncomp + i) * slot
         for s in range(2):
             plan = lib.cfx_plan_create(ctx)
-            assert lib.cfx_plan_use_exchange_stream(plan, _streams(ctx, lib)[1]) == 0
             for l in range(Lb):
                 c = (_lib.CompItem * ncomp)(*[_lib.CompItem(x[s][l, i].data_ptr(), own[l, i].data_ptr(), own[l, i].data_ptr() if update else None,
-                                                            pk[l, i].data_ptr()) for i in range(ncomp)])
+                                                            pkp(l, i)) for i in range(ncomp)])
                 if one_op:
-                    d = (_lib.DecompItem * nrec)(*[_lib.DecompItem(pk[l, j % ncomp].data_ptr(), peers[l, j].data_ptr(), peers[l, j].data_ptr())
+                    d = (_lib.DecompItem * nrec)(*[_lib.DecompItem(pkp(l, j % ncomp), peers[l, j].data_ptr(), peers[l, j].data_ptr())
                                                    for j in range(nrec)])
-                    rc = lib.cfx_plan_add_exchange_layer(plan, cid, N, C, param, 1 if update else 0, ncomp, c, nrec, d, None, None, None, 0, ws.data_ptr(), wsb)
+                    rc = lib.cfx_plan_add_exchange_layer_p2p(plan, cid, N, C, param, 1 if update else 0, ncomp, c, nrec, d,
+                                                             ipc.value + flags_off + (s * Lb + l) * 64, 0, (ctypes.c_void_p * 1)(), ws.data_ptr(), wsb)
                     assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
                     continue
                 assert lib.cfx_plan_add_compress(plan, cid, N, C, param, 1 if update else 0, ncomp, c, ws.data_ptr(), wsb) >= 0
                 for a in range(0, nrec, 16):
                     n = min(16, nrec - a)
-                    d = (_lib.DecompItem * n)(*[_lib.DecompItem(pk[l, (a + j) % ncomp].data_ptr(), peers[l, a + j].data_ptr(), peers[l, a + j].data_ptr())
+                    d = (_lib.DecompItem * n)(*[_lib.DecompItem(pkp(l, (a + j) % ncomp), peers[l, a + j].data_ptr(), peers[l, a + j].data_ptr())
                                                 for j in range(n)])
                     assert lib.cfx_plan_add_decompress(plan, cid, N, C, param, n, d) >= 0
             plans.append(plan)
@@ -151,6 +159,8 @@ def gpu_step(cid, param, N, C, L, ncomp, nrec, update, min_steps=20, budget_s=0.
     ms = (time.perf_counter() - t0) / steps * 1e3
     for plan in plans:
         lib.cfx_plan_destroy(plan)
+    while _IPC:
+        lib.cfx_ipc_free(ctx, _IPC.pop())
     return ms
 
 
