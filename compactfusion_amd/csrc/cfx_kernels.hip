@@ -1628,6 +1628,8 @@ struct MinMaxLayerArgs {
     // 0 .. MML_NRED - 1 of the block reduce 64 channels' P partials each (a wave takes every 8th partial) and publish the scales as tagged
     // words; every tile polls the 512 scales of its block
     int tall;
+    int coop;                         // the reduce by tiles 0 .. MML_NRED - 1 (always in the tall form; otherwise wherever a channel has more than
+                                      // 32 partials: every tile reducing all of them itself would take P / 8 dependent rounds of loads)
     u64* stamps;                      // cfx_debug_stamps: 16 words per workgroup (100 MHz wall clock per phase; word 7: 1 = S tile, 4 = D tile)
 };
 #define MML_STAMP(i) do { if (st && threadIdx.x == 0) st[i] = (u64)wall_clock64(); } while (0)
@@ -1799,7 +1801,7 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
     h16 scale;
     u16 second;
     constexpr int NB = RW == 4 ? 16 : 8;                    // partials in flight per thread (registers: the tile stays live)
-    if (!a.tall || by < MML_NRED) {
+    if (!a.coop || by < MML_NRED) {
         // one wave watches ONE word per tile of the block (lane i: tile i's first channel) until all carry the tag; only then does every
         // thread load its channel's P words (and checks their tags: a tile's 512 stores are not ordered among themselves).  Every thread
         // polling its own words from the start is a hop shorter on an idle chip - and a storm of 8192 loads per tile and round that starves
@@ -1817,7 +1819,7 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
         }
         __syncthreads();
     }
-    if (!a.tall) {
+    if (!a.coop) {
         // ---- every tile of the column block reduces the block's P partials itself: no last arriver, no second hand-over ----
         h16 lo = hfrom(0x7c00), hi = hfrom(0xfc00);
         for (int p0 = 0; p0 < a.P; p0 += NB) {
@@ -2043,7 +2045,7 @@ __device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, c
             const unsigned* f = a.codedone + ((size_t)a.src[item] * a.CB + bx) * a.P;
             const int by0 = t.r0 / a.R, by1 = (t.r1 - 1) / a.R;
             const int lane = threadIdx.x & 63;
-            const int nsc = a.tall ? MML_NRED : 1;
+            const int nsc = a.coop ? MML_NRED : 1;
             unsigned spins = 0;
             for (;;) {
                 const int idx = lane < nsc ? lane : by0 + lane - nsc;
@@ -3224,6 +3226,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             a.stamps = (u64*)ctx->dbg_stamps;
             a.codedone = ctx->colgate + (size_t)ring * MML_MAX_TILES;
             a.tall = tall ? 1 : 0;
+            a.coop = (tall || PL > 32) ? 1 : 0;
             a.seq = ++ctx->mml_seq;
             a.err = ctx->gate_err;
             memcpy(a.src, src, sizeof(src));

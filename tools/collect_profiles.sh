@@ -85,8 +85,16 @@ timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --mas
 cd /tmp
 TR2=$OUT/trace_xl
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$TR2" -- python3 "$R/bench.py" --steps 8 --warmup 2 --no-secondary --no-cpu-baseline --no-kernel-events --overlap-steps 0 --plugin-steps 0 --no-config-table > /dev/null 2>&1 < /dev/null
+python3 "$R/tools/xlayer_trace.py" "$(find "$TR2" -name '*kernel_trace.csv' | head -1)" > "$OUT/r04_layer_kernel_trace.txt" 2>&1
+rm -rf "$TR2"
+# (the same step with the exchange as a kernel on the exchange stream - the form until mid round 4, still what `--p2p off` runs)
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$TR2" -- python3 "$R/bench.py" --p2p off --steps 8 --warmup 2 --no-secondary --no-cpu-baseline --no-kernel-events --overlap-steps 0 --plugin-steps 0 --no-config-table > /dev/null 2>&1 < /dev/null
 python3 "$R/tools/xlayer_trace.py" "$(find "$TR2" -name '*kernel_trace.csv' | head -1)" > "$OUT/r04_layer_vs_flag_kernel_trace.txt" 2>&1
 rm -rf "$TR2"
+cd "$R"
+# the int4 / int8 layer launch's phase timeline at BASELINE's shards (config 2, config 1, config 4 = the tall form)
+{ N=1024 C=1152 B=2 NP=2 CODEC=3 python3 tools/mml_stamps.py; N=4096 C=1152 B=1 NP=0 CODEC=4 python3 tools/mml_stamps.py; N=4448 C=3072 B=2 NP=6 CODEC=3 python3 tools/mml_stamps.py; } 2>&1 | grep -v amdgpu.ids > "$OUT/r04_minmax_layer_timeline.txt"
+cd /tmp
 mkdir -p "$OUT/pmc_codecs"
 for cfg in 1 2 3 3b 4 5; do for form in layer launches; do
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pf" -o pmc -- python3 "$R/tools/codec_pmc_run.py" $cfg $form > /dev/null 2>&1 < /dev/null

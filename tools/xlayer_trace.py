@@ -1,5 +1,7 @@
-"""Developer tool: from a rocprofv3 kernel-trace CSV, how the layer launch and the exchange stream's flag kernel of each layer sit relative
-to each other: flag kernel start / end after the layer kernel's start, layer kernel end after the flag kernel's end (us, medians).
+"""Developer tool: from a rocprofv3 kernel-trace CSV of a bench step, the layer launches' durations and the gaps between them; where the
+exchange runs as a kernel of its own on the exchange stream (`--p2p off`, or the collective form) also how that flag kernel sits relative to
+the layer kernel: start / end after the layer kernel's start, layer kernel end after the flag kernel's end (us).  With the peer-to-peer
+exchange INSIDE the layer launch (the default since mid round 4) there is no flag kernel: the step is one kernel per layer.
 usage: python tools/xlayer_trace.py <kernel_trace.csv>"""
 import csv, sys, statistics as st
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -21,6 +23,9 @@ for i, r in enumerate(lay):
 def q(v): return "n=%d p10 %.1f p50 %.1f p90 %.1f" % (len(v), st.quantiles(v, n=10)[0], st.median(v), st.quantiles(v, n=10)[-1]) if len(v) > 10 else str(v)
 print("layer kernel duration      ", q(dur))
 print("gap between layer kernels  ", q(gap))
-print("flag kernel start - layer start", q(ds))
-print("flag kernel end   - layer start", q(de))
-print("layer end - flag kernel end    ", q(tail))
+if flg:
+    print("flag kernel start - layer start", q(ds))
+    print("flag kernel end   - layer start", q(de))
+    print("layer end - flag kernel end    ", q(tail))
+else:
+    print("no exchange-stream kernel in the trace: the exchange runs inside the layer launch (one kernel per layer)")
