@@ -3,7 +3,7 @@
 What the reference does per layer and denoise step in Python (xfuser/compact/main.py:390-420 `compact_all_gather`: compress, list
 all-gather, W decompress calls; patchpara/fwd.py:88-102; ring.py:188-206 + 265-269: compress K and V, W-1 relay hops, a
 decompress per hop) is here ONE host call into libcfx per layer: `cfx_plan_add_exchange_layer[_p2p]` replayed by `cfx_plan_run_x`
-(include/cfx.h).  For the quantising codecs (1-bit, 2-bit, int4, int8) that is ONE codec launch whose reconstruction workgroups wait, state
+(include/cfx.h).  For every streaming codec (1-bit, 2-bit, int4, int8, top-k) that is ONE codec launch whose reconstruction workgroups wait, state
 tiles already in registers, for the packets' arrival - and in the peer-to-peer transport the exchange itself (publish this rank's word, await
 the peers') runs inside that launch; top-k and shapes without the one-launch form run the same work in stream order
 (compress ; exchange ; reconstruct) - same results, still one host call.

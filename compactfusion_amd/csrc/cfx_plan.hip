@@ -221,8 +221,6 @@ int cfx_plan_add_compress_gated(cfx_plan* p, int codec, int N, int C, int param,
                                 void* workspace, size_t workspace_bytes) {
     if (!p) return CFX_ERR_NULL;
     if (n_gated < 0 || n_gated > CFX_MAX_BATCH || (n_gated && !gated)) return fail(p->ctx, CFX_ERR_BATCH, "plan: gated batch out of range");
-    if (n_gated && codec == CFX_CODEC_TOPK)
-        return fail(p->ctx, CFX_ERR_CODEC, "plan: gated reconstruction items need one of the quantising codecs (1-bit, 2-bit, int4, int8)");
     const int op = cfx_plan_add_compress_ex(p, codec, N, C, param, flags, batch, items, n_ride, ride, workspace, workspace_bytes);
     if (op < 0) return op;
     p->ops[op].n_gated = n_gated;
@@ -635,7 +633,7 @@ static int plan_run_impl(cfx_plan* p, int first_op, int n_ops, void* stream, boo
                 if (inline_p2p) { xg.p2p_own = o->own_flag; xg.p2p_peer = o->peer_flag; xg.p2p_n = o->n_peers; }
                 if (own_stream) {
                     rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, 0, nullptr, o->n_gated, o->g, o->ws, o->ws_bytes, stream, &xg);
-                } else if (o->kind == 9 && !o->comm && o->codec != CFX_CODEC_TOPK) {
+                } else if (o->kind == 9 && !o->comm) {
                     // nothing moves and nobody else publishes: the reconstruction items' packets are this launch's own - the ordinary gated launch
                     rc = compress_impl(p->ctx, o->codec, o->N, o->C, o->param, o->flags, o->batch, o->c, 0, nullptr, o->n_gated, o->g, o->ws, o->ws_bytes, stream);
                     break;

@@ -121,14 +121,16 @@ int cfx_compress_batch_ex(cfx_ctx* ctx, int codec, int N, int C, int param, int 
                           int batch, const cfx_comp_item* items, int n_ride, const cfx_decomp_item* ride,
                           void* workspace, size_t workspace_bytes, void* stream);
 
-/* cfx_compress_batch_ex plus `n_gated` reconstruction items (1-bit or 2-bit codec, same shape) whose PACKETS ARE PRODUCED BY THIS CALL:
+/* cfx_compress_batch_ex plus `n_gated` reconstruction items (any streaming codec, same shape) whose PACKETS ARE PRODUCED BY THIS CALL:
  * typically the call's own packets applied to the rank's own state (the error-feedback update, fastpath.py:88-120) and -
  * when logical peers are looped back on one GPU - to the peers' states.  They run in the SAME launch as the compress: their
  * workgroups first pull the state tiles into registers (bandwidth work that overlaps the scale reduction, which is pure
  * latency), wait on an arrival counter until the packet is complete, then finish from registers.  One launch per layer instead
  * of two, 2.125 instead of 4.125 B/el behind the dependency.  With CFX_FLAG_UPDATE_CACHE the call's own error-feedback update
  * (new_base) is part of the launch too (1-bit: as two more gated tensors; 2-bit: the statistics workgroups quantise their own
- * tiles from registers once the scales exist, a second gate releases the gated items).  Results are identical to compress
+ * tiles from registers once the scales exist, a second gate releases the gated items; int4 / int8: k_minmax_layer, the statistics tile kept
+ * in registers, codes and the state update from them; top-k: k_topk_layer, nothing global to wait for - the gate counts the compress
+ * workgroups).  Results are identical to compress
  * followed by cfx_decompress_batch; when the shape does not qualify (C % 128 != 0, statistics tile != 32 rows, in-launch
  * finalize off, too many items for one launch) exactly that sequence runs.
  * A gated item's base/recon must not alias this call's x / packet operands; recon may equal base, and a gated item may

@@ -548,7 +548,7 @@ def test_gated_reconstruction_in_the_compress_launch(shape, B, NG, own_ef):
             assert torch.equal(peer[l][g - B].view(torch.int16), own[l * B + src[g]].view(torch.int16)), f"peer {g} of layer {l} diverged from its owner"
 
 
-@pytest.mark.parametrize("name,cid", [("int2", 2), ("int4", 3), ("int8", 4)])
+@pytest.mark.parametrize("name,cid", [("int2", 2), ("int4", 3), ("int8", 4), ("topk", 5)])
 @pytest.mark.parametrize("shape,B,NP", [((544, 3072), 2, 14), ((512, 1536), 2, 14), ((256, 1152), 1, 3), ((130, 1024), 2, 5), ((64, 264), 1, 2),
                                         ((2, 512), 1, 2), ((34, 8192), 2, 6), ((1024, 1152), 2, 4), ((4096, 1152), 1, 1), ((4448, 3072), 2, 6)])
 def test_gated_int2_layer_in_one_launch(shape, B, NP, name, cid):
@@ -562,6 +562,9 @@ def test_gated_int2_layer_in_one_launch(shape, B, NP, name, cid):
     N, C = shape
     ctx = K.context(0)
     CID = cid
+    PRM = 8 if cid == 5 else 0                      # top-k: 1:8
+    if cid == 5 and (N * C) % 1024:
+        pytest.skip("the top-k codec works on the flat (-1, 1024) view")
     L = 3
     xs, bs = [], []
     for l in range(L):
@@ -572,8 +575,9 @@ def test_gated_int2_layer_in_one_launch(shape, B, NP, name, cid):
     own = [dev(b) for b in bs]
     src = [i % B for i in range(NP)]
     peer = [[dev(bs[l * B + src[g]]) for g in range(NP)] for l in range(L)]
-    pk = [torch.zeros(K.packet_halves(CID, N, C), dtype=torch.float16, device="cuda") for _ in range(L * B)]
-    ws = K.workspace(CID, N, C, 0, B, 0)
+    pk = [torch.zeros(K.packet_halves(CID, N, C, PRM), dtype=torch.float16, device="cuda") for _ in range(L * B)]
+    ws = K.workspace(CID, N, C, PRM, B, 0)
+    wsp, wsn = (None, 0) if ws is None else (ws.data_ptr(), ws.numel())
     sh = torch.cuda.current_stream().cuda_stream
     hog_s = torch.cuda.Stream()
     hog = torch.empty(64 << 20, dtype=torch.float16, device="cuda")
@@ -585,11 +589,11 @@ def test_gated_int2_layer_in_one_launch(shape, B, NP, name, cid):
                                               for g in range(NP)]))
 
     def go(l):
-        assert lib.cfx_compress_batch_gated(ctx, CID, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, comp[l], 0, None, NP, gated[l],
-                                            ws.data_ptr(), ws.numel(), sh) == 0
+        assert lib.cfx_compress_batch_gated(ctx, CID, N, C, PRM, _lib.FLAG_UPDATE_CACHE, B, comp[l], 0, None, NP, gated[l],
+                                            wsp, wsn, sh) == 0
     RL = 32 if (N + 31) // 32 <= 32 else 64
     PL, CBk = (N + RL - 1) // RL, (C + 511) // 512
-    if cid in (3, 4) and C % 16 == 0 and PL <= 128 and (PL * CBk * B <= 500 or (RL == 64 and PL * 4 <= 512)):
+    if cid == 5 or (cid in (3, 4) and C % 16 == 0 and PL <= 128 and (PL * CBk * B <= 500 or (RL == 64 and PL * 4 <= 512))):
         # the layer launch itself: one kernel (id 31), no statistics / quantise / reconstruction launch beside it
         import ctypes as _ct
         torch.cuda.synchronize()
@@ -615,7 +619,7 @@ def test_gated_int2_layer_in_one_launch(shape, B, NP, name, cid):
             go(l)
             for i in range(B):
                 k = l * B + i
-                p, nb = R.residual_compress(name, xs[k], ostate[k].view(F16), 0)
+                p, nb = R.residual_compress(name, xs[k], ostate[k].view(F16), PRM)
                 opk[k] = p; ostate[k] = R.bits(nb).copy()
     torch.cuda.synchronize()
     assert lib.cfx_gate_errors(ctx) == 0
@@ -636,7 +640,7 @@ def test_gated_int2_layer_in_one_launch(shape, B, NP, name, cid):
         l = r % L
         c = (_lib.CompItem * B)(*[_lib.CompItem(xd[l * B + i].data_ptr(), ref_own[l * B + i].data_ptr(), ref_own[l * B + i].data_ptr(),
                                                 ref_pk[l * B + i].data_ptr()) for i in range(B)])
-        assert lib.cfx_compress_batch_ex(ctx, CID, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, c, 0, None, ws.data_ptr(), ws.numel(), sh) == 0
+        assert lib.cfx_compress_batch_ex(ctx, CID, N, C, PRM, _lib.FLAG_UPDATE_CACHE, B, c, 0, None, wsp, wsn, sh) == 0
     torch.cuda.synchronize()
     for k in range(L * B):
         assert torch.equal(own[k].view(torch.int16), ref_own[k].view(torch.int16)), f"own state {k} after {reps} gated launches"
@@ -647,8 +651,8 @@ def test_gated_int2_layer_in_one_launch(shape, B, NP, name, cid):
 
 
 def test_gated_launch_argument_errors():
-    """cfx_compress_batch_gated / cfx_plan_add_compress_gated refuse what they cannot run: a codec without a gated form, too many
-    gated items, a null item list, misaligned pointers."""
+    """cfx_compress_batch_gated / cfx_plan_add_compress_gated refuse what they cannot run: an unknown codec, too many gated items, a null
+    item list, misaligned pointers."""
     from compactfusion_amd import _lib, codecs as K
     lib = _lib.load()
     N, C = 64, 256
@@ -659,13 +663,13 @@ def test_gated_launch_argument_errors():
     sh = torch.cuda.current_stream().cuda_stream
     c = (_lib.CompItem * 1)(_lib.CompItem(x.data_ptr(), b.data_ptr(), None, pk.data_ptr()))
     g = (_lib.DecompItem * 1)(_lib.DecompItem(pk.data_ptr(), b.data_ptr(), b.data_ptr()))
-    assert lib.cfx_compress_batch_gated(ctx, 5, 64, 256, 8, 0, 1, c, 0, None, 1, g, ws.data_ptr(), ws.numel(), sh) == -4      # top-k: no gated form
+    assert lib.cfx_compress_batch_gated(ctx, 9, 64, 256, 8, 0, 1, c, 0, None, 1, g, ws.data_ptr(), ws.numel(), sh) == -4      # no such codec
     assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, 0, 1, c, 0, None, 17, g, ws.data_ptr(), ws.numel(), sh) == -5     # > CFX_MAX_BATCH
     assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, 0, 1, c, 0, None, 1, None, ws.data_ptr(), ws.numel(), sh) == -5
     bad = (_lib.DecompItem * 1)(_lib.DecompItem(pk.data_ptr() + 2, b.data_ptr(), b.data_ptr()))
     assert lib.cfx_compress_batch_gated(ctx, 1, N, C, 0, 0, 1, c, 0, None, 1, bad, ws.data_ptr(), ws.numel(), sh) == -3    # alignment
     plan = lib.cfx_plan_create(ctx)
-    assert lib.cfx_plan_add_compress_gated(plan, 5, N, C, 8, 0, 1, c, 0, None, 1, g, ws.data_ptr(), ws.numel()) == -4
+    assert lib.cfx_plan_add_compress_gated(plan, 9, N, C, 8, 0, 1, c, 0, None, 1, g, ws.data_ptr(), ws.numel()) == -2     # (a plan op checks codec and shape together)
     assert lib.cfx_plan_add_compress_gated(plan, 1, N, C, 0, 0, 1, c, 0, None, 1, g, ws.data_ptr(), ws.numel()) == 0
     lib.cfx_plan_destroy(plan)
     torch.cuda.synchronize()

@@ -542,10 +542,11 @@ def test_p2p_exchange_two_processes_one_gpu(tmp_path, N, C, masked):
         assert np.array_equal(own, _oracle_replay(tmp_path, r, 1, N, C, steps)), f"rank {r}: error-feedback states differ from the oracle's replay"
 
 
-@pytest.mark.parametrize("codec,N,C,P", [(3, 1024, 1152, 1), (4, 1024, 1152, 1), (3, 4448, 3072, 3), (4, 4096, 1152, 2), (2, 544, 3072, 7), (3, 96, 1024, 3)])
+@pytest.mark.parametrize("codec,N,C,P", [(3, 1024, 1152, 1), (4, 1024, 1152, 1), (3, 4448, 3072, 3), (4, 4096, 1152, 2), (2, 544, 3072, 7), (3, 96, 1024, 3),
+                                         (5, 512, 1536, 7), (5, 64, 512, 2)])
 def test_p2p_exchange_layer_of_the_other_codecs_in_one_launch(codec, N, C, P):
     """cfx_plan_add_exchange_layer_p2p with no live peer (what compact/xlayer.py issues on one GPU, and the launch structure at any N) for the
-    int4 / int8 / 2-bit codecs at BASELINE's shards - (1024, 1152) config 2, (4448, 3072) config 4 (the TALL form of the min/max layer launch:
+    int4 / int8 / 2-bit / top-k codecs at BASELINE's shards - (1024, 1152) config 2, (4448, 3072) config 4 (the TALL form of the min/max layer launch:
     its statistics tiles do not fit the chip at once), (4096, 1152) config 1's tensor: ONE kernel per layer (id 31: statistics, scales,
     codes, error feedback, the exchange's published word and the gated reconstruction of every looped-back peer), states equal to the
     in-order sequence compress ; reconstruct bit for bit after several steps, and to the C oracle's replay."""
@@ -554,14 +555,15 @@ def test_p2p_exchange_layer_of_the_other_codecs_in_one_launch(codec, N, C, P):
     from oracle import c_oracle as CO
     lib, ctx = _lib.load(), K.context(0)
     L, steps = 2, 4
+    PRM = 8 if codec == 5 else 0                     # top-k: 1:8 (BASELINE config 5)
     g = torch.Generator(device="cuda").manual_seed(11 + N)
     x0 = torch.randn(L, 2, N, C, generator=g, device="cuda").half()
     xs = [(x0.float() + 0.1 * (s + 1) * torch.randn(L, 2, N, C, generator=g, device="cuda")).half() for s in range(2)]
-    slot = (K.packet_bytes(codec, N, C, 0) + 255) // 256 * 256
+    slot = (K.packet_bytes(codec, N, C, PRM) + 255) // 256 * 256
     flags_off = L * 2 * slot
     ipc, handle = ctypes.c_void_p(), (ctypes.c_ubyte * 64)()
     assert lib.cfx_ipc_alloc(ctx, flags_off + 2 * L * 64, ctypes.byref(ipc), handle) == 0, lib.cfx_last_error_string(ctx)
-    wsb = lib.cfx_workspace_bytes(codec, N, C, 0, 2)
+    wsb = lib.cfx_workspace_bytes(codec, N, C, PRM, 2)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
     run = torch.cuda.Stream()
     res = {}
@@ -578,12 +580,12 @@ def test_p2p_exchange_layer_of_the_other_codecs_in_one_launch(codec, N, C, P):
                     items = [_lib.DecompItem(ipc.value + (l * 2 + b) * slot, peer[l, p, b].data_ptr(), peer[l, p, b].data_ptr()) for p in range(P) for b in range(2)]
                     d = (_lib.DecompItem * len(items))(*items)
                     if kind == "p2p":
-                        rc = lib.cfx_plan_add_exchange_layer_p2p(plan, codec, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, c, len(items), d,
+                        rc = lib.cfx_plan_add_exchange_layer_p2p(plan, codec, N, C, PRM, _lib.FLAG_UPDATE_CACHE, 2, c, len(items), d,
                                                                  ipc.value + flags_off + (s * L + l) * 64, 0, (ctypes.c_void_p * 1)(), ws.data_ptr(), wsb)
                         assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
                     else:
-                        assert lib.cfx_plan_add_compress(plan, codec, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, c, ws.data_ptr(), wsb) >= 0
-                        assert lib.cfx_plan_add_decompress(plan, codec, N, C, 0, len(items), d) >= 0
+                        assert lib.cfx_plan_add_compress(plan, codec, N, C, PRM, _lib.FLAG_UPDATE_CACHE, 2, c, ws.data_ptr(), wsb) >= 0
+                        assert lib.cfx_plan_add_decompress(plan, codec, N, C, PRM, len(items), d) >= 0
                 assert lib.cfx_plan_finalize(plan) == 0
                 plans.append(plan)
             torch.cuda.synchronize()
@@ -606,10 +608,10 @@ def test_p2p_exchange_layer_of_the_other_codecs_in_one_launch(codec, N, C, P):
         for p in range(P):
             assert torch.equal(res["p2p"][1][:, p].view(torch.int16), res["p2p"][0].view(torch.int16)), f"looped-back peer {p} diverged from its owner"
         # the C oracle's replay of layer 0, tensor 0
-        name = {2: "int2", 3: "int4", 4: "int8"}[codec]
+        name = {2: "int2", 3: "int4", 4: "int8", 5: "topk"}[codec]
         st = np.ascontiguousarray(x0[0, 0].cpu().numpy().view(np.uint16))
         for i in range(steps):
-            CO.compress(name, np.ascontiguousarray(xs[i & 1][0, 0].cpu().numpy()), st, N, C, 0, new_base=st)
+            CO.compress(name, np.ascontiguousarray(xs[i & 1][0, 0].cpu().numpy()), st, N, C, PRM, new_base=st)
         assert np.array_equal(res["p2p"][0][0, 0].cpu().numpy().view(np.uint16), st), "own state differs from the C oracle's replay"
     finally:
         lib.cfx_ipc_free(ctx, ipc)
