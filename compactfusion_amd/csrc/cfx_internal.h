@@ -25,7 +25,7 @@ static const char* const kid_names[KID_MAX] = {
     "k_lr_prep | k_lrs (slab-resident chain, one launch)", "k_lr_aq", "k_lr_aty", "k_lr_chol", "k_lr_apply", "k_lr_decode",
     "k_binary_pipe", "k_binary_pipe(prologue/epilogue)", "k_residual2_delta", "k_residual2_update",
     "k_absmean_compress<bits>", "k_absmean_compress", "k_minmax_compress", "k_attn_merge",
-    "gated layer launch (k_absmean_compress<bits,gated> / k_int2_compress_gated / k_minmax_layer)"};
+    "gated layer launch (k_absmean_compress<bits,gated> / k_int2_compress_gated / k_minmax_layer / k_topk_layer)"};
 
 struct ProfRec { int kid; hipEvent_t a, b; };
 #define CFX_RING_STREAMS 8       // ticket / gate rings of a context: one per stream that issues compress launches
@@ -56,6 +56,8 @@ struct cfx_ctx {
     unsigned mml_seq;               // sequence number of the min/max layer launches of this context: the value of a launch's flags and the tag of its partials
     unsigned long long* mml_arena[CFX_RING_STREAMS];        // per ring: tagged partials + scales of the min/max layer launch (zeroed at allocation, grown on demand)
     size_t mml_arena_bytes[CFX_RING_STREAMS];
+    bool mml_arena_owned[CFX_RING_STREAMS];
+    void* mml_arena_owner[CFX_RING_STREAMS];   // the stream whose launches use the ring's arena (a change of owner waits for the previous one's launches)
     unsigned* gate_err;             // pinned HOST word (device-visible): waits that timed out since the last cfx_gate_errors
     long long gate_timeout;         // ticks of the 100 MHz wall clock a flag wait may last
     int fused;                      // 1 (default): compress = statistics + in-launch finalize; 0: separate finalize kernel

@@ -3377,6 +3377,13 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             // later launch expects, so it starts zeroed and only ever takes this context's sequence numbers (which are not reused)
             a.part_stride = (size_t)(PL + 1) * C;
             const size_t need = a.part_stride * batch * sizeof(u64);
+            if (!ctx->mml_arena_owned[ring] || ctx->mml_arena_owner[ring] != stream) {
+                // the ring - and with it the arena - changed hands (more than CFX_RING_STREAMS streams issue compress launches): whatever its
+                // previous owner still has in flight reads this arena.  Rare by construction; wait for it
+                if (ctx->mml_arena_owned[ring]) (void)hipDeviceSynchronize();
+                ctx->mml_arena_owner[ring] = stream;
+                ctx->mml_arena_owned[ring] = true;
+            }
             if (ctx->mml_arena_bytes[ring] < need) {
                 if (ctx->mml_arena[ring]) (void)hipFree(ctx->mml_arena[ring]);      // (synchronises the device: no launch still reads it)
                 ctx->mml_arena[ring] = nullptr;

@@ -676,6 +676,42 @@ def test_gated_launch_argument_errors():
     assert lib.cfx_gate_errors(ctx) == 0
 
 
+@pytest.mark.parametrize("name,cid", [("int4", 3), ("int8", 4)])
+def test_minmax_layer_launches_from_more_streams_than_rings(name, cid):
+    """The int4 / int8 layer launch hands its partials over as tagged words in an arena the context keeps PER STREAM (per ticket ring: 8).
+    Twelve streams taking turns make the rings - and their arenas - change hands again and again while launches are in flight: every
+    launch must still equal the oracle (a change of owner waits for the previous owner's launches), and no wait may time out."""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    ctx = K.context(0)
+    N, C, S, ROUNDS = 256, 1024, 12, 3
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    xs = [[make_inputs(700 + 10 * s + r, N, C)[0] for r in range(ROUNDS)] for s in range(S)]
+    b0 = [make_inputs(900 + s, N, C)[1] for s in range(S)]
+    xd = [[dev(x) for x in row] for row in xs]
+    own = [dev(b) for b in b0]
+    peer = [dev(b) for b in b0]
+    pk = [torch.zeros(K.packet_halves(cid, N, C), dtype=torch.float16, device="cuda") for _ in range(S)]
+    ws = [K.workspace(cid, N, C, 0, 1, 0, stream_handle=st.cuda_stream) for st in streams]
+    torch.cuda.synchronize()
+    for r in range(ROUNDS):
+        for s, st in enumerate(streams):
+            c = (_lib.CompItem * 1)(_lib.CompItem(xd[s][r].data_ptr(), own[s].data_ptr(), own[s].data_ptr(), pk[s].data_ptr()))
+            g = (_lib.DecompItem * 1)(_lib.DecompItem(pk[s].data_ptr(), peer[s].data_ptr(), peer[s].data_ptr()))
+            assert lib.cfx_compress_batch_gated(ctx, cid, N, C, 0, _lib.FLAG_UPDATE_CACHE, 1, c, 0, None, 1, g, ws[s].data_ptr(), ws[s].numel(),
+                                                st.cuda_stream) == 0, lib.cfx_last_error_string(ctx)
+    torch.cuda.synchronize()
+    assert lib.cfx_gate_errors(ctx) == 0
+    for s in range(S):
+        st = R.bits(b0[s]).copy()
+        for r in range(ROUNDS):
+            p, nb = R.residual_compress(name, xs[s][r], st.view(F16), 0)
+            st = R.bits(nb).copy()
+        same_bits(host_bits(own[s]), st, f"stream {s}: own state")
+        same_bits(host_bits(peer[s]), st, f"stream {s}: looped-back peer state")
+        same_bits(host_bits(pk[s]), p, f"stream {s}: last packet")
+
+
 def test_gated_item_with_a_packet_from_an_earlier_launch():
     """A gated item whose packet was NOT produced by this launch (an older packet of the same codec and shape) is legal: it waits
     for the gate like the others and reconstructs from the packet as it stands."""
