@@ -178,6 +178,17 @@ def test_two_processes_two_generations_peer_to_peer(tmp_path, mode, codec):
     _check_states(res, codec, mode, 2, 2)
 
 
+@pytest.mark.parametrize("world,mode,codec", [(4, "ring", "BINARY"), (3, "gather", "INT4")])
+def test_more_than_two_rank_processes_peer_to_peer(tmp_path, world, mode, codec):
+    """Three / four rank processes on one GPU: every layer launch publishes its word and awaits world - 1 peers' words inside the launch, its
+    reconstruction workgroups read world - 1 other processes' packets in place (which peer's packet goes to which state, and which word is
+    whose, only shows with more than one peer).  States of every rank's view of every rank == the oracle's chains."""
+    res = _spawn(W.w_xlayer, world, tmp_path, codec, mode, -1, 1)
+    for r in range(world):
+        assert int(res[r]["n_ops"][0]) == 3 and int(res[r]["p2p"][0]) == 3 and int(res[r]["fell_back"][0]) == 0, "the peer-to-peer layer op was not taken"
+    _check_states(res, codec, mode, world, 1)
+
+
 @pytest.mark.parametrize("poison", [0, 1])
 def test_poisoned_reconstruction_sends_every_rank_to_the_next_transport(tmp_path, poison):
     """A reconstruction that differs from its owner's state (what a stale cache line would produce - from the SECOND use of an address on)
