@@ -1634,37 +1634,6 @@ struct MinMaxLayerArgs {
     u64* stamps;                      // cfx_debug_stamps: 16 words per workgroup (100 MHz wall clock per phase; word 7: 1 = S tile, 4 = D tile)
 };
 #define MML_STAMP(i) do { if (st && threadIdx.x == 0) st[i] = (u64)wall_clock64(); } while (0)
-// codes of 8 channels of one row (int8) / one row pair (int4), exactly as k_int8_quant / k_int4_quant compute them
-__device__ __forceinline__ u64 int8_codes(h16x8 d, h16x8 sc, h16x8 zp) {
-    u64 outb = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        h16 v = hrint(hdiv(d[i], sc[i]) + zp[i]);
-        if (hisnan(v)) v = (h16)0;
-        v = v < (h16)-128.0f ? (h16)-128.0f : v;
-        v = v > (h16)127.0f ? (h16)127.0f : v;
-        const int qi = (int)(float)v;
-        outb |= (u64)(unsigned char)(signed char)qi << (8 * i);
-    }
-    return outb;
-}
-__device__ __forceinline__ u64 int4_codes(h16x8 d0, h16x8 d1, h16x8 sc, h16x8 mn) {
-    u64 outb = 0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const h16x8 dm = (h ? d1 : d0) - mn;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            h16 v = hrint(hdiv(dm[i], sc[i]));
-            if (hisnan(v)) v = (h16)0;
-            v = v < (h16)0 ? (h16)0 : v;
-            v = v > (h16)15.0f ? (h16)15.0f : v;
-            const unsigned qi = (unsigned)(float)v & 15u;
-            outb |= (u64)qi << (8 * i + 4 * h);
-        }
-    }
-    return outb;
-}
 // received values of 8 channels of row h of a code row (int8: h = 0): k_int8_dequant / k_int4_dequant arithmetic
 template <bool INT4>
 __device__ __forceinline__ h16x8 minmax_recv(u64 codes, int h, h16x8 sc, h16x8 mz) {
@@ -1721,19 +1690,6 @@ __device__ __forceinline__ void minmax_scale_of(h16 mn, h16 mx, h16& scale, u16&
 #ifndef MML_POLL_SLEEP
 #define MML_POLL_SLEEP 2
 #endif
-// one wave: wait until the `n` (<= 128) flag words f[0 .. n) have all reached `seq`
-__device__ __forceinline__ void wave_wait_flags(const unsigned* f, int n, unsigned seq, unsigned* err) {
-    const int lane = threadIdx.x & 63;
-    unsigned spins = 0;
-    for (;;) {
-        const unsigned v = lane < n ? ld_wt(f + lane) : seq;
-        const unsigned v2 = lane + 64 < n ? ld_wt(f + lane + 64) : seq;
-        if (__builtin_amdgcn_ballot_w64((int)(v - seq) < 0 || (int)(v2 - seq) < 0) == 0) break;
-        __builtin_amdgcn_s_sleep(MML_POLL_SLEEP);
-        if (++spins > GATE_SPIN_LIMIT) { if (lane == 0) gate_fail(err); break; }
-    }
-}
-
 // RW = rows a wave holds: 4 (tiles of 32 rows) or 8 (tiles of 64 rows: tall tensors, fewer partials per channel)
 template <bool INT4, int RW>
 __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, const MinMaxLayerArgs& a, int z, int bx, int by, u64 (*sm)[TILE_C]) {
@@ -1940,7 +1896,7 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
     // ---- own tile: codes from registers ----
     u64* stage = &sm[0][0] + (size_t)t.w * CR * 64;         // this wave's CR code rows x 64 lanes x 8 bytes (same wave writes and reads: in order)
     {
-        // arithmetic of int4_codes / int8_codes (= k_int4_quant / k_int8_quant), channel by channel: the division by the channel's scale as
+        // codes exactly as k_int4_quant / k_int8_quant compute them, channel by channel: the division by the channel's scale as
         // hdiv_r with one reciprocal per channel - this loop is the kernel's instruction count (tall tensors: it ran at the VALU's pace)
         u64 cj[CR];
 #pragma unroll
@@ -1955,7 +1911,7 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
                     for (int h = 0; h < 2; ++h) {
                         const h16 d = xk[2 * j + h][i] - bk[2 * j + h][i];
                         h16 v = hrint(hdiv_r(d - mz[i], bf, rb));
-                        v = __builtin_fmaxf16(v, (h16)0);              // (NaN -> 0, as the explicit test of int4_codes)
+                        v = __builtin_fmaxf16(v, (h16)0);              // (NaN -> 0, as k_int4_quant's explicit test)
                         v = __builtin_fminf16(v, (h16)15.0f);
                         cj[j] |= (u64)((unsigned)(unsigned short)v & 15u) << (8 * i + 4 * h);
                     }
@@ -2130,6 +2086,9 @@ __global__ __launch_bounds__(NTHR) void k_int8_quant(BatchC batch, int N, int C,
 #pragma unroll
         for (int i = 0; i < 8; ++i) { sc[i] = S[t.c + i]; zp[i] = (h16)(float)Z[t.c + i]; }
     }
+    float scf[8], scr[8];                                    // the channel's scale and its reciprocal: hdiv_r
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { scf[i] = (float)sc[i]; scr[i] = __builtin_amdgcn_rcpf(scf[i]); }
     for (int r = t.r0 + t.w; r < t.r1; r += WAVES * UNROLL) {
         h16x8 xv[UNROLL], bv[UNROLL];
 #pragma unroll
@@ -2150,7 +2109,7 @@ __global__ __launch_bounds__(NTHR) void k_int8_quant(BatchC batch, int N, int C,
                 h16x8 qh;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    h16 v = hrint(hdiv(d[i], sc[i]) + zp[i]);            // round(x/scale + zp), fp16 after each op
+                    h16 v = hrint(hdiv_r(d[i], scf[i], scr[i]) + zp[i]);   // round(x/scale + zp), fp16 after each op
                     if (hisnan(v)) v = (h16)0;
                     v = v < (h16)-128.0f ? (h16)-128.0f : v;
                     v = v > (h16)127.0f ? (h16)127.0f : v;
@@ -2230,6 +2189,9 @@ __global__ __launch_bounds__(NTHR) void k_int4_quant(BatchC batch, int N, int C,
     const bool al16 = ((((uintptr_t)S) | ((uintptr_t)M)) & 15) == 0;
     h16x8 sc = (h16x8)(h16)1.0f, mn = (h16x8)(h16)0;
     if (t.act) { sc = ld8_tail(S + t.c, al16); mn = ld8_tail(M + t.c, al16); }
+    float scf[8], scr[8];                                    // the channel's scale and its reciprocal: hdiv_r
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { scf[i] = (float)sc[i]; scr[i] = __builtin_amdgcn_rcpf(scf[i]); }
     const int k0 = t.r0 >> 1, k1 = t.r1 >> 1;
     constexpr int U2 = 1;   // one row PAIR per wave step
     for (int k = k0 + t.w; k < k1; k += WAVES * U2) {
@@ -2258,7 +2220,7 @@ __global__ __launch_bounds__(NTHR) void k_int4_quant(BatchC batch, int N, int C,
                     const h16x8 dm = d - mn;                               // (r - min)
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        h16 v = hrint(hdiv(dm[i], sc[i]));
+                        h16 v = hrint(hdiv_r(dm[i], scf[i], scr[i]));
                         if (hisnan(v)) v = (h16)0;
                         v = v < (h16)0 ? (h16)0 : v;
                         v = v > (h16)15.0f ? (h16)15.0f : v;
