@@ -808,8 +808,9 @@ def main():
     long_ms, other_ms, two_ms, loop_ms, relay_ms, part_ms, coll_ms = None, None, None, None, None, None, None
     if not args.no_secondary:
         base_step = steps_run
-        long_ms = timed_leg(args.long_steps, lambda i: one_step(base_step + i))
-        steps_run += args.long_steps
+        if args.long_steps > 0:
+            long_ms = timed_leg(args.long_steps, lambda i: one_step(base_step + i))
+            steps_run += args.long_steps
 
         def side_leg(plset, run_fn, what):
             """args.steps steps of a collective-free plan set on the same states (every replay advances them identically)."""
