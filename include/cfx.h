@@ -137,7 +137,10 @@ int cfx_compress_batch_ex(cfx_ctx* ctx, int codec, int N, int C, int param, int 
  * update a compress item's `base` in place (the compress group has finished reading it when the gate opens).
  * NOT capturable into a hipGraph: the value a gate opens at is a launch argument that advances with every launch (monotonic
  * arrival counters, no reset, no memset node), so a replayed node would wait for a value that has already gone by.  The ungated
- * launches (cfx_compress_batch / _ex) are capturable: their tickets reset themselves. */
+ * launches (cfx_compress_batch / _ex) are capturable: their tickets reset themselves.  (An int4 / int8 compress call outside a capture runs
+ * as ONE launch too - statistics, scales, codes and the state update from the tile in registers, k_minmax_layer - handing its partials over
+ * as sequence-tagged words in an arena the context keeps per stream; under stream capture the same call runs the capturable sequence
+ * statistics ; quantise, with identical results.) */
 int cfx_compress_batch_gated(cfx_ctx* ctx, int codec, int N, int C, int param, int flags,
                              int batch, const cfx_comp_item* items, int n_ride, const cfx_decomp_item* ride,
                              int n_gated, const cfx_decomp_item* gated,
