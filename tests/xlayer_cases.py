@@ -184,7 +184,7 @@ def test_collective_kernels_that_need_room(fat):
     fat = 1: a kernel with the register footprint of RCCL's on gfx950 (rcclGenericKernel: 256 threads x 280 VGPRs, read from librccl's
     code object).  Unpartitioned it is placed in most runs (CUs with a single waiting workgroup exist) and not in others: nothing is
     asserted about that leg except that it never hangs and that a gate which did not open is REPORTED.
-    fat = 2: a kernel that needs an empty CU (512 VGPRs per wave): never placed - the launch gives up after the context's gate
+    fat = 2: a kernel that needs an empty CU (512 VGPRs per wave): (almost) never placed - the launch gives up after the context's gate
     timeout and the NEXT call on the context reports CFX_ERR_GATE.
     Both: with the run stream on CUs [0, 224) and the exchange stream on [224, 256) the same plans run and leave the states of
     compress ; all-gather ; reconstruct."""
@@ -211,7 +211,10 @@ def test_collective_kernels_that_need_room(fat):
         torch.cuda.synchronize()
         errs = lib.cfx_gate_errors(ctx)
         assert (rc == -8) == (errs > 0) or rc == 0, (rc, errs)        # a timeout of the first launch surfaces at the next call
-        if fat == "2":
+        if fat == "2" and (rc != 0 or errs):
+            # (almost always: the kernel is never placed.  Now and then a CU stands empty for a moment - between a statistics workgroup
+            # leaving and a reconstruction workgroup taking its place - and even this kernel gets in: 1 of 4 full-suite runs on the last day
+            # of round 4; then there is nothing to report)
             assert rc == -8 and errs > 0, "a gate that never opened must surface as CFX_ERR_GATE at the next call"
         assert lib.cfx_gate_errors(ctx) == 0                          # read-and-clear
         for p in plans:
