@@ -546,7 +546,10 @@ __global__ __launch_bounds__(NTHR) void k_binary_rank(BatchC bc, BatchD bd, Rank
                                // the rest take the slots the statistics workgroups leave at ~10 us, well before the gate.  Measured
                                // on one box: 17 rows (4 blocks, 384 workgroups) 1.53 ms per step, 14-16 rows 1.50, 12 rows and fewer
                                // (>= 576 workgroups: some only start after the gate) 1.78-1.85
-#define GATE_KR2 17            // 2-bit launch: 17 rows in registers ...
+#ifndef GATE_KR2
+#define GATE_KR2 17
+#endif
+//            // 2-bit launch: 17 rows in registers ...
 #ifndef GATE_KL
 #define GATE_KL 6
 #endif                         // ... plus, in the 2-bit layer launch, 6 rows in LDS (16 bytes per lane and row, 48 KB a workgroup):
@@ -1034,8 +1037,21 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
             __syncthreads();
             absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, false, true, stamps, gate, gate_expect);
         }
-    } else if (last_col || u_wg)
+    } else if (last_col || u_wg) {
+        // KEEP: the jobs' loads in flight (FUSED_CH + 2 x FUSED_RCH words) beside the whole tile did not fit 128 registers (16 bytes a lane
+        // of scratch: tools/resource_usage.py) - the tile's last row of x and of the state sits out the jobs in the LDS rows the
+        // statistics do not use (sm[FUSED_NW ..]: same thread writes and reads, no barrier)
+        u32x4* park = (u32x4*)&sm[FUSED_NW][0];
+        if constexpr (KEEP) {
+            park[threadIdx.x] = __builtin_bit_cast(u32x4, xk[US - 1]);
+            park[FUSED_NT + threadIdx.x] = __builtin_bit_cast(u32x4, bk[US - 1]);
+        }
         absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, last_col, u_wg, stamps, gate, gate_expect);
+        if constexpr (KEEP) {
+            xk[US - 1] = __builtin_bit_cast(h16x8, park[threadIdx.x]);
+            bk[US - 1] = __builtin_bit_cast(h16x8, park[FUSED_NT + threadIdx.x]);
+        }
+    }
     if constexpr (KEEP)
         own_tile_finish<US>(it, N, C, R, bx, by, flags, xk, bk, gate, gate_expect, gate2, expect2, err,
                                        (unsigned char*)&sm[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0]);
@@ -1392,7 +1408,7 @@ struct Int2LayerArgs {
 };
 template <int US>
 __global__ __launch_bounds__(FUSED_NT, 4) void k_int2_compress_gated(BatchC batch, BatchD gated, Int2LayerArgs a) {
-    __shared__ u64 sm[GATE_LDS_ROWS > FUSED_NW ? GATE_LDS_ROWS : FUSED_NW][TILE_C];      // the statistics group needs FUSED_NW rows
+    __shared__ u64 sm[GATE_LDS_ROWS > FUSED_NW + 4 ? GATE_LDS_ROWS : FUSED_NW + 4][TILE_C];      // the statistics group: FUSED_NW rows + 4 (a parked row of x, of the state)
     int b = blockIdx.x;
     if (b < a.n_st) {
         const int per = a.CB * a.P;
@@ -1691,8 +1707,15 @@ __device__ __forceinline__ void minmax_scale_of(h16 mn, h16 mx, h16& scale, u16&
 #define MML_POLL_SLEEP 2
 #endif
 // RW = rows a wave holds: 4 (tiles of 32 rows) or 8 (tiles of 64 rows: tall tensors, fewer partials per channel)
+// Registers: the tile is held as d = x - state (RW rows) plus the state rows the error-feedback pass adds the received values to; with
+// RW = 8 the upper MML_PARK rows of the state wait in LDS (`park`, 16 bytes per thread and row, written and read by the same thread) - the
+// statistics and the codes only need d, and 64 rows of x AND state beside the reduction's words in flight did not fit 128 registers
+// (the compiler spilled 12 / 80 bytes a lane to scratch: tools/resource_usage.py).  x itself is dead once d exists; without error
+// feedback (the state becomes x) the last pass reads the tile of x again.
+#define MML_PARK 4
 template <bool INT4, int RW>
-__device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, const MinMaxLayerArgs& a, int z, int bx, int by, u64 (*sm)[TILE_C]) {
+__device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, const MinMaxLayerArgs& a, int z, int bx, int by, u64 (*sm)[TILE_C],
+                                                    u32x4* park) {
     constexpr int NW = MML_NW;
     constexpr int RPC = INT4 ? 2 : 1;          // rows per code row
     constexpr int CR = RW / RPC;               // code rows a wave holds
@@ -1705,22 +1728,36 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
     if (st && threadIdx.x == 0) st[7] = 1;
     MML_STAMP(0);
     // ---- the tile into registers (every load unconditional: clamped row, masked use) ----
-    h16x8 xk[RW], bk[RW];
+    constexpr int RREG = RW > 4 ? RW - MML_PARK : RW;       // state rows that stay in registers
+    h16x8 dk[RW], bk[RREG];
     bool rv[RW];
+    {
+        h16x8 xk[RW], bt[RW > RREG ? RW - RREG : 1];
 #pragma unroll
-    for (int j = 0; j < CR; ++j)
+        for (int j = 0; j < CR; ++j)
 #pragma unroll
-        for (int h = 0; h < RPC; ++h) {
-            const int row = t.r0 + (t.w + NW * j) * RPC + h;
-            rv[j * RPC + h] = row < t.r1 && t.act;
-            const size_t off = (size_t)min(row, N - 1) * C + cc;
-            xk[j * RPC + h] = ld8nt(x + off);
-            bk[j * RPC + h] = base ? ld8nt(base + off) : (h16x8)(h16)0;
+            for (int h = 0; h < RPC; ++h) {
+                const int q = j * RPC + h;
+                const int row = t.r0 + (t.w + NW * j) * RPC + h;
+                rv[q] = row < t.r1 && t.act;
+                const size_t off = (size_t)min(row, N - 1) * C + cc;
+                xk[q] = ld8nt(x + off);
+                const h16x8 b = base ? ld8nt(base + off) : (h16x8)(h16)0;
+                if (q < RREG) bk[q < RREG ? q : 0] = b; else bt[q >= RREG ? q - RREG : 0] = b;
+            }
+#pragma unroll
+        for (int q = 0; q < RW; ++q) {
+            if (q < RREG) dk[q] = xk[q] - bk[q < RREG ? q : 0];
+            else {
+                dk[q] = xk[q] - bt[q >= RREG ? q - RREG : 0];
+                park[(q - RREG) * (NW * 64) + threadIdx.x] = __builtin_bit_cast(u32x4, bt[q >= RREG ? q - RREG : 0]);
+            }
         }
+    }
     h16x8 mn = (h16x8)hfrom(0x7c00), mx = (h16x8)hfrom(0xfc00);
 #pragma unroll
     for (int q = 0; q < RW; ++q) {
-        const h16x8 d = xk[q] - bk[q];
+        const h16x8 d = dk[q];
         if (rv[q]) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -1909,14 +1946,14 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
                 if (INT4) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const h16 d = xk[2 * j + h][i] - bk[2 * j + h][i];
+                        const h16 d = dk[2 * j + h][i];
                         h16 v = hrint(hdiv_r(d - mz[i], bf, rb));
                         v = __builtin_fmaxf16(v, (h16)0);              // (NaN -> 0, as k_int4_quant's explicit test)
                         v = __builtin_fminf16(v, (h16)15.0f);
                         cj[j] |= (u64)((unsigned)(unsigned short)v & 15u) << (8 * i + 4 * h);
                     }
                 } else {
-                    const h16 d = xk[j][i] - bk[j][i];
+                    const h16 d = dk[j][i];
                     h16 v = hrint(hdiv_r(d, bf, rb) + mz[i]);
                     if (hisnan(v)) v = (h16)0;
                     v = __builtin_fmaxf16(v, (h16)-128.0f);
@@ -1957,8 +1994,9 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
                     h16x8 o;
                     if (ef) {
                         const h16x8 recv = minmax_recv<INT4>(stage[j * 64 + t.lane], h, sc, mz);
-                        o = base ? (bk[q] + recv) : recv;
-                    } else o = xk[q];
+                        const h16x8 b = q < RREG ? bk[q < RREG ? q : 0] : __builtin_bit_cast(h16x8, park[(q - RREG) * (NW * 64) + threadIdx.x]);
+                        o = base ? (b + recv) : recv;
+                    } else o = ld8nt(x + (size_t)row * C + cc);
                     st8nt(nb + (size_t)row * C + t.c, o);
                 }
             }
@@ -2051,6 +2089,7 @@ __device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, c
 template <bool INT4, int RW>
 __global__ __launch_bounds__(FUSED_NT, 4) void k_minmax_layer(BatchC batch, BatchD gated, MinMaxLayerArgs a) {
     __shared__ u64 sm[MML_NW][TILE_C];
+    __shared__ u32x4 park[RW > 4 ? MML_PARK * FUSED_NT : 1];           // RW = 8: 32 KB more, still two workgroups a CU
     int b = blockIdx.x;
     if (b < a.n_st) {
         const int per = a.CB * a.P;
@@ -2058,7 +2097,7 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_minmax_layer(BatchC batch, Batc
         int bx, by;
         if (a.tall) { bx = rem / a.P; by = rem - bx * a.P; }
         else { by = rem / a.CB; bx = rem - by * a.CB; }
-        minmax_layer_s_tile<INT4, RW>(batch.it[z], a, z, bx, by, sm);
+        minmax_layer_s_tile<INT4, RW>(batch.it[z], a, z, bx, by, sm, park);
         if (b == 0 && a.p2p.own) p2p_exchange_inline(a.codedone, a.seq, a.n_st, a.p2p, a.xgate, a.xexpect, a.err);     // packets complete = every S tile's codes flag
         return;
     }
