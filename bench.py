@@ -1192,7 +1192,7 @@ def main():
             with tempfile.TemporaryDirectory() as td:
                 jpath = os.path.join(td, "overlap.json")
                 r_ov = subprocess.run([sys.executable, os.path.join(REPO, "tools", "overlap_bench.py"), "--quiet", "--steps", str(args.overlap_steps),
-                                       "--layers", str(L), "--legs", "attention_on_compute_lane,lane,attention_distinct_kv_on_compute_lane",
+                                       "--layers", str(L), "--legs", "attention_on_compute_lane,default,lane,attention_distinct_kv_on_compute_lane",
                                        "--json", jpath], capture_output=True, text=True, timeout=900, cwd=REPO)
                 if r_ov.returncode != 0:
                     raise RuntimeError("tools/overlap_bench.py failed: " + r_ov.stderr[-400:])
@@ -1202,12 +1202,17 @@ def main():
                 "protocol": ov["protocol"], "steps": ov["steps"], "lane": ov["lane"],
                 "attention_only_ms_per_step": legs["attention_on_compute_lane"]["wall"],
                 "attention_over_distinct_kv_ms_per_step": legs["attention_distinct_kv_on_compute_lane"]["wall"],
+                "with_exchange_default_path_ms_per_step": legs["default"]["wall"],
                 "with_exchange_on_the_lane_ms_per_step": legs["lane"]["wall"],
-                "exposed_exchange_ms_per_step": ov["exposed_exchange_ms_per_step"]["lane"],
+                "exposed_exchange_ms_per_step": ov["exposed_exchange_ms_per_step"]["default"],
+                "exposed_exchange_ms_per_step_caller_on_the_lane": ov["exposed_exchange_ms_per_step"]["lane"],
                 "exposed_exchange_ms_per_step_vs_attention_over_distinct_kv": ov["exposed_exchange_ms_per_step_vs_attention_over_distinct_kv"],
                 "what": "compact_fwd (gather schedule) with PyTorch-ROCm SDPA at the FLUX shape: the layer's chain on the CU-masked exchange stream, "
-                        "ordered with the compute stream by flags in device memory; exposed = step with the exchange - attention alone"}
-            out["exposed_exchange_ms_per_step"] = ov["exposed_exchange_ms_per_step"]["lane"]
+                        "ordered with the compute stream by flags in device memory; exposed = step with the exchange - attention alone.  "
+                        "exposed_exchange_ms_per_step = the path compact_fwd takes with NO user opt-in (caller on an ordinary stream: it forks to "
+                        "the lane's compute stream and joins back per call); ..._caller_on_the_lane = the model run on lanes.compute_stream()"}
+            out["exposed_exchange_ms_per_step"] = ov["exposed_exchange_ms_per_step"]["default"]
+            out["exposed_exchange_ms_per_step_caller_on_the_lane"] = ov["exposed_exchange_ms_per_step"]["lane"]
         except Exception as e:  # pragma: no cover
             out["overlap_with_attention"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.emulate_live and not args.no_secondary and args.plugin_steps > 0:

@@ -6,14 +6,19 @@ behind a C-ABI (include/cfx.h, libcfx.so).  See DESIGN.md / INTEGRATION.md.
 __version__ = "0.1.0"
 
 
+from .config import configure  # noqa: E402,F401
+
+
 def _default_hw_queues() -> None:
-    """Flag-ordered streams (the one-launch exchange layer, the exchange lane) need hardware queues of their own: HIP only gives every
-    stream one when GPU_MAX_HW_QUEUES is set before the runtime initialises (include/cfx.h: cfx_hw_queues_ok).
-    Importing the package before the first CUDA / HIP call sets a default; if HIP is already up the variable is left alone - libcfx
-    then sees it unset and runs those ops in stream order on one stream instead (same results, two launches per layer)."""
+    """Flag-ordered streams (the exchange lane, the collective form of the one-launch exchange layer) need hardware queues of their own:
+    HIP only gives every stream one when GPU_MAX_HW_QUEUES is set before the runtime initialises (include/cfx.h: cfx_hw_queues_ok).
+    Importing the package before the first CUDA / HIP call exports a default for the process - said ONCE on stderr, because it reaches
+    every stream of the process, the model's included; `compactfusion_amd.configure(hw_queues=n)` or the variable itself choose another
+    value; CFX_NO_DEFAULT_HW_QUEUES=1 opts out - libcfx then runs those ops in stream order on one stream
+    (same results, two launches per layer).  If HIP is already up the variable is left alone."""
     import os
     import sys
-    if "GPU_MAX_HW_QUEUES" in os.environ:
+    if "GPU_MAX_HW_QUEUES" in os.environ or os.environ.get("CFX_NO_DEFAULT_HW_QUEUES") == "1":
         return
     torch = sys.modules.get("torch")
     try:
@@ -22,6 +27,8 @@ def _default_hw_queues() -> None:
     except Exception:  # noqa: BLE001
         return
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    print("compactfusion_amd: GPU_MAX_HW_QUEUES=8 exported for this process (flag-ordered streams need hardware queues of their own; "
+          "set the variable, call compactfusion_amd.configure(hw_queues=n) first, or CFX_NO_DEFAULT_HW_QUEUES=1 to opt out)", file=sys.stderr)
 
 
 _default_hw_queues()

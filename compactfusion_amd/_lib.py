@@ -10,6 +10,7 @@ from .build import LIB, build_lib
 CFX_MAX_BATCH = 16
 
 CFX_OK = 0
+CFX_ERR_GATE = -8
 ERR_NAMES = {
     -1: "CFX_ERR_NULL", -2: "CFX_ERR_SHAPE", -3: "CFX_ERR_ALIGN", -4: "CFX_ERR_CODEC",
     -5: "CFX_ERR_BATCH", -6: "CFX_ERR_LAUNCH", -7: "CFX_ERR_WORKSPACE", -8: "CFX_ERR_GATE", -9: "CFX_ERR_QUEUES",
@@ -47,6 +48,7 @@ SYMBOLS = [
                                                 ctypes.c_int, ctypes.POINTER(CompItem), ctypes.c_int, ctypes.POINTER(DecompItem),
                                                 ctypes.c_int, ctypes.POINTER(DecompItem), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     ("cfx_gate_errors", ctypes.c_int, [ctypes.c_void_p]),
+    ("cfx_gate_recover", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_prepare", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_set_fused_finalize", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_debug_stamps", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

@@ -22,6 +22,7 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from .. import config as _settings
 from ..collector import collector as _collector_mod
 from ..prof import Profiler
 from . import main as cm
@@ -74,7 +75,34 @@ def compact_fwd(q, k, v, dropout_p=0, softmax_scale=None, causal=True, window_si
     if compact_config().override_with_patch_gather_fwd:
         from .patchpara.fwd import patch_gather_fwd
         return patch_gather_fwd(*args)
-    return _compact_ring_fwd(*args)
+    # The overlapped form is the DEFAULT: the reference posts the exchange and then attends locally (ring.py:191-208); here the layer's
+    # chain runs on the exchange lane beside the attention blocks whenever the layer has peers to hear from.  A caller that is not on the
+    # lane's compute stream is put there for the duration of the call (configure(lane="auto"): forked from and joined to its own stream
+    # by flag kernels) or for good (lane="sticky"); lane="off" keeps the exchange as one op on the caller's stream.
+    token = dev = None
+    if q.is_cuda and _auto_lane(q, group):
+        from .. import lanes
+        dev = q.device.index if q.device.index is not None else torch.cuda.current_device()
+        token = lanes.fork_to_compute(dev)
+        if token is not None and _settings.get("lane") == "sticky":
+            token = None                       # the compute stream stays the thread's current stream
+    try:
+        return _compact_ring_fwd(*args)
+    finally:
+        if token is not None:
+            lanes.join_from_compute(dev, token)
+
+
+def _auto_lane(q, group) -> bool:
+    if _settings.get("lane") == "off" or _settings.get("ring_exchange_stream") not in ("auto", "lane") or _schedule(q) != "gather":
+        return False
+    try:
+        if dist.get_world_size(group) < 2:
+            return False
+    except Exception:  # noqa: BLE001  (no process group: a single rank has nobody to overlap with)
+        return False
+    from .. import lanes
+    return lanes.usable(q.device.index if q.device.index is not None else torch.cuda.current_device())
 
 
 def _joint_mode(joint_tensor_key, joint_tensor_value, joint_strategy) -> Optional[str]:
@@ -96,10 +124,9 @@ def _with_joint(k, v, jk, jv, mode, step, world):
 
 
 def _schedule(q: torch.Tensor) -> str:
-    s = os.environ.get("CFX_RING_SCHEDULE", "auto")
+    s = _settings.get("ring_schedule")
     if s == "auto":
         return "gather" if q.is_cuda else "relay"
-    assert s in ("gather", "relay"), "CFX_RING_SCHEDULE must be auto | gather | relay"
     return s
 
 
@@ -304,7 +331,7 @@ class _SteadyLayer:
 def _exchange_stream(device) -> "torch.cuda.Stream":
     s = _xstreams.get(device)
     if s is None:
-        s = _xstreams[device] = torch.cuda.Stream(device, priority=int(os.environ.get("CFX_RING_EXCHANGE_PRIORITY", "-1")))
+        s = _xstreams[device] = torch.cuda.Stream(device, priority=int(_settings.get("ring_exchange_priority")))
     return s
 
 
@@ -350,7 +377,7 @@ class _LayerExchange:
         reconstruction launches read them in place; the all-gather of the layer's plan becomes a publish-and-wait op
         (cfx_plan_add_p2p_sync).  Collective over the group (the handles travel once); all ranks or none."""
         self._p2p_tried = True
-        if os.environ.get("CFX_RING_P2P", "0") not in ("1", "on", "auto") or self.world < 2 or not self.send.is_cuda or self.world - 1 > 15:
+        if _settings.get("ring_p2p") not in ("1", "on", "auto") or self.world < 2 or not self.send.is_cuda or self.world - 1 > 15:
             return
         import ctypes
         from .. import _lib, codecs
@@ -459,7 +486,7 @@ class _LayerExchange:
         (then the chain runs beside the attention blocks on the CU-masked exchange stream) or asked for one of the multi-launch forms."""
         from . import xlayer
         from .. import lanes
-        xmode = os.environ.get("CFX_RING_EXCHANGE_STREAM", "auto")     # auto | xlayer | lane | chain | side | main
+        xmode = _settings.get("ring_exchange_stream")     # auto | xlayer | lane | chain | side | main
         if xmode not in ("auto", "xlayer") or not xlayer.usable(cid, self.world, self.send.is_cuda):
             return False
         dev = self.send.device.index if self.send.device.index is not None else torch.cuda.current_device()
@@ -494,7 +521,7 @@ class _LayerExchange:
         self._drop_plan()
         self.lane = False
         self.plan_updates_state = False
-        mode = os.environ.get("CFX_RING_EXCHANGE", "auto")
+        mode = _settings.get("ring_exchange")
         if mode == "torch" or not self.send.is_cuda or cid >= 100:
             return
         import ctypes
@@ -510,7 +537,7 @@ class _LayerExchange:
         ctx = codecs.context(dev)
         plan = lib.cfx_plan_create(ctx)
         # ONE exchange stream per device, shared by every layer's plan (a stream per plan would be a hardware queue per layer)
-        xmode = os.environ.get("CFX_RING_EXCHANGE_STREAM", "auto")     # auto | xlayer | lane | chain | side | main
+        xmode = _settings.get("ring_exchange_stream")     # auto | xlayer | lane | chain | side | main
         if xmode in ("auto", "xlayer"):
             xmode = "lane"           # (here: the caller is on the lane's compute stream, or the shape has no layer op)
         assert xmode in ("lane", "chain", "side", "main"), "CFX_RING_EXCHANGE_STREAM must be auto | xlayer | lane | chain | side | main"

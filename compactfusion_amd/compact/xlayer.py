@@ -11,10 +11,14 @@ the peers') runs inside that launch; top-k and shapes with
 Transports, tried in this order (`CFX_EXCHANGE` = auto | p2p | rccl | torch):
   p2p    ranks of ONE node: every rank's packets stay in uncached IPC device memory of its own GPU (`P2PArena`), the peers'
          reconstruction workgroups read them in place over xGMI; what is exchanged is one word per rank and layer, by the launch itself
-         (no exchange stream, any run stream).  The first two
-         executions of every layer are VALIDATED (gate time-outs, and every rank's reconstruction of a shard against its owner's state,
-         by checksum over the process group); on any failure every rank restores the layer's states, the group's arena is marked
-         bad and all its layers continue on the next transport.
+         (no exchange stream, any run stream).  The first VALIDATE_FIRST
+         executions of every layer - through the first REUSE of both packet parities, where a stale line in a reader's cache would first
+         show - are VALIDATED (gate time-outs, and every rank's reconstruction of a shard against what its owner says the peers must
+         hold, by checksum over the process group); arenas whose memory did not come out uncached keep validating every
+         REVALIDATE_EVERY-th execution.  On any failure every rank restores the layer's states, the peers' copies are re-synchronised
+         from the owners' states, the group's arena is marked bad and all its layers continue on the next transport.  A gate time-out in
+         the steady path (a peer more than the gate timeout late) stores nothing (include/cfx.h: cfx_gate_recover); the ranks agree on it
+         at the next step boundary (`GroupHealth`) and validate every layer again.
   rccl   ncclAllGather issued by libcfx's own communicator between a flag-wait and a flag-set kernel on the exchange stream.
   torch  compress ; torch.distributed.all_gather_into_tensor ; reconstruct (three host calls) - the last resort.
 """
@@ -29,17 +33,20 @@ import torch
 import torch.distributed as dist
 
 from .. import _lib, codecs
+from .. import config as _settings
 
 MAX_ITEMS = codecs.CFX_MAX_BATCH
+VALIDATE_FIRST = 4           # validated executions of every p2p layer: parity 0, parity 1, and the first reuse of each
+REVALIDATE_EVERY = 64        # ... and every so many executions afterwards where the arena's memory is not uncached (cfx_ipc_memory_kind != 2)
 
 
 def transport_pref() -> str:
-    pref = os.environ.get("CFX_EXCHANGE", "auto")
-    if os.environ.get("CFX_RING_EXCHANGE", "auto") == "torch":
+    """compactfusion_amd.configure(exchange=..., ring_exchange=..., ring_p2p=...) (compactfusion_amd/config.py)"""
+    pref = _settings.get("exchange")
+    if _settings.get("ring_exchange") == "torch":
         pref = "torch"
-    if os.environ.get("CFX_RING_P2P", "") in ("0", "off"):
+    if _settings.get("ring_p2p") in ("0", "off"):
         pref = "rccl" if pref in ("auto", "p2p") else pref
-    assert pref in ("auto", "p2p", "rccl", "torch"), "CFX_EXCHANGE must be auto | p2p | rccl | torch"
     return pref
 
 
@@ -49,12 +56,13 @@ def transport_pref() -> str:
 class _Region:
     """A layer's slice of the arena: [parity 0: K slot | V slot][parity 1: K slot | V slot][flag word of parity 0, 64 B][parity 1]."""
 
-    __slots__ = ("own", "peer", "slot", "n_exec", "validated")
+    __slots__ = ("own", "peer", "slot", "n_exec", "validated", "recheck")
 
     def __init__(self, own: int, peer: Dict[int, int], slot: int):
         self.own, self.peer, self.slot = own, peer, slot
         self.n_exec = 0          # executions so far: the NEXT one writes parity n_exec & 1 (kept across plan rebuilds, like the device-side epochs)
-        self.validated = 0       # validated executions so far (p2p with real peers: the first two are checked)
+        self.validated = 0       # validated executions so far (p2p with real peers: the first VALIDATE_FIRST are checked)
+        self.recheck = 0         # executions still to validate after the group agreed that somebody's wait had timed out
 
     def packet(self, r: Optional[int], parity: int, kv: int) -> int:
         base = self.own if r is None else self.peer[r]
@@ -63,6 +71,42 @@ class _Region:
     def flag(self, r: Optional[int], parity: int) -> int:
         base = self.own if r is None else self.peer[r]
         return base + 4 * self.slot + 64 * parity
+
+
+class GroupHealth:
+    """Do the ranks of a group agree that nobody's in-launch wait has timed out?  A time-out is local knowledge (the late rank itself
+    notices nothing), but what follows - validating the layers again - is collective.  Once per denoise step (the first layer op that
+    sees a new step number) every rank contributes its flag to a MAX all-reduce whose result lands in pinned host memory and is read
+    at the NEXT boundary: no host synchronisation in the steady path, the agreement is one step late and the same on every rank."""
+
+    def __init__(self, group, device: int):
+        self.group, self.device = group, device
+        self.local_error = False
+        self.step = None
+        self.pending = None          # (event, pinned result) of the all-reduce issued at the previous boundary
+
+    def note_error(self) -> None:
+        self.local_error = True
+
+    def boundary(self, step) -> bool:
+        """Called by every layer op before it runs; True once per agreement that some rank had a time-out."""
+        if step is None or step == self.step:
+            return False
+        self.step = step
+        agreed = False
+        if self.pending is not None:
+            ev, host = self.pending
+            ev.synchronize()         # (issued a whole step ago)
+            agreed = bool(int(host[0]))
+        flag = torch.tensor([1 if self.local_error else 0], dtype=torch.int32, device=f"cuda:{self.device}")
+        self.local_error = False
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.pending = (ev, host)
+        return agreed
 
 
 class P2PArena:
@@ -80,6 +124,7 @@ class P2PArena:
         self.chunks: List[Tuple[int, int, Dict[int, int]]] = []     # (own pointer, bytes, {peer rank: its mapping here})
         self.off = 0
         self.regions: Dict[Tuple, _Region] = {}
+        self.health = None if loopback else GroupHealth(group, device)
         self.ok = True               # False: IPC unavailable, or a validation failed - the group's layers use another transport
         self.why = None
         self.kind = None             # cfx_ipc_memory_kind of the chunks: 2 uncached, 1 fine-grained, 0 ordinary device memory
@@ -117,7 +162,12 @@ class P2PArena:
                 self.lib.cfx_ipc_free(self.ctx, ptr)
             self.ok, self.why = False, "IPC-shared device memory is not available between the ranks of this group"
             return False
-        self.kind = self.lib.cfx_ipc_memory_kind(self.ctx)
+        kind = int(self.lib.cfx_ipc_memory_kind(self.ctx))
+        if not self.loopback:
+            kinds = [None] * self.world
+            dist.all_gather_object(kinds, kind, group=self.group)
+            kind = min(kinds)                                       # every rank takes the same decisions: the weakest kind of the group
+        self.kind = kind if self.kind is None else min(self.kind, kind)
         self.chunks.append((ptr.value, size, opened))
         self.off = 0
         return True
@@ -162,6 +212,15 @@ class P2PArena:
         self.chunks, self.regions, self.off = [], {}, 0
 
 
+def _current_step():
+    global _get_step
+    if _get_step is None:
+        from .main import compact_get_step
+        _get_step = compact_get_step
+    return _get_step()
+
+
+_get_step = None
 _arenas: Dict[Tuple, P2PArena] = {}
 _loopback = False            # tests / one-GPU measurements: the W logical ranks of a group are all this process
 
@@ -196,7 +255,6 @@ def release(collective: bool = True) -> None:
 # the layer op
 # ---------------------------------------------------------------------------------------------------------------------------
 _xstreams: Dict[Tuple[int, bool], "torch.cuda.Stream"] = {}
-_TEST_POISON = None          # tests: (rank, validated-execution index) -> corrupt a peer's reconstruction before that check
 
 
 def _exchange_stream(device: int, beside_null_stream: bool):
@@ -377,12 +435,22 @@ class LayerOp:
         t = self.transport
         if t == "p2p":
             if not self.arena.ok:              # another layer of the group failed its validation: every layer leaves p2p (all ranks alike)
+                if self.region.recheck:        # ... while this one still owed the group its proof after a time-out: the owners' states are the truth
+                    self._resync(self.own)
+                    self.region.recheck = 0
                 self.fallback_reason = self.arena.why
                 self._choose_transport(exclude=("p2p",))
                 return self.run(k, v, sh)
             reg = self.region
-            if reg.validated < 2 and not self.arena.loopback:
-                return self._run_validated(k, v, sh)
+            if not self.arena.loopback:
+                if self.arena.health.boundary(_current_step()):
+                    # some rank's wait timed out a step or two ago (every rank reads the same agreement at the same boundary): the launch
+                    # it belonged to stored nothing, so its states are a delta behind their owners' - every layer proves itself again
+                    self.lib.cfx_gate_recover(self.ctx)
+                    for r_ in self.arena.regions.values():
+                        r_.recheck = 1
+                if reg.validated < VALIDATE_FIRST or reg.recheck or (self.arena.kind != 2 and reg.n_exec % REVALIDATE_EVERY == 0):
+                    return self._run_validated(k, v, sh)
             op = reg.n_exec & 1
             reg.n_exec += 1
         else:
@@ -390,6 +458,14 @@ class LayerOp:
         xs = self._xs
         xs[0], xs[1] = k.data_ptr(), v.data_ptr()
         rc = self._run_x(ent[0], op, 1, xs, 2, sh)
+        if rc == _lib.CFX_ERR_GATE and t == "p2p" and not self.arena.loopback:
+            # an EARLIER launch's wait gave up (a peer later than the gate timeout): it stored nothing.  Clear the word, tell the group at
+            # the next step boundary, and issue this layer's launch - the flag epochs have to keep step with the peers'
+            if self.lib.cfx_gate_errors(self.ctx) > 0:
+                self.arena.health.note_error()
+                warnings.warn("compactfusion_amd: an in-launch wait of the peer-to-peer exchange timed out (a peer was later than the gate "
+                              "timeout); nothing was stored, the group validates its layers again at the next step boundary")
+            rc = self._run_x(ent[0], op, 1, xs, 2, sh)
         if rc == 0 and t == "torch":
             dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
             rc = self._run(ent[0], 1, 1, sh)
@@ -399,10 +475,33 @@ class LayerOp:
     def _checksums(self, tensors: Sequence[torch.Tensor]) -> torch.Tensor:
         return torch.stack([t.view(torch.int32).sum(dtype=torch.int64) for t in tensors])
 
+    def _packet_view(self, r: Optional[int], parity: int, kv: int, n_half: int) -> torch.Tensor:
+        """The packet of rank r (None: this rank's own) as a tensor over the arena / the IPC mapping (an even number of halves: int32 sums)."""
+        from .ring import _raw_halves
+        return _raw_halves(self.region.packet(r, parity, kv), n_half & ~1, self.device)
+
+    def _resync(self, snap: Sequence[torch.Tensor]) -> None:
+        """After a failed validation: every rank's copy of a shard's state <- its owner's state (as it was before the failed execution).
+        A launch whose wait timed out stored nothing, so a rank may be a delta behind; the owner's state is what the next residual is
+        taken against and therefore the truth.  (Without error feedback the owner keeps the activation instead of what its peers
+        hold - there is no authoritative copy to fetch, the restored states are all there is.)"""
+        if self.own_update != "ef":
+            return
+        n = snap[0].numel()
+        own = torch.cat([snap[0].reshape(-1), snap[1].reshape(-1)]).view(torch.int16)       # (int16: a dtype every backend moves)
+        every = torch.empty(self.world * 2 * n, dtype=torch.int16, device=own.device)
+        dist.all_gather_into_tensor(every, own, group=self.group)
+        every = every.view(self.world, 2, n)
+        for r, ks, vs in self.peers:
+            ks.view(torch.int16).reshape(-1).copy_(every[r, 0])
+            vs.view(torch.int16).reshape(-1).copy_(every[r, 1])
+
     def _run_validated(self, k, v, sh) -> None:
-        """One of the first two p2p executions of this layer: run it, then check that no gate timed out and that what this rank
-        reconstructed for every peer's shard IS that peer's own state (checksums over the group).  All ranks decide together; on a
-        failure the layer's states are restored, the group's arena is marked bad and the execution is repeated on the next transport."""
+        """A validated p2p execution of this layer: run it, then check that no gate timed out and that what this rank reconstructed for
+        every peer's shard IS what that shard's owner says its peers must hold (checksums over the group): the owner's own state with
+        error feedback, the owner's previous state + its decoded packet without (own_update "x": the owner keeps the activation,
+        main.py:233).  All ranks decide together; on a failure the layer's states are restored, the peers' copies are re-synchronised
+        from their owners, the group's arena is marked bad and the execution is repeated on the next transport."""
         reg, lib, ctx = self.region, self.lib, self.ctx
         states = list(self.own) + [t for _, ks, vs in self.peers for t in (ks, vs)]
         snap = [t.clone() for t in states]
@@ -416,18 +515,40 @@ class LayerOp:
         bad = 1 if rc != 0 else 0
         if lib.cfx_gate_errors(ctx) != 0:
             bad = 1
-        if _TEST_POISON is not None and _TEST_POISON == (self.rank, reg.validated):
-            self.peers[0][1].view(torch.int16)[0, :8] += 1          # a stale line's worth of wrong bits in a peer's reconstruction
-        mine = self._checksums(self.own)
-        allc = torch.empty(self.world * 2, dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(allc, mine, group=self.group)
-        for r, ks, vs in self.peers:
-            if not torch.equal(self._checksums([ks, vs]), allc[2 * r:2 * r + 2]):
-                bad = 1
+        if self.own_update == "ef":
+            # error feedback: what every peer reconstructed of a shard IS its owner's state
+            mine = self._checksums(self.own)
+            allc = torch.empty(self.world * 2, dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(allc, mine, group=self.group)
+            for r, ks, vs in self.peers:
+                if not torch.equal(self._checksums([ks, vs]), allc[2 * r:2 * r + 2]):
+                    bad = 1
+        else:
+            # without error feedback the owner keeps the activation and only its peers hold previous copy + decoded packet (main.py:233):
+            # there is no owner's state to compare with.  Checked instead: (1) the packet AS THIS RANK READS IT through its mapping is the
+            # packet its owner wrote (checksums over the group), and (2) what the launch made of it is what the receiver's kernel makes of
+            # that packet and this rank's previous copy when run again now, in stream order
+            n_half = self.pkt_bytes // 2
+            mine = self._checksums([self._packet_view(None, op, kv, n_half) for kv in (0, 1)])
+            allc = torch.empty(self.world * 2, dtype=torch.int64, device=self.device)
+            dist.all_gather_into_tensor(allc, mine, group=self.group)
+            for i, (r, ks, vs) in enumerate(self.peers):
+                seen = self._checksums([self._packet_view(r, op, kv, n_half) for kv in (0, 1)])
+                if not torch.equal(seen, allc[2 * r:2 * r + 2]):
+                    bad = 1
+                for kv, got in ((0, ks), (1, vs)):
+                    again = torch.empty_like(got)
+                    if lib.cfx_decompress(ctx, self.cid, reg.packet(r, op, kv), snap[2 + 2 * i + kv].data_ptr(), again.data_ptr(), self.N, self.C,
+                                          self.param, sh) != 0:
+                        bad = 1
+                    stream.synchronize()
+                    if not torch.equal(again.view(torch.int16), got.view(torch.int16)):
+                        bad = 1
         verdict = torch.tensor([bad], dtype=torch.int32, device=self.device)
         dist.all_reduce(verdict, op=dist.ReduceOp.MAX, group=self.group)
         if int(verdict.item()) == 0:
             reg.validated += 1
+            reg.recheck = 0
             return
         why = ("the peer-to-peer exchange failed its validation (execution %d of layer %r: gate time-out or a reconstruction that differs "
                "from its owner's state); this group's layers continue on the next transport" % (reg.validated + 1, self.key))
@@ -435,6 +556,8 @@ class LayerOp:
             warnings.warn("compactfusion_amd: " + why)
         for t, s in zip(states, snap):
             t.copy_(s)
+        self._resync(snap)
+        reg.recheck = 0
         self.arena.mark_bad(why)
         self.fallback_reason = why
         self._choose_transport(exclude=("p2p",))

@@ -58,6 +58,9 @@ struct cfx_ctx {
     size_t mml_arena_bytes[CFX_RING_STREAMS];
     bool mml_arena_owned[CFX_RING_STREAMS];
     void* mml_arena_owner[CFX_RING_STREAMS];   // the stream whose launches use the ring's arena (a change of owner waits for the previous one's launches)
+    unsigned long long* abs_arena[CFX_RING_STREAMS];        // per ring: tagged partial sums of the 1-bit / 2-bit layer launches (zeroed at allocation, grown on demand)
+    size_t abs_arena_bytes[CFX_RING_STREAMS];
+    unsigned abs_seq;               // tags of those launches: 24 bits of this counter, never 0
     unsigned* gate_err;             // pinned HOST word (device-visible): waits that timed out since the last cfx_gate_errors
     long long gate_timeout;         // ticks of the 100 MHz wall clock a flag wait may last
     int fused;                      // 1 (default): compress = statistics + in-launch finalize; 0: separate finalize kernel

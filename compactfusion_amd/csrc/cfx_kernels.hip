@@ -167,6 +167,42 @@ __device__ __forceinline__ void put_part(unsigned* p32, u64* p64, size_t i, u64 
     if (big) st_wt(p64 + i, v);
 }
 
+// The LAYER launches (GATED) hand their partial sums over as TAGGED 8-byte words in an arena the context owns (zeroed once, like the
+// min/max layer's): {24-bit launch tag | 40-bit value} in ONE store - the reader polls the data itself: no drain of the stores, no
+// ticket, no second round trip for the data once a counter says it is there.  40 bits of 2^-24 units hold a partial up to 65536 (a
+// 512-channel row partial at an average |d| of 128: round 4's 32-bit words gave out at 0.5 and cost the launch a second round trip);
+// beyond that the word carries TAG_SAT and the exact sum is in the 64-bit side array, stored AND drained first.
+#define TAG_SAT ((u64)0xFFFFFFFFFFull)
+__device__ __forceinline__ void put_tagged(u64* t, u64* side, size_t i, u64 v, u64 tagbits) {
+    if (v >= TAG_SAT) {
+        st_wt(side + i, v);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        v = TAG_SAT;
+    }
+    st_wt(t + i, tagbits | v);
+}
+__device__ __forceinline__ bool tag_is(u64 w, u64 tagbits) { return ((w ^ tagbits) >> 40) == 0; }
+struct TagArena {
+    u64* trow;             // [CB][N] tagged row partials of this tensor
+    u64* tcol;             // [P][C] tagged column partials
+    u64* tU;               // [N] the finished token scales as tagged words {tag | fp16 bits}: a reconstruction workgroup of the same launch
+    u64* tV;               // [C] ... and the channel scales       polls THESE - no drain of the packet's copy, no arrival counter, no relay
+    u64* tdone;            // [CB][P] 2-bit layer: "this tile's codes are in memory" (the launch's tag), written by the tile once its stores have drained
+    u64 tagbits;           // the launch's tag << 40
+};
+
+__device__ __forceinline__ TagArena tag_arena_of(u64* arena, size_t stride, int z, int N, int C, int CB, int P, unsigned tag) {
+    TagArena ta;
+    ta.trow = arena ? arena + (size_t)z * stride : nullptr;
+    ta.tcol = arena ? ta.trow + (size_t)N * CB : nullptr;
+    ta.tU = arena ? ta.tcol + (size_t)P * C : nullptr;
+    ta.tV = arena ? ta.tU + N : nullptr;
+    ta.tdone = arena ? ta.tV + C : nullptr;
+    ta.tagbits = (u64)tag << 40;
+    return ta;
+}
+__host__ __device__ inline size_t tag_arena_words(int N, int C, int CB, int P) { return (size_t)N * CB + (size_t)P * C + (size_t)N + (size_t)C + (size_t)CB * P; }
+
 __device__ __forceinline__ h16x8 habs8(h16x8 v) {
     u16x8 b = __builtin_bit_cast(u16x8, v);
     b &= (u16)0x7fff;
@@ -216,10 +252,13 @@ __device__ __forceinline__ TileCoord tile_coord(int N, int C, int R) { return ti
 // and 4 lanes per row store 16 bytes.
 // KEEP (needs R == NW * US: one trip of the row loop): the tile of x and of the state stays in the caller's registers (xk, bk) -
 // the workgroup finishes its own tile from them once the scales exist (absmean_fused_body).
-template <bool EMIT_BITS, int US, bool WT = false, int NW = WAVES, bool PUB = false, bool KEEP = false>
+// TAG (the layer launches): the partials go out as tagged words (put_tagged).  The sign bits a reconstruction workgroup will read are
+// drained BEFORE the tile's column partials are stored: the gate only opens once every column block's V job has read every tile's
+// column partials, so a tile's bits are in memory by then; its row partials need not wait for anything.
+template <bool EMIT_BITS, int US, bool WT = false, int NW = WAVES, bool PUB = false, bool KEEP = false, bool TAG = false>
 __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int N, int C, int R, int CB, int bx, int by,
                                                    u64* rowpart, u64 (*sm)[TILE_C], u64* stamps = nullptr,
-                                                   h16x8* xk = nullptr, h16x8* bk = nullptr) {
+                                                   h16x8* xk = nullptr, h16x8* bk = nullptr, TagArena ta = TagArena()) {
 #define SSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
     const TileCoord t = tile_coord_at(bx, by, N, C, R);
     const int cb = bx;
@@ -298,13 +337,18 @@ __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int 
         SSTAMP(10);
         if ((t.lane & 15) == 0 && (t.lane >> 4) < US) {
             const int rr = r + NW * (t.lane >> 4);
-            if (rr < t.r1) { if (WT) put_part(part32_of(rowpart, N, C, CB), rowpart, (size_t)cb * N + rr, tot); else rowpart[(size_t)cb * N + rr] = tot; }
+            if (rr < t.r1) {
+                if (TAG) put_tagged(ta.trow, rowpart, (size_t)cb * N + rr, tot, ta.tagbits);
+                else if (WT) put_part(part32_of(rowpart, N, C, CB), rowpart, (size_t)cb * N + rr, tot);
+                else rowpart[(size_t)cb * N + rr] = tot;
+            }
         }
     }
 #pragma unroll
     // exact; [i][lane ^ 8i]: conflict-free here AND in the column-order read below ([i][lane] made that one 8-way conflicted)
     for (int i = 0; i < 8; ++i) sm[t.w][i * 64 + (t.lane ^ (i << 3))] = (u64)(col[i] * 16777216.0);
     SSTAMP(11);
+    if (TAG && EMIT_BITS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's sign bits are in memory (see above)
     if (WT) lds_barrier(); else __syncthreads();
     SSTAMP(12);
     for (int k = threadIdx.x; k < TILE_C; k += NW * 64) {   // k = channel within the tile: coalesced global writes
@@ -314,7 +358,9 @@ __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int 
             u64 v = 0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) v += sm[w][s];
-            if (WT) put_part(part32_of(rowpart, N, C, CB) + (size_t)N * CB, colpart, (size_t)by * C + cc, v); else colpart[(size_t)by * C + cc] = v;
+            if (TAG) put_tagged(ta.tcol, colpart, (size_t)by * C + cc, v, ta.tagbits);
+            else if (WT) put_part(part32_of(rowpart, N, C, CB) + (size_t)N * CB, colpart, (size_t)by * C + cc, v);
+            else colpart[(size_t)by * C + cc] = v;
         }
     }
 #undef SSTAMP
@@ -560,7 +606,6 @@ __global__ __launch_bounds__(NTHR) void k_binary_rank(BatchC bc, BatchD bd, Rank
                                // take over their slots spread the preload burst, and that measured faster than the all-resident
                                // forms (1.60 vs 1.77 - 1.91 ms per step)
 #define GATE_LDS_ROWS ((GATE_KL * FUSED_NT * 16 + TILE_C * 8 - 1) / (TILE_C * 8))   // rows of the u64[..][TILE_C] LDS array of the 2-bit layer kernel (>= FUSED_NW)
-#define GATE_SPIN_LIMIT (1u << 21)
 #ifndef GATE_LOCAL_SLEEP
 #define GATE_LOCAL_SLEEP 1        // s_sleep units between two polls of the XCD-local word (L2 hits)
 #endif
@@ -599,31 +644,48 @@ __device__ __forceinline__ unsigned ld_l2(const unsigned* p) {          // L1-by
 }
 // FEW: the gate counts a dozen arrivals (gate_arrive_few) and the relay polls the counter directly - one hop less than waiting for
 // the last arriver to learn that it was last (a returned atomic) and to write the "open" words.
+// Every in-launch wait gives up on ONE time base: the 100 MHz wall clock against the context's gate_timeout (cfx_set_gate_timeout_ms) -
+// never on an iteration count, whose length in seconds depends on what else loads the fabric.  Only a FAILED poll reads the clock.
+struct SpinClock {
+    long long t0 = 0;
+    __device__ __forceinline__ bool expired(long long timeout) {
+        const long long now = wall_clock64();
+        if (!t0) { t0 = now; return false; }
+        return now - t0 > timeout;
+    }
+};
+// Returns whether the gate opened.  A workgroup whose wait gave up must NOT store: what it would reconstruct from has not arrived; the
+// states it owns stay as they were and the context's error word (pinned host memory) says so to the host.
 template <bool FEW = false>
-__device__ __forceinline__ void gate_wait(unsigned* gate, unsigned expect, unsigned* err) {
+__device__ __forceinline__ bool gate_wait(unsigned* gate, unsigned expect, unsigned* err, long long timeout) {
+    bool failed = false;
     if (threadIdx.x == 0) {
         const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // HW_REG_XCC_ID[3:0]
         unsigned* open = FEW ? gate : gate + (1 + xcc) * GATE_LINE;   // the counter, or the word the gate's last arriver writes (write-through)
         unsigned* local = gate + (9 + xcc) * GATE_LINE;           // written by this XCD's relay (plain store)
         unsigned* claim = gate + (17 + xcc) * GATE_LINE;
         const bool relay = __hip_atomic_exchange(claim, expect, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != expect;
+        SpinClock clk;
         unsigned n = 0;
         if (relay) {
             while (ld_wt(open) != expect) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++n > GATE_SPIN_LIMIT) { gate_fail(err); break; }
+                if (clk.expired(timeout)) { failed = true; break; }
             }
-            *(volatile unsigned*)local = expect;
+            if (!failed) *(volatile unsigned*)local = expect;
         } else {
             while (ld_l2(local) != expect) {
                 if (GATE_LOCAL_SLEEP) __builtin_amdgcn_s_sleep(GATE_LOCAL_SLEEP);
                 ++n;
-                if ((n & (FEW ? 255u : 15u)) == 0 && ld_wt(open) == expect) break;
-                if (n > GATE_SPIN_LIMIT) { gate_fail(err); break; }
+                if ((n & (FEW ? 255u : 15u)) == 0) {
+                    if (ld_wt(open) == expect) break;
+                    if (clk.expired(timeout)) { failed = true; break; }
+                }
             }
         }
+        if (failed) gate_fail(err);
     }
-    __syncthreads();
+    return __syncthreads_or(failed ? 1 : 0) == 0;
 }
 // 8 channel scales of a packet another workgroup of this launch published
 __device__ __forceinline__ h16x8 ld8_wt(const u16* p) {
@@ -637,10 +699,54 @@ __device__ __forceinline__ h16x8 ld8_wt(const u16* p) {
     return __builtin_bit_cast(h16x8, vb);
 }
 
+// A workgroup's scales out of the launch's TAGGED copies (absmean_tagged_jobs): wave 0 polls the 512 channel words of its column block
+// and the token words of its rows - the data is its own "published" mark - and hands them to the other waves through LDS:
+// s16[0 .. 512) channel scales, s16[512 + i] token scale of row r0 + i.  Who sees a column block's channel scales tagged knows the
+// sign bits / codes prerequisites of that block are in memory too: the V job read every tile's column partials, and a tile stores
+// those only after its own packet stores have drained.  Returns false when the wait gave up (the caller stores nothing).
+template <int ROWS, bool WATCH = true>
+__device__ __forceinline__ bool scales_from_tagged(const TagArena& ta, int N, int C, int c0, int r0, u16* s16, long long timeout, unsigned* err) {
+    // every thread polls ONE channel word (512 threads = the column block) and, the first ROWS of them, one token word: two registers a
+    // thread instead of a wave's worth of words in one wave's registers (the reconstruction tiles hold 14 - 23 rows of state meanwhile)
+    static_assert(ROWS <= TILE_C, "one token word per thread (512 threads = the column block's channels)");
+    const int tid = threadIdx.x;
+    const u64* pv = ta.tV + min(c0 + tid, C - 1);
+    const u64* pu = ta.tU + min(r0 + tid, N - 1);
+    SpinClock clk;
+    // WATCH first: two lanes poll one word each - a channel word and a token word of this workgroup's own (other workgroups watch other
+    // lines) - until they carry the tag; only then does everybody load.  Hundreds of workgroups polling all their words from the moment
+    // their state tile has landed measured 9 % slower than the arrival gate they replaced (1.56 vs 1.43 ms per step): the polls load the
+    // fabric the statistics chain needs.
+    if (WATCH) {
+        if (tid < 2) {
+            const u64* w = tid ? pu : ta.tV + min(c0 + ((r0 >> 1) & (TILE_C - 1)), C - 1);
+            while (!tag_is(ld_wt(w), ta.tagbits)) {
+                __builtin_amdgcn_s_sleep(4);
+                if (clk.expired(timeout)) break;              // (the loop below gives up for everybody)
+            }
+        }
+        lds_barrier();
+    }
+    for (;;) {
+        const u64 v = ld_wt(pv);
+        const u64 u = tid < ROWS ? ld_wt(pu) : ta.tagbits;
+        const bool ok = tag_is(v, ta.tagbits) && tag_is(u, ta.tagbits);
+        s16[tid] = (u16)v;
+        if (tid < ROWS) s16[TILE_C + tid] = (u16)u;
+        if (!__syncthreads_or(ok ? 0 : 1)) return true;
+        __builtin_amdgcn_s_sleep(2);
+        if (__syncthreads_or(!ok && clk.expired(timeout) ? 1 : 0)) {
+            if (tid == 0) gate_fail(err);
+            return false;
+        }
+    }
+}
+
 template <int NW, int KR, int KL, bool ST>
 __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item& it, int N, int C, int R, int tile_x, int tile_y,
-                                                         unsigned* gate, unsigned expect, unsigned* err, u32x4* lds, u64* stamps = nullptr,
-                                                         bool remote = false) {
+                                                         unsigned* gate, unsigned expect, unsigned* err, long long timeout, u32x4* lds,
+                                                         u64* stamps = nullptr, bool remote = false, bool tagged = false, TagArena ta = TagArena(),
+                                                         u16* s16 = nullptr) {
     constexpr int K = KR + KL;
 #define GSTAMP(k) do { if (ST && stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 0) stamps[k] = wall_clock64(); } } while (0)
     const TileCoord t = tile_coord_at(tile_x, tile_y, N, C, R);
@@ -670,12 +776,20 @@ __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item&
         for (int j = 0; j < KR; ++j) bv[j] = (h16x8)(h16)0;
     }
     GSTAMP(1);
-    gate_wait<true>(gate, expect, err);
-    if (ST && stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
     h16x8 v8;
     u16 ul;
     unsigned by[K];
-    if (remote) {                                            // (uniform) the packet sits in a peer GPU's memory: system-scope loads
+    if (tagged) {
+        // the packet is one of THIS launch's: its scales come as tagged words (no gate); then the sign bits
+        if (!scales_from_tagged<NW * K>(ta, N, C, tile_x * TILE_C, t.r0, s16, timeout, err)) return;
+        if (ST && stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
+        v8 = __builtin_bit_cast(h16x8, *(const u16x8*)(s16 + 8 * t.lane));
+        ul = s16[TILE_C + min(t.w + NW * min(t.lane, K - 1), t.r1 - 1 - t.r0)];
+#pragma unroll
+        for (int j = 0; j < K; ++j) by[j] = ld_wt(pk + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C8 + (cc >> 3));
+    } else if (!gate_wait<true>(gate, expect, err, timeout)) return;
+    else if (remote) {
+        if (ST && stamps && threadIdx.x == 0) stamps[2] = wall_clock64();                                            // (uniform) the packet sits in a peer GPU's memory: system-scope loads
         u16x8 vb;
 #pragma unroll
         for (int i = 0; i < 8; ++i) vb[i] = ld_sys(V + cc + i);
@@ -684,6 +798,7 @@ __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item&
 #pragma unroll
         for (int j = 0; j < K; ++j) by[j] = ld_sys(pk + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C8 + (cc >> 3));
     } else {
+        if (ST && stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
         v8 = ld8_wt(V + cc);
         // a row's token scale is wave-uniform: lane j fetches row j's, broadcast by readlane below
         ul = ld_wt(U + min(t.r0 + t.w + NW * min(t.lane, K - 1), t.r1 - 1));
@@ -733,7 +848,10 @@ __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item&
 
 #define FUSED_NW 8             // waves per workgroup of the single-launch compress kernel (512 threads: the last arriver of a
 #define FUSED_NT (FUSED_NW * 64)   //   column block owns one column per thread, of a tensor one row per thread)
-#define FUSED_CH 18            // partial sums a last-arriver thread keeps in flight per batch (one fabric round trip each batch;
+#ifndef FUSED_CH
+#define FUSED_CH 18
+#endif
+//            // partial sums a last-arriver thread keeps in flight per batch (one fabric round trip each batch;
                                //   a last arriver reads fresh cross-CU data at ~65 GB/s, so every redundant load counts)
 #define FUSED_RCH 6            // column blocks of a row's partials per batch
 
@@ -887,26 +1005,142 @@ __device__ __forceinline__ void absmean_last_arriver_jobs(const cfx_comp_item& i
 #undef STAMP
 }
 
+// The layer launches' jobs on TAGGED partials (put_tagged): no last arriver - a FIXED workgroup per job, the last-dispatched tiles of the
+// tensor (V of column block bx: tile (bx, P - 1); U: tile (CB - 1, P - 2)), polls the very words it reduces until all carry the
+// launch's tag.  Fourteen workgroups polling ~70 KB a round is nothing beside the launch's traffic (every TILE polling was: the min/max
+// layer's first form).  A thread's loads of a round are issued together, then the tags compared (a test per load serialises them).
+// Arithmetic = absmean_last_arriver_jobs (exact integer sums: bit-identical for any order).  do_col / do_row: uniform per workgroup.
+__device__ __forceinline__ void absmean_tagged_jobs(const cfx_comp_item& it, int N, int C, int CB, int P, int bx, u64* rowpart, const TagArena& ta,
+                                                    int per_byte, int eps_mode, u64 (*sm)[TILE_C], bool do_col, bool do_row, u64* stamps,
+                                                    unsigned* gate, unsigned* err, long long timeout) {
+    constexpr int NT = FUSED_NT;
+#define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
+    lds_barrier();                             // sm may be reused
+    const int tid = threadIdx.x;
+    const u64* colpart = rowpart + (size_t)N * CB;
+    h16* U = (h16*)((char*)it.packet + (size_t)N * (C / per_byte));
+    h16* V = U + N;
+    SpinClock clk;
+    bool failed = false;
+#define PUT16(ptr, val) st_wt((u16*)(ptr), hbits(val))
+    if (do_col) {
+        // V of column block bx: one column per thread, FUSED_CH partials a round
+        const int c = bx * TILE_C + tid, cc = min(c, C - 1);
+        u64 a = 0;
+        for (int p0 = 0; p0 < P && !failed; p0 += FUSED_CH) {
+            u64 v[FUSED_CH];
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < FUSED_CH; ++j) v[j] = ld_wt(&ta.tcol[(size_t)min(p0 + j, P - 1) * C + cc]);
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < FUSED_CH; ++j) ok = ok && tag_is(v[j], ta.tagbits);
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (clk.expired(timeout)) { failed = true; break; }
+            }
+#pragma unroll
+            for (int j = 0; j < FUSED_CH; ++j) {
+                const u64 w = v[j] & TAG_SAT;
+                if (p0 + j < P) a += (w == TAG_SAT && !failed) ? ld_wt(&colpart[(size_t)(p0 + j) * C + cc]) : w;      // rare: the exact sum beside it
+            }
+        }
+        STAMP(4);
+        failed = __syncthreads_or(failed ? 1 : 0) != 0;
+        if (!failed) {
+            if (c < C) {
+                const h16 vm = mean16(a, N);
+                st_wt(&ta.tV[c], ta.tagbits | (u64)hbits(vm));      // first: the copy the launch's own reconstruction workgroups poll
+                PUT16(&V[c], vm);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            if (tid == 0) gate_arrive_few(gate, 1u);
+        }
+        STAMP(5);
+    }
+    if (do_row && !failed) {
+        // U: one row per thread and pass; its CB partials in one round
+        u64* smem = &sm[1][0];
+        auto row_sum = [&](int n) {
+            const int nc = min(n, N - 1);
+            u64 s_ = 0;
+            for (int k0 = 0; k0 < CB && !failed; k0 += FUSED_RCH) {
+                u64 q[FUSED_RCH];
+                for (;;) {
+#pragma unroll
+                    for (int j = 0; j < FUSED_RCH; ++j) q[j] = ld_wt(&ta.trow[(size_t)min(k0 + j, CB - 1) * N + nc]);
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 0; j < FUSED_RCH; ++j) ok = ok && tag_is(q[j], ta.tagbits);
+                    if (ok) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (clk.expired(timeout)) { failed = true; break; }
+                }
+#pragma unroll
+                for (int j = 0; j < FUSED_RCH; ++j) {
+                    const u64 w = q[j] & TAG_SAT;
+                    if (k0 + j < CB) s_ += (w == TAG_SAT && !failed) ? ld_wt(&rowpart[(size_t)(k0 + j) * N + nc]) : w;
+                }
+            }
+            return s_;
+        };
+        // pass 1: every row's fp16 mean -> the sum of the means (the tensor's grand mean); a thread keeps its first two rows' means
+        h16 h0 = (h16)0, h1 = (h16)0;
+        u64 acc = 0;
+        for (int n0 = tid, i = 0; n0 - tid < N; n0 += NT, ++i) {
+            const h16 h = mean16(row_sum(n0), C);
+            if (i == 0) h0 = h;
+            if (i == 1) h1 = h;
+            if (n0 < N) acc += habs_units(hbits(h));
+        }
+        STAMP(13);
+        const u64 wtot = wave_sum_u64(acc);
+        if ((tid & 63) == 0) smem[tid >> 6] = wtot;
+        failed = __syncthreads_or(failed ? 1 : 0) != 0;
+        STAMP(15);
+        if (!failed) {
+            u64 tot = 0;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) tot += smem[w];
+            const h16 mu = mean16(tot, N);
+            const float den = eps_mode ? (float)(h16)((float)mu + 1e-6f) : (float)mu;
+            for (int n0 = tid, i = 0; n0 < N; n0 += NT, ++i) {
+                const h16 h = i == 0 ? h0 : (i == 1 ? h1 : mean16(row_sum(n0), C));      // (beyond 2 NT rows: the partials are read again)
+                const h16 un = (h16)((float)h / den);
+                st_wt(&ta.tU[n0], ta.tagbits | (u64)hbits(un));
+                PUT16(&U[n0], un);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            if (tid == 0) gate_arrive_few(gate, 1u);
+        }
+        STAMP(6);
+    }
+#undef PUT16
+#undef STAMP
+    if (failed && tid == 0) gate_fail(err);
+}
+
 // What a statistics workgroup of the 2-bit layer launch does with its own tile once the scales exist (R == FUSED_NW * US, the tile
 // of x and of the state still in registers): wait for gate 1, quantise (the codes depend on the scales), publish the codes
 // write-through, error feedback, one arrival on gate 2 - the arithmetic of k_int2_quant without reading x and the state again.
 template <int US>
 __device__ __forceinline__ void own_tile_finish(const cfx_comp_item& it, int N, int C, int R, int bx, int by, int flags, const h16x8* xk,
                                                 const h16x8* bk, unsigned* gate1, unsigned expect1, unsigned* gate2, unsigned expect2,
-                                                unsigned* err, unsigned char* smw) {
+                                                unsigned* err, long long timeout, unsigned char* smw, const TagArena& ta, u16* s16) {
     constexpr int NW = FUSED_NW;
     static_assert(US * 8 <= 64, "a wave publishes its US rows of codes with 8 lanes a row");
     const TileCoord t = tile_coord_at(bx, by, N, C, R);
     h16* nb = (h16*)it.new_base;
     const bool upd = (flags & CFX_FLAG_UPDATE_CACHE) && nb;
     const bool ef = !(flags & CFX_FLAG_NO_EF);
-    gate_wait<true>(gate1, expect1, err);
+    // the scales: the launch's tagged copies, polled (no gate 1: scales_from_tagged)
+    (void)gate1; (void)expect1;
+    if (!scales_from_tagged<NW * US>(ta, N, C, bx * TILE_C, t.r0, s16, timeout, err)) return;   // (no codes, no arrival on gate 2: the reconstruction group gives up as well)
     unsigned char* pk = (unsigned char*)it.packet;
-    const u16* TOK = (const u16*)(pk + (size_t)N * (C >> 2));
-    const u16* CH = TOK + N;
-    const int cc = min(t.c, C - 8);
-    const h16x8 ch8 = ld8_wt(CH + cc);
-    const u16 ul = ld_wt(TOK + min(t.r0 + t.w + NW * min(t.lane, US - 1), t.r1 - 1));
+    const h16x8 ch8 = __builtin_bit_cast(h16x8, *(const u16x8*)(s16 + 8 * t.lane));
+    const u16 ul = s16[TILE_C + min(t.w + NW * min(t.lane, US - 1), t.r1 - 1 - t.r0)];
     const bool has_base = it.base != nullptr;
     u16 codes[US];
 #pragma unroll
@@ -939,7 +1173,10 @@ __device__ __forceinline__ void own_tile_finish(const cfx_comp_item& it, int N, 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
-    if (threadIdx.x == 0) gate_arrive(gate2, 1u, expect2);
+    if (threadIdx.x == 0) {
+        st_wt(&ta.tdone[(size_t)bx * ((N + R - 1) / R) + by], ta.tagbits);      // for the launch's own reconstruction tiles: they wait for the tiles whose codes they read
+        gate_arrive(gate2, 1u, expect2);                                        // for whoever ships the packets: all tiles in
+    }
     if (upd) {
 #pragma unroll
         for (int j = 0; j < US; ++j) {
@@ -959,7 +1196,8 @@ template <bool EMIT_BITS, int US, bool GATED = false, bool KEEP = false>
 __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int N, int C, int R, int CB, int P, int bx, int by,
                                                    u64* rowpart, unsigned* tick, int per_byte, int eps_mode, u64 (*sm)[TILE_C], int dbg,
                                                    u64* stamps, unsigned* gate = nullptr, unsigned gate_expect = 0, int flags = 0,
-                                                   unsigned* gate2 = nullptr, unsigned expect2 = 0, unsigned* err = nullptr) {
+                                                   unsigned* gate2 = nullptr, unsigned expect2 = 0, unsigned* err = nullptr, long long timeout = 0,
+                                                   TagArena ta = TagArena()) {
     // developer hook (cfx_debug_stamps): per-workgroup phase times, 100 MHz wall clock
 #define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
     STAMP(0);
@@ -984,8 +1222,29 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
     }
 #endif
     h16x8 xk[KEEP ? US : 1], bk[KEEP ? US : 1];
-    absmean_stats_body<EMIT_BITS, US, true, FUSED_NW, GATED, KEEP>(it, N, C, R, CB, bx, by, rowpart, sm, stamps, xk, bk);
+    absmean_stats_body<EMIT_BITS, US, true, FUSED_NW, GATED, KEEP, GATED>(it, N, C, R, CB, bx, by, rowpart, sm, stamps, xk, bk, ta);
     STAMP(1);
+    if constexpr (GATED) {
+        // the layer launches: tagged partials, fixed reducers (absmean_tagged_jobs) - nothing to drain, no ticket to draw
+        const bool v_wg = by == P - 1;
+        const bool u_wg = P >= 2 ? (by == P - 2 && bx == CB - 1) : (bx == CB - 1);
+        if (stamps && threadIdx.x == 0) { stamps[2] = stamps[3] = stamps[1]; stamps[7] = (v_wg ? 1 : 0) | (u_wg ? 2 : 0); }
+        if (v_wg || u_wg) {
+            // KEEP: the jobs' loads in flight beside the whole tile do not fit 128 registers (tools/resource_usage.py, tests/test_resource_usage.py)
+            // - the tile's last two rows of x and of the state sit out the jobs in the LDS rows the statistics do not use (sm[FUSED_NW ..]:
+            // same thread writes and reads, no barrier)
+            u32x4* park = (u32x4*)&sm[FUSED_NW][0];
+            if constexpr (KEEP) {
+                park[threadIdx.x] = __builtin_bit_cast(u32x4, xk[US - 1]);
+                park[FUSED_NT + threadIdx.x] = __builtin_bit_cast(u32x4, bk[US - 1]);
+            }
+            absmean_tagged_jobs(it, N, C, CB, P, bx, rowpart, ta, per_byte, eps_mode, sm, v_wg, u_wg, stamps, gate, err, timeout);
+            if constexpr (KEEP) {
+                xk[US - 1] = __builtin_bit_cast(h16x8, park[threadIdx.x]);
+                bk[US - 1] = __builtin_bit_cast(h16x8, park[FUSED_NT + threadIdx.x]);
+            }
+        }
+    } else {
     // publish: EVERY storing wave drains its write-through stores, then one lane pair draws the two tickets
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -993,68 +1252,47 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
 #ifdef CFX_DEV_PROBES
     if (dbg == 1) return;
 #endif
-    // Who does what: the column ticket (a returned atomic) elects the workgroup that reduces column block bx (V).  The tensor-wide
-    // job (U):
-    //  * gated launches: a second returned ticket elects the last tile of all, as before;
-    //  * stand-alone launches (UPOLL): that workgroup is always also the last of its column block and would read both jobs'
-    //    partials at the ~65 GB/s a single workgroup gets from other CUs - so the job goes to a FIXED workgroup, tile (0, 0):
-    //    every tile counts itself on tick[TICK_ALL] without waiting for the result, and tile (0, 0), once done with its own work,
-    //    polls that word (one reader on a line of its own) and reads only the row partials: -0.9 us on the launch.  Under a
-    //    gated launch's preload burst a poll round trip costs more than the returned ticket, there it measured +1 us.
-    constexpr bool UPOLL = !GATED;
+    // Who does what: the column ticket (a returned atomic) elects the workgroup that reduces column block bx (V).  The tensor-wide job (U)
+    // goes to a FIXED workgroup, tile (0, 0): the last tile of all is always also the last of its column block and would read both jobs'
+    // partials at the ~65 GB/s a single workgroup gets from other CUs; every tile counts itself on tick[TICK_ALL] without waiting for the
+    // result, and tile (0, 0), once done with its own work, polls that word (one reader on a line of its own) and reads only the row
+    // partials: -0.9 us on the launch.
     unsigned* flag = (unsigned*)&sm[0][0];
     if (threadIdx.x == 0) flag[0] = __hip_atomic_fetch_add(tick + 1 + bx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x == 64) {
-        if (UPOLL) (void)__hip_atomic_fetch_add(tick + TICK_ALL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else flag[1] = __hip_atomic_fetch_add(tick + TICK_ALL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 64) (void)__hip_atomic_fetch_add(tick + TICK_ALL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lds_barrier();
     const bool last_col = flag[0] == (unsigned)(P - 1);
-    const bool u_wg = UPOLL ? (bx == 0 && by == 0) : (flag[1] == (unsigned)(CB * P - 1));
+    const bool u_wg = bx == 0 && by == 0;
     STAMP(3);
     if (stamps && threadIdx.x == 0) stamps[7] = (last_col ? 1 : 0) | (u_wg ? 2 : 0);
 #ifdef CFX_DEV_PROBES
     if (dbg == 2) {
         if (last_col && threadIdx.x == 0) st_wt(tick + 1 + bx, 0u);
         if (u_wg && threadIdx.x == 0) {
-            if (UPOLL) while (ld_wt(tick + TICK_ALL) != (unsigned)(CB * P)) __builtin_amdgcn_s_sleep(1);
+            while (ld_wt(tick + TICK_ALL) != (unsigned)(CB * P)) __builtin_amdgcn_s_sleep(1);
             st_wt(tick + TICK_ALL, 0u);
         }
         return;
     }
 #endif
-    if (UPOLL) {
-        if (last_col)                          // uniform per workgroup
-            absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, true, false, stamps, gate, gate_expect);
-        if (u_wg) {
-            if (threadIdx.x == 0) {
-                unsigned n = 0;
-                while (ld_wt(tick + TICK_ALL) != (unsigned)(CB * P)) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++n > GATE_SPIN_LIMIT) { gate_fail(err); break; }
-                }
+    if (last_col)                          // uniform per workgroup
+        absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, true, false, stamps, gate, gate_expect);
+    if (u_wg) {
+        bool failed = false;
+        if (threadIdx.x == 0) {
+            SpinClock clk;
+            while (ld_wt(tick + TICK_ALL) != (unsigned)(CB * P)) {
+                __builtin_amdgcn_s_sleep(1);
+                if (clk.expired(timeout)) { failed = true; gate_fail(err); break; }
             }
-            __syncthreads();
-            absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, false, true, stamps, gate, gate_expect);
         }
-    } else if (last_col || u_wg) {
-        // KEEP: the jobs' loads in flight (FUSED_CH + 2 x FUSED_RCH words) beside the whole tile did not fit 128 registers (16 bytes a lane
-        // of scratch: tools/resource_usage.py) - the tile's last row of x and of the state sits out the jobs in the LDS rows the
-        // statistics do not use (sm[FUSED_NW ..]: same thread writes and reads, no barrier)
-        u32x4* park = (u32x4*)&sm[FUSED_NW][0];
-        if constexpr (KEEP) {
-            park[threadIdx.x] = __builtin_bit_cast(u32x4, xk[US - 1]);
-            park[FUSED_NT + threadIdx.x] = __builtin_bit_cast(u32x4, bk[US - 1]);
-        }
-        absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, last_col, u_wg, stamps, gate, gate_expect);
-        if constexpr (KEEP) {
-            xk[US - 1] = __builtin_bit_cast(h16x8, park[threadIdx.x]);
-            bk[US - 1] = __builtin_bit_cast(h16x8, park[FUSED_NT + threadIdx.x]);
-        }
+        if (__syncthreads_or(failed ? 1 : 0)) return;           // (tiles that never arrived: no row scales - the error word says so)
+        absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, false, true, stamps, gate, gate_expect);
+    }
     }
     if constexpr (KEEP)
-        own_tile_finish<US>(it, N, C, R, bx, by, flags, xk, bk, gate, gate_expect, gate2, expect2, err,
-                                       (unsigned char*)&sm[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0]);
+        own_tile_finish<US>(it, N, C, R, bx, by, flags, xk, bk, gate, gate_expect, gate2, expect2, err, timeout,
+                                       (unsigned char*)&sm[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0], ta, (u16*)&sm[FUSED_NW + 4][0]);
 #undef STAMP
 }
 
@@ -1086,6 +1324,7 @@ __device__ __forceinline__ void p2p_exchange_inline(const unsigned* p_gate, unsi
         __builtin_amdgcn_s_sleep(1);
         if (wall_clock64() - t0 > p.timeout) { gave_up = true; break; }
     }
+    if (__builtin_amdgcn_ballot_w64(gave_up) != 0) { if (lane == 0) gate_fail(err); return; }      // own packets incomplete: nothing to announce
     // the packets were stored write-through and drained before they were counted complete: publishing after having SEEN that orders them
     // before the word for anybody who reads the word first
     if (lane == 0) __hip_atomic_store(p.own, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1096,7 +1335,9 @@ __device__ __forceinline__ void p2p_exchange_inline(const unsigned* p_gate, unsi
             if (wall_clock64() - t0 > p.timeout) { gave_up = true; break; }
         }
     }
-    if (__builtin_amdgcn_ballot_w64(gave_up) != 0 && lane == 0) gate_fail(err);
+    // a wait that gave up leaves the gate SHUT: the reconstruction groups started with this wave, give up on the same clock a moment later
+    // and store nothing - nobody reconstructs from packets that have not arrived
+    if (__builtin_amdgcn_ballot_w64(gave_up) != 0) { if (lane == 0) gate_fail(err); return; }
     if (lane == 0) st_wt(f_gate, f_expect);
 }
 
@@ -1116,6 +1357,9 @@ struct FusedArgs {
     unsigned* gate;
     unsigned gate_expect;
     unsigned* gate_err;
+    long long timeout;       // every in-launch wait gives up after this many ticks of the 100 MHz wall clock (cfx_set_gate_timeout_ms)
+    u64* tarena; size_t tarena_stride; unsigned tag;      // GATED: the context's tagged-words arena (per tensor: tag_arena_words), the launch's 24-bit tag
+    signed char src[CFX_MAX_BATCH];                        // gated item -> the own tensor of THIS launch whose packet it reads, or -1 (somebody else's packet: gate)
     // external gate (exchange-layer op, cfx_plan_add_exchange_layer): the gated group waits for this word instead of the arrival
     // counter - whoever moves the packets (a collective on the exchange stream) sets it once they have arrived.  NULL: wait on `gate`.
     unsigned* xgate;
@@ -1136,7 +1380,8 @@ __global__ __launch_bounds__(FUSED_NT, GATE_WPE) void k_absmean_compress(BatchC 
         const int by = rem / a.CB;
         absmean_fused_body<EMIT_BITS, US, GATED>(batch.it[z], a.N, a.C, a.R, a.CB, a.P, rem - by * a.CB, by, a.ws + (size_t)z * a.ws_stride,
                                                  a.tick + z * TICK_WORDS, a.per_byte, a.eps_mode, sm, a.dbg,
-                                                 a.stamps ? a.stamps + (size_t)b * 16 : nullptr, a.gate, a.gate_expect, 0, nullptr, 0u, a.gate_err);
+                                                 a.stamps ? a.stamps + (size_t)b * 16 : nullptr, a.gate, a.gate_expect, 0, nullptr, 0u, a.gate_err, a.timeout,
+                                                 tag_arena_of(a.tarena, a.tarena_stride, z, a.N, a.C, a.CB, a.P, a.tag));
         if constexpr (GATED) {
             if (b == 0 && a.p2p.own) p2p_exchange_inline(a.gate, a.gate_expect, 1, a.p2p, a.xgate, a.xexpect, a.gate_err);
         }
@@ -1150,10 +1395,33 @@ __global__ __launch_bounds__(FUSED_NT, GATE_WPE) void k_absmean_compress(BatchC 
                 for (int t = b; t < a.n_gt; t += a.n_g) {             // (one trip unless the group is persistent)
                     const int item = t / per, rem = t - item * per;
                     const int ty = rem / a.CB;
+#ifdef GATE_HOLD
+                    // experiment: hold the state preload back until a statistics tile of this column block has published its row partials
+                    // (= its loads have landed): the statistics group's loads go first
+                    if (a.tarena) {
+                        if (threadIdx.x == 0) {
+                            const u64* w = a.tarena + (size_t)(rem - ty * a.CB) * a.N + min(ty * a.g_R, a.N - 1);
+                            SpinClock clk;
+                            while (!tag_is(ld_wt(w), (u64)a.tag << 40)) {
+                                __builtin_amdgcn_s_sleep(4);
+                                if (clk.expired(a.timeout)) break;
+                            }
+                        }
+                        __syncthreads();
+                    }
+#endif
+                    const int sz = a.src[item];
+                    const TagArena ta = tag_arena_of(a.tarena, a.tarena_stride, sz >= 0 ? sz : 0, a.N, a.C, a.CB, a.P, a.tag);
                     binary_dequant_gated_body<FUSED_NW, GATE_KR, 0, ST>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.xgate ? a.xgate : a.gate,
-                                                                a.xgate ? a.xexpect : a.gate_expect, a.gate_err,
+                                                                a.xgate ? a.xexpect : a.gate_expect, a.gate_err, a.timeout,
                                                                 nullptr,
-                                                                a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr, a.remote != 0);
+                                                                a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr, a.remote != 0 && sz < 0,
+#ifdef ONEBIT_D_GATE
+                                                                false,
+#else
+                                                                sz >= 0,
+#endif
+                                                                ta, (u16*)&sm[0][0]);
                 }
                 return;
             }
@@ -1332,8 +1600,9 @@ __global__ __launch_bounds__(NTHR) void k_int2_dequant(BatchD batch, int N, int 
 // ---------------------------------------------------------------------------------------------------
 template <int NW, int KR, int KL>
 __device__ __forceinline__ void int2_dequant_gated_body(const cfx_decomp_item& it, int N, int C, int R, int tile_x, int tile_y,
-                                                       unsigned* gate, unsigned expect, unsigned* err, u32x4* lds,
-                                                       unsigned* xgate = nullptr, unsigned xexpect = 0, bool remote = false) {
+                                                       unsigned* gate, unsigned expect, unsigned* err, long long timeout, u32x4* lds,
+                                                       unsigned* xgate = nullptr, unsigned xexpect = 0, bool remote = false,
+                                                       bool tagged = false, TagArena ta = TagArena(), int Rs = 0, u16* s16 = nullptr) {
     constexpr int K = KR + KL;
     const TileCoord t = tile_coord_at(tile_x, tile_y, N, C, R);
     const int C4 = C >> 2;
@@ -1358,12 +1627,33 @@ __device__ __forceinline__ void int2_dequant_gated_body(const cfx_decomp_item& i
 #pragma unroll
         for (int j = 0; j < KR; ++j) bv[j] = (h16x8)(h16)0;
     }
-    if (xgate) gate_wait<true>(xgate, xexpect, err);
-    else gate_wait(gate, expect, err);
     h16x8 ch8;
     u16 ul;
     u16 cd[K];
-    if (remote) {                                            // (uniform) the packet sits in a peer GPU's memory: system-scope loads
+    if (tagged) {
+        // the packet is one of THIS launch's: wait for the statistics tiles whose codes this tile reads (their flags carry the launch's
+        // tag once the codes are in memory) - not for the slowest tile of the launch -, then the scales' tagged copies (complete by then:
+        // a tile quantises only after it has seen them)
+        bool failed = false;
+        if (t.w == 0) {
+            const int P = (N + Rs - 1) / Rs, by0 = t.r0 / Rs, by1 = (t.r1 - 1) / Rs;
+            const u64* f = ta.tdone + (size_t)tile_x * P;
+            SpinClock clk;
+            for (;;) {
+                const u64 v = by0 + t.lane <= by1 ? ld_wt(f + by0 + t.lane) : ta.tagbits;
+                if (__builtin_amdgcn_ballot_w64(!tag_is(v, ta.tagbits)) == 0) break;
+                __builtin_amdgcn_s_sleep(2);
+                if (clk.expired(timeout)) { failed = true; if (t.lane == 0) gate_fail(err); break; }
+            }
+        }
+        if (__syncthreads_or(failed ? 1 : 0)) return;
+        if (!scales_from_tagged<NW * K>(ta, N, C, tile_x * TILE_C, t.r0, s16, timeout, err)) return;
+        ch8 = __builtin_bit_cast(h16x8, *(const u16x8*)(s16 + 8 * t.lane));
+        ul = s16[TILE_C + min(t.w + NW * min(t.lane, K - 1), t.r1 - 1 - t.r0)];
+#pragma unroll
+        for (int j = 0; j < K; ++j) cd[j] = ld_wt((const u16*)(pk + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C4) + (cc >> 3));
+    } else if (!(xgate ? gate_wait<true>(xgate, xexpect, err, timeout) : gate_wait(gate, expect, err, timeout))) return;
+    else if (remote) {                                            // (uniform) the packet sits in a peer GPU's memory: system-scope loads
         u16x8 vb;
 #pragma unroll
         for (int i = 0; i < 8; ++i) vb[i] = ld_sys(CH + cc + i);
@@ -1402,20 +1692,25 @@ struct Int2LayerArgs {
     unsigned* gate1; unsigned expect1;
     unsigned* gate2; unsigned expect2;
     unsigned* err;
+    long long timeout;                     // in-launch waits: ticks of the 100 MHz wall clock
+    u64* tarena; size_t tarena_stride; unsigned tag;      // the context's tagged-words arena, the launch's 24-bit tag
+    signed char src[CFX_MAX_BATCH];                        // gated item -> the own tensor of this launch whose packet it reads, or -1
     unsigned* xgate; unsigned xexpect;     // external gate for group D (exchange-layer op): NULL = group D waits on gate2
     int remote;                            // group D's packets may sit in a peer GPU's memory
     P2PInline p2p;                         // own != NULL: workgroup 0 runs the peer-to-peer exchange and opens xgate itself
 };
 template <int US>
 __global__ __launch_bounds__(FUSED_NT, 4) void k_int2_compress_gated(BatchC batch, BatchD gated, Int2LayerArgs a) {
-    __shared__ u64 sm[GATE_LDS_ROWS > FUSED_NW + 4 ? GATE_LDS_ROWS : FUSED_NW + 4][TILE_C];      // the statistics group: FUSED_NW rows + 4 (a parked row of x, of the state)
+    // the statistics group: FUSED_NW rows + 4 (a parked row of x, of the state); the reconstruction group: GATE_LDS_ROWS of parked state + 1 of scales
+    __shared__ u64 sm[(GATE_LDS_ROWS > FUSED_NW + 4 ? GATE_LDS_ROWS : FUSED_NW + 4) + 1][TILE_C];
     int b = blockIdx.x;
     if (b < a.n_st) {
         const int per = a.CB * a.P;
         const int z = b / per, rem = b - z * per;
         const int by = rem / a.CB;
         absmean_fused_body<false, US, true, true>(batch.it[z], a.N, a.C, a.R, a.CB, a.P, rem - by * a.CB, by, a.ws + (size_t)z * a.ws_stride,
-                                                  a.tick + z * TICK_WORDS, 4, 1, sm, 0, nullptr, a.gate1, a.expect1, a.flags, a.gate2, a.expect2, a.err);
+                                                  a.tick + z * TICK_WORDS, 4, 1, sm, 0, nullptr, a.gate1, a.expect1, a.flags, a.gate2, a.expect2, a.err, a.timeout,
+                                                  tag_arena_of(a.tarena, a.tarena_stride, z, a.N, a.C, a.CB, a.P, a.tag));
         // (packets complete = the codes gate's last arriver has written the "open" words: XCD 0's)
         if (b == 0 && a.p2p.own) p2p_exchange_inline(a.gate2 + 1 * GATE_LINE, a.expect2, 1, a.p2p, a.xgate, a.xexpect, a.err);
         return;
@@ -1424,8 +1719,12 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_int2_compress_gated(BatchC batc
     const int per = a.CB * a.g_rb;
     const int item = b / per, rem = b - item * per;
     const int ty = rem / a.CB;
-    int2_dequant_gated_body<FUSED_NW, GATE_KR2, GATE_KL>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.gate2, a.expect2, a.err,
-                                                        (u32x4*)&sm[0][0], a.xgate, a.xexpect, a.remote != 0);
+    const int sz = a.src[item];
+    const TagArena ta = tag_arena_of(a.tarena, a.tarena_stride, sz >= 0 ? sz : 0, a.N, a.C, a.CB, a.P, a.tag);
+    // (s16: behind the KL rows of state the workgroup parks in LDS)
+    int2_dequant_gated_body<FUSED_NW, GATE_KR2, GATE_KL>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.gate2, a.expect2, a.err, a.timeout,
+                                                        (u32x4*)&sm[0][0], a.xgate, a.xexpect, a.remote != 0 && sz < 0, sz >= 0, ta, a.R,
+                                                        (u16*)&sm[GATE_LDS_ROWS][0]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1637,6 +1936,7 @@ struct MinMaxLayerArgs {
                                       // the scales) published" = the launch's sequence number (context-wide, never reused)
     unsigned* xgate; unsigned xexpect;     // external gate for group D (NULL: a D tile waits for the S tiles whose codes it reads)
     unsigned* err;
+    long long timeout;                // in-launch waits: ticks of the 100 MHz wall clock
     int remote;
     signed char src[CFX_MAX_BATCH];   // gated item -> the own tensor whose packet it reads (loop-back forms)
     P2PInline p2p;                    // own != NULL: workgroup 0 runs the peer-to-peer exchange and opens xgate itself
@@ -1727,6 +2027,11 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
     u64* st = a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr;
     if (st && threadIdx.x == 0) st[7] = 1;
     MML_STAMP(0);
+    // every wait of this tile gives up a.timeout after the tile started (one time base, no cascade of waits); a tile that gave up stores
+    // neither codes nor state nor its flag - whoever waits for it gives up in turn, and the context's error word says so
+    SpinClock clk;
+    clk.t0 = wall_clock64();
+    bool failed = false;
     // ---- the tile into registers (every load unconditional: clamped row, masked use) ----
     constexpr int RREG = RW > 4 ? RW - MML_PARK : RW;       // state rows that stay in registers
     h16x8 dk[RW], bk[RREG];
@@ -1802,13 +2107,12 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
         // whatever shares the chip, including the tiles being waited for (measured: waits of seconds beside a copy stream)
         if (t.w == 0) {
             const u64* w0 = part + (size_t)bx * TILE_C;
-            unsigned spins = 0;
             for (;;) {
                 const u64 v0 = t.lane < a.P ? ld_wt(w0 + (size_t)t.lane * C) : tag;
                 const u64 v1 = t.lane + 64 < a.P ? ld_wt(w0 + (size_t)(t.lane + 64) * C) : tag;
                 if (__builtin_amdgcn_ballot_w64((unsigned)(v0 >> 32) != a.seq || (unsigned)(v1 >> 32) != a.seq) == 0) break;
                 __builtin_amdgcn_s_sleep(MML_POLL_SLEEP);
-                if (++spins > GATE_SPIN_LIMIT) { if (t.lane == 0) gate_fail(a.err); break; }
+                if (clk.expired(a.timeout)) { failed = true; break; }
             }
         }
         __syncthreads();
@@ -1818,7 +2122,6 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
         h16 lo = hfrom(0x7c00), hi = hfrom(0xfc00);
         for (int p0 = 0; p0 < a.P; p0 += NB) {
             u64 v[NB];
-            unsigned spins = 0;
             for (;;) {
                 // (all loads issued, THEN the tags compared: a test per load makes the compiler wait for each load in turn)
 #pragma unroll
@@ -1828,10 +2131,7 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
                 for (int j = 0; j < NB; ++j) bad |= (unsigned)(v[j] >> 32) ^ a.seq;
                 if (!bad) break;
                 __builtin_amdgcn_s_sleep(MML_POLL_SLEEP);
-                if (++spins > GATE_SPIN_LIMIT) {
-                    gate_fail(a.err);
-                    break;
-                }
+                if (failed || clk.expired(a.timeout)) { failed = true; break; }
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
@@ -1841,7 +2141,7 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
             }
         }
         minmax_scale_of<INT4>(lo, hi, scale, second);
-        if (by == 0 && ch < C) {                               // the block's scales into the packet: once
+        if (by == 0 && ch < C && !failed) {                    // the block's scales into the packet: once
             st_wt(S + ch, hbits(scale));
             st_wt(S + C + ch, second);
         }
@@ -1852,7 +2152,6 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
             h16 lo = hfrom(0x7c00), hi = hfrom(0xfc00);
             for (int p0 = t.w; p0 < a.P; p0 += NW * 8) {
                 u64 v[8];
-                unsigned spins = 0;
                 for (;;) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = ld_wt(&part[(size_t)min(p0 + NW * j, a.P - 1) * C + chrc]);
@@ -1861,7 +2160,7 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
                     for (int j = 0; j < 8; ++j) bad |= (unsigned)(v[j] >> 32) ^ a.seq;
                     if (!bad) break;
                     __builtin_amdgcn_s_sleep(MML_POLL_SLEEP);
-                    if (++spins > GATE_SPIN_LIMIT) { gate_fail(a.err); break; }
+                    if (failed || clk.expired(a.timeout)) { failed = true; break; }
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -1870,7 +2169,7 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
                     hi = b0 > hi ? b0 : hi;
                 }
             }
-            __syncthreads();                                    // (sm32: the publish above has read it)
+            failed = __syncthreads_or(failed ? 1 : 0) != 0;     // (sm32: the publish above has read it) - a wave that gave up: no scales from this tile
             sm32[t.w * 64 + t.lane] = (unsigned)hbits(lo) | ((unsigned)hbits(hi) << 16);
             __syncthreads();
             if (t.w == 0) {
@@ -1884,7 +2183,7 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
                 h16 sc1;
                 u16 sec1;
                 minmax_scale_of<INT4>(lo, hi, sc1, sec1);
-                if (chr < C) {
+                if (chr < C && !failed) {
                     st_wt(&sca[chr], tag | (unsigned)hbits(sc1) | ((unsigned)sec1 << 16));
                     st_wt(S + chr, hbits(sc1));                 // (the packet's copy: for the receivers, behind this tile's codes flag)
                     st_wt(S + C + chr, sec1);
@@ -1892,22 +2191,20 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
             }
         }
         if (t.w == 0) {                                         // (one wave watches one word per reducer tile first: see above)
-            unsigned spins = 0;
             for (;;) {
                 const u64 v0 = t.lane < MML_NRED ? ld_wt(&sca[min(bx * TILE_C + t.lane * 64, C - 1)]) : tag;
                 if (__builtin_amdgcn_ballot_w64((unsigned)(v0 >> 32) != a.seq) == 0) break;
                 __builtin_amdgcn_s_sleep(MML_POLL_SLEEP);
-                if (++spins > GATE_SPIN_LIMIT) { if (t.lane == 0) gate_fail(a.err); break; }
+                if (failed || clk.expired(a.timeout)) { failed = true; break; }
             }
         }
         __syncthreads();
-        unsigned spins = 0;
         u64 v;
         for (;;) {
             v = ld_wt(&sca[chc]);
             if ((unsigned)(v >> 32) == a.seq) break;
             __builtin_amdgcn_s_sleep(16);
-            if (++spins > GATE_SPIN_LIMIT) { gate_fail(a.err); break; }
+            if (failed || clk.expired(a.timeout)) { failed = true; break; }
         }
         scale = hfrom((u16)(v & 0xffff));
         second = (u16)((unsigned)v >> 16);
@@ -1915,7 +2212,10 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
     MML_STAMP(2);                                           // scales known
     // a lane's 8 channels from the 512 per-thread values: through LDS
     u16* sl = (u16*)&sm[0][0];                              // [2][TILE_C] halves (the min / max words are consumed)
-    __syncthreads();
+    if (__syncthreads_or(failed ? 1 : 0)) {                 // somebody's wait gave up: no codes, no state, no flag from this tile
+        if (k == 0) gate_fail(a.err);
+        return;
+    }
     sl[k] = hbits(scale);
     sl[TILE_C + k] = second;
     __syncthreads();
@@ -2022,6 +2322,7 @@ __device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, c
     if (st && threadIdx.x == 0) st[7] = 4;
     MML_STAMP(0);
     const int kc = a.g_R / (NW * RPC);         // code rows per wave of THIS launch's tiles (<= KC; uniform)
+    bool failed = false;
     h16x8 bv[MML_KC];
 #pragma unroll
     for (int j = 0; j < KC; ++j)
@@ -2032,7 +2333,7 @@ __device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, c
                 bv[j * RPC + h] = base ? ld8nt(base + (size_t)min(row, N - 1) * C + cc) : (h16x8)(h16)0;
             }
         }
-    if (a.xgate) gate_wait<true>(a.xgate, a.xexpect, a.err);
+    if (a.xgate) { if (!gate_wait<true>(a.xgate, a.xexpect, a.err, a.timeout)) return; }
     else {
         // the S tiles whose codes this tile reads (same column block, the row tiles its rows fall into) - and the tiles that wrote the
         // scales: tile 0, tall form tiles 0 .. MML_NRED - 1
@@ -2041,16 +2342,16 @@ __device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, c
             const int by0 = t.r0 / a.R, by1 = (t.r1 - 1) / a.R;
             const int lane = threadIdx.x & 63;
             const int nsc = a.coop ? MML_NRED : 1;
-            unsigned spins = 0;
+            SpinClock clk;
             for (;;) {
                 const int idx = lane < nsc ? lane : by0 + lane - nsc;
                 const unsigned v = (lane < nsc || idx <= by1) ? ld_wt(f + min(idx, a.P - 1)) : a.seq;
                 if (__builtin_amdgcn_ballot_w64((int)(v - a.seq) < 0) == 0) break;
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > GATE_SPIN_LIMIT) { if (lane == 0) gate_fail(a.err); break; }
+                if (clk.expired(a.timeout)) { failed = true; if (lane == 0) gate_fail(a.err); break; }
             }
         }
-        __syncthreads();
+        if (__syncthreads_or(failed ? 1 : 0)) return;       // the codes never came: the state stays as it was
     }
     if (st) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2459,6 +2760,7 @@ struct TopkLayerArgs {
     unsigned* gate; unsigned gate_expect;
     unsigned* xgate; unsigned xexpect;
     unsigned* err;
+    long long timeout;
     int remote;
     P2PInline p2p;
 };
@@ -2498,8 +2800,7 @@ __global__ __launch_bounds__(256) void k_topk_layer(BatchC batch, BatchD gated, 
         const size_t e = (((size_t)dw * TKL_DU + u) * 256 + threadIdx.x) * 8;
         bv[u] = (base && e < a.E) ? ld8nt(base + e) : (h16x8)(h16)0;
     }
-    if (a.xgate) gate_wait<true>(a.xgate, a.xexpect, a.err);
-    else gate_wait<false>(a.gate, a.gate_expect, a.err);
+    if (!(a.xgate ? gate_wait<true>(a.xgate, a.xexpect, a.err, a.timeout) : gate_wait<false>(a.gate, a.gate_expect, a.err, a.timeout))) return;
     const u16* val = (const u16*)it.packet;
     const unsigned char* idx = (const unsigned char*)(val + a.E / M);
     // the packet words of G units in flight at once (as many as 16 small registers hold), then their stores
@@ -2820,6 +3121,8 @@ void cfx_destroy(cfx_ctx* ctx) {
         if (ctx->lrs_arena[i]) (void)hipFree(ctx->lrs_arena[i]);
     for (int i = 0; i < CFX_RING_STREAMS; ++i)
         if (ctx->mml_arena[i]) (void)hipFree(ctx->mml_arena[i]);
+    for (int i = 0; i < CFX_RING_STREAMS; ++i)
+        if (ctx->abs_arena[i]) (void)hipFree(ctx->abs_arena[i]);
     if (ctx->lrs_ev) (void)hipEventDestroy(ctx->lrs_ev);
     if (ctx->gate_err) (void)hipHostFree(ctx->gate_err);
     delete ctx;
@@ -3027,6 +3330,44 @@ static void fill_p2p(cfx_ctx* ctx, CfxXGate* xg, P2PInline& p) {
     xg->inline_done = 1;
 }
 
+// The tagged-partials arena of a ring (= a stream) for the abs-mean layer launches: context-owned because its words are TAGGED - a stale
+// word must never carry a tag a later launch expects, so it starts zeroed and only ever takes this context's tags, handed out in
+// sequence (24 bits, never 0; when they wrap the arenas are zeroed again, in stream order).  Returns the launch's tag, 0 on failure.
+static unsigned abs_arena_for(cfx_ctx* ctx, unsigned ring, void* stream, size_t need_bytes, u64** arena) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!ctx->mml_arena_owned[ring] || ctx->mml_arena_owner[ring] != stream) {
+        // the ring - and with it its arenas - changed hands: whatever its previous owner still has in flight reads them.  Rare; wait for it
+        if (ctx->mml_arena_owned[ring]) (void)hipDeviceSynchronize();
+        ctx->mml_arena_owner[ring] = stream;
+        ctx->mml_arena_owned[ring] = true;
+    }
+    if (ctx->abs_arena_bytes[ring] < need_bytes) {
+        if (ctx->abs_arena[ring]) (void)hipFree(ctx->abs_arena[ring]);      // (synchronises the device: no launch still reads it)
+        ctx->abs_arena[ring] = nullptr;
+        ctx->abs_arena_bytes[ring] = 0;
+        const size_t cap = (std::max(need_bytes, (size_t)2 << 20) + 4095) & ~(size_t)4095;
+        void* m = nullptr;
+        if (hipMalloc(&m, cap) != hipSuccess || hipMemsetAsync(m, 0, cap, s) != hipSuccess) {
+            (void)hipGetLastError();
+            if (m) (void)hipFree(m);
+            return 0;
+        }
+        ctx->abs_arena[ring] = (u64*)m;
+        ctx->abs_arena_bytes[ring] = cap;
+    }
+    unsigned tag = ++ctx->abs_seq & 0xFFFFFFu;
+    if (tag == 0) {
+        // 16.7 million launches later: a word a smaller layout has not touched since could carry a tag again - start over
+        (void)hipDeviceSynchronize();
+        for (int i = 0; i < CFX_RING_STREAMS; ++i)
+            if (ctx->abs_arena[i]) (void)hipMemset(ctx->abs_arena[i], 0, ctx->abs_arena_bytes[i]);
+        (void)hipDeviceSynchronize();
+        tag = ++ctx->abs_seq & 0xFFFFFFu;
+    }
+    *arena = ctx->abs_arena[ring];
+    return tag;
+}
+
 static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                          int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
                          void* workspace, size_t workspace_bytes, void* stream, CfxXGate* xg = nullptr) {
@@ -3097,6 +3438,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             ctx->gate_expect[3 * slot] += (unsigned)a.n_st;
             a.gate_expect = ctx->gate_expect[3 * slot];
             a.err = ctx->gate_err;
+            a.timeout = ctx->gate_timeout;
             if (xg) {
                 a.xgate = a.gate + GATE_BLOCK;
                 a.xexpect = ++ctx->gate_expect[3 * slot + 1];
@@ -3206,6 +3548,15 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             ctx->gate_expect[3 * slot + 1] += (unsigned)a.n_st;
             a.expect1 = ctx->gate_expect[3 * slot]; a.expect2 = ctx->gate_expect[3 * slot + 1];
             a.err = ctx->gate_err;
+            a.timeout = ctx->gate_timeout;
+            a.tarena_stride = tag_arena_words(N, C, CB, P);
+            a.tag = abs_arena_for(ctx, slot / TICK_RING, stream, a.tarena_stride * batch * sizeof(u64), &a.tarena);
+            if (!a.tag) return fail(ctx, CFX_ERR_LAUNCH, "2-bit layer launch: cannot allocate the partials' arena");
+            for (int g_ = 0; g_ < n_gated; ++g_) {
+                a.src[g_] = -1;
+                for (int i = 0; i < batch; ++i)
+                    if (gd.it[g_].packet == items[i].packet) a.src[g_] = (signed char)i;
+            }
             if (xg) {
                 a.xgate = a.gate1 + 2 * GATE_BLOCK;
                 a.xexpect = ++ctx->gate_expect[3 * slot + 2];
@@ -3251,6 +3602,16 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                 a.gate = ctx->gate + (size_t)slot * GATE_STRIDE;
                 ctx->gate_expect[3 * slot] += (unsigned)batch * (unsigned)(CB + 1);
                 a.gate_expect = ctx->gate_expect[3 * slot];
+                a.tarena_stride = tag_arena_words(N, C, CB, P);
+                a.tag = abs_arena_for(ctx, slot / TICK_RING, stream, a.tarena_stride * batch * sizeof(u64), &a.tarena);
+                if (!a.tag) return fail(ctx, CFX_ERR_LAUNCH, "1-bit layer launch: cannot allocate the partials' arena");
+                // a gated item whose packet is one of this launch's own takes its scales from the tagged words (no gate, with live peers or
+                // without: the own error-feedback update never waits for a peer); anybody else's packet waits for the gate
+                for (int g_ = 0; g_ < n_gated_k; ++g_) {
+                    a.src[g_] = -1;
+                    for (int i = 0; i < batch; ++i)
+                        if (gd.it[g_].packet == items[i].packet) a.src[g_] = (signed char)i;
+                }
                 if (xg) {
                     a.xgate = a.gate + GATE_BLOCK;                    // the slot's second gate block (the 2-bit layer launch's gate 2)
                     a.xexpect = ++ctx->gate_expect[3 * slot + 1];
@@ -3262,6 +3623,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                 }
             }
             a.gate_err = ctx->gate_err;
+            a.timeout = ctx->gate_timeout;
             const dim3 g(a.n_st + a.n_g + CB * a.dq_rb * n_ride);
             if (one_launch_1bit && a.stamps && R % 32 == 0) {
                 LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_absmean_compress<true, 4, true, true>), g, dim3(FUSED_NT), 0, s, b, rd, gd, a);
@@ -3407,6 +3769,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             a.coop = (tall || PL > 32) ? 1 : 0;
             a.seq = ++ctx->mml_seq;
             a.err = ctx->gate_err;
+            a.timeout = ctx->gate_timeout;
             memcpy(a.src, src, sizeof(src));
             if (xg && n_gated) {
                 a.xgate = ctx->gate + (size_t)slot * GATE_STRIDE + GATE_BLOCK;
@@ -3459,6 +3822,30 @@ int cfx_gate_errors(cfx_ctx* ctx) {
     if (!ctx->gate_err) return 0;
     const unsigned v = __atomic_exchange_n(ctx->gate_err, 0u, __ATOMIC_RELAXED);      // pinned host memory: no device synchronisation
     return (int)v;
+}
+
+// After a wait gave up: the launch it belonged to left arrival counters short of what the host expects of the ring slot, ticket words
+// undrawn, possibly a low-rank hand-over arena mid-sum.  Drain the device, zero the counters and what the host expects of them, have the
+// low-rank arenas re-zeroed at their next use, clear the error word.  Sequence-tagged words (min/max and abs-mean partials, tile flags)
+// need nothing: their sequence numbers are never reused.  Returns the number of failed waits that were pending, or < 0.
+int cfx_gate_recover(cfx_ctx* ctx) {
+    if (!ctx) return CFX_ERR_NULL;
+    if (!ctx->tick) return 0;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != ctx->device && hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, CFX_ERR_LAUNCH, "gate_recover: hipSetDevice failed");
+    int rc = 0;
+    const size_t words = (size_t)((char*)ctx->colgate - (char*)ctx->tick) / sizeof(unsigned);      // ticket blocks + gate blocks
+    if (hipDeviceSynchronize() != hipSuccess || hipMemset(ctx->tick, 0, words * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        rc = fail(ctx, CFX_ERR_LAUNCH, "gate_recover: cannot reset the ticket / gate blocks");
+    } else {
+        memset(ctx->gate_expect, 0, sizeof(ctx->gate_expect));
+        for (int i = 0; i < ctx->lrs_n; ++i) ctx->lrs_key[i] = ~0ull;
+        rc = ctx->gate_err ? (int)__atomic_exchange_n(ctx->gate_err, 0u, __ATOMIC_RELAXED) : 0;
+    }
+    if (cur >= 0 && cur != ctx->device) (void)hipSetDevice(cur);
+    return rc;
 }
 
 int cfx_set_gate_timeout_ms(cfx_ctx* ctx, int ms) {

@@ -330,6 +330,9 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
 
     // Sum of the partials over the slabs into the N x r matrix (LDS, [rank][row] fp32): this workgroup's share of the cells over all
     // partials (fixed order), published; then everybody polls the whole result
+    // A wait that gives up (a.timeout ticks of the 100 MHz wall clock after its first failed poll) ends the chain for this workgroup: the
+    // phases that follow are skipped, nothing more is stored - no factors from sums that never completed, the state stays as it was.
+    bool failed = false;
     auto allreduce = [&](unsigned tag, bool with_gram) {
         const unsigned seq = tag & 3u;
         const int tcells = with_gram ? pcells : cells;                // with_gram: the r x r fp64 matrix behind the values is summed (in fp64) too -> Gd
@@ -357,10 +360,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
                         if (ok) break;
                         const long long now = wall_clock64();
                         if (!t0) t0 = now;
-                        else if (now - t0 > a.timeout) {
-                            if (a.err) (void)__hip_atomic_fetch_add(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            break;
-                        }
+                        else if (failed || now - t0 > a.timeout) { failed = true; break; }
                     }
 #pragma unroll
                     for (int j = 0; j < LRS_J; ++j)
@@ -412,10 +412,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
                 if (ok) break;
                 const long long now = wall_clock64();
                 if (!t0) t0 = now;
-                else if (now - t0 > a.timeout) {
-                    if (a.err) (void)__hip_atomic_fetch_add(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
+                else if (failed || now - t0 > a.timeout) { failed = true; break; }
             }
 #pragma unroll
             for (int j = 0; j < LRS_J; ++j) {
@@ -431,7 +428,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
                 }
             }
         }
-        __syncthreads();
+        failed = __syncthreads_or(failed ? 1 : 0) != 0;              // (uniform from here on)
     };
 
     // P = W^T W into Gd: fp64 from the fp32 values (exact products, fp64 sums).  The waves split K = N; a wave loads its rows of the
@@ -548,6 +545,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     LSTAMP(2);
     run_max = 0.f;
     allreduce(tag0, false);
+    if (!failed) {
     norm_scale(0);
     LSTAMP(3);
 
@@ -557,6 +555,8 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     LSTAMP(4);
     allreduce(tag0 + 1, true);                                        // W1 and M1
     LSTAMP(5);
+    }
+    if (!failed) {
     if (w == 0) lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_TOL, false);     // chol(M1)
     __syncthreads();
     LSTAMP(14);
@@ -570,6 +570,8 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     LSTAMP(7);
     allreduce(tag0 + 2, false);
     LSTAMP(8);
+    }
+    if (!failed) {
     // The N-space chain's T2 T3 (T2 = chol(Y1^T W2)^-T, T3 = chol(T2^T P T2)^-T, P = W2^T W2) is upper triangular and makes W2
     // orthonormal, so it IS the inverse Cholesky factor of P: one factorisation.  W2's columns are graded (norms ~ sigma^3), P's
     // pivots span ~ sigma^6 - Cholesky without pivoting does not mind (its error goes with the condition of the matrix scaled to unit
@@ -641,6 +643,8 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
         }
     }
     LSTAMP(11);
+    }
+    if (failed && tid == 0 && a.err) (void)__hip_atomic_fetch_add(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #undef LSTAMP
     // ---------------- leave: the last workgroup of the launch resets the ticket and moves the arena's launch count on ----------------
     __syncthreads();

@@ -24,6 +24,7 @@ from typing import Dict, Optional
 import torch
 
 from . import _lib
+from . import config as _settings
 from .codecs import context
 
 
@@ -73,7 +74,7 @@ def lane(device: Optional[int] = None) -> Lane:
         device = torch.cuda.current_device()
     ln = _lanes.get(device)
     if ln is None:
-        ln = _lanes[device] = Lane(device, int(os.environ.get("CFX_LANE_EXCHANGE_CUS", "32")))
+        ln = _lanes[device] = Lane(device, int(_settings.get("lane_exchange_cus")))
     return ln
 
 
@@ -90,3 +91,56 @@ def on_compute_stream(device: int) -> bool:
     """True when the CURRENT stream of `device` is the lane's compute stream (a lane exists and the caller opted in)."""
     ln = _lanes.get(device)
     return ln is not None and torch.cuda.current_stream(device).cuda_stream == ln.compute.cuda_stream
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# getting onto the lane without the caller's help (compactfusion_amd.configure(lane="auto" | "sticky" | "off"))
+# ---------------------------------------------------------------------------------------------------------------------------
+_handover: Dict[int, dict] = {}
+
+
+def _hand(device: int) -> dict:
+    h = _handover.get(device)
+    if h is None:
+        buf = torch.zeros(64, dtype=torch.int32, device=torch.device("cuda", device))      # two flag words, 128 bytes apart
+        torch.cuda.synchronize(device)                                                      # zeroed before a flag kernel of another stream reads them
+        h = _handover[device] = {"buf": buf, "fork": buf.data_ptr(), "join": buf.data_ptr() + 128, "epoch": 0,
+                                 "lib": _lib.load(), "ctx": context(device)}
+    return h
+
+
+def usable(device: int) -> bool:
+    """Can this process order streams by flag words at all (hardware queues: include/cfx.h cfx_hw_queues_ok)?"""
+    return bool(_lib.load().cfx_hw_queues_ok())
+
+
+def fork_to_compute(device: int):
+    """The caller's current stream hands over to the lane's compute stream: `flag set` behind everything the caller has enqueued, `flag
+    wait` in front of everything that follows on the compute stream - two one-wave kernels, ~3 us of hop (an event pair costs ~14) -
+    and the compute stream becomes the thread's current stream.  Returns the token `join_from_compute` takes, or None when the caller is
+    on the compute stream already.  Tensor lifetimes need no record_stream: every use on the compute stream lies between a fork and a
+    join (or, sticky, stays there), so whatever the caching allocator hands out again on either stream is ordered behind its last use."""
+    ln = lane(device)
+    cur = torch.cuda.current_stream(device)
+    if cur.cuda_stream == ln.compute.cuda_stream:
+        return None
+    h = _hand(device)
+    h["epoch"] += 1
+    e, lib, ctx = h["epoch"], h["lib"], h["ctx"]
+    if lib.cfx_flag_set(ctx, h["fork"], e, cur.cuda_stream) != 0 or lib.cfx_flag_wait(ctx, h["fork"], e, ln.compute.cuda_stream) != 0:
+        raise _lib.CfxError("exchange lane hand-over failed: " + (lib.cfx_last_error_string(ctx) or b"").decode())
+    torch.cuda.set_stream(ln.compute)
+    return (cur, e)
+
+
+def join_from_compute(device: int, token) -> None:
+    """The reverse hand-over: the caller's stream continues behind everything enqueued on the compute stream since the fork."""
+    if token is None:
+        return
+    cur, e = token
+    ln = lane(device)
+    h = _hand(device)
+    lib, ctx = h["lib"], h["ctx"]
+    if lib.cfx_flag_set(ctx, h["join"], e, ln.compute.cuda_stream) != 0 or lib.cfx_flag_wait(ctx, h["join"], e, cur.cuda_stream) != 0:
+        raise _lib.CfxError("exchange lane hand-over failed: " + (lib.cfx_last_error_string(ctx) or b"").decode())
+    torch.cuda.set_stream(cur)

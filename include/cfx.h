@@ -150,6 +150,15 @@ int cfx_compress_batch_gated(cfx_ctx* ctx, int codec, int N, int C, int param, i
  * synchronisation (a complete count needs the streams drained first).  While the count is non-zero every compress / plan / merge
  * call on the context returns CFX_ERR_GATE. */
 int cfx_gate_errors(cfx_ctx* ctx);
+/* Every in-launch wait (arrival gates, tagged-word and flag polls, the peer-to-peer exchange inside a layer launch, the low-rank
+ * hand-overs) gives up on ONE time base: the 100 MHz wall clock against the context's gate timeout (default 5 s,
+ * cfx_set_gate_timeout_ms), never on an iteration count.  A workgroup whose wait gave up does NOT store: reconstructions from packets
+ * that have not arrived are never written, the states the workgroup owns stay as they were, and the error word counts the failure.
+ * The launch it belonged to leaves the context's arrival counters short; cfx_gate_recover drains the device, resets them (and the
+ * low-rank hand-over arenas) and clears the error word, after which the context is usable again.  Returns the number of failed waits
+ * that were pending, or < 0.  What the caller does about the layer whose exchange failed (run it again over another transport, or drop
+ * the generation) is its business: compact/xlayer.py re-validates. */
+int cfx_gate_recover(cfx_ctx* ctx);
 
 /* The statistics pass of a compress call reduces its partial sums INSIDE the launch (last-arriving workgroups, ticket
  * counters; replaces the eager scale prologue of fastpath.py:150-166 / compress_quantize.py:452-463 and the separate

@@ -331,21 +331,36 @@ def w_stack(rank, world, codec_name):
     return res
 
 
-def w_xlayer(rank, world, codec_name, mode, poison, gens):
+def w_xlayer(rank, world, codec_name, mode, poison, gens, steps=4, ef=True, late=None, gate_timeout_ms=0):
     """The product path of the gather schedules - ONE native op per layer (compact/xlayer.py) - over `gens` generations with
     compact_reset in between: `mode` = "ring" (compact_fwd, gather schedule) or "gather" (compact_all_gather_kv, what patch_gather_fwd
     calls).  poison >= 0: rank 1 corrupts a peer's reconstruction right before its validated p2p execution `poison` - every rank must
-    fall back to the next transport together and the states must come out as if nothing had happened."""
+    fall back to the next transport together and the states must come out as if nothing had happened.  late = (step, seconds, layer):
+    rank 1 arrives that late at that layer of that step - rank 0's launch waits for it INSIDE the kernel (layer >= 1: the first layer op of
+    a step meets the group's health all-reduce, which absorbs a late rank on the host)."""
+    import time
     import compactfusion_amd.compact.main as cm
     from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig, PatchConfig, xlayer
     from compactfusion_amd.compact import ring as ring_mod
     from compactfusion_amd.compact.ring import compact_fwd
-    L, STEPS = 3, 4
+    L, STEPS = 3, steps
     B, S, Hh, Dh = (1, 16, 4, 32) if DEV == "cpu" else (1, 64, 8, 64)
+    os.environ["CFX_LANE"] = "off"                 # the one-op layer exchange on the caller's stream is what these runs are about
+    if gate_timeout_ms:
+        from compactfusion_amd import _lib, codecs
+        assert _lib.load().cfx_set_gate_timeout_ms(codecs.context(torch.cuda.current_device()), gate_timeout_ms) == 0
     if poison >= 0:
-        xlayer._TEST_POISON = (1, poison)
+        # test-side only: the checksum of the first peer tensor is taken over a corrupted copy of what the launch reconstructed
+        orig, done = xlayer.LayerOp._checksums, []
+
+        def poisoned(self, tensors):
+            if rank == 1 and not done and self.region is not None and self.region.validated == poison and tensors[0] is self.peers[0][1]:
+                tensors[0].view(torch.int16)[0, :8] += 1          # a stale line's worth of wrong bits in a peer's reconstruction
+                done.append(1)
+            return orig(self, tensors)
+        xlayer.LayerOp._checksums = poisoned
     fast = codec_name in ("BINARY", "INT2")
-    kw = dict(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T[codec_name], residual=1, ef=True, fastpath=fast,
+    kw = dict(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T[codec_name], residual=1, ef=ef, fastpath=fast and ef,
               comp_rank=-1, sparse_ratio=8)
     if mode == "gather":
         kw.update(override_with_patch_gather_fwd=True, patch_gather_fwd_config=PatchConfig(True, False, 1))
@@ -361,6 +376,9 @@ def w_xlayer(rank, world, codec_name, mode, poison, gens):
         for step in range(STEPS):
             cm.compact_set_step(step)
             for l in range(L):
+                if late is not None and rank == 1 and step == late[0] and l == (late[2] if len(late) > 2 else 0):
+                    torch.cuda.synchronize()
+                    time.sleep(late[1])
                 out, lse, _ = compact_fwd(TD(qs[l][step]), TD(ks[l][step]), TD(vs[l][step]), causal=False, group=None, mod_idx=l, current_iter=step)
                 assert out.shape == (B, S, Hh, Dh)
             if gens <= 2:

@@ -33,10 +33,12 @@ def _bench(*args):
 
 def test_bench_falls_back_when_the_collective_cannot_be_placed():
     """a collective kernel that needs an EMPTY CU (CFX_FAKE_RCCL_FAT=2) never runs beside the waiting layer launch: the validation step times
-    out (300 ms gates), every rank switches to two launches per layer, the line says so and the states are still consistent"""
+    out (300 ms gates), every rank switches to two launches per layer, the line says so and the states are still consistent.  (8 live
+    ranks: 14 peer tensors' reconstruction tiles wait on every CU; with 2 live ranks only the one peer's tiles wait - the own
+    error-feedback update takes its scales from the launch's tagged words since round 5 - and most CUs are empty)"""
     os.environ["CFX_FAKE_RCCL_FAT"] = "2"
     try:
-        d = _bench("--emulate-live", "2", "--rccl-lib", _fake(), "--no-cpu-baseline", "--no-raw-baseline", "--layers", "3")
+        d = _bench("--emulate-live", "8", "--rccl-lib", _fake(), "--no-cpu-baseline", "--no-raw-baseline", "--layers", "3")
     finally:
         os.environ.pop("CFX_FAKE_RCCL_FAT", None)
     assert d["launches_per_layer"] == 2 and "failed validation" in d["schedule_fallback"] and "gate" in d["schedule_fallback"]

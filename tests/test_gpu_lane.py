@@ -93,13 +93,24 @@ def _late(t):
 
 @pytest.mark.parametrize("masked,ef,xmode,late", [(False, True, "lane", False), (True, True, "lane", False), (True, False, "lane", False),
                                                   (False, False, "lane", False), (False, False, "chain", False), (False, True, "chain", False),
-                                                  (False, True, "lane", True), (True, True, "lane", True)])
+                                                  (False, True, "lane", True), (True, True, "lane", True),
+                                                  ("auto", True, "auto", True), ("auto", False, "auto", False), ("auto-side", True, "auto", True),
+                                                  ("sticky", True, "auto", True)])
 def test_lane_ring_forward_vs_oracle(loopback, monkeypatch, masked, ef, xmode, late):
+    """masked False / True: the caller on an ordinary stream with the lane switched off (flags on unmasked streams) / on the lane's compute
+    stream.  "auto" / "auto-side" / "sticky": the DEFAULT settings, caller on the default stream / a side stream - compact_fwd puts itself on
+    the lane (forked from and joined to the caller's stream by flag kernels, or - sticky - the compute stream becomes the current one)."""
     ring, cm = loopback
     from compactfusion_amd import lanes
     from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
     from compactfusion_amd.compact.attention import block_attention
-    monkeypatch.setenv("CFX_RING_EXCHANGE_STREAM", xmode)
+    auto = isinstance(masked, str)
+    if auto:
+        monkeypatch.delenv("CFX_RING_EXCHANGE_STREAM", raising=False)
+        monkeypatch.setenv("CFX_LANE", "sticky" if masked == "sticky" else "auto")
+    else:
+        monkeypatch.setenv("CFX_RING_EXCHANGE_STREAM", xmode)
+        monkeypatch.setenv("CFX_LANE", "off")
     L, STEPS = 3, 5
     shape = (1, 64, 8, 64)
     N, C = 64, 512
@@ -109,7 +120,10 @@ def test_lane_ring_forward_vs_oracle(loopback, monkeypatch, masked, ef, xmode, l
     ks = [_drift(17 + l, shape, STEPS) for l in range(L)]
     vs = [_drift(27 + l, shape, STEPS) for l in range(L)]
     dev = torch.device("cuda:0")
-    stream = lanes.compute_stream(0) if masked else torch.cuda.current_stream(dev)
+    if auto:
+        stream = torch.cuda.Stream(dev) if masked == "auto-side" else torch.cuda.default_stream(dev)
+    else:
+        stream = lanes.compute_stream(0) if masked else torch.cuda.current_stream(dev)
     # oracle replay per (layer, K|V): own[s] = the sender's state after step s, peer[s] = what every receiver holds after step s
     own_w, peer_w = {}, {}
     for l in range(L):
@@ -134,6 +148,11 @@ def test_lane_ring_forward_vs_oracle(loopback, monkeypatch, masked, ef, xmode, l
             for l in range(L):
                 kin, vin = (_late(dk[l][s]), _late(dv[l][s])) if late else (dk[l][s], dv[l][s])     # late: K,V produced right in front of the call
                 out, lse, _ = ring.compact_fwd(dq[l][s], kin, vin, causal=False, mod_idx=l, current_iter=s)
+                if auto and masked != "sticky":
+                    assert torch.cuda.current_stream(dev).cuda_stream == stream.cuda_stream, "the caller's stream is the current stream again"
+                elif auto:
+                    assert torch.cuda.current_stream(dev).cuda_stream == lanes.compute_stream(0).cuda_stream, "sticky: the compute stream stays current"
+                out = out * 1.0                        # consumed right away on whatever stream the caller now has: the join must order it
                 outs[(s, l)] = (out, lse)
             torch.cuda.synchronize()
             cache = cm.compact_cache()
@@ -153,10 +172,10 @@ def test_lane_ring_forward_vs_oracle(loopback, monkeypatch, masked, ef, xmode, l
                 torch.testing.assert_close(lse.float(), ref_l.float(), rtol=1e-3, atol=1e-3)
     exs = [e for e in ring._xbuf.values() if e.sig is not None]
     assert exs and all(e.plan is not None for e in exs), "the native per-layer plan was not used"
-    assert all(e.lane == (xmode == "lane") for e in exs)
+    assert all(e.lane == (xmode in ("lane", "auto")) for e in exs)
     assert len(ring._steady) == L, "the steady-state lane never engaged"
     from compactfusion_amd import _lib, codecs as K
-    if xmode == "lane":
+    if xmode in ("lane", "auto"):
         assert _lib.load().cfx_plan_epoch(exs[0].plan) == STEPS - 1            # exactly one epoch per compressed step since the plan was bound (the general path advances it too)
     assert _lib.load().cfx_gate_errors(K.context(0)) == 0
 

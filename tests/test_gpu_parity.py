@@ -741,14 +741,47 @@ def test_gated_item_with_a_packet_from_an_earlier_launch():
 
 
 @pytest.mark.parametrize("name,cid", [("binary", 1), ("int2", 2)])
-@pytest.mark.parametrize("shape,drift", [((544, 3072), 50.0), ((130, 1024), 400.0), ((544, 3072), 1.5)])
+@pytest.mark.parametrize("shape,drift", [((544, 3072), 50.0), ((130, 1024), 400.0), ((544, 3072), 1.5), ((544, 3072), 3000.0)])
 def test_statistics_partials_beyond_32_bits(name, cid, shape, drift):
-    """The fused paths hand their partial sums from workgroup to workgroup as 32-bit words with a sentinel + 64-bit side channel for
-    sums that do not fit: residuals large enough that every row partial, every column partial (drift 50, 400) or only the row
-    partials (drift 1.5: 512 channels x 1.2 > 256) take the side channel still match the oracle bit for bit."""
+    """The fused paths hand their partial sums from workgroup to workgroup in words narrower than the sums can get, with a sentinel + a
+    64-bit side channel for sums that do not fit: 32-bit words in the stand-alone launches (every row and column partial at drift 50
+    and 400, only the row partials at drift 1.5: 512 channels x 1.2 > 256), 40-bit tagged words in the layer launches (a tile's sum of
+    |d| beyond 65536: the row partials at drift 400, the column partials too at drift 3000).  All still match the oracle bit for bit."""
     N, C = shape
     x, base = make_inputs(900 + int(drift), N, C, drift=drift)
     run_case(name, cid, 0, x, base, N, C)
+
+
+@pytest.mark.parametrize("name,cid", [("binary", 1), ("int2", 2)])
+@pytest.mark.parametrize("drift", [1.5, 400.0, 3000.0])
+def test_layer_launch_partials_beyond_the_tagged_words(name, cid, drift):
+    """cfx_compress_batch_gated at the FLUX shard with residuals of order 1 (round 4: the 32-bit row partials overflowed at an average |d|
+    of 0.5 and the launch took a second round trip) and far beyond (the 40-bit tagged words' own side channel: row partials at drift 400,
+    column partials at drift 3000): packets, sender states and looped-back peer states == the oracle, bit for bit, two launches in a row
+    (the second meets the first one's tags in the arena)."""
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    N, C, B, NP = 544, 3072, 2, 6
+    ctx = K.context(0)
+    sh = torch.cuda.current_stream().cuda_stream
+    ws = K.workspace(cid, N, C, 0, B, 0)
+    for rep in range(2):
+        xs = [make_inputs(4000 + 10 * rep + i + int(drift), N, C, drift=drift) for i in range(B)]
+        xd = [dev(x) for x, _ in xs]
+        own = [dev(b) for _, b in xs]
+        peer = [dev(xs[g % B][1]) for g in range(NP)]
+        pk = [torch.zeros(K.packet_halves(cid, N, C), dtype=torch.float16, device="cuda") for _ in range(B)]
+        comp = (_lib.CompItem * B)(*[_lib.CompItem(xd[i].data_ptr(), own[i].data_ptr(), own[i].data_ptr(), pk[i].data_ptr()) for i in range(B)])
+        gated = (_lib.DecompItem * NP)(*[_lib.DecompItem(pk[g % B].data_ptr(), peer[g].data_ptr(), peer[g].data_ptr()) for g in range(NP)])
+        assert lib.cfx_compress_batch_gated(ctx, cid, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, comp, 0, None, NP, gated, ws.data_ptr(), ws.numel(), sh) == 0
+        torch.cuda.synchronize()
+        assert lib.cfx_gate_errors(ctx) == 0
+        for i in range(B):
+            pkt_ref, nb_ref = R.residual_compress(name, xs[i][0], xs[i][1], 0)
+            same_bits(host_bits(pk[i]), pkt_ref, f"{name} packet {i} (drift {drift})")
+            same_bits(host_bits(own[i]), R.bits(nb_ref), f"{name} sender state {i}")
+            for g in range(i, NP, B):
+                same_bits(host_bits(peer[g]), R.bits(nb_ref), f"{name} peer state {g}")
 
 
 def test_gated_launches_on_two_streams_at_once():

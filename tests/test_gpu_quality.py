@@ -37,11 +37,22 @@ def _inputs(T):
     return ks[:T], vs[:T], q
 
 
-# LOW_RANK_Q re-quantises the factors to int4 (16 levels over the column range): a last-bit difference in a factor entry -
-# Cholesky-QR here, Householder QR in the reference, both fp32 - flips whole quantisation levels, and error feedback carries
-# the flip forward.  The curve is matched to 1e-2 there (the reference's own eager and compiled int4 paths differ by 0.6 % of the
-# elements); every other preset to the north-star 1e-3.
-TOL = {"lrq32": (1e-2, 0.25)}        # 0.25 dB = 3 % in attention-output error, the same order as the 1e-2 above squared up by softmax
+# LOW_RANK_Q re-quantises the factors to int4 (16 levels over the column range): a last-bit difference in a factor entry flips whole
+# quantisation levels, and error feedback carries the flip forward.  The reference itself does not reproduce this trace more closely
+# than that: its two execution modes - eager, in which the goldens were captured, and @torch.compile, which it runs on its own hardware
+# (compress_lowrank.py:14, compress_quantize.py:522-640) - differ on this very trace by up to 5.8e-3 relative in the reconstruction error
+# and 0.26 dB in attention-output PSNR (tests/golden/measure_lrq_spread.py -> g12_lrq32_modes.json, measured by importing the reference).
+# The HIP path (Cholesky-QR in fp64 where the reference runs Householder QR in fp32) is held to the eager golden within THAT band - the
+# reference's own reproducibility - and every other preset to the north-star 1e-3.
+def _lrq_band():
+    with open(os.path.join(HERE, "golden", "g12_lrq32_modes.json")) as f:
+        m = json.load(f)
+    assert m["eager_equals_the_committed_golden"]
+    return m["max_rel_err_difference_relative"], m["max_psnr_difference_db"]
+
+
+TOL = {"lrq32": _lrq_band()}
+GAPS = {}
 
 
 def _check(name, rows, want):
@@ -49,6 +60,12 @@ def _check(name, rows, want):
     tol_rel, tol_db = TOL.get(name, (1e-3, 0.02))
     assert rows.shape == want.shape
     assert np.all(rows[0, :2] == 0) and rows[0, 2] > 200            # WARMUP step is exact
+    gaps = [float((np.abs(rows[1:, c] - want[1:, c]) / want[1:, c]).max()) for c in (0, 1)] + [float(np.abs(rows[1:, 2] - want[1:, 2]).max())]
+    GAPS[name] = {"rel_err_k": gaps[0], "rel_err_v": gaps[1], "psnr_db": gaps[2], "band": [tol_rel, tol_db]}
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "quality_gaps.json"), "w") as f:
+            json.dump(GAPS, f, indent=1)
     for col, what in ((0, "relative error of K"), (1, "relative error of V")):
         rel = np.abs(rows[1:, col] - want[1:, col]) / want[1:, col]
         assert rel.max() < tol_rel, f"{name}: {what} departs from the reference trace by {rel.max():.2e} (step {1 + int(rel.argmax())})"

@@ -37,3 +37,13 @@ def test_layer_kernels_keep_two_workgroups_a_cu(rows):
     for k in rows:
         if any(n in k["demangled"] for n in ("k_absmean_compress", "k_int2_compress_gated", "k_minmax_layer")):
             assert k["vgpr"] + k.get("agpr", 0) <= 128 and k["lds"] <= 80 * 1024, k
+
+
+def test_one_bit_layer_kernel_leaves_room_for_a_collective_kernel(rows):
+    # the collective form of the exchange layer needs RCCL's kernel (256 threads x 280 VGPRs) placed BESIDE a waiting reconstruction
+    # workgroup: two waves a SIMD of at most 104 registers leave 512 - 208 = 304 (include/cfx.h, cfx_plan_add_exchange_layer;
+    # tests/test_gpu_bench.py::test_bench_with_a_collective_kernel_of_rccl_footprint is the run-time check)
+    ks = [k for k in rows if k["demangled"].startswith("k_absmean_compress<true, 4, true")]
+    assert ks
+    for k in ks:
+        assert k["vgpr"] <= 104 or k["demangled"].endswith("true>"), k      # (the <.., true> instantiation carries the developer stamps)

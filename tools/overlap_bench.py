@@ -5,10 +5,14 @@ logical ranks are looped back: every peer's packet is this rank's own packet (te
 RCCL - same stream-ordered all-gather, device copies instead of xGMI; with real peers the collective's wire time adds to what
 must hide under the local attention block).  Legs, all on the same inputs:
   attention      the 8 attention blocks + merges of every layer on resident K,V (no exchange at all)
-  lane           compact_fwd on the EXCHANGE LANE (the default): the model on the lane's CU-masked compute stream (224 CUs), the layer's
+  default        what compact_fwd does with NO user opt-in (round 5): called on an ordinary stream, it puts itself on the exchange lane for the
+                 duration of the call - flag-kernel fork to the lane's compute stream, the lane leg's schedule, flag-kernel join back
+                 (compactfusion_amd.configure(lane="auto"), compactfusion_amd/lanes.py)
+  sticky         configure(lane="sticky"): the first call makes the lane's compute stream the caller's current stream and leaves it there
+  lane           compact_fwd on the EXCHANGE LANE, the caller already on it: the model on the lane's CU-masked compute stream (224 CUs), the layer's
                  whole chain - compress, all-gather, per-peer reconstruction - on the CU-masked exchange stream (32 CUs), ordered only
                  by flags in device memory (cfx_plan_run_lane + cfx_attn_merge_wait: one host call per layer for the exchange)
-  layer_op       the default off the lane (round 4): the layer's exchange as ONE native op (compact/xlayer.py: one codec launch gated on the
+  layer_op       configure(lane="off") (round 4's default): the layer's exchange as ONE native op (compact/xlayer.py: one codec launch gated on the
                  packets' arrival) on the model's own stream, in front of the local attention block - nothing overlaps, one launch per layer
   lane_unmasked  the same flags, but the model on an ordinary stream and the chain on an unmasked exchange stream
   native         round 2's schedule: the chain on the exchange stream, forked and joined with EVENTS (cfx_plan_run_async + cfx_plan_join)
@@ -125,9 +129,10 @@ def fwd(i):
         ring.compact_fwd(qs[l], ks[i & 1][l], vs[i & 1][l], causal=False, mod_idx=l, current_iter=i)
 
 
-def init(mode, xstream="chain"):
+def init(mode, xstream="chain", lane_mode="off"):
     os.environ["CFX_RING_EXCHANGE"] = mode
     os.environ["CFX_RING_EXCHANGE_STREAM"] = xstream
+    os.environ["CFX_LANE"] = lane_mode
     exchange.set_comm_factory(LoopComm if mode != "torch" else None)
     ring._xbuf.clear()
     ring._steady.clear()
@@ -156,7 +161,7 @@ def timed(fn, first):
 
 from compactfusion_amd import lanes
 comp_stream = lanes.compute_stream(0)
-ALL = ["attention_on_compute_lane", "lane", "attention_distinct_kv_on_compute_lane", "attention", "layer_op", "lane_unmasked", "native", "native_gather_only_on_side", "torchdist"]
+ALL = ["attention_on_compute_lane", "default", "sticky", "lane", "attention_distinct_kv_on_compute_lane", "attention", "layer_op", "lane_unmasked", "native", "native_gather_only_on_side", "torchdist"]
 legs = [x for x in (args.legs.split(",") if args.legs else ALL) if x]
 assert all(x in ALL for x in legs), f"legs must be among {ALL}"
 if args.quick:
@@ -168,6 +173,12 @@ for leg in legs:
         with torch.cuda.stream(comp_stream):
             attention_only(0); torch.cuda.synchronize()
             res[leg] = timed(attention_only, 0)
+    elif leg in ("default", "sticky"):
+        # the caller on an ORDINARY stream, every switch at its default
+        with torch.cuda.stream(torch.cuda.Stream(dev)):
+            init("native", "auto", "auto" if leg == "default" else "sticky")
+            assert all(ex.plan is not None and ex.lane for ex in ring._xbuf.values() if ex.sig is not None), "the default path did not take the lane"
+            res[leg] = timed(fwd, 3)
     elif leg == "lane":
         with torch.cuda.stream(comp_stream):
             init("native", "lane")
@@ -237,7 +248,7 @@ if not args.legs:
 att = res["attention"][0] if "attention" in res else None
 att_lane = res["attention_on_compute_lane"][0] if "attention_on_compute_lane" in res else None
 att_dist = res["attention_distinct_kv_on_compute_lane"][0] if "attention_distinct_kv_on_compute_lane" in res else None
-base_of = lambda k: att_lane if k == "lane" else att                      # noqa: E731   each leg against attention on ITS compute stream
+base_of = lambda k: att_lane if k in ("lane", "default", "sticky") else att       # noqa: E731   each leg against attention on ITS compute stream
 out = {
     "protocol": "SURVEY.md 8d(2): compact_fwd (gather schedule) with PyTorch-ROCm SDPA, one MI355X, 8 logical ranks looped back",
     "shape": {"q_k_v": [1, N, H, D], "layers": L, "ring": W, "codec": "BINARY 1-bit residual + EF"},
