@@ -1019,8 +1019,16 @@ def main():
         # exchange shares its step with the codec launches, so its figure is a lower bound of the link rate while a collective is in flight.
         def xg(wire, ms_, pattern):
             links = 1 if pattern == "relay" else min(live - 1, 7)
-            return None if ms_ is None else {"ms_per_step": round(ms_, 4), "achieved": round(wire / (ms_ * 1e-3) / 1e9, 2), "peak": 153.0 * links,
-                                             "unit": "GB/s", "frac": round(wire / (ms_ * 1e-3) / 1e9 / (153.0 * links), 4), "links": links}
+            if ms_ is None:
+                return None
+            o = {"ms_per_step": round(ms_, 4), "achieved": round(wire / (ms_ * 1e-3) / 1e9, 2), "peak": 153.0 * links, "unit": "GB/s", "links": links}
+            # a fraction of a LINK roofline only where links carried the bytes: over the loop-back library the "wire" is a device copy, its
+            # rate says nothing about xGMI and may exceed the link peak - no `frac` key there
+            if args.emulate_live:
+                o["loopback_device_copy"] = True
+            else:
+                o["frac"] = round(wire / (ms_ * 1e-3) / 1e9 / (153.0 * links), 4)
+            return o
         wire = (live - 1) * 2 * L * pkt_bytes
         wire_raw = (live - 1) * 2 * L * N * C * 2
         this_p, other_p = ("relay", "allgather") if relay else ("allgather", "relay")
@@ -1102,32 +1110,40 @@ def main():
                 "achieved": round(alga / (usa * 1e-6) / 1e9, 1), "frac": round(alga / (usa * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "latency-bound: a global reduction (scales) sits between reading K,V and the packet being complete"}
         # PMC traffic / rocprof cross-reference: only when the committed profile was taken with THIS configuration
-        prof = os.path.join(REPO, "profiles", "r04_pmc_traffic.json")
+        # ... AND from this tree's kernel sources (tools/provenance.py): a stale profile is not quoted
+        prof = os.path.join(REPO, "profiles", "r05_pmc_traffic.json")
         cfg_key = config_key(args, live)
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        from provenance import source_sha
+        src_sha = source_sha()
         if os.path.exists(prof):
             try:
                 pj = json.load(open(prof))
-                if pj.get("config") == cfg_key:
+                if pj.get("config") == cfg_key and pj.get("source_sha") != src_sha:
+                    out["roofline"]["traffic_source"] = "profiles/r05_pmc_traffic.json was taken from other kernel sources (source_sha differs): not quoted"
+                if pj.get("config") == cfg_key and pj.get("source_sha") == src_sha:
                     pk_ = "k_binary_pipe<true>" if pipelined else (("k_int2_compress_gated" if int2 else "k_absmean_compress<true, 4, true") if one_launch else "k_binary_dequant")
                     out["roofline"]["traffic"] = next((v for k_, v in pj["bytes_per_launch"].items() if k_.startswith(pk_)), None)
-                    out["roofline"]["traffic_source"] = ("profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes" +
+                    out["roofline"]["traffic_source"] = ("profiles/r05_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes" +
                                                          ("; " + pj["measured_with"] + ")" if pj.get("measured_with") else " of this command)"))
                     if pj.get("measured_with"):
                         out["roofline"]["step"]["traffic_source"] = "the same counter passes (loop-back form of the step: no flag kernels, no collective call)"
                     out["roofline"]["step"]["traffic"] = pj.get("bytes_per_step")
             except Exception:
                 pass
-        trace_json = os.path.join(REPO, "profiles", "r04_bench_kernel_durations.json")
+        trace_json = os.path.join(REPO, "profiles", "r05_bench_kernel_durations.json")
         if os.path.exists(trace_json):
             try:
                 tj = json.load(open(trace_json))
-                if tj.get("config") == cfg_key:
+                if tj.get("config") == cfg_key and tj.get("source_sha") != src_sha:
+                    out["roofline"]["rocprof_source"] = "profiles/r05_bench_kernel_durations.json was taken from other kernel sources (source_sha differs): not quoted"
+                if tj.get("config") == cfg_key and tj.get("source_sha") == src_sha:
                     pk_ = "k_binary_pipe<true>" if pipelined else (("k_int2_compress_gated" if int2 else "k_absmean_compress<true, 4, true") if one_launch else "k_binary_dequant")
                     ent = next((v for k_, v in tj["kernels"].items() if k_.startswith(pk_)), None)
                     if ent:
                         out["roofline"]["avg_launch_us_rocprof"] = ent["avg_us"]
                         out["roofline"]["median_launch_us_rocprof"] = ent.get("median_us")
-                        out["roofline"]["rocprof_source"] = "profiles/r04_bench_kernel_durations.json (rocprofv3 --kernel-trace of this command)"
+                        out["roofline"]["rocprof_source"] = "profiles/r05_bench_kernel_durations.json (rocprofv3 --kernel-trace of this command)"
             except Exception:
                 pass
     else:

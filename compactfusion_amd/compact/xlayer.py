@@ -487,14 +487,14 @@ class LayerOp:
         hold - there is no authoritative copy to fetch, the restored states are all there is.)"""
         if self.own_update != "ef":
             return
-        n = snap[0].numel()
-        own = torch.cat([snap[0].reshape(-1), snap[1].reshape(-1)]).view(torch.int16)       # (int16: a dtype every backend moves)
-        every = torch.empty(self.world * 2 * n, dtype=torch.int16, device=own.device)
+        n = snap[0].numel() // 2                                                              # fp16 pairs as int32: a dtype every backend moves
+        own = torch.cat([snap[0].reshape(-1).view(torch.int32), snap[1].reshape(-1).view(torch.int32)])
+        every = torch.empty(self.world * 2 * n, dtype=torch.int32, device=own.device)
         dist.all_gather_into_tensor(every, own, group=self.group)
         every = every.view(self.world, 2, n)
         for r, ks, vs in self.peers:
-            ks.view(torch.int16).reshape(-1).copy_(every[r, 0])
-            vs.view(torch.int16).reshape(-1).copy_(every[r, 1])
+            ks.view(torch.int32).reshape(-1).copy_(every[r, 0])
+            vs.view(torch.int32).reshape(-1).copy_(every[r, 1])
 
     def _run_validated(self, k, v, sh) -> None:
         """A validated p2p execution of this layer: run it, then check that no gate timed out and that what this rank reconstructed for

@@ -704,6 +704,23 @@ __device__ __forceinline__ h16x8 ld8_wt(const u16* p) {
 // s16[0 .. 512) channel scales, s16[512 + i] token scale of row r0 + i.  Who sees a column block's channel scales tagged knows the
 // sign bits / codes prerequisites of that block are in memory too: the V job read every tile's column partials, and a tile stores
 // those only after its own packet stores have drained.  Returns false when the wait gave up (the caller stores nothing).
+// WATCH: two lanes poll one word each - a channel word of this workgroup's column block and a token word of its rows (other workgroups
+// watch other lines) - until they carry the tag; only then does everybody load.  Who has seen the channel word tagged may read the
+// block's sign bits / nothing else is needed for them (see above): the caller issues those loads BEFORE scales_from_tagged<.., false>,
+// one round trip for both.  Hundreds of workgroups polling ALL their words from the moment their state tile has landed measured 9 %
+// slower than the arrival gate they replaced (1.56 vs 1.43 ms per step): the polls load the fabric the statistics chain needs.
+__device__ __forceinline__ void scales_watch(const TagArena& ta, int N, int C, int c0, int r0, long long timeout) {
+    const int tid = threadIdx.x;
+    if (tid < 2) {
+        const u64* w = tid ? ta.tU + min(r0, N - 1) : ta.tV + min(c0 + ((r0 >> 1) & (TILE_C - 1)), C - 1);
+        SpinClock clk;
+        while (!tag_is(ld_wt(w), ta.tagbits)) {
+            __builtin_amdgcn_s_sleep(4);
+            if (clk.expired(timeout)) break;              // (scales_from_tagged then gives up for everybody)
+        }
+    }
+    lds_barrier();
+}
 template <int ROWS, bool WATCH = true>
 __device__ __forceinline__ bool scales_from_tagged(const TagArena& ta, int N, int C, int c0, int r0, u16* s16, long long timeout, unsigned* err) {
     // every thread polls ONE channel word (512 threads = the column block) and, the first ROWS of them, one token word: two registers a
@@ -717,16 +734,7 @@ __device__ __forceinline__ bool scales_from_tagged(const TagArena& ta, int N, in
     // lines) - until they carry the tag; only then does everybody load.  Hundreds of workgroups polling all their words from the moment
     // their state tile has landed measured 9 % slower than the arrival gate they replaced (1.56 vs 1.43 ms per step): the polls load the
     // fabric the statistics chain needs.
-    if (WATCH) {
-        if (tid < 2) {
-            const u64* w = tid ? pu : ta.tV + min(c0 + ((r0 >> 1) & (TILE_C - 1)), C - 1);
-            while (!tag_is(ld_wt(w), ta.tagbits)) {
-                __builtin_amdgcn_s_sleep(4);
-                if (clk.expired(timeout)) break;              // (the loop below gives up for everybody)
-            }
-        }
-        lds_barrier();
-    }
+    if (WATCH) scales_watch(ta, N, C, c0, r0, timeout);
     for (;;) {
         const u64 v = ld_wt(pv);
         const u64 u = tid < ROWS ? ld_wt(pu) : ta.tagbits;
@@ -742,6 +750,13 @@ __device__ __forceinline__ bool scales_from_tagged(const TagArena& ta, int N, in
     }
 }
 
+// The 1-bit launch's reconstruction tiles could take their scales from the tagged copies as well (own packets: no gate, no relay).
+// Measured, twice, against the arrival gate on one box: 1.59 vs 1.43-1.45 ms per step - 480 workgroups each polling two fabric words lose
+// more than the gate's drain + atomic + relay hop cost (the relays poll through the fabric, everybody else an XCD-local word in L2).  The
+// path stays compiled out; the 2-bit launch, whose tiles wait for 4-6 tile flags instead of the slowest of 204 arrivals, keeps it.
+#ifndef ONEBIT_D_TAGGED
+#define ONEBIT_D_TAGGED 0
+#endif
 template <int NW, int KR, int KL, bool ST>
 __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item& it, int N, int C, int R, int tile_x, int tile_y,
                                                          unsigned* gate, unsigned expect, unsigned* err, long long timeout, u32x4* lds,
@@ -780,13 +795,14 @@ __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item&
     u16 ul;
     unsigned by[K];
     if (tagged) {
-        // the packet is one of THIS launch's: its scales come as tagged words (no gate); then the sign bits
-        if (!scales_from_tagged<NW * K>(ta, N, C, tile_x * TILE_C, t.r0, s16, timeout, err)) return;
+        // the packet is one of THIS launch's: its scales come as tagged words (no gate); the sign bits' loads go out with the scale words'
+        scales_watch(ta, N, C, tile_x * TILE_C, t.r0, timeout);
         if (ST && stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
-        v8 = __builtin_bit_cast(h16x8, *(const u16x8*)(s16 + 8 * t.lane));
-        ul = s16[TILE_C + min(t.w + NW * min(t.lane, K - 1), t.r1 - 1 - t.r0)];
 #pragma unroll
         for (int j = 0; j < K; ++j) by[j] = ld_wt(pk + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C8 + (cc >> 3));
+        if (!scales_from_tagged<NW * K, false>(ta, N, C, tile_x * TILE_C, t.r0, s16, timeout, err)) return;
+        v8 = __builtin_bit_cast(h16x8, *(const u16x8*)(s16 + 8 * t.lane));
+        ul = s16[TILE_C + min(t.w + NW * min(t.lane, K - 1), t.r1 - 1 - t.r0)];
     } else if (!gate_wait<true>(gate, expect, err, timeout)) return;
     else if (remote) {
         if (ST && stamps && threadIdx.x == 0) stamps[2] = wall_clock64();                                            // (uniform) the packet sits in a peer GPU's memory: system-scope loads
@@ -1136,11 +1152,19 @@ __device__ __forceinline__ void own_tile_finish(const cfx_comp_item& it, int N, 
     const bool upd = (flags & CFX_FLAG_UPDATE_CACHE) && nb;
     const bool ef = !(flags & CFX_FLAG_NO_EF);
     // the scales: the launch's tagged copies, polled (no gate 1: scales_from_tagged)
+    unsigned char* pk = (unsigned char*)it.packet;
+#ifdef INT2_S_GATE
+    if (!gate_wait<true>(gate1, expect1, err, timeout)) return;
+    const u16* TOK = (const u16*)(pk + (size_t)N * (C >> 2));
+    const u16* CH = TOK + N;
+    const h16x8 ch8 = ld8_wt(CH + min(t.c, C - 8));
+    const u16 ul = ld_wt(TOK + min(t.r0 + t.w + NW * min(t.lane, US - 1), t.r1 - 1));
+#else
     (void)gate1; (void)expect1;
     if (!scales_from_tagged<NW * US>(ta, N, C, bx * TILE_C, t.r0, s16, timeout, err)) return;   // (no codes, no arrival on gate 2: the reconstruction group gives up as well)
-    unsigned char* pk = (unsigned char*)it.packet;
     const h16x8 ch8 = __builtin_bit_cast(h16x8, *(const u16x8*)(s16 + 8 * t.lane));
     const u16 ul = s16[TILE_C + min(t.w + NW * min(t.lane, US - 1), t.r1 - 1 - t.r0)];
+#endif
     const bool has_base = it.base != nullptr;
     u16 codes[US];
 #pragma unroll
@@ -1416,12 +1440,7 @@ __global__ __launch_bounds__(FUSED_NT, GATE_WPE) void k_absmean_compress(BatchC 
                                                                 a.xgate ? a.xexpect : a.gate_expect, a.gate_err, a.timeout,
                                                                 nullptr,
                                                                 a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr, a.remote != 0 && sz < 0,
-#ifdef ONEBIT_D_GATE
-                                                                false,
-#else
-                                                                sz >= 0,
-#endif
-                                                                ta, (u16*)&sm[0][0]);
+                                                                ONEBIT_D_TAGGED && sz >= 0, ta, (u16*)&sm[0][0]);
                 }
                 return;
             }
@@ -1647,11 +1666,11 @@ __device__ __forceinline__ void int2_dequant_gated_body(const cfx_decomp_item& i
             }
         }
         if (__syncthreads_or(failed ? 1 : 0)) return;
-        if (!scales_from_tagged<NW * K>(ta, N, C, tile_x * TILE_C, t.r0, s16, timeout, err)) return;
-        ch8 = __builtin_bit_cast(h16x8, *(const u16x8*)(s16 + 8 * t.lane));
-        ul = s16[TILE_C + min(t.w + NW * min(t.lane, K - 1), t.r1 - 1 - t.r0)];
 #pragma unroll
         for (int j = 0; j < K; ++j) cd[j] = ld_wt((const u16*)(pk + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C4) + (cc >> 3));
+        if (!scales_from_tagged<NW * K, false>(ta, N, C, tile_x * TILE_C, t.r0, s16, timeout, err)) return;     // (one round trip with the codes')
+        ch8 = __builtin_bit_cast(h16x8, *(const u16x8*)(s16 + 8 * t.lane));
+        ul = s16[TILE_C + min(t.w + NW * min(t.lane, K - 1), t.r1 - 1 - t.r0)];
     } else if (!(xgate ? gate_wait<true>(xgate, xexpect, err, timeout) : gate_wait(gate, expect, err, timeout))) return;
     else if (remote) {                                            // (uniform) the packet sits in a peer GPU's memory: system-scope loads
         u16x8 vb;
@@ -1682,6 +1701,9 @@ __device__ __forceinline__ void int2_dequant_gated_body(const cfx_decomp_item& i
     }
 }
 
+#ifndef INT2_D_TAGGED
+#define INT2_D_TAGGED 1
+#endif
 struct Int2LayerArgs {
     int N, C, CB, R, P, n_st;           // group S: CB x P tiles of R rows per own tensor
     int g_R, g_rb, n_g;                 // group D
@@ -1723,7 +1745,7 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_int2_compress_gated(BatchC batc
     const TagArena ta = tag_arena_of(a.tarena, a.tarena_stride, sz >= 0 ? sz : 0, a.N, a.C, a.CB, a.P, a.tag);
     // (s16: behind the KL rows of state the workgroup parks in LDS)
     int2_dequant_gated_body<FUSED_NW, GATE_KR2, GATE_KL>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.gate2, a.expect2, a.err, a.timeout,
-                                                        (u32x4*)&sm[0][0], a.xgate, a.xexpect, a.remote != 0 && sz < 0, sz >= 0, ta, a.R,
+                                                        (u32x4*)&sm[0][0], a.xgate, a.xexpect, a.remote != 0 && sz < 0, INT2_D_TAGGED && sz >= 0, ta, a.R,
                                                         (u16*)&sm[GATE_LDS_ROWS][0]);
 }
 
@@ -2392,6 +2414,33 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_minmax_layer(BatchC batch, Batc
     __shared__ u64 sm[MML_NW][TILE_C];
     __shared__ u32x4 park[RW > 4 ? MML_PARK * FUSED_NT : 1];           // RW = 8: 32 KB more, still two workgroups a CU
     int b = blockIdx.x;
+    if (a.tall == 2) {
+        // Tall tensors (the S tiles do not fit the chip at once), group D waiting for the launch's OWN codes (no external gate: with one,
+        // D tiles parked on every slot would wait for a gate that only opens after S tiles that find no slot - the host keeps S first
+        // there): the launch is ordered COLUMN BLOCK by column block, and group D's tiles of a
+        // block follow the S tiles of the NEXT block -  S(0) S(1) D(0) S(2) D(1) ... S(CB-1) D(CB-2) D(CB-1)  - so that reconstruction tiles
+        // stream their state in while statistics tiles sit out their scales' hops, instead of the whole of D queueing behind the whole of S
+        // (round 4: S at 3 TB/s for 60 us, then D).  Every workgroup still waits only for workgroups EARLIER in dispatch order - a D tile for
+        // the S tiles of its own block, an S tile for its block's siblings, which nothing later than them holds up - so the launch drains.
+        const int nS = a.n_st / a.CB, nD = a.n_g / a.CB;              // workgroups of a column block: S (every own tensor's P tiles), D
+        bool is_s;
+        int cb, idx;
+        if (b < nS) { is_s = true; cb = 0; idx = b; }
+        else {
+            const int b1 = b - nS, per = nS + nD, p = b1 / per, r = b1 - p * per;
+            if (p < a.CB - 1) { is_s = r < nS; cb = is_s ? p + 1 : p; idx = is_s ? r : r - nS; }
+            else { is_s = false; cb = a.CB - 1; idx = b1 - (a.CB - 1) * per; }
+        }
+        if (is_s) {
+            const int z = idx / a.P, by = idx - z * a.P;
+            minmax_layer_s_tile<INT4, RW>(batch.it[z], a, z, cb, by, sm, park);
+            if (b == 0 && a.p2p.own) p2p_exchange_inline(a.codedone, a.seq, a.n_st, a.p2p, a.xgate, a.xexpect, a.err);
+        } else {
+            const int item = idx / a.g_rb, ty = idx - item * a.g_rb;
+            minmax_layer_d_tile<INT4>(gated.it[item], a, item, cb, ty);
+        }
+        return;
+    }
     if (b < a.n_st) {
         const int per = a.CB * a.P;
         const int z = b / per, rem = b - z * per;
@@ -3765,7 +3814,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             a.part = ctx->mml_arena[ring];
             a.stamps = (u64*)ctx->dbg_stamps;
             a.codedone = ctx->colgate + (size_t)ring * MML_MAX_TILES;
-            a.tall = tall ? 1 : 0;
+            a.tall = tall ? ((xg || !n_gated) ? 1 : 2) : 0;      // 2: group D interleaved with group S, column block by column block (k_minmax_layer)
             a.coop = (tall || PL > 32) ? 1 : 0;
             a.seq = ++ctx->mml_seq;
             a.err = ctx->gate_err;

@@ -92,7 +92,8 @@ def test_bench_n_gt_1_plumbing_over_the_loopback_library(live, pattern):
     assert x["pattern"] == pattern and x["links"] == (1 if pattern == "relay" else min(live - 1, 7))
     assert set(x["compressed"]) == {"allgather", "relay"} and set(x["raw"]) == {"allgather", "relay"}
     for leg in list(x["compressed"].values()) + list(x["raw"].values()):
-        assert leg["ms_per_step"] > 0 and leg["frac"] > 0 and leg["unit"] == "GB/s"
+        # loop-back device copies: a rate, no fraction of a LINK roofline (a device copy may exceed the link peak; VERDICT round 4, task 8)
+        assert leg["ms_per_step"] > 0 and leg["achieved"] > 0 and leg["unit"] == "GB/s" and "frac" not in leg and leg["loopback_device_copy"]
     assert x["wire_bytes_per_gpu_per_step"] == (live - 1) * 2 * 6 * d["config"]["packet_bytes"]
     assert x["raw_bytes_per_gpu_per_step"] == (live - 1) * 2 * 6 * d["config"]["raw_bytes"]
     assert "no Python-issued collective" in x["issued_by"]

@@ -72,6 +72,9 @@ def main():
     # what bench.py matches against: the configuration the counters were taken with, bytes per launch of every libcfx kernel
     # and the bytes one denoise step moves (all libcfx launches of the profiled run / steps profiled)
     res["config"] = cfg
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from provenance import source_sha
+    res["source_sha"] = source_sha()
     if note:
         res["measured_with"] = note
     res["bytes_per_launch"] = {k: int(v["hbm_bytes"]) for k, v in res["kernels"].items() if k.startswith("k_") and v["hbm_bytes"]}

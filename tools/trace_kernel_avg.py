@@ -16,7 +16,10 @@ def main():
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")          # template arguments kept: k_binary_pipe<true> = steady state
         grid = int(r.get("Grid_Size", 0) or 0) or (int(r.get("Grid_Size_X", 1)) * int(r.get("Grid_Size_Y", 1)) * int(r.get("Grid_Size_Z", 1)))
         by[name].append((grid, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
-    res = {"source": "rocprofv3 --kernel-trace", "unit": "us", "config": cfg, "kernels": {}}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from provenance import source_sha
+    res = {"source": "rocprofv3 --kernel-trace", "unit": "us", "config": cfg, "source_sha": source_sha(), "kernels": {}}
     for name, v in by.items():
         if not name.startswith("k_"):
             continue
