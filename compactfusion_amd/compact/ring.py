@@ -105,6 +105,18 @@ def _auto_lane(q, group) -> bool:
     return lanes.usable(q.device.index if q.device.index is not None else torch.cuda.current_device())
 
 
+def compact_update_awl_scale(q, k, v) -> None:
+    """ring.py:77-118 (deprecated upstream, only active with USE_AWL=1): key-token importance for LOW_RANK_AWL - tokens whose V row is
+    small get a larger weight (mean |v| over |v| per token) - handed to the simulate-mode codec (slowpath.set_current_lowrank_scale)."""
+    if os.getenv("USE_AWL", "0") != "1":
+        return
+    from .slowpath import set_current_lowrank_scale
+    with torch.no_grad():
+        bs, seq_len, head_cnt, head_size = q.shape
+        v_norm = torch.norm(v.reshape(bs * seq_len, head_cnt * head_size), dim=-1).flatten()
+        set_current_lowrank_scale((v_norm.mean() / v_norm).flatten(), None)
+
+
 def _joint_mode(joint_tensor_key, joint_tensor_value, joint_strategy) -> Optional[str]:
     if (joint_tensor_key is None) != (joint_tensor_value is None):
         raise ValueError("joint_tensor_key and joint_tensor_value should be None or not None simultaneously.")

@@ -66,6 +66,43 @@ def slowpath_decompress(x: torch.Tensor, shape: tuple, compress_type: T, rank: i
     return codecs.decompress(cid, x, None, N, C, param)
 
 
+# ---- LOW_RANK_AWL ("attention-aware" low rank; deprecated in the reference: simulate mode only, behind COMPACT_ALLOW_DEPRECATED) -------
+_current_lowrank_scale_k = None      # (C,) or (N,): per-channel or per-token importance, set by compact_update_awl_scale (ring.py)
+_current_lowrank_scale_v = None
+
+
+def set_current_lowrank_scale(scale_k, scale_v) -> None:
+    """slowpath.py:177-183"""
+    global _current_lowrank_scale_k, _current_lowrank_scale_v
+    _current_lowrank_scale_k, _current_lowrank_scale_v = scale_k, scale_v
+
+
+def _sim_lowrank_awl(x: torch.Tensor, rank: int):
+    """slowpath.py:217-237: rank-r approximation of the residual WEIGHTED by the current importance scale (rows or columns), the
+    weight divided out of the factors again.  The factorisation is the function-level subspace_iter (library GEMM / QR on whatever
+    device x is on): this type only exists in the reference's simulate mode, there is no wire format to be fast about."""
+    from .utils import ALLOW_DEPRECATED
+    from .lowrank import subspace_iter
+    from .main import compact_get_current_cache_key
+    assert rank is not None
+    assert ALLOW_DEPRECATED, "LOW_RANK_AWL is deprecated"
+    N, C = x.shape
+    is_k = compact_get_current_cache_key().split("-")[-1] == "k"
+    scale = _current_lowrank_scale_k if is_k else _current_lowrank_scale_v
+    by_col = scale is not None and tuple(scale.shape) == (C,)
+    by_row = scale is not None and tuple(scale.shape) == (N,)
+    if by_col:
+        x = x.float() * scale.view(1, C)
+    elif by_row:
+        x = x.float() * scale.view(N, 1)
+    u, v, _ = subspace_iter(x, rank, 2)
+    if by_col:
+        v = v / scale.view(1, C)
+    elif by_row:
+        u = u / scale.view(N, 1)
+    return torch.matmul(u, v)
+
+
 def sim_compress(x: torch.Tensor, compress_type: T, sparse_ratio: int = None, rank: int = None):
     """decode(encode(x)) at full size - the reference's `simulate=True` primitive."""
     if compress_type == T.IDENTITY:
@@ -74,6 +111,6 @@ def sim_compress(x: torch.Tensor, compress_type: T, sparse_ratio: int = None, ra
         from .compress_quantize import sim_int2_minmax
         return sim_int2_minmax(x)
     if compress_type == T.LOW_RANK_AWL:
-        raise NotImplementedError("LOW_RANK_AWL is deprecated in the reference")
+        return _sim_lowrank_awl(x, rank)
     pkt = slowpath_compress(x.half(), compress_type, rank=rank, sparse_ratio=sparse_ratio)
     return slowpath_decompress(pkt, tuple(x.shape), compress_type, rank=rank, sparse_ratio=sparse_ratio)

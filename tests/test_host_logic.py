@@ -350,3 +350,49 @@ def test_quantized_cache_int8_storage(cpu_kernels, monkeypatch):
         if step:
             assert pkt.numel() == 64 * 256 // 16 + 64 + 256
             assert float((rec.float() - xt.float()).norm() / xt.float().norm()) < 0.2
+
+
+def test_lowrank_awl_simulate_codec_matches_the_reference(monkeypatch):
+    """LOW_RANK_AWL (deprecated upstream; simulate mode only, slowpath.py:217-237 + ring.py:77-118): the importance-weighted rank-r
+    approximation against golden G14 captured from the reference (tests/golden/make_golden_awl.py) - same seeded start matrix, per-token
+    scale on a K key, per-channel scale on a V key, no scale; and the deprecation guard."""
+    import os
+    import numpy as np
+    import torch
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import slowpath as sp, utils
+    from compactfusion_amd.compact.utils import COMPACT_COMPRESS_TYPE as T
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g14_lowrank_awl.npz"))
+    x = torch.from_numpy(g["x"].copy()).view(torch.float16)
+    tok, chan = torch.from_numpy(g["tok"].copy()), torch.from_numpy(g["chan"].copy())
+    monkeypatch.setattr(utils, "ALLOW_DEPRECATED", False)
+    monkeypatch.setattr(cm, "_current_cache_key", "0-0-k")
+    with pytest.raises(AssertionError, match="deprecated"):
+        sp.sim_compress(x, T.LOW_RANK_AWL, rank=8)
+    monkeypatch.setattr(utils, "ALLOW_DEPRECATED", True)
+    for name, key, sk, sv in (("k_token_scale", "0-0-k", tok, None), ("v_channel_scale", "0-0-v", None, chan), ("k_no_scale", "0-0-k", None, None)):
+        monkeypatch.setattr(cm, "_current_cache_key", key)
+        sp.set_current_lowrank_scale(sk, sv)
+        torch.manual_seed(4321)
+        y = sp.sim_compress(x, T.LOW_RANK_AWL, rank=8).float().numpy()
+        want = g[name]
+        assert y.shape == want.shape
+        assert np.linalg.norm(y - want) / np.linalg.norm(want) < 1e-3, name
+    sp.set_current_lowrank_scale(None, None)
+
+
+def test_compact_update_awl_scale_sets_the_token_importance(monkeypatch):
+    """ring.py:77-103: only with USE_AWL=1; scale_k[token] = mean |v| / |v[token]|, scale_v stays unset."""
+    import torch
+    from compactfusion_amd.compact import ring, slowpath as sp
+    q = torch.randn(1, 12, 2, 8)
+    v = torch.randn(1, 12, 2, 8)
+    sp.set_current_lowrank_scale(None, None)
+    monkeypatch.delenv("USE_AWL", raising=False)
+    ring.compact_update_awl_scale(q, q, v)
+    assert sp._current_lowrank_scale_k is None
+    monkeypatch.setenv("USE_AWL", "1")
+    ring.compact_update_awl_scale(q, q, v)
+    n = v.reshape(12, 16).norm(dim=-1)
+    assert torch.allclose(sp._current_lowrank_scale_k, n.mean() / n) and sp._current_lowrank_scale_v is None
+    sp.set_current_lowrank_scale(None, None)
