@@ -2414,33 +2414,10 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_minmax_layer(BatchC batch, Batc
     __shared__ u64 sm[MML_NW][TILE_C];
     __shared__ u32x4 park[RW > 4 ? MML_PARK * FUSED_NT : 1];           // RW = 8: 32 KB more, still two workgroups a CU
     int b = blockIdx.x;
-    if (a.tall == 2) {
-        // Tall tensors (the S tiles do not fit the chip at once), group D waiting for the launch's OWN codes (no external gate: with one,
-        // D tiles parked on every slot would wait for a gate that only opens after S tiles that find no slot - the host keeps S first
-        // there): the launch is ordered COLUMN BLOCK by column block, and group D's tiles of a
-        // block follow the S tiles of the NEXT block -  S(0) S(1) D(0) S(2) D(1) ... S(CB-1) D(CB-2) D(CB-1)  - so that reconstruction tiles
-        // stream their state in while statistics tiles sit out their scales' hops, instead of the whole of D queueing behind the whole of S
-        // (round 4: S at 3 TB/s for 60 us, then D).  Every workgroup still waits only for workgroups EARLIER in dispatch order - a D tile for
-        // the S tiles of its own block, an S tile for its block's siblings, which nothing later than them holds up - so the launch drains.
-        const int nS = a.n_st / a.CB, nD = a.n_g / a.CB;              // workgroups of a column block: S (every own tensor's P tiles), D
-        bool is_s;
-        int cb, idx;
-        if (b < nS) { is_s = true; cb = 0; idx = b; }
-        else {
-            const int b1 = b - nS, per = nS + nD, p = b1 / per, r = b1 - p * per;
-            if (p < a.CB - 1) { is_s = r < nS; cb = is_s ? p + 1 : p; idx = is_s ? r : r - nS; }
-            else { is_s = false; cb = a.CB - 1; idx = b1 - (a.CB - 1) * per; }
-        }
-        if (is_s) {
-            const int z = idx / a.P, by = idx - z * a.P;
-            minmax_layer_s_tile<INT4, RW>(batch.it[z], a, z, cb, by, sm, park);
-            if (b == 0 && a.p2p.own) p2p_exchange_inline(a.codedone, a.seq, a.n_st, a.p2p, a.xgate, a.xexpect, a.err);
-        } else {
-            const int item = idx / a.g_rb, ty = idx - item * a.g_rb;
-            minmax_layer_d_tile<INT4>(gated.it[item], a, item, cb, ty);
-        }
-        return;
-    }
+    // (Tried in round 5 for tall tensors: S and D interleaved column block by column block - S(0) S(1) D(0) S(2) D(1) ... - so that
+    // reconstruction tiles stream their state in while statistics tiles sit out their scales' hops.  Config 4: 4.78 ms per step either
+    // way, the stamped launch 121 instead of 106 us - the D tiles take the slots the NEXT block's S tiles need; what bounds the S phase is
+    // a tile's lifetime in its slot, ~20 us of which ~8 move bytes.)
     if (b < a.n_st) {
         const int per = a.CB * a.P;
         const int z = b / per, rem = b - z * per;
@@ -3814,7 +3791,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             a.part = ctx->mml_arena[ring];
             a.stamps = (u64*)ctx->dbg_stamps;
             a.codedone = ctx->colgate + (size_t)ring * MML_MAX_TILES;
-            a.tall = tall ? ((xg || !n_gated) ? 1 : 2) : 0;      // 2: group D interleaved with group S, column block by column block (k_minmax_layer)
+            a.tall = tall ? 1 : 0;
             a.coop = (tall || PL > 32) ? 1 : 0;
             a.seq = ++ctx->mml_seq;
             a.err = ctx->gate_err;
