@@ -625,8 +625,10 @@ def compact_all_gather_kv(tag_k, tag_v, k: torch.Tensor, v: torch.Tensor, comp_t
     # steady state of the synchronous exchange: the layer is bound to ONE native op and nothing it was bound against has changed - straight to it
     if ex is not None and not displaced:
         st = ex.steady
-        if (st is not None and st[0] is comp_type and st[1] is cfg and k.shape == st[2] and v.shape == st[2] and _generation == st[3]
-                and _cache.version == st[4] and k.device == st[5] and not cfg.log_compress_stats and k.is_contiguous() and v.is_contiguous()):
+        # (identity of the config object AND the mutable fields the op was bound against; a displaced step in between cleared `steady`)
+        if (st is not None and ex.pending is None and st[0] is comp_type and st[1] is cfg and k.shape == st[2] and v.shape == st[2]
+                and _generation == st[3] and _cache.version == st[4] and k.device == st[5] and st[6] == _steady_flags(cfg, k)
+                and not cfg.log_compress_stats and k.is_contiguous() and v.is_contiguous()):
             return ex.step_steady(k, v)
     fusable = (comp_type != T.WARMUP and not cfg.simulate_compress and cfg.compress_residual == 1
                and not cfg.log_compress_stats and k.shape == v.shape and k.is_contiguous() and v.is_contiguous()
@@ -658,5 +660,11 @@ def compact_all_gather_kv(tag_k, tag_v, k: torch.Tensor, v: torch.Tensor, comp_t
         ex.bind(sig, cid, param, N, C, n_half, k.shape, cfg.error_feedback)
     out = ex.step(k, v, displaced)
     if not displaced and ex.xop is not None and ex.pending is None and not cfg.simulate_compress and cfg.compress_residual == 1:
-        ex.steady = (comp_type, cfg, k.shape, _generation, _cache.version, k.device)
+        ex.steady = (comp_type, cfg, k.shape, _generation, _cache.version, k.device, _steady_flags(cfg, k))
+    elif displaced or ex.pending is not None:
+        ex.steady = None             # a displaced delta is in flight: the next synchronous call takes the general path (which flushes it)
     return out
+
+
+def _steady_flags(cfg, k):
+    return (cfg.simulate_compress, cfg.compress_residual, cfg.error_feedback, bool(_cache.quantize), k.dtype)

@@ -84,6 +84,7 @@ class GroupHealth:
         self.local_error = False
         self.step = None
         self.pending = None          # (event, pinned result) of the all-reduce issued at the previous boundary
+        self._flag, self._host, self._turn = None, None, 0
 
     def note_error(self) -> None:
         self.local_error = True
@@ -98,10 +99,15 @@ class GroupHealth:
             ev, host = self.pending
             ev.synchronize()         # (issued a whole step ago)
             agreed = bool(int(host[0]))
-        flag = torch.tensor([1 if self.local_error else 0], dtype=torch.int32, device=f"cuda:{self.device}")
+        if self._flag is None:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=f"cuda:{self.device}")
+            self._host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+        flag = self._flag
+        flag.fill_(1 if self.local_error else 0)          # (a kernel on the current stream: no host-to-device copy to wait for)
         self.local_error = False
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        self._turn ^= 1
+        host = self._host[self._turn]                       # (the other one is what the previous boundary's copy landed in)
         host.copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))

@@ -709,13 +709,19 @@ __device__ __forceinline__ h16x8 ld8_wt(const u16* p) {
 // block's sign bits / nothing else is needed for them (see above): the caller issues those loads BEFORE scales_from_tagged<.., false>,
 // one round trip for both.  Hundreds of workgroups polling ALL their words from the moment their state tile has landed measured 9 %
 // slower than the arrival gate they replaced (1.56 vs 1.43 ms per step): the polls load the fabric the statistics chain needs.
+#ifndef WATCH_SLEEP
+#define WATCH_SLEEP 4
+#endif
+#ifndef INT2_FLAG_SLEEP
+#define INT2_FLAG_SLEEP 2
+#endif
 __device__ __forceinline__ void scales_watch(const TagArena& ta, int N, int C, int c0, int r0, long long timeout) {
     const int tid = threadIdx.x;
     if (tid < 2) {
         const u64* w = tid ? ta.tU + min(r0, N - 1) : ta.tV + min(c0 + ((r0 >> 1) & (TILE_C - 1)), C - 1);
         SpinClock clk;
         while (!tag_is(ld_wt(w), ta.tagbits)) {
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(WATCH_SLEEP);
             if (clk.expired(timeout)) break;              // (scales_from_tagged then gives up for everybody)
         }
     }
@@ -1661,7 +1667,7 @@ __device__ __forceinline__ void int2_dequant_gated_body(const cfx_decomp_item& i
             for (;;) {
                 const u64 v = by0 + t.lane <= by1 ? ld_wt(f + by0 + t.lane) : ta.tagbits;
                 if (__builtin_amdgcn_ballot_w64(!tag_is(v, ta.tagbits)) == 0) break;
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(INT2_FLAG_SLEEP);
                 if (clk.expired(timeout)) { failed = true; if (t.lane == 0) gate_fail(err); break; }
             }
         }

@@ -135,8 +135,15 @@ int cfx_compress_batch_ex(cfx_ctx* ctx, int codec, int N, int C, int param, int 
  * finalize off, too many items for one launch) exactly that sequence runs.
  * A gated item's base/recon must not alias this call's x / packet operands; recon may equal base, and a gated item may
  * update a compress item's `base` in place (the compress group has finished reading it when the gate opens).
- * NOT capturable into a hipGraph: the value a gate opens at is a launch argument that advances with every launch (monotonic
- * arrival counters, no reset, no memset node), so a replayed node would wait for a value that has already gone by.  The ungated
+ * Inside the launch (round 5): the 1-bit / 2-bit statistics tiles hand their partial sums over as TAGGED 8-byte words {24-bit launch
+ * tag | 40-bit sum} in an arena the context keeps per stream (zeroed at allocation, tags never reused) - the data is its own "published"
+ * mark: no drain, no ticket, and no 32-bit cliff (round 4's words gave out at an average |residual| of 0.5; beyond 40 bits - an average
+ * of 128 - the exact sum travels in the caller's workspace); FIXED workgroups (the last-dispatched tiles) poll the words they reduce and
+ * publish the scales into the packet and, tagged, into the arena.  2-bit: a statistics tile polls those tagged scales (no gate 1), and a
+ * reconstruction tile waits for the 4 - 6 tiles whose codes it reads (per-tile flags) instead of the slowest of all (2.10 -> 1.89 ms per
+ * FLUX step).  1-bit: the reconstruction tiles keep the arrival gate (XCD-relayed; tagged scales measured 10 % slower there).
+ * NOT capturable into a hipGraph: the value a gate opens at and the launch's tag are launch arguments that advance with every launch
+ * (monotonic arrival counters, no reset, no memset node), so a replayed node would wait for a value that has already gone by.  The ungated
  * launches (cfx_compress_batch / _ex) are capturable: their tickets reset themselves.  (An int4 / int8 compress call outside a capture runs
  * as ONE launch too - statistics, scales, codes and the state update from the tile in registers, k_minmax_layer - handing its partials over
  * as sequence-tagged words in an arena the context keeps per stream; under stream capture the same call runs the capturable sequence
