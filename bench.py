@@ -1195,113 +1195,21 @@ def main():
             pass
     if world > 1:
         dist.destroy_process_group()
-    if rank == 0 and world == 1 and args.overlap_steps > 0 and not args.emulate_live and not args.no_secondary:
-        # the deployable path beside real attention: what the exchange costs a model step once it runs on the exchange lane
-        try:
-            del xs, own_base, peer_base
-            torch.cuda.empty_cache()
-            # a process of its own: this one has had RCCL, the exchange stream and half a dozen plan sets in it, and the lane's figure is
-            # about two flag-ordered streams beside attention kernels, nothing else (in-process it read 0.15 ms/step higher, same box)
-            import subprocess
-            import tempfile
-            torch.cuda.synchronize(dev)
-            with tempfile.TemporaryDirectory() as td:
-                jpath = os.path.join(td, "overlap.json")
-                r_ov = subprocess.run([sys.executable, os.path.join(REPO, "tools", "overlap_bench.py"), "--quiet", "--steps", str(args.overlap_steps),
-                                       "--layers", str(L), "--legs", "attention_on_compute_lane,default,lane,attention_distinct_kv_on_compute_lane",
-                                       "--json", jpath], capture_output=True, text=True, timeout=900, cwd=REPO)
-                if r_ov.returncode != 0:
-                    raise RuntimeError("tools/overlap_bench.py failed: " + r_ov.stderr[-400:])
-                ov = json.load(open(jpath))
-            legs = ov["legs_ms_per_step"]
-            out["overlap_with_attention"] = {
-                "protocol": ov["protocol"], "steps": ov["steps"], "lane": ov["lane"],
-                "attention_only_ms_per_step": legs["attention_on_compute_lane"]["wall"],
-                "attention_over_distinct_kv_ms_per_step": legs["attention_distinct_kv_on_compute_lane"]["wall"],
-                "with_exchange_default_path_ms_per_step": legs["default"]["wall"],
-                "with_exchange_on_the_lane_ms_per_step": legs["lane"]["wall"],
-                "exposed_exchange_ms_per_step": ov["exposed_exchange_ms_per_step"]["default"],
-                "exposed_exchange_ms_per_step_caller_on_the_lane": ov["exposed_exchange_ms_per_step"]["lane"],
-                "exposed_exchange_ms_per_step_vs_attention_over_distinct_kv": ov["exposed_exchange_ms_per_step_vs_attention_over_distinct_kv"],
-                "what": "compact_fwd (gather schedule) with PyTorch-ROCm SDPA at the FLUX shape: the layer's chain on the CU-masked exchange stream, "
-                        "ordered with the compute stream by flags in device memory; exposed = step with the exchange - attention alone.  "
-                        "exposed_exchange_ms_per_step = the path compact_fwd takes with NO user opt-in (caller on an ordinary stream: it forks to "
-                        "the lane's compute stream and joins back per call); ..._caller_on_the_lane = the model run on lanes.compute_stream()"}
-            out["exposed_exchange_ms_per_step"] = ov["exposed_exchange_ms_per_step"]["default"]
-            out["exposed_exchange_ms_per_step_caller_on_the_lane"] = ov["exposed_exchange_ms_per_step"]["lane"]
-        except Exception as e:  # pragma: no cover
-            out["overlap_with_attention"] = {"error": f"{type(e).__name__}: {e}"}
-    if rank == 0 and world == 1 and not args.emulate_live and not args.no_secondary and args.plugin_steps > 0:
-        # protocol 1 THROUGH THE PLUGIN API (compact_all_gather_kv / compact_fwd with a no-op attention): what the product path - one native
-        # op per layer, compact/xlayer.py - takes for the same 57-layer step, host issue included.  A process of its own (it loops the 8
-        # logical ranks back by patching torch.distributed's rank / world queries)
-        try:
-            import subprocess
-            import tempfile
-            with tempfile.TemporaryDirectory() as td:
-                jpath = os.path.join(td, "plugin.json")
-                r_pp = subprocess.run([sys.executable, os.path.join(REPO, "tools", "plugin_path_bench.py"), "--quiet", "--steps", str(args.plugin_steps),
-                                       "--layers", str(L), "--json", jpath], capture_output=True, text=True, timeout=600, cwd=REPO)
-                if r_pp.returncode != 0:
-                    raise RuntimeError("tools/plugin_path_bench.py failed: " + r_pp.stderr[-400:])
-                pp = json.load(open(jpath))
-            out["plugin_path"] = {"ms_per_step": pp["ms_per_step"], "host_us_per_layer": pp["host_us_per_layer"], "legs": pp["legs"],
-                                  "ipc_memory": pp.get("ipc_memory_kind"),
-                                  "what": "the same step issued through the plugin API, attention replaced by a no-op: compact_all_gather_kv (what patch_gather_fwd "
-                                          "calls) and compact_fwd (gather schedule), ONE native op per layer (cfx_plan_add_exchange_layer_p2p through "
-                                          "compact/xlayer.py); `ms_per_step` / `host_us_per_layer` = compact_all_gather_kv on a side stream; 8 logical ranks looped back"}
-            out["plugin_path_ms_per_step"] = pp["ms_per_step"]
-        except Exception as e:  # pragma: no cover
-            out["plugin_path"] = {"error": f"{type(e).__name__}: {e}"}
-    if rank == 0 and world == 1 and not args.emulate_live and not args.no_secondary and not args.no_config_table:
-        # every BASELINE.json configuration, one rank's codec work of one denoise step replayed layer by layer in order, peers looped back
-        # (tools/config_table.py; SURVEY 8d shapes): ms per step, algorithmic bytes, fraction of the 8 TB/s HBM roofline
-        try:
-            sys.path.insert(0, os.path.join(REPO, "tools"))
-            import config_table as CT
-            torch.cuda.empty_cache()
-            cfgs = {}
-            for name, cid_, param_, (n_, c_), l_, ncomp, nrec, upd in CT.CONFIGS:
-                ms_ = CT.gpu_step(cid_, param_, n_, c_, l_, ncomp, nrec, upd, min_steps=8, budget_s=0.05)
-                ab = CT.alg_bytes(cid_, n_, c_, l_, ncomp, nrec, upd)
-                cfgs[name.split()[0] + (" " + " ".join(name.split()[-2:]) if name.startswith("5") else "")] = {
-                    "workload": name, "shard": [n_, c_], "layers": l_, "ms_per_step": round(ms_, 4), "alg_bytes": ab,
-                    "frac": round(ab / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                torch.cuda.empty_cache()
-            out["configs"] = cfgs
-        except Exception as e:  # pragma: no cover
-            out["configs"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.emulate_live and not args.no_secondary:
-        # the low-rank presets of the reference (examples/configs.py:63-110) on the same shard: one K,V pair per call, distinct pairs
-        # in turn (cold caches), event-timed through the Python API (compress = factors + state update; LOW_RANK_Q also quantises them)
-        try:
-            lr = {}
-            Lr = 24
-            g2 = torch.Generator(device=dev).manual_seed(5)
-            xl = torch.randn(Lr, 2, N, C, generator=g2, device=dev).half()
-            sl = (xl.float() + 0.1 * torch.randn(Lr, 2, N, C, generator=g2, device=dev)).half()
-            for name, q_, r_ in (("LOW_RANK r=8", False, 8), ("LOW_RANK r=16", False, 16), ("LOW_RANK_Q r=32", True, 32)):
-                pkl = [torch.empty(K.lr_packet_halves(q_, N, C, r_), dtype=torch.float16, device=dev) for _ in range(2)]
-                q0 = [torch.randn(C, K.lr_rank_pad(r_), generator=g2, device=dev) for _ in range(2)]
-
-                def lay(l):
-                    K.lr_compress_batch(q_, [xl[l, 0], xl[l, 1]], [sl[l, 0], sl[l, 1]], [sl[l, 0], sl[l, 1]], pkl, q0, N, C, r_, True)
-                for l in range(4):
-                    lay(l)
-                torch.cuda.synchronize(dev)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(3):
-                    for l in range(Lr):
-                        lay(l)
-                e1.record()
-                torch.cuda.synchronize(dev)
-                lr[name] = round(e0.elapsed_time(e1) / (3 * Lr) * 1e3, 1)
-            out["low_rank_presets"] = {"us_per_kv_pair_compress": lr, "shard": [N, C],
-                                       "what": "cfx_lr_compress_batch, one persistent launch per K,V pair (csrc/cfx_lrslab.hip) + the int4 factor quantiser "
-                                               "for LOW_RANK_Q; profiles/r04_lowrank_*"}
-        except Exception as e:  # pragma: no cover
-            out["low_rank_presets"] = {"error": f"{type(e).__name__}: {e}"}
+        # the secondary legs that need nothing of this process's state (tools/bench_secondary.py): protocol 2 beside real attention and the
+        # plugin path (child processes), every BASELINE configuration, the low-rank presets
+        del xs, own_base, peer_base
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize(dev)
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import bench_secondary as BS
+        if args.overlap_steps > 0:
+            BS.overlap_leg(out, args.overlap_steps, L)
+        if args.plugin_steps > 0:
+            BS.plugin_leg(out, args.plugin_steps, L)
+        if not args.no_config_table:
+            BS.configs_leg(out, HBM_PEAK_GBS)
+        BS.lowrank_leg(out, dev, N, C)
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:

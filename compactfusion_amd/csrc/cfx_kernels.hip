@@ -1159,18 +1159,10 @@ __device__ __forceinline__ void own_tile_finish(const cfx_comp_item& it, int N, 
     const bool ef = !(flags & CFX_FLAG_NO_EF);
     // the scales: the launch's tagged copies, polled (no gate 1: scales_from_tagged)
     unsigned char* pk = (unsigned char*)it.packet;
-#ifdef INT2_S_GATE
-    if (!gate_wait<true>(gate1, expect1, err, timeout)) return;
-    const u16* TOK = (const u16*)(pk + (size_t)N * (C >> 2));
-    const u16* CH = TOK + N;
-    const h16x8 ch8 = ld8_wt(CH + min(t.c, C - 8));
-    const u16 ul = ld_wt(TOK + min(t.r0 + t.w + NW * min(t.lane, US - 1), t.r1 - 1));
-#else
     (void)gate1; (void)expect1;
     if (!scales_from_tagged<NW * US>(ta, N, C, bx * TILE_C, t.r0, s16, timeout, err)) return;   // (no codes, no arrival on gate 2: the reconstruction group gives up as well)
     const h16x8 ch8 = __builtin_bit_cast(h16x8, *(const u16x8*)(s16 + 8 * t.lane));
     const u16 ul = s16[TILE_C + min(t.w + NW * min(t.lane, US - 1), t.r1 - 1 - t.r0)];
-#endif
     const bool has_base = it.base != nullptr;
     u16 codes[US];
 #pragma unroll
@@ -1425,21 +1417,6 @@ __global__ __launch_bounds__(FUSED_NT, GATE_WPE) void k_absmean_compress(BatchC 
                 for (int t = b; t < a.n_gt; t += a.n_g) {             // (one trip unless the group is persistent)
                     const int item = t / per, rem = t - item * per;
                     const int ty = rem / a.CB;
-#ifdef GATE_HOLD
-                    // experiment: hold the state preload back until a statistics tile of this column block has published its row partials
-                    // (= its loads have landed): the statistics group's loads go first
-                    if (a.tarena) {
-                        if (threadIdx.x == 0) {
-                            const u64* w = a.tarena + (size_t)(rem - ty * a.CB) * a.N + min(ty * a.g_R, a.N - 1);
-                            SpinClock clk;
-                            while (!tag_is(ld_wt(w), (u64)a.tag << 40)) {
-                                __builtin_amdgcn_s_sleep(4);
-                                if (clk.expired(a.timeout)) break;
-                            }
-                        }
-                        __syncthreads();
-                    }
-#endif
                     const int sz = a.src[item];
                     const TagArena ta = tag_arena_of(a.tarena, a.tarena_stride, sz >= 0 ? sz : 0, a.N, a.C, a.CB, a.P, a.tag);
                     binary_dequant_gated_body<FUSED_NW, GATE_KR, 0, ST>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.xgate ? a.xgate : a.gate,

@@ -557,6 +557,10 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     LSTAMP(5);
     }
     if (!failed) {
+    // (Round 5 tried the factorisation over the WHOLE workgroup - thread t holding entries t and t + 512, column j through LDS, one barrier a
+    // step, bit-identical results: k_lrs<32> went from 238 to 145 VGPRs and from 99 to 117 us, rank 16 from 53 to 61 - a barrier of eight
+    // waves per step costs more than one wave's v_readlane chain.  Out again; so is two rows per lane in wave 0's substitution, which
+    // spilled 2 KB a lane.)
     if (w == 0) lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_TOL, false);     // chol(M1)
     __syncthreads();
     LSTAMP(14);

@@ -55,13 +55,13 @@ TOL = {"lrq32": _lrq_band()}
 GAPS = {}
 
 
-def _check(name, rows, want):
+def _check(name, rows, want, who="hip"):
     rows = np.array(rows)
     tol_rel, tol_db = TOL.get(name, (1e-3, 0.02))
     assert rows.shape == want.shape
     assert np.all(rows[0, :2] == 0) and rows[0, 2] > 200            # WARMUP step is exact
     gaps = [float((np.abs(rows[1:, c] - want[1:, c]) / want[1:, c]).max()) for c in (0, 1)] + [float(np.abs(rows[1:, 2] - want[1:, 2]).max())]
-    GAPS[name] = {"rel_err_k": gaps[0], "rel_err_v": gaps[1], "psnr_db": gaps[2], "band": [tol_rel, tol_db]}
+    GAPS[f"{name}/{who}"] = {"steps": int(rows.shape[0]), "rel_err_k": gaps[0], "rel_err_v": gaps[1], "psnr_db": gaps[2], "band": [tol_rel, tol_db]}
     out = os.path.join(os.path.dirname(HERE), "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "quality_gaps.json"), "w") as f:
@@ -124,4 +124,4 @@ def test_oracle_stays_on_the_reference_quality_trace(name):
                 _, state[kv] = R.residual_compress(name, xa, state[kv], 0)
             rec.append(torch.from_numpy(R.bits(state[kv]).view(np.int16).copy()).view(torch.float16).reshape(GEN.N, GEN.C))
         rows.append(GEN.metrics(q, ks[t], vs[t], rec[0], rec[1]))
-    _check(name, rows, want[:T])
+    _check(name, rows, want[:T], who="oracle")

@@ -30,8 +30,10 @@ ap.add_argument("--json", default=None)
 ap.add_argument("--quiet", action="store_true")
 args = ap.parse_args()
 
+import compactfusion_amd
 from compactfusion_amd import _lib, codecs as K
 from compactfusion_amd.compact import ring, main as cm, xlayer
+compactfusion_amd.configure(lane="off")       # this tool is about the ONE-op layer exchange on the caller's stream (round 5's default is the lane)
 from compactfusion_amd.compact.utils import CompactConfig, COMPACT_COMPRESS_TYPE as T
 from compactfusion_amd.collector import collector
 from compactfusion_amd.prof import Profiler
