@@ -79,16 +79,27 @@ def compact_fwd(q, k, v, dropout_p=0, softmax_scale=None, causal=True, window_si
     # chain runs on the exchange lane beside the attention blocks whenever the layer has peers to hear from.  A caller that is not on the
     # lane's compute stream is put there for the duration of the call (configure(lane="auto"): forked from and joined to its own stream
     # by flag kernels) or for good (lane="sticky"); lane="off" keeps the exchange as one op on the caller's stream.
-    token = dev = None
+    token = dev = key = None
     if q.is_cuda and _auto_lane(q, group):
         from .. import lanes
         dev = q.device.index if q.device.index is not None else torch.cuda.current_device()
-        token = lanes.fork_to_compute(dev)
+        key = (mod_idx, id(group) if group is not None else None)
+        st = _steady.get(key)
+        if st is not None and st.ex.lane and st.ex.plan is not None and not lanes.on_compute_stream(dev):
+            # steady layer: ONE flag word does both jobs - "K,V exist", published by the caller's stream (what cfx_plan_lane_begin does on
+            # the compute stream when the caller is there already), is also what the compute lane waits for before it goes on.  The
+            # compute lane runs neither a wait-for-fork nor a publish kernel of its own in front of the local attention block.
+            token = lanes.fork_to_compute(dev, begin=st.ex.lane_begin, flag=lambda e: st.ex.flag_ptr(0))
+            _prebegun[key] = token[2]
+        else:
+            token = lanes.fork_to_compute(dev)
         if token is not None and _settings.get("lane") == "sticky":
             token = None                       # the compute stream stays the thread's current stream
     try:
         return _compact_ring_fwd(*args)
     finally:
+        if key is not None:
+            _prebegun.pop(key, None)           # (not consumed: the call took the general path, which publishes its own epoch)
         if token is not None:
             lanes.join_from_compute(dev, token)
 
@@ -205,6 +216,7 @@ def _compact_ring_fwd(q, k, v, dropout_p=0, softmax_scale=None, causal=True, win
 _xbuf = {}
 _xstreams = {}
 _steady = {}
+_prebegun = {}           # (layer, group) -> the lane epoch compact_fwd already published from the caller's stream (auto lane)
 
 
 class _SteadyLayer:
@@ -220,6 +232,7 @@ class _SteadyLayer:
         self.N, self.C = cm._nc_shape(k.shape)
         self.kk, self.vk = ex.kkeys[rank], ex.vkeys[rank]
         self.last_key = ex.vkeys[ex.peers[-1]]
+        self._key = None             # set by whoever files the layer under _steady
 
     def matches(self, q, k, v, ctype, cfg, causal, dropout_p) -> bool:
         # (cheap comparisons only: this runs once per layer and step in front of ONE native call)
@@ -290,7 +303,9 @@ class _SteadyLayer:
         if ex.lane:
             # exchange lane: ONE native call issues the layer's whole chain on the exchange stream; the compute stream never sees
             # an event - the merge launch of block s also waits (in-kernel, on a flag) for peer s+1's reconstruction
-            epoch = ex.lane_begin(sh)                       # "K, V exist" on the compute stream ...
+            epoch = _prebegun.pop((self._key), None)        # (auto lane: already published, from the caller's stream, before the hand-over)
+            if epoch is None:
+                epoch = ex.lane_begin(sh)                   # "K, V exist" on the compute stream ...
             fast = self._fast_ok(q)
             if fast:
                 # lean host path (the step is host-bound long before it is GPU-bound: 8 attention + 8 merge calls per layer): cached
@@ -796,7 +811,9 @@ def _gather_schedule(q, k, v, ctype, mod_idx, rank, world, group, kkey, vkey, at
         for step, (kk, vv) in enumerate(ex.peer_views, start=1):
             out, lse = attend(out, lse, kk, vv, step)
         if native_x and cfg.error_feedback is not None:
-            _steady[(mod_idx, id(group) if group is not None else None)] = _SteadyLayer(ex, q, k, v, ctype, cfg, rank, world)
+            skey = (mod_idx, id(group) if group is not None else None)
+            _steady[skey] = _SteadyLayer(ex, q, k, v, ctype, cfg, rank, world)
+            _steady[skey]._key = skey
         return out, lse
     if native and compact_cache().quantize:
         native = False           # state lives as int8 packets: go through compact_decompress (get_base / put) per tensor

@@ -114,30 +114,40 @@ def usable(device: int) -> bool:
     return bool(_lib.load().cfx_hw_queues_ok())
 
 
-def fork_to_compute(device: int):
+def fork_to_compute(device: int, begin=None, flag=None):
     """The caller's current stream hands over to the lane's compute stream: `flag set` behind everything the caller has enqueued, `flag
     wait` in front of everything that follows on the compute stream - two one-wave kernels, ~3 us of hop (an event pair costs ~14) -
     and the compute stream becomes the thread's current stream.  Returns the token `join_from_compute` takes, or None when the caller is
-    on the compute stream already.  Tensor lifetimes need no record_stream: every use on the compute stream lies between a fork and a
-    join (or, sticky, stays there), so whatever the caching allocator hands out again on either stream is ordered behind its last use."""
+    on the compute stream already.  `begin(stream_handle) -> epoch` / `flag(epoch) -> address`: the set kernel is somebody else's
+    publication (a layer plan's "K,V exist": cfx_plan_lane_begin launched on the CALLER's stream) and the compute stream waits for that
+    word - one kernel fewer in front of the local attention block; the token then carries the epoch as a third element.
+    Tensor lifetimes need no record_stream: every use on the compute stream lies between a fork and a join (or, sticky, stays there), so
+    whatever the caching allocator hands out again on either stream is ordered behind its last use."""
     ln = lane(device)
     cur = torch.cuda.current_stream(device)
     if cur.cuda_stream == ln.compute.cuda_stream:
         return None
     h = _hand(device)
+    lib, ctx = h["lib"], h["ctx"]
     h["epoch"] += 1
-    e, lib, ctx = h["epoch"], h["lib"], h["ctx"]
-    if lib.cfx_flag_set(ctx, h["fork"], e, cur.cuda_stream) != 0 or lib.cfx_flag_wait(ctx, h["fork"], e, ln.compute.cuda_stream) != 0:
+    je = h["epoch"]                              # the JOIN's epoch is always the hand-over's own
+    if begin is not None:
+        e = begin(cur.cuda_stream)
+        rc = lib.cfx_flag_wait(ctx, flag(e), e, ln.compute.cuda_stream)
+    else:
+        e = None
+        rc = lib.cfx_flag_set(ctx, h["fork"], je, cur.cuda_stream) or lib.cfx_flag_wait(ctx, h["fork"], je, ln.compute.cuda_stream)
+    if rc != 0:
         raise _lib.CfxError("exchange lane hand-over failed: " + (lib.cfx_last_error_string(ctx) or b"").decode())
     torch.cuda.set_stream(ln.compute)
-    return (cur, e)
+    return (cur, je, e)
 
 
 def join_from_compute(device: int, token) -> None:
     """The reverse hand-over: the caller's stream continues behind everything enqueued on the compute stream since the fork."""
     if token is None:
         return
-    cur, e = token
+    cur, e = token[0], token[1]
     ln = lane(device)
     h = _hand(device)
     lib, ctx = h["lib"], h["ctx"]

@@ -161,13 +161,17 @@ def timed(fn, first):
 
 from compactfusion_amd import lanes
 comp_stream = lanes.compute_stream(0)
-ALL = ["attention_on_compute_lane", "default", "sticky", "lane", "attention_distinct_kv_on_compute_lane", "attention", "layer_op", "lane_unmasked", "native", "native_gather_only_on_side", "torchdist"]
+# (`default` / `sticky` come LAST: they bring two more streams into the process, and with more streams than hardware queues
+# (GPU_MAX_HW_QUEUES = 8) the flag-ordered legacy legs that follow share queues with something and are time-sliced - measured 36-43 ms per
+# step for `lane_unmasked` / `native` behind them, 23.2 / 23.9 in a process of their own)
+ALL = ["attention_on_compute_lane", "lane", "attention_distinct_kv_on_compute_lane", "attention", "layer_op", "lane_unmasked", "native", "native_gather_only_on_side", "torchdist", "default", "sticky"]
 legs = [x for x in (args.legs.split(",") if args.legs else ALL) if x]
 assert all(x in ALL for x in legs), f"legs must be among {ALL}"
 if args.quick:
     legs = [x for x in legs if x not in ("native_gather_only_on_side", "torchdist")]
 res = {}
 lane_used = native_used = None
+_side = None
 for leg in legs:
     if leg == "attention_on_compute_lane":
         with torch.cuda.stream(comp_stream):
@@ -175,7 +179,9 @@ for leg in legs:
             res[leg] = timed(attention_only, 0)
     elif leg in ("default", "sticky"):
         # the caller on an ORDINARY stream, every switch at its default
-        with torch.cuda.stream(torch.cuda.Stream(dev)):
+        if _side is None:
+            _side = torch.cuda.Stream(dev)
+        with torch.cuda.stream(_side):
             init("native", "auto", "auto" if leg == "default" else "sticky")
             assert all(ex.plan is not None and ex.lane for ex in ring._xbuf.values() if ex.sig is not None), "the default path did not take the lane"
             res[leg] = timed(fwd, 3)
