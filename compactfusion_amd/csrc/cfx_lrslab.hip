@@ -76,8 +76,12 @@ __device__ __forceinline__ lrs_u2 lrs_pack64(double d, unsigned seq) {
 __device__ __forceinline__ double lrs_val64(unsigned hi, unsigned lo) { return (double)__builtin_bit_cast(float, hi & ~3u) + (double)__builtin_bit_cast(float, lo & ~3u); }
 #define LRS_LD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
 template <int J> __device__ __forceinline__ void lrs_wait(lrs_u4 (&q)[J]) {
-    static_assert(J == 6, "operand list below");
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5])::"memory");
+    static_assert(J == 6 || J == 10, "operand lists below");
+    if constexpr (J == 6)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5])::"memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]),
+                     "+v"(q[9])::"memory");
 }
 __device__ __forceinline__ bool lrs_tagged(lrs_u4 q, unsigned seq) { return ((q[0] & q[1] & q[2] & q[3] & 3u) == seq) && (((q[0] | q[1] | q[2] | q[3]) & 3u) == seq); }
 
@@ -93,6 +97,84 @@ __device__ __forceinline__ void lrs_chol_L(const double (*G)[RP + 1], int r, flo
         dinvf[i] = ((dead >> i) & 1u) ? 0.f : (float)myinv;         // a dropped direction: zero column of the result
     }
     if (i == 0) *deadw = dead;
+}
+
+// Rank 32: the same factorisation BLOCKED (round 5).  lr_chol_rows updates the whole trailing matrix after every pivot: ~500 dependent
+// v_readlane + v_fma_f64 pairs in one wave's registers, 10-12 us, twice a launch.  Here a panel of 4 columns is factorised in the lanes'
+// registers (lane i = row i; the same step, the same masks, the same dead-direction rule as lr_chol_rows, restricted to the panel), and the
+// rest of the matrix takes the panel's rank-4 update as ONE v_mfma_f64_16x16x4_f64 per 16 x 16 tile (D = C + (-Lp) Lp^T: the four
+// products of an entry in the order the four steps would have applied them).  The matrix lives in LDS (`M`, 32 x 33 doubles) between panels;
+// a wave's LDS operations execute in order, so the only waits are for data.  8 panels x (4 short steps + 3 tile updates).  One wave calls it.
+__device__ __forceinline__ void lrs_chol_L_blocked32(const double (*G)[33], int r, float* Lf, float* dinvf, unsigned* deadw, double tol, bool own_diag,
+                                                     double* M /* LDS: 32 x 33 */) {
+    constexpr int RP = 32, MS = 33;
+    const int lane = threadIdx.x & 63, i = lane & 31, l16 = lane & 15, lq = lane >> 4;
+    auto bcast = [](double v, int src) -> double {
+        const int2 q = __builtin_bit_cast(int2, v);
+        int2 o;
+        o.x = __builtin_amdgcn_readlane(q.x, src);
+        o.y = __builtin_amdgcn_readlane(q.y, src);
+        return __builtin_bit_cast(double, o);
+    };
+    // symmetrised copy (lanes 0 - 31: a row each), the original diagonal kept for the dead-direction test
+    double gmax = 0.0;
+#pragma unroll
+    for (int k = 0; k < RP; ++k) gmax = (k < r) ? fmax(gmax, G[k][k]) : gmax;
+    const double thr = gmax * tol;
+    if (lane < RP) {
+#pragma unroll
+        for (int k = 0; k < RP; ++k) M[i * MS + k] = 0.5 * (G[i][k] + G[k][i]);
+    }
+    unsigned dead = 0;
+    double myinv = 1.0;
+#pragma unroll 1
+    for (int p = 0; p < RP / 4; ++p) {
+        const int j0 = 4 * p;
+        double c[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) c[t] = M[i * MS + j0 + t];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = j0 + t;
+            const double piv = bcast(c[t], j);
+            const bool ok = (j < r) && (piv > (own_diag ? G[j][j] * tol : thr));
+            const double pv = ok ? piv : 1.0;
+            double inv = __builtin_amdgcn_rsq(pv);
+            inv = inv * __builtin_fma(pv * inv, -0.5 * inv, 1.5);
+            double l = ok ? c[t] * inv : (i == j ? 1.0 : 0.0);
+            l = (i >= j && i < r) ? l : 0.0;
+            myinv = (i == j && ok) ? inv : myinv;
+            dead |= (ok || j >= r) ? 0u : (1u << j);
+            c[t] = l;
+#pragma unroll
+            for (int t2 = t + 1; t2 < 4; ++t2) c[t2] = __builtin_fma(-l, bcast(l, j0 + t2), c[t2]);
+        }
+        if (lane < RP) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { Lf[i * RP + j0 + t] = (float)c[t]; M[i * MS + j0 + t] = c[t]; }     // (M's panel columns: the MFMA operands)
+        }
+        if (j0 + 4 >= RP) break;
+        // trailing update, columns >= j0 + 4: tiles (a, b) = (rows 16 a .., columns 16 b ..) of the lower triangle that still have such columns
+#pragma unroll
+        for (int tl = 0; tl < 3; ++tl) {
+            const int a = tl == 0 ? 0 : 1, b = tl == 2 ? 1 : 0;
+            if (16 * b + 15 < j0 + 4) continue;                        // (uniform) every column of the tile is final already
+            const double av = -M[(16 * a + l16) * MS + j0 + lq];       // A[i = l16][k = lq] = -Lp
+            const double bv = M[(16 * b + l16) * MS + j0 + lq];        // B[k = lq][j = l16] = Lp^T
+            f64x4 cv;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cv[v] = M[(16 * a + lq + 4 * v) * MS + 16 * b + l16];        // D[i = lq + 4 v][j = l16]
+            cv = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, cv, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int col = 16 * b + l16;
+                if (col >= j0 + 4) M[(16 * a + lq + 4 * v) * MS + col] = cv[v];                      // (the panel's own columns stay what the panel made them)
+            }
+        }
+    }
+    // rows above the diagonal of L: zero (lr_chol_rows writes the masked l there: 0)
+    if (lane < RP) dinvf[i] = ((dead >> i) & 1u) ? 0.f : (float)myinv;
+    if (lane == 0) *deadw = dead;
 }
 
 // LDS carve-up (bytes).  NPK = N rounded up to 32 (the K step of the fp16 MFMA); RR = RP rounded up to 16 (the rank groups of the MFMA
@@ -333,6 +415,9 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     // A wait that gives up (a.timeout ticks of the 100 MHz wall clock after its first failed poll) ends the chain for this workgroup: the
     // phases that follow are skipped, nothing more is stored - no factors from sums that never completed, the state stays as it was.
     bool failed = false;
+    // (rank 32, 10 cells a thread in flight instead of 6 - one round trip instead of two for the gather and for a workgroup's share of the
+    // reduction: 95.7 vs 95.2 us, nothing; a sum there moves 210 KB per workgroup through sc1 loads and stores, that is what it takes)
+    constexpr int JJ = LRS_J;
     auto allreduce = [&](unsigned tag, bool with_gram) {
         const unsigned seq = tag & 3u;
         const int tcells = with_gram ? pcells : cells;                // with_gram: the r x r fp64 matrix behind the values is summed (in fp64) too -> Gd
@@ -347,23 +432,23 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             double d0 = 0.0, d1 = 0.0;
             if (act) {
                 const lrs_u4* src = part + cell;
-                for (int p0 = sub; p0 < nwg; p0 += subs * LRS_J) {    // slab order: the result does not depend on the batch
-                    lrs_u4 q[LRS_J];
+                for (int p0 = sub; p0 < nwg; p0 += subs * JJ) {    // slab order: the result does not depend on the batch
+                    lrs_u4 q[JJ];
                     long long t0 = 0;
                     for (;;) {
 #pragma unroll
-                        for (int j = 0; j < LRS_J; ++j) LRS_LD16(q[j], src + (size_t)min(p0 + subs * j, nwg - 1) * pcells);     // unconditional: one round trip
+                        for (int j = 0; j < JJ; ++j) LRS_LD16(q[j], src + (size_t)min(p0 + subs * j, nwg - 1) * pcells);     // unconditional: one round trip
                         lrs_wait(q);
                         bool ok = true;
 #pragma unroll
-                        for (int j = 0; j < LRS_J; ++j) ok = ok && lrs_tagged(q[j], seq);
+                        for (int j = 0; j < JJ; ++j) ok = ok && lrs_tagged(q[j], seq);
                         if (ok) break;
                         const long long now = wall_clock64();
                         if (!t0) t0 = now;
                         else if (failed || now - t0 > a.timeout) { failed = true; break; }
                     }
 #pragma unroll
-                    for (int j = 0; j < LRS_J; ++j)
+                    for (int j = 0; j < JJ; ++j)
                         if (p0 + subs * j < nwg) {
                             if (dbl) { d0 += lrs_val64(q[j][0], q[j][1]); d1 += lrs_val64(q[j][2], q[j][3]); }
                             else {
@@ -399,23 +484,23 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             __syncthreads();
         }
         if (with_gram) LSTAMP(12);
-        for (int i0 = tid; i0 < tcells; i0 += LRS_NT * LRS_J) {
-            lrs_u4 q[LRS_J];
+        for (int i0 = tid; i0 < tcells; i0 += LRS_NT * JJ) {
+            lrs_u4 q[JJ];
             long long t0 = 0;
             for (;;) {
 #pragma unroll
-                for (int j = 0; j < LRS_J; ++j) LRS_LD16(q[j], full + min(i0 + LRS_NT * j, tcells - 1));
+                for (int j = 0; j < JJ; ++j) LRS_LD16(q[j], full + min(i0 + LRS_NT * j, tcells - 1));
                 lrs_wait(q);
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < LRS_J; ++j) ok = ok && lrs_tagged(q[j], seq);
+                for (int j = 0; j < JJ; ++j) ok = ok && lrs_tagged(q[j], seq);
                 if (ok) break;
                 const long long now = wall_clock64();
                 if (!t0) t0 = now;
                 else if (failed || now - t0 > a.timeout) { failed = true; break; }
             }
 #pragma unroll
-            for (int j = 0; j < LRS_J; ++j) {
+            for (int j = 0; j < JJ; ++j) {
                 const int c = i0 + LRS_NT * j;
                 if (c < cells) {
                     const int n = c / (RP / 4), rq = c - n * (RP / 4);
@@ -561,7 +646,10 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     // step, bit-identical results: k_lrs<32> went from 238 to 145 VGPRs and from 99 to 117 us, rank 16 from 53 to 61 - a barrier of eight
     // waves per step costs more than one wave's v_readlane chain.  Out again; so is two rows per lane in wave 0's substitution, which
     // spilled 2 KB a lane.)
-    if (w == 0) lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_TOL, false);     // chol(M1)
+    if (w == 0) {
+        if constexpr (RP == 32) lrs_chol_L_blocked32(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_TOL, false, scr64);
+        else lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_TOL, false);     // chol(M1)
+    }
     __syncthreads();
     LSTAMP(14);
     apply_l();                                                        // Y1 = W1 chol(M1)^-T
@@ -584,7 +672,10 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     // directions: > 1e-8 of it; the null directions of a rank-deficient residual: < 1e-10)
     gram64();
     LSTAMP(13);
-    if (w == 0) lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_REL, true);
+    if (w == 0) {
+        if constexpr (RP == 32) lrs_chol_L_blocked32(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_REL, true, scr64);
+        else lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_REL, true);
+    }
     __syncthreads();
     LSTAMP(9);
     apply_l();                                                        // U, fp32 in place: its fp16 rounding is what the packet carries
