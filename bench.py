@@ -241,6 +241,15 @@ def config_key(args, n_gpus):
 
 
 def main():
+    # Map of this function (one process per GPU; everything below the workload is closures over it):
+    #   1  set-up: ranks, the synthetic workload resident in HBM (warm_state / reset_state), packet buffers, the context's switches
+    #   2  schedules: add_layer / build_plans (N = 1 forms), build_step_plans (N > 1: peer-to-peer layer op, collective in the path, relay)
+    #   3  one_step / sync_all, states_consistent / validate / fall_back - the N > 1 safety net: validate after warm-up AND after the timed
+    #      region, on any failure every rank drops to the next schedule (p2p -> two launches around ncclAllGather -> torch.distributed)
+    #   4  warm-up, the timed region (barrier + synchronize on both sides, MAX over ranks), kernel-event sampling for `roofline`
+    #   5  secondary legs of THIS process (long run, the other schedules, the raw uncompressed exchange at N > 1), `xgmi`, `roofline`
+    #      (+ committed profiles quoted only on a matching configuration key and source hash), `cpu_baseline` + the oracle spot check
+    #   6  tear-down, then tools/bench_secondary.py: protocol 2 beside attention, the plugin path, every BASELINE config, low-rank presets
     args = parse()
     if args.print_config_key:
         print(json.dumps(config_key(args, args.gpus)))
