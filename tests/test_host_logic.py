@@ -396,3 +396,28 @@ def test_compact_update_awl_scale_sets_the_token_importance(monkeypatch):
     n = v.reshape(12, 16).norm(dim=-1)
     assert torch.allclose(sp._current_lowrank_scale_k, n.mean() / n) and sp._current_lowrank_scale_v is None
     sp.set_current_lowrank_scale(None, None)
+
+
+def test_install_xfuser_alias_resolves_the_reference_import_paths():
+    """compat.install_xfuser_alias: the reference's call sites import xfuser.compact.* / xfuser.prof / xfuser.collector.collector by name
+    (attn_layer.py:59-64, pipeline_flux.py:447-450, examples/flux_example.py:92-127) - after the alias those names are this package's modules.
+    A process of its own: sys.modules is global."""
+    import subprocess
+    import sys
+    import os
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from compactfusion_amd.compat import install_xfuser_alias\n"
+        "names = install_xfuser_alias()\n"
+        "from xfuser.compact.main import compact_init, compact_reset, compact_hello, compact_set_step, compact_compress, compact_decompress, compact_all_gather\n"
+        "from xfuser.compact.utils import CompactConfig, COMPACT_COMPRESS_TYPE\n"
+        "from xfuser.compact.ring import compact_fwd, compact_update_awl_scale\n"
+        "from xfuser.compact.patchpara.df_utils import PatchConfig\n"
+        "from xfuser.compact.slowpath import slowpath_compress, sim_compress, set_current_lowrank_scale\n"
+        "from xfuser.prof import Profiler, prof_summary\n"
+        "from xfuser.collector.collector import Collector, init, collect\n"
+        "import compactfusion_amd.compact.main as m\n"
+        "assert compact_init is m.compact_init and len(names) >= 15\n"
+        "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]
