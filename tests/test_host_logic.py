@@ -421,3 +421,37 @@ def test_install_xfuser_alias_resolves_the_reference_import_paths():
         "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]
+
+
+def test_configure_is_the_one_place_for_host_switches(monkeypatch):
+    """compactfusion_amd.configure: default < environment variable (the round 1-4 switches) < explicit call; unknown names and values are
+    refused; hw_queues exports HIP's own variable and only before HIP is up."""
+    import compactfusion_amd
+    from compactfusion_amd import config
+    config.reset()
+    for v in ("CFX_EXCHANGE", "CFX_LANE", "CFX_RING_SCHEDULE", "CFX_LANE_EXCHANGE_CUS"):
+        monkeypatch.delenv(v, raising=False)
+    assert config.get("exchange") == "auto" and config.get("lane") == "auto" and config.get("lane_exchange_cus") == "32"
+    monkeypatch.setenv("CFX_EXCHANGE", "rccl")
+    assert config.get("exchange") == "rccl"
+    eff = compactfusion_amd.configure(exchange="torch", lane="sticky", lane_exchange_cus=48)
+    assert eff["exchange"] == "torch" and eff["lane"] == "sticky" and config.get("lane_exchange_cus") == "48"
+    config.reset()
+    assert config.get("exchange") == "rccl"                      # back to the environment layer
+    with pytest.raises(ValueError):
+        compactfusion_amd.configure(lane="sometimes")
+    with pytest.raises(TypeError):
+        compactfusion_amd.configure(no_such_switch=1)
+    monkeypatch.setenv("CFX_LANE", "bogus")
+    with pytest.raises(ValueError):
+        config.get("lane")
+    monkeypatch.delenv("CFX_LANE")
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    monkeypatch.setattr(config, "_hip_is_up", lambda: False)
+    compactfusion_amd.configure(hw_queues=4)
+    import os
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "4"
+    monkeypatch.setattr(config, "_hip_is_up", lambda: True)
+    with pytest.raises(RuntimeError, match="before the first CUDA call"):
+        compactfusion_amd.configure(hw_queues=8)
+    config.reset()
