@@ -22,7 +22,8 @@ CASES = ['test_flag_relay_without_a_communicator',
          'test_two_rank_threads_exchange_for_real',
          'test_p2p_exchange_two_processes_one_gpu',
          'test_p2p_sync_chain_two_processes_one_gpu',
-         'test_p2p_exchange_layer_of_the_other_codecs_in_one_launch']
+         'test_p2p_exchange_layer_of_the_other_codecs_in_one_launch',
+         'test_a_layer_launch_whose_peer_never_answers_stores_nothing_and_the_context_recovers']
 
 
 @pytest.mark.parametrize("case", CASES)

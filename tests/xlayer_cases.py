@@ -618,3 +618,78 @@ def test_p2p_exchange_layer_of_the_other_codecs_in_one_launch(codec, N, C, P):
         assert np.array_equal(res["p2p"][0][0, 0].cpu().numpy().view(np.uint16), st), "own state differs from the C oracle's replay"
     finally:
         lib.cfx_ipc_free(ctx, ipc)
+
+
+@pytest.mark.parametrize("codec,N,C", [(1, 544, 3072), (2, 544, 3072), (3, 1024, 1152), (5, 512, 1536)])
+def test_a_layer_launch_whose_peer_never_answers_stores_nothing_and_the_context_recovers(codec, N, C):
+    """cfx_plan_add_exchange_layer_p2p with ONE live peer whose word never advances, gate timeout 200 ms: the launch's in-kernel wait gives
+    up on the wall clock, the reconstruction groups give up with it and STORE NOTHING (the peer's state and - its update is a gated item -
+    the own state stay bit for bit what they were; round 4 stored reconstructions from packets that had not arrived), the next call
+    reports CFX_ERR_GATE, cfx_gate_recover returns the count and puts the context back in order; with the peer's word in place the same
+    plan then runs and the states are the oracle's after ONE step."""
+    import numpy as np
+    from compactfusion_amd import _lib, codecs as K
+    from oracle import c_oracle as CO
+    lib, ctx = _lib.load(), K.context(0)
+    PRM = 8 if codec == 5 else 0
+    g = torch.Generator(device="cuda").manual_seed(77 + N)
+    x0 = torch.randn(2, N, C, generator=g, device="cuda").half()
+    x1 = (x0.float() + 0.1 * torch.randn(2, N, C, generator=g, device="cuda")).half()
+    own, peer = x0.clone(), x0.clone()
+    slot = (K.packet_bytes(codec, N, C, PRM) + 255) // 256 * 256
+    ipc, handle = ctypes.c_void_p(), (ctypes.c_ubyte * 64)()
+    assert lib.cfx_ipc_alloc(ctx, 4 * slot + 256, ctypes.byref(ipc), handle) == 0, lib.cfx_last_error_string(ctx)
+    own_flag, peer_flag = ipc.value + 4 * slot, ipc.value + 4 * slot + 64          # the "peer" is a word of ours that nobody advances
+    wsb = lib.cfx_workspace_bytes(codec, N, C, PRM, 2)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+    run = torch.cuda.Stream()
+    assert lib.cfx_set_gate_timeout_ms(ctx, 200) == 0
+    try:
+        plan = lib.cfx_plan_create(ctx)
+        c = (_lib.CompItem * 2)(*[_lib.CompItem(x1[b].data_ptr(), own[b].data_ptr(), own[b].data_ptr(), ipc.value + b * slot) for b in range(2)])
+        # the peer's packets would sit in ITS memory: here slots 2, 3 of the same arena, never written
+        d = (_lib.DecompItem * 2)(*[_lib.DecompItem(ipc.value + (2 + b) * slot, peer[b].data_ptr(), peer[b].data_ptr()) for b in range(2)])
+        op = lib.cfx_plan_add_exchange_layer_p2p(plan, codec, N, C, PRM, _lib.FLAG_UPDATE_CACHE, 2, c, 2, d, own_flag, 1,
+                                                 (ctypes.c_void_p * 1)(peer_flag), ws.data_ptr(), wsb)
+        assert op >= 0, lib.cfx_last_error_string(ctx)
+        assert lib.cfx_plan_finalize(plan) == 0
+        torch.cuda.synchronize()
+        rc = lib.cfx_plan_run(plan, 0, lib.cfx_plan_size(plan), run.cuda_stream)
+        assert rc == 0, lib.cfx_last_error_string(ctx)
+        torch.cuda.synchronize()
+        one_launch = torch.equal(own.view(torch.int16), x0.view(torch.int16))
+        # nothing of the peer was touched; where the codec has the one-launch form, neither was the own state (its update waits at the same gate)
+        assert torch.equal(peer.view(torch.int16), x0.view(torch.int16)), "a reconstruction was stored from a packet that never arrived"
+        assert lib.cfx_plan_run(plan, 0, lib.cfx_plan_size(plan), run.cuda_stream) == _lib.CFX_ERR_GATE, "the next call must report the time-out"
+        n_err = lib.cfx_gate_recover(ctx)
+        assert n_err >= 1, n_err
+        assert lib.cfx_gate_errors(ctx) == 0
+        if not one_launch:
+            own.copy_(x0)          # (stream-ordered fall-back form: compress + error feedback ran, only the reconstruction was withheld)
+        # the peer answers: its word reaches what this rank's next execution waits for (own word + 1), its packets = ours, looped back
+        word = torch.zeros(1, dtype=torch.int32, device="cuda")
+        import compactfusion_amd.compact.ring as ring_mod
+        own_w = ring_mod._raw_halves(own_flag, 2, torch.device("cuda", 0)).view(torch.int32)
+        peer_w = ring_mod._raw_halves(peer_flag, 2, torch.device("cuda", 0)).view(torch.int32)
+        peer_w.copy_(own_w + 1)
+        torch.cuda.synchronize()
+        plan2 = lib.cfx_plan_create(ctx)
+        d2 = (_lib.DecompItem * 2)(*[_lib.DecompItem(ipc.value + b * slot, peer[b].data_ptr(), peer[b].data_ptr()) for b in range(2)])
+        assert lib.cfx_plan_add_exchange_layer_p2p(plan2, codec, N, C, PRM, _lib.FLAG_UPDATE_CACHE, 2, c, 2, d2, own_flag, 1,
+                                                   (ctypes.c_void_p * 1)(peer_flag), ws.data_ptr(), wsb) >= 0
+        assert lib.cfx_plan_finalize(plan2) == 0
+        assert lib.cfx_plan_run(plan2, 0, lib.cfx_plan_size(plan2), run.cuda_stream) == 0, lib.cfx_last_error_string(ctx)
+        torch.cuda.synchronize()
+        assert lib.cfx_gate_errors(ctx) == 0
+        name = {1: "binary", 2: "int2", 3: "int4", 4: "int8", 5: "topk"}[codec]
+        for b in range(2):
+            st = np.ascontiguousarray(x0[b].cpu().numpy().view(np.uint16))
+            CO.compress(name, np.ascontiguousarray(x1[b].cpu().numpy()), st, N, C, PRM, new_base=st)
+            assert np.array_equal(own[b].cpu().numpy().view(np.uint16), st), "own state after the recovered step differs from the oracle"
+            assert np.array_equal(peer[b].cpu().numpy().view(np.uint16), st), "peer state after the recovered step differs from the oracle"
+        lib.cfx_plan_destroy(plan)
+        lib.cfx_plan_destroy(plan2)
+    finally:
+        lib.cfx_set_gate_timeout_ms(ctx, 5000)
+        lib.cfx_gate_recover(ctx)
+        lib.cfx_ipc_free(ctx, ipc)
