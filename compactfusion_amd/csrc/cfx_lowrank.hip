@@ -5,9 +5,9 @@
 // LOW_RANK_Q branches of slowpath.py (:54-75 encode, :120-131 + :151-164 decode) with a fixed chain of small kernels:
 //
 //   D  = x - base ; Y = D Q0                        k_lr_aq<FROMX>  (fp16 residual, formed on the fly and materialised once)
-//   2x { Z = D^T Y ; T = chol(Z^T Z)^-T ; Q = Z T ; Y = D Q }   k_lr_aty (+ partial Gram), k_lr_chol, k_lr_apply2, k_lr_aq
+//   2x { Z = D^T Y ; T = chol(Z^T Z)^-T ; Q = Z T ; Y = D Q }   k_lr_aty (+ partial Gram), k_lr_apply2 (factor + product), k_lr_aq
 //   Z' = D^T Y ; G = Q^T Z' (= Y^T Y)                 k_lr_aty (+ partial Q^T Z')
-//   T  = chol(G)^-T ; U = Y T ; V = (Z' T)^T          k_lr_chol, k_lr_apply2      (U = orth(Y), V = U^T D without re-reading D)
+//   T  = chol(G)^-T ; U = Y T ; V = (Z' T)^T          k_lr_apply2                 (U = orth(Y), V = U^T D without re-reading D)
 //   new_base = base + fp16(U16 V16)                   k_lr_decode   (the receiver's kernel, run on the sender's packet)
 //
 // orth() is Cholesky-QR with the r x r Gram matrix accumulated and factorised in fp64 (Z = Q R, R = chol(Z^T Z)^T): the
@@ -21,14 +21,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <algorithm>
 #include "cfx.h"
 #include "cfx_internal.h"
 #include "cfx_lr.h"
 
 // workspace carve-up (per tensor), all offsets 256-byte aligned
 struct LrWs {
-    size_t D, Qa, Zb, Y, Gp, T, U16, V16, Uq, Vq, Vsec, gram, total;
+    size_t D, Qa, Zb, Y, Gp, T, U16, V16, Uq, Vq, Vsec, Zp, tick, Ymax, gram, total;
 };
+#define LR_NS_MAX 8            // row splits of Z = D^T Y (k_lr_aty): partial tiles of up to 8 workgroups, summed by the last to arrive
+// Row splits of Z = D^T Y: enough workgroups to fill the machine (a column tile x all N is C / 32 workgroups a tensor - 72 for K,V of
+// (4096, 1152), each walking 4096 rows: 50 us), at least two 128-row chunks each.
+static int lr_aty_splits(int N, int C, int batch) {
+    const int tiles = ((C + 31) / 32) * batch;
+    int ns = (768 + tiles - 1) / tiles;
+    ns = std::min(ns, std::min(LR_NS_MAX, N / 256));
+    return std::max(ns, 1);
+}
 static LrWs lr_layout(int N, int C, int RP) {
     LrWs w;
     size_t o = 0;
@@ -43,6 +53,9 @@ static LrWs lr_layout(int N, int C, int RP) {
     w.Uq = o;  o += al256((size_t)N * RP * 2 + 256);
     w.Vq = o;  o += al256((size_t)C * RP * 2 + 256);
     w.Vsec = o; o += al256((size_t)C * RP / 2 + 4 * RP + 256);
+    w.Zp = o;  o += al256((size_t)lr_aty_splits(N, C, 1) * C * RP * 4);     // (batch 1: the most splits a tensor can get)
+    w.tick = o; o += al256((size_t)((C + 31) / 32) * 4);
+    w.Ymax = o; o += al256((size_t)((N + 31) / 32) * 4 * 4);               // one float per workgroup of k_lr_aq
     w.gram = o; o += cfx_i_lrg_extra_bytes(N, C, RP);       // the N-space chain's Gram matrix, N x r intermediates (0 when it does not apply)
     w.total = o;
     return w;
@@ -50,32 +63,44 @@ static LrWs lr_layout(int N, int C, int RP) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Ypart[g] (N x RP) = D[:, cols of group g] . Q[cols of group g, :]      Y = sum of the 4 group partials (summed, in fixed
-// order, by whoever reads Y).  grid (ceil(N/32), 4, batch): a workgroup owns 32 rows x every 4th 256-column chunk.
-// fp32-input MFMA (v_mfma_f32_32x32x2_f32 = exact fp32 FMA chain): A[i][kk] = D[n0+i][c], B[kk][j] = Q[c][j].  The D and Q
-// chunks are staged through LDS with coalesced 16-byte loads (next chunk prefetched into registers while the current one is
-// multiplied); each of the 4 waves takes 64 of the chunk's 256 columns and the 4 partial tiles are summed in fixed order.
+// order, by whoever reads Y).  grid (ceil(N/32), g, batch), g = 1, 2 or 4 column groups: a workgroup owns 32 rows x every g-th 256-column chunk.
+// v_mfma_f32_32x32x16_f16: A = D (fp16 as it is: exact), B = Q as fp16 hi + lo (two instructions; Q scaled by 16 so that the lo halves
+// of an orthonormal basis's entries stay normal numbers - Q0 ~ randn and |Q| <= 1 afterwards are far from fp16's range), fp32 sums: 22
+// bits of Q instead of the 24 an fp32-input MFMA keeps, at an eighth of its issue time - the pass was bound by v_mfma_f32_32x32x2_f32
+// (2 N C 32 flops whatever the rank: 8 us of MFMA for K,V of (4096, 1152)).  The D and Q chunks go through LDS (D rows as they are, Q
+// transposed: an operand is 8 consecutive k of one row / column); the next chunk's loads are in flight while this one is multiplied;
+// each of the 4 waves takes 64 of the chunk's 256 columns and the 4 partial tiles are summed in fixed order.
+// Also written: the largest |entry| of this workgroup's partial (Ymax, one slot a workgroup) - k_lr_aty scales Y into fp16's range by it.
 // ---------------------------------------------------------------------------------------------------------------------
 // FROMX (the first product of a chain): D = x - base is formed on the fly (fp16, one rounding, as torch eager) and written to the
 //   workspace for the later passes - every element of D is read by exactly one workgroup here, so k_lr_prep is not needed.
+#define LR_Q_SCALE 16.f
 template <int RP, bool FROMX>
-__global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t offD, size_t offQ, size_t offY, int use_q0, int absd) {
-    constexpr int CK = 256, LDD = CK + 2;            // LDD/2 = 129 dwords: odd row stride -> conflict-free column reads
-    constexpr int QV = CK * RP / 4 / 256;            // float4 of Q per thread per chunk (8 at RP = 32)
+__global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t offD, size_t offQ, size_t offY, int use_q0, int absd, size_t offTick,
+                                               size_t offYmax) {
+    constexpr int CK = 256, LDD = CK + 8;            // 528-byte rows: 16-byte aligned operands
+    constexpr int QI = (CK / 2) * (RP / 4) / 256;    // (column pair, 4 ranks) items of the Q chunk per thread (4 at RP = 32)
     const LrItem it = b.it[blockIdx.z];
     h16* D = (h16*)(it.ws + offD);
     const float* Q = use_q0 ? it.q0 : (const float*)(it.ws + offQ);
     float* Y = (float*)(it.ws + offY) + (size_t)blockIdx.y * N * RP;
-    __shared__ h16 dsm[32 * LDD];                    // 16.1 KB
-    __shared__ float qs[CK * RP > 4 * 32 * 33 ? CK * RP : 4 * 32 * 33];   // 32 KB at RP = 32; reused for the wave partials
-    float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(qs);
+    __shared__ __attribute__((aligned(16))) h16 dsm[32 * LDD];                    // 16.5 KB
+    __shared__ __attribute__((aligned(16))) h16 qsm[2 * 32 * LDD];                // Q^T hi | lo: [rank][column], 33 KB; reused for the wave partials
+    float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(qsm);              // 4 x 32 x 33 floats = 16.5 KB
+    __shared__ float wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
     const int n0 = blockIdx.x * 32;
+    if (FROMX && blockIdx.x == 0 && blockIdx.y == 0) {      // the chain's first launch: k_lr_aty's tickets start at zero
+        unsigned* tick = (unsigned*)(it.ws + offTick);
+        for (int i = tid; i < (C + 31) / 32; i += 256) tick[i] = 0u;
+    }
+    for (int i = tid; i < 2 * 32 * LDD / 8; i += 256) reinterpret_cast<h16x8*>(qsm)[i] = (h16x8)(h16)0;     // ranks >= RP: zero columns of B
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     h16x8 dreg[4];
-    float4 qreg[QV];
+    float4 qreg[QI][2];
     auto load_chunk = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                // 32 rows x 32 sixteen-byte pieces
@@ -98,134 +123,258 @@ __global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t o
             }
         }
 #pragma unroll
-        for (int u = 0; u < QV; ++u) {
-            const int i = tid + 256 * u, rr = i / (RP / 4), k4 = i - rr * (RP / 4);
-            qreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c0 + rr < C) qreg[u] = *reinterpret_cast<const float4*>(Q + (size_t)(c0 + rr) * RP + 4 * k4);
+        for (int u = 0; u < QI; ++u) {               // columns 2 cp, 2 cp + 1 (C is even), ranks 4 k4 .. + 3
+            const int i = tid + 256 * u, cp = i / (RP / 4), k4 = i - cp * (RP / 4);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                qreg[u][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + 2 * cp + h < C) qreg[u][h] = *reinterpret_cast<const float4*>(Q + (size_t)(c0 + 2 * cp + h) * RP + 4 * k4);
+            }
         }
     };
+    const int cstep = gridDim.y * CK;                // (1, 2 or 4 column groups: the host's choice - enough workgroups, as few partials as that allows)
     int c0 = blockIdx.y * CK;
     if (c0 < C) load_chunk(c0);
-    for (; c0 < C; c0 += 4 * CK) {
+    for (; c0 < C; c0 += cstep) {
         __syncthreads();                             // previous chunk fully consumed
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = tid + 256 * u, rr = i >> 5, pc = (i & 31) * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dsm[rr * LDD + pc + e] = dreg[u][e];
+            *reinterpret_cast<h16x8*>(&dsm[rr * LDD + pc]) = dreg[u];
         }
 #pragma unroll
-        for (int u = 0; u < QV; ++u) *reinterpret_cast<float4*>(&qs[(tid + 256 * u) * 4]) = qreg[u];
+        for (int u = 0; u < QI; ++u) {
+            const int i = tid + 256 * u, cp = i / (RP / 4), k4 = i - cp * (RP / 4);
+            const float* q0p = reinterpret_cast<const float*>(&qreg[u][0]);
+            const float* q1p = reinterpret_cast<const float*>(&qreg[u][1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a0 = q0p[e] * LR_Q_SCALE, a1 = q1p[e] * LR_Q_SCALE;
+                const h16 h0 = (h16)a0, h1 = (h16)a1;
+                h16x2 hi, lo;
+                hi[0] = h0; hi[1] = h1;
+                lo[0] = (h16)(a0 - (float)h0); lo[1] = (h16)(a1 - (float)h1);
+                *reinterpret_cast<h16x2*>(&qsm[(4 * k4 + e) * LDD + 2 * cp]) = hi;
+                *reinterpret_cast<h16x2*>(&qsm[(32 + 4 * k4 + e) * LDD + 2 * cp]) = lo;
+            }
+        }
         __syncthreads();
-        if (c0 + 4 * CK < C) load_chunk(c0 + 4 * CK);   // in flight while this chunk is multiplied
+        if (c0 + cstep < C) load_chunk(c0 + cstep);  // in flight while this chunk is multiplied
         const int cw = w * 64;                       // this wave's 64 columns of the chunk
-#pragma unroll 8
-        for (int m = 0; m < 32; ++m) {
-            const int c = cw + 2 * m + lk;
-            const float av = (float)dsm[li * LDD + c];
-            const float bv = (li < RP) ? qs[c * RP + li] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const h16x8 av = *reinterpret_cast<const h16x8*>(&dsm[li * LDD + cw + kk * 16 + lk * 8]);
+            const h16x8 bh = *reinterpret_cast<const h16x8*>(&qsm[li * LDD + cw + kk * 16 + lk * 8]);
+            const h16x8 bl = *reinterpret_cast<const h16x8*>(&qsm[(32 + li) * LDD + cw + kk * 16 + lk * 8]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl, acc, 0, 0, 0);
         }
     }
-    __syncthreads();                                 // every wave is done reading qs before it becomes `red`
+    __syncthreads();                                 // every wave is done reading qsm before it becomes `red`
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) red[w][(rg & 3) + 8 * (rg >> 2) + 4 * lk][li] = acc[rg];
     __syncthreads();
+    float mx = 0.f;
     for (int i = tid; i < 32 * RP; i += 256) {
         const int rr = i / RP, k = i - rr * RP;
-        const float sum = ((red[0][rr][k] + red[1][rr][k]) + red[2][rr][k]) + red[3][rr][k];
-        if (n0 + rr < N) Y[(size_t)(n0 + rr) * RP + k] = sum;
+        const float sum = (((red[0][rr][k] + red[1][rr][k]) + red[2][rr][k]) + red[3][rr][k]) * (1.f / LR_Q_SCALE);
+        if (n0 + rr < N) { Y[(size_t)(n0 + rr) * RP + k] = sum; mx = fmaxf(mx, fabsf(sum)); }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) wmax[w] = mx;
+    __syncthreads();
+    if (tid == 0) ((float*)(it.ws + offYmax))[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Z (C x RP) = D^T (C x N) . Y (N x RP)      the one GEMM-shaped step with a long inner dimension (K = N): fp32-input MFMA
-// (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain, operands straight from L2 in the instruction's own layout, no LDS).
-//   workgroup = one 32-column tile of D x all N; its 4 waves split N, partial 32x32 tiles are summed in fixed order.
-//   lane l feeds A[i = l&31][k = l>>5] = D[n + (l>>5)][c0 + (l&31)]  and  B[k = l>>5][j = l&31] = Y[n + (l>>5)][l&31]
-//   (Y = fixed-order sum of the 4 column-group slabs k_lr_aq wrote).  Epilogue: this tile's part of the r x r Gram matrix
+// Z (C x RP) = D^T (C x N) . Y (N x RP)      the one GEMM-shaped step with a long inner dimension (K = N).
+//   v_mfma_f32_32x32x16_f16: A[i][k] = D[n + k][c0 + i] (fp16 as it is), B[k][j] = Y[n + k][j] as fp16 hi + lo of Y scaled by a power of
+//   two that brings its largest entry below 1 (from k_lr_aq's per-workgroup maxima; exact, undone on the result): 22 bits of Y instead
+//   of an fp32-input MFMA's 24, at an eighth of its issue time.  An operand is 8 consecutive k - rows of D and Y - of one column: both
+//   chunks are staged TRANSPOSED in LDS (two rows a thread, one 4-byte write per column).
+//   workgroup = one 32-column tile of D x its share of N (blockIdx.z); its 4 waves split a 128-row chunk, partial 32x32 tiles are summed
+//   in fixed order.  (Y = fixed-order sum of the 4 column-group slabs k_lr_aq wrote.)  Epilogue: this tile's part of the r x r Gram matrix
 //   in fp64.  gram_mode 0: Ztile^T Ztile ; 1: Qtile^T Ztile (Q = the orthonormal basis Y was formed with).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int RP>
-__global__ __launch_bounds__(256) void k_lr_aty(LrBatch b, int N, int C, size_t offD, size_t offY, size_t offZ, size_t offQ, size_t offG, int gram_mode) {
-    constexpr int NCH = 128;                         // rows of D / Y per chunk: each wave multiplies 32 of them (16 MFMAs)
-    constexpr int YV = NCH * RP / 4 / 256;           // float4 positions of the Y chunk per thread (4 at RP = 32)
+__global__ __launch_bounds__(256) void k_lr_aty(LrBatch b, int N, int C, size_t offD, size_t offY, size_t offZ, size_t offQ, size_t offG, int gram_mode,
+                                                size_t offZp, size_t offTick, int rows_per_split, size_t offYmax, int nymax, int ny) {
+    constexpr int NCH = 128, LDT = NCH + 8;          // rows of D / Y per chunk: each wave multiplies 32 of them; 272-byte LDS rows
+    constexpr int YI = (NCH / 2) * (RP / 4) / 256 > 0 ? (NCH / 2) * (RP / 4) / 256 : 1;     // (row pair, 4 ranks) items per thread (2 at RP = 32)
+    constexpr int YN = (NCH / 2) * (RP / 4);         // items of a chunk (128 at RP = 8: half the threads)
     const LrItem it = b.it[blockIdx.y];
     const h16* D = (const h16*)(it.ws + offD);
     const float* Y = (const float*)(it.ws + offY);
     float* Z = (float*)(it.ws + offZ);
     const float* Qb = (const float*)(it.ws + offQ);
-    double* Gp = (double*)(it.ws + offG) + (size_t)blockIdx.x * RP * RP;
-    __shared__ h16 dsm[NCH][34];                     // 8.5 KB; 17-dword rows: conflict-free row-pair reads
-    __shared__ float ys[NCH * RP];                   // 16 KB at RP = 32
+    // column tiles 2j and 2j + 1 share every 128-byte line of D: workgroups i and i + 8 of a run of 16 take them - the same XCD, whose L2
+    // then serves the line's second half (workgroups go to the XCDs round-robin)
+    int tx = blockIdx.x;
+    if ((tx | 15) < (int)gridDim.x) tx = (tx & ~15) + 2 * (tx & 7) + ((tx >> 3) & 1);
+    double* Gp = (double*)(it.ws + offG) + (size_t)tx * RP * RP;
+    __shared__ __attribute__((aligned(16))) h16 dT[32 * LDT];                      // D chunk transposed [column][row]: 8.5 KB
+    __shared__ __attribute__((aligned(16))) h16 yT[2 * 32 * LDT];                  // Y chunk transposed, hi | lo: [rank][row], 17 KB
     __shared__ float red[4][32][33];
+    __shared__ float wmax[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int c0 = blockIdx.x * 32;
+    const int c0 = tx * 32;
     const int li = lane & 31, lk = lane >> 5;
     const size_t slab = (size_t)N * RP;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     h16x8 dreg[2];
-    float4 yreg[YV];
+    float4 yreg[YI][2];
+    const int nlim = min(N, (int)(blockIdx.z + 1) * rows_per_split);
     auto load_chunk = [&](int nb) {
+        {                                            // rows 2 rp, 2 rp + 1 of the chunk, 8 columns
+            const int rp = tid >> 2, pc = (tid & 3) * 8;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {                // 128 rows x 4 sixteen-byte pieces (32 columns)
-            const int i = tid + 256 * u, rr = i >> 2, pc = (i & 3) * 8;
-            dreg[u] = (h16x8)(h16)0;
-            if (nb + rr < N && c0 + pc < C) dreg[u] = *reinterpret_cast<const h16x8*>(D + (size_t)(nb + rr) * C + c0 + pc);
+            for (int h = 0; h < 2; ++h) {
+                dreg[h] = (h16x8)(h16)0;
+                if (nb + 2 * rp + h < nlim && c0 + pc < C) dreg[h] = *reinterpret_cast<const h16x8*>(D + (size_t)(nb + 2 * rp + h) * C + c0 + pc);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < YV; ++u) {
-            const int i = tid + 256 * u, rr = i / (RP / 4);
-            yreg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (nb + rr < N) {
-                const float* yp = Y + (size_t)nb * RP + (size_t)i * 4;
-                const float4 s0 = *reinterpret_cast<const float4*>(yp), s1 = *reinterpret_cast<const float4*>(yp + slab);
-                const float4 s2 = *reinterpret_cast<const float4*>(yp + 2 * slab), s3 = *reinterpret_cast<const float4*>(yp + 3 * slab);
-                yreg[u] = make_float4(((s0.x + s1.x) + s2.x) + s3.x, ((s0.y + s1.y) + s2.y) + s3.y,
-                                      ((s0.z + s1.z) + s2.z) + s3.z, ((s0.w + s1.w) + s2.w) + s3.w);   // fixed order
+        for (int u = 0; u < YI; ++u) {
+            const int i = tid + 256 * u, rp = i / (RP / 4), k4 = i - rp * (RP / 4);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                yreg[u][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < YN && nb + 2 * rp + h < nlim) {
+                    const float* yp = Y + (size_t)(nb + 2 * rp + h) * RP + 4 * k4;
+                    float4 sv = *reinterpret_cast<const float4*>(yp);
+                    if (ny > 1) {                    // (uniform) the column groups' partials, in fixed order
+                        const float4 s1 = *reinterpret_cast<const float4*>(yp + slab);
+                        sv = make_float4(sv.x + s1.x, sv.y + s1.y, sv.z + s1.z, sv.w + s1.w);
+                        if (ny > 2) {
+                            const float4 s2 = *reinterpret_cast<const float4*>(yp + 2 * slab), s3 = *reinterpret_cast<const float4*>(yp + 3 * slab);
+                            sv = make_float4((sv.x + s2.x) + s3.x, (sv.y + s2.y) + s3.y, (sv.z + s2.z) + s3.z, (sv.w + s2.w) + s3.w);
+                        }
+                    }
+                    yreg[u][h] = sv;
+                }
             }
         }
     };
-    load_chunk(0);
-    for (int nb = 0; nb < N; nb += NCH) {
+    // blockIdx.z: this workgroup's share of the rows (a multiple of NCH); the last of a column tile's workgroups to arrive sums the
+    // partial tiles in split order (bits do not depend on who is last) and goes on to the tile's Gram part
+    const int NS = gridDim.z, nbeg = blockIdx.z * rows_per_split, nend = min(N, nbeg + rows_per_split);
+    load_chunk(nbeg);
+    // the power of two that brings |Y| below 1: Y is the sum of the column groups' partials, each workgroup of k_lr_aq left the largest
+    // |entry| of its own
+    float ysc, yinv;
+    {
+        const float* ym = (const float*)(it.ws + offYmax);
+        float mx = 0.f;
+        for (int i = tid; i < nymax; i += 256) mx = fmaxf(mx, ym[i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if (lane == 0) wmax[w] = mx;
+        for (int i = tid; i < 2 * 32 * LDT / 8; i += 256) reinterpret_cast<h16x8*>(yT)[i] = (h16x8)(h16)0;        // ranks >= RP: zero columns of B
         __syncthreads();
+        const float bound = (float)ny * fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        int e = 0;
+        if (bound > 0.f && bound < 3.0e38f) (void)frexpf(bound, &e);
+        e = max(-100, min(100, e));
+        ysc = ldexpf(1.f, -e); yinv = ldexpf(1.f, e);
+    }
+    for (int nb = nbeg; nb < nend; nb += NCH) {
+        __syncthreads();
+        {
+            const int rp = tid >> 2, pc = (tid & 3) * 8;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = tid + 256 * u, rr = i >> 2, pc = (i & 3) * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dsm[rr][pc + e] = dreg[u][e];
+            for (int e = 0; e < 8; ++e) {
+                h16x2 v; v[0] = dreg[0][e]; v[1] = dreg[1][e];
+                *reinterpret_cast<h16x2*>(&dT[(pc + e) * LDT + 2 * rp]) = v;
+            }
         }
 #pragma unroll
-        for (int u = 0; u < YV; ++u) *reinterpret_cast<float4*>(&ys[(tid + 256 * u) * 4]) = yreg[u];
+        for (int u = 0; u < YI; ++u) {
+            const int i = tid + 256 * u, rp = i / (RP / 4), k4 = i - rp * (RP / 4);
+            if (i < YN) {
+                const float* y0p = reinterpret_cast<const float*>(&yreg[u][0]);
+                const float* y1p = reinterpret_cast<const float*>(&yreg[u][1]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = y0p[e] * ysc, a1 = y1p[e] * ysc;
+                    const h16 h0 = (h16)a0, h1 = (h16)a1;
+                    h16x2 hi, lo;
+                    hi[0] = h0; hi[1] = h1;
+                    lo[0] = (h16)(a0 - (float)h0); lo[1] = (h16)(a1 - (float)h1);
+                    *reinterpret_cast<h16x2*>(&yT[(4 * k4 + e) * LDT + 2 * rp]) = hi;
+                    *reinterpret_cast<h16x2*>(&yT[(32 + 4 * k4 + e) * LDT + 2 * rp]) = lo;
+                }
+            }
+        }
         __syncthreads();
-        if (nb + NCH < N) load_chunk(nb + NCH);      // in flight while this chunk is multiplied
-#pragma unroll 8
-        for (int m = 0; m < 16; ++m) {
-            const int rr = w * 32 + 2 * m + lk;      // rows beyond N were staged as zeros
-            const float av = (float)dsm[rr][li];
-            const float bv = (li < RP) ? ys[rr * RP + li] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        if (nb + NCH < nend) load_chunk(nb + NCH);   // in flight while this chunk is multiplied
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {             // this wave's 32 rows of the chunk (rows beyond the share were staged as zeros)
+            const int r8 = w * 32 + kk * 16 + lk * 8;
+            const h16x8 av = *reinterpret_cast<const h16x8*>(&dT[li * LDT + r8]);
+            const h16x8 bh = *reinterpret_cast<const h16x8*>(&yT[li * LDT + r8]);
+            const h16x8 bl = *reinterpret_cast<const h16x8*>(&yT[(32 + li) * LDT + r8]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bl, acc, 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] *= yinv;
     // C/D layout: column j = lane & 31, row i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) red[w][(rg & 3) + 8 * (rg >> 2) + 4 * lk][li] = acc[rg];
     __syncthreads();
-    for (int i = tid; i < 32 * 32; i += 256) {
-        const int cc = i >> 5, k = i & 31;
-        const float s = ((red[0][cc][k] + red[1][cc][k]) + red[2][cc][k]) + red[3][cc][k];
-        red[0][cc][k] = s;          // (cc, k) is read and written by this thread only
-        if (c0 + cc < C && k < RP) Z[(size_t)(c0 + cc) * RP + k] = s;
+    if (NS == 1) {
+        for (int i = tid; i < 32 * 32; i += 256) {
+            const int cc = i >> 5, k = i & 31;
+            const float s = ((red[0][cc][k] + red[1][cc][k]) + red[2][cc][k]) + red[3][cc][k];
+            red[0][cc][k] = s;          // (cc, k) is read and written by this thread only
+            if (c0 + cc < C && k < RP) Z[(size_t)(c0 + cc) * RP + k] = s;
+        }
+    } else {
+        float* Zp = (float*)(it.ws + offZp);
+        for (int i = tid; i < 32 * RP; i += 256) {
+            const int cc = i / RP, k = i - cc * RP;
+            const float s = ((red[0][cc][k] + red[1][cc][k]) + red[2][cc][k]) + red[3][cc][k];
+            if (c0 + cc < C) __hip_atomic_store(&Zp[((size_t)blockIdx.z * C + c0 + cc) * RP + k], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // publish: every storing wave drains its write-through stores, then one lane draws the tile's ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ int last_flag;
+        if (tid == 0) {
+            unsigned* tick = (unsigned*)(it.ws + offTick) + tx;
+            const unsigned old = __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = old == (unsigned)(NS - 1);
+            if (last_flag) __hip_atomic_store(tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // self-resetting
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        for (int i = tid; i < 32 * RP; i += 256) {
+            const int cc = i / RP, k = i - cc * RP;
+            float pv[LR_NS_MAX];
+#pragma unroll
+            for (int t = 0; t < LR_NS_MAX; ++t)       // every load unconditional and in flight together (clamped split, masked value)
+                pv[t] = __hip_atomic_load(&Zp[((size_t)min(t, NS - 1) * C + min(c0 + cc, C - 1)) * RP + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < LR_NS_MAX; ++t) s += (t < NS) ? pv[t] : 0.f;                              // fixed order
+            if (c0 + cc >= C) s = 0.f;
+            red[0][cc][k] = s;
+            if (c0 + cc < C) Z[(size_t)(c0 + cc) * RP + k] = s;
+        }
     }
+    float* qt = reinterpret_cast<float*>(yT);        // the tile's 32 rows of Q (gram_mode 1): one load a thread instead of 32 dependent ones
+    if (gram_mode)
+        for (int i = tid; i < 32 * RP; i += 256) qt[i] = (c0 + i / RP < C) ? Qb[(size_t)c0 * RP + i] : 0.f;
     __syncthreads();
     for (int i = tid; i < RP * RP; i += 256) {
         const int a = i / RP, bb = i - a * RP;
         double g = 0.0;
         if (gram_mode) {
-            for (int cc = 0; cc < 32; ++cc)
-                if (c0 + cc < C) g += (double)Qb[(size_t)(c0 + cc) * RP + a] * (double)red[0][cc][bb];
+            for (int cc = 0; cc < 32; ++cc) g += (double)qt[cc * RP + a] * (double)red[0][cc][bb];     // (rows beyond C: zeros)
         } else {
             for (int cc = 0; cc < 32; ++cc)
                 if (c0 + cc < C) g += (double)red[0][cc][a] * (double)red[0][cc][bb];
@@ -235,85 +384,76 @@ __global__ __launch_bounds__(256) void k_lr_aty(LrBatch b, int N, int C, size_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// T (RP x RP fp32, upper triangular) = chol(G)^-T with G = sum of the partial Grams (fp64), symmetrised; rank = r <= RP.
-// A non-positive pivot (rank-deficient residual, e.g. x == base) zeroes that direction instead of producing NaNs.
+// The factor every k_lr_apply2 workgroup needs, formed BY every workgroup (no launch of its own, nobody waits for a broadcast - what the
+// slab-resident chain does with everything r x r sized): G = sum of the column tiles' partial Grams (fp64, fixed order: the same bits in
+// every workgroup), symmetrised, factorised in one wave's registers (cfx_lr.h); ts (LDS, fp32) = L row-major with 1 / L[j][j] ON the
+// diagonal (0 for a dropped direction - a non-positive pivot of a rank-deficient residual, e.g. x == base: its column of the result is
+// zero instead of NaNs).  No triangular inverse: the caller solves Out L^T = In row by row.  256 threads.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int RP>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lr_chol(LrBatch b, int r, int nparts, size_t offG, size_t offT) {
-    const LrItem it = b.it[blockIdx.x];
-    const double* Gp = (const double*)(it.ws + offG);
-    float* T = (float*)(it.ws + offT);
+__device__ __forceinline__ void lr_factor_to_lds(const double* Gp, int nparts, int r, float* ts) {
+    constexpr int E = RP * RP, GRP = (256 / E) > 0 ? (256 / E) : 1, EPT = (E + 255) / 256, U = 8;
     __shared__ double G[RP][RP + 1];
+    __shared__ double part[GRP][E];
     const int tid = threadIdx.x;
     {
-        // 512 threads reduce the partial Grams: element e, part group g, 8 independent loads in flight each
-        // (512, not 1024, threads: the single-wave factorisation below needs > 128 registers per lane)
-        constexpr int E = RP * RP, GRP = (512 / E) > 0 ? (512 / E) : 1, EPT = (E + 511) / 512;
-        __shared__ double part[GRP][E];
-        {
-            constexpr int U = (EPT > 1) ? 24 : 12;   // parts in flight per element (r = 32: 192 loads per thread, 8 round trips instead of 16)
-            const int e0 = tid % (E < 512 ? E : 512), g = (E < 512) ? tid / E : 0;
-            double a[EPT][U];
+        const int e0 = tid % (E < 256 ? E : 256), g = (E < 256) ? tid / E : 0;
+        double a[EPT][U];
 #pragma unroll
-            for (int q = 0; q < EPT; ++q)
+        for (int q = 0; q < EPT; ++q)
 #pragma unroll
-                for (int u = 0; u < U; ++u) a[q][u] = 0.0;
-            if (g < GRP) {
-                int p = g;
-                for (; p + (U - 1) * GRP < nparts; p += U * GRP) {
+            for (int u = 0; u < U; ++u) a[q][u] = 0.0;
+        if (g < GRP) {
+            int p = g;
+            for (; p + (U - 1) * GRP < nparts; p += U * GRP) {
 #pragma unroll
-                    for (int q = 0; q < EPT; ++q)
+                for (int q = 0; q < EPT; ++q)
 #pragma unroll
-                        for (int u = 0; u < U; ++u) a[q][u] += Gp[(size_t)(p + u * GRP) * E + e0 + q * 512];
-                }
-                for (; p < nparts; p += GRP) {
-#pragma unroll
-                    for (int q = 0; q < EPT; ++q) a[q][0] += Gp[(size_t)p * E + e0 + q * 512];
-                }
-#pragma unroll
-                for (int q = 0; q < EPT; ++q) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int u = 0; u < U; ++u) t += a[q][u];
-                    part[g][e0 + q * 512] = t;
-                }
+                    for (int u = 0; u < U; ++u) a[q][u] += Gp[(size_t)(p + u * GRP) * E + e0 + q * 256];
             }
-        }
-        __syncthreads();
-        for (int e = tid; e < E; e += 512) {
-            double t = 0.0;
+            for (; p < nparts; p += GRP) {
 #pragma unroll
-            for (int q = 0; q < GRP; ++q) t += part[q][e];
-            G[e / RP][e % RP] = t;
+                for (int q = 0; q < EPT; ++q) a[q][0] += Gp[(size_t)p * E + e0 + q * 256];
+            }
+#pragma unroll
+            for (int q = 0; q < EPT; ++q) {
+                double t = 0.0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) t += a[q][u];
+                part[g][e0 + q * 256] = t;
+            }
         }
     }
     __syncthreads();
-    // The factor only (one wave, branch-free: cfx_lr.h), no triangular inverse: k_lr_apply2 solves Out L^T = In row by row.  What it
-    // reads from T: L row-major with 1 / L[j][j] ON the diagonal (0 for a dropped direction: its column of the result is zero).
-    // (The routine with the explicit inverse took 25 of this kernel's 36 us at r = 32.)
+    for (int e = tid; e < E; e += 256) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < GRP; ++q) t += part[q][e];
+        G[e / RP][e % RP] = t;
+    }
+    __syncthreads();
     if (tid < 64) {
         double g[RP], myinv;
         const unsigned dead = lr_chol_rows<RP>(G, r, 1e-13, false, g, myinv);
         if (tid < RP) {
 #pragma unroll
-            for (int k = 0; k < RP; ++k) T[tid * RP + k] = (k == tid) ? (((dead >> tid) & 1u) ? 0.f : (float)myinv) : (float)g[k];
+            for (int k = 0; k < RP; ++k) ts[tid * RP + k] = (k == tid) ? (((dead >> tid) & 1u) ? 0.f : (float)myinv) : (float)g[k];
         }
     }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Out = In (rows x RP fp32) . chol(G)^-T   one thread per row (the factor from k_lr_chol).
+// Out = In (rows x RP fp32) . chol(G)^-T   one thread per row (the factor: lr_factor_to_lds, by the workgroup itself).
 //   mode 0: fp32 rows x RP (the next Q) ; mode 1: fp16 rows x r, row-major (U, or V^T for LOW_RANK_Q) ;
 //   mode 2: fp16 r x rows, i.e. transposed (V in the LOW_RANK wire layout)
 // ---------------------------------------------------------------------------------------------------------------------
-struct LrApply { int rows, r, in_slabs, mode, out_in_packet; size_t offIn, offT, offOut, pkt_off_halves; };
+struct LrApply { int rows, r, in_slabs, mode, out_in_packet; size_t offIn, offG, offOut, pkt_off_halves; };
 template <int RP>
-__device__ __forceinline__ void lr_apply_body(const LrItem& it, int bx, int rows, int r, size_t offIn, int in_slabs, size_t offT, int mode,
+__device__ __forceinline__ void lr_apply_body(const LrItem& it, int bx, int rows, int r, size_t offIn, int in_slabs, size_t offG, int nparts, int mode,
                                               size_t offOut, int out_in_packet, size_t pkt_off_halves, float* ts) {
     const float* In = (const float*)(it.ws + offIn);
-    const float* T = (const float*)(it.ws + offT);
-    for (int i = threadIdx.x; i < RP * RP; i += 256) ts[i] = T[i];
-    __syncthreads();
+    lr_factor_to_lds<RP>((const double*)(it.ws + offG), nparts, r, ts);
     const int row = bx * 256 + threadIdx.x;
     if (row >= rows) return;
     float in[RP], out[RP];
@@ -324,7 +464,7 @@ __device__ __forceinline__ void lr_apply_body(const LrItem& it, int bx, int rows
         for (int p = 1; p < in_slabs; ++p) v += In[(size_t)p * slab + (size_t)row * RP + k];     // fixed order
         in[k] = v;
     }
-    // Out = In L^-T by forward substitution (ts: L with 1 / diagonal on the diagonal, k_lr_chol); a row of L is read as 16-byte broadcasts
+    // Out = In L^-T by forward substitution (ts: L with 1 / diagonal on the diagonal); a row of L is read as 16-byte broadcasts
 #pragma unroll
     for (int j = 0; j < RP; ++j) {
         float lrow[RP];
@@ -487,11 +627,11 @@ __global__ __launch_bounds__(1024) void k_lr_dq4(LrDq4Batch b, int N, int C, int
 
 // two products by the same factor in one launch (U = Y T and V = Z' T at the end of the chain): blocks [0, nb0) do `a`, the rest `c`
 template <int RP>
-__global__ __launch_bounds__(256) void k_lr_apply2(LrBatch b, LrApply a, LrApply c, int nb0) {
+__global__ __launch_bounds__(256) void k_lr_apply2(LrBatch b, LrApply a, LrApply c, int nb0, int nparts) {
     __shared__ __attribute__((aligned(16))) float ts[RP * RP];
     const bool first = (int)blockIdx.x < nb0;
     const LrApply& p = first ? a : c;
-    lr_apply_body<RP>(b.it[blockIdx.y], first ? blockIdx.x : blockIdx.x - nb0, p.rows, p.r, p.offIn, p.in_slabs, p.offT, p.mode, p.offOut,
+    lr_apply_body<RP>(b.it[blockIdx.y], first ? blockIdx.x : blockIdx.x - nb0, p.rows, p.r, p.offIn, p.in_slabs, p.offG, nparts, p.mode, p.offOut,
                       p.out_in_packet, p.pkt_off_halves, ts);
 }
 
@@ -775,7 +915,15 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
     hipStream_t s = (hipStream_t)stream;
     const size_t E = (size_t)N * C;
     const int nparts = (C + 31) / 32;
-    const dim3 g_aq((N + 31) / 32, 4, batch), g_aty(nparts, batch), g_chol(batch), g_apc((C + 255) / 256, batch), g_apn((N + 255) / 256, batch);
+    const int ns_ = lr_aty_splits(N, C, batch);
+    const int rps = ((N + ns_ - 1) / ns_ + 127) / 128 * 128;          // rows per split: whole 128-row chunks
+    // column groups of Y = D Q (each writes a partial of Y every reader sums): as few as still give the machine a workgroup per CU
+    const int rt_ = ((N + 31) / 32) * batch, gy_ = rt_ >= 256 ? 1 : (rt_ >= 128 ? 2 : 4);
+#ifndef LR_GY0_MUL
+#define LR_GY0_MUL 2
+#endif
+    const int gy0_ = std::min(4, gy_ * LR_GY0_MUL);      // the first product also forms D = x - base: three times the bytes
+    const dim3 g_aq((N + 31) / 32, gy_, batch), g_aq0((N + 31) / 32, gy0_, batch), g_aty(nparts, batch, (N + rps - 1) / rps), g_apc((C + 255) / 256, batch), g_apn((N + 255) / 256, batch);
     // The N-space chain (cfx_lrgram.hip: 5 launches up to the factors) for shards whose Gram matrix is small, else the C-space chain.
     // (rank > 16: the two factorisations the chain's last launch runs back to back in one wave spill at RP = 32 - measured slower than the
     // C-space chain's separate launches)
@@ -790,24 +938,23 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
     } else {
         // D = x - base is formed (and stored) by the first product.  (Forming Q = orth(Z) = Z T inside the next product instead of by a
         // launch of its own was measured slower at every rank: 17 row tiles redo the same RP x RP products per chunk.)
-        const LrApply aq_ = {C, rank, 1, 0, 0, w.Zb, w.T, w.Qa, 0};
+        const LrApply aq_ = {C, rank, 1, 0, 0, w.Zb, w.Gp, w.Qa, 0};
         for (int iter = 0; iter < 2; ++iter) {
-            if (iter == 0) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, true>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 1, absd));
-            else LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0, 0));
-            LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 0));
-            LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(512), 0, s, b, rank, nparts, w.Gp, w.T));
-            LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), g_apc, dim3(256), 0, s, b, aq_, aq_, (int)g_apc.x));
+            if (iter == 0) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, true>), g_aq0, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 1, absd, w.tick, w.Ymax));
+            else LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0, 0, w.tick, w.Ymax));
+            LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 0, w.Zp, w.tick, rps, w.Ymax,
+                                    (int)(g_aq.x * (iter == 0 ? gy0_ : gy_)), iter == 0 ? gy0_ : gy_));
+            LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), g_apc, dim3(256), 0, s, b, aq_, aq_, (int)g_apc.x, nparts));
         }
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0, 0));
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 1));
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_CHOL, s, (k_lr_chol<RP>), g_chol, dim3(512), 0, s, b, rank, nparts, w.Gp, w.T));
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0, 0, w.tick, w.Ymax));
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 1, w.Zp, w.tick, rps, w.Ymax, (int)(g_aq.x * g_aq.y), gy_));
     }
     int rc = CFX_OK;
     LrDec dec[LR_MAXB];
     if (!quantized) {
         // U (N x r) and V (r x C) straight into the packet: [U | V]
-        const LrApply au = {N, rank, 4, 1, 1, w.Y, w.T, 0, 0}, av = {C, rank, 1, 2, 1, w.Zb, w.T, 0, (size_t)N * rank};
-        if (!gram) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), dim3(g_apn.x + g_apc.x, batch), dim3(256), 0, s, b, au, av, (int)g_apn.x));
+        const LrApply au = {N, rank, gy_, 1, 1, w.Y, w.Gp, 0, 0}, av = {C, rank, 1, 2, 1, w.Zb, w.Gp, 0, (size_t)N * rank};
+        if (!gram) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), dim3(g_apn.x + g_apc.x, batch), dim3(256), 0, s, b, au, av, (int)g_apn.x, nparts));
         for (int i = 0; i < batch; ++i) {
             dec[i].U = (const h16*)items[i].packet; dec[i].V = (const h16*)items[i].packet + (size_t)N * rank;
             dec[i].base = (const h16*)items[i].base; dec[i].out = (h16*)items[i].new_base;
@@ -815,8 +962,8 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
     } else {
         // U16 (N x r), V^T16 (C x r) -> int4 factor quantiser (the native int4 kernel) -> packet sections; then the dequantised
         // factors (what the receiver will see) feed the error-feedback decode
-        const LrApply au = {N, rank, 4, 1, 0, w.Y, w.T, w.U16, 0}, av = {C, rank, 1, 1, 0, w.Zb, w.T, w.V16, 0};
-        if (!gram) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), dim3(g_apn.x + g_apc.x, batch), dim3(256), 0, s, b, au, av, (int)g_apn.x));
+        const LrApply au = {N, rank, gy_, 1, 0, w.Y, w.Gp, w.U16, 0}, av = {C, rank, 1, 1, 0, w.Zb, w.Gp, w.V16, 0};
+        if (!gram) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), dim3(g_apn.x + g_apc.x, batch), dim3(256), 0, s, b, au, av, (int)g_apn.x, nparts));
         if (factors_only) return check_launch(ctx, "lr factor launch");
         const size_t secU = (size_t)N * rank / 2 + 4 * rank, secV = (size_t)C * rank / 2 + 4 * rank;       // bytes
         const size_t i4ws_off = w.total;

@@ -23,6 +23,9 @@ def prof(fn, n=10):
     ids = (ctypes.c_int * 4096)(); ms = (ctypes.c_float * 4096)()
     k = lib.cfx_profile_read(ctx, ids, ms, 4096)
     lib.cfx_profile_enable(ctx, 0, 0, 1)
+    if os.environ.get("LR_SEQ"):        # the launches of one call, in order (average over the n calls)
+        per = k // n
+        print("   seq:", " ".join(f"{lib.cfx_kernel_name(ids[j]).decode().split()[0]}={sum(ms[c * per + j] for c in range(n)) / n * 1e3:.1f}" for j in range(per)))
     agg = {}
     for i in range(k): agg.setdefault(lib.cfx_kernel_name(ids[i]).decode(), []).append(ms[i] * 1e3)
     return {a: (round(sum(v) / len(v), 2), len(v) // n) for a, v in agg.items()}
