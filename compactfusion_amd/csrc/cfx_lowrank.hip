@@ -497,16 +497,18 @@ __device__ __forceinline__ void lr_apply_body(const LrItem& it, int bx, int rows
 // round((x - min) / scale) clamped to 0 .. 15, two ROWS per byte) and - want_dq - the factors the receiver will see
 // (q * scale + min, two fp16 roundings: compress_quantize.py:626-636) for the error-feedback decode.  The arithmetic of
 // k_minmax_compress / k_int4_quant / k_int4_dequant applied to a rows x r matrix (bit-identical: tests), without their nine launches and
-// copies for matrices of 17 K and 98 K elements.  grid.x: block 0 = U (N x r), blocks 1 .. LRQ_VS = V^T (C x r) in row shares; every
-// block finds the column statistics of its whole matrix itself (32 columns: cheaper than waiting for each other).
+// copies for matrices of 17 K and 98 K elements.  grid.x: blocks [0, nsu) = U (N x r) in row shares (one for a shard of up to ~1000 rows),
+// the next LRQ_VS = V^T (C x r) in row shares; every block finds the column statistics of its whole matrix itself (32 columns: cheaper
+// than waiting for each other).
 // ---------------------------------------------------------------------------------------------------------------------
 #define LRQ_VS 6
+static inline int lrq_u_shares(int N) { return std::max(1, std::min(8, N / 512)); }
 struct LrQ4 { const h16* U; const h16* V; unsigned char* secU; unsigned char* secV; h16* Uq; h16* Vq; };
 struct LrQ4Batch { LrQ4 it[LR_MAXB]; };
-__global__ __launch_bounds__(1024) void k_lr_q4(LrQ4Batch b, int N, int C, int r, int want_dq) {
+__global__ __launch_bounds__(1024) void k_lr_q4(LrQ4Batch b, int N, int C, int r, int want_dq, int nsu) {
     const LrQ4 it = b.it[blockIdx.y];
-    const bool isu = blockIdx.x == 0;
-    const int R = isu ? N : C, share = isu ? 0 : (int)blockIdx.x - 1, ns = isu ? 1 : LRQ_VS;
+    const bool isu = (int)blockIdx.x < nsu;
+    const int R = isu ? N : C, share = isu ? (int)blockIdx.x : (int)blockIdx.x - nsu, ns = isu ? nsu : LRQ_VS;
     const h16* X = isu ? it.U : it.V;
     unsigned char* sec = isu ? it.secU : it.secV;
     h16* Xq = isu ? it.Uq : it.Vq;
@@ -596,13 +598,13 @@ __global__ __launch_bounds__(1024) void k_lr_q4(LrQ4Batch b, int N, int C, int r
 
 // The receiver's side of k_lr_q4: both int4 factors of every tensor back to fp16 (q * scale + min, two roundings:
 // compress_quantize.py:626-636; the arithmetic of k_int4_dequant) in one launch.  Sections may start at addresses that are only 8-byte
-// aligned: the codes are read 8 bytes at a time.  grid.x: block 0 = U (N x r), blocks 1 .. LRQ_VS = V^T (C x r) in row shares.
+// aligned: the codes are read 8 bytes at a time.  grid.x as k_lr_q4's.
 struct LrDq4 { const unsigned char* secU; const unsigned char* secV; h16* Uq; h16* Vq; };
 struct LrDq4Batch { LrDq4 it[LR_MAXB]; };
-__global__ __launch_bounds__(1024) void k_lr_dq4(LrDq4Batch b, int N, int C, int r) {
+__global__ __launch_bounds__(1024) void k_lr_dq4(LrDq4Batch b, int N, int C, int r, int nsu) {
     const LrDq4 it = b.it[blockIdx.y];
-    const bool isu = blockIdx.x == 0;
-    const int R = isu ? N : C, share = isu ? 0 : (int)blockIdx.x - 1, ns = isu ? 1 : LRQ_VS;
+    const bool isu = (int)blockIdx.x < nsu;
+    const int R = isu ? N : C, share = isu ? (int)blockIdx.x : (int)blockIdx.x - nsu, ns = isu ? nsu : LRQ_VS;
     const unsigned char* sec = isu ? it.secU : it.secV;
     h16* Xq = isu ? it.Uq : it.Vq;
     const int tid = threadIdx.x, oc = r >> 3, cq = tid % oc, rw = tid / oc, rpass = 1024 / oc;
@@ -980,7 +982,7 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
             dec[i].base = (const h16*)items[i].base; dec[i].out = (h16*)items[i].new_base;
         }
         (void)secV; (void)i4ws_off;
-        LAUNCH(ctx, KID_INT4_QUANT, s, k_lr_q4, dim3(1 + LRQ_VS, batch), dim3(1024), 0, s, qb, N, C, rank, (upd && !(flags & CFX_FLAG_NO_EF)) ? 1 : 0);
+        LAUNCH(ctx, KID_INT4_QUANT, s, k_lr_q4, dim3(lrq_u_shares(N) + LRQ_VS, batch), dim3(1024), 0, s, qb, N, C, rank, (upd && !(flags & CFX_FLAG_NO_EF)) ? 1 : 0, lrq_u_shares(N));
     }
     if (upd) {
         if (flags & CFX_FLAG_NO_EF) {
@@ -1027,7 +1029,7 @@ int cfx_lr_decompress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank,
         dec[i].U = (const h16*)(wsi + w.Uq); dec[i].V = (const h16*)(wsi + w.Vq);
         dec[i].base = (const h16*)items[i].base; dec[i].out = (h16*)items[i].recon;
     }
-    LAUNCH(ctx, KID_INT4_DEQUANT, s, k_lr_dq4, dim3(1 + LRQ_VS, batch), dim3(1024), 0, s, qb, N, C, rank);
+    LAUNCH(ctx, KID_INT4_DEQUANT, s, k_lr_dq4, dim3(lrq_u_shares(N) + LRQ_VS, batch), dim3(1024), 0, s, qb, N, C, rank, lrq_u_shares(N));
     return cfx_i_lr_decode_launch(ctx, N, C, rank, batch, dec, true, s);
 }
 

@@ -16,6 +16,13 @@ def t(fn, n=30):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 
+def t_host(fn, n=30):
+    """host time of one call (enqueue only): a chain whose launches take longer to issue than to run is host-bound"""
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    dt = (time.perf_counter() - t0) / n * 1e6
+    torch.cuda.synchronize(); return dt
+
 def prof(fn, n=10):
     lib.cfx_profile_enable(ctx, 4096, 0xffffffff, 1)
     for _ in range(n): fn()
@@ -41,4 +48,4 @@ for (N, C) in [(544, 3072), (512, 1536), (4096, 1152)]:
             f = lambda: K.lr_compress_batch(q, xs, bs, nb, pk, q0, N, C, r, True)
             out = [torch.empty_like(x) for x in xs] * 7
             g = lambda: K.lr_decompress_batch(q, (pk * 7)[:14], (bs * 7)[:14], out[:14], N, C, r)
-            print(f"({N},{C}) q={int(q)} r={r} batch {B}: compress {t(f):7.1f} us | decompress(14) {t(g):7.1f} us | {prof(f)} | {prof(g)}", flush=True)
+            print(f"({N},{C}) q={int(q)} r={r} batch {B}: compress {t(f):7.1f} us (host {t_host(f):5.1f}) | decompress(14) {t(g):7.1f} us | {prof(f)} | {prof(g)}", flush=True)
