@@ -31,11 +31,12 @@ struct LrWs {
     size_t D, Qa, Zb, Y, Gp, T, U16, V16, Uq, Vq, Vsec, Zp, tick, Ymax, gram, total;
 };
 #define LR_NS_MAX 8            // row splits of Z = D^T Y (k_lr_aty): partial tiles of up to 8 workgroups, summed by the last to arrive
+#define LR_NS_TARGET 768       //   ... as many as make ~768 workgroups (measured at (4096, 1152): 4 splits 98.5 us, 8: 92.2, 11: 98.8, 16: 100.6)
 // Row splits of Z = D^T Y: enough workgroups to fill the machine (a column tile x all N is C / 32 workgroups a tensor - 72 for K,V of
 // (4096, 1152), each walking 4096 rows: 50 us), at least two 128-row chunks each.
 static int lr_aty_splits(int N, int C, int batch) {
     const int tiles = ((C + 31) / 32) * batch;
-    int ns = (768 + tiles - 1) / tiles;
+    int ns = (LR_NS_TARGET + tiles - 1) / tiles;
     ns = std::min(ns, std::min(LR_NS_MAX, N / 256));
     return std::max(ns, 1);
 }
@@ -921,9 +922,7 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
     const int rps = ((N + ns_ - 1) / ns_ + 127) / 128 * 128;          // rows per split: whole 128-row chunks
     // column groups of Y = D Q (each writes a partial of Y every reader sums): as few as still give the machine a workgroup per CU
     const int rt_ = ((N + 31) / 32) * batch, gy_ = rt_ >= 256 ? 1 : (rt_ >= 128 ? 2 : 4);
-#ifndef LR_GY0_MUL
-#define LR_GY0_MUL 2
-#endif
+#define LR_GY0_MUL 2          // (measured at (4096, 1152): x1 20.6 + 11.9 us for the first two launches, x2 16.5 + 13.7, x4 15.0 + 15.8)
     const int gy0_ = std::min(4, gy_ * LR_GY0_MUL);      // the first product also forms D = x - base: three times the bytes
     const dim3 g_aq((N + 31) / 32, gy_, batch), g_aq0((N + 31) / 32, gy0_, batch), g_aty(nparts, batch, (N + rps - 1) / rps), g_apc((C + 255) / 256, batch), g_apn((N + 255) / 256, batch);
     // The N-space chain (cfx_lrgram.hip: 5 launches up to the factors) for shards whose Gram matrix is small, else the C-space chain.
