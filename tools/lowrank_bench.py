@@ -37,7 +37,7 @@ def prof(fn, n=10):
     for i in range(k): agg.setdefault(lib.cfx_kernel_name(ids[i]).decode(), []).append(ms[i] * 1e3)
     return {a: (round(sum(v) / len(v), 2), len(v) // n) for a, v in agg.items()}
 
-for (N, C) in [(544, 3072), (512, 1536), (4096, 1152)]:
+for (N, C) in [(544, 3072), (512, 1536), (4096, 1152), (1024, 1152)]:
     for B in (2,):
         xs = [torch.randn(N, C, device="cuda").half() for _ in range(B)]
         bs = [(x.float() + 0.1 * torch.randn(N, C, device="cuda")).half() for x in xs]
