@@ -73,9 +73,9 @@ python3 tools/fused_stamps.py 2>&1 | grep -v amdgpu.ids > "$OUT/r05_compress_tim
 # 6. per-codec, per-configuration and low-rank tables
 python3 tools/codec_table.py 2>&1 | grep "^|" > "$OUT/r05_codec_table.md"
 python3 tools/config_table.py 2>&1 | grep "^|" > "$OUT/r05_config_table.md"
-python3 tools/lowrank_bench.py 2>&1 | grep -v amdgpu.ids > "$OUT/r05_lowrank_bench.txt"
-LR_CHAIN=2 python3 tools/lowrank_bench.py 2>&1 | grep -v amdgpu.ids | head -6 > "$OUT/r05_lowrank_bench_cspace_chain.txt"
-LR_CHAIN=1 python3 tools/lowrank_bench.py 2>&1 | grep -v amdgpu.ids | head -6 > "$OUT/r05_lowrank_bench_six_launch_chain.txt"
+python3 tools/lowrank_bench.py 2>&1 | grep -v "amdgpu.ids\|^compactfusion_amd:" > "$OUT/r05_lowrank_bench.txt"
+LR_CHAIN=2 python3 tools/lowrank_bench.py 2>&1 | grep -v "amdgpu.ids\|^compactfusion_amd:" | head -6 > "$OUT/r05_lowrank_bench_cspace_chain.txt"
+LR_CHAIN=1 python3 tools/lowrank_bench.py 2>&1 | grep -v "amdgpu.ids\|^compactfusion_amd:" | head -6 > "$OUT/r05_lowrank_bench_six_launch_chain.txt"
 python3 tools/lrs_stamps.py 2>&1 | grep -v amdgpu.ids > "$OUT/r05_lowrank_slab_timeline.txt"
 # 7. rounds 4-5: the plugin path (protocol 1 through compact_all_gather_kv / compact_fwd), the gated layer launch's timeline, validate-then-fall-back,
 #    PMC traffic of the other codecs' launches at their BASELINE shapes
