@@ -5,7 +5,7 @@
 // LOW_RANK_Q branches of slowpath.py (:54-75 encode, :120-131 + :151-164 decode) with a fixed chain of small kernels:
 //
 //   D  = x - base ; Y = D Q0                        k_lr_aq<FROMX>  (fp16 residual, formed on the fly and materialised once)
-//   2x { Z = D^T Y ; T = chol(Z^T Z)^-T ; Q = Z T ; Y = D Q }   k_lr_aty (+ partial Gram), k_lr_apply2 (factor + product), k_lr_aq
+//   2x { Z = D^T Y ; Y = D orth(Z), orth(Z) = Z chol(Z^T Z)^-T }   k_lr_aty (+ partial Gram), k_lr_aq<ORTH> (factor + substitution + product)
 //   Z' = D^T Y ; G = Q^T Z' (= Y^T Y)                 k_lr_aty (+ partial Q^T Z')
 //   T  = chol(G)^-T ; U = Y T ; V = (Z' T)^T          k_lr_apply2                 (U = orth(Y), V = U^T D without re-reading D)
 //   new_base = base + fp16(U16 V16)                   k_lr_decode   (the receiver's kernel, run on the sender's packet)
@@ -75,15 +75,23 @@ static LrWs lr_layout(int N, int C, int RP) {
 // ---------------------------------------------------------------------------------------------------------------------
 // FROMX (the first product of a chain): D = x - base is formed on the fly (fp16, one rounding, as torch eager) and written to the
 //   workspace for the later passes - every element of D is read by exactly one workgroup here, so k_lr_prep is not needed.
+// ORTH (the second and third product): the operand is Q = orth(Z) = Z chol(Z^T Z)^-T, formed HERE - every workgroup sums the column tiles'
+//   partial Grams and factorises for itself (lr_factor_to_lds), then a thread turns the row of Z of its column of the chunk into a row of Q
+//   by forward substitution on the way into LDS: no launch for it, no round trip of Q through memory.  The row tile 0 workgroups also write
+//   Q out (k_lr_aty's Gram part of the last pass wants it).
 #define LR_Q_SCALE 16.f
-template <int RP, bool FROMX>
+template <int RP> __device__ __forceinline__ void lr_factor_to_lds(const double* Gp, int nparts, int r, float* ts);
+template <int RP, bool FROMX, bool ORTH>
 __global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t offD, size_t offQ, size_t offY, int use_q0, int absd, size_t offTick,
-                                               size_t offYmax) {
+                                               size_t offYmax, size_t offZ, size_t offG, int nparts, int r) {
     constexpr int CK = 256, LDD = CK + 8;            // 528-byte rows: 16-byte aligned operands
     constexpr int QI = (CK / 2) * (RP / 4) / 256;    // (column pair, 4 ranks) items of the Q chunk per thread (4 at RP = 32)
     const LrItem it = b.it[blockIdx.z];
     h16* D = (h16*)(it.ws + offD);
     const float* Q = use_q0 ? it.q0 : (const float*)(it.ws + offQ);
+    const float* Zin = (const float*)(it.ws + offZ);
+    float* Qout = (float*)(it.ws + offQ);
+    __shared__ __attribute__((aligned(16))) float ts[ORTH ? RP * RP : 4];
     float* Y = (float*)(it.ws + offY) + (size_t)blockIdx.y * N * RP;
     __shared__ __attribute__((aligned(16))) h16 dsm[32 * LDD];                    // 16.5 KB
     __shared__ __attribute__((aligned(16))) h16 qsm[2 * 32 * LDD];                // Q^T hi | lo: [rank][column], 33 KB; reused for the wave partials
@@ -101,7 +109,8 @@ __global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t o
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     h16x8 dreg[4];
-    float4 qreg[QI][2];
+    float4 qreg[ORTH ? 1 : QI][2];
+    float4 zreg[ORTH ? RP / 4 : 1];                  // ORTH: the row of Z of this thread's column of the chunk
     auto load_chunk = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                // 32 rows x 32 sixteen-byte pieces
@@ -123,19 +132,28 @@ __global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t o
                 } else dreg[u] = *reinterpret_cast<const h16x8*>(D + o);
             }
         }
+        if constexpr (ORTH) {
 #pragma unroll
-        for (int u = 0; u < QI; ++u) {               // columns 2 cp, 2 cp + 1 (C is even), ranks 4 k4 .. + 3
-            const int i = tid + 256 * u, cp = i / (RP / 4), k4 = i - cp * (RP / 4);
+            for (int k4 = 0; k4 < RP / 4; ++k4) {
+                zreg[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + tid < C) zreg[k4] = *reinterpret_cast<const float4*>(Zin + (size_t)(c0 + tid) * RP + 4 * k4);
+            }
+        } else {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                qreg[u][h] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c0 + 2 * cp + h < C) qreg[u][h] = *reinterpret_cast<const float4*>(Q + (size_t)(c0 + 2 * cp + h) * RP + 4 * k4);
+            for (int u = 0; u < QI; ++u) {           // columns 2 cp, 2 cp + 1 (C is even), ranks 4 k4 .. + 3
+                const int i = tid + 256 * u, cp = i / (RP / 4), k4 = i - cp * (RP / 4);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    qreg[u][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c0 + 2 * cp + h < C) qreg[u][h] = *reinterpret_cast<const float4*>(Q + (size_t)(c0 + 2 * cp + h) * RP + 4 * k4);
+                }
             }
         }
     };
     const int cstep = gridDim.y * CK;                // (1, 2 or 4 column groups: the host's choice - enough workgroups, as few partials as that allows)
     int c0 = blockIdx.y * CK;
     if (c0 < C) load_chunk(c0);
+    if constexpr (ORTH) lr_factor_to_lds<RP>((const double*)(it.ws + offG), nparts, r, ts);      // (the first chunk's loads are in flight under it)
     for (; c0 < C; c0 += cstep) {
         __syncthreads();                             // previous chunk fully consumed
 #pragma unroll
@@ -143,20 +161,49 @@ __global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t o
             const int i = tid + 256 * u, rr = i >> 5, pc = (i & 31) * 8;
             *reinterpret_cast<h16x8*>(&dsm[rr * LDD + pc]) = dreg[u];
         }
+        if constexpr (ORTH) {
+            // q = z L^-T by forward substitution (ts: L row-major with 1 / diagonal on the diagonal, 0 for a dropped direction), as k_lr_apply2
+            const float* zin = reinterpret_cast<const float*>(zreg);
+            float out[RP];
 #pragma unroll
-        for (int u = 0; u < QI; ++u) {
-            const int i = tid + 256 * u, cp = i / (RP / 4), k4 = i - cp * (RP / 4);
-            const float* q0p = reinterpret_cast<const float*>(&qreg[u][0]);
-            const float* q1p = reinterpret_cast<const float*>(&qreg[u][1]);
+            for (int j = 0; j < RP; ++j) {
+                float lrow[RP];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a0 = q0p[e] * LR_Q_SCALE, a1 = q1p[e] * LR_Q_SCALE;
-                const h16 h0 = (h16)a0, h1 = (h16)a1;
-                h16x2 hi, lo;
-                hi[0] = h0; hi[1] = h1;
-                lo[0] = (h16)(a0 - (float)h0); lo[1] = (h16)(a1 - (float)h1);
-                *reinterpret_cast<h16x2*>(&qsm[(4 * k4 + e) * LDD + 2 * cp]) = hi;
-                *reinterpret_cast<h16x2*>(&qsm[(32 + 4 * k4 + e) * LDD + 2 * cp]) = lo;
+                for (int c = 0; c < (j + 4) / 4; ++c) *reinterpret_cast<float4*>(&lrow[4 * c]) = *reinterpret_cast<const float4*>(&ts[j * RP + 4 * c]);
+                float sacc = zin[j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) sacc = fmaf(-out[k], lrow[k], sacc);
+                out[j] = sacc * lrow[j];
+                if (RP > 16 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < RP; ++j) {
+                const float a0 = out[j] * LR_Q_SCALE;
+                const h16 h0 = (h16)a0;
+                qsm[j * LDD + tid] = h0;
+                qsm[(32 + j) * LDD + tid] = (h16)(a0 - (float)h0);
+            }
+            if (blockIdx.x == 0 && c0 + tid < C) {
+#pragma unroll
+                for (int k4 = 0; k4 < RP / 4; ++k4)
+                    *reinterpret_cast<float4*>(Qout + (size_t)(c0 + tid) * RP + 4 * k4) = make_float4(out[4 * k4], out[4 * k4 + 1], out[4 * k4 + 2], out[4 * k4 + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < QI; ++u) {
+                const int i = tid + 256 * u, cp = i / (RP / 4), k4 = i - cp * (RP / 4);
+                const float* q0p = reinterpret_cast<const float*>(&qreg[u][0]);
+                const float* q1p = reinterpret_cast<const float*>(&qreg[u][1]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = q0p[e] * LR_Q_SCALE, a1 = q1p[e] * LR_Q_SCALE;
+                    const h16 h0 = (h16)a0, h1 = (h16)a1;
+                    h16x2 hi, lo;
+                    hi[0] = h0; hi[1] = h1;
+                    lo[0] = (h16)(a0 - (float)h0); lo[1] = (h16)(a1 - (float)h1);
+                    *reinterpret_cast<h16x2*>(&qsm[(4 * k4 + e) * LDD + 2 * cp]) = hi;
+                    *reinterpret_cast<h16x2*>(&qsm[(32 + 4 * k4 + e) * LDD + 2 * cp]) = lo;
+                }
             }
         }
         __syncthreads();
@@ -393,7 +440,7 @@ __global__ __launch_bounds__(256) void k_lr_aty(LrBatch b, int N, int C, size_t 
 // ---------------------------------------------------------------------------------------------------------------------
 template <int RP>
 __device__ __forceinline__ void lr_factor_to_lds(const double* Gp, int nparts, int r, float* ts) {
-    constexpr int E = RP * RP, GRP = (256 / E) > 0 ? (256 / E) : 1, EPT = (E + 255) / 256, U = 8;
+    constexpr int E = RP * RP, GRP = (256 / E) > 0 ? (256 / E) : 1, EPT = (E + 255) / 256, U = 8;   // (24 parts in flight: slower, registers)
     __shared__ double G[RP][RP + 1];
     __shared__ double part[GRP][E];
     const int tid = threadIdx.x;
@@ -937,18 +984,25 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
                                          (upd && !(flags & CFX_FLAG_NO_EF) && !factors_only) ? 1 : 0, &decoded, s);
         if (rg != CFX_OK) return rg;
     } else {
-        // D = x - base is formed (and stored) by the first product.  (Forming Q = orth(Z) = Z T inside the next product instead of by a
-        // launch of its own was measured slower at every rank: 17 row tiles redo the same RP x RP products per chunk.)
+        // D = x - base is formed (and stored) by the first product.
+        // Y = D Q0 ; Z = D^T Y ; then twice: Y = D orth(Z) (the orthonormalisation inside the product) ; Z = D^T Y.  The last Z comes with
+        // Q^T Z = Y^T Y for the factor U = Y chol(.)^-T and V = (Z chol(.)^-T)^T (k_lr_apply2 below): 7 launches up to the factors.
         const LrApply aq_ = {C, rank, 1, 0, 0, w.Zb, w.Gp, w.Qa, 0};
-        for (int iter = 0; iter < 2; ++iter) {
-            if (iter == 0) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, true>), g_aq0, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 1, absd, w.tick, w.Ymax));
-            else LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0, 0, w.tick, w.Ymax));
-            LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 0, w.Zp, w.tick, rps, w.Ymax,
-                                    (int)(g_aq.x * (iter == 0 ? gy0_ : gy_)), iter == 0 ? gy0_ : gy_));
-            LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), g_apc, dim3(256), 0, s, b, aq_, aq_, (int)g_apc.x, nparts));
+        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, true, false>), g_aq0, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 1, absd, w.tick, w.Ymax, w.Zb, w.Gp, nparts, rank));
+        for (int iter = 0; iter < 3; ++iter) {
+            const int gy_i = iter == 0 ? gy0_ : gy_;
+            LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, iter == 2 ? 1 : 0, w.Zp, w.tick, rps, w.Ymax,
+                                    (int)(g_aq.x * gy_i), gy_i));
+            if (iter < 2) {
+                // rank <= 16: the orthonormalisation inside the product (measured at (4096, 1152): r = 8 92 -> 87 us; at rank 32 the 32-step
+                // factorisation and substitution in 256 workgroups of one wave a SIMD cost more than the launch they save: 202 -> 215)
+                if (RPv <= 16) LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<(RP <= 16 ? RP : 16), false, true>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0, 0, w.tick, w.Ymax, w.Zb, w.Gp, nparts, rank));
+                else {
+                    LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_APPLY, s, (k_lr_apply2<RP>), g_apc, dim3(256), 0, s, b, aq_, aq_, (int)g_apc.x, nparts));
+                    LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0, 0, w.tick, w.Ymax, w.Zb, w.Gp, nparts, rank));
+                }
+            }
         }
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_AQ, s, (k_lr_aq<RP, false>), g_aq, dim3(256), 0, s, b, N, C, w.D, w.Qa, w.Y, 0, 0, w.tick, w.Ymax));
-        LR_DISPATCH(RPv, LAUNCH(ctx, KID_LR_ATY, s, (k_lr_aty<RP>), g_aty, dim3(256), 0, s, b, N, C, w.D, w.Y, w.Zb, w.Qa, w.Gp, 1, w.Zp, w.tick, rps, w.Ymax, (int)(g_aq.x * g_aq.y), gy_));
     }
     int rc = CFX_OK;
     LrDec dec[LR_MAXB];
