@@ -254,6 +254,11 @@ def main():
     if args.print_config_key:
         print(json.dumps(config_key(args, args.gpus)))
         return
+    # stdout carries ONE line, the JSON.  Whatever a library prints on the way (RCCL announces its version on stdout when a communicator
+    # comes up) goes to stderr: file descriptor 1 points there until the line is written through the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -1225,7 +1230,7 @@ def main():
         pass
     sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

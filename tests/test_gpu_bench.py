@@ -28,7 +28,9 @@ def _bench(*args):
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--layers", "6", "--steps", "3", "--warmup", "1", "--long-steps", "3",
                         "--cpu-seconds", "0.5", "--overlap-steps", "0", *args], capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stderr[-2000:]
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, "stdout carries ONE line, the JSON (library chatter - RCCL's version banner - belongs on stderr): %r" % lines[:-1]
+    return json.loads(lines[-1])
 
 
 def test_bench_falls_back_when_the_collective_cannot_be_placed():
