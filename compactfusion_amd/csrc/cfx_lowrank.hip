@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t o
     const float* Q = use_q0 ? it.q0 : (const float*)(it.ws + offQ);
     const float* Zin = (const float*)(it.ws + offZ);
     float* Qout = (float*)(it.ws + offQ);
+    const float qscale = use_q0 ? 1.f : LR_Q_SCALE;  // the caller's start matrix goes in as it is (randn: no small entries to protect; |q0| < 65504)
     __shared__ __attribute__((aligned(16))) float ts[ORTH ? RP * RP : 4];
     float* Y = (float*)(it.ws + offY) + (size_t)blockIdx.y * N * RP;
     __shared__ __attribute__((aligned(16))) h16 dsm[32 * LDD];                    // 16.5 KB
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t o
                 const float* q1p = reinterpret_cast<const float*>(&qreg[u][1]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float a0 = q0p[e] * LR_Q_SCALE, a1 = q1p[e] * LR_Q_SCALE;
+                    const float a0 = q0p[e] * qscale, a1 = q1p[e] * qscale;
                     const h16 h0 = (h16)a0, h1 = (h16)a1;
                     h16x2 hi, lo;
                     hi[0] = h0; hi[1] = h1;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t o
     float mx = 0.f;
     for (int i = tid; i < 32 * RP; i += 256) {
         const int rr = i / RP, k = i - rr * RP;
-        const float sum = (((red[0][rr][k] + red[1][rr][k]) + red[2][rr][k]) + red[3][rr][k]) * (1.f / LR_Q_SCALE);
+        const float sum = (((red[0][rr][k] + red[1][rr][k]) + red[2][rr][k]) + red[3][rr][k]) * (1.f / qscale);
         if (n0 + rr < N) { Y[(size_t)(n0 + rr) * RP + k] = sum; mx = fmaxf(mx, fabsf(sum)); }
     }
 #pragma unroll

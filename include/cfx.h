@@ -224,7 +224,8 @@ int cfx_int2_quantize(cfx_ctx* ctx, int N, int C, int flags, int batch, const cf
  * quantized = 0: LOW_RANK   wire [ U (N,r) fp16 | V (r,C) fp16 ]
  * quantized = 1: LOW_RANK_Q wire [ int4(U) (N/2,r) | scale r | min r | int4(V^T) (C/2,r) | scale r | min r ]   (rank % 8 == 0)
  * rank even, <= 32.  init_q[i] -> device C x RP fp32 row-major start matrix, RP = 8/16/32 = rank rounded up, columns >= rank
- * zero; it need not be orthonormal (the iteration only sees its span).  Workspace from cfx_lr_workspace_bytes.
+ * zero; it need not be orthonormal (the iteration only sees its span); its entries enter the first product as fp16 (hi + lo): keep them
+ * below 65504 in magnitude (randn is what the reference draws).  Workspace from cfx_lr_workspace_bytes.
  * rank <= 16 on a shard of at most 576 tokens: ONE persistent launch (csrc/cfx_lrslab.hip) whose workgroups wait for each other - taken
  * only where C / 32 workgroups per tensor fit the CUs of `stream` (otherwise a multi-launch chain runs; same results within the codec's
  * tolerance).  It hands its partial sums over through an arena the context owns (allocated on the first call of a stream, zeroed when

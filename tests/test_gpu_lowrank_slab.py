@@ -99,7 +99,8 @@ def test_rank_deficient_residual_and_zero_residual():
     assert torch.equal(nb[0], base)
 
 
-@pytest.mark.parametrize("N,C,rank", [(544, 3072, 8), (544, 3072, 16), (512, 1536, 8), (512, 1536, 32)])
+@pytest.mark.parametrize("N,C,rank", [(544, 3072, 8), (544, 3072, 16), (512, 1536, 8), (512, 1536, 32),
+                                      (1024, 1152, 8), (1024, 1152, 32), (2048, 1152, 16)])     # (N > 576: the multi-launch chain, whose Y is scaled per product too)
 @pytest.mark.parametrize("amp", [0.02, 40.0, 300.0])
 def test_residual_magnitude(N, C, rank, amp):
     """The iteration is scale-free but its fp16 MFMA operands are not: Y = A Q grows with sigma, A^T Y with sigma^2.  The kernel
