@@ -34,8 +34,9 @@ struct LrWs {
 #define LR_NS_TARGET 768       //   ... as many as make ~768 workgroups (measured at (4096, 1152): 4 splits 98.5 us, 8: 92.2, 11: 98.8, 16: 100.6)
 // Row splits of Z = D^T Y: enough workgroups to fill the machine (a column tile x all N is C / 32 workgroups a tensor - 72 for K,V of
 // (4096, 1152), each walking 4096 rows: 50 us), at least two 128-row chunks each.
-static int lr_aty_splits(int N, int C, int batch) {
-    const int tiles = ((C + 31) / 32) * batch;
+static int lr_aty_splits(int N, int C, int /*batch*/) {
+    // (as if for a K,V pair whatever the batch: the order of a sum - hence the bits - must not depend on what else is in the launch)
+    const int tiles = ((C + 31) / 32) * 2;
     int ns = (LR_NS_TARGET + tiles - 1) / tiles;
     ns = std::min(ns, std::min(LR_NS_MAX, N / 256));
     return std::max(ns, 1);
@@ -969,7 +970,7 @@ int cfx_lr_compress_batch(cfx_ctx* ctx, int quantized, int N, int C, int rank, i
     const int ns_ = lr_aty_splits(N, C, batch);
     const int rps = ((N + ns_ - 1) / ns_ + 127) / 128 * 128;          // rows per split: whole 128-row chunks
     // column groups of Y = D Q (each writes a partial of Y every reader sums): as few as still give the machine a workgroup per CU
-    const int rt_ = ((N + 31) / 32) * batch, gy_ = rt_ >= 256 ? 1 : (rt_ >= 128 ? 2 : 4);
+    const int rt_ = ((N + 31) / 32) * 2, gy_ = rt_ >= 256 ? 1 : (rt_ >= 128 ? 2 : 4);       // (a K,V pair's worth whatever the batch: same bits)
 #define LR_GY0_MUL 2          // (measured at (4096, 1152): x1 20.6 + 11.9 us for the first two launches, x2 16.5 + 13.7, x4 15.0 + 15.8)
     const int gy0_ = std::min(4, gy_ * LR_GY0_MUL);      // the first product also forms D = x - base: three times the bytes
     const dim3 g_aq((N + 31) / 32, gy_, batch), g_aq0((N + 31) / 32, gy0_, batch), g_aty(nparts, batch, (N + rps - 1) / rps), g_apc((C + 255) / 256, batch), g_apn((N + 255) / 256, batch);

@@ -155,6 +155,32 @@ def test_batches_bigger_than_one_launch_and_reproducible():
         assert torch.equal(p1[0], pk[i]) and torch.equal(n1[0], nb[i])
 
 
+@pytest.mark.parametrize("N,C,rank", [(4096, 1152, 8), (1024, 1152, 16), (2048, 1536, 32)])
+def test_multi_launch_chain_above_576_rows_reproducible_and_batch_independent(N, C, rank):
+    """Shards with more than 576 rows take the multi-launch chain (csrc/cfx_lowrank.hip): Z = D^T Y is summed by whichever workgroup of a
+    column tile arrives last, in split order - the bits must not depend on who that is, nor on what else is in the batch."""
+    data = [make(N, C, rank, seed=300 + i, decay=0.85 if rank > 16 else 0.7) for i in range(3)]
+    xs, bs, qs = [d[0] for d in data], [d[1] for d in data], [d[2] for d in data]
+    pk, nb = run(xs, bs, qs, N, C, rank)
+    for i in range(3):
+        check(xs[i], bs[i], qs[i], pk[i], nb[i], N, C, rank)
+    hog_a = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    hog_b = torch.empty_like(hog_a)
+    side = torch.cuda.Stream()
+    for rep in range(6):
+        if rep >= 3:                                              # beside a copy stream: other arrival orders
+            with torch.cuda.stream(side):
+                for _ in range(8):
+                    hog_b.copy_(hog_a)
+        pk2, nb2 = run(xs, bs, qs, N, C, rank)
+        for i in range(3):
+            assert torch.equal(pk[i], pk2[i]) and torch.equal(nb[i], nb2[i]), "not reproducible run to run"
+    torch.cuda.synchronize()
+    for i in (0, 2):
+        p1, n1 = run([xs[i]], [bs[i]], [qs[i]], N, C, rank)
+        assert torch.equal(p1[0], pk[i]) and torch.equal(n1[0], nb[i]), "the bits depend on the batch"
+
+
 def test_arena_survives_changing_shapes():
     """the hand-over arena is re-laid-out (and zeroed) when the shape changes; stale tagged words of another layout must never
     be taken for this launch's"""
