@@ -1040,6 +1040,8 @@ def main():
             # rate says nothing about xGMI and may exceed the link peak - no `frac` key there
             if args.emulate_live:
                 o["loopback_device_copy"] = True
+            elif args.same_gpu:
+                o["same_gpu"] = True             # rank processes sharing ONE GPU (protocol test): the peers' packets are read from the same HBM
             else:
                 o["frac"] = round(wire / (ms_ * 1e-3) / 1e9 / (153.0 * links), 4)
             return o
@@ -1053,6 +1055,8 @@ def main():
                            issued_by="every leg is one native plan per step (cfx_plan_run): no Python-issued collective on either side")
         if args.emulate_live:
             out["xgmi"]["note"] = "--emulate-live: loop-back collective library on ONE GPU - device copies, not xGMI links; layout and plumbing only"
+        elif args.same_gpu:
+            out["xgmi"]["note"] = "--same-gpu: the rank processes share ONE GPU - no link carried a byte; protocol and plumbing only"
     # ---- roofline --------------------------------------------------------------------------------------------------------
     # step level (every launch of the step, edge layers included), SURVEY.md §8d: own tensors compress + error feedback 6.125 B/el,
     # peers' tensors 4.125 B/el

@@ -117,6 +117,10 @@ def test_bench_two_rank_processes_exchange_peer_to_peer():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["exchange_issued_by"] == "p2p" and d["launches_per_layer"] == 1 and d["schedule_fallback"] is None
     assert "NO collective" in d["schedule"] and d["scaling"] == "weak"
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, "under torch.distributed.run too stdout carries ONE line, rank 0's JSON: %r" % lines[:-1]
+    # the rank processes share one GPU: a rate, but no fraction of a LINK roofline - no link carried a byte
+    assert d["xgmi"]["same_gpu"] and "frac" not in d["xgmi"] and "frac" not in d["xgmi"]["compressed"]["allgather"]
 
 
 @pytest.mark.parametrize("poison_step", [1, 3])
