@@ -22,7 +22,7 @@ static const char* const kid_names[KID_MAX] = {
     "", "k_absmean_stats<bits>", "k_absmean_stats", "k_absmean_finalize", "k_binary_dequant", "k_int2_quant", "k_int2_dequant",
     "k_minmax_stats", "k_minmax_finalize", "k_int8_quant", "k_int8_dequant", "k_int4_quant", "k_int4_dequant",
     "k_topk_compress", "k_topk_decompress", "k_copy_probe", "k_binary_dequant(ef)",
-    "k_lr_prep | k_lrs (slab-resident chain, one launch)", "k_lr_aq", "k_lr_aty", "k_lr_chol", "k_lr_apply", "k_lr_decode",
+    "k_lr_prep | k_lrs (slab-resident chain, one launch)", "k_lr_aq", "k_lr_aty", "k_lrg_gy (last arriver: factorisations)", "k_lr_apply", "k_lr_decode",
     "k_binary_pipe", "k_binary_pipe(prologue/epilogue)", "k_residual2_delta", "k_residual2_update",
     "k_absmean_compress<bits>", "k_absmean_compress", "k_minmax_compress", "k_attn_merge",
     "gated layer launch (k_absmean_compress<bits,gated> / k_int2_compress_gated / k_minmax_layer / k_topk_layer)"};

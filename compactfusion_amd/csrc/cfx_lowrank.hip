@@ -15,9 +15,11 @@
 // free can differ, and fp32 rounding.  The random start is NOT orthonormalised (compress_lowrank.py:41-42 does QR(randn)):
 // span(D^T D Q0) does not depend on the basis chosen for span(Q0).
 //
-// Everything is fp32 FMA on the vector ALU: at r <= 32 a pass is 2*N*C*r <= 0.1 GFLOP (<1 us of a 157 TFLOP/s machine) over
-// a 3 MB matrix that stays in L2/MALL; the chain is bound by its 13 launches, not by FLOPs or bytes, so no MFMA.
-// All reductions have a fixed order (no float atomics): results are reproducible run to run.
+// This is the chain for shards of more than 576 rows (below that: the one-launch slab-resident chain, cfx_lrslab.hip; on CU-masked lanes
+// the N-space chain, cfx_lrgram.hip).  Both products are v_mfma_f32_32x32x16_f16 with D as it is (fp16: exact) and the fp32 operand split
+// into fp16 hi + lo under an exact power-of-two scale (an MFMA tile is 32 wide whatever the rank: fp32-input MFMA cost 8 us a pass at
+// (4096, 1152)); 8 launches up to rank 16, 10 at rank 32.
+// All reductions have a fixed order (no float atomics) that does not depend on the batch: results are reproducible run to run.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -47,7 +49,7 @@ static LrWs lr_layout(int N, int C, int RP) {
     w.D = o;   o += al256((size_t)((N + 63) / 64 * 64) * C * 2);     // 64-row padded (the N-space chain reads whole tiles)
     w.Qa = o;  o += al256((size_t)C * RP * 4);
     w.Zb = o;  o += al256((size_t)C * RP * 4);
-    w.Y = o;   o += al256((size_t)4 * N * RP * 4);        // 4 column-group partials of Y
+    w.Y = o;   o += al256((size_t)4 * N * RP * 4);        // up to 4 column-group partials of Y
     w.Gp = o;  o += al256((size_t)((C + 31) / 32) * RP * RP * 8);
     w.T = o;   o += al256((size_t)RP * RP * 4);
     w.U16 = o; o += al256((size_t)N * RP * 2);
@@ -64,7 +66,7 @@ static LrWs lr_layout(int N, int C, int RP) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Ypart[g] (N x RP) = D[:, cols of group g] . Q[cols of group g, :]      Y = sum of the 4 group partials (summed, in fixed
+// Ypart[g] (N x RP) = D[:, cols of group g] . Q[cols of group g, :]      Y = sum of the group partials (summed, in fixed
 // order, by whoever reads Y).  grid (ceil(N/32), g, batch), g = 1, 2 or 4 column groups: a workgroup owns 32 rows x every g-th 256-column chunk.
 // v_mfma_f32_32x32x16_f16: A = D (fp16 as it is: exact), B = Q as fp16 hi + lo (two instructions; Q scaled by 16 so that the lo halves
 // of an orthonormal basis's entries stay normal numbers - Q0 ~ randn and |Q| <= 1 afterwards are far from fp16's range), fp32 sums: 22
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void k_lr_aq(LrBatch b, int N, int C, size_t o
 //   of an fp32-input MFMA's 24, at an eighth of its issue time.  An operand is 8 consecutive k - rows of D and Y - of one column: both
 //   chunks are staged TRANSPOSED in LDS (two rows a thread, one 4-byte write per column).
 //   workgroup = one 32-column tile of D x its share of N (blockIdx.z); its 4 waves split a 128-row chunk, partial 32x32 tiles are summed
-//   in fixed order.  (Y = fixed-order sum of the 4 column-group slabs k_lr_aq wrote.)  Epilogue: this tile's part of the r x r Gram matrix
+//   in fixed order.  (Y = fixed-order sum of the `ny` column-group slabs k_lr_aq wrote.)  Epilogue: this tile's part of the r x r Gram matrix
 //   in fp64.  gram_mode 0: Ztile^T Ztile ; 1: Qtile^T Ztile (Q = the orthonormal basis Y was formed with).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int RP>

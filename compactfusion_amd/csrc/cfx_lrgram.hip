@@ -2,8 +2,8 @@
 //
 // The reference's subspace_iter (xfuser/compact/compress_lowrank.py:14-61) is, for A = x - base (N x C, N << C):
 //     Q <- orth(A^T (A Q))  twice ;  U = orth(A Q) ;  V = U^T A
-// The C-space chain of cfx_lowrank.hip follows it product by product: 13 launches, each 5-35 us for a few microseconds of
-// traffic.  Here the same iteration runs in N-space.  With G = A A^T (N x N) and Y0 = A Q0:
+// The C-space chain of cfx_lowrank.hip follows it product by product: 8-10 launches (13 when this file was written), each 5-35 us for
+// a few microseconds of traffic.  Here the same iteration runs in N-space.  With G = A A^T (N x N) and Y0 = A Q0:
 //     W1 = G Y0        M1 = Y0^T W1 (= Z1^T Z1, Z1 = A^T Y0)     T1 = chol(M1)^-T     Y1 = W1 T1   (= A orth(Z1))
 //     W2 = G Y1        M2 = Y1^T W2 (= Z2^T Z2)                  T2 = chol(M2)^-T     Y2 = W2 T2   (= A orth(Z2))
 //     M3 = Y2^T Y2 = T2^T (W2^T W2) T2                           T3 = chol(M3)^-T     U  = Y2 T3   (= orth(A Q2))
