@@ -25,14 +25,9 @@ import torch  # noqa: E402
 
 
 def preset(name):
-    from xfuser.compact.utils import CompactConfig, COMPACT_COMPRESS_TYPE as T        # = compactfusion_amd.compact.utils
-    kinds = {"binary": (T.BINARY, dict(comp_rank=-1, fastpath=True)), "int2": (T.INT2, dict(comp_rank=-1, fastpath=True)),
-             "lowrank8": (T.LOW_RANK, dict(comp_rank=8, fastpath=False)), "lowrankq32": (T.LOW_RANK_Q, dict(comp_rank=32, fastpath=False))}
-    if name == "off":
-        return CompactConfig(enabled=False)
-    ctype, kw = kinds[name]
-    return CompactConfig(enabled=True, compress_func=lambda layer, step: T.WARMUP if step < 1 else ctype, residual=1, ef=True, simulate=False,
-                         log_stats=False, **kw)
+    """the reference's named configurations (examples/configs.py there; compactfusion_amd/compact/presets.py here)"""
+    from xfuser.compact.presets import get_config                                      # = compactfusion_amd.compact.presets
+    return get_config("Flux", "ring" if name == "off" else name)
 
 
 def psnr(a, b):
@@ -45,7 +40,7 @@ def main():
     ap.add_argument("--model", default="black-forest-labs/FLUX.1-dev")
     ap.add_argument("--prompt", default="a photo of an astronaut riding a horse on the moon")
     ap.add_argument("--ring-degree", type=int, default=int(os.environ.get("WORLD_SIZE", "1")))
-    ap.add_argument("--preset", default="binary", choices=["binary", "int2", "lowrank8", "lowrankq32"])
+    ap.add_argument("--preset", default="binary", choices=["binary", "int2", "lowrank8", "lowrank12", "lowrankq32"])
     ap.add_argument("--steps", type=int, default=28)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--out", default="out")

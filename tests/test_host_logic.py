@@ -455,3 +455,35 @@ def test_configure_is_the_one_place_for_host_switches(monkeypatch):
     with pytest.raises(RuntimeError, match="before the first CUDA call"):
         compactfusion_amd.configure(hw_queues=8)
     config.reset()
+
+
+def test_named_configurations_equal_the_reference_presets():
+    """compact/presets.py::get_config against G15 (tests/golden/make_golden_presets.py: the reference's examples/configs.py:6-200 run for
+    every model x method): the same CompactConfig fields, the same PatchConfig, the same compress_func answers.  Where the reference's own
+    dispatcher raises (`patch`: it passes an argument `_patch_config()` does not take) ours returns what that function builds."""
+    import json
+    import os
+    from compactfusion_amd.compact import presets
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g15_presets.json")))
+    assert len(gold) == 33
+    fields = ("enabled", "override_with_patch_gather_fwd", "comp_rank", "compress_residual", "error_feedback", "simulate_compress",
+              "log_compress_stats", "fastpath", "quantized_cache", "sparse_ratio", "delta_decay_factor", "check_cache_consistency")
+    for key, g in gold.items():
+        model, method = key.split("/")
+        c = presets.get_config(model, method)
+        if "raises" in g:
+            assert method == "patch" and g["raises"] == "TypeError"
+            assert c.enabled and c.override_with_patch_gather_fwd and c.compress_func is None and not c.error_feedback
+            p = c.patch_gather_fwd_config
+            assert (p.use_compact, p.async_comm, p.async_warmup) == (False, False, 0)          # configs.py:153-158
+            continue
+        for f in fields:
+            if f in g:
+                assert getattr(c, f) == g[f], (key, f, getattr(c, f), g[f])
+        p = c.patch_gather_fwd_config
+        assert (None if p is None else {"use_compact": p.use_compact, "async_comm": p.async_comm, "async_warmup": p.async_warmup}) == g["patch"], key
+        sched = None if c.compress_func is None else [[c.compress_func(layer, step).name for step in range(4)] for layer in (0, 5)]
+        assert sched == g["schedule"], key
+    with pytest.raises(ValueError):
+        presets.get_config("SDXL", "binary")                                                    # configs.py:35
+    assert presets.get_config("Flux", "lowrank16").comp_rank == 16                              # defined upstream (:96-107), not dispatched there
