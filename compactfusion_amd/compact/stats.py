@@ -6,7 +6,7 @@ the volume counters, the environment switches (CALC_SIMILARITY, CALC_MORE_SIMILA
 REF_ACTIVATION_PATH, DUMP_ACTIVATIONS, CALC_TOTAL_ERROR), the singular-value capture and the two `.pt` dumps
 (`average_error_vs_steps.pt`, `average_norms_and_similarity_vs_steps.pt`, same keys as `plot.py:413-560` writes) are
 kept, so the reference's analysis scripts read our output.  Pinned by golden G11 (`tests/golden/g11_stats.npz`).
-What is not restated: the matplotlib figures (`plot.py`); `plot_eigenvalues` / `plot_low_rank_factors` say so and return.
+The matplotlib figures are `compact/plot.py` (`plot_eigenvalues`, `plot_low_rank_factors` call into it).
 
 Everything here is diagnostics run with `CompactConfig(log_stats=True)`; it is torch glue, never on the timed path.
 """
@@ -319,16 +319,24 @@ class StatsLogger:
                     torch.save(spectra, os.path.join(save_dir, f"{key}_{step}_{kind}.pt"))
         print(f"Saved eigenvalues to {save_dir}")
 
-    def plot_eigenvalue_distribution(self, *args, **kwargs):
-        print("plots are not part of compactfusion_amd: use save_eigenvalues() and plot offline")
+    # -- figures (stats.py:350-371, :634-647 -> compact/plot.py) ------------------------------------------------------------------
+    def plot_eigenvalue_distribution(self, key=None, step=None, data_type="activation", save_dir=None, log_scale=True, top_k=None, num_bins=100):
+        from .plot import plot_eigenvalue_distribution
+        return plot_eigenvalue_distribution(self.eigenvalues, key, step, data_type, save_dir, log_scale, top_k, num_bins)
 
-    plot_eigenvalue_cumsum = plot_eigenvalue_distribution
+    def plot_eigenvalue_cumsum(self, key=None, step=None, data_type="activation", save_dir=None, log_scale=True, top_k=None):
+        from .plot import plot_eigenvalue_cumsum
+        return plot_eigenvalue_cumsum(self.eigenvalues, key, step, data_type, save_dir, log_scale, top_k)
 
     def plot_low_rank_factors(self, u, v, key, step, save_dir):
+        """The U / V figure for the layers and steps the module constants select (the factors themselves are kept beside it)."""
         assert step is not None, f"Step is None for key {key}, cannot save U/V plot with step index."
-        if int(str(key).split("-")[0]) in UV_PLOT_LAYERS and step in UV_PLOT_STEPS:
-            os.makedirs(save_dir, exist_ok=True)
-            torch.save({"u": u.detach().cpu(), "v": v.detach().cpu()}, os.path.join(save_dir, f"uv_{key}_{step}.pt"))
+        if int(str(key).split("-")[0]) not in UV_PLOT_LAYERS or step not in UV_PLOT_STEPS:
+            return None
+        os.makedirs(save_dir, exist_ok=True)
+        torch.save({"u": u.detach().cpu(), "v": v.detach().cpu()}, os.path.join(save_dir, f"uv_{key}_{step}.pt"))
+        from .plot import plot_low_rank_factors
+        return plot_low_rank_factors(u, v, key, step, save_dir)
 
     # kept for callers of the earlier, smaller logger
     @property
@@ -377,7 +385,9 @@ def plot_eigenvalues(key=None, step=None, data_type="activation", save_dir=None,
     if _stats is None:
         print("No statistics logged.")
         return
-    _stats.plot_eigenvalue_distribution()
+    if cum_sum:
+        return _stats.plot_eigenvalue_cumsum(key, step, data_type, save_dir, log_scale, top_k)
+    return _stats.plot_eigenvalue_distribution(key, step, data_type, save_dir, log_scale, top_k)
 
 
 def save_eigenvalues(save_dir="eigenvalues"):
