@@ -52,6 +52,7 @@ SYMBOLS = [
     ("cfx_prepare", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_set_fused_finalize", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_debug_stamps", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    ("cfx_debug_set_launch_tags", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
     ("cfx_set_stats_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_set_gated_launch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_set_lr_chain", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),

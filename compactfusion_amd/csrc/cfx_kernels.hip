@@ -3054,6 +3054,15 @@ int cfx_debug_stamps(cfx_ctx* ctx, void* buf) {
     return CFX_OK;
 }
 
+int cfx_debug_set_launch_tags(cfx_ctx* ctx, unsigned abs_seq, unsigned mml_seq) {
+    if (!ctx) return CFX_ERR_NULL;
+    if (!ctx->tick && cfx_prepare(ctx) != CFX_OK) return CFX_ERR_LAUNCH;
+    (void)hipDeviceSynchronize();                     // (nothing in flight carries the old numbers)
+    ctx->abs_seq = abs_seq;
+    ctx->mml_seq = mml_seq;
+    return CFX_OK;
+}
+
 int cfx_set_fused_finalize(cfx_ctx* ctx, int on) {
     if (!ctx) return CFX_ERR_NULL;
     ctx->fused = on != 0;
@@ -3777,6 +3786,18 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             a.tall = tall ? 1 : 0;
             a.coop = (tall || PL > 32) ? 1 : 0;
             a.seq = ++ctx->mml_seq;
+            if (a.seq >= 0x7FFFFFFFu) {
+                // 2.1 billion launches later: the tiles' "codes published" flags are compared as signed distances (a flag from an earlier
+                // launch - or a word never written - must read as BEHIND this launch's number), and a tagged word a smaller layout has not
+                // rewritten since could carry a number again - start over at 1 (arenas and flags zeroed, nothing in flight)
+                (void)hipDeviceSynchronize();
+                for (int i = 0; i < CFX_RING_STREAMS; ++i)
+                    if (ctx->mml_arena[i]) (void)hipMemset(ctx->mml_arena[i], 0, ctx->mml_arena_bytes[i]);
+                (void)hipMemset(ctx->colgate, 0, (size_t)CFX_RING_STREAMS * MML_MAX_TILES * sizeof(unsigned));
+                (void)hipDeviceSynchronize();
+                ctx->mml_seq = 0;
+                a.seq = ++ctx->mml_seq;
+            }
             a.err = ctx->gate_err;
             a.timeout = ctx->gate_timeout;
             memcpy(a.src, src, sizeof(src));

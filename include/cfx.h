@@ -179,6 +179,11 @@ int cfx_set_fused_finalize(cfx_ctx* ctx, int on);
 /* Developer hook: when `buf` is non-NULL every statistics workgroup of a compress launch writes 8 u64 words there (phase
  * times on the 100 MHz wall clock + its last-arriver roles): tools/fused_stamps.py.  NULL switches it off. */
 int cfx_debug_stamps(cfx_ctx* ctx, void* buf);
+/* Test hook: the layer launches tag what they hand over with numbers a context gives out in sequence (24 bits for the 1-bit / 2-bit layer,
+ * 31 for the int4 / int8 layer); where a sequence wraps - 16.7 million, 2.1 billion launches in - the tagged arenas are zeroed and the
+ * numbers start over.  This sets the two counters (after a device synchronisation) so that a test can walk a context across the wrap:
+ * tests/test_gpu_parity.py::test_layer_launches_across_the_tag_wrap. */
+int cfx_debug_set_launch_tags(cfx_ctx* ctx, unsigned abs_seq, unsigned mml_seq);
 /* Tuning / measurement switches of a context.  The library reads NO environment variable for its behaviour (the one variable it looks
  * at, GPU_MAX_HW_QUEUES, belongs to the HIP runtime: see cfx_prepare below); what earlier builds read from the environment is set here:
  *   cfx_set_stats_rows    statistics tile height of the one-launch compress (multiple of 16; 0 = automatic)
