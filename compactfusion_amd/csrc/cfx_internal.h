@@ -68,7 +68,6 @@ struct cfx_ctx {
     int stats_rows;                 // cfx_set_stats_rows: override of the statistics tile height (experiments), 0 = automatic
     int gated_on;                   // cfx_set_gated_launch: 1 (default) the one-launch gated / exchange-layer forms where they qualify
     int lr_chain, lr_decode;        // cfx_set_lr_chain / cfx_set_lr_decode (0 = automatic)
-    int lrs_force_wt;               // cfx_set_lr_chain(3): the slab-resident launch's sums take the write-through form in every block
     int dev_probe;                  // cfx_set_dev_probe (developer builds)
     int allow_shared_queues;        // cfx_set_allow_shared_queues: flag-ordered streams even when cfx_hw_queues_ok() == 0
     int ipc_want;                   // cfx_set_ipc_memory_kind: what cfx_ipc_alloc asks for first (2 uncached - default -, 1 fine-grained, 0 ordinary)

@@ -3006,7 +3006,6 @@ cfx_ctx* cfx_create(int device) {
     c->stats_rows = 0;
     c->gated_on = 1;
     c->lr_chain = c->lr_decode = 0;
-    c->lrs_force_wt = 0;
     c->dev_probe = 0;
     c->allow_shared_queues = 0;
     c->ipc_kind = 0;
@@ -3085,10 +3084,8 @@ int cfx_set_gated_launch(cfx_ctx* ctx, int on) {
 
 int cfx_set_lr_chain(cfx_ctx* ctx, int chain) {
     if (!ctx) return CFX_ERR_NULL;
-    if (chain < 0 || chain > 3)
-        return fail(ctx, CFX_ERR_BATCH, "lr chain must be 0 (automatic), 1 (no single launch), 2 (C-space chain) or 3 (automatic, write-through sums)");
-    ctx->lr_chain = chain == 3 ? 0 : chain;
-    ctx->lrs_force_wt = chain == 3 ? 1 : 0;
+    if (chain < 0 || chain > 2) return fail(ctx, CFX_ERR_BATCH, "lr chain must be 0 (automatic), 1 (no single launch) or 2 (C-space chain)");
+    ctx->lr_chain = chain;
     return CFX_OK;
 }
 

@@ -15,25 +15,12 @@
 // and what remains between two products is the sum of the N x r partials over the slabs - three such sums in the chain (Y0, W1,
 // W2).  No barrier anywhere: every fp32 word that changes hands carries a 2-bit SEQUENCE TAG in its two lowest mantissa bits (the
 // value is rounded to 22 bits of mantissa - what the fp16 hi + lo operands of the products keep anyway), the n-th sum since the
-// hand-over arena was zeroed writes tag (n + 1) mod 4, and a reader polls the words it needs (16-byte loads that miss the CU's
-// vector cache) until all carry this sum's tag: a word holds either what the previous sum left there or the new value, never
-// anything else, because the arena belongs to the context and nothing but this kernel writes to it.
-//
-// A sum has TWO LEVELS (round 6).  The workgroups of a tensor are dealt to the XCDs round robin, the L2 of an XCD is shared by
-// its CUs and invisible to the other seven.  The slabs of a tensor form 8 logical groups of neighbouring slabs (a fixed function
-// of C); the workgroups that the dispatcher is expected to put on one XCD - a BLOCK: 8 / batch XCDs per tensor, hence 1, 2, 4 or 8
-// whole logical groups - take neighbouring groups.  Level 1: a block's workgroups leave their partials in the L2 they share
-// (plain stores: the lines stay there, dirty), each of them sums its 1 / count share of the cells over the block's slabs - the
-// slabs of a logical group four at a time in slab order, the groups by a pairwise tree - and publishes that share of the BLOCK
-// partial write-through.  Level 2: the same workgroup polls its cells of every block's partial (memory: 8 / batch small reads),
-// finishes the tree and leaves the total in the block's own copy of the sum (plain stores again), where every workgroup of the
-// block picks up the whole N x r matrix from L2.  One memory hop and two L2 hops per sum, ~1 % of the bytes of a flat sum through
-// memory.  The order of additions is a function of C alone - slab order inside a logical group, the tree above it - whatever the
-// batch, the placement or the timing: packets and states are bit-reproducible.
-// NOTHING here relies on where a workgroup really runs: every workgroup publishes the XCD it found itself on (HW_REG_XCC_ID) in
-// a roster word, and a block whose workgroups do not ALL report the same XCD takes the same steps with write-through stores (three
-// memory hops: slower, same bits).  The count of launches lives in the arena (the last workgroup of a launch moves it on): nothing
-// depends on a host-side counter, the launch can be captured in a hipGraph.
+// hand-over arena was zeroed writes tag (n + 1) mod 4, and a reader polls the words it needs (16-byte L2-bypassing loads) until all
+// carry this sum's tag: a word holds either what the previous sum left there or the new value, never anything else, because the
+// arena belongs to the context and nothing but this kernel writes to it.  A workgroup sums its 1 / nwg share of the cells over all
+// partials in fixed order (reproducible run to run), publishes the share the same way, and every workgroup polls the N x r result:
+// two memory hops per sum (~1.7 us each) instead of two grid barriers and two hops.  The count of sums lives in the arena (the last
+// workgroup of a launch moves it on): nothing depends on a host-side counter, the launch can be captured in a hipGraph.
 // Everything r x r sized - the fp64 Gram
 // matrices (v_mfma_f64_16x16x4_f64 over the fp32 values: exact products), the factorisations, Y = W T (v_mfma_f32_16x16x4_f32) - is
 // done by every workgroup redundantly: nobody waits for a broadcast.  V = U^T slab and the state update of the slab's columns come
@@ -57,32 +44,19 @@ typedef unsigned lrs_u4 __attribute__((ext_vector_type(4)));
 #define LRS_NT (64 * LRS_NW)
 #define LRS_TQ 5              // 16-row tiles per wave: 8 waves x 5 x 16 = 640 rows at most (the LDS allows ~576)
 #define LRS_ZH 40             // halves per LDS row of Z^T (32 + 8: 16-byte aligned rows spread over the banks)
-#ifndef LRS_J
-#define LRS_J 6               // cells (16 bytes each) a thread polls at once when it picks up a whole sum
-#endif
-#define LRS_CH 12             // partials of a logical group a thread has in flight at once (a group of FLUX's 96 slabs: one round trip)
-#ifndef LRS_D1
-#define LRS_D1 0
-#define LRS_D2 0
-#define LRS_D3 0
-#endif
-#define LRS_LG 8              // logical groups of neighbouring slabs per tensor (the leaves of the tree of a sum)
+#define LRS_J 6               // partials / cells (16 bytes each) a thread polls at once
 
 struct LrsArgs {
     int N, C, NPK, r, batch, nwg_t, zmod;
     int absd, u_in_packet, fuse_decode;
+    // the geometry of a sum, worked out by the host (an integer division by a run-time value is ~40 instructions, a vector one more;
+    // round 6: the index arithmetic of a sum cost ~0.4 us of the chain three times): cells a workgroup sums and threads / sub-lists
+    // per cell, [0] without / [1] with the r x r matrix behind the values; 2^20 / cw rounded up (tid / cw by multiplication: exact for tid < 512);
+    // log2 of the batch when the workgroup -> (tensor, index) map is tensors-interleaved
+    int cpw[2], cw[2], subs[2], cwinv[2], batch_log2, nxs_log2;
     size_t offU16, offV16;
-    int nx;                          // XCDs the workgroups of one tensor are dealt to (blocks of a sum): 8 / batch, or 8
-    int nx_log2, batch_log2;         // (powers of two: index arithmetic by shifts - an integer division is ~40 instructions)
-    int nch;                         // chunks of LRS_CH slabs in the largest logical group
-    unsigned pstr;                   // cells (16 bytes) from one partial to the next
-    int force_wt;                    // every block takes the write-through form (developer switch: the fall-back's bits and time)
-    // the geometry of a sum, worked out by the host (lrs_geometry): first slab of logical group g; the block that the workgroups
-    // idx = k mod nx take; per block: first slab, cells a workgroup of the block sums (without / with the r x r matrix behind the values)
-    unsigned short lgb[LRS_LG + 1], blk_of[LRS_LG], blo[LRS_LG + 1], cpw_v[LRS_LG], cpw_g[LRS_LG];
-    char* arena;                     // [256 B: word 0 = launches since the arena was zeroed] then per tensor
-                                     // [partials of every slab | 8 block partials | 8 copies of the sum | roster]
-    size_t arena_stride, offBpart, offFull, offRoster;    // bytes per tensor; offsets inside a tensor's part
+    char* arena;                     // [256 B: word 0 = launches since the arena was zeroed] then per tensor [partials of every slab | the sum]
+    size_t arena_stride, offFull;    // bytes per tensor; offset of the sum inside a tensor's part
     unsigned* tick;                  // a zeroed ticket word: workgroups that have left
     unsigned* err;
     long long timeout;
@@ -97,11 +71,6 @@ __device__ __forceinline__ float lrs_val(unsigned q) { return __builtin_bit_cast
 __device__ __forceinline__ void lrs_st16(void* p, lrs_u4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
 typedef unsigned lrs_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void lrs_st8(void* p, lrs_u2 v) { asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
-// the same stores without write-through: the line stays (dirty) in the L2 of the XCD the workgroup runs on
-__device__ __forceinline__ void lrs_st16_l2(void* p, lrs_u4 v) { asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void lrs_st8_l2(void* p, lrs_u2 v) { asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void lrs_put16(void* p, lrs_u4 v, bool l2) { if (l2) lrs_st16_l2(p, v); else lrs_st16(p, v); }
-__device__ __forceinline__ void lrs_put8(void* p, lrs_u2 v, bool l2) { if (l2) lrs_st8_l2(p, v); else lrs_st8(p, v); }
 // an fp64 value as two tagged words (hi, lo: ~44 bits of mantissa between them)
 __device__ __forceinline__ lrs_u2 lrs_pack64(double d, unsigned seq) {
     lrs_u2 o;
@@ -111,22 +80,13 @@ __device__ __forceinline__ lrs_u2 lrs_pack64(double d, unsigned seq) {
 }
 __device__ __forceinline__ double lrs_val64(unsigned hi, unsigned lo) { return (double)__builtin_bit_cast(float, hi & ~3u) + (double)__builtin_bit_cast(float, lo & ~3u); }
 #define LRS_LD16(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
-// the load that goes with the plain stores: past the CU's vector cache, served by the XCD's L2 (no coherence request to the fabric)
-#define LRS_LD16_L2(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(ptr) : "memory")
 template <int J> __device__ __forceinline__ void lrs_wait(lrs_u4 (&q)[J]) {
-    static_assert(J == 4 || J == 6 || J == 8 || J == 10 || J == 12, "operand lists below");
-    if constexpr (J == 4)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3])::"memory");
-    else if constexpr (J == 6)
+    static_assert(J == 6 || J == 10, "operand lists below");
+    if constexpr (J == 6)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5])::"memory");
-    else if constexpr (J == 8)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])::"memory");
-    else if constexpr (J == 10)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]),
-                     "+v"(q[9])::"memory");
     else
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]),
-                     "+v"(q[9]), "+v"(q[10]), "+v"(q[11])::"memory");
+                     "+v"(q[9])::"memory");
 }
 __device__ __forceinline__ bool lrs_tagged(lrs_u4 q, unsigned seq) { return ((q[0] & q[1] & q[2] & q[3] & 3u) == seq) && (((q[0] | q[1] | q[2] | q[3]) & 3u) == seq); }
 
@@ -263,40 +223,19 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     float* Lf = reinterpret_cast<float*>(Gd + RP);                    // Cholesky factor (fp32, row-major), 1 / diagonal, dead directions
     float* dinvf = Lf + RP * RP;
     unsigned* deadw = reinterpret_cast<unsigned*>(dinvf + RP);
-    char* tarena = a.arena + 256 + (size_t)z * a.arena_stride;
-    lrs_u4* part = reinterpret_cast<lrs_u4*>(tarena);                                         // [slab][pcells] cells of 4 tagged words
-    lrs_u4* bpart = reinterpret_cast<lrs_u4*>(tarena + a.offBpart);                           // [block][pcells]
-    unsigned* roster = reinterpret_cast<unsigned*>(tarena + a.offRoster);                     // [slab]: {launch | XCD of the workgroup that owns the slab}
+    lrs_u4* part = reinterpret_cast<lrs_u4*>(a.arena + 256 + (size_t)z * a.arena_stride);     // [slab][pcells] cells of 4 tagged words
+    lrs_u4* full = reinterpret_cast<lrs_u4*>(a.arena + 256 + (size_t)z * a.arena_stride + a.offFull);      // [pcells]
     const unsigned launches = __hip_atomic_load(reinterpret_cast<const unsigned*>(a.arena), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned tag0 = launches * 3u + 1u;                         // sum n since the arena was zeroed carries tag (n + 1) mod 4
     // cells (4 words) of a partial: the N x r values row by row, then an r x r fp64 matrix as (hi, lo) word pairs
     const int cells = NPK * RP / 4, gcells = RP * RP / 2, pcells = cells + gcells;
-    const size_t pstr = a.pstr;                                       // cells from one partial to the next (lrs_partial_bytes)
-    // Which slab is this workgroup's.  The dispatcher deals workgroups to the 8 XCDs round robin, so the workgroups idx = k, k + nx, ... of
-    // a tensor (nx = 8 / batch, or 8) are expected on ONE XCD: they take the slabs of one BLOCK - neighbouring slabs, whole logical
-    // groups (block b = slabs [b nwg / nx, (b + 1) nwg / nx), logical group g = slabs [g nwg / 8, (g + 1) nwg / 8)); when nwg is not
-    // a multiple of nx, the larger sets take the larger blocks.  Neighbouring slabs on one XCD also means that the two 64-byte halves
-    // of a 128-byte line of x and base are asked for by the same L2.  (Expected, not relied upon: the roster below.)
-    const int nx = a.nx, PG = LRS_LG >> a.nx_log2, pg_log2 = 3 - a.nx_log2;
-    const int hk = idx & (nx - 1), mrank = idx >> a.nx_log2;
-    const int blk = a.blk_of[hk];
-    const int bfirst = a.blo[blk], bcnt = a.blo[blk + 1] - bfirst;    // slabs (= workgroups) of this block
-    const int slab = bfirst + mrank;
-    // (what a sum needs of the tables, fetched once - under the slab's loads)
-    const int cpw_v = a.cpw_v[blk], cpw_g = a.cpw_g[blk];             // cells this workgroup sums: without / with the r x r matrix behind the values
-    const int my_lg = (blk << pg_log2) + (tid & (PG - 1));            // the logical group this THREAD sums in level 1
-    const int my_s0 = a.lgb[my_lg], my_gn = (int)a.lgb[my_lg + 1] - my_s0;
-    lrs_u4* full = reinterpret_cast<lrs_u4*>(tarena + a.offFull) + (size_t)blk * pstr;     // this block's copy of a sum, [pcells]
+    // the slab of this workgroup: with the round-robin dispatch of workgroups over the 8 XCDs, the workgroups of tensor z sit on the
+    // XCDs = z mod batch; neighbouring slabs go to ONE of them, so that the two 64-byte halves of a 128-byte line of x and base are
+    // asked for by the same L2 (a hint only: nothing depends on where a workgroup really runs)
+    int slab = idx;
+    if (a.nxs_log2 >= 0) { const int nx = 1 << a.nxs_log2; slab = (idx & (nx - 1)) * (nwg >> a.nxs_log2) + (idx >> a.nxs_log2); }      // (host: nwg is a multiple of nx)
     const int c0 = slab * LRS_SW;
-    const unsigned myxcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;                  // HW_REG_XCC_ID[3:0]
-    const unsigned rtag = (launches + 1u) & 0x0fffffffu;
-    if (tid == 0) __hip_atomic_store(&roster[slab], (rtag << 4) | myxcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #define LSTAMP(k) do { if (a.stamps && tid == 0) a.stamps[(size_t)bid * 16 + (k)] = wall_clock64(); } while (0)
-#ifdef LRS_XSTAMP
-#define XSTAMP(k) do { if (with_gram && a.stamps && tid == 0) a.stamps[(size_t)(a.nwg_t * a.batch + bid) * 16 + (k)] = wall_clock64(); } while (0)
-#else
-#define XSTAMP(k) do { } while (0)
-#endif
     LSTAMP(0);
 
     // ---------------- the slab: registers (rows t * 16 + l16 of tile t = w + LRS_NW q, columns c0 + 8 lq .. + 7) and LDS (transposed) ----------------
@@ -340,27 +279,8 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             }
         }
     }
-    // Does every workgroup of this block sit on the XCD this one sits on?  (All of them started microseconds ago: one round trip, under the
-    // LDS traffic above.)  Yes: the block's partials and its copy of the sums stay in the shared L2; no: write-through, same steps.
-    bool failed = false, l2 = false;
-    {
-        bool other = false;
-        for (int i = tid; i < bcnt; i += LRS_NT) {
-            long long t0 = 0;
-                int nfail = 0;
-            for (;;) {
-                const unsigned v = __hip_atomic_load(&roster[bfirst + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v >> 4) == rtag) { other = (v & 15u) != myxcc; break; }
-                const long long now = wall_clock64();
-                if (!t0) t0 = now;
-                else if (now - t0 > a.timeout) { failed = true; break; }
-            }
-        }
-        failed = __syncthreads_or(failed ? 1 : 0) != 0;
-        l2 = __syncthreads_or(other ? 1 : 0) == 0 && !failed && !a.force_wt;
-    }
+    __syncthreads();
     LSTAMP(1);
-    if (a.stamps && tid == 0) a.stamps[(size_t)bid * 16 + 15] = (l2 ? 1u : 0u) | (myxcc << 8) | ((unsigned)blk << 16);
 
     // Wp = slab Z as [n][RP] fp32 partial of this workgroup (write-through): D[i = rank][j = row], a lane holds 4 consecutive ranks
     auto product_b = [&](unsigned tag) {
@@ -370,7 +290,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             zh[g] = *reinterpret_cast<const h16x8*>(&Zth[(16 * g + l16) * LRS_ZH + 8 * lq]);
             zl[g] = *reinterpret_cast<const h16x8*>(&Ztl[(16 * g + l16) * LRS_ZH + 8 * lq]);
         }
-        lrs_u4* P = part + (size_t)slab * pstr;
+        lrs_u4* P = part + (size_t)slab * pcells;
         const unsigned seq = tag & 3u;
 #pragma unroll
         for (int q = 0; q < LRS_TQ; ++q) {
@@ -385,7 +305,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
                         lrs_u4 o;
 #pragma unroll
                         for (int v = 0; v < 4; ++v) o[v] = lrs_pack(acc[v], seq);
-                        lrs_put16(&P[(size_t)(t * 16 + l16) * (RP / 4) + 4 * g + lq], o, l2);
+                        lrs_st16(&P[(size_t)(t * 16 + l16) * (RP / 4) + 4 * g + lq], o);
                     }
                 }
             }
@@ -486,209 +406,107 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             for (int ks = 0; ks < 8; ++ks) { za[ks] = (double)Zf[(4 * ks + lq) * RR + 16 * gi + l16]; zb[ks] = (double)Zf[(4 * ks + lq) * RR + 16 * gj + l16]; }
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(za[ks], zb[ks], acc2, 0, 0, 0);
-            unsigned* G2 = reinterpret_cast<unsigned*>(part + (size_t)slab * pstr + cells);
+            unsigned* G2 = reinterpret_cast<unsigned*>(part + (size_t)slab * pcells + cells);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int ri = 16 * gi + lq + 4 * v, rj = 16 * gj + l16;      // D[i = lq + 4 v][j = l16]
-                if (ri < RP && rj < RP) lrs_put8(&G2[2 * (ri * RP + rj)], lrs_pack64(acc2[v], tag & 3u), l2);
+                if (ri < RP && rj < RP) lrs_st8(&G2[2 * (ri * RP + rj)], lrs_pack64(acc2[v], tag & 3u));
             }
         }
     };
 
-    // Sum of the partials over the slabs into the N x r matrix (LDS, [rank][row] fp32) - the two levels of the header.  This workgroup's
-    // share: cells [mrank cpw, (mrank + 1) cpw) of its block.
+    // Sum of the partials over the slabs into the N x r matrix (LDS, [rank][row] fp32): this workgroup's share of the cells over all
+    // partials (fixed order), published; then everybody polls the whole result
     // A wait that gives up (a.timeout ticks of the 100 MHz wall clock after its first failed poll) ends the chain for this workgroup: the
     // phases that follow are skipped, nothing more is stored - no factors from sums that never completed, the state stays as it was.
+    bool failed = false;
+    // (rank 32, 10 cells a thread in flight instead of 6 - one round trip instead of two for the gather and for a workgroup's share of the
+    // reduction: 95.7 vs 95.2 us, nothing; a sum there moves 210 KB per workgroup through sc1 loads and stores, that is what it takes)
     constexpr int JJ = LRS_J;
-    // A sum is a tree with the 8 logical groups as leaves: ((0 + 1) + (2 + 3)) + ((4 + 5) + (6 + 7)).  Which of its nodes are formed inside a
-    // block (lane exchanges) and which across blocks (through memory) depends on the batch; a value that goes through memory is rounded to
-    // the hand-over format (22 bits of mantissa; the fp64 matrix: a (hi, lo) pair).  So EVERY node is rounded to that format, wherever it
-    // is formed: the bits do not depend on the partition.
-    auto rnd4 = [](f32x4 v) -> f32x4 {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = lrs_val(lrs_pack(v[k], 0u));
-        return v;
-    };
-    auto rnd64 = [](double d) -> double { const lrs_u2 q = lrs_pack64(d, 0u); return lrs_val64(q[0], q[1]); };
-    auto tree4 = [&](f32x4 (&v)[LRS_LG], int n) -> f32x4 {
-        for (; n > 1; n >>= 1)
-#pragma unroll
-            for (int i = 0; i < LRS_LG / 2; ++i)
-                if (i < n / 2) v[i] = rnd4(v[2 * i] + v[2 * i + 1]);
-        return v[0];
-    };
-    auto tree2d = [&](double (&v)[LRS_LG][2], int n) {
-        for (; n > 1; n >>= 1)
-#pragma unroll
-            for (int i = 0; i < LRS_LG / 2; ++i)
-                if (i < n / 2) { v[i][0] = rnd64(v[2 * i][0] + v[2 * i + 1][0]); v[i][1] = rnd64(v[2 * i][1] + v[2 * i + 1][1]); }
-    };
     auto allreduce = [&](unsigned tag, bool with_gram) {
-        XSTAMP(0);
         const unsigned seq = tag & 3u;
         const int tcells = with_gram ? pcells : cells;                // with_gram: the r x r fp64 matrix behind the values is summed (in fp64) too -> Gd
-        const int cpw = with_gram ? cpw_g : cpw_v, cbase = mrank * cpw;
-        if (LRS_D1 && tag != tag0) __builtin_amdgcn_s_sleep(LRS_D1);
-        // ---- level 1: the block's partial of my cells.  A thread: one cell, the slabs of ONE logical group in slab order; the PG groups of
-        // a cell sit in neighbouring lanes and meet by the tree (lane exchanges: no LDS, no barrier) ----
-        for (int cb = 0; cb < cpw; cb += LRS_NT >> pg_log2) {
-            const int cl = cb + (tid >> pg_log2), cell = cbase + cl;
-            const bool act = cl < cpw && cell < tcells;
+        const int gi = with_gram ? 1 : 0;
+        const int cpw = a.cpw[gi], cw = a.cw[gi], subs = a.subs[gi];
+        const int sub = (int)(((unsigned)tid * (unsigned)a.cwinv[gi]) >> 20), ci = tid - sub * cw;
+        for (int cb = 0; cb < cpw; cb += cw) {
+            const int cl = cb + ci, cell = idx * cpw + cl;
+            const bool act = sub < subs && cl < cpw && cell < tcells;
             const bool dbl = cell >= cells;                           // a cell of the fp64 matrix: two (hi, lo) pairs
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
             double d0 = 0.0, d1 = 0.0;
             if (act) {
-                XSTAMP(1);
-                for (int j0 = 0; j0 < my_gn; j0 += LRS_CH) {          // (more than LRS_CH slabs a group: C > 3072)
-                    const int ns = my_gn - j0 < LRS_CH ? my_gn - j0 : LRS_CH;
-                    const lrs_u4* src = part + (size_t)(my_s0 + j0) * pstr + cell;
-                    lrs_u4 q[LRS_CH];
+                const lrs_u4* src = part + cell;
+                for (int p0 = sub; p0 < nwg; p0 += subs * JJ) {    // slab order: the result does not depend on the batch
+                    lrs_u4 q[JJ];
                     long long t0 = 0;
-                int nfail = 0;
+                    int nfail = 0;
                     for (;;) {
-                        if (l2) {
 #pragma unroll
-                            for (int j = 0; j < LRS_CH; ++j) LRS_LD16_L2(q[j], src + (size_t)(j < ns ? j : ns - 1) * pstr);  // unconditional: one round trip
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < LRS_CH; ++j) LRS_LD16(q[j], src + (size_t)(j < ns ? j : ns - 1) * pstr);
-                        }
+                        for (int j = 0; j < JJ; ++j) LRS_LD16(q[j], src + (size_t)min(p0 + subs * j, nwg - 1) * pcells);     // unconditional: one round trip
                         lrs_wait(q);
                         bool ok = true;
 #pragma unroll
-                        for (int j = 0; j < LRS_CH; ++j) ok = ok && lrs_tagged(q[j], seq);
+                        for (int j = 0; j < JJ; ++j) ok = ok && lrs_tagged(q[j], seq);
                         if (ok) break;
                         if (failed) break;
-                        if ((++nfail & 7) == 0) {                         // (the clock is a scalar memory read: not after every failed poll)
+                        if ((++nfail & 7) == 0) {                     // (the clock is a scalar memory read: not after every failed poll)
                             const long long now = wall_clock64();
                             if (!t0) t0 = now;
                             else if (now - t0 > a.timeout) { failed = true; break; }
                         }
                     }
-                    if (dbl) {
 #pragma unroll
-                        for (int j = 0; j < LRS_CH; ++j)
-                            if (j < ns) { d0 += lrs_val64(q[j][0], q[j][1]); d1 += lrs_val64(q[j][2], q[j][3]); }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < LRS_CH; ++j)
-                            if (j < ns) {
+                    for (int j = 0; j < JJ; ++j)
+                        if (p0 + subs * j < nwg) {
+                            if (dbl) { d0 += lrs_val64(q[j][0], q[j][1]); d1 += lrs_val64(q[j][2], q[j][3]); }
+                            else {
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) s[k] += lrs_val(q[j][k]);
                             }
-                    }
-                }
-                XSTAMP(2);
-            }
-            if (dbl) { const double dd[2] = {rnd64(d0), rnd64(d1)}; s = __builtin_bit_cast(f32x4, dd); }
-            else s = rnd4(s);                                         // (a leaf of the tree: rounded like every node)
-            // the tree over the PG groups of the cell: lanes l, l ^ 1 -> l (even), then l, l ^ 2, then l, l ^ 4.  Every lane of the wave takes
-            // part in the exchanges (the partner of an active lane is active: a cell's PG lanes are all in or all out)
-            int any_failed = failed ? 1 : 0;
-#pragma unroll
-            for (int st = 1; st < LRS_LG; st <<= 1) {
-                if (st < PG) {
-                    f32x4 o;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = __shfl_xor(s[k], st, 64);
-                    any_failed |= __shfl_xor(any_failed, st, 64);
-                    if (dbl) {
-                        double mine[2], theirs[2];
-                        __builtin_memcpy(mine, &s, 16); __builtin_memcpy(theirs, &o, 16);
-                        mine[0] = rnd64(mine[0] + theirs[0]); mine[1] = rnd64(mine[1] + theirs[1]);
-                        __builtin_memcpy(&s, mine, 16);
-                    } else s = rnd4(s + o);
+                        }
                 }
             }
-            if (act && (tid & (PG - 1)) == 0 && !any_failed) {        // (nobody publishes a sum one of whose terms never came)
+            if (dbl) { const double dd[2] = {d0, d1}; s = __builtin_bit_cast(f32x4, dd); }
+            if (sub < subs) red4[sub * cw + ci] = s;
+            __syncthreads();
+            if (sub == 0 && act) {
                 lrs_u4 o;
                 if (dbl) {
-                    double dd[2];
-                    __builtin_memcpy(dd, &s, 16);
-                    const lrs_u2 a0 = lrs_pack64(dd[0], seq), a1 = lrs_pack64(dd[1], seq);
-                    o[0] = a0[0]; o[1] = a0[1]; o[2] = a1[0]; o[3] = a1[1];
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) o[k] = lrs_pack(s[k], seq);
-                }
-                if (nx > 1) lrs_st16(&bpart[(size_t)blk * pstr + cell], o);      // the block's partial: through memory, for every block
-                else lrs_put16(&full[cell], o, l2);                                // one block: this IS the sum
-            }
-            XSTAMP(4);
-        }
-        if (with_gram) LSTAMP(13);
-        if (LRS_D2) __builtin_amdgcn_s_sleep(LRS_D2);
-        // ---- level 2: my cells of every block's partial (my own as it reads back: the rounded value the others see), the tree ----
-        if (nx > 1) {
-            for (int cl = tid; cl < cpw; cl += LRS_NT) {
-                const int cell = cbase + cl;
-                if (cell >= tcells) break;
-                const bool dbl = cell >= cells;
-                lrs_u4 q[LRS_LG];
-                long long t0 = 0;
-                int nfail = 0;
-                int it2 = 0;
-                for (;;) {
-                    if (++it2 <= 4) XSTAMP(4 + it2);
-#pragma unroll
-                    for (int j = 0; j < LRS_LG; ++j) LRS_LD16(q[j], bpart + (size_t)(j < nx ? j : nx - 1) * pstr + cell);
-                    lrs_wait(q);
-                    bool ok = true;
-#pragma unroll
-                    for (int j = 0; j < LRS_LG; ++j) ok = ok && lrs_tagged(q[j], seq);
-                    if (ok) break;
-                    if (failed) break;
-                    if ((++nfail & 7) == 0) {                         // (the clock is a scalar memory read: not after every failed poll)
-                        const long long now = wall_clock64();
-                        if (!t0) t0 = now;
-                        else if (now - t0 > a.timeout) { failed = true; break; }
+                    double t0d = 0.0, t1d = 0.0;
+                    for (int s2 = 0; s2 < subs; ++s2) {
+                        const f32x4 rv = red4[s2 * cw + ci];
+                        double dd[2];
+                        __builtin_memcpy(dd, &rv, 16);
+                        t0d += dd[0]; t1d += dd[1];
                     }
-                }
-                lrs_u4 o;
-                if (dbl) {
-                    double gv[LRS_LG][2];
-#pragma unroll
-                    for (int j = 0; j < LRS_LG; ++j) { gv[j][0] = lrs_val64(q[j][0], q[j][1]); gv[j][1] = lrs_val64(q[j][2], q[j][3]); }
-                    tree2d(gv, nx);
-                    const lrs_u2 a0 = lrs_pack64(gv[0][0], seq), a1 = lrs_pack64(gv[0][1], seq);
+                    const lrs_u2 a0 = lrs_pack64(t0d, seq), a1 = lrs_pack64(t1d, seq);
                     o[0] = a0[0]; o[1] = a0[1]; o[2] = a1[0]; o[3] = a1[1];
                 } else {
-                    f32x4 gv[LRS_LG];
-#pragma unroll
-                    for (int j = 0; j < LRS_LG; ++j)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) gv[j][k] = lrs_val(q[j][k]);
-                    const f32x4 t = tree4(gv, nx);
+                    f32x4 t = red4[ci];
+                    for (int s2 = 1; s2 < subs; ++s2) t += red4[s2 * cw + ci];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) o[k] = lrs_pack(t[k], seq);
                 }
-                if (!failed) lrs_put16(&full[cell], o, l2);
+                lrs_st16(&full[cell], o);
             }
+            __syncthreads();
         }
         if (with_gram) LSTAMP(12);
-        if (LRS_D3) __builtin_amdgcn_s_sleep(LRS_D3);
-        // ---- the whole sum, from this block's copy ----
-#ifndef LRS_PW
-#define LRS_PW LRS_NW
-#endif
-        constexpr int PT = 64 * LRS_PW;                               // threads that pick the sum up (the others wait at the barrier below)
-        for (int i0 = tid; i0 < tcells && tid < PT; i0 += PT * JJ) {
+        for (int i0 = tid; i0 < tcells; i0 += LRS_NT * JJ) {
             lrs_u4 q[JJ];
             long long t0 = 0;
-                int nfail = 0;
+            int nfail = 0;
             for (;;) {
 #pragma unroll
-                for (int j = 0; j < JJ; ++j) {
-                    if (l2) LRS_LD16_L2(q[j], full + min(i0 + PT * j, tcells - 1));
-                    else LRS_LD16(q[j], full + min(i0 + PT * j, tcells - 1));
-                }
+                for (int j = 0; j < JJ; ++j) LRS_LD16(q[j], full + min(i0 + LRS_NT * j, tcells - 1));
                 lrs_wait(q);
                 bool ok = true;
 #pragma unroll
                 for (int j = 0; j < JJ; ++j) ok = ok && lrs_tagged(q[j], seq);
                 if (ok) break;
                 if (failed) break;
-                if ((++nfail & 7) == 0) {                         // (the clock is a scalar memory read: not after every failed poll)
+                if ((++nfail & 7) == 0) {                     // (the clock is a scalar memory read: not after every failed poll)
                     const long long now = wall_clock64();
                     if (!t0) t0 = now;
                     else if (now - t0 > a.timeout) { failed = true; break; }
@@ -696,7 +514,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < JJ; ++j) {
-                const int c = i0 + PT * j;
+                const int c = i0 + LRS_NT * j;
                 if (c < cells) {
                     const int n = c / (RP / 4), rq = c - n * (RP / 4);
 #pragma unroll
@@ -821,12 +639,10 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     };
 
     // ---------------- Y0 = A Q0 ----------------
-    if (!failed) {
     product_b(tag0);
     LSTAMP(2);
     run_max = 0.f;
     allreduce(tag0, false);
-    }
     if (!failed) {
     norm_scale(0);
     LSTAMP(3);
@@ -835,9 +651,6 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     product_a(false, true, tag0 + 1);                                 // also: this slab's share of M1 = Z1^T Z1 (= Y0^T W1), behind the partial
     product_b(tag0 + 1);
     LSTAMP(4);
-#ifdef LRS_ACKSTAMP
-    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); LSTAMP(15); }
-#endif
     allreduce(tag0 + 1, true);                                        // W1 and M1
     LSTAMP(5);
     }
@@ -871,6 +684,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     // diagonal entry" is the wrong test for a dead direction here: a pivot is compared with its OWN diagonal entry (legitimate
     // directions: > 1e-8 of it; the null directions of a rank-deficient residual: < 1e-10)
     gram64();
+    LSTAMP(13);
     if (w == 0) {
         if constexpr (RP == 32) lrs_chol_L_blocked32(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_REL, true, scr64);
         else lrs_chol_L<RP>(Gd, r, Lf, dinvf, deadw, LRS_PIVOT_REL, true);
@@ -881,7 +695,7 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     ysc = 1.f;                                                        // (orthonormal columns: no scale - V = U^T A is wanted as it is)
     if (idx == 0) {
         h16* U16g = a.u_in_packet ? (h16*)it.packet : (h16*)(it.ws + a.offU16);
-        for (int n = tid; n < N; n += LRS_NT)
+        for (int n = tid; n < N; n += LRS_NT)                           // (a row a thread: no division per element)
             for (int m = 0; m < r; ++m) U16g[(size_t)n * r + m] = (h16)Yt[m * NPS + n];
     }
     LSTAMP(10);
@@ -965,33 +779,18 @@ bool cfx_i_lrs_ok(int N, int C, int RP) {
 
 size_t cfx_i_lrs_extra_bytes(int, int, int) { return 0; }       // nothing in the caller's workspace: the hand-over arena is the context's
 
-// Bytes from one partial to the next: the N x r values, then an r x r fp64 matrix as word pairs, rounded up to an ODD number of 256-byte
-// units.  Every workgroup writes the same rows of its partial at the same time: with a stride of a multiple of 4 KB (rank 16 and 32 at
-// N = 544: 36 864 and 77 824 bytes) all those stores went to ONE memory channel (16 channels of 256 bytes an XCD) and queued there for
-// microseconds; an odd unit count walks the channels.  (Also: no 128-byte line belongs to two partials, whose writers may sit on two XCDs.)
-static size_t lrs_partial_bytes(int npk, int RP) {
-    size_t u = (al256((size_t)npk * RP * 4 + (size_t)RP * RP * 8)) / 256;
-    if ((u & 1) == 0) ++u;
-    return u * 256;
-}
-
-// bytes of one tensor's part of the arena: the partials of every slab, 8 block partials, 8 block copies of the sum (4-byte tagged
-// words; every partial starts on a 256-byte boundary), the roster
-static size_t lrs_tensor_bytes(int N, int C, int RP, size_t* off_bpart, size_t* off_full, size_t* off_roster) {
+// bytes of one tensor's part of the arena: the partials of every slab, then the sum (4-byte tagged words)
+static size_t lrs_tensor_bytes(int N, int C, int RP, size_t* off_full) {
     const size_t npk = lrs_npk(N);
-    const size_t pbytes = lrs_partial_bytes((int)npk, RP);
-    const size_t nwg = (size_t)(C / LRS_SW);
-    const size_t part = nwg * pbytes;
-    if (off_bpart) *off_bpart = part;
-    if (off_full) *off_full = part + LRS_LG * pbytes;
-    if (off_roster) *off_roster = part + 2 * LRS_LG * pbytes;
-    return part + 2 * LRS_LG * pbytes + al256(nwg * 4);
+    const size_t pbytes = npk * RP * 4 + (size_t)RP * RP * 8;           // a partial: the N x r values, then an r x r fp64 matrix as word pairs
+    const size_t part = al256((size_t)(C / LRS_SW) * pbytes);
+    if (off_full) *off_full = part;
+    return part + al256(pbytes);
 }
 
 // The arena of `stream` laid out for this shape (allocated / zeroed as needed; the zeroing is stream-ordered before the launch).
-static char* lrs_arena(cfx_ctx* ctx, void* stream, int N, int C, int RP, int nb, size_t* stride, size_t* off_bpart, size_t* off_full,
-                       size_t* off_roster) {
-    *stride = lrs_tensor_bytes(N, C, RP, off_bpart, off_full, off_roster);
+static char* lrs_arena(cfx_ctx* ctx, void* stream, int N, int C, int RP, int nb, size_t* stride, size_t* off_full) {
+    *stride = lrs_tensor_bytes(N, C, RP, off_full);
     const size_t need = 256 + *stride * nb;
     const unsigned long long key = ((unsigned long long)N << 40) ^ ((unsigned long long)C << 16) ^ ((unsigned long long)RP << 8) ^ (unsigned long long)nb;
     int slot = -1;
@@ -1024,39 +823,6 @@ static char* lrs_arena(cfx_ctx* ctx, void* stream, int N, int C, int RP, int nb,
     return ctx->lrs_arena[slot];
 }
 
-// The geometry of a sum for `nwg` slabs a tensor and `nb` tensors a launch (see the kernel's header): 8 logical groups of neighbouring
-// slabs; nx = 8 / nb blocks (8 when nb does not divide 8) of 8 / nx whole groups; the workgroups idx = k mod nx - one XCD under round-robin
-// dispatch - take a block of their own size (nwg not a multiple of nx: the larger sets take the larger blocks).
-static void lrs_geometry(LrsArgs& a, int nwg, int nb, int cells, int pcells) {
-    a.zmod = (nb <= 8 && 8 % nb == 0) ? 1 : 0;                         // workgroup -> (tensor, index): tensors interleaved, so that a tensor's
-    a.nx = a.zmod ? 8 / nb : 8;                                       // workgroups land on 8 / batch XCDs
-    a.nx_log2 = a.nx == 8 ? 3 : (a.nx == 4 ? 2 : (a.nx == 2 ? 1 : 0));
-    a.batch_log2 = a.zmod ? 3 - a.nx_log2 : 0;
-    const int nx = a.nx;
-    for (int g = 0; g <= LRS_LG; ++g) a.lgb[g] = (unsigned short)((g * nwg) / LRS_LG);
-    int gmax = 0;
-    for (int g = 0; g < LRS_LG; ++g) gmax = a.lgb[g + 1] - a.lgb[g] > gmax ? a.lgb[g + 1] - a.lgb[g] : gmax;
-    a.nch = (gmax + LRS_CH - 1) / LRS_CH;
-    for (int q = 0; q <= LRS_LG; ++q) a.blo[q] = (unsigned short)(q <= nx ? (q * nwg) / nx : nwg);
-    const int qn = nwg / nx, rem = nwg % nx;
-    for (int k = 0; k < LRS_LG; ++k) {
-        a.blk_of[k] = 0;
-        if (k >= nx) continue;
-        const bool large = k < rem;
-        int j = large ? k : k - rem;
-        for (int q = 0; q < nx; ++q)
-            if (((a.blo[q + 1] - a.blo[q]) == qn + 1) == large) {
-                if (j == 0) { a.blk_of[k] = (unsigned short)q; break; }
-                --j;
-            }
-    }
-    for (int q = 0; q < LRS_LG; ++q) {
-        const int cnt = q < nx ? a.blo[q + 1] - a.blo[q] : 1;
-        a.cpw_v[q] = (unsigned short)((cells + cnt - 1) / cnt);
-        a.cpw_g[q] = (unsigned short)((pcells + cnt - 1) / cnt);
-    }
-}
-
 template <int RP>
 static int lrs_run(cfx_ctx* ctx, const LrBatch& b, LrsArgs a, hipStream_t s) {
     const size_t lds = (size_t)LrsLds<RP>::total(a.NPK);
@@ -1068,7 +834,19 @@ static int lrs_run(cfx_ctx* ctx, const LrBatch& b, LrsArgs a, hipStream_t s) {
         }
         attr_bytes = lds;
     }
-    // (a.zmod, a.nx: set by the caller - the arena's layout goes with them)
+    a.zmod = (a.batch <= 8 && 8 % a.batch == 0) ? 1 : 0;
+    a.batch_log2 = a.batch == 8 ? 3 : (a.batch == 4 ? 2 : (a.batch == 2 ? 1 : 0));
+    a.nxs_log2 = (a.zmod && a.nwg_t % (8 / a.batch) == 0) ? 3 - a.batch_log2 : -1;
+    {
+        const int cells = a.NPK * RP / 4, pcells = cells + RP * RP / 2;
+        for (int gi = 0; gi < 2; ++gi) {
+            const int tcells = gi ? pcells : cells;
+            a.cpw[gi] = (tcells + a.nwg_t - 1) / a.nwg_t;
+            a.cw[gi] = a.cpw[gi] < LRS_NT ? a.cpw[gi] : LRS_NT;
+            a.subs[gi] = LRS_NT / a.cw[gi];
+            a.cwinv[gi] = ((1 << 20) + a.cw[gi] - 1) / a.cw[gi];     // floor(t / cw) = (t * cwinv) >> 20: exact for every cw <= 512, t < 512
+        }
+    }
     // Two of these launches in flight at once - from two streams - could each hold only a part of the CUs and wait for workgroups
     // that find no room.  Launches of ONE stream are in order; when the stream changes, the new one first waits for everything the
     // previous one has been given so far (an event recorded there now: nothing is paid while a context keeps to one stream).
@@ -1115,10 +893,7 @@ int cfx_i_lrs_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int b
         a.absd = absd; a.u_in_packet = quantized ? 0 : 1;
         a.fuse_decode = (want_decode && !quantized && RPv <= 16) ? 1 : 0;      // (rank 32: the receiver's kernel is the MFMA form - the caller runs it)
         a.offU16 = offU16; a.offV16 = offV16;
-        a.pstr = (unsigned)(lrs_partial_bytes((int)npk, RPv) / 16);
-        lrs_geometry(a, C / LRS_SW, nb, (int)npk * RPv / 4, (int)npk * RPv / 4 + RPv * RPv / 2);
-        a.force_wt = ctx->lrs_force_wt;
-        a.arena = lrs_arena(ctx, (void*)s, N, C, RPv, nb, &a.arena_stride, &a.offBpart, &a.offFull, &a.offRoster);
+        a.arena = lrs_arena(ctx, (void*)s, N, C, RPv, nb, &a.arena_stride, &a.offFull);
         a.tick = cfx_i_ticket_block(ctx, (void*)s);
         if (!a.arena || !a.tick) return fail(ctx, CFX_ERR_LAUNCH, "low-rank: cannot set up the hand-over arena");
         a.err = ctx->gate_err;

@@ -190,9 +190,7 @@ int cfx_debug_set_launch_tags(cfx_ctx* ctx, unsigned abs_seq, unsigned mml_seq);
  *   cfx_set_gated_launch  0: the gated / exchange-layer ops always run as compress ; exchange ; reconstruct in stream order (1 = default:
  *                         the one-launch forms where they qualify)
  *   cfx_set_lr_chain      low-rank factor chain: 0 = automatic (slab-resident single launch where its workgroups fit the stream, else
- *                         the six-launch N-space chain, else the C-space chain), 1 = never the single launch, 2 = C-space chain only,
- *                         3 = automatic, but the single launch hands its sums over write-through everywhere (the form a block of
- *                         workgroups takes by itself when it does not sit on one XCD: same bits, for tests and timing)
+ *                         the six-launch N-space chain, else the C-space chain), 1 = never the single launch, 2 = C-space chain only
  *   cfx_set_lr_decode     low-rank reconstruction kernel: 0 = automatic (MFMA form at rank 32), 1 = VALU form, 2 = MFMA form
  *   cfx_set_dev_probe     developer builds only (-DCFX_DEV_PROBES): early exits of the compress kernel (tools/fused_probe.py); the product
  *                         build accepts 0 only */

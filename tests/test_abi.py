@@ -141,7 +141,7 @@ def test_context_setters_replace_the_environment_switches():
     ctx = lib.cfx_create(0)
     assert lib.cfx_set_stats_rows(ctx, 64) == 0 and lib.cfx_set_stats_rows(ctx, -1) == -5 and lib.cfx_set_stats_rows(ctx, 0) == 0
     assert lib.cfx_set_gated_launch(ctx, 0) == 0 and lib.cfx_set_gated_launch(ctx, 1) == 0
-    assert lib.cfx_set_lr_chain(ctx, 1) == 0 and lib.cfx_set_lr_chain(ctx, 3) == 0 and lib.cfx_set_lr_chain(ctx, 4) == -5 and lib.cfx_set_lr_chain(ctx, 0) == 0
+    assert lib.cfx_set_lr_chain(ctx, 1) == 0 and lib.cfx_set_lr_chain(ctx, 3) == -5 and lib.cfx_set_lr_chain(ctx, 0) == 0
     assert lib.cfx_set_lr_decode(ctx, 2) == 0 and lib.cfx_set_lr_decode(ctx, 3) == -5 and lib.cfx_set_lr_decode(ctx, 0) == 0
     assert lib.cfx_set_dev_probe(ctx, 0) == 0 and lib.cfx_set_dev_probe(ctx, 1) == -5          # the product build has no probes
     assert b"dev-probes" in lib.cfx_last_error_string(ctx)

@@ -156,12 +156,10 @@ def test_batches_bigger_than_one_launch_and_reproducible():
 
 
 @pytest.mark.parametrize("N,C,rank", [(128, 512, 8), (96, 640, 16), (160, 1152, 8), (160, 1024, 32), (544, 3072, 16)])
-def test_two_level_sums_do_not_depend_on_batch_or_transport(N, C, rank):
-    """A sum of the slab-resident launch has two levels (csrc/cfx_lrslab.hip): inside a block of workgroups that found themselves on ONE XCD
-    through the L2 they share, across the blocks through memory.  How many XCDs a tensor's workgroups are dealt to depends on the launch's
-    batch (8 / batch, or 8 when the batch does not divide 8), the order of additions must not: the same bits for every batch size, and the
-    same bits when every block hands over write-through (cfx_set_lr_chain 3 - what a block does by itself when the roster shows its
-    workgroups on different XCDs)."""
+def test_sums_do_not_depend_on_the_batch(N, C, rank):
+    """How the workgroups of a tensor are dealt to the XCDs depends on the launch's batch (tensors interleaved when the batch divides 8,
+    tensor after tensor otherwise), and so does who sums which share of a sum; the order of additions must not: the same bits for every
+    batch size, and again when the launch finds the hand-over arena as an earlier launch left it."""
     from compactfusion_amd import _lib, codecs as K
     lib = _lib.load()
     ctx = K.context(0)
@@ -173,18 +171,13 @@ def test_two_level_sums_do_not_depend_on_batch_or_transport(N, C, rank):
         p1, n1 = run([xs[i]], [bs[i]], [qs[i]], N, C, rank)
         check(xs[i], bs[i], qs[i], p1[0], n1[0], N, C, rank)
         ref_pk.append(p1[0]); ref_nb.append(n1[0])
-    try:
-        for mode in (0, 3):
-            assert lib.cfx_set_lr_chain(ctx, mode) == 0
-            for B in (1, 2, 3, 4, 5, 8):
-                if B > max(fit, 1) and B not in (2, 8):
-                    continue                                          # (a batch above what fits is split into launches of `fit`: covered by 2 and 8)
-                for rep in range(2):                                  # twice: the second launch finds the arena as the first left it
-                    pk, nb = run(xs[:B], bs[:B], qs[:B], N, C, rank)
-                    for i in range(B):
-                        assert torch.equal(pk[i], ref_pk[i]) and torch.equal(nb[i], ref_nb[i]), f"mode {mode} batch {B} tensor {i} run {rep}: bits differ"
-    finally:
-        assert lib.cfx_set_lr_chain(ctx, 0) == 0
+    for B in (1, 2, 3, 4, 5, 8):
+        if B > max(fit, 1) and B not in (2, 8):
+            continue                                                  # (a batch above what fits is split into launches of `fit`: covered by 2 and 8)
+        for rep in range(2):
+            pk, nb = run(xs[:B], bs[:B], qs[:B], N, C, rank)
+            for i in range(B):
+                assert torch.equal(pk[i], ref_pk[i]) and torch.equal(nb[i], ref_nb[i]), f"batch {B} tensor {i} run {rep}: bits differ"
     assert lib.cfx_gate_errors(ctx) == 0
 
 

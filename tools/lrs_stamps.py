@@ -9,7 +9,7 @@ from compactfusion_amd import _lib, codecs as K
 lib = _lib.load(); ctx = K.context(0)
 N, C = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (544, 3072)
 names = ["start", "slab in registers + LDS", "Y0 partial written", "Y0 summed", "W1 + M1 partial written", "W1 + M1 summed", "factor of M1, Y1",
-         "W2 partial written", "W2 summed", "P = W2^T W2, its factor", "U", "V + state done", "W1: level 2 done", "W1: level 1 done", "factor of M1"]
+         "W2 partial written", "W2 summed", "P = W2^T W2, its factor", "U", "V + state done", "W1: share summed + published", "P = W2^T W2 formed", "factor of M1"]
 for r in (8, 16, 32):
     B = 2
     xs = [torch.randn(N, C, device="cuda").half() for _ in range(B)]
@@ -24,18 +24,11 @@ for r in (8, 16, 32):
     f(); torch.cuda.synchronize()
     lib.cfx_debug_stamps(ctx, None)
     a = st.cpu().numpy().reshape(-1, 16)
-    if os.environ.get("LRS_X"):
-        xa = a[192:384][0::2]; base = a[a[:, 0] > 0][:, 0].min()
-        for k in range(10):
-            v = xa[:, k]; v = v[v > 0]
-            if len(v): print(f"   x{k}: n={len(v)} min {(v.min()-base)/100:.2f} med {(np.median(v)-base)/100:.2f} max {(v.max()-base)/100:.2f}")
     t0 = a[a[:, 0] > 0][:, 0].min()
     a = a[0::2]                                  # tensor 0 (z = workgroup % batch)
     a = a[a[:, 0] > 0]
     a = np.where(a == 0, t0, a)
-    if not os.environ.get("LRS_ACK"): print(f"({N},{C}) r={r}: {len(a)} workgroups of tensor 0; L2 form in {int((a[:, 15] & 1).sum())} of them; (block, XCD) pairs seen: {sorted(set((int(v >> 16), int((v >> 8) & 255)) for v in a[:, 15]))}")
-    if os.environ.get("LRS_ACK"):
-        names = names[:15] + ["W1 partial: stores acknowledged"]
+    print(f"({N},{C}) r={r}: {len(a)} workgroups of tensor 0")
     for k, nm in enumerate(names):
         v = (a[:, k] - t0) / 100.0
         print(f"  {nm:22s} min {v.min():7.2f}  med {np.median(v):7.2f}  max {v.max():7.2f}")
