@@ -164,7 +164,7 @@ def test_sums_do_not_depend_on_the_batch(N, C, rank):
     lib = _lib.load()
     ctx = K.context(0)
     fit = 254 // (C // 32)
-    data = [make(N, C, rank, seed=400 + i, decay=0.9 if rank == 32 else 0.7) for i in range(8)]
+    data = [make(N, C, rank, seed=400 + i, decay={8: 0.7, 16: 0.8, 32: 0.9}[rank]) for i in range(8)]
     xs, bs, qs = [d[0] for d in data], [d[1] for d in data], [d[2] for d in data]
     ref_pk, ref_nb = [], []
     for i in range(8):
