@@ -152,6 +152,8 @@ def parse():
     ap.add_argument("--copy-probe", type=int, default=0,
                     help="also launch the 96 MiB float4 copy probe this many times before the timed region "
                          "(known byte count: calibrates FETCH_SIZE / WRITE_SIZE in PMC profiles)")
+    ap.add_argument("--no-copy-rate", action="store_true",
+                    help="skip the copy-bandwidth measurement behind roofline.achievable_gbs (eight 96 MiB copy launches before the warm-up)")
     ap.add_argument("--print-config-key", action="store_true",
                     help="print the configuration key profile summaries are matched against (tools/collect_profiles.sh) and exit")
     ap.add_argument("--event-stride", type=int, default=29,
@@ -216,6 +218,32 @@ def cpu_baseline(seconds: float, codec: str = "binary"):
                       f"C oracle oracle/cfx_oracle.c with OpenMP on {best_t} threads = the fastest of a sweep over 4 .. {most} (the box reports {most} hardware threads; "
                       f"`all_threads` = the same on all of them) "
                       f"({'F16C conversions' if CO.load().oracle_uses_f16c() else 'software fp16 conversions'}); GB/s of fp16 activations through the codec"}
+
+
+def measure_copy_rate(lib, ctx, dev, stream_handle, reps=6):
+    """What this box's HBM sustains on a plain copy (the roofline fraction is quoted against the 8 TB/s spec AND against
+    this): the 96 MiB float4 copy probe of libcfx (read 96 MiB + write 96 MiB per launch, four buffer pairs in turn: 768 MiB, past the
+    Infinity Cache), hipEvents on the launch stream around each launch after two warm-up launches; the median launch."""
+    import torch
+    nb = 96 * 1024 * 1024
+    src = [torch.empty(nb, dtype=torch.uint8, device=dev).random_(0, 255) for _ in range(4)]
+    dst = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(4)]
+    st = torch.cuda.ExternalStream(stream_handle, device=dev)
+    ev = []
+    for i in range(reps + 2):
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_.record(st)
+        rc = lib.cfx_copy_probe(ctx, dst[i % 4].data_ptr(), src[i % 4].data_ptr(), nb, stream_handle)
+        b_.record(st)
+        if rc != 0:
+            return None
+        ev.append((a_, b_))
+    torch.cuda.synchronize(dev)
+    us = sorted(a_.elapsed_time(b_) * 1e3 for a_, b_ in ev[2:])
+    del src, dst
+    med = us[len(us) // 2]
+    return {"achievable_gbs": round(2 * nb / (med * 1e-6) / 1e9, 1), "copy_probe_us": round(med, 2), "copy_probe_launches": reps,
+            "copy_probe": "k_copy_probe: 96 MiB read + 96 MiB written per launch (16 B per lane, non-temporal), median of the launches"}
 
 
 def group_recv_offset(l: int, r: int, kv: int, G: int, L: int, live: int, slot: int) -> int:
@@ -636,6 +664,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    copy_rate = None
+    if real_live == 1 and not args.emulate_live and not args.no_copy_rate:
+        copy_rate = measure_copy_rate(lib, ctx, dev, sh)
     if args.copy_probe:
         nb = 96 * 1024 * 1024
         src = [torch.empty(nb, dtype=torch.uint8, device=dev).random_(0, 255) for _ in range(4)]
@@ -1167,6 +1198,11 @@ def main():
     else:
         out["roofline"] = {"bound": "hbm", "kernel": None, "achieved": step_obj["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": step_obj["frac"], "traffic": None, "step": step_obj}
+    if copy_rate is not None:
+        # the same fraction against what THIS box's HBM sustains on a plain copy (SURVEY.md section 8d asks for both)
+        out["roofline"].update(copy_rate)
+        out["roofline"]["frac_of_achievable"] = round(out["roofline"]["achieved"] / copy_rate["achievable_gbs"], 4)
+        out["roofline"]["step"]["frac_of_achievable"] = round(step_obj["achieved"] / copy_rate["achievable_gbs"], 4)
     if rank == 0 and real_live == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.codec)

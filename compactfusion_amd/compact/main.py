@@ -58,6 +58,10 @@ def compact_init(config: CompactConfig):
         _allgather_cache = AllGatherCache()
     _current_cache_key = None
     _packets.clear()
+    import sys
+    ring_ = sys.modules.get(__package__ + ".ring")
+    if ring_ is not None:
+        ring_._lane_ok.clear()                 # (process groups and the lane's streams may have changed between generations)
 
 
 def compact_reset():

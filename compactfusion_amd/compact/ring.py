@@ -104,16 +104,27 @@ def compact_fwd(q, k, v, dropout_p=0, softmax_scale=None, causal=True, window_si
             lanes.join_from_compute(dev, token)
 
 
+_lane_ok = {}        # (device, id(group)) -> world size >= 2 and the lane's streams usable: asked once, not on every layer call
+
+
 def _auto_lane(q, group) -> bool:
     if _settings.get("lane") == "off" or _settings.get("ring_exchange_stream") not in ("auto", "lane") or _schedule(q) != "gather":
         return False
-    try:
-        if dist.get_world_size(group) < 2:
-            return False
-    except Exception:  # noqa: BLE001  (no process group: a single rank has nobody to overlap with)
-        return False
-    from .. import lanes
-    return lanes.usable(q.device.index if q.device.index is not None else torch.cuda.current_device())
+    if torch.cuda.is_current_stream_capturing():
+        return False                           # the lane's flag kernels spin on words another stream writes: not capturable - the one-op path is
+    dev = q.device.index if q.device.index is not None else torch.cuda.current_device()
+    key = (dev, id(group) if group is not None else None)
+    ok = _lane_ok.get(key)
+    if ok is None:
+        try:
+            ok = dist.get_world_size(group) >= 2
+        except Exception:  # noqa: BLE001  (no process group: a single rank has nobody to overlap with)
+            ok = False
+        if ok:
+            from .. import lanes
+            ok = bool(lanes.usable(dev))
+        _lane_ok[key] = ok
+    return ok
 
 
 def compact_update_awl_scale(q, k, v) -> None:

@@ -441,9 +441,14 @@ class LayerOp:
         t = self.transport
         if t == "p2p":
             if not self.arena.ok:              # another layer of the group failed its validation: every layer leaves p2p (all ranks alike)
-                if self.region.recheck:        # ... while this one still owed the group its proof after a time-out: the owners' states are the truth
+                # ... and takes its peers' copies from their owners on the way out, whether or not it owed the group a proof: the failed
+                # validation may have been the FIRST native call after this layer's own steady launch gave up waiting (the context's error
+                # word makes that call return CFX_ERR_GATE without launching and is cleared by it) - this layer then stored nothing, nobody
+                # set its `recheck`, and under error feedback its copies would stay a delta behind for good.  One all-gather of the layer's
+                # K,V per layer, once, on a path that has already failed.
+                if not self.arena.loopback:
                     self._resync(self.own)
-                    self.region.recheck = 0
+                self.region.recheck = 0
                 self.fallback_reason = self.arena.why
                 self._choose_transport(exclude=("p2p",))
                 return self.run(k, v, sh)
@@ -469,6 +474,8 @@ class LayerOp:
             # the next step boundary, and issue this layer's launch - the flag epochs have to keep step with the peers'
             if self.lib.cfx_gate_errors(self.ctx) > 0:
                 self.arena.health.note_error()
+                self.lib.cfx_gate_recover(self.ctx)      # local counters only: without it every launch of this ring slot would sit out the whole
+                #                                          timeout on the short arrival count until the group's boundary a step or two later
                 warnings.warn("compactfusion_amd: an in-launch wait of the peer-to-peer exchange timed out (a peer was later than the gate "
                               "timeout); nothing was stored, the group validates its layers again at the next step boundary")
             rc = self._run_x(ent[0], op, 1, xs, 2, sh)
@@ -519,8 +526,10 @@ class LayerOp:
         stream = torch.cuda.current_stream(self.device)
         stream.synchronize()
         bad = 1 if rc != 0 else 0
-        if lib.cfx_gate_errors(ctx) != 0:
+        if lib.cfx_gate_errors(ctx) != 0:      # (also the word an EARLIER layer's steady launch left: rc is CFX_ERR_GATE then and nothing was launched)
             bad = 1
+            self.arena.health.note_error()
+            lib.cfx_gate_recover(ctx)          # local counters only: the launches that follow must not sit out the timeout on a short count
         if self.own_update == "ef":
             # error feedback: what every peer reconstructed of a shard IS its owner's state
             mine = self._checksums(self.own)

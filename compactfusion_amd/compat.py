@@ -10,8 +10,15 @@ from __future__ import annotations
 import importlib
 import sys
 
-_COMPACT_MODULES = ("main", "utils", "ring", "fastpath", "slowpath", "compress_quantize", "compress_topk", "compress_lowrank", "stats",
-                    "patchpara.df_utils", "patchpara.df_cache", "patchpara.fwd")
+import pkgutil
+
+
+def _compact_modules() -> list:
+    """Every submodule of compactfusion_amd.compact (walked, not listed: a module that is reachable only through the aliased parent's
+    __path__ would be imported a SECOND time under the xfuser.* name - duplicate classes, duplicate module-level state)."""
+    pkg = importlib.import_module("compactfusion_amd.compact")
+    return sorted(m.name[len("compactfusion_amd.compact."):] for m in pkgutil.walk_packages(pkg.__path__, "compactfusion_amd.compact.")
+                  if not m.ispkg)
 
 
 def install_xfuser_alias(overwrite: bool = False) -> list:
@@ -27,7 +34,7 @@ def install_xfuser_alias(overwrite: bool = False) -> list:
         done.append(alias)
     reg("xfuser.compact", "compactfusion_amd.compact")
     reg("xfuser.compact.patchpara", "compactfusion_amd.compact.patchpara")
-    for m in _COMPACT_MODULES:
+    for m in _compact_modules():
         reg(f"xfuser.compact.{m}", f"compactfusion_amd.compact.{m}")
     reg("xfuser.prof", "compactfusion_amd.prof")
     reg("xfuser.collector.collector", "compactfusion_amd.collector.collector")

@@ -331,7 +331,7 @@ def w_stack(rank, world, codec_name):
     return res
 
 
-def w_xlayer(rank, world, codec_name, mode, poison, gens, steps=4, ef=True, late=None, gate_timeout_ms=0):
+def w_xlayer(rank, world, codec_name, mode, poison, gens, steps=4, ef=True, late=None, gate_timeout_ms=0, revalidate_every=0):
     """The product path of the gather schedules - ONE native op per layer (compact/xlayer.py) - over `gens` generations with
     compact_reset in between: `mode` = "ring" (compact_fwd, gather schedule) or "gather" (compact_all_gather_kv, what patch_gather_fwd
     calls).  poison >= 0: rank 1 corrupts a peer's reconstruction right before its validated p2p execution `poison` - every rank must
@@ -349,6 +349,11 @@ def w_xlayer(rank, world, codec_name, mode, poison, gens, steps=4, ef=True, late
     if gate_timeout_ms:
         from compactfusion_amd import _lib, codecs
         assert _lib.load().cfx_set_gate_timeout_ms(codecs.context(torch.cuda.current_device()), gate_timeout_ms) == 0
+    if revalidate_every:
+        # the periodic re-validation of arenas that did not come out uncached: ask for fine-grained memory and shorten the period
+        from compactfusion_amd import _lib, codecs
+        assert _lib.load().cfx_set_ipc_memory_kind(codecs.context(torch.cuda.current_device()), 1) == 0
+        xlayer.REVALIDATE_EVERY = revalidate_every
     if poison >= 0:
         # test-side only: the checksum of the first peer tensor is taken over a corrupted copy of what the launch reconstructed
         orig, done = xlayer.LayerOp._checksums, []
@@ -367,6 +372,7 @@ def w_xlayer(rank, world, codec_name, mode, poison, gens, steps=4, ef=True, late
     cm.compact_init(CompactConfig(**kw))
     res = {}
     free = []
+    late_done = []
     for gen in range(gens):
         if gen:
             cm.compact_reset()
@@ -376,9 +382,17 @@ def w_xlayer(rank, world, codec_name, mode, poison, gens, steps=4, ef=True, late
         for step in range(STEPS):
             cm.compact_set_step(step)
             for l in range(L):
-                if late is not None and rank == 1 and step == late[0] and l == (late[2] if len(late) > 2 else 0):
-                    torch.cuda.synchronize()
-                    time.sleep(late[1])
+                if late is not None and rank == 1 and l == (late[2] if len(late) > 2 else 0):
+                    due = step == late[0]
+                    if late[0] == "before_revalidation" and not late_done:
+                        # the step after which layer 0's next execution is a periodic re-validation (its region has executed this step already)
+                        op0 = [e.xop for k_, e in ring_mod._xbuf.items() if k_[0] == 0 and e.xop is not None]
+                        due = bool(op0) and op0[0].region is not None and op0[0].region.validated >= xlayer.VALIDATE_FIRST \
+                            and op0[0].region.n_exec % xlayer.REVALIDATE_EVERY == 0 and op0[0].transport == "p2p"
+                    if due:
+                        late_done.append(step)
+                        torch.cuda.synchronize()
+                        time.sleep(late[1])
                 out, lse, _ = compact_fwd(TD(qs[l][step]), TD(ks[l][step]), TD(vs[l][step]), causal=False, group=None, mod_idx=l, current_iter=step)
                 assert out.shape == (B, S, Hh, Dh)
             if gens <= 2:
@@ -396,6 +410,7 @@ def w_xlayer(rank, world, codec_name, mode, poison, gens, steps=4, ef=True, late
     res["fell_back"] = np.array([sum(1 for o in ops if o.fallback_reason is not None)])
     res["validated"] = np.array([min([o.region.validated for o in ops if o.region is not None] or [-1])])
     res["free"] = np.array(free, dtype=np.int64)
+    res["late_at_step"] = np.array(late_done or [-1])
     dist.barrier()
     xlayer.release()
     return res

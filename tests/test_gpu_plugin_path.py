@@ -278,6 +278,29 @@ def test_a_wait_that_times_out_stores_nothing_and_the_group_recovers(tmp_path):
                         assert np.array_equal(res[1][f"g0/s{s}/l{l}/{nm}{q}"].reshape(-1), want[s].reshape(-1)), (l, q, nm, s)
 
 
+def test_a_timeout_in_the_last_launch_before_a_revalidation_step_is_not_swallowed(tmp_path):
+    """the arena is not uncached, so every 6th execution of a layer validates itself.  Rank 1 arrives 2.5 s late (gate timeout
+    1 s) at the LAST layer of the step before such a step: rank 0's launch of that layer gives up and stores nothing, and the next native
+    call - layer 0's VALIDATED execution - finds the context's error word: it returns without launching and clears the word.  The
+    validation fails for layer 0; the layer that really missed its update never owed the group a proof (`recheck` 0).  Every layer must
+    nevertheless leave the failed transport with its peers' copies taken from their owners: at the end both ranks hold the SAME state of
+    every shard of every layer."""
+    STEPS, EVERY = 16, 6
+    res = _spawn(W.w_xlayer, 2, tmp_path, "BINARY", "ring", -1, 1, STEPS, True, ("before_revalidation", 2.5, 2), 1000, EVERY)
+    assert 0 < int(res[1]["late_at_step"][0]) < STEPS - 3, "the run never reached a step before a periodic re-validation"
+    for r in range(2):
+        assert int(res[r]["fell_back"][0]) >= 1, (r, res[r]["p2p"], res[r]["fell_back"])
+    shape = (1, 64, 8, 64)
+    for l in range(3):
+        for q in range(2):
+            for nm, seed in (("k", 17), ("v", 27)):
+                want = _chain("BINARY", W.drift(seed + 10 * l + q, shape, STEPS))
+                for s in (STEPS - 2, STEPS - 1):
+                    assert np.array_equal(res[0][f"g0/s{s}/l{l}/{nm}{q}"], res[1][f"g0/s{s}/l{l}/{nm}{q}"]), (l, q, nm, s)
+                    if q == 1:
+                        assert np.array_equal(res[1][f"g0/s{s}/l{l}/{nm}{q}"].reshape(-1), want[s].reshape(-1)), (l, q, nm, s)
+
+
 def test_twenty_resets_leave_device_memory_flat(tmp_path):
     res = _spawn(W.w_xlayer, 2, tmp_path, "BINARY", "ring", -1, 22)
     for r in range(2):

@@ -418,6 +418,12 @@ def test_install_xfuser_alias_resolves_the_reference_import_paths():
         "from xfuser.collector.collector import Collector, init, collect\n"
         "import compactfusion_amd.compact.main as m\n"
         "assert compact_init is m.compact_init and len(names) >= 15\n"
+        "import compactfusion_amd.compact as c, importlib\n"
+        "for sub in ('presets', 'plot', 'lowrank', 'xlayer', 'patchpara.state', 'patchpara.fwd', 'attention'):\n"
+        "    assert sys.modules['xfuser.compact.' + sub] is importlib.import_module('compactfusion_amd.compact.' + sub), sub\n"
+        "from xfuser.compact.presets import get_config\n"
+        "from xfuser.compact.patchpara.state import PatchConfig as P2\n"
+        "assert P2 is PatchConfig, 'PatchConfig exists twice'\n"
         "print('ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]

@@ -85,6 +85,9 @@ def configs_leg(out, hbm_peak_gbs):
             key = name.split()[0] + (" " + " ".join(name.split()[-2:]) if name.startswith("5") else "")
             cfgs[key] = {"workload": name, "shard": [n_, c_], "layers": l_, "ms_per_step": round(ms_, 4), "alg_bytes": ab,
                          "frac": round(ab / (ms_ * 1e-3) / 1e9 / hbm_peak_gbs, 4)}
+            ach_ = (out.get("roofline") or {}).get("achievable_gbs")
+            if ach_:
+                cfgs[key]["frac_of_achievable"] = round(ab / (ms_ * 1e-3) / 1e9 / ach_, 4)
             torch.cuda.empty_cache()
         out["configs"] = cfgs
     except Exception as e:  # pragma: no cover
@@ -120,6 +123,6 @@ def lowrank_leg(out, dev, N, C):
             lr[name] = round(e0.elapsed_time(e1) / (3 * Lr) * 1e3, 1)
         out["low_rank_presets"] = {"us_per_kv_pair_compress": lr, "shard": [N, C],
                                    "what": "cfx_lr_compress_batch, one persistent launch per K,V pair (csrc/cfx_lrslab.hip) + the int4 factor "
-                                           "quantiser for LOW_RANK_Q; profiles/r05_lowrank_*"}
+                                           "quantiser for LOW_RANK_Q; profiles/r06_lowrank_*"}
     except Exception as e:  # pragma: no cover
         out["low_rank_presets"] = {"error": f"{type(e).__name__}: {e}"}
