@@ -223,27 +223,28 @@ def cpu_baseline(seconds: float, codec: str = "binary"):
 def measure_copy_rate(lib, ctx, dev, stream_handle, reps=6):
     """What this box's HBM sustains on a plain copy (the roofline fraction is quoted against the 8 TB/s spec AND against
     this): the 96 MiB float4 copy probe of libcfx (read 96 MiB + write 96 MiB per launch, four buffer pairs in turn: 768 MiB, past the
-    Infinity Cache), hipEvents on the launch stream around each launch after two warm-up launches; the median launch."""
+    Infinity Cache), hipEvents on the launch stream around groups of four launches after a warm-up group; the median group."""
     import torch
     nb = 96 * 1024 * 1024
     src = [torch.empty(nb, dtype=torch.uint8, device=dev).random_(0, 255) for _ in range(4)]
     dst = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(4)]
     st = torch.cuda.ExternalStream(stream_handle, device=dev)
     ev = []
-    for i in range(reps + 2):
+    for g_ in range(reps + 1):                     # groups of four back-to-back launches (an event pair around ONE launch adds the launch gap)
         a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a_.record(st)
-        rc = lib.cfx_copy_probe(ctx, dst[i % 4].data_ptr(), src[i % 4].data_ptr(), nb, stream_handle)
+        for i in range(4):
+            if lib.cfx_copy_probe(ctx, dst[i].data_ptr(), src[i].data_ptr(), nb, stream_handle) != 0:
+                return None
         b_.record(st)
-        if rc != 0:
-            return None
         ev.append((a_, b_))
     torch.cuda.synchronize(dev)
-    us = sorted(a_.elapsed_time(b_) * 1e3 for a_, b_ in ev[2:])
+    us = sorted(a_.elapsed_time(b_) * 1e3 / 4 for a_, b_ in ev[1:])
     del src, dst
     med = us[len(us) // 2]
-    return {"achievable_gbs": round(2 * nb / (med * 1e-6) / 1e9, 1), "copy_probe_us": round(med, 2), "copy_probe_launches": reps,
-            "copy_probe": "k_copy_probe: 96 MiB read + 96 MiB written per launch (16 B per lane, non-temporal), median of the launches"}
+    return {"achievable_gbs": round(2 * nb / (med * 1e-6) / 1e9, 1), "copy_probe_us": round(med, 2), "copy_probe_launches": 4 * reps,
+            "copy_probe": "k_copy_probe: 96 MiB read + 96 MiB written per launch (16 B per lane), four buffer pairs back to back between two "
+                          "hipEvents, median group / 4"}
 
 
 def group_recv_offset(l: int, r: int, kv: int, G: int, L: int, live: int, slot: int) -> int:

@@ -51,13 +51,10 @@ SYMBOLS = [
     ("cfx_gate_recover", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_prepare", ctypes.c_int, [ctypes.c_void_p]),
     ("cfx_set_fused_finalize", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
-    ("cfx_debug_stamps", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
-    ("cfx_debug_set_launch_tags", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
     ("cfx_set_stats_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_set_gated_launch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_set_lr_chain", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_set_lr_decode", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
-    ("cfx_set_dev_probe", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_hw_queues_ok", ctypes.c_int, []),
     ("cfx_set_allow_shared_queues", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("cfx_ipc_memory_kind", ctypes.c_int, [ctypes.c_void_p]),
@@ -154,11 +151,29 @@ SYMBOLS = [
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]),
 ]
 
+# include/cfx_dev.h: exported by the DEVELOPER library only (libcfx_dev.so, -DCFX_DEV_PROBES).  Bound when - and only when - that library
+# was loaded in place of the product one (CFX_LIBCFX_PATH, or use_dev_library() before the first load): tools/*_stamps.py, tests/tagwrap_child.py
+DEV_SYMBOLS = [
+    ("cfx_dev_stamps", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    ("cfx_dev_set_launch_tags", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint]),
+    ("cfx_dev_set_probe", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+]
+
 _lib = None
 
 
 class CfxError(RuntimeError):
     pass
+
+
+def use_dev_library() -> str:
+    """Developer tools: make this process load libcfx_dev.so (built on demand) instead of libcfx.so.  Must run before the first load()."""
+    if _lib is not None:
+        raise CfxError("the library is loaded already: call use_dev_library() first")
+    from .build import build_lib
+    path = build_lib(dev_probes=True)
+    os.environ["CFX_LIBCFX_PATH"] = path
+    return path
 
 
 def load(build_if_missing: bool = True) -> ctypes.CDLL:
@@ -177,5 +192,10 @@ def load(build_if_missing: bool = True) -> ctypes.CDLL:
         fn.argtypes = args
     if lib.cfx_abi_version() != 1:
         raise CfxError("libcfx.so ABI version mismatch")
+    if hasattr(lib, "cfx_dev_stamps"):                               # the developer library: its extra entry points too
+        for name, res, args in DEV_SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib

@@ -6,6 +6,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include "cfx.h"
+#ifdef CFX_DEV_PROBES
+#include "cfx_dev.h"
+#endif
 
 enum {
     KID_ABSMEAN_STATS_BITS = 1, KID_ABSMEAN_STATS = 2, KID_ABSMEAN_FINALIZE = 3, KID_BINARY_DEQUANT = 4,
@@ -26,6 +29,30 @@ static const char* const kid_names[KID_MAX] = {
     "k_binary_pipe", "k_binary_pipe(prologue/epilogue)", "k_residual2_delta", "k_residual2_update",
     "k_absmean_compress<bits>", "k_absmean_compress", "k_minmax_compress", "k_attn_merge",
     "gated layer launch (k_absmean_compress<bits,gated> / k_int2_compress_gated / k_minmax_layer / k_topk_layer)"};
+
+// Developer probes (include/cfx_dev.h; `python -m compactfusion_amd.build --dev-probes` builds libcfx_dev.so with -DCFX_DEV_PROBES): phase
+// times of a workgroup on the 100 MHz wall clock, 16 words a workgroup.  In the PRODUCT build `Probe` is an empty type - no kernel
+// argument, no register, no branch in any kernel - and the entry points that would set one up do not exist.
+#ifdef CFX_DEV_PROBES
+struct Probe {
+    unsigned long long* p;
+    __host__ __device__ Probe(unsigned long long* q = nullptr) : p(q) {}
+    __device__ __forceinline__ bool on() const { return p != nullptr; }
+    __device__ __forceinline__ void at(int k) const { if (p && threadIdx.x == 0) p[k] = (unsigned long long)wall_clock64(); }
+    __device__ __forceinline__ void set(int k, unsigned long long v) const { if (p && threadIdx.x == 0) p[k] = v; }
+    __device__ __forceinline__ void copy(int dst, int src) const { if (p && threadIdx.x == 0) p[dst] = p[src]; }
+    __device__ __forceinline__ Probe of(size_t wg) const { return Probe(p ? p + wg * 16 : nullptr); }
+};
+#else
+struct Probe {
+    __host__ __device__ Probe() {}
+    __device__ __forceinline__ constexpr bool on() const { return false; }
+    __device__ __forceinline__ void at(int) const {}
+    __device__ __forceinline__ void set(int, unsigned long long) const {}
+    __device__ __forceinline__ void copy(int, int) const {}
+    __device__ __forceinline__ Probe of(size_t) const { return Probe(); }
+};
+#endif
 
 struct ProfRec { int kid; hipEvent_t a, b; };
 #define CFX_RING_STREAMS 8       // ticket / gate rings of a context: one per stream that issues compress launches
@@ -64,7 +91,7 @@ struct cfx_ctx {
     unsigned* gate_err;             // pinned HOST word (device-visible): waits that timed out since the last cfx_gate_errors
     long long gate_timeout;         // ticks of the 100 MHz wall clock a flag wait may last
     int fused;                      // 1 (default): compress = statistics + in-launch finalize; 0: separate finalize kernel
-    void* dbg_stamps;               // developer hook (cfx_debug_stamps)
+    void* dev_buf;                  // cfx_dev_stamps (developer build): where the probes write
     int stats_rows;                 // cfx_set_stats_rows: override of the statistics tile height (experiments), 0 = automatic
     int gated_on;                   // cfx_set_gated_launch: 1 (default) the one-launch gated / exchange-layer forms where they qualify
     int lr_chain, lr_decode;        // cfx_set_lr_chain / cfx_set_lr_decode (0 = automatic)
@@ -84,6 +111,17 @@ struct cfx_ctx {
     hipEvent_t lrs_ev;
     char err[256];
 };
+
+// what the launches of a context hand their kernels as `Probe` (developer build: the buffer cfx_dev_stamps set; product build: nothing)
+static inline Probe cfx_i_probe(const cfx_ctx* ctx) {
+#ifdef CFX_DEV_PROBES
+    return Probe((unsigned long long*)ctx->dev_buf);
+#else
+    (void)ctx;
+    return Probe();
+#endif
+}
+
 
 // Returns the record slot for this launch or -1.  A profiled launch goes through hipExtLaunchKernelGGL, which ties the
 // two events to the dispatch packet itself: their elapsed time is the kernel's execution time (as rocprofv3 reports it),

@@ -257,9 +257,9 @@ __device__ __forceinline__ TileCoord tile_coord(int N, int C, int R) { return ti
 // column partials, so a tile's bits are in memory by then; its row partials need not wait for anything.
 template <bool EMIT_BITS, int US, bool WT = false, int NW = WAVES, bool PUB = false, bool KEEP = false, bool TAG = false>
 __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int N, int C, int R, int CB, int bx, int by,
-                                                   u64* rowpart, u64 (*sm)[TILE_C], u64* stamps = nullptr,
+                                                   u64* rowpart, u64 (*sm)[TILE_C], Probe probe = Probe(),
                                                    h16x8* xk = nullptr, h16x8* bk = nullptr, TagArena ta = TagArena()) {
-#define SSTAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
+#define SSTAMP(k) probe.at(k)
     const TileCoord t = tile_coord_at(bx, by, N, C, R);
     const int cb = bx;
     u64* colpart = rowpart + (size_t)N * CB;
@@ -293,7 +293,7 @@ __device__ __forceinline__ void absmean_stats_body(const cfx_comp_item& it, int 
             for (int j = 0; j < US; ++j) { xk[j] = xv[j]; bk[j] = bv[j]; }
         }
         u64 rs[4] = {0, 0, 0, 0};           // the butterfly reduces 4 rows; unused ones stay 0
-        if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SSTAMP(8); }
+        if (probe.on()) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SSTAMP(8); }
 #pragma unroll
         for (int j = 0; j < US; ++j) {
             const int rr = r + NW * j;
@@ -766,12 +766,12 @@ __device__ __forceinline__ bool scales_from_tagged(const TagArena& ta, int N, in
 template <int NW, int KR, int KL, bool ST>
 __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item& it, int N, int C, int R, int tile_x, int tile_y,
                                                          unsigned* gate, unsigned expect, unsigned* err, long long timeout, u32x4* lds,
-                                                         u64* stamps = nullptr, bool remote = false, bool tagged = false, TagArena ta = TagArena(),
+                                                         Probe probe = Probe(), bool remote = false, bool tagged = false, TagArena ta = TagArena(),
                                                          u16* s16 = nullptr) {
     constexpr int K = KR + KL;
-#define GSTAMP(k) do { if (ST && stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (threadIdx.x == 0) stamps[k] = wall_clock64(); } } while (0)
+#define GSTAMP(k) do { if (ST && probe.on()) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); probe.at(k); } } while (0)
     const TileCoord t = tile_coord_at(tile_x, tile_y, N, C, R);
-    if (ST && stamps && threadIdx.x == 0) { stamps[0] = wall_clock64(); stamps[7] = 4; }
+    if (ST) { probe.at(0); probe.set(7, 4); }
     const unsigned char* pk = (const unsigned char*)it.packet;
     const int C8 = C >> 3;
     const u16* U = (const u16*)(pk + (size_t)N * C8);
@@ -803,7 +803,7 @@ __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item&
     if (tagged) {
         // the packet is one of THIS launch's: its scales come as tagged words (no gate); the sign bits' loads go out with the scale words'
         scales_watch(ta, N, C, tile_x * TILE_C, t.r0, timeout);
-        if (ST && stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
+        if (ST) probe.at(2);
 #pragma unroll
         for (int j = 0; j < K; ++j) by[j] = ld_wt(pk + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C8 + (cc >> 3));
         if (!scales_from_tagged<NW * K, false>(ta, N, C, tile_x * TILE_C, t.r0, s16, timeout, err)) return;
@@ -811,7 +811,7 @@ __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item&
         ul = s16[TILE_C + min(t.w + NW * min(t.lane, K - 1), t.r1 - 1 - t.r0)];
     } else if (!gate_wait<true>(gate, expect, err, timeout)) return;
     else if (remote) {
-        if (ST && stamps && threadIdx.x == 0) stamps[2] = wall_clock64();                                            // (uniform) the packet sits in a peer GPU's memory: system-scope loads
+        if (ST) probe.at(2);                                            // (uniform) the packet sits in a peer GPU's memory: system-scope loads
         u16x8 vb;
 #pragma unroll
         for (int i = 0; i < 8; ++i) vb[i] = ld_sys(V + cc + i);
@@ -820,7 +820,7 @@ __device__ __forceinline__ void binary_dequant_gated_body(const cfx_decomp_item&
 #pragma unroll
         for (int j = 0; j < K; ++j) by[j] = ld_sys(pk + (size_t)min(t.r0 + t.w + NW * j, t.r1 - 1) * C8 + (cc >> 3));
     } else {
-        if (ST && stamps && threadIdx.x == 0) stamps[2] = wall_clock64();
+        if (ST) probe.at(2);
         v8 = ld8_wt(V + cc);
         // a row's token scale is wave-uniform: lane j fetches row j's, broadcast by readlane below
         ul = ld_wt(U + min(t.r0 + t.w + NW * min(t.lane, K - 1), t.r1 - 1));
@@ -918,9 +918,9 @@ __device__ __forceinline__ void row_sums2_wt(const u64* rowpart, const unsigned*
 template <bool GATED>
 __device__ __forceinline__ void absmean_last_arriver_jobs(const cfx_comp_item& it, int N, int C, int CB, int P, int bx, u64* rowpart,
                                                           unsigned* tick, int per_byte, int eps_mode, u64 (*sm)[TILE_C], bool last_col,
-                                                          bool last_all, u64* stamps, unsigned* gate, unsigned gate_expect) {
+                                                          bool last_all, Probe probe, unsigned* gate, unsigned gate_expect) {
     constexpr int NT = FUSED_NT;
-#define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
+#define STAMP(k) probe.at(k)
     lds_barrier();                             // the flags have been read: sm may be reused
     // The last arrivers' reductions are ONE fabric round trip when N <= 2 NT and P <= FUSED_CH: every load is unconditional
     // (clamped index, masked value) and the loads of BOTH jobs - a workgroup is often last of its column block and of the
@@ -1033,10 +1033,10 @@ __device__ __forceinline__ void absmean_last_arriver_jobs(const cfx_comp_item& i
 // layer's first form).  A thread's loads of a round are issued together, then the tags compared (a test per load serialises them).
 // Arithmetic = absmean_last_arriver_jobs (exact integer sums: bit-identical for any order).  do_col / do_row: uniform per workgroup.
 __device__ __forceinline__ void absmean_tagged_jobs(const cfx_comp_item& it, int N, int C, int CB, int P, int bx, u64* rowpart, const TagArena& ta,
-                                                    int per_byte, int eps_mode, u64 (*sm)[TILE_C], bool do_col, bool do_row, u64* stamps,
+                                                    int per_byte, int eps_mode, u64 (*sm)[TILE_C], bool do_col, bool do_row, Probe probe,
                                                     unsigned* gate, unsigned* err, long long timeout) {
     constexpr int NT = FUSED_NT;
-#define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
+#define STAMP(k) probe.at(k)
     lds_barrier();                             // sm may be reused
     const int tid = threadIdx.x;
     const u64* colpart = rowpart + (size_t)N * CB;
@@ -1217,11 +1217,11 @@ __device__ __forceinline__ void own_tile_finish(const cfx_comp_item& it, int N, 
 template <bool EMIT_BITS, int US, bool GATED = false, bool KEEP = false>
 __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int N, int C, int R, int CB, int P, int bx, int by,
                                                    u64* rowpart, unsigned* tick, int per_byte, int eps_mode, u64 (*sm)[TILE_C], int dbg,
-                                                   u64* stamps, unsigned* gate = nullptr, unsigned gate_expect = 0, int flags = 0,
+                                                   Probe probe, unsigned* gate = nullptr, unsigned gate_expect = 0, int flags = 0,
                                                    unsigned* gate2 = nullptr, unsigned expect2 = 0, unsigned* err = nullptr, long long timeout = 0,
                                                    TagArena ta = TagArena()) {
-    // developer hook (cfx_debug_stamps): per-workgroup phase times, 100 MHz wall clock
-#define STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
+    // developer probes (cfx_dev.h): per-workgroup phase times, 100 MHz wall clock
+#define STAMP(k) probe.at(k)
     STAMP(0);
 #ifdef CFX_DEV_PROBES                          // experiment early exits: only in a developer build (python -m compactfusion_amd.build --dev-probes)
     if (dbg == 3) return;                      // experiments: launch cost of the empty grid
@@ -1244,13 +1244,13 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
     }
 #endif
     h16x8 xk[KEEP ? US : 1], bk[KEEP ? US : 1];
-    absmean_stats_body<EMIT_BITS, US, true, FUSED_NW, GATED, KEEP, GATED>(it, N, C, R, CB, bx, by, rowpart, sm, stamps, xk, bk, ta);
+    absmean_stats_body<EMIT_BITS, US, true, FUSED_NW, GATED, KEEP, GATED>(it, N, C, R, CB, bx, by, rowpart, sm, probe, xk, bk, ta);
     STAMP(1);
     if constexpr (GATED) {
         // the layer launches: tagged partials, fixed reducers (absmean_tagged_jobs) - nothing to drain, no ticket to draw
         const bool v_wg = by == P - 1;
         const bool u_wg = P >= 2 ? (by == P - 2 && bx == CB - 1) : (bx == CB - 1);
-        if (stamps && threadIdx.x == 0) { stamps[2] = stamps[3] = stamps[1]; stamps[7] = (v_wg ? 1 : 0) | (u_wg ? 2 : 0); }
+        probe.copy(2, 1); probe.copy(3, 1); probe.set(7, (v_wg ? 1 : 0) | (u_wg ? 2 : 0));
         if (v_wg || u_wg) {
             // KEEP: the jobs' loads in flight beside the whole tile do not fit 128 registers (tools/resource_usage.py, tests/test_resource_usage.py)
             // - the tile's last two rows of x and of the state sit out the jobs in the LDS rows the statistics do not use (sm[FUSED_NW ..]:
@@ -1260,7 +1260,7 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
                 park[threadIdx.x] = __builtin_bit_cast(u32x4, xk[US - 1]);
                 park[FUSED_NT + threadIdx.x] = __builtin_bit_cast(u32x4, bk[US - 1]);
             }
-            absmean_tagged_jobs(it, N, C, CB, P, bx, rowpart, ta, per_byte, eps_mode, sm, v_wg, u_wg, stamps, gate, err, timeout);
+            absmean_tagged_jobs(it, N, C, CB, P, bx, rowpart, ta, per_byte, eps_mode, sm, v_wg, u_wg, probe, gate, err, timeout);
             if constexpr (KEEP) {
                 xk[US - 1] = __builtin_bit_cast(h16x8, park[threadIdx.x]);
                 bk[US - 1] = __builtin_bit_cast(h16x8, park[FUSED_NT + threadIdx.x]);
@@ -1286,7 +1286,7 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
     const bool last_col = flag[0] == (unsigned)(P - 1);
     const bool u_wg = bx == 0 && by == 0;
     STAMP(3);
-    if (stamps && threadIdx.x == 0) stamps[7] = (last_col ? 1 : 0) | (u_wg ? 2 : 0);
+    probe.set(7, (last_col ? 1 : 0) | (u_wg ? 2 : 0));
 #ifdef CFX_DEV_PROBES
     if (dbg == 2) {
         if (last_col && threadIdx.x == 0) st_wt(tick + 1 + bx, 0u);
@@ -1298,7 +1298,7 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
     }
 #endif
     if (last_col)                          // uniform per workgroup
-        absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, true, false, stamps, gate, gate_expect);
+        absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, true, false, probe, gate, gate_expect);
     if (u_wg) {
         bool failed = false;
         if (threadIdx.x == 0) {
@@ -1309,7 +1309,7 @@ __device__ __forceinline__ void absmean_fused_body(const cfx_comp_item& it, int 
             }
         }
         if (__syncthreads_or(failed ? 1 : 0)) return;           // (tiles that never arrived: no row scales - the error word says so)
-        absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, false, true, stamps, gate, gate_expect);
+        absmean_last_arriver_jobs<GATED>(it, N, C, CB, P, bx, rowpart, tick, per_byte, eps_mode, sm, false, true, probe, gate, gate_expect);
     }
     }
     if constexpr (KEEP)
@@ -1372,7 +1372,7 @@ struct FusedArgs {
     u64* ws;
     size_t ws_stride;
     unsigned* tick;
-    u64* stamps;             // developer hook: 16 words per statistics workgroup, or NULL
+    Probe probe;             // developer build: 16 words per workgroup (empty in the product build)
     // gated reconstruction group (GATED kernels): workgroups [n_st, n_st + n_g), tiles of g_R rows, g_rb per tensor; n_gt tiles in all:
     // n_g == n_gt, one tile per workgroup, or n_g < n_gt: a PERSISTENT group, workgroup g takes tiles g, g + n_g, ...
     int n_g, g_R, g_rb, n_gt;
@@ -1402,7 +1402,7 @@ __global__ __launch_bounds__(FUSED_NT, GATE_WPE) void k_absmean_compress(BatchC 
         const int by = rem / a.CB;
         absmean_fused_body<EMIT_BITS, US, GATED>(batch.it[z], a.N, a.C, a.R, a.CB, a.P, rem - by * a.CB, by, a.ws + (size_t)z * a.ws_stride,
                                                  a.tick + z * TICK_WORDS, a.per_byte, a.eps_mode, sm, a.dbg,
-                                                 a.stamps ? a.stamps + (size_t)b * 16 : nullptr, a.gate, a.gate_expect, 0, nullptr, 0u, a.gate_err, a.timeout,
+                                                 a.probe.of(b), a.gate, a.gate_expect, 0, nullptr, 0u, a.gate_err, a.timeout,
                                                  tag_arena_of(a.tarena, a.tarena_stride, z, a.N, a.C, a.CB, a.P, a.tag));
         if constexpr (GATED) {
             if (b == 0 && a.p2p.own) p2p_exchange_inline(a.gate, a.gate_expect, 1, a.p2p, a.xgate, a.xexpect, a.gate_err);
@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(FUSED_NT, GATE_WPE) void k_absmean_compress(BatchC 
                     binary_dequant_gated_body<FUSED_NW, GATE_KR, 0, ST>(gated.it[item], a.N, a.C, a.g_R, rem - ty * a.CB, ty, a.xgate ? a.xgate : a.gate,
                                                                 a.xgate ? a.xexpect : a.gate_expect, a.gate_err, a.timeout,
                                                                 nullptr,
-                                                                a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr, a.remote != 0 && sz < 0,
+                                                                a.probe.of(blockIdx.x), a.remote != 0 && sz < 0,
                                                                 ONEBIT_D_TAGGED && sz >= 0, ta, (u16*)&sm[0][0]);
                 }
                 return;
@@ -1714,7 +1714,7 @@ __global__ __launch_bounds__(FUSED_NT, 4) void k_int2_compress_gated(BatchC batc
         const int z = b / per, rem = b - z * per;
         const int by = rem / a.CB;
         absmean_fused_body<false, US, true, true>(batch.it[z], a.N, a.C, a.R, a.CB, a.P, rem - by * a.CB, by, a.ws + (size_t)z * a.ws_stride,
-                                                  a.tick + z * TICK_WORDS, 4, 1, sm, 0, nullptr, a.gate1, a.expect1, a.flags, a.gate2, a.expect2, a.err, a.timeout,
+                                                  a.tick + z * TICK_WORDS, 4, 1, sm, 0, Probe(), a.gate1, a.expect1, a.flags, a.gate2, a.expect2, a.err, a.timeout,
                                                   tag_arena_of(a.tarena, a.tarena_stride, z, a.N, a.C, a.CB, a.P, a.tag));
         // (packets complete = the codes gate's last arriver has written the "open" words: XCD 0's)
         if (b == 0 && a.p2p.own) p2p_exchange_inline(a.gate2 + 1 * GATE_LINE, a.expect2, 1, a.p2p, a.xgate, a.xexpect, a.err);
@@ -1952,9 +1952,9 @@ struct MinMaxLayerArgs {
     int tall;
     int coop;                         // the reduce by tiles 0 .. MML_NRED - 1 (always in the tall form; otherwise wherever a channel has more than
                                       // 32 partials: every tile reducing all of them itself would take P / 8 dependent rounds of loads)
-    u64* stamps;                      // cfx_debug_stamps: 16 words per workgroup (100 MHz wall clock per phase; word 7: 1 = S tile, 4 = D tile)
+    Probe probe;                      // developer build: 16 words per workgroup (100 MHz wall clock per phase; word 7: 1 = S tile, 4 = D tile)
 };
-#define MML_STAMP(i) do { if (st && threadIdx.x == 0) st[i] = (u64)wall_clock64(); } while (0)
+#define MML_STAMP(i) st.at(i)
 // received values of 8 channels of row h of a code row (int8: h = 0): k_int8_dequant / k_int4_dequant arithmetic
 template <bool INT4>
 __device__ __forceinline__ h16x8 minmax_recv(u64 codes, int h, h16x8 sc, h16x8 mz) {
@@ -2029,8 +2029,8 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
     const h16* x = (const h16*)it.x;
     const h16* base = (const h16*)it.base;
     const int cc = min(t.c, C - 8);
-    u64* st = a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr;
-    if (st && threadIdx.x == 0) st[7] = 1;
+    const Probe st = a.probe.of(blockIdx.x);
+    st.set(7, 1);
     MML_STAMP(0);
     // every wait of this tile gives up a.timeout after the tile started (one time base, no cascade of waits); a tile that gave up stores
     // neither codes nor state nor its flag - whoever waits for it gives up in turn, and the context's error word says so
@@ -2306,7 +2306,7 @@ __device__ __forceinline__ void minmax_layer_s_tile(const cfx_comp_item& it, con
                 }
             }
     }
-    if (st) {
+    if (st.on()) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MML_STAMP(5);                                       // state stores acknowledged
     }
@@ -2323,8 +2323,8 @@ __device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, c
     const h16* base = (const h16*)it.base;
     h16* out = (h16*)it.recon;
     const int cc = min(t.c, C - 8);
-    u64* st = a.stamps ? a.stamps + (size_t)blockIdx.x * 16 : nullptr;
-    if (st && threadIdx.x == 0) st[7] = 4;
+    const Probe st = a.probe.of(blockIdx.x);
+    st.set(7, 4);
     MML_STAMP(0);
     const int kc = a.g_R / (NW * RPC);         // code rows per wave of THIS launch's tiles (<= KC; uniform)
     bool failed = false;
@@ -2358,7 +2358,7 @@ __device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, c
         }
         if (__syncthreads_or(failed ? 1 : 0)) return;       // the codes never came: the state stays as it was
     }
-    if (st) {
+    if (st.on()) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MML_STAMP(1);                                       // state tile in registers AND gate seen
     }
@@ -2385,7 +2385,7 @@ __device__ __forceinline__ void minmax_layer_d_tile(const cfx_decomp_item& it, c
                 }
             }
         }
-    if (st) {
+    if (st.on()) {
         MML_STAMP(2);                                       // codes landed, stores issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         MML_STAMP(3);
@@ -2938,10 +2938,23 @@ __global__ __launch_bounds__(256) void k_attn_merge(float* __restrict__ out, flo
     if (wflag && blockIdx.x == 0 && threadIdx.x == 0) flag_spin(wflag, wval, err, timeout);
 }
 
+// The plain copy the roofline's `achievable` is measured with (bench.py) and the PMC counters are calibrated on (tools/pmc_summary.py): 16 bytes
+// a lane, four loads in flight per thread before the first store, non-temporal both ways (a one-touch stream).
 __global__ __launch_bounds__(256) void k_copy_probe(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_* s4 = reinterpret_cast<const u32x4_*>(src);
+    u32x4_* d4 = reinterpret_cast<u32x4_*>(dst);
     const size_t stride = (size_t)gridDim.x * 256;
-    for (; i < n16; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u32x4_ a0 = __builtin_nontemporal_load(s4 + i), a1 = __builtin_nontemporal_load(s4 + i + stride);
+        const u32x4_ a2 = __builtin_nontemporal_load(s4 + i + 2 * stride), a3 = __builtin_nontemporal_load(s4 + i + 3 * stride);
+        __builtin_nontemporal_store(a0, d4 + i);
+        __builtin_nontemporal_store(a1, d4 + i + stride);
+        __builtin_nontemporal_store(a2, d4 + i + 2 * stride);
+        __builtin_nontemporal_store(a3, d4 + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + i), d4 + i);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2998,7 +3011,7 @@ cfx_ctx* cfx_create(int device) {
     c->cu_cache_next = 0;
     c->ring_clock = 0;
     memset(c->ring_used, 0, sizeof(c->ring_used));
-    c->dbg_stamps = nullptr;
+    c->dev_buf = nullptr;
     c->gate = nullptr;
     c->gate_err = nullptr;
     c->gate_timeout = 500000000LL;     // 5 s of the 100 MHz wall clock
@@ -3048,13 +3061,14 @@ int cfx_prepare(cfx_ctx* ctx) {
     return rc;
 }
 
-int cfx_debug_stamps(cfx_ctx* ctx, void* buf) {
+#ifdef CFX_DEV_PROBES      // ---- the developer library only (include/cfx_dev.h) ----
+int cfx_dev_stamps(cfx_ctx* ctx, void* buf) {
     if (!ctx) return CFX_ERR_NULL;
-    ctx->dbg_stamps = buf;
+    ctx->dev_buf = buf;
     return CFX_OK;
 }
 
-int cfx_debug_set_launch_tags(cfx_ctx* ctx, unsigned abs_seq, unsigned mml_seq) {
+int cfx_dev_set_launch_tags(cfx_ctx* ctx, unsigned abs_seq, unsigned mml_seq) {
     if (!ctx) return CFX_ERR_NULL;
     if (!ctx->tick && cfx_prepare(ctx) != CFX_OK) return CFX_ERR_LAUNCH;
     (void)hipDeviceSynchronize();                     // (nothing in flight carries the old numbers)
@@ -3062,6 +3076,14 @@ int cfx_debug_set_launch_tags(cfx_ctx* ctx, unsigned abs_seq, unsigned mml_seq) 
     ctx->mml_seq = mml_seq;
     return CFX_OK;
 }
+
+int cfx_dev_set_probe(cfx_ctx* ctx, int mode) {
+    if (!ctx) return CFX_ERR_NULL;
+    if (mode < 0 || mode > 4) return fail(ctx, CFX_ERR_BATCH, "dev probe must be 0..4");
+    ctx->dev_probe = mode;
+    return CFX_OK;
+}
+#endif
 
 int cfx_set_fused_finalize(cfx_ctx* ctx, int on) {
     if (!ctx) return CFX_ERR_NULL;
@@ -3094,18 +3116,6 @@ int cfx_set_lr_decode(cfx_ctx* ctx, int mode) {
     if (mode < 0 || mode > 2) return fail(ctx, CFX_ERR_BATCH, "lr decode must be 0 (automatic), 1 (VALU) or 2 (MFMA)");
     ctx->lr_decode = mode;
     return CFX_OK;
-}
-
-int cfx_set_dev_probe(cfx_ctx* ctx, int mode) {
-    if (!ctx) return CFX_ERR_NULL;
-#ifdef CFX_DEV_PROBES
-    if (mode < 0 || mode > 4) return fail(ctx, CFX_ERR_BATCH, "dev probe must be 0..4");
-    ctx->dev_probe = mode;
-    return CFX_OK;
-#else
-    if (mode != 0) return fail(ctx, CFX_ERR_BATCH, "this build has no developer probes (python -m compactfusion_amd.build --dev-probes)");
-    return CFX_OK;
-#endif
 }
 
 int cfx_set_allow_shared_queues(cfx_ctx* ctx, int on) {
@@ -3611,7 +3621,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             a.per_byte = per_byte; a.eps_mode = codec == CFX_CODEC_INT2 ? 1 : 0;
             a.ws = ws; a.ws_stride = wstride; a.tick = tick;
             a.dbg = ctx->dev_probe;
-            a.stamps = (u64*)ctx->dbg_stamps;
+            a.probe = cfx_i_probe(ctx);
             if (one_launch_1bit) {
                 // tiles of the gated group: as few row blocks as GATE_KR rows per wave allow, heights a multiple of FUSED_NW
                 a.g_rb = (N + FUSED_NW * GATE_KR - 1) / (FUSED_NW * GATE_KR);
@@ -3643,9 +3653,12 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
             a.gate_err = ctx->gate_err;
             a.timeout = ctx->gate_timeout;
             const dim3 g(a.n_st + a.n_g + CB * a.dq_rb * n_ride);
-            if (one_launch_1bit && a.stamps && R % 32 == 0) {
+#ifdef CFX_DEV_PROBES
+            if (one_launch_1bit && ctx->dev_buf && R % 32 == 0) {          // (the instantiation whose reconstruction tiles drain before they stamp)
                 LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_absmean_compress<true, 4, true, true>), g, dim3(FUSED_NT), 0, s, b, rd, gd, a);
-            } else if (one_launch_1bit) {
+            } else
+#endif
+            if (one_launch_1bit) {
                 LAUNCH(ctx, KID_ABSMEAN_COMPRESS_GATED, s, (k_absmean_compress<true, 4, true>), g, dim3(FUSED_NT), 0, s, b, rd, gd, a);
             } else if (codec == CFX_CODEC_BINARY) {
                 if (R % 32 == 0) LAUNCH(ctx, KID_ABSMEAN_COMPRESS_BITS, s, (k_absmean_compress<true, 4>), g, dim3(FUSED_NT), 0, s, b, rd, gd, a);
@@ -3781,7 +3794,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
                 ctx->mml_arena_bytes[ring] = cap;
             }
             a.part = ctx->mml_arena[ring];
-            a.stamps = (u64*)ctx->dbg_stamps;
+            a.probe = cfx_i_probe(ctx);
             a.codedone = ctx->colgate + (size_t)ring * MML_MAX_TILES;
             a.tall = tall ? 1 : 0;
             a.coop = (tall || PL > 32) ? 1 : 0;

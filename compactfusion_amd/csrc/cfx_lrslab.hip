@@ -60,7 +60,7 @@ struct LrsArgs {
     unsigned* tick;                  // a zeroed ticket word: workgroups that have left
     unsigned* err;
     long long timeout;
-    unsigned long long* stamps;      // developer hook (cfx_debug_stamps): 16 words per workgroup, 100 MHz wall clock
+    Probe probe;                     // developer build (cfx_dev.h): 16 words per workgroup, 100 MHz wall clock
 };
 
 // A word that changes hands: the fp32 value rounded to 22 bits of mantissa, its two lowest bits the sequence tag of the sum it belongs to.
@@ -235,7 +235,8 @@ __global__ __launch_bounds__(LRS_NT) void k_lrs(LrBatch b, LrsArgs a) {
     int slab = idx;
     if (a.nxs_log2 >= 0) { const int nx = 1 << a.nxs_log2; slab = (idx & (nx - 1)) * (nwg >> a.nxs_log2) + (idx >> a.nxs_log2); }      // (host: nwg is a multiple of nx)
     const int c0 = slab * LRS_SW;
-#define LSTAMP(k) do { if (a.stamps && tid == 0) a.stamps[(size_t)bid * 16 + (k)] = wall_clock64(); } while (0)
+    const Probe probe = a.probe.of(bid);
+#define LSTAMP(k) probe.at(k)
     LSTAMP(0);
 
     // ---------------- the slab: registers (rows t * 16 + l16 of tile t = w + LRS_NW q, columns c0 + 8 lq .. + 7) and LDS (transposed) ----------------
@@ -898,7 +899,7 @@ int cfx_i_lrs_factors(cfx_ctx* ctx, int quantized, int N, int C, int rank, int b
         if (!a.arena || !a.tick) return fail(ctx, CFX_ERR_LAUNCH, "low-rank: cannot set up the hand-over arena");
         a.err = ctx->gate_err;
         a.timeout = ctx->gate_timeout;
-        a.stamps = (unsigned long long*)ctx->dbg_stamps;
+        a.probe = cfx_i_probe(ctx);
         const int rc = RPv == 8 ? lrs_run<8>(ctx, bb, a, s) : (RPv == 16 ? lrs_run<16>(ctx, bb, a, s) : lrs_run<32>(ctx, bb, a, s));
         if (rc != CFX_OK) return rc;
     }

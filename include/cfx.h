@@ -176,14 +176,8 @@ int cfx_gate_recover(cfx_ctx* ctx);
  * cfx_set_fused_finalize(ctx, 0) selects the two-kernel sequence (statistics, finalize); results are bit-identical. */
 int cfx_prepare(cfx_ctx* ctx);
 int cfx_set_fused_finalize(cfx_ctx* ctx, int on);
-/* Developer hook: when `buf` is non-NULL every statistics workgroup of a compress launch writes 8 u64 words there (phase
- * times on the 100 MHz wall clock + its last-arriver roles): tools/fused_stamps.py.  NULL switches it off. */
-int cfx_debug_stamps(cfx_ctx* ctx, void* buf);
-/* Test hook: the layer launches tag what they hand over with numbers a context gives out in sequence (24 bits for the 1-bit / 2-bit layer,
- * 31 for the int4 / int8 layer); where a sequence wraps - 16.7 million, 2.1 billion launches in - the tagged arenas are zeroed and the
- * numbers start over.  This sets the two counters (after a device synchronisation) so that a test can walk a context across the wrap:
- * tests/test_gpu_parity.py::test_layer_launches_across_the_tag_wrap. */
-int cfx_debug_set_launch_tags(cfx_ctx* ctx, unsigned abs_seq, unsigned mml_seq);
+/* (Developer probes - per-workgroup phase stamps, the launch-tag test hook, early exits of the compress kernel - are NOT part of this
+ * library: include/cfx_dev.h, libcfx_dev.so, built with -DCFX_DEV_PROBES.) */
 /* Tuning / measurement switches of a context.  The library reads NO environment variable for its behaviour (the one variable it looks
  * at, GPU_MAX_HW_QUEUES, belongs to the HIP runtime: see cfx_prepare below); what earlier builds read from the environment is set here:
  *   cfx_set_stats_rows    statistics tile height of the one-launch compress (multiple of 16; 0 = automatic)
@@ -191,14 +185,11 @@ int cfx_debug_set_launch_tags(cfx_ctx* ctx, unsigned abs_seq, unsigned mml_seq);
  *                         the one-launch forms where they qualify)
  *   cfx_set_lr_chain      low-rank factor chain: 0 = automatic (slab-resident single launch where its workgroups fit the stream, else
  *                         the six-launch N-space chain, else the C-space chain), 1 = never the single launch, 2 = C-space chain only
- *   cfx_set_lr_decode     low-rank reconstruction kernel: 0 = automatic (MFMA form at rank 32), 1 = VALU form, 2 = MFMA form
- *   cfx_set_dev_probe     developer builds only (-DCFX_DEV_PROBES): early exits of the compress kernel (tools/fused_probe.py); the product
- *                         build accepts 0 only */
+ *   cfx_set_lr_decode     low-rank reconstruction kernel: 0 = automatic (MFMA form at rank 32), 1 = VALU form, 2 = MFMA form */
 int cfx_set_stats_rows(cfx_ctx* ctx, int rows);
 int cfx_set_gated_launch(cfx_ctx* ctx, int on);
 int cfx_set_lr_chain(cfx_ctx* ctx, int chain);
 int cfx_set_lr_decode(cfx_ctx* ctx, int mode);
-int cfx_set_dev_probe(cfx_ctx* ctx, int mode);
 /* Flag-ordered launches (the exchange-layer ops, the exchange lane) need the streams they order to sit on hardware queues of their own:
  * a polling kernel is never scheduled out for the kernel it waits for.  HIP multiplexes streams over a pool of hardware queues; with
  * GPU_MAX_HW_QUEUES unset a stream created after a collective library initialised can be time-sliced against the exchange stream's

@@ -17,6 +17,9 @@ same seeds and holds it to these PSNRs within 0.1 dB.
 
 usage: TORCHDYNAMO_DISABLE=1 TRITON_INTERPRET=1 python tests/golden/make_golden_stack.py
        (G13_ONLY=lowrank8,lowrankq32 adds / refreshes only those codecs in the committed file)
+       TORCHDYNAMO_DISABLE=0 G13_ONLY=lowrankq32 G13_OUT=tests/golden/g13_stack_lrq32_compiled.npz python tests/golden/make_golden_stack.py
+       (the reference's OTHER execution mode - @torch.compile - on the same stack: how far its own two modes are apart per step is the
+       tolerance tests/test_gpu_stack.py gives the HIP path for LOW_RANK_Q, whose int4 factors turn last-bit differences into whole levels)
 """
 import hashlib
 import json
@@ -161,7 +164,7 @@ def main():
     out = "/tmp/cfx_g13"
     mp.spawn(_worker, args=(WORLD, 29541, out), nprocs=WORLD, join=True)
     res = {}
-    dst = os.path.join(HERE, "g13_stack.npz")
+    dst = os.environ.get("G13_OUT") or os.path.join(HERE, "g13_stack.npz")       # (G13_OUT: another file - e.g. the compiled-mode run below)
     if os.environ.get("G13_ONLY") and os.path.exists(dst):      # add / refresh some codecs, keep the others as generated before
         old = np.load(dst)
         res = {k: old[k] for k in old.files}
@@ -169,7 +172,9 @@ def main():
         d = np.load(out + f".r{r}.npz")
         for k in d.files:
             res[k] = d[k]
-    np.savez_compressed(os.path.join(HERE, "g13_stack.npz"), **res)
+    np.savez_compressed(dst, **res)
+    if os.environ.get("G13_OUT"):
+        return
     sha = lambda t: hashlib.sha256(t.contiguous().view(torch.int16).numpy().tobytes()).hexdigest()   # noqa: E731
     meta = {"world": WORLD, "layers": LAYERS, "steps": STEPS, "shard": [B, S, H, D], "seed": SEED,
             "sha_input_last": [sha(inputs(r)[-1]) for r in range(WORLD)], "sha_w_last": sha(weights()[-1][-1].half())}

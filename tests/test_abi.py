@@ -143,8 +143,6 @@ def test_context_setters_replace_the_environment_switches():
     assert lib.cfx_set_gated_launch(ctx, 0) == 0 and lib.cfx_set_gated_launch(ctx, 1) == 0
     assert lib.cfx_set_lr_chain(ctx, 1) == 0 and lib.cfx_set_lr_chain(ctx, 3) == -5 and lib.cfx_set_lr_chain(ctx, 0) == 0
     assert lib.cfx_set_lr_decode(ctx, 2) == 0 and lib.cfx_set_lr_decode(ctx, 3) == -5 and lib.cfx_set_lr_decode(ctx, 0) == 0
-    assert lib.cfx_set_dev_probe(ctx, 0) == 0 and lib.cfx_set_dev_probe(ctx, 1) == -5          # the product build has no probes
-    assert b"dev-probes" in lib.cfx_last_error_string(ctx)
     assert lib.cfx_set_allow_shared_queues(ctx, 1) == 0 and lib.cfx_set_allow_shared_queues(ctx, 0) == 0
     assert lib.cfx_set_fused_finalize(ctx, 0) == 0 and lib.cfx_set_fused_finalize(ctx, 1) == 0
     assert lib.cfx_ipc_memory_kind(ctx) == 0 and lib.cfx_ipc_memory_kind(None) == -1
@@ -179,3 +177,30 @@ def test_header_is_plain_c():
     hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "cfx.h")
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_product_library_has_no_developer_entry_points():
+    """include/cfx_dev.h (per-workgroup phase stamps, the launch-tag test hook, early exits of the compress kernel) belongs to libcfx_dev.so
+    - the same sources with -DCFX_DEV_PROBES.  The product library exports none of it, binds none of it, and its kernels take no probe
+    argument (csrc/cfx_internal.h: `Probe` is an empty type without the macro); the developer library exports exactly what the header
+    declares."""
+    import re
+    import subprocess
+    from compactfusion_amd import _lib
+    from compactfusion_amd.build import LIB, build_lib
+    lib = _lib.load()
+    hdr = open(os.path.join(REPO, "include", "cfx_dev.h")).read()
+    dev_syms = re.findall(r"^int\s+(cfx_dev_\w+)\s*\(", hdr, flags=re.M)
+    assert sorted(dev_syms) == sorted(n for n, _, _ in _lib.DEV_SYMBOLS) and len(dev_syms) == 3
+    exported = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
+    assert not re.search(r"debug|cfx_dev_|stamp", exported), "the product library exports a developer symbol"
+    for sym in dev_syms:
+        assert not hasattr(lib, sym) or os.environ.get("CFX_LIBCFX_PATH"), sym
+    assert not any(n.startswith(("cfx_dev", "cfx_debug")) for n, _, _ in _lib.SYMBOLS)
+    dev = build_lib(dev_probes=True)
+    exported_dev = subprocess.run(["nm", "-D", "--defined-only", dev], capture_output=True, text=True, check=True).stdout
+    for sym in dev_syms:
+        assert re.search(r"\b%s\b" % sym, exported_dev), f"{sym} declared in include/cfx_dev.h but not exported by libcfx_dev.so"
+    # no kernel of the product build mentions a probe: the only `Probe` with a pointer in it sits behind the macro
+    src = open(os.path.join(REPO, "compactfusion_amd", "csrc", "cfx_internal.h")).read()
+    assert "#ifdef CFX_DEV_PROBES\nstruct Probe {\n    unsigned long long* p;" in src

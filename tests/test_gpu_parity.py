@@ -4,6 +4,8 @@ Bar: bit-exact for everything.  The HIP kernels and the oracle both use the exac
 sum for the scale reductions, so even the fp16 scale vectors and the error-feedback state are bit-identical;
 tolerances only enter where the *reference's* own fp32 accumulation order is involved
 (tests/test_oracle_golden.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -784,38 +786,51 @@ def test_layer_launch_partials_beyond_the_tagged_words(name, cid, drift):
                 same_bits(host_bits(peer[g]), R.bits(nb_ref), f"{name} peer state {g}")
 
 
-@pytest.mark.parametrize("name,cid,shape", [("binary", 1, (544, 3072)), ("int2", 2, (544, 3072)), ("int4", 3, (1024, 1152)), ("int8", 4, (1024, 1152))])
-def test_layer_launches_across_the_tag_wrap(name, cid, shape):
-    """The layer launches tag what they hand over with numbers the context gives out in sequence - 24 bits (1-bit / 2-bit), 31 bits (int4 /
-    int8) - and where a sequence wraps the tagged arenas are zeroed and the numbers start over (never 0: that is what an untouched word
-    carries).  A serving process gets there (16.7 million layer launches are a few thousand FLUX images); cfx_debug_set_launch_tags walks
-    this context to three launches before both wraps, then eight launches in a row must equal the oracle bit for bit."""
+def tagwrap_case(name, cid, N, C):
+    """Body of test_layer_launches_across_the_tag_wrap: runs in a process of its own that loaded the DEVELOPER library (the hook that sets a
+    context's launch tags - cfx_dev_set_launch_tags, include/cfx_dev.h - is not part of the product library)."""
     from compactfusion_amd import _lib, codecs as K
     lib = _lib.load()
-    N, C = shape
     B, NP = 2, 4
     ctx = K.context(0)
     sh = torch.cuda.current_stream().cuda_stream
     ws = K.workspace(cid, N, C, 0, B, 0)
-    assert lib.cfx_debug_set_launch_tags(ctx, (1 << 24) - 4, (1 << 31) - 5) == 0
-    if True:
-        for rep in range(8):
-            xs = [make_inputs(9100 + 10 * rep + i, N, C) for i in range(B)]
-            xd = [dev(x) for x, _ in xs]
-            own = [dev(b) for _, b in xs]
-            peer = [dev(xs[g % B][1]) for g in range(NP)]
-            pk = [torch.zeros(K.packet_halves(cid, N, C), dtype=torch.float16, device="cuda") for _ in range(B)]
-            comp = (_lib.CompItem * B)(*[_lib.CompItem(xd[i].data_ptr(), own[i].data_ptr(), own[i].data_ptr(), pk[i].data_ptr()) for i in range(B)])
-            gated = (_lib.DecompItem * NP)(*[_lib.DecompItem(pk[g % B].data_ptr(), peer[g].data_ptr(), peer[g].data_ptr()) for g in range(NP)])
-            assert lib.cfx_compress_batch_gated(ctx, cid, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, comp, 0, None, NP, gated, ws.data_ptr(), ws.numel(), sh) == 0
-            torch.cuda.synchronize()
-            assert lib.cfx_gate_errors(ctx) == 0, f"launch {rep}"
-            for i in range(B):
-                pkt_ref, nb_ref = R.residual_compress(name, xs[i][0], xs[i][1], 0)
-                same_bits(host_bits(pk[i]), pkt_ref, f"{name} packet {i}, launch {rep}")
-                same_bits(host_bits(own[i]), R.bits(nb_ref), f"{name} sender state {i}, launch {rep}")
-                for g in range(i, NP, B):
-                    same_bits(host_bits(peer[g]), R.bits(nb_ref), f"{name} peer state {g}, launch {rep}")
+    assert lib.cfx_dev_set_launch_tags(ctx, (1 << 24) - 4, (1 << 31) - 5) == 0
+    for rep in range(8):
+        xs = [make_inputs(9100 + 10 * rep + i, N, C) for i in range(B)]
+        xd = [dev(x) for x, _ in xs]
+        own = [dev(b) for _, b in xs]
+        peer = [dev(xs[g % B][1]) for g in range(NP)]
+        pk = [torch.zeros(K.packet_halves(cid, N, C), dtype=torch.float16, device="cuda") for _ in range(B)]
+        comp = (_lib.CompItem * B)(*[_lib.CompItem(xd[i].data_ptr(), own[i].data_ptr(), own[i].data_ptr(), pk[i].data_ptr()) for i in range(B)])
+        gated = (_lib.DecompItem * NP)(*[_lib.DecompItem(pk[g % B].data_ptr(), peer[g].data_ptr(), peer[g].data_ptr()) for g in range(NP)])
+        assert lib.cfx_compress_batch_gated(ctx, cid, N, C, 0, _lib.FLAG_UPDATE_CACHE, B, comp, 0, None, NP, gated, ws.data_ptr(), ws.numel(), sh) == 0
+        torch.cuda.synchronize()
+        assert lib.cfx_gate_errors(ctx) == 0, f"launch {rep}"
+        for i in range(B):
+            pkt_ref, nb_ref = R.residual_compress(name, xs[i][0], xs[i][1], 0)
+            same_bits(host_bits(pk[i]), pkt_ref, f"{name} packet {i}, launch {rep}")
+            same_bits(host_bits(own[i]), R.bits(nb_ref), f"{name} sender state {i}, launch {rep}")
+            for g in range(i, NP, B):
+                same_bits(host_bits(peer[g]), R.bits(nb_ref), f"{name} peer state {g}, launch {rep}")
+
+
+@pytest.mark.parametrize("name,cid,shape", [("binary", 1, (544, 3072)), ("int2", 2, (544, 3072)), ("int4", 3, (1024, 1152)), ("int8", 4, (1024, 1152))])
+def test_layer_launches_across_the_tag_wrap(name, cid, shape):
+    """The layer launches tag what they hand over with numbers the context gives out in sequence - 24 bits (1-bit / 2-bit), 31 bits (int4 /
+    int8) - and where a sequence wraps the tagged arenas are zeroed and the numbers start over (never 0: that is what an untouched word
+    carries).  A serving process gets there (16.7 million layer launches are a few thousand FLUX images); cfx_dev_set_launch_tags walks
+    a context to three launches before both wraps, then eight launches in a row must equal the oracle bit for bit.  The hook lives in the
+    developer library only (include/cfx_dev.h): the case runs in a child process that loads libcfx_dev.so - same sources, same kernels
+    plus the probes - in place of libcfx.so (tests/tagwrap_child.py)."""
+    import subprocess
+    import sys
+    from compactfusion_amd.build import build_lib
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, CFX_LIBCFX_PATH=build_lib(dev_probes=True))
+    r = subprocess.run([sys.executable, os.path.join(here, "tagwrap_child.py"), name, str(cid), str(shape[0]), str(shape[1])],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
 
 
 def test_gated_launches_on_two_streams_at_once():

@@ -106,6 +106,77 @@ def test_hip_path_stays_on_the_reference_quality_trace(name, tmp_path):
     _check(name, rows, want)
 
 
+def _hip_trace(name, ks, vs, q, seed_q, tmp_path):
+    """The HIP path's [step][rel_err_k, rel_err_v, PSNR] on a drift (the loop of test_hip_path_stays_on_the_reference_quality_trace)."""
+    from compactfusion_amd.collector import collector
+    collector.init(collector.Collector(str(tmp_path), enabled=False))
+    import compactfusion_amd.compact.main as cm
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as CT, CompactConfig, lowrank
+    tname, kw = GEN.PRESETS[name]
+    cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: None, residual=1, ef=True, simulate=False, log_stats=False, **kw))
+    rows = []
+    try:
+        for t in range(len(ks)):
+            typ = CT.WARMUP if t == 0 else CT[tname]
+            rec = []
+            for kv, x in enumerate((ks[t], vs[t])):
+                torch.manual_seed(seed_q + 2 * t + kv)
+                lowrank.set_init_q(torch.randn(GEN.C, kw["comp_rank"], dtype=torch.float))
+                skey, rkey = f"0-0-{'kv'[kv]}", f"0-1-{'kv'[kv]}"
+                pkt = cm.compact_compress(skey, x.cuda().view(1, GEN.N, GEN.HEADS, GEN.HD), typ, update_cache=True)
+                r = cm.compact_decompress(rkey, pkt.clone(), typ, (1, GEN.N, GEN.HEADS, GEN.HD), update_cache=True)
+                rec.append(r.reshape(GEN.N, GEN.C).cpu().clone())
+            rows.append(GEN.metrics(q, ks[t], vs[t], rec[0], rec[1]))
+    finally:
+        lowrank.set_init_q(None)
+    return np.array(rows)
+
+
+@pytest.mark.gpu
+def test_lowrank_q_gap_over_seeds(tmp_path):
+    """LOW_RANK_Q-32 on 8 more seeds of the G12 recipe (tests/golden/measure_lrq_spread_seeds.py ran the REFERENCE on them in both of its
+    execution modes).  A last-bit difference in a factor flips whole int4 levels and error feedback carries the flip on, so the distance
+    between two correct implementations is a random variable; the one committed trace of G12 (HIP 3.0e-3 / 5.3e-3 for K / V against a band
+    of 5.8e-3) says little about margin.  Here, seed by seed: the HIP path's distance from the reference's eager trace beside the
+    reference's OWN eager-to-compiled distance.  Asserted: on every seed the HIP distance is inside the range of the reference's own
+    distances (its largest over the seeds), and the MEDIAN HIP distance is not above the median reference distance - i.e. the HIP path
+    is as close to the eager reference as the reference's compiled mode is.  The table goes to gpurun_out/lrq32_seeds.json
+    (committed as profiles/r06_lrq32_seeds.json)."""
+    f = os.path.join(HERE, "golden", "g12_lrq32_seeds.npz")
+    if not os.path.exists(f):
+        pytest.skip("g12_lrq32_seeds.npz not generated")
+    g = np.load(f)
+    eager, compiled, seeds = g["eager"], g["compiled"], g["seeds"]
+
+    def gap(a, b):
+        rel = np.abs(a[1:, :2] - b[1:, :2]) / b[1:, :2]
+        return [float(rel[:, 0].max()), float(rel[:, 1].max()), float(np.abs(a[1:, 2] - b[1:, 2]).max())]
+    rows = []
+    for s in range(len(seeds)):
+        sx, sq = int(seeds[s][0]), int(seeds[s][1])
+        T = eager[s].shape[0]
+        ks, vs, q = GEN.drift(sx, T), GEN.drift(sx + 1, T), GEN.query(sx + 2)
+        hip = _hip_trace("lrq32", ks, vs, q, sq, tmp_path)
+        assert np.all(hip[0, :2] == 0)
+        rows.append({"seed_x": sx, "hip_vs_eager": gap(hip, eager[s]), "compiled_vs_eager": gap(compiled[s], eager[s]),
+                     "hip_vs_compiled": gap(hip, compiled[s])})
+    H = np.array([r["hip_vs_eager"] for r in rows])
+    Rf = np.array([r["compiled_vs_eager"] for r in rows])
+    summary = {"columns": ["rel_err_k", "rel_err_v", "psnr_db"], "seeds": rows,
+               "hip_vs_eager": {"median": np.median(H, 0).tolist(), "max": H.max(0).tolist()},
+               "reference_compiled_vs_eager": {"median": np.median(Rf, 0).tolist(), "max": Rf.max(0).tolist()},
+               "ratio_of_medians": (np.median(H, 0) / np.median(Rf, 0)).tolist(),
+               "what": "distance = max over the 27 compressed steps of |err - err_ref| / err_ref (reconstruction error of K, of V at the receiver) and "
+                       "of the attention-output PSNR difference in dB; reference traces: tests/golden/g12_lrq32_seeds.npz"}
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "lrq32_seeds.json"), "w") as fo:
+            json.dump(summary, fo, indent=1)
+    for c, what in enumerate(("relative error of K", "relative error of V", "attention PSNR")):
+        assert H[:, c].max() <= Rf[:, c].max() * 1.0, f"LOW_RANK_Q {what}: HIP is further from the eager reference ({H[:, c].max():.2e}) than the reference's own modes ever are ({Rf[:, c].max():.2e})"
+        assert np.median(H[:, c]) <= np.median(Rf[:, c]) * 1.0, f"LOW_RANK_Q {what}: median HIP distance {np.median(H[:, c]):.2e} above the reference's own {np.median(Rf[:, c]):.2e}"
+
+
 @pytest.mark.parametrize("name", ["binary", "int2"])
 def test_oracle_stays_on_the_reference_quality_trace(name):
     """The CPU oracle on the same trace (keeps the oracle pinned to the reference over a long error-feedback chain)."""

@@ -32,8 +32,12 @@ def _entry(rank, fn_name, world, port, out, args):
 def test_stack_psnr_matches_the_reference(tmp_path, codec, tol):
     """lowrank8 / lowrankq32: the reference's LOW_RANK r = 8 and LOW_RANK_Q r = 32 presets (slow path), both sides iterating from
     the same pinned start matrix; q32 wider: the int4 re-quantisation of the factors turns last-bit differences between Cholesky-QR
-    and Householder QR into whole quantisation levels (as in the single-layer trace G12): per step within 0.5 dB (measured: up to 0.38,
-    either sign), averaged over the steps within 0.15 dB"""
+    and Householder QR into whole quantisation levels (as in the single-layer trace G12).  Round 6 ran the reference's OTHER execution mode
+    (@torch.compile) on the same stack (tests/golden/g13_stack_lrq32_compiled.npz, make_golden_stack.py with TORCHDYNAMO_DISABLE=0): its own two
+    modes differ by up to 0.29 dB on single steps and by 0.02-0.04 dB in the mean over the steps; the HIP path sits 0.34 / 0.43 dB (single
+    step) and 0.02 dB (mean) from the eager golden, 0.38 / 0.33 from the compiled trace (profiles/r06_stack_lrq32.txt) - three
+    implementations of one arithmetic, pairwise equally far apart on single steps, together in the mean.  Held: per step within 0.5 dB,
+    MEAN over the steps within 0.05 dB (the other codecs: per step 0.1, mean 0.05)"""
     if not os.path.exists(GOLD):
         pytest.skip("G13 golden vectors not generated")
     gold = np.load(GOLD)
@@ -49,4 +53,9 @@ def test_stack_psnr_matches_the_reference(tmp_path, codec, tol):
         d = np.abs(got[1:] - want[1:])
         assert d.max() < tol, f"{codec} rank {r}: final-output PSNR departs from the reference by {d.max():.3f} dB (step {1 + int(d.argmax())}): {got} vs {want}"
         assert np.all(want[1:] < 80), "the compressed run must differ from the exact one"
-        assert abs(float(got[1:].mean() - want[1:].mean())) < 0.15, f"{codec} rank {r}: mean PSNR {got[1:].mean():.3f} vs {want[1:].mean():.3f}"
+        assert abs(float(got[1:].mean() - want[1:].mean())) < 0.05, f"{codec} rank {r}: mean PSNR {got[1:].mean():.3f} vs {want[1:].mean():.3f}"
+        comp = os.path.join(HERE, "golden", "g13_stack_lrq32_compiled.npz")
+        if codec == "lowrankq32" and os.path.exists(comp):
+            # ... and not further from the reference's compiled trace than 0.5 dB either (the reference runs compiled on its own hardware)
+            other = np.load(comp)[f"lowrankq32/r{r}/psnr"]
+            assert np.abs(got[1:] - other[1:]).max() < tol and abs(float(got[1:].mean() - other[1:].mean())) < 0.08

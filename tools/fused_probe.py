@@ -7,6 +7,7 @@ from compactfusion_amd import _lib, codecs as K
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 N, C, B, L = 544, 3072, 2, 24
+_lib.use_dev_library()          # per-workgroup stamps exist in libcfx_dev.so only (include/cfx_dev.h)
 lib = _lib.load(); ctx = K.context(0)
 torch.manual_seed(0)
 base = torch.randn(L, B, N, C, device="cuda").half()
@@ -19,7 +20,7 @@ for l in range(L):
     items.append((_lib.CompItem * B)(*[_lib.CompItem(x[l, i].data_ptr(), base[l, i].data_ptr(), None, pk[l, i].data_ptr()) for i in range(B)]))
 dbg = int(os.environ.get("DBG", "0"))     # developer build (python -m compactfusion_amd.build --dev-probes): early exits 1..4 of the compress kernel
 if dbg:
-    assert lib.cfx_set_dev_probe(ctx, dbg) == 0, "DBG needs a --dev-probes build"
+    assert lib.cfx_dev_set_probe(ctx, dbg) == 0, "DBG needs a --dev-probes build"
 for fused in ([1, 0] if not dbg else [1]):
     lib.cfx_set_fused_finalize(ctx, fused)
     for r in range(reps):

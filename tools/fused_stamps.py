@@ -1,4 +1,4 @@
-"""Developer probe: phase timeline of the single-launch compress kernel (cfx_debug_stamps), FLUX shard, K and V.
+"""Developer probe: phase timeline of the single-launch compress kernel (cfx_dev_stamps), FLUX shard, K and V.
 Prints, over the workgroups of one launch, when each phase ends relative to the first workgroup's start (us)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,6 +7,7 @@ import torch
 from compactfusion_amd import _lib, codecs as K
 
 N, C, B, L = 544, 3072, 2, 16
+_lib.use_dev_library()          # per-workgroup stamps exist in libcfx_dev.so only (include/cfx_dev.h)
 lib = _lib.load(); ctx = K.context(0)
 torch.manual_seed(0)
 base = torch.randn(L, B, N, C, device="cuda").half()
@@ -24,10 +25,10 @@ names = ["start", "tile done (loads+math+partial stores issued)", "partials drai
 agg = []
 for rep in range(8):
     st.zero_()
-    lib.cfx_debug_stamps(ctx, st.data_ptr())
+    lib.cfx_dev_stamps(ctx, st.data_ptr())
     lib.cfx_compress_batch_ex(ctx, 1, N, C, 0, 0, B, items[rep % L], 0, None, ws.data_ptr(), ws.numel(), sh)
     torch.cuda.synchronize()
-    lib.cfx_debug_stamps(ctx, None)
+    lib.cfx_dev_stamps(ctx, None)
     a = st.cpu().numpy().reshape(nwg, 16)
     a = a[a[:, 0] > 0]
     t0 = a[:, 0].min()

@@ -6,6 +6,7 @@ import torch
 from compactfusion_amd import _lib, codecs as K
 
 N, C, L, P = 544, 3072, 8, 14
+_lib.use_dev_library()          # per-workgroup stamps exist in libcfx_dev.so only (include/cfx_dev.h)
 lib = _lib.load(); ctx = K.context(0)
 
 torch.manual_seed(0)
@@ -29,10 +30,10 @@ for l in range(L): go(l)
 torch.cuda.synchronize()
 for rep in range(4):
     st.zero_()
-    lib.cfx_debug_stamps(ctx, st.data_ptr())
+    lib.cfx_dev_stamps(ctx, st.data_ptr())
     go(rep % L)
     torch.cuda.synchronize()
-    lib.cfx_debug_stamps(ctx, None)
+    lib.cfx_dev_stamps(ctx, None)
 a = st.cpu().numpy().reshape(nwg, 16)
 # per own tensor (K = item 0, V = item 1): compress workgroup b belongs to tensor b // (CB * P)
 CBP = ((C + 511) // 512) * ((N + 31) // 32)

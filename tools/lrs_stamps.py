@@ -1,4 +1,4 @@
-"""Developer probe: stage timeline of the slab-resident low-rank chain (k_lrs, cfx_debug_stamps).  Per stamp: min / median / max over
+"""Developer probe: stage timeline of the slab-resident low-rank chain (k_lrs, cfx_dev_stamps).  Per stamp: min / median / max over
 the workgroups, microseconds after the earliest workgroup's start."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,6 +6,7 @@ import numpy as np
 import torch
 from compactfusion_amd import _lib, codecs as K
 
+_lib.use_dev_library()          # per-workgroup stamps exist in libcfx_dev.so only (include/cfx_dev.h)
 lib = _lib.load(); ctx = K.context(0)
 N, C = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (544, 3072)
 names = ["start", "slab in registers + LDS", "Y0 partial written", "Y0 summed", "W1 + M1 partial written", "W1 + M1 summed", "factor of M1, Y1",
@@ -20,9 +21,9 @@ for r in (8, 16, 32):
     f = lambda: K.lr_compress_batch(False, xs, bs, nb, pk, q0, N, C, r, True)
     for _ in range(5): f()
     st = torch.zeros(1024 * 16, dtype=torch.int64, device="cuda")
-    lib.cfx_debug_stamps(ctx, st.data_ptr())
+    lib.cfx_dev_stamps(ctx, st.data_ptr())
     f(); torch.cuda.synchronize()
-    lib.cfx_debug_stamps(ctx, None)
+    lib.cfx_dev_stamps(ctx, None)
     a = st.cpu().numpy().reshape(-1, 16)
     t0 = a[a[:, 0] > 0][:, 0].min()
     a = a[0::2]                                  # tensor 0 (z = workgroup % batch)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer probe: phase timeline of ONE int4 / int8 layer launch (k_minmax_layer; loop-back form: B own tensors + NP reconstructions) from
-the per-workgroup wall-clock stamps (cfx_debug_stamps).  N, C, B, NP, CODEC from the environment."""
+the per-workgroup wall-clock stamps (cfx_dev_stamps).  N, C, B, NP, CODEC from the environment."""
 import os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,6 +8,7 @@ import numpy as np
 import torch
 from compactfusion_amd import _lib, codecs as K
 N, C, B, NP, CID, L = (int(os.environ.get(k, d)) for k, d in (("N", 1024), ("C", 1152), ("B", 2), ("NP", 2), ("CODEC", 3), ("L", 8)))
+_lib.use_dev_library()          # per-workgroup stamps exist in libcfx_dev.so only (include/cfx_dev.h)
 lib, ctx = _lib.load(), K.context(0)
 g = torch.Generator(device="cuda").manual_seed(0)
 own = torch.randn(L, B, N, C, device="cuda", generator=g).half()
@@ -27,10 +28,10 @@ for l in range(L): go(l)
 torch.cuda.synchronize()
 for rep in range(3):
     st.zero_()
-    lib.cfx_debug_stamps(ctx, st.data_ptr())
+    lib.cfx_dev_stamps(ctx, st.data_ptr())
     go(rep % L)
     torch.cuda.synchronize()
-    lib.cfx_debug_stamps(ctx, None)
+    lib.cfx_dev_stamps(ctx, None)
 a = st.cpu().numpy().reshape(nwg, 16)
 a = a[a[:, 0] > 0]
 t0 = a[:, 0].min()
