@@ -3436,12 +3436,26 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
     const size_t wstride = ws_words(codec, N, C);
     u64* ws = (u64*)workspace;
     const int CB = (C + TILE_C - 1) / TILE_C;
+    // Under stream capture NO layer form is taken (round 6).  The one-launch forms take the value their gates open at, their ticket-ring
+    // slot and their launch tags as launch ARGUMENTS that the host advances with every launch - a replayed graph node would wait for
+    // numbers that have gone by - so a capturing stream gets the capturable sequence instead, from this very call: compress (tickets that
+    // reset themselves) ; reconstruct the gated items in stream order (an exchange-layer op: the caller's exchange in between, xg->taken
+    // stays 0).  Bit-identical results; two (int4 / int8: three) launches per layer instead of one, and no host call per replay.
+    // (Device-side counters would keep the one-launch form capturable: every workgroup of a launch has to read the launch's number and
+    // exactly one has to advance it once ALL have read it - the last workgroup to leave, an exit ticket per workgroup - and the gate
+    // blocks have to be reset by it as well: ~0.5 us on every launch of the headline path for a mode the plan replay does not need.)
+    bool capturing = false;
+    if (n_gated || xg) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        capturing = cs != hipStreamCaptureStatusNone;
+    }
 
     if (codec == CFX_CODEC_TOPK) {
         const size_t E = (size_t)N * C;
         // ---- the layer in ONE launch (k_topk_layer): the reconstruction group launched with the compress group, gated on the packets ----
         const int stream_cus_t = n_gated ? stream_cu_count(ctx, stream) : 0;
-        bool layer = n_gated && ctx->gated_on && !ctx->dev_probe && stream_cus_t >= 128;
+        bool layer = n_gated && ctx->gated_on && !ctx->dev_probe && stream_cus_t >= 128 && !capturing;
         if (layer && !xg) {
             // loop-back: every reconstruction item reads one of this launch's packets
             for (int g_ = 0; g_ < n_gated && layer; ++g_) {
@@ -3522,7 +3536,8 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
     // way was measured slower (K,V of the FLUX shard: 20.8 vs 19.2 us 1-bit, 19.9 vs 18.6 us 2-bit) - the gate hop and the write tail
     // cost more than the kernel boundary they replace when only two tensors wait behind the gate
     // (2-bit: the tile stays in registers - exactly one trip of the row loop; 1-bit: any whole number of trips)
-    bool one_launch = n_gated && gated_one_launch(ctx, codec, C, CB) && (R == FUSED_NW * 4 || (codec == CFX_CODEC_BINARY && R % (FUSED_NW * 4) == 0));
+    bool one_launch = n_gated && !capturing && gated_one_launch(ctx, codec, C, CB) &&
+                      (R == FUSED_NW * 4 || (codec == CFX_CODEC_BINARY && R % (FUSED_NW * 4) == 0));
     if (one_launch && codec == CFX_CODEC_INT2) {
         // the 2-bit layer launch needs every statistics workgroup CO-RESIDENT (each waits at gate 1 for all the others' partial sums
         // while holding its tile in registers): only when they fit the CUs this stream may use, otherwise the multi-launch form
@@ -3712,7 +3727,7 @@ static int compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int f
         const long n_st = (long)CB * PL * batch;
         long n_g = (long)CB * g_rb * n_gated;
         bool layer = fused && ctx->gated_on && !ctx->dev_probe && C % 16 == 0 && stream_cus >= 128 && ctx->stats_rows == 0 && PL <= MML_MAX_P_TALL &&
-                     n_st <= MML_MAX_TILES;
+                     n_st <= MML_MAX_TILES && !capturing;
         if (layer && !n_gated && !xg) {
             // a plain compress call may be under stream capture (the ungated launches are capturable: include/cfx.h); the layer launch is not -
             // its tags and flags are launch arguments that advance with every launch, a replayed node would meet its own old tags

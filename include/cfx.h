@@ -142,12 +142,15 @@ int cfx_compress_batch_ex(cfx_ctx* ctx, int codec, int N, int C, int param, int 
  * publish the scales into the packet and, tagged, into the arena.  2-bit: a statistics tile polls those tagged scales (no gate 1), and a
  * reconstruction tile waits for the 4 - 6 tiles whose codes it reads (per-tile flags) instead of the slowest of all (2.10 -> 1.89 ms per
  * FLUX step).  1-bit: the reconstruction tiles keep the arrival gate (XCD-relayed; tagged scales measured 10 % slower there).
- * NOT capturable into a hipGraph: the value a gate opens at and the launch's tag are launch arguments that advance with every launch
- * (monotonic arrival counters, no reset, no memset node), so a replayed node would wait for a value that has already gone by.  The ungated
- * launches (cfx_compress_batch / _ex) are capturable: their tickets reset themselves.  (An int4 / int8 compress call outside a capture runs
- * as ONE launch too - statistics, scales, codes and the state update from the tile in registers, k_minmax_layer - handing its partials over
- * as sequence-tagged words in an arena the context keeps per stream; under stream capture the same call runs the capturable sequence
- * statistics ; quantise, with identical results.) */
+ * Stream capture (round 6): the ONE-launch forms take the value their gates open at, their ticket-ring slot and their launch tags as launch
+ * arguments the host advances with every launch (monotonic arrival counters, no reset, no memset node) - a replayed node would wait for
+ * numbers that have gone by.  So on a CAPTURING stream this call - and the exchange-layer ops of a plan - enqueue the capturable sequence
+ * instead: compress (tickets that reset themselves) ; reconstruct the gated items in stream order; identical results, two launches (int4 /
+ * int8: three) instead of one, no host call per replay.  tests/test_gpu_api.py::test_layer_calls_are_graph_capturable replays every codec's
+ * layer call and the peer-to-peer layer op four times between eager launches of the same context.  The ungated launches (cfx_compress_batch
+ * / _ex) are capturable as they are.  (An int4 / int8 compress call outside a capture runs as ONE launch too - statistics, scales, codes
+ * and the state update from the tile in registers, k_minmax_layer - handing its partials over as sequence-tagged words in an arena the
+ * context keeps per stream; under stream capture the same call runs the capturable sequence statistics ; quantise, with identical results.) */
 int cfx_compress_batch_gated(cfx_ctx* ctx, int codec, int N, int C, int param, int flags,
                              int batch, const cfx_comp_item* items, int n_ride, const cfx_decomp_item* ride,
                              int n_gated, const cfx_decomp_item* gated,

@@ -544,6 +544,99 @@ def test_codec_calls_are_graph_capturable(codec):
         assert torch.equal(peer[i].view(torch.int16), ref_peer[i].view(torch.int16))
 
 
+@pytest.mark.parametrize("codec,shape", [(1, (544, 3072)), (2, (544, 3072)), (3, (256, 1152)), (4, (256, 1152)), (5, (128, 1024))])
+@pytest.mark.parametrize("op", ["gated", "p2p_layer"])
+def test_layer_calls_are_graph_capturable(codec, shape, op):
+    """VERDICT round 5, task 5: the LAYER call of every codec - cfx_compress_batch_gated, and the peer-to-peer exchange-layer op of a plan at
+    N = 1 - captured into a HIP graph and replayed.  Outside a capture the call is ONE launch whose gate value, ticket slot and launch
+    tag are launch arguments the host advances; a capturing stream gets the capturable sequence from the same call (compress with
+    self-resetting tickets ; reconstruct in stream order, csrc/cfx_kernels.hip compress_impl).  Four replays with fresh activations in
+    the static input buffers, eager layer launches of the same context before and BETWEEN the replays (their tags and ring slots advance
+    underneath): packets, sender states and peer states == the oracle bit for bit after every replay."""
+    import ctypes
+    from compactfusion_amd import _lib, codecs as K
+    lib = _lib.load()
+    ctx = K.context(0)
+    N, C = shape
+    name = {1: "binary", 2: "int2", 3: "int4", 4: "int8", 5: "topk"}[codec]
+    param = 8 if codec == 5 else 0
+    B, NP = 2, 4
+    rng = np.random.default_rng(77 + codec)
+
+    def fresh():
+        return [(rng.standard_normal((N, C)) * 0.5).astype(np.float16) for _ in range(B)]
+
+    def devt(a):
+        return torch.from_numpy(a.view(np.int16).copy()).view(torch.float16).cuda()
+    base = fresh()
+    xin = [devt(b) for b in base]                                          # static input buffers of the graph
+    own = [devt(b) for b in base]
+    peer = [devt(base[g % B]) for g in range(NP)]
+    want = [b.copy() for b in base]
+    slot = (K.packet_bytes(codec, N, C, param) + 255) // 256 * 256
+    pk = torch.zeros(B, slot, dtype=torch.uint8, device="cuda")
+    wsb = lib.cfx_workspace_bytes(codec, N, C, param, B)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device="cuda")
+    comp = (_lib.CompItem * B)(*[_lib.CompItem(xin[i].data_ptr(), own[i].data_ptr(), own[i].data_ptr(), pk[i].data_ptr()) for i in range(B)])
+    gated = (_lib.DecompItem * NP)(*[_lib.DecompItem(pk[g % B].data_ptr(), peer[g].data_ptr(), peer[g].data_ptr()) for g in range(NP)])
+    side = torch.cuda.Stream()
+    plan = None
+    if op == "p2p_layer":
+        flag = torch.zeros(64, dtype=torch.int32, device="cuda")
+        plan = lib.cfx_plan_create(ctx)
+        rc = lib.cfx_plan_add_exchange_layer_p2p(plan, codec, N, C, param, _lib.FLAG_UPDATE_CACHE, B, comp, NP, gated, flag.data_ptr(), 0,
+                                                 (ctypes.c_void_p * 1)(), ws.data_ptr(), wsb)
+        assert rc >= 0 and lib.cfx_plan_finalize(plan) == 0, lib.cfx_last_error_string(ctx)
+
+    def call(sh):
+        if op == "gated":
+            rc = lib.cfx_compress_batch_gated(ctx, codec, N, C, param, _lib.FLAG_UPDATE_CACHE, B, comp, 0, None, NP, gated, ws.data_ptr(), wsb, sh)
+        else:
+            rc = lib.cfx_plan_run(plan, 0, 1, sh)
+        assert rc == 0, lib.cfx_last_error_string(ctx)
+
+    def step_oracle(xs):
+        for i in range(B):
+            pkt_ref, want[i] = R.residual_compress(name, xs[i], want[i], param)
+        return pkt_ref
+
+    def load(xs):
+        for i in range(B):
+            xin[i].copy_(devt(xs[i]))
+
+    def check(what):
+        torch.cuda.synchronize()
+        assert lib.cfx_gate_errors(ctx) == 0, what
+        for i in range(B):
+            assert np.array_equal(bits(own[i]).reshape(N, C), R.bits(want[i])), f"{what}: sender state {i}"
+        for g in range(NP):
+            assert np.array_equal(bits(peer[g]).reshape(N, C), R.bits(want[g % B])), f"{what}: peer state {g}"
+    # an eager layer launch first (the one-launch form: advances the context's tags and ring slot)
+    xs = fresh(); load(xs); step_oracle(xs)
+    with torch.cuda.stream(side):
+        call(side.cuda_stream)
+    check("eager launch before the capture")
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            call(side.cuda_stream)
+    torch.cuda.synchronize()
+    check("capture must not execute")
+    for rep in range(4):
+        xs = fresh(); load(xs); step_oracle(xs)
+        torch.cuda.synchronize()
+        graph.replay()
+        check(f"replay {rep}")
+        if rep == 1:                                                   # an eager launch between two replays
+            xs = fresh(); load(xs); step_oracle(xs)
+            with torch.cuda.stream(side):
+                call(side.cuda_stream)
+            check("eager launch between replays")
+    if plan is not None:
+        lib.cfx_plan_destroy(plan)
+
+
 def test_native_comm_single_rank(tmp_path):
     """libcfx's own RCCL communicator (1 rank): unique id, init, all-gather through a plan on every stream mode."""
     import torch.distributed as dist
