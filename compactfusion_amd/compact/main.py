@@ -529,7 +529,7 @@ class _KVExchange:
         # as ONE native call (built on first use)
         from . import xlayer
         self._drop_xop()
-        if xlayer.usable(cid, self.world, self.cuda):
+        if xlayer.usable(cid, self.world, self.cuda, ef=ef):
             peers = [(r, kb[r], vb[r]) for r in range(self.world) if r != self.rank]
             self._xop_args = (("gather",) + self.tags + (id(self.group) if self.group is not None else None,), cid, param, N, C,
                               self.rank, self.world, self.group, self.device, own, peers)

@@ -466,7 +466,7 @@ class _LayerExchange:
             return b
         own = [state(self.kkeys[self.rank]), state(self.vkeys[self.rank])]
         self._drop_xop()
-        if self._xop_wanted(cid):
+        if self._xop_wanted(cid, ef):
             # ONE native op per layer (xlayer.LayerOp): compress ; exchange ; reconstruct all peers - on the caller's stream, in front of
             # the local attention block.  The states are updated in place; the consumer reads them as the peers' K,V.
             from . import xlayer
@@ -519,13 +519,13 @@ class _LayerExchange:
             self.xop.close()
         self.xop = None
 
-    def _xop_wanted(self, cid) -> bool:
+    def _xop_wanted(self, cid, ef: bool = True) -> bool:
         """The layer's exchange as one native op on the caller's stream - unless the caller runs on the exchange lane's compute stream
         (then the chain runs beside the attention blocks on the CU-masked exchange stream) or asked for one of the multi-launch forms."""
         from . import xlayer
         from .. import lanes
         xmode = _settings.get("ring_exchange_stream")     # auto | xlayer | lane | chain | side | main
-        if xmode not in ("auto", "xlayer") or not xlayer.usable(cid, self.world, self.send.is_cuda):
+        if xmode not in ("auto", "xlayer") or not xlayer.usable(cid, self.world, self.send.is_cuda, ef=ef):
             return False
         dev = self.send.device.index if self.send.device.index is not None else torch.cuda.current_device()
         return xmode == "xlayer" or not lanes.on_compute_stream(dev)
@@ -762,7 +762,9 @@ def _gather_schedule(q, k, v, ctype, mod_idx, rank, world, group, kkey, vkey, at
     ex = _layer_exchange(mod_idx, rank, world, slot, k, group)
     send, recv, side = ex.send, ex.recv, ex.side
     # steady state: K and V in ONE native compress sequence straight into the send slots, in-place EF state update
-    fast = native and cid < 100 and not cfg.log_compress_stats and v.shape == k.shape and not compact_cache().quantize
+    # (the low-rank family - ids >= 100 - has the one-op form only: where that is not wanted, e.g. on the exchange lane, the general path below)
+    fast = (native and (cid < 100 or ex._xop_wanted(cid, bool(cfg.error_feedback))) and not cfg.log_compress_stats and v.shape == k.shape
+            and not compact_cache().quantize)
     cur = torch.cuda.current_stream(k.device) if side is not None else None
     sh = cur.cuda_stream if cur is not None else None
     if fast:

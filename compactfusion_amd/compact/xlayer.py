@@ -302,9 +302,25 @@ class LayerOp:
         self.own, self.peers, self.own_update = list(own_states), list(peer_states), own_update
         self.lib = _lib.load()
         self.ctx = codecs.context(self.dev)
-        self.pkt_bytes = codecs.packet_bytes(self.cid, N, C, self.param)
+        # low-rank family (LOW_RANK / LOW_RANK_Q, compact/lowrank.py ids 101 / 102; param = rank): the same op as a CHAIN of native plan ops -
+        # factor chain of K,V (cfx_plan_add_lr_compress) ; the exchange (publish-and-wait kernel / collective) ; ONE batched reconstruction
+        # of every peer tensor (cfx_plan_add_lr_decompress) - replayed by one host call.  Round 6: the generic path issued one compress
+        # per tensor and one reconstruction per peer tensor from Python (16 launches and 0.44 ms of host time per FLUX layer).
+        self.lowrank = self.cid >= 100
+        self.quantized = self.cid == 102
+        if self.lowrank:
+            assert self.cid in (101, 102) and own_update == "ef", "the low-rank layer op exists with error feedback only"
+            self.pkt_bytes = 2 * codecs.lr_packet_halves(self.quantized, N, C, self.param)
+            rp = codecs.lr_rank_pad(self.param)
+            self._q0 = torch.zeros(2, C, rp, dtype=torch.float32, device=device)      # start matrices of K and V, redrawn per execution
+            self._q0_draw = self._q0 if rp == self.param else self._q0[:, :, :self.param]
+            self._q0p = (ctypes.c_void_p * 2)(self._q0[0].data_ptr(), self._q0[1].data_ptr())
+            self._pinned = None
+        else:
+            self.pkt_bytes = codecs.packet_bytes(self.cid, N, C, self.param)
         self.slot = (self.pkt_bytes + 255) // 256 * 256
         self.flags = _lib.FLAG_UPDATE_CACHE | (0 if own_update == "ef" else _lib.FLAG_NO_EF)
+        self.nops = 1                          # plan ops of one execution on the p2p / collective transports (low-rank chain: 3)
         self._xs = (ctypes.c_void_p * 2)()
         self._plans: Dict[int, Tuple] = {}       # run-stream handle -> (plan, keep-alive)
         self._run_x = self.lib.cfx_plan_run_x
@@ -379,6 +395,8 @@ class LayerOp:
         cid, param, N, C = self.cid, self.param, self.N, self.C
         plan = lib.cfx_plan_create(ctx)
         self._check(plan, "cfx_plan_create")
+        if self.lowrank:
+            return self._build_lowrank(plan, sh)
         ws = codecs.workspace(cid, N, C, param, 2, self.dev, stream_handle=sh)
         wsp, wsn = (None, 0) if ws is None else (ws.data_ptr(), ws.numel())
         keep = [ws]
@@ -427,6 +445,75 @@ class LayerOp:
         ent = self._plans[sh] = (plan, keep)
         return ent
 
+    def _build_lowrank(self, plan, sh: int):
+        """The low-rank layer as plan ops: [factor chain of K,V -> packets, own state updated] ; [exchange] ; [batched reconstruction of
+        the peers' K,V].  p2p: the packets sit in the arena region, the exchange is the publish-and-wait kernel (cfx_plan_add_p2p_sync),
+        the reconstruction reads the peers' packets in place - three ops per parity, one host call per execution."""
+        lib, q, N, C, rank = self.lib, int(self.quantized), self.N, self.C, self.param
+        n_rec = 2 * len(self.peers)
+        wsn = int(lib.cfx_lr_workspace_bytes(q, N, C, rank, max(2, n_rec)))
+        self._check(wsn > 0, "low-rank workspace")
+        ws = torch.empty(wsn, dtype=torch.uint8, device=self.device)
+        keep = [ws, self._q0]
+        wsp = ws.data_ptr()
+        t = self.transport
+
+        def comp(pk_k, pk_v):
+            c = self._comp_items(pk_k, pk_v)
+            keep.append(c)
+            return lib.cfx_plan_add_lr_compress(plan, q, N, C, rank, self.flags, 2, c, self._q0p, wsp, wsn)
+
+        def recon(packet_of):
+            items = []
+            for r, ks, vs in self.peers:
+                items.append(_lib.DecompItem(packet_of(r, 0), ks.data_ptr(), ks.data_ptr()))
+                items.append(_lib.DecompItem(packet_of(r, 1), vs.data_ptr(), vs.data_ptr()))
+            arr = (_lib.DecompItem * n_rec)(*items)
+            keep.append(arr)
+            return lib.cfx_plan_add_lr_decompress(plan, q, N, C, rank, n_rec, arr, wsp, wsn)
+        if t == "none":
+            solo = self._solo_packets()
+            self._check(comp(solo[0].data_ptr(), solo[1].data_ptr()) == 0, "low-rank compress")
+            self.nops = 1
+        elif t == "p2p":
+            reg = self.region
+            live = sorted({r for r, _, _ in self.peers}) if not self.arena.loopback else []
+            for parity in (0, 1):
+                self._check(comp(reg.packet(None, parity, 0), reg.packet(None, parity, 1)) == 3 * parity, "low-rank compress")
+                pf = (ctypes.c_void_p * max(1, len(live)))(*[reg.flag(r, parity) for r in live])
+                keep.append(pf)
+                self._check(lib.cfx_plan_add_p2p_sync(plan, reg.flag(None, parity), len(live), pf) == 3 * parity + 1, "p2p sync")
+                self._check(recon(lambda r, kv, parity=parity: reg.packet(r, parity, kv)) == 3 * parity + 2, "low-rank reconstruct")
+            self.nops = 3
+        elif t == "rccl":
+            recv, slot = self._recv.data_ptr(), self.slot
+            self._check(comp(recv + (2 * self.rank) * slot, recv + (2 * self.rank + 1) * slot) == 0, "low-rank compress")
+            self._check(lib.cfx_plan_add_all_gather(plan, self._comm.handle, recv + 2 * self.rank * slot, recv, 2 * slot) == 1, "all-gather")
+            self._check(recon(lambda r, kv: recv + (2 * r + kv) * slot) == 2, "low-rank reconstruct")
+            self.nops = 3
+        else:
+            send, recv, slot = self._send.data_ptr(), self._recv.data_ptr(), self.slot
+            self._check(comp(send, send + slot) == 0, "low-rank compress")
+            self._check(recon(lambda r, kv: recv + (2 * r + kv) * slot) == 1, "low-rank reconstruct")
+            self.nops = 1                      # (the collective is issued from Python between the two ops)
+        self._check(lib.cfx_plan_finalize(plan) == 0, "finalize")
+        ent = self._plans[sh] = (plan, keep)
+        return ent
+
+    def _draw_start(self) -> None:
+        """The start matrices of this execution's subspace iterations: drawn per call as the reference does (compress_lowrank.py:41) - one
+        normal_() over both - or the matrix a test pinned (lowrank.set_init_q)."""
+        from . import lowrank
+        pinned = lowrank._pinned_q
+        if pinned is None:
+            self._q0_draw.normal_()
+            self._pinned = None
+        elif pinned is not self._pinned:
+            assert tuple(pinned.shape) == (self.C, self.param), f"pinned init_q must be ({self.C}, {self.param})"
+            self._q0.zero_()
+            self._q0[:, :, :self.param] = pinned.to(device=self.device, dtype=torch.float32)
+            self._pinned = pinned
+
     def _solo_packets(self):
         if getattr(self, "_solo", None) is None:
             self._solo = [torch.empty(self.slot, dtype=torch.uint8, device=self.device) for _ in range(2)]
@@ -462,13 +549,16 @@ class LayerOp:
                         r_.recheck = 1
                 if reg.validated < VALIDATE_FIRST or reg.recheck or (self.arena.kind != 2 and reg.n_exec % REVALIDATE_EVERY == 0):
                     return self._run_validated(k, v, sh)
-            op = reg.n_exec & 1
+            op = (reg.n_exec & 1) * self.nops
             reg.n_exec += 1
         else:
             op = 0
+        if self.lowrank:
+            self._draw_start()
         xs = self._xs
         xs[0], xs[1] = k.data_ptr(), v.data_ptr()
-        rc = self._run_x(ent[0], op, 1, xs, 2, sh)
+        nops = self.nops
+        rc = self._run_x(ent[0], op, nops, xs, 2, sh)
         if rc == _lib.CFX_ERR_GATE and t == "p2p" and not self.arena.loopback:
             # an EARLIER launch's wait gave up (a peer later than the gate timeout): it stored nothing.  Clear the word, tell the group at
             # the next step boundary, and issue this layer's launch - the flag epochs have to keep step with the peers'
@@ -478,7 +568,7 @@ class LayerOp:
                 #                                          timeout on the short arrival count until the group's boundary a step or two later
                 warnings.warn("compactfusion_amd: an in-launch wait of the peer-to-peer exchange timed out (a peer was later than the gate "
                               "timeout); nothing was stored, the group validates its layers again at the next step boundary")
-            rc = self._run_x(ent[0], op, 1, xs, 2, sh)
+            rc = self._run_x(ent[0], op, nops, xs, 2, sh)
         if rc == 0 and t == "torch":
             dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
             rc = self._run(ent[0], 1, 1, sh)
@@ -521,8 +611,10 @@ class LayerOp:
         ent = self._plans[sh]
         op = reg.n_exec & 1
         reg.n_exec += 1
+        if self.lowrank:
+            self._draw_start()
         self._xs[0], self._xs[1] = k.data_ptr(), v.data_ptr()
-        rc = self._run_x(ent[0], op, 1, self._xs, 2, sh)
+        rc = self._run_x(ent[0], op * self.nops, self.nops, self._xs, 2, sh)
         stream = torch.cuda.current_stream(self.device)
         stream.synchronize()
         bad = 1 if rc != 0 else 0
@@ -579,6 +671,7 @@ class LayerOp:
         self.run(k, v, sh)
 
 
-def usable(cid: int, world: int, is_cuda: bool) -> bool:
-    """Can the layer's exchange run as a LayerOp: a native streaming codec, W ranks whose 2 (W - 1) peer tensors + own K,V fit one batch."""
-    return is_cuda and 1 <= cid <= 5 and 2 * (world - 1) + 2 <= MAX_ITEMS
+def usable(cid: int, world: int, is_cuda: bool, ef: bool = True) -> bool:
+    """Can the layer's exchange run as a LayerOp: a native streaming codec - or the low-rank family with error feedback -, W ranks whose
+    2 (W - 1) peer tensors + own K,V fit one batch."""
+    return is_cuda and (1 <= cid <= 5 or (cid in (101, 102) and ef)) and 2 * (world - 1) + 2 <= MAX_ITEMS

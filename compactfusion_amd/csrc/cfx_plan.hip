@@ -201,8 +201,8 @@ void cfx_plan_destroy(cfx_plan* p) {
     delete p;
 }
 
-// op kinds whose items' x operands are the activations a run re-points (cfx_plan_run_x): the 1-bit .. top-k compress, the exchange layers
-static inline bool takes_activations(int kind) { return kind == 0 || kind == 9 || kind == 10; }
+// op kinds whose items' x operands are the activations a run re-points (cfx_plan_run_x): the 1-bit .. top-k compress, the low-rank compress, the exchange layers
+static inline bool takes_activations(int kind) { return kind == 0 || kind == 7 || kind == 9 || kind == 10; }
 
 static PlanOp* plan_push(cfx_plan* p) {
     if (p->n == p->cap) {

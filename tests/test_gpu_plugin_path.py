@@ -156,6 +156,74 @@ def test_plugin_call_other_codecs_one_native_op(loop8, api, codec):
     assert lib.cfx_gate_errors(ctx) == 0
 
 
+@pytest.mark.parametrize("codec,rank", [("LOW_RANK", 8), ("LOW_RANK", 12), ("LOW_RANK_Q", 32)])
+@pytest.mark.parametrize("api", ["ring", "gather"])
+def test_plugin_call_low_rank_family_one_native_call_per_layer(loop8, api, codec, rank):
+    """Round 6: the LOW_RANK / LOW_RANK_Q presets through compact_fwd / compact_all_gather_kv take the layer op too - a chain of native
+    plan ops (factor chain of K,V ; publish-and-wait ; ONE batched reconstruction of the 14 peer tensors) replayed by one host call.
+    Before, the ring forward issued one compress per tensor and one reconstruction per peer tensor from Python (16+ launches and 0.44 ms
+    of host time per FLUX layer: 25 ms per step).  Checked: the launches of a step (one factor chain and one reconstruction launch per
+    layer; LOW_RANK_Q: plus its int4 quantise / dequantise), every peer's state == the sender's bit for bit, and the states == the
+    codec called directly, tensor by tensor, with the same pinned start matrix (the chain's sums do not depend on the batch)."""
+    ring, cm, xlayer = loop8
+    from compactfusion_amd import _lib, codecs as K
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig, PatchConfig, lowrank
+    lib, ctx = _lib.load(), K.context(0)
+    L, STEPS = 2, 4
+    shape, N, C = (1, 128, 16, 64), 128, 1024
+    quant = codec == "LOW_RANK_Q"
+    kw = dict(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T[codec], comp_rank=rank, residual=1, ef=True, fastpath=False)
+    if api == "gather":
+        kw.update(override_with_patch_gather_fwd=True, patch_gather_fwd_config=PatchConfig(True, False, 1))
+    cm.compact_init(CompactConfig(**kw))
+    qs = [W.drift(7 + l, shape, STEPS) for l in range(L)]
+    ks = [W.drift(17 + l, shape, STEPS) for l in range(L)]
+    vs = [W.drift(27 + l, shape, STEPS) for l in range(L)]
+    dev = torch.device("cuda:0")
+    pinned = torch.randn(C, rank, generator=torch.Generator().manual_seed(5))
+    q0 = torch.zeros(C, K.lr_rank_pad(rank), device=dev)
+    q0[:, :rank] = pinned.to(dev)
+    want = {}
+    for l in range(L):
+        for n, seq in (("k", ks), ("v", vs)):
+            st = seq[l][0].to(dev).reshape(N, C).clone()
+            outs = [bits(st).copy()]
+            for x in seq[l][1:]:
+                pk = torch.empty(K.lr_packet_halves(quant, N, C, rank), dtype=torch.float16, device=dev)
+                K.lr_compress_batch(quant, [x.to(dev).reshape(N, C)], [st], [st], [pk], [q0], N, C, rank, update_cache=True, ef=True)
+                torch.cuda.synchronize()
+                outs.append(bits(st).copy())
+            want[(l, n)] = outs
+    lowrank.set_init_q(pinned)
+    try:
+        with torch.cuda.stream(torch.cuda.Stream(dev)):
+            for s in range(STEPS):
+                cm.compact_set_step(s)
+                torch.cuda.synchronize()
+                assert lib.cfx_profile_enable(ctx, 8192, 0xffffffff, 1) == 0
+                for l in range(L):
+                    ring.compact_fwd(qs[l][s].to(dev), ks[l][s].to(dev), vs[l][s].to(dev), causal=False, mod_idx=l, current_iter=s)
+                torch.cuda.synchronize()
+                got = _kernel_ids(lib, ctx)
+                lib.cfx_profile_enable(ctx, 0, 0, 1)
+                if s > 0:
+                    n_dec = got.count(22)
+                    assert got.count(17) == L and L <= n_dec <= 2 * L, (api, codec, s, got)      # (k_lr_decode also closes the sender's own update where the chain does not fuse it)
+                cache = cm.compact_cache()
+                for l in range(L):
+                    for n in ("k", "v"):
+                        own = bits(cache.get_base(f"{l}-0-{n}" if api == "ring" else f"{l}-{n}-0")).reshape(N, C)
+                        assert np.array_equal(own, want[(l, n)][s].reshape(N, C)), (api, codec, s, l, n, "vs the codec called directly")
+                        for r in range(1, WL):
+                            key = f"{l}-{r}-{n}" if api == "ring" else f"{l}-{n}-{r}"
+                            assert np.array_equal(bits(cache.get_base(key)).reshape(N, C), own), (api, codec, s, l, n, r)
+    finally:
+        lowrank.set_init_q(None)
+    ops = [e.xop for e in ring._xbuf.values() if e.xop is not None] + [e.xop for e in cm._kv_exchanges.values() if e.xop is not None]
+    assert len(ops) == L and all(o.transport == "p2p" and o.lowrank and o.nops == 3 for o in ops)
+    assert lib.cfx_gate_errors(ctx) == 0
+
+
 def _check_states(res, codec, mode, world, gens, L=3, STEPS=4, shape=(1, 64, 8, 64)):
     for gen in range(gens):
         for l in range(L):
