@@ -1264,6 +1264,10 @@ def main():
             BS.plugin_leg(out, args.plugin_steps, L)
         if not args.no_config_table:
             BS.configs_leg(out, HBM_PEAK_GBS)
+            if args.plugin_steps > 0:
+                BS.plugin_configs_leg(out)
+        if args.overlap_steps > 0:
+            BS.overlap_presets_leg(out, max(4, args.overlap_steps // 2), L)
         BS.lowrank_leg(out, dev, N, C)
     try:
         ctypes.CDLL(None).fflush(None)

@@ -80,7 +80,7 @@ def compact_fwd(q, k, v, dropout_p=0, softmax_scale=None, causal=True, window_si
     # lane's compute stream is put there for the duration of the call (configure(lane="auto"): forked from and joined to its own stream
     # by flag kernels) or for good (lane="sticky"); lane="off" keeps the exchange as one op on the caller's stream.
     token = dev = key = None
-    if q.is_cuda and _auto_lane(q, group):
+    if q.is_cuda and _auto_lane(q, group) and _lane_has_chain(mod_idx, current_iter):
         from .. import lanes
         dev = q.device.index if q.device.index is not None else torch.cuda.current_device()
         key = (mod_idx, id(group) if group is not None else None)
@@ -102,6 +102,19 @@ def compact_fwd(q, k, v, dropout_p=0, softmax_scale=None, causal=True, window_si
             _prebegun.pop(key, None)           # (not consumed: the call took the general path, which publishes its own epoch)
         if token is not None:
             lanes.join_from_compute(dev, token)
+
+
+def _lane_has_chain(mod_idx, current_iter) -> bool:
+    """The exchange lane runs the layer's chain of the STREAMING codecs (compress ; all-gather ; per-peer reconstruction, flag-ordered
+    against the attention blocks).  The low-rank family has no lane chain - its factor chain is one persistent launch that wants the
+    whole chip - so a LOW_RANK / LOW_RANK_Q layer keeps the caller's stream and takes the one-call layer op there (round 6: on the lane
+    it fell through to one Python call per tensor, 25 ms per FLUX step)."""
+    cfg = compact_config()
+    try:
+        ctype = cfg.compress_func(mod_idx, current_iter if current_iter is not None else cm.compact_get_step())
+    except Exception:  # noqa: BLE001  (a compress_func that needs arguments this call does not have: the forward itself will say so)
+        return True
+    return ctype not in (COMPACT_COMPRESS_TYPE.LOW_RANK, COMPACT_COMPRESS_TYPE.LOW_RANK_Q)
 
 
 _lane_ok = {}        # (device, id(group)) -> world size >= 2 and the lane's streams usable: asked once, not on every layer call

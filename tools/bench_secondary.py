@@ -70,6 +70,50 @@ def plugin_leg(out, steps, layers):
         out["plugin_path"] = {"error": f"{type(e).__name__}: {e}"}
 
 
+def plugin_configs_leg(out):
+    # every BASELINE configuration and every shipped preset THROUGH THE PLUGIN API (tools/plugin_config_bench.py, a child process): one Python
+    # call per layer - compact_fwd / compact_all_gather_kv / compact_compress + compact_decompress - instead of the native plan replay
+    # `configs` is timed with.  Adds `plugin_ms_per_step` and `plugin_host_us_per_layer` to the rows of `configs`, and `presets_through_the_plugin_api`
+    try:
+        pc = _child("plugin_config_bench.py", ["--quiet", "--budget", "0.12"], 900)["rows"]
+        for key, row in (out.get("configs") or {}).items():
+            src = pc.get(key)
+            if src and "plugin_ms_per_step" in src:
+                row["plugin_ms_per_step"] = src["plugin_ms_per_step"]
+                row["plugin_host_us_per_layer"] = src["host_us_per_layer_idle_queue"]
+                row["plugin_api"] = src["api"]
+                row["plugin_vs_native_replay"] = round(src["plugin_ms_per_step"] / row["ms_per_step"], 3) if row.get("ms_per_step") else None
+            elif src:
+                row["plugin_error"] = src.get("error")
+        out["presets_through_the_plugin_api"] = {
+            k[len("preset "):]: ({"ms_per_step": v["plugin_ms_per_step"], "host_us_per_layer": v["host_us_per_layer_idle_queue"],
+                                  "kernels_per_layer": v["kernels_per_layer"], "one_native_call_per_layer": v["one_native_op_per_layer"]}
+                                 if "plugin_ms_per_step" in v else v)
+            for k, v in pc.items() if k.startswith("preset ")}
+        out["presets_through_the_plugin_api"]["what"] = ("protocol 1 through compact_fwd (no-op attention, lane off) at the FLUX shard, 57 layers, 8 logical ranks "
+                                                          "looped back: the reference's shipped presets (examples/configs.py:39-98); host_us_per_layer = one step "
+                                                          "issued into an idle queue / layers")
+    except Exception as e:  # pragma: no cover
+        out["presets_through_the_plugin_api"] = {"error": f"{type(e).__name__}: {e}"}
+
+
+def overlap_presets_leg(out, steps, layers):
+    # SURVEY 8d protocol 2 for the presets other than BINARY (task 4): exposed exchange of INT2 and LOW_RANK r = 8 beside SDPA
+    res = {}
+    for preset in ("int2", "lowrank8"):
+        try:
+            ov = _child("overlap_bench.py", ["--quiet", "--steps", str(steps), "--layers", str(layers), "--preset", preset, "--legs",
+                                             "attention_on_compute_lane,attention,default"], 900)
+            legs = ov["legs_ms_per_step"]
+            res[preset] = {"default_path": ov["default_path"], "attention_only_ms_per_step": legs["attention"]["wall"],
+                           "with_exchange_ms_per_step": legs["default"]["wall"], "exposed_exchange_ms_per_step": ov["exposed_exchange_ms_per_step"]["default"]}
+        except Exception as e:  # pragma: no cover
+            res[preset] = {"error": f"{type(e).__name__}: {e}"}
+    res["what"] = ("compact_fwd with every switch at its default beside PyTorch-ROCm SDPA at the FLUX shape; INT2 takes the exchange lane, the low-rank "
+                   "family the one-call layer op on the caller's stream (its factor chain is one persistent launch over the whole chip: nothing overlaps)")
+    out["overlap_with_attention_other_presets"] = res
+
+
 def configs_leg(out, hbm_peak_gbs):
     # every BASELINE.json configuration, one rank's codec work of one denoise step replayed layer by layer in order, peers looped back
     # (SURVEY 8d shapes): ms per step, algorithmic bytes, fraction of the HBM roofline

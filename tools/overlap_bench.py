@@ -42,7 +42,15 @@ ap.add_argument("--json", default=None)
 ap.add_argument("--quick", action="store_true", help="only the attention, lane and event-fork legs")
 ap.add_argument("--quiet", action="store_true", help="do not print the JSON (bench.py runs this file as a child process and reads --json)")
 ap.add_argument("--legs", default=None, help="comma-separated subset of the legs (for kernel traces); default all")
+ap.add_argument("--preset", default="binary", choices=["binary", "int2", "lowrank8", "lowrank16", "lowrankq32"],
+                help="the shipped preset the exchange runs (reference examples/configs.py:39-98); other than binary: the legs `attention`, "
+                     "`attention_on_compute_lane`, `layer_op` (lane off: the one-call exchange on the caller's stream) and `default` "
+                     "(every switch at its default: the lane for the streaming codecs, the layer op for the low-rank family)")
 args = ap.parse_args()
+PRESETS = {"binary": ("BINARY", dict(comp_rank=-1, fastpath=True)), "int2": ("INT2", dict(comp_rank=-1, fastpath=True)),
+           "lowrank8": ("LOW_RANK", dict(comp_rank=8, fastpath=False)), "lowrank16": ("LOW_RANK", dict(comp_rank=16, fastpath=False)),
+           "lowrankq32": ("LOW_RANK_Q", dict(comp_rank=32, fastpath=False))}
+PTYPE, PKW = PRESETS[args.preset]
 
 os.environ["CFX_FAKE_RCCL_MODE"] = "loopback"
 from compactfusion_amd import _lib, codecs as K, exchange
@@ -136,8 +144,7 @@ def init(mode, xstream="chain", lane_mode="off"):
     exchange.set_comm_factory(LoopComm if mode != "torch" else None)
     ring._xbuf.clear()
     ring._steady.clear()
-    cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T.BINARY, comp_rank=-1,
-                                  residual=1, ef=True, fastpath=True))
+    cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T[PTYPE], residual=1, ef=True, **PKW))
     fwd(0); fwd(1); fwd(2)
     torch.cuda.synchronize()
 
@@ -165,11 +172,14 @@ comp_stream = lanes.compute_stream(0)
 # (GPU_MAX_HW_QUEUES = 8) the flag-ordered legacy legs that follow share queues with something and are time-sliced - measured 36-43 ms per
 # step for `lane_unmasked` / `native` behind them, 23.2 / 23.9 in a process of their own)
 ALL = ["attention_on_compute_lane", "lane", "attention_distinct_kv_on_compute_lane", "attention", "layer_op", "lane_unmasked", "native", "native_gather_only_on_side", "torchdist", "default", "sticky"]
+if args.preset != "binary" and not args.legs:
+    ALL = ["attention_on_compute_lane", "attention", "layer_op", "default"]
 legs = [x for x in (args.legs.split(",") if args.legs else ALL) if x]
 assert all(x in ALL for x in legs), f"legs must be among {ALL}"
 if args.quick:
     legs = [x for x in legs if x not in ("native_gather_only_on_side", "torchdist")]
 res = {}
+default_path = None
 lane_used = native_used = None
 _side = None
 for leg in legs:
@@ -182,9 +192,20 @@ for leg in legs:
         if _side is None:
             _side = torch.cuda.Stream(dev)
         with torch.cuda.stream(_side):
+            from compactfusion_amd.compact import xlayer as _xl
+            if PTYPE.startswith("LOW_RANK"):
+                _xl.set_p2p_loopback(True)             # (the low-rank family's default is the layer op on the caller's stream: packets in the arena)
             init("native", "auto", "auto" if leg == "default" else "sticky")
-            assert all(ex.plan is not None and ex.lane for ex in ring._xbuf.values() if ex.sig is not None), "the default path did not take the lane"
+            took_lane = all(ex.plan is not None and ex.lane for ex in ring._xbuf.values() if ex.sig is not None)
+            took_xop = all(ex.xop is not None for ex in ring._xbuf.values() if ex.sig is not None)
+            assert took_lane or (PTYPE.startswith("LOW_RANK") and took_xop), "the default path took neither the lane nor the layer op"
+            default_path = "exchange lane" if took_lane else "layer op on the caller's stream"
             res[leg] = timed(fwd, 3)
+            if PTYPE.startswith("LOW_RANK"):
+                for ex in ring._xbuf.values():
+                    ex.close()
+                ring._xbuf.clear(); ring._steady.clear()
+                _xl.set_p2p_loopback(False)
     elif leg == "lane":
         with torch.cuda.stream(comp_stream):
             init("native", "lane")
@@ -240,7 +261,7 @@ def _host_us(fn, n=200):
 
 
 direct = None
-if not args.legs:
+if not args.legs and args.preset == "binary":
     init("native", "lane")
     _ex = [e for e in ring._xbuf.values() if e.sig is not None and e.plan is not None][0]
     _st = next(iter(ring._steady.values()))
@@ -257,7 +278,9 @@ att_dist = res["attention_distinct_kv_on_compute_lane"][0] if "attention_distinc
 base_of = lambda k: att_lane if k in ("lane", "default", "sticky") else att       # noqa: E731   each leg against attention on ITS compute stream
 out = {
     "protocol": "SURVEY.md 8d(2): compact_fwd (gather schedule) with PyTorch-ROCm SDPA, one MI355X, 8 logical ranks looped back",
-    "shape": {"q_k_v": [1, N, H, D], "layers": L, "ring": W, "codec": "BINARY 1-bit residual + EF"},
+    "shape": {"q_k_v": [1, N, H, D], "layers": L, "ring": W, "codec": f"{PTYPE} residual + EF" + (f", rank {PKW['comp_rank']}" if PKW["comp_rank"] > 0 else ""),
+              "preset": args.preset},
+    "default_path": default_path,
     "steps": args.steps,
     "lane": {"exchange_cus": lanes.lane(0).exchange_cus, "compute_cus": lanes.lane(0).compute_cus, "lane_plan_used": lane_used},
     "native_plan_used": native_used,
