@@ -69,216 +69,19 @@ import time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tools"))
 
-L_LAYERS, N_TOK, C_CH, W_LOGICAL = 57, 544, 3072, 8
-HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s float4-copy achievable)
-ALG_BYTES = {"binary": {"compress": 6.125, "decompress": 4.125},   # SURVEY.md §8d, bytes per element
-             "int2": {"compress": 6.25, "decompress": 4.25}}
-ALG_BYTES_PER_EL = ALG_BYTES["binary"]
-
-
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)      # 100 x ~1.5 ms: a timed region of ~150 ms (20 steps were a 30 ms sample, clocks still settling)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--layers", type=int, default=L_LAYERS, help="debug only; the judged workload uses 57")
-    ap.add_argument("--rows", type=int, default=0, help="rows per tile override (0 = auto)")
-    ap.add_argument("--ipc-memory", type=int, default=2, choices=[0, 1, 2],
-                    help="debug: what cfx_ipc_alloc asks for first: 2 uncached (default), 1 fine-grained, 0 ordinary device memory")
-    ap.add_argument("--stats-rows", type=int, default=0, help="debug: statistics tile height of the compress launches (cfx_set_stats_rows; 0 = auto)")
-    ap.add_argument("--replay", choices=["inorder", "pipelined"], default="inorder",
-                    help="inorder (default, the deployable schedule): cfx_plan_run, two launches per layer one after the other; "
-                         "pipelined: cfx_plan_run_pipelined, reorders work ACROSS layers (resident synthetic inputs only)")
-    ap.add_argument("--own-ef", choices=["gated", "ride", "inline", "xgate"], default="xgate",
-                    help="inorder replay. xgate (default; 1-bit, all-gather pattern, native exchange - otherwise it behaves as ride): ONE launch per "
-                         "layer with the collective IN the path - the reconstruction workgroups are launched with the compress group, pull their "
-                         "state tiles into registers and wait for a gate the exchange stream sets after ncclAllGather "
-                         "(cfx_plan_add_exchange_layer).  gated (1-bit, no collective between compress and reconstruction, i.e. N = 1): ONE launch per layer - "
-                         "the reconstruction of everything whose packet the layer's compress produces (own error feedback + looped-back peers) "
-                         "runs in the compress launch behind an arrival gate (cfx_compress_batch_gated); with a collective in between it "
-                         "behaves as ride.  ride: the own error-feedback update rides in the NEXT layer's compress launch, two launches "
-                         "per layer.  inline: it sits in the same layer's reconstruction launch (16 tensors per launch)")
-    ap.add_argument("--exchange-stream", choices=["main", "side", "prio"], default="prio",
-                    help="N > 1, pipelined replay only: 'main' issues every all-gather in order on the compute stream; 'side' / 'prio' "
-                         "(prioritised stream) issue it on an exchange stream one unit ahead, underneath the next fused launch")
-    ap.add_argument("--gather-group", type=int, default=0,
-                    help="N > 1, native exchange: layers (1..7) whose packets travel in ONE all-gather; 0 = 1 for the in-order replay "
-                         "(a model has one layer's packets at a time), 7 for the pipelined replay")
-    ap.add_argument("--codec", choices=["binary", "int2"], default="binary",
-                    help="binary (default, the judged workload: BASELINE.json configs[2]); int2 = the reference's other fused preset "
-                         "(examples/configs.py:51-61), in-order replay only, reported as a secondary line")
-    ap.add_argument("--no-collective", action="store_true",
-                    help="N = 1 debug: build the step WITHOUT the collective between compress and reconstruction (the codec launches alone; "
-                         "--own-ef gated needs it: one launch per layer only exists when nothing sits between the two)")
-    ap.add_argument("--emulate-live", type=int, default=0,
-                    help="N = 1 debug: lay the exchange out for this many live ranks (2..8) over a LOOP-BACK collective library (--rccl-lib: "
-                         "tests/fake_rccl in loopback mode, every peer is this rank) - exercises the N > 1 plans, the raw baseline and the "
-                         "xgmi object on one GPU; the figures are not link measurements")
-    ap.add_argument("--rccl-lib", default=None, help="debug: collective library to load instead of the RCCL the process already uses")
-    ap.add_argument("--no-raw-baseline", action="store_true", help="N > 1: skip the uncompressed all-gather legs")
-    ap.add_argument("--overlap-steps", type=int, default=12,
-                    help="N = 1: after the timed legs, also run SURVEY 8d protocol 2 for this many steps (tools/overlap_bench.py in-process: compact_fwd "
-                         "on the exchange lane beside real SDPA attention, 8 logical ranks looped back) and carry its exposed-exchange figure; 0 = skip")
-    ap.add_argument("--plugin-steps", type=int, default=40,
-                    help="N = 1: steps of the plugin_path leg (tools/plugin_path_bench.py as a child process: the same step through compact_all_gather_kv / "
-                         "compact_fwd with a no-op attention); 0 = skip")
-    ap.add_argument("--no-config-table", action="store_true", help="N = 1: skip the per-BASELINE-configuration table (`configs`)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with events")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the long run and the pipelined upper-bound leg")
-    ap.add_argument("--long-steps", type=int, default=200, help="steps of the long timed leg that follows the contract's K steps")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--backend", default="nccl", help="debug: 'gloo' lets several ranks share one GPU to exercise the N>1 path")
-    ap.add_argument("--same-gpu", action="store_true", help="debug: every rank uses cuda:0")
-    ap.add_argument("--p2p", choices=["auto", "off"], default="auto",
-                    help="--own-ef xgate, every N: auto (default) = no collective at all - every rank's packets stay in IPC-shared memory and the peers' "
-                         "reconstruction workgroups read them in place (cfx_plan_add_exchange_layer_p2p; single node; no live peer at N = 1); "
-                         "off = ncclAllGather between a flag-wait and a flag-set kernel on the exchange stream")
-    ap.add_argument("--dist-path", action="store_true",
-                    help="debug: take the N>1 code path (per-layer collectives) even with one rank, to measure its host overhead")
-    ap.add_argument("--exchange", choices=["native", "torch"], default="native",
-                    help="N>1: who issues the per-layer all-gather - libcfx's own RCCL communicator from the native plan "
-                         "(one host call per step) or torch.distributed (one Python call per layer)")
-    ap.add_argument("--exchange-pattern", choices=["allgather", "relay"], default="allgather",
-                    help="N>1, in-order replay: one direct all-gather per layer (default; xGMI is a point-to-point mesh) or the "
-                         "reference's ring relay (W-1 grouped send/recv hops per layer, xfuser/compact/ring.py:193-195)")
-    ap.add_argument("--allow-fallback", action="store_true",
-                    help="(kept for old command lines; a multi-rank run now ALWAYS falls back in-process - p2p -> ncclAllGather in stream order -> "
-                         "torch.distributed per layer - instead of exiting non-zero, and records it in `schedule_fallback`)")
-    ap.add_argument("--poison-after-step", type=int, default=-1,
-                    help="debug (N > 1, p2p): after this step rank 0 corrupts one reconstructed state - what a stale cache line would leave - to "
-                         "exercise validate-then-fall-back")
-    ap.add_argument("--copy-probe", type=int, default=0,
-                    help="also launch the 96 MiB float4 copy probe this many times before the timed region "
-                         "(known byte count: calibrates FETCH_SIZE / WRITE_SIZE in PMC profiles)")
-    ap.add_argument("--no-copy-rate", action="store_true",
-                    help="skip the copy-bandwidth measurement behind roofline.achievable_gbs (eight 96 MiB copy launches before the warm-up)")
-    ap.add_argument("--print-config-key", action="store_true",
-                    help="print the configuration key profile summaries are matched against (tools/collect_profiles.sh) and exit")
-    ap.add_argument("--event-stride", type=int, default=29,
-                    help="bracket every k-th launch of the profiled kernels with hipEvents (an event pair costs a few us of stream time)")
-    return ap.parse_args()
-
-
-def cpu_baseline(seconds: float, codec: str = "binary"):
-    """C oracle on the host cores: one layer of the workload = 2 compress + 14 decompress at (544, 3072)."""
-    import numpy as np
-    from oracle import c_oracle as CO
-    N, C = N_TOK, C_CH
-    rng = np.random.default_rng(0)
-    base = rng.standard_normal((N, C)).astype(np.float16)
-    xs = [(base.astype(np.float32) + 0.1 * rng.standard_normal((N, C)).astype(np.float32)).astype(np.float16) for _ in range(2)]
-    own = [base.copy().view(np.uint16) for _ in range(2)]
-    peers = [base.copy().view(np.uint16) for _ in range(14)]
-    pk = [np.zeros(CO.load().oracle_packet_bytes(1 if codec == "binary" else 2, N, C, 0) // 2, dtype=np.uint16) for _ in range(2)]
-    def one_layer():
-        for i in range(2):
-            CO.compress(codec, xs[i], own[i], N, C, packet=pk[i], new_base=own[i])
-        for j in range(14):
-            CO.decompress(codec, pk[j % 2], peers[j], N, C, out=peers[j])
-
-    one_layer()                                       # warm up (tables, threads, page faults)
-    # The baseline is the CPU's BEST: the fastest thread count of a short sweep (a box may report more hardware threads than it schedules
-    # for us - 128 reported threads measured 3.6x slower than 64 on the round-4 box); the all-threads figure is carried beside it.
-    most = int(CO.num_threads())
-
-    def timed_run(threads, budget):
-        CO.set_num_threads(threads)
-        one_layer()
-        t0 = time.perf_counter()
-        reps = 0
-        while True:
-            one_layer()
-            reps += 1
-            dt = time.perf_counter() - t0
-            if dt >= budget or reps >= 2000:
-                break
-        return reps, dt
-
-    def rate(reps, dt):
-        return round(reps * 16 * N * C * 2 / dt / 1e9, 4)
-    reps_all, dt_all = timed_run(most, seconds * 0.4)
-    best_t, best = most, dt_all / reps_all
-    for t in sorted({c for c in (4, 8, 16, 32, 64, 128, 256) if c < most}):
-        CO.set_num_threads(t)
-        one_layer()
-        t0 = time.perf_counter()
-        one_layer()
-        dt1 = time.perf_counter() - t0
-        if dt1 < best:
-            best, best_t = dt1, t
-    reps, dt = (reps_all, dt_all) if best_t == most else timed_run(best_t, seconds * 0.6)
-    if best_t != most and rate(reps, dt) < rate(reps_all, dt_all):      # (the sweep's single-shot pick did not hold up over the longer run)
-        best_t, reps, dt = most, reps_all, dt_all
-    CO.set_num_threads(most)
-    return {"value": rate(reps, dt), "unit": "GB/s", "cores": best_t, "kind": "port",
-            "all_threads": {"value": rate(reps_all, dt_all), "cores": most},
-            "sample": f"{reps} x one layer of the workload (2 compress + 14 decompress, {'1-bit' if codec == 'binary' else '2-bit'}, (544,3072) fp16) in {dt:.1f} s, "
-                      f"C oracle oracle/cfx_oracle.c with OpenMP on {best_t} threads = the fastest of a sweep over 4 .. {most} (the box reports {most} hardware threads; "
-                      f"`all_threads` = the same on all of them) "
-                      f"({'F16C conversions' if CO.load().oracle_uses_f16c() else 'software fp16 conversions'}); GB/s of fp16 activations through the codec"}
-
-
-def measure_copy_rate(lib, ctx, dev, stream_handle, reps=6):
-    """What this box's HBM sustains on a plain copy (the roofline fraction is quoted against the 8 TB/s spec AND against
-    this): the 96 MiB float4 copy probe of libcfx (read 96 MiB + write 96 MiB per launch, four buffer pairs in turn: 768 MiB, past the
-    Infinity Cache), hipEvents on the launch stream around groups of four launches after a warm-up group; the median group."""
-    import torch
-    nb = 96 * 1024 * 1024
-    src = [torch.empty(nb, dtype=torch.uint8, device=dev).random_(0, 255) for _ in range(4)]
-    dst = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(4)]
-    st = torch.cuda.ExternalStream(stream_handle, device=dev)
-    ev = []
-    for g_ in range(reps + 1):                     # groups of four back-to-back launches (an event pair around ONE launch adds the launch gap)
-        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a_.record(st)
-        for i in range(4):
-            if lib.cfx_copy_probe(ctx, dst[i].data_ptr(), src[i].data_ptr(), nb, stream_handle) != 0:
-                return None
-        b_.record(st)
-        ev.append((a_, b_))
-    torch.cuda.synchronize(dev)
-    us = sorted(a_.elapsed_time(b_) * 1e3 / 4 for a_, b_ in ev[1:])
-    del src, dst
-    med = us[len(us) // 2]
-    return {"achievable_gbs": round(2 * nb / (med * 1e-6) / 1e9, 1), "copy_probe_us": round(med, 2), "copy_probe_launches": 4 * reps,
-            "copy_probe": "k_copy_probe: 96 MiB read + 96 MiB written per launch (16 B per lane), four buffer pairs back to back between two "
-                          "hipEvents, median group / 4"}
-
-
-def group_recv_offset(l: int, r: int, kv: int, G: int, L: int, live: int, slot: int) -> int:
-    """Byte offset of rank r's packet (kv = 0: K, 1: V) of layer l in the grouped receive buffer.
-
-    Layers travel G at a time: group g = layers [a, b) = [gG, min(L, gG + G)).  One all-gather per group sends
-    send[a:b] = [layer][K|V][slot] (contiguous, (b-a)*2*slot bytes per rank) and receives [rank][layer in group][K|V][slot];
-    the groups' receive regions follow each other, so the region of group g starts after a*live*2*slot bytes."""
-    a = (l // G) * G
-    b = min(L, a + G)
-    return (a * live * 2 + (r * (b - a) + (l - a)) * 2 + kv) * slot
-
-
-def config_key(args, n_gpus):
-    """What a committed profile must have been taken with for its figures to be quoted beside this run's."""
-    pipelined = args.replay == "pipelined"
-    own_ef = args.own_ef
-    if own_ef == "xgate" and ((args.codec != "binary" and args.p2p != "auto") or args.no_collective or args.exchange != "native" or args.exchange_pattern == "relay"):
-        own_ef = "ride"
-    return {"codec": args.codec, "replay": args.replay, "own_ef": own_ef if not pipelined else None, "layers": args.layers,
-            "shard": [N_TOK, C_CH], "rows": args.rows, "n_gpus": n_gpus, "collective": not args.no_collective,
-            "p2p": (args.p2p if (own_ef == "xgate" and not args.emulate_live) else None)}
+from benchlib import report, runner, schedules          # noqa: E402
+from benchlib.workload import HBM_PEAK_GBS, config_key, measure_copy_rate, parse, setup          # noqa: E402
 
 
 def main():
-    # Map of this function (one process per GPU; everything below the workload is closures over it):
-    #   1  set-up: ranks, the synthetic workload resident in HBM (warm_state / reset_state), packet buffers, the context's switches
-    #   2  schedules: add_layer / build_plans (N = 1 forms), build_step_plans (N > 1: peer-to-peer layer op, collective in the path, relay)
-    #   3  one_step / sync_all, states_consistent / validate / fall_back - the N > 1 safety net: validate after warm-up AND after the timed
-    #      region, on any failure every rank drops to the next schedule (p2p -> two launches around ncclAllGather -> torch.distributed)
-    #   4  warm-up, the timed region (barrier + synchronize on both sides, MAX over ranks), kernel-event sampling for `roofline`
-    #   5  secondary legs of THIS process (long run, the other schedules, the raw uncompressed exchange at N > 1), `xgmi`, `roofline`
-    #      (+ committed profiles quoted only on a matching configuration key and source hash), `cpu_baseline` + the oracle spot check
-    #   6  tear-down, then tools/bench_secondary.py: protocol 2 beside attention, the plugin path, every BASELINE config, low-rank presets
+    # One process per GPU.  The four parts (tools/benchlib/):
+    #   workload.py   (a) ranks, the synthetic workload resident in HBM, packet buffers, the context's switches          setup()
+    #   schedules.py  (b) the plans: N = 1 forms, the step with the collective in it, the peer-to-peer exchange layer     decide / build_* / setup_exchange
+    #   safety.py     (c) states_consistent / validate / the fall-back ladder - the N > 1 safety net                     (applied by runner.py)
+    #   report.py     (d) the JSON line: value, schedules, xgmi, roofline (+ committed profiles), cpu_baseline + the oracle spot check
+    # then tools/bench_secondary.py: protocol 2 beside attention, the plugin path, every BASELINE config, the presets
     args = parse()
     if args.print_config_key:
         print(json.dumps(config_key(args, args.gpus)))
@@ -288,993 +91,59 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    if args.same_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE {world}"
-    real_live = world                  # ranks that really exist (processes / GPUs)
-    if args.emulate_live:
-        assert world == 1 and 2 <= args.emulate_live <= W_LOGICAL and args.rccl_lib, "--emulate-live needs one process and --rccl-lib (a loop-back library)"
-        os.environ["CFX_FAKE_RCCL_MODE"] = "loopback"
-    live = args.emulate_live or world  # ranks the exchange is LAID OUT for (= real_live unless --emulate-live)
-    assert live <= W_LOGICAL
-    pipelined = args.replay == "pipelined"
-    int2 = args.codec == "int2"
-    if int2 and pipelined:
-        raise SystemExit("--codec int2 runs the in-order replay only (the cross-layer pipeline is 1-bit only)")
-    global ALG_BYTES_PER_EL
-    ALG_BYTES_PER_EL = ALG_BYTES[args.codec]
-    G = args.gather_group if args.gather_group > 0 else (7 if pipelined else 1)
-    G = max(1, min(7, G))
-
-    relay = args.exchange_pattern == "relay"
-    if relay and (pipelined or G != 1):
-        raise SystemExit("--exchange-pattern relay is an in-order, one-layer-per-exchange schedule")
-
-    from compactfusion_amd import _lib, codecs as K
-    lib = _lib.load()
-    ctx = K.context(local_rank)
-    if args.rows:
-        K.set_rows_per_tile(args.rows, local_rank)
-    if args.stats_rows:
-        assert lib.cfx_set_stats_rows(ctx, args.stats_rows) == 0
-    if args.ipc_memory != 2:
-        assert lib.cfx_set_ipc_memory_kind(ctx, args.ipc_memory) == 0
-
-    L, N, C = args.layers, N_TOK, C_CH
-    CODEC = int(K.Codec.INT2 if int2 else K.Codec.BINARY)
-    pkt_bytes = K.packet_bytes(CODEC, N, C)
-    slot = (pkt_bytes + 255) // 256 * 256          # per-tensor slot in the exchange buffer, 256-B aligned
-    # ---- resident state and inputs --------------------------------------------------------------------------
-    def warm_state(src_rank):
-        """x_0 of rank `src_rank` (what a WARMUP step leaves in every rank's cache for that rank's shard)."""
-        gg = torch.Generator(device=dev).manual_seed(1234 + src_rank)
-        return gg, torch.randn(L, 2, N, C, generator=gg, device=dev, dtype=torch.float32).half()
-
-    g, x0 = warm_state(rank)
-    xs = [(x0.float() + 0.1 * torch.randn(L, 2, N, C, generator=g, device=dev)).half() for _ in range(2)]
-    own_base = torch.empty_like(x0)                                          # [L,2,N,C] sender EF state
-    peer_base = torch.empty(L, W_LOGICAL - 1, 2, N, C, dtype=torch.float16, device=dev)   # receiver states
-    del x0
-
-    def reset_state():
-        """State as a WARMUP step leaves it: every rank holds x_0 of every shard it tracks."""
-        x0_ = warm_state(rank)[1]
-        own_base.copy_(x0_)
-        for p in range(W_LOGICAL - 1):
-            if real_live > 1 and p < real_live - 1:
-                peer_base[:, p] = warm_state((rank + 1 + p) % real_live)[1]      # a real peer: its own x_0
-            else:
-                peer_base[:, p] = x0_                                       # looped-back logical peer
-    reset_state()
-    send = torch.zeros(L, 2, slot, dtype=torch.uint8, device=dev)           # own packets (K,V) per layer
-    # the collective sits in the path at EVERY N (N = 1: a one-rank RCCL communicator - what N = 8 executes minus the wire)
-    use_dist = not args.no_collective
-    if args.own_ef == "gated" and use_dist and not pipelined:
-        raise SystemExit("--own-ef gated (one launch per layer) only exists without a collective between compress and reconstruction: add --no-collective")
-    recv = torch.zeros(L, live, 2, slot, dtype=torch.uint8, device=dev) if (use_dist and real_live > 1) else None
-    grecv = torch.zeros(L * live * 2 * slot, dtype=torch.uint8, device=dev) if use_dist else None   # grouped receive regions
-    ws_bytes = lib.cfx_workspace_bytes(CODEC, N, C, 0, 2)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-
-    def own_pkt_ptr(l, kv, gathered):
-        """Where the rank's own packet of layer l is written: with a collective, straight into ITS slot of the gather buffer - the
-        all-gather is then in place (no local copy; with one live rank RCCL has nothing to move at all)."""
-        if gathered:
-            return grecv.data_ptr() + group_recv_offset(l, rank, kv, G, L, live, slot)
-        return send[l, kv].data_ptr()
-
-    def peer_packet_ptr(l, p, kv, gathered):
-        """Packet of logical peer p for layer l: a real rank's slot of the gathered buffer, or (looped-back peer) our own packet
-        - taken from OUR slot of the gathered buffer when there is one, so a collective's result is consumed even with one live rank."""
-        if gathered:
-            real = live > 1 and p < live - 1
-            r = (rank + 1 + p) % live if real else rank          # a looped-back peer reads OUR slot (the compress launch wrote it there)
-            return grecv.data_ptr() + group_recv_offset(l, r, kv, G, L, live, slot)
-        if real_live > 1 and p < real_live - 1:
-            return recv[l, (rank + 1 + p) % real_live, kv].data_ptr()
-        return send[l, kv].data_ptr()
-
-    def comp_items(s_, l, gathered=False):
-        carr = (_lib.CompItem * 2)()
-        for kv in range(2):
-            carr[kv] = _lib.CompItem(xs[s_][l, kv].data_ptr(), own_base[l, kv].data_ptr(), None, own_pkt_ptr(l, kv, gathered))
-        return carr
-
-    def own_ef_items(l, gathered=False):
-        return [_lib.DecompItem(own_pkt_ptr(l, kv, gathered), own_base[l, kv].data_ptr(), own_base[l, kv].data_ptr()) for kv in range(2)]
-
-    def peer_items(l, gathered):
-        return [_lib.DecompItem(peer_packet_ptr(l, p, kv, gathered), peer_base[l, p, kv].data_ptr(), peer_base[l, p, kv].data_ptr())
-                for p in range(W_LOGICAL - 1) for kv in range(2)]
-
-    def add_layer(plan, s_, l, ride, gathered, comm=None, gated=False, relay_=None, xlayer=False):
-        relay_ = relay if relay_ is None else relay_
-        if xlayer:
-            # ONE op: compress + own EF ; all-gather ; reconstruct 14 - the reconstruction group launched with the compress group,
-            # gated on the collective's arrival (cfx_plan_add_exchange_layer)
-            assert gathered
-            carr = comp_items(s_, l, True)
-            for kv in range(2):
-                carr[kv].new_base = own_base[l, kv].data_ptr()
-            items = peer_items(l, True)
-            rc = lib.cfx_plan_add_exchange_layer(plan, CODEC, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, carr, len(items), (_lib.DecompItem * len(items))(*items),
-                                                 comm, own_pkt_ptr(l, 0, True), grecv.data_ptr() + l * live * 2 * slot, 2 * slot, ws.data_ptr(), ws_bytes)
-            assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
-            return
-        """Layer l of the in-order schedule: A = compress (+ previous layer's own EF riding along), X = all-gather, B = reconstruct;
-        gated (no X): one launch = A + the 16 reconstructions behind the arrival gate."""
-        if gated:
-            assert comm is None and not gathered
-            # CFX_FLAG_UPDATE_CACHE = the rank's own error feedback in the same launch (1-bit: two more gated reconstructions; 2-bit:
-            # the statistics workgroups quantise their own tiles from registers); the gated items are the 7 looped-back peers' K,V
-            carr = comp_items(s_, l)
-            for kv in range(2):
-                carr[kv].new_base = own_base[l, kv].data_ptr()
-            items = peer_items(l, False)
-            rc = lib.cfx_plan_add_compress_gated(plan, CODEC, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, carr, 0, None, len(items),
-                                                 (_lib.DecompItem * len(items))(*items), ws.data_ptr(), ws_bytes)
-            assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
-            return
-        if int2:
-            # 2-bit: the codes depend on the scales, so compress = statistics + in-launch finalize, then quantise + error feedback
-            # (in place on the rank's own state); the reconstruction launch carries the 7 peers' K,V
-            carr = comp_items(s_, l, gathered)
-            for kv in range(2):
-                carr[kv].new_base = own_base[l, kv].data_ptr()
-            rc = lib.cfx_plan_add_compress(plan, CODEC, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, carr, ws.data_ptr(), ws_bytes)
-            assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
-            if comm is not None:
-                assert lib.cfx_plan_add_all_gather(plan, comm, own_pkt_ptr(l, 0, True), grecv.data_ptr() + l * live * 2 * slot, 2 * slot) >= 0
-            items = peer_items(l, gathered)
-            assert lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, len(items), (_lib.DecompItem * len(items))(*items)) >= 0
-            return
-        if ride and l > 0:
-            rd = (_lib.DecompItem * 2)(*own_ef_items(l - 1, gathered))
-            rc = lib.cfx_plan_add_compress_ex(plan, CODEC, N, C, 0, 0, 2, comp_items(s_, l, gathered), 2, rd, ws.data_ptr(), ws_bytes)
-        else:
-            rc = lib.cfx_plan_add_compress(plan, CODEC, N, C, 0, 0, 2, comp_items(s_, l, gathered), ws.data_ptr(), ws_bytes)
-        assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
-        if comm is not None and relay_:
-            # ring relay: hop h moves what arrived at hop h-1 (hop 0: our own packets) to rank+1; after hop h the region
-            # [rank - h - 1] of the layer's receive area holds that rank's K,V packets - the same layout an all-gather leaves
-            base_ptr = grecv.data_ptr() + l * live * 2 * slot
-            src = own_pkt_ptr(l, 0, True)
-            for h in range(live - 1):
-                dst = base_ptr + ((rank - h - 1) % live) * 2 * slot
-                rc = lib.cfx_plan_add_ring_hop(plan, comm, src, dst, 2 * slot)
-                assert rc >= 0, rc
-                src = dst
-        elif comm is not None:
-            rc = lib.cfx_plan_add_all_gather(plan, comm, own_pkt_ptr(l, 0, True), grecv.data_ptr() + l * live * 2 * slot, 2 * slot)
-            assert rc >= 0, rc
-        items = peer_items(l, gathered)
-        if not ride or l == L - 1:
-            items = own_ef_items(l, gathered) + items
-        darr = (_lib.DecompItem * len(items))(*items)
-        rc = lib.cfx_plan_add_decompress(plan, CODEC, N, C, 0, len(items), darr)
-        assert rc >= 0, (rc, lib.cfx_last_error_string(ctx))
-
-    # (2-bit: one launch per layer only in the peer-to-peer form, where the exchange runs inside the launch; beside an exchange stream's kernel
-    # its layer launch is slower than three launches in stream order)
-    xgate = (args.own_ef == "xgate" and not pipelined and (not int2 or args.p2p == "auto") and use_dist and not relay and args.exchange == "native")
-    if args.own_ef == "xgate" and not xgate:
-        args.own_ef = "ride"
-    ride = args.own_ef in ("ride", "gated")
-    gated = args.own_ef == "gated" and not pipelined and not use_dist
-    one_launch = gated or xgate
-    # ---- native plans without collectives (one per input set) -----------------------------------------------------------------
-    #   inorder:   per layer  A(l) [+ EF(l-1)] ; B(l)                        (ops 2l, 2l+1)
-    #   pipelined: per layer  compress(l) ; reconstruct own + peers (16)     (the op pattern cfx_plan_run_pipelined recognises)
-    #   gated:     per layer  ONE launch: A(l) + own EF(l) + B(l) behind the gate (op l)
-    def build_plans(kind):
-        built = []
-        for s_ in range(2):
-            plan = lib.cfx_plan_create(ctx)
-            for l in range(L):
-                add_layer(plan, s_, l, ride if kind == "inorder" else False, False, gated=(kind == "gated"))
-            assert lib.cfx_plan_finalize(plan) == 0
-            built.append(plan)
-        return built
-    plans_inorder = build_plans("inorder")
-    plans_pipe = None if int2 else build_plans("pipelined")
-    plans_gated = build_plans("gated") if (gated or (real_live == 1 and not args.emulate_live and not pipelined and not args.no_secondary)) else None
-    plans = plans_pipe if pipelined else (plans_gated if gated else plans_inorder)
-
-    xside = None
-    if xgate:
-        # the exchange-layer op orders its two streams by flag words: the run stream must not be the legacy NULL stream (it serialises
-        # with every blocking stream, the CU-masked exchange stream included)
-        if args.same_gpu and world > 1:
-            # debug: the ranks share one GPU - a waiting layer launch of one rank must not hold the CUs another rank's compress group needs
-            hm = ctypes.c_void_p()
-            share = 256 // world
-            assert lib.cfx_stream_create_masked(ctx, share * rank, share, ctypes.byref(hm)) == 0
-            torch.cuda.set_stream(torch.cuda.ExternalStream(hm.value, device=dev))
-        else:
-            torch.cuda.set_stream(torch.cuda.Stream(dev))
-        hx = ctypes.c_void_p()
-        assert lib.cfx_stream_create_masked(ctx, 0, 256, ctypes.byref(hx)) == 0      # ONE exchange stream for every plan: each stream is a hardware queue
-        xside = hx.value
-    compute = torch.cuda.current_stream(dev)
-    sh = compute.cuda_stream
-
-    # ---- N > 1: the whole step as ONE native plan, the all-gathers issued by libcfx's own RCCL communicator -----------------
-    #   inorder:   A(l) ; all-gather(l) ; B(l)   layer by layer, everything in order on the compute stream
-    #   pipelined: --gather-group layers share one all-gather and form one unit of the pipelined replay; --exchange-stream
-    #              prio|side runs the collective of unit u on an exchange stream underneath the next fused launch
-    native_comm, step_plans, exchange_mode, stream_mode, build_step_plans = None, None, "none", 0, None
-    setup_fallback = None
-    p2p_ptr, p2p_peer = None, {}
-    if use_dist:
-        exchange_mode = "torch"
-        if args.exchange == "torch" and world == 1:
-            raise SystemExit("--exchange torch needs N > 1 (torch.distributed is not initialised for one rank)")
-        if args.exchange == "native":
-            try:
-                from compactfusion_amd.exchange import NativeComm
-                try:
-                    native_comm = NativeComm(local_rank, solo_ranks=live if world == 1 else 0, library=args.rccl_lib)
-                    if not args.emulate_live:
-                        native_comm.self_test()
-                except Exception as e_comm:
-                    # --same-gpu (debug): RCCL refuses two ranks on one device; the peer-to-peer exchange needs no collective library
-                    if not (args.same_gpu and world > 1 and xgate and args.p2p == "auto"):
-                        raise
-                    native_comm = None
-                    if rank == 0:
-                        print(f"[bench] no collective library here ({e_comm}); peer-to-peer exchange only, raw-exchange legs skipped", file=sys.stderr)
-                groups = [(a, min(L, a + G)) for a in range(0, L, G)]
-
-                def build_step_plans(mode, relay_=None, xlayer=None, comm_=True, side_=None):
-                    xlayer = (xgate if xlayer is None else xlayer) and not (relay if relay_ is None else relay_)
-                    side_ = side_ or xside
-                    built = []
-                    for s_ in range(2):
-                        sp = lib.cfx_plan_create(ctx)
-                        if xlayer and side_:
-                            assert lib.cfx_plan_use_exchange_stream(sp, side_) == 0
-                        elif not xlayer:
-                            assert lib.cfx_plan_set_exchange_stream(sp, mode) == 0
-                        if not pipelined:
-                            for l in range(L):
-                                add_layer(sp, s_, l, ride or xgate, True, native_comm.handle if comm_ else None, relay_=relay_,
-                                          xlayer=xlayer)
-                        else:
-                            for a, b in groups:
-                                for l in range(a, b):
-                                    assert lib.cfx_plan_add_compress(sp, CODEC, N, C, 0, 0, 2, comp_items(s_, l, True), ws.data_ptr(), ws_bytes) >= 0
-                                rcx = lib.cfx_plan_add_all_gather(sp, native_comm.handle, own_pkt_ptr(a, 0, True),
-                                                                  grecv.data_ptr() + a * live * 2 * slot, (b - a) * 2 * slot)
-                                assert rcx >= 0, rcx
-                                for l in range(a, b):
-                                    items = own_ef_items(l, True) + peer_items(l, True)
-                                    assert lib.cfx_plan_add_decompress(sp, CODEC, N, C, 0, 16, (_lib.DecompItem * 16)(*items)) >= 0
-                        assert lib.cfx_plan_finalize(sp) == 0
-                        built.append(sp)
-                    return built
-                stream_mode = {"main": 0, "side": 1, "prio": 2}[args.exchange_stream] if pipelined else 0
-                if native_comm is not None:
-                    step_plans = build_step_plans(stream_mode)
-                    exchange_mode = "native"
-                if xgate and args.p2p == "auto" and not args.emulate_live:
-                    # ---- no collective at all: packets stay in IPC-shared memory, the peers read them in place ---------------------------
-                    flags_off = L * 2 * slot
-                    p2p_ptr, p2p_handle = ctypes.c_void_p(), ctypes.create_string_buffer(64)
-                    check_rc = lib.cfx_ipc_alloc(ctx, flags_off + 2 * L * 64, ctypes.byref(p2p_ptr), p2p_handle)
-                    ok_all = torch.tensor([1 if check_rc == 0 else 0], device=dev, dtype=torch.int32)
-                    if world > 1:
-                        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
-                    if int(ok_all.item()) == 1:
-                        handles = [bytes(p2p_handle.raw)]
-                        if world > 1:
-                            handles = [None] * world
-                            dist.all_gather_object(handles, bytes(p2p_handle.raw))
-                        p2p_peer = {}
-                        opened = 1
-                        for q in range(world):
-                            if q != rank:
-                                pq = ctypes.c_void_p()
-                                if lib.cfx_ipc_open(ctx, handles[q], ctypes.byref(pq)) != 0:
-                                    opened = 0
-                                    break
-                                p2p_peer[q] = pq.value
-                        ok_all = torch.tensor([opened], device=dev, dtype=torch.int32)
-                        if world > 1:
-                            dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
-                    if int(ok_all.item()) == 1:
-                        def build_p2p_plans():
-                            built = []
-                            for s_ in range(2):
-                                sp = lib.cfx_plan_create(ctx)
-                                assert lib.cfx_plan_use_exchange_stream(sp, xside) == 0
-                                for l in range(L):
-                                    carr = (_lib.CompItem * 2)()
-                                    for kv in range(2):
-                                        carr[kv] = _lib.CompItem(xs[s_][l, kv].data_ptr(), own_base[l, kv].data_ptr(), own_base[l, kv].data_ptr(),
-                                                                 p2p_ptr.value + (l * 2 + kv) * slot)
-                                    items = []
-                                    for p in range(W_LOGICAL - 1):
-                                        real = p < world - 1
-                                        src = p2p_peer[(rank + 1 + p) % world] if real else p2p_ptr.value        # a looped-back logical peer reads OUR packets
-                                        for kv in range(2):
-                                            items.append(_lib.DecompItem(src + (l * 2 + kv) * slot, peer_base[l, p, kv].data_ptr(), peer_base[l, p, kv].data_ptr()))
-                                    pf = (ctypes.c_void_p * max(1, world - 1))(*[p2p_peer[q] + flags_off + (s_ * L + l) * 64 for q in sorted(p2p_peer)])
-                                    rc_ = lib.cfx_plan_add_exchange_layer_p2p(sp, CODEC, N, C, 0, _lib.FLAG_UPDATE_CACHE, 2, carr, len(items),
-                                                                              (_lib.DecompItem * len(items))(*items), p2p_ptr.value + flags_off + (s_ * L + l) * 64,
-                                                                              world - 1, pf, ws.data_ptr(), ws_bytes)
-                                    assert rc_ >= 0, (rc_, lib.cfx_last_error_string(ctx))
-                                assert lib.cfx_plan_finalize(sp) == 0
-                                built.append(sp)
-                            return built
-                        for pl_ in (step_plans or []):
-                            lib.cfx_plan_destroy(pl_)
-                        step_plans = build_p2p_plans()
-                        exchange_mode = "p2p"
-                    elif rank == 0:
-                        print("[bench] IPC-shared packet buffers unavailable; the collective stays in the path (ncclAllGather on the exchange stream)", file=sys.stderr)
-            except Exception as e:  # pragma: no cover
-                if world == 1:
-                    raise SystemExit(f"[bench] native exchange unavailable ({e})")
-                # never end a multi-rank run while a collective fall-back exists: torch.distributed per layer (the line says so)
-                print(f"[bench] native exchange unavailable ({e}); FALLBACK to torch.distributed per layer", file=sys.stderr)
-                native_comm, step_plans, exchange_mode = None, None, "torch"
-                setup_fallback = f"the native exchange could not be set up ({e}); torch.distributed per layer instead"
-
-    def check(rc, what):
-        if rc != 0:
-            raise RuntimeError(f"{what}: rc={rc} {lib.cfx_last_error_string(ctx)}")
-
-    run_native = lib.cfx_plan_run_pipelined if pipelined else lib.cfx_plan_run
-
-    def one_step(step):
-        plan = plans[step & 1]
-        if not use_dist:
-            check(run_native(plan, 0, lib.cfx_plan_size(plan), sh), "plan_run")     # the whole step from native code
-            return
-        if step_plans is not None:
-            sp = step_plans[step & 1]
-            check(run_native(sp, 0, lib.cfx_plan_size(sp), sh), "plan_run(exchange)")
-            return
-        # torch.distributed per layer (fallback / --exchange torch): layer by layer in order
-        pl = plans_inorder[step & 1]
-        for l in range(L):
-            check(lib.cfx_plan_run(pl, 2 * l, 1, sh), "compress")
-            dist.all_gather_into_tensor(recv[l].view(-1), send[l].view(-1))
-            check(lib.cfx_plan_run(pl, 2 * l + 1, 1, sh), "reconstruct")
-
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    copy_rate = None
-    if real_live == 1 and not args.emulate_live and not args.no_copy_rate:
-        copy_rate = measure_copy_rate(lib, ctx, dev, sh)
+    S = setup(args)                               # (a)
+    schedules.decide(S)                           # (b)
+    schedules.build_local_plans(S)
+    schedules.setup_streams(S)
+    schedules.setup_exchange(S)
+    torch = S.torch
+    S.copy_rate = None
+    if S.real_live == 1 and not args.emulate_live and not args.no_copy_rate:
+        S.copy_rate = measure_copy_rate(S.lib, S.ctx, S.dev, S.sh)
     if args.copy_probe:
         nb = 96 * 1024 * 1024
-        src = [torch.empty(nb, dtype=torch.uint8, device=dev).random_(0, 255) for _ in range(4)]
-        dst = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(4)]
+        src = [torch.empty(nb, dtype=torch.uint8, device=S.dev).random_(0, 255) for _ in range(4)]
+        dst = [torch.empty(nb, dtype=torch.uint8, device=S.dev) for _ in range(4)]
         for i in range(args.copy_probe):
-            check(lib.cfx_copy_probe(ctx, dst[i % 4].data_ptr(), src[i % 4].data_ptr(), nb, sh), "copy_probe")
-        torch.cuda.synchronize(dev)
+            S.check(S.lib.cfx_copy_probe(S.ctx, dst[i % 4].data_ptr(), src[i % 4].data_ptr(), nb, S.sh), "copy_probe")
+        torch.cuda.synchronize(S.dev)
         del src, dst
-
-    def states_consistent():
-        """What a rank holds for its own shard must be, bit for bit, what every peer reconstructed for that shard."""
-        torch.cuda.synchronize(dev)
-        # sampled over layers that sit at different positions of an all-gather group, K and V
-        samples = sorted({(l, kv) for l in (0, 1, min(L - 1, G - 1), L // 2, L - 1) for kv in (0, 1) if l < L})
-        if real_live == 1:
-            same = all(torch.equal(own_base[l, kv].view(torch.int16), peer_base[l, p, kv].view(torch.int16))
-                       for l, kv in samples for p in range(W_LOGICAL - 1))
-            return same, "EF state of a looped-back peer diverged from the sender's"
-        good = torch.ones(1, dtype=torch.int32, device=dev)
-        for l, kv in samples:
-            mine = own_base[l, kv].reshape(-1)[:8192].view(torch.int32).contiguous()       # int32: a dtype every backend moves
-            allm = torch.empty(live * 4096, dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(allm, mine)
-            for p in range(live - 1):
-                src = (rank + 1 + p) % live
-                got = peer_base[l, p, kv].reshape(-1)[:8192].view(torch.int32)
-                if not torch.equal(got, allm[src * 4096:(src + 1) * 4096]):
-                    good.zero_()
-        dist.all_reduce(good, op=dist.ReduceOp.MIN)
-        return bool(good.item()), f"rank {rank}: a peer's reconstructed state diverged from its owner's"
-
-    steps_run = 0
-    # ---- warm-up, validation, timed region, validation - and, on ANY inconsistency, an in-process fall-back to the next schedule ----------
-    # N > 1: packets are read in place from the peers' memory (p2p) or delivered by a collective kernel that has to find CUs beside the
-    # waiting reconstruction workgroups; neither has ever run here on more than one GPU.  So the run is validated AFTER the warm-up steps
-    # and AGAIN after the timed region (a stale cache line only shows from the second use of an address on): gate time-outs, and every
-    # rank's reconstruction of a shard against its owner's state.  A failed check never ends the run: every rank (the verdict is
-    # all-reduced) resets its states, rebuilds the step as compress ; ncclAllGather ; reconstruct in stream order (libcfx's communicator;
-    # torch.distributed per layer if there is none), and warm-up + timed region run again.  `schedule_fallback` records which check tripped.
-    n_warm = max(args.warmup, 1 if use_dist else 0)
-    schedule_fallback = setup_fallback
-    if exchange_mode == "torch":
-        xgate = one_launch = False
-        args.own_ef = "ride"
-        ride = True
-    KIDS, prof_cap = (), 0
-    poisoned = [False]
-
-    def maybe_poison(step_no):
-        """--poison-after-step (debug): what a stale line in a reader's cache would leave behind - a reconstruction that differs from its
-        owner's state - planted once, while the peer-to-peer schedule runs."""
-        if args.poison_after_step >= 0 and not poisoned[0] and exchange_mode == "p2p" and step_no == args.poison_after_step and rank == 0:
-            torch.cuda.synchronize(dev)
-            peer_base[0, 0, 0].view(torch.int16)[0, :8] += 1
-            poisoned[0] = True
-
-    def validate(label):
-        """None when this rank AND every other rank is fine, else what tripped (the same answer on every rank)."""
-        if not use_dist:
-            return None
-        torch.cuda.synchronize(dev)
-        ge = lib.cfx_gate_errors(ctx)                    # reads and clears the count
-        ok, why = states_consistent()
-        bad = torch.tensor([2 if ge else (0 if ok else 1)], device=dev, dtype=torch.int32)
-        if world > 1:
-            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        code = int(bad.item())
-        if code == 0:
-            return None
-        return label + ": " + ("a gate / flag wait timed out (the packets did not arrive in time)" if code == 2 else
-                               "a reconstructed state differs from its owner's (" + why + ")")
-
-    def fall_back(reason):
-        """Every rank together: the next schedule down.  one launch per layer (p2p or collective in the path) -> two launches per layer around
-        ncclAllGather in stream order -> torch.distributed per layer."""
-        nonlocal schedule_fallback, exchange_mode, xgate, one_launch, ride, step_plans, stream_mode
-        was = ("the peer-to-peer exchange layer (packets read in place through IPC mappings)" if exchange_mode == "p2p" else
-               "the exchange-layer launch around ncclAllGather" if xgate else
-               "two launches per layer around ncclAllGather" if step_plans is not None else "torch.distributed per layer")
-        if rank == 0:
-            print(f"[bench] {was} failed validation ({reason}); falling back in-process", file=sys.stderr)
-        for pl_ in (step_plans or []):
-            lib.cfx_plan_destroy(pl_)
-        step_plans = None
-        if (exchange_mode == "p2p" or xgate or stream_mode != 0) and native_comm is not None:
-            exchange_mode, stream_mode = "native", 0
-            xgate = one_launch = False
-            args.own_ef = "ride"
-            ride = True
-            step_plans = build_step_plans(0, xlayer=False)
-            now = "compress ; ncclAllGather ; reconstruct, two launches per layer in stream order (libcfx's own RCCL communicator)"
-        elif exchange_mode != "torch" and world > 1:
-            exchange_mode = "torch"
-            xgate = one_launch = False
-            args.own_ef = "ride"
-            ride = True
-            now = "compress ; torch.distributed.all_gather_into_tensor ; reconstruct, issued per layer from Python"
-        else:
-            raise SystemExit(f"[bench] {was} failed validation ({reason}) and no schedule is left to fall back to")
-        schedule_fallback = ((schedule_fallback + " ; then " if schedule_fallback else "") + was + " failed validation - " + reason + " - and the run continued as: " + now)
-
-    while True:
-        reset_state()
-        steps_run = 0
-        sync_all()
-        first_short = xgate and live > 1
-        if first_short:
-            lib.cfx_set_gate_timeout_ms(ctx, 300)         # (the ranks enter the first step together: a gate that cannot open gives up quickly)
-        for i in range(n_warm):
-            one_step(i)
-            maybe_poison(i)
-            if i == 0 and first_short:
-                sync_all()
-                lib.cfx_set_gate_timeout_ms(ctx, 5000)
-        steps_run = n_warm
-        sync_all()
-        why_bad = validate("after the warm-up steps")
-        if why_bad is not None:
-            fall_back(why_bad)
-            continue
-        # profiled kernels: in-order replay: k_binary_dequant (4, launch B, dominant) and k_absmean_compress<bits> (27, launch A);
-        # pipelined replay: the fused k_binary_pipe (23: full three-group launches; 24: prologue / epilogue / ragged launches)
-        KIDS = (23, 24) if pipelined else ((31,) if one_launch else ((6, 28, 5) if int2 else (4, 27)))
-        prof_cap = (args.steps * 2 * L) // max(1, args.event_stride) + 64
-        if not args.no_kernel_events:
-            mask = 0
-            for k in KIDS:
-                mask |= 1 << k
-            check(lib.cfx_profile_enable(ctx, prof_cap, mask, args.event_stride), "profile_enable")
-        sync_all()
-        step_events = []          # gated schedule: hipEvents on the launch stream around every 4th step (every launch of a step is the
-        t0 = time.perf_counter()  # same kernel, so elapsed / layers = its average duration with the kernel boundaries in)
-        for i in range(args.steps):
-            if one_launch and not args.no_kernel_events and i % 4 == 1:
-                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ea.record(compute)
-                one_step(steps_run + i)
-                eb.record(compute)
-                step_events.append((ea, eb))
-            else:
-                one_step(steps_run + i)
-            maybe_poison(steps_run + i)
-        sync_all()
-        t1 = time.perf_counter()
-        steps_run += args.steps
-        elapsed = t1 - t0
-        why_bad = validate("after the timed region")
-        if why_bad is not None:
-            if not args.no_kernel_events:
-                ids_ = (ctypes.c_int * prof_cap)()
-                ms_ = (ctypes.c_float * prof_cap)()
-                lib.cfx_profile_read(ctx, ids_, ms_, prof_cap)
-                lib.cfx_profile_enable(ctx, 0, 0, 1)
-            fall_back(why_bad)
-            continue
-        break
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    kern_us = {}
-    if not args.no_kernel_events:
-        ids = (ctypes.c_int * prof_cap)()
-        ms = (ctypes.c_float * prof_cap)()
-        n = lib.cfx_profile_read(ctx, ids, ms, prof_cap)
-        for k in KIDS:
-            vals = [ms[i] * 1e3 for i in range(n) if ids[i] == k and ms[i] > 0]
-            if vals:
-                kern_us[k] = (sum(vals) / len(vals), len(vals))
-        lib.cfx_profile_enable(ctx, 0, 0, 1)
-
-    def timed_leg(n_steps, fn):
-        sync_all()
-        ta = time.perf_counter()
-        for i in range(n_steps):
-            fn(i)
-        sync_all()
-        dt = time.perf_counter() - ta
-        if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt * 1e3 / n_steps
-
-    # ---- secondary legs (no events): a long run of the same replay, the other replay ------------------------------------------
-    long_ms, other_ms, two_ms, loop_ms, relay_ms, part_ms, coll_ms = None, None, None, None, None, None, None
-    if not args.no_secondary:
-        base_step = steps_run
-        if args.long_steps > 0:
-            long_ms = timed_leg(args.long_steps, lambda i: one_step(base_step + i))
-            steps_run += args.long_steps
-
-        def side_leg(plset, run_fn, what):
-            """args.steps steps of a collective-free plan set on the same states (every replay advances them identically)."""
-            nonlocal steps_run
-            b0 = steps_run
-            fn = lambda i: check(run_fn(plset[(b0 + i) & 1], 0, lib.cfx_plan_size(plset[0]), sh), what)      # noqa: E731
-            for i in range(2):
-                fn(i)
-            b0 += 2
-            ms_ = timed_leg(args.steps, fn)
-            steps_run += 2 + args.steps
-            return ms_
-        if real_live == 1 and not args.emulate_live:
-            # (looped-back peers only) the cross-layer pipeline and the one-launch-per-layer form: neither can carry a collective
-            if not int2 and not pipelined:
-                other_ms = side_leg(plans_pipe, lib.cfx_plan_run_pipelined, "plan_run(pipelined)")
-            if pipelined:
-                other_ms = side_leg(plans_inorder, lib.cfx_plan_run, "plan_run(in order)")
-            if plans_gated is not None and not gated:
-                loop_ms = side_leg(plans_gated, lib.cfx_plan_run, "plan_run(one launch per layer, loop-back)")
-            if gated:
-                two_ms = side_leg(plans_inorder, lib.cfx_plan_run, "plan_run(two launches)")
-            if xgate and build_step_plans is not None:
-                def step_leg(plset, what, stream_handle=sh):
-                    nonlocal steps_run
-                    b0 = steps_run
-                    fn = lambda i: check(lib.cfx_plan_run(plset[(b0 + i) & 1], 0, lib.cfx_plan_size(plset[0]), stream_handle), what)      # noqa: E731
-                    for i in range(2):
-                        fn(i)
-                    b0 += 2
-                    ms_ = timed_leg(args.steps, fn)
-                    steps_run += 2 + args.steps
-                    for pl_ in plset:
-                        lib.cfx_plan_destroy(pl_)
-                    return ms_
-                # the same exchange-layer launch with ncclAllGather in the path (flag-wait kernel ; ncclAllGather ; flag-set kernel on the exchange stream)
-                if exchange_mode == "p2p" and native_comm is not None:
-                    coll_ms = step_leg(build_step_plans(0), "plan_run(exchange layer, ncclAllGather in the path)")
-                # the same step, collective in the path, as two launches per layer in stream order (round 2's deployable schedule)
-                two_ms = step_leg(build_step_plans(0, xlayer=False), "plan_run(two launches, collective in the path)")
-                # no communicator: the exchange stream only relays the flag (one kernel instead of wait ; ncclAllGather ; set)
-                relay_ms = step_leg(build_step_plans(0, comm_=False), "plan_run(exchange layer, flag relay)")
-                # the configuration a run with MORE than one rank uses: run stream on CUs [0, 224), exchange stream on the other 32
-                hm, hx = ctypes.c_void_p(), ctypes.c_void_p()
-                assert lib.cfx_stream_create_masked(ctx, 0, 224, ctypes.byref(hm)) == 0 and lib.cfx_stream_create_masked(ctx, 224, 32, ctypes.byref(hx)) == 0
-                torch.cuda.synchronize(dev)
-                part_ms = step_leg(build_step_plans(0, side_=hx.value), "plan_run(exchange layer, CU partition)", hm.value)
-                torch.cuda.synchronize(dev)
-                lib.cfx_stream_destroy(ctx, hm); lib.cfx_stream_destroy(ctx, hx)
-    torch.cuda.synchronize(dev)
-    ge = lib.cfx_gate_errors(ctx)
+    runner.timed_region(S)                        # warm-up ; validate ; K timed steps ; validate - falling back in-process (c)
+    runner.secondary_legs(S)
+    torch.cuda.synchronize(S.dev)
+    ge = S.lib.cfx_gate_errors(S.ctx)
     if ge != 0:
         raise SystemExit(f"[bench] cfx_gate_errors = {ge}: a gated launch gave up waiting for its packets")
-
-    # ---- state sanity (bit-exact error-feedback consistency) ---------------------------------------------------------
-    ok, why = states_consistent()
+    ok, why = runner.consistent(S)                # state sanity (bit-exact error-feedback consistency)
     assert ok, why
-
-    # ---- the north-star comparison, N > 1: the UNCOMPRESSED exchange of the same K,V shards (reference patchpara/fwd.py:108-109,
-    # ring.py:193-195) issued the same way as the compressed one - a native plan, one host call per step - as a direct all-gather
-    # and as the reference's W-1-hop ring relay; and the compressed step in the OTHER exchange pattern -------------------------
-    raw_legs, other_pattern_ms = {}, None
-    if live > 1 and native_comm is not None and not pipelined and not args.no_raw_baseline:
-        raw_in = xs[0]                                                       # [L, 2, N, C]: one layer's K,V = 2 x 3.3 MB per rank
-        raw_buf = torch.empty(live, 2, N, C, dtype=torch.float16, device=dev)    # a layer's gathered K,V (consumed before the next layer's)
-        raw_bytes = 2 * N * C * 2
-        reps = max(3, min(args.steps, 10))
-        for pattern in ("allgather", "relay"):
-            rp = lib.cfx_plan_create(ctx)
-            assert lib.cfx_plan_set_exchange_stream(rp, 0) == 0
-            for l in range(L):
-                if pattern == "allgather":
-                    assert lib.cfx_plan_add_all_gather(rp, native_comm.handle, raw_in[l].data_ptr(), raw_buf.data_ptr(), raw_bytes) >= 0
-                else:
-                    src = raw_in[l].data_ptr()
-                    for h in range(live - 1):
-                        dst = raw_buf[(rank - h - 1) % live].data_ptr()
-                        assert lib.cfx_plan_add_ring_hop(rp, native_comm.handle, src, dst, raw_bytes) >= 0
-                        src = dst
-            assert lib.cfx_plan_finalize(rp) == 0
-            fnr = lambda i: check(lib.cfx_plan_run(rp, 0, lib.cfx_plan_size(rp), sh), "plan_run(raw " + pattern + ")")      # noqa: E731
-            fnr(0); fnr(1)
-            raw_legs[pattern] = timed_leg(reps, fnr)
-            torch.cuda.synchronize(dev)
-            lib.cfx_plan_destroy(rp)
-        # the compressed step in the other pattern (same states: every replay advances them identically)
-        if step_plans is not None and G == 1:
-            op_plans = build_step_plans(0, relay_=not relay)
-            b0 = steps_run
-            fno = lambda i: check(lib.cfx_plan_run(op_plans[(b0 + i) & 1], 0, lib.cfx_plan_size(op_plans[0]), sh), "plan_run(other pattern)")   # noqa: E731
-            fno(0); fno(1)
-            b0 += 2
-            other_pattern_ms = timed_leg(args.steps, fno)
-            steps_run += 2 + args.steps
-            ok, why = states_consistent()
-            assert ok, why
-    raw_ms = raw_legs.get("relay" if relay else "allgather")
-
-    ms_per_step = elapsed / args.steps * 1e3
-    act_bytes_rank = L * 16 * N * C * 2
-    value = real_live * act_bytes_rank / (elapsed / args.steps) / 1e9
-    inorder_ms = other_ms if pipelined else ms_per_step
-    pipe_ms = ms_per_step if pipelined else other_ms
-
-    P2P = exchange_mode == "p2p"
-    XNAME = ("no collective (--no-collective)" if not use_dist else
-             ("ring relay: " + str(live - 1) + " grouped ncclSend/ncclRecv hops" if relay else "ncclAllGather, in place (packets are written straight into the rank's slot of the gather buffer)")
-             + f" over libcfx's own {'loop-back stand-in' if args.emulate_live else 'RCCL'} communicator of {live} rank(s), issued from the native plan")
-    out = {
-        "metric": "residual_compressed_activation_exchange_throughput",
-        "value": round(value, 3),
-        "unit": "GB/s",
-        "n_gpus": real_live,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f16",
-        "data": "synthetic",
-        "config": {
-            "workload": f"FLUX.1-dev 1024x1024 ring-attention SP degree 8 (logical), {'2' if int2 else '1'}-bit residual + error feedback: per rank per step "
-                        f"{L} layers x (compress K,V + reconstruct 7 peers' K,V), shard (544,3072) fp16, layer by layer in order; "
-                        f"{live} live rank(s), {W_LOGICAL - live} peer(s) looped back",
-            "codec": "INT2(2-bit fastpath)" if int2 else "BINARY(1-bit, comp_rank=-1)", "layers": L, "shard": [N, C], "logical_ring": W_LOGICAL,
-            "packet_bytes": pkt_bytes, "raw_bytes": N * C * 2,
-        },
-        "exchange_ms_per_step": round(ms_per_step, 4),
-        "exchange_issued_by": exchange_mode,
-        "exchange_pattern": (args.exchange_pattern if use_dist else None),
-        "replay": args.replay,
-        "schedule": ("cross-layer software pipeline (NOT deployable: needs every layer's K,V resident)" if pipelined else
-                     ("layer by layer in order (deployable): ONE launch per layer, two groups of workgroups and two arrival gates: statistics + "
-                      "in-launch finalize of own K,V, then every statistics workgroup quantises its own tile (+ error feedback) from the registers "
-                      "it loaded -> reconstruction of the 7 looped-back peers' K,V (state tiles already in registers)") if (int2 and gated) else
-                     ("layer by layer in order (deployable): per layer A1 = statistics + in-launch finalize of own K,V, A2 = quantise + error "
-                      "feedback, X = " + XNAME + ", B = reconstruct 7 peers' K,V") if int2 else
-                     ("layer by layer in order, LOOP-BACK ONLY (no collective can sit inside it): ONE launch per layer = compress K,V [statistics + sign bits + in-launch "
-                      "finalize] + the 16 reconstructions its packets feed (own error feedback, 7 looped-back peers' K,V): their workgroups "
-                      "pull the state tiles into registers while the scale reduction completes, wait on an arrival gate, finish from registers") if gated else
-                     ("layer by layer in order (deployable), NO collective: every rank's packets stay in IPC-shared memory of its own GPU, the peers' "
-                      "reconstruction workgroups read them in place over xGMI.  Per layer ONE codec launch on the run stream = compress K,V [statistics + "
-                      "sign bits + in-launch finalize] + own error-feedback update + reconstruction of the 7 peers' K,V, whose workgroups pull their state "
-                      "tiles into registers and then wait for a gate word; workgroup 0 of the same launch waits for the launch's packets, publishes "
-                      f"a word the {live - 1} live peer(s) have mapped, waits for their words and opens the gate (cfx_plan_add_exchange_layer_p2p): no second launch, no second stream.  " +
-                      ("One live rank: no peer to read from or to wait for - the same op, launch and kernel as any N, minus the remote reads "
-                       "(`collective_in_the_path`: the same launch around ncclAllGather)" if live == 1 else
-                       "Validated after the warm-up steps and again after the timed region (gate time-outs, every rank's reconstruction of a shard against its owner's state)")) if (xgate and P2P) else
-                     ("layer by layer in order (deployable), the collective in the path: per layer ONE codec launch on the run stream = compress K,V "
-                      "[statistics + sign bits + in-launch finalize; packets written straight into the rank's slot of the gather buffer] + own "
-                      "error-feedback update + reconstruction of the 7 peers' K,V, whose workgroups pull their state tiles into registers and "
-                      "then wait for a gate word; on the exchange stream: flag-wait kernel (this launch's packets complete) ; X = " + XNAME +
-                      " ; flag-set kernel (opens the gate).  " +
-                      ("One live rank: the collective enqueues no kernel." if live == 1 else
-                       "More than one live rank: the collective is a kernel that is placed beside the waiting workgroups (the reconstruction "
-                       "group leaves >= 32 workgroup slots free); validated after the warm-up steps (first step: 300 ms gate timeout) and after the timed region")) if xgate else
-                     "layer by layer in order (deployable): per layer A = compress K,V [statistics + sign bits + in-launch finalize"
-                     + (" + previous layer's own error-feedback update riding along" if ride else "") + "], X = " + XNAME + ", B = reconstruct "
-                     + ("7 peers' K,V" if ride else "own + 7 peers' K,V")),
-        "schedule_fallback": schedule_fallback,
-        "launches_per_layer": None if pipelined else (1 if one_launch else (3 if int2 else 2)),
-        "two_launches_per_layer": None if two_ms is None else {
-            "ms_per_step": round(two_ms, 4),
-            "what": ("the same layer-ordered step as A1 = statistics + finalize ; A2 = quantise + error feedback ; B = reconstruct 7 peers" if int2 else
-                     "the same layer-ordered step as A = compress (+ previous layer's own error feedback riding along) ; B = reconstruct 7 peers")
-                    + (" ; the collective between them, everything in stream order (the fall-back schedule)" if xgate else
-                       " - the schedule a collective between compress and reconstruction forces (N > 1)")},
-        "collective_in_the_path": None if coll_ms is None else {
-            "ms_per_step": round(coll_ms, 4),
-            "what": "the same exchange-layer launch with a collective library in the path: flag-wait kernel ; ncclAllGather (in place, libcfx's own RCCL "
-                    "communicator of this many ranks) ; flag-set kernel on the exchange stream - round 3's earlier default, `--p2p off`"},
-        "flag_relay_no_communicator": None if relay_ms is None else {
-            "ms_per_step": round(relay_ms, 4),
-            "what": "the same exchange-layer plans built WITHOUT a communicator: the exchange stream runs one relay kernel per layer (wait + set) instead of "
-                    "flag-wait kernel ; ncclAllGather ; flag-set kernel - what the two kernel boundaries around the collective cost, and the launch "
-                    "structure of the peer-to-peer exchange layer runs with N > 1 use (there the one kernel also publishes a word and waits for the peers')"},
-        "with_cu_partition": None if part_ms is None else {
-            "ms_per_step": round(part_ms, 4),
-            "what": "the same exchange-layer plans with the run stream masked to CUs [0, 224) and the exchange stream to [224, 256): CUs of its own for a "
-                    "collective kernel whatever the shape; any partial CU mask costs this launch ~5 us, so the streams are not partitioned (the "
-                    "reconstruction group of this shape leaves 32 workgroup slots free, which is room enough)"},
-        "inorder_ms_per_step": None if inorder_ms is None else round(inorder_ms, 4),
-        "pure_exchange_upper_bound": None if pipe_ms is None else {
-            "ms_per_step": round(pipe_ms, 4),
-            "what": "cfx_plan_run_pipelined: statistics / finalize of later layers run beside the reconstruction of earlier ones; "
-                    "legal only with every layer's K,V resident before the step (this bench's synthetic inputs) - a model cannot run it"},
-        "long_run": None if long_ms is None else {"steps": args.long_steps, "ms_per_step": round(long_ms, 4)},
-        "exchange_stream": (["main", "side", "prio"][stream_mode] if (use_dist and step_plans is not None) else None),
-        "layers_per_all_gather": (G if (use_dist and step_plans is not None) else None),
-        "raw_allgather_ms_per_step": None if raw_ms is None else round(raw_ms, 4),
-        "raw_exchange_ms_per_step": {k_: round(v_, 4) for k_, v_ in raw_legs.items()} or None,
-        "speedup_vs_raw_allgather": None if raw_ms is None else round(raw_ms / ms_per_step, 3),
-        "loopback_one_launch_per_layer": None if loop_ms is None else {
-            "ms_per_step": round(loop_ms, 4),
-            "what": "cfx_compress_batch_gated: the layer as ONE launch (reconstruction behind an in-launch arrival gate). Exists only when the "
-                    "packets a reconstruction needs are produced by the same launch - looped-back peers, no collective - so it is NOT what N > 1 runs"},
-    }
-    if live > 1:
-        # wire side of the roofline pair (north star: "fraction of HBM / xGMI roofline"): bytes RECEIVED per GPU per step over the step
-        # time, against the xGMI links the pattern can use: a direct all-gather among `live` GPUs one link per peer (7 at most), the ring
-        # relay ONE link (every hop receives from rank-1); ~153 GB/s per direction per link (MI355X_MICROARCH.md).  The compressed
-        # exchange shares its step with the codec launches, so its figure is a lower bound of the link rate while a collective is in flight.
-        def xg(wire, ms_, pattern):
-            links = 1 if pattern == "relay" else min(live - 1, 7)
-            if ms_ is None:
-                return None
-            o = {"ms_per_step": round(ms_, 4), "achieved": round(wire / (ms_ * 1e-3) / 1e9, 2), "peak": 153.0 * links, "unit": "GB/s", "links": links}
-            # a fraction of a LINK roofline only where links carried the bytes: over the loop-back library the "wire" is a device copy, its
-            # rate says nothing about xGMI and may exceed the link peak - no `frac` key there
-            if args.emulate_live:
-                o["loopback_device_copy"] = True
-            elif args.same_gpu:
-                o["same_gpu"] = True             # rank processes sharing ONE GPU (protocol test): the peers' packets are read from the same HBM
-            else:
-                o["frac"] = round(wire / (ms_ * 1e-3) / 1e9 / (153.0 * links), 4)
-            return o
-        wire = (live - 1) * 2 * L * pkt_bytes
-        wire_raw = (live - 1) * 2 * L * N * C * 2
-        this_p, other_p = ("relay", "allgather") if relay else ("allgather", "relay")
-        out["xgmi"] = dict(xg(wire, ms_per_step, this_p), wire_bytes_per_gpu_per_step=int(wire), raw_bytes_per_gpu_per_step=int(wire_raw),
-                           pattern=this_p,
-                           compressed={this_p: xg(wire, ms_per_step, this_p), other_p: xg(wire, other_pattern_ms, other_p)},
-                           raw={k_: xg(wire_raw, v_, k_) for k_, v_ in raw_legs.items()},
-                           issued_by="every leg is one native plan per step (cfx_plan_run): no Python-issued collective on either side")
-        if args.emulate_live:
-            out["xgmi"]["note"] = "--emulate-live: loop-back collective library on ONE GPU - device copies, not xGMI links; layout and plumbing only"
-        elif args.same_gpu:
-            out["xgmi"]["note"] = "--same-gpu: the rank processes share ONE GPU - no link carried a byte; protocol and plumbing only"
-    # ---- roofline --------------------------------------------------------------------------------------------------------
-    # step level (every launch of the step, edge layers included), SURVEY.md §8d: own tensors compress + error feedback 6.125 B/el,
-    # peers' tensors 4.125 B/el
-    EL = N * C
-    step_alg = L * (2 * ALG_BYTES_PER_EL["compress"] + 14 * ALG_BYTES_PER_EL["decompress"]) * EL
-    step_obj = {"algorithmic_bytes": int(step_alg), "achieved": round(step_alg / (ms_per_step * 1e-3) / 1e9, 1), "unit": "GB/s",
-                "frac": round(step_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "floor_ms_at_peak": round(step_alg / (HBM_PEAK_GBS * 1e9) * 1e3, 4)}
-    dom = 23 if pipelined else (31 if one_launch else (6 if int2 else 4))
-    if dom in kern_us:
-        us, n_samples = kern_us[dom]
-        if pipelined:
-            ul = 7                                              # cfx_plan_set_pipe_unit_layers default
-            if use_dist and step_plans is not None:
-                ul = max(G, (ul // G) * G)                      # units are whole all-gather groups
-            ul = min(ul, 7, L)
-            # one steady-state launch: reconstruct 14*ul peers' tensors (4.125) + own 2*ul tensors' error-feedback pass and, two units
-            # ahead, their statistics pass: together the own tensors' compress + EF = 6.125 B/el (the second read of x / state is
-            # implementation traffic, SURVEY.md §8d)
-            alg = (ALG_BYTES_PER_EL["decompress"] * 14 + ALG_BYTES_PER_EL["compress"] * 2) * ul * EL
-            kname = (f"k_binary_pipe (one launch = {ul} layers: dequant+add of {16 * ul} tensors x (544,3072) + finalize of the next {ul} "
-                     f"layers' K,V scales + stats/sign bits of the {ul} layers after those)")
-        elif xgate:
-            alg = (ALG_BYTES_PER_EL["compress"] * 2 + ALG_BYTES_PER_EL["decompress"] * 14) * EL
-            kname = (("k_int2_compress_gated" if int2 else "k_absmean_compress<bits,gated>") + " (the layer's only codec launch: compress + error feedback of own K,V at " + str(ALG_BYTES_PER_EL["compress"]) +
-                     " B/el, 7 peers' K,V at " + str(ALG_BYTES_PER_EL["decompress"]) + " B/el; between reading K,V and the first reconstructed byte sit a global "
-                     "reduction - the scales - and the collective's arrival)")
-        elif gated:
-            alg = (ALG_BYTES_PER_EL["compress"] * 2 + ALG_BYTES_PER_EL["decompress"] * 14) * EL
-            kname = (("k_int2_compress_gated" if int2 else "k_absmean_compress<bits,gated>") + " (the layer's only launch: compress + error feedback of own K,V at " + str(ALG_BYTES_PER_EL["compress"]) + " B/el, "
-                     "7 looped-back peers' K,V at " + str(ALG_BYTES_PER_EL["decompress"]) + " B/el; a global reduction - the scales - sits between reading K,V and the first "
-                     "reconstructed byte)")
-        elif int2:
-            alg = ALG_BYTES_PER_EL["decompress"] * 14 * EL
-            kname = "k_int2_dequant (launch B: 7 peers K,V = 14 tensors x (544,3072) per launch)"
-        else:
-            n_t = (14 * (L - 1) + 16) / L if ride else 16.0     # tensors per launch B, averaged over the step's launches
-            alg = ALG_BYTES_PER_EL["decompress"] * n_t * EL
-            kname = (f"k_binary_dequant (launch B: {'7 peers K,V = 14' if ride else 'own + 7 peers K,V = 16'} tensors x (544,3072) per launch"
-                     + ("; the last layer's launch carries 16" if ride else "") + ")")
-        ach = alg / (us * 1e-6) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": kname,
-                           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                           "traffic": None, "traffic_source": None, "avg_launch_us": round(us, 3), "algorithmic_bytes_per_launch": int(alg),
-                           "event_samples": n_samples, "event_stride": args.event_stride, "step": step_obj}
-        if one_launch and step_events:
-            # one launch per layer: hipEvents around whole steps / the launches of a step = the launch duration with the kernel
-            # boundaries in (what rocprofv3's per-kernel durations add up to); a dispatch that itself carries profiling events runs
-            # ~1.5 us longer on this kernel, so the roofline uses the step-bracketing events and keeps the other figure beside it
-            us_ev = sum(a_.elapsed_time(b_) for a_, b_ in step_events) * 1e3 / len(step_events) / L
-            ach2 = alg / (us_ev * 1e-6) / 1e9
-            out["roofline"].update({"avg_launch_us_dispatch_events": out["roofline"]["avg_launch_us"], "avg_launch_us": round(us_ev, 3),
-                                    "achieved": round(ach2, 1), "frac": round(ach2 / HBM_PEAK_GBS, 4),
-                                    "event_samples": len(step_events) * L,
-                                    "event_method": "hipEvents on the launch stream around every 4th step of the timed region / launches per step"})
-        if int2 and 28 in kern_us and 5 in kern_us:
-            out["roofline"]["compress_launches"] = {
-                "k_absmean_compress (A1: statistics + in-launch finalize)": round(kern_us[28][0], 3),
-                "k_int2_quant (A2: codes + error feedback, own K,V)": round(kern_us[5][0], 3), "unit": "us",
-                "algorithmic_bytes_per_layer": int(ALG_BYTES_PER_EL["compress"] * 2 * EL)}
-        if not pipelined and 27 in kern_us:
-            usa, na = kern_us[27]
-            # launch A: the rank's own K,V - compress now, error feedback of the previous layer riding along: 6.125 B/el algorithmic
-            alga = ALG_BYTES_PER_EL["compress"] * 2 * EL if ride else 4.125 * 2 * EL
-            out["roofline"]["compress_launch"] = {
-                "kernel": "k_absmean_compress<bits> (launch A: statistics + sign bits + in-launch finalize of own K,V"
-                          + (" + previous layer's own error-feedback update" if ride else "") + ")",
-                "avg_launch_us": round(usa, 3), "event_samples": na, "algorithmic_bytes_per_launch": int(alga),
-                "achieved": round(alga / (usa * 1e-6) / 1e9, 1), "frac": round(alga / (usa * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "latency-bound: a global reduction (scales) sits between reading K,V and the packet being complete"}
-        # PMC traffic / rocprof cross-reference: only when the committed profile was taken with THIS configuration
-        # ... AND from this tree's kernel sources (tools/provenance.py): a stale profile is not quoted
-        prof = os.path.join(REPO, "profiles", "r05_pmc_traffic.json")
-        cfg_key = config_key(args, live)
-        sys.path.insert(0, os.path.join(REPO, "tools"))
-        from provenance import source_sha
-        src_sha = source_sha()
-        if os.path.exists(prof):
-            try:
-                pj = json.load(open(prof))
-                if pj.get("config") == cfg_key and pj.get("source_sha") != src_sha:
-                    out["roofline"]["traffic_source"] = "profiles/r05_pmc_traffic.json was taken from other kernel sources (source_sha differs): not quoted"
-                if pj.get("config") == cfg_key and pj.get("source_sha") == src_sha:
-                    pk_ = "k_binary_pipe<true>" if pipelined else (("k_int2_compress_gated" if int2 else "k_absmean_compress<true, 4, true") if one_launch else "k_binary_dequant")
-                    out["roofline"]["traffic"] = next((v for k_, v in pj["bytes_per_launch"].items() if k_.startswith(pk_)), None)
-                    out["roofline"]["traffic_source"] = ("profiles/r05_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes" +
-                                                         ("; " + pj["measured_with"] + ")" if pj.get("measured_with") else " of this command)"))
-                    if pj.get("measured_with"):
-                        out["roofline"]["step"]["traffic_source"] = "the same counter passes (loop-back form of the step: no flag kernels, no collective call)"
-                    out["roofline"]["step"]["traffic"] = pj.get("bytes_per_step")
-            except Exception:
-                pass
-        trace_json = os.path.join(REPO, "profiles", "r05_bench_kernel_durations.json")
-        if os.path.exists(trace_json):
-            try:
-                tj = json.load(open(trace_json))
-                if tj.get("config") == cfg_key and tj.get("source_sha") != src_sha:
-                    out["roofline"]["rocprof_source"] = "profiles/r05_bench_kernel_durations.json was taken from other kernel sources (source_sha differs): not quoted"
-                if tj.get("config") == cfg_key and tj.get("source_sha") == src_sha:
-                    pk_ = "k_binary_pipe<true>" if pipelined else (("k_int2_compress_gated" if int2 else "k_absmean_compress<true, 4, true") if one_launch else "k_binary_dequant")
-                    ent = next((v for k_, v in tj["kernels"].items() if k_.startswith(pk_)), None)
-                    if ent:
-                        out["roofline"]["avg_launch_us_rocprof"] = ent["avg_us"]
-                        out["roofline"]["median_launch_us_rocprof"] = ent.get("median_us")
-                        out["roofline"]["rocprof_source"] = "profiles/r05_bench_kernel_durations.json (rocprofv3 --kernel-trace of this command)"
-            except Exception:
-                pass
-    else:
-        out["roofline"] = {"bound": "hbm", "kernel": None, "achieved": step_obj["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": step_obj["frac"], "traffic": None, "step": step_obj}
-    if copy_rate is not None:
-        # the same fraction against what THIS box's HBM sustains on a plain copy (SURVEY.md section 8d asks for both)
-        out["roofline"].update(copy_rate)
-        out["roofline"]["frac_of_achievable"] = round(out["roofline"]["achieved"] / copy_rate["achievable_gbs"], 4)
-        out["roofline"]["step"]["frac_of_achievable"] = round(step_obj["achieved"] / copy_rate["achievable_gbs"], 4)
-    if rank == 0 and real_live == 1 and not args.no_cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.codec)
-        except Exception as e:  # pragma: no cover
-            out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-        if real_live == 1:
-            # the oracle as the checker of what was just timed: replay every step this process ran (warm-up + timed + long +
-            # the other replay) for two tensors on the host and compare the error-feedback states bit for bit - fails loudly
-            from oracle import c_oracle as CO
-            import numpy as np
-            x0_host = warm_state(rank)[1]
-            checked = []
-            for l, kv in ((0, 0), (L - 1, 1)):
-                state = x0_host[l, kv].cpu().numpy().view(np.uint16).copy()
-                pk = np.zeros(pkt_bytes // 2, dtype=np.uint16)
-                ins = [xs[s][l, kv].cpu().numpy() for s in range(2)]
-                for t in range(steps_run):
-                    CO.compress(args.codec, ins[t & 1], state, N, C, packet=pk, new_base=state)
-                for name, got in (("sender state", own_base[l, kv]), ("looped-back peer state", peer_base[l, W_LOGICAL - 2, kv])):
-                    if not np.array_equal(got.cpu().numpy().view(np.uint16), state):
-                        raise RuntimeError(f"parity spot check failed: layer {l} {'KV'[kv]} {name} differs from the C oracle after {steps_run} steps")
-                checked.append(f"layer {l} {'KV'[kv]}")
-            out["cpu_baseline"]["parity_spot_check"] = (f"error-feedback states of {', '.join(checked)} (sender and a looped-back peer) after all "
-                                                       f"{steps_run} steps of this run == C oracle replay, bit for bit")
-    # tear the communicators down first and flush C stdio (RCCL prints a version banner through its own stdio buffer),
-    # so that the JSON line is the LAST thing on stdout
-    torch.cuda.synchronize(dev)
-    if p2p_ptr is not None and p2p_ptr.value:
-        sync_all()                                   # nobody unmaps or frees while a peer may still read
-        for q_, pq_ in p2p_peer.items():
-            lib.cfx_ipc_close(ctx, ctypes.c_void_p(pq_))
-        sync_all()
-        lib.cfx_ipc_free(ctx, p2p_ptr)
-    for plset in (step_plans, plans_inorder, plans_pipe, plans_gated):
-        for pl_ in (plset or []):
-            lib.cfx_plan_destroy(pl_)
-    if xside:
-        lib.cfx_stream_destroy(ctx, ctypes.c_void_p(xside))
-    if native_comm is not None:
-        try:
-            torch.cuda.synchronize(dev)
-            native_comm.close()
-        except Exception:
-            pass
-    if world > 1:
-        dist.destroy_process_group()
-    if rank == 0 and world == 1 and not args.emulate_live and not args.no_secondary:
+    runner.raw_exchange_legs(S)
+    out = report.build_line(S)                    # (d)
+    report.add_cpu_baseline(S, out)
+    report.teardown(S)
+    if S.rank == 0 and S.world == 1 and not args.emulate_live and not args.no_secondary:
         # the secondary legs that need nothing of this process's state (tools/bench_secondary.py): protocol 2 beside real attention and the
-        # plugin path (child processes), every BASELINE configuration, the low-rank presets
-        del xs, own_base, peer_base
+        # plugin path (child processes), every BASELINE configuration through the native replay AND through the plugin API, the presets
+        del S.xs, S.own_base, S.peer_base
         torch.cuda.empty_cache()
-        torch.cuda.synchronize(dev)
-        sys.path.insert(0, os.path.join(REPO, "tools"))
+        torch.cuda.synchronize(S.dev)
         import bench_secondary as BS
         if args.overlap_steps > 0:
-            BS.overlap_leg(out, args.overlap_steps, L)
+            BS.overlap_leg(out, args.overlap_steps, S.L)
         if args.plugin_steps > 0:
-            BS.plugin_leg(out, args.plugin_steps, L)
+            BS.plugin_leg(out, args.plugin_steps, S.L)
         if not args.no_config_table:
             BS.configs_leg(out, HBM_PEAK_GBS)
             if args.plugin_steps > 0:
                 BS.plugin_configs_leg(out)
         if args.overlap_steps > 0:
-            BS.overlap_presets_leg(out, max(4, args.overlap_steps // 2), L)
-        BS.lowrank_leg(out, dev, N, C)
+            BS.overlap_presets_leg(out, max(4, args.overlap_steps // 2), S.L)
+        BS.lowrank_leg(out, S.dev, S.N, S.C)
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
     sys.stdout.flush()
-    if rank == 0:
+    if S.rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 

@@ -1392,8 +1392,14 @@ struct FusedArgs {
 #ifndef GATE_WPE
 #define GATE_WPE 4               // waves per SIMD the single-launch compress kernels are compiled for (2 workgroups / CU)
 #endif
+// Register budget: 104 VGPRs.  A collective KERNEL (RCCL: 256 threads x ~280 VGPRs) has to find room beside the waiting reconstruction
+// group when the collective sits in the path (cfx_plan_add_exchange_layer, needs_room in compress_impl): on a CU that holds one of these
+// workgroups - two waves a SIMD - 512 - 2 x 104 = 304 registers stay free, with the launch bound's 128 only 256.  The kernel fits 101
+// by itself when the developer probes' branches are compiled in and took 122 without them (same code, other schedule), so the budget is
+// stated: amdgpu_num_vgpr counts HALF registers on gfx90a+ (unified 512-entry file: LLVM doubles the request), 52 -> 104.  No spills
+// (tests/test_resource_usage.py reads the compiler's remarks: ScratchSize 0, VGPRs <= 104).
 template <bool EMIT_BITS, int US, bool GATED = false, bool ST = false>
-__global__ __launch_bounds__(FUSED_NT, GATE_WPE) void k_absmean_compress(BatchC batch, BatchD ride, BatchD gated, FusedArgs a) {
+__global__ __launch_bounds__(FUSED_NT, GATE_WPE) __attribute__((amdgpu_num_vgpr(52))) void k_absmean_compress(BatchC batch, BatchD ride, BatchD gated, FusedArgs a) {
     __shared__ u64 sm[FUSED_NW][TILE_C];
     int b = blockIdx.x;
     if (b < a.n_st) {
