@@ -72,7 +72,7 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tools"))
 
 from benchlib import report, runner, schedules          # noqa: E402
-from benchlib.workload import HBM_PEAK_GBS, config_key, measure_copy_rate, parse, setup          # noqa: E402
+from benchlib.workload import HBM_PEAK_GBS, config_key, group_recv_offset, measure_copy_rate, parse, setup          # noqa: E402,F401
 
 
 def main():
