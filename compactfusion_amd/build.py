@@ -12,7 +12,7 @@ import sys
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG_DIR)
-SRC = [os.path.join(PKG_DIR, "csrc", f) for f in ("cfx_kernels.hip", "cfx_plan.hip", "cfx_lowrank.hip", "cfx_lrgram.hip", "cfx_lrslab.hip")]
+SRC = [os.path.join(PKG_DIR, "csrc", f) for f in ("cfx_api.hip", "cfx_absmean.hip", "cfx_minmax.hip", "cfx_topk.hip", "cfx_plan.hip", "cfx_lowrank.hip", "cfx_lrgram.hip", "cfx_lrslab.hip")]
 INC = os.path.join(REPO, "include")
 LIB = os.path.join(PKG_DIR, "libcfx.so")
 LIB_DEV = os.path.join(PKG_DIR, "libcfx_dev.so")      # the same sources with -DCFX_DEV_PROBES (include/cfx_dev.h): tools and one test only
@@ -37,7 +37,7 @@ def needs_build(lib: str = LIB) -> bool:
         return True
     t = os.path.getmtime(lib)
     deps = SRC + [os.path.join(INC, "cfx.h"), os.path.join(INC, "cfx_dev.h"), os.path.join(PKG_DIR, "csrc", "cfx_internal.h"),
-                  os.path.join(PKG_DIR, "csrc", "cfx_lr.h")]
+                  os.path.join(PKG_DIR, "csrc", "cfx_lr.h"), os.path.join(PKG_DIR, "csrc", "cfx_device.h"), os.path.join(PKG_DIR, "csrc", "cfx_host.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -170,7 +170,7 @@ static inline int check_launch(cfx_ctx* ctx, const char* what) {
 #define AL16(p) ((((uintptr_t)(p)) & 15) == 0)
 
 // ---------------------------------------------------------------------------------------------------
-// Plan / communicator internals, shared by cfx_kernels.hip (the fused pipeline launch) and cfx_plan.hip (everything else)
+// Plan / communicator internals, shared by cfx_absmean.hip (the fused pipeline launch) and cfx_plan.hip (everything else)
 // ---------------------------------------------------------------------------------------------------
 // ---- plan: a prebuilt schedule of batch ops replayed from native code (no per-op Python marshalling) -------------
 // ---- RCCL, loaded at run time (the same library instance PyTorch-ROCm uses; no link-time dependency) ----------------
@@ -268,7 +268,7 @@ struct PipeSched {
     PipeUnit* units;
 };
 
-// cfx_kernels.hip, for cfx_plan.hip (hidden: not part of the ABI)
+// cfx_api.hip (the fused pipeline launch: cfx_absmean.hip), for cfx_plan.hip (hidden: not part of the ABI)
 #define CFX_HIDDEN __attribute__((visibility("hidden")))
 CFX_HIDDEN bool cfx_i_shape_ok(int codec, int N, int C, int param);
 CFX_HIDDEN size_t cfx_i_ws_words(int codec, int N, int C);
@@ -281,7 +281,7 @@ CFX_HIDDEN bool cfx_i_has_xlayer_form(int codec);
 CFX_HIDDEN int cfx_i_decompress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int batch, const cfx_decomp_item* items, void* stream,
                                      unsigned* pre, unsigned pre_val);
 // `xg` != NULL: the gated items wait on an EXTERNAL gate (their packets are delivered by a collective behind this launch), see
-// compress_impl in cfx_kernels.hip; xg->taken == 0 on return: only the compress part was launched
+// compress_impl in cfx_api.hip; xg->taken == 0 on return: only the compress part was launched
 CFX_HIDDEN int cfx_i_compress_impl(cfx_ctx* ctx, int codec, int N, int C, int param, int flags, int batch, const cfx_comp_item* items,
                                    int n_ride, const cfx_decomp_item* ride, int n_gated, const cfx_decomp_item* gated,
                                    void* workspace, size_t workspace_bytes, void* stream, CfxXGate* xg = nullptr);

@@ -12,7 +12,7 @@
 // reference by up to 3e-3 on fast-decaying spectra; with it 1e-5 .. 6e-5, measured in numpy).  A is touched by three passes
 // instead of seven, two of them pure fp16-input MFMA work with no range issue (A is fp16; Q0 and U are split hi + lo), and
 // everything between is N x r sized.  Launches (r x r factorisations run in the LAST-ARRIVING workgroup of the launch that
-// produced their input: ticket counter, write-through partials - the in-launch finalize of cfx_kernels.hip):
+// produced their input: ticket counter, write-through partials - the in-launch finalize of cfx_absmean.hip):
 //     k_lrg_prep   D = x - base                                                      (materialised once, 3.3 MB at the FLUX shard)
 //     k_lrg_gram   G = D D^T (64 x 64 tiles, upper triangle + mirror, 2 column slabs), Y0 = D Q0       v_mfma_f32_32x32x16_f16
 //     k_lrg_gy<0>  W1 = G Y0, M1 partials; last arriver: T1                                           v_mfma_f32_32x32x2_f32

@@ -1,5 +1,5 @@
 // libcfx.so - plan replay, library-owned RCCL communicator and the flag-synchronised exchange lane (host side of the C-ABI of
-// include/cfx.h; the streaming kernels are in cfx_kernels.hip, the low-rank chain in cfx_lowrank.hip).
+// include/cfx.h; the streaming kernels are in cfx_absmean / cfx_minmax / cfx_topk.hip, their C-ABI in cfx_api.hip, the low-rank chain in cfx_lowrank.hip).
 //
 // Reference citations are relative to /root/reference/xfuser/compact/.
 #include <hip/hip_runtime.h>

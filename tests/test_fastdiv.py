@@ -1,5 +1,5 @@
 """The min/max codecs divide every residual by its channel's scale in fp16 arithmetic (reference compress_quantize.py:465, :560: fp16
-tensors, i.e. the correctly rounded fp16 quotient).  The kernels' `hdiv_r` (csrc/cfx_kernels.hip) replaces the IEEE fp32 division with
+tensors, i.e. the correctly rounded fp16 quotient).  The kernels' `hdiv_r` (csrc/cfx_device.h) replaces the IEEE fp32 division with
 t = a * rcp(b); q = t + (a - t * b) * rcp(b) and rounds q to fp16.  This file shows on the CPU that the replacement is exact: for EVERY
 pair of fp16 significands, and for a reciprocal that is off by one unit in the last place either way (v_rcp_f32's error bound), q is
 within half an fp32 ulp of a / b and its fp16 rounding equals the correctly rounded quotient.  (Scaling by powers of two is exact, so the

@@ -550,7 +550,7 @@ def test_layer_calls_are_graph_capturable(codec, shape, op):
     """VERDICT round 5, task 5: the LAYER call of every codec - cfx_compress_batch_gated, and the peer-to-peer exchange-layer op of a plan at
     N = 1 - captured into a HIP graph and replayed.  Outside a capture the call is ONE launch whose gate value, ticket slot and launch
     tag are launch arguments the host advances; a capturing stream gets the capturable sequence from the same call (compress with
-    self-resetting tickets ; reconstruct in stream order, csrc/cfx_kernels.hip compress_impl).  Four replays with fresh activations in
+    self-resetting tickets ; reconstruct in stream order, csrc/cfx_api.hip compress_impl).  Four replays with fresh activations in
     the static input buffers, eager layer launches of the same context before and BETWEEN the replays (their tags and ring slots advance
     underneath): packets, sender states and peer states == the oracle bit for bit after every replay."""
     import ctypes
