@@ -83,17 +83,33 @@ class GroupHealth:
         self.group, self.device = group, device
         self.local_error = False
         self.step = None
+        self.first_key = None        # the layer key that opened the current boundary interval (fallback boundary: seen again = one pass over the layers)
         self.pending = None          # (event, pinned result) of the all-reduce issued at the previous boundary
         self._flag, self._host, self._turn = None, None, 0
 
     def note_error(self) -> None:
         self.local_error = True
 
-    def boundary(self, step) -> bool:
-        """Called by every layer op before it runs; True once per agreement that some rank had a time-out."""
-        if step is None or step == self.step:
+    def _new_interval(self, step, key) -> bool:
+        """Is this call the first of a new boundary interval?  A new step number (compact_set_step) - or, for callers that never set one
+        or sit on one step (such a run never reached a boundary, a timed-out launch produced a warning and nothing else),
+        the layer that opened the interval coming round AGAIN: one pass over the model's layers.  Pure bookkeeping (no device, no
+        collective): every rank runs the same layers in the same order, so every rank sees the same boundaries."""
+        if step is not None and step != self.step:
+            self.step = step
+        elif key is not None and key == self.first_key:
+            pass                                             # (a full pass since the last boundary, the step number did not move)
+        else:
+            if self.first_key is None:
+                self.first_key = key
             return False
-        self.step = step
+        self.first_key = key
+        return True
+
+    def boundary(self, step, key=None) -> bool:
+        """Called by every layer op before it runs; True once per agreement that some rank had a time-out."""
+        if not self._new_interval(step, key):
+            return False
         agreed = False
         if self.pending is not None:
             ev, host = self.pending
@@ -541,7 +557,7 @@ class LayerOp:
                 return self.run(k, v, sh)
             reg = self.region
             if not self.arena.loopback:
-                if self.arena.health.boundary(_current_step()):
+                if self.arena.health.boundary(_current_step(), self.key):
                     # some rank's wait timed out a step or two ago (every rank reads the same agreement at the same boundary): the launch
                     # it belonged to stored nothing, so its states are a delta behind their owners' - every layer proves itself again
                     self.lib.cfx_gate_recover(self.ctx)

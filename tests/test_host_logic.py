@@ -493,3 +493,26 @@ def test_named_configurations_equal_the_reference_presets():
     with pytest.raises(ValueError):
         presets.get_config("SDXL", "binary")                                                    # configs.py:35
     assert presets.get_config("Flux", "lowrank16").comp_rank == 16                              # defined upstream (:96-107), not dispatched there
+
+
+def test_group_health_boundaries_with_and_without_step_numbers():
+    """compact/xlayer.py GroupHealth: the ranks agree on time-outs at BOUNDARIES.  A boundary is a new step number - or, when the caller
+    never sets one (or sits on one), the layer that opened the interval coming round again.  The decision is pure bookkeeping over the
+    call sequence (every rank sees the same one)."""
+    from compactfusion_amd.compact.xlayer import GroupHealth
+    h = GroupHealth(None, 0)
+    layers = [("ring", f"{l}-0-k", None) for l in range(3)]
+    # explicit steps: one boundary per step, at the first layer that sees the new number
+    seq = [(s, k) for s in (1, 2, 3) for k in layers]
+    assert [h._new_interval(s, k) for s, k in seq] == [True, False, False] * 3
+    # no step numbers at all: the first pass opens the interval, every later pass starts a boundary at the same layer
+    h = GroupHealth(None, 0)
+    got = [h._new_interval(None, k) for _ in range(3) for k in layers]
+    assert got == [False, False, False, True, False, False, True, False, False]
+    # a loop that sits on ONE step number (several forwards per step): still a boundary per pass after the first
+    h = GroupHealth(None, 0)
+    got = [h._new_interval(7, k) for _ in range(3) for k in layers]
+    assert got == [True, False, False, True, False, False, True, False, False]
+    # a single-layer model without steps: every call after the first is a boundary
+    h = GroupHealth(None, 0)
+    assert [h._new_interval(None, layers[0]) for _ in range(3)] == [False, True, True]
