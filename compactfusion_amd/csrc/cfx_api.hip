@@ -718,7 +718,7 @@ int cfx_attn_merge(cfx_ctx* ctx, void* out, void* lse, const void* block_out, co
 int cfx_copy_probe(cfx_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {
     if (!ctx || !dst || !src) return fail(ctx, CFX_ERR_NULL, "copy_probe: null");
     if ((bytes & 15) || !AL16(dst) || !AL16(src)) return fail(ctx, CFX_ERR_ALIGN, "copy_probe: 16-byte granularity");
-    { hipStream_t s = (hipStream_t)stream; LAUNCH(ctx, KID_COPY_PROBE, s, k_copy_probe, dim3(2048), dim3(256), 0, s, (uint4*)dst, (const uint4*)src, bytes / 16); }
+    { hipStream_t s = (hipStream_t)stream; const size_t n16 = bytes / 16; const unsigned g = (unsigned)(n16 / 1024 < 8192 ? (n16 / 1024 ? n16 / 1024 : 1) : 8192); LAUNCH(ctx, KID_COPY_PROBE, s, k_copy_probe, dim3(g), dim3(256), 0, s, (uint4*)dst, (const uint4*)src, n16); }
     return check_launch(ctx, "copy_probe launch");
 }
 

@@ -393,23 +393,25 @@ __device__ __forceinline__ void p2p_exchange_inline(const unsigned* p_gate, unsi
 }
 
 
-// The plain copy the roofline's `achievable` is measured with (bench.py) and the PMC counters are calibrated on (tools/pmc_summary.py): 16 bytes
-// a lane, four loads in flight per thread before the first store, non-temporal both ways (a one-touch stream).
+// The plain copy the roofline's `achievable` is measured with (bench.py) and the PMC counters are calibrated on (tools/pmc_summary.py).  Every
+// workgroup copies ONE contiguous chunk, 16 bytes a lane, four loads in flight per thread before the first store, non-temporal both ways
+// (a one-touch stream): 6.1 TB/s at 96 MiB with 8192 workgroups (round 6, build/cb/copybench.hip: the grid-stride form it replaces gave
+// 5.1-5.7, hipMemcpyAsync 5.1; the guide's float4 copy: 6.3).
 static __global__ __launch_bounds__(256) void k_copy_probe(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
     typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
     const u32x4_* s4 = reinterpret_cast<const u32x4_*>(src);
     u32x4_* d4 = reinterpret_cast<u32x4_*>(dst);
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const u32x4_ a0 = __builtin_nontemporal_load(s4 + i), a1 = __builtin_nontemporal_load(s4 + i + stride);
-        const u32x4_ a2 = __builtin_nontemporal_load(s4 + i + 2 * stride), a3 = __builtin_nontemporal_load(s4 + i + 3 * stride);
-        __builtin_nontemporal_store(a0, d4 + i);
-        __builtin_nontemporal_store(a1, d4 + i + stride);
-        __builtin_nontemporal_store(a2, d4 + i + 2 * stride);
-        __builtin_nontemporal_store(a3, d4 + i + 3 * stride);
+    const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
+    const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n16 ? b0 + per : n16;
+    for (size_t i = b0 + threadIdx.x; i < b1; i += 256 * 4) {
+        u32x4_ a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + 256 * u < b1) a[u] = __builtin_nontemporal_load(s4 + i + 256 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + 256 * u < b1) __builtin_nontemporal_store(a[u], d4 + i + 256 * u);
     }
-    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + i), d4 + i);
 }
 
 #endif
