@@ -215,7 +215,7 @@ def build_line(S) -> dict:
                 "note": "latency-bound: a global reduction (scales) sits between reading K,V and the packet being complete"}
         # PMC traffic / rocprof cross-reference: only when the committed profile was taken with THIS configuration
         # ... AND from this tree's kernel sources (tools/provenance.py): a stale profile is not quoted
-        prof = os.path.join(REPO, "profiles", "r05_pmc_traffic.json")
+        prof = os.path.join(REPO, "profiles", "r06_pmc_traffic.json")
         cfg_key = config_key(S.args, S.live)
         sys.path.insert(0, os.path.join(REPO, "tools"))
         from provenance import source_sha
@@ -224,30 +224,30 @@ def build_line(S) -> dict:
             try:
                 pj = json.load(open(prof))
                 if pj.get("config") == cfg_key and pj.get("source_sha") != src_sha:
-                    out["roofline"]["traffic_source"] = "profiles/r05_pmc_traffic.json was taken from other kernel sources (source_sha differs): not quoted"
+                    out["roofline"]["traffic_source"] = "profiles/r06_pmc_traffic.json was taken from other kernel sources (source_sha differs): not quoted"
                 if pj.get("config") == cfg_key and pj.get("source_sha") == src_sha:
                     pk_ = "k_binary_pipe<true>" if S.pipelined else (("k_int2_compress_gated" if S.int2 else "k_absmean_compress<true, 4, true") if S.one_launch else "k_binary_dequant")
                     out["roofline"]["traffic"] = next((v for k_, v in pj["bytes_per_launch"].items() if k_.startswith(pk_)), None)
-                    out["roofline"]["traffic_source"] = ("profiles/r05_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes" +
+                    out["roofline"]["traffic_source"] = ("profiles/r06_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes" +
                                                          ("; " + pj["measured_with"] + ")" if pj.get("measured_with") else " of this command)"))
                     if pj.get("measured_with"):
                         out["roofline"]["step"]["traffic_source"] = "the same counter passes (loop-back form of the step: no flag kernels, no collective call)"
                     out["roofline"]["step"]["traffic"] = pj.get("bytes_per_step")
             except Exception:
                 pass
-        trace_json = os.path.join(REPO, "profiles", "r05_bench_kernel_durations.json")
+        trace_json = os.path.join(REPO, "profiles", "r06_bench_kernel_durations.json")
         if os.path.exists(trace_json):
             try:
                 tj = json.load(open(trace_json))
                 if tj.get("config") == cfg_key and tj.get("source_sha") != src_sha:
-                    out["roofline"]["rocprof_source"] = "profiles/r05_bench_kernel_durations.json was taken from other kernel sources (source_sha differs): not quoted"
+                    out["roofline"]["rocprof_source"] = "profiles/r06_bench_kernel_durations.json was taken from other kernel sources (source_sha differs): not quoted"
                 if tj.get("config") == cfg_key and tj.get("source_sha") == src_sha:
                     pk_ = "k_binary_pipe<true>" if S.pipelined else (("k_int2_compress_gated" if S.int2 else "k_absmean_compress<true, 4, true") if S.one_launch else "k_binary_dequant")
                     ent = next((v for k_, v in tj["kernels"].items() if k_.startswith(pk_)), None)
                     if ent:
                         out["roofline"]["avg_launch_us_rocprof"] = ent["avg_us"]
                         out["roofline"]["median_launch_us_rocprof"] = ent.get("median_us")
-                        out["roofline"]["rocprof_source"] = "profiles/r05_bench_kernel_durations.json (rocprofv3 --kernel-trace of this command)"
+                        out["roofline"]["rocprof_source"] = "profiles/r06_bench_kernel_durations.json (rocprofv3 --kernel-trace of this command)"
             except Exception:
                 pass
     else:

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Reproduces the round-5 files under profiles/ on a 1-GPU MI355X box.  Run from the repo root:
+# Reproduces the round-6 files under profiles/ on a 1-GPU MI355X box.  Run from the repo root:
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'
-# then copy gpurun_out/r05/* into profiles/.  Counter passes are separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass)
+# then copy gpurun_out/r06/* into profiles/.  Counter passes are separate runs (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 # and are never combined with trace domains other than the kernel trace; the profiled program follows `--` directly.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r05
+OUT=$R/gpurun_out/r06
 mkdir -p "$OUT"; rm -rf "$OUT"/*
 KEY=$(python3 "$R/bench.py" --print-config-key)
 FAKE=$R/tests/fake_rccl/libcfx_fake_rccl.so
@@ -19,7 +19,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace"
 # 1b. the same trace of the two-launch schedule (what runs with more than one rank execute)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace2" -o bench -- python3 "$R/bench.py" --own-ef ride --steps 20 --warmup 3 --no-secondary --overlap-steps 0 --plugin-steps 0 --no-config-table > "$OUT/bench2_under_rocprof.log" 2>&1 < /dev/null
 ST2=$(find "$OUT/trace2" -name "*kernel_stats.csv" 2>/dev/null | head -1)
-[ -n "$ST2" ] && cp "$ST2" "$OUT/r05_bench_two_launch_kernel_stats.csv"
+[ -n "$ST2" ] && cp "$ST2" "$OUT/r06_bench_two_launch_kernel_stats.csv"
 rm -rf "$OUT/trace2"
 # 2. HBM traffic (short run + the copy probe used for calibration).  Counter collection SERIALISES dispatches, which the flag-ordered launch cannot
 #    survive (its flag kernels would queue behind it), so the counters are taken on the loop-back form of the SAME kernel
@@ -29,71 +29,71 @@ PNOTE="counter passes serialise dispatches: taken on --no-collective --own-ef ga
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 "$R/bench.py" --no-collective --own-ef gated --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --overlap-steps 0 --copy-probe 8 > "$OUT/pmc_fetch.log" 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 "$R/bench.py" --no-collective --own-ef gated --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --overlap-steps 0 --copy-probe 8 > "$OUT/pmc_write.log" 2>&1 < /dev/null
 cd "$R"
-python3 tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/r05_pmc_traffic.json" "$KEY" $PSTEPS "$PNOTE" > /dev/null
+python3 tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/r06_pmc_traffic.json" "$KEY" $PSTEPS "$PNOTE" > /dev/null
 # 2b. the same counters for the two-launch schedule
 cd /tmp
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch2" -o pmc -- python3 "$R/bench.py" --own-ef ride --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --overlap-steps 0 --copy-probe 8 > "$OUT/pmc_fetch2.log" 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write2" -o pmc -- python3 "$R/bench.py" --own-ef ride --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-secondary --overlap-steps 0 --copy-probe 8 > "$OUT/pmc_write2.log" 2>&1 < /dev/null
 cd "$R"
 KEY2=$(python3 "$R/bench.py" --own-ef ride --print-config-key)
-python3 tools/pmc_summary.py "$OUT/pmc_fetch2" "$OUT/pmc_write2" "$OUT/r05_pmc_traffic_two_launch.json" "$KEY2" $PSTEPS > /dev/null
+python3 tools/pmc_summary.py "$OUT/pmc_fetch2" "$OUT/pmc_write2" "$OUT/r06_pmc_traffic_two_launch.json" "$KEY2" $PSTEPS > /dev/null
 rm -rf "$OUT/pmc_fetch2" "$OUT/pmc_write2"
 TR=$(find "$OUT/trace" -name "*kernel_trace.csv" | head -1)
 ST=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)
-[ -n "$TR" ] && python3 tools/trace_kernel_avg.py "$TR" "$OUT/r05_bench_kernel_durations.json" "$KEY" > /dev/null
-[ -n "$ST" ] && cp "$ST" "$OUT/r05_bench_kernel_stats.csv"
+[ -n "$TR" ] && python3 tools/trace_kernel_avg.py "$TR" "$OUT/r06_bench_kernel_durations.json" "$KEY" > /dev/null
+[ -n "$ST" ] && cp "$ST" "$OUT/r06_bench_kernel_stats.csv"
 rm -rf "$OUT/trace" "$OUT/pmc_fetch" "$OUT/pmc_write"
-# the bench reads profiles/r05_pmc_traffic.json and profiles/r05_bench_kernel_durations.json: refresh them before the plain runs
-cp "$OUT/r05_pmc_traffic.json" profiles/r05_pmc_traffic.json
-cp "$OUT/r05_bench_kernel_durations.json" profiles/r05_bench_kernel_durations.json
+# the bench reads profiles/r06_pmc_traffic.json and profiles/r06_bench_kernel_durations.json: refresh them before the plain runs
+cp "$OUT/r06_pmc_traffic.json" profiles/r06_pmc_traffic.json
+cp "$OUT/r06_bench_kernel_durations.json" profiles/r06_bench_kernel_durations.json
 # 3. the bench lines themselves: headline, 2-bit preset, loop-back one-launch form, N > 1 plumbing over the loop-back library
-python3 bench.py > "$OUT/r05_bench_n1.json" 2>/dev/null
-python3 bench.py --codec int2 --overlap-steps 0 --plugin-steps 0 --no-config-table > "$OUT/r05_bench_n1_int2.json" 2>/dev/null
-python3 bench.py --no-collective --own-ef gated --overlap-steps 0 --no-cpu-baseline --plugin-steps 0 --no-config-table > "$OUT/r05_bench_n1_loopback_one_launch.json" 2>/dev/null
-python3 bench.py --own-ef ride --overlap-steps 0 --no-cpu-baseline --plugin-steps 0 --no-config-table > "$OUT/r05_bench_n1_two_launch.json" 2>/dev/null
-python3 bench.py --p2p off --overlap-steps 0 --no-cpu-baseline --plugin-steps 0 --no-config-table > "$OUT/r05_bench_n1_collective_in_path.json" 2>/dev/null
-python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --no-cpu-baseline --long-steps 20 > "$OUT/r05_bench_emulated_live8.json" 2>/dev/null
-CFX_FAKE_RCCL_FAT=1 python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --no-cpu-baseline --long-steps 20 > "$OUT/r05_bench_emulated_live8_fat.json" 2>/dev/null
-timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29617 bench.py --gpus 2 --same-gpu --backend gloo --no-cpu-baseline --overlap-steps 0 --steps 20 --warmup 3 --long-steps 20 2>/dev/null | tail -1 > "$OUT/r05_bench_p2p_two_processes_one_gpu.json"
-python3 tools/xlayer_room_loop.py 2>&1 | grep -v amdgpu.ids > "$OUT/r05_xlayer_room_loop.txt"
-SHARE=0 python3 tools/xlayer_room_loop.py 2>&1 | grep -v amdgpu.ids > "$OUT/r05_xlayer_room_loop_stream_churn.txt"
-python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --exchange-pattern relay --no-cpu-baseline --long-steps 20 > "$OUT/r05_bench_emulated_live8_relay.json" 2>/dev/null
+python3 bench.py > "$OUT/r06_bench_n1.json" 2>/dev/null
+python3 bench.py --codec int2 --overlap-steps 0 --plugin-steps 0 --no-config-table > "$OUT/r06_bench_n1_int2.json" 2>/dev/null
+python3 bench.py --no-collective --own-ef gated --overlap-steps 0 --no-cpu-baseline --plugin-steps 0 --no-config-table > "$OUT/r06_bench_n1_loopback_one_launch.json" 2>/dev/null
+python3 bench.py --own-ef ride --overlap-steps 0 --no-cpu-baseline --plugin-steps 0 --no-config-table > "$OUT/r06_bench_n1_two_launch.json" 2>/dev/null
+python3 bench.py --p2p off --overlap-steps 0 --no-cpu-baseline --plugin-steps 0 --no-config-table > "$OUT/r06_bench_n1_collective_in_path.json" 2>/dev/null
+python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --no-cpu-baseline --long-steps 20 > "$OUT/r06_bench_emulated_live8.json" 2>/dev/null
+CFX_FAKE_RCCL_FAT=1 python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --no-cpu-baseline --long-steps 20 > "$OUT/r06_bench_emulated_live8_fat.json" 2>/dev/null
+timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29617 bench.py --gpus 2 --same-gpu --backend gloo --no-cpu-baseline --overlap-steps 0 --steps 20 --warmup 3 --long-steps 20 2>/dev/null | tail -1 > "$OUT/r06_bench_p2p_two_processes_one_gpu.json"
+python3 tools/xlayer_room_loop.py 2>&1 | grep -v amdgpu.ids > "$OUT/r06_xlayer_room_loop.txt"
+SHARE=0 python3 tools/xlayer_room_loop.py 2>&1 | grep -v amdgpu.ids > "$OUT/r06_xlayer_room_loop_stream_churn.txt"
+python3 bench.py --emulate-live 8 --rccl-lib "$FAKE" --exchange-pattern relay --no-cpu-baseline --long-steps 20 > "$OUT/r06_bench_emulated_live8_relay.json" 2>/dev/null
 # 4. the deployable path with real attention (SURVEY 8d protocol 2): all legs, then kernel traces of the lane leg and of attention alone
-python3 tools/overlap_bench.py --steps 20 --json "$OUT/r05_overlap.json" > /dev/null 2>&1
+python3 tools/overlap_bench.py --steps 20 --json "$OUT/r06_overlap.json" > /dev/null 2>&1
 bash tools/lane_trace.sh "$OUT/lane" > /dev/null 2>&1
-cp "$OUT/lane/overlap_trace_lane.json" "$OUT/r05_overlap_trace.json" 2>/dev/null
-cp "$OUT/lane/overlap_trace_attention_on_compute_lane.json" "$OUT/r05_overlap_trace_attention_only.json" 2>/dev/null
-cp "$OUT/lane/lane_layer_timeline.txt" "$OUT/r05_lane_layer_timeline.txt" 2>/dev/null
+cp "$OUT/lane/overlap_trace_lane.json" "$OUT/r06_overlap_trace.json" 2>/dev/null
+cp "$OUT/lane/overlap_trace_attention_on_compute_lane.json" "$OUT/r06_overlap_trace_attention_only.json" 2>/dev/null
+cp "$OUT/lane/lane_layer_timeline.txt" "$OUT/r06_lane_layer_timeline.txt" 2>/dev/null
 rm -rf "$OUT/lane"
 # 5. what the lane is built on: CU-mask geometry + hand-off prices, SDPA beside a masked bandwidth hog, flag hand-off coherence
-[ -x tools/lane_probe ] && ./tools/lane_probe > "$OUT/r05_lane_probe.txt" 2>&1
-python3 tools/sdpa_mask_probe.py 2>&1 | grep -v amdgpu.ids > "$OUT/r05_sdpa_mask_probe.txt"
-[ -x tools/flag_coherence_probe ] && ./tools/flag_coherence_probe > "$OUT/r05_flag_coherence_probe.txt" 2>&1
-python3 tools/fused_stamps.py 2>&1 | grep -v amdgpu.ids > "$OUT/r05_compress_timeline.txt"
+[ -x tools/lane_probe ] && ./tools/lane_probe > "$OUT/r06_lane_probe.txt" 2>&1
+python3 tools/sdpa_mask_probe.py 2>&1 | grep -v amdgpu.ids > "$OUT/r06_sdpa_mask_probe.txt"
+[ -x tools/flag_coherence_probe ] && ./tools/flag_coherence_probe > "$OUT/r06_flag_coherence_probe.txt" 2>&1
+python3 tools/fused_stamps.py 2>&1 | grep -v amdgpu.ids > "$OUT/r06_compress_timeline.txt"
 # 6. per-codec, per-configuration and low-rank tables
-python3 tools/codec_table.py 2>&1 | grep "^|" > "$OUT/r05_codec_table.md"
-python3 tools/config_table.py 2>&1 | grep "^|" > "$OUT/r05_config_table.md"
-python3 tools/lowrank_bench.py 2>&1 | grep -v "amdgpu.ids\|^compactfusion_amd:" > "$OUT/r05_lowrank_bench.txt"
-LR_CHAIN=2 python3 tools/lowrank_bench.py 2>&1 | grep -v "amdgpu.ids\|^compactfusion_amd:" | head -6 > "$OUT/r05_lowrank_bench_cspace_chain.txt"
-LR_CHAIN=1 python3 tools/lowrank_bench.py 2>&1 | grep -v "amdgpu.ids\|^compactfusion_amd:" | head -6 > "$OUT/r05_lowrank_bench_six_launch_chain.txt"
-python3 tools/lrs_stamps.py 2>&1 | grep -v amdgpu.ids > "$OUT/r05_lowrank_slab_timeline.txt"
+python3 tools/codec_table.py 2>&1 | grep "^|" > "$OUT/r06_codec_table.md"
+python3 tools/config_table.py 2>&1 | grep "^|" > "$OUT/r06_config_table.md"
+python3 tools/lowrank_bench.py 2>&1 | grep -v "amdgpu.ids\|^compactfusion_amd:" > "$OUT/r06_lowrank_bench.txt"
+LR_CHAIN=2 python3 tools/lowrank_bench.py 2>&1 | grep -v "amdgpu.ids\|^compactfusion_amd:" | head -6 > "$OUT/r06_lowrank_bench_cspace_chain.txt"
+LR_CHAIN=1 python3 tools/lowrank_bench.py 2>&1 | grep -v "amdgpu.ids\|^compactfusion_amd:" | head -6 > "$OUT/r06_lowrank_bench_six_launch_chain.txt"
+python3 tools/lrs_stamps.py 2>&1 | grep -v amdgpu.ids > "$OUT/r06_lowrank_slab_timeline.txt"
 # 7. rounds 4-5: the plugin path (protocol 1 through compact_all_gather_kv / compact_fwd), the gated layer launch's timeline, validate-then-fall-back,
 #    PMC traffic of the other codecs' launches at their BASELINE shapes
-python3 tools/plugin_path_bench.py --json "$OUT/r05_plugin_path.json" --quiet > /dev/null 2>&1
-python3 tools/gated_stamps.py 2>&1 | grep -v amdgpu.ids > "$OUT/r05_gated_layer_timeline.txt"
-timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29618 bench.py --gpus 2 --same-gpu --backend gloo --no-cpu-baseline --overlap-steps 0 --steps 20 --warmup 3 --long-steps 20 --poison-after-step 5 2>"$OUT/r05_bench_poisoned_p2p.stderr.txt" | tail -1 > "$OUT/r05_bench_poisoned_p2p_two_processes_one_gpu.json"
+python3 tools/plugin_path_bench.py --json "$OUT/r06_plugin_path.json" --quiet > /dev/null 2>&1
+python3 tools/gated_stamps.py 2>&1 | grep -v amdgpu.ids > "$OUT/r06_gated_layer_timeline.txt"
+timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29618 bench.py --gpus 2 --same-gpu --backend gloo --no-cpu-baseline --overlap-steps 0 --steps 20 --warmup 3 --long-steps 20 --poison-after-step 5 2>"$OUT/r06_bench_poisoned_p2p.stderr.txt" | tail -1 > "$OUT/r06_bench_poisoned_p2p_two_processes_one_gpu.json"
 cd /tmp
 TR2=$OUT/trace_xl
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$TR2" -- python3 "$R/bench.py" --steps 8 --warmup 2 --no-secondary --no-cpu-baseline --no-kernel-events --overlap-steps 0 --plugin-steps 0 --no-config-table > /dev/null 2>&1 < /dev/null
-python3 "$R/tools/xlayer_trace.py" "$(find "$TR2" -name '*kernel_trace.csv' | head -1)" > "$OUT/r05_layer_kernel_trace.txt" 2>&1
+python3 "$R/tools/xlayer_trace.py" "$(find "$TR2" -name '*kernel_trace.csv' | head -1)" > "$OUT/r06_layer_kernel_trace.txt" 2>&1
 rm -rf "$TR2"
 # (the same step with the exchange as a kernel on the exchange stream - the form until mid round 4, still what `--p2p off` runs)
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$TR2" -- python3 "$R/bench.py" --p2p off --steps 8 --warmup 2 --no-secondary --no-cpu-baseline --no-kernel-events --overlap-steps 0 --plugin-steps 0 --no-config-table > /dev/null 2>&1 < /dev/null
-python3 "$R/tools/xlayer_trace.py" "$(find "$TR2" -name '*kernel_trace.csv' | head -1)" > "$OUT/r05_layer_vs_flag_kernel_trace.txt" 2>&1
+python3 "$R/tools/xlayer_trace.py" "$(find "$TR2" -name '*kernel_trace.csv' | head -1)" > "$OUT/r06_layer_vs_flag_kernel_trace.txt" 2>&1
 rm -rf "$TR2"
 cd "$R"
 # the int4 / int8 layer launch's phase timeline at BASELINE's shards (config 2, config 1, config 4 = the tall form)
-{ N=1024 C=1152 B=2 NP=2 CODEC=3 python3 tools/mml_stamps.py; N=4096 C=1152 B=1 NP=0 CODEC=4 python3 tools/mml_stamps.py; N=4448 C=3072 B=2 NP=6 CODEC=3 python3 tools/mml_stamps.py; } 2>&1 | grep -v amdgpu.ids > "$OUT/r05_minmax_layer_timeline.txt"
+{ N=1024 C=1152 B=2 NP=2 CODEC=3 python3 tools/mml_stamps.py; N=4096 C=1152 B=1 NP=0 CODEC=4 python3 tools/mml_stamps.py; N=4448 C=3072 B=2 NP=6 CODEC=3 python3 tools/mml_stamps.py; } 2>&1 | grep -v amdgpu.ids > "$OUT/r06_minmax_layer_timeline.txt"
 cd /tmp
 mkdir -p "$OUT/pmc_codecs"
 for cfg in 1 2 3 3b 4 5; do for form in layer launches; do
@@ -103,11 +103,19 @@ for cfg in 1 2 3 3b 4 5; do for form in layer launches; do
   rm -rf "$OUT/pf" "$OUT/pw"
 done; done
 cd "$R"
-python3 tools/codec_pmc_table.py "$OUT/pmc_codecs" "$OUT/r05_pmc_traffic_codecs.json" > "$OUT/r05_pmc_traffic_codecs.txt" 2>&1
+python3 tools/codec_pmc_table.py "$OUT/pmc_codecs" "$OUT/r06_pmc_traffic_codecs.json" > "$OUT/r06_pmc_traffic_codecs.txt" 2>&1
 rm -rf "$OUT/pmc_codecs"
 # 8. round 5: the low-rank launch's kernel trace + HBM counters of THIS round's build (task 2), the reference-mode spread
 #    file the LOW_RANK_Q tolerance comes from is tests/golden/g12_lrq32_modes.json (build container, not here)
 bash tools/lowrank_profile.sh > /dev/null 2>&1
-cp gpurun_out/lrprof/r05_lowrank_pmc_traffic.json gpurun_out/lrprof/r05_lowrank_kernel_stats.csv "$OUT/" 2>/dev/null
-cp gpurun_out/lrprof/plain.txt "$OUT/r05_lowrank_cold.txt" 2>/dev/null
-tail -c 800 "$OUT/r05_bench_n1.json"
+cp gpurun_out/lrprof/r06_lowrank_pmc_traffic.json gpurun_out/lrprof/r06_lowrank_kernel_stats.csv "$OUT/" 2>/dev/null
+cp gpurun_out/lrprof/plain.txt "$OUT/r06_lowrank_cold.txt" 2>/dev/null
+# 9. round 6: every BASELINE configuration and every shipped preset THROUGH THE PLUGIN API (one Python call per layer), protocol 2 for the
+#    presets other than BINARY, the LOW_RANK_Q gap over 8 more seeds and on the 4-layer stack against the reference's own two modes
+python3 tools/plugin_config_bench.py --quiet --json "$OUT/r06_plugin_configs.json" > /dev/null 2>&1
+for p in int2 lowrank8 lowrankq32; do python3 tools/overlap_bench.py --preset $p --steps 10 --quiet --json "$OUT/r06_overlap_$p.json" > /dev/null 2>&1; done
+python3 tools/stack_lrq_probe.py 2>&1 | grep "^[01] hip-eager" > "$OUT/r06_stack_lrq32_probe.txt"
+python3 -m pytest tests/test_gpu_quality.py -q -m gpu > /dev/null 2>&1
+cp gpurun_out/quality_gaps.json "$OUT/r06_quality_gaps.json" 2>/dev/null
+cp gpurun_out/lrq32_seeds.json "$OUT/r06_lrq32_seeds.json" 2>/dev/null
+tail -c 800 "$OUT/r06_bench_n1.json"
