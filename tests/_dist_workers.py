@@ -328,7 +328,21 @@ def w_stack(rank, world, codec_name):
         lowrank.set_init_q(None)
     res["psnr"] = np.array([G.psnr(finals["exact"][t].cpu(), finals[codec_name][t].cpu()) for t in range(G.STEPS)])
     res["exact_final"] = bits(finals["exact"][-1])
+    # did an in-launch wait give up on the way?  (two rank PROCESSES time-slicing one GPU can starve each other's polling kernels past the
+    # gate timeout; the run recovers - states re-synchronised from their owners - but a sender whose launch gave up has skipped one
+    # error-feedback update, so its chain is no longer the golden run's)
+    from compactfusion_amd.compact import ring as ring_mod
+    ops = [e.xop for e in ring_mod._xbuf.values() if getattr(e, "xop", None) is not None]
+    res["timeouts"] = np.array([sum(1 for o in ops if o.fallback_reason is not None) + (1 if DEV != "cpu" and _gate_errors_seen() else 0)])
     return res
+
+
+def _gate_errors_seen() -> int:
+    try:
+        from compactfusion_amd import _lib, codecs
+        return int(_lib.load().cfx_gate_errors(codecs.context(torch.cuda.current_device())) > 0)
+    except Exception:  # noqa: BLE001
+        return 0
 
 
 def w_xlayer(rank, world, codec_name, mode, poison, gens, steps=4, ef=True, late=None, gate_timeout_ms=0, revalidate_every=0):

@@ -44,7 +44,14 @@ def test_stack_psnr_matches_the_reference(tmp_path, codec, tol):
     if f"{codec.lower()}/r0/psnr" not in gold.files:
         pytest.skip(f"G13 has no {codec} run")
     out = str(tmp_path / "res")
-    mp.start_processes(_entry, args=("w_stack", 2, _port(), out, (codec,)), nprocs=2, join=True, start_method="spawn")
+    for attempt in range(2):
+        mp.start_processes(_entry, args=("w_stack", 2, _port(), out, (codec,)), nprocs=2, join=True, start_method="spawn")
+        # The two rank processes share ONE GPU here, and a layer launch waits INSIDE the kernel for the peer's packets: when the scheduler
+        # time-slices the two processes coarsely a wait can outlast the 5 s gate timeout (seen as runs of 30+ s instead of 10).  The run
+        # recovers and the ranks stay consistent, but a sender whose launch gave up skipped one error-feedback update - its chain is not the
+        # golden run's any more.  That is the test rig, not the product (one GPU per rank): such a run is repeated once.
+        if all(int(np.load(out + f".r{r}.npz")["timeouts"][0]) == 0 for r in range(2)):
+            break
     for r in range(2):
         got = np.load(out + f".r{r}.npz")["psnr"]
         want = gold[f"{codec.lower()}/r{r}/psnr"]
