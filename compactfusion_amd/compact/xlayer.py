@@ -271,6 +271,78 @@ def release(collective: bool = True) -> None:
         except Exception:  # noqa: BLE001  (interpreter shutdown / a torn-down process group)
             pass
     _arenas.clear()
+    _start_pools.clear()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# start matrices of the low-rank layer ops
+# ---------------------------------------------------------------------------------------------------------------------------
+class StartPool:
+    """Start matrices (2, C, rp) fp32 for the subspace iterations of the low-rank layer ops of one shape, drawn a CHUNK at a time.
+
+    The reference draws torch.randn per compress call (compress_lowrank.py:41): through the layer op that is one tiny launch in front
+    of every layer's chain - 57 a FLUX step.  Every layer op owns one slot of a chunk of `CHUNK` slots for its lifetime (the plan ops
+    hold the slot's address); an execution consumes its slot's draw, and the first execution that finds its slot consumed redraws the
+    whole chunk with one normal_() - one launch per CHUNK layers and step, every execution still starts from its own fresh i.i.d.
+    Gaussian matrix.  A draw is ordered with its consumers by the stream: a chunk is redrawn as a whole only while all its slots were
+    last used on the drawing stream; a slot used from another stream draws for itself (what every slot did before round 6).
+    No GPU needed: tests/test_host_logic.py drives the bookkeeping with CPU tensors."""
+    CHUNK = 32
+
+    def __init__(self, C: int, rp: int, rank: int, device):
+        self.C, self.rp, self.r, self.device = C, rp, rank, device
+        self.chunks: List[dict] = []
+        self.free: List[Tuple[int, int]] = []
+        self.draws = 0                          # normal_() launches so far (tests, tools)
+
+    def acquire(self) -> Tuple[int, int, "torch.Tensor"]:
+        if not self.free:
+            t = torch.zeros(self.CHUNK, 2, self.C, self.rp, dtype=torch.float32, device=self.device)
+            self.chunks.append({"t": t, "fresh": [False] * self.CHUNK, "last": [None] * self.CHUNK, "stream": None, "gen": 0})
+            self.free = [(len(self.chunks) - 1, i) for i in reversed(range(self.CHUNK))]
+        c, i = self.free.pop()
+        ch = self.chunks[c]
+        ch["last"][i] = None                    # (an unconsumed draw in the slot stays valid: nobody has read it; the padding columns are never written)
+        return c, i, ch["t"][i]
+
+    def give_back(self, c: int, i: int) -> None:
+        self.chunks[c]["last"][i] = None
+        self.free.append((c, i))
+
+    def take(self, c: int, i: int, stream) -> None:
+        """Slot (c, i) is about to be read by a chain enqueued on `stream` (any hashable; None on CPU): make sure it holds a draw
+        nobody has consumed, enqueued on that stream."""
+        ch = self.chunks[c]
+        ch["last"][i] = stream
+        if ch["fresh"][i] and ch["stream"] == stream:
+            ch["fresh"][i] = False
+            return
+        if all(s is None or s == stream for s in ch["last"]):
+            ch["t"][..., :self.r].normal_()
+            ch["stream"], ch["fresh"] = stream, [True] * self.CHUNK
+            ch["gen"] += 1                      # (a pinned matrix in another slot is gone: its owner pins again, see LayerOp._draw_start)
+        else:
+            ch["t"][i][..., :self.r].normal_()
+        ch["fresh"][i] = False
+        self.draws += 1
+
+    def pin(self, c: int, i: int, q: "torch.Tensor") -> int:
+        t = self.chunks[c]["t"][i]
+        t.zero_()
+        t[:, :, :self.r] = q.to(device=t.device, dtype=torch.float32)
+        self.chunks[c]["fresh"][i] = False
+        return self.chunks[c]["gen"]
+
+
+_start_pools: Dict[Tuple, StartPool] = {}
+
+
+def start_pool(device, C: int, rp: int, rank: int) -> StartPool:
+    key = (str(device), C, rp, rank)
+    sp = _start_pools.get(key)
+    if sp is None:
+        sp = _start_pools[key] = StartPool(C, rp, rank, device)
+    return sp
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -328,10 +400,11 @@ class LayerOp:
             assert self.cid in (101, 102) and own_update == "ef", "the low-rank layer op exists with error feedback only"
             self.pkt_bytes = 2 * codecs.lr_packet_halves(self.quantized, N, C, self.param)
             rp = codecs.lr_rank_pad(self.param)
-            self._q0 = torch.zeros(2, C, rp, dtype=torch.float32, device=device)      # start matrices of K and V, redrawn per execution
-            self._q0_draw = self._q0 if rp == self.param else self._q0[:, :, :self.param]
+            self._pool = start_pool(device, C, rp, self.param)                         # start matrices of K and V: a fresh draw per execution
+            self._slot = self._pool.acquire()
+            self._q0 = self._slot[2]
             self._q0p = (ctypes.c_void_p * 2)(self._q0[0].data_ptr(), self._q0[1].data_ptr())
-            self._pinned = None
+            self._pinned, self._pin_gen = None, -1
         else:
             self.pkt_bytes = codecs.packet_bytes(self.cid, N, C, self.param)
         self.slot = (self.pkt_bytes + 255) // 256 * 256
@@ -388,12 +461,19 @@ class LayerOp:
             self.lib.cfx_plan_destroy(plan)
         self._plans = {}
 
+    def _drop_slot(self) -> None:
+        if getattr(self, "_slot", None) is not None:
+            self._pool.give_back(self._slot[0], self._slot[1])
+            self._slot = None
+
     def close(self) -> None:
         self._drop_plans()
+        self._drop_slot()
 
     def __del__(self):
         try:
             self._drop_plans()
+            self._drop_slot()
         except Exception:  # noqa: BLE001  (interpreter shutdown)
             pass
 
@@ -516,18 +596,18 @@ class LayerOp:
         ent = self._plans[sh] = (plan, keep)
         return ent
 
-    def _draw_start(self) -> None:
-        """The start matrices of this execution's subspace iterations: drawn per call as the reference does (compress_lowrank.py:41) - one
-        normal_() over both - or the matrix a test pinned (lowrank.set_init_q)."""
+    def _draw_start(self, sh: int) -> None:
+        """The start matrices of this execution's subspace iterations: a fresh Gaussian draw per call as the reference makes
+        (compress_lowrank.py:41) - from the shape's StartPool, one launch per 32 layer executions - or the matrix a test pinned
+        (lowrank.set_init_q)."""
         from . import lowrank
         pinned = lowrank._pinned_q
         if pinned is None:
-            self._q0_draw.normal_()
+            self._pool.take(self._slot[0], self._slot[1], sh)
             self._pinned = None
-        elif pinned is not self._pinned:
+        elif pinned is not self._pinned or self._pool.chunks[self._slot[0]]["gen"] != self._pin_gen:
             assert tuple(pinned.shape) == (self.C, self.param), f"pinned init_q must be ({self.C}, {self.param})"
-            self._q0.zero_()
-            self._q0[:, :, :self.param] = pinned.to(device=self.device, dtype=torch.float32)
+            self._pin_gen = self._pool.pin(self._slot[0], self._slot[1], pinned)
             self._pinned = pinned
 
     def _solo_packets(self):
@@ -570,7 +650,7 @@ class LayerOp:
         else:
             op = 0
         if self.lowrank:
-            self._draw_start()
+            self._draw_start(sh)
         xs = self._xs
         xs[0], xs[1] = k.data_ptr(), v.data_ptr()
         nops = self.nops
@@ -628,7 +708,7 @@ class LayerOp:
         op = reg.n_exec & 1
         reg.n_exec += 1
         if self.lowrank:
-            self._draw_start()
+            self._draw_start(sh)
         self._xs[0], self._xs[1] = k.data_ptr(), v.data_ptr()
         rc = self._run_x(ent[0], op * self.nops, self.nops, self._xs, 2, sh)
         stream = torch.cuda.current_stream(self.device)

@@ -224,6 +224,53 @@ def test_plugin_call_low_rank_family_one_native_call_per_layer(loop8, api, codec
     assert lib.cfx_gate_errors(ctx) == 0
 
 
+def test_plugin_call_low_rank_draws_its_start_matrices_a_chunk_at_a_time(loop8):
+    """The path a model takes (no pinned start matrix): every execution of a low-rank layer op starts from its own fresh Gaussian draw
+    (reference compress_lowrank.py:41 draws per call), made one launch per chunk of layers and step (compact/xlayer.py StartPool) instead
+    of one per layer.  Checked over 3 compressed steps of 5 layers: the draws counted, two layers' / two steps' matrices differ, every
+    peer's state == the sender's bit for bit, and the residual the rank-8 packets leave shrinks with the steps (error feedback)."""
+    ring, cm, xlayer = loop8
+    from compactfusion_amd import _lib, codecs as K
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig
+    lib, ctx = _lib.load(), K.context(0)
+    L, STEPS, rank = 5, 4, 8
+    shape, N, C = (1, 128, 16, 64), 128, 1024
+    cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T.LOW_RANK, comp_rank=rank, residual=1, ef=True, fastpath=False))
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    low = [torch.randn(N, 6, generator=g) @ torch.randn(6, C, generator=g) for _ in range(L)]      # rank-6 activations: a rank-8 packet can carry them
+    q = torch.randn(shape, generator=g).half().to(dev)
+    starts, errs = [], []
+    with torch.cuda.stream(torch.cuda.Stream(dev)):
+        for s in range(STEPS):
+            cm.compact_set_step(s)
+            for l in range(L):
+                x = ((1.0 + 0.05 * s) * low[l]).half().reshape(shape).to(dev)
+                ring.compact_fwd(q, x, x.clone(), causal=False, mod_idx=l, current_iter=s)
+            torch.cuda.synchronize()
+            ops = {e.xop.key: e.xop for e in ring._xbuf.values() if e.xop is not None}
+            if s > 0:
+                starts.append({k_: o._q0.clone() for k_, o in ops.items()})
+                cache = cm.compact_cache()
+                e = 0.0
+                for l in range(L):
+                    own = cache.get_base(f"{l}-0-k").reshape(N, C)
+                    for r in range(1, WL):
+                        assert torch.equal(cache.get_base(f"{l}-{r}-k").reshape(N, C).view(torch.int16), own.view(torch.int16)), (s, l, r)
+                    want = ((1.0 + 0.05 * s) * low[l]).half().to(dev)
+                    e = max(e, float((own.float() - want.float()).norm() / want.float().norm()))
+                errs.append(e)
+    ops = [e.xop for e in ring._xbuf.values() if e.xop is not None]
+    assert len(ops) == L and all(o.lowrank and o.transport == "p2p" for o in ops)
+    pool = ops[0]._pool
+    assert all(o._pool is pool for o in ops) and pool.draws == STEPS - 1, (pool.draws, "one draw per chunk (32 layers) and compressed step")
+    mats = [m for st in starts for m in st.values()]
+    assert all(bool(m.any()) for m in mats)
+    assert len({m.cpu().numpy().tobytes() for m in mats}) == len(mats), "two executions started from the same matrix"
+    assert errs[-1] < 2e-3 and errs[0] < 0.05, errs
+    assert lib.cfx_gate_errors(ctx) == 0
+
+
 def _check_states(res, codec, mode, world, gens, L=3, STEPS=4, shape=(1, 64, 8, 64)):
     for gen in range(gens):
         for l in range(L):

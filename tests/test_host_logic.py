@@ -516,3 +516,43 @@ def test_group_health_boundaries_with_and_without_step_numbers():
     # a single-layer model without steps: every call after the first is a boundary
     h = GroupHealth(None, 0)
     assert [h._new_interval(None, layers[0]) for _ in range(3)] == [False, True, True]
+
+
+def test_start_pool_draws_once_per_chunk_and_never_hands_out_a_draw_twice():
+    """compact/xlayer.py StartPool: the low-rank layer ops' start matrices, one normal_() per chunk of layers and step; every
+    execution reads a draw nobody consumed before; another stream draws for itself; a pinned matrix survives until a redraw."""
+    from compactfusion_amd.compact import xlayer
+    sp = xlayer.StartPool(C=16, rp=8, rank=6, device=torch.device("cpu"))
+    sp.CHUNK = 4
+    slots = [sp.acquire() for _ in range(6)]                     # two chunks: 4 + 2 slots
+    assert len(sp.chunks) == 2 and {c for c, _, _ in slots} == {0, 1}
+    assert all(t.shape == (2, 16, 8) and not t.any() for _, _, t in slots)
+    seen = []
+    torch.manual_seed(0)
+    for step in range(3):
+        for c, i, t in slots:
+            sp.take(c, i, "s0")
+            assert not t[:, :, 6:].any(), "the padding columns stay zero"
+            seen.append(t[:, :, :6].clone())
+    assert sp.draws == 2 * 3, "one draw per chunk and step"
+    flat = torch.stack(seen).reshape(len(seen), -1)
+    assert len({tuple(r.tolist()) for r in flat}) == len(seen), "two executions read the same draw"
+    # a slot used from another stream: draws for itself, and the chunk is no longer redrawn as a whole while that holds
+    before = [t.clone() for _, _, t in slots[:4]]
+    sp.take(0, 1, "s1")
+    assert not torch.equal(slots[1][2], before[1]) and all(torch.equal(slots[j][2], before[j]) for j in (0, 2, 3))
+    d0 = sp.draws
+    sp.take(0, 0, "s0")                                            # consumed on s0 in step 2: needs a draw; slot 1 sits on s1 -> own slot only
+    assert sp.draws == d0 + 1 and torch.equal(slots[2][2], before[2]) and not torch.equal(slots[0][2], before[0])
+    # pinning: the slot holds the pinned matrix; a chunk redraw bumps the generation so the owner knows to pin again
+    q = torch.arange(16 * 6, dtype=torch.float32).reshape(16, 6)
+    gen = sp.pin(1, 0, q)
+    assert torch.equal(slots[4][2][0, :, :6], q) and torch.equal(slots[4][2][1, :, :6], q) and not slots[4][2][:, :, 6:].any()
+    sp.take(1, 1, "s0"); sp.take(1, 1, "s0")
+    assert sp.chunks[1]["gen"] != gen
+    # give-back and reuse
+    sp.give_back(0, 1)
+    c, i, t = sp.acquire()
+    assert (c, i) == (0, 1) and not t[:, :, 6:].any()
+    sp.take(0, 1, "s0"); sp.take(0, 0, "s0"); sp.take(0, 0, "s0")  # everything on s0 again: whole-chunk draws come back
+    assert all(sp.chunks[0]["fresh"][j] for j in (1, 2, 3))

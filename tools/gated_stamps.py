@@ -42,8 +42,11 @@ for z, nm in ((0, "K"), (1, "V")):
     blk = a[z * CBP:(z + 1) * CBP]
     uj = blk[(blk[:, 7] & 2) != 0]
     vj = blk[(blk[:, 7] & 1) != 0]
-    print(f"tensor {nm}: tiles done p50 {(np.median(blk[:, 1]) - t00) / 100:.2f} max {(blk[:, 1].max() - t00) / 100:.2f}; V jobs end max {(vj[:, 6].max() - t00) / 100:.2f}; "
-          f"U job end {(uj[:, 6].max() - t00) / 100:.2f} us (tail loads back {(uj[:, 4].max() - t00) / 100:.2f})")
+    def at(col):                                          # latest stamp of a column, "n/a" where this form of the launch never sets it
+        col = col[col > 0]
+        return f"{(col.max() - t00) / 100:.2f}" if len(col) else "n/a"
+    print(f"tensor {nm}: tiles done p50 {(np.median(blk[:, 1]) - t00) / 100:.2f} max {at(blk[:, 1])}; V jobs end max {at(vj[:, 6])}; "
+          f"U job end {at(uj[:, 6])} us (tail loads back {at(uj[:, 4])})")
 a = a[a[:, 0] > 0]
 t0 = a[:, 0].min()
 A = a[a[:, 7] != 4]; G = a[a[:, 7] == 4]

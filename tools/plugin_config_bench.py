@@ -54,6 +54,7 @@ ap.add_argument("--rows", default=",".join(ROWS))
 ap.add_argument("--budget", type=float, default=0.25, help="seconds of back-to-back steps per row (at least 6 steps)")
 ap.add_argument("--json", default=None)
 ap.add_argument("--quiet", action="store_true")
+ap.add_argument("--pin-start", action="store_true", help="low-rank rows: one pinned start matrix instead of a fresh draw per execution (what a model runs)")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -100,7 +101,7 @@ def one_row(name):
     ring.block_attention = lambda q, k, v, *a, **kw_: (out_, lse_)
     ring.update_out_and_lse = lambda out, lse, bo, bl, wait=None: (out_, lse_)
     ring._SteadyLayer._fast_ok = lambda self, q: False
-    if kw.get("comp_rank", -1) > 0:
+    if kw.get("comp_rank", -1) > 0 and args.pin_start:
         lowrank.set_init_q(torch.randn(H * D, kw["comp_rank"], generator=torch.Generator().manual_seed(3)))
     torch.cuda.synchronize()
 
