@@ -360,13 +360,13 @@ def lr_decompress_batch(quantized: bool, packets, bases, recons, N: int, C: int,
 def binary_rank_packet_halves(N: int, C: int, rank: int) -> int:
     n = _lib.load().cfx_binary_rank_packet_bytes(N, C, rank)
     if n == 0:
-        raise ValueError(f"invalid shape / rank for the rank-K 1-bit codec: ({N}, {C}), rank {rank} (1..8)")
+        raise ValueError(f"invalid shape / rank for the rank-K 1-bit codec: ({N}, {C}), rank {rank} (1..32)")
     return n // 2
 
 
 def binary_rank_compress_batch(xs, bases, new_bases, packets, init_qs, N: int, C: int, rank: int, update_cache: bool = True,
                                ef: bool = True, stream: Optional[torch.cuda.Stream] = None) -> None:
-    """bits + rank-K scale factors of |x - base| (+ error-feedback state) for a batch; init_q_i: (C, 8) fp32, columns >= rank zero."""
+    """bits + rank-K scale factors of |x - base| (+ error-feedback state) for a batch; init_q_i: (C, lr_rank_pad(rank)) fp32, columns >= rank zero."""
     B = len(xs)
     if not (1 <= B <= CFX_MAX_BATCH):
         raise ValueError(f"batch {B} out of range 1..{CFX_MAX_BATCH}")
@@ -378,8 +378,8 @@ def binary_rank_compress_batch(xs, bases, new_bases, packets, init_qs, N: int, C
     for i in range(B):
         _check_nc(xs[i], N, C, "x")
         q = init_qs[i]
-        if q.dtype != torch.float32 or tuple(q.shape) != (C, 8) or not q.is_contiguous():
-            raise ValueError(f"init_q must be a contiguous fp32 ({C}, 8) tensor")
+        if q.dtype != torch.float32 or tuple(q.shape) != (C, lr_rank_pad(rank)) or not q.is_contiguous():
+            raise ValueError(f"init_q must be a contiguous fp32 ({C}, {lr_rank_pad(rank)}) tensor")
         items[i] = CompItem(_ptr(xs[i]), _ptr(bases[i]), _ptr(new_bases[i]) if update_cache else None, _ptr(packets[i]))
         qptr[i] = q.data_ptr()
     need = lib.cfx_binary_rank_workspace_bytes(N, C, rank, B)

@@ -26,7 +26,7 @@ def _cat_packet(*parts):
 
 # ---- 1 bit -------------------------------------------------------------------------------------------------------
 def quantize_1bit(input_tensor: torch.Tensor, rank):
-    """-> packed (N, C//8) uint8, scale_u (N,K), scale_v (K,C)   (rank = -1: K = 1 mean scales; rank 1..8: rank-K factors of |x|,
+    """-> packed (N, C//8) uint8, scale_u (N,K), scale_v (K,C)   (rank = -1: K = 1 mean scales; rank 1..32: rank-K factors of |x|,
     compress_quantize.py:37-49 - note V is (K, C) here and (C, K) in the fastpath wire)."""
     assert rank >= 1 or rank == -1, "Rank must be >= 1 or -1"
     x = _nc(input_tensor)
@@ -35,7 +35,7 @@ def quantize_1bit(input_tensor: torch.Tensor, rank):
     if rank != -1:
         from . import lowrank
         pkt = torch.empty(codecs.binary_rank_packet_halves(N, C, rank), dtype=torch.float16, device=x.device)
-        codecs.binary_rank_compress_batch([x], [None], [None], [pkt], [lowrank._start(C, rank, x.device, 8)], N, C, rank, update_cache=False)
+        codecs.binary_rank_compress_batch([x], [None], [None], [pkt], [lowrank._start(C, rank, x.device)], N, C, rank, update_cache=False)
         qh = N * C // 16
         return (pkt[:qh].view(torch.uint8).view(N, C // 8), pkt[qh:qh + N * rank].view(N, rank),
                 pkt[qh + N * rank:].view(C, rank).t().contiguous())

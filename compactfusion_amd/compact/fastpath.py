@@ -43,7 +43,7 @@ def _dequant(cid, per_byte, packed, u, v, base):
 
 @Profiler.prof_func("compact.binary_quant_fastpath")
 def binary_quant_fastpath(x_tensor_nc: torch.Tensor, base_tensor_nc: torch.Tensor, rank: int, update_cache: bool):
-    """-> packed (N, C//8) uint8, scale_u (N,K), scale_v (C,K), new_base (N,C) | None.   rank -1 (K = 1: mean scales) or 1..8."""
+    """-> packed (N, C//8) uint8, scale_u (N,K), scale_v (C,K), new_base (N,C) | None.   rank -1 (K = 1: mean scales) or 1..32."""
     assert rank >= 1 or rank == -1, "Rank must be >= 1 or -1"
     _check(x_tensor_nc, base_tensor_nc)
     if rank != -1:
@@ -53,7 +53,7 @@ def binary_quant_fastpath(x_tensor_nc: torch.Tensor, base_tensor_nc: torch.Tenso
         N, C = x.shape
         pkt = torch.empty(codecs.binary_rank_packet_halves(N, C, rank), dtype=torch.float16, device=x.device)
         nb = torch.empty_like(x) if update_cache else None
-        codecs.binary_rank_compress_batch([x], [base], [nb], [pkt], [lowrank._start(C, rank, x.device, 8)], N, C, rank, update_cache=update_cache)
+        codecs.binary_rank_compress_batch([x], [base], [nb], [pkt], [lowrank._start(C, rank, x.device)], N, C, rank, update_cache=update_cache)
         qh = N * (C // 8) // 2
         return pkt[:qh].view(torch.uint8).view(N, C // 8), pkt[qh:qh + N * rank].view(N, rank), pkt[qh + N * rank:].view(C, rank), nb
     return _quant(_BIN, 8, x_tensor_nc, base_tensor_nc, update_cache)

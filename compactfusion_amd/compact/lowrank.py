@@ -61,7 +61,7 @@ def compress(cid: int, rank: int, x: torch.Tensor, base: Optional[torch.Tensor],
              packet: torch.Tensor, update: bool, ef: bool = True) -> None:
     N, C = x.shape
     if cid == BINARY_RANK_ID:
-        codecs.binary_rank_compress_batch([x], [base], [new_base if update else None], [packet], [_start(C, rank, x.device, 8)], N, C, rank,
+        codecs.binary_rank_compress_batch([x], [base], [new_base if update else None], [packet], [_start(C, rank, x.device)], N, C, rank,
                                           update_cache=update, ef=ef)
         return
     codecs.lr_compress_batch(cid == LOW_RANK_Q_ID, [x], [base], [new_base if update else None], [packet],

@@ -144,7 +144,7 @@ def _native(compress_type: T) -> Tuple[int, int]:
         rank = _config.comp_rank
         if rank is not None and rank != -1:
             assert ALLOW_DEPRECATED, "Binary compression with rank != -1 is deprecated"      # main.py:188-189
-            assert 1 <= rank <= 8, "1-bit with subspace-iteration scales: comp_rank must be 1..8"
+            assert 1 <= rank <= 32, "1-bit with subspace-iteration scales: comp_rank must be 1..32 (the factor chain's limit)"
             from . import lowrank
             return lowrank.BINARY_RANK_ID, int(rank)
         return int(codecs.Codec.BINARY), 0

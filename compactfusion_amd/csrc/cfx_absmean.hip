@@ -298,7 +298,8 @@ __global__ __launch_bounds__(NTHR) void k_binary_dequant(BatchD batch, int N, in
 //   out = base + (2 b - 1) * scale                                 wire [ bits N*C/8 | U N*K | V C*K ]   (main.py:149-152)
 // (Triton's tl.sum adds the fp16 products in fp16 in an unspecified tree order; here they are added in fp32 in index order and
 // rounded once - equal for K = 1, within an ulp otherwise; sender and receiver run this same arithmetic on the same fp16 factors.)
-// QUANT: x and the factor workspace in, bits + factors + new state out; else packet in, reconstruction out.  K <= 8.
+// QUANT: x and the factor workspace in, bits + factors + new state out; else packet in, reconstruction out.  K <= 32 (the factor chain's
+// limit), eight factors at a time: the partial sums of a thread's rows x 8 channels stay in registers between the chunks.
 // ---------------------------------------------------------------------------------------------------
 struct RankFac { const h16* U[CFX_MAX_BATCH]; const h16* VT[CFX_MAX_BATCH]; };
 template <bool QUANT>
@@ -316,24 +317,45 @@ __global__ __launch_bounds__(NTHR) void k_binary_rank(BatchC bc, BatchD bd, Rank
     h16* out = QUANT ? (h16*)bc.it[z].new_base : (h16*)bd.it[z].recon;
     const bool upd = QUANT ? ((flags & CFX_FLAG_UPDATE_CACHE) && out) : true;
     const bool ef = !(flags & CFX_FLAG_NO_EF);
-    h16 v[8][8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[e][k] = (t.act && k < K) ? VT[(size_t)(t.c + e) * K + k] : (h16)0;
     if (QUANT) {
         // the factors go into the packet as they are: V by the first row block, U by the first column block
         if (blockIdx.y == 0 && t.act)
             for (int e = 0; e < 8; ++e)
-                for (int k = 0; k < K; ++k) Vp[(size_t)(t.c + e) * K + k] = v[e][k];
+                for (int k = 0; k < K; ++k) Vp[(size_t)(t.c + e) * K + k] = VT[(size_t)(t.c + e) * K + k];
         if (blockIdx.x == 0)
             for (int i = threadIdx.x; i < (t.r1 - t.r0) * K; i += NTHR) Up[(size_t)t.r0 * K + i] = U[(size_t)t.r0 * K + i];
     }
-    for (int r = t.r0 + t.w; r < t.r1; r += WAVES) {
-        if (!t.act) continue;
-        h16 u[8];
+    if (!t.act) return;
+    // scale[r][e] = fp16( sum_k fp32( fp16(U[r,k] * V[c+e,k]) ) ), k in index order: chunks of 8 factors, the sums carried across
+    constexpr int RPT = UNROLL;                                     // rows of the tile a wave visits (the launches use R = WAVES * UNROLL)
+    float acc[RPT][8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) u[k] = (k < K) ? U[(size_t)r * K + k] : (h16)0;
+    for (int j = 0; j < RPT; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        h16 v[8][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[e][k] = (k0 + k < K) ? VT[(size_t)(t.c + e) * K + k0 + k] : (h16)0;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int r = t.r0 + t.w + j * WAVES;
+            if (r >= t.r1) continue;
+            h16 u[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) u[k] = (k0 + k < K) ? U[(size_t)r * K + k0 + k] : (h16)0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[j][e] += (float)(h16)(u[k] * v[e][k]);   // fp16 product (one rounding), fp32 sum in index order
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const int r = t.r0 + t.w + j * WAVES;
+        if (r >= t.r1) continue;
         h16x8 bv = (h16x8)(h16)0, xv = (h16x8)(h16)0;
         if (base) bv = ld8(base + (size_t)r * C + t.c);
         unsigned byte;
@@ -349,10 +371,7 @@ __global__ __launch_bounds__(NTHR) void k_binary_rank(BatchC bc, BatchD bd, Rank
         h16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float acc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc += (float)(h16)(u[k] * v[e][k]);       // fp16 product (one rounding), fp32 sum in index order
-            const h16 sc = (h16)acc;
+            const h16 sc = (h16)acc[j][e];
             const h16 recv = ((byte >> e) & 1u) ? sc : -sc;
             o[e] = base ? (h16)(bv[e] + recv) : recv;
         }
@@ -1691,7 +1710,7 @@ int cfx_i_launch_pipe(cfx_plan* p, hipStream_t s, int N, int C, const int* comp_
 extern "C" {
 
 size_t cfx_binary_rank_packet_bytes(int N, int C, int rank) {
-    if (N <= 0 || C <= 0 || (C % 8) || rank < 1 || rank > 8 || (((size_t)N * (C / 8)) % 2)) return 0;
+    if (N <= 0 || C <= 0 || (C % 8) || rank < 1 || rank > 32 || (((size_t)N * (C / 8)) % 2)) return 0;
     return (size_t)N * C / 8 + 2 * ((size_t)N + C) * rank;
 }
 
@@ -1704,7 +1723,7 @@ int cfx_binary_rank_compress_batch(cfx_ctx* ctx, int N, int C, int rank, int fla
                                    const void* const* init_q, void* workspace, size_t workspace_bytes, void* stream) {
     if (!ctx || !items || !init_q) return fail(ctx, CFX_ERR_NULL, "binary rank-K compress: null ctx/items/init_q");
     if (batch < 1 || batch > CFX_MAX_BATCH) return fail(ctx, CFX_ERR_BATCH, "binary rank-K compress: batch out of range");
-    if (!cfx_binary_rank_packet_bytes(N, C, rank)) return fail(ctx, CFX_ERR_SHAPE, "binary rank-K compress: bad shape / rank (1 .. 8)");
+    if (!cfx_binary_rank_packet_bytes(N, C, rank)) return fail(ctx, CFX_ERR_SHAPE, "binary rank-K compress: bad shape / rank (1 .. 32)");
     const size_t need = cfx_binary_rank_workspace_bytes(N, C, rank, batch);
     if (!workspace || workspace_bytes < need) return fail(ctx, CFX_ERR_WORKSPACE, "binary rank-K compress: workspace too small");
     const bool upd = flags & CFX_FLAG_UPDATE_CACHE;
@@ -1742,7 +1761,7 @@ int cfx_binary_rank_compress_batch(cfx_ctx* ctx, int N, int C, int rank, int fla
 int cfx_binary_rank_decompress_batch(cfx_ctx* ctx, int N, int C, int rank, int batch, const cfx_decomp_item* items, void* stream) {
     if (!ctx || !items) return fail(ctx, CFX_ERR_NULL, "binary rank-K decompress: null ctx/items");
     if (batch < 1 || batch > CFX_MAX_BATCH) return fail(ctx, CFX_ERR_BATCH, "binary rank-K decompress: batch out of range");
-    if (!cfx_binary_rank_packet_bytes(N, C, rank)) return fail(ctx, CFX_ERR_SHAPE, "binary rank-K decompress: bad shape / rank (1 .. 8)");
+    if (!cfx_binary_rank_packet_bytes(N, C, rank)) return fail(ctx, CFX_ERR_SHAPE, "binary rank-K decompress: bad shape / rank (1 .. 32)");
     BatchD b;
     memset(&b, 0, sizeof(b));
     for (int i = 0; i < batch; ++i) {

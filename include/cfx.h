@@ -243,7 +243,8 @@ int    cfx_lr_decompress_batch(cfx_ctx* ctx, int quantized, int N, int C, int ra
  *                                    (compress_quantize.py:37-49)
  *   cfx_binary_rank_decompress_batch replaces binary_dequant_fastpath (fastpath.py:371-438, K-loop :330-360) / dequantize_1bit
  * scale[n, c] = fp16(sum_k fp16(U[n,k] * V[c,k])), out = base + (2 b - 1) * scale.  Wire [ bits N*C/8 | U (N,K) fp16 | V (C,K) fp16 ]
- * (main.py:149-152).  rank 1 .. 8; init_q[i] as for cfx_lr_compress_batch (device C x 8 fp32, columns >= rank zero). */
+ * (main.py:149-152).  rank 1 .. 32 (the reference's Triton kernels take the powers of two, fastpath.py:91 tl.arange(0, RANK); 32 is the
+ * factor chain's limit); init_q[i] as for cfx_lr_compress_batch (device C x {8, 16, 32} fp32 - the rank rounded up -, columns >= rank zero). */
 size_t cfx_binary_rank_packet_bytes(int N, int C, int rank);
 size_t cfx_binary_rank_workspace_bytes(int N, int C, int rank, int batch);
 int    cfx_binary_rank_compress_batch(cfx_ctx* ctx, int N, int C, int rank, int flags, int batch, const cfx_comp_item* items,

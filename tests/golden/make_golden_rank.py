@@ -5,7 +5,10 @@ parametrises (tests/compact/compress_fastpath_test.py:45-101) - on the G1 input 
 rank, 2)` whose start matrix is the first `torch.randn(C, rank)` after `torch.manual_seed(SEED_Q)` (compress_lowrank.py:41); it is
 stored, so the oracle and the HIP path can start from the same span.  Deprecated branch in the reference (main.py:188-189).
 
-usage: TORCHDYNAMO_DISABLE=1 TRITON_INTERPRET=1 python tests/golden/make_golden_rank.py
+`wide` writes g1c_binary_rank_wide.npz: ranks 16 and 32 - the reference's Triton kernels take any power of two (fastpath.py:91
+tl.arange(0, RANK)); 32 is this repo's factor-chain limit - on one shape each, so the file stays small.
+
+usage: TORCHDYNAMO_DISABLE=1 TRITON_INTERPRET=1 python tests/golden/make_golden_rank.py [wide]
 """
 import os
 import sys
@@ -41,10 +44,12 @@ def main():
     Profiler.instance().disable()
     from xfuser.compact.fastpath import binary_dequant_fastpath, binary_quant_fastpath
     res = {}
-    for (N, C) in [(64, 256), (256, 1152)]:
-        for seed in (42, 43):
+    wide = len(sys.argv) > 1 and sys.argv[1] == "wide"
+    cases = [((64, 256), (42,), (16, 32)), ((128, 1152), (43,), (16,))] if wide else [((64, 256), (42, 43), (1, 4)), ((256, 1152), (42, 43), (1, 4))]
+    for (N, C), seeds, ranks in cases:
+        for seed in seeds:
             x, base = gen_inputs(seed, N, C)
-            for rank in (1, 4):
+            for rank in ranks:
                 tag = f"{N}x{C}_s{seed}/r{rank}"
                 torch.manual_seed(SEED_Q + rank)
                 q0 = torch.randn(C, rank, dtype=torch.float)              # what subspace_iter is about to draw
@@ -58,7 +63,7 @@ def main():
                 res[f"{tag}/v"] = np16(v)
                 res[f"{tag}/new_base"] = np16(nb)
                 print("G1b", tag, "scale rel. to |d| mean:", float((u.float() @ v.float().t()).mean() / (x - base).abs().float().mean()), flush=True)
-    np.savez_compressed(os.path.join(HERE, "g1b_binary_rank.npz"), **res)
+    np.savez_compressed(os.path.join(HERE, "g1c_binary_rank_wide.npz" if wide else "g1b_binary_rank.npz"), **res)
 
 
 if __name__ == "__main__":

@@ -3,7 +3,9 @@ deprecated in the reference, main.py:188-189, but its own test parametrises rank
 Golden group G1b (tests/golden/make_golden_rank.py) holds the reference's packed bits, U, V, new_base for ranks 1 and 4 and the start
 matrix its subspace iteration drew.  Parity: sign bits bit-exact; the scale matrix U V^T within 3e-3 (the low-rank tolerance: the result
 depends on GEMM / QR rounding order); the new state within 1e-3 of the reference's; decoding the REFERENCE's packet with the receiver
-kernel reproduces the reference's state (an ulp on few entries: the reference adds the K fp16 products in fp16, tree order unspecified)."""
+kernel reproduces the reference's state (an ulp on few entries: the reference adds the K fp16 products in fp16, tree order unspecified).
+Group G1c (`make_golden_rank.py wide`): ranks 16 and 32 - the reference's Triton kernels take any power of two (fastpath.py:91), this repo
+up to the factor chain's 32 (until round 6: 8)."""
 import os
 
 import numpy as np
@@ -14,7 +16,9 @@ from oracle import ref_np as R
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden", "g1b_binary_rank.npz")
-CASES = [(N, C, seed, r) for (N, C) in ((64, 256), (256, 1152)) for seed in (42, 43) for r in (1, 4)]
+GOLD_WIDE = os.path.join(HERE, "golden", "g1c_binary_rank_wide.npz")
+WIDE = [(64, 256, 42, 16), (64, 256, 42, 32), (128, 1152, 43, 16)]
+CASES = [(N, C, seed, r) for (N, C) in ((64, 256), (256, 1152)) for seed in (42, 43) for r in (1, 4)] + WIDE
 F16 = np.float16
 
 
@@ -31,7 +35,7 @@ def _rel(a, b):
 
 
 def _gold(tag, name):
-    g = np.load(GOLD)
+    g = np.load(GOLD_WIDE if int(tag.rsplit("/r", 1)[1]) > 8 else GOLD)
     a = g[f"{tag}/{name}"]
     return a.view(F16) if a.dtype == np.uint16 else a
 
@@ -49,7 +53,7 @@ def test_oracle_vs_reference(N, C, seed, r):
     # the receiver arithmetic on the reference's own factors: the reference's state up to the order its fp16 sum takes
     mine = R.binary_rank_apply(base.numpy(), R.unpack_bits_1(_gold(tag, "packed")), gu, gv)
     d = np.abs(mine.astype(np.float32) - gnb.astype(np.float32))
-    assert d.max() <= 2e-3 and (d > 0).mean() <= (0.0 if r == 1 else 0.05), (d.max(), (d > 0).mean())
+    assert d.max() <= 2e-3 and (d > 0).mean() <= (0.0 if r == 1 else (0.05 if r <= 4 else 0.15)), (d.max(), (d > 0).mean())
 
 
 @pytest.mark.gpu
@@ -80,12 +84,13 @@ def test_hip_vs_reference_and_oracle(N, C, seed, r):
     rec_ref = FP.binary_dequant_fastpath(torch.from_numpy(_gold(tag, "packed")).cuda(), torch.from_numpy(gu.copy()).cuda(),
                                          torch.from_numpy(gv.copy()).cuda(), base.cuda())
     d = (rec_ref.float().cpu() - torch.from_numpy(gnb.astype(np.float32))).abs()
-    assert float(d.max()) <= 2e-3 and float((d > 0).float().mean()) <= (0.0 if r == 1 else 0.05)
+    assert float(d.max()) <= 2e-3 and float((d > 0).float().mean()) <= (0.0 if r == 1 else (0.05 if r <= 4 else 0.15))
 
 
 @pytest.mark.gpu
-def test_state_machine_with_rank_scales(monkeypatch, tmp_path):
-    """compact_compress / compact_decompress with BINARY, comp_rank = 4 (COMPACT_ALLOW_DEPRECATED): sender and receiver states stay
+@pytest.mark.parametrize("rank", [4, 16])
+def test_state_machine_with_rank_scales(monkeypatch, tmp_path, rank):
+    """compact_compress / compact_decompress with BINARY, comp_rank = 4 / 16 (COMPACT_ALLOW_DEPRECATED): sender and receiver states stay
     bit-identical over error-feedback steps, and the slow-path wire [q | U (N,K) | V (K,C)] round-trips."""
     import compactfusion_amd.compact.main as cm
     from compactfusion_amd.collector import collector
@@ -93,21 +98,21 @@ def test_state_machine_with_rank_scales(monkeypatch, tmp_path):
     from compactfusion_amd.compact.slowpath import slowpath_compress, slowpath_decompress
     collector.init(collector.Collector(str(tmp_path), enabled=False))
     monkeypatch.setattr(cm, "ALLOW_DEPRECATED", True)
-    cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: None, residual=1, ef=True, fastpath=True, comp_rank=4))
+    cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: None, residual=1, ef=True, fastpath=True, comp_rank=rank))
     g = torch.Generator().manual_seed(3)
     cur = torch.randn(1, 64, 8, 64, generator=g).half()
     for t in range(4):
         typ = T.WARMUP if t == 0 else T.BINARY
         pkt = cm.compact_compress("0-0-k", cur.cuda(), typ, update_cache=True)
         if t:
-            assert pkt.numel() == 64 * 512 // 16 + (64 + 512) * 4
+            assert pkt.numel() == 64 * 512 // 16 + (64 + 512) * rank
         rec = cm.compact_decompress("0-1-k", pkt.clone(), typ, (1, 64, 8, 64), update_cache=True)
         assert torch.equal(cm.compact_cache().get_base("0-0-k"), cm.compact_cache().get_base("0-1-k")), f"step {t}: sender / receiver diverged"
         err = float((rec.float().cpu() - cur.float()).norm() / cur.float().norm())
         assert err < (1e-6 if t == 0 else 0.12)
         cur = (cur.float() + 0.1 * torch.randn(1, 64, 8, 64, generator=g)).half()
     x = torch.randn(128, 256, generator=g).half().cuda()
-    p = slowpath_compress(x, T.BINARY, rank=4)
-    assert p.numel() == 128 * 256 // 16 + (128 + 256) * 4
-    d = slowpath_decompress(p, (128, 256), T.BINARY, rank=4)
+    p = slowpath_compress(x, T.BINARY, rank=rank)
+    assert p.numel() == 128 * 256 // 16 + (128 + 256) * rank
+    d = slowpath_decompress(p, (128, 256), T.BINARY, rank=rank)
     assert float((d.float() - x.float()).norm() / x.float().norm()) < 0.75 and torch.isfinite(d.float()).all()
