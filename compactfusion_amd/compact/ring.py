@@ -80,7 +80,7 @@ def compact_fwd(q, k, v, dropout_p=0, softmax_scale=None, causal=True, window_si
     # lane's compute stream is put there for the duration of the call (configure(lane="auto"): forked from and joined to its own stream
     # by flag kernels) or for good (lane="sticky"); lane="off" keeps the exchange as one op on the caller's stream.
     token = dev = key = None
-    if q.is_cuda and _auto_lane(q, group) and _lane_has_chain(mod_idx, current_iter):
+    if q.is_cuda and _auto_lane(q, group) and _lane_has_chain(mod_idx, current_iter, group):
         from .. import lanes
         dev = q.device.index if q.device.index is not None else torch.cuda.current_device()
         key = (mod_idx, id(group) if group is not None else None)
@@ -104,17 +104,26 @@ def compact_fwd(q, k, v, dropout_p=0, softmax_scale=None, causal=True, window_si
             lanes.join_from_compute(dev, token)
 
 
-def _lane_has_chain(mod_idx, current_iter) -> bool:
+def _lane_has_chain(mod_idx, current_iter, group=None) -> bool:
     """The exchange lane runs the layer's chain of the STREAMING codecs (compress ; all-gather ; per-peer reconstruction, flag-ordered
-    against the attention blocks).  The low-rank family has no lane chain - its factor chain is one persistent launch that wants the
-    whole chip - so a LOW_RANK / LOW_RANK_Q layer keeps the caller's stream and takes the one-call layer op there (round 6: on the lane
-    it fell through to one Python call per tensor, 25 ms per FLUX step)."""
+    against the attention blocks).  The low-rank family's factor chain is one persistent launch that wants the whole chip: it has no
+    chain of that kind.  A LOW_RANK / LOW_RANK_Q layer goes to the lane once it is a steady layer whose one-call layer op can leave the
+    peers' reconstructions to the exchange lane (xlayer.LayerOp.lane_capable: peer-to-peer transport, configure(lowrank_lane="on")) -
+    the factor chain then runs on the compute lane, exposed, the reconstructions beside the attention blocks; otherwise it keeps the
+    caller's stream and takes the one-call layer op there (round 6: on the lane it fell through to one Python call per tensor, 25 ms per
+    FLUX step)."""
     cfg = compact_config()
     try:
         ctype = cfg.compress_func(mod_idx, current_iter if current_iter is not None else cm.compact_get_step())
     except Exception:  # noqa: BLE001  (a compress_func that needs arguments this call does not have: the forward itself will say so)
         return True
-    return ctype not in (COMPACT_COMPRESS_TYPE.LOW_RANK, COMPACT_COMPRESS_TYPE.LOW_RANK_Q)
+    if ctype not in (COMPACT_COMPRESS_TYPE.LOW_RANK, COMPACT_COMPRESS_TYPE.LOW_RANK_Q):
+        return True
+    # (... and only while the steady layer is what will run: with the profiler's scopes or a live collector the general path takes the
+    # call, which runs the layer op in stream order - it would pay the hand-over for nothing)
+    st = _steady.get((mod_idx, id(group) if group is not None else None))
+    return (st is not None and st.ctype is ctype and st.ex.xop is not None and st.ex.xop.lane_capable()
+            and not _profiler.enabled and not _collector_live())
 
 
 _lane_ok = {}        # (device, id(group)) -> world size >= 2 and the lane's streams usable: asked once, not on every layer call
@@ -300,8 +309,21 @@ class _SteadyLayer:
         sh = torch.cuda.current_stream(q.device).cuda_stream
         if ex.xop is not None:
             # ONE native call: the layer's whole exchange on this stream, then the blocks over own K,V and the peers' states
-            ex.xop.run(k, v, sh)
+            xop = ex.xop
+            epoch = None
+            if xop.lowrank and xop.lane_capable():
+                from .. import lanes
+                dev = q.device.index if q.device.index is not None else torch.cuda.current_device()
+                if lanes.on_compute_stream(dev):
+                    # low-rank family on the lane: the factor chain + publish-and-wait here, the peers' reconstructions on the exchange lane
+                    epoch = xop.run(k, v, sh, lane=True)
+                else:
+                    xop.run(k, v, sh)
+            else:
+                xop.run(k, v, sh)
             cm._current_cache_key = self.last_key
+            if epoch is not None:
+                return self._lowrank_lane_blocks(q, k, v, softmax_scale, sh, epoch)
             if self._fast_ok(q):
                 sdpa, merge, ctx = self._sdpa, self._merge, self._ctx
                 B, S, H, D = q.shape
@@ -377,6 +399,44 @@ class _SteadyLayer:
             bo, bl = block_attention(q, kk, vv, 0.0, softmax_scale, causal=False)
             out, lse = update_out_and_lse(out, lse, bo, bl)
         return out.to(q.dtype), lse.squeeze(dim=-1).transpose(1, 2), None
+
+
+def _lowrank_lane_blocks(self, q, k, v, softmax_scale, sh, epoch):
+    """The attention blocks of a low-rank layer whose peers are being reconstructed on the exchange lane: the local block first (the
+    chain's launches are issued while it runs), then peer s's block behind a merge launch that waited in-kernel for peer s's flag."""
+    xop = self.ex.xop
+    last = self.world - 1
+    if self._fast_ok(q):
+        sdpa, merge, ctx = self._sdpa, self._merge, self._ctx
+        B, S, H, D = q.shape
+        qt = q.transpose(1, 2)
+        res = sdpa(qt, k.transpose(1, 2), v.transpose(1, 2), 0.0, False, False, scale=softmax_scale)
+        xop.lane_chain(1, 2)                           # peers 1 and 2 while the local block runs, peer s + 2 behind peer s's block
+        out = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
+        lse = torch.empty((B, S, H, 1), dtype=torch.float32, device=q.device)
+        op, lp = out.data_ptr(), lse.data_ptr()
+        if merge(ctx, op, lp, res[0].data_ptr(), res[1].data_ptr(), B, S, H, D, 1, 1, xop.lane_flag(1), epoch, sh) != 0:
+            raise RuntimeError("cfx_attn_merge_wait failed: " + (xop.lib.cfx_last_error_string(ctx) or b"").decode())
+        keep = [res]
+        for s_, (kt, vt) in enumerate(self._peer_t, start=1):
+            res = sdpa(qt, kt, vt, 0.0, False, False, scale=softmax_scale)
+            keep.append(res)
+            xop.lane_chain(s_ + 2, 1)
+            if merge(ctx, op, lp, res[0].data_ptr(), res[1].data_ptr(), B, S, H, D, 1, 0,
+                     None if s_ == last else xop.lane_flag(s_ + 1), epoch, sh) != 0:
+                raise RuntimeError("cfx_attn_merge_wait failed: " + (xop.lib.cfx_last_error_string(ctx) or b"").decode())
+        return out.to(q.dtype), lse.squeeze(dim=-1).transpose(1, 2), None
+    bo, bl = block_attention(q, k, v, 0.0, softmax_scale, causal=False)
+    xop.lane_chain(1, 2)
+    out, lse = update_out_and_lse(None, None, bo, bl, wait=(xop.lane_flag(1), epoch))
+    for s_, (kk, vv) in enumerate(self.ex.peer_views, start=1):
+        bo, bl = block_attention(q, kk, vv, 0.0, softmax_scale, causal=False)
+        xop.lane_chain(s_ + 2, 1)
+        out, lse = update_out_and_lse(out, lse, bo, bl, wait=None if s_ == last else (xop.lane_flag(s_ + 1), epoch))
+    return out.to(q.dtype), lse.squeeze(dim=-1).transpose(1, 2), None
+
+
+_SteadyLayer._lowrank_lane_blocks = _lowrank_lane_blocks
 
 
 def _exchange_stream(device) -> "torch.cuda.Stream":
@@ -541,7 +601,9 @@ class _LayerExchange:
         if xmode not in ("auto", "xlayer") or not xlayer.usable(cid, self.world, self.send.is_cuda, ef=ef):
             return False
         dev = self.send.device.index if self.send.device.index is not None else torch.cuda.current_device()
-        return xmode == "xlayer" or not lanes.on_compute_stream(dev)
+        # (the low-rank family has no chain of its own on the lane: on the compute stream too it takes the layer op, which leaves the peers'
+        # reconstructions to the exchange lane - xlayer.LayerOp.run(lane=True))
+        return xmode == "xlayer" or cid >= 100 or not lanes.on_compute_stream(dev)
 
     def close(self):
         """Release what the layer holds outside torch's allocator: native plans and (legacy CFX_RING_P2P chain) its IPC buffer + mappings."""

@@ -457,6 +457,10 @@ class LayerOp:
 
     # ---- plans -----------------------------------------------------------------------------------------------------
     def _drop_plans(self) -> None:
+        ln = getattr(self, "_lane", None)
+        if ln is not None:
+            self.lib.cfx_plan_destroy(ln["plan"])
+            self._lane = None
         for plan, _ in getattr(self, "_plans", {}).values():
             self.lib.cfx_plan_destroy(plan)
         self._plans = {}
@@ -616,8 +620,12 @@ class LayerOp:
         return self._solo
 
     # ---- run -------------------------------------------------------------------------------------------------------
-    def run(self, k: torch.Tensor, v: torch.Tensor, sh: int) -> None:
-        """The layer's exchange on the stream with handle `sh` (the caller's current stream): ONE native call."""
+    def run(self, k: torch.Tensor, v: torch.Tensor, sh: int, lane: bool = False) -> Optional[int]:
+        """The layer's exchange on the stream with handle `sh` (the caller's current stream): ONE native call.
+        lane = True (low-rank family on the peer-to-peer transport, the caller on the exchange lane's compute stream): only the factor chain
+        runs on `sh`; the publish-and-wait and the reconstructions of the peers are left to `lane_chain()`, which puts them on the exchange
+        lane behind a flag published here - the epoch the caller's merge launches wait for is returned.  None: everything ran in stream
+        order on `sh` (a validated execution, another transport), nothing is left to wait for."""
         ent = self._plans.get(sh)
         if ent is None:
             ent = self._build(sh)
@@ -634,7 +642,7 @@ class LayerOp:
                 self.region.recheck = 0
                 self.fallback_reason = self.arena.why
                 self._choose_transport(exclude=("p2p",))
-                return self.run(k, v, sh)
+                return self.run(k, v, sh, lane)
             reg = self.region
             if not self.arena.loopback:
                 if self.arena.health.boundary(_current_step(), self.key):
@@ -653,7 +661,8 @@ class LayerOp:
             self._draw_start(sh)
         xs = self._xs
         xs[0], xs[1] = k.data_ptr(), v.data_ptr()
-        nops = self.nops
+        split = lane and self.lowrank and t == "p2p" and self.nops == 3
+        nops = 1 if split else self.nops          # (lane: the factor chain only - the publish-and-wait opens the lane's chain instead)
         rc = self._run_x(ent[0], op, nops, xs, 2, sh)
         if rc == _lib.CFX_ERR_GATE and t == "p2p" and not self.arena.loopback:
             # an EARLIER launch's wait gave up (a peer later than the gate timeout): it stored nothing.  Clear the word, tell the group at
@@ -670,6 +679,73 @@ class LayerOp:
             rc = self._run(ent[0], 1, 1, sh)
         if rc != 0:
             raise _lib.CfxError("the layer exchange op failed: " + (self.lib.cfx_last_error_string(self.ctx) or b"").decode())
+        return self._lane_begin(op // self.nops, sh) if split else None
+
+    # ---- the low-rank layer beside the attention blocks (protocol 2) ---------------------------------------------------------------
+    # The factor chain is one persistent launch that wants the chip: it stays on the caller's (compute-lane) stream, exposed.  The
+    # reconstruction of the 7 peers' K,V - 14 tensors read and written, as long as the chain itself at rank 8 - needs nothing but the
+    # packets: it runs on the exchange lane, peer by peer in the order the attention blocks visit them, each peer's flag waited for
+    # inside the merge launch of the block in front of it (the streaming codecs' lane, compact/ring.py, with the compress left where it is).
+    def lane_capable(self) -> bool:
+        return self.lowrank and self.transport == "p2p" and self.nops == 3 and _settings.get("lowrank_lane") == "on"
+
+    def _build_lane(self):
+        from .. import lanes
+        lib, q, N, C, rank = self.lib, int(self.quantized), self.N, self.C, self.param
+        plan = lib.cfx_plan_create(self.ctx)
+        self._check(bool(plan), "lane plan")
+        xstream = lanes.exchange_stream(self.dev)
+        self._check(lib.cfx_plan_use_exchange_stream(plan, xstream.cuda_stream) == 0, "lane stream")
+        n_peers = len(self.peers)
+        flags = lib.cfx_plan_flags(plan, n_peers + 1)            # 0: own packets complete (compute lane) ; s = 1 .. W-1: peer s reconstructed
+        self._check(bool(flags), "lane flags")
+        wsn = int(lib.cfx_lr_workspace_bytes(q, N, C, rank, 2))
+        ws = torch.empty(max(wsn, 16), dtype=torch.uint8, device=self.device)
+        keep = [ws, xstream]
+        reg = self.region
+        per = 2 + 2 * n_peers
+        live = sorted({r for r, _, _ in self.peers}) if not self.arena.loopback else []
+        for parity in (0, 1):
+            self._check(lib.cfx_plan_add_flag_wait(plan, 0) == parity * per, "lane wait")
+            pf = (ctypes.c_void_p * max(1, len(live)))(*[reg.flag(r, parity) for r in live])
+            keep.append(pf)
+            self._check(lib.cfx_plan_add_p2p_sync(plan, reg.flag(None, parity), len(live), pf) >= 0, "lane p2p sync")
+            for s_, (r, ks, vs) in enumerate(self.peers, start=1):
+                arr = (_lib.DecompItem * 2)(_lib.DecompItem(reg.packet(r, parity, 0), ks.data_ptr(), ks.data_ptr()),
+                                            _lib.DecompItem(reg.packet(r, parity, 1), vs.data_ptr(), vs.data_ptr()))
+                keep.append(arr)
+                self._check(lib.cfx_plan_add_lr_decompress(plan, q, N, C, rank, 2, arr, ws.data_ptr(), wsn) >= 0, "lane reconstruct")
+                self._check(lib.cfx_plan_add_flag_set(plan, s_) >= 0, "lane flag")
+        self._check(lib.cfx_plan_finalize(plan) == 0, "lane finalize")
+        self._lane = {"plan": plan, "keep": keep, "flags": int(flags), "per": per, "epoch": ctypes.c_uint(0), "first": 0}
+        return self._lane
+
+    def _lane_begin(self, parity: int, sh: int) -> int:
+        ln = getattr(self, "_lane", None) or self._build_lane()
+        ln["first"] = parity * ln["per"]
+        if self.lib.cfx_plan_lane_begin(ln["plan"], 0, sh, ln["epoch"]) != 0:
+            raise _lib.CfxError("the low-rank layer's lane hand-over failed: " + (self.lib.cfx_last_error_string(self.ctx) or b"").decode())
+        return ln["epoch"].value
+
+    def lane_chain(self, first_peer: int = 1, n_peers: Optional[int] = None) -> None:
+        """After `run(..., lane=True)` returned an epoch: the reconstructions of peers first_peer .. first_peer + n_peers - 1 (in the order
+        the attention blocks visit them, 1-based; default: all) onto the exchange lane.  The caller issues them a few at a time between
+        its attention blocks: the chain is 15 launches at W = 8, and a compute queue that has run dry behind the local block while the
+        host is still issuing them is exposed time (measured: 120 us per layer with the whole chain in one go)."""
+        ln = self._lane
+        total = len(self.peers)
+        if n_peers is None:
+            n_peers = total - first_peer + 1
+        n_peers = min(n_peers, total - first_peer + 1)
+        if n_peers <= 0:
+            return
+        first = ln["first"] + (0 if first_peer == 1 else 2 + 2 * (first_peer - 1))
+        count = 2 * n_peers + (2 if first_peer == 1 else 0)
+        if self.lib.cfx_plan_run_lane(ln["plan"], first, count, None, 0, 0, None, ln["epoch"]) != 0:
+            raise _lib.CfxError("the low-rank layer's lane chain failed: " + (self.lib.cfx_last_error_string(self.ctx) or b"").decode())
+
+    def lane_flag(self, i: int) -> int:
+        return self._lane["flags"] + 64 * i
 
     def _checksums(self, tensors: Sequence[torch.Tensor]) -> torch.Tensor:
         return torch.stack([t.view(torch.int32).sum(dtype=torch.int64) for t in tensors])

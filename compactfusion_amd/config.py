@@ -24,6 +24,9 @@ lane                   CFX_LANE                      auto | sticky | off - how c
                                                      call and stays it (no per-layer hand-over; the rest of the model runs on 224 CUs);
                                                      off = never (the exchange runs as one op on the caller's stream, nothing overlaps)
 lane_exchange_cus      CFX_LANE_EXCHANGE_CUS         CUs of the exchange lane (32); the compute lane gets the rest
+lowrank_lane           CFX_LOWRANK_LANE              on | off - on: a LOW_RANK / LOW_RANK_Q layer keeps its factor chain (one persistent launch that
+                                                     wants the chip) on the compute lane and puts the peers' reconstructions on the exchange lane
+                                                     beside the attention blocks; off: the whole layer op on the caller's stream
 hw_queues              GPU_MAX_HW_QUEUES             hardware queues HIP may give its streams - HIP reads it ONCE when it initialises:
                                                      configure(hw_queues=8) must run before the first CUDA call of the process
 """
@@ -42,6 +45,7 @@ _SETTINGS = {
     "ring_exchange_priority": ("CFX_RING_EXCHANGE_PRIORITY", "-1", None),
     "lane": ("CFX_LANE", "auto", ("auto", "sticky", "off")),
     "lane_exchange_cus": ("CFX_LANE_EXCHANGE_CUS", "32", None),
+    "lowrank_lane": ("CFX_LOWRANK_LANE", "on", ("on", "off")),
 }
 _explicit: Dict[str, str] = {}
 

@@ -283,10 +283,11 @@ def w_hook_layer(rank, world, ulysses, ring, compact_on):
     return res
 
 
-def w_stack(rank, world, codec_name):
+def w_stack(rank, world, codec_name, steady=False):
     """Golden group G13's 4-layer attention stack over two ranks through `compact_fwd` (tests/golden/make_golden_stack.py holds the
     seeded recipe): the stack's final output per step with the compressed exchange and with the exact K,V exchanged (every step
-    WARMUP = raw fp16 through the same ring path)."""
+    WARMUP = raw fp16 through the same ring path).  steady: profiler scopes and collector off - what a production run has - so that the
+    steady layers take the calls (with the defaults of both, as here otherwise, the general path does)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("make_golden_stack", os.path.join(HERE, "golden", "make_golden_stack.py"))
     G = importlib.util.module_from_spec(spec)
@@ -297,6 +298,11 @@ def w_stack(rank, world, codec_name):
     W = [[TD(w) for w in lw] for lw in G.weights()]
     xs = [TD(x) for x in G.inputs(rank)]
     res = {}
+    if steady:
+        from compactfusion_amd.collector import collector
+        from compactfusion_amd.prof import Profiler
+        Profiler.instance().disable()
+        collector.init(collector.Collector("/tmp/none", enabled=False))
 
     def qkv(h, Wl):
         return [(h.float() @ w).half().view(G.B, G.S, G.H, G.D).contiguous() for w in Wl]
@@ -334,6 +340,8 @@ def w_stack(rank, world, codec_name):
     from compactfusion_amd.compact import ring as ring_mod
     ops = [e.xop for e in ring_mod._xbuf.values() if getattr(e, "xop", None) is not None]
     res["timeouts"] = np.array([sum(1 for o in ops if o.fallback_reason is not None) + (1 if DEV != "cpu" and _gate_errors_seen() else 0)])
+    # low-rank family, lane at its default: the steady layers left their peers' reconstructions to the exchange lane (xlayer.LayerOp.run(lane=True))
+    res["lane_ops"] = np.array([sum(1 for o in ops if getattr(o, "_lane", None) is not None)])
     return res
 
 

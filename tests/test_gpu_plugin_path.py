@@ -224,6 +224,77 @@ def test_plugin_call_low_rank_family_one_native_call_per_layer(loop8, api, codec
     assert lib.cfx_gate_errors(ctx) == 0
 
 
+@pytest.mark.parametrize("codec,rank", [("LOW_RANK", 8), ("LOW_RANK_Q", 32)])
+@pytest.mark.parametrize("lane", ["auto", "sticky"])
+def test_low_rank_layer_beside_the_attention_blocks(loop8, monkeypatch, codec, rank, lane):
+    """Protocol 2 for the low-rank family (round 6): with the lane at its default, a steady LOW_RANK / LOW_RANK_Q layer keeps its factor
+    chain (+ publish-and-wait) on the compute lane and leaves the peers' reconstructions to the exchange lane, peer by peer behind flags
+    the merge launches wait for (xlayer.LayerOp.run(lane=True) / lane_chain).  Against the same steps with the lane off (the one-call
+    layer op on the caller's stream): every state bit for bit (same pinned start matrix: the chain's sums do not depend on the stream),
+    the attention output to merge-order tolerance; and the launches say the lane form ran: one reconstruction launch per peer."""
+    ring, cm, xlayer = loop8
+    from compactfusion_amd import _lib, codecs as K, lanes
+    from compactfusion_amd.compact import COMPACT_COMPRESS_TYPE as T, CompactConfig, lowrank
+    lib, ctx = _lib.load(), K.context(0)
+    L, STEPS = 3, 5
+    shape, N, C = (1, 128, 16, 64), 128, 1024
+    qs = [W.drift(7 + l, shape, STEPS) for l in range(L)]
+    ks = [W.drift(17 + l, shape, STEPS) for l in range(L)]
+    vs = [W.drift(27 + l, shape, STEPS) for l in range(L)]
+    dev = torch.device("cuda:0")
+    pinned = torch.randn(C, rank, generator=torch.Generator().manual_seed(5))
+
+    def run(lane_mode):
+        monkeypatch.setenv("CFX_LANE", lane_mode)
+        cm._drop_kv_exchanges()
+        for e in ring._xbuf.values():
+            e.close()
+        ring._xbuf.clear()
+        ring._steady.clear()
+        ring._lane_ok.clear()
+        cm.compact_init(CompactConfig(enabled=True, compress_func=lambda l, s: T.WARMUP if s == 0 else T[codec], comp_rank=rank, residual=1, ef=True, fastpath=False))
+        states, outs, decodes = {}, {}, []
+        lowrank.set_init_q(pinned)
+        caller = torch.cuda.Stream(dev)
+        try:
+            with torch.cuda.stream(caller):
+                for s in range(STEPS):
+                    cm.compact_set_step(s)
+                    torch.cuda.synchronize()
+                    assert lib.cfx_profile_enable(ctx, 8192, 0xffffffff, 1) == 0
+                    for l in range(L):
+                        out, lse, _ = ring.compact_fwd(qs[l][s].to(dev), ks[l][s].to(dev), vs[l][s].to(dev), causal=False, mod_idx=l, current_iter=s)
+                        want_stream = lanes.compute_stream(0) if (lane_mode == "sticky" and s >= 2) else None
+                        if lane_mode == "auto":
+                            assert torch.cuda.current_stream(dev).cuda_stream == caller.cuda_stream, "the caller's stream is the current stream again"
+                        elif want_stream is not None:
+                            assert torch.cuda.current_stream(dev).cuda_stream == want_stream.cuda_stream
+                        outs[(s, l)] = (out * 1.0, lse * 1.0)
+                    torch.cuda.synchronize()
+                    decodes.append(_kernel_ids(lib, ctx).count(22))
+                    lib.cfx_profile_enable(ctx, 0, 0, 1)
+                    cache = cm.compact_cache()
+                    for l in range(L):
+                        for n in ("k", "v"):
+                            for r in range(WL):
+                                states[(s, l, n, r)] = bits(cache.get_base(f"{l}-{r}-{n}")).copy()
+        finally:
+            lowrank.set_init_q(None)
+            torch.cuda.set_stream(torch.cuda.default_stream(dev))
+        assert lib.cfx_gate_errors(ctx) == 0
+        return states, outs, decodes
+    st_off, out_off, dec_off = run("off")
+    st_on, out_on, dec_on = run(lane)
+    ops = [e.xop for e in ring._xbuf.values() if e.xop is not None]
+    assert len(ops) == L and all(o.lowrank and o.transport == "p2p" and getattr(o, "_lane", None) is not None for o in ops), "the lane form never engaged"
+    assert all(d >= (WL - 1) * L for d in dec_on[2:]) and all(d <= 2 * L for d in dec_off[1:]), (dec_on, dec_off)
+    for key, want in st_off.items():
+        assert np.array_equal(st_on[key], want), (key, "state differs between the lane form and the one-call form")
+    for key, (o, lse) in out_off.items():
+        torch.testing.assert_close(out_on[key][0].float(), o.float(), rtol=2e-3, atol=2e-3)
+        torch.testing.assert_close(out_on[key][1].float(), lse.float(), rtol=1e-3, atol=1e-3)
+
+
 def test_plugin_call_low_rank_draws_its_start_matrices_a_chunk_at_a_time(loop8):
     """The path a model takes (no pinned start matrix): every execution of a low-rank layer op starts from its own fresh Gaussian draw
     (reference compress_lowrank.py:41 draws per call), made one launch per chunk of layers and step (compact/xlayer.py StartPool) instead

@@ -109,8 +109,9 @@ def overlap_presets_leg(out, steps, layers):
                            "with_exchange_ms_per_step": legs["default"]["wall"], "exposed_exchange_ms_per_step": ov["exposed_exchange_ms_per_step"]["default"]}
         except Exception as e:  # pragma: no cover
             res[preset] = {"error": f"{type(e).__name__}: {e}"}
-    res["what"] = ("compact_fwd with every switch at its default beside PyTorch-ROCm SDPA at the FLUX shape; INT2 takes the exchange lane, the low-rank "
-                   "family the one-call layer op on the caller's stream (its factor chain is one persistent launch over the whole chip: nothing overlaps)")
+    res["what"] = ("compact_fwd with every switch at its default beside PyTorch-ROCm SDPA at the FLUX shape; INT2 takes the exchange lane; the low-rank "
+                   "family keeps its factor chain - one persistent launch over the chip, exposed - on the compute lane and leaves the publish-and-wait and "
+                   "the 7 peers' reconstructions to the exchange lane, peer by peer behind flags the merge launches wait for")
     out["overlap_with_attention_other_presets"] = res
 
 

@@ -173,7 +173,7 @@ comp_stream = lanes.compute_stream(0)
 # step for `lane_unmasked` / `native` behind them, 23.2 / 23.9 in a process of their own)
 ALL = ["attention_on_compute_lane", "lane", "attention_distinct_kv_on_compute_lane", "attention", "layer_op", "lane_unmasked", "native", "native_gather_only_on_side", "torchdist", "default", "sticky"]
 if args.preset != "binary" and not args.legs:
-    ALL = ["attention_on_compute_lane", "attention", "layer_op", "default"]
+    ALL = ["attention_on_compute_lane", "attention", "layer_op", "default", "sticky"]
 legs = [x for x in (args.legs.split(",") if args.legs else ALL) if x]
 assert all(x in ALL for x in legs), f"legs must be among {ALL}"
 if args.quick:
@@ -194,12 +194,14 @@ for leg in legs:
         with torch.cuda.stream(_side):
             from compactfusion_amd.compact import xlayer as _xl
             if PTYPE.startswith("LOW_RANK"):
-                _xl.set_p2p_loopback(True)             # (the low-rank family's default is the layer op on the caller's stream: packets in the arena)
+                _xl.set_p2p_loopback(True)             # (the low-rank family's default is the layer op: packets in the arena)
             init("native", "auto", "auto" if leg == "default" else "sticky")
             took_lane = all(ex.plan is not None and ex.lane for ex in ring._xbuf.values() if ex.sig is not None)
             took_xop = all(ex.xop is not None for ex in ring._xbuf.values() if ex.sig is not None)
             assert took_lane or (PTYPE.startswith("LOW_RANK") and took_xop), "the default path took neither the lane nor the layer op"
-            default_path = "exchange lane" if took_lane else "layer op on the caller's stream"
+            lr_lane = PTYPE.startswith("LOW_RANK") and all(getattr(ex.xop, "_lane", None) is not None for ex in ring._xbuf.values() if ex.sig is not None)
+            default_path = "exchange lane" if took_lane else ("layer op: factor chain on the compute lane, the peers' reconstructions on the exchange lane"
+                                                              if lr_lane else "layer op on the caller's stream")
             res[leg] = timed(fwd, 3)
             if PTYPE.startswith("LOW_RANK"):
                 for ex in ring._xbuf.values():
