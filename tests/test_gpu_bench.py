@@ -33,14 +33,18 @@ def _bench(*args):
     return json.loads(lines[-1])
 
 
-def test_bench_falls_back_when_the_collective_cannot_be_placed():
+@pytest.mark.parametrize("warmup", [1, 4])
+def test_bench_falls_back_when_the_collective_cannot_be_placed(warmup):
     """a collective kernel that needs an EMPTY CU (CFX_FAKE_RCCL_FAT=2) never runs beside the waiting layer launch: the validation step times
     out (300 ms gates), every rank switches to two launches per layer, the line says so and the states are still consistent.  (8 live
     ranks: 14 peer tensors' reconstruction tiles wait on every CU; with 2 live ranks only the one peer's tiles wait - the own
-    error-feedback update takes its scales from the launch's tagged words since round 5 - and most CUs are empty)"""
+    error-feedback update takes its scales from the launch's tagged words since round 5 - and most CUs are empty)
+    warmup 4 (round 6): the launch of the SECOND step is refused on a context whose first step timed out (CFX_ERR_GATE) - that used to end
+    the bench with a RuntimeError for every --warmup > 1, i.e. for the driver's own command line; now the first step is validated by itself
+    and a refused step waits for the validation instead of raising (runner.guarded_step)."""
     os.environ["CFX_FAKE_RCCL_FAT"] = "2"
     try:
-        d = _bench("--emulate-live", "8", "--rccl-lib", _fake(), "--no-cpu-baseline", "--no-raw-baseline", "--layers", "3")
+        d = _bench("--emulate-live", "8", "--rccl-lib", _fake(), "--no-cpu-baseline", "--no-raw-baseline", "--layers", "3", "--warmup", str(warmup))
     finally:
         os.environ.pop("CFX_FAKE_RCCL_FAT", None)
     assert d["launches_per_layer"] == 2 and "failed validation" in d["schedule_fallback"] and "gate" in d["schedule_fallback"]

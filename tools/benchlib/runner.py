@@ -11,7 +11,7 @@ import time
 
 from . import safety
 from .schedules import build_step_plans, one_step
-from .workload import W_LOGICAL
+from .workload import W_LOGICAL, GateTripped
 
 
 def consistent(S):
@@ -25,8 +25,23 @@ def check_run(S, label):
     if not S.use_dist:
         return None
     S.torch.cuda.synchronize(S.dev)
-    ge = S.lib.cfx_gate_errors(S.ctx)                    # reads and clears the count
+    ge = S.lib.cfx_gate_errors(S.ctx) + (1 if S.gate_tripped else 0)   # (reads and clears the count; a step this rank refused to issue counts too)
+    S.gate_tripped = False
     return safety.validate(S.torch, S.dist, label, S.use_dist, S.world, ge, lambda: consistent(S), S.dev)
+
+
+def guarded_step(S, i) -> None:
+    """one_step, except that a refused launch (an earlier wait of this rank timed out: CFX_ERR_GATE) does not end the run: this rank stops
+    issuing steps until the next validation - its peers' waits run into their timeouts in turn and they stop as well - where every rank
+    reports the time-out and the ladder takes the run down a rung.  (The schedules below the flag-ordered ones have no in-kernel waits:
+    on them a step is never refused, so no rank ever leaves another alone inside a collective.)"""
+    if S.gate_tripped:
+        return
+    try:
+        one_step(S, i)
+    except GateTripped as e:
+        S.gate_tripped = True
+        print(f"[bench] rank {S.rank}: step {i} refused ({e}); waiting for the validation", file=sys.stderr)
 
 
 def current_rung(S) -> str:
@@ -75,19 +90,28 @@ def timed_region(S) -> None:
     while True:
         S.reset_state()
         S.steps_run = 0
+        S.gate_tripped = False
         S.sync_all()
         first_short = S.xgate and S.live > 1
         if first_short:
             S.lib.cfx_set_gate_timeout_ms(S.ctx, 300)         # (the ranks enter the first step together: a gate that cannot open gives up quickly)
+        why_bad = None
         for i in range(S.n_warm):
-            one_step(S, i)
+            guarded_step(S, i)
             maybe_poison(S, i)
             if i == 0 and first_short:
                 S.sync_all()
                 S.lib.cfx_set_gate_timeout_ms(S.ctx, 5000)
+                if S.n_warm > 1:
+                    # a transport that does not work at all (packets or flags that never arrive) shows in the very first step: say so now -
+                    # the next step's launch would be refused on the rank that timed out while its peers wait 5 s per layer for it
+                    why_bad = check_run(S, "in the first warm-up step")
+                    if why_bad is not None:
+                        break
         S.steps_run = S.n_warm
         S.sync_all()
-        why_bad = check_run(S, "after the warm-up steps")
+        if why_bad is None:
+            why_bad = check_run(S, "after the warm-up steps")
         if why_bad is not None:
             fall_back(S, why_bad)
             continue
@@ -107,11 +131,11 @@ def timed_region(S) -> None:
             if S.one_launch and not S.args.no_kernel_events and i % 4 == 1:
                 ea, eb = S.torch.cuda.Event(enable_timing=True), S.torch.cuda.Event(enable_timing=True)
                 ea.record(S.compute)
-                one_step(S, S.steps_run + i)
+                guarded_step(S, S.steps_run + i)
                 eb.record(S.compute)
                 S.step_events.append((ea, eb))
             else:
-                one_step(S, S.steps_run + i)
+                guarded_step(S, S.steps_run + i)
             maybe_poison(S, S.steps_run + i)
         S.sync_all()
         t1 = time.perf_counter()
@@ -166,8 +190,11 @@ def secondary_legs(S) -> None:
     if not S.args.no_secondary:
         base_step = S.steps_run
         if S.args.long_steps > 0:
-            S.long_ms = timed_leg(S, S.args.long_steps, lambda i: one_step(S, base_step + i))
+            S.long_ms = timed_leg(S, S.args.long_steps, lambda i: guarded_step(S, base_step + i))
             S.steps_run += S.args.long_steps
+            if S.gate_tripped:                    # (after two clean validations: a late rank; the line is the timed region's, this leg says nothing)
+                S.long_ms, S.gate_tripped = None, False
+                S.lib.cfx_gate_errors(S.ctx)
 
         def side_leg(plset, run_fn, what):
             """args.steps steps of a collective-free plan set on the same states (every replay advances them identically)."""

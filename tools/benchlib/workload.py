@@ -214,6 +214,11 @@ def config_key(args, n_gpus):
 
 
 
+class GateTripped(RuntimeError):
+    """A native call refused to launch because an earlier launch's in-kernel wait gave up (include/cfx.h CFX_ERR_GATE).  Not fatal for a
+    multi-rank run: the step loop stops issuing on this rank, every rank meets at the validation, the ladder takes the run down a rung."""
+
+
 class Run:
     """Everything one bench process holds: set up once by `setup`, read by the schedule builders, the safety net and the report.
 
@@ -226,6 +231,7 @@ class Run:
 
     def __init__(self, args):
         self.args = args
+        self.gate_tripped = False          # a native call refused to launch (CFX_ERR_GATE) since the last validation: runner.guarded_step
 
     # ---- resident state and inputs -----------------------------------------------------------------------------------------
     def warm_state(self, src_rank):
@@ -281,6 +287,8 @@ class Run:
                 for p in range(W_LOGICAL - 1) for kv in range(2)]
 
     def check(self, rc, what):
+        if rc == -8:                              # CFX_ERR_GATE: an EARLIER launch's gate / flag wait timed out; nothing was launched by this call
+            raise GateTripped(f"{what}: {self.lib.cfx_last_error_string(self.ctx)}")
         if rc != 0:
             raise RuntimeError(f"{what}: rc={rc} {self.lib.cfx_last_error_string(self.ctx)}")
 
