@@ -134,6 +134,21 @@ def main():
     if S.secondary_error is not None:
         out["secondary_legs_error"] = S.secondary_error
     report.add_cpu_baseline(S, out)
+
+    def write_line():
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        if S.rank == 0:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if S.world > 1:
+        # the line first: descriptor 1 points at stderr, so whatever the communicators print while they are torn down cannot get in front
+        # of it - and a tear-down that hangs on hardware this code has never seen (IPC unmapping, ncclCommDestroy) must not cost the line
+        write_line()
+        report.teardown(S)
+        return
     report.teardown(S)
     if S.rank == 0 and S.world == 1 and not args.emulate_live and not args.no_secondary:
         # the secondary legs that need nothing of this process's state (tools/bench_secondary.py): protocol 2 beside real attention and the
@@ -153,13 +168,7 @@ def main():
         if args.overlap_steps > 0:
             BS.overlap_presets_leg(out, max(4, args.overlap_steps // 2), S.L)
         BS.lowrank_leg(out, S.dev, S.N, S.C)
-    try:
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    sys.stdout.flush()
-    if S.rank == 0:
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    write_line()
 
 
 if __name__ == "__main__":
