@@ -94,6 +94,11 @@ def timed_region(S) -> None:
         S.sync_all()
         first_short = S.xgate and S.live > 1
         if first_short:
+            # (libcfx's code object is loaded by its first launch - tens of milliseconds that would otherwise sit inside the first step's
+            # 300 ms gates on some ranks and not on others)
+            warm = S.torch.zeros(2, 4096, dtype=S.torch.uint8, device=S.dev)
+            S.check(S.lib.cfx_copy_probe(S.ctx, warm[0].data_ptr(), warm[1].data_ptr(), 4096, S.sh), "copy_probe")
+            S.sync_all()
             S.lib.cfx_set_gate_timeout_ms(S.ctx, 300)         # (the ranks enter the first step together: a gate that cannot open gives up quickly)
         why_bad = None
         for i in range(S.n_warm):
