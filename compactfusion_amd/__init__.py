@@ -27,6 +27,8 @@ def _default_hw_queues() -> None:
     except Exception:  # noqa: BLE001
         return
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    if os.environ.get("RANK", "0") != "0" or os.environ.get("CFX_QUIET") == "1":
+        return                                 # (said once per job - by rank 0 - not once per rank)
     print("compactfusion_amd: GPU_MAX_HW_QUEUES=8 exported for this process (flag-ordered streams need hardware queues of their own; "
           "set the variable, call compactfusion_amd.configure(hw_queues=n) first, or CFX_NO_DEFAULT_HW_QUEUES=1 to opt out)", file=sys.stderr)
 
