@@ -64,6 +64,7 @@ bash tools/lane_trace.sh "$OUT/lane" > /dev/null 2>&1
 cp "$OUT/lane/overlap_trace_lane.json" "$OUT/r06_overlap_trace.json" 2>/dev/null
 cp "$OUT/lane/overlap_trace_attention_on_compute_lane.json" "$OUT/r06_overlap_trace_attention_only.json" 2>/dev/null
 cp "$OUT/lane/lane_layer_timeline.txt" "$OUT/r06_lane_layer_timeline.txt" 2>/dev/null
+cp "$OUT/lane/lowrank_lane_layer_timeline.txt" "$OUT/r06_lowrank_lane_layer_timeline.txt" 2>/dev/null
 rm -rf "$OUT/lane"
 # 5. what the lane is built on: CU-mask geometry + hand-off prices, SDPA beside a masked bandwidth hog, flag hand-off coherence
 [ -x tools/lane_probe ] && ./tools/lane_probe > "$OUT/r06_lane_probe.txt" 2>&1

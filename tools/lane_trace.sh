@@ -16,4 +16,10 @@ for LEG in lane attention_on_compute_lane; do
   fi
   rm -rf "$OUT/tr_$LEG"
 done
+# the low-rank preset's default path (factor chain on the compute lane, the peers' reconstructions on the exchange lane): one layer
+rm -rf "$OUT/tr_lr"
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/tr_lr" -o ov -- python3 "$R/tools/overlap_bench.py" --preset lowrank8 --steps 3 --legs default --quiet > "$OUT/trace_lowrank8.log" 2>&1
+T=$(find "$OUT/tr_lr" -name "*kernel_trace.csv" | head -1)
+[ -n "$T" ] && python3 "$R/tools/lowrank_lane_dump.py" "$T" > "$OUT/lowrank_lane_layer_timeline.txt" 2>&1
+rm -rf "$OUT/tr_lr"
 cd "$R"
