@@ -118,3 +118,49 @@ def test_ladder_refuses_when_nothing_is_left():
     assert safety.Ladder("xgate").down("r", True, 1) == "native"
     assert safety.Ladder("native").down("r", True, 2, stream_mode=2) == "native"      # the exchange stream of the pipelined replay counts as a rung
     assert np.isclose(1, 1)
+
+
+def test_a_refused_step_waits_for_the_validation_instead_of_ending_the_run(monkeypatch, capsys):
+    """runner.guarded_step (round 6): a native call that refuses to launch because an earlier wait of this rank timed out (CFX_ERR_GATE ->
+    workload.GateTripped) stops the rank's step loop until the next validation, where check_run reports it like a counted gate error -
+    with --warmup > 1 the second step's refusal used to end a multi-rank run with a RuntimeError.  Any other error still raises."""
+    from benchlib import runner, workload
+
+    class FakeLib:
+        def cfx_last_error_string(self, ctx):
+            return b"an earlier gate / flag wait on this context timed out"
+
+        def cfx_gate_errors(self, ctx):
+            return 0
+
+    class S:
+        gate_tripped, rank, use_dist, world, dev, ctx, lib = False, 0, True, 1, None, None, FakeLib()
+        check = workload.Run.check
+    s = S()
+    with pytest.raises(workload.GateTripped):
+        s.check(-8, "plan_run")
+    with pytest.raises(RuntimeError) as ei:
+        s.check(-3, "plan_run")
+    assert not isinstance(ei.value, workload.GateTripped)
+    issued = []
+
+    def fake_step(S_, i):
+        issued.append(i)
+        if i == 1:
+            S_.check(-8, "plan_run(exchange)")
+    monkeypatch.setattr(runner, "one_step", fake_step)
+    for i in range(5):
+        runner.guarded_step(s, i)
+    assert issued == [0, 1] and s.gate_tripped, "steps behind the refused one must not be issued"
+    assert "refused" in capsys.readouterr().err
+    # the validation counts the refusal as a gate time-out (and clears it)
+    seen = {}
+    monkeypatch.setattr(runner.safety, "validate", lambda torch, dist, label, use_dist, world, ge, consistent, dev: seen.setdefault("ge", ge) and "tripped")
+
+    class T:
+        class cuda:
+            @staticmethod
+            def synchronize(dev):
+                pass
+    s.torch, s.dist = T, None
+    assert runner.check_run(s, "after the warm-up steps") == "tripped" and seen["ge"] == 1 and not s.gate_tripped
